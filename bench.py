@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X imgproc backend (driver contract in the task brief).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one pass of the hot path over one resident batch of synthetic frames.  The default
+workload is BASELINE.json configs[2] — the north star: fused NV12 -> normalized CHW f32,
+1920x1080, batch 1024 per GPU, Stretch at scale 1 with ImageNet mean/std.  Inputs are generated
+once (LCG bytes, frame k = base pattern shifted by 31*k, like the reference's batch test
+crates/kornia-imgproc/src/preprocess.rs:1869) and are resident in HBM before the timed region.
+
+Weak scaling: each rank owns its own 1024-frame batch on its own GPU; there is no collective on
+the data path (frames are independent units — SURVEY.md §8e).  torch.distributed (RCCL) is used
+only for the start/stop barrier and the max-over-ranks of the elapsed time.
+
+The JSON line additionally carries
+  roofline     — algorithmic bytes per launch / mean launch duration (HIP events recorded on the
+                 launch stream around every timed launch), against the 8 TB/s HBM3E peak;
+  cpu_baseline — the CPU oracle (a C restatement of the reference, `kind: "port"`) timed on this
+                 box's host cores over a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "kornia-rs_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def lcg_bytes(n: int) -> np.ndarray:
+    """pattern_u8 of the reference's GPU tests (cuda/color/mod.rs:303-317), vectorised: the LCG
+    state after k steps is A_k*s0 + C_k (mod 2^32); blocks are extended by doubling."""
+    prefix = np.array([0, 255, 255, 0, 0, 0, 255, 255, 255, 1, 254, 128, 128, 128, 64], np.uint8)
+    if n <= 15:
+        return prefix[:n].copy()
+    m = n - 15
+    mask = np.uint64(0xFFFFFFFF)
+    a, c = np.uint64(1664525), np.uint64(1013904223)
+    states = np.empty(m, np.uint64)
+    states[0] = (np.uint64(0x12345678) * a + c) & mask
+    have, A, Cc = 1, a, c  # (A, Cc) = `have`-step jump
+    while have < m:
+        take = min(have, m - have)
+        states[have:have + take] = (states[:take] * A + Cc) & mask
+        Cc = (A * Cc + Cc) & mask
+        A = (A * A) & mask
+        have += take
+    return np.concatenate([prefix, (states >> np.uint64(24)).astype(np.uint8)])
+
+
+class Workload:
+    name = ""
+    units_per_step = 0           # Mpixels (source pixels) processed per step per GPU
+    alg_bytes_per_launch = 0     # algorithmic HBM bytes of the dominant kernel per launch
+    kernel = ""
+    dtype = ""
+
+    def setup(self, stream): ...
+    def step(self): ...
+    def describe(self) -> dict: ...
+    def cpu_baseline(self) -> dict: ...
+
+
+class NorthStarNV12(Workload):
+    """configs[2]: fused NV12 -> normalized CHW f32, 1920x1080, batch 1024 on 1 GPU."""
+
+    name = "nv12_1080p_to_chw_f32_b1024"
+    W, H = 1920, 1080
+    kernel = "preprocess_nv12_identity"
+    dtype = "f32"
+
+    def __init__(self, batch: int = 1024, out: int = 0):
+        self.N = batch
+        self.out = out  # 0: same-size (north star); else letterbox to out x out (secondary row)
+        self.frame_bytes = self.W * self.H * 3 // 2
+        px = self.W * self.H
+        self.units_per_step = self.N * px / 1e6
+        if out == 0:
+            # 1.5 B/px read + 12 B/px written = 27 993 600 B per frame
+            self.alg_bytes_per_launch = self.N * (self.frame_bytes + 12 * px)
+        else:
+            self.name = f"nv12_1080p_to_chw_f32_letterbox{out}_b{batch}"
+            self.kernel = "preprocess_generic"
+            # out*out*12 B written + taps actually required (<= 4 taps * 1.5 B per output pixel)
+            self.alg_bytes_per_launch = self.N * (out * out * 12 + out * out * 4 * 3 // 2)
+
+    def setup(self, stream):
+        from kornia_rs import Preprocessor, Tensor
+        from kornia_rs.hip import DeviceBuffer, lib, check
+        self.stream = stream
+        base = lcg_bytes(self.frame_bytes + 31 * self.N)
+        dbase = DeviceBuffer.from_numpy(base, stream)
+        self.src = DeviceBuffer(self.frame_bytes * self.N, stream, zeroed=False)
+        for k in range(self.N):  # frame k = base[31k : 31k + frame_bytes], assembled on device
+            check(lib.kh_memcpy_d2d_async(self.src.ptr + k * self.frame_bytes, dbase.ptr + 31 * k,
+                                          self.frame_bytes, stream.cuda_stream_ptr))
+        stream.synchronize()
+        self.base = base
+        oh, ow = (self.H, self.W) if self.out == 0 else (self.out, self.out)
+        self.dst = Tensor.uninit((self.N, 3, oh, ow), "float32", stream)
+        self.pre = Preprocessor(mode="stretch" if self.out == 0 else "letterbox", format="nv12",
+                                sampling="bilinear", mean=IMAGENET_MEAN, std=IMAGENET_STD,
+                                stream=stream)
+
+    def step(self):
+        self.pre.run_raw_batch(self.src, self.W, self.H, self.dst, frame_stride=self.frame_bytes)
+
+    def describe(self):
+        return {"workload": self.name, "op": "Preprocessor.run_raw_batch (fused NV12 decode + "
+                "bilinear + ImageNet normalize + HWC->CHW)", "src": "1920x1080 NV12",
+                "dst": f"[{self.N},3,{self.dst.shape[2]},{self.dst.shape[3]}] f32",
+                "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        """Chained rgb_from_nv12 (Q20) -> direct bilinear/normalise/CHW, the comparator BASELINE.md
+        §3 names (the reference has no CPU fused-NV12 path).  Bounded to ~10-20 s."""
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
+        threads = O.ko.ko_max_threads()
+        oh, ow = (self.H, self.W) if self.out == 0 else (self.out, self.out)
+        frames, t0, budget = 0, time.perf_counter(), 12.0
+        while True:
+            raw = self.base[31 * frames: 31 * frames + self.frame_bytes]
+            rgb = O.rgb_from_nv12(raw, self.W, self.H)
+            O.preprocess(rgb, self.W, self.H, ow, oh, fmt="rgb",
+                         mode="stretch" if self.out == 0 else "letterbox",
+                         mean=IMAGENET_MEAN, std=IMAGENET_STD)
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or frames >= 256:
+                break
+        return {"value": round(frames * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s",
+                "cores": threads, "kind": "port",
+                "sample": f"{frames} frames of the same 1080p NV12 workload in {dt:.1f} s; C oracle "
+                          "(faithful restatement of kornia-imgproc, not the upstream Rust binary), "
+                          f"chained rgb_from_nv12 -> bilinear/normalize/CHW, OpenMP x{threads}"}
+
+
+WORKLOADS = {
+    "nv12_chw": lambda a: NorthStarNV12(a.batch or 1024, 0),
+    "nv12_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="nv12_chw", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # first: one HIP runtime (torch's bundled libamdhip64) for the whole process
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from kornia_rs import hip
+    hip.set_device(local_rank)
+    stream = hip.Stream.new(local_rank)
+    wl = WORKLOADS[args.workload](args)
+    wl.setup(stream)
+
+    def barrier():
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    for _ in range(args.warmup):
+        wl.step()
+    starts = [hip.Event(timing=True) for _ in range(args.steps)]
+    stops = [hip.Event(timing=True) for _ in range(args.steps)]
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        starts[k].record(stream)   # HIP events on the stream the kernel is launched on
+        wl.step()
+        stops[k].record(stream)
+    stream.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier(device_ids=[local_rank])
+
+    kernel_ms = [starts[k].elapsed_ms(stops[k]) for k in range(args.steps)]
+    mean_kernel_s = float(np.mean(kernel_ms)) / 1e3 if kernel_ms else float("nan")
+
+    if rank == 0:
+        value = world * wl.units_per_step * args.steps / elapsed
+        achieved = wl.alg_bytes_per_launch / mean_kernel_s / 1e9
+        traffic = None
+        tfile = ROOT / "profiles" / "pmc_traffic.json"  # written from a rocprofv3 --pmc run
+        if tfile.exists():
+            traffic = json.loads(tfile.read_text()).get(wl.name)
+        name, cus, mem = hip.device_info(local_rank)
+        line = {
+            "metric": "Mpixels/s, fused 1080p NV12->normalized CHW f32 (achieved HBM GB/s in roofline)",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,
+            "data": "synthetic (LCG bytes, reference pattern_u8; frame k shifted by 31k)",
+            "config": wl.describe(),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": wl.kernel, "alg_bytes_per_launch": wl.alg_bytes_per_launch,
+                         "mean_launch_ms": round(mean_kernel_s * 1e3, 4),
+                         "min_launch_ms": round(float(np.min(kernel_ms)), 4)},
+            "device": {"name": name, "cus": cus, "hbm_bytes": mem},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = wl.cpu_baseline()
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

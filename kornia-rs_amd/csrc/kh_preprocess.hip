@@ -1,0 +1,388 @@
+// Fused camera preprocess for gfx950: raw frame (RGB/BGR/RGBA/BGRA/Gray/NV12/YUYV) ->
+// sampled, normalised, channel-planar f32/f16 tensor in one pass.
+//
+// Behavioural contract = the reference's NVRTC kernel family
+// `resize_normalize_to_chw_{bilinear,nearest,lanczos}[_f16]`
+// (crates/kornia-imgproc/src/preprocess.rs:430-647) and its launcher `launch_view`
+// (:1324-1375).  The reference compiles with fmad=false; this file is built with
+// -ffp-contract=off and IEEE division, and keeps the same expression trees, so results are
+// bit-identical for nearest/bilinear (Lanczos calls sinf and is only loosely comparable, as in
+// the reference's own cpu_close_to_cuda test, :1685).
+//
+// Two kernels:
+//   * preprocess_generic  — one thread per destination pixel, any geometry/format/sampler.
+//     Batched with grid.y = frame (the reference launches once per frame, :1277-1280).
+//   * preprocess_nv12_identity — the north-star case (NV12, scale 1, pad 0, same size): every
+//     source byte is read exactly once (1.5 B/px) and 12 B/px are written.  A thread owns a
+//     4x2 pixel block: two dword luma loads, one dword chroma load (2 UV pairs shared by both
+//     rows), six 16-byte plane stores, so a wave writes 1 KiB contiguous per store instruction.
+//     At scale 1 the bilinear weights are exactly 0 (`ax == ay == 0.0f`), hence
+//     `t00 + (t10 - t00) * 0 == t00` for the finite 0..255 taps and the result equals the
+//     generic kernel bit for bit; tests assert that equality.
+#include "kh_common.h"
+
+using namespace kh;
+
+namespace {
+
+struct PreArgs {
+    float scale_x, scale_y, pad_x, pad_y;
+    int src_w, src_h, src_pitch, src_bpp;
+    int dst_w, dst_h;
+    float m0, m1, m2, is0, is1, is2;
+    float pad_value;
+    long long src_frame_stride;  // bytes
+    long long dst_frame_stride;  // elements
+};
+
+// BT.601 limited-range Q20 decode, constants of P/color/yuv/kernels.rs:696-702 and the fused
+// kernel's yuv_to_rgbf (P/preprocess.rs:501-508).
+constexpr int kCY = 1220542, kCUB = 2116026, kCUG = -409993, kCVG = -852492, kCVR = 1673527;
+constexpr int kHalf20 = 1 << 19;
+
+__device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }
+
+__device__ __forceinline__ void yuv_to_rgbf(int yv, int u, int v, float px[3]) {
+    int yy = max(yv - 16, 0) * kCY;
+    u -= 128;
+    v -= 128;
+    px[2] = (float)clamp255((yy + kCUB * u + kHalf20) >> 20);
+    px[1] = (float)clamp255((yy + kCUG * u + kCVG * v + kHalf20) >> 20);
+    px[0] = (float)clamp255((yy + kCVR * v + kHalf20) >> 20);
+}
+
+template <int FMT>
+__device__ __forceinline__ void fetch_px(const uint8_t* __restrict__ src, int x, int y,
+                                         const PreArgs& a, float px[3]) {
+    if constexpr (FMT == KH_FMT_RGB || FMT == KH_FMT_BGR) {
+        const uint8_t* p = src + (long long)y * a.src_pitch + x * a.src_bpp;
+        if constexpr (FMT == KH_FMT_RGB) {
+            px[0] = (float)p[0]; px[1] = (float)p[1]; px[2] = (float)p[2];
+        } else {
+            px[0] = (float)p[2]; px[1] = (float)p[1]; px[2] = (float)p[0];
+        }
+    } else if constexpr (FMT == KH_FMT_GRAY) {
+        float v = (float)src[(long long)y * a.src_pitch + x];
+        px[0] = v; px[1] = v; px[2] = v;
+    } else if constexpr (FMT == KH_FMT_NV12) {
+        int yv = src[(long long)y * a.src_w + x];
+        const uint8_t* uv =
+            src + (long long)a.src_w * a.src_h + (long long)(y >> 1) * a.src_w + (x >> 1) * 2;
+        yuv_to_rgbf(yv, uv[0], uv[1], px);
+    } else {  // YUYV
+        const uint8_t* grp = src + (long long)y * a.src_pitch + (x >> 1) * 4;
+        int yv = grp[(x & 1) ? 2 : 0];
+        yuv_to_rgbf(yv, grp[1], grp[3], px);
+    }
+}
+
+template <int FMT>
+__device__ __forceinline__ void sample_nearest(const uint8_t* __restrict__ src, float sx, float sy,
+                                               const PreArgs& a, float px[3]) {
+    int xn = min(max((int)roundf(sx), 0), a.src_w - 1);
+    int yn = min(max((int)roundf(sy), 0), a.src_h - 1);
+    fetch_px<FMT>(src, xn, yn, a, px);
+}
+
+template <int FMT>
+__device__ __forceinline__ void sample_bilinear(const uint8_t* __restrict__ src, float sx, float sy,
+                                                const PreArgs& a, float px[3]) {
+    int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+    float ax = sx - (float)x0, ay = sy - (float)y0;
+    int x1 = min(x0 + 1, a.src_w - 1), y1 = min(y0 + 1, a.src_h - 1);
+    x0 = max(x0, 0);
+    y0 = max(y0, 0);
+    float t00[3], t10[3], t01[3], t11[3];
+    fetch_px<FMT>(src, x0, y0, a, t00);
+    fetch_px<FMT>(src, x1, y0, a, t10);
+    fetch_px<FMT>(src, x0, y1, a, t01);
+    fetch_px<FMT>(src, x1, y1, a, t11);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float top = t00[c] + (t10[c] - t00[c]) * ax;
+        float bot = t01[c] + (t11[c] - t01[c]) * ax;
+        px[c] = top + (bot - top) * ay;
+    }
+}
+
+__device__ __forceinline__ float lanczos_w(float d) {
+    float ad = fabsf(d);
+    if (ad < 1e-6f) return 1.0f;
+    if (ad >= 3.0f) return 0.0f;
+    float pd = 3.14159265358979f * d;
+    return 3.0f * sinf(pd) * sinf(pd / 3.0f) / (pd * pd);
+}
+
+template <int FMT>
+__device__ __forceinline__ void sample_lanczos(const uint8_t* __restrict__ src, float sx, float sy,
+                                               const PreArgs& a, float px[3]) {
+    int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    float wsum = 0.0f;
+    for (int j = -2; j <= 3; ++j) {
+        int yj = y0 + j;
+        float wy = lanczos_w(sy - (float)yj);
+        int yc = min(max(yj, 0), a.src_h - 1);
+        for (int i = -2; i <= 3; ++i) {
+            int xi = x0 + i;
+            float w = wy * lanczos_w(sx - (float)xi);
+            int xc = min(max(xi, 0), a.src_w - 1);
+            float t[3];
+            fetch_px<FMT>(src, xc, yc, a, t);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] += w * t[c];
+            wsum += w;
+        }
+    }
+    px[0] = acc[0] / wsum;
+    px[1] = acc[1] / wsum;
+    px[2] = acc[2] / wsum;
+}
+
+// f32 -> binary16 bits, round-to-nearest-even.  v_cvt_f16_f32 implements exactly the
+// reference's manual f2h (P/preprocess.rs:452-477) for every |f| < 65536 (f16 denormals are on
+// for gfx9 kernels).  At or above 2^16 the reference does NOT saturate to Inf: its `exp >= 31`
+// branch returns sign|0x7C00 plus the quiet bit whenever the f32 mantissa is non-zero, so a
+// large finite value such as 1e9 becomes a NaN pattern (0x7E00) and only exact powers of two
+// and Inf map to 0x7C00.  Reproduced here bit for bit.
+__device__ __forceinline__ unsigned short f2h_bits(float f) {
+    unsigned int x = __float_as_uint(f);
+    if ((x & 0x7FFFFFFFu) >= 0x47800000u)
+        return (unsigned short)(((x >> 16) & 0x8000u) | 0x7C00u | ((x & 0x7FFFFFu) ? 0x0200u : 0u));
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+template <typename OutT>
+__device__ __forceinline__ OutT to_out(float v);
+template <>
+__device__ __forceinline__ float to_out<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ unsigned short to_out<unsigned short>(float v) { return f2h_bits(v); }
+
+template <int FMT, int SAMPLER, typename OutT>
+__global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __restrict__ src_base,
+                                                             OutT* __restrict__ dst_base,
+                                                             PreArgs a) {
+    const int pixels = a.dst_w * a.dst_h;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= pixels) return;
+    const uint8_t* src = src_base + (long long)blockIdx.y * a.src_frame_stride;
+    OutT* dst = dst_base + (long long)blockIdx.y * a.dst_frame_stride;
+
+    // plan_pixel (P/preprocess.rs:437-448)
+    const int ox = i % a.dst_w;
+    const int oy = i / a.dst_w;
+    const float sx = ((float)ox - a.pad_x) / a.scale_x;
+    const float sy = ((float)oy - a.pad_y) / a.scale_y;
+    const bool inside = !(sx < 0.0f || sy < 0.0f || sx >= (float)a.src_w || sy >= (float)a.src_h);
+
+    float px[3];
+    if (inside) {
+        if constexpr (SAMPLER == KH_SAMPLE_NEAREST) sample_nearest<FMT>(src, sx, sy, a, px);
+        else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) sample_bilinear<FMT>(src, sx, sy, a, px);
+        else sample_lanczos<FMT>(src, sx, sy, a, px);
+    } else {
+        px[0] = a.pad_value; px[1] = a.pad_value; px[2] = a.pad_value;
+    }
+    const float o0 = (px[0] / 255.0f - a.m0) * a.is0;
+    const float o1 = (px[1] / 255.0f - a.m1) * a.is1;
+    const float o2 = (px[2] / 255.0f - a.m2) * a.is2;
+    dst[i] = to_out<OutT>(o0);
+    dst[pixels + i] = to_out<OutT>(o1);
+    dst[2 * pixels + i] = to_out<OutT>(o2);
+}
+
+// ---- north-star fast path ------------------------------------------------------------------
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    f32x4 v = {a, b, c, d};
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+    else *reinterpret_cast<f32x4*>(p) = v;
+}
+
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void preprocess_nv12_identity(
+    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a) {
+    const int wq = a.src_w >> 2;             // 4-pixel groups per row
+    const int groups = wq * (a.src_h >> 1);  // 4x2 blocks per frame
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= groups) return;
+    const uint8_t* src = src_base + (long long)blockIdx.y * a.src_frame_stride;
+    float* dst = dst_base + (long long)blockIdx.y * a.dst_frame_stride;
+
+    const int rp = g / wq;       // chroma row == luma row pair
+    const int xq = g - rp * wq;  // 4-pixel group within the row
+    const int w = a.src_w;
+    const long long plane = (long long)w * a.src_h;
+
+    const uint32_t ytop = *reinterpret_cast<const uint32_t*>(src + (long long)(2 * rp) * w + 4 * xq);
+    const uint32_t ybot =
+        *reinterpret_cast<const uint32_t*>(src + (long long)(2 * rp + 1) * w + 4 * xq);
+    const uint32_t uv4 = *reinterpret_cast<const uint32_t*>(src + plane + (long long)rp * w + 4 * xq);
+
+    // Chroma terms shared by the 2x2 block; integer adds are exact so hoisting the rounding
+    // constant is the same value as (yy + c*u + half).
+    int tb[2], tg[2], tr[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = (int)((uv4 >> (16 * k)) & 0xFFu) - 128;
+        const int v = (int)((uv4 >> (16 * k + 8)) & 0xFFu) - 128;
+        tb[k] = kCUB * u + kHalf20;
+        tg[k] = kCUG * u + kCVG * v + kHalf20;
+        tr[k] = kCVR * v + kHalf20;
+    }
+
+    float o[2][3][4];
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        const uint32_t y4 = row ? ybot : ytop;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int yy = max((int)((y4 >> (8 * j)) & 0xFFu) - 16, 0) * kCY;
+            const int k = j >> 1;
+            const float r = (float)clamp255((yy + tr[k]) >> 20);
+            const float gg = (float)clamp255((yy + tg[k]) >> 20);
+            const float b = (float)clamp255((yy + tb[k]) >> 20);
+            o[row][0][j] = (r / 255.0f - a.m0) * a.is0;
+            o[row][1][j] = (gg / 255.0f - a.m1) * a.is1;
+            o[row][2][j] = (b / 255.0f - a.m2) * a.is2;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            float* p = dst + c * plane + (long long)(2 * rp + row) * w + 4 * xq;
+            store4<NT>(p, o[row][c][0], o[row][c][1], o[row][c][2], o[row][c][3]);
+        }
+    }
+}
+
+bool identity_fast_path(const kh_preprocess_params* p, const uint8_t* src, const void* dst) {
+    return !(p->flags & KH_PRE_FORCE_GENERIC) && p->fmt == KH_FMT_NV12 &&
+           p->out_dtype == KH_OUT_F32 &&
+           (p->sampling == KH_SAMPLE_BILINEAR || p->sampling == KH_SAMPLE_NEAREST) &&
+           p->scale_x == 1.0f && p->scale_y == 1.0f && p->pad_x == 0.0f && p->pad_y == 0.0f &&
+           p->dst_w == p->src_w && p->dst_h == p->src_h && (p->src_w % 4) == 0 &&
+           (reinterpret_cast<uintptr_t>(src) % 4) == 0 && (p->src_frame_stride % 4) == 0 &&
+           (reinterpret_cast<uintptr_t>(dst) % 16) == 0 && (p->dst_frame_stride % 4) == 0;
+}
+
+int32_t validate(const kh_preprocess_params* p, const uint8_t* src, const void* dst) {
+    KH_REQUIRE(p, KH_ERR_INVALID_ARG, "preprocess: null params");
+    KH_REQUIRE(p->nframes >= 0, KH_ERR_INVALID_ARG, "preprocess: negative frame count");
+    KH_REQUIRE(p->src_w > 0 && p->src_h > 0 && p->dst_w > 0 && p->dst_h > 0, KH_ERR_INVALID_ARG,
+               "preprocess: zero-sized image (src %dx%d, dst %dx%d)", p->src_w, p->src_h, p->dst_w,
+               p->dst_h);
+    KH_REQUIRE(p->fmt >= KH_FMT_RGB && p->fmt <= KH_FMT_YUYV, KH_ERR_INVALID_ARG,
+               "preprocess: unknown source format %d", p->fmt);
+    KH_REQUIRE(p->sampling >= KH_SAMPLE_NEAREST && p->sampling <= KH_SAMPLE_LANCZOS,
+               KH_ERR_INVALID_ARG, "preprocess: unknown sampling mode %d", p->sampling);
+    KH_REQUIRE(p->out_dtype == KH_OUT_F32 || p->out_dtype == KH_OUT_F16, KH_ERR_INVALID_ARG,
+               "preprocess: unknown output dtype %d", p->out_dtype);
+    // Subsampling constraints (SourceFormat::dims_ok, P/preprocess.rs:191-197).
+    if (p->fmt == KH_FMT_NV12)
+        KH_REQUIRE(p->src_w % 2 == 0 && p->src_h % 2 == 0, KH_ERR_INVALID_ARG,
+                   "preprocess: NV12 needs even dimensions, got %dx%d", p->src_w, p->src_h);
+    if (p->fmt == KH_FMT_YUYV)
+        KH_REQUIRE(p->src_w % 2 == 0, KH_ERR_INVALID_ARG,
+                   "preprocess: YUYV needs an even width, got %d", p->src_w);
+    if (p->fmt == KH_FMT_RGB || p->fmt == KH_FMT_BGR)
+        KH_REQUIRE(p->src_bpp == 3 || p->src_bpp == 4, KH_ERR_INVALID_ARG,
+                   "preprocess: interleaved formats need bpp 3 or 4, got %d", p->src_bpp);
+    const int min_bpp = p->fmt == KH_FMT_YUYV ? 2 : (p->fmt <= KH_FMT_BGR ? p->src_bpp : 1);
+    KH_REQUIRE((int64_t)p->src_pitch >= (int64_t)p->src_w * min_bpp, KH_ERR_SLICE_TOO_SMALL,
+               "preprocess: pitch %d shorter than a %d-px row", p->src_pitch, p->src_w);
+    // 32-bit kernel indexing guard (P/preprocess.rs:1336-1339).
+    KH_REQUIRE((int64_t)p->dst_w * p->dst_h <= kI32Max / 4 &&
+                   (int64_t)p->src_pitch * p->src_h <= kI32Max,
+               KH_ERR_TOO_LARGE, "preprocess: dimensions exceed the 32-bit kernel index limit");
+    KH_REQUIRE(p->nframes <= 65535, KH_ERR_TOO_LARGE,
+               "preprocess: at most 65535 frames per launch, got %d", p->nframes);
+    if (p->nframes > 0) {
+        KH_REQUIRE(src && dst, KH_ERR_INVALID_ARG, "preprocess: null device pointer");
+    }
+    return KH_OK;
+}
+
+template <int FMT, int SAMPLER>
+void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst, const PreArgs& a,
+                        int out_dtype) {
+    if (out_dtype == KH_OUT_F32)
+        hipLaunchKernelGGL((preprocess_generic<FMT, SAMPLER, float>), grid, dim3(kBlock), 0, s, src,
+                           (float*)dst, a);
+    else
+        hipLaunchKernelGGL((preprocess_generic<FMT, SAMPLER, unsigned short>), grid, dim3(kBlock), 0,
+                           s, src, (unsigned short*)dst, a);
+}
+
+template <int FMT>
+void launch_generic_fmt(hipStream_t s, dim3 grid, const uint8_t* src, void* dst, const PreArgs& a,
+                        int sampling, int out_dtype) {
+    switch (sampling) {
+        case KH_SAMPLE_NEAREST:
+            launch_generic_out<FMT, KH_SAMPLE_NEAREST>(s, grid, src, dst, a, out_dtype);
+            break;
+        case KH_SAMPLE_BILINEAR:
+            launch_generic_out<FMT, KH_SAMPLE_BILINEAR>(s, grid, src, dst, a, out_dtype);
+            break;
+        default:
+            launch_generic_out<FMT, KH_SAMPLE_LANCZOS>(s, grid, src, dst, a, out_dtype);
+            break;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* kh_preprocess_variant(const kh_preprocess_params* p) {
+    // Alignment of the actual buffers is only known at launch; report for aligned buffers.
+    if (validate(p, reinterpret_cast<const uint8_t*>(16), reinterpret_cast<void*>(16)) != KH_OK)
+        return nullptr;
+    return identity_fast_path(p, reinterpret_cast<const uint8_t*>(16), reinterpret_cast<void*>(16))
+               ? "nv12_identity"
+               : "generic";
+}
+
+int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
+                             const kh_preprocess_params* p) {
+    int32_t rc = validate(p, src, dst);
+    if (rc != KH_OK) return rc;
+    if (p->nframes == 0) return KH_OK;
+
+    PreArgs a;
+    a.scale_x = p->scale_x; a.scale_y = p->scale_y; a.pad_x = p->pad_x; a.pad_y = p->pad_y;
+    a.src_w = p->src_w; a.src_h = p->src_h; a.src_pitch = p->src_pitch; a.src_bpp = p->src_bpp;
+    a.dst_w = p->dst_w; a.dst_h = p->dst_h;
+    a.m0 = p->mean[0]; a.m1 = p->mean[1]; a.m2 = p->mean[2];
+    a.is0 = p->inv_std[0]; a.is1 = p->inv_std[1]; a.is2 = p->inv_std[2];
+    a.pad_value = p->pad_value;
+    a.src_frame_stride = p->src_frame_stride;
+    a.dst_frame_stride = p->dst_frame_stride;
+    hipStream_t s = as_hip(stream);
+
+    if (identity_fast_path(p, src, dst)) {
+        const int groups = (p->src_w / 4) * (p->src_h / 2);
+        dim3 grid(cdiv(groups, kBlock), (unsigned)p->nframes);
+        hipLaunchKernelGGL((preprocess_nv12_identity<true>), grid, dim3(kBlock), 0, s, src,
+                           (float*)dst, a);
+        return check_launch("preprocess_nv12_identity");
+    }
+
+    dim3 grid(cdiv((int64_t)p->dst_w * p->dst_h, kBlock), (unsigned)p->nframes);
+    switch (p->fmt) {
+        case KH_FMT_RGB: launch_generic_fmt<KH_FMT_RGB>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
+        case KH_FMT_BGR: launch_generic_fmt<KH_FMT_BGR>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
+        case KH_FMT_GRAY: launch_generic_fmt<KH_FMT_GRAY>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
+        case KH_FMT_NV12: launch_generic_fmt<KH_FMT_NV12>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
+        default: launch_generic_fmt<KH_FMT_YUYV>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
+    }
+    return check_launch("preprocess_generic");
+}
+
+}  // extern "C"

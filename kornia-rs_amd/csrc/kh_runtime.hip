@@ -1,0 +1,285 @@
+// Device runtime + HIP allocator behind the C ABI (include/kornia_hip.h).
+//
+// Stands in for the cudarc-based half of the reference's tensor crate
+// (crates/kornia-tensor/src/cuda.rs): stream-ordered zeroed/uninit device allocation from the
+// device mem-pool (:238-298, :860, :891), pinned host buffers (:355-380), managed memory
+// (:440-511), H2D/D2H copies on the buffer's stream (:1208-1384) and the cross-stream event
+// fence of the residency dispatch (crates/kornia-imgproc/src/cuda/dispatch.rs:50-82).
+#include <stdarg.h>
+#include <string.h>
+
+#include "kh_common.h"
+
+namespace kh {
+
+static thread_local char g_err[512] = {0};
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int32_t fail(int32_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int32_t fail_hip(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return KH_ERR_HIP;
+}
+
+}  // namespace kh
+
+using namespace kh;
+
+extern "C" {
+
+size_t kh_last_error(char* buf, size_t cap) {
+    size_t n = strlen(g_err);
+    if (buf && cap) {
+        size_t m = n < cap - 1 ? n : cap - 1;
+        memcpy(buf, g_err, m);
+        buf[m] = 0;
+    }
+    return n;
+}
+
+const char* kh_version(void) { return "kornia-hip 0.1.0 (gfx950)"; }
+
+int32_t kh_device_count(int32_t* count) {
+    KH_REQUIRE(count, KH_ERR_INVALID_ARG, "kh_device_count: null out pointer");
+    int n = 0;
+    KH_HIP(hipGetDeviceCount(&n));
+    *count = n;
+    return KH_OK;
+}
+
+int32_t kh_set_device(int32_t device) {
+    KH_HIP(hipSetDevice(device));
+    return KH_OK;
+}
+
+int32_t kh_get_device(int32_t* device) {
+    KH_REQUIRE(device, KH_ERR_INVALID_ARG, "kh_get_device: null out pointer");
+    int d = 0;
+    KH_HIP(hipGetDevice(&d));
+    *device = d;
+    return KH_OK;
+}
+
+int32_t kh_device_info(int32_t device, char* name, size_t name_cap, int32_t* cu_count,
+                       uint64_t* total_mem_bytes) {
+    hipDeviceProp_t prop;
+    KH_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && name_cap) {
+        snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (total_mem_bytes) *total_mem_bytes = (uint64_t)prop.totalGlobalMem;
+    return KH_OK;
+}
+
+int32_t kh_stream_create(kh_stream_t* out) {
+    KH_REQUIRE(out, KH_ERR_INVALID_ARG, "kh_stream_create: null out pointer");
+    hipStream_t s = nullptr;
+    KH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = reinterpret_cast<kh_stream_t>(s);
+    return KH_OK;
+}
+
+int32_t kh_stream_destroy(kh_stream_t stream) {
+    KH_REQUIRE(stream, KH_ERR_INVALID_ARG, "kh_stream_destroy: the default stream is not owned");
+    KH_HIP(hipStreamDestroy(as_hip(stream)));
+    return KH_OK;
+}
+
+int32_t kh_stream_synchronize(kh_stream_t stream) {
+    KH_HIP(hipStreamSynchronize(as_hip(stream)));
+    return KH_OK;
+}
+
+int32_t kh_stream_wait_event(kh_stream_t stream, kh_event_t event) {
+    KH_REQUIRE(event, KH_ERR_INVALID_ARG, "kh_stream_wait_event: null event");
+    KH_HIP(hipStreamWaitEvent(as_hip(stream), as_hip(event), 0));
+    return KH_OK;
+}
+
+int32_t kh_event_create(kh_event_t* out, int32_t enable_timing) {
+    KH_REQUIRE(out, KH_ERR_INVALID_ARG, "kh_event_create: null out pointer");
+    hipEvent_t e = nullptr;
+    KH_HIP(hipEventCreateWithFlags(&e, enable_timing ? hipEventDefault : hipEventDisableTiming));
+    *out = reinterpret_cast<kh_event_t>(e);
+    return KH_OK;
+}
+
+int32_t kh_event_destroy(kh_event_t event) {
+    KH_REQUIRE(event, KH_ERR_INVALID_ARG, "kh_event_destroy: null event");
+    KH_HIP(hipEventDestroy(as_hip(event)));
+    return KH_OK;
+}
+
+int32_t kh_event_record(kh_event_t event, kh_stream_t stream) {
+    KH_REQUIRE(event, KH_ERR_INVALID_ARG, "kh_event_record: null event");
+    KH_HIP(hipEventRecord(as_hip(event), as_hip(stream)));
+    return KH_OK;
+}
+
+int32_t kh_event_synchronize(kh_event_t event) {
+    KH_REQUIRE(event, KH_ERR_INVALID_ARG, "kh_event_synchronize: null event");
+    KH_HIP(hipEventSynchronize(as_hip(event)));
+    return KH_OK;
+}
+
+int32_t kh_event_elapsed_ms(kh_event_t start, kh_event_t stop, float* ms) {
+    KH_REQUIRE(start && stop && ms, KH_ERR_INVALID_ARG, "kh_event_elapsed_ms: null argument");
+    KH_HIP(hipEventElapsedTime(ms, as_hip(start), as_hip(stop)));
+    return KH_OK;
+}
+
+int32_t kh_stream_fence(kh_stream_t producer, kh_stream_t consumer) {
+    if (producer == consumer) return KH_OK;  // same queue: already ordered
+    hipEvent_t e = nullptr;
+    KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t r = hipEventRecord(e, as_hip(producer));
+    if (r == hipSuccess) r = hipStreamWaitEvent(as_hip(consumer), e, 0);
+    hipError_t d = hipEventDestroy(e);  // safe: the wait keeps its own reference
+    if (r != hipSuccess) return fail_hip(r, "kh_stream_fence");
+    if (d != hipSuccess) return fail_hip(d, "kh_stream_fence(destroy)");
+    return KH_OK;
+}
+
+int32_t kh_malloc_async(void** out, size_t bytes, int32_t zeroed, kh_stream_t stream) {
+    KH_REQUIRE(out, KH_ERR_INVALID_ARG, "kh_malloc_async: null out pointer");
+    *out = nullptr;
+    if (bytes == 0) return KH_OK;  // empty tensors own no storage
+    void* p = nullptr;
+    KH_HIP(hipMallocAsync(&p, bytes, as_hip(stream)));
+    if (zeroed) {
+        hipError_t e = hipMemsetAsync(p, 0, bytes, as_hip(stream));
+        if (e != hipSuccess) {
+            (void)hipFreeAsync(p, as_hip(stream));
+            return fail_hip(e, "hipMemsetAsync (zeroed allocation)");
+        }
+    }
+    *out = p;
+    return KH_OK;
+}
+
+int32_t kh_free_async(void* ptr, kh_stream_t stream) {
+    if (!ptr) return KH_OK;
+    KH_HIP(hipFreeAsync(ptr, as_hip(stream)));
+    return KH_OK;
+}
+
+int32_t kh_mempool_set_release_threshold(int32_t device, uint64_t bytes) {
+    hipMemPool_t pool = nullptr;
+    KH_HIP(hipDeviceGetDefaultMemPool(&pool, device));
+    uint64_t v = bytes;
+    KH_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &v));
+    return KH_OK;
+}
+
+int32_t kh_host_alloc(void** out, size_t bytes) {
+    KH_REQUIRE(out, KH_ERR_INVALID_ARG, "kh_host_alloc: null out pointer");
+    *out = nullptr;
+    if (bytes == 0) return KH_OK;
+    void* p = nullptr;
+    KH_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    memset(p, 0, bytes);
+    *out = p;
+    return KH_OK;
+}
+
+int32_t kh_host_free(void* ptr) {
+    if (!ptr) return KH_OK;
+    KH_HIP(hipHostFree(ptr));
+    return KH_OK;
+}
+
+int32_t kh_malloc_managed(void** out, size_t bytes) {
+    KH_REQUIRE(out, KH_ERR_INVALID_ARG, "kh_malloc_managed: null out pointer");
+    *out = nullptr;
+    if (bytes == 0) return KH_OK;
+    void* p = nullptr;
+    KH_HIP(hipMallocManaged(&p, bytes, hipMemAttachGlobal));
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail_hip(e, "hipMemset (managed allocation)");
+    }
+    *out = p;
+    return KH_OK;
+}
+
+int32_t kh_free(void* ptr) {
+    if (!ptr) return KH_OK;
+    KH_HIP(hipFree(ptr));
+    return KH_OK;
+}
+
+int32_t kh_memcpy_h2d_async(void* dst, const void* src, size_t bytes, kh_stream_t stream) {
+    if (bytes == 0) return KH_OK;
+    KH_REQUIRE(dst && src, KH_ERR_INVALID_ARG, "kh_memcpy_h2d_async: null pointer");
+    KH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_hip(stream)));
+    return KH_OK;
+}
+
+int32_t kh_memcpy_d2h_async(void* dst, const void* src, size_t bytes, kh_stream_t stream) {
+    if (bytes == 0) return KH_OK;
+    KH_REQUIRE(dst && src, KH_ERR_INVALID_ARG, "kh_memcpy_d2h_async: null pointer");
+    KH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_hip(stream)));
+    return KH_OK;
+}
+
+int32_t kh_memcpy_d2d_async(void* dst, const void* src, size_t bytes, kh_stream_t stream) {
+    if (bytes == 0) return KH_OK;
+    KH_REQUIRE(dst && src, KH_ERR_INVALID_ARG, "kh_memcpy_d2d_async: null pointer");
+    KH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_hip(stream)));
+    return KH_OK;
+}
+
+int32_t kh_memset_async(void* dst, int32_t value, size_t bytes, kh_stream_t stream) {
+    if (bytes == 0) return KH_OK;
+    KH_REQUIRE(dst, KH_ERR_INVALID_ARG, "kh_memset_async: null pointer");
+    KH_HIP(hipMemsetAsync(dst, value, bytes, as_hip(stream)));
+    return KH_OK;
+}
+
+int32_t kh_pointer_domain(const void* ptr, int32_t* domain, int32_t* device) {
+    KH_REQUIRE(domain && device, KH_ERR_INVALID_ARG, "kh_pointer_domain: null out pointer");
+    *domain = KH_DOMAIN_HOST;
+    *device = -1;
+    if (!ptr) return KH_OK;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, ptr);
+    if (e != hipSuccess) {
+        // Plain malloc'd memory is "invalid value" to the runtime: that IS the Host answer.
+        (void)hipGetLastError();
+        return KH_OK;
+    }
+    switch (attr.type) {
+        case hipMemoryTypeDevice:
+            *domain = KH_DOMAIN_DEVICE;
+            *device = attr.device;
+            break;
+        case hipMemoryTypeManaged:
+            *domain = KH_DOMAIN_UNIFIED;
+            *device = attr.device;
+            break;
+        case hipMemoryTypeHost:
+            *domain = KH_DOMAIN_HOST_PINNED;
+            *device = attr.device;
+            break;
+        default:
+            break;
+    }
+    return KH_OK;
+}
+
+}  // extern "C"

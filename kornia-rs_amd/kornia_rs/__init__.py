@@ -1,0 +1,18 @@
+"""``kornia_rs`` — host-side mirror of the reference's Python package for the imgproc hot path,
+running on the MI355X HIP backend (``libkornia_hip.so``) instead of CUDA.
+
+Only the hot-path surface exists here: ``Image`` / ``Tensor`` with host/device
+residency, ``Stream``, the ``imgproc`` free functions and the fused ``Preprocessor``.
+Importing the package loads the shared library and fails loudly if it is missing.
+"""
+from . import _ffi
+from . import hip
+from .hip import IMAGENET_MEAN, IMAGENET_STD, Stream
+from .tensor import Tensor
+from .preprocess import Preprocessor, PreprocessError, ResizeMode, SourceFormat
+
+__version__ = "0.1.0"
+__all__ = [
+    "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Preprocessor", "PreprocessError",
+    "ResizeMode", "SourceFormat", "hip",
+]

@@ -1,0 +1,127 @@
+"""ctypes binding of ``libkornia_hip.so`` — the C ABI declared in ``include/kornia_hip.h``.
+
+This is the Python twin of the thin ``extern "C"`` FFI crate the Rust host would use
+(INTEGRATION.md).  There is deliberately no fallback: if the shared library is missing or a
+symbol does not resolve, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("KORNIA_HIP_LIB", _HERE.parent / "lib" / "libkornia_hip.so"))
+
+# status codes (kornia_hip.h)
+KH_OK = 0
+KH_ERR_INVALID_ARG = -1
+KH_ERR_HIP = -2
+KH_ERR_UNSUPPORTED = -3
+KH_ERR_TOO_LARGE = -4
+KH_ERR_SINGULAR = -5
+KH_ERR_SLICE_TOO_SMALL = -6
+
+KH_DOMAIN_HOST, KH_DOMAIN_DEVICE, KH_DOMAIN_UNIFIED, KH_DOMAIN_HOST_PINNED = 0, 1, 2, 3
+
+KH_FMT_RGB, KH_FMT_BGR, KH_FMT_GRAY, KH_FMT_NV12, KH_FMT_YUYV = 0, 1, 2, 3, 4
+KH_SAMPLE_NEAREST, KH_SAMPLE_BILINEAR, KH_SAMPLE_LANCZOS = 0, 1, 2
+KH_OUT_F32, KH_OUT_F16 = 0, 1
+KH_PRE_FORCE_GENERIC = 1
+
+
+class KorniaHipError(RuntimeError):
+    """A failed C-ABI call; ``code`` is the KH_ERR_* status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+
+
+class PreprocessParams(C.Structure):
+    """``kh_preprocess_params`` (include/kornia_hip.h)."""
+
+    _fields_ = [
+        ("scale_x", C.c_float), ("scale_y", C.c_float), ("pad_x", C.c_float), ("pad_y", C.c_float),
+        ("src_w", C.c_int32), ("src_h", C.c_int32), ("src_pitch", C.c_int32), ("src_bpp", C.c_int32),
+        ("fmt", C.c_int32), ("dst_w", C.c_int32), ("dst_h", C.c_int32),
+        ("mean", C.c_float * 3), ("inv_std", C.c_float * 3), ("pad_value", C.c_float),
+        ("sampling", C.c_int32), ("out_dtype", C.c_int32), ("nframes", C.c_int32),
+        ("flags", C.c_int32), ("src_frame_stride", C.c_int64), ("dst_frame_stride", C.c_int64),
+    ]
+
+
+_vp, _i32, _u64, _sz, _f32 = C.c_void_p, C.c_int32, C.c_uint64, C.c_size_t, C.c_float
+_P = C.POINTER
+
+# name -> (restype, argtypes); every symbol kornia_hip.h declares must appear here
+# (tests/test_abi.py cross-checks the header against this table and the built library).
+SIGNATURES = {
+    "kh_last_error": (_sz, [C.c_char_p, _sz]),
+    "kh_version": (C.c_char_p, []),
+    "kh_device_count": (_i32, [_P(_i32)]),
+    "kh_set_device": (_i32, [_i32]),
+    "kh_get_device": (_i32, [_P(_i32)]),
+    "kh_device_info": (_i32, [_i32, C.c_char_p, _sz, _P(_i32), _P(_u64)]),
+    "kh_stream_create": (_i32, [_P(_vp)]),
+    "kh_stream_destroy": (_i32, [_vp]),
+    "kh_stream_synchronize": (_i32, [_vp]),
+    "kh_stream_wait_event": (_i32, [_vp, _vp]),
+    "kh_event_create": (_i32, [_P(_vp), _i32]),
+    "kh_event_destroy": (_i32, [_vp]),
+    "kh_event_record": (_i32, [_vp, _vp]),
+    "kh_event_synchronize": (_i32, [_vp]),
+    "kh_event_elapsed_ms": (_i32, [_vp, _vp, _P(_f32)]),
+    "kh_stream_fence": (_i32, [_vp, _vp]),
+    "kh_malloc_async": (_i32, [_P(_vp), _sz, _i32, _vp]),
+    "kh_free_async": (_i32, [_vp, _vp]),
+    "kh_mempool_set_release_threshold": (_i32, [_i32, _u64]),
+    "kh_host_alloc": (_i32, [_P(_vp), _sz]),
+    "kh_host_free": (_i32, [_vp]),
+    "kh_malloc_managed": (_i32, [_P(_vp), _sz]),
+    "kh_free": (_i32, [_vp]),
+    "kh_memcpy_h2d_async": (_i32, [_vp, _vp, _sz, _vp]),
+    "kh_memcpy_d2h_async": (_i32, [_vp, _vp, _sz, _vp]),
+    "kh_memcpy_d2d_async": (_i32, [_vp, _vp, _sz, _vp]),
+    "kh_memset_async": (_i32, [_vp, _i32, _sz, _vp]),
+    "kh_pointer_domain": (_i32, [_vp, _P(_i32), _P(_i32)]),
+    "kh_preprocess_to_chw": (_i32, [_vp, _vp, _vp, _P(PreprocessParams)]),
+    "kh_preprocess_variant": (C.c_char_p, [_P(PreprocessParams)]),
+}
+
+
+def _load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found — build it with `make -C kornia-rs_amd` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback for the device path."
+        )
+    # If torch is already in the process, its bundled libamdhip64.so.7 is the HIP runtime in
+    # use; loading ours afterwards binds to that same runtime (same SONAME).  Importing torch
+    # first keeps one runtime when both are wanted.
+    lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib.kh_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(code: int) -> None:
+    if code != KH_OK:
+        raise KorniaHipError(code, last_error())
+
+
+def version() -> str:
+    return lib.kh_version().decode()

@@ -1,0 +1,212 @@
+"""Device runtime objects over the C ABI: ``Stream``, ``Event``, raw device/pinned buffers.
+
+Mirrors ``kornia_rs.cuda`` of the reference (kornia-py/python/kornia_rs/cuda.pyi:22-75 —
+``Stream.new/default/from_handle/from_cuda_stream/synchronize/cuda_stream_ptr/__cuda_stream__``,
+``is_available``, ``mem_get_info``) with the HIP allocator of
+crates/kornia-tensor/src/cuda.rs underneath.  The module is named for HIP; there is no CUDA
+code path anywhere — ``__cuda_stream__`` / ``__cuda_array_interface__`` are kept only because
+they are the protocol names torch-ROCm and cupy-ROCm speak.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, lib
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    rc = lib.kh_device_count(C.byref(n))
+    return int(n.value) if rc == _ffi.KH_OK else 0
+
+
+def is_available() -> bool:
+    """True if a HIP device is usable in this process."""
+    return device_count() > 0
+
+
+def set_device(device: int) -> None:
+    check(lib.kh_set_device(device))
+
+
+def current_device() -> int:
+    d = C.c_int32(0)
+    check(lib.kh_get_device(C.byref(d)))
+    return int(d.value)
+
+
+def device_info(device: int = 0) -> Tuple[str, int, int]:
+    """(name, compute units, total bytes)."""
+    name = C.create_string_buffer(256)
+    cu = C.c_int32(0)
+    mem = C.c_uint64(0)
+    check(lib.kh_device_info(device, name, 256, C.byref(cu), C.byref(mem)))
+    return name.value.decode(), int(cu.value), int(mem.value)
+
+
+class Stream:
+    """A HIP stream handle.  The stream's device selects where ``Image.to_hip(stream)`` /
+    ``Image.zeros(..., stream=stream)`` place data."""
+
+    def __init__(self, handle: int, device: int, owned: bool):
+        self._handle = int(handle)
+        self.device = int(device)
+        self._owned = owned
+
+    @staticmethod
+    def new(device: int = 0) -> "Stream":
+        prev = current_device()
+        set_device(device)
+        try:
+            h = C.c_void_p(0)
+            check(lib.kh_stream_create(C.byref(h)))
+        finally:
+            set_device(prev)
+        return Stream(h.value or 0, device, owned=True)
+
+    @staticmethod
+    def default(device: int = 0) -> "Stream":
+        return Stream(0, device, owned=False)
+
+    @staticmethod
+    def from_handle(handle: int, device: Optional[int] = None) -> "Stream":
+        """Adopt a raw ``hipStream_t`` (e.g. ``torch.cuda.current_stream().cuda_stream``).
+        Not owned: never destroyed here."""
+        return Stream(int(handle), current_device() if device is None else device, owned=False)
+
+    @staticmethod
+    def from_cuda_stream(obj: Any) -> "Stream":
+        """Adopt a stream from any object speaking ``__cuda_stream__() -> (version, handle)``,
+        exposing ``.cuda_stream`` (torch), ``.ptr`` / ``.handle`` (cupy / cuda-python), or an int."""
+        if isinstance(obj, Stream):
+            return obj
+        if isinstance(obj, int):
+            return Stream.from_handle(obj)
+        if hasattr(obj, "__cuda_stream__"):
+            return Stream.from_handle(int(obj.__cuda_stream__()[1]), getattr(obj, "device_index", None))
+        for attr in ("cuda_stream", "ptr", "handle"):
+            if hasattr(obj, attr):
+                dev = getattr(obj, "device_index", None)
+                if dev is None and hasattr(obj, "device") and hasattr(obj.device, "index"):
+                    dev = obj.device.index
+                return Stream.from_handle(int(getattr(obj, attr)), dev)
+        raise TypeError(f"cannot adopt a stream from {type(obj).__name__}")
+
+    def synchronize(self) -> None:
+        check(lib.kh_stream_synchronize(self._handle))
+
+    @property
+    def cuda_stream_ptr(self) -> int:
+        return self._handle
+
+    hip_stream_ptr = cuda_stream_ptr
+
+    def __cuda_stream__(self) -> Tuple[int, int]:
+        return (0, self._handle)
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and self._handle:
+            try:
+                lib.kh_stream_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = 0
+
+    def __repr__(self) -> str:
+        return f"Stream(device={self.device}, handle=0x{self._handle:x})"
+
+
+class Event:
+    def __init__(self, timing: bool = True):
+        h = C.c_void_p(0)
+        check(lib.kh_event_create(C.byref(h), 1 if timing else 0))
+        self._handle = h.value
+
+    def record(self, stream: Stream) -> None:
+        check(lib.kh_event_record(self._handle, stream.cuda_stream_ptr))
+
+    def synchronize(self) -> None:
+        check(lib.kh_event_synchronize(self._handle))
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float(0)
+        check(lib.kh_event_elapsed_ms(self._handle, stop._handle, C.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            try:
+                lib.kh_event_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+
+def _stream_handle(stream: Optional[Stream]) -> int:
+    return 0 if stream is None else stream.cuda_stream_ptr
+
+
+class DeviceBuffer:
+    """An owned, stream-ordered device allocation (``CudaResource`` with ``Backing::Device`` in
+    crates/kornia-tensor/src/cuda.rs:89-169): carries its stream, freed on that stream."""
+
+    def __init__(self, nbytes: int, stream: Optional[Stream] = None, zeroed: bool = True):
+        self.stream = stream if stream is not None else Stream.default(current_device())
+        self.nbytes = int(nbytes)
+        p = C.c_void_p(0)
+        prev = current_device()
+        set_device(self.stream.device)
+        try:
+            check(lib.kh_malloc_async(C.byref(p), self.nbytes, 1 if zeroed else 0,
+                                      self.stream.cuda_stream_ptr))
+        finally:
+            set_device(prev)
+        self.ptr = p.value or 0
+
+    @staticmethod
+    def from_numpy(a: np.ndarray, stream: Optional[Stream] = None) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        buf = DeviceBuffer(a.nbytes, stream, zeroed=False)
+        buf.copy_from_host(a)
+        return buf
+
+    def copy_from_host(self, a: np.ndarray, offset: int = 0) -> None:
+        a = np.ascontiguousarray(a)
+        assert offset + a.nbytes <= self.nbytes
+        check(lib.kh_memcpy_h2d_async(self.ptr + offset, a.ctypes.data, a.nbytes,
+                                      self.stream.cuda_stream_ptr))
+        # pageable source: the runtime may still be reading `a`; keep the contract simple
+        self.stream.synchronize()
+
+    def to_numpy(self, dtype, shape, offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        check(lib.kh_memcpy_d2h_async(out.ctypes.data, self.ptr + offset, out.nbytes,
+                                      self.stream.cuda_stream_ptr))
+        self.stream.synchronize()
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            lib.kh_free_async(self.ptr, self.stream.cuda_stream_ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pointer_domain(ptr: int) -> Tuple[int, int]:
+    d = C.c_int32(0)
+    dev = C.c_int32(-1)
+    check(lib.kh_pointer_domain(ptr, C.byref(d), C.byref(dev)))
+    return int(d.value), int(dev.value)

@@ -1,0 +1,369 @@
+"""Fused camera preprocess — host side of ``kh_preprocess_to_chw``.
+
+Mirrors ``kornia_imgproc::preprocess`` (crates/kornia-imgproc/src/preprocess.rs): the
+``ResizeMode`` / ``Normalize`` / ``SourceFormat`` enums (:67-251), ``PreprocessError`` (:253-340),
+the shared ``Affine`` geometry (:350-369), the builder defaults (:662-672) and the ``run_raw`` /
+``run_raw_batch`` / ``run_surface`` / ``run`` entry points with their validation order
+(:887-1375) — and the Python class ``kornia_rs.Preprocessor``
+(kornia-py/python/kornia_rs/__init__.pyi:70-111).
+
+Device only: the kernel is the product.  A ``Preprocessor`` needs a ``Stream``; host operands are
+rejected with the reference's ``NotDeviceImage`` / ``NotDeviceTensor`` errors — never silently
+processed on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import PreprocessParams, check, lib
+from .hip import IMAGENET_MEAN, IMAGENET_STD, DeviceBuffer, Stream
+from .tensor import Tensor
+
+f32 = np.float32
+
+
+class PreprocessError(ValueError):
+    """``kind`` names the reference enum variant (P/preprocess.rs:253-340)."""
+
+    def __init__(self, kind: str, message: str, **fields):
+        super().__init__(message)
+        self.kind = kind
+        self.fields = fields
+
+
+class ResizeMode:
+    LETTERBOX = "letterbox"
+    STRETCH = "stretch"
+
+
+_SAMPLING = {"nearest": _ffi.KH_SAMPLE_NEAREST, "bilinear": _ffi.KH_SAMPLE_BILINEAR,
+             "lanczos": _ffi.KH_SAMPLE_LANCZOS}
+
+
+@dataclass(frozen=True)
+class SourceFormat:
+    """P/preprocess.rs:131-250."""
+
+    name: str
+    fmt_code: int
+    bpp: int
+    interleaved: bool
+
+    def pitch(self, w: int) -> int:
+        return w * self.bpp
+
+    def buffer_len(self, w: int, h: int) -> int:
+        chroma = w * h // 2 if self.name == "nv12" else 0
+        return self.pitch(w) * h + chroma
+
+    def dims_ok(self, w: int, h: int) -> bool:
+        if self.name == "nv12":
+            return w % 2 == 0 and h % 2 == 0
+        if self.name == "yuyv":
+            return w % 2 == 0
+        return True
+
+    @staticmethod
+    def from_name(name: str) -> Optional["SourceFormat"]:
+        return _FORMATS.get(name.lower())
+
+
+_FORMATS = {}
+for _names, _f in (
+    (("rgb", "rgb8"), SourceFormat("rgb8", _ffi.KH_FMT_RGB, 3, True)),
+    (("bgr", "bgr8"), SourceFormat("bgr8", _ffi.KH_FMT_BGR, 3, True)),
+    (("rgba", "rgba8"), SourceFormat("rgba8", _ffi.KH_FMT_RGB, 4, True)),
+    (("bgra", "bgra8"), SourceFormat("bgra8", _ffi.KH_FMT_BGR, 4, True)),
+    (("gray", "gray8"), SourceFormat("gray8", _ffi.KH_FMT_GRAY, 1, False)),
+    (("nv12",), SourceFormat("nv12", _ffi.KH_FMT_NV12, 1, False)),
+    (("yuyv",), SourceFormat("yuyv", _ffi.KH_FMT_YUYV, 2, False)),
+):
+    for _n in _names:
+        _FORMATS[_n] = _f
+
+
+def affine(mode: str, sw: int, sh: int, dw: int, dh: int) -> Tuple[f32, f32, f32, f32]:
+    """``Affine::new`` in f32 arithmetic (P/preprocess.rs:350-369): (scale_x, scale_y, pad_x, pad_y)."""
+    sw_, sh_, dw_, dh_ = f32(sw), f32(sh), f32(dw), f32(dh)
+    if mode == ResizeMode.LETTERBOX:
+        s = min(f32(dw_ / sw_), f32(dh_ / sh_))
+        return s, s, f32(f32(dw_ - f32(sw_ * s)) * f32(0.5)), f32(f32(dh_ - f32(sh_ * s)) * f32(0.5))
+    return f32(dw_ / sw_), f32(dh_ / sh_), f32(0.0), f32(0.0)
+
+
+def mean_inv_std(mean, std) -> Tuple[np.ndarray, np.ndarray]:
+    """``Normalize::mean_inv_std`` (P/preprocess.rs:107-121); ``None`` = UnitScale."""
+    if mean is None and std is None:
+        return np.zeros(3, f32), np.ones(3, f32)
+    mean = np.asarray(IMAGENET_MEAN if mean is None else mean, dtype=f32)
+    std = np.asarray(IMAGENET_STD if std is None else std, dtype=f32)
+    if mean.shape != (3,) or std.shape != (3,):
+        raise PreprocessError("InvalidNormalize", "mean/std must have 3 entries")
+    if not (np.all(np.isfinite(std)) and np.all(std > 0) and np.all(np.isfinite(mean))):
+        raise PreprocessError(
+            "InvalidNormalize",
+            f"invalid normalize: mean {mean.tolist()} must be finite, std {std.tolist()} must be finite and > 0",
+            mean=mean.tolist(), std=std.tolist())
+    return mean, (f32(1.0) / std).astype(f32)
+
+
+RawSource = Union[DeviceBuffer, Tensor, int]
+
+
+def _ptr_len(src: Any) -> Tuple[int, Optional[int]]:
+    if isinstance(src, DeviceBuffer):
+        return src.ptr, src.nbytes
+    if isinstance(src, Tensor):
+        if not src.is_device:
+            raise PreprocessError("NotDeviceImage",
+                                  "HIP preprocessor requires a device-resident source image")
+        return src.data_ptr, src.nbytes
+    if hasattr(src, "__cuda_array_interface__"):
+        cai = src.__cuda_array_interface__
+        n = int(np.prod(cai["shape"], dtype=np.int64)) * np.dtype(cai["typestr"]).itemsize
+        return int(cai["data"][0]), n
+    if isinstance(src, np.ndarray):
+        raise PreprocessError("NotDeviceImage",
+                              "HIP preprocessor requires a device-resident source image")
+    return int(src), None
+
+
+class Preprocessor:
+    """Resize (+pad) + normalise a raw frame into ``[N, 3, H, W]`` on a HIP stream."""
+
+    def __init__(self, mode: str = "letterbox", format: str = "rgb", sampling: str = "bilinear",
+                 f16: bool = False, mean: Optional[Sequence[float]] = None,
+                 std: Optional[Sequence[float]] = None, pad_value: float = 114,
+                 stream: Optional[Stream] = None):
+        if mode not in (ResizeMode.LETTERBOX, ResizeMode.STRETCH):
+            raise ValueError(f"unknown mode {mode!r} (expected 'letterbox' or 'stretch')")
+        fmt = SourceFormat.from_name(format)
+        if fmt is None:
+            raise ValueError(f"unknown source format {format!r}")
+        if sampling not in _SAMPLING:
+            raise PreprocessError(
+                "UnsupportedSampling",
+                f"unsupported sampling mode {sampling!r} (expected Nearest, Bilinear, or Lanczos)")
+        if stream is None:
+            raise PreprocessError(
+                "NotDeviceImage",
+                "this build has no CPU preprocessor: pass stream=Stream.default(device) "
+                "(the device kernel is the product; there is no CPU fallback)")
+        self.mode = mode
+        self.source_format = fmt
+        self.sampling = sampling
+        self.f16 = bool(f16)
+        self.mean, self.inv_std = mean_inv_std(mean, std)
+        self.pad_value = f32(pad_value)
+        self.stream = stream
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _params(self, sw: int, sh: int, pitch: int, bpp: int, fmt_code: int, dw: int, dh: int,
+                nframes: int, src_stride: int, out_f16: bool, force_generic: bool) -> PreprocessParams:
+        lim = 2**31 - 1
+        if sw > lim or sh > lim or pitch > lim or dw * dh > lim:
+            raise PreprocessError("DimensionsTooLarge",
+                                  "dimensions exceed the 32-bit kernel index limit")
+        sx, sy, px, py = affine(self.mode, sw, sh, dw, dh)
+        p = PreprocessParams()
+        p.scale_x, p.scale_y, p.pad_x, p.pad_y = sx, sy, px, py
+        p.src_w, p.src_h, p.src_pitch, p.src_bpp, p.fmt = sw, sh, pitch, bpp, fmt_code
+        p.dst_w, p.dst_h = dw, dh
+        for c in range(3):
+            p.mean[c] = self.mean[c]
+            p.inv_std[c] = self.inv_std[c]
+        p.pad_value = self.pad_value
+        p.sampling = _SAMPLING[self.sampling]
+        p.out_dtype = _ffi.KH_OUT_F16 if out_f16 else _ffi.KH_OUT_F32
+        p.nframes = nframes
+        p.flags = _ffi.KH_PRE_FORCE_GENERIC if force_generic else 0
+        p.src_frame_stride = src_stride
+        p.dst_frame_stride = 3 * dw * dh
+        return p
+
+    @staticmethod
+    def _validate_dst(dst: Tensor, expected_n: int, want_f16: bool) -> None:
+        """validate_dst_shape (P/preprocess.rs:805-818) + residency."""
+        if not isinstance(dst, Tensor) or not dst.is_device:
+            raise PreprocessError("NotDeviceTensor",
+                                  "HIP preprocessor requires a device-resident destination tensor")
+        shape = dst.shape
+        if len(shape) != 4 or shape[1] != 3 or (expected_n == 1 and shape[0] != 1):
+            raise PreprocessError("BadOutputShape",
+                                  f"destination tensor must be [1, 3, H, W], got {list(shape)}",
+                                  shape=list(shape))
+        if shape[0] != expected_n:
+            raise PreprocessError("BatchMismatch",
+                                  f"destination batch dim {shape[0]} != frame count {expected_n}",
+                                  dst_n=shape[0], frames=expected_n)
+        want = "float16" if want_f16 else "float32"
+        if dst.dtype != want:
+            raise PreprocessError("BadOutputShape", f"destination dtype {dst.dtype} != {want}")
+
+    def _validate_raw(self, got: Optional[int], w: int, h: int) -> None:
+        """validate_raw (P/preprocess.rs:1287-1301)."""
+        f = self.source_format
+        need = f.buffer_len(w, h)
+        if not f.dims_ok(w, h) or w <= 0 or h <= 0 or (got is not None and got < need):
+            raise PreprocessError(
+                "InvalidRawSource",
+                f"invalid raw source for {f.name} at {w}x{h} (got {got} bytes, need {need})",
+                format=f.name, width=w, height=h, got=got, need=need)
+
+    def _launch(self, src_ptr: int, dst: Tensor, p: PreprocessParams) -> None:
+        # Launch on the preprocessor's stream; if dst was produced on another stream, fence it
+        # in first (DeviceExec::for_streams, P/cuda/dispatch.rs:50-67).
+        if dst.stream is not None and dst.stream.cuda_stream_ptr != self.stream.cuda_stream_ptr:
+            check(lib.kh_stream_fence(dst.stream.cuda_stream_ptr, self.stream.cuda_stream_ptr))
+        check(lib.kh_preprocess_to_chw(self.stream.cuda_stream_ptr, src_ptr, dst.data_ptr, C.byref(p)))
+
+    # -- Rust-shaped entry points ---------------------------------------------------------------
+    def run_raw(self, src: RawSource, src_w: int, src_h: int, dst: Tensor, *,
+                _force_generic: bool = False) -> None:
+        """One raw frame -> ``[1, 3, H, W]`` (P/preprocess.rs:1184-1222)."""
+        want_f16 = isinstance(dst, Tensor) and dst.dtype == "float16"
+        self._validate_dst(dst, 1, want_f16)
+        ptr, n = _ptr_len(src)
+        self._validate_raw(n, src_w, src_h)
+        f = self.source_format
+        p = self._params(src_w, src_h, f.pitch(src_w), f.bpp, f.fmt_code, dst.shape[3], dst.shape[2],
+                         1, 0, want_f16, _force_generic)
+        self._launch(ptr, dst, p)
+
+    def run_raw_batch(self, frames: Union[Sequence[RawSource], RawSource], src_w: int, src_h: int,
+                      dst: Tensor, *, frame_stride: Optional[int] = None,
+                      _force_generic: bool = False) -> None:
+        """``N`` same-sized raw frames -> ``[N, 3, H, W]`` (P/preprocess.rs:1234-1282).
+
+        ``frames`` is either a sequence of per-frame device buffers (the reference signature) or
+        ONE device buffer holding ``N`` frames ``frame_stride`` bytes apart.  Equally-spaced
+        frames go out as a single batched launch; otherwise one launch per frame, like the
+        reference."""
+        f = self.source_format
+        need = f.buffer_len(src_w, src_h)
+        if frame_stride is not None:
+            n_frames = dst.shape[0] if isinstance(dst, Tensor) and len(dst.shape) == 4 else 0
+            want_f16 = isinstance(dst, Tensor) and dst.dtype == "float16"
+            self._validate_dst(dst, n_frames, want_f16)
+            ptr, n = _ptr_len(frames)
+            if frame_stride < need:
+                raise PreprocessError("InvalidRawSource",
+                                      f"frame stride {frame_stride} shorter than a frame ({need})",
+                                      format=f.name, width=src_w, height=src_h, got=frame_stride, need=need)
+            got = n if (n is None or n_frames == 0) else n - (n_frames - 1) * frame_stride
+            self._validate_raw(got, src_w, src_h)
+            ptrs = [ptr + k * frame_stride for k in range(n_frames)]
+        else:
+            frames = list(frames)
+            want_f16 = isinstance(dst, Tensor) and dst.dtype == "float16"
+            self._validate_dst(dst, len(frames), want_f16)
+            ptrs = []
+            for fr in frames:
+                ptr, n = _ptr_len(fr)
+                self._validate_raw(n, src_w, src_h)
+                ptrs.append(ptr)
+        if not ptrs:
+            return
+        dw, dh = dst.shape[3], dst.shape[2]
+        strides = {b - a for a, b in zip(ptrs, ptrs[1:])}
+        if len(strides) <= 1 and (not strides or next(iter(strides)) >= 0):
+            stride = strides.pop() if strides else 0
+            p = self._params(src_w, src_h, f.pitch(src_w), f.bpp, f.fmt_code, dw, dh, len(ptrs),
+                             stride, want_f16, _force_generic)
+            self._launch(ptrs[0], dst, p)
+        else:
+            item = 2 if want_f16 else 4
+            plane = 3 * dw * dh
+            for k, ptr in enumerate(ptrs):
+                view = Tensor((1, 3, dh, dw), dst.dtype, device_ptr=dst.data_ptr + k * plane * item,
+                              device=dst.device_id, stream=dst.stream, keepalive=dst)
+                p = self._params(src_w, src_h, f.pitch(src_w), f.bpp, f.fmt_code, dw, dh, 1, 0,
+                                 want_f16, _force_generic)
+                self._launch(ptr, view, p)
+
+    def run_surface(self, data: RawSource, width: int, height: int, row_pitch: int, channels: int,
+                    dst: Tensor) -> None:
+        """Pitched interleaved surface (``PitchedSurface``, P/preprocess.rs:380-391, 1112-1180)."""
+        want_f16 = isinstance(dst, Tensor) and dst.dtype == "float16"
+        self._validate_dst(dst, 1, want_f16)
+        f = self.source_format
+        if not f.interleaved:
+            raise PreprocessError("FormatNeedsRawBuffer",
+                                  f"source format {f.name} needs run_raw (raw device buffer), not the typed run()")
+        if channels not in (3, 4):
+            raise PreprocessError("UnsupportedChannels",
+                                  f"unsupported source channel count {channels} (expected 3 or 4)")
+        ptr, n = _ptr_len(data)
+        if (row_pitch < width * channels or width == 0 or height == 0
+                or (n is not None and n < row_pitch * height)):
+            raise PreprocessError("InvalidSurface",
+                                  "invalid pitched surface (need pitch >= width*channels and len >= pitch*height)")
+        if f.bpp == 4 and channels != 4:
+            raise PreprocessError("FormatNeedsRawBuffer", f"source format {f.name} needs 4 channels")
+        p = self._params(width, height, row_pitch, channels, f.fmt_code, dst.shape[3], dst.shape[2],
+                         1, 0, want_f16, False)
+        self._launch(ptr, dst, p)
+
+    def run_image(self, image: Any, dst: Tensor) -> None:
+        """Typed ``run(&Image<u8, C>, &mut Tensor)`` (P/preprocess.rs:887-905): interleaved
+        formats only; ``C`` comes from the image."""
+        c = int(image.channels)
+        if c not in (3, 4):
+            raise PreprocessError("UnsupportedChannels",
+                                  f"unsupported source channel count {c} (expected 3 or 4)")
+        want_f16 = isinstance(dst, Tensor) and dst.dtype == "float16"
+        self._validate_dst(dst, 1, want_f16)
+        f = self.source_format
+        ok = (c == 4) if f.name in ("rgba8", "bgra8") else f.interleaved
+        if not ok:
+            raise PreprocessError("FormatNeedsRawBuffer",
+                                  f"source format {f.name} needs run_raw (raw device buffer), not the typed run()")
+        if not image.is_device:
+            raise PreprocessError("NotDeviceImage",
+                                  "HIP preprocessor requires a device-resident source image")
+        w, h = int(image.width), int(image.height)
+        p = self._params(w, h, w * c, c, f.fmt_code, dst.shape[3], dst.shape[2], 1, 0, want_f16, False)
+        self._launch(image.data_ptr, dst, p)
+
+    # -- Python-shaped entry points (kornia_rs/__init__.pyi:88-111) ------------------------------
+    def alloc_output(self, out_height: int, out_width: int, batch: int = 1) -> Tensor:
+        return Tensor.zeros((batch, 3, out_height, out_width),
+                            "float16" if self.f16 else "float32", stream=self.stream)
+
+    def run(self, frame: Any, width: int, height: int, out_height: int, out_width: int,
+            out: Optional[Tensor] = None, consumer_stream: Any = None) -> Tensor:
+        """A raw frame (1-D uint8 numpy array, uploaded on the preprocessor's stream), a list of
+        them (batch), a device buffer, or an interleaved device ``Image``."""
+        frames: Optional[List[Any]] = None
+        if isinstance(frame, (list, tuple)):
+            frames = list(frame)
+            if out is not None:
+                raise ValueError("out= is only valid for a single raw frame")
+        n = len(frames) if frames is not None else 1
+        dst = out if out is not None else self.alloc_output(out_height, out_width, n)
+        if (dst.shape[2], dst.shape[3]) != (out_height, out_width):
+            raise PreprocessError("BadOutputShape",
+                                  f"out= is {list(dst.shape)}, expected [*, 3, {out_height}, {out_width}]")
+
+        def upload(a):
+            if isinstance(a, np.ndarray):
+                if a.dtype != np.uint8:
+                    raise TypeError("raw frames must be uint8")
+                return DeviceBuffer.from_numpy(a.reshape(-1), self.stream)
+            return a
+
+        if frames is not None:
+            self.run_raw_batch([upload(a) for a in frames], width, height, dst)
+        elif hasattr(frame, "channels") and hasattr(frame, "is_device"):
+            self.run_image(frame, dst)
+        else:
+            self.run_raw(upload(frame), width, height, dst)
+        if consumer_stream is not None:
+            cs = Stream.from_cuda_stream(consumer_stream)
+            check(lib.kh_stream_fence(self.stream.cuda_stream_ptr, cs.cuda_stream_ptr))
+        return dst

@@ -1,0 +1,75 @@
+/*
+ * ko_oracle.h — CPU oracle for the kornia-rs imgproc hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load libkornia_oracle.so; nothing under kornia-rs_amd/ links, imports
+ * or calls it, and the product path fails loudly when the HIP library is missing.
+ *
+ * Every function is a plain-C restatement of the reference's scalar arithmetic (the reference
+ * itself cannot be built here: no cargo/rustc).  Each cites the reference file:line it follows
+ * (paths relative to /root/reference: P/ = crates/kornia-imgproc/src/).  Built with
+ * `gcc -O2 -ffp-contract=off -fno-fast-math` so no multiply-add is fused unless the reference
+ * asks for `mul_add` (written as fmaf here).
+ *
+ * Pinning: tests/test_oracle_*.py check these functions against every known-answer vector the
+ * reference's own tests hold for the path — see tests/golden/README.md.
+ */
+#ifndef KO_ORACLE_H
+#define KO_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Number of OpenMP threads the oracle will use (1 when built without OpenMP). */
+int ko_max_threads(void);
+void ko_set_threads(int n);
+
+/* LCG fixture generator shared by the reference's GPU parity tests
+ * (P/cuda/color/mod.rs:303-321 pattern_u8 / pattern_f32).                                    */
+void ko_pattern_u8(uint8_t* out, size_t n);
+void ko_pattern_f32(float* out, size_t n);
+
+/* ---- fused camera preprocess (P/preprocess.rs:430-622, the CUDA kernel's arithmetic) ------ */
+typedef struct ko_preprocess_params {
+    float scale_x, scale_y, pad_x, pad_y;
+    int32_t src_w, src_h, src_pitch, src_bpp, fmt;
+    int32_t dst_w, dst_h;
+    float mean[3];
+    float inv_std[3];
+    float pad_value;
+    int32_t sampling;  /* 0 nearest, 1 bilinear, 2 lanczos */
+    int32_t out_dtype; /* 0 f32, 1 f16 bits */
+    int32_t nframes;
+    int32_t flags;
+    int64_t src_frame_stride; /* bytes */
+    int64_t dst_frame_stride; /* elements */
+} ko_preprocess_params;
+
+void ko_preprocess_to_chw(const uint8_t* src, void* dst, const ko_preprocess_params* p);
+/* Affine::new (P/preprocess.rs:350-369): mode 0 = Letterbox, 1 = Stretch; out = {sx, sy, px, py} */
+void ko_preprocess_affine(int mode, int sw, int sh, int dw, int dh, float out[4]);
+/* the kernel's manual f32 -> binary16 RNE (P/preprocess.rs:452-477) */
+uint16_t ko_f2h(float f);
+
+/* ---- colour: gray (P/color/gray/kernels.rs) ----------------------------------------------- */
+void ko_gray_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t npixels);
+void ko_gray_from_rgb_f32(const float* src, float* dst, size_t npixels);
+void ko_rgb_from_gray_u8(const uint8_t* src, uint8_t* dst, size_t npixels);
+void ko_rgb_from_gray_f32(const float* src, float* dst, size_t npixels);
+
+/* ---- colour: video decode / encode (P/color/yuv/kernels.rs Family B / C) ------------------ */
+/* layout: 0 NV12, 1 NV21, 2 I420, 3 YV12.  `buf` = Y plane then chroma, tightly packed.       */
+void ko_rgb_from_planar420(const uint8_t* buf, uint8_t* dst, int width, int height, int layout);
+/* layout: 0 YUYV, 1 UYVY, 2 YVYU */
+void ko_rgb_from_packed422(const uint8_t* src, uint8_t* dst, int width, int height, int layout);
+void ko_nv12_from_rgb(const uint8_t* src, uint8_t* dst, int width, int height);
+void ko_yuyv_from_rgb(const uint8_t* src, uint8_t* dst, int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

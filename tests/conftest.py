@@ -1,0 +1,39 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "kornia-rs_amd"))
+sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    """Build the HIP library and the oracle if a fresh checkout has neither (cross-compiles on CPU)."""
+    import subprocess
+
+    if not (ROOT / "kornia-rs_amd" / "lib" / "libkornia_hip.so").exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "kornia-rs_amd"), "-j8"], stdout=subprocess.DEVNULL)
+    if not (ROOT / "oracle" / "libkornia_oracle.so").exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "oracle")], stdout=subprocess.DEVNULL)
+
+
+_ensure_built()
+
+
+@pytest.fixture(scope="session")
+def gpu_stream():
+    """A non-default HIP stream on device 0; GPU tests fail (not skip) if the device or the
+    native library is missing — a silent fallback must never look green."""
+    import kornia_rs
+    from kornia_rs import hip
+
+    assert hip.is_available(), "no HIP device visible: -m gpu tests must run on the GPU box"
+    hip.set_device(0)
+    return hip.Stream.new(0)

@@ -1,0 +1,268 @@
+"""Pin the CPU oracle for the fused preprocess + video decode/encode against every known answer
+the reference's own tests hold for this path.  No GPU.
+
+Reference tests restated here (crates/kornia-imgproc/src/...):
+  color/gray/mod.rs:395-412        test_gray_from_rgb_u8            -> [104, 53]
+  color/yuv/kernels.rs:2068        packed422_known_gray             -> zeros
+  color/yuv/kernels.rs:2078-2104   planar420_nv12_matches_reference -> independent per-pixel ref
+  color/yuv/kernels.rs:1890-1921   encode_decode_constant_is_exact  -> |d| <= 2
+  color/yuv/kernels.rs:1923-1936   yuyv_layout_and_values
+  preprocess.rs:1429-1451          *_stretch_solid_all_sampling     -> v/255 within 1e-4
+  preprocess.rs:1454-1473          *_letterbox_pad_geometry
+  preprocess.rs:1493-1510          *_imagenet_normalize
+  preprocess.rs:1646-1680          f16_matches_f32_rounded          -> RNE bits == half::from_f32
+  preprocess.rs:1777-1848          cuda_fused_formats_match_chained -> fused == decode-then-RGB
+  preprocess.rs:1852-1893          cuda_run_raw_batch_matches_single
+  cuda/color/mod.rs:303-317        pattern_u8 (LCG fixture)
+"""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+CY, CUB, CUG, CVG, CVR = 1220542, 2116026, -409993, -852492, 1673527
+
+
+def ref_decode_px(y, u, v):
+    """Pure-python BT.601 Q20 decode, written from the published constants (independent of the C)."""
+    yy = max(int(y) - 16, 0) * CY
+    u, v = int(u) - 128, int(v) - 128
+    b = (yy + CUB * u + (1 << 19)) >> 20
+    g = (yy + CUG * u + CVG * v + (1 << 19)) >> 20
+    r = (yy + CVR * v + (1 << 19)) >> 20
+    return [min(max(c, 0), 255) for c in (r, g, b)]
+
+
+def raw_bytes(n):  # preprocess.rs:1770-1772
+    return np.array([(i * 7 + 13) % 251 for i in range(n)], np.uint8)
+
+
+def test_pattern_u8_prefix_and_lcg():
+    p = O.pattern_u8(20)
+    assert p[:15].tolist() == [0, 255, 255, 0, 0, 0, 255, 255, 255, 1, 254, 128, 128, 128, 64]
+    state = 0x12345678
+    want = []
+    for _ in range(5):
+        state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+        want.append(state >> 24)
+    assert p[15:].tolist() == want
+    assert O.pattern_u8(7).tolist() == [0, 255, 255, 0, 0, 0, 255]
+    f = O.pattern_f32(20)
+    assert np.array_equal(f, p.astype(np.float32) / np.float32(255.0))
+
+
+def test_gray_from_rgb_u8_known():
+    rgb = np.array([[[0, 128, 255]], [[128, 0, 128]]], np.uint8)
+    assert O.gray_from_rgb_u8(rgb).reshape(-1).tolist() == [104, 53]
+
+
+def test_packed422_known_gray():
+    out = O.rgb_from_yuyv(np.array([16, 128, 16, 128], np.uint8), 2, 1)
+    assert out.reshape(-1).tolist() == [0] * 6
+
+
+def test_planar420_nv12_matches_reference():
+    w = h = 4
+    y = np.array([(v * 9 + 16) & 0xFF for v in range(w * h)], np.uint8)
+    uv = np.array([(v * 5 + 100) & 0xFF for v in range(w * h // 2)], np.uint8)
+    got = O.rgb_from_nv12(np.concatenate([y, uv]), w, h)
+    cw = w // 2
+    for row in range(h):
+        for col in range(w):
+            idx = (row // 2) * cw * 2 + (col // 2) * 2
+            assert got[row, col].tolist() == ref_decode_px(y[row * w + col], uv[idx], uv[idx + 1])
+
+
+@pytest.mark.parametrize("w,h", [(64, 6), (70, 4)])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
+def test_planar420_all_layouts(w, h, layout):
+    # color/yuv/kernels.rs:2106-2160 planar420_neon_bulk_matches_reference
+    cw, ch = w // 2, h // 2
+    y = np.array([(i * 7 + 16) % 240 for i in range(w * h)], np.uint8)
+    if layout in (0, 1):
+        c0 = np.array([(i * 5 + 90) % 250 for i in range(cw * ch * 2)], np.uint8)
+        c1 = np.zeros(0, np.uint8)
+    else:
+        c0 = np.array([(i * 5 + 90) % 250 for i in range(cw * ch)], np.uint8)
+        c1 = np.array([(i * 3 + 40) % 250 for i in range(cw * ch)], np.uint8)
+    got = O.rgb_from_nv12(np.concatenate([y, c0, c1]), w, h, layout)
+    for row in range(h):
+        for col in range(w):
+            cy, cx = row // 2, col // 2
+            if layout == 0:
+                u, v = c0[cy * cw * 2 + cx * 2], c0[cy * cw * 2 + cx * 2 + 1]
+            elif layout == 1:
+                v, u = c0[cy * cw * 2 + cx * 2], c0[cy * cw * 2 + cx * 2 + 1]
+            elif layout == 2:
+                u, v = c0[cy * cw + cx], c1[cy * cw + cx]
+            else:
+                v, u = c0[cy * cw + cx], c1[cy * cw + cx]
+            assert got[row, col].tolist() == ref_decode_px(y[row * w + col], u, v)
+
+
+@pytest.mark.parametrize("layout,offs", [(0, (0, 1, 2, 3)), (1, (1, 0, 3, 2)), (2, (0, 3, 2, 1))])
+def test_packed422_layouts(layout, offs):
+    w, h = 70, 3
+    src = np.arange(w * h * 2, dtype=np.uint32).astype(np.uint8)  # ramp_u8
+    got = O.rgb_from_yuyv(src, w, h, layout)
+    oy0, ou, oy1, ov = offs
+    for row in range(h):
+        for g in range(w // 2):
+            q = src[row * w * 2 + g * 4: row * w * 2 + g * 4 + 4]
+            assert got[row, 2 * g].tolist() == ref_decode_px(q[oy0], q[ou], q[ov])
+            assert got[row, 2 * g + 1].tolist() == ref_decode_px(q[oy1], q[ou], q[ov])
+
+
+def test_encode_decode_constant_is_exact():
+    w, h = 8, 6
+    for rgbv in [(200, 50, 25), (0, 0, 0), (255, 255, 255), (17, 200, 99)]:
+        rgb = np.tile(np.array(rgbv, np.uint8), (h, w, 1))
+        back = O.rgb_from_yuyv(O.yuyv_from_rgb(rgb), w, h)
+        assert np.abs(back.astype(int) - rgb.astype(int)).max() <= 2
+        back2 = O.rgb_from_nv12(O.nv12_from_rgb(rgb), w, h)
+        assert np.abs(back2.astype(int) - rgb.astype(int)).max() <= 2
+
+
+def test_yuyv_layout_and_values():
+    rgb = np.array([[[255, 0, 0], [0, 0, 255]]], np.uint8)
+    out = O.yuyv_from_rgb(rgb).tolist()
+
+    def enc_y(r, g, b):
+        return min(max(((66 * r + 129 * g + 25 * b + 128) >> 8) + 16, 0), 255)
+
+    def enc_uv(r, g, b):
+        u = ((-38 * r - 74 * g + 112 * b + 128) >> 8) + 128
+        v = ((112 * r - 94 * g - 18 * b + 128) >> 8) + 128
+        return min(max(u, 0), 255), min(max(v, 0), 255)
+
+    u, v = enc_uv((255 + 0 + 1) >> 1, 0, (0 + 255 + 1) >> 1)
+    assert out == [enc_y(255, 0, 0), u, enc_y(0, 0, 255), v]
+
+
+# ---- fused preprocess ---------------------------------------------------------------------------
+
+def solid(w, h, px):
+    return np.tile(np.array(px, np.uint8), (h, w, 1))
+
+
+@pytest.mark.parametrize("sampling", ["nearest", "bilinear", "lanczos"])
+def test_stretch_solid_all_sampling(sampling):
+    out = O.preprocess(solid(5, 3, (10, 20, 30)), 5, 3, 4, 4, mode="stretch", sampling=sampling)[0]
+    for c, v in enumerate((10.0, 20.0, 30.0)):
+        assert np.abs(out[c] - np.float32(v) / np.float32(255.0)).max() < 1e-4
+
+
+def test_letterbox_pad_geometry():
+    out = O.preprocess(solid(4, 4, (100, 100, 100)), 4, 4, 8, 4, mode="letterbox", pad_value=32.0)[0]
+    want = np.full((4, 8), 32.0 / 255.0, np.float32)
+    want[:, 2:6] = 100.0 / 255.0
+    for c in range(3):
+        assert np.abs(out[c] - want).max() < 1e-4
+
+
+def test_affine_values():
+    # Letterbox 4x4 -> 8x4: scale 1, pad_x 2 (preprocess.rs:1457 comment); stretch has no pad.
+    assert O.affine("letterbox", 4, 4, 8, 4) == (1.0, 1.0, 2.0, 0.0)
+    sx, sy, px, py = O.affine("stretch", 1920, 1080, 640, 640)
+    assert (sx, sy, px, py) == (np.float32(640) / np.float32(1920), np.float32(640) / np.float32(1080), 0.0, 0.0)
+    s = O.affine("letterbox", 20, 10, 8, 6)  # preprocess.rs:1696: scale 0.4, one pad row
+    assert s[0] == s[1] == np.float32(0.4) and s[2] == 0.0 and abs(s[3] - 1.0) < 1e-6
+
+
+def test_rgba_matches_rgb():
+    d3 = O.preprocess(solid(6, 4, (40, 80, 120)), 6, 4, 8, 8, mode="stretch")
+    d4 = O.preprocess(np.tile(np.array((40, 80, 120, 200), np.uint8), (4, 6, 1)), 6, 4, 8, 8,
+                      fmt="rgba", mode="stretch")
+    assert np.array_equal(d3, d4)
+
+
+def test_imagenet_normalize():
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    out = O.preprocess(solid(4, 4, (128, 128, 128)), 4, 4, 4, 4, mode="stretch", mean=mean, std=std)[0]
+    for c in range(3):
+        want = (128.0 / 255.0 - mean[c]) / std[c]
+        assert abs(out[c, 0, 0] - want) < 1e-4
+
+
+def host_gradient(w, h, c):  # preprocess.rs:1397-1418
+    img = np.zeros((h, w, c), np.uint8)
+    for y in range(h):
+        for x in range(w):
+            for k in range(c):
+                img[y, x, k] = min(((x * 127 // (w - 1) + y * 127 // (h - 1)) & 0xFF) + k * 20, 255)
+    return img
+
+
+@pytest.mark.parametrize("sampling", ["nearest", "bilinear", "lanczos"])
+def test_f16_matches_f32_rounded(sampling):
+    src = host_gradient(23, 17, 3)
+    kw = dict(mode="letterbox", sampling=sampling, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225))
+    f32 = O.preprocess(src, 23, 17, 8, 6, **kw)
+    f16 = O.preprocess(src, 23, 17, 8, 6, f16=True, **kw)
+    assert np.array_equal(f32.astype(np.float16).view(np.uint16), f16)
+
+
+def test_f2h_sweep_matches_ieee_rne():
+    rng = np.random.default_rng(7)
+    vals = np.concatenate([
+        rng.standard_normal(4000).astype(np.float32) * np.float32(3.0),
+        (rng.standard_normal(2000) * 1e-6).astype(np.float32),  # f16 denormal range
+        np.array([0.0, -0.0, 65504.0, 65520.0, 1e9, -1e9, 2.0**-24, 2.0**-25, 2.0**-25 * 1.0001,
+                  5.9604645e-08, 6.1e-5, np.inf, -np.inf], np.float32),
+    ])
+    got = np.array([O.ko.ko_f2h(float(v)) for v in vals], np.uint16)
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)
+    # Reference quirk (preprocess.rs:459-464): |f| >= 2^16 takes the `exp >= 31` branch, which sets
+    # the quiet-NaN bit whenever the f32 mantissa is non-zero — 1e9 -> 0x7E00, not Inf.
+    big = np.abs(vals) >= 65536.0
+    man = vals.view(np.uint32) & 0x7FFFFF
+    want[big] = ((vals.view(np.uint32)[big] >> 16) & 0x8000) | 0x7C00 | np.where(man[big] != 0, 0x200, 0)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("sampling", ["nearest", "bilinear", "lanczos"])
+@pytest.mark.parametrize("fmt", ["nv12", "yuyv", "gray", "bgr"])
+def test_fused_formats_match_chained(fmt, sampling):
+    w, h = 8, 6
+    if fmt == "nv12":
+        raw = raw_bytes(w * h * 3 // 2)
+        rgb = O.rgb_from_nv12(raw, w, h)
+    elif fmt == "yuyv":
+        raw = raw_bytes(w * h * 2)
+        rgb = O.rgb_from_yuyv(raw, w, h)
+    elif fmt == "gray":
+        raw = raw_bytes(w * h)
+        rgb = np.repeat(raw.reshape(h, w, 1), 3, axis=2)
+    else:
+        raw = raw_bytes(w * h * 3)
+        rgb = raw.reshape(h, w, 3)[:, :, ::-1]
+    fused = O.preprocess(raw, w, h, 7, 5, fmt=fmt, sampling=sampling)
+    chained = O.preprocess(rgb, w, h, 7, 5, fmt="rgb", sampling=sampling)
+    assert np.abs(fused - chained).max() <= 1e-6
+
+
+def test_run_raw_batch_matches_single():
+    w, h = 8, 6
+    n = w * h * 3 // 2
+    frames = [((raw_bytes(n).astype(np.uint32) + k * 31) & 0xFF).astype(np.uint8) for k in range(3)]
+    batch = O.preprocess(np.concatenate(frames), w, h, 7, 5, fmt="nv12", nframes=3, src_frame_stride=n)
+    for k in range(3):
+        one = O.preprocess(frames[k], w, h, 7, 5, fmt="nv12")
+        assert np.array_equal(batch[k], one[0])
+
+
+def test_identity_geometry_is_plain_decode():
+    """At scale 1 / pad 0 the bilinear weights vanish: the fused output equals
+    (decode(Y,U,V)/255 - m) * is exactly — the property the device fast path relies on."""
+    w, h = 16, 8
+    raw = O.pattern_u8(w * h * 3 // 2)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    out = O.preprocess(raw, w, h, w, h, fmt="nv12", mode="stretch", mean=mean, std=std)[0]
+    rgb = O.rgb_from_nv12(raw, w, h).astype(np.float32)
+    m = np.asarray(mean, np.float32)
+    inv = (np.float32(1.0) / np.asarray(std, np.float32)).astype(np.float32)
+    want = ((rgb / np.float32(255.0)) - m) * inv
+    assert np.array_equal(out, want.transpose(2, 0, 1))
+    near = O.preprocess(raw, w, h, w, h, fmt="nv12", mode="stretch", sampling="nearest", mean=mean, std=std)[0]
+    assert np.array_equal(out, near)

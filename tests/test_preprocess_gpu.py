@@ -1,0 +1,248 @@
+"""GPU parity: fused preprocess HIP kernels vs the CPU oracle, through the C ABI.
+
+Bar: bit-exact for nearest / bilinear (integer decode + uncontracted f32, same expression tree
+as crates/kornia-imgproc/src/preprocess.rs:430-622), f16 bit-exact, Lanczos <= 2e-4 (device sinf
+vs libm sinf; the reference itself only compares Lanczos loosely, preprocess.rs:1685).
+Also restates the reference's own GPU tests for this kernel (preprocess.rs:1560-1939).
+"""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+IMAGENET = dict(mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225))
+
+
+def _pre(stream, **kw):
+    from kornia_rs import Preprocessor
+    return Preprocessor(stream=stream, **kw)
+
+
+def _run(stream, raw, w, h, dw, dh, *, fmt, mode="letterbox", sampling="bilinear", f16=False,
+         mean=None, std=None, pad_value=114, force_generic=False):
+    from kornia_rs import Tensor
+    from kornia_rs.hip import DeviceBuffer
+    pre = _pre(stream, mode=mode, format=fmt, sampling=sampling, f16=f16, mean=mean, std=std,
+               pad_value=pad_value)
+    src = DeviceBuffer.from_numpy(np.ascontiguousarray(raw).reshape(-1), stream)
+    dst = Tensor.uninit((1, 3, dh, dw), "float16" if f16 else "float32", stream)
+    pre.run_raw(src, w, h, dst, _force_generic=force_generic) if fmt in ("nv12", "yuyv", "gray") else \
+        pre.run_surface(src, w, h, w * (4 if fmt in ("rgba", "bgra") else 3),
+                        4 if fmt in ("rgba", "bgra") else 3, dst)
+    out = dst.numpy_raw()
+    return out.view(np.uint16) if f16 else out
+
+
+def _raw_for(fmt, w, h, seed=0):
+    n = {"rgb": 3 * w * h, "bgr": 3 * w * h, "rgba": 4 * w * h, "bgra": 4 * w * h, "gray": w * h,
+         "nv12": w * h * 3 // 2, "yuyv": 2 * w * h}[fmt]
+    return np.roll(O.pattern_u8(n + seed), -seed)[:n].copy()
+
+
+def _assert_bits_equal(got, want, what):
+    g = got.view(np.uint32) if got.dtype == np.float32 else got
+    w_ = want.view(np.uint32) if want.dtype == np.float32 else want
+    bad = np.nonzero(g != w_)
+    assert bad[0].size == 0, f"{what}: {bad[0].size} mismatching elements, first at {tuple(b[0] for b in bad)}: " \
+                             f"{got[tuple(b[0] for b in bad)]} vs {want[tuple(b[0] for b in bad)]}"
+
+
+@pytest.mark.parametrize("fmt", ["rgb", "bgr", "rgba", "bgra", "gray", "nv12", "yuyv"])
+@pytest.mark.parametrize("mode", ["letterbox", "stretch"])
+@pytest.mark.parametrize("sampling", ["nearest", "bilinear"])
+@pytest.mark.parametrize("f16", [False, True])
+def test_matches_oracle_bit_exact(gpu_stream, fmt, mode, sampling, f16):
+    for (w, h, dw, dh) in [(46, 34, 31, 27), (22, 18, 57, 41), (8, 6, 7, 5)]:
+        raw = _raw_for(fmt, w, h)
+        got = _run(gpu_stream, raw, w, h, dw, dh, fmt=fmt, mode=mode, sampling=sampling, f16=f16, **IMAGENET)
+        want = O.preprocess(raw, w, h, dw, dh, fmt=fmt, mode=mode, sampling=sampling, f16=f16, **IMAGENET)
+        _assert_bits_equal(got, want, f"{fmt}/{mode}/{sampling}/f16={f16} {w}x{h}->{dw}x{dh}")
+
+
+@pytest.mark.parametrize("fmt", ["rgb", "nv12", "yuyv", "gray"])
+@pytest.mark.parametrize("mode", ["letterbox", "stretch"])
+def test_lanczos_close_to_oracle(gpu_stream, fmt, mode):
+    w, h, dw, dh = 46, 34, 31, 27
+    raw = _raw_for(fmt, w, h)
+    got = _run(gpu_stream, raw, w, h, dw, dh, fmt=fmt, mode=mode, sampling="lanczos")
+    want = O.preprocess(raw, w, h, dw, dh, fmt=fmt, mode=mode, sampling="lanczos")
+    assert np.abs(got - want).max() <= 2e-4
+
+
+@pytest.mark.parametrize("sampling", ["nearest", "bilinear", "lanczos"])
+def test_solid_all_sampling(gpu_stream, sampling):  # preprocess.rs:1560-1590
+    src = np.tile(np.array((10, 20, 30), np.uint8), (3, 5, 1))
+    out = _run(gpu_stream, src, 5, 3, 4, 4, fmt="rgb", mode="stretch", sampling=sampling)[0]
+    for c, v in enumerate((10.0, 20.0, 30.0)):
+        assert np.abs(out[c] - v / 255.0).max() < 1e-4
+
+
+def test_pitched_surface_matches_tight(gpu_stream):  # preprocess.rs:1596-1641
+    from kornia_rs import Tensor
+    from kornia_rs.hip import DeviceBuffer
+    w, h, pitch = 23, 17, 23 * 4 + 13
+    tight = O.pattern_u8(w * h * 4).reshape(h, w * 4)
+    pitched = np.full((h, pitch), 0xAA, np.uint8)
+    pitched[:, : w * 4] = tight
+    for mode in ("letterbox", "stretch"):
+        pre = _pre(gpu_stream, mode=mode, format="rgba", **IMAGENET)
+        a = Tensor.uninit((1, 3, 6, 8), "float32", gpu_stream)
+        b = Tensor.uninit((1, 3, 6, 8), "float32", gpu_stream)
+        pre.run_surface(DeviceBuffer.from_numpy(tight, gpu_stream), w, h, w * 4, 4, a)
+        pre.run_surface(DeviceBuffer.from_numpy(pitched, gpu_stream), w, h, pitch, 4, b)
+        assert np.array_equal(a.numpy(), b.numpy())
+
+
+@pytest.mark.parametrize("sampling", ["nearest", "bilinear", "lanczos"])
+def test_f16_matches_f32_rounded(gpu_stream, sampling):  # preprocess.rs:1646-1680
+    w, h = 23, 17
+    raw = _raw_for("rgb", w, h)
+    f32 = _run(gpu_stream, raw, w, h, 8, 6, fmt="rgb", sampling=sampling, **IMAGENET)
+    f16 = _run(gpu_stream, raw, w, h, 8, 6, fmt="rgb", sampling=sampling, f16=True, **IMAGENET)
+    assert np.array_equal(f32.astype(np.float16).view(np.uint16), f16)
+
+
+def test_f16_overflow_quirk(gpu_stream):
+    """|v| >= 2^16 follows the reference's manual f2h (NaN pattern unless the mantissa is 0)."""
+    src = np.tile(np.array((255, 128, 0), np.uint8), (4, 4, 1))
+    kw = dict(fmt="rgb", mode="stretch", mean=(0.0, 0.0, 0.0), std=(1e-6, 2.0 ** -17, 1.0), f16=True)
+    got = _run(gpu_stream, src, 4, 4, 4, 4, **kw)
+    want = O.preprocess(src, 4, 4, 4, 4, **kw)
+    assert np.array_equal(got, want)
+    assert want[0, 0, 0, 0] == 0x7E00  # 1e6 is finite in f32 but not representable: NaN pattern
+
+
+@pytest.mark.parametrize("sampling", ["nearest", "bilinear", "lanczos"])
+@pytest.mark.parametrize("fmt", ["nv12", "yuyv", "gray", "bgr"])
+def test_fused_formats_match_chained(gpu_stream, fmt, sampling):  # preprocess.rs:1777-1848
+    w, h = 8, 6
+    raw = np.array([(i * 7 + 13) % 251 for i in range({"nv12": w * h * 3 // 2, "yuyv": w * h * 2,
+                                                         "gray": w * h, "bgr": w * h * 3}[fmt])], np.uint8)
+    rgb = {"nv12": lambda: O.rgb_from_nv12(raw, w, h), "yuyv": lambda: O.rgb_from_yuyv(raw, w, h),
+           "gray": lambda: np.repeat(raw.reshape(h, w, 1), 3, axis=2),
+           "bgr": lambda: raw.reshape(h, w, 3)[:, :, ::-1]}[fmt]()
+    fused = _run(gpu_stream, raw, w, h, 7, 5, fmt=fmt, sampling=sampling)
+    chained = _run(gpu_stream, rgb, w, h, 7, 5, fmt="rgb", sampling=sampling)
+    assert np.abs(fused - chained).max() <= 1e-6
+
+
+def test_run_raw_batch_matches_single(gpu_stream):  # preprocess.rs:1852-1893
+    from kornia_rs import PreprocessError, Tensor
+    from kornia_rs.hip import DeviceBuffer
+    w, h = 8, 6
+    n = w * h * 3 // 2
+    base = np.array([(i * 7 + 13) % 251 for i in range(n)], np.uint32)
+    raws = [((base + k * 31) & 0xFF).astype(np.uint8) for k in range(3)]
+    pre = _pre(gpu_stream, format="nv12")
+    bufs = [DeviceBuffer.from_numpy(r, gpu_stream) for r in raws]
+    batch = Tensor.uninit((3, 3, 5, 7), "float32", gpu_stream)
+    pre.run_raw_batch(bufs, w, h, batch)  # separate allocations: arbitrary strides
+    got = batch.numpy()
+    for k in range(3):
+        one = Tensor.uninit((1, 3, 5, 7), "float32", gpu_stream)
+        pre.run_raw(bufs[k], w, h, one)
+        assert np.array_equal(got[k], one.numpy()[0]), f"frame {k}"
+    # contiguous frames -> one batched launch; same answer
+    packed = DeviceBuffer.from_numpy(np.concatenate(raws), gpu_stream)
+    batch2 = Tensor.uninit((3, 3, 5, 7), "float32", gpu_stream)
+    pre.run_raw_batch(packed, w, h, batch2, frame_stride=n)
+    assert np.array_equal(batch2.numpy(), got)
+    bad = Tensor.uninit((2, 3, 5, 7), "float32", gpu_stream)
+    with pytest.raises(PreprocessError) as e:
+        pre.run_raw_batch(bufs, w, h, bad)
+    assert e.value.kind == "BatchMismatch" and e.value.fields == {"dst_n": 2, "frames": 3}
+
+
+def test_run_raw_validates_source(gpu_stream):  # preprocess.rs:1897-1937
+    from kornia_rs import PreprocessError, Tensor
+    from kornia_rs.hip import DeviceBuffer
+    pre = _pre(gpu_stream, format="nv12")
+    dst = Tensor.uninit((1, 3, 4, 4), "float32", gpu_stream)
+    short = DeviceBuffer.from_numpy(np.zeros(60, np.uint8), gpu_stream)
+    with pytest.raises(PreprocessError) as e:
+        pre.run_raw(short, 8, 6, dst)
+    assert e.value.kind == "InvalidRawSource" and e.value.fields["need"] == 72
+    odd = DeviceBuffer.from_numpy(np.zeros(8 * 5 * 2, np.uint8), gpu_stream)
+    with pytest.raises(PreprocessError) as e:
+        pre.run_raw(odd, 8, 5, dst)
+    assert e.value.kind == "InvalidRawSource"
+    surf = DeviceBuffer.from_numpy(np.zeros(8 * 6 * 4, np.uint8), gpu_stream)
+    with pytest.raises(PreprocessError) as e:
+        pre.run_surface(surf, 8, 6, 32, 4, dst)
+    assert e.value.kind == "FormatNeedsRawBuffer"
+    host = Tensor.zeros((1, 3, 4, 4), "float32")
+    with pytest.raises(PreprocessError) as e:
+        pre.run_raw(odd, 8, 6, host)
+    assert e.value.kind == "NotDeviceTensor"
+
+
+# ---- the north-star variant ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("w,h", [(64, 32), (1920, 1080), (20, 6), (4, 2)])
+@pytest.mark.parametrize("sampling", ["bilinear", "nearest"])
+def test_nv12_identity_fast_path_equals_generic_and_oracle(gpu_stream, w, h, sampling):
+    import ctypes as C
+    from kornia_rs import _ffi
+    raw = _raw_for("nv12", w, h, seed=3)
+    kw = dict(fmt="nv12", mode="stretch", sampling=sampling, **IMAGENET)
+    fast = _run(gpu_stream, raw, w, h, w, h, **kw)
+    slow = _run(gpu_stream, raw, w, h, w, h, force_generic=True, **kw)
+    want = O.preprocess(raw, w, h, w, h, **kw)
+    _assert_bits_equal(fast, want, "fast path vs oracle")
+    _assert_bits_equal(slow, want, "generic vs oracle")
+    # and the dispatcher really picks the specialised kernel for this geometry
+    pre = _pre(gpu_stream, mode="stretch", format="nv12", sampling=sampling, **IMAGENET)
+    p = pre._params(w, h, w, 1, _ffi.KH_FMT_NV12, w, h, 1, 0, False, False)
+    assert _ffi.lib.kh_preprocess_variant(C.byref(p)) == b"nv12_identity"
+    p.flags = _ffi.KH_PRE_FORCE_GENERIC
+    assert _ffi.lib.kh_preprocess_variant(C.byref(p)) == b"generic"
+
+
+def test_nv12_identity_batch_1080p(gpu_stream):
+    """Batched launch at the BASELINE frame size: every frame equals its single-frame result,
+    and a D2H checksum-of-frames matches the oracle on two sampled frames."""
+    from kornia_rs import Tensor
+    from kornia_rs.hip import DeviceBuffer
+    w, h, n = 1920, 1080, 8
+    fb = w * h * 3 // 2
+    base = O.pattern_u8(fb + 31 * n)
+    frames = np.stack([base[31 * k: 31 * k + fb] for k in range(n)])
+    pre = _pre(gpu_stream, mode="stretch", format="nv12", **IMAGENET)
+    src = DeviceBuffer.from_numpy(frames.reshape(-1), gpu_stream)
+    dst = Tensor.uninit((n, 3, h, w), "float32", gpu_stream)
+    pre.run_raw_batch(src, w, h, dst, frame_stride=fb)
+    got = dst.numpy()
+    gen = Tensor.uninit((n, 3, h, w), "float32", gpu_stream)
+    pre.run_raw_batch(src, w, h, gen, frame_stride=fb, _force_generic=True)
+    assert np.array_equal(got.view(np.uint32), gen.numpy().view(np.uint32))
+    for k in (0, n - 1):
+        want = O.preprocess(frames[k], w, h, w, h, fmt="nv12", mode="stretch", **IMAGENET)[0]
+        assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), f"frame {k}"
+
+
+def test_unaligned_nv12_identity_falls_back_to_generic_kernel(gpu_stream):
+    """Width not divisible by 4: the dispatcher must use the generic kernel (still on device) and
+    stay bit-exact."""
+    w, h = 22, 10
+    raw = _raw_for("nv12", w, h)
+    got = _run(gpu_stream, raw, w, h, w, h, fmt="nv12", mode="stretch")
+    want = O.preprocess(raw, w, h, w, h, fmt="nv12", mode="stretch")
+    _assert_bits_equal(got, want, "22x10 identity")
+
+
+def test_python_run_api(gpu_stream):
+    """kornia_rs.Preprocessor.run(frame, w, h, oh, ow) with numpy frames (uploads on its stream)."""
+    w, h = 32, 16
+    raw = _raw_for("nv12", w, h)
+    pre = _pre(gpu_stream, mode="letterbox", format="nv12", **IMAGENET)
+    out = pre.run(raw, w, h, 24, 24)
+    assert out.shape == (1, 3, 24, 24) and out.device == "cuda:0" and out.dtype == "float32"
+    want = O.preprocess(raw, w, h, 24, 24, fmt="nv12", **IMAGENET)
+    assert np.array_equal(out.numpy(), want)
+    outs = pre.run([raw, raw[::-1].copy()], w, h, 24, 24)
+    assert outs.shape == (2, 3, 24, 24)
+    assert np.array_equal(outs.numpy()[0], want[0])
+    cai = out.__cuda_array_interface__
+    assert cai["shape"] == (1, 3, 24, 24) and cai["typestr"] == "<f4" and cai["data"][0] == out.data_ptr
