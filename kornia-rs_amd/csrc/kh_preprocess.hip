@@ -13,9 +13,9 @@
 //   * preprocess_generic  — one thread per destination pixel, any geometry/format/sampler.
 //     Batched with grid.y = frame (the reference launches once per frame, :1277-1280).
 //   * preprocess_nv12_identity — the north-star case (NV12, scale 1, pad 0, same size): every
-//     source byte is read exactly once (1.5 B/px) and 12 B/px are written.  A thread owns a
-//     4x2 pixel block: two dword luma loads, one dword chroma load (2 UV pairs shared by both
-//     rows), six 16-byte plane stores, so a wave writes 1 KiB contiguous per store instruction.
+//     source byte is needed exactly once (1.5 B/px) and 12 B/px are written.  A thread owns 4
+//     pixels of one row: one dword luma load, one dword chroma load (2 UV pairs), three
+//     16-byte plane stores, so a wave writes 1 KiB contiguous per store instruction.
 //     At scale 1 the bilinear weights are exactly 0 (`ax == ay == 0.0f`), hence
 //     `t00 + (t10 - t00) * 0 == t00` for the finite 0..255 taps and the result equals the
 //     generic kernel bit for bit; tests assert that equality.
@@ -204,28 +204,43 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
     else *reinterpret_cast<f32x4*>(p) = v;
 }
 
+// x / 255.0f for x an integer in [0, 255], without the ~10-instruction IEEE division sequence:
+// q = x * (1/255), one fma residual, one fma correction.  Exhaustively equal to the correctly
+// rounded quotient for all 256 inputs (tests/test_host_math.py proves it on the host with the
+// same IEEE fma; the GPU parity tests sweep every byte value through this path).
+__device__ __forceinline__ float div255_u8(float x) {
+    const float rc = 1.0f / 255.0f;
+    const float q = x * rc;
+    const float r = __builtin_fmaf(-q, 255.0f, x);
+    return __builtin_fmaf(r, rc, q);
+}
+
+// One thread = 4 pixels of ONE row, all three planes: a wave writes three 1 KiB-contiguous
+// segments (3 store streams; the 4x2 variant's 6 streams measured ~8 % slower, see
+// profiles/r01b_ubench_nv12.txt).  The chroma dword is read by both rows of a pair; the second
+// read is an L2 / Infinity-Cache hit.
 template <bool NT>
 __global__ __launch_bounds__(kBlock) void preprocess_nv12_identity(
     const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a) {
-    const int wq = a.src_w >> 2;             // 4-pixel groups per row
-    const int groups = wq * (a.src_h >> 1);  // 4x2 blocks per frame
+    const int wq = a.src_w >> 2;     // 4-pixel groups per row
+    const int groups = wq * a.src_h;
     const int g = blockIdx.x * kBlock + threadIdx.x;
     if (g >= groups) return;
     const uint8_t* src = src_base + (long long)blockIdx.y * a.src_frame_stride;
     float* dst = dst_base + (long long)blockIdx.y * a.dst_frame_stride;
 
-    const int rp = g / wq;       // chroma row == luma row pair
-    const int xq = g - rp * wq;  // 4-pixel group within the row
+    const int r = g / wq;
+    const int xq = g - r * wq;
     const int w = a.src_w;
     const long long plane = (long long)w * a.src_h;
+    const long long off = (long long)r * w + 4 * xq;
 
-    const uint32_t ytop = *reinterpret_cast<const uint32_t*>(src + (long long)(2 * rp) * w + 4 * xq);
-    const uint32_t ybot =
-        *reinterpret_cast<const uint32_t*>(src + (long long)(2 * rp + 1) * w + 4 * xq);
-    const uint32_t uv4 = *reinterpret_cast<const uint32_t*>(src + plane + (long long)rp * w + 4 * xq);
+    const uint32_t y4 = *reinterpret_cast<const uint32_t*>(src + off);
+    const uint32_t uv4 =
+        *reinterpret_cast<const uint32_t*>(src + plane + (long long)(r >> 1) * w + 4 * xq);
 
-    // Chroma terms shared by the 2x2 block; integer adds are exact so hoisting the rounding
-    // constant is the same value as (yy + c*u + half).
+    // Chroma terms shared by each pixel pair; integer adds are exact, so hoisting the rounding
+    // constant gives the same value as (yy + c*u + half).
     int tb[2], tg[2], tr[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -236,30 +251,21 @@ __global__ __launch_bounds__(kBlock) void preprocess_nv12_identity(
         tr[k] = kCVR * v + kHalf20;
     }
 
-    float o[2][3][4];
+    float o[3][4];
 #pragma unroll
-    for (int row = 0; row < 2; ++row) {
-        const uint32_t y4 = row ? ybot : ytop;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int yy = max((int)((y4 >> (8 * j)) & 0xFFu) - 16, 0) * kCY;
-            const int k = j >> 1;
-            const float r = (float)clamp255((yy + tr[k]) >> 20);
-            const float gg = (float)clamp255((yy + tg[k]) >> 20);
-            const float b = (float)clamp255((yy + tb[k]) >> 20);
-            o[row][0][j] = (r / 255.0f - a.m0) * a.is0;
-            o[row][1][j] = (gg / 255.0f - a.m1) * a.is1;
-            o[row][2][j] = (b / 255.0f - a.m2) * a.is2;
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int yy = max((int)((y4 >> (8 * j)) & 0xFFu) - 16, 0) * kCY;
+        const int k = j >> 1;
+        const float rr = (float)clamp255((yy + tr[k]) >> 20);
+        const float gg = (float)clamp255((yy + tg[k]) >> 20);
+        const float bb = (float)clamp255((yy + tb[k]) >> 20);
+        o[0][j] = (div255_u8(rr) - a.m0) * a.is0;
+        o[1][j] = (div255_u8(gg) - a.m1) * a.is1;
+        o[2][j] = (div255_u8(bb) - a.m2) * a.is2;
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-#pragma unroll
-        for (int row = 0; row < 2; ++row) {
-            float* p = dst + c * plane + (long long)(2 * rp + row) * w + 4 * xq;
-            store4<NT>(p, o[row][c][0], o[row][c][1], o[row][c][2], o[row][c][3]);
-        }
-    }
+    for (int c = 0; c < 3; ++c)
+        store4<NT>(dst + c * plane + off, o[c][0], o[c][1], o[c][2], o[c][3]);
 }
 
 bool identity_fast_path(const kh_preprocess_params* p, const uint8_t* src, const void* dst) {
@@ -367,7 +373,7 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
     hipStream_t s = as_hip(stream);
 
     if (identity_fast_path(p, src, dst)) {
-        const int groups = (p->src_w / 4) * (p->src_h / 2);
+        const int groups = (p->src_w / 4) * p->src_h;
         dim3 grid(cdiv(groups, kBlock), (unsigned)p->nframes);
         hipLaunchKernelGGL((preprocess_nv12_identity<true>), grid, dim3(kBlock), 0, s, src,
                            (float*)dst, a);

@@ -54,6 +54,8 @@ void ko_preprocess_to_chw(const uint8_t* src, void* dst, const ko_preprocess_par
 void ko_preprocess_affine(int mode, int sw, int sh, int dw, int dh, float out[4]);
 /* the kernel's manual f32 -> binary16 RNE (P/preprocess.rs:452-477) */
 uint16_t ko_f2h(float f);
+/* see ko_preprocess.c: exhaustively-checked x/255 shortcut used by the device fast path */
+float ko_div255_fma(float x);
 
 /* ---- colour: gray (P/color/gray/kernels.rs) ----------------------------------------------- */
 void ko_gray_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t npixels);

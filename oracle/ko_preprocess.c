@@ -237,3 +237,13 @@ void ko_preprocess_to_chw(const uint8_t* src_base, void* dst_base, const ko_prep
         }
     }
 }
+
+/* Host twin of the device fast path's x/255 shortcut (kornia-rs_amd/csrc/kh_preprocess.hip
+ * div255_u8): q = x*(1/255); r = fma(-q,255,x); q' = fma(r,1/255,q).  tests/test_host_math.py
+ * checks q' == x / 255.0f for every integer x in [0,255], the only inputs the path ever sees. */
+float ko_div255_fma(float x) {
+    const float rc = 1.0f / 255.0f;
+    const float q = x * rc;
+    const float r = fmaf(-q, 255.0f, x);
+    return fmaf(r, rc, q);
+}

@@ -1,0 +1,237 @@
+// Dev micro-benchmark #3 (not shipped): real NV12->CHW compute with (a) occupancy caps,
+// (b) one wide load per wave staged through LDS, (c) 4x1 (3 store streams) mapping; plus a flat
+// mixed read/write ceiling with the same 1:8 read:write byte ratio.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kCY = 1220542, kCUB = 2116026, kCUG = -409993, kCVG = -852492, kCVR = 1673527, kHalf20 = 1 << 19;
+__device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }
+struct Args { int w, h; float m0, m1, m2, is0, is1, is2; long long sfs, dfs; };
+template <bool NT> __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
+    f32x4 v = {a, b, c, d};
+    if constexpr (NT) __builtin_nontemporal_store(v, (f32x4*)p); else *(f32x4*)p = v;
+}
+extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+
+template <int DIV>
+__device__ __forceinline__ float norm1(int v, float m, float is) {
+    const float x = (float)v;
+    if constexpr (DIV == 1) {
+        const float rc = 1.0f / 255.0f;
+        float q = x * rc, r = __builtin_fmaf(-q, 255.0f, x);
+        q = __builtin_fmaf(r, rc, q);
+        return (q - m) * is;
+    } else {
+        return (x / 255.0f - m) * is;
+    }
+}
+
+template <int DIV>
+__device__ __forceinline__ void decode_row(uint32_t y4, const int tb[2], const int tg[2], const int tr[2], const Args& a, float o[3][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int yy = max((int)((y4 >> (8 * j)) & 0xFFu) - 16, 0) * kCY;
+        const int k = j >> 1;
+        o[0][j] = norm1<DIV>(clamp255((yy + tr[k]) >> 20), a.m0, a.is0);
+        o[1][j] = norm1<DIV>(clamp255((yy + tg[k]) >> 20), a.m1, a.is1);
+        o[2][j] = norm1<DIV>(clamp255((yy + tb[k]) >> 20), a.m2, a.is2);
+    }
+}
+__device__ __forceinline__ void chroma_terms(uint32_t uv4, int tb[2], int tg[2], int tr[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = (int)((uv4 >> (16 * k)) & 0xFFu) - 128, v = (int)((uv4 >> (16 * k + 8)) & 0xFFu) - 128;
+        tb[k] = kCUB * u + kHalf20; tg[k] = kCUG * u + kCVG * v + kHalf20; tr[k] = kCVR * v + kHalf20;
+    }
+}
+
+// baseline: 4x2 per thread, 3 dword loads per thread
+template <bool NT, int DIV>
+__global__ __launch_bounds__(256) void k_base(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    const int wq = a.w >> 2, groups = wq * (a.h >> 1);
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const int rp = g / wq, xq = g - rp * wq, w = a.w;
+    const long long plane = (long long)w * a.h;
+    const uint32_t yt = *(const uint32_t*)(src + (long long)(2 * rp) * w + 4 * xq);
+    const uint32_t yb = *(const uint32_t*)(src + (long long)(2 * rp + 1) * w + 4 * xq);
+    const uint32_t uv4 = *(const uint32_t*)(src + plane + (long long)rp * w + 4 * xq);
+    int tb[2], tg[2], tr[2];
+    chroma_terms(uv4, tb, tg, tr);
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        float o[3][4];
+        decode_row<DIV>(row ? yb : yt, tb, tg, tr, a, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            st4<NT>(dst + c * plane + (long long)(2 * rp + row) * w + 4 * xq, o[c][0], o[c][1], o[c][2], o[c][3]);
+    }
+}
+
+// staged: a wave owns 256 px x 2 rows (64 quads) of ONE row pair; w % 256 == 0 NOT required:
+// waves are laid out per row pair (ceil(w/256) waves each), idle lanes at the right edge.
+// One global_load_dwordx4 by 48 lanes (Y top / Y bottom / UV, 256 B each) -> LDS -> dword per lane.
+template <bool NT, int DIV>
+__global__ __launch_bounds__(256) void k_staged(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    u32x4* lds = (u32x4*)dyn_lds;                       // [4 waves][48] x 16 B
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wpr = (a.w + 255) >> 8;                   // waves per row pair
+    const int gw = blockIdx.x * 4 + wv;                 // global wave id within the frame
+    const int rp = gw / wpr, seg = gw - rp * wpr;
+    const bool live = rp < (a.h >> 1);
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const int w = a.w;
+    const long long plane = (long long)w * a.h;
+    const int x0 = seg * 256;                           // first pixel of this wave
+    if (live && lane < 48) {
+        const int part = lane >> 4, l16 = lane & 15;    // 0: Y top, 1: Y bottom, 2: UV
+        const int xb = x0 + 16 * l16;
+        if (xb < w) {                                   // w % 16 == 0 assumed for this variant
+            const uint8_t* p = part == 2 ? src + plane + (long long)rp * w + xb
+                                         : src + (long long)(2 * rp + part) * w + xb;
+            lds[wv * 48 + lane] = *(const u32x4*)p;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const int x = x0 + 4 * lane;
+    if (x >= w) return;
+    const uint32_t* l32 = (const uint32_t*)(lds + wv * 48);
+    const uint32_t yt = l32[lane], yb = l32[64 + lane], uv4 = l32[128 + lane];
+    int tb[2], tg[2], tr[2];
+    chroma_terms(uv4, tb, tg, tr);
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        float o[3][4];
+        decode_row<DIV>(row ? yb : yt, tb, tg, tr, a, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            st4<NT>(dst + c * plane + (long long)(2 * rp + row) * w + x, o[c][0], o[c][1], o[c][2], o[c][3]);
+    }
+}
+
+// 4x1: thread = 4 px of one row (3 store streams); UV row is read by both rows of the pair
+template <bool NT, int DIV>
+__global__ __launch_bounds__(256) void k_4x1(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const int r = g / wq, xq = g - r * wq, w = a.w;
+    const long long plane = (long long)w * a.h;
+    const uint32_t y4 = *(const uint32_t*)(src + (long long)r * w + 4 * xq);
+    const uint32_t uv4 = *(const uint32_t*)(src + plane + (long long)(r >> 1) * w + 4 * xq);
+    int tb[2], tg[2], tr[2];
+    chroma_terms(uv4, tb, tg, tr);
+    float o[3][4];
+    decode_row<DIV>(y4, tb, tg, tr, a, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        st4<NT>(dst + c * plane + (long long)r * w + 4 * xq, o[c][0], o[c][1], o[c][2], o[c][3]);
+}
+
+// flat mixed ceiling: each wave writes 1 KiB contiguous and reads 128 B contiguous (8 lanes x 16 B)
+__global__ __launch_bounds__(256) void k_flat_rw(const uint8_t* __restrict__ sb, float* __restrict__ db, long long n4) {
+    const long long i = (long long)blockIdx.y * gridDim.x * 256 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int lane = threadIdx.x & 63;
+    float f = 1.0f;
+    if (lane < 8) { u32x4 v = *(const u32x4*)(sb + (i >> 6) * 128 + 16 * lane); f = __uint_as_float(v.x ^ v.y ^ v.z ^ v.w); }
+    f = __shfl(f, lane & 7);
+    st4<false>(db + 4 * i, f, f, f, f);
+}
+
+int main(int argc, char** argv) {
+    const int W = 1920, H = 1080, N = argc > 1 ? atoi(argv[1]) : 1024, ROUNDS = 5;
+    const size_t fb = (size_t)W * H * 3 / 2, ob = (size_t)W * H * 3;
+    uint8_t* src; float *dst, *ref;
+    CK(hipMalloc(&src, fb * N)); CK(hipMalloc(&dst, ob * N * 4)); CK(hipMalloc(&ref, ob * 2 * 4));
+    {
+        std::vector<uint8_t> h(fb + 31 * 64); uint32_t s = 0x12345678u;
+        for (auto& b : h) { s = s * 1664525u + 1013904223u; b = (uint8_t)(s >> 24); }
+        for (int k = 0; k < N; ++k) CK(hipMemcpy(src + k * fb, h.data() + 31 * (k % 64), fb, hipMemcpyHostToDevice));
+    }
+    Args a{W, H, 0.485f, 0.456f, 0.406f, 1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f, (long long)fb, (long long)ob};
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int g2 = (W / 4) * (H / 2), g1 = (W / 4) * H;
+    const int wpr = (W + 255) / 256, nw = wpr * (H / 2);
+    const long long n4 = (long long)ob * N / 4;
+    const double full = (double)(fb + ob * 4) * N;
+    struct V { std::string name; std::function<void(int)> run; std::vector<float> ms; };
+    std::vector<V> vs;
+    auto G = [&](int groups, int n) { return dim3((groups + 255) / 256, n); };
+    for (int lds : {0, 40, 53, 80}) {
+        int bytes = lds ? lds * 1024 - 256 : 0;
+        std::string s = lds ? " lds=" + std::to_string(lds) + "K" : "";
+        vs.push_back({"base 4x2 st div" + s, [&, bytes](int n) { hipLaunchKernelGGL((k_base<false, 0>), G(g2, n), dim3(256), bytes, st, src, dst, a); }, {}});
+        vs.push_back({"base 4x2 st rcpfma" + s, [&, bytes](int n) { hipLaunchKernelGGL((k_base<false, 1>), G(g2, n), dim3(256), bytes, st, src, dst, a); }, {}});
+    }
+    for (int lds : {4, 40, 53, 80}) {
+        int bytes = lds * 1024 - (lds > 4 ? 256 : 0);
+        std::string s = " lds=" + std::to_string(lds) + "K";
+        vs.push_back({"staged 4x2 st div" + s, [&, bytes](int n) { hipLaunchKernelGGL((k_staged<false, 0>), dim3((nw + 3) / 4, n), dim3(256), bytes, st, src, dst, a); }, {}});
+        vs.push_back({"staged 4x2 st rcpfma" + s, [&, bytes](int n) { hipLaunchKernelGGL((k_staged<false, 1>), dim3((nw + 3) / 4, n), dim3(256), bytes, st, src, dst, a); }, {}});
+    }
+    vs.push_back({"staged 4x2 NT rcpfma lds=53K", [&](int n) { hipLaunchKernelGGL((k_staged<true, 1>), dim3((nw + 3) / 4, n), dim3(256), 53 * 1024 - 256, st, src, dst, a); }, {}});
+    for (int lds : {0, 40, 53, 80}) {
+        int bytes = lds ? lds * 1024 - 256 : 0;
+        std::string s = lds ? " lds=" + std::to_string(lds) + "K" : "";
+        vs.push_back({"4x1 st rcpfma" + s, [&, bytes](int n) { hipLaunchKernelGGL((k_4x1<false, 1>), G(g1, n), dim3(256), bytes, st, src, dst, a); }, {}});
+    }
+    for (int lds : {0, 40, 80}) {
+        int bytes = lds ? lds * 1024 - 256 : 0;
+        std::string s = lds ? " lds=" + std::to_string(lds) + "K" : "";
+        vs.push_back({"flat R(128B)+W(1KiB) per wave" + s, [&, bytes](int n) {
+            long long m4 = (long long)ob * n / 4;
+            hipLaunchKernelGGL(k_flat_rw, dim3(65536, (unsigned)((m4 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), bytes, st, src, dst, m4); }, {}});
+    }
+    const int cap = 160 * 1024 - 256;
+    CK(hipFuncSetAttribute((const void*)k_base<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    CK(hipFuncSetAttribute((const void*)k_base<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    CK(hipFuncSetAttribute((const void*)k_staged<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    CK(hipFuncSetAttribute((const void*)k_staged<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    CK(hipFuncSetAttribute((const void*)k_staged<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    CK(hipFuncSetAttribute((const void*)k_4x1<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    CK(hipFuncSetAttribute((const void*)k_flat_rw, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+
+    // correctness of every real variant vs base/div on 2 frames (bitwise)
+    std::vector<float> want(ob * 2), got(ob * 2);
+    hipLaunchKernelGGL((k_base<false, 0>), G(g2, 2), dim3(256), 0, st, src, dst, a);
+    CK(hipMemcpyAsync(want.data(), dst, ob * 2 * 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+    for (auto& v : vs) {
+        if (v.name.rfind("flat", 0) == 0) continue;
+        CK(hipMemsetAsync(dst, 0xFF, ob * 2 * 4, st));
+        v.run(2); CK(hipGetLastError());
+        CK(hipMemcpyAsync(got.data(), dst, ob * 2 * 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+        size_t bad = 0;
+        for (size_t i = 0; i < want.size(); ++i) bad += (*(uint32_t*)&want[i] != *(uint32_t*)&got[i]);
+        if (bad) printf("MISMATCH %-36s %zu elements\n", v.name.c_str(), bad);
+    }
+    for (int r = 0; r < ROUNDS + 1; ++r)
+        for (auto& v : vs) {
+            CK(hipEventRecord(e0, st)); v.run(N); CK(hipGetLastError()); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) v.ms.push_back(ms);
+        }
+    printf("%-40s %9s %9s %9s\n", "variant (N frames of 1080p)", "med ms", "min ms", "GB/s@med");
+    for (auto& v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        float med = v.ms[v.ms.size() / 2];
+        printf("%-40s %9.3f %9.3f %9.0f\n", v.name.c_str(), med, v.ms[0], full / med / 1e6);
+    }
+    return 0;
+}
