@@ -162,6 +162,128 @@ KH_API int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void
  * "generic" or "nv12_identity".  Returns NULL and sets the error on invalid params.           */
 KH_API const char* kh_preprocess_variant(const kh_preprocess_params* p);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Colour conversions: one entry per reference launcher of P/cuda/color/{gray,swizzle,yuv,
+ * hsv_hls,misc,video}.rs (adapters P/color/cuda_dispatch.rs:32-47).  Interleaved HWC pixels,
+ * `npixels` = rows*cols; src and dst must not alias.                                           */
+
+/* gray: u8 Q14 `(4899R+9617G+1868B+8192)>>14`, f32 `0.299r+0.587g+0.114b`
+ * (P/cuda/color/gray.rs:24,56,82,97; CPU P/color/gray/kernels.rs:229-244,405-412)             */
+KH_API int32_t kh_gray_from_rgb_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int64_t npixels);
+KH_API int32_t kh_gray_from_rgb_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels);
+KH_API int32_t kh_rgb_from_gray_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int64_t npixels);
+KH_API int32_t kh_rgb_from_gray_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels);
+
+/* channel swizzles (P/cuda/color/swizzle.rs:20-175; CPU P/color/rgb/mod.rs:128-316).
+ * swap_rb: 0 = rgba_from_rgb / rgb_from_rgba, 1 = bgra_from_rgb / rgb_from_bgra.  Alpha is 255 /
+ * 1.0.  `background` is a HOST pointer to 3 bytes or NULL (NULL = drop alpha; else
+ * `round(c*a/255 + bg*(1-a/255))`, P/color/rgb/mod.rs:311-316).                                */
+KH_API int32_t kh_bgr_from_rgb_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int64_t npixels);
+KH_API int32_t kh_bgr_from_rgb_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels);
+KH_API int32_t kh_rgba_from_rgb_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int64_t npixels, int32_t swap_rb);
+KH_API int32_t kh_rgba_from_rgb_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels, int32_t swap_rb);
+KH_API int32_t kh_rgb_from_rgba_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int64_t npixels,
+                                   int32_t swap_rb, const uint8_t* background);
+
+/* full-range YCbCr / YUV, "Family A" (P/cuda/color/yuv.rs:110,189,236; CPU
+ * P/color/yuv/kernels.rs:23-126,541-690).  order: KH_YCC_YCRCB stores [Y,Cr,Cb] (OpenCV YCrCb),
+ * KH_YCC_YUV stores [Y,U,V] with the cv2 RGB2YUV constants.                                    */
+enum { KH_YCC_YCRCB = 0, KH_YCC_YUV = 1 };
+KH_API int32_t kh_ycc_from_rgb_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int64_t npixels, int32_t order);
+KH_API int32_t kh_rgb_from_ycc_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int64_t npixels, int32_t order);
+KH_API int32_t kh_ycc_from_rgb_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels, int32_t order);
+KH_API int32_t kh_rgb_from_ycc_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels, int32_t order);
+
+/* HSV / HLS, f32 in the 0..255 domain (P/cuda/color/hsv_hls.rs:49-266; CPU
+ * P/color/hsv/kernels.rs:150-177,310-334, P/color/hls/kernels.rs:159-187,357-391)             */
+KH_API int32_t kh_hsv_from_rgb_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels);
+KH_API int32_t kh_rgb_from_hsv_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels);
+KH_API int32_t kh_hls_from_rgb_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels);
+KH_API int32_t kh_rgb_from_hls_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels);
+
+/* sepia (Q8 u8 / f32 matrix) and 256-entry colour LUT (P/cuda/color/misc.rs:32,64,109; CPU
+ * P/color/sepia.rs:17-104, P/color/colormap.rs:115-122).  `lut_device`: r[256] g[256] b[256]
+ * in device memory.                                                                            */
+KH_API int32_t kh_sepia_from_rgb_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int64_t npixels);
+KH_API int32_t kh_sepia_from_rgb_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels);
+KH_API int32_t kh_apply_colormap_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int64_t npixels,
+                                    const uint8_t* lut_device);
+
+/* video formats, BT.601 limited range: Q20 decode, Q8 encode (P/cuda/color/video.rs:67-240; CPU
+ * P/color/yuv/kernels.rs:696-1216 and 1223-1573).  Buffers are tightly packed.
+ * planar420 layout: 0 NV12, 1 NV21, 2 I420, 3 YV12;  packed422 layout: 0 YUYV, 1 UYVY, 2 YVYU. */
+KH_API int32_t kh_rgb_from_planar420_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t width,
+                                        int32_t height, int32_t layout);
+KH_API int32_t kh_rgb_from_packed422_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t width,
+                                        int32_t height, int32_t layout);
+KH_API int32_t kh_nv12_from_rgb_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t width, int32_t height);
+KH_API int32_t kh_yuyv_from_rgb_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t width, int32_t height);
+
+/* ------------------------------------------------------------------------------------------ */
+/* f32 geometric resampling.  One entry per reference launcher family of
+ * P/cuda/{resize,warp_affine,warp_perspective,remap}.rs (adapters P/resize/cuda.rs:34,
+ * P/warp/cuda.rs:29-130, P/interpolation/remap.rs:384); results are bit-identical to the
+ * reference CPU ops `resize`, `warp_affine`, `warp_perspective`, `remap`
+ * (P/resize/mod.rs:114, P/warp/affine.rs:123, P/warp/perspective.rs:115, P/interpolation/remap.rs:43).
+ * Images are HWC f32, channels in {1, 3, 4} (the reference device path has C == 3 only).
+ * `batch` same-sized images `src_stride` / `dst_stride` ELEMENTS apart go out as one launch.
+ * Matrices are the FORWARD (src -> dst) transform in host memory, inverted on the host like the
+ * reference adapters do (P/warp/cuda.rs:65).                                                  */
+enum { KH_INTERP_NEAREST = 0, KH_INTERP_BILINEAR = 1, KH_INTERP_BICUBIC = 2 };
+
+KH_API int32_t kh_resize_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w, int32_t src_h,
+                             int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode, int32_t batch,
+                             int64_t src_stride, int64_t dst_stride);
+KH_API int32_t kh_warp_affine_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w, int32_t src_h,
+                                  int32_t dst_w, int32_t dst_h, int32_t channels, const float* m2x3, int32_t mode,
+                                  int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* KH_ERR_SINGULAR if the homography cannot be inverted (checked before any launch).           */
+KH_API int32_t kh_warp_perspective_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w, int32_t src_h,
+                                       int32_t dst_w, int32_t dst_h, int32_t channels, const float* m3x3, int32_t mode,
+                                       int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* map_x / map_y: dst_h x dst_w f32 in device memory, shared by every image of the batch;
+ * out-of-range or NaN coordinates write 0 (P/cuda/remap.rs:80-85).                            */
+KH_API int32_t kh_remap_f32(kh_stream_t stream, const float* src, const float* map_x, const float* map_y, float* dst,
+                            int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode,
+                            int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* Brown-Conrady undistortion maps written directly in device memory (the reference builds them
+ * on the host: P/calibration/distortion.rs:135-152).  intrinsic = {fx, fy, cx, cy},
+ * distortion = {k1, k2, k3, k4, k5, k6, p1, p2}, host pointers, all-f64 arithmetic.          */
+KH_API int32_t kh_correction_map_polynomial_f32(kh_stream_t stream, float* map_x, float* map_y, int32_t width,
+                                                int32_t height, const double* intrinsic, const double* distortion);
+/* host helpers (no device work): P/warp/affine.rs:18-38, :70-79; P/warp/perspective.rs:41-60  */
+KH_API void kh_invert_affine_transform(const float m2x3[6], float out[6]);
+KH_API void kh_get_rotation_matrix2d(float center_x, float center_y, float angle_deg, float scale, float out[6]);
+KH_API int32_t kh_invert_homography(const float m3x3[9], float out[9]);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Separable f32 filters — ONE fused LDS-tiled kernel per call (the reference launches H and V
+ * passes through a scratch image, P/cuda/filter.rs:361-385; sobel/scharr five launches,
+ * P/filter/cuda.rs:185-237).  Semantics of P/filter/separable_filter.rs:87-164 and
+ * P/filter/ops.rs:39-247: zero border (out-of-image taps skipped), f32 intermediate,
+ * ascending-tap accumulation.  Any channel count; kernels up to 63 taps; src != dst.         */
+enum { KH_GRAD_SOBEL = 0, KH_GRAD_SCHARR = 1 };
+
+KH_API int32_t kh_separable_filter_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
+                                       int32_t channels, const float* kernel_x, int32_t nx, const float* kernel_y,
+                                       int32_t ny, int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* kernel size 0 = derive from sigma, sigma 0 = derive from kernel size (SciPy conventions,
+ * P/filter/ops.rs:122-155); taps built on the host with expf (P/filter/kernels.rs:25-43).     */
+KH_API int32_t kh_gaussian_blur_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
+                                    int32_t channels, int32_t ksize_x, int32_t ksize_y, float sigma_x, float sigma_y,
+                                    int32_t batch, int64_t src_stride, int64_t dst_stride);
+KH_API int32_t kh_box_blur_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
+                               int32_t channels, int32_t ksize_x, int32_t ksize_y, int32_t batch, int64_t src_stride,
+                               int64_t dst_stride);
+/* sobel (ksize 3|5) / scharr (ksize 3): sqrt(gx^2 + gy^2), P/filter/ops.rs:174-247            */
+KH_API int32_t kh_gradient_magnitude_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
+                                         int32_t channels, int32_t kind, int32_t ksize, int32_t batch,
+                                         int64_t src_stride, int64_t dst_stride);
+/* host tap builders (P/filter/kernels.rs:10-43) and parameter resolution                      */
+KH_API int32_t kh_box_blur_kernel_1d(int32_t n, float* out);
+KH_API int32_t kh_gaussian_kernel_1d(int32_t n, float sigma, float* out);
+KH_API int32_t kh_gaussian_resolve(int32_t ksize_xy[2], float sigma_xy[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,280 @@
+// Separable f32 filters for gfx950: gaussian_blur, box_blur, sobel, scharr, separable_filter.
+//
+// Behavioural contract: P/filter/separable_filter.rs:87-164 — a horizontal pass into an f32
+// intermediate, then a vertical pass; `acc += v * k` in ascending tap order, uncontracted; taps
+// that fall outside the image are skipped (zero border, no renormalisation).  The reference's
+// device path runs that as TWO launches through a full-size scratch image
+// (P/cuda/filter.rs:361-385: 2 reads + 2 writes per element) and sobel/scharr as FIVE launches
+// with three scratch images (P/filter/cuda.rs:185-237).
+//
+// Here each filter is ONE kernel: a 256-thread block stages a (TH + ky - 1) x (256 + halo)
+// tile of the flat row-major float image in LDS, runs the horizontal pass LDS -> LDS (the f32
+// intermediate is kept, so every rounding of the two-pass reference survives), then the vertical
+// pass LDS -> registers -> global with each thread owning one column for 8 consecutive rows
+// (ky + 7 LDS reads per 8 outputs).  HBM traffic is 1 read (+ halo) + 1 write per element.
+// The image is treated as H rows of W*C floats; a horizontal tap is a flat offset of +-C floats,
+// which is in-bounds iff the flat index stays inside the row — so any channel count works.
+// Skipping an out-of-image tap equals adding (0 * k): the accumulator starts at +0 and can never
+// become -0, so zero-filling the halo is bit-identical to the reference's `if in-bounds` test.
+#include <math.h>
+
+#include "kh_common.h"
+
+using namespace kh;
+
+namespace {
+
+constexpr int kTF = 256;      // tile width in flat floats (one float per thread per row)
+constexpr int kVR = 8;        // rows per thread in the vertical pass
+constexpr int kMaxTaps = 63;
+
+struct Taps {
+    float k[64];
+    int n;
+};
+
+struct FilterArgs {
+    const float* src;
+    float* dst;
+    int rows, rowlen, C;  // rowlen = cols * C
+    int th;               // output rows per tile (multiple of kVR)
+    long long src_stride, dst_stride;
+    int tiles_x;
+};
+
+extern __shared__ __attribute__((aligned(16))) float lds_f[];
+
+// GRAD = false: dst = V_ky(H_kx(src)).  GRAD = true: dst = sqrt(gx^2 + gy^2) with
+// gx = V_ky(H_kx(src)), gy = V_kx(H_ky(src))  (sobel / scharr, P/filter/ops.rs:174-247).
+template <bool GRAD>
+__global__ __launch_bounds__(kBlock) void sep_filter_kernel(FilterArgs a, Taps kx, Taps ky) {
+    const int tid = threadIdx.x;
+    const int hx = kx.n / 2, hy = ky.n / 2;
+    const int halo = (GRAD ? max(hx, hy) : hx) * a.C;  // flat floats on each side
+    const int vhalo = GRAD ? max(hx, hy) : hy;
+    const int in_w = kTF + 2 * halo;
+    const int in_h = a.th + 2 * vhalo;
+    float* tile = lds_f;                   // [in_h][in_w]   input
+    float* mid = tile + in_h * in_w;       // [in_h][kTF]    H-pass output (gx path)
+    float* mid2 = mid + in_h * kTF;        // [in_h][kTF]    (GRAD only: gy path)
+
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int x0 = tx * kTF, y0 = ty * a.th;
+    const float* src = a.src + (long long)blockIdx.y * a.src_stride;
+    float* dst = a.dst + (long long)blockIdx.y * a.dst_stride;
+
+    // 1. stage the input tile, zero outside the image
+    for (int r = 0; r < in_h; ++r) {
+        const int gy = y0 - vhalo + r;
+        const bool row_ok = gy >= 0 && gy < a.rows;
+        const float* srow = src + (long long)gy * a.rowlen;
+        for (int i = tid; i < in_w; i += kBlock) {
+            const int gx = x0 - halo + i;
+            tile[r * in_w + i] = (row_ok && gx >= 0 && gx < a.rowlen) ? srow[gx] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    // 2. horizontal pass: thread = one flat column, all tile rows
+    for (int r = 0; r < in_h; ++r) {
+        const float* trow = tile + r * in_w + halo + tid;
+        float acc = 0.0f;
+        for (int i = 0; i < kx.n; ++i) acc += trow[(i - hx) * a.C] * kx.k[i];
+        mid[r * kTF + tid] = acc;
+        if constexpr (GRAD) {
+            float acc2 = 0.0f;
+            for (int i = 0; i < ky.n; ++i) acc2 += trow[(i - hy) * a.C] * ky.k[i];
+            mid2[r * kTF + tid] = acc2;
+        }
+    }
+    __syncthreads();
+
+    // 3. vertical pass: thread = one flat column, kVR consecutive rows per step
+    const int gx = x0 + tid;
+    if (gx >= a.rowlen) return;
+    for (int rb = 0; rb < a.th; rb += kVR) {
+        float acc[kVR], acc2[kVR];
+#pragma unroll
+        for (int j = 0; j < kVR; ++j) { acc[j] = 0.0f; acc2[j] = 0.0f; }
+        // out row (rb + j) uses mid rows (rb + j + vhalo - hy + i), i ascending
+        {
+            const int base = rb + vhalo - hy;
+            for (int t = 0; t < ky.n + kVR - 1; ++t) {
+                const float v = mid[(base + t) * kTF + tid];
+#pragma unroll
+                for (int j = 0; j < kVR; ++j) {
+                    const int i = t - j;
+                    if (i >= 0 && i < ky.n) acc[j] += v * ky.k[i];
+                }
+            }
+        }
+        if constexpr (GRAD) {
+            const int base = rb + vhalo - hx;
+            for (int t = 0; t < kx.n + kVR - 1; ++t) {
+                const float v = mid2[(base + t) * kTF + tid];
+#pragma unroll
+                for (int j = 0; j < kVR; ++j) {
+                    const int i = t - j;
+                    if (i >= 0 && i < kx.n) acc2[j] += v * kx.k[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kVR; ++j) {
+            const int gy = y0 + rb + j;
+            if (gy < a.rows) {
+                float o = acc[j];
+                if constexpr (GRAD) o = sqrtf(acc[j] * acc[j] + acc2[j] * acc2[j]);
+                dst[(long long)gy * a.rowlen + gx] = o;
+            }
+        }
+    }
+}
+
+int32_t set_taps(Taps& t, const float* k, int n, const char* what) {
+    KH_REQUIRE(k && n >= 1 && n <= kMaxTaps, KH_ERR_UNSUPPORTED, "%s: kernel length %d outside [1, %d]", what, n,
+               kMaxTaps);
+    for (int i = 0; i < 64; ++i) t.k[i] = i < n ? k[i] : 0.0f;
+    t.n = n;
+    return KH_OK;
+}
+
+int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int rows, int C, const Taps& kx,
+               const Taps& ky, bool grad, int batch, int64_t ss, int64_t ds, const char* what) {
+    KH_REQUIRE(cols > 0 && rows > 0 && C > 0, KH_ERR_INVALID_ARG, "%s: zero-sized image %dx%dx%d", what, cols, rows, C);
+    KH_REQUIRE(batch >= 0 && batch <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, batch);
+    KH_REQUIRE((int64_t)cols * rows * C <= kI32Max, KH_ERR_TOO_LARGE, "%s: image exceeds 32-bit indexing", what);
+    if (batch == 0) return KH_OK;
+    KH_REQUIRE(src && dst, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
+    KH_REQUIRE(src != dst, KH_ERR_INVALID_ARG, "%s: in-place filtering is not supported", what);
+
+    FilterArgs a;
+    a.src = src; a.dst = dst; a.rows = rows; a.rowlen = cols * C; a.C = C;
+    a.src_stride = ss; a.dst_stride = ds;
+    const int hmax = grad ? (kx.n > ky.n ? kx.n : ky.n) / 2 : 0;
+    const int halo = (grad ? hmax : kx.n / 2) * C, vhalo = grad ? hmax : ky.n / 2;
+    // Pick the tallest tile (fewest halo re-reads) that still lets two blocks share a CU's LDS.
+    int th = 64;
+    size_t bytes = 0;
+    for (;; th -= kVR) {
+        const size_t in_h = th + 2 * vhalo;
+        bytes = (in_h * (kTF + 2 * halo) + in_h * kTF * (grad ? 2 : 1)) * sizeof(float);
+        if (bytes <= 78 * 1024 || th == kVR) break;
+    }
+    KH_REQUIRE(bytes <= 160 * 1024, KH_ERR_UNSUPPORTED, "%s: %dx%d taps with %d channels need %zu B of LDS", what, kx.n,
+               ky.n, C, bytes);
+    if (rows < th) th = ((rows + kVR - 1) / kVR) * kVR;
+    a.th = th;
+    a.tiles_x = (int)cdiv(a.rowlen, kTF);
+    const unsigned tiles_y = cdiv(rows, th);
+    auto kern = grad ? sep_filter_kernel<true> : sep_filter_kernel<false>;
+    const size_t in_h = th + 2 * vhalo;
+    bytes = (in_h * (kTF + 2 * halo) + in_h * kTF * (grad ? 2 : 1)) * sizeof(float);
+    if (bytes > 48 * 1024)  // opt in to the full 160 KiB LDS of a gfx950 CU (per device, idempotent)
+        KH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_x * tiles_y, (unsigned)batch), dim3(kBlock), bytes, as_hip(stream), a, kx, ky);
+    return check_launch(what);
+}
+
+}  // namespace
+
+extern "C" {
+
+// P/filter/kernels.rs:10-13
+int32_t kh_box_blur_kernel_1d(int32_t n, float* out) {
+    KH_REQUIRE(n >= 1 && out, KH_ERR_INVALID_ARG, "kh_box_blur_kernel_1d: bad arguments");
+    for (int i = 0; i < n; ++i) out[i] = 1.0f / (float)n;
+    return KH_OK;
+}
+
+// P/filter/kernels.rs:25-43 — host expf (the reference evaluates exp on the host too)
+int32_t kh_gaussian_kernel_1d(int32_t n, float sigma, float* out) {
+    KH_REQUIRE(n >= 1 && out, KH_ERR_INVALID_ARG, "kh_gaussian_kernel_1d: bad arguments");
+    const float mean = (float)(n - 1) / 2.0f, sigma_sq = sigma * sigma;
+    for (int i = 0; i < n; ++i) {
+        const float x = (float)i - mean;
+        out[i] = expf(-(x * x) / (2.0f * sigma_sq));
+    }
+    float norm = 0.0f;
+    for (int i = 0; i < n; ++i) norm += out[i];
+    for (int i = 0; i < n; ++i) out[i] /= norm;
+    return KH_OK;
+}
+
+// P/filter/ops.rs:122-155 (SciPy conventions); k = {kx, ky}, s = {sx, sy}, updated in place
+int32_t kh_gaussian_resolve(int32_t k[2], float s[2]) {
+    KH_REQUIRE(k && s, KH_ERR_INVALID_ARG, "kh_gaussian_resolve: null pointer");
+    int kx = k[0], ky = k[1];
+    float sx = s[0], sy = s[1];
+    if (sy <= 0.0f) sy = sx;
+    if (kx == 0 && sx > 0.0f) kx = (int)(2.0f * roundf(4.0f * sx) + 1.0f) | 1;
+    if (ky == 0 && sy > 0.0f) ky = (int)(2.0f * roundf(4.0f * sy) + 1.0f) | 1;
+    KH_REQUIRE(kx > 0 && kx % 2 == 1 && ky > 0 && ky % 2 == 1, KH_ERR_INVALID_ARG,
+               "invalid sigma/kernel-size combination: kernel (%d, %d), sigma (%g, %g)", kx, ky, (double)sx, (double)sy);
+    sx = sx > 0.0f ? sx : 0.0f;
+    sy = sy > 0.0f ? sy : 0.0f;
+    if (sx == 0.0f) sx = ((float)kx - 1.0f) / 8.0f;
+    if (sy == 0.0f) sy = ((float)ky - 1.0f) / 8.0f;
+    k[0] = kx; k[1] = ky; s[0] = sx; s[1] = sy;
+    return KH_OK;
+}
+
+int32_t kh_separable_filter_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
+                                int32_t channels, const float* kernel_x, int32_t nx, const float* kernel_y, int32_t ny,
+                                int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    Taps kx, ky;
+    if (int32_t rc = set_taps(kx, kernel_x, nx, "kh_separable_filter_f32")) return rc;
+    if (int32_t rc = set_taps(ky, kernel_y, ny, "kh_separable_filter_f32")) return rc;
+    return launch(stream, src, dst, cols, rows, channels, kx, ky, false, batch, src_stride, dst_stride,
+                  "kh_separable_filter_f32");
+}
+
+int32_t kh_gaussian_blur_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
+                             int32_t channels, int32_t ksize_x, int32_t ksize_y, float sigma_x, float sigma_y,
+                             int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    int32_t k[2] = {ksize_x, ksize_y};
+    float s[2] = {sigma_x, sigma_y};
+    if (int32_t rc = kh_gaussian_resolve(k, s)) return rc;
+    KH_REQUIRE(k[0] <= kMaxTaps && k[1] <= kMaxTaps, KH_ERR_UNSUPPORTED, "kh_gaussian_blur_f32: kernel (%d, %d) exceeds %d taps",
+               k[0], k[1], kMaxTaps);
+    float tx[64], ty[64];
+    kh_gaussian_kernel_1d(k[0], s[0], tx);
+    kh_gaussian_kernel_1d(k[1], s[1], ty);
+    Taps kx, ky;
+    set_taps(kx, tx, k[0], "kh_gaussian_blur_f32");
+    set_taps(ky, ty, k[1], "kh_gaussian_blur_f32");
+    return launch(stream, src, dst, cols, rows, channels, kx, ky, false, batch, src_stride, dst_stride, "kh_gaussian_blur_f32");
+}
+
+int32_t kh_box_blur_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows, int32_t channels,
+                        int32_t ksize_x, int32_t ksize_y, int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    KH_REQUIRE(ksize_x >= 1 && ksize_y >= 1 && ksize_x <= kMaxTaps && ksize_y <= kMaxTaps, KH_ERR_UNSUPPORTED,
+               "kh_box_blur_f32: kernel (%d, %d) outside [1, %d]", ksize_x, ksize_y, kMaxTaps);
+    float tx[64], ty[64];
+    kh_box_blur_kernel_1d(ksize_x, tx);
+    kh_box_blur_kernel_1d(ksize_y, ty);
+    Taps kx, ky;
+    set_taps(kx, tx, ksize_x, "kh_box_blur_f32");
+    set_taps(ky, ty, ksize_y, "kh_box_blur_f32");
+    return launch(stream, src, dst, cols, rows, channels, kx, ky, false, batch, src_stride, dst_stride, "kh_box_blur_f32");
+}
+
+// kind: KH_GRAD_SOBEL (size 3 | 5) or KH_GRAD_SCHARR (size 3) — P/filter/kernels.rs:55-100
+int32_t kh_gradient_magnitude_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
+                                  int32_t channels, int32_t kind, int32_t ksize, int32_t batch, int64_t src_stride,
+                                  int64_t dst_stride) {
+    static const float s3x[3] = {-1, 0, 1}, s3y[3] = {1, 2, 1}, s5x[5] = {-1, -2, 0, 2, 1}, s5y[5] = {1, 4, 6, 4, 1},
+                       c3y[3] = {3, 10, 3};
+    const float *tx = nullptr, *ty = nullptr;
+    if (kind == KH_GRAD_SOBEL && ksize == 3) { tx = s3x; ty = s3y; }
+    else if (kind == KH_GRAD_SOBEL && ksize == 5) { tx = s5x; ty = s5y; }
+    else if (kind == KH_GRAD_SCHARR && ksize == 3) { tx = s3x; ty = c3y; }
+    KH_REQUIRE(tx, KH_ERR_INVALID_ARG, "invalid kernel length %d for gradient kind %d", ksize, kind);
+    Taps kx, ky;
+    set_taps(kx, tx, ksize, "kh_gradient_magnitude_f32");
+    set_taps(ky, ty, ksize, "kh_gradient_magnitude_f32");
+    return launch(stream, src, dst, cols, rows, channels, kx, ky, true, batch, src_stride, dst_stride,
+                  "kh_gradient_magnitude_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,367 @@
+// f32 geometric resampling for gfx950: resize, warp_affine, warp_perspective, remap, and the
+// Brown-Conrady undistortion maps.
+//
+// Device twins of P/cuda/{resize,warp_affine,warp_perspective,remap}.rs; arithmetic follows the
+// reference CPU paths (P/resize/mod.rs:134-238, P/warp/affine.rs:123-372,
+// P/warp/perspective.rs:115-166, P/interpolation/{bilinear,nearest,bicubic,remap}.rs,
+// P/calibration/distortion.rs:68-152) with identical expression trees, uncontracted f32
+// (-ffp-contract=off), IEEE division, and fmaf exactly where the reference writes mul_add — so
+// outputs are bit-identical to the CPU reference (asserted by tests/test_geom_gpu.py).
+//
+// All of these are gathers: one thread per destination pixel (all channels), 64x4 blocks so a
+// wave owns 64 consecutive pixels of one output row — 768 B contiguous stores for C = 3 and
+// source taps confined to two (bilinear) or four (bicubic) source rows.  grid.z = image in the
+// batch (the reference launches once per image).
+#include <math.h>
+
+#include "kh_common.h"
+
+using namespace kh;
+
+namespace {
+
+constexpr int kBx = 64, kBy = 4;
+
+struct Img {  // one batch of same-sized HWC f32 images
+    const float* src;
+    float* dst;
+    int sw, sh, dw, dh;
+    long long src_stride, dst_stride;  // elements between consecutive images
+};
+
+// ---- samplers (expression trees of P/interpolation/*.rs; do not regroup) --------------------------
+
+// bilinear_interpolation (P/interpolation/bilinear.rs:16-66): trunc, edge taps replicate val00
+template <int C>
+__device__ __forceinline__ void sample_bilinear(const float* __restrict__ img, int rows, int cols, float u,
+                                                float v, float out[C]) {
+    const int iu = (int)u, iv = (int)v;
+    const float frac_u = u - truncf(u), frac_v = v - truncf(v);
+    const float* p00 = img + ((long long)iv * cols + iu) * C;
+    const bool hx = iu + 1 < cols, hy = iv + 1 < rows;
+    const float* p01 = hx ? p00 + C : p00;
+    const float* p10 = hy ? p00 + (long long)cols * C : p00;
+    const float* p11 = (hx && hy) ? p00 + (long long)cols * C + C : p00;
+    const float frac_uu = 1.0f - frac_u, frac_vv = 1.0f - frac_v;
+    const float w00 = frac_vv * frac_uu, w10 = frac_vv * frac_u, w01 = frac_v * frac_uu, w11 = frac_v * frac_u;
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = w00 * p00[c] + w10 * p01[c] + w01 * p10[c] + w11 * p11[c];
+}
+
+// nearest_neighbor_interpolation (P/interpolation/nearest.rs:15-30)
+template <int C>
+__device__ __forceinline__ void sample_nearest(const float* __restrict__ img, int rows, int cols, float u,
+                                               float v, float out[C]) {
+    const float ru = roundf(u), rv = roundf(v);
+    long long iu = ru > 0.0f ? (long long)ru : 0, iv = rv > 0.0f ? (long long)rv : 0;
+    iu = min(iu, (long long)cols - 1);
+    iv = min(iv, (long long)rows - 1);
+    const float* p = img + (iv * cols + iu) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = p[c];
+}
+
+// keys_weights + bicubic_sample (P/interpolation/bicubic.rs:15-62)
+__device__ __forceinline__ void keys_weights(float frac, float w[4]) {
+    float t;
+    t = 1.0f + frac; w[0] = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-0.5f, t, 2.5f), t, -4.0f), t, 2.0f);
+    t = frac;        w[1] = __builtin_fmaf(__builtin_fmaf(1.5f, t, -2.5f) * t, t, 1.0f);
+    t = 1.0f - frac; w[2] = __builtin_fmaf(__builtin_fmaf(1.5f, t, -2.5f) * t, t, 1.0f);
+    t = 2.0f - frac; w[3] = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-0.5f, t, 2.5f), t, -4.0f), t, 2.0f);
+}
+template <int C>
+__device__ __forceinline__ void sample_bicubic(const float* __restrict__ img, int rows, int cols, float sx,
+                                               float sy, float out[C]) {
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    float wx[4], wy[4];
+    keys_weights(sx - x0f, wx);
+    keys_weights(sy - y0f, wy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+        const int yi = min(max(y0 + dy - 1, 0), rows - 1);
+        const float* row = img + (long long)yi * cols * C;
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const int xi = min(max(x0 + dx - 1, 0), cols - 1);
+            const float w = wx[dx] * wy[dy];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(w, row[(long long)xi * C + c], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = acc[c];
+}
+
+template <int C, int MODE>
+__device__ __forceinline__ void sample(const float* __restrict__ img, int rows, int cols, float u, float v,
+                                       float out[C]) {
+    if constexpr (MODE == KH_INTERP_NEAREST) sample_nearest<C>(img, rows, cols, u, v, out);
+    else if constexpr (MODE == KH_INTERP_BILINEAR) sample_bilinear<C>(img, rows, cols, u, v, out);
+    else sample_bicubic<C>(img, rows, cols, u, v, out);
+}
+
+template <int C>
+__device__ __forceinline__ void put(float* p, const float v[C]) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = v[c];
+}
+template <int C>
+__device__ __forceinline__ void put_zero(float* p) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = 0.0f;
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+#define KH_PIXEL_PROLOGUE                                             \
+    const int x = blockIdx.x * kBx + threadIdx.x;                     \
+    const int y = blockIdx.y * kBy + threadIdx.y;                     \
+    if (x >= im.dw || y >= im.dh) return;                             \
+    const float* src = im.src + (long long)blockIdx.z * im.src_stride; \
+    float* o = im.dst + (long long)blockIdx.z * im.dst_stride + ((long long)y * im.dw + x) * C;
+
+// resize (P/resize/mod.rs:161-176): half-pixel grid a*x + b, clamped to the source
+template <int C, int MODE>
+__global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, float bx, float ay, float by) {
+    KH_PIXEL_PROLOGUE
+    const float sx = clampf(ax * (float)x + bx, 0.0f, (float)(im.sw - 1));
+    const float sy = clampf(ay * (float)y + by, 0.0f, (float)(im.sh - 1));
+    float v[C];
+    sample<C, MODE>(src, im.sh, im.sw, sx, sy, v);
+    put<C>(o, v);
+}
+
+struct Mat6 { float m[6]; };
+struct Mat9 { float m[9]; };
+
+// warp_affine (P/warp/affine.rs:123-372); mi = inverse 2x3
+template <int C, int MODE>
+__global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi) {
+    KH_PIXEL_PROLOGUE
+    const float swf = (float)im.sw, shf = (float)im.sh;
+    const float sx0 = mi.m[1] * (float)y + mi.m[2], sy0 = mi.m[4] * (float)y + mi.m[5];
+    const float sx = mi.m[0] * (float)x + sx0, sy = mi.m[3] * (float)x + sy0;
+    // in_bounds incl. the degenerate-axis rule (:201-215)
+    const bool x_ok = fabsf(mi.m[0]) < 1e-6f ? (sx0 >= 0.0f && sx0 < swf) : (sx >= 0.0f && sx < swf);
+    const bool y_ok = fabsf(mi.m[3]) < 1e-6f ? (sy0 >= 0.0f && sy0 < shf) : (sy >= 0.0f && sy < shf);
+    if (!(x_ok && y_ok)) { put_zero<C>(o); return; }
+    float v[C];
+    if constexpr (MODE == KH_INTERP_NEAREST) {  // :270-276
+        const long long xi = (long long)clampf(roundf(sx), 0.0f, swf - 1.0f);
+        const long long yi = (long long)clampf(roundf(sy), 0.0f, shf - 1.0f);
+        const float* p = src + (yi * im.sw + xi) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = p[c];
+    } else if constexpr (MODE == KH_INTERP_BILINEAR) {  // inlined sampler, :281-318
+        const float sxc = clampf(sx, 0.0f, swf - 1.0f), syc = clampf(sy, 0.0f, shf - 1.0f);
+        const int x0 = (int)sxc, y0 = (int)syc;
+        const int x1 = min(x0 + 1, im.sw - 1), y1 = min(y0 + 1, im.sh - 1);
+        const float fx = sxc - (float)x0, fy = syc - (float)y0;
+        const float w00 = (1.0f - fy) * (1.0f - fx), w10 = (1.0f - fy) * fx, w01 = fy * (1.0f - fx), w11 = fy * fx;
+        const float* p00 = src + ((long long)y0 * im.sw + x0) * C;
+        const float* p10 = src + ((long long)y0 * im.sw + x1) * C;
+        const float* p01 = src + ((long long)y1 * im.sw + x0) * C;
+        const float* p11 = src + ((long long)y1 * im.sw + x1) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = w00 * p00[c] + w10 * p10[c] + w01 * p01[c] + w11 * p11[c];
+    } else {
+        sample_bicubic<C>(src, im.sh, im.sw, sx, sy, v);
+    }
+    put<C>(o, v);
+}
+
+// warp_perspective (P/warp/perspective.rs:67-72,115-166); im9 = inverse 3x3
+template <int C, int MODE>
+__global__ __launch_bounds__(kBx* kBy) void warp_perspective_kernel(Img im, Mat9 h) {
+    KH_PIXEL_PROLOGUE
+    const float xf = (float)x, yf = (float)y;
+    const float w = h.m[6] * xf + h.m[7] * yf + h.m[8];
+    const float u = (h.m[0] * xf + h.m[1] * yf + h.m[2]) / w;
+    const float v = (h.m[3] * xf + h.m[4] * yf + h.m[5]) / w;
+    if (u >= 0.0f && u < (float)im.sw && v >= 0.0f && v < (float)im.sh) {
+        float val[C];
+        sample<C, MODE>(src, im.sh, im.sw, u, v, val);
+        put<C>(o, val);
+    } else {
+        put_zero<C>(o);  // also catches NaN / Inf from w == 0
+    }
+}
+
+// remap (P/interpolation/remap.rs:43-107), maps shared by the whole batch
+template <int C, int MODE>
+__global__ __launch_bounds__(kBx* kBy) void remap_kernel(Img im, const float* __restrict__ map_x,
+                                                         const float* __restrict__ map_y) {
+    KH_PIXEL_PROLOGUE
+    const long long i = (long long)y * im.dw + x;
+    const float u = map_x[i], v = map_y[i];
+    if (u >= 0.0f && u < (float)im.sw && v >= 0.0f && v < (float)im.sh) {
+        float val[C];
+        sample<C, MODE>(src, im.sh, im.sw, u, v, val);
+        put<C>(o, val);
+    } else {
+        put_zero<C>(o);
+    }
+}
+
+// generate_correction_map_polynomial (P/calibration/distortion.rs:68-152): all-f64 Brown-Conrady
+struct Camera { double fx, fy, cx, cy, k1, k2, k3, k4, k5, k6, p1, p2; };
+__global__ __launch_bounds__(kBx* kBy) void correction_map_kernel(float* __restrict__ map_x,
+                                                                  float* __restrict__ map_y, int w, int h, Camera c) {
+    const int xx = blockIdx.x * kBx + threadIdx.x, yy = blockIdx.y * kBy + threadIdx.y;
+    if (xx >= w || yy >= h) return;
+    const double x = ((double)xx - c.cx) / c.fx, y = ((double)yy - c.cy) / c.fy;
+    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const double kr = (1.0 + c.k1 * r2 + c.k2 * r4 + c.k3 * r6) / (1.0 + c.k4 * r2 + c.k5 * r4 + c.k6 * r6);
+    const double x_2 = 2.0 * x, y_2 = 2.0 * y, xy_2 = x_2 * y;
+    const double xd = x * kr + xy_2 * c.p1 + c.p2 * (r2 + x_2 * x);
+    const double yd = y * kr + c.p1 * (r2 + y_2 * y) + xy_2 * c.p2;
+    map_x[(long long)yy * w + xx] = (float)(c.fx * xd + c.cx);
+    map_y[(long long)yy * w + xx] = (float)(c.fy * yd + c.cy);
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+
+int32_t check_img(const char* what, const void* src, const void* dst, int sw, int sh, int dw, int dh, int channels,
+                  int mode, int batch, int64_t ss, int64_t ds) {
+    KH_REQUIRE(sw > 0 && sh > 0 && dw > 0 && dh > 0, KH_ERR_INVALID_ARG, "%s: zero-sized image (src %dx%d, dst %dx%d)",
+               what, sw, sh, dw, dh);
+    KH_REQUIRE(channels == 1 || channels == 3 || channels == 4, KH_ERR_UNSUPPORTED,
+               "%s: no device kernel for %d channels (supported: 1, 3, 4)", what, channels);
+    KH_REQUIRE(mode >= KH_INTERP_NEAREST && mode <= KH_INTERP_BICUBIC, KH_ERR_UNSUPPORTED,
+               "%s: interpolation mode %d has no device kernel (nearest, bilinear, bicubic)", what, mode);
+    KH_REQUIRE(batch >= 0 && batch <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, batch);
+    KH_REQUIRE((int64_t)sw * sh * channels <= kI32Max && (int64_t)dw * dh * channels <= kI32Max, KH_ERR_TOO_LARGE,
+               "%s: image exceeds 32-bit indexing", what);
+    KH_REQUIRE(ss >= 0 && ds >= 0, KH_ERR_INVALID_ARG, "%s: negative batch stride", what);
+    if (batch > 0) KH_REQUIRE(src && dst, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
+    return KH_OK;
+}
+
+dim3 grid_for(int dw, int dh, int batch) { return dim3(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)batch); }
+
+#define KH_DISPATCH_C_MODE(KERNEL, channels, mode, grid, stream, ...)                                              \
+    do {                                                                                                           \
+        const dim3 blk(kBx, kBy);                                                                                  \
+        switch ((channels) * 10 + (mode)) {                                                                        \
+            case 10: hipLaunchKernelGGL((KERNEL<1, 0>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 11: hipLaunchKernelGGL((KERNEL<1, 1>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 12: hipLaunchKernelGGL((KERNEL<1, 2>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 30: hipLaunchKernelGGL((KERNEL<3, 0>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 31: hipLaunchKernelGGL((KERNEL<3, 1>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 32: hipLaunchKernelGGL((KERNEL<3, 2>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 40: hipLaunchKernelGGL((KERNEL<4, 0>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 41: hipLaunchKernelGGL((KERNEL<4, 1>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            default: hipLaunchKernelGGL((KERNEL<4, 2>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+        }                                                                                                          \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+// P/warp/affine.rs:18-38
+void kh_invert_affine_transform(const float m[6], float out[6]) {
+    const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5];
+    const float determinant = a * e - b * d;
+    const float inv = determinant != 0.0f ? 1.0f / determinant : 0.0f;
+    const float na = e * inv, nb = -b * inv, nd = -d * inv, ne = a * inv;
+    out[0] = na; out[1] = nb; out[2] = -(na * c + nb * f);
+    out[3] = nd; out[4] = ne; out[5] = -(nd * c + ne * f);
+}
+
+// P/warp/affine.rs:70-79
+void kh_get_rotation_matrix2d(float cx, float cy, float angle_deg, float scale, float out[6]) {
+    const float angle = angle_deg * 3.14159265358979323846f / 180.0f;
+    const float alpha = scale * cosf(angle), beta = scale * sinf(angle);
+    out[0] = alpha; out[1] = beta; out[2] = (1.0f - alpha) * cx - beta * cy;
+    out[3] = -beta; out[4] = alpha; out[5] = beta * cx + (1.0f - alpha) * cy;
+}
+
+// P/warp/perspective.rs:12-60
+int32_t kh_invert_homography(const float m[9], float inv[9]) {
+    const float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+                      m[2] * (m[3] * m[7] - m[4] * m[6]);
+    const float h8_sq = m[8] * m[8];
+    const float det_norm = h8_sq > 1.1920929e-7f ? det / (h8_sq * fabsf(m[8])) : det;
+    KH_REQUIRE(!(fabsf(det_norm) < 1e-10f), KH_ERR_SINGULAR, "cannot compute the determinant: singular homography");
+    const float adj[9] = {
+        m[4] * m[8] - m[5] * m[7], m[2] * m[7] - m[1] * m[8], m[1] * m[5] - m[2] * m[4],
+        m[5] * m[6] - m[3] * m[8], m[0] * m[8] - m[2] * m[6], m[2] * m[3] - m[0] * m[5],
+        m[3] * m[7] - m[4] * m[6], m[1] * m[6] - m[0] * m[7], m[0] * m[4] - m[1] * m[3],
+    };
+    const float inv_det = 1.0f / det;
+    for (int i = 0; i < 9; ++i) inv[i] = adj[i] * inv_det;
+    return KH_OK;
+}
+
+int32_t kh_resize_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw, int32_t dh,
+                      int32_t channels, int32_t mode, int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    if (int32_t rc = check_img("kh_resize_f32", src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride, dst_stride))
+        return rc;
+    if (batch == 0) return KH_OK;
+    // PixelMapping::HalfPixel coefficients, exactly the CPU LUT's expression (P/resize/mod.rs:169-171)
+    const float ax = (float)sw / (float)dw, bx = 0.5f * ax - 0.5f;
+    const float ay = (float)sh / (float)dh, by = 0.5f * ay - 0.5f;
+    const Img im{src, dst, sw, sh, dw, dh, src_stride, dst_stride};
+    KH_DISPATCH_C_MODE(resize_kernel, channels, mode, grid_for(dw, dh, batch), as_hip(stream), im, ax, bx, ay, by);
+    return check_launch("kh_resize_f32");
+}
+
+int32_t kh_warp_affine_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw,
+                           int32_t dh, int32_t channels, const float* m, int32_t mode, int32_t batch,
+                           int64_t src_stride, int64_t dst_stride) {
+    if (int32_t rc = check_img("kh_warp_affine_f32", src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride, dst_stride))
+        return rc;
+    KH_REQUIRE(m, KH_ERR_INVALID_ARG, "kh_warp_affine_f32: null matrix");
+    if (batch == 0) return KH_OK;
+    Mat6 mi;
+    kh_invert_affine_transform(m, mi.m);
+    const Img im{src, dst, sw, sh, dw, dh, src_stride, dst_stride};
+    KH_DISPATCH_C_MODE(warp_affine_kernel, channels, mode, grid_for(dw, dh, batch), as_hip(stream), im, mi);
+    return check_launch("kh_warp_affine_f32");
+}
+
+int32_t kh_warp_perspective_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw,
+                                int32_t dh, int32_t channels, const float* m, int32_t mode, int32_t batch,
+                                int64_t src_stride, int64_t dst_stride) {
+    if (int32_t rc = check_img("kh_warp_perspective_f32", src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride, dst_stride))
+        return rc;
+    KH_REQUIRE(m, KH_ERR_INVALID_ARG, "kh_warp_perspective_f32: null matrix");
+    Mat9 h;
+    if (int32_t rc = kh_invert_homography(m, h.m)) return rc;  // rejected on the host, before any launch
+    if (batch == 0) return KH_OK;
+    const Img im{src, dst, sw, sh, dw, dh, src_stride, dst_stride};
+    KH_DISPATCH_C_MODE(warp_perspective_kernel, channels, mode, grid_for(dw, dh, batch), as_hip(stream), im, h);
+    return check_launch("kh_warp_perspective_f32");
+}
+
+int32_t kh_remap_f32(kh_stream_t stream, const float* src, const float* map_x, const float* map_y, float* dst,
+                     int32_t sw, int32_t sh, int32_t dw, int32_t dh, int32_t channels, int32_t mode, int32_t batch,
+                     int64_t src_stride, int64_t dst_stride) {
+    if (int32_t rc = check_img("kh_remap_f32", src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride, dst_stride))
+        return rc;
+    if (batch == 0) return KH_OK;
+    KH_REQUIRE(map_x && map_y, KH_ERR_INVALID_ARG, "kh_remap_f32: null map pointer");
+    const Img im{src, dst, sw, sh, dw, dh, src_stride, dst_stride};
+    KH_DISPATCH_C_MODE(remap_kernel, channels, mode, grid_for(dw, dh, batch), as_hip(stream), im, map_x, map_y);
+    return check_launch("kh_remap_f32");
+}
+
+int32_t kh_correction_map_polynomial_f32(kh_stream_t stream, float* map_x, float* map_y, int32_t w, int32_t h,
+                                         const double* intrinsic, const double* distortion) {
+    KH_REQUIRE(w > 0 && h > 0, KH_ERR_INVALID_ARG, "kh_correction_map_polynomial_f32: zero-sized map %dx%d", w, h);
+    KH_REQUIRE(map_x && map_y && intrinsic && distortion, KH_ERR_INVALID_ARG,
+               "kh_correction_map_polynomial_f32: null pointer");
+    KH_REQUIRE((int64_t)w * h <= kI32Max, KH_ERR_TOO_LARGE, "kh_correction_map_polynomial_f32: map too large");
+    const Camera c{intrinsic[0], intrinsic[1], intrinsic[2], intrinsic[3], distortion[0], distortion[1],
+                   distortion[2], distortion[3], distortion[4], distortion[5], distortion[6], distortion[7]};
+    hipLaunchKernelGGL(correction_map_kernel, dim3(cdiv(w, kBx), cdiv(h, kBy)), dim3(kBx, kBy), 0, as_hip(stream),
+                       map_x, map_y, w, h, c);
+    return check_launch("kh_correction_map_polynomial_f32");
+}
+
+}  // extern "C"

@@ -53,6 +53,7 @@ class PreprocessParams(C.Structure):
 
 
 _vp, _i32, _u64, _sz, _f32 = C.c_void_p, C.c_int32, C.c_uint64, C.c_size_t, C.c_float
+_i64 = C.c_int64
 _P = C.POINTER
 
 # name -> (restype, argtypes); every symbol kornia_hip.h declares must appear here
@@ -88,6 +89,37 @@ SIGNATURES = {
     "kh_pointer_domain": (_i32, [_vp, _P(_i32), _P(_i32)]),
     "kh_preprocess_to_chw": (_i32, [_vp, _vp, _vp, _P(PreprocessParams)]),
     "kh_preprocess_variant": (C.c_char_p, [_P(PreprocessParams)]),
+    # colour
+    **{n: (_i32, [_vp, _vp, _vp, _i64]) for n in (
+        "kh_gray_from_rgb_u8", "kh_gray_from_rgb_f32", "kh_rgb_from_gray_u8", "kh_rgb_from_gray_f32",
+        "kh_bgr_from_rgb_u8", "kh_bgr_from_rgb_f32", "kh_hsv_from_rgb_f32", "kh_rgb_from_hsv_f32",
+        "kh_hls_from_rgb_f32", "kh_rgb_from_hls_f32", "kh_sepia_from_rgb_u8", "kh_sepia_from_rgb_f32")},
+    **{n: (_i32, [_vp, _vp, _vp, _i64, _i32]) for n in (
+        "kh_rgba_from_rgb_u8", "kh_rgba_from_rgb_f32", "kh_ycc_from_rgb_u8", "kh_rgb_from_ycc_u8",
+        "kh_ycc_from_rgb_f32", "kh_rgb_from_ycc_f32")},
+    "kh_rgb_from_rgba_u8": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "kh_apply_colormap_u8": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "kh_rgb_from_planar420_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),
+    "kh_rgb_from_packed422_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),
+    "kh_nv12_from_rgb_u8": (_i32, [_vp, _vp, _vp, _i32, _i32]),
+    "kh_yuyv_from_rgb_u8": (_i32, [_vp, _vp, _vp, _i32, _i32]),
+    # geometry
+    "kh_resize_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_warp_affine_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i32, _i64, _i64]),
+    "kh_warp_perspective_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i32, _i64, _i64]),
+    "kh_remap_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_correction_map_polynomial_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _P(C.c_double), _P(C.c_double)]),
+    "kh_invert_affine_transform": (None, [_P(_f32), _P(_f32)]),
+    "kh_get_rotation_matrix2d": (None, [_f32, _f32, _f32, _f32, _P(_f32)]),
+    "kh_invert_homography": (_i32, [_P(_f32), _P(_f32)]),
+    # filters
+    "kh_separable_filter_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _P(_f32), _i32, _P(_f32), _i32, _i32, _i64, _i64]),
+    "kh_gaussian_blur_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i64, _i64]),
+    "kh_box_blur_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_gradient_magnitude_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_box_blur_kernel_1d": (_i32, [_i32, _P(_f32)]),
+    "kh_gaussian_kernel_1d": (_i32, [_i32, _f32, _P(_f32)]),
+    "kh_gaussian_resolve": (_i32, [_P(_i32), _P(_f32)]),
 }
 
 

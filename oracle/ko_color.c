@@ -160,3 +160,227 @@ void ko_yuyv_from_rgb(const uint8_t* src, uint8_t* dst, int width, int height) {
         }
     }
 }
+
+/* ---- Family A: full-range RGB <-> YCbCr / YUV (P/color/yuv/kernels.rs:23-62) ---------------- */
+/* order: 0 = YCrCb (stores [Y, Cr, Cb]); 1 = YuvCbCr (stores [Y, U=Cb, V=Cr]) */
+
+/* ycc_from_rgb_u8_px, :82-98 */
+void ko_ycc_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t npixels, int order) {
+    const int c_rv = order == 0 ? 11682 : 14369, c_bu = order == 0 ? 9241 : 8061;
+    for (size_t i = 0; i < npixels; ++i) {
+        int r = src[3 * i], g = src[3 * i + 1], b = src[3 * i + 2];
+        int y = (4899 * r + 9617 * g + 1868 * b + 8192) >> 14;
+        int cr = ((r - y) * c_rv + (128 << 14) + 8192) >> 14;
+        int cb = ((b - y) * c_bu + (128 << 14) + 8192) >> 14;
+        dst[3 * i] = (uint8_t)iclamp255(y);
+        if (order == 0) { dst[3 * i + 1] = (uint8_t)iclamp255(cr); dst[3 * i + 2] = (uint8_t)iclamp255(cb); }
+        else            { dst[3 * i + 1] = (uint8_t)iclamp255(cb); dst[3 * i + 2] = (uint8_t)iclamp255(cr); }
+    }
+}
+
+/* rgb_from_ycc_u8_px, :100-126 */
+void ko_rgb_from_ycc_u8(const uint8_t* src, uint8_t* dst, size_t npixels, int order) {
+    for (size_t i = 0; i < npixels; ++i) {
+        int y = src[3 * i];
+        int cr = (order == 0 ? src[3 * i + 1] : src[3 * i + 2]) - 128;
+        int cb = (order == 0 ? src[3 * i + 2] : src[3 * i + 1]) - 128;
+        int r, g, b;
+        if (order == 0) {
+            r = y + ((22987 * cr + 8192) >> 14);
+            g = y + ((-11698 * cr + -5636 * cb + 8192) >> 14);
+            b = y + ((29049 * cb + 8192) >> 14);
+        } else {
+            r = y + ((18678 * cr + 8192) >> 14);
+            g = y + ((-9519 * cr + -6472 * cb + 8192) >> 14);
+            b = y + (((16646 * cb) * 2 + 8192) >> 14);
+        }
+        dst[3 * i] = (uint8_t)iclamp255(r);
+        dst[3 * i + 1] = (uint8_t)iclamp255(g);
+        dst[3 * i + 2] = (uint8_t)iclamp255(b);
+    }
+}
+
+/* ycc_from_rgb_f32_px, :541-551 */
+void ko_ycc_from_rgb_f32(const float* src, float* dst, size_t npixels, int order) {
+    const float k_rv = order == 0 ? 0.713f : 0.877f, k_bu = order == 0 ? 0.564f : 0.492f;
+    for (size_t i = 0; i < npixels; ++i) {
+        float r = src[3 * i], g = src[3 * i + 1], b = src[3 * i + 2];
+        float y = 0.299f * r + 0.587f * g + 0.114f * b;
+        float cr = (r - y) * k_rv + 0.5f;
+        float cb = (b - y) * k_bu + 0.5f;
+        dst[3 * i] = y;
+        if (order == 0) { dst[3 * i + 1] = cr; dst[3 * i + 2] = cb; }
+        else            { dst[3 * i + 1] = cb; dst[3 * i + 2] = cr; }
+    }
+}
+
+/* rgb_from_ycc_f32_px, :673-690 */
+void ko_rgb_from_ycc_f32(const float* src, float* dst, size_t npixels, int order) {
+    for (size_t i = 0; i < npixels; ++i) {
+        float y = src[3 * i];
+        float cr = order == 0 ? src[3 * i + 1] : src[3 * i + 2];
+        float cb = order == 0 ? src[3 * i + 2] : src[3 * i + 1];
+        float r, g, b;
+        if (order == 0) {
+            r = y + (cr - 0.5f) / 0.713f;
+            b = y + (cb - 0.5f) / 0.564f;
+            g = (y - 0.299f * r - 0.114f * b) / 0.587f;
+        } else {
+            r = y + 1.140f * (cr - 0.5f);
+            g = y + -0.395f * (cb - 0.5f) + -0.581f * (cr - 0.5f);
+            b = y + 2.032f * (cb - 0.5f);
+        }
+        dst[3 * i] = r; dst[3 * i + 1] = g; dst[3 * i + 2] = b;
+    }
+}
+
+/* ---- HSV / HLS, 0..255 domain (P/color/hsv/kernels.rs:150-177,310-334; hls/kernels.rs:159-187,357-391) */
+#include <math.h>
+static const float INV_255 = 1.0f / 255.0f;
+static const float DEG_TO_BYTE = 255.0f / 360.0f;
+static const float BYTE_TO_DEG = 360.0f / 255.0f;
+static inline float fmax3(float a, float b, float c) { float m = a > b ? a : b; return m > c ? m : c; }
+static inline float fmin3(float a, float b, float c) { float m = a < b ? a : b; return m < c ? m : c; }
+
+void ko_hsv_from_rgb_f32(const float* src, float* dst, size_t npixels) {
+    for (size_t i = 0; i < npixels; ++i) {
+        float r = src[3 * i] * INV_255, g = src[3 * i + 1] * INV_255, b = src[3 * i + 2] * INV_255;
+        float max = fmax3(r, g, b), min = fmin3(r, g, b), delta = max - min;
+        float h;
+        if (delta == 0.0f) h = 0.0f;
+        else if (max == r) h = 60.0f * fmodf((g - b) / delta, 6.0f);
+        else if (max == g) h = 60.0f * (((b - r) / delta) + 2.0f);
+        else h = 60.0f * (((r - g) / delta) + 4.0f);
+        if (h < 0.0f) h = h + 360.0f;
+        dst[3 * i] = h * DEG_TO_BYTE;
+        dst[3 * i + 1] = max == 0.0f ? 0.0f : (delta / max) * 255.0f;
+        dst[3 * i + 2] = max * 255.0f;
+    }
+}
+
+void ko_rgb_from_hsv_f32(const float* src, float* dst, size_t npixels) {
+    for (size_t i = 0; i < npixels; ++i) {
+        float s = src[3 * i + 1] * INV_255, v = src[3 * i + 2] * INV_255;
+        float hh = src[3 * i] * (BYTE_TO_DEG / 60.0f);
+        float c = v * s;
+        float hmod2 = hh - 2.0f * floorf(hh * 0.5f);
+        float x = c * (1.0f - fabsf(hmod2 - 1.0f));
+        float m = v - c;
+        int sext = (int)floorf(hh);
+        float r1, g1, b1;
+        switch (sext) {
+            case 0: r1 = c; g1 = x; b1 = 0.0f; break;
+            case 1: r1 = x; g1 = c; b1 = 0.0f; break;
+            case 2: r1 = 0.0f; g1 = c; b1 = x; break;
+            case 3: r1 = 0.0f; g1 = x; b1 = c; break;
+            case 4: r1 = x; g1 = 0.0f; b1 = c; break;
+            default: r1 = c; g1 = 0.0f; b1 = x; break;
+        }
+        dst[3 * i] = (r1 + m) * 255.0f; dst[3 * i + 1] = (g1 + m) * 255.0f; dst[3 * i + 2] = (b1 + m) * 255.0f;
+    }
+}
+
+void ko_hls_from_rgb_f32(const float* src, float* dst, size_t npixels) {
+    for (size_t i = 0; i < npixels; ++i) {
+        float r = src[3 * i] * INV_255, g = src[3 * i + 1] * INV_255, b = src[3 * i + 2] * INV_255;
+        float max = fmax3(r, g, b), min = fmin3(r, g, b), diff = max - min, sum = max + min;
+        float l = sum * 0.5f, h = 0.0f, s = 0.0f;
+        if (diff != 0.0f) {
+            s = l <= 0.5f ? diff / sum : diff / (2.0f - sum);
+            if (max == r) h = 60.0f * fmodf((g - b) / diff, 6.0f);
+            else if (max == g) h = 60.0f * (((b - r) / diff) + 2.0f);
+            else h = 60.0f * (((r - g) / diff) + 4.0f);
+            if (h < 0.0f) h = h + 360.0f;
+        }
+        dst[3 * i] = h * DEG_TO_BYTE; dst[3 * i + 1] = l * 255.0f; dst[3 * i + 2] = s * 255.0f;
+    }
+}
+
+static inline float hue2rgb(float p, float q, float t) {
+    if (t < 0.0f) t = t + 1.0f;
+    if (t > 1.0f) t = t - 1.0f;
+    if (t < 1.0f / 6.0f) return p + (q - p) * 6.0f * t;
+    if (t < 0.5f) return q;
+    if (t < 2.0f / 3.0f) return p + (q - p) * (2.0f / 3.0f - t) * 6.0f;
+    return p;
+}
+
+void ko_rgb_from_hls_f32(const float* src, float* dst, size_t npixels) {
+    for (size_t i = 0; i < npixels; ++i) {
+        float l = src[3 * i + 1] * INV_255, s = src[3 * i + 2] * INV_255;
+        if (s == 0.0f) {
+            float v = l * 255.0f;
+            dst[3 * i] = v; dst[3 * i + 1] = v; dst[3 * i + 2] = v;
+            continue;
+        }
+        float h_deg = src[3 * i] * BYTE_TO_DEG;
+        float q = l < 0.5f ? l * (1.0f + s) : l + s - l * s;
+        float p = 2.0f * l - q;
+        float hk = h_deg / 360.0f;
+        dst[3 * i] = hue2rgb(p, q, hk + 1.0f / 3.0f) * 255.0f;
+        dst[3 * i + 1] = hue2rgb(p, q, hk) * 255.0f;
+        dst[3 * i + 2] = hue2rgb(p, q, hk - 1.0f / 3.0f) * 255.0f;
+    }
+}
+
+/* ---- swizzles (P/color/rgb/mod.rs:128-316, rgb/kernels.rs) ---------------------------------- */
+void ko_bgr_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t n) {
+    for (size_t i = 0; i < n; ++i) { dst[3 * i] = src[3 * i + 2]; dst[3 * i + 1] = src[3 * i + 1]; dst[3 * i + 2] = src[3 * i]; }
+}
+void ko_bgr_from_rgb_f32(const float* src, float* dst, size_t n) {
+    for (size_t i = 0; i < n; ++i) { dst[3 * i] = src[3 * i + 2]; dst[3 * i + 1] = src[3 * i + 1]; dst[3 * i + 2] = src[3 * i]; }
+}
+/* swap_rb = 0: rgba_from_rgb; 1: bgra_from_rgb; alpha = 255 / 1.0 (rgb/kernels.rs:177-186,236-245) */
+void ko_rgba_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t n, int swap_rb) {
+    for (size_t i = 0; i < n; ++i) {
+        dst[4 * i] = src[3 * i + (swap_rb ? 2 : 0)]; dst[4 * i + 1] = src[3 * i + 1];
+        dst[4 * i + 2] = src[3 * i + (swap_rb ? 0 : 2)]; dst[4 * i + 3] = 255;
+    }
+}
+void ko_rgba_from_rgb_f32(const float* src, float* dst, size_t n, int swap_rb) {
+    for (size_t i = 0; i < n; ++i) {
+        dst[4 * i] = src[3 * i + (swap_rb ? 2 : 0)]; dst[4 * i + 1] = src[3 * i + 1];
+        dst[4 * i + 2] = src[3 * i + (swap_rb ? 0 : 2)]; dst[4 * i + 3] = 1.0f;
+    }
+}
+/* rgb_from_rgba / rgb_from_bgra with optional background blend (rgb/mod.rs:128-227, alpha_blend :311-316) */
+void ko_rgb_from_rgba_u8(const uint8_t* src, uint8_t* dst, size_t n, int swap_rb, const uint8_t* bg) {
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t r = src[4 * i + (swap_rb ? 2 : 0)], g = src[4 * i + 1], b = src[4 * i + (swap_rb ? 0 : 2)];
+        if (bg) {
+            float alpha = (float)src[4 * i + 3] / 255.0f;
+            dst[3 * i] = (uint8_t)roundf((float)r * alpha + (float)bg[0] * (1.0f - alpha));
+            dst[3 * i + 1] = (uint8_t)roundf((float)g * alpha + (float)bg[1] * (1.0f - alpha));
+            dst[3 * i + 2] = (uint8_t)roundf((float)b * alpha + (float)bg[2] * (1.0f - alpha));
+        } else {
+            dst[3 * i] = r; dst[3 * i + 1] = g; dst[3 * i + 2] = b;
+        }
+    }
+}
+
+/* ---- sepia (P/color/sepia.rs:17-22,86-104; matrix.rs:122-136) and colormap LUT (colormap.rs:115-122) */
+void ko_sepia_from_rgb_f32(const float* src, float* dst, size_t n) {
+    static const float m[9] = {0.393f, 0.769f, 0.189f, 0.349f, 0.686f, 0.168f, 0.272f, 0.534f, 0.131f};
+    for (size_t i = 0; i < n; ++i) {
+        float c0 = src[3 * i], c1 = src[3 * i + 1], c2 = src[3 * i + 2];
+        dst[3 * i] = 0.0f + m[0] * c0 + m[1] * c1 + m[2] * c2;
+        dst[3 * i + 1] = 0.0f + m[3] * c0 + m[4] * c1 + m[5] * c2;
+        dst[3 * i + 2] = 0.0f + m[6] * c0 + m[7] * c1 + m[8] * c2;
+    }
+}
+void ko_sepia_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t n) {
+    static const uint32_t q[9] = {101, 197, 48, 89, 176, 43, 70, 137, 34};
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t r = src[3 * i], g = src[3 * i + 1], b = src[3 * i + 2];
+        for (int c = 0; c < 3; ++c) {
+            uint32_t v = (q[3 * c] * r + q[3 * c + 1] * g + q[3 * c + 2] * b + 128) >> 8;
+            dst[3 * i + c] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    }
+}
+/* lut = r[256] g[256] b[256] */
+void ko_apply_colormap_u8(const uint8_t* src, uint8_t* dst, size_t n, const uint8_t* lut) {
+    for (size_t i = 0; i < n; ++i) {
+        dst[3 * i] = lut[src[i]]; dst[3 * i + 1] = lut[256 + src[i]]; dst[3 * i + 2] = lut[512 + src[i]];
+    }
+}

@@ -71,6 +71,41 @@ void ko_rgb_from_packed422(const uint8_t* src, uint8_t* dst, int width, int heig
 void ko_nv12_from_rgb(const uint8_t* src, uint8_t* dst, int width, int height);
 void ko_yuyv_from_rgb(const uint8_t* src, uint8_t* dst, int width, int height);
 
+/* ---- colour: full-range YCbCr/YUV (Family A), HSV/HLS, swizzles, sepia, LUT -------------- */
+void ko_ycc_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t npixels, int order);
+void ko_rgb_from_ycc_u8(const uint8_t* src, uint8_t* dst, size_t npixels, int order);
+void ko_ycc_from_rgb_f32(const float* src, float* dst, size_t npixels, int order);
+void ko_rgb_from_ycc_f32(const float* src, float* dst, size_t npixels, int order);
+void ko_hsv_from_rgb_f32(const float* src, float* dst, size_t npixels);
+void ko_rgb_from_hsv_f32(const float* src, float* dst, size_t npixels);
+void ko_hls_from_rgb_f32(const float* src, float* dst, size_t npixels);
+void ko_rgb_from_hls_f32(const float* src, float* dst, size_t npixels);
+void ko_bgr_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t n);
+void ko_bgr_from_rgb_f32(const float* src, float* dst, size_t n);
+void ko_rgba_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t n, int swap_rb);
+void ko_rgba_from_rgb_f32(const float* src, float* dst, size_t n, int swap_rb);
+void ko_rgb_from_rgba_u8(const uint8_t* src, uint8_t* dst, size_t n, int swap_rb, const uint8_t* bg);
+void ko_sepia_from_rgb_f32(const float* src, float* dst, size_t n);
+void ko_sepia_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t n);
+void ko_apply_colormap_u8(const uint8_t* src, uint8_t* dst, size_t n, const uint8_t* lut);
+
+/* ---- geometry, f32 (ko_geom.c): mode 0 nearest, 1 bilinear, 2 bicubic --------------------- */
+void ko_resize_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int C, int mode);
+void ko_invert_affine_transform(const float m[6], float out[6]);
+void ko_warp_affine_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int C, const float m[6], int mode);
+int ko_invert_homography(const float m[9], float inv[9]);
+int ko_warp_perspective_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int C, const float m[9], int mode);
+void ko_remap_f32(const float* src, int sw, int sh, const float* map_x, const float* map_y, float* dst, int dw, int dh, int C, int mode);
+void ko_correction_map_polynomial(const double intr[4], const double dist[8], int w, int h, float* map_x, float* map_y);
+
+/* ---- separable filters, f32 (ko_filter.c) ---------------------------------------------------- */
+void ko_box_blur_kernel_1d(int n, float* out);
+void ko_gaussian_kernel_1d(int n, float sigma, float* out);
+int ko_gradient_kernels_1d(int kind, int n, float* kx, float* ky);
+int ko_gaussian_resolve(int k[2], float s[2]);
+void ko_separable_filter_f32(const float* src, float* dst, int cols, int rows, int C, const float* kx, int nx, const float* ky, int ny);
+void ko_gradient_magnitude_f32(const float* src, float* dst, int cols, int rows, int C, const float* kx, const float* ky, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,159 @@ def gray_from_rgb_f32(rgb: np.ndarray) -> np.ndarray:
     out = np.empty(n, np.float32)
     ko.ko_gray_from_rgb_f32(np.ascontiguousarray(rgb, np.float32).reshape(-1), out, n)
     return out.reshape(rgb.shape[:-1] + (1,))
+
+
+# ---- colour family helpers -----------------------------------------------------------------------
+for _n in ("ko_ycc_from_rgb_u8", "ko_rgb_from_ycc_u8"):
+    getattr(ko, _n).argtypes = [_u8p, _u8p, C.c_size_t, C.c_int]
+for _n in ("ko_ycc_from_rgb_f32", "ko_rgb_from_ycc_f32"):
+    getattr(ko, _n).argtypes = [_f32p, _f32p, C.c_size_t, C.c_int]
+for _n in ("ko_hsv_from_rgb_f32", "ko_rgb_from_hsv_f32", "ko_hls_from_rgb_f32", "ko_rgb_from_hls_f32",
+           "ko_bgr_from_rgb_f32", "ko_sepia_from_rgb_f32"):
+    getattr(ko, _n).argtypes = [_f32p, _f32p, C.c_size_t]
+for _n in ("ko_bgr_from_rgb_u8", "ko_sepia_from_rgb_u8"):
+    getattr(ko, _n).argtypes = [_u8p, _u8p, C.c_size_t]
+ko.ko_rgba_from_rgb_u8.argtypes = [_u8p, _u8p, C.c_size_t, C.c_int]
+ko.ko_rgba_from_rgb_f32.argtypes = [_f32p, _f32p, C.c_size_t, C.c_int]
+ko.ko_rgb_from_rgba_u8.argtypes = [_u8p, _u8p, C.c_size_t, C.c_int, C.c_void_p]
+ko.ko_apply_colormap_u8.argtypes = [_u8p, _u8p, C.c_size_t, _u8p]
+
+
+def color_map(name: str, src: np.ndarray, cout: int, *extra) -> np.ndarray:
+    """Run oracle function ko_<name> on a flat interleaved pixel array; returns [npixels*cout]."""
+    src = np.ascontiguousarray(src).reshape(-1)
+    fn = getattr(ko, "ko_" + name)
+    cin = {"gray_from_rgb": 3, "rgb_from_gray": 1, "apply_colormap": 1, "rgb_from_rgba": 4}.get(
+        name.rsplit("_", 1)[0], 3)
+    n = src.size // cin
+    out = np.empty(n * cout, src.dtype)
+    fn(src, out, n, *extra)
+    return out
+
+
+# ---- geometry + filters ---------------------------------------------------------------------------
+MODE = {"nearest": 0, "bilinear": 1, "bicubic": 2}
+_f6, _f9 = C.c_float * 6, C.c_float * 9
+ko.ko_resize_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]
+ko.ko_invert_affine_transform.argtypes = [C.POINTER(_f6), C.POINTER(_f6)]
+ko.ko_warp_affine_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.POINTER(_f6), C.c_int]
+ko.ko_invert_homography.argtypes = [C.POINTER(_f9), C.POINTER(_f9)]
+ko.ko_warp_perspective_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.POINTER(_f9), C.c_int]
+ko.ko_remap_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]
+ko.ko_correction_map_polynomial.argtypes = [C.POINTER(C.c_double * 4), C.POINTER(C.c_double * 8), C.c_int, C.c_int, _f32p, _f32p]
+ko.ko_box_blur_kernel_1d.argtypes = [C.c_int, _f32p]
+ko.ko_gaussian_kernel_1d.argtypes = [C.c_int, C.c_float, _f32p]
+ko.ko_gradient_kernels_1d.argtypes = [C.c_int, C.c_int, _f32p, _f32p]
+ko.ko_gaussian_resolve.argtypes = [C.POINTER(C.c_int * 2), C.POINTER(C.c_float * 2)]
+ko.ko_separable_filter_f32.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, _f32p, C.c_int]
+ko.ko_gradient_magnitude_f32.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int]
+
+
+def _img(a):
+    a = np.ascontiguousarray(a, np.float32)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return a
+
+
+def resize(src, dw, dh, mode="bilinear"):
+    src = _img(src)
+    sh, sw, c = src.shape
+    out = np.empty((dh, dw, c), np.float32)
+    ko.ko_resize_f32(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, c, MODE[mode])
+    return out
+
+
+def invert_affine(m):
+    a, o = _f6(*[float(v) for v in m]), _f6()
+    ko.ko_invert_affine_transform(C.byref(a), C.byref(o))
+    return np.array(list(o), np.float32)
+
+
+def warp_affine(src, m, dw, dh, mode="bilinear"):
+    src = _img(src)
+    sh, sw, c = src.shape
+    out = np.empty((dh, dw, c), np.float32)
+    mm = _f6(*[float(v) for v in m])
+    ko.ko_warp_affine_f32(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, c, C.byref(mm), MODE[mode])
+    return out
+
+
+def invert_homography(m):
+    a, o = _f9(*[float(v) for v in m]), _f9()
+    ok = ko.ko_invert_homography(C.byref(a), C.byref(o))
+    return np.array(list(o), np.float32) if ok else None
+
+
+def warp_perspective(src, m, dw, dh, mode="bilinear"):
+    src = _img(src)
+    sh, sw, c = src.shape
+    out = np.empty((dh, dw, c), np.float32)
+    mm = _f9(*[float(v) for v in m])
+    ok = ko.ko_warp_perspective_f32(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, c, C.byref(mm), MODE[mode])
+    return out if ok else None
+
+
+def remap(src, map_x, map_y, mode="bilinear"):
+    src = _img(src)
+    sh, sw, c = src.shape
+    map_x = np.ascontiguousarray(map_x, np.float32)
+    map_y = np.ascontiguousarray(map_y, np.float32)
+    dh, dw = map_x.shape[:2]
+    out = np.empty((dh, dw, c), np.float32)
+    ko.ko_remap_f32(src.reshape(-1), sw, sh, map_x.reshape(-1), map_y.reshape(-1), out.reshape(-1), dw, dh, c, MODE[mode])
+    return out
+
+
+def correction_map(intr, dist, w, h):
+    mx, my = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+    a, d = (C.c_double * 4)(*intr), (C.c_double * 8)(*dist)
+    ko.ko_correction_map_polynomial(C.byref(a), C.byref(d), w, h, mx.reshape(-1), my.reshape(-1))
+    return mx, my
+
+
+def gaussian_kernel_1d(n, sigma):
+    out = np.empty(n, np.float32)
+    ko.ko_gaussian_kernel_1d(n, sigma, out)
+    return out
+
+
+def box_kernel_1d(n):
+    out = np.empty(n, np.float32)
+    ko.ko_box_blur_kernel_1d(n, out)
+    return out
+
+
+def gradient_kernels(kind, n):
+    kx, ky = np.empty(n, np.float32), np.empty(n, np.float32)
+    return (kx, ky) if ko.ko_gradient_kernels_1d(kind, n, kx, ky) else None
+
+
+def gaussian_resolve(ksize, sigma):
+    k, s = (C.c_int * 2)(*ksize), (C.c_float * 2)(*sigma)
+    if not ko.ko_gaussian_resolve(C.byref(k), C.byref(s)):
+        return None
+    return (k[0], k[1]), (np.float32(s[0]), np.float32(s[1]))
+
+
+def separable_filter(src, kx, ky):
+    src = _img(src)
+    h, w, c = src.shape
+    out = np.empty_like(src)
+    kx, ky = np.ascontiguousarray(kx, np.float32), np.ascontiguousarray(ky, np.float32)
+    ko.ko_separable_filter_f32(src.reshape(-1), out.reshape(-1), w, h, c, kx, len(kx), ky, len(ky))
+    return out
+
+
+def gaussian_blur(src, ksize, sigma):
+    (kx, ky), (sx, sy) = gaussian_resolve(ksize, sigma)
+    return separable_filter(src, gaussian_kernel_1d(kx, sx), gaussian_kernel_1d(ky, sy))
+
+
+def gradient_magnitude(src, kind, n):
+    src = _img(src)
+    h, w, c = src.shape
+    kx, ky = gradient_kernels(kind, n)
+    out = np.empty_like(src)
+    ko.ko_gradient_magnitude_f32(src.reshape(-1), out.reshape(-1), w, h, c, kx, ky, n)
+    return out
