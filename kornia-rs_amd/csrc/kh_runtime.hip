@@ -154,10 +154,29 @@ int32_t kh_stream_fence(kh_stream_t producer, kh_stream_t consumer) {
     return KH_OK;
 }
 
+// The default mem-pool trims itself to the release threshold (0) at every synchronisation point.
+// The reference raises the threshold so steady-state alloc/free never goes back to the driver
+// (crates/kornia-tensor/src/cuda.rs:238-262); here it is also a correctness matter: on ROCm 7.2 /
+// gfx950 we observed a trim of a large freed block invalidate a small block re-allocated from it
+// (reads came back as zeros).  Keep everything cached; kh_mempool_set_release_threshold can lower it.
+static int32_t pin_pool_once() {
+    static bool done[64] = {false};
+    int dev = 0;
+    KH_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || done[dev]) return KH_OK;
+    hipMemPool_t pool = nullptr;
+    KH_HIP(hipDeviceGetDefaultMemPool(&pool, dev));
+    uint64_t v = UINT64_MAX;
+    KH_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &v));
+    done[dev] = true;
+    return KH_OK;
+}
+
 int32_t kh_malloc_async(void** out, size_t bytes, int32_t zeroed, kh_stream_t stream) {
     KH_REQUIRE(out, KH_ERR_INVALID_ARG, "kh_malloc_async: null out pointer");
     *out = nullptr;
     if (bytes == 0) return KH_OK;  // empty tensors own no storage
+    if (int32_t rc = pin_pool_once()) return rc;
     void* p = nullptr;
     KH_HIP(hipMallocAsync(&p, bytes, as_hip(stream)));
     if (zeroed) {

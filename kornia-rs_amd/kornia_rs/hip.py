@@ -149,6 +149,18 @@ class Event:
             self._handle = None
 
 
+def d2h(out: np.ndarray, device_ptr: int, stream: Stream) -> None:
+    """Device -> pageable host copy (to_host, crates/kornia-tensor/src/cuda.rs:1258-1300).
+    The stream is drained BEFORE the copy as well as after it: a pageable destination lets the
+    runtime service small copies from the host side, and we observed such copies overtaking
+    kernels still queued on the stream (stale reads) on ROCm 7.2 / gfx950."""
+    if out.nbytes == 0:
+        return
+    stream.synchronize()
+    check(lib.kh_memcpy_d2h_async(out.ctypes.data, device_ptr, out.nbytes, stream.cuda_stream_ptr))
+    stream.synchronize()
+
+
 def _stream_handle(stream: Optional[Stream]) -> int:
     return 0 if stream is None else stream.cuda_stream_ptr
 
@@ -180,17 +192,19 @@ class DeviceBuffer:
     def copy_from_host(self, a: np.ndarray, offset: int = 0) -> None:
         a = np.ascontiguousarray(a)
         assert offset + a.nbytes <= self.nbytes
+        if a.nbytes == 0:
+            return
+        # Pageable source: drain first (a host-serviced copy must not overtake a queued memset /
+        # kernel on this stream, see d2h) and after (the runtime may still be reading `a`).
+        self.stream.synchronize()
         check(lib.kh_memcpy_h2d_async(self.ptr + offset, a.ctypes.data, a.nbytes,
                                       self.stream.cuda_stream_ptr))
-        # pageable source: the runtime may still be reading `a`; keep the contract simple
         self.stream.synchronize()
 
     def to_numpy(self, dtype, shape, offset: int = 0) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
         assert offset + out.nbytes <= self.nbytes
-        check(lib.kh_memcpy_d2h_async(out.ctypes.data, self.ptr + offset, out.nbytes,
-                                      self.stream.cuda_stream_ptr))
-        self.stream.synchronize()
+        d2h(out, self.ptr + offset, self.stream)
         return out
 
     def free(self) -> None:

@@ -129,12 +129,7 @@ class Tensor:
         if self._host is not None:
             out = self._host
         else:
-            out = np.empty(self._shape, dtype=self._dtype)
-            if out.nbytes:
-                stream = self._stream if self._stream is not None else Stream.default(self._device)
-                hip.check(hip.lib.kh_memcpy_d2h_async(out.ctypes.data, self._ptr, out.nbytes,
-                                                     stream.cuda_stream_ptr))
-                stream.synchronize()
+            out = self.numpy_raw()
         return out.astype(np.float32) if self._dtype == np.float16 else out
 
     def numpy_raw(self) -> np.ndarray:
@@ -142,11 +137,7 @@ class Tensor:
         if self._host is not None:
             return self._host
         out = np.empty(self._shape, dtype=self._dtype)
-        if out.nbytes:
-            stream = self._stream if self._stream is not None else Stream.default(self._device)
-            hip.check(hip.lib.kh_memcpy_d2h_async(out.ctypes.data, self._ptr, out.nbytes,
-                                                 stream.cuda_stream_ptr))
-            stream.synchronize()
+        hip.d2h(out, self._ptr, self._stream if self._stream is not None else Stream.default(self._device))
         return out
 
     def to_hip(self, stream: Optional[Stream] = None) -> "Tensor":

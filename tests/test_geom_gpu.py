@@ -170,10 +170,10 @@ def test_remap_identity_is_exact_copy(gpu_stream):  # P/cuda/remap.rs:770-790
     w, h = 65, 33
     src = img(w, h, 3)
     xs, ys = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    d_src, d_xs, d_ys = dev(gpu_stream, src), dev(gpu_stream, xs), dev(gpu_stream, ys)  # keep alive
     for mode in ("bilinear", "nearest"):
         d_dst = out_buf(gpu_stream, src.nbytes)
-        call(gpu_stream, "kh_remap_f32", dev(gpu_stream, src).ptr, dev(gpu_stream, xs).ptr, dev(gpu_stream, ys).ptr,
-             d_dst.ptr, w, h, w, h, 3, O.MODE[mode], 1, 0, 0)
+        call(gpu_stream, "kh_remap_f32", d_src.ptr, d_xs.ptr, d_ys.ptr, d_dst.ptr, w, h, w, h, 3, O.MODE[mode], 1, 0, 0)
         assert np.array_equal(d_dst.to_numpy(np.float32, src.shape), src)
 
 
