@@ -149,9 +149,195 @@ class NorthStarNV12(Workload):
                           f"chained rgb_from_nv12 -> bilinear/normalize/CHW, OpenMP x{threads}"}
 
 
+class F32Images(Workload):
+    """Shared setup for the f32 HWC configs: `batch` images assembled on device from one LCG
+    base pattern (image k = base shifted by 31*k floats, values u8/255)."""
+
+    dtype = "f32"
+
+    def _make_src(self, stream, w, h, c, batch):
+        from kornia_rs.hip import DeviceBuffer, lib, check
+        n = w * h * c
+        base = (lcg_bytes(n + 31 * batch).astype(np.float32) / np.float32(255.0))
+        dbase = DeviceBuffer.from_numpy(base, stream)
+        src = DeviceBuffer(n * 4 * batch, stream, zeroed=False)
+        for k in range(batch):
+            check(lib.kh_memcpy_d2d_async(src.ptr + k * n * 4, dbase.ptr + 31 * k * 4, n * 4, stream.cuda_stream_ptr))
+        stream.synchronize()
+        self.base = base
+        return src
+
+    def _oracle(self):
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
+        return O
+
+
+class ResizeBilinear(F32Images):
+    """configs[1]: resize bilinear 1920x1080 -> 224x224 f32x3, batch 256."""
+
+    name, kernel = "resize_bilinear_1080p_to_224_f32_b256", "resize_kernel<3,bilinear>"
+    SW, SH, DW, DH, C = 1920, 1080, 224, 224, 3
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.SW * self.SH / 1e6
+        # SURVEY.md §8(d): taps actually required = 224*224*(4 taps*12 B + 12 B) = 3 010 560 B / image
+        self.alg_bytes_per_launch = self.N * self.DW * self.DH * (4 * 12 + 12)
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        self.src = self._make_src(stream, self.SW, self.SH, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.DW * self.DH * self.C * 4, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        check(lib.kh_resize_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.SW, self.SH, self.DW,
+                                self.DH, self.C, 1, self.N, self.SW * self.SH * self.C, self.DW * self.DH * self.C))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::resize (bilinear, half-pixel)", "src": "1920x1080x3 f32",
+                "dst": "224x224x3 f32", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective",
+                "source_Mpx_per_step": round(self.units_per_step, 1), "output_Mpx_per_step": round(self.N * 224 * 224 / 1e6, 2)}
+
+    def cpu_baseline(self):
+        O = self._oracle()
+        threads = O.ko.ko_max_threads()
+        n = self.SW * self.SH * self.C
+        frames, t0 = 0, time.perf_counter()
+        while True:
+            O.resize(self.base[31 * frames: 31 * frames + n].reshape(self.SH, self.SW, self.C), self.DW, self.DH)
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt > 10.0 or frames >= 256:
+                break
+        return {"value": round(frames * self.SW * self.SH / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads,
+                "kind": "port", "sample": f"{frames} images in {dt:.1f} s; C oracle (restatement of kornia-imgproc "
+                f"resize, not the upstream Rust binary), OpenMP x{threads} over output rows"}
+
+
+class Gaussian4K(F32Images):
+    """configs[3]: separable gaussian_blur 7x7 sigma 1.5 f32x3, 3840x2160, batch 256 (LDS stencil)."""
+
+    name, kernel = "gaussian_blur_7x7_4k_f32_b256", "sep_filter_kernel<false>"
+    W, H, C = 3840, 2160, 3
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C * 4  # 1R + 1W = 199 065 600 B / image
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.W * self.H * self.C * 4, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        n = self.W * self.H * self.C
+        check(lib.kh_gaussian_blur_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.C,
+                                       7, 7, 1.5, 1.5, self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::filter::gaussian_blur (7,7) sigma (1.5,1.5), fused H+V in LDS",
+                "src": "3840x2160x3 f32", "dst": "same", "batch_per_gpu": self.N,
+                "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        O = self._oracle()
+        n = self.W * self.H * self.C
+        img = self.base[:n].reshape(self.H, self.W, self.C)
+        O.ko.ko_set_threads(1)  # the reference's separable_filter is single-threaded (separable_filter.rs:87)
+        t0 = time.perf_counter()
+        O.gaussian_blur(img, (7, 7), (1.5, 1.5))
+        dt1 = time.perf_counter() - t0
+        O.ko.ko_set_threads(0)
+        threads = O.ko.ko_max_threads()
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 5.0 and reps < 16:
+            O.gaussian_blur(img, (7, 7), (1.5, 1.5))
+            reps += 1
+        dtn = (time.perf_counter() - t0) / max(reps, 1)
+        return {"value": round(self.W * self.H / 1e6 / dt1, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                "sample": f"1 image, single thread as in the reference ({dt1:.2f} s); beyond-reference OpenMP x{threads}: "
+                          f"{self.W * self.H / 1e6 / dtn:.1f} Mpixels/s; C oracle, not the upstream Rust binary"}
+
+
+class UndistortWarp4K(F32Images):
+    """configs[4] per-GPU share: remap (Brown-Conrady maps, Oak-D parameters scaled to 4K) then
+    warp_perspective (projective H), bilinear, f32x3 3840x2160, batch 256 per GPU."""
+
+    name, kernel = "undistort_remap_then_warp_perspective_4k_f32_b256", "remap_kernel<3,bilinear>+warp_perspective_kernel<3,bilinear>"
+    W, H, C = 3840, 2160, 3
+    # examples/undistort_image/src/main.rs:30-50 (1280x800 calibration), intrinsics scaled by 3840/1280, 2160/800
+    INTR = (577.48583984375 * 3.0, 652.8748779296875 * 3.0, 577.48583984375 * 2.7, 386.1428833007812 * 2.7)
+    DIST = (1.7547749280929563, 0.0097926277667284, -0.027250492945313457, 2.1092164516448975, 0.462927520275116,
+            -0.08215277642011642, -0.00005535508171073161, 0.00003768636770639569)
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        img = self.W * self.H * self.C * 4
+        self.alg_bytes_per_launch = self.N * (4 * img + 2 * self.W * self.H * 4)  # 464 486 400 B / image (two passes + maps)
+        w, h = float(self.W), float(self.H)
+        self.hm = [1.03, 0.05, -3.0 * w / 129.0, -0.02, 0.97, 4.0 * h / 97.0, 2.0 / (h * w), 1.5 / (w * h), 1.0]
+
+    def setup(self, stream):
+        import ctypes as C
+        from kornia_rs.hip import DeviceBuffer
+        from kornia_rs._ffi import lib, check
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        n = self.N * self.W * self.H * self.C * 4
+        self.tmp = DeviceBuffer(n, stream, zeroed=False)
+        self.dst = DeviceBuffer(n, stream, zeroed=False)
+        self.mx = DeviceBuffer(self.W * self.H * 4, stream, zeroed=False)
+        self.my = DeviceBuffer(self.W * self.H * 4, stream, zeroed=False)
+        check(lib.kh_correction_map_polynomial_f32(stream.cuda_stream_ptr, self.mx.ptr, self.my.ptr, self.W, self.H,
+                                                   (C.c_double * 4)(*self.INTR), (C.c_double * 8)(*self.DIST)))
+        self.hptr = (C.c_float * 9)(*self.hm)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        n = self.W * self.H * self.C
+        s = self.stream.cuda_stream_ptr
+        check(lib.kh_remap_f32(s, self.src.ptr, self.mx.ptr, self.my.ptr, self.tmp.ptr, self.W, self.H, self.W, self.H,
+                               self.C, 1, self.N, n, n))
+        check(lib.kh_warp_perspective_f32(s, self.tmp.ptr, self.dst.ptr, self.W, self.H, self.W, self.H, self.C,
+                                          self.hptr, 1, self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "interpolation::remap (undistort) -> warp::warp_perspective, bilinear",
+                "src": "3840x2160x3 f32", "dst": "same", "batch_per_gpu": self.N,
+                "parallelism": "batch-sharded (2048 images = 256 per GPU on 8 GPUs), no collective"}
+
+    def cpu_baseline(self):
+        O = self._oracle()
+        threads = O.ko.ko_max_threads()
+        n = self.W * self.H * self.C
+        mx, my = O.correction_map(self.INTR, self.DIST, self.W, self.H)
+        frames, t0 = 0, time.perf_counter()
+        while True:
+            img = self.base[31 * frames: 31 * frames + n].reshape(self.H, self.W, self.C)
+            O.warp_perspective(O.remap(img, mx, my), self.hm, self.W, self.H)
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt > 10.0 or frames >= 64:
+                break
+        return {"value": round(frames * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads,
+                "kind": "port", "sample": f"{frames} images in {dt:.1f} s; C oracle remap+warp_perspective "
+                f"(restatement, not the upstream Rust binary), OpenMP x{threads} over rows"}
+
+
 WORKLOADS = {
     "nv12_chw": lambda a: NorthStarNV12(a.batch or 1024, 0),
     "nv12_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640),
+    "resize_224": lambda a: ResizeBilinear(a.batch or 256),
+    "gaussian_4k": lambda a: Gaussian4K(a.batch or 256),
+    "undistort_warp_4k": lambda a: UndistortWarp4K(a.batch or 256),
 }
 
 
@@ -224,7 +410,8 @@ def main():
             traffic = json.loads(tfile.read_text()).get(wl.name)
         name, cus, mem = hip.device_info(local_rank)
         line = {
-            "metric": "Mpixels/s, fused 1080p NV12->normalized CHW f32 (achieved HBM GB/s in roofline)",
+            "metric": ("Mpixels/s, fused 1080p NV12->normalized CHW f32 (achieved HBM GB/s in roofline)"
+                       if args.workload.startswith("nv12") else f"Mpixels/s (source pixels), {wl.name}"),
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,

@@ -284,6 +284,31 @@ KH_API int32_t kh_box_blur_kernel_1d(int32_t n, float* out);
 KH_API int32_t kh_gaussian_kernel_1d(int32_t n, float sigma, float* out);
 KH_API int32_t kh_gaussian_resolve(int32_t ksize_xy[2], float sigma_xy[2]);
 
+/* ------------------------------------------------------------------------------------------ */
+/* normalize / crop / flip (P/normalize.rs:56-420, P/crop.rs:187-240, P/flip.rs:39-360).  The
+ * reference has no device twin for normalize; these follow its CPU arithmetic: true division
+ * in normalize_mean_std, `(x-min_v)*(max-min)/(max_v-min_v)+min` in normalize_min_max, the
+ * scalar `x*scale+offset` in normalize_rgb_u8.                                                 */
+/* mean / std: HOST pointers to `channels` floats, channels in 1..4                             */
+KH_API int32_t kh_normalize_mean_std_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels,
+                                         int32_t channels, const float* mean, const float* std);
+/* RGB8 -> f32 with per-channel scale/offset (HOST pointers to 3 floats)                        */
+KH_API int32_t kh_normalize_rgb_u8_f32(kh_stream_t stream, const uint8_t* src, float* dst, int64_t npixels,
+                                       const float* scale, const float* offset);
+/* min / max over `n` floats, no host round trip: minmax_device <- {min, max} (2 floats, device),
+ * scratch_device = 2 x uint32 of device scratch.  NaNs lose every comparison, except a NaN first
+ * element which yields (NaN, NaN) — the behaviour of the reference loop (P/normalize.rs:123-146). */
+KH_API int32_t kh_find_min_max_f32(kh_stream_t stream, const float* src, int64_t n, float* minmax_device,
+                                   uint32_t* scratch_device);
+KH_API int32_t kh_normalize_min_max_f32(kh_stream_t stream, const float* src, float* dst, int64_t n, float min,
+                                        float max, float* minmax_device, uint32_t* scratch_device);
+/* crop a dst_w x dst_h window at (x, y); pixel_bytes = channels * sizeof(T)                    */
+KH_API int32_t kh_crop(kh_stream_t stream, const void* src, void* dst, int32_t src_w, int32_t src_h, int32_t dst_w,
+                       int32_t dst_h, int32_t x, int32_t y, int32_t pixel_bytes);
+/* horizontal != 0: mirror columns; 0: mirror rows                                              */
+KH_API int32_t kh_flip(kh_stream_t stream, const void* src, void* dst, int32_t width, int32_t height,
+                       int32_t pixel_bytes, int32_t horizontal);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@
 // Skipping an out-of-image tap equals adding (0 * k): the accumulator starts at +0 and can never
 // become -0, so zero-filling the halo is bit-identical to the reference's `if in-bounds` test.
 #include <math.h>
+#include <stdlib.h>
 
 #include "kh_common.h"
 
@@ -131,12 +132,122 @@ __global__ __launch_bounds__(kBlock) void sep_filter_kernel(FilterArgs a, Taps k
     }
 }
 
+
+// ---- rolling-column kernel (the fast path) -------------------------------------------------------
+// A wave owns 64 adjacent flat columns and walks down a strip of rows.  Per input row it loads its
+// 64 floats (+ the horizontal halo, by the first 2*halo lanes), parks them in a 512-byte wave-private
+// LDS row, computes the horizontal pass from LDS (K conflict-free ds_read_b32) and pushes the result
+// into a K-deep REGISTER ring; the vertical pass is K multiply-adds on that ring.  No block barrier,
+// 2 KiB of LDS per block, every input row read once per strip (+ ky-1 warm-up rows per strip), four
+// rows of global loads in flight per lane.  Ascending-tap `acc += v*k` order and the f32
+// intermediate are exactly those of the two-pass reference.
+constexpr int kRollPF = 4;      // rows of prefetch per lane
+constexpr int kRollStrip = 90;  // output rows per strip (2160 = 24 strips)
+
+struct TapsK { float k[16]; };
+
+template <int K, bool GRAD>
+__global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx, TapsK ky) {
+    __shared__ float rowbuf[4][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int H = K / 2;
+    const int halo = H * a.C;  // <= 32 (checked on the host)
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int gx0 = tx * kTF + wv * 64;  // first flat column of this wave
+    if (gx0 >= a.rowlen) return;         // whole wave idle (no block barrier below)
+    const int y0 = ty * a.th;
+    const float* src = a.src + (long long)blockIdx.y * a.src_stride;
+    float* dst = a.dst + (long long)blockIdx.y * a.dst_stride;
+    float* buf = rowbuf[wv];
+
+    const int gx = gx0 + lane;
+    // halo lanes: [0, halo) fetch the left neighbours, [halo, 2*halo) the right ones
+    const bool is_halo = lane < 2 * halo;
+    const int hgx = lane < halo ? gx0 - halo + lane : gx0 + 64 + (lane - halo);
+    const int hslot = lane < halo ? lane : 64 + lane;  // LDS slot: left [0,halo), main [halo,halo+64), right after
+    const bool gx_ok = gx < a.rowlen, hgx_ok = is_halo && hgx >= 0 && hgx < a.rowlen;
+    const int nrows = min(a.th, a.rows - y0) + 2 * H;  // input rows to walk (incl. warm-up)
+
+    auto fetch = [&](int r, float& m, float& hv) {
+        const int gy = y0 - H + r;
+        const bool row_ok = r < nrows && gy >= 0 && gy < a.rows;
+        const float* srow = src + (long long)gy * a.rowlen;
+        m = (row_ok && gx_ok) ? srow[gx] : 0.0f;
+        hv = (row_ok && hgx_ok) ? srow[hgx] : 0.0f;
+    };
+
+    float qm[kRollPF], qh[kRollPF];
+#pragma unroll
+    for (int p = 0; p < kRollPF; ++p) fetch(p, qm[p], qh[p]);
+
+    float ring[K], ring2[GRAD ? K : 1];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { ring[i] = 0.0f; if constexpr (GRAD) ring2[i] = 0.0f; }
+
+    for (int rb = 0; rb < nrows; rb += kRollPF) {
+#pragma unroll
+        for (int p = 0; p < kRollPF; ++p) {
+            const int r = rb + p;
+            const float m = qm[p], hv = qh[p];
+            fetch(r + kRollPF, qm[p], qh[p]);  // keep kRollPF rows in flight
+            if (r >= nrows) break;
+            buf[halo + lane] = m;
+            if (is_halo) buf[hslot] = hv;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float h1 = 0.0f, h2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float v = buf[halo + lane + (i - H) * a.C];
+                h1 += v * kx.k[i];
+                if constexpr (GRAD) h2 += v * ky.k[i];
+            }
+            __builtin_amdgcn_wave_barrier();  // all lanes have read the row before it is overwritten
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) { ring[i] = ring[i + 1]; if constexpr (GRAD) ring2[i] = ring2[i + 1]; }
+            ring[K - 1] = h1;
+            if constexpr (GRAD) ring2[K - 1] = h2;
+            if (r >= 2 * H && gx_ok) {
+                float o = 0.0f, o2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    o += ring[i] * ky.k[i];
+                    if constexpr (GRAD) o2 += ring2[i] * kx.k[i];
+                }
+                if constexpr (GRAD) o = sqrtf(o * o + o2 * o2);
+                dst[(long long)(y0 + r - 2 * H) * a.rowlen + gx] = o;
+            }
+        }
+    }
+}
+
+template <int K>
+void launch_roll(hipStream_t st, dim3 grid, bool grad, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
+    if (grad) hipLaunchKernelGGL((sep_roll_kernel<K, true>), grid, dim3(kBlock), 0, st, a, kx, ky);
+    else hipLaunchKernelGGL((sep_roll_kernel<K, false>), grid, dim3(kBlock), 0, st, a, kx, ky);
+}
+
+// Centre an n-tap kernel inside K taps.  The zero pad taps contribute (+-0) to the accumulator,
+// which never changes it (see the header comment), so the result equals the unpadded filter for
+// all finite inputs.
+void pad_taps(TapsK& out, const Taps& in, int K) {
+    const int off = (K - in.n) / 2;
+    for (int i = 0; i < 16; ++i) out.k[i] = (i >= off && i < off + in.n) ? in.k[i - off] : 0.0f;
+}
+
 int32_t set_taps(Taps& t, const float* k, int n, const char* what) {
     KH_REQUIRE(k && n >= 1 && n <= kMaxTaps, KH_ERR_UNSUPPORTED, "%s: kernel length %d outside [1, %d]", what, n,
                kMaxTaps);
     for (int i = 0; i < 64; ++i) t.k[i] = i < n ? k[i] : 0.0f;
     t.n = n;
     return KH_OK;
+}
+
+// KH_FILTER_FORCE_TILE=1 routes every call to the LDS-tile kernel (parity tests cover both).
+bool force_tile_kernel() {
+    const char* e = getenv("KH_FILTER_FORCE_TILE");
+    return e && e[0] == '1';
 }
 
 int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int rows, int C, const Taps& kx,
@@ -151,6 +262,31 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
     FilterArgs a;
     a.src = src; a.dst = dst; a.rows = rows; a.rowlen = cols * C; a.C = C;
     a.src_stride = ss; a.dst_stride = ds;
+
+    // Fast path: rolling-column kernel for odd kernels up to 15 taps whose horizontal halo fits
+    // the 32-float side buffers; everything else takes the LDS-tile kernel below.
+    const int kmax = kx.n > ky.n ? kx.n : ky.n;
+    if ((kx.n & 1) && (ky.n & 1) && kmax <= 15 && (kmax / 2) * C <= 32 && !force_tile_kernel()) {
+        const int K = kmax < 3 ? 3 : kmax;
+        TapsK px, py;
+        pad_taps(px, kx, K);
+        pad_taps(py, ky, K);
+        a.th = kRollStrip;
+        a.tiles_x = (int)cdiv(a.rowlen, kTF);
+        const dim3 grid(a.tiles_x * cdiv(rows, a.th), (unsigned)batch);
+        hipStream_t st = as_hip(stream);
+        switch (K) {
+            case 3: launch_roll<3>(st, grid, grad, a, px, py); break;
+            case 5: launch_roll<5>(st, grid, grad, a, px, py); break;
+            case 7: launch_roll<7>(st, grid, grad, a, px, py); break;
+            case 9: launch_roll<9>(st, grid, grad, a, px, py); break;
+            case 11: launch_roll<11>(st, grid, grad, a, px, py); break;
+            case 13: launch_roll<13>(st, grid, grad, a, px, py); break;
+            default: launch_roll<15>(st, grid, grad, a, px, py); break;
+        }
+        return check_launch(what);
+    }
+
     const int hmax = grad ? (kx.n > ky.n ? kx.n : ky.n) / 2 : 0;
     const int halo = (grad ? hmax : kx.n / 2) * C, vhalo = grad ? hmax : ky.n / 2;
     // Pick the tallest tile (fewest halo re-reads) that still lets two blocks share a CU's LDS.

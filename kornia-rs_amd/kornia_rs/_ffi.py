@@ -120,6 +120,13 @@ SIGNATURES = {
     "kh_box_blur_kernel_1d": (_i32, [_i32, _P(_f32)]),
     "kh_gaussian_kernel_1d": (_i32, [_i32, _f32, _P(_f32)]),
     "kh_gaussian_resolve": (_i32, [_P(_i32), _P(_f32)]),
+    # pointwise
+    "kh_normalize_mean_std_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _P(_f32), _P(_f32)]),
+    "kh_normalize_rgb_u8_f32": (_i32, [_vp, _vp, _vp, _i64, _P(_f32), _P(_f32)]),
+    "kh_find_min_max_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "kh_normalize_min_max_f32": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+    "kh_crop": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "kh_flip": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32]),
 }
 
 

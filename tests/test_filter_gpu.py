@@ -52,6 +52,32 @@ def test_gaussian_matches_oracle(gpu_stream, c, shape, ks):
     assert_same_bits(got, O.gaussian_blur(src, (kx, ky), (sx, sy)), f"gaussian {shape} c{c} k{kx}x{ky}")
 
 
+@pytest.fixture(params=["roll", "tile"])
+def kernel_path(request, monkeypatch):
+    """Both device kernels behind the filter entry points: the rolling-column fast path and the
+    LDS-tile kernel (forced through KH_FILTER_FORCE_TILE=1)."""
+    if request.param == "tile":
+        monkeypatch.setenv("KH_FILTER_FORCE_TILE", "1")
+    else:
+        monkeypatch.delenv("KH_FILTER_FORCE_TILE", raising=False)
+    return request.param
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("ks", [((3, 3), (0.8, 0.8)), ((7, 7), (1.5, 1.5)), ((5, 9), (1.0, 2.0)), ((15, 15), (3.0, 3.0)),
+                                ((13, 3), (2.5, 0.0)), ((17, 17), (3.0, 3.0)), ((31, 5), (6.0, 1.0))])
+def test_both_kernels_match_oracle(gpu_stream, kernel_path, c, ks):
+    (kx, ky), (sx, sy) = ks
+    for (w, h) in [(67, 43), (300, 200), (64, 91)]:
+        src = img(w, h, c, seed=3)
+        got = run(gpu_stream, "kh_gaussian_blur_f32", src, kx, ky, sx, sy)
+        assert_same_bits(got, O.gaussian_blur(src, (kx, ky), (sx, sy)), f"{kernel_path} {w}x{h} c{c} k{kx}x{ky}")
+    src = img(131, 120, c)
+    for kind, n in [(0, 3), (0, 5), (1, 3)]:
+        got = run(gpu_stream, "kh_gradient_magnitude_f32", src, kind, n)
+        assert_same_bits(got, O.gradient_magnitude(src, kind, n), f"{kernel_path} grad {kind} {n} c{c}")
+
+
 def test_gaussian_4k_tile_seams_and_batch(gpu_stream):
     """config[3] geometry: 3840x2160x3, 7x7 sigma 1.5 — one full-size image checked against the
     oracle everywhere (covers every tile seam), plus a 2-image batched launch."""
