@@ -9,10 +9,15 @@ from . import _ffi
 from . import hip
 from .hip import IMAGENET_MEAN, IMAGENET_STD, Stream
 from .tensor import Tensor
+from .image import Image, ImageError
 from .preprocess import Preprocessor, PreprocessError, ResizeMode, SourceFormat
+from . import imgproc
+from . import sharding
+
+cuda = hip  # reference module name (kornia_rs.cuda.Stream); same objects, HIP underneath
 
 __version__ = "0.1.0"
 __all__ = [
-    "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Preprocessor", "PreprocessError",
-    "ResizeMode", "SourceFormat", "hip",
+    "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Image", "ImageError", "Preprocessor",
+    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "hip", "cuda", "sharding",
 ]

@@ -28,6 +28,9 @@ KH_FMT_RGB, KH_FMT_BGR, KH_FMT_GRAY, KH_FMT_NV12, KH_FMT_YUYV = 0, 1, 2, 3, 4
 KH_SAMPLE_NEAREST, KH_SAMPLE_BILINEAR, KH_SAMPLE_LANCZOS = 0, 1, 2
 KH_OUT_F32, KH_OUT_F16 = 0, 1
 KH_PRE_FORCE_GENERIC = 1
+KH_YCC_YCRCB, KH_YCC_YUV = 0, 1
+KH_INTERP_NEAREST, KH_INTERP_BILINEAR, KH_INTERP_BICUBIC = 0, 1, 2
+KH_GRAD_SOBEL, KH_GRAD_SCHARR = 0, 1
 
 
 class KorniaHipError(RuntimeError):

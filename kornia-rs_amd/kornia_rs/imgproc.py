@@ -1,0 +1,464 @@
+"""``imgproc`` free functions with the reference's residency dispatch, running on the HIP backend.
+
+Mirrors the public ops of ``kornia-imgproc`` (``color::*``, ``resize::resize``, ``warp::*``,
+``interpolation::remap``, ``filter::*``, ``normalize::*``, ``crop``, ``flip``) and their Python
+spellings (kornia-py/python/kornia_rs/imgproc.pyi:23-158).  Every op starts with the residency
+classification of crates/kornia-imgproc/src/cuda/dispatch.rs:105-130:
+
+* device/device pair  -> the HIP kernel, launched on the SOURCE image's stream; if the destination
+  carries a different stream it is fenced in first (``DeviceExec::for_streams``, :50-67);
+* mixed host/device   -> ``ImageError('MixedResidency')`` — never an implicit transfer (:128);
+* different devices   -> ``ImageError('DeviceMismatch')`` (:51-53);
+* host/host           -> ``ImageError('HostPathUnavailable')``: this build ships the device backend
+  only; the CPU implementation stays in the reference crate.  It is NOT silently computed
+  elsewhere.
+* unsupported dtype / channel count -> ``ImageError('NoDeviceKernel')``, never a fallback
+  (``no_gpu_kernel_err``, dispatch.rs:203-211).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import lib
+from .hip import DeviceBuffer, Stream
+from .image import Image, ImageError
+from .tensor import Tensor
+
+_INTERP = {"nearest": 0, "bilinear": 1, "bicubic": 2}
+
+
+def _check(rc: int) -> None:
+    if rc == _ffi.KH_OK:
+        return
+    msg = _ffi.last_error()
+    kind = {_ffi.KH_ERR_SINGULAR: "CannotComputeDeterminant", _ffi.KH_ERR_UNSUPPORTED: "NoDeviceKernel",
+            _ffi.KH_ERR_HIP: "Hip"}.get(rc, "InvalidArgument")
+    raise ImageError(kind, msg)
+
+
+def _pair_residency(src: Image, dst: Image) -> Stream:
+    """Host/Device/Mixed classification + same-device check + cross-stream fence.  Returns the
+    stream to launch on (the source image's)."""
+    if src.is_device != dst.is_device:
+        raise ImageError("MixedResidency", "source and destination images must both be on the host or both on the "
+                                           "device; there is no implicit transfer")
+    if not src.is_device:
+        raise ImageError("HostPathUnavailable", "host images: this build provides the HIP device backend only — move "
+                                                "the image with .to_hip(stream) (the CPU path lives in the reference crate)")
+    if src.device_id != dst.device_id:
+        raise ImageError("DeviceMismatch", f"images live on different devices ({src.device} vs {dst.device})")
+    s_src, s_dst = src.stream, dst.stream
+    if s_src is None or s_dst is None:
+        raise ImageError("UnsupportedDevice", "device image without a stream (untyped foreign memory); re-wrap it "
+                                              "with Image.from_dlpack(obj, stream=...)")
+    if s_src.cuda_stream_ptr != s_dst.cuda_stream_ptr:
+        _check(lib.kh_stream_fence(s_dst.cuda_stream_ptr, s_src.cuda_stream_ptr))
+    return s_src
+
+
+def _require(img: Image, dtype: str, channels: Tuple[int, ...], what: str) -> None:
+    if img.dtype != dtype or img.channels not in channels:
+        raise ImageError("NoDeviceKernel", f"{what}: no device kernel for {img.dtype} x {img.channels} channels "
+                                           f"(supported: {dtype} x {channels})")
+
+
+def _same_size(a: Image, b: Image) -> None:
+    if a.size != b.size:
+        raise ImageError("InvalidImageSize", f"image sizes differ: {a.width}x{a.height} vs {b.width}x{b.height}")
+
+
+def _new_like(src: Image, channels: Optional[int] = None, dtype: Optional[str] = None,
+              size: Optional[Tuple[int, int]] = None) -> Image:
+    if not src.is_device:
+        raise ImageError("HostPathUnavailable", "host images: this build provides the HIP device backend only — move "
+                                                "the image with .to_hip(stream)")
+    w, h = size if size is not None else (src.width, src.height)
+    return Image.uninit(w, h, channels or src.channels, dtype or src.dtype, src.stream)
+
+
+# ---- colour maps --------------------------------------------------------------------------------
+
+def _map(name: str, src: Image, dst: Optional[Image], cin: int, cout: int, dtypes: Sequence[str], *extra) -> Image:
+    if src.dtype not in dtypes:
+        raise ImageError("NoDeviceKernel", f"{name}: no device kernel for dtype {src.dtype} (supported: {tuple(dtypes)})")
+    _require(src, src.dtype, (cin,), name)
+    out = dst if dst is not None else _new_like(src, channels=cout)
+    _require(out, src.dtype, (cout,), name)
+    _same_size(src, out)
+    stream = _pair_residency(src, out)
+    suffix = {"uint8": "u8", "float32": "f32"}[src.dtype]
+    fn = getattr(lib, f"kh_{name}_{suffix}")
+    _check(fn(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height, *extra))
+    return out
+
+
+def gray_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("gray_from_rgb", src, dst, 3, 1, ("uint8", "float32"))
+
+
+def rgb_from_gray(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("rgb_from_gray", src, dst, 1, 3, ("uint8", "float32"))
+
+
+def bgr_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("bgr_from_rgb", src, dst, 3, 3, ("uint8", "float32"))
+
+
+def rgba_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("rgba_from_rgb", src, dst, 3, 4, ("uint8", "float32"), 0)
+
+
+def bgra_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("rgba_from_rgb", src, dst, 3, 4, ("uint8", "float32"), 1)
+
+
+def _rgb_from_4(src: Image, dst: Optional[Image], swap: int, background) -> Image:
+    bg = None
+    if background is not None:
+        arr = (C.c_uint8 * 3)(*[int(v) for v in background])
+        bg = C.cast(arr, C.c_void_p)
+    return _map("rgb_from_rgba", src, dst, 4, 3, ("uint8",), swap, bg)
+
+
+def rgb_from_rgba(src: Image, dst: Optional[Image] = None, background: Optional[Sequence[int]] = None) -> Image:
+    return _rgb_from_4(src, dst, 0, background)
+
+
+def rgb_from_bgra(src: Image, dst: Optional[Image] = None, background: Optional[Sequence[int]] = None) -> Image:
+    return _rgb_from_4(src, dst, 1, background)
+
+
+def ycbcr_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("ycc_from_rgb", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YCRCB)
+
+
+def rgb_from_ycbcr(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("rgb_from_ycc", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YCRCB)
+
+
+def yuv_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("ycc_from_rgb", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YUV)
+
+
+def rgb_from_yuv(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("rgb_from_ycc", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YUV)
+
+
+def hsv_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("hsv_from_rgb", src, dst, 3, 3, ("float32",))
+
+
+def rgb_from_hsv(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("rgb_from_hsv", src, dst, 3, 3, ("float32",))
+
+
+def hls_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("hls_from_rgb", src, dst, 3, 3, ("float32",))
+
+
+def rgb_from_hls(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("rgb_from_hls", src, dst, 3, 3, ("float32",))
+
+
+def sepia_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
+    return _map("sepia_from_rgb", src, dst, 3, 3, ("uint8", "float32"))
+
+
+def apply_colormap(src: Image, lut: np.ndarray, dst: Optional[Image] = None) -> Image:
+    """``lut``: uint8 array of shape (3, 256) = r[256], g[256], b[256] (the reference's
+    ``ColormapLut``, P/color/colormap.rs).  Named OpenCV tables are not bundled."""
+    lut = np.ascontiguousarray(lut, np.uint8).reshape(-1)
+    if lut.size != 768:
+        raise ImageError("InvalidArgument", "colormap LUT must hold 3 x 256 bytes")
+    if not src.is_device:
+        raise ImageError("HostPathUnavailable", "host images: move the image with .to_hip(stream)")
+    dlut = DeviceBuffer.from_numpy(lut, src.stream)
+    out = _map("apply_colormap", src, dst, 1, 3, ("uint8",), dlut.ptr)
+    out._lut_keepalive = dlut  # freed stream-ordered after the launch
+    return out
+
+
+# ---- video formats (raw buffers <-> RGB8) ----------------------------------------------------------
+
+def _raw_ptr(buf, need: int, what: str) -> Tuple[int, Stream]:
+    if isinstance(buf, (Tensor, Image)):
+        if not buf.is_device:
+            raise ImageError("HostPathUnavailable", f"{what}: host buffer; upload it first (DeviceBuffer.from_numpy)")
+        n, ptr, st = buf.nbytes, buf.data_ptr, buf.stream
+    elif isinstance(buf, DeviceBuffer):
+        n, ptr, st = buf.nbytes, buf.ptr, buf.stream
+    else:
+        raise ImageError("HostPathUnavailable", f"{what}: expected a device buffer, got {type(buf).__name__}")
+    if n < need:
+        raise ImageError("InvalidImageSize", f"{what}: buffer holds {n} bytes, the format needs {need}")
+    return ptr, st
+
+
+def _decode(kind: str, layout: int, data, width: int, height: int, dst: Optional[Image]) -> Image:
+    need = width * height * 3 // 2 if kind == "planar420" else width * height * 2
+    ptr, st = _raw_ptr(data, need, f"rgb_from_{kind}")
+    out = dst if dst is not None else Image.uninit(width, height, 3, "uint8", st)
+    _require(out, "uint8", (3,), f"rgb_from_{kind}")
+    if out.size != (width, height):
+        raise ImageError("InvalidImageSize", f"destination is {out.width}x{out.height}, expected {width}x{height}")
+    _check(getattr(lib, f"kh_rgb_from_{kind}_u8")(st.cuda_stream_ptr, ptr, out.data_ptr, width, height, layout))
+    return out
+
+
+def rgb_from_nv12(data, width, height, dst=None): return _decode("planar420", 0, data, width, height, dst)
+def rgb_from_nv21(data, width, height, dst=None): return _decode("planar420", 1, data, width, height, dst)
+def rgb_from_i420(data, width, height, dst=None): return _decode("planar420", 2, data, width, height, dst)
+def rgb_from_yv12(data, width, height, dst=None): return _decode("planar420", 3, data, width, height, dst)
+def rgb_from_yuyv(data, width, height, dst=None): return _decode("packed422", 0, data, width, height, dst)
+def rgb_from_uyvy(data, width, height, dst=None): return _decode("packed422", 1, data, width, height, dst)
+def rgb_from_yvyu(data, width, height, dst=None): return _decode("packed422", 2, data, width, height, dst)
+
+
+def _encode(name: str, src: Image, nbytes: int) -> Tensor:
+    _require(src, "uint8", (3,), name)
+    if not src.is_device:
+        raise ImageError("HostPathUnavailable", "host images: move the image with .to_hip(stream)")
+    out = Tensor.uninit((nbytes,), "uint8", src.stream)
+    _check(getattr(lib, f"kh_{name}_u8")(src.stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height))
+    return out
+
+
+def nv12_from_rgb(src: Image) -> Tensor:
+    return _encode("nv12_from_rgb", src, src.width * src.height * 3 // 2)
+
+
+def yuyv_from_rgb(src: Image) -> Tensor:
+    return _encode("yuyv_from_rgb", src, src.width * src.height * 2)
+
+
+# ---- geometry ---------------------------------------------------------------------------------------
+
+def _interp(name: str) -> int:
+    mode = _INTERP.get(str(name).lower())
+    if mode is None:
+        raise ImageError("NoDeviceKernel", f"interpolation {name!r} has no device kernel (nearest, bilinear, bicubic)")
+    return mode
+
+
+def _geom_pair(src: Image, dst: Optional[Image], new_size: Optional[Tuple[int, int]], what: str) -> Tuple[Image, Stream]:
+    _require(src, "float32", (1, 3, 4), what)
+    if dst is None:
+        h, w = new_size  # the Python API takes (height, width)
+        dst = _new_like(src, size=(w, h))
+    _require(dst, "float32", (src.channels,), what)
+    return dst, _pair_residency(src, dst)
+
+
+def resize(src: Image, new_size: Optional[Tuple[int, int]] = None, interpolation: str = "bilinear",
+           out: Optional[Image] = None) -> Image:
+    """``new_size`` = (height, width) as in kornia_rs (imgproc.pyi:80-93)."""
+    mode = _interp(interpolation)
+    dst, stream = _geom_pair(src, out, new_size, "resize")
+    _check(lib.kh_resize_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
+                             dst.height, src.channels, mode, 1, 0, 0))
+    return dst
+
+
+def _matrix(m: Sequence[float], n: int, what: str):
+    m = [float(v) for v in np.asarray(m, dtype=np.float32).reshape(-1)]
+    if len(m) != n:
+        raise ImageError("InvalidArgument", f"{what}: matrix needs {n} entries, got {len(m)}")
+    return (C.c_float * n)(*m)
+
+
+def warp_affine(src: Image, m: Sequence[float], new_size: Optional[Tuple[int, int]] = None,
+                interpolation: str = "bilinear", out: Optional[Image] = None) -> Image:
+    mode = _interp(interpolation)
+    dst, stream = _geom_pair(src, out, new_size, "warp_affine")
+    _check(lib.kh_warp_affine_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
+                                  dst.height, src.channels, _matrix(m, 6, "warp_affine"), mode, 1, 0, 0))
+    return dst
+
+
+def warp_perspective(src: Image, m: Sequence[float], new_size: Optional[Tuple[int, int]] = None,
+                     interpolation: str = "bilinear", out: Optional[Image] = None) -> Image:
+    mode = _interp(interpolation)
+    mm = _matrix(m, 9, "warp_perspective")
+    inv = (C.c_float * 9)()
+    _check(lib.kh_invert_homography(mm, inv))  # singular matrices are rejected before anything is allocated
+    dst, stream = _geom_pair(src, out, new_size, "warp_perspective")
+    _check(lib.kh_warp_perspective_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height,
+                                       dst.width, dst.height, src.channels, mm, mode, 1, 0, 0))
+    return dst
+
+
+def remap(src: Image, map_x: Image, map_y: Image, interpolation: str = "bilinear", out: Optional[Image] = None) -> Image:
+    mode = _interp(interpolation)
+    if map_x.size != map_y.size:
+        raise ImageError("InvalidImageSize", "map_x and map_y must have the same size")
+    for mp in (map_x, map_y):
+        _require(mp, "float32", (1,), "remap map")
+    dst, stream = _geom_pair(src, out, (map_x.height, map_x.width), "remap")
+    if dst.size != map_x.size:
+        raise ImageError("InvalidImageSize", "dst must have the size of the maps")
+    if not (map_x.is_device and map_y.is_device):
+        raise ImageError("Hip", "remap: map_x and map_y must be device-resident when src/dst are on GPU")
+    for mp in (map_x, map_y):
+        if mp.stream is not None and mp.stream.cuda_stream_ptr != stream.cuda_stream_ptr:
+            _check(lib.kh_stream_fence(mp.stream.cuda_stream_ptr, stream.cuda_stream_ptr))
+    _check(lib.kh_remap_f32(stream.cuda_stream_ptr, src.data_ptr, map_x.data_ptr, map_y.data_ptr, dst.data_ptr,
+                            src.width, src.height, dst.width, dst.height, src.channels, mode, 1, 0, 0))
+    return dst
+
+
+def generate_correction_map_polynomial(intrinsic: Sequence[float], distortion: Sequence[float], size: Tuple[int, int],
+                                       stream: Stream) -> Tuple[Image, Image]:
+    """``intrinsic`` = (fx, fy, cx, cy), ``distortion`` = (k1..k6, p1, p2), ``size`` = (width, height);
+    returns device ``(map_x, map_y)`` (P/calibration/distortion.rs:135-152)."""
+    w, h = size
+    mx, my = Image.uninit(w, h, 1, "float32", stream), Image.uninit(w, h, 1, "float32", stream)
+    _check(lib.kh_correction_map_polynomial_f32(stream.cuda_stream_ptr, mx.data_ptr, my.data_ptr, w, h,
+                                                (C.c_double * 4)(*intrinsic), (C.c_double * 8)(*distortion)))
+    return mx, my
+
+
+def get_rotation_matrix2d(center: Tuple[float, float], angle: float, scale: float):
+    out = (C.c_float * 6)()
+    lib.kh_get_rotation_matrix2d(center[0], center[1], angle, scale, out)
+    return [float(v) for v in out]
+
+
+def invert_affine_transform(m: Sequence[float]):
+    out = (C.c_float * 6)()
+    lib.kh_invert_affine_transform(_matrix(m, 6, "invert_affine_transform"), out)
+    return [float(v) for v in out]
+
+
+# ---- filters ----------------------------------------------------------------------------------------
+
+def _filter_pair(src: Image, dst: Optional[Image], what: str) -> Tuple[Image, Stream]:
+    _require(src, "float32", tuple(range(1, 9)), what)
+    out = dst if dst is not None else _new_like(src)
+    _require(out, "float32", (src.channels,), what)
+    _same_size(src, out)
+    return out, _pair_residency(src, out)
+
+
+def gaussian_blur(src: Image, kernel_size: Tuple[int, int], sigma: Tuple[float, float], dst: Optional[Image] = None) -> Image:
+    k = (C.c_int32 * 2)(*kernel_size)
+    s = (C.c_float * 2)(*sigma)
+    if lib.kh_gaussian_resolve(k, s) != _ffi.KH_OK:
+        raise ImageError("InvalidSigmaValue", _ffi.last_error())
+    out, stream = _filter_pair(src, dst, "gaussian_blur")
+    _check(lib.kh_gaussian_blur_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
+                                    src.channels, kernel_size[0], kernel_size[1], sigma[0], sigma[1], 1, 0, 0))
+    return out
+
+
+def box_blur(src: Image, kernel_size: Tuple[int, int], dst: Optional[Image] = None) -> Image:
+    out, stream = _filter_pair(src, dst, "box_blur")
+    _check(lib.kh_box_blur_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels,
+                               kernel_size[0], kernel_size[1], 1, 0, 0))
+    return out
+
+
+def _gradient(src: Image, kind: int, kernel_size: int, dst: Optional[Image], what: str) -> Image:
+    ok = kernel_size in ((3, 5) if kind == _ffi.KH_GRAD_SOBEL else (3,))
+    if not ok:
+        raise ImageError("InvalidKernelLength", f"{what}: invalid kernel length ({kernel_size}, {kernel_size})")
+    out, stream = _filter_pair(src, dst, what)
+    _check(lib.kh_gradient_magnitude_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
+                                         src.channels, kind, kernel_size, 1, 0, 0))
+    return out
+
+
+def sobel(src: Image, kernel_size: int = 3, dst: Optional[Image] = None) -> Image:
+    return _gradient(src, _ffi.KH_GRAD_SOBEL, kernel_size, dst, "sobel")
+
+
+def scharr(src: Image, kernel_size: int = 3, dst: Optional[Image] = None) -> Image:
+    return _gradient(src, _ffi.KH_GRAD_SCHARR, kernel_size, dst, "scharr")
+
+
+def separable_filter(src: Image, kernel_x: Sequence[float], kernel_y: Sequence[float], dst: Optional[Image] = None) -> Image:
+    kx, ky = np.asarray(kernel_x, np.float32), np.asarray(kernel_y, np.float32)
+    out, stream = _filter_pair(src, dst, "separable_filter")
+    _check(lib.kh_separable_filter_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
+                                       src.channels, (C.c_float * kx.size)(*kx), kx.size, (C.c_float * ky.size)(*ky),
+                                       ky.size, 1, 0, 0))
+    return out
+
+
+# ---- normalize / crop / flip ----------------------------------------------------------------------------
+
+def normalize_mean_std(src: Image, mean: Sequence[float], std: Sequence[float], dst: Optional[Image] = None) -> Image:
+    _require(src, "float32", (1, 2, 3, 4), "normalize_mean_std")
+    if len(mean) != src.channels or len(std) != src.channels:
+        raise ImageError("InvalidChannelShape", "mean/std need one entry per channel")
+    out = dst if dst is not None else _new_like(src)
+    _require(out, "float32", (src.channels,), "normalize_mean_std")
+    _same_size(src, out)
+    stream = _pair_residency(src, out)
+    _check(lib.kh_normalize_mean_std_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height,
+                                         src.channels, (C.c_float * src.channels)(*mean), (C.c_float * src.channels)(*std)))
+    return out
+
+
+def find_min_max(src: Image) -> Tuple[float, float]:
+    _require(src, "float32", tuple(range(1, 9)), "find_min_max")
+    if not src.is_device:
+        raise ImageError("HostPathUnavailable", "host images: move the image with .to_hip(stream)")
+    n = src.width * src.height * src.channels
+    if n == 0:
+        raise ImageError("ImageDataNotInitialized", "image data is not initialized")
+    mm, scratch = Tensor.uninit((2,), "float32", src.stream), Tensor.uninit((2,), "int32", src.stream)
+    _check(lib.kh_find_min_max_f32(src.stream.cuda_stream_ptr, src.data_ptr, n, mm.data_ptr, scratch.data_ptr))
+    lo, hi = mm.numpy()
+    return float(lo), float(hi)
+
+
+def normalize_min_max(src: Image, min: float, max: float, dst: Optional[Image] = None) -> Image:
+    _require(src, "float32", tuple(range(1, 9)), "normalize_min_max")
+    out = dst if dst is not None else _new_like(src)
+    _require(out, "float32", (src.channels,), "normalize_min_max")
+    _same_size(src, out)
+    stream = _pair_residency(src, out)
+    n = src.width * src.height * src.channels
+    if n == 0:
+        raise ImageError("ImageDataNotInitialized", "image data is not initialized")
+    mm, scratch = Tensor.uninit((2,), "float32", stream), Tensor.uninit((2,), "int32", stream)
+    _check(lib.kh_normalize_min_max_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, n, min, max, mm.data_ptr,
+                                        scratch.data_ptr))
+    out._scratch_keepalive = (mm, scratch)
+    return out
+
+
+def crop(src: Image, x: int, y: int, width: int, height: int, dst: Optional[Image] = None) -> Image:
+    out = dst if dst is not None else _new_like(src, size=(width, height))
+    if out.dtype != src.dtype or out.channels != src.channels or out.size != (width, height):
+        raise ImageError("InvalidImageSize", "crop destination must be width x height with the source's type")
+    if x + width > src.width or y + height > src.height:
+        raise ImageError("PixelIndexOutOfBounds", f"pixel index out of bounds: ({x + width}, {y + height}) exceeds "
+                                                  f"{src.width}x{src.height}")
+    stream = _pair_residency(src, out)
+    pb = src.channels * np.dtype(src.dtype).itemsize
+    _check(lib.kh_crop(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, width, height, x, y, pb))
+    return out
+
+
+def _flip(src: Image, dst: Optional[Image], horizontal: int) -> Image:
+    out = dst if dst is not None else _new_like(src)
+    if out.dtype != src.dtype or out.channels != src.channels:
+        raise ImageError("InvalidChannelShape", "flip destination must have the source's type")
+    _same_size(src, out)
+    stream = _pair_residency(src, out)
+    pb = src.channels * np.dtype(src.dtype).itemsize
+    _check(lib.kh_flip(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, pb, horizontal))
+    return out
+
+
+def horizontal_flip(src: Image, dst: Optional[Image] = None) -> Image:
+    return _flip(src, dst, 1)
+
+
+def vertical_flip(src: Image, dst: Optional[Image] = None) -> Image:
+    return _flip(src, dst, 0)

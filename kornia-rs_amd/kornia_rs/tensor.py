@@ -9,6 +9,7 @@ ran on (cuda.rs:89-108).
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Any, Optional, Sequence, Tuple
 
 import numpy as np
@@ -150,6 +151,44 @@ class Tensor:
         if self._host is not None:
             return self
         return Tensor(self._shape, self._dtype, host=self.numpy_raw())
+
+    # -- DLPack (T/dlpack.rs:72-290, PY/cuda_ext/mod.rs:196-216) ---------------------------------
+    def __dlpack_device__(self) -> Tuple[int, int]:
+        from . import dlpack
+        return (dlpack.kDLCPU, 0) if self._host is not None else (dlpack.kDLROCM, self._device)
+
+    def __dlpack__(self, *, stream: Any = None, max_version: Any = None, dl_device: Any = None,
+                   copy: Any = None) -> Any:
+        """Zero-copy capsule; this tensor is the keepalive.  For a device tensor the consumer's
+        ``stream`` (an integer handle, array-API convention) is fenced behind the producing stream
+        so the consumer never reads before our kernels finish."""
+        from . import dlpack
+        if copy:
+            raise BufferError("DLPack export never copies")
+        if self._host is not None:
+            return dlpack.export(self, int(self._host.ctypes.data), self._shape, self._dtype, dlpack.kDLCPU, 0)
+        if stream is not None and stream != -1 and self._stream is not None:
+            consumer = 0 if stream in (0, 1, 2) else int(stream)  # 0/1/2 = default-stream aliases
+            hip.check(hip.lib.kh_stream_fence(self._stream.cuda_stream_ptr, consumer))
+        return dlpack.export(self, self._ptr, self._shape, self._dtype, dlpack.kDLROCM, self._device)
+
+    @staticmethod
+    def from_dlpack(obj: Any, stream: Optional[Stream] = None) -> "Tensor":
+        """Zero-copy alias of the producer's buffer, residency inferred from the DLPack device
+        (T/dlpack.rs:267-290: any non-host type is Device).  The producer is kept alive for this
+        tensor's lifetime (``Backing::Foreign`` with a keepalive, T/cuda.rs:139-169); a device
+        import carries ``stream`` (default: the device's default stream) like
+        ``from_foreign_cudaslice`` does (T/cuda.rs:1022-1029)."""
+        from . import dlpack
+        ptr, shape, dtype, dev_type, dev_id, keep = dlpack.from_object(
+            obj, stream.cuda_stream_ptr if stream is not None else None)
+        if dev_type in dlpack._HOST_TYPES:
+            n = int(np.prod(shape, dtype=np.int64))
+            buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr) if n else b""
+            host = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+            return Tensor(shape, dtype, host=host, keepalive=keep)
+        st = stream if stream is not None else Stream.default(dev_id)
+        return Tensor(shape, dtype, device_ptr=ptr, device=dev_id, stream=st, keepalive=keep)
 
     def __repr__(self) -> str:
         return f"Tensor(shape={self._shape}, dtype={self.dtype}, device={self.device})"

@@ -1,0 +1,167 @@
+"""Host logic above the C ABI, no GPU: residency dispatch, typed errors, DLPack, sharding.
+
+The reference tests the same things with a ``FakeDeviceResource`` that reports
+``MemoryDomain::Device`` without a GPU (crates/kornia-tensor/src/storage.rs:493-517); here a
+``Tensor`` built around a dummy device pointer plays that role — every check below fires before
+any HIP call.  Cf. ``mixed_residency_is_a_typed_error`` / ``unsupported_channels_error_not_fallback``
+(crates/kornia-imgproc/src/warp/cuda.rs:369-400) and kornia-py/tests/test_dlpack.py."""
+import numpy as np
+import pytest
+
+import kornia_rs as K
+from kornia_rs import Image, ImageError, Stream, Tensor, imgproc, sharding
+
+
+def fake_device_image(w, h, c, dtype="float32", device=0, stream_handle=0):
+    t = Tensor((h, w, c), dtype, device_ptr=0x10000, device=device, stream=Stream.from_handle(stream_handle, device))
+    return Image(t)
+
+
+def host_image(w, h, c, dtype="float32"):
+    return Image.from_numpy(np.zeros((h, w, c), dtype))
+
+
+def test_mixed_residency_is_a_typed_error():
+    dev, host = fake_device_image(8, 8, 3), host_image(8, 8, 3)
+    for a, b in ((dev, host), (host, dev)):
+        with pytest.raises(ImageError) as e:
+            imgproc.resize(a, out=b)
+        assert e.value.kind == "MixedResidency"
+        with pytest.raises(ImageError) as e:
+            imgproc.gaussian_blur(a, (3, 3), (1.0, 1.0), dst=b)
+        assert e.value.kind == "MixedResidency"
+
+
+def test_host_pair_is_not_silently_computed():
+    with pytest.raises(ImageError) as e:
+        imgproc.gray_from_rgb(host_image(4, 4, 3, "uint8"))
+    assert e.value.kind == "HostPathUnavailable"
+    with pytest.raises(ImageError) as e:
+        imgproc.resize(host_image(4, 4, 3), out=host_image(2, 2, 3))
+    assert e.value.kind == "HostPathUnavailable"
+
+
+def test_device_mismatch_and_unsupported_kernels():
+    a, b = fake_device_image(8, 8, 3, device=0), fake_device_image(8, 8, 3, device=1)
+    with pytest.raises(ImageError) as e:
+        imgproc.resize(a, out=b)
+    assert e.value.kind == "DeviceMismatch"
+    with pytest.raises(ImageError) as e:  # unsupported_channels_error_not_fallback
+        imgproc.warp_perspective(fake_device_image(8, 8, 2), [1, 0, 0, 0, 1, 0, 0, 0, 1], out=fake_device_image(8, 8, 2))
+    assert e.value.kind == "NoDeviceKernel"
+    with pytest.raises(ImageError) as e:
+        imgproc.hsv_from_rgb(fake_device_image(8, 8, 3, "uint8"))
+    assert e.value.kind == "NoDeviceKernel"
+    with pytest.raises(ImageError) as e:
+        imgproc.resize(fake_device_image(8, 8, 3), (4, 4), "lanczos")
+    assert e.value.kind == "NoDeviceKernel"
+    with pytest.raises(ImageError) as e:  # singular homography rejected on the host, before any launch
+        imgproc.warp_perspective(a, [1, 2, 3, 2, 4, 6, 3, 6, 9], out=fake_device_image(8, 8, 3))
+    assert e.value.kind == "CannotComputeDeterminant"
+    with pytest.raises(ImageError) as e:
+        imgproc.gaussian_blur(a, (4, 3), (1.0, 1.0), dst=fake_device_image(8, 8, 3))
+    assert e.value.kind == "InvalidSigmaValue"
+    with pytest.raises(ImageError) as e:
+        imgproc.sobel(a, 7, dst=fake_device_image(8, 8, 3))
+    assert e.value.kind == "InvalidKernelLength"
+    with pytest.raises(ImageError) as e:
+        imgproc.crop(a, 4, 4, 8, 8, dst=fake_device_image(8, 8, 3))
+    assert e.value.kind == "PixelIndexOutOfBounds"
+    with pytest.raises(ImageError) as e:
+        imgproc.gray_from_rgb(fake_device_image(8, 8, 3, "uint8"), fake_device_image(9, 8, 1, "uint8"))
+    assert e.value.kind == "InvalidImageSize"
+
+
+def test_host_access_to_device_memory_is_refused():
+    dev = fake_device_image(4, 4, 3)
+    with pytest.raises(ImageError) as e:
+        dev.as_slice()
+    assert e.value.kind == "UnsupportedDevice"
+    assert dev.device == "cuda:0" and dev.is_device and host_image(2, 2, 1).device == "cpu"
+    with pytest.raises(AttributeError):
+        host_image(2, 2, 1).__cuda_array_interface__
+    cai = dev.__cuda_array_interface__
+    assert cai["shape"] == (4, 4, 3) and cai["typestr"] == "<f4" and cai["data"] == (0x10000, False) and cai["version"] == 3
+
+
+def test_image_basics_and_matrix_helpers():
+    img = Image.from_numpy(np.arange(24, dtype=np.uint8).reshape(2, 4, 3))
+    assert (img.width, img.height, img.channels, img.dtype, img.size) == (4, 2, 3, "uint8", (4, 2))
+    assert img.numpy().base is not None or img.numpy().flags["C_CONTIGUOUS"]
+    z = Image.zeros(5, 3, 1, "float32")
+    assert z.shape == (3, 5, 1) and not z.is_device and float(z.numpy().sum()) == 0.0
+    assert imgproc.invert_affine_transform([2, 0, 1, 0, 4, -2]) == [0.5, -0.0, -0.5, -0.0, 0.25, 0.5]
+    m = imgproc.get_rotation_matrix2d((0.5, 0.5), 90.0, 1.0)
+    assert abs(m[1] - 1.0) < 1e-6 and abs(m[0]) < 1e-6
+
+
+def test_dlpack_host_round_trip_and_keepalive():
+    from kornia_rs import dlpack
+    a = np.arange(24, dtype=np.float32).reshape(2, 4, 3)
+    t = Tensor.from_numpy(a)
+    before = (dlpack.export_count, dlpack.release_count)
+    b = np.from_dlpack(t)  # numpy consumes our capsule
+    assert np.shares_memory(a, b) and np.array_equal(a, b)
+    assert t.__dlpack_device__() == (dlpack.kDLCPU, 0)
+    del b
+    assert dlpack.export_count == before[0] + 1 and dlpack.release_count == before[1] + 1  # deleter ran once
+    # import: numpy producer -> our Tensor / Image, zero-copy, producer kept alive
+    src = np.arange(12, dtype=np.uint8).reshape(2, 2, 3)
+    img = Image.from_dlpack(src)
+    assert img.shape == (2, 2, 3) and img.dtype == "uint8" and not img.is_device
+    assert img.numpy().ctypes.data == src.ctypes.data
+    # non-contiguous producers are rejected (C-contiguous only, T/dlpack.rs:172-265)
+    with pytest.raises(ValueError):
+        Tensor.from_dlpack(np.arange(12, dtype=np.float32).reshape(3, 4).T)
+    # an unconsumed capsule releases its keepalive when dropped
+    before = dlpack.release_count
+    cap = t.__dlpack__()
+    del cap
+    assert dlpack.release_count == before + 1
+
+
+def test_dlpack_torch_host_interop():
+    torch = pytest.importorskip("torch")
+    t = Tensor.from_numpy(np.arange(6, dtype=np.float32).reshape(2, 3))
+    tt = torch.from_dlpack(t)
+    tt[0, 0] = 42.0  # shared memory
+    assert t.numpy()[0, 0] == 42.0
+    back = Tensor.from_dlpack(torch.arange(8, dtype=torch.int32).reshape(2, 4))
+    assert back.dtype == "int32" and back.numpy().tolist() == [[0, 1, 2, 3], [4, 5, 6, 7]]
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 1024, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert sharding.shard_range(2048, 3, 8) == (768, 1024)  # configs[4]: 256 images per GPU
+    with pytest.raises(ValueError):
+        sharding.shard_range(8, 8, 8)
+
+
+def test_preprocessor_host_validation():
+    from kornia_rs import PreprocessError, Preprocessor
+    with pytest.raises(PreprocessError) as e:
+        Preprocessor(std=(0.0, 0.2, 0.2), mean=(0.5, 0.5, 0.5), stream=Stream.default(0))
+    assert e.value.kind == "InvalidNormalize"
+    with pytest.raises(PreprocessError) as e:
+        Preprocessor(sampling="bicubic", stream=Stream.default(0))
+    assert e.value.kind == "UnsupportedSampling"
+    with pytest.raises(PreprocessError) as e:
+        Preprocessor()  # no stream = CPU preprocessor in the reference; not shipped here
+    assert e.value.kind == "NotDeviceImage"
+    pre = Preprocessor(format="nv12", stream=Stream.default(0))
+    dst = Tensor((1, 1, 4, 4), "float32", device_ptr=0x1000, device=0, stream=Stream.default(0))
+    with pytest.raises(PreprocessError) as e:
+        pre.run_raw(0x2000, 8, 6, dst)
+    assert e.value.kind == "BadOutputShape"
+    with pytest.raises(PreprocessError) as e:
+        pre.run_raw(0x2000, 8, 6, Tensor.zeros((1, 3, 4, 4)))
+    assert e.value.kind == "NotDeviceTensor"
+    assert K.preprocess.SourceFormat.from_name("NV12").buffer_len(8, 6) == 72
+    assert K.preprocess.SourceFormat.from_name("yuyv").buffer_len(8, 6) == 96
+    assert K.preprocess.SourceFormat.from_name("nope") is None

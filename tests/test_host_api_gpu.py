@@ -1,0 +1,94 @@
+"""The host mirror on a real device: Image residency, imgproc dispatch end-to-end, cross-stream
+fences, DLPack / __cuda_array_interface__ zero-copy with torch-ROCm (kornia-py/tests/
+test_image_device.py, test_dlpack.py, test_torch_zero_copy.py, test_cuda.py)."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_image_to_hip_roundtrip_and_ops(gpu_stream):
+    from kornia_rs import Image, imgproc
+    rgb = O.pattern_u8(258 * 195 * 3).reshape(195, 258, 3)  # config[0] shape, on the device path
+    dev = Image.from_numpy(rgb).to_hip(gpu_stream)
+    assert dev.is_device and dev.device == "cuda:0" and dev.to_cuda(gpu_stream) is dev
+    assert np.array_equal(dev.numpy(), rgb) and not dev.numpy().flags.writeable
+    gray = imgproc.gray_from_rgb(dev)
+    assert gray.is_device and gray.shape == (195, 258, 1)
+    assert np.array_equal(gray.numpy().reshape(-1), O.color_map("gray_from_rgb_u8", rgb, 1))
+    back = gray.cpu()
+    assert not back.is_device and np.array_equal(back.numpy(), gray.numpy())
+
+    f = Image.from_numpy(O.pattern_f32(129 * 97 * 3).reshape(97, 129, 3)).to_hip(gpu_stream)
+    small = imgproc.resize(f, (48, 64), "bilinear")
+    assert small.shape == (48, 64, 3)
+    assert np.array_equal(small.numpy(), O.resize(f.numpy(), 64, 48))
+    blur = imgproc.gaussian_blur(f, (7, 7), (1.5, 1.5))
+    assert np.array_equal(blur.numpy(), O.gaussian_blur(f.numpy(), (7, 7), (1.5, 1.5)))
+    hm = [1.03, 0.05, -3.0, -0.02, 0.97, 4.0, 2.0 / (97.0 * 129.0), 1.5 / (129.0 * 97.0), 1.0]
+    warped = imgproc.warp_perspective(f, hm, (97, 129), "bilinear")
+    assert np.array_equal(warped.numpy(), O.warp_perspective(f.numpy(), hm, 129, 97))
+    mx, my = imgproc.generate_correction_map_polynomial((300.0, 300.0, 64.0, 48.0), (0.1, 0.01, 0, 0, 0, 0, 1e-4, 1e-4),
+                                                        (129, 97), gpu_stream)
+    und = imgproc.remap(f, mx, my)
+    assert np.array_equal(und.numpy(), O.remap(f.numpy(), mx.numpy()[:, :, 0], my.numpy()[:, :, 0]))
+    lo, hi = imgproc.find_min_max(f)
+    assert (lo, hi) == (float(f.numpy().min()), float(f.numpy().max()))
+    norm = imgproc.normalize_mean_std(f, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+    want = ((f.numpy() - np.array((0.485, 0.456, 0.406), np.float32)) / np.array((0.229, 0.224, 0.225), np.float32)).astype(np.float32)
+    assert np.array_equal(norm.numpy(), want)
+    assert np.array_equal(imgproc.horizontal_flip(f).numpy(), f.numpy()[:, ::-1])
+    assert np.array_equal(imgproc.crop(f, 3, 5, 40, 30).numpy(), f.numpy()[5:35, 3:43])
+    raw = O.pattern_u8(64 * 32 * 3 // 2)
+    from kornia_rs.hip import DeviceBuffer
+    dec = imgproc.rgb_from_nv12(DeviceBuffer.from_numpy(raw, gpu_stream), 64, 32)
+    assert np.array_equal(dec.numpy(), O.rgb_from_nv12(raw, 64, 32))
+    enc = imgproc.nv12_from_rgb(dec)
+    assert np.array_equal(enc.numpy(), O.nv12_from_rgb(dec.numpy()))
+
+
+def test_cross_stream_destination_is_fenced(gpu_stream):
+    """dst allocated (and zero-filled) on another stream: the dispatch must fence it into the
+    source's stream before launching (P/cuda/dispatch.rs:50-67)."""
+    from kornia_rs import Image, Stream, imgproc
+    other = Stream.new(0)
+    src = Image.from_numpy(O.pattern_f32(300 * 200 * 3).reshape(200, 300, 3)).to_hip(gpu_stream)
+    for _ in range(5):
+        dst = Image.zeros(300, 200, 3, "float32", stream=other)  # memset queued on `other`
+        imgproc.gaussian_blur(src, (5, 5), (1.0, 1.0), dst=dst)
+        gpu_stream.synchronize()
+        assert np.array_equal(dst.numpy(), O.gaussian_blur(src.numpy(), (5, 5), (1.0, 1.0)))
+
+
+def test_torch_rocm_zero_copy_interop(gpu_stream):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("torch sees no HIP device on the GPU box")
+    from kornia_rs import Image, Preprocessor, Stream, Tensor, dlpack, imgproc
+    # 1. our device tensor -> torch (DLPack, kDLROCM) : same pointer, no copy
+    raw = O.pattern_u8(64 * 32 * 3 // 2)
+    pre = Preprocessor(mode="stretch", format="nv12", stream=gpu_stream)
+    out = pre.run(raw, 64, 32, 32, 64)
+    assert out.__dlpack_device__() == (dlpack.kDLROCM, 0)
+    tt = torch.from_dlpack(out)
+    assert tt.is_cuda and tt.data_ptr() == out.data_ptr and tuple(tt.shape) == (1, 3, 32, 64)
+    torch.cuda.synchronize()
+    assert np.array_equal(tt.cpu().numpy(), O.preprocess(raw, 64, 32, 64, 32, fmt="nv12", mode="stretch"))
+    # 2. __cuda_array_interface__ consumer
+    t2 = torch.as_tensor(out, device="cuda")
+    assert t2.data_ptr() == out.data_ptr
+    # 3. torch tensor -> our Image (zero-copy alias on torch's stream) -> device op -> back to torch
+    x = torch.rand(97, 129, 3, device="cuda", dtype=torch.float32)
+    ts = Stream.from_cuda_stream(torch.cuda.current_stream())
+    img = Image.from_dlpack(x, stream=ts)
+    assert img.is_device and img.data_ptr == x.data_ptr() and img.shape == (97, 129, 3)
+    g = imgproc.gray_from_rgb(img)
+    torch.cuda.synchronize()
+    want = O.color_map("gray_from_rgb_f32", x.cpu().numpy(), 1).reshape(97, 129, 1)
+    assert np.array_equal(g.numpy(), want)
+    # keepalive: dropping the torch name must not free memory we still alias
+    ptr = x.data_ptr()
+    del x
+    assert img.data_ptr == ptr and np.array_equal(imgproc.gray_from_rgb(img).numpy(), want)
