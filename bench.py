@@ -220,7 +220,7 @@ class ResizeBilinear(F32Images):
 class Gaussian4K(F32Images):
     """configs[3]: separable gaussian_blur 7x7 sigma 1.5 f32x3, 3840x2160, batch 256 (LDS stencil)."""
 
-    name, kernel = "gaussian_blur_7x7_4k_f32_b256", "sep_filter_kernel<false>"
+    name, kernel = "gaussian_blur_7x7_4k_f32_b256", "sep_roll_kernel<7,false>"
     W, H, C = 3840, 2160, 3
 
     def __init__(self, batch):

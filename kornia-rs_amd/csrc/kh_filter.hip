@@ -138,17 +138,16 @@ __global__ __launch_bounds__(kBlock) void sep_filter_kernel(FilterArgs a, Taps k
 // 64 floats (+ the horizontal halo, by the first 2*halo lanes), parks them in a 512-byte wave-private
 // LDS row, computes the horizontal pass from LDS (K conflict-free ds_read_b32) and pushes the result
 // into a K-deep REGISTER ring; the vertical pass is K multiply-adds on that ring.  No block barrier,
-// 2 KiB of LDS per block, every input row read once per strip (+ ky-1 warm-up rows per strip), four
-// rows of global loads in flight per lane.  Ascending-tap `acc += v*k` order and the f32
+// 2 KiB of LDS per block, every input row read once per strip (+ ky-1 warm-up rows per strip), K rows
+// of global loads in flight per lane; the walk is unrolled K times so ring slots are static registers.  Ascending-tap `acc += v*k` order and the f32
 // intermediate are exactly those of the two-pass reference.
-constexpr int kRollPF = 4;      // rows of prefetch per lane
-constexpr int kRollStrip = 90;  // output rows per strip (2160 = 24 strips)
+constexpr int kRollStripMax = 360;  // tallest strip (output rows)
 
 struct TapsK { float k[16]; };
 
 template <int K, bool GRAD>
 __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx, TapsK ky) {
-    __shared__ float rowbuf[4][128];
+    __shared__ float rowbuf[4][160];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int H = K / 2;
     const int halo = H * a.C;  // <= 32 (checked on the host)
@@ -156,70 +155,91 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
     const int gx0 = tx * kTF + wv * 64;  // first flat column of this wave
     if (gx0 >= a.rowlen) return;         // whole wave idle (no block barrier below)
     const int y0 = ty * a.th;
-    const float* src = a.src + (long long)blockIdx.y * a.src_stride;
-    float* dst = a.dst + (long long)blockIdx.y * a.dst_stride;
+    const float* __restrict__ src = a.src + (long long)blockIdx.y * a.src_stride;
+    float* __restrict__ dst = a.dst + (long long)blockIdx.y * a.dst_stride;
     float* buf = rowbuf[wv];
 
     const int gx = gx0 + lane;
     // halo lanes: [0, halo) fetch the left neighbours, [halo, 2*halo) the right ones
     const bool is_halo = lane < 2 * halo;
     const int hgx = lane < halo ? gx0 - halo + lane : gx0 + 64 + (lane - halo);
-    const int hslot = lane < halo ? lane : 64 + lane;  // LDS slot: left [0,halo), main [halo,halo+64), right after
+    const int hslot = lane < halo ? lane : 64 + lane;  // left [0,halo), main [halo,halo+64), right after
     const bool gx_ok = gx < a.rowlen, hgx_ok = is_halo && hgx >= 0 && hgx < a.rowlen;
     const int nrows = min(a.th, a.rows - y0) + 2 * H;  // input rows to walk (incl. warm-up)
 
-    auto fetch = [&](int r, float& m, float& hv) {
-        const int gy = y0 - H + r;
-        const bool row_ok = r < nrows && gy >= 0 && gy < a.rows;
-        const float* srow = src + (long long)gy * a.rowlen;
-        m = (row_ok && gx_ok) ? srow[gx] : 0.0f;
-        hv = (row_ok && hgx_ok) ? srow[hgx] : 0.0f;
+    // Loads are UNCONDITIONAL (clamped addresses, zero selected afterwards): with a load inside a
+    // divergent branch the compiler falls back to `s_waitcnt vmcnt(0)` at every use, which drains
+    // the K rows of loads in flight each step (measured 3x slower).  Non-halo lanes re-load their
+    // own main element as the "halo" value (an L1 hit) so the instruction needs no exec mask.
+    const int cx_m = min(gx, a.rowlen - 1);
+    const int cx_h = is_halo ? min(max(hgx, 0), a.rowlen - 1) : cx_m;
+    int pf_row = y0 - H;  // image row of the next prefetch (may be outside the image: clamped)
+
+    float qm[K], qh[K];  // K rows of loads in flight per lane
+    // The queue holds RAW loaded values; the zero-select for out-of-image rows/columns happens at
+    // use time, K steps later, so nothing consumes a load right after it is issued.
+    auto prefetch = [&](float& m, float& hv) {
+        const int base = min(max(pf_row, 0), a.rows - 1) * a.rowlen;  // 32-bit: host-checked
+        m = src[base + cx_m];
+        hv = src[base + cx_h];
+        ++pf_row;
     };
-
-    float qm[kRollPF], qh[kRollPF];
 #pragma unroll
-    for (int p = 0; p < kRollPF; ++p) fetch(p, qm[p], qh[p]);
+    for (int p = 0; p < K; ++p) prefetch(qm[p], qh[p]);
 
-    float ring[K], ring2[GRAD ? K : 1];
+    float ring[K], ring2[GRAD ? K : 1];  // slot p holds the horizontal result of walk step == p (mod K)
 #pragma unroll
     for (int i = 0; i < K; ++i) { ring[i] = 0.0f; if constexpr (GRAD) ring2[i] = 0.0f; }
 
-    for (int rb = 0; rb < nrows; rb += kRollPF) {
+    // The walk is branch-free except for the store predicate: steps past `nrows` (the last,
+    // partial group of K) recompute clamped rows and store nothing; the first 2H steps are the
+    // ring warm-up and store nothing either.
+    const int hs = is_halo ? hslot : 159;  // non-halo lanes park their duplicate in a slot nobody reads
+    int out_off = (y0 - 2 * H) * a.rowlen + gx;  // destination offset of walk step 0's (virtual) output row
+    const float* tap = buf + halo + lane - H * a.C;
+    for (int rb = 0; rb < nrows; rb += K) {
 #pragma unroll
-        for (int p = 0; p < kRollPF; ++p) {
+        for (int p = 0; p < K; ++p) {
             const int r = rb + p;
-            const float m = qm[p], hv = qh[p];
-            fetch(r + kRollPF, qm[p], qh[p]);  // keep kRollPF rows in flight
-            if (r >= nrows) break;
+            const int row = y0 - H + r;
+            const bool row_ok = row >= 0 && row < a.rows;  // wave-uniform
+            const float m = (row_ok && gx_ok) ? qm[p] : 0.0f;
+            const float hv = (row_ok && hgx_ok) ? qh[p] : 0.0f;
+            prefetch(qm[p], qh[p]);
             buf[halo + lane] = m;
-            if (is_halo) buf[hslot] = hv;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            buf[hs] = hv;
+            // Cross-lane hand-off inside ONE wave: DS operations of a wave execute in issue order, so
+            // the reads below see the writes above; the scheduling barrier only stops the compiler
+            // from reordering them.  (A wavefront-scope fence here would also drain vmcnt and
+            // serialise the K rows of loads in flight — measured 3x slower.)
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float h1 = 0.0f, h2 = 0.0f;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                const float v = buf[halo + lane + (i - H) * a.C];
+                const float v = tap[i * a.C];
                 h1 += v * kx.k[i];
                 if constexpr (GRAD) h2 += v * ky.k[i];
             }
-            __builtin_amdgcn_wave_barrier();  // all lanes have read the row before it is overwritten
+            __builtin_amdgcn_wave_barrier();  // every lane has read the row before it is overwritten
+            ring[p] = h1;
+            if constexpr (GRAD) ring2[p] = h2;
+            float o = 0.0f, o2 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < K - 1; ++i) { ring[i] = ring[i + 1]; if constexpr (GRAD) ring2[i] = ring2[i + 1]; }
-            ring[K - 1] = h1;
-            if constexpr (GRAD) ring2[K - 1] = h2;
-            if (r >= 2 * H && gx_ok) {
-                float o = 0.0f, o2 = 0.0f;
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    o += ring[i] * ky.k[i];
-                    if constexpr (GRAD) o2 += ring2[i] * kx.k[i];
-                }
-                if constexpr (GRAD) o = sqrtf(o * o + o2 * o2);
-                dst[(long long)(y0 + r - 2 * H) * a.rowlen + gx] = o;
+            for (int i = 0; i < K; ++i) {  // oldest row first: ascending vertical taps
+                o += ring[(p + 1 + i) % K] * ky.k[i];
+                if constexpr (GRAD) o2 += ring2[(p + 1 + i) % K] * kx.k[i];
             }
+            if constexpr (GRAD) o = sqrtf(o * o + o2 * o2);
+            if (gx_ok && r >= 2 * H && r < nrows) dst[out_off] = o;
+            out_off += a.rowlen;
         }
     }
+}
+
+// tuning knob (dev): KH_FILTER_STRIP = output rows per strip
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
 }
 
 template <int K>
@@ -271,8 +291,16 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         TapsK px, py;
         pad_taps(px, kx, K);
         pad_taps(py, ky, K);
-        a.th = kRollStrip;
         a.tiles_x = (int)cdiv(a.rowlen, kTF);
+        // Strip height: tall strips amortise the ky-1 warm-up rows (4K x 256 images: 360 rows is
+        // 5 % faster than 90), short strips keep a small launch wide enough to fill 256 CUs.
+        {
+            const long long cols_blocks = (long long)a.tiles_x * batch;
+            long long strips = (2048 + cols_blocks - 1) / cols_blocks;          // >= 8 blocks per CU
+            const long long min_strips = cdiv(rows, kRollStripMax), max_strips = cdiv(rows, 32);
+            strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
+            a.th = env_int("KH_FILTER_STRIP", (int)cdiv(rows, strips));
+        }
         const dim3 grid(a.tiles_x * cdiv(rows, a.th), (unsigned)batch);
         hipStream_t st = as_hip(stream);
         switch (K) {
