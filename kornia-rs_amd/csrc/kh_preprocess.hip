@@ -219,12 +219,13 @@ __device__ __forceinline__ float div255_u8(float x) {
 // segments (3 store streams; the 4x2 variant's 6 streams measured ~8 % slower, see
 // profiles/r01b_ubench_nv12.txt).  The chroma dword is read by both rows of a pair; the second
 // read is an L2 / Infinity-Cache hit.
+constexpr int kIdBlock = 512;  // 8 KiB contiguous per plane per block; +2 % over 256 (profiles/r01b_ubench_nv12.txt)
 template <bool NT>
-__global__ __launch_bounds__(kBlock) void preprocess_nv12_identity(
+__global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
     const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a) {
     const int wq = a.src_w >> 2;     // 4-pixel groups per row
     const int groups = wq * a.src_h;
-    const int g = blockIdx.x * kBlock + threadIdx.x;
+    const int g = blockIdx.x * kIdBlock + threadIdx.x;
     if (g >= groups) return;
     const uint8_t* src = src_base + (long long)blockIdx.y * a.src_frame_stride;
     float* dst = dst_base + (long long)blockIdx.y * a.dst_frame_stride;
@@ -374,8 +375,8 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
 
     if (identity_fast_path(p, src, dst)) {
         const int groups = (p->src_w / 4) * p->src_h;
-        dim3 grid(cdiv(groups, kBlock), (unsigned)p->nframes);
-        hipLaunchKernelGGL((preprocess_nv12_identity<true>), grid, dim3(kBlock), 0, s, src,
+        dim3 grid(cdiv(groups, kIdBlock), (unsigned)p->nframes);
+        hipLaunchKernelGGL((preprocess_nv12_identity<true>), grid, dim3(kIdBlock), 0, s, src,
                            (float*)dst, a);
         return check_launch("preprocess_nv12_identity");
     }
