@@ -229,7 +229,7 @@ KH_API int32_t kh_yuyv_from_rgb_u8(kh_stream_t stream, const uint8_t* src, uint8
  * `batch` same-sized images `src_stride` / `dst_stride` ELEMENTS apart go out as one launch.
  * Matrices are the FORWARD (src -> dst) transform in host memory, inverted on the host like the
  * reference adapters do (P/warp/cuda.rs:65).                                                  */
-enum { KH_INTERP_NEAREST = 0, KH_INTERP_BILINEAR = 1, KH_INTERP_BICUBIC = 2 };
+enum { KH_INTERP_NEAREST = 0, KH_INTERP_BILINEAR = 1, KH_INTERP_BICUBIC = 2, KH_INTERP_LANCZOS = 3 };
 
 KH_API int32_t kh_resize_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w, int32_t src_h,
                              int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode, int32_t batch,
@@ -283,6 +283,43 @@ KH_API int32_t kh_gradient_magnitude_f32(kh_stream_t stream, const float* src, f
 KH_API int32_t kh_box_blur_kernel_1d(int32_t n, float* out);
 KH_API int32_t kh_gaussian_kernel_1d(int32_t n, float sigma, float* out);
 KH_API int32_t kh_gaussian_resolve(int32_t ksize_xy[2], float sigma_xy[2]);
+
+/* ------------------------------------------------------------------------------------------ */
+/* u8 fixed-point twins.  Byte-identical to the reference CPU ops they replace the
+ * device launchers of; HWC u8, channels in {1, 3, 4}, `batch` images `*_stride` BYTES apart.
+ *
+ * Blur — replaces launch_gaussian_blur_u8 / launch_box_blur_u8 and the binomial special case
+ * (P/cuda/filter.rs:116-250, adapters P/filter/cuda.rs:282) == gaussian_blur_u8 / box_blur_u8
+ * (P/filter/ops.rs:639, 59): taps quantised to Q8 with the centre absorbing the rounding error
+ * (quantize_kernel_256, :748-760), replicate border, `(acc + 128) >> 8` after EACH pass; a 3x3
+ * kernel with both sigmas in [0.6, 1.2] is the [1,2,1]/4 binomial of rounding halving adds
+ * (blur_u8_path, :21-27).  One fused launch, no scratch image (kernels wider than 15 taps fall back
+ * to the reference's two-pass structure through stream-ordered scratch).  src != dst.            */
+KH_API void kh_quantize_kernel_256(const float* kernel, int32_t n, uint8_t* out);
+KH_API int32_t kh_gaussian_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t cols, int32_t rows,
+                                   int32_t channels, int32_t ksize_x, int32_t ksize_y, float sigma_x, float sigma_y,
+                                   int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* odd kernel sizes only (P/filter/ops.rs:66-75)                                                 */
+KH_API int32_t kh_box_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t cols, int32_t rows,
+                              int32_t channels, int32_t ksize_x, int32_t ksize_y, int32_t batch, int64_t src_stride,
+                              int64_t dst_stride);
+/* Q10 bilinear gathers — replace launch_remap_u8 (P/cuda/remap.rs), launch_warp_affine_u8
+ * (P/cuda/warp_affine_u8.rs) and launch_warp_perspective_u8 (P/cuda/warp_perspective_u8.rs) ==
+ * remap_u8 (P/interpolation/remap.rs:157; nearest | bilinear only), warp_affine_u8
+ * (P/warp/affine.rs:373: per-row valid span, Q16 stepped coordinates) and warp_perspective_u8
+ * (P/warp/perspective.rs:179: analytic span on constant-sign rows, direct per-column coordinates).
+ * Sampler: P/warp/common.rs:16-165, `(top*fy1 + bot*fy + 2^19) >> 20`, zeros outside.  Matrices
+ * are FORWARD (src -> dst), host memory.                                                          */
+KH_API int32_t kh_remap_u8(kh_stream_t stream, const uint8_t* src, const float* map_x, const float* map_y,
+                           uint8_t* dst, int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h, int32_t channels,
+                           int32_t mode, int32_t batch, int64_t src_stride, int64_t dst_stride);
+KH_API int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t src_w, int32_t src_h,
+                                 int32_t dst_w, int32_t dst_h, int32_t channels, const float* m2x3, int32_t batch,
+                                 int64_t src_stride, int64_t dst_stride);
+/* KH_ERR_SINGULAR if the homography cannot be inverted                                          */
+KH_API int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t src_w,
+                                      int32_t src_h, int32_t dst_w, int32_t dst_h, int32_t channels, const float* m3x3,
+                                      int32_t batch, int64_t src_stride, int64_t dst_stride);
 
 /* ------------------------------------------------------------------------------------------ */
 /* normalize / crop / flip (P/normalize.rs:56-420, P/crop.rs:187-240, P/flip.rs:39-360).  The

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "kornia_hip.h"
 
@@ -28,6 +29,37 @@ constexpr int kBlock = 256;     // 4 waves: one per SIMD of a CU
 constexpr int64_t kI32Max = 2147483647LL;
 
 inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its
+// own L2, so a plain (x, y, image) grid puts tiles that share halo rows / columns on different L2s
+// and the shared lines are fetched from the fabric once per XCD (r01h PMC: +39 % on the 7x7 filter,
+// +47 % on warp_perspective).  XcdTiles hands XCD k the k-th contiguous eighth of the row-major
+// tile list of a 1-D launch, so neighbours run on the same L2 at about the same time.
+// KH_XCD_TILES=0 (dev knob) restores the plain order.
+struct XcdTiles { unsigned tiles_x, tiles_y, total, chunk; };
+constexpr int kXcds = 8;
+inline bool xcd_tiles_enabled() {
+    static const bool on = [] { const char* e = getenv("KH_XCD_TILES"); return !(e && e[0] == '0'); }();
+    return on;
+}
+inline XcdTiles xcd_tiles(unsigned tiles_x, unsigned tiles_y, unsigned images) {
+    const uint64_t total = (uint64_t)tiles_x * tiles_y * images;
+    XcdTiles t{tiles_x, tiles_y, (unsigned)total, 0};
+    if (total > 0x7fffff00ull) t.total = 0;  // caller rejects (KH_ERR_TOO_LARGE)
+    else if (xcd_tiles_enabled()) t.chunk = (unsigned)((total + kXcds - 1) / kXcds);
+    return t;
+}
+inline dim3 xcd_grid(const XcdTiles& t) { return dim3(t.chunk ? kXcds * t.chunk : t.total); }
+__device__ __forceinline__ bool xcd_tile(const XcdTiles& t, unsigned& bx, unsigned& by, unsigned& bz) {
+    const unsigned b = blockIdx.x;
+    const unsigned id = t.chunk ? (b % kXcds) * t.chunk + b / kXcds : b;
+    if (id >= t.total) return false;
+    const unsigned per_img = t.tiles_x * t.tiles_y, r = id % per_img;
+    bz = id / per_img;
+    by = r / t.tiles_x;
+    bx = r % t.tiles_x;
+    return true;
+}
 
 }  // namespace kh
 

@@ -40,7 +40,7 @@ struct FilterArgs {
     int rows, rowlen, C;  // rowlen = cols * C
     int th;               // output rows per tile (multiple of kVR)
     long long src_stride, dst_stride;
-    int tiles_x;
+    XcdTiles tiles;  // (column tile, row strip, image), XCD-contiguous order
 };
 
 extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -59,10 +59,11 @@ __global__ __launch_bounds__(kBlock) void sep_filter_kernel(FilterArgs a, Taps k
     float* mid = tile + in_h * in_w;       // [in_h][kTF]    H-pass output (gx path)
     float* mid2 = mid + in_h * kTF;        // [in_h][kTF]    (GRAD only: gy path)
 
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;  // block-uniform
     const int x0 = tx * kTF, y0 = ty * a.th;
-    const float* src = a.src + (long long)blockIdx.y * a.src_stride;
-    float* dst = a.dst + (long long)blockIdx.y * a.dst_stride;
+    const float* src = a.src + (long long)bz * a.src_stride;
+    float* dst = a.dst + (long long)bz * a.dst_stride;
 
     // 1. stage the input tile, zero outside the image
     for (int r = 0; r < in_h; ++r) {
@@ -151,12 +152,13 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int H = K / 2;
     const int halo = H * a.C;  // <= 32 (checked on the host)
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
     const int gx0 = tx * kTF + wv * 64;  // first flat column of this wave
     if (gx0 >= a.rowlen) return;         // whole wave idle (no block barrier below)
     const int y0 = ty * a.th;
-    const float* __restrict__ src = a.src + (long long)blockIdx.y * a.src_stride;
-    float* __restrict__ dst = a.dst + (long long)blockIdx.y * a.dst_stride;
+    const float* __restrict__ src = a.src + (long long)bz * a.src_stride;
+    float* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
     float* buf = rowbuf[wv];
 
     const int gx = gx0 + lane;
@@ -291,17 +293,19 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         TapsK px, py;
         pad_taps(px, kx, K);
         pad_taps(py, ky, K);
-        a.tiles_x = (int)cdiv(a.rowlen, kTF);
+        const unsigned tiles_x = cdiv(a.rowlen, kTF);
         // Strip height: tall strips amortise the ky-1 warm-up rows (4K x 256 images: 360 rows is
         // 5 % faster than 90), short strips keep a small launch wide enough to fill 256 CUs.
         {
-            const long long cols_blocks = (long long)a.tiles_x * batch;
+            const long long cols_blocks = (long long)tiles_x * batch;
             long long strips = (2048 + cols_blocks - 1) / cols_blocks;          // >= 8 blocks per CU
             const long long min_strips = cdiv(rows, kRollStripMax), max_strips = cdiv(rows, 32);
             strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
             a.th = env_int("KH_FILTER_STRIP", (int)cdiv(rows, strips));
         }
-        const dim3 grid(a.tiles_x * cdiv(rows, a.th), (unsigned)batch);
+        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch);
+        KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        const dim3 grid = xcd_grid(a.tiles);
         hipStream_t st = as_hip(stream);
         switch (K) {
             case 3: launch_roll<3>(st, grid, grad, a, px, py); break;
@@ -329,14 +333,14 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
                ky.n, C, bytes);
     if (rows < th) th = ((rows + kVR - 1) / kVR) * kVR;
     a.th = th;
-    a.tiles_x = (int)cdiv(a.rowlen, kTF);
-    const unsigned tiles_y = cdiv(rows, th);
+    a.tiles = xcd_tiles(cdiv(a.rowlen, kTF), cdiv(rows, th), (unsigned)batch);
+    KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
     auto kern = grad ? sep_filter_kernel<true> : sep_filter_kernel<false>;
     const size_t in_h = th + 2 * vhalo;
     bytes = (in_h * (kTF + 2 * halo) + in_h * kTF * (grad ? 2 : 1)) * sizeof(float);
     if (bytes > 48 * 1024)  // opt in to the full 160 KiB LDS of a gfx950 CU (per device, idempotent)
         KH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_x * tiles_y, (unsigned)batch), dim3(kBlock), bytes, as_hip(stream), a, kx, ky);
+    hipLaunchKernelGGL(kern, xcd_grid(a.tiles), dim3(kBlock), bytes, as_hip(stream), a, kx, ky);
     return check_launch(what);
 }
 

@@ -27,6 +27,7 @@ struct Img {  // one batch of same-sized HWC f32 images
     float* dst;
     int sw, sh, dw, dh;
     long long src_stride, dst_stride;  // elements between consecutive images
+    XcdTiles tiles;                    // kBx x kBy output tiles, XCD-contiguous order
 };
 
 // ---- samplers (expression trees of P/interpolation/*.rs; do not regroup) --------------------------
@@ -96,12 +97,95 @@ __device__ __forceinline__ void sample_bicubic(const float* __restrict__ img, in
     for (int c = 0; c < C; ++c) out[c] = acc[c];
 }
 
+// Lanczos-3 (P/interpolation/lanczos.rs).  sin_pi is the reference's libm-free polynomial (:19-37),
+// plain mul/add; lanczos3 (:40-51) feeds the resize tables, lanczos3_weights (:107-141) the warps.
+constexpr float kPi = 3.14159265358979323846f;
+__host__ __device__ __forceinline__ float sin_pi(float x) {
+    const float k = roundf(x);
+    const float r = x - k;
+    const float z = kPi * r;
+    const float z2 = z * z;
+    float p = -2.5052108e-8f;
+    p = p * z2 + 2.7557319e-6f;
+    p = p * z2 + -1.984127e-4f;
+    p = p * z2 + 8.333334e-3f;
+    p = p * z2 + -1.6666667e-1f;
+    const float s = z + z * z2 * p;
+    return ((int)k & 1) ? -s : s;
+}
+__host__ __device__ __forceinline__ float lanczos3(float x) {
+    if (fabsf(x) < 1e-5f) return 1.0f;
+    if (fabsf(x) >= 3.0f) return 0.0f;
+    const float pix = kPi * x;
+    const float pix3 = pix * 0.33333334f;
+    return sin_pi(x) * sin_pi(x * (1.0f / 3.0f)) / (pix * pix3);
+}
+__device__ __forceinline__ float lanczos_den(float x) {
+    const float pix = kPi * x;
+    const float pix3 = pix * 0.33333334f;
+    return pix * pix3;
+}
+__device__ __forceinline__ void lanczos3_weights(float frac, float w[6]) {
+    const float s = sin_pi(frac);
+    const float t0 = sin_pi(frac * (1.0f / 3.0f));
+    const float t1 = sin_pi((frac - 1.0f) * (1.0f / 3.0f));
+    const float t2 = sin_pi((frac - 2.0f) * (1.0f / 3.0f));
+    const float st0 = s * t0, st1 = s * t1, st2 = s * t2;
+    w[0] = -st1 / lanczos_den(frac + 2.0f);
+    w[1] = st2 / lanczos_den(frac + 1.0f);
+    w[2] = st0 / lanczos_den(frac);
+    w[3] = -st1 / lanczos_den(frac - 1.0f);
+    w[4] = st2 / lanczos_den(frac - 2.0f);
+    w[5] = st0 / lanczos_den(frac - 3.0f);
+    if (frac < 1e-5f) w[2] = 1.0f;
+    if (fabsf(frac - 1.0f) < 1e-5f) w[3] = 1.0f;
+}
+// lanczos_sample (:143-187): per-axis normalisation, per-row fmaf chain, then fmaf by wy
+template <int C>
+__device__ __forceinline__ void sample_lanczos(const float* __restrict__ img, int rows, int cols, float sx,
+                                               float sy, float out[C]) {
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    float wx[6], wy[6];
+    lanczos3_weights(sx - x0f, wx);
+    lanczos3_weights(sy - y0f, wy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float sum_wx = wx[0] + wx[1] + wx[2] + wx[3] + wx[4] + wx[5];
+    const float sum_wy = wy[0] + wy[1] + wy[2] + wy[3] + wy[4] + wy[5];
+    const float inv_x = 1.0f / sum_wx, inv_y = 1.0f / sum_wy;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) { wx[t] *= inv_x; wy[t] *= inv_y; }
+    int xo[6];
+#pragma unroll
+    for (int dx = 0; dx < 6; ++dx) xo[dx] = min(max(x0 + dx - 2, 0), cols - 1) * C;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int dy = 0; dy < 6; ++dy) {
+        const int yi = min(max(y0 + dy - 2, 0), rows - 1);
+        const float* row = img + (long long)yi * cols * C;
+        float rx[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) rx[c] = 0.0f;
+#pragma unroll
+        for (int dx = 0; dx < 6; ++dx) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) rx[c] = __builtin_fmaf(wx[dx], row[xo[dx] + c], rx[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(wy[dy], rx[c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = acc[c];
+}
+
 template <int C, int MODE>
 __device__ __forceinline__ void sample(const float* __restrict__ img, int rows, int cols, float u, float v,
                                        float out[C]) {
     if constexpr (MODE == KH_INTERP_NEAREST) sample_nearest<C>(img, rows, cols, u, v, out);
     else if constexpr (MODE == KH_INTERP_BILINEAR) sample_bilinear<C>(img, rows, cols, u, v, out);
-    else sample_bicubic<C>(img, rows, cols, u, v, out);
+    else if constexpr (MODE == KH_INTERP_BICUBIC) sample_bicubic<C>(img, rows, cols, u, v, out);
+    else sample_lanczos<C>(img, rows, cols, u, v, out);
 }
 
 template <int C>
@@ -118,11 +202,13 @@ __device__ __forceinline__ void put_zero(float* p) {
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
 #define KH_PIXEL_PROLOGUE                                             \
-    const int x = blockIdx.x * kBx + threadIdx.x;                     \
-    const int y = blockIdx.y * kBy + threadIdx.y;                     \
+    unsigned bx_, by_, bz_;                                           \
+    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;                   \
+    const int x = bx_ * kBx + threadIdx.x;                            \
+    const int y = by_ * kBy + threadIdx.y;                            \
     if (x >= im.dw || y >= im.dh) return;                             \
-    const float* src = im.src + (long long)blockIdx.z * im.src_stride; \
-    float* o = im.dst + (long long)blockIdx.z * im.dst_stride + ((long long)y * im.dw + x) * C;
+    const float* src = im.src + (long long)bz_ * im.src_stride;       \
+    float* o = im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C;
 
 // resize (P/resize/mod.rs:161-176): half-pixel grid a*x + b, clamped to the source
 template <int C, int MODE>
@@ -133,6 +219,59 @@ __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, floa
     float v[C];
     sample<C, MODE>(src, im.sh, im.sw, sx, sy, v);
     put<C>(o, v);
+}
+
+// Lanczos resize is separable in the reference (resize_lanczos_separable, lanczos.rs:189-245): an H
+// pass into a dst_w x src_h f32 intermediate, then a V pass, both fmaf chains over six host-built
+// table weights.  Here the two passes run fused per destination pixel — the row value `rx` IS the
+// intermediate element (same chain, same f32 rounding), so the bits are identical and the
+// dst_w x src_h scratch image never exists.  The tables are built on the device by the textual twin
+// of lanczos_axis (:59-101): tab[i] = {x0, w0..w5} per destination index.
+struct LzTap { int x0; float w[6]; };
+__global__ __launch_bounds__(kBlock) void lanczos_axis_kernel(LzTap* __restrict__ tab, int dst_len, float a, float b,
+                                                              float maxv) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= dst_len) return;
+    const float s = clampf(a * (float)i + b, 0.0f, maxv);
+    const float x0 = floorf(s), frac = s - x0;
+    float w[6] = {lanczos3(frac + 2.0f), lanczos3(frac + 1.0f), lanczos3(frac),
+                  lanczos3(frac - 1.0f), lanczos3(frac - 2.0f), lanczos3(frac - 3.0f)};
+    const float sum = w[0] + w[1] + w[2] + w[3] + w[4] + w[5];
+    const float inv = 1.0f / sum;
+    LzTap t;
+    t.x0 = (int)x0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t.w[k] = w[k] * inv;
+    tab[i] = t;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void resize_lanczos_kernel(Img im, const LzTap* __restrict__ tx,
+                                                                  const LzTap* __restrict__ ty) {
+    KH_PIXEL_PROLOGUE
+    const LzTap ax = tx[x], ay = ty[y];
+    int xo[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) xo[t] = min(max(ax.x0 + t - 2, 0), im.sw - 1) * C;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int dy = 0; dy < 6; ++dy) {
+        const int yi = min(max(ay.x0 + dy - 2, 0), im.sh - 1);
+        const float* row = src + (long long)yi * im.sw * C;
+        float rx[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) rx[c] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) rx[c] = __builtin_fmaf(ax.w[t], row[xo[t] + c], rx[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(ay.w[dy], rx[c], acc[c]);
+    }
+    put<C>(o, acc);
 }
 
 struct Mat6 { float m[6]; };
@@ -168,8 +307,8 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi) 
         const float* p11 = src + ((long long)y1 * im.sw + x1) * C;
 #pragma unroll
         for (int c = 0; c < C; ++c) v[c] = w00 * p00[c] + w10 * p10[c] + w01 * p01[c] + w11 * p11[c];
-    } else {
-        sample_bicubic<C>(src, im.sh, im.sw, sx, sy, v);
+    } else {  // per-pixel samplers on the unclamped coordinate (:322-362)
+        sample<C, MODE>(src, im.sh, im.sw, sx, sy, v);
     }
     put<C>(o, v);
 }
@@ -198,13 +337,15 @@ constexpr int kRemapNB = 4;
 template <int C, int MODE>
 __global__ __launch_bounds__(kBx* kBy) void remap_kernel(Img im, const float* __restrict__ map_x,
                                                          const float* __restrict__ map_y, int batch) {
-    const int x = blockIdx.x * kBx + threadIdx.x;
-    const int y = blockIdx.y * kBy + threadIdx.y;
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;
+    const int x = bx_ * kBx + threadIdx.x;
+    const int y = by_ * kBy + threadIdx.y;
     if (x >= im.dw || y >= im.dh) return;
     const long long i = (long long)y * im.dw + x;
     const float u = map_x[i], v = map_y[i];
     const bool inside = u >= 0.0f && u < (float)im.sw && v >= 0.0f && v < (float)im.sh;
-    const int z0 = blockIdx.z * kRemapNB;
+    const int z0 = bz_ * kRemapNB;
 #pragma unroll
     for (int k = 0; k < kRemapNB; ++k) {
         const int z = z0 + k;
@@ -245,8 +386,8 @@ int32_t check_img(const char* what, const void* src, const void* dst, int sw, in
                what, sw, sh, dw, dh);
     KH_REQUIRE(channels == 1 || channels == 3 || channels == 4, KH_ERR_UNSUPPORTED,
                "%s: no device kernel for %d channels (supported: 1, 3, 4)", what, channels);
-    KH_REQUIRE(mode >= KH_INTERP_NEAREST && mode <= KH_INTERP_BICUBIC, KH_ERR_UNSUPPORTED,
-               "%s: interpolation mode %d has no device kernel (nearest, bilinear, bicubic)", what, mode);
+    KH_REQUIRE(mode >= KH_INTERP_NEAREST && mode <= KH_INTERP_LANCZOS, KH_ERR_UNSUPPORTED,
+               "%s: interpolation mode %d has no device kernel (nearest, bilinear, bicubic, lanczos)", what, mode);
     KH_REQUIRE(batch >= 0 && batch <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, batch);
     KH_REQUIRE((int64_t)sw * sh * channels <= kI32Max && (int64_t)dw * dh * channels <= kI32Max, KH_ERR_TOO_LARGE,
                "%s: image exceeds 32-bit indexing", what);
@@ -255,7 +396,11 @@ int32_t check_img(const char* what, const void* src, const void* dst, int sw, in
     return KH_OK;
 }
 
-dim3 grid_for(int dw, int dh, int batch) { return dim3(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)batch); }
+Img make_img(const float* src, float* dst, int sw, int sh, int dw, int dh, int64_t ss, int64_t ds, int groups) {
+    return Img{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups)};
+}
+#define KH_REQUIRE_TILES(what, im) \
+    KH_REQUIRE((im).tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what)
 
 #define KH_DISPATCH_C_MODE(KERNEL, channels, mode, grid, stream, ...)                                              \
     do {                                                                                                           \
@@ -267,6 +412,9 @@ dim3 grid_for(int dw, int dh, int batch) { return dim3(cdiv(dw, kBx), cdiv(dh, k
             case 30: hipLaunchKernelGGL((KERNEL<3, 0>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
             case 31: hipLaunchKernelGGL((KERNEL<3, 1>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
             case 32: hipLaunchKernelGGL((KERNEL<3, 2>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 13: hipLaunchKernelGGL((KERNEL<1, 3>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 33: hipLaunchKernelGGL((KERNEL<3, 3>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 43: hipLaunchKernelGGL((KERNEL<4, 3>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
             case 40: hipLaunchKernelGGL((KERNEL<4, 0>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
             case 41: hipLaunchKernelGGL((KERNEL<4, 1>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
             default: hipLaunchKernelGGL((KERNEL<4, 2>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
@@ -320,8 +468,29 @@ int32_t kh_resize_f32(kh_stream_t stream, const float* src, float* dst, int32_t 
     // PixelMapping::HalfPixel coefficients, exactly the CPU LUT's expression (P/resize/mod.rs:169-171)
     const float ax = (float)sw / (float)dw, bx = 0.5f * ax - 0.5f;
     const float ay = (float)sh / (float)dh, by = 0.5f * ay - 0.5f;
-    const Img im{src, dst, sw, sh, dw, dh, src_stride, dst_stride};
-    KH_DISPATCH_C_MODE(resize_kernel, channels, mode, grid_for(dw, dh, batch), as_hip(stream), im, ax, bx, ay, by);
+    const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
+    KH_REQUIRE_TILES("kh_resize_f32", im);
+    if (mode == KH_INTERP_LANCZOS) {  // P/resize/mod.rs:139-146
+        // (dw + dh) x 28 B of stream-ordered scratch for the axis tables, as the reference adapter
+        // allocates its tables/intermediate per call (P/resize/cuda.rs:151-190)
+        LzTap* tab = nullptr;
+        if (int32_t rc = kh_malloc_async((void**)&tab, sizeof(LzTap) * ((size_t)dw + dh), 0, stream)) return rc;
+        hipStream_t st = as_hip(stream);
+        hipLaunchKernelGGL(lanczos_axis_kernel, dim3(cdiv(dw, kBlock)), dim3(kBlock), 0, st, tab, dw, ax, bx,
+                           (float)(sw - 1));
+        hipLaunchKernelGGL(lanczos_axis_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, st, tab + dw, dh, ay, by,
+                           (float)(sh - 1));
+        const dim3 blk(kBx, kBy);
+        switch (channels) {
+            case 1: hipLaunchKernelGGL(resize_lanczos_kernel<1>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw); break;
+            case 3: hipLaunchKernelGGL(resize_lanczos_kernel<3>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw); break;
+            default: hipLaunchKernelGGL(resize_lanczos_kernel<4>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw); break;
+        }
+        const int32_t rc = check_launch("kh_resize_f32 (lanczos)");
+        (void)kh_free_async(tab, stream);
+        return rc;
+    }
+    KH_DISPATCH_C_MODE(resize_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, ax, bx, ay, by);
     return check_launch("kh_resize_f32");
 }
 
@@ -334,8 +503,9 @@ int32_t kh_warp_affine_f32(kh_stream_t stream, const float* src, float* dst, int
     if (batch == 0) return KH_OK;
     Mat6 mi;
     kh_invert_affine_transform(m, mi.m);
-    const Img im{src, dst, sw, sh, dw, dh, src_stride, dst_stride};
-    KH_DISPATCH_C_MODE(warp_affine_kernel, channels, mode, grid_for(dw, dh, batch), as_hip(stream), im, mi);
+    const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
+    KH_REQUIRE_TILES("kh_warp_affine_f32", im);
+    KH_DISPATCH_C_MODE(warp_affine_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, mi);
     return check_launch("kh_warp_affine_f32");
 }
 
@@ -348,8 +518,9 @@ int32_t kh_warp_perspective_f32(kh_stream_t stream, const float* src, float* dst
     Mat9 h;
     if (int32_t rc = kh_invert_homography(m, h.m)) return rc;  // rejected on the host, before any launch
     if (batch == 0) return KH_OK;
-    const Img im{src, dst, sw, sh, dw, dh, src_stride, dst_stride};
-    KH_DISPATCH_C_MODE(warp_perspective_kernel, channels, mode, grid_for(dw, dh, batch), as_hip(stream), im, h);
+    const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
+    KH_REQUIRE_TILES("kh_warp_perspective_f32", im);
+    KH_DISPATCH_C_MODE(warp_perspective_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, h);
     return check_launch("kh_warp_perspective_f32");
 }
 
@@ -360,8 +531,9 @@ int32_t kh_remap_f32(kh_stream_t stream, const float* src, const float* map_x, c
         return rc;
     if (batch == 0) return KH_OK;
     KH_REQUIRE(map_x && map_y, KH_ERR_INVALID_ARG, "kh_remap_f32: null map pointer");
-    const Img im{src, dst, sw, sh, dw, dh, src_stride, dst_stride};
-    KH_DISPATCH_C_MODE(remap_kernel, channels, mode, grid_for(dw, dh, (batch + kRemapNB - 1) / kRemapNB), as_hip(stream), im,
+    const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, (batch + kRemapNB - 1) / kRemapNB);
+    KH_REQUIRE_TILES("kh_remap_f32", im);
+    KH_DISPATCH_C_MODE(remap_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im,
                        map_x, map_y, batch);
     return check_launch("kh_remap_f32");
 }

@@ -1,0 +1,613 @@
+// u8 fixed-point twins for gfx950: Q8 separable blur (+ the 3x3 binomial), Q10 bilinear remap,
+// warp_affine and warp_perspective.
+//
+// Device twins of P/cuda/filter.rs:116-250 and P/cuda/{remap,warp_affine_u8,warp_perspective_u8}.rs;
+// the integer arithmetic is that of the CPU ops gaussian_blur_u8 / box_blur_u8 (P/filter/ops.rs:59,
+// 639), remap_u8 (P/interpolation/remap.rs:157), warp_affine_u8 (P/warp/affine.rs:373) and
+// warp_perspective_u8 (P/warp/perspective.rs:179): byte-identical results (tests/test_u8_gpu.py).
+//
+// Blur: the rolling-column structure of the f32 filter (kh_filter.hip) on bytes.  A lane owns 4
+// consecutive flat bytes, a wave 256, and walks down a strip of rows; each input row is loaded once
+// (one dword per lane + a 32-byte halo each side by 16 lanes), parked in a 320-byte wave-private LDS
+// row where the replicate border is patched in, reduced horizontally from LDS (`(acc+128)>>8`, the
+// reference's u8 intermediate) into a K-deep register ring, and reduced vertically from the ring.
+// 1 read + 1 write of HBM per byte instead of the reference's two passes through a scratch image.
+#include <math.h>
+
+#include "kh_common.h"
+
+using namespace kh;
+
+namespace {
+
+// ---- blur --------------------------------------------------------------------------------------------
+
+constexpr int kU8Halo = 32;         // halo bytes staged on each side of a wave's 256
+constexpr int kU8Wave = 256;        // flat bytes per wave per row
+constexpr int kU8Tile = 4 * kU8Wave;  // per 256-thread block
+constexpr int kU8StripMax = 360;
+
+struct U8FilterArgs {
+    const uint8_t* src;
+    uint8_t* dst;
+    int rows, rowlen, cols;  // rowlen = cols * C bytes
+    int th;                  // output rows per strip
+    long long src_stride, dst_stride;
+    XcdTiles tiles;
+};
+struct TapsQ { uint32_t k[16]; };
+
+typedef uint32_t u32u __attribute__((aligned(1)));  // unaligned dword access (global_load/store_dword)
+
+__device__ __forceinline__ uint32_t rhadd(uint32_t a, uint32_t b) { return (a + b + 1u) >> 1; }
+
+template <int K, int C, bool BINOMIAL>
+__global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky) {
+    __shared__ uint32_t rowbuf[4][84];  // 80 dwords of row + a dummy slot
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int H = K / 2;
+    constexpr int D = (H * C + 3) / 4;  // halo dwords actually read on each side
+    static_assert(H * C <= kU8Halo, "halo does not fit");
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int gx0 = tx * kU8Tile + wv * kU8Wave;
+    if (gx0 >= a.rowlen) return;  // whole wave idle (no block barrier below)
+    const int y0 = ty * a.th;
+    const uint8_t* __restrict__ src = a.src + (long long)bz * a.src_stride;
+    uint8_t* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
+    uint32_t* buf = rowbuf[wv];
+    uint8_t* bufb = reinterpret_cast<uint8_t*>(buf);
+
+    // Loads are unconditional, from clamped addresses (see kh_filter.hip): a dword that straddles the
+    // end of the row is fetched from rowlen-4 and shifted down; bytes outside the row are garbage
+    // until the replicate patch below overwrites them.
+    const int g = gx0 + 4 * lane;
+    const int gm = min(g, a.rowlen - 4);
+    const int sm = min(g - gm, 3) * 8;
+    const bool is_halo = lane < 16;
+    const int gh_raw = lane < 8 ? gx0 - kU8Halo + 4 * lane : gx0 + kU8Wave + 4 * (lane - 8);
+    const int gh = is_halo ? min(max(gh_raw, 0), a.rowlen - 4) : gm;
+    const int sh = is_halo ? min(max(gh_raw - gh, 0), 3) * 8 : 0;
+    const int hslot = is_halo ? (lane < 8 ? lane : 64 + lane) : 80;
+    const bool left_edge = gx0 == 0, right_edge = gx0 + kU8Wave + kU8Halo > a.rowlen;
+    const int nrows = min(a.th, a.rows - y0) + 2 * H;
+    int pf_row = y0 - H;
+
+    uint32_t qm[K], qh[K];
+    auto prefetch = [&](uint32_t& m, uint32_t& hv) {
+        const int base = min(max(pf_row, 0), a.rows - 1) * a.rowlen;  // replicate rows; 32-bit: host-checked
+        m = *reinterpret_cast<const u32u*>(src + base + gm);
+        hv = *reinterpret_cast<const u32u*>(src + base + gh);
+        ++pf_row;
+    };
+#pragma unroll
+    for (int p = 0; p < K; ++p) prefetch(qm[p], qh[p]);
+
+    uint32_t ring[K][4];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ring[i][b] = 0;
+
+    const bool full = g + 3 < a.rowlen;
+    int out_off = (y0 - 2 * H) * a.rowlen + g;
+    const uint32_t* tap = buf + 8 + lane - D;
+    for (int rb = 0; rb < nrows; rb += K) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            const int r = rb + p;
+            const uint32_t m = qm[p] >> sm, hv = qh[p] >> sh;
+            prefetch(qm[p], qh[p]);
+            buf[8 + lane] = m;
+            buf[hslot] = hv;
+            __builtin_amdgcn_wave_barrier();
+            // replicate border (P/cuda/filter.rs:131-139): positions left of pixel 0 / right of the last
+            // pixel take that pixel's byte of the same channel.  Wave-uniform, LDS only.
+            if (left_edge) {
+                if (lane < kU8Halo) {
+                    const int gg = lane - kU8Halo;              // flat index, negative
+                    const int ch = ((gg % C) + C) % C;
+                    bufb[lane] = bufb[kU8Halo + ch];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (right_edge) {
+                const int last = a.rowlen - C - gx0 + kU8Halo;  // LDS byte position of the last pixel
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int j = lane + 64 * i;
+                    const int gg = gx0 - kU8Halo + j;
+                    if (gg >= a.rowlen) bufb[j] = bufb[last + (gg % C)];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            uint32_t d[2 * D + 1];
+#pragma unroll
+            for (int i = 0; i < 2 * D + 1; ++i) d[i] = tap[i];
+            __builtin_amdgcn_wave_barrier();  // row consumed before the next one overwrites it
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                auto byte_at = [&](int t) -> uint32_t {  // tap t of output byte b; offsets are compile-time
+                    const int rel = b + (t - H) * C + 4 * D;
+                    return (d[rel / 4] >> ((rel % 4) * 8)) & 0xffu;
+                };
+                if constexpr (BINOMIAL) {
+                    ring[p][b] = rhadd(rhadd(byte_at(0), byte_at(1)), rhadd(byte_at(1), byte_at(2)));
+                } else {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int t = 0; t < K; ++t) acc += byte_at(t) * kx.k[t];
+                    ring[p][b] = ((acc + 128u) >> 8) & 0xffu;  // `as u8`
+                }
+            }
+            uint32_t packed = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                uint32_t o;
+                if constexpr (BINOMIAL) {
+                    o = rhadd(rhadd(ring[(p + 1) % K][b], ring[(p + 2) % K][b]), rhadd(ring[(p + 2) % K][b], ring[p][b]));
+                } else {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int i = 0; i < K; ++i) acc += ring[(p + 1 + i) % K][b] * ky.k[i];  // oldest row first
+                    o = ((acc + 128u) >> 8) & 0xffu;
+                }
+                packed |= o << (8 * b);
+            }
+            if (r >= 2 * H && r < nrows) {
+                if (full) {
+                    *reinterpret_cast<u32u*>(dst + out_off) = packed;
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        if (g + b < a.rowlen) dst[out_off + b] = (uint8_t)(packed >> (8 * b));
+                }
+            }
+            out_off += a.rowlen;
+        }
+    }
+}
+
+// Fallback for what the rolling kernel does not take (kernels wider than 15 taps, halos beyond 32
+// bytes, rows shorter than 4 bytes): one Q8 pass per launch through a scratch image, one thread per
+// byte — the reference's own structure (P/cuda/filter.rs:116-165).
+struct Taps64 { uint8_t k[64]; int n; };
+template <bool HORIZ, bool BINOMIAL>
+__global__ __launch_bounds__(kBlock) void blur_u8_pass_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                              int cols, int rows, int C, long long ss, long long ds,
+                                                              Taps64 k) {
+    const int rowlen = cols * C;
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (long long)rows * rowlen) return;
+    const int y = (int)(i / rowlen), f = (int)(i % rowlen), x = f / C, ch = f % C;
+    const uint8_t* s = src + (long long)blockIdx.y * ss;
+    const int half = k.n / 2;
+    auto at = [&](int t) -> uint32_t {
+        const int xx = HORIZ ? min(max(x + t - half, 0), cols - 1) : x;
+        const int yy = HORIZ ? y : min(max(y + t - half, 0), rows - 1);
+        return s[((long long)yy * cols + xx) * C + ch];
+    };
+    uint32_t o;
+    if constexpr (BINOMIAL) {
+        o = rhadd(rhadd(at(0), at(1)), rhadd(at(1), at(2)));
+    } else {
+        uint32_t acc = 0;
+        for (int t = 0; t < k.n; ++t) acc += at(t) * k.k[t];
+        o = (acc + 128u) >> 8;
+    }
+    dst[(long long)blockIdx.y * ds + i] = (uint8_t)o;
+}
+
+template <int K, int C>
+void launch_blur_kc(hipStream_t st, bool binomial, const U8FilterArgs& a, const TapsQ& kx, const TapsQ& ky) {
+    const dim3 grid = xcd_grid(a.tiles);
+    if constexpr (K == 3) {
+        if (binomial) {
+            hipLaunchKernelGGL((blur_u8_roll_kernel<3, C, true>), grid, dim3(kBlock), 0, st, a, kx, ky);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((blur_u8_roll_kernel<K, C, false>), grid, dim3(kBlock), 0, st, a, kx, ky);
+}
+template <int K>
+void launch_blur_k(hipStream_t st, int C, bool binomial, const U8FilterArgs& a, const TapsQ& kx, const TapsQ& ky) {
+    if (C == 1) launch_blur_kc<K, 1>(st, binomial, a, kx, ky);
+    else if (C == 3) launch_blur_kc<K, 3>(st, binomial, a, kx, ky);
+    else launch_blur_kc<K, 4>(st, binomial, a, kx, ky);
+}
+
+void pad_q(TapsQ& out, const uint8_t* k, int n, int K) {
+    const int off = (K - n) / 2;  // zero taps add nothing to the integer accumulator
+    for (int i = 0; i < 16; ++i) out.k[i] = (i >= off && i < off + n) ? k[i - off] : 0u;
+}
+
+int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int cols, int rows, int C,
+                       const uint8_t* qx, int nx, const uint8_t* qy, int ny, bool binomial, int batch, int64_t ss,
+                       int64_t ds, const char* what) {
+    const int rowlen = cols * C;
+    const int kmax = nx > ny ? nx : ny;
+    hipStream_t st = as_hip(stream);
+    if (kmax <= 15 && (kmax / 2) * C <= kU8Halo && rowlen >= 4) {
+        const int K = kmax < 3 ? 3 : kmax;
+        TapsQ px, py;
+        pad_q(px, qx, nx, K);
+        pad_q(py, qy, ny, K);
+        U8FilterArgs a;
+        a.src = src; a.dst = dst; a.rows = rows; a.rowlen = rowlen; a.cols = cols;
+        a.src_stride = ss; a.dst_stride = ds;
+        const unsigned tiles_x = cdiv(rowlen, kU8Tile);
+        const long long cols_blocks = (long long)tiles_x * batch;
+        long long strips = (2048 + cols_blocks - 1) / cols_blocks;  // >= 8 blocks per CU
+        const long long min_strips = cdiv(rows, kU8StripMax), max_strips = cdiv(rows, 32);
+        strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
+        a.th = (int)cdiv(rows, strips);
+        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch);
+        KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        switch (K) {
+            case 3: launch_blur_k<3>(st, C, binomial, a, px, py); break;
+            case 5: launch_blur_k<5>(st, C, false, a, px, py); break;
+            case 7: launch_blur_k<7>(st, C, false, a, px, py); break;
+            case 9: launch_blur_k<9>(st, C, false, a, px, py); break;
+            case 11: launch_blur_k<11>(st, C, false, a, px, py); break;
+            case 13: launch_blur_k<13>(st, C, false, a, px, py); break;
+            default: launch_blur_k<15>(st, C, false, a, px, py); break;
+        }
+        return check_launch(what);
+    }
+    // two passes through stream-ordered scratch (P/filter/cuda.rs:119)
+    const size_t img = (size_t)rows * rowlen;
+    uint8_t* tmp = nullptr;
+    if (int32_t rc = kh_malloc_async((void**)&tmp, img * batch, 0, stream)) return rc;
+    Taps64 tx{}, tyv{};
+    tx.n = nx; tyv.n = ny;
+    for (int i = 0; i < nx; ++i) tx.k[i] = qx[i];
+    for (int i = 0; i < ny; ++i) tyv.k[i] = qy[i];
+    const dim3 grid(cdiv((int64_t)img, kBlock), (unsigned)batch);
+    if (binomial) {
+        hipLaunchKernelGGL((blur_u8_pass_kernel<true, true>), grid, dim3(kBlock), 0, st, src, tmp, cols, rows, C,
+                           (long long)ss, (long long)img, tx);
+        hipLaunchKernelGGL((blur_u8_pass_kernel<false, true>), grid, dim3(kBlock), 0, st, (const uint8_t*)tmp, dst, cols,
+                           rows, C, (long long)img, (long long)ds, tyv);
+    } else {
+        hipLaunchKernelGGL((blur_u8_pass_kernel<true, false>), grid, dim3(kBlock), 0, st, src, tmp, cols, rows, C,
+                           (long long)ss, (long long)img, tx);
+        hipLaunchKernelGGL((blur_u8_pass_kernel<false, false>), grid, dim3(kBlock), 0, st, (const uint8_t*)tmp, dst, cols,
+                           rows, C, (long long)img, (long long)ds, tyv);
+    }
+    const int32_t rc = check_launch(what);
+    (void)kh_free_async(tmp, stream);
+    return rc;
+}
+
+int32_t check_u8_img(const char* what, const void* src, const void* dst, int sw, int sh, int dw, int dh, int channels,
+                     int batch, int64_t ss, int64_t ds) {
+    KH_REQUIRE(sw > 0 && sh > 0 && dw > 0 && dh > 0, KH_ERR_INVALID_ARG, "%s: zero-sized image (src %dx%d, dst %dx%d)",
+               what, sw, sh, dw, dh);
+    KH_REQUIRE(channels == 1 || channels == 3 || channels == 4, KH_ERR_UNSUPPORTED,
+               "%s: no device kernel for %d channels (supported: 1, 3, 4)", what, channels);
+    KH_REQUIRE(batch >= 0 && batch <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, batch);
+    KH_REQUIRE((int64_t)sw * sh * channels <= kI32Max && (int64_t)dw * dh * channels <= kI32Max, KH_ERR_TOO_LARGE,
+               "%s: image exceeds 32-bit indexing", what);
+    KH_REQUIRE(ss >= 0 && ds >= 0, KH_ERR_INVALID_ARG, "%s: negative batch stride", what);
+    if (batch > 0) KH_REQUIRE(src && dst, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
+    return KH_OK;
+}
+
+// ---- Q10 bilinear gathers ----------------------------------------------------------------------------
+
+constexpr int kBx = 64, kBy = 4;
+
+struct ImgU8 {
+    const uint8_t* src;
+    uint8_t* dst;
+    int sw, sh, dw, dh;
+    long long src_stride, dst_stride;  // bytes between consecutive images
+    XcdTiles tiles;
+};
+
+template <int C>
+__device__ __forceinline__ void put_u8(uint8_t* o, const uint32_t v[C]) {
+    if constexpr (C == 4) {
+        *reinterpret_cast<uint32_t*>(o) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);  // pixel-aligned
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = (uint8_t)v[c];
+    }
+}
+template <int C>
+__device__ __forceinline__ void put_zero_u8(uint8_t* o) {
+    const uint32_t z[4] = {0, 0, 0, 0};
+    put_u8<C>(o, z);
+}
+
+// bilinear_sample_u8_valid (P/warp/common.rs:79-165): xi, yi in range; fx, fy in Q10
+template <int C>
+__device__ __forceinline__ void sample_q10(const uint8_t* __restrict__ src, int sw, int sh, int xi, int yi, uint32_t fx,
+                                           uint32_t fy, uint8_t* o) {
+    const uint32_t fx1 = 1024u - fx, fy1 = 1024u - fy;
+    const int xi1 = xi + 1 < sw ? xi + 1 : xi, yi1 = yi + 1 < sh ? yi + 1 : yi;
+    const uint8_t* r0 = src + (long long)yi * sw * C;
+    const uint8_t* r1 = src + (long long)yi1 * sw * C;
+    uint32_t v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const uint32_t p00 = r0[xi * C + c], p01 = r0[xi1 * C + c], p10 = r1[xi * C + c], p11 = r1[xi1 * C + c];
+        const uint32_t top = p00 * fx1 + p01 * fx, bot = p10 * fx1 + p11 * fx;
+        v[c] = ((top * fy1 + bot * fy + (1u << 19)) >> 20) & 0xffu;
+    }
+    put_u8<C>(o, v);
+}
+
+// bilinear_sample_u8 (P/warp/common.rs:16-70): zeros when non-finite or outside
+template <int C>
+__device__ __forceinline__ void sample_q10_checked(const uint8_t* __restrict__ src, int sw, int sh, float xf, float yf,
+                                                   uint8_t* o) {
+    bool ok = __builtin_isfinite(xf) && __builtin_isfinite(yf);
+    // floor(..) as i32 saturates in the reference; clamping first keeps the range test identical
+    const int xi = (int)fminf(fmaxf(floorf(xf), -1.0f), 2147483520.0f);
+    const int yi = (int)fminf(fmaxf(floorf(yf), -1.0f), 2147483520.0f);
+    ok = ok && xi >= 0 && xi < sw && yi >= 0 && yi < sh;
+    if (!ok) { put_zero_u8<C>(o); return; }
+    sample_q10<C>(src, sw, sh, xi, yi, (uint32_t)((xf - (float)xi) * 1024.0f), (uint32_t)((yf - (float)yi) * 1024.0f), o);
+}
+
+#define KH_U8_PROLOGUE                                          \
+    unsigned bx_, by_, bz_;                                     \
+    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;             \
+    const int x = bx_ * kBx + threadIdx.x;                      \
+    const int y = by_ * kBy + threadIdx.y;                      \
+    if (x >= im.dw || y >= im.dh) return;
+
+// remap_u8 (P/interpolation/remap.rs:157-300); maps shared by the batch, kU8RemapNB images per thread
+constexpr int kU8RemapNB = 4;
+template <int C, int MODE>
+__global__ __launch_bounds__(kBx* kBy) void remap_u8_kernel(ImgU8 im, const float* __restrict__ map_x,
+                                                            const float* __restrict__ map_y, int batch) {
+    KH_U8_PROLOGUE
+    const long long i = (long long)y * im.dw + x;
+    const float xf = map_x[i], yf = map_y[i];
+    const int z0 = bz_ * kU8RemapNB;
+#pragma unroll
+    for (int k = 0; k < kU8RemapNB; ++k) {
+        const int z = z0 + k;
+        if (z >= batch) break;
+        const uint8_t* src = im.src + (long long)z * im.src_stride;
+        uint8_t* o = im.dst + (long long)z * im.dst_stride + i * C;
+        if constexpr (MODE == KH_INTERP_BILINEAR) {
+            sample_q10_checked<C>(src, im.sw, im.sh, xf, yf, o);
+        } else {  // nearest, :268-298
+            if (xf >= 0.0f && xf < (float)im.sw && yf >= 0.0f && yf < (float)im.sh) {
+                const int xi = min(max((int)roundf(xf), 0), im.sw - 1), yi = min(max((int)roundf(yf), 0), im.sh - 1);
+                const uint8_t* p = src + ((long long)yi * im.sw + xi) * C;
+                uint32_t v[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[c] = p[c];
+                put_u8<C>(o, v);
+            } else {
+                put_zero_u8<C>(o);
+            }
+        }
+    }
+}
+
+// Rust `f32 as i64` / `as i32`: saturating, NaN -> 0.  Spans only compare against [0, dst_w], so
+// clamping to +-4e18 before the conversion is equivalent.
+__device__ __forceinline__ long long f2ll_sat(float v) {
+    return v != v ? 0ll : (long long)fminf(fmaxf(v, -4.0e18f), 4.0e18f);
+}
+__host__ __device__ __forceinline__ int f2i_sat(float v) {
+    return v != v ? 0 : (v >= 2147483648.0f ? 2147483647 : (v <= -2147483648.0f ? (-2147483647 - 1) : (int)v));
+}
+
+// constrain_span (P/warp/span.rs:36-59)
+__device__ __forceinline__ void constrain_span(float a, float b, bool ge, float eps, long long& lo, long long& hi) {
+    if (fabsf(a) < eps || a == 0.0f) {
+        const bool feasible = ge ? (b >= 0.0f) : (b < 0.0f);
+        if (!feasible) hi = lo;
+        return;
+    }
+    const float k = -b / a;
+    if (ge && a > 0.0f) lo = max(lo, f2ll_sat(ceilf(k)));
+    else if (ge) hi = min(hi, f2ll_sat(floorf(k)) + 1);
+    else if (a > 0.0f) hi = min(hi, f2ll_sat(ceilf(k)));
+    else lo = max(lo, f2ll_sat(floorf(k)) + 1);
+}
+
+struct Mat6 { float m[6]; };
+struct Mat9 { float m[9]; };
+
+// warp_affine_u8 (P/warp/affine.rs:373-445): per-row valid span (P/warp/span.rs:61-85), Q16
+// coordinates stepped from the span start with wrapping adds (P/warp/kernels.rs:386-415) — here
+// sx_q_lo + (x - x_lo) * dsx_q in wrapping arithmetic, the same value.
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void warp_affine_u8_kernel(ImgU8 im, Mat6 mi, int dsx_q, int dsy_q) {
+    KH_U8_PROLOGUE
+    const uint8_t* src = im.src + (long long)bz_ * im.src_stride;
+    uint8_t* o = im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C;
+    const float dsx = mi.m[0], dsy = mi.m[3];
+    const float sx0 = mi.m[1] * (float)y + mi.m[2], sy0 = mi.m[4] * (float)y + mi.m[5];
+    long long lo = 0, hi = im.dw;
+    constrain_span(dsx, sx0, true, 1e-12f, lo, hi);
+    constrain_span(dsx, sx0 - (float)im.sw, false, 1e-12f, lo, hi);
+    bool empty = lo >= hi;
+    if (!empty) {
+        constrain_span(dsy, sy0, true, 1e-12f, lo, hi);
+        constrain_span(dsy, sy0 - (float)im.sh, false, 1e-12f, lo, hi);
+        empty = lo >= hi;
+    }
+    lo = min(max(lo, 0ll), (long long)im.dw);
+    hi = min(max(hi, 0ll), (long long)im.dw);
+    if (empty || lo >= hi || x < lo || x >= hi) { put_zero_u8<C>(o); return; }
+    const int x_lo = (int)lo;
+    const uint32_t sx_lo = (uint32_t)f2i_sat((sx0 + dsx * (float)x_lo) * 65536.0f);
+    const uint32_t sy_lo = (uint32_t)f2i_sat((sy0 + dsy * (float)x_lo) * 65536.0f);
+    const int sx_q = (int)(sx_lo + (uint32_t)(x - x_lo) * (uint32_t)dsx_q);
+    const int sy_q = (int)(sy_lo + (uint32_t)(x - x_lo) * (uint32_t)dsy_q);
+    // The span keeps the indices in range in exact arithmetic; the clamp only matters where Q16
+    // rounding drift would take the reference's unchecked sampler outside the image.
+    const int xi = min(max(sx_q >> 16, 0), im.sw - 1), yi = min(max(sy_q >> 16, 0), im.sh - 1);
+    sample_q10<C>(src, im.sw, im.sh, xi, yi, ((uint32_t)(sx_q & 0xFFFF)) >> 6, ((uint32_t)(sy_q & 0xFFFF)) >> 6, o);
+}
+
+// warp_perspective_u8 (P/warp/perspective.rs:179-322): rows whose denominator keeps one sign get
+// the analytic span, other rows the bounds-checked sampler on every column; coordinates are
+// evaluated directly per column (perspective_coord_at, P/warp/kernels.rs:107-122).
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void warp_perspective_u8_kernel(ImgU8 im, Mat9 inv) {
+    KH_U8_PROLOGUE
+    const uint8_t* src = im.src + (long long)bz_ * im.src_stride;
+    uint8_t* o = im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C;
+    const float yf = (float)y, swf = (float)im.sw, shf = (float)im.sh;
+    float nx0 = inv.m[1] * yf + inv.m[2], ny0 = inv.m[4] * yf + inv.m[5], nd0 = inv.m[7] * yf + inv.m[8];
+    float dnx = inv.m[0], dny = inv.m[3], dnd = inv.m[6];
+    const float nd_end = nd0 + dnd * ((float)im.dw - 1.0f);
+    const bool pos = nd0 > 1e-6f && nd_end > 1e-6f, neg = nd0 < -1e-6f && nd_end < -1e-6f;
+    if (pos || neg) {
+        if (neg) { nx0 = -nx0; ny0 = -ny0; nd0 = -nd0; dnx = -dnx; dny = -dny; dnd = -dnd; }
+        long long lo = 0, hi = im.dw;
+        constrain_span(dnx, nx0, true, 0.0f, lo, hi);
+        constrain_span(dnx - swf * dnd, nx0 - swf * nd0, false, 0.0f, lo, hi);
+        constrain_span(dny, ny0, true, 0.0f, lo, hi);
+        constrain_span(dny - shf * dnd, ny0 - shf * nd0, false, 0.0f, lo, hi);
+        lo = min(max(lo, 0ll), (long long)im.dw);
+        hi = min(max(hi, 0ll), (long long)im.dw);
+        if (lo >= hi || x < lo || x >= hi) { put_zero_u8<C>(o); return; }
+    }
+    const float xf_ = (float)x;
+    const float nx = nx0 + dnx * xf_, ny = ny0 + dny * xf_, nd = nd0 + dnd * xf_;
+    const float inv_nd = 1.0f / nd;
+    sample_q10_checked<C>(src, im.sw, im.sh, nx * inv_nd, ny * inv_nd, o);
+}
+
+ImgU8 make_img_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int64_t ss, int64_t ds, int groups) {
+    return ImgU8{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups)};
+}
+
+#define KH_DISPATCH_C(KERNEL, channels, grid, stream, ...)                                              \
+    do {                                                                                                \
+        const dim3 blk(kBx, kBy);                                                                       \
+        if ((channels) == 1) hipLaunchKernelGGL((KERNEL<1>), grid, blk, 0, stream, __VA_ARGS__);        \
+        else if ((channels) == 3) hipLaunchKernelGGL((KERNEL<3>), grid, blk, 0, stream, __VA_ARGS__);   \
+        else hipLaunchKernelGGL((KERNEL<4>), grid, blk, 0, stream, __VA_ARGS__);                        \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+// quantize_kernel_256 (P/filter/ops.rs:748-760)
+void kh_quantize_kernel_256(const float* k, int32_t n, uint8_t* out) {
+    int sum = 0;
+    for (int i = 0; i < n; ++i) {
+        const float v = k[i] * 256.0f + 0.5f;
+        const int q = v <= 0.0f ? 0 : (v >= 255.0f ? 255 : (int)v);  // `as u8` saturates (NaN -> 0)
+        out[i] = (uint8_t)q;
+        sum += q;
+    }
+    if (n > 0 && sum != 256) {
+        const int c = (int)out[n / 2] + (256 - sum);
+        out[n / 2] = (uint8_t)(c < 0 ? 0 : (c > 255 ? 255 : c));
+    }
+}
+
+int32_t kh_gaussian_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t cols, int32_t rows,
+                            int32_t channels, int32_t ksize_x, int32_t ksize_y, float sigma_x, float sigma_y,
+                            int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    if (int32_t rc = check_u8_img("kh_gaussian_blur_u8", src, dst, cols, rows, cols, rows, channels, batch, src_stride, dst_stride))
+        return rc;
+    int32_t k[2] = {ksize_x, ksize_y};
+    float s[2] = {sigma_x, sigma_y};
+    KH_REQUIRE(kh_gaussian_resolve(k, s) == KH_OK, KH_ERR_INVALID_ARG,
+               "kh_gaussian_blur_u8: invalid kernel size (%d, %d) / sigma (%g, %g)", ksize_x, ksize_y, sigma_x, sigma_y);
+    KH_REQUIRE(k[0] <= 63 && k[1] <= 63, KH_ERR_UNSUPPORTED, "kh_gaussian_blur_u8: kernel (%d, %d) wider than 63 taps", k[0], k[1]);
+    KH_REQUIRE(src != dst || batch == 0, KH_ERR_INVALID_ARG, "kh_gaussian_blur_u8: in-place filtering is not supported");
+    if (batch == 0) return KH_OK;
+    // blur_u8_path (P/filter/ops.rs:21-27): the 3x3 / sigma in [0.6, 1.2] case is the [1,2,1]/4 binomial
+    const bool binomial = k[0] == 3 && k[1] == 3 && s[0] >= 0.6f && s[0] <= 1.2f && s[1] >= 0.6f && s[1] <= 1.2f;
+    float fx[64], fy[64];
+    uint8_t qx[64], qy[64];
+    kh_gaussian_kernel_1d(k[0], s[0], fx);
+    kh_gaussian_kernel_1d(k[1], s[1], fy);
+    kh_quantize_kernel_256(fx, k[0], qx);
+    kh_quantize_kernel_256(fy, k[1], qy);
+    return launch_blur_u8(stream, src, dst, cols, rows, channels, qx, k[0], qy, k[1], binomial, batch, src_stride,
+                          dst_stride, "kh_gaussian_blur_u8");
+}
+
+int32_t kh_box_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t cols, int32_t rows,
+                       int32_t channels, int32_t ksize_x, int32_t ksize_y, int32_t batch, int64_t src_stride,
+                       int64_t dst_stride) {
+    if (int32_t rc = check_u8_img("kh_box_blur_u8", src, dst, cols, rows, cols, rows, channels, batch, src_stride, dst_stride))
+        return rc;
+    // P/filter/ops.rs:66-75: odd, positive sizes only
+    KH_REQUIRE(ksize_x > 0 && ksize_y > 0 && (ksize_x & 1) && (ksize_y & 1), KH_ERR_INVALID_ARG,
+               "kh_box_blur_u8: kernel size (%d, %d) must be odd and positive", ksize_x, ksize_y);
+    KH_REQUIRE(ksize_x <= 63 && ksize_y <= 63, KH_ERR_UNSUPPORTED, "kh_box_blur_u8: kernel (%d, %d) wider than 63 taps", ksize_x, ksize_y);
+    KH_REQUIRE(src != dst || batch == 0, KH_ERR_INVALID_ARG, "kh_box_blur_u8: in-place filtering is not supported");
+    if (batch == 0) return KH_OK;
+    float fx[64], fy[64];
+    uint8_t qx[64], qy[64];
+    kh_box_blur_kernel_1d(ksize_x, fx);
+    kh_box_blur_kernel_1d(ksize_y, fy);
+    kh_quantize_kernel_256(fx, ksize_x, qx);
+    kh_quantize_kernel_256(fy, ksize_y, qy);
+    return launch_blur_u8(stream, src, dst, cols, rows, channels, qx, ksize_x, qy, ksize_y, false, batch, src_stride,
+                          dst_stride, "kh_box_blur_u8");
+}
+
+int32_t kh_remap_u8(kh_stream_t stream, const uint8_t* src, const float* map_x, const float* map_y, uint8_t* dst,
+                    int32_t sw, int32_t sh, int32_t dw, int32_t dh, int32_t channels, int32_t mode, int32_t batch,
+                    int64_t src_stride, int64_t dst_stride) {
+    if (int32_t rc = check_u8_img("kh_remap_u8", src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride)) return rc;
+    // P/interpolation/remap.rs:171-178: only nearest and bilinear exist for u8
+    KH_REQUIRE(mode == KH_INTERP_NEAREST || mode == KH_INTERP_BILINEAR, KH_ERR_UNSUPPORTED,
+               "kh_remap_u8: interpolation mode %d is not supported for u8 (nearest, bilinear)", mode);
+    if (batch == 0) return KH_OK;
+    KH_REQUIRE(map_x && map_y, KH_ERR_INVALID_ARG, "kh_remap_u8: null map pointer");
+    const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, (batch + kU8RemapNB - 1) / kU8RemapNB);
+    KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_remap_u8: batch x tiles exceeds one launch");
+    const dim3 blk(kBx, kBy), grid = xcd_grid(im.tiles);
+    hipStream_t st = as_hip(stream);
+    switch (channels * 10 + mode) {
+        case 10: hipLaunchKernelGGL((remap_u8_kernel<1, 0>), grid, blk, 0, st, im, map_x, map_y, batch); break;
+        case 11: hipLaunchKernelGGL((remap_u8_kernel<1, 1>), grid, blk, 0, st, im, map_x, map_y, batch); break;
+        case 30: hipLaunchKernelGGL((remap_u8_kernel<3, 0>), grid, blk, 0, st, im, map_x, map_y, batch); break;
+        case 31: hipLaunchKernelGGL((remap_u8_kernel<3, 1>), grid, blk, 0, st, im, map_x, map_y, batch); break;
+        case 40: hipLaunchKernelGGL((remap_u8_kernel<4, 0>), grid, blk, 0, st, im, map_x, map_y, batch); break;
+        default: hipLaunchKernelGGL((remap_u8_kernel<4, 1>), grid, blk, 0, st, im, map_x, map_y, batch); break;
+    }
+    return check_launch("kh_remap_u8");
+}
+
+int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t dw,
+                          int32_t dh, int32_t channels, const float* m, int32_t batch, int64_t src_stride,
+                          int64_t dst_stride) {
+    if (int32_t rc = check_u8_img("kh_warp_affine_u8", src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride))
+        return rc;
+    KH_REQUIRE(m, KH_ERR_INVALID_ARG, "kh_warp_affine_u8: null matrix");
+    if (batch == 0) return KH_OK;
+    Mat6 mi;
+    kh_invert_affine_transform(m, mi.m);
+    const int dsx_q = f2i_sat(mi.m[0] * 65536.0f), dsy_q = f2i_sat(mi.m[3] * 65536.0f);
+    const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
+    KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_affine_u8: batch x tiles exceeds one launch");
+    KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, mi, dsx_q, dsy_q);
+    return check_launch("kh_warp_affine_u8");
+}
+
+int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh,
+                               int32_t dw, int32_t dh, int32_t channels, const float* m, int32_t batch,
+                               int64_t src_stride, int64_t dst_stride) {
+    if (int32_t rc = check_u8_img("kh_warp_perspective_u8", src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride))
+        return rc;
+    KH_REQUIRE(m, KH_ERR_INVALID_ARG, "kh_warp_perspective_u8: null matrix");
+    Mat9 inv;
+    if (int32_t rc = kh_invert_homography(m, inv.m)) return rc;
+    if (batch == 0) return KH_OK;
+    const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
+    KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_perspective_u8: batch x tiles exceeds one launch");
+    KH_DISPATCH_C(warp_perspective_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, inv);
+    return check_launch("kh_warp_perspective_u8");
+}
+
+}  // extern "C"

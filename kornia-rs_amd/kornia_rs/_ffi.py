@@ -29,7 +29,7 @@ KH_SAMPLE_NEAREST, KH_SAMPLE_BILINEAR, KH_SAMPLE_LANCZOS = 0, 1, 2
 KH_OUT_F32, KH_OUT_F16 = 0, 1
 KH_PRE_FORCE_GENERIC = 1
 KH_YCC_YCRCB, KH_YCC_YUV = 0, 1
-KH_INTERP_NEAREST, KH_INTERP_BILINEAR, KH_INTERP_BICUBIC = 0, 1, 2
+KH_INTERP_NEAREST, KH_INTERP_BILINEAR, KH_INTERP_BICUBIC, KH_INTERP_LANCZOS = 0, 1, 2, 3
 KH_GRAD_SOBEL, KH_GRAD_SCHARR = 0, 1
 
 
@@ -123,6 +123,13 @@ SIGNATURES = {
     "kh_box_blur_kernel_1d": (_i32, [_i32, _P(_f32)]),
     "kh_gaussian_kernel_1d": (_i32, [_i32, _f32, _P(_f32)]),
     "kh_gaussian_resolve": (_i32, [_P(_i32), _P(_f32)]),
+    # u8 fixed-point twins
+    "kh_quantize_kernel_256": (None, [_P(_f32), _i32, _P(C.c_uint8)]),
+    "kh_gaussian_blur_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i64, _i64]),
+    "kh_box_blur_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_remap_u8": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_warp_affine_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i64, _i64]),
+    "kh_warp_perspective_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i64, _i64]),
     # pointwise
     "kh_normalize_mean_std_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _P(_f32), _P(_f32)]),
     "kh_normalize_rgb_u8_f32": (_i32, [_vp, _vp, _vp, _i64, _P(_f32), _P(_f32)]),

@@ -28,7 +28,7 @@ from .hip import DeviceBuffer, Stream
 from .image import Image, ImageError
 from .tensor import Tensor
 
-_INTERP = {"nearest": 0, "bilinear": 1, "bicubic": 2}
+_INTERP = {"nearest": 0, "bilinear": 1, "bicubic": 2, "lanczos": 3}
 
 
 def _check(rc: int) -> None:
@@ -240,17 +240,24 @@ def yuyv_from_rgb(src: Image) -> Tensor:
 def _interp(name: str) -> int:
     mode = _INTERP.get(str(name).lower())
     if mode is None:
-        raise ImageError("NoDeviceKernel", f"interpolation {name!r} has no device kernel (nearest, bilinear, bicubic)")
+        raise ImageError("NoDeviceKernel", f"interpolation {name!r} has no device kernel (nearest, bilinear, bicubic, lanczos)")
     return mode
 
 
-def _geom_pair(src: Image, dst: Optional[Image], new_size: Optional[Tuple[int, int]], what: str) -> Tuple[Image, Stream]:
-    _require(src, "float32", (1, 3, 4), what)
+def _geom_pair(src: Image, dst: Optional[Image], new_size: Optional[Tuple[int, int]], what: str,
+               dtype: str = "float32") -> Tuple[Image, Stream]:
+    _require(src, dtype, (1, 3, 4), what)
     if dst is None:
         h, w = new_size  # the Python API takes (height, width)
         dst = _new_like(src, size=(w, h))
-    _require(dst, "float32", (src.channels,), what)
+    _require(dst, dtype, (src.channels,), what)
     return dst, _pair_residency(src, dst)
+
+
+def _u8_bilinear_only(interpolation: str, what: str) -> None:
+    if str(interpolation).lower() != "bilinear":
+        raise ImageError("NoDeviceKernel", f"{what}: u8 images are sampled with the Q10 bilinear kernel only "
+                                           f"(got {interpolation!r}); convert to float32 for other modes")
 
 
 def resize(src: Image, new_size: Optional[Tuple[int, int]] = None, interpolation: str = "bilinear",
@@ -272,6 +279,12 @@ def _matrix(m: Sequence[float], n: int, what: str):
 
 def warp_affine(src: Image, m: Sequence[float], new_size: Optional[Tuple[int, int]] = None,
                 interpolation: str = "bilinear", out: Optional[Image] = None) -> Image:
+    if src.dtype == "uint8":  # warp_affine_u8, P/warp/affine.rs:373
+        _u8_bilinear_only(interpolation, "warp_affine")
+        dst, stream = _geom_pair(src, out, new_size, "warp_affine_u8", "uint8")
+        _check(lib.kh_warp_affine_u8(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
+                                     dst.height, src.channels, _matrix(m, 6, "warp_affine"), 1, 0, 0))
+        return dst
     mode = _interp(interpolation)
     dst, stream = _geom_pair(src, out, new_size, "warp_affine")
     _check(lib.kh_warp_affine_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
@@ -285,6 +298,12 @@ def warp_perspective(src: Image, m: Sequence[float], new_size: Optional[Tuple[in
     mm = _matrix(m, 9, "warp_perspective")
     inv = (C.c_float * 9)()
     _check(lib.kh_invert_homography(mm, inv))  # singular matrices are rejected before anything is allocated
+    if src.dtype == "uint8":  # warp_perspective_u8, P/warp/perspective.rs:179
+        _u8_bilinear_only(interpolation, "warp_perspective")
+        dst, stream = _geom_pair(src, out, new_size, "warp_perspective_u8", "uint8")
+        _check(lib.kh_warp_perspective_u8(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height,
+                                          dst.width, dst.height, src.channels, mm, 1, 0, 0))
+        return dst
     dst, stream = _geom_pair(src, out, new_size, "warp_perspective")
     _check(lib.kh_warp_perspective_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height,
                                        dst.width, dst.height, src.channels, mm, mode, 1, 0, 0))
@@ -297,7 +316,11 @@ def remap(src: Image, map_x: Image, map_y: Image, interpolation: str = "bilinear
         raise ImageError("InvalidImageSize", "map_x and map_y must have the same size")
     for mp in (map_x, map_y):
         _require(mp, "float32", (1,), "remap map")
-    dst, stream = _geom_pair(src, out, (map_x.height, map_x.width), "remap")
+    u8 = src.dtype == "uint8"  # remap_u8, P/interpolation/remap.rs:157: nearest | bilinear
+    if u8 and mode not in (_ffi.KH_INTERP_NEAREST, _ffi.KH_INTERP_BILINEAR):
+        raise ImageError("NoDeviceKernel", f"remap: u8 images support nearest and bilinear only (got {interpolation!r})")
+    dst, stream = _geom_pair(src, out, (map_x.height, map_x.width), "remap_u8" if u8 else "remap",
+                             "uint8" if u8 else "float32")
     if dst.size != map_x.size:
         raise ImageError("InvalidImageSize", "dst must have the size of the maps")
     if not (map_x.is_device and map_y.is_device):
@@ -305,8 +328,9 @@ def remap(src: Image, map_x: Image, map_y: Image, interpolation: str = "bilinear
     for mp in (map_x, map_y):
         if mp.stream is not None and mp.stream.cuda_stream_ptr != stream.cuda_stream_ptr:
             _check(lib.kh_stream_fence(mp.stream.cuda_stream_ptr, stream.cuda_stream_ptr))
-    _check(lib.kh_remap_f32(stream.cuda_stream_ptr, src.data_ptr, map_x.data_ptr, map_y.data_ptr, dst.data_ptr,
-                            src.width, src.height, dst.width, dst.height, src.channels, mode, 1, 0, 0))
+    fn = lib.kh_remap_u8 if u8 else lib.kh_remap_f32
+    _check(fn(stream.cuda_stream_ptr, src.data_ptr, map_x.data_ptr, map_y.data_ptr, dst.data_ptr,
+              src.width, src.height, dst.width, dst.height, src.channels, mode, 1, 0, 0))
     return dst
 
 
@@ -335,10 +359,10 @@ def invert_affine_transform(m: Sequence[float]):
 
 # ---- filters ----------------------------------------------------------------------------------------
 
-def _filter_pair(src: Image, dst: Optional[Image], what: str) -> Tuple[Image, Stream]:
-    _require(src, "float32", tuple(range(1, 9)), what)
+def _filter_pair(src: Image, dst: Optional[Image], what: str, dtype: str = "float32") -> Tuple[Image, Stream]:
+    _require(src, dtype, tuple(range(1, 9)) if dtype == "float32" else (1, 3, 4), what)
     out = dst if dst is not None else _new_like(src)
-    _require(out, "float32", (src.channels,), what)
+    _require(out, dtype, (src.channels,), what)
     _same_size(src, out)
     return out, _pair_residency(src, out)
 
@@ -348,6 +372,11 @@ def gaussian_blur(src: Image, kernel_size: Tuple[int, int], sigma: Tuple[float, 
     s = (C.c_float * 2)(*sigma)
     if lib.kh_gaussian_resolve(k, s) != _ffi.KH_OK:
         raise ImageError("InvalidSigmaValue", _ffi.last_error())
+    if src.dtype == "uint8":  # gaussian_blur_u8, P/filter/ops.rs:639
+        out, stream = _filter_pair(src, dst, "gaussian_blur_u8", "uint8")
+        _check(lib.kh_gaussian_blur_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
+                                       src.channels, kernel_size[0], kernel_size[1], sigma[0], sigma[1], 1, 0, 0))
+        return out
     out, stream = _filter_pair(src, dst, "gaussian_blur")
     _check(lib.kh_gaussian_blur_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
                                     src.channels, kernel_size[0], kernel_size[1], sigma[0], sigma[1], 1, 0, 0))
@@ -355,6 +384,13 @@ def gaussian_blur(src: Image, kernel_size: Tuple[int, int], sigma: Tuple[float, 
 
 
 def box_blur(src: Image, kernel_size: Tuple[int, int], dst: Optional[Image] = None) -> Image:
+    if src.dtype == "uint8":  # box_blur_u8, P/filter/ops.rs:59
+        if not all(int(k) > 0 and int(k) % 2 == 1 for k in kernel_size):
+            raise ImageError("InvalidKernelLength", f"box_blur: invalid kernel length {tuple(kernel_size)} (u8 needs odd sizes)")
+        out, stream = _filter_pair(src, dst, "box_blur_u8", "uint8")
+        _check(lib.kh_box_blur_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels,
+                                  kernel_size[0], kernel_size[1], 1, 0, 0))
+        return out
     out, stream = _filter_pair(src, dst, "box_blur")
     _check(lib.kh_box_blur_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels,
                                kernel_size[0], kernel_size[1], 1, 0, 0))
@@ -462,3 +498,21 @@ def horizontal_flip(src: Image, dst: Optional[Image] = None) -> Image:
 
 def vertical_flip(src: Image, dst: Optional[Image] = None) -> Image:
     return _flip(src, dst, 0)
+
+
+# Rust-API names of the u8 twins (P/warp/affine.rs:373, P/warp/perspective.rs:179,
+# P/interpolation/remap.rs:157, P/filter/ops.rs:59,639): same functions, dtype-dispatched above.
+def _u8_only(fn, name):
+    def wrapper(src: Image, *args, **kwargs):
+        if src.dtype != "uint8":
+            raise ImageError("NoDeviceKernel", f"{name}: expects a uint8 image, got {src.dtype}")
+        return fn(src, *args, **kwargs)
+    wrapper.__name__ = name
+    return wrapper
+
+
+warp_affine_u8 = _u8_only(warp_affine, "warp_affine_u8")
+warp_perspective_u8 = _u8_only(warp_perspective, "warp_perspective_u8")
+remap_u8 = _u8_only(remap, "remap_u8")
+gaussian_blur_u8 = _u8_only(gaussian_blur, "gaussian_blur_u8")
+box_blur_u8 = _u8_only(box_blur, "box_blur_u8")

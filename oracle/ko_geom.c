@@ -9,6 +9,7 @@
  * equal to the CPU result on the zero-initialised `dst` every reference test and example uses.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ko_oracle.h"
@@ -65,21 +66,149 @@ static inline float sample_bicubic(const float* img, int rows, int cols, int C, 
     return acc;
 }
 
+/* ---- Lanczos-3 (P/interpolation/lanczos.rs) ---------------------------------------------------- */
+#define KO_PI 3.14159265358979323846f /* std::f32::consts::PI */
+
+/* sin_pi, lanczos.rs:19-37: integer reduction + odd polynomial in plain mul/add */
+float ko_sin_pi(float x) {
+    float k = roundf(x);
+    float r = x - k;
+    float z = KO_PI * r;
+    float z2 = z * z;
+    float p = -2.5052108e-8f;
+    p = p * z2 + 2.7557319e-6f;
+    p = p * z2 + -1.984127e-4f;
+    p = p * z2 + 8.333334e-3f;
+    p = p * z2 + -1.6666667e-1f;
+    float s = z + z * z2 * p;
+    return ((int)k & 1) ? -s : s;
+}
+
+/* lanczos3, lanczos.rs:40-51 */
+float ko_lanczos3(float x) {
+    if (fabsf(x) < 1e-5f) return 1.0f;
+    if (fabsf(x) >= 3.0f) return 0.0f;
+    float pix = KO_PI * x;
+    float pix3 = pix * 0.33333334f;
+    return ko_sin_pi(x) * ko_sin_pi(x * (1.0f / 3.0f)) / (pix * pix3);
+}
+
+/* lanczos_axis, lanczos.rs:59-101: tap base + six normalised weights per destination index */
+void ko_lanczos_axis(int src_len, int dst_len, int32_t* x0s, float* weights) {
+    const float a = (float)src_len / (float)dst_len, b = 0.5f * a - 0.5f, max = (float)(src_len - 1);
+    for (int i = 0; i < dst_len; ++i) {
+        float s = a * (float)i + b;
+        s = s < 0.0f ? 0.0f : (s > max ? max : s);
+        float x0 = floorf(s), frac = s - x0;
+        x0s[i] = (int32_t)x0;
+        float w[6] = {ko_lanczos3(frac + 2.0f), ko_lanczos3(frac + 1.0f), ko_lanczos3(frac),
+                      ko_lanczos3(frac - 1.0f), ko_lanczos3(frac - 2.0f), ko_lanczos3(frac - 3.0f)};
+        float sum = w[0] + w[1] + w[2] + w[3] + w[4] + w[5];
+        float inv = 1.0f / sum;
+        for (int t = 0; t < 6; ++t) weights[i * 6 + t] = w[t] * inv;
+    }
+}
+
+/* lanczos3_weights, lanczos.rs:107-141: four sin_pi evaluations */
+static inline float lz_den(float x) {
+    float pix = KO_PI * x;
+    float pix3 = pix * 0.33333334f;
+    return pix * pix3;
+}
+void ko_lanczos3_weights(float frac, float w[6]) {
+    float s = ko_sin_pi(frac);
+    float t0 = ko_sin_pi(frac * (1.0f / 3.0f));
+    float t1 = ko_sin_pi((frac - 1.0f) * (1.0f / 3.0f));
+    float t2 = ko_sin_pi((frac - 2.0f) * (1.0f / 3.0f));
+    float st0 = s * t0, st1 = s * t1, st2 = s * t2;
+    w[0] = -st1 / lz_den(frac + 2.0f);
+    w[1] = st2 / lz_den(frac + 1.0f);
+    w[2] = st0 / lz_den(frac);
+    w[3] = -st1 / lz_den(frac - 1.0f);
+    w[4] = st2 / lz_den(frac - 2.0f);
+    w[5] = st0 / lz_den(frac - 3.0f);
+    if (frac < 1e-5f) w[2] = 1.0f;
+    if (fabsf(frac - 1.0f) < 1e-5f) w[3] = 1.0f;
+}
+
+/* lanczos_sample, lanczos.rs:143-187: per-axis normalisation, two-level fma accumulation */
+static inline float sample_lanczos(const float* img, int rows, int cols, int C, float sx, float sy, int c) {
+    float x0f = floorf(sx), y0f = floorf(sy);
+    float wx[6], wy[6];
+    ko_lanczos3_weights(sx - x0f, wx);
+    ko_lanczos3_weights(sy - y0f, wy);
+    long x0 = (long)x0f, y0 = (long)y0f;
+    float sum_wx = wx[0] + wx[1] + wx[2] + wx[3] + wx[4] + wx[5];
+    float sum_wy = wy[0] + wy[1] + wy[2] + wy[3] + wy[4] + wy[5];
+    float inv_x = 1.0f / sum_wx, inv_y = 1.0f / sum_wy;
+    for (int t = 0; t < 6; ++t) { wx[t] *= inv_x; wy[t] *= inv_y; }
+    float acc = 0.0f;
+    for (int dy = 0; dy < 6; ++dy) {
+        long yi = y0 + dy - 2; if (yi < 0) yi = 0; if (yi > rows - 1) yi = rows - 1;
+        float rx = 0.0f;
+        for (int dx = 0; dx < 6; ++dx) {
+            long xi = x0 + dx - 2; if (xi < 0) xi = 0; if (xi > cols - 1) xi = cols - 1;
+            rx = fmaf(wx[dx], img[((size_t)yi * cols + xi) * C + c], rx);
+        }
+        acc = fmaf(wy[dy], rx, acc);
+    }
+    return acc;
+}
+
 static inline float sample(int mode, const float* img, int rows, int cols, int C, float u, float v, int c) {
     switch (mode) {
         case 0: return sample_nearest(img, rows, cols, C, u, v, c);
         case 1: return sample_bilinear(img, rows, cols, C, u, v, c);
-        default: return sample_bicubic(img, rows, cols, C, u, v, c);
+        case 2: return sample_bicubic(img, rows, cols, C, u, v, c);
+        default: return sample_lanczos(img, rows, cols, C, u, v, c);
     }
+}
+
+/* resize_lanczos_separable, lanczos.rs:189-245: H pass into a dst_w x src_h f32 intermediate, then V */
+static void resize_lanczos_separable(const float* s, int sw, int sh, float* d, int dw, int dh, int C) {
+    int32_t* x0s = (int32_t*)malloc(sizeof(int32_t) * (size_t)(dw + dh));
+    int32_t* y0s = x0s + dw;
+    float* wx = (float*)malloc(sizeof(float) * 6 * (size_t)(dw + dh));
+    float* wy = wx + 6 * (size_t)dw;
+    ko_lanczos_axis(sw, dw, x0s, wx);
+    ko_lanczos_axis(sh, dh, y0s, wy);
+    float* inter = (float*)malloc(sizeof(float) * (size_t)dw * sh * C);
+#pragma omp parallel for schedule(static)
+    for (int sy = 0; sy < sh; ++sy)
+        for (int dx = 0; dx < dw; ++dx)
+            for (int k = 0; k < C; ++k) {
+                float acc = 0.0f;
+                for (int t = 0; t < 6; ++t) {
+                    long xi = (long)x0s[dx] + t - 2; if (xi < 0) xi = 0; if (xi > sw - 1) xi = sw - 1;
+                    acc = fmaf(wx[dx * 6 + t], s[((size_t)sy * sw + xi) * C + k], acc);
+                }
+                inter[((size_t)sy * dw + dx) * C + k] = acc;
+            }
+#pragma omp parallel for schedule(static)
+    for (int dy = 0; dy < dh; ++dy)
+        for (int dx = 0; dx < dw; ++dx)
+            for (int k = 0; k < C; ++k) {
+                float acc = 0.0f;
+                for (int t = 0; t < 6; ++t) {
+                    long yi = (long)y0s[dy] + t - 2; if (yi < 0) yi = 0; if (yi > sh - 1) yi = sh - 1;
+                    acc = fmaf(wy[dy * 6 + t], inter[((size_t)yi * dw + dx) * C + k], acc);
+                }
+                d[((size_t)dy * dw + dx) * C + k] = acc;
+            }
+    free(inter); free(wx); free(x0s);
 }
 
 /* ---- resize (P/resize/mod.rs:114-238) -------------------------------------------------------- */
 static inline float fclamp(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-/* mode: 0 nearest, 1 bilinear, 2 bicubic */
+/* mode: 0 nearest, 1 bilinear, 2 bicubic, 3 lanczos */
 void ko_resize_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int C, int mode) {
     if (sw == dw && sh == dh) { /* same-size short circuit, :134-137 */
         memcpy(dst, src, (size_t)sw * sh * C * sizeof(float));
+        return;
+    }
+    if (mode == 3) { /* :139-146 */
+        resize_lanczos_separable(src, sw, sh, dst, dw, dh, C);
         return;
     }
     const float ax = (float)sw / (float)dw, bx = 0.5f * ax - 0.5f;
@@ -132,8 +261,8 @@ void ko_warp_affine_f32(const float* src, int sw, int sh, float* dst, int dw, in
                 float w00 = (1.0f - fy) * (1.0f - fx), w10 = (1.0f - fy) * fx, w01 = fy * (1.0f - fx), w11 = fy * fx;
                 size_t b00 = (y0 * sw + x0) * C, b10 = (y0 * sw + x1) * C, b01 = (y1 * sw + x0) * C, b11 = (y1 * sw + x1) * C;
                 for (int c = 0; c < C; ++c) o[c] = w00 * src[b00 + c] + w10 * src[b10 + c] + w01 * src[b01 + c] + w11 * src[b11 + c];
-            } else {
-                for (int c = 0; c < C; ++c) o[c] = sample_bicubic(src, sh, sw, C, sx, sy, c);
+            } else { /* per-pixel samplers, :322-362 */
+                for (int c = 0; c < C; ++c) o[c] = sample(mode, src, sh, sw, C, sx, sy, c);
             }
         }
     }

@@ -106,6 +106,11 @@ int ko_gaussian_resolve(int k[2], float s[2]);
 void ko_separable_filter_f32(const float* src, float* dst, int cols, int rows, int C, const float* kx, int nx, const float* ky, int ny);
 void ko_gradient_magnitude_f32(const float* src, float* dst, int cols, int rows, int C, const float* kx, const float* ky, int n);
 
+float ko_sin_pi(float x);
+float ko_lanczos3(float x);
+void ko_lanczos3_weights(float frac, float w[6]);
+void ko_lanczos_axis(int src_len, int dst_len, int32_t* x0s, float* weights);
+
 /* ---- u8 fixed-point twins (ko_u8.c) ---------------------------------------------------------- */
 void ko_quantize_kernel_256(const float* k, int n, uint8_t* out);
 void ko_separable_blur_u8(const uint8_t* src, uint8_t* dst, int cols, int rows, int C, const uint8_t* kx, int nx, const uint8_t* ky, int ny);
@@ -114,6 +119,7 @@ int ko_gaussian_blur_u8(const uint8_t* src, uint8_t* dst, int cols, int rows, in
 int ko_box_blur_u8(const uint8_t* src, uint8_t* dst, int cols, int rows, int C, int kx, int ky);
 void ko_remap_u8(const uint8_t* src, int sw, int sh, const float* map_x, const float* map_y, uint8_t* dst, int dw, int dh, int C, int mode);
 void ko_warp_affine_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int C, const float m[6]);
+int ko_warp_perspective_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int C, const float m[9]);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,23 @@ void ko_remap_u8(const uint8_t* src, int sw, int sh, const float* map_x, const f
         }
 }
 
+/* Rust `f32 as i64`: saturating, NaN -> 0 */
+static inline long long f2ll(float v) {
+    if (v != v) return 0;
+    if (v >= 9223372036854775808.0f) return 9223372036854775807LL;
+    if (v <= -9223372036854775808.0f) return -9223372036854775807LL - 1;
+    return (long long)v;
+}
+static inline long long inc_sat(long long v) { return v == 9223372036854775807LL ? v : v + 1; }
+
+/* Rust `f32 as i32`: saturating, NaN -> 0 */
+static inline int f2i(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return -2147483647 - 1;
+    return (int)v;
+}
+
 /* constrain_span, span.rs:36-59 */
 static void constrain_span(float a, float b, int ge, float eps, long long* lo, long long* hi) {
     if (fabsf(a) < eps || a == 0.0f) {
@@ -152,10 +169,10 @@ static void constrain_span(float a, float b, int ge, float eps, long long* lo, l
         return;
     }
     float k = -b / a;
-    if (ge && a > 0.0f) { long long v = (long long)ceilf(k); if (v > *lo) *lo = v; }
-    else if (ge) { long long v = (long long)floorf(k) + 1; if (v < *hi) *hi = v; }
-    else if (a > 0.0f) { long long v = (long long)ceilf(k); if (v < *hi) *hi = v; }
-    else { long long v = (long long)floorf(k) + 1; if (v > *lo) *lo = v; }
+    if (ge && a > 0.0f) { long long v = f2ll(ceilf(k)); if (v > *lo) *lo = v; }
+    else if (ge) { long long v = inc_sat(f2ll(floorf(k))); if (v < *hi) *hi = v; }
+    else if (a > 0.0f) { long long v = f2ll(ceilf(k)); if (v < *hi) *hi = v; }
+    else { long long v = inc_sat(f2ll(floorf(k))); if (v > *lo) *lo = v; }
 }
 
 /* warp_affine_u8, affine.rs:373-445 (m = forward 2x3) */
@@ -163,7 +180,7 @@ void ko_warp_affine_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw,
     float mi[6];
     ko_invert_affine_transform(m, mi);
     const float dsx = mi[0], dsy = mi[3];
-    const int dsx_q = (int)(dsx * 65536.0f), dsy_q = (int)(dsy * 65536.0f);
+    const int dsx_q = f2i(dsx * 65536.0f), dsy_q = f2i(dsy * 65536.0f);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < dh; ++y) {
         uint8_t* row = dst + (size_t)y * dw * C;
@@ -181,7 +198,7 @@ void ko_warp_affine_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw,
         memset(row, 0, (size_t)lo_c * C);
         memset(row + (size_t)hi_c * C, 0, (size_t)(dw - hi_c) * C);
         if (lo_c >= hi_c) continue;
-        int sx_q = (int)((sx0 + dsx * (float)lo_c) * 65536.0f), sy_q = (int)((sy0 + dsy * (float)lo_c) * 65536.0f);
+        int sx_q = f2i((sx0 + dsx * (float)lo_c) * 65536.0f), sy_q = f2i((sy0 + dsy * (float)lo_c) * 65536.0f);
         for (long long x = lo_c; x < hi_c; ++x) { /* process_affine_span_scalar, kernels.rs:386-415 */
             /* the span guarantees in-range indices in exact arithmetic; clamp so Q16 drift can never
              * read out of bounds (a no-op whenever the reference itself is memory-safe) */
@@ -191,4 +208,54 @@ void ko_warp_affine_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw,
             sy_q = (int)((unsigned)sy_q + (unsigned)dsy_q);
         }
     }
+}
+
+/* bilinear_sample_u8, common.rs:16-70: bounds-checked, zeros when non-finite or outside */
+static inline void sample_q10_checked(const uint8_t* src, int sw, int sh, int C, float xf, float yf, uint8_t* o) {
+    if (!isfinite(xf) || !isfinite(yf)) { memset(o, 0, C); return; }
+    const float fxf = floorf(xf), fyf = floorf(yf);
+    const int xi = fxf >= 2147483648.0f ? 2147483647 : (fxf <= -2147483648.0f ? -2147483647 - 1 : (int)fxf);
+    const int yi = fyf >= 2147483648.0f ? 2147483647 : (fyf <= -2147483648.0f ? -2147483647 - 1 : (int)fyf);
+    if (xi < 0 || xi >= sw || yi < 0 || yi >= sh) { memset(o, 0, C); return; }
+    sample_q10(src, sw, sh, C, xi, yi, (unsigned)((xf - (float)xi) * 1024.0f), (unsigned)((yf - (float)yi) * 1024.0f), o);
+}
+
+/* warp_perspective_u8, perspective.rs:179-322 (m = forward 3x3).  Returns 0 if m is singular.
+ * Rows whose denominator keeps one sign get the analytic column span (zeros outside); inside the
+ * span the reference's edge pixels use the bounds-checked sampler and the interior the unchecked
+ * one — the two agree whenever the interior coordinate is in bounds, i.e. whenever the reference
+ * itself is memory-safe, so the checked sampler is used throughout. */
+int ko_warp_perspective_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int C, const float m[9]) {
+    float inv[9];
+    if (!ko_invert_homography(m, inv)) return 0;
+    const float swf = (float)sw, shf = (float)sh;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; ++y) {
+        uint8_t* row = dst + (size_t)y * dw * C;
+        const float yf = (float)y;
+        float nx0 = inv[1] * yf + inv[2], ny0 = inv[4] * yf + inv[5], nd0 = inv[7] * yf + inv[8];
+        float dnx = inv[0], dny = inv[3], dnd = inv[6];
+        const float nd_end = nd0 + dnd * ((float)dw - 1.0f);
+        const int pos = nd0 > 1e-6f && nd_end > 1e-6f, neg = nd0 < -1e-6f && nd_end < -1e-6f;
+        long long lo = 0, hi = dw;
+        if (pos || neg) {
+            if (neg) { nx0 = -nx0; ny0 = -ny0; nd0 = -nd0; dnx = -dnx; dny = -dny; dnd = -dnd; }
+            constrain_span(dnx, nx0, 1, 0.0f, &lo, &hi);
+            constrain_span(dnx - swf * dnd, nx0 - swf * nd0, 0, 0.0f, &lo, &hi);
+            constrain_span(dny, ny0, 1, 0.0f, &lo, &hi);
+            constrain_span(dny - shf * dnd, ny0 - shf * nd0, 0, 0.0f, &lo, &hi);
+            lo = lo < 0 ? 0 : (lo > dw ? dw : lo);
+            hi = hi < 0 ? 0 : (hi > dw ? dw : hi);
+            if (lo >= hi) { lo = 0; hi = 0; }
+        }
+        memset(row, 0, (size_t)lo * C);
+        memset(row + (size_t)hi * C, 0, (size_t)(dw - hi) * C);
+        for (long long x = lo; x < hi; ++x) { /* perspective_coord_at, kernels.rs:107-122 */
+            const float xf_ = (float)x;
+            const float nx = nx0 + dnx * xf_, ny = ny0 + dny * xf_, nd = nd0 + dnd * xf_;
+            const float inv_nd = 1.0f / nd;
+            sample_q10_checked(src, sw, sh, C, nx * inv_nd, ny * inv_nd, row + (size_t)x * C);
+        }
+    }
+    return 1;
 }

@@ -168,7 +168,7 @@ def color_map(name: str, src: np.ndarray, cout: int, *extra) -> np.ndarray:
 
 
 # ---- geometry + filters ---------------------------------------------------------------------------
-MODE = {"nearest": 0, "bilinear": 1, "bicubic": 2}
+MODE = {"nearest": 0, "bilinear": 1, "bicubic": 2, "lanczos": 3}
 _f6, _f9 = C.c_float * 6, C.c_float * 9
 ko.ko_resize_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]
 ko.ko_invert_affine_transform.argtypes = [C.POINTER(_f6), C.POINTER(_f6)]
@@ -292,4 +292,117 @@ def gradient_magnitude(src, kind, n):
     kx, ky = gradient_kernels(kind, n)
     out = np.empty_like(src)
     ko.ko_gradient_magnitude_f32(src.reshape(-1), out.reshape(-1), w, h, c, kx, ky, n)
+    return out
+
+
+# ---- Lanczos-3 helpers ------------------------------------------------------------------------------
+ko.ko_sin_pi.argtypes = [C.c_float]
+ko.ko_sin_pi.restype = C.c_float
+ko.ko_lanczos3.argtypes = [C.c_float]
+ko.ko_lanczos3.restype = C.c_float
+ko.ko_lanczos3_weights.argtypes = [C.c_float, C.POINTER(C.c_float * 6)]
+ko.ko_lanczos_axis.argtypes = [C.c_int, C.c_int, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), _f32p]
+
+
+def lanczos3_weights(frac):
+    w = (C.c_float * 6)()
+    ko.ko_lanczos3_weights(float(frac), C.byref(w))
+    return np.array(list(w), np.float32)
+
+
+def lanczos_axis(src_len, dst_len):
+    x0 = np.empty(dst_len, np.int32)
+    w = np.empty(dst_len * 6, np.float32)
+    ko.ko_lanczos_axis(src_len, dst_len, x0, w)
+    return x0, w.reshape(dst_len, 6)
+
+
+# ---- u8 fixed-point twins (ko_u8.c) --------------------------------------------------------------------
+ko.ko_quantize_kernel_256.argtypes = [_f32p, C.c_int, _u8p]
+ko.ko_separable_blur_u8.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]
+ko.ko_binomial3_u8.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+ko.ko_gaussian_blur_u8.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+ko.ko_box_blur_u8.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+ko.ko_remap_u8.argtypes = [_u8p, C.c_int, C.c_int, _f32p, _f32p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+ko.ko_warp_affine_u8.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(_f6)]
+ko.ko_warp_perspective_u8.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(_f9)]
+
+
+def _img8(a):
+    a = np.ascontiguousarray(a, np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return a
+
+
+def quantize_kernel_256(k):
+    k = np.ascontiguousarray(k, np.float32)
+    out = np.empty(k.size, np.uint8)
+    ko.ko_quantize_kernel_256(k, k.size, out)
+    return out
+
+
+def separable_blur_u8(src, qx, qy):
+    src = _img8(src)
+    h, w, c = src.shape
+    out = np.empty_like(src)
+    qx, qy = np.ascontiguousarray(qx, np.uint8), np.ascontiguousarray(qy, np.uint8)
+    ko.ko_separable_blur_u8(src.reshape(-1), out.reshape(-1), w, h, c, qx, qx.size, qy, qy.size)
+    return out
+
+
+def binomial3_u8(src):
+    src = _img8(src)
+    h, w, c = src.shape
+    out = np.empty_like(src)
+    ko.ko_binomial3_u8(src.reshape(-1), out.reshape(-1), w, h, c)
+    return out
+
+
+def gaussian_blur_u8(src, ksize, sigma):
+    """-> (image, path) with path 1 = binomial, 2 = general Q8; raises on invalid parameters."""
+    src = _img8(src)
+    h, w, c = src.shape
+    out = np.empty_like(src)
+    path = ko.ko_gaussian_blur_u8(src.reshape(-1), out.reshape(-1), w, h, c, ksize[0], ksize[1], sigma[0], sigma[1])
+    if path == 0:
+        raise ValueError("invalid gaussian parameters")
+    return out, path
+
+
+def box_blur_u8(src, ksize):
+    src = _img8(src)
+    h, w, c = src.shape
+    out = np.empty_like(src)
+    if not ko.ko_box_blur_u8(src.reshape(-1), out.reshape(-1), w, h, c, ksize[0], ksize[1]):
+        raise ValueError("invalid box kernel")
+    return out
+
+
+def remap_u8(src, map_x, map_y, mode="bilinear"):
+    src = _img8(src)
+    sh, sw, c = src.shape
+    map_x, map_y = np.ascontiguousarray(map_x, np.float32), np.ascontiguousarray(map_y, np.float32)
+    dh, dw = map_x.shape
+    out = np.empty((dh, dw, c), np.uint8)
+    ko.ko_remap_u8(src.reshape(-1), sw, sh, map_x.reshape(-1), map_y.reshape(-1), out.reshape(-1), dw, dh, c, MODE[mode])
+    return out
+
+
+def warp_affine_u8(src, m, dw, dh):
+    src = _img8(src)
+    sh, sw, c = src.shape
+    out = np.empty((dh, dw, c), np.uint8)
+    mm = _f6(*[float(v) for v in m])
+    ko.ko_warp_affine_u8(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, c, C.byref(mm))
+    return out
+
+
+def warp_perspective_u8(src, m, dw, dh):
+    src = _img8(src)
+    sh, sw, c = src.shape
+    out = np.empty((dh, dw, c), np.uint8)
+    mm = _f9(*[float(v) for v in m])
+    if not ko.ko_warp_perspective_u8(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, c, C.byref(mm)):
+        raise ValueError("singular homography")
     return out

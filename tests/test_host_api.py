@@ -53,8 +53,15 @@ def test_device_mismatch_and_unsupported_kernels():
         imgproc.hsv_from_rgb(fake_device_image(8, 8, 3, "uint8"))
     assert e.value.kind == "NoDeviceKernel"
     with pytest.raises(ImageError) as e:
-        imgproc.resize(fake_device_image(8, 8, 3), (4, 4), "lanczos")
+        imgproc.resize(fake_device_image(8, 8, 3), (4, 4), "area")
     assert e.value.kind == "NoDeviceKernel"
+    with pytest.raises(ImageError) as e:  # u8 warps have the Q10 bilinear kernel only
+        imgproc.warp_affine(fake_device_image(8, 8, 3, "uint8"), [1, 0, 0, 0, 1, 0], out=fake_device_image(8, 8, 3, "uint8"),
+                            interpolation="bicubic")
+    assert e.value.kind == "NoDeviceKernel"
+    with pytest.raises(ImageError) as e:  # box_blur_u8 rejects even kernels (P/filter/ops.rs:66-75)
+        imgproc.box_blur(fake_device_image(8, 8, 3, "uint8"), (4, 3), dst=fake_device_image(8, 8, 3, "uint8"))
+    assert e.value.kind == "InvalidKernelLength"
     with pytest.raises(ImageError) as e:  # singular homography rejected on the host, before any launch
         imgproc.warp_perspective(a, [1, 2, 3, 2, 4, 6, 3, 6, 9], out=fake_device_image(8, 8, 3))
     assert e.value.kind == "CannotComputeDeterminant"

@@ -126,3 +126,48 @@ def test_correction_map_identity_when_no_distortion():
     mx, my = O.correction_map((500.0, 500.0, 320.0, 240.0), (0,) * 8, 64, 48)
     xs, ys = np.meshgrid(np.arange(64, dtype=np.float32), np.arange(48, dtype=np.float32))
     assert np.abs(mx - xs).max() < 1e-4 and np.abs(my - ys).max() < 1e-4
+
+
+# ---- Lanczos-3 (P/interpolation/lanczos.rs) --------------------------------------------------------
+
+def test_lanczos_four_eval_weights_match_per_tap_form():  # lanczos.rs:252-281
+    for i in range(0, 10001, 7):
+        frac = np.float32(i) / np.float32(10001.0)
+        w = O.lanczos3_weights(frac)
+        per_tap = [O.ko.ko_lanczos3(float(np.float32(frac + d))) for d in (2.0, 1.0, 0.0, -1.0, -2.0, -3.0)]
+        assert np.abs(w - np.array(per_tap, np.float32)).max() < 1e-6, frac
+    w0 = O.lanczos3_weights(0.0)
+    assert w0[2] == 1.0 and w0[5] == 0.0
+
+
+def test_sin_pi_tracks_libm_and_is_exact_at_integers():
+    xs = np.linspace(-3.0, 3.0, 2001, dtype=np.float32)
+    got = np.array([O.ko.ko_sin_pi(float(x)) for x in xs], np.float32)
+    assert np.abs(got - np.sin(np.pi * xs.astype(np.float64))).max() < 5e-7
+    assert all(O.ko.ko_sin_pi(float(k)) == 0.0 for k in range(-3, 4))
+
+
+def test_lanczos_axis_tables_are_normalised_and_clamped():  # lanczos.rs:59-101
+    for src_len, dst_len in [(129, 64), (63, 127), (5, 5), (1, 4)]:
+        x0, w = O.lanczos_axis(src_len, dst_len)
+        assert x0.min() >= 0 and x0.max() <= src_len - 1
+        assert np.abs(w.sum(axis=1) - 1.0).max() < 1e-6
+    x0, w = O.lanczos_axis(5, 5)  # identity grid: frac == 0 -> delta weights
+    assert x0.tolist() == [0, 1, 2, 3, 4] and np.array_equal(w, np.tile(np.array([0, 0, 1, 0, 0, 0], np.float32), (5, 1)))
+
+
+def test_lanczos_resize_and_warps_reproduce_constants_and_identity():
+    img = np.full((9, 13, 3), 0.25, np.float32)
+    assert np.abs(O.resize(img, 15, 11, "lanczos") - 0.25).max() < 1e-6
+    src = O.pattern_f32(33 * 21 * 3).reshape(21, 33, 3)
+    assert np.array_equal(O.resize(src, 33, 21, "lanczos"), src)  # same-size short circuit, resize/mod.rs:134
+    ident = O.warp_perspective(src, [1, 0, 0, 0, 1, 0, 0, 0, 1], 33, 21, "lanczos")
+    assert np.abs(ident - src).max() < 1e-6
+    # resize == the two-pass definition written independently in numpy (f64 accumulate, loose tolerance)
+    x0, wx = O.lanczos_axis(33, 20)
+    y0, wy = O.lanczos_axis(21, 30)
+    xi = np.clip(x0[:, None] + np.arange(6) - 2, 0, 32)
+    yi = np.clip(y0[:, None] + np.arange(6) - 2, 0, 20)
+    inter = np.einsum("yxtc,xt->yxc", src[:, xi, :].astype(np.float64), wx)
+    want = np.einsum("ytxc,yt->yxc", inter[yi, :, :], wy)
+    assert np.abs(O.resize(src, 20, 30, "lanczos") - want).max() < 1e-5

@@ -1,0 +1,205 @@
+"""GPU parity for the u8 fixed-point twins: Q8 blur / binomial, Q10 remap, warp_affine_u8,
+warp_perspective_u8 — byte-exact against the CPU oracle.  Shapes and matrices follow the reference's
+device==host tests (P/filter/cuda.rs:282-330, P/warp/cuda.rs:174-300, P/interpolation/remap.rs:833-870)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from gpu_util import assert_same_bits, dev, fptr, out_buf
+from test_oracle_u8 import hash_image
+
+pytestmark = pytest.mark.gpu
+
+
+def pat(w, h, c, seed=0):
+    return np.roll(O.pattern_u8(w * h * c + seed), -seed)[: w * h * c].reshape(h, w, c).copy()
+
+
+def blur_gpu(gpu_stream, kind, src, ksize, sigma=None, batch=1):
+    from kornia_rs import _ffi
+    h, w, c = src.shape[-3:]
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, batch * h * w * c)
+    if kind == "gaussian":
+        rc = _ffi.lib.kh_gaussian_blur_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, w, h, c, ksize[0], ksize[1],
+                                          sigma[0], sigma[1], batch, h * w * c, h * w * c)
+    else:
+        rc = _ffi.lib.kh_box_blur_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, w, h, c, ksize[0], ksize[1], batch,
+                                     h * w * c, h * w * c)
+    if rc != 0:
+        return rc
+    return d_dst.to_numpy(np.uint8, (batch, h, w, c))
+
+
+GAUSS = [((3, 3), (1.0, 1.0)), ((3, 3), (0.5, 0.5)), ((5, 5), (1.0, 1.0)), ((7, 7), (2.0, 2.0)), ((7, 7), (1.5, 1.5)),
+         ((3, 7), (1.0, 2.0)), ((9, 5), (2.5, 1.2)), ((15, 15), (3.0, 3.0)), ((13, 11), (2.0, 4.0)), ((0, 0), (1.1, 0.0)),
+         ((17, 17), (3.0, 3.0)), ((5, 21), (1.0, 4.0))]
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("ksize,sigma", GAUSS)
+def test_gaussian_blur_u8_matches_oracle(gpu_stream, c, ksize, sigma):
+    for w, h in [(83, 37), (300, 41)]:
+        src = hash_image(h, w, c)
+        got = blur_gpu(gpu_stream, "gaussian", src, ksize, sigma)[0]
+        assert_same_bits(got, O.gaussian_blur_u8(src, ksize, sigma)[0], f"gaussian_u8 {ksize} {sigma} c{c} {w}x{h}")
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("ksize", [(3, 3), (5, 3), (1, 1), (7, 7), (15, 9), (31, 5)])
+def test_box_blur_u8_matches_oracle(gpu_stream, c, ksize):
+    src = hash_image(45, 131, c)
+    got = blur_gpu(gpu_stream, "box", src, ksize)[0]
+    assert_same_bits(got, O.box_blur_u8(src, ksize), f"box_u8 {ksize} c{c}")
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 5, 1), (5, 1, 1), (1, 1, 3), (2, 1, 3), (3, 2, 1), (4, 1, 1), (257, 3, 1),
+                                   (1024, 2, 1), (1025, 2, 3), (342, 5, 3), (85, 400, 3), (64, 33, 4), (1, 700, 4)])
+def test_blur_u8_edge_shapes(gpu_stream, shape):
+    """1-pixel axes, rows shorter than a dword (fallback kernel), widths around the 256/1024-byte
+    wave/tile boundaries, strips taller than the image."""
+    w, h, c = shape
+    src = pat(w, h, c, seed=7)
+    for ksize, sigma in [((3, 3), (1.0, 1.0)), ((7, 7), (2.0, 2.0)), ((15, 3), (3.0, 0.5))]:
+        got = blur_gpu(gpu_stream, "gaussian", src, ksize, sigma)[0]
+        assert_same_bits(got, O.gaussian_blur_u8(src, ksize, sigma)[0], f"{shape} {ksize}")
+
+
+def test_blur_u8_batch_4k_strip_and_errors(gpu_stream):
+    from kornia_rs import _ffi
+    n = 3
+    src = np.stack([pat(1920, 1080, 3, seed=31 * k) for k in range(n)])
+    got = blur_gpu(gpu_stream, "gaussian", src, (7, 7), (1.5, 1.5), batch=n)
+    for k in range(n):
+        assert_same_bits(got[k], O.gaussian_blur_u8(src[k], (7, 7), (1.5, 1.5))[0], f"frame {k}")
+    assert blur_gpu(gpu_stream, "box", src[0], (4, 3)) == _ffi.KH_ERR_INVALID_ARG
+    assert blur_gpu(gpu_stream, "gaussian", src[0], (4, 3), (1.0, 1.0)) == _ffi.KH_ERR_INVALID_ARG
+    assert blur_gpu(gpu_stream, "gaussian", pat(8, 8, 2), (3, 3), (1.0, 1.0)) == _ffi.KH_ERR_UNSUPPORTED
+
+
+def test_quantize_kernel_256_host_helper():
+    from kornia_rs import _ffi
+    for n, s in [(3, 0.85), (5, 1.0), (7, 2.0), (15, 3.0)]:
+        k = (C.c_float * n)()
+        _ffi.lib.kh_gaussian_kernel_1d(n, s, k)
+        q = (C.c_uint8 * n)()
+        _ffi.lib.kh_quantize_kernel_256(k, n, q)
+        assert list(q) == O.quantize_kernel_256(np.array(list(k), np.float32)).tolist()
+
+
+# ---- Q10 gathers ---------------------------------------------------------------------------------------
+
+def warp_u8_gpu(gpu_stream, kind, src, m, dw, dh, batch=1):
+    from kornia_rs import _ffi
+    h, w, c = src.shape[-3:]
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, batch * dh * dw * c)
+    rc = getattr(_ffi.lib, f"kh_warp_{kind}_u8")(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, w, h, dw, dh, c, fptr(m),
+                                                 batch, h * w * c, dh * dw * c)
+    if rc != 0:
+        return rc
+    return d_dst.to_numpy(np.uint8, (batch, dh, dw, c))
+
+
+def rotation(cx, cy, angle, scale):
+    from kornia_rs import _ffi
+    out = (C.c_float * 6)()
+    _ffi.lib.kh_get_rotation_matrix2d(cx, cy, angle, scale, out)
+    return list(out)
+
+
+AFFINES = {"flip": [-1.0, 0.0, 128.0, 0.0, 1.0, 0.0], "half": [1.0, 0.0, 0.5, 0.0, 1.0, 0.5], "identity": [1, 0, 0, 0, 1, 0],
+           "general": [0.9, 0.15, 10.0, -0.1, 1.1, -6.0], "vflip_shear": [1.0, 0.3, -5.0, 0.0, -1.0, 96.0],
+           "degenerate_x": [0.0, 1.0, 3.0, 1.0, 1e-13, 0.0], "zoom": [3.7, 0.0, -100.0, 0.0, 3.7, -80.0]}
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("name", list(AFFINES) + ["rot37", "rot90"])
+def test_warp_affine_u8_matches_oracle(gpu_stream, c, name):  # P/warp/cuda.rs:174-222
+    m = AFFINES.get(name) or {"rot37": rotation(64.0, 48.0, 37.0, 1.3), "rot90": rotation(64.0, 48.0, 90.0, 1.0)}[name]
+    for (w, h), (dw, dh) in [((129, 97), (129, 97)), ((33, 21), (33, 21)), ((129, 97), (80, 150))]:
+        src = pat(w, h, c)
+        got = warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0]
+        assert_same_bits(got, O.warp_affine_u8(src, m, dw, dh), f"affine_u8 {name} c{c} {w}x{h}->{dw}x{dh}")
+
+
+PROJ = [0.9, 0.12, 4.0, -0.08, 1.05, -2.0, 6.0e-4, -4.5e-4, 1.0]
+HOMOGRAPHIES = {"proj": PROJ, "affine_h": [1.1, 0.1, -3.0, -0.05, 0.95, 2.0, 0.0, 0.0, 1.0], "neg": [-v for v in PROJ],
+                "flip": [-1, 0, 128, 0, 1, 0, 0, 0, 1], "identity": [1, 0, 0, 0, 1, 0, 0, 0, 1],
+                "strong": [0.7, -0.2, 30.0, 0.25, 0.8, -10.0, 0.002, -0.001, 1.0],
+                "horizon": [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.02, 0.0, -1.0]}  # denominator changes sign inside rows
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("name", list(HOMOGRAPHIES))
+def test_warp_perspective_u8_matches_oracle(gpu_stream, c, name):  # P/warp/cuda.rs:224-300
+    m = HOMOGRAPHIES[name]
+    for w, h in [(129, 97), (33, 21)]:
+        src = pat(w, h, c)
+        got = warp_u8_gpu(gpu_stream, "perspective", src, m, w, h)[0]
+        assert_same_bits(got, O.warp_perspective_u8(src, m, w, h), f"perspective_u8 {name} c{c} {w}x{h}")
+
+
+def test_warp_u8_known_answers_batch_and_errors(gpu_stream):
+    from kornia_rs import _ffi
+    src = np.array([[10, 20, 30, 40], [50, 60, 70, 80]], np.uint8)[:, :, None]
+    flip = [-1, 0, 3, 0, 1, 0, 0, 0, 1]
+    assert warp_u8_gpu(gpu_stream, "perspective", src, flip, 4, 2)[0].reshape(-1).tolist() == [40, 30, 20, 10, 80, 70, 60, 50]
+    assert warp_u8_gpu(gpu_stream, "affine", src, flip[:6], 4, 2)[0].reshape(-1).tolist() == [40, 30, 20, 10, 80, 70, 60, 50]
+    rc = warp_u8_gpu(gpu_stream, "perspective", src, [1, 2, 3, 2, 4, 6, 3, 6, 9], 4, 2)
+    assert rc == _ffi.KH_ERR_SINGULAR
+    assert warp_u8_gpu(gpu_stream, "affine", pat(8, 8, 2), flip[:6], 8, 8) == _ffi.KH_ERR_UNSUPPORTED
+    n = 5
+    batch = np.stack([pat(640, 360, 3, seed=31 * k) for k in range(n)])
+    m = rotation(320.0, 180.0, 12.0, 0.9)
+    got = warp_u8_gpu(gpu_stream, "affine", batch, m, 640, 360, batch=n)
+    gotp = warp_u8_gpu(gpu_stream, "perspective", batch, PROJ, 640, 360, batch=n)
+    for k in range(n):
+        assert_same_bits(got[k], O.warp_affine_u8(batch[k], m, 640, 360), f"affine frame {k}")
+        assert_same_bits(gotp[k], O.warp_perspective_u8(batch[k], PROJ, 640, 360), f"perspective frame {k}")
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+def test_remap_u8_matches_oracle(gpu_stream, c, mode):  # P/interpolation/remap.rs:833-870
+    from kornia_rs import _ffi
+    w, h, dw, dh, n = 129, 97, 80, 60, 6  # 6 images: one full group of 4 + a partial one
+    src = np.stack([pat(w, h, c, seed=31 * k) for k in range(n)])
+    rng = np.random.default_rng(5)
+    xs, ys = np.meshgrid(np.arange(dw, dtype=np.float32), np.arange(dh, dtype=np.float32))
+    mx = (xs * np.float32(1.6) + rng.uniform(-2, 2, xs.shape).astype(np.float32)).astype(np.float32)
+    my = (ys * np.float32(1.6) + rng.uniform(-2, 2, ys.shape).astype(np.float32)).astype(np.float32)
+    mx[0, 0], my[1, 1], mx[2, 2], mx[3, 3], my[4, 4], mx[5, 5] = -0.25, 97.0, np.nan, 128.99, np.inf, 3.0e9
+    d_src, d_mx, d_my = dev(gpu_stream, src), dev(gpu_stream, mx), dev(gpu_stream, my)
+    d_dst = out_buf(gpu_stream, n * dh * dw * c)
+    _ffi.check(_ffi.lib.kh_remap_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_mx.ptr, d_my.ptr, d_dst.ptr, w, h, dw, dh, c,
+                                    O.MODE[mode], n, h * w * c, dh * dw * c))
+    got = d_dst.to_numpy(np.uint8, (n, dh, dw, c))
+    for k in range(n):
+        assert_same_bits(got[k], O.remap_u8(src[k], mx, my, mode), f"remap_u8 {mode} c{c} frame {k}")
+    rc = _ffi.lib.kh_remap_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_mx.ptr, d_my.ptr, d_dst.ptr, w, h, dw, dh, c,
+                              O.MODE["bicubic"], 1, 0, 0)
+    assert rc == _ffi.KH_ERR_UNSUPPORTED
+
+
+def test_remap_u8_known_answers_and_identity(gpu_stream):  # remap.rs:552-672
+    from kornia_rs import _ffi
+
+    def run(src, mx, my, mode):
+        h, w, c = src.shape
+        d_src, d_mx, d_my = dev(gpu_stream, src), dev(gpu_stream, mx), dev(gpu_stream, my)
+        d_dst = out_buf(gpu_stream, mx.size * c)
+        _ffi.check(_ffi.lib.kh_remap_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_mx.ptr, d_my.ptr, d_dst.ptr, w, h,
+                                        mx.shape[1], mx.shape[0], c, O.MODE[mode], 1, 0, 0))
+        return d_dst.to_numpy(np.uint8, mx.shape + (c,))
+
+    two = np.array([[0, 255]], np.uint8)[:, :, None]
+    assert run(two, np.array([[0.1]], np.float32), np.array([[0.0]], np.float32), "bilinear").reshape(-1).tolist() == [25]
+    sq = np.array([[10, 20], [30, 40]], np.uint8)[:, :, None]
+    mx = np.array([[0.49, 1.49], [-1.0, 0.5]], np.float32)
+    my = np.array([[0.49, 0.49], [0.5, 2.0]], np.float32)
+    assert run(sq, mx, my, "nearest").reshape(-1).tolist() == [10, 20, 0, 0]
+    img = pat(65, 33, 3)
+    xs, ys = np.meshgrid(np.arange(65, dtype=np.float32), np.arange(33, dtype=np.float32))
+    for mode in ("bilinear", "nearest"):
+        assert np.array_equal(run(img, xs, ys, mode), img)
