@@ -33,26 +33,42 @@ inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b);
 // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its
 // own L2, so a plain (x, y, image) grid puts tiles that share halo rows / columns on different L2s
 // and the shared lines are fetched from the fabric once per XCD (r01h PMC: +39 % on the 7x7 filter,
-// +47 % on warp_perspective).  XcdTiles hands XCD k the k-th contiguous eighth of the row-major
-// tile list of a 1-D launch, so neighbours run on the same L2 at about the same time.
-// KH_XCD_TILES=0 (dev knob) restores the plain order.
-struct XcdTiles { unsigned tiles_x, tiles_y, total, chunk; };
+// +47 % on warp_perspective).  XcdTiles cuts the row-major tile list into runs of `run` consecutive
+// tiles and deals the runs to the XCDs, so the tiles of a run — neighbours — execute on one L2 at
+// about the same time, while the 8 XCDs stay within 8 runs of each other in memory (handing each
+// XCD a contiguous eighth of the whole launch instead costs DRAM locality: resize 1080p->224 was
+// 13 % slower that way).  KH_XCD_TILES=0 (dev knob) restores the plain order.
+struct XcdTiles { unsigned tiles_x, tiles_y, total, run; };
 constexpr int kXcds = 8;
 inline bool xcd_tiles_enabled() {
     static const bool on = [] { const char* e = getenv("KH_XCD_TILES"); return !(e && e[0] == '0'); }();
     return on;
 }
-inline XcdTiles xcd_tiles(unsigned tiles_x, unsigned tiles_y, unsigned images) {
+inline XcdTiles xcd_tiles(unsigned tiles_x, unsigned tiles_y, unsigned images, unsigned run) {
     const uint64_t total = (uint64_t)tiles_x * tiles_y * images;
     XcdTiles t{tiles_x, tiles_y, (unsigned)total, 0};
-    if (total > 0x7fffff00ull) t.total = 0;  // caller rejects (KH_ERR_TOO_LARGE)
-    else if (xcd_tiles_enabled()) t.chunk = (unsigned)((total + kXcds - 1) / kXcds);
+    if (total > 0x7ff00000ull) t.total = 0;  // caller rejects (KH_ERR_TOO_LARGE)
+    else if (xcd_tiles_enabled()) {
+        // KH_XCD_RUN (dev knob): n > 0 = run length, -1 = one contiguous eighth of the launch per XCD
+        static const int env_run = [] { const char* e = getenv("KH_XCD_RUN"); return e && *e ? atoi(e) : 0; }();
+        if (env_run > 0) run = (unsigned)env_run;
+        if (env_run < 0) run = (unsigned)((total + kXcds - 1) / kXcds);
+        if (run > 1 && total > run) t.run = run;
+    }
     return t;
 }
-inline dim3 xcd_grid(const XcdTiles& t) { return dim3(t.chunk ? kXcds * t.chunk : t.total); }
+inline dim3 xcd_grid(const XcdTiles& t) {
+    if (!t.run) return dim3(t.total);
+    const unsigned group = kXcds * t.run;
+    return dim3((t.total + group - 1) / group * group);
+}
 __device__ __forceinline__ bool xcd_tile(const XcdTiles& t, unsigned& bx, unsigned& by, unsigned& bz) {
     const unsigned b = blockIdx.x;
-    const unsigned id = t.chunk ? (b % kXcds) * t.chunk + b / kXcds : b;
+    unsigned id = b;
+    if (t.run) {
+        const unsigned xcd = b % kXcds, slot = b / kXcds;
+        id = (slot / t.run * kXcds + xcd) * t.run + slot % t.run;
+    }
     if (id >= t.total) return false;
     const unsigned per_img = t.tiles_x * t.tiles_y, r = id % per_img;
     bz = id / per_img;

@@ -303,7 +303,7 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
             strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
             a.th = env_int("KH_FILTER_STRIP", (int)cdiv(rows, strips));
         }
-        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch);
+        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch, tiles_x);
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const dim3 grid = xcd_grid(a.tiles);
         hipStream_t st = as_hip(stream);
@@ -333,7 +333,7 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
                ky.n, C, bytes);
     if (rows < th) th = ((rows + kVR - 1) / kVR) * kVR;
     a.th = th;
-    a.tiles = xcd_tiles(cdiv(a.rowlen, kTF), cdiv(rows, th), (unsigned)batch);
+    a.tiles = xcd_tiles(cdiv(a.rowlen, kTF), cdiv(rows, th), (unsigned)batch, cdiv(a.rowlen, kTF) * 2);
     KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
     auto kern = grad ? sep_filter_kernel<true> : sep_filter_kernel<false>;
     const size_t in_h = th + 2 * vhalo;

@@ -397,7 +397,7 @@ int32_t check_img(const char* what, const void* src, const void* dst, int sw, in
 }
 
 Img make_img(const float* src, float* dst, int sw, int sh, int dw, int dh, int64_t ss, int64_t ds, int groups) {
-    return Img{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups)};
+    return Img{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups, cdiv(dw, kBx) * 8)};
 }
 #define KH_REQUIRE_TILES(what, im) \
     KH_REQUIRE((im).tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what)

@@ -241,7 +241,7 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         const long long min_strips = cdiv(rows, kU8StripMax), max_strips = cdiv(rows, 32);
         strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
         a.th = (int)cdiv(rows, strips);
-        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch);
+        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch, tiles_x);
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         switch (K) {
             case 3: launch_blur_k<3>(st, C, binomial, a, px, py); break;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kBx* kBy) void warp_perspective_u8_kernel(ImgU8 im,
 }
 
 ImgU8 make_img_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int64_t ss, int64_t ds, int groups) {
-    return ImgU8{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups)};
+    return ImgU8{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups, cdiv(dw, kBx) * 8)};
 }
 
 #define KH_DISPATCH_C(KERNEL, channels, grid, stream, ...)                                              \

@@ -121,6 +121,12 @@ void ko_remap_u8(const uint8_t* src, int sw, int sh, const float* map_x, const f
 void ko_warp_affine_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int C, const float m[6]);
 int ko_warp_perspective_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int C, const float m[9]);
 
+/* ---- u8 resize cascade + OpenCV-compatible resize (ko_resize_u8.c) -------------------------------- */
+int ko_resize_contribs(int src_size, int dst_size, int filt, int antialias, int32_t* offsets, int32_t* weights, int max_ksize);
+int ko_resize_fast_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int C, int mode, int antialias);
+int ko_resize_opencv_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int C, int mode);
+int ko_resize_opencv_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int C, int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -406,3 +406,46 @@ def warp_perspective_u8(src, m, dw, dh):
     if not ko.ko_warp_perspective_u8(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, c, C.byref(mm)):
         raise ValueError("singular homography")
     return out
+
+
+# ---- u8 resize cascade + OpenCV-compatible resize (ko_resize_u8.c) ---------------------------------------
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
+ko.ko_resize_contribs.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+ko.ko_resize_fast_u8.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+ko.ko_resize_opencv_u8.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+ko.ko_resize_opencv_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]
+RESIZE_U8_PATHS = {1: "pyrdown2x", 2: "pyrup2x", 3: "nearest", 4: "bilinear", 5: "separable"}
+
+
+def resize_contribs(src_size, dst_size, filt, antialias):
+    """filt: 'cubic' | 'lanczos3' -> (offsets[dst], weights[dst, ksize])"""
+    f = {"cubic": 0, "lanczos3": 1}[filt]
+    k = ko.ko_resize_contribs(src_size, dst_size, f, int(antialias), None, None, 0)
+    ofs, w = np.empty(dst_size, np.int32), np.empty(dst_size * k, np.int32)
+    ko.ko_resize_contribs(src_size, dst_size, f, int(antialias), ofs.ctypes.data, w.ctypes.data, k)
+    return ofs, w.reshape(dst_size, k)
+
+
+def resize_fast_u8(src, dw, dh, mode="bilinear", antialias=True):
+    """-> (image, path name); raises ValueError for the reference's typed errors."""
+    src = np.ascontiguousarray(src, np.uint8)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    sh, sw, c = src.shape
+    out = np.empty((dh, dw, c), np.uint8)
+    path = ko.ko_resize_fast_u8(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, c, MODE[mode], int(antialias))
+    if path == 0:
+        raise ValueError("unsupported channel count or source smaller than 2x2")
+    return out, RESIZE_U8_PATHS[path]
+
+
+def resize_opencv(src, dw, dh, mode="bilinear"):
+    src = np.ascontiguousarray(src)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    sh, sw, c = src.shape
+    out = np.empty((dh, dw, c), src.dtype)
+    fn = ko.ko_resize_opencv_u8 if src.dtype == np.uint8 else ko.ko_resize_opencv_f32
+    if not fn(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, c, MODE[mode]):
+        raise ValueError("unsupported interpolation")
+    return out
