@@ -321,6 +321,24 @@ KH_API int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, ui
                                       int32_t src_h, int32_t dst_w, int32_t dst_h, int32_t channels, const float* m3x3,
                                       int32_t batch, int64_t src_stride, int64_t dst_stride);
 
+/* u8 resize cascade — replaces resize_fast_u8_cuda (P/resize/cuda.rs:207-330, kernels
+ * P/cuda/resize_u8.rs) == resize_fast_u8_aa (P/resize/mod.rs:348): routed by the reference's single
+ * selector resize_u8_path (:283-340) — exact-2x RGB bilinear -> box / 75-25 fast paths, nearest (any
+ * channel count 1..4), Q14 bilinear (C in {1,3,4}, source >= 2x2 else KH_ERR_INVALID_ARG), bicubic /
+ * lanczos -> two-pass Q14 separable (antialias != 0 widens the kernel by the downscale factor, PIL
+ * semantics; 0 = fixed 4 / 6 taps, OpenCV semantics).  Strides in BYTES.                        */
+KH_API int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t src_w, int32_t src_h,
+                                 int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode, int32_t antialias,
+                                 int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* cv2.resize-compatible INTER_NEAREST / INTER_LINEAR == resize_opencv_{u8,f32}
+ * (P/resize/opencv_compat.rs:76-250; CPU-only in the reference).  Strides in ELEMENTS.           */
+KH_API int32_t kh_resize_opencv_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t src_w, int32_t src_h,
+                                   int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode, int32_t batch,
+                                   int64_t src_stride, int64_t dst_stride);
+KH_API int32_t kh_resize_opencv_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w, int32_t src_h,
+                                    int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode, int32_t batch,
+                                    int64_t src_stride, int64_t dst_stride);
+
 /* ------------------------------------------------------------------------------------------ */
 /* normalize / crop / flip (P/normalize.rs:56-420, P/crop.rs:187-240, P/flip.rs:39-360).  The
  * reference has no device twin for normalize; these follow its CPU arithmetic: true division

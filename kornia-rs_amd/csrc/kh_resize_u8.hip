@@ -1,0 +1,491 @@
+// u8 resize cascade (resize_fast_u8_aa) and the OpenCV-compatible resize for gfx950.
+//
+// Device twins of P/cuda/resize_u8.rs (adapters P/resize/cuda.rs:207-330); arithmetic and routing are
+// those of the CPU ops: resize_u8_path + resize_fast_u8_aa (P/resize/mod.rs:283-400), the exact-2x RGB
+// box / 75-25 paths (P/resize/pyramid.rs, P/resize/kernels.rs:62-74,166-183,272-281), nearest
+// (P/resize/nearest.rs:18-21), Q14 bilinear with f64 coordinates (P/resize/bilinear.rs:25-39,
+// P/resize/kernels.rs:1141-1165), Q14 separable bicubic / Lanczos-3 with optional antialias
+// (P/resize/common.rs:62-125, P/resize/kernels.rs:403-425,699-708), and resize_opencv_{u8,f32}
+// (P/resize/opencv_compat.rs:22-250; CPU-only in the reference).  Byte-identical results
+// (tests/test_resize_u8_gpu.py, incl. the reference's cv2 golden vectors).
+//
+// All gathers, one thread per destination pixel in 64x4 tiles.  Coordinates of the nearest / bilinear
+// / OpenCV paths are evaluated per thread in f64 exactly as the reference's host LUT builders do
+// (IEEE f64, no contraction), so no tables exist; the separable path's Q14 contribution tables need
+// libm `sin` in f64 and are therefore built on the HOST by the reference's algorithm, uploaded once
+// and cached per (src, dst, filter, antialias, device) — the reference's sync-before-publish rule
+// (P/resize/cuda.rs:151-190).
+#include <math.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "kh_common.h"
+
+using namespace kh;
+
+namespace {
+
+constexpr int kBx = 64, kBy = 4;
+
+struct Rz {
+    const uint8_t* src;
+    uint8_t* dst;
+    int sw, sh, dw, dh;
+    long long ss, ds;  // bytes between consecutive images
+    double scale_x, scale_y;
+    XcdTiles tiles;
+};
+
+#define KH_RZ_PROLOGUE                                          \
+    unsigned bx_, by_, bz_;                                     \
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;              \
+    const int x = bx_ * kBx + threadIdx.x;                      \
+    const int y = by_ * kBy + threadIdx.y;                      \
+    if (x >= a.dw || y >= a.dh) return;                         \
+    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss; \
+    uint8_t* __restrict__ dst = a.dst + (long long)bz_ * a.ds;
+
+// ---- exact-2x RGB -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBx* kBy) void pyrdown2x_rgb_kernel(Rz a) {
+    KH_RZ_PROLOGUE
+    const uint8_t* r0 = src + ((long long)(2 * y) * a.sw + 2 * x) * 3;
+    const uint8_t* r1 = r0 + (long long)a.sw * 3;
+    uint8_t* o = dst + ((long long)y * a.dw + x) * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) o[ch] = (uint8_t)(((uint32_t)r0[ch] + r0[3 + ch] + r1[ch] + r1[3 + ch] + 2u) >> 2);
+}
+
+__device__ __forceinline__ uint32_t rh(uint32_t p, uint32_t q) { return (p + q + 1u) >> 1; }
+// hinterp_row_rgb_u8 at output column X of one source row (P/resize/kernels.rs:166-183)
+__device__ __forceinline__ uint32_t hval(const uint8_t* row, int sw, int X, int ch) {
+    if (X == 0) return row[ch];
+    if (X == 2 * sw - 1) return row[(sw - 1) * 3 + ch];
+    const int j = (X - 1) >> 1;
+    const uint32_t p = row[j * 3 + ch], q = row[(j + 1) * 3 + ch], avg = rh(p, q);
+    return (X & 1) ? rh(p, avg) : rh(q, avg);
+}
+__global__ __launch_bounds__(kBx* kBy) void pyrup2x_rgb_kernel(Rz a) {
+    KH_RZ_PROLOGUE
+    uint8_t* o = dst + ((long long)y * a.dw + x) * 3;
+    const long long stride = (long long)a.sw * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        uint32_t v;
+        if (y == 0) v = hval(src, a.sw, x, ch);
+        else if (y == 2 * a.sh - 1) v = hval(src + (a.sh - 1) * stride, a.sw, x, ch);
+        else {
+            const int i = (y - 1) >> 1;  // rows 2i+1, 2i+2 blend source rows i and i+1
+            const uint32_t ha = hval(src + i * stride, a.sw, x, ch), hb = hval(src + (i + 1) * stride, a.sw, x, ch);
+            v = (y & 1) ? rh(ha, rh(ha, hb)) : rh(hb, rh(hb, ha));  // blend_75_25_row
+        }
+        o[ch] = (uint8_t)v;
+    }
+}
+
+// ---- nearest / bilinear -------------------------------------------------------------------------------
+__device__ __forceinline__ int nearest_index(int i, double scale, int src_len) {  // nearest.rs:18-21
+    const double v = floor(((double)i + 0.5) * scale);
+    return (int)fmin(fmax(v, 0.0), (double)(src_len - 1));
+}
+__device__ __forceinline__ void bilinear_tap(int i, double scale, int src_len, int& ofs, uint32_t& fq) {  // bilinear.rs:25-39
+    const double s = ((double)i + 0.5) * scale - 0.5;
+    const double fl = floor(s);
+    double f = s - fl;
+    long long i0 = (long long)fl;
+    if (i0 < 0) { i0 = 0; f = 0.0; }
+    else if (i0 >= (long long)src_len - 1) { i0 = (long long)src_len - 2; f = 1.0; }
+    const uint32_t q = (uint32_t)round(f * 16384.0);
+    ofs = (int)i0;
+    fq = q > 16384u ? 16384u : q;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void nearest_u8_kernel(Rz a) {
+    KH_RZ_PROLOGUE
+    const int sx = nearest_index(x, a.scale_x, a.sw), sy = nearest_index(y, a.scale_y, a.sh);
+    const uint8_t* p = src + ((long long)sy * a.sw + sx) * C;
+    uint8_t* o = dst + ((long long)y * a.dw + x) * C;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) o[ch] = p[ch];
+}
+
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void bilinear_u8_kernel(Rz a) {
+    KH_RZ_PROLOGUE
+    int xi, yi;
+    uint32_t fx, fy;
+    bilinear_tap(x, a.scale_x, a.sw, xi, fx);
+    bilinear_tap(y, a.scale_y, a.sh, yi, fy);
+    const uint64_t fx1 = 16384u - fx, fy1 = 16384u - fy;
+    const uint8_t* r0 = src + ((long long)yi * a.sw + xi) * C;
+    const uint8_t* r1 = r0 + (long long)a.sw * C;
+    uint8_t* o = dst + ((long long)y * a.dw + x) * C;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {  // bilinear_row_u8_scalar, kernels.rs:1141-1165 (u64 accumulate)
+        const uint64_t top = (uint64_t)r0[ch] * fx1 + (uint64_t)r0[C + ch] * fx;
+        const uint64_t bot = (uint64_t)r1[ch] * fx1 + (uint64_t)r1[C + ch] * fx;
+        o[ch] = (uint8_t)((top * fy1 + bot * fy + (1ull << 27)) >> 28);
+    }
+}
+
+// ---- separable Q14 ------------------------------------------------------------------------------------
+struct SepTab { const int32_t* ofs; const int16_t* w; int k; };
+
+// horizontal_row_scalar (kernels.rs:403-425): (x, source row) -> i16
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void sep_h_u8_kernel(Rz a, int16_t* __restrict__ hbuf, SepTab tx) {
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int x = bx_ * kBx + threadIdx.x, sy = by_ * kBy + threadIdx.y;
+    if (x >= a.dw || sy >= a.sh) return;
+    const uint8_t* __restrict__ row = a.src + (long long)bz_ * a.ss + (long long)sy * a.sw * C;
+    const int x0 = tx.ofs[x];
+    const int16_t* w = tx.w + (long long)x * tx.k;
+    int32_t acc[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) acc[ch] = 0;
+    for (int t = 0; t < tx.k; ++t) {
+        const int sx = min(max(x0 + t, 0), a.sw - 1);  // build_xsrc_lut, common.rs:127-137
+        const int32_t wt = w[t];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) acc[ch] += (int32_t)row[sx * C + ch] * wt;
+    }
+    int16_t* o = hbuf + (((long long)bz_ * a.sh + sy) * a.dw + x) * C;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) o[ch] = (int16_t)min(max((acc[ch] + 8192) >> 14, -32768), 32767);
+}
+
+// vertical_row_scalar (kernels.rs:699-708): thread = one flat i16 column of the intermediate
+__global__ __launch_bounds__(kBx* kBy) void sep_v_u8_kernel(Rz a, const int16_t* __restrict__ hbuf, SepTab ty, int hrow) {
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int i = bx_ * kBx + threadIdx.x, y = by_ * kBy + threadIdx.y;
+    if (i >= hrow || y >= a.dh) return;
+    const int16_t* __restrict__ h = hbuf + (long long)bz_ * a.sh * hrow + i;
+    const int y0 = ty.ofs[y];
+    const int16_t* w = ty.w + (long long)y * ty.k;
+    int32_t acc = 0;
+    for (int k = 0; k < ty.k; ++k) {
+        const int sy = min(max(y0 + k, 0), a.sh - 1);
+        acc += (int32_t)h[(long long)sy * hrow] * (int32_t)w[k];
+    }
+    a.dst[(long long)bz_ * a.ds + (long long)y * hrow + i] = (uint8_t)min(max((acc + 8192) >> 14, 0), 255);
+}
+
+// ---- OpenCV-compatible (opencv_compat.rs) -------------------------------------------------------------
+struct LinTap { int ofs; bool border; float w0, w1; int i0, i1; };
+__device__ __forceinline__ LinTap linear_tap(int d, double scale, int src_len) {  // linear_axis, :22-65
+    float fx = (float)(((double)d + 0.5) * scale - 0.5);
+    const float fl = floorf(fx);
+    long long sx = (long long)fl;
+    fx -= (float)sx;
+    LinTap t;
+    t.border = false;
+    if (sx < 0) { sx = 0; fx = 0.0f; }
+    if (sx >= (long long)src_len - 1) { sx = (long long)src_len - 1; fx = 0.0f; t.border = true; }
+    t.ofs = (int)sx;
+    t.w0 = 1.0f - fx;
+    t.w1 = fx;
+    t.i0 = (int)rintf((1.0f - fx) * 2048.0f);  // round_ties_even
+    t.i1 = (int)rintf(fx * 2048.0f);
+    return t;
+}
+__device__ __forceinline__ int cv_nearest_index(int i, double iscale, int src_len) {  // nearest_axis, :67-74
+    return (int)fmin(floor((double)i * iscale), (double)(src_len - 1));
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(kBx* kBy) void cv_nearest_kernel(Rz a) {
+    KH_RZ_PROLOGUE
+    const int sx = cv_nearest_index(x, a.scale_x, a.sw), sy = cv_nearest_index(y, a.scale_y, a.sh);
+    const T* p = reinterpret_cast<const T*>(src) + ((long long)sy * a.sw + sx) * C;
+    T* o = reinterpret_cast<T*>(dst) + ((long long)y * a.dw + x) * C;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) o[ch] = p[ch];
+}
+
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void cv_linear_u8_kernel(Rz a) {  // resize_linear_u8, :139-195
+    KH_RZ_PROLOGUE
+    const LinTap tx = linear_tap(x, a.scale_x, a.sw), ty = linear_tap(y, a.scale_y, a.sh);
+    const int sy1 = min(ty.ofs + 1, a.sh - 1);
+    const uint8_t* r0 = src + ((long long)ty.ofs * a.sw + tx.ofs) * C;
+    const uint8_t* r1 = src + ((long long)sy1 * a.sw + tx.ofs) * C;
+    uint8_t* o = dst + ((long long)y * a.dw + x) * C;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        int32_t s0, s1;
+        if (tx.border) { s0 = (int32_t)r0[k] << 11; s1 = (int32_t)r1[k] << 11; }
+        else { s0 = (int32_t)r0[k] * tx.i0 + (int32_t)r0[C + k] * tx.i1; s1 = (int32_t)r1[k] * tx.i0 + (int32_t)r1[C + k] * tx.i1; }
+        o[k] = (uint8_t)((((ty.i0 * (s0 >> 4)) >> 16) + ((ty.i1 * (s1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void cv_linear_f32_kernel(Rz a) {  // resize_linear_f32, :197-250
+    KH_RZ_PROLOGUE
+    const LinTap tx = linear_tap(x, a.scale_x, a.sw), ty = linear_tap(y, a.scale_y, a.sh);
+    const int sy1 = min(ty.ofs + 1, a.sh - 1);
+    const float* r0 = reinterpret_cast<const float*>(src) + ((long long)ty.ofs * a.sw + tx.ofs) * C;
+    const float* r1 = reinterpret_cast<const float*>(src) + ((long long)sy1 * a.sw + tx.ofs) * C;
+    float* o = reinterpret_cast<float*>(dst) + ((long long)y * a.dw + x) * C;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const float s0 = tx.border ? r0[k] : r0[k] * tx.w0 + r0[C + k] * tx.w1;
+        const float s1 = tx.border ? r1[k] : r1[k] * tx.w0 + r1[C + k] * tx.w1;
+        o[k] = s0 * ty.w0 + s1 * ty.w1;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+
+// FilterKind (common.rs:11-47): 0 = Cubic (a = -0.5), 1 = Lanczos3
+double filt_weight(int filt, double x) {
+    const double ax = fabs(x);
+    if (filt == 0) {
+        const double a = -0.5;
+        if (ax < 1.0) return (a + 2.0) * ax * ax * ax - (a + 3.0) * ax * ax + 1.0;
+        if (ax < 2.0) return a * ax * ax * ax - 5.0 * a * ax * ax + 8.0 * a * ax - 4.0 * a;
+        return 0.0;
+    }
+    if (ax < 1e-12) return 1.0;
+    if (ax < 3.0) {
+        const double px = 3.14159265358979323846 * x;
+        return 3.0 * sin(px) * sin(px / 3.0) / (px * px);
+    }
+    return 0.0;
+}
+
+// precompute_contribs (common.rs:62-125) + pack_xw_i16 (:141-143)
+int build_contribs(int src_size, int dst_size, int filt, bool antialias, std::vector<int32_t>& offsets,
+                   std::vector<int16_t>& weights) {
+    const double scale = (double)src_size / (double)dst_size;
+    const double filt_scale = antialias ? (scale > 1.0 ? scale : 1.0) : 1.0;
+    const double support = (filt == 0 ? 2.0 : 3.0) * filt_scale;
+    int ksize = (int)ceil(support) * 2;
+    if (ksize < 2) ksize = 2;
+    offsets.assign(dst_size, 0);
+    weights.assign((size_t)dst_size * ksize, 0);
+    std::vector<double> raw(ksize);
+    std::vector<int32_t> qw(ksize);
+    const double inv_filt_scale = 1.0 / filt_scale;
+    for (int i = 0; i < dst_size; ++i) {
+        const double center = ((double)i + 0.5) * scale - 0.5;
+        const long long left = (long long)ceil(center - support);
+        offsets[i] = (int32_t)left;
+        double sum = 0.0;
+        for (int k = 0; k < ksize; ++k) {
+            const double x = (double)(left + k) - center;
+            const double w = filt_weight(filt, x * inv_filt_scale) * inv_filt_scale;
+            raw[k] = w;
+            sum += w;
+        }
+        int qsum = 0;
+        const double norm = fabs(sum) > 1e-12 ? 16384.0 / sum : 0.0;
+        for (int k = 0; k < ksize; ++k) {
+            qw[k] = (int32_t)round(raw[k] * norm);
+            qsum += qw[k];
+        }
+        if (qsum != 16384) {
+            int max_k = 0, max_abs = 0;
+            for (int k = 0; k < ksize; ++k)
+                if (abs(qw[k]) > max_abs) { max_abs = abs(qw[k]); max_k = k; }
+            qw[max_k] += 16384 - qsum;
+        }
+        for (int k = 0; k < ksize; ++k) weights[(size_t)i * ksize + k] = (int16_t)qw[k];
+    }
+    return ksize;
+}
+
+// Contribution tables live on the device for the life of the process, keyed like the reference's
+// per-(device, geometry) cache.  A table is uploaded with a blocking copy into a fresh allocation
+// BEFORE it is published, so no stream ever observes a half-written table.
+struct TabEntry { void* dev = nullptr; int k = 0; int dst = 0; };
+std::mutex g_tab_mu;
+std::map<std::tuple<int, int, int, int, int>, TabEntry> g_tabs;
+
+int32_t get_tab(int src_size, int dst_size, int filt, bool aa, SepTab& out) {
+    int dev = 0;
+    KH_HIP(hipGetDevice(&dev));
+    const auto key = std::make_tuple(dev, src_size, dst_size, filt, (int)aa);
+    std::lock_guard<std::mutex> lock(g_tab_mu);
+    auto it = g_tabs.find(key);
+    if (it == g_tabs.end()) {
+        if (g_tabs.size() >= 256) {  // bounded: drop everything (hipFree waits for the device)
+            for (auto& kv : g_tabs) (void)hipFree(kv.second.dev);
+            g_tabs.clear();
+        }
+        std::vector<int32_t> ofs;
+        std::vector<int16_t> w;
+        TabEntry e;
+        e.k = build_contribs(src_size, dst_size, filt, aa, ofs, w);
+        e.dst = dst_size;
+        const size_t ofs_bytes = sizeof(int32_t) * ofs.size(), w_bytes = sizeof(int16_t) * w.size();
+        KH_HIP(hipMalloc(&e.dev, ofs_bytes + w_bytes));
+        hipError_t err = hipMemcpy(e.dev, ofs.data(), ofs_bytes, hipMemcpyHostToDevice);
+        if (err == hipSuccess) err = hipMemcpy((char*)e.dev + ofs_bytes, w.data(), w_bytes, hipMemcpyHostToDevice);
+        if (err != hipSuccess) {
+            (void)hipFree(e.dev);
+            return fail_hip(err, "hipMemcpy (resize contribution table)");
+        }
+        it = g_tabs.emplace(key, e).first;
+    }
+    out.ofs = (const int32_t*)it->second.dev;
+    out.w = (const int16_t*)((const char*)it->second.dev + sizeof(int32_t) * (size_t)it->second.dst);
+    out.k = it->second.k;
+    return KH_OK;
+}
+
+int32_t check_rz(const char* what, const void* src, const void* dst, int sw, int sh, int dw, int dh, int channels,
+                 int batch, int64_t ss, int64_t ds, int elem) {
+    KH_REQUIRE(sw > 0 && sh > 0 && dw > 0 && dh > 0, KH_ERR_INVALID_ARG, "%s: zero-sized image (src %dx%d, dst %dx%d)",
+               what, sw, sh, dw, dh);
+    KH_REQUIRE(channels >= 1 && channels <= 4, KH_ERR_UNSUPPORTED, "%s: no device kernel for %d channels (supported: 1..4)",
+               what, channels);
+    KH_REQUIRE(batch >= 0 && batch <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, batch);
+    KH_REQUIRE((int64_t)sw * sh * channels * elem <= kI32Max && (int64_t)dw * dh * channels * elem <= kI32Max &&
+                   (int64_t)dw * sh * channels * 2 <= kI32Max,
+               KH_ERR_TOO_LARGE, "%s: image exceeds 32-bit indexing", what);
+    KH_REQUIRE(ss >= 0 && ds >= 0, KH_ERR_INVALID_ARG, "%s: negative batch stride", what);
+    if (batch > 0) KH_REQUIRE(src && dst, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
+    return KH_OK;
+}
+
+Rz make_rz(const void* src, void* dst, int sw, int sh, int dw, int dh, int64_t ss, int64_t ds, int batch, int gw, int gh) {
+    Rz a;
+    a.src = (const uint8_t*)src; a.dst = (uint8_t*)dst;
+    a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh; a.ss = ss; a.ds = ds;
+    a.scale_x = (double)sw / (double)dw;
+    a.scale_y = (double)sh / (double)dh;
+    a.tiles = xcd_tiles(cdiv(gw, kBx), cdiv(gh, kBy), (unsigned)batch, cdiv(gw, kBx) * 8);
+    return a;
+}
+
+#define KH_RZ_LAUNCH_C(KERNEL, channels, a, st)                                                           \
+    do {                                                                                                  \
+        const dim3 blk(kBx, kBy), grid = xcd_grid((a).tiles);                                             \
+        switch (channels) {                                                                               \
+            case 1: hipLaunchKernelGGL((KERNEL<1>), grid, blk, 0, st, a); break;                          \
+            case 2: hipLaunchKernelGGL((KERNEL<2>), grid, blk, 0, st, a); break;                          \
+            case 3: hipLaunchKernelGGL((KERNEL<3>), grid, blk, 0, st, a); break;                          \
+            default: hipLaunchKernelGGL((KERNEL<4>), grid, blk, 0, st, a); break;                         \
+        }                                                                                                 \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t dw,
+                          int32_t dh, int32_t channels, int32_t mode, int32_t antialias, int32_t batch,
+                          int64_t src_stride, int64_t dst_stride) {
+    const char* what = "kh_resize_fast_u8";
+    if (int32_t rc = check_rz(what, src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, 1)) return rc;
+    KH_REQUIRE(mode >= KH_INTERP_NEAREST && mode <= KH_INTERP_LANCZOS, KH_ERR_UNSUPPORTED,
+               "%s: unknown interpolation mode %d", what, mode);
+    // resize_u8_path (P/resize/mod.rs:283-340): errors are decided before anything is launched
+    const bool down2 = mode == KH_INTERP_BILINEAR && channels == 3 && sw == dw * 2 && sh == dh * 2 && sw >= 2 && sh >= 2;
+    const bool up2 = mode == KH_INTERP_BILINEAR && channels == 3 && dw == sw * 2 && dh == sh * 2 && sw >= 2 && sh >= 2;
+    if (!down2 && !up2 && mode != KH_INTERP_NEAREST) {
+        KH_REQUIRE(channels == 1 || channels == 3 || channels == 4, KH_ERR_UNSUPPORTED,
+                   "%s: unsupported channel count %d (1, 3 or 4)", what, channels);
+        if (mode == KH_INTERP_BILINEAR)
+            KH_REQUIRE(sw >= 2 && sh >= 2, KH_ERR_INVALID_ARG, "%s: bilinear needs a source of at least 2x2 (got %dx%d)",
+                       what, sw, sh);
+    }
+    if (batch == 0) return KH_OK;
+    hipStream_t st = as_hip(stream);
+    Rz a = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, dw, dh);
+    KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+    const dim3 blk(kBx, kBy);
+    if (down2) {
+        hipLaunchKernelGGL(pyrdown2x_rgb_kernel, xcd_grid(a.tiles), blk, 0, st, a);
+    } else if (up2) {
+        hipLaunchKernelGGL(pyrup2x_rgb_kernel, xcd_grid(a.tiles), blk, 0, st, a);
+    } else if (mode == KH_INTERP_NEAREST) {
+        KH_RZ_LAUNCH_C(nearest_u8_kernel, channels, a, st);
+    } else if (mode == KH_INTERP_BILINEAR) {
+        KH_RZ_LAUNCH_C(bilinear_u8_kernel, channels, a, st);
+    } else {
+        const int filt = mode == KH_INTERP_BICUBIC ? 0 : 1;
+        SepTab tx, ty;
+        if (int32_t rc = get_tab(sw, dw, filt, antialias != 0, tx)) return rc;
+        if (int32_t rc = get_tab(sh, dh, filt, antialias != 0, ty)) return rc;
+        const int hrow = dw * channels;
+        int16_t* hbuf = nullptr;  // dst_w x src_h i16 intermediate, stream-ordered (P/resize/cuda.rs:262)
+        if (int32_t rc = kh_malloc_async((void**)&hbuf, sizeof(int16_t) * (size_t)hrow * sh * batch, 0, stream)) return rc;
+        Rz ah = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, dw, sh);
+        Rz av = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, hrow, dh);
+        if (ah.tiles.total == 0 || av.tiles.total == 0) {
+            (void)kh_free_async(hbuf, stream);
+            return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        }
+        switch (channels) {
+            case 1: hipLaunchKernelGGL(sep_h_u8_kernel<1>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
+            case 3: hipLaunchKernelGGL(sep_h_u8_kernel<3>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
+            default: hipLaunchKernelGGL(sep_h_u8_kernel<4>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
+        }
+        hipLaunchKernelGGL(sep_v_u8_kernel, xcd_grid(av.tiles), blk, 0, st, av, (const int16_t*)hbuf, ty, hrow);
+        const int32_t rc = check_launch(what);
+        (void)kh_free_async(hbuf, stream);
+        return rc;
+    }
+    return check_launch(what);
+}
+
+static int32_t resize_opencv(const char* what, kh_stream_t stream, const void* src, void* dst, int sw, int sh, int dw,
+                             int dh, int channels, int mode, int batch, int64_t ss, int64_t ds, int elem) {
+    if (int32_t rc = check_rz(what, src, dst, sw, sh, dw, dh, channels, batch, ss, ds, elem)) return rc;
+    // opencv_compat.rs:95-101: nearest and linear only
+    KH_REQUIRE(mode == KH_INTERP_NEAREST || mode == KH_INTERP_BILINEAR, KH_ERR_UNSUPPORTED,
+               "%s: unsupported interpolation mode %d (nearest, bilinear)", what, mode);
+    if (batch == 0) return KH_OK;
+    hipStream_t st = as_hip(stream);
+    Rz a = make_rz(src, dst, sw, sh, dw, dh, ss * elem, ds * elem, batch, dw, dh);
+    // linear_axis / nearest_axis use scale = 1 / (dst / src), not src / dst
+    a.scale_x = 1.0 / ((double)dw / (double)sw);
+    a.scale_y = 1.0 / ((double)dh / (double)sh);
+    KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+    const dim3 blk(kBx, kBy), grid = xcd_grid(a.tiles);
+    if (mode == KH_INTERP_NEAREST) {
+        if (elem == 1) {
+            switch (channels) {
+                case 1: hipLaunchKernelGGL((cv_nearest_kernel<uint8_t, 1>), grid, blk, 0, st, a); break;
+                case 2: hipLaunchKernelGGL((cv_nearest_kernel<uint8_t, 2>), grid, blk, 0, st, a); break;
+                case 3: hipLaunchKernelGGL((cv_nearest_kernel<uint8_t, 3>), grid, blk, 0, st, a); break;
+                default: hipLaunchKernelGGL((cv_nearest_kernel<uint8_t, 4>), grid, blk, 0, st, a); break;
+            }
+        } else {
+            switch (channels) {
+                case 1: hipLaunchKernelGGL((cv_nearest_kernel<float, 1>), grid, blk, 0, st, a); break;
+                case 2: hipLaunchKernelGGL((cv_nearest_kernel<float, 2>), grid, blk, 0, st, a); break;
+                case 3: hipLaunchKernelGGL((cv_nearest_kernel<float, 3>), grid, blk, 0, st, a); break;
+                default: hipLaunchKernelGGL((cv_nearest_kernel<float, 4>), grid, blk, 0, st, a); break;
+            }
+        }
+    } else if (elem == 1) {
+        KH_RZ_LAUNCH_C(cv_linear_u8_kernel, channels, a, st);
+    } else {
+        KH_RZ_LAUNCH_C(cv_linear_f32_kernel, channels, a, st);
+    }
+    return check_launch(what);
+}
+
+int32_t kh_resize_opencv_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t dw,
+                            int32_t dh, int32_t channels, int32_t mode, int32_t batch, int64_t src_stride,
+                            int64_t dst_stride) {
+    return resize_opencv("kh_resize_opencv_u8", stream, src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride,
+                         dst_stride, 1);
+}
+
+int32_t kh_resize_opencv_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw,
+                             int32_t dh, int32_t channels, int32_t mode, int32_t batch, int64_t src_stride,
+                             int64_t dst_stride) {
+    return resize_opencv("kh_resize_opencv_f32", stream, src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride,
+                         dst_stride, 4);
+}
+
+}  // extern "C"

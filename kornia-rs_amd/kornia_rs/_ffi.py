@@ -130,6 +130,9 @@ SIGNATURES = {
     "kh_remap_u8": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
     "kh_warp_affine_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i64, _i64]),
     "kh_warp_perspective_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i64, _i64]),
+    "kh_resize_fast_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_resize_opencv_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_resize_opencv_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
     # pointwise
     "kh_normalize_mean_std_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _P(_f32), _P(_f32)]),
     "kh_normalize_rgb_u8_f32": (_i32, [_vp, _vp, _vp, _i64, _P(_f32), _P(_f32)]),

@@ -262,7 +262,10 @@ def _u8_bilinear_only(interpolation: str, what: str) -> None:
 
 def resize(src: Image, new_size: Optional[Tuple[int, int]] = None, interpolation: str = "bilinear",
            out: Optional[Image] = None) -> Image:
-    """``new_size`` = (height, width) as in kornia_rs (imgproc.pyi:80-93)."""
+    """``new_size`` = (height, width) as in kornia_rs (imgproc.pyi:80-93).  uint8 images take the
+    antialiased u8 cascade (resize_fast_u8, P/resize/mod.rs:254), float32 the per-pixel resize."""
+    if src.dtype == "uint8":
+        return resize_fast(src, new_size, interpolation, True, out)
     mode = _interp(interpolation)
     dst, stream = _geom_pair(src, out, new_size, "resize")
     _check(lib.kh_resize_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
@@ -275,6 +278,47 @@ def _matrix(m: Sequence[float], n: int, what: str):
     if len(m) != n:
         raise ImageError("InvalidArgument", f"{what}: matrix needs {n} entries, got {len(m)}")
     return (C.c_float * n)(*m)
+
+
+def resize_fast(src: Image, new_size: Optional[Tuple[int, int]] = None, interpolation: str = "bilinear",
+                antialias: bool = True, out: Optional[Image] = None) -> Image:
+    """resize_fast_u8_aa (P/resize/mod.rs:348): exact-2x RGB fast paths, nearest, Q14 bilinear, Q14
+    separable bicubic / lanczos; ``antialias`` widens the separable kernels on downscale (PIL semantics)."""
+    mode = _interp(interpolation)
+    _require(src, "uint8", (1, 2, 3, 4), "resize_fast")
+    if out is None:
+        h, w = new_size
+        out = _new_like(src, size=(w, h))
+    _require(out, "uint8", (src.channels,), "resize_fast")
+    stream = _pair_residency(src, out)
+    if mode != _ffi.KH_INTERP_NEAREST and src.channels == 2:
+        raise ImageError("UnsupportedChannelCount", "resize_fast: 2-channel images support nearest only")
+    if mode == _ffi.KH_INTERP_BILINEAR and (src.width < 2 or src.height < 2):
+        raise ImageError("InvalidImageSize", f"resize_fast: bilinear needs a source of at least 2x2, got {src.width}x{src.height}")
+    _check(lib.kh_resize_fast_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, out.width,
+                                 out.height, src.channels, mode, int(bool(antialias)), 1, 0, 0))
+    return out
+
+
+def resize_opencv(src: Image, new_size: Optional[Tuple[int, int]] = None, interpolation: str = "bilinear",
+                  out: Optional[Image] = None) -> Image:
+    """cv2.resize-compatible nearest / bilinear for uint8 and float32 (resize_opencv_{u8,f32},
+    P/resize/opencv_compat.rs:76-112)."""
+    mode = _interp(interpolation)
+    if mode not in (_ffi.KH_INTERP_NEAREST, _ffi.KH_INTERP_BILINEAR):
+        raise ImageError("UnsupportedInterpolation", f"resize_opencv: {interpolation!r} (nearest, bilinear)")
+    if src.dtype not in ("uint8", "float32"):
+        raise ImageError("NoDeviceKernel", f"resize_opencv: no device kernel for {src.dtype}")
+    _require(src, src.dtype, (1, 2, 3, 4), "resize_opencv")
+    if out is None:
+        h, w = new_size
+        out = _new_like(src, size=(w, h))
+    _require(out, src.dtype, (src.channels,), "resize_opencv")
+    stream = _pair_residency(src, out)
+    fn = lib.kh_resize_opencv_u8 if src.dtype == "uint8" else lib.kh_resize_opencv_f32
+    _check(fn(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, out.width, out.height,
+              src.channels, mode, 1, 0, 0))
+    return out
 
 
 def warp_affine(src: Image, m: Sequence[float], new_size: Optional[Tuple[int, int]] = None,

@@ -1,0 +1,130 @@
+"""GPU parity for the u8 resize cascade (kh_resize_fast_u8) and the OpenCV-compatible resize
+(kh_resize_opencv_{u8,f32}): byte-exact against the CPU oracle on the reference's device==host shapes
+(P/resize/cuda.rs:386-470) and on the reference's cv2 golden vectors (tests/golden/opencv_resize)."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from gpu_util import assert_same_bits, dev, out_buf
+from test_oracle_resize_u8 import KEYS, corridor_ok, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def pat(w, h, c, seed=0):
+    return np.roll(O.pattern_u8(w * h * c + seed), -seed)[: w * h * c].reshape(h, w, c).copy()
+
+
+def resize_gpu(gpu_stream, src, dw, dh, mode, antialias=True, batch=1):
+    from kornia_rs import _ffi
+    h, w, c = src.shape[-3:]
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, batch * dh * dw * c)
+    rc = _ffi.lib.kh_resize_fast_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, w, h, dw, dh, c, O.MODE[mode],
+                                    int(antialias), batch, h * w * c, dh * dw * c)
+    if rc != 0:
+        return rc
+    return d_dst.to_numpy(np.uint8, (batch, dh, dw, c))
+
+
+def check(gpu_stream, s, d, c, mode, aa=True):
+    src = pat(s[0], s[1], c)
+    got = resize_gpu(gpu_stream, src, d[0], d[1], mode, aa)[0]
+    want, path = O.resize_fast_u8(src, d[0], d[1], mode, aa)
+    assert_same_bits(got, want, f"{s}->{d} c{c} {mode} aa={aa} ({path})")
+    return path
+
+
+def test_pyr2x_fast_paths(gpu_stream):  # cuda.rs:386-392
+    assert check(gpu_stream, (130, 98), (65, 49), 3, "bilinear") == "pyrdown2x"
+    assert check(gpu_stream, (65, 49), (130, 98), 3, "bilinear") == "pyrup2x"
+    for w, h in [(2, 2), (3, 4), (17, 9), (32, 5), (33, 6)]:  # mod.rs:593-645
+        assert check(gpu_stream, (w, h), (2 * w, 2 * h), 3, "bilinear") == "pyrup2x"
+        assert check(gpu_stream, (2 * w, 2 * h), (w, h), 3, "bilinear") == "pyrdown2x"
+    assert check(gpu_stream, (130, 98), (65, 49), 1, "bilinear") == "bilinear"  # RGB-only fast paths
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+def test_nearest(gpu_stream, c):  # cuda.rs:394-403
+    for s, d in [((129, 97), (64, 48)), ((63, 41), (127, 90)), ((1, 1), (5, 3)), ((7, 5), (1, 1))]:
+        assert check(gpu_stream, s, d, c, "nearest") == "nearest"
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_bilinear_q14(gpu_stream, c):  # cuda.rs:405-418
+    for s, d in [((129, 97), (64, 48)), ((63, 41), (127, 90)), ((33, 21), (33, 21)), ((2, 2), (9, 7)), ((1920, 1080), (224, 224))]:
+        assert check(gpu_stream, s, d, c, "bilinear") == "bilinear"
+
+
+@pytest.mark.parametrize("mode", ["bicubic", "lanczos"])
+@pytest.mark.parametrize("aa", [True, False])
+def test_separable_q14(gpu_stream, mode, aa):  # cuda.rs:420-440
+    for s, d, c in [((129, 97), (64, 48), 3), ((63, 41), (127, 90), 1), ((100, 80), (47, 33), 4), ((33, 21), (33, 21), 3),
+                    ((1, 1), (4, 4), 1), ((5, 1), (2, 3), 3)]:
+        assert check(gpu_stream, s, d, c, mode, aa) == "separable"
+
+
+def test_separable_extreme_downscale_and_batch(gpu_stream):  # cuda.rs:442-448
+    check(gpu_stream, (1024, 64), (50, 40), 3, "lanczos", True)
+    check(gpu_stream, (1024, 64), (50, 40), 3, "bicubic", True)
+    n = 5
+    src = np.stack([pat(640, 360, 3, seed=31 * k) for k in range(n)])
+    for mode in ("bicubic", "bilinear", "nearest"):
+        got = resize_gpu(gpu_stream, src, 224, 224, mode, True, batch=n)
+        for k in range(n):
+            assert_same_bits(got[k], O.resize_fast_u8(src[k], 224, 224, mode, True)[0], f"{mode} frame {k}")
+    got = resize_gpu(gpu_stream, src, 320, 180, "bilinear", True, batch=n)  # pyrdown in a batch
+    for k in range(n):
+        assert_same_bits(got[k], O.resize_fast_u8(src[k], 320, 180, "bilinear")[0], f"pyrdown frame {k}")
+    # second call with the same geometry hits the contribution-table cache
+    check(gpu_stream, (1024, 64), (50, 40), 3, "lanczos", True)
+
+
+def test_error_semantics(gpu_stream):  # cuda.rs:450-470, mod.rs:310-325
+    from kornia_rs import _ffi
+    assert resize_gpu(gpu_stream, pat(8, 8, 2), 4, 4, "bilinear") == _ffi.KH_ERR_UNSUPPORTED
+    assert resize_gpu(gpu_stream, pat(8, 8, 2), 4, 4, "bicubic") == _ffi.KH_ERR_UNSUPPORTED
+    assert resize_gpu(gpu_stream, pat(8, 1, 3), 4, 4, "bilinear") == _ffi.KH_ERR_INVALID_ARG
+    assert "2x2" in _ffi.last_error()
+    assert resize_gpu(gpu_stream, pat(8, 8, 3), 4, 0, "nearest") == _ffi.KH_ERR_INVALID_ARG
+
+
+# ---- OpenCV-compatible ---------------------------------------------------------------------------------
+
+def cv_gpu(gpu_stream, src, dw, dh, mode):
+    from kornia_rs import _ffi
+    h, w, c = src.shape
+    f32 = src.dtype == np.float32
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, dh * dw * c * (4 if f32 else 1))
+    fn = _ffi.lib.kh_resize_opencv_f32 if f32 else _ffi.lib.kh_resize_opencv_u8
+    rc = fn(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, w, h, dw, dh, c, O.MODE[mode], 1, 0, 0)
+    if rc != 0:
+        return rc
+    return d_dst.to_numpy(src.dtype, (dh, dw, c))
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_opencv_resize_golden_vectors(gpu_stream, key):
+    src, want, mode = load_case(key)
+    src = np.ascontiguousarray(src.astype(src.dtype.newbyteorder("=")))
+    got = cv_gpu(gpu_stream, src, want.shape[1], want.shape[0], mode)
+    assert_same_bits(got, O.resize_opencv(src, want.shape[1], want.shape[0], mode), key)  # bit-exact vs oracle
+    ok, d = corridor_ok(got, want, mode)                                                   # reference corridor vs cv2
+    assert ok, f"{key}: max deviation {d}"
+
+
+def test_opencv_resize_unit_vectors_and_channels(gpu_stream):  # opencv_compat.rs:253-330
+    from kornia_rs import _ffi
+    src = np.array([[0, 100, 200, 255], [0, 100, 200, 255]], np.uint8)[:, :, None]
+    assert cv_gpu(gpu_stream, src, 2, 1, "bilinear").reshape(-1).tolist() == [50, 228]
+    assert cv_gpu(gpu_stream, np.array([[10, 20, 30, 40]], np.uint8)[:, :, None], 2, 1, "nearest").reshape(-1).tolist() == [10, 30]
+    out = cv_gpu(gpu_stream, np.array([[0.125, 0.875]], np.float32)[:, :, None], 4, 1, "bilinear").reshape(-1)
+    assert out.tolist() == [0.125, np.float32(0.125 * 0.75 + 0.875 * 0.25), np.float32(0.125 * 0.25 + 0.875 * 0.75), 0.875]
+    assert cv_gpu(gpu_stream, src, 2, 2, "bicubic") == _ffi.KH_ERR_UNSUPPORTED
+    for c in (2, 4):
+        u8 = pat(37, 23, c)
+        f32 = O.pattern_f32(37 * 23 * c).reshape(23, 37, c)
+        for img in (u8, f32):
+            for mode in ("nearest", "bilinear"):
+                for dw, dh in [(11, 17), (80, 51), (37, 23)]:
+                    assert_same_bits(cv_gpu(gpu_stream, img, dw, dh, mode), O.resize_opencv(img, dw, dh, mode),
+                                     f"cv {img.dtype} c{c} {mode} {dw}x{dh}")
