@@ -35,9 +35,12 @@ inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b);
 // and the shared lines are fetched from the fabric once per XCD (r01h PMC: +39 % on the 7x7 filter,
 // +47 % on warp_perspective).  XcdTiles cuts the row-major tile list into runs of `run` consecutive
 // tiles and deals the runs to the XCDs, so the tiles of a run — neighbours — execute on one L2 at
-// about the same time, while the 8 XCDs stay within 8 runs of each other in memory (handing each
-// XCD a contiguous eighth of the whole launch instead costs DRAM locality: resize 1080p->224 was
-// 13 % slower that way).  KH_XCD_TILES=0 (dev knob) restores the plain order.
+// about the same time, while the 8 XCDs stay within 8 runs of each other in memory.  run =
+// kXcdEighth hands each XCD one contiguous eighth of the launch.  Measured (r01i/r01j, same box A/B):
+// the rolling filter gains 7 % from eighths (9.87 -> 9.17 ms on C4) and nothing from short runs; the
+// gathers are neutral with short runs and resize 1080p->224 LOSES 13 % with eighths, so gathers use
+// runs of 8 tile rows.  KH_XCD_TILES=0 (dev knob) restores the plain order.
+constexpr unsigned kXcdEighth = ~0u;
 struct XcdTiles { unsigned tiles_x, tiles_y, total, run; };
 constexpr int kXcds = 8;
 inline bool xcd_tiles_enabled() {
@@ -53,6 +56,7 @@ inline XcdTiles xcd_tiles(unsigned tiles_x, unsigned tiles_y, unsigned images, u
         static const int env_run = [] { const char* e = getenv("KH_XCD_RUN"); return e && *e ? atoi(e) : 0; }();
         if (env_run > 0) run = (unsigned)env_run;
         if (env_run < 0) run = (unsigned)((total + kXcds - 1) / kXcds);
+        if (run == kXcdEighth) run = (unsigned)((total + kXcds - 1) / kXcds);
         if (run > 1 && total > run) t.run = run;
     }
     return t;

@@ -303,7 +303,7 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
             strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
             a.th = env_int("KH_FILTER_STRIP", (int)cdiv(rows, strips));
         }
-        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch, tiles_x);
+        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch, kXcdEighth);
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const dim3 grid = xcd_grid(a.tiles);
         hipStream_t st = as_hip(stream);

@@ -241,7 +241,7 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         const long long min_strips = cdiv(rows, kU8StripMax), max_strips = cdiv(rows, 32);
         strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
         a.th = (int)cdiv(rows, strips);
-        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch, tiles_x);
+        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch, kXcdEighth);
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         switch (K) {
             case 3: launch_blur_k<3>(st, C, binomial, a, px, py); break;
