@@ -330,6 +330,17 @@ KH_API int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, ui
 KH_API int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t src_w, int32_t src_h,
                                  int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode, int32_t antialias,
                                  int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* Fused resize + normalise + HWC->CHW for RGB8 == resize_normalize_to_tensor_u8_to_f32{,_bilinear,
+ * _nearest,_separable} (P/resize/fused.rs:57,147,885,938; CPU-only in the reference — "the CPU timing
+ * twin" of the camera preprocess).  out[c] = sample * scale[c] + bias[c] with the pre-combined
+ * NormalizeParams (scale = 1/(std*255), bias = -mean/std; HOST pointers to 3 floats).  bilinear
+ * dispatches exact-2x downscales to the f32 box average like the reference (:172-174); bicubic /
+ * lanczos = Q14 horizontal pass, i32 vertical accumulate, no u8 requantisation.  dst = [3, dst_h,
+ * dst_w] f32 planes; src stride in BYTES, dst stride in ELEMENTS.                                */
+KH_API int32_t kh_resize_normalize_to_chw_u8_f32(kh_stream_t stream, const uint8_t* src, float* dst, int32_t src_w,
+                                                 int32_t src_h, int32_t dst_w, int32_t dst_h, const float* scale,
+                                                 const float* bias, int32_t mode, int32_t antialias, int32_t batch,
+                                                 int64_t src_stride, int64_t dst_stride);
 /* cv2.resize-compatible INTER_NEAREST / INTER_LINEAR == resize_opencv_{u8,f32}
  * (P/resize/opencv_compat.rs:76-250; CPU-only in the reference).  Strides in ELEMENTS.           */
 KH_API int32_t kh_resize_opencv_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t src_w, int32_t src_h,

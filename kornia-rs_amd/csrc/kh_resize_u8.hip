@@ -175,6 +175,72 @@ __global__ __launch_bounds__(kBx* kBy) void sep_v_u8_kernel(Rz a, const int16_t*
     a.dst[(long long)bz_ * a.ds + (long long)y * hrow + i] = (uint8_t)min(max((acc + 8192) >> 14, 0), 255);
 }
 
+// ---- fused RGB8 -> normalised CHW f32 (P/resize/fused.rs) ---------------------------------------------
+struct Norm3 { float scale[3], bias[3]; };
+
+// MODE 0 nearest (:885-936), 1 bilinear (:147-232 + blerp :285-289), 2 exact-2x box (:528-558)
+template <int MODE>
+__global__ __launch_bounds__(kBx* kBy) void fused_rgb_chw_kernel(Rz a, Norm3 n, float scale_xf, float scale_yf) {
+    KH_RZ_PROLOGUE
+    float* __restrict__ out = reinterpret_cast<float*>(a.dst) + (long long)bz_ * a.ds + (long long)y * a.dw + x;
+    (void)dst;
+    const long long plane = (long long)a.dw * a.dh;
+    float v[3];
+    if constexpr (MODE == 0) {
+        const uint8_t* p = src + ((long long)nearest_index(y, a.scale_y, a.sh) * a.sw + nearest_index(x, a.scale_x, a.sw)) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (float)p[c] * n.scale[c] + n.bias[c];
+    } else if constexpr (MODE == 2) {
+        const uint8_t* r0 = src + ((long long)(2 * y) * a.sw + 2 * x) * 3;
+        const uint8_t* r1 = r0 + (long long)a.sw * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t sum = (uint32_t)r0[c] + r0[3 + c] + r1[c] + r1[3 + c];
+            v[c] = (float)sum * (n.scale[c] * 0.25f) + n.bias[c];
+        }
+    } else {
+        const float fy = fmaxf(((float)y + 0.5f) * scale_yf - 0.5f, 0.0f);
+        const float fx = fmaxf(((float)x + 0.5f) * scale_xf - 0.5f, 0.0f);
+        const int y0 = min((int)fy, a.sh - 1), y1 = min(y0 + 1, a.sh - 1);
+        const int x0 = min((int)fx, a.sw - 1), x1 = min(x0 + 1, a.sw - 1);
+        const float wy = fy - (float)y0, w = fx - (float)x0;
+        const uint8_t* row0 = src + (long long)y0 * a.sw * 3;
+        const uint8_t* row1 = src + (long long)y1 * a.sw * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float p = row0[x0 * 3 + c], q = row0[x1 * 3 + c], r = row1[x0 * 3 + c], s = row1[x1 * 3 + c];
+            const float top = p + w * (q - p), bot = r + w * (s - r);
+            v[c] = (top + wy * (bot - top)) * n.scale[c] + n.bias[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c * plane] = v[c];
+}
+
+// vertical pass of the separable variant (:1003-1035): i32 accumulate, acc * (scale / 2^14) + bias
+__global__ __launch_bounds__(kBx* kBy) void fused_sep_v_kernel(Rz a, const int16_t* __restrict__ hbuf, SepTab ty, Norm3 n) {
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int x = bx_ * kBx + threadIdx.x, y = by_ * kBy + threadIdx.y;
+    if (x >= a.dw || y >= a.dh) return;
+    const int hrow = a.dw * 3;
+    const int16_t* __restrict__ h = hbuf + (long long)bz_ * a.sh * hrow + x * 3;
+    const int y0 = ty.ofs[y];
+    const int16_t* w = ty.w + (long long)y * ty.k;
+    int32_t acc[3] = {0, 0, 0};
+    for (int k = 0; k < ty.k; ++k) {
+        const int sy = min(max(y0 + k, 0), a.sh - 1);
+        const int32_t wt = w[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += (int32_t)h[(long long)sy * hrow + c] * wt;
+    }
+    float* out = reinterpret_cast<float*>(a.dst) + (long long)bz_ * a.ds + (long long)y * a.dw + x;
+    const long long plane = (long long)a.dw * a.dh;
+    const float inv_q = 1.0f / 16384.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c * plane] = (float)acc[c] * (n.scale[c] * inv_q) + n.bias[c];
+}
+
 // ---- OpenCV-compatible (opencv_compat.rs) -------------------------------------------------------------
 struct LinTap { int ofs; bool border; float w0, w1; int i0, i1; };
 __device__ __forceinline__ LinTap linear_tap(int d, double scale, int src_len) {  // linear_axis, :22-65
@@ -429,6 +495,49 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
             default: hipLaunchKernelGGL(sep_h_u8_kernel<4>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
         }
         hipLaunchKernelGGL(sep_v_u8_kernel, xcd_grid(av.tiles), blk, 0, st, av, (const int16_t*)hbuf, ty, hrow);
+        const int32_t rc = check_launch(what);
+        (void)kh_free_async(hbuf, stream);
+        return rc;
+    }
+    return check_launch(what);
+}
+
+int32_t kh_resize_normalize_to_chw_u8_f32(kh_stream_t stream, const uint8_t* src, float* dst, int32_t sw, int32_t sh,
+                                          int32_t dw, int32_t dh, const float* scale, const float* bias, int32_t mode,
+                                          int32_t antialias, int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    const char* what = "kh_resize_normalize_to_chw_u8_f32";
+    if (int32_t rc = check_rz(what, src, dst, sw, sh, dw, dh, 3, batch, src_stride, dst_stride, 1)) return rc;
+    KH_REQUIRE((int64_t)dw * dh * 3 <= kI32Max / 4, KH_ERR_TOO_LARGE, "%s: output exceeds 32-bit indexing", what);
+    KH_REQUIRE(scale && bias, KH_ERR_INVALID_ARG, "%s: null scale / bias", what);
+    KH_REQUIRE(mode >= KH_INTERP_NEAREST && mode <= KH_INTERP_LANCZOS, KH_ERR_UNSUPPORTED,
+               "%s: unknown interpolation mode %d", what, mode);
+    if (batch == 0) return KH_OK;
+    hipStream_t st = as_hip(stream);
+    Norm3 n;
+    for (int c = 0; c < 3; ++c) { n.scale[c] = scale[c]; n.bias[c] = bias[c]; }
+    Rz a = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, dw, dh);
+    KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+    const dim3 blk(kBx, kBy), grid = xcd_grid(a.tiles);
+    const float sxf = (float)sw / (float)dw, syf = (float)sh / (float)dh;
+    if (mode == KH_INTERP_NEAREST) {
+        hipLaunchKernelGGL(fused_rgb_chw_kernel<0>, grid, blk, 0, st, a, n, sxf, syf);
+    } else if (mode == KH_INTERP_BILINEAR) {
+        if (sw == 2 * dw && sh == 2 * dh) hipLaunchKernelGGL(fused_rgb_chw_kernel<2>, grid, blk, 0, st, a, n, sxf, syf);
+        else hipLaunchKernelGGL(fused_rgb_chw_kernel<1>, grid, blk, 0, st, a, n, sxf, syf);
+    } else {
+        const int filt = mode == KH_INTERP_BICUBIC ? 0 : 1;
+        SepTab tx, ty;
+        if (int32_t rc = get_tab(sw, dw, filt, antialias != 0, tx)) return rc;
+        if (int32_t rc = get_tab(sh, dh, filt, antialias != 0, ty)) return rc;
+        int16_t* hbuf = nullptr;
+        if (int32_t rc = kh_malloc_async((void**)&hbuf, sizeof(int16_t) * (size_t)dw * 3 * sh * batch, 0, stream)) return rc;
+        Rz ah = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, dw, sh);
+        if (ah.tiles.total == 0) {
+            (void)kh_free_async(hbuf, stream);
+            return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        }
+        hipLaunchKernelGGL(sep_h_u8_kernel<3>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx);
+        hipLaunchKernelGGL(fused_sep_v_kernel, grid, blk, 0, st, a, (const int16_t*)hbuf, ty, n);
         const int32_t rc = check_launch(what);
         (void)kh_free_async(hbuf, stream);
         return rc;

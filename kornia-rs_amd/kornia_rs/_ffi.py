@@ -131,6 +131,7 @@ SIGNATURES = {
     "kh_warp_affine_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i64, _i64]),
     "kh_warp_perspective_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i64, _i64]),
     "kh_resize_fast_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_resize_normalize_to_chw_u8_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _P(_f32), _P(_f32), _i32, _i32, _i32, _i64, _i64]),
     "kh_resize_opencv_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
     "kh_resize_opencv_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
     # pointwise

@@ -120,6 +120,11 @@ class Image:
             raise ImageError("UnsupportedDevice", "host access to device-resident image data; call .cpu() first")
         return self._t.numpy_raw().reshape(-1)
 
+    def resize_normalize_to_tensor(self, width: int, height: int, mean, std) -> Tensor:
+        """Fused bilinear resize + normalise + HWC->CHW (image.pyi:216-228); device images only here."""
+        from . import imgproc
+        return imgproc.resize_normalize_to_tensor(self, width, height, mean, std)
+
     @property
     def __cuda_array_interface__(self) -> dict:
         return self._t.__cuda_array_interface__

@@ -300,6 +300,38 @@ def resize_fast(src: Image, new_size: Optional[Tuple[int, int]] = None, interpol
     return out
 
 
+def normalize_params(mean: Sequence[float], std: Sequence[float]) -> Tuple[np.ndarray, np.ndarray]:
+    """NormalizeParams::from_mean_std (P/resize/fused.rs:29-38), f32 arithmetic:
+    scale = 1 / (std * 255), bias = -mean / std."""
+    m, s = np.asarray(mean, np.float32), np.asarray(std, np.float32)
+    if m.shape != (3,) or s.shape != (3,):
+        raise ImageError("InvalidChannelShape", "mean / std must have 3 entries")
+    return (np.float32(1.0) / (s * np.float32(255.0))).astype(np.float32), (-m / s).astype(np.float32)
+
+
+def resize_normalize_to_tensor(src: Image, width: int, height: int, mean: Sequence[float], std: Sequence[float],
+                               interpolation: str = "bilinear", antialias: bool = True,
+                               out: Optional[Tensor] = None) -> Tensor:
+    """Fused resize + per-channel normalise + HWC->CHW of an RGB8 image into a ``[3, height, width]``
+    float32 tensor: ``(x/255 - mean) / std`` (``Image.resize_normalize_to_tensor``, image.pyi:216;
+    resize_normalize_to_tensor_u8_to_f32{_bilinear,_nearest,_separable}, P/resize/fused.rs)."""
+    mode = _interp(interpolation)
+    _require(src, "uint8", (3,), "resize_normalize_to_tensor")
+    if not src.is_device:
+        raise ImageError("HostPathUnavailable", "host images: this build provides the HIP device backend only — move "
+                                                "the image with .to_hip(stream)")
+    scale, bias = normalize_params(mean, std)
+    if out is None:
+        out = Tensor.uninit((3, height, width), "float32", src.stream)
+    elif tuple(out.shape) != (3, height, width) or out.dtype != "float32" or not out.is_device:
+        raise ImageError("InvalidChannelShape", f"out must be a device float32 tensor of shape (3, {height}, {width})")
+    _check(lib.kh_resize_normalize_to_chw_u8_f32(
+        src.stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, width, height,
+        scale.ctypes.data_as(C.POINTER(C.c_float)), bias.ctypes.data_as(C.POINTER(C.c_float)), mode, int(bool(antialias)),
+        1, 0, 0))
+    return out
+
+
 def resize_opencv(src: Image, new_size: Optional[Tuple[int, int]] = None, interpolation: str = "bilinear",
                   out: Optional[Image] = None) -> Image:
     """cv2.resize-compatible nearest / bilinear for uint8 and float32 (resize_opencv_{u8,f32},

@@ -126,6 +126,9 @@ int ko_resize_contribs(int src_size, int dst_size, int filt, int antialias, int3
 int ko_resize_fast_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int C, int mode, int antialias);
 int ko_resize_opencv_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int C, int mode);
 int ko_resize_opencv_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int C, int mode);
+void ko_normalize_params(const float mean[3], const float std[3], float scale[3], float bias[3]);
+int ko_resize_normalize_to_chw(const uint8_t* src, int sw, int sh, float* dst, int dw, int dh, const float scale[3],
+                               const float bias[3], int mode, int antialias);
 
 #ifdef __cplusplus
 }

@@ -294,3 +294,111 @@ int ko_resize_opencv_f32(const float* src, int sw, int sh, float* dst, int dw, i
     }
     return 1;
 }
+
+/* ---- fused resize + normalize + HWC->CHW for RGB8 (P/resize/fused.rs) --------------------------------
+ * out = sample * scale[c] + bias[c] with NormalizeParams::from_mean_std (fused.rs:29-38):
+ * scale = 1/(std*255), bias = -mean/std.  The oracle is the SCALAR expression of each path (the
+ * reference's NEON/AVX2 rows use FMA and differ by <= 1 ulp, cf. SURVEY.md 8c caveat). */
+void ko_normalize_params(const float mean[3], const float std[3], float scale[3], float bias[3]) {
+    for (int c = 0; c < 3; ++c) {
+        scale[c] = 1.0f / (std[c] * 255.0f);
+        bias[c] = -mean[c] / std[c];
+    }
+}
+
+/* mode: 0 nearest (fused.rs:885-936), 1 bilinear incl. the exact-2x box dispatch (:147-232, :528-558,
+ * :273-320), 2 bicubic / 3 lanczos separable (:938-1040).  Returns the path: 1 box2x, 2 bilinear,
+ * 3 nearest, 4 separable. */
+int ko_resize_normalize_to_chw(const uint8_t* src, int sw, int sh, float* dst, int dw, int dh, const float scale[3],
+                               const float bias[3], int mode, int antialias) {
+    const size_t plane = (size_t)dw * dh;
+    if (mode == 1 && sw == 2 * dw && sh == 2 * dh) { /* fused_row_scalar */
+        const float s[3] = {scale[0] * 0.25f, scale[1] * 0.25f, scale[2] * 0.25f};
+#pragma omp parallel for schedule(static)
+        for (int y = 0; y < dh; ++y) {
+            const uint8_t *r0 = src + (size_t)(2 * y) * sw * 3, *r1 = r0 + (size_t)sw * 3;
+            for (int x = 0; x < dw; ++x)
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t sum = (uint32_t)r0[6 * x + c] + r0[6 * x + 3 + c] + r1[6 * x + c] + r1[6 * x + 3 + c];
+                    dst[c * plane + (size_t)y * dw + x] = (float)sum * s[c] + bias[c];
+                }
+        }
+        return 1;
+    }
+    if (mode == 1) {
+        const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+#pragma omp parallel for schedule(static)
+        for (int y = 0; y < dh; ++y) {
+            float fy = ((float)y + 0.5f) * scale_y - 0.5f;
+            fy = fy > 0.0f ? fy : 0.0f; /* .max(0.0) */
+            int y0 = (int)fy; if (y0 > sh - 1) y0 = sh - 1;
+            const int y1 = y0 + 1 < sh - 1 ? y0 + 1 : sh - 1;
+            const float wy = fy - (float)y0;
+            const uint8_t *row0 = src + (size_t)y0 * sw * 3, *row1 = src + (size_t)y1 * sw * 3;
+            for (int x = 0; x < dw; ++x) {
+                float fx = ((float)x + 0.5f) * scale_x - 0.5f;
+                fx = fx > 0.0f ? fx : 0.0f;
+                int x0 = (int)fx; if (x0 > sw - 1) x0 = sw - 1;
+                const int x1 = x0 + 1 < sw - 1 ? x0 + 1 : sw - 1;
+                const float w = fx - (float)x0;
+                for (int c = 0; c < 3; ++c) { /* blerp, :285-289 */
+                    const float a = row0[x0 * 3 + c], b = row0[x1 * 3 + c], cc = row1[x0 * 3 + c], d = row1[x1 * 3 + c];
+                    const float top = a + w * (b - a), bot = cc + w * (d - cc);
+                    const float v = top + wy * (bot - top);
+                    dst[c * plane + (size_t)y * dw + x] = v * scale[c] + bias[c];
+                }
+            }
+        }
+        return 2;
+    }
+    if (mode == 0) {
+        const double sx = (double)sw / (double)dw, sy = (double)sh / (double)dh;
+#pragma omp parallel for schedule(static)
+        for (int y = 0; y < dh; ++y) {
+            const uint8_t* srow = src + (size_t)nearest_index(y, sy, sh) * sw * 3;
+            for (int x = 0; x < dw; ++x) {
+                const int o = nearest_index(x, sx, sw) * 3;
+                for (int c = 0; c < 3; ++c) dst[c * plane + (size_t)y * dw + x] = (float)srow[o + c] * scale[c] + bias[c];
+            }
+        }
+        return 3;
+    }
+    /* separable: Q14 horizontal pass to i16 as in resize_separable_u8, vertical pass accumulates i32 and
+     * emits acc * (scale / 2^14) + bias without rounding back to u8 */
+    const int filt = mode == 2 ? 0 : 1;
+    const int kx = ko_resize_contribs(sw, dw, filt, antialias, NULL, NULL, 0);
+    const int ky = ko_resize_contribs(sh, dh, filt, antialias, NULL, NULL, 0);
+    int32_t *xofs = (int32_t*)malloc(sizeof(int32_t) * (size_t)dw), *xw = (int32_t*)malloc(sizeof(int32_t) * (size_t)dw * kx);
+    int32_t *yofs = (int32_t*)malloc(sizeof(int32_t) * (size_t)dh), *yw = (int32_t*)malloc(sizeof(int32_t) * (size_t)dh * ky);
+    ko_resize_contribs(sw, dw, filt, antialias, xofs, xw, kx);
+    ko_resize_contribs(sh, dh, filt, antialias, yofs, yw, ky);
+    const size_t hrow = (size_t)dw * 3;
+    int16_t* hbuf = (int16_t*)malloc(sizeof(int16_t) * hrow * sh);
+#pragma omp parallel for schedule(static)
+    for (int sy = 0; sy < sh; ++sy)
+        for (int x = 0; x < dw; ++x)
+            for (int ch = 0; ch < 3; ++ch) {
+                int32_t acc = 0;
+                for (int t = 0; t < kx; ++t) {
+                    const int sx = (int)llclamp((long long)xofs[x] + t, 0, sw - 1);
+                    acc += (int32_t)src[((size_t)sy * sw + sx) * 3 + ch] * (int32_t)(int16_t)xw[(size_t)x * kx + t];
+                }
+                int32_t v = (acc + 8192) >> 14;
+                hbuf[(size_t)sy * hrow + (size_t)x * 3 + ch] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+            }
+    const float inv_q = 1.0f / 16384.0f;
+    const float s[3] = {scale[0] * inv_q, scale[1] * inv_q, scale[2] * inv_q};
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x)
+            for (int c = 0; c < 3; ++c) {
+                int32_t acc = 0;
+                for (int k = 0; k < ky; ++k) {
+                    const int sy = (int)llclamp((long long)yofs[y] + k, 0, sh - 1);
+                    acc += (int32_t)hbuf[(size_t)sy * hrow + (size_t)x * 3 + c] * yw[(size_t)y * ky + k]; /* i32 weight here */
+                }
+                dst[c * plane + (size_t)y * dw + x] = (float)acc * s[c] + bias[c];
+            }
+    free(hbuf); free(xofs); free(xw); free(yofs); free(yw);
+    return 4;
+}

@@ -449,3 +449,28 @@ def resize_opencv(src, dw, dh, mode="bilinear"):
     if not fn(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, c, MODE[mode]):
         raise ValueError("unsupported interpolation")
     return out
+
+
+# ---- fused RGB8 -> normalised CHW (P/resize/fused.rs) -------------------------------------------------------
+_f3 = C.c_float * 3
+ko.ko_normalize_params.argtypes = [C.POINTER(_f3), C.POINTER(_f3), C.POINTER(_f3), C.POINTER(_f3)]
+ko.ko_resize_normalize_to_chw.argtypes = [_u8p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.POINTER(_f3), C.POINTER(_f3),
+                                          C.c_int, C.c_int]
+FUSED_PATHS = {1: "box2x", 2: "bilinear", 3: "nearest", 4: "separable"}
+
+
+def normalize_params(mean, std):
+    m, s, sc, bi = _f3(*mean), _f3(*std), _f3(), _f3()
+    ko.ko_normalize_params(C.byref(m), C.byref(s), C.byref(sc), C.byref(bi))
+    return np.array(list(sc), np.float32), np.array(list(bi), np.float32)
+
+
+def resize_normalize_to_chw(src, dw, dh, scale, bias, mode="bilinear", antialias=True):
+    src = np.ascontiguousarray(src, np.uint8)
+    sh, sw, c = src.shape
+    assert c == 3
+    out = np.empty((3, dh, dw), np.float32)
+    sc, bi = _f3(*[float(v) for v in scale]), _f3(*[float(v) for v in bias])
+    path = ko.ko_resize_normalize_to_chw(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, C.byref(sc), C.byref(bi),
+                                         MODE[mode], int(antialias))
+    return out, FUSED_PATHS[path]

@@ -135,3 +135,38 @@ def test_separable_resize_properties():
     got = O.resize_fast_u8(ramp, 64, 16, "lanczos", True)[0][:, 2:-2, 0].astype(np.float64)
     want = np.linspace(0, 255, 256).reshape(64, 4).mean(axis=1)[2:-2]
     assert np.abs(got - want[None, :]).max() <= 2.0
+
+
+# ---- fused resize + normalise + CHW (P/resize/fused.rs) ----------------------------------------------------
+IMAGENET = ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+
+
+def test_fused_2x_matches_f64_reference():  # fused.rs:1046-1090
+    dw, dh = 37, 5
+    src = ((np.arange(2 * dh * 2 * dw * 3) * 7 + 3) % 256).astype(np.uint8).reshape(2 * dh, 2 * dw, 3)
+    scale, bias = O.normalize_params(*IMAGENET)
+    got, path = O.resize_normalize_to_chw(src, dw, dh, scale, bias, "bilinear")
+    assert path == "box2x"
+    s = src.astype(np.float64)
+    avg = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2]) / 4.0
+    want = ((avg / 255.0 - np.array(IMAGENET[0])) / np.array(IMAGENET[1])).transpose(2, 0, 1)
+    assert np.abs(got - want).max() < 1e-4
+    zero, _ = O.resize_normalize_to_chw(np.zeros((4, 32, 3), np.uint8), 16, 2, *O.normalize_params([0.5, 0.25, 0.75], [0.5, 0.25, 0.75]))
+    assert np.abs(zero + 1.0).max() < 1e-6  # fused_2x_normalize_zero_input: (0 - mean)/std = -1
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bilinear", "bicubic", "lanczos"])
+def test_fused_paths_track_resize_then_normalize(mode):
+    src = O.pattern_u8(96 * 64 * 3).reshape(64, 96, 3)
+    from test_oracle_u8 import hash_image
+    src = O.gaussian_blur_u8(hash_image(64, 96, 3), (7, 7), (2.0, 2.0))[0]  # smooth: resampling differences stay small
+    scale, bias = O.normalize_params(*IMAGENET)
+    got, path = O.resize_normalize_to_chw(src, 40, 30, scale, bias, mode, True)
+    assert path == {"nearest": "nearest", "bilinear": "bilinear"}.get(mode, "separable")
+    u8 = O.resize_fast_u8(src, 40, 30, mode, True)[0].astype(np.float32)
+    want = (u8 * scale + bias).transpose(2, 0, 1)
+    tol = {"nearest": 1e-6, "bilinear": 0.03, "bicubic": 0.012, "lanczos": 0.012}[mode]  # u8 rounding = 0.5/255/std
+    assert np.abs(got - want).max() <= tol
+    const = np.full((9, 14, 3), 200, np.uint8)
+    got, _ = O.resize_normalize_to_chw(const, 5, 4, scale, bias, mode, True)
+    assert np.abs(got - (np.float32(200) * scale + bias)[:, None, None]).max() < 1e-5

@@ -128,3 +128,47 @@ def test_opencv_resize_unit_vectors_and_channels(gpu_stream):  # opencv_compat.r
                 for dw, dh in [(11, 17), (80, 51), (37, 23)]:
                     assert_same_bits(cv_gpu(gpu_stream, img, dw, dh, mode), O.resize_opencv(img, dw, dh, mode),
                                      f"cv {img.dtype} c{c} {mode} {dw}x{dh}")
+
+
+# ---- fused RGB8 -> normalised CHW f32 (P/resize/fused.rs) -------------------------------------------------
+
+def fused_gpu(gpu_stream, src, dw, dh, scale, bias, mode, aa=True, batch=1):
+    import ctypes as C
+    from kornia_rs import _ffi
+    h, w, c = src.shape[-3:]
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, batch * 3 * dh * dw * 4)
+    f3 = C.c_float * 3
+    _ffi.check(_ffi.lib.kh_resize_normalize_to_chw_u8_f32(
+        gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, w, h, dw, dh, f3(*[float(v) for v in scale]),
+        f3(*[float(v) for v in bias]), O.MODE[mode], int(aa), batch, h * w * 3, 3 * dh * dw))
+    return d_dst.to_numpy(np.float32, (batch, 3, dh, dw))
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bilinear", "bicubic", "lanczos"])
+def test_fused_resize_normalize_matches_oracle(gpu_stream, mode):
+    scale, bias = O.normalize_params([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    for (sw, sh), (dw, dh) in [((74, 10), (37, 5)), ((129, 97), (64, 48)), ((63, 41), (127, 90)), ((33, 21), (33, 21)),
+                               ((1, 1), (4, 3)), ((640, 360), (224, 224))]:
+        src = pat(sw, sh, 3)
+        for aa in ((True, False) if mode in ("bicubic", "lanczos") else (True,)):
+            got = fused_gpu(gpu_stream, src, dw, dh, scale, bias, mode, aa)[0]
+            want, path = O.resize_normalize_to_chw(src, dw, dh, scale, bias, mode, aa)
+            assert_same_bits(got, want, f"fused {mode} aa={aa} {sw}x{sh}->{dw}x{dh} ({path})")
+
+
+def test_fused_resize_normalize_batch_and_host_api(gpu_stream):
+    from kornia_rs import Image, imgproc
+    scale, bias = O.normalize_params([0.5, 0.25, 0.75], [0.5, 0.25, 0.75])
+    n = 4
+    src = np.stack([pat(640, 360, 3, seed=31 * k) for k in range(n)])
+    for mode, (dw, dh) in [("bilinear", (320, 180)), ("bilinear", (224, 224)), ("lanczos", (224, 224))]:
+        got = fused_gpu(gpu_stream, src, dw, dh, scale, bias, mode, True, batch=n)
+        for k in range(n):
+            assert_same_bits(got[k], O.resize_normalize_to_chw(src[k], dw, dh, scale, bias, mode, True)[0], f"{mode} frame {k}")
+    img = Image.from_numpy(src[0]).to_hip(gpu_stream)
+    t = img.resize_normalize_to_tensor(224, 224, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    sc, bi = O.normalize_params([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    assert t.shape == (3, 224, 224) and t.dtype == "float32" and t.is_device
+    assert_same_bits(t.numpy(), O.resize_normalize_to_chw(src[0], 224, 224, sc, bi, "bilinear")[0], "Image.resize_normalize_to_tensor")
+    psc, pbi = imgproc.normalize_params([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    assert np.array_equal(psc, sc) and np.array_equal(pbi, bi)
