@@ -351,6 +351,36 @@ KH_API int32_t kh_resize_opencv_f32(kh_stream_t stream, const float* src, float*
                                     int64_t src_stride, int64_t dst_stride);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Gaussian pyramid + morphology.  Replace launch_pyrdown / launch_pyrup {f32,u8}
+ * (P/cuda/pyramid.rs:84-362) and launch_morphology (P/cuda/morphology.rs) == pyrdown_f32 / pyrup_f32
+ * / pyrdown_u8 / pyrup_u8 (P/pyramid.rs:312,210,469,804) and dilate / erode (P/morphology/ops.rs:22,
+ * 125).  pyrdown: dst = ceil(src/2) per axis, 5x5 [1 4 6 4 1]^2/256, reflect-101; pyrup: dst = 2*src,
+ * [1 6 1]/8 even / [1 1]/2 odd taps (f32: the reference's special border rows and columns; u8:
+ * reflect-101 with a u8 intermediate).  One launch, no intermediate image.  HWC, channels in
+ * {1,3,4}; strides in ELEMENTS.                                                                  */
+KH_API int32_t kh_pyrdown_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w, int32_t src_h,
+                              int32_t channels, int32_t batch, int64_t src_stride, int64_t dst_stride);
+KH_API int32_t kh_pyrup_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w, int32_t src_h,
+                            int32_t channels, int32_t batch, int64_t src_stride, int64_t dst_stride);
+KH_API int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t src_w, int32_t src_h,
+                             int32_t channels, int32_t batch, int64_t src_stride, int64_t dst_stride);
+KH_API int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t src_w, int32_t src_h,
+                           int32_t channels, int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* u8 dilate / erode over a structuring element `mask` (HOST, kernel_w * kernel_h bytes, 1 = active,
+ * at most 32x32; anchor = (kernel_h/2, kernel_w/2)).  Border = PaddingMode (P/padding.rs:6-31);
+ * `constant_value`: HOST pointer to `channels` bytes (KH_BORDER_CONSTANT only).  open / close are
+ * erode-then-dilate / dilate-then-erode through a caller-provided temporary, as in the reference
+ * (P/morphology/ops.rs:227-275).  src != dst.                                                      */
+enum { KH_MORPH_DILATE = 0, KH_MORPH_ERODE = 1 };
+enum { KH_BORDER_CONSTANT = 0, KH_BORDER_REPLICATE = 1, KH_BORDER_REFLECT101 = 2, KH_BORDER_REFLECT = 3, KH_BORDER_WRAP = 4 };
+enum { KH_MORPH_BOX = 0, KH_MORPH_CROSS = 1, KH_MORPH_ELLIPSE = 2 };
+KH_API int32_t kh_morph_kernel(int32_t shape, int32_t width, int32_t height, uint8_t* out_mask);
+KH_API int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t width, int32_t height,
+                                int32_t channels, int32_t op, const uint8_t* mask, int32_t kernel_w, int32_t kernel_h,
+                                int32_t border, const uint8_t* constant_value, int32_t batch, int64_t src_stride,
+                                int64_t dst_stride);
+
+/* ------------------------------------------------------------------------------------------ */
 /* normalize / crop / flip (P/normalize.rs:56-420, P/crop.rs:187-240, P/flip.rs:39-360).  The
  * reference has no device twin for normalize; these follow its CPU arithmetic: true division
  * in normalize_mean_std, `(x-min_v)*(max-min)/(max_v-min_v)+min` in normalize_min_max, the

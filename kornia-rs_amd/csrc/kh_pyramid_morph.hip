@@ -1,0 +1,322 @@
+// Gaussian pyramid (pyrdown / pyrup, f32 and u8) and u8 morphology (dilate / erode) for gfx950.
+//
+// Device twins of P/cuda/pyramid.rs:84-362 and P/cuda/morphology.rs (adapters P/pyramid.rs
+// `cuda_adapters`, P/morphology/cuda.rs:52-200); arithmetic of the CPU ops pyrdown_f32 / pyrup_f32 /
+// pyrdown_u8 / pyrup_u8 (P/pyramid.rs:210,312,469,804) and dilate / erode (P/morphology/ops.rs:22,125)
+// over PaddingMode::map_index (P/padding.rs:32-80).  Results are bit-identical
+// (tests/test_pyramid_morph_gpu.py).
+//
+// The reference runs the pyramids as an H pass into an intermediate image and a V pass; here each
+// destination pixel evaluates both passes itself — the intermediate values it needs are recomputed
+// from at most 5x5 (down) / 3x3 (up) source taps that sit in L1/L2, with exactly the reference's
+// per-pass expressions and roundings (u16 / u8 / f32 intermediates), so no scratch image is written.
+#include <math.h>
+
+#include "kh_common.h"
+
+using namespace kh;
+
+namespace {
+
+constexpr int kBx = 64, kBy = 4;
+
+template <typename T>
+struct Pyr {
+    const T* src;
+    T* dst;
+    int sw, sh, dw, dh;
+    long long ss, ds;  // elements between consecutive images
+    XcdTiles tiles;
+};
+
+#define KH_PYR_PROLOGUE(T)                                      \
+    unsigned bx_, by_, bz_;                                     \
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;              \
+    const int X = bx_ * kBx + threadIdx.x;                      \
+    const int Y = by_ * kBy + threadIdx.y;                      \
+    if (X >= a.dw || Y >= a.dh) return;                         \
+    const T* __restrict__ src = a.src + (long long)bz_ * a.ss;  \
+    T* __restrict__ o = a.dst + (long long)bz_ * a.ds + ((long long)Y * a.dw + X) * C;
+
+__device__ __forceinline__ int reflect_101(int p, int len) {  // pyramid.rs:252-270
+    if (len == 1) return 0;
+    if (p < 0) p = -p;
+    const int period = 2 * (len - 1);
+    p %= period;
+    return p >= len ? period - p : p;
+}
+
+// pyrdown_f32 (:312-430): 5x5 outer-product taps, ky-major accumulation, reflect-101 border
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void pyrdown_f32_kernel(Pyr<float> a) {
+    KH_PYR_PROLOGUE(float)
+    const float k1[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    int sx[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) sx[t] = reflect_101(2 * X + t - 2, a.sw) * C;
+    float sum[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) sum[c] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        const float* row = src + (long long)reflect_101(2 * Y + ky - 2, a.sh) * a.sw * C;
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const float w = k1[ky] * k1[kx];  // exact products of powers of two and 3
+#pragma unroll
+            for (int c = 0; c < C; ++c) sum[c] += row[sx[kx] + c] * w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = sum[c];
+}
+
+// pyrup_horizontal_pass_f32 (:22-96) at column X of one source row
+template <int C>
+__device__ __forceinline__ float pyrup_h(const float* __restrict__ row, int sw, int X, int c) {
+    if (sw == 1) return row[c];
+    const int x = X >> 1;
+    const bool odd = X & 1;
+    if (x == 0) {
+        const float l = row[c], r = row[C + c];
+        return odd ? (l + r) * 0.5f : (6.0f * l + 2.0f * r) * 0.125f;
+    }
+    if (x == sw - 1) {
+        const float prev = row[(x - 1) * C + c], curr = row[x * C + c];
+        return odd ? curr : (1.0f * prev + 7.0f * curr) * 0.125f;
+    }
+    const float prev = row[(x - 1) * C + c], curr = row[x * C + c], next = row[(x + 1) * C + c];
+    return odd ? (curr + next) * 0.5f : (1.0f * prev + 6.0f * curr + 1.0f * next) * 0.125f;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void pyrup_f32_kernel(Pyr<float> a) {  // + vertical pass (:98-170)
+    KH_PYR_PROLOGUE(float)
+    const int y = Y >> 1;
+    const bool odd = Y & 1;
+    int rt, rc, rb;
+    if (a.sh == 1) { rt = rc = rb = 0; }
+    else if (y == 0) { rt = 0; rc = 0; rb = 1; }
+    else if (y == a.sh - 1) { rt = a.sh - 2; rc = a.sh - 1; rb = a.sh - 1; }
+    else { rt = y - 1; rc = y; rb = y + 1; }
+    const long long stride = (long long)a.sw * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float top = pyrup_h<C>(src + rt * stride, a.sw, X, c);
+        const float cen = pyrup_h<C>(src + rc * stride, a.sw, X, c);
+        const float bot = pyrup_h<C>(src + rb * stride, a.sw, X, c);
+        float v;
+        if (y == 0) v = odd ? (cen + bot) * 0.5f : (6.0f * cen + 2.0f * bot) * 0.125f;
+        else if (y == a.sh - 1) v = odd ? cen : (1.0f * top + 7.0f * cen) * 0.125f;
+        else v = odd ? (cen + bot) * 0.5f : (1.0f * top + 6.0f * cen + 1.0f * bot) * 0.125f;
+        o[c] = v;
+    }
+}
+
+// pyrdown_u8 (:469-655): [1 4 6 4 1] rows into u16, then columns, (sum + 128) >> 8, min 255
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void pyrdown_u8_kernel(Pyr<uint8_t> a) {
+    KH_PYR_PROLOGUE(uint8_t)
+    int sx[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) sx[t] = reflect_101(2 * X + t - 2, a.sw) * C;
+    const uint32_t wv[5] = {1, 4, 6, 4, 1};
+    uint32_t sum[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) sum[c] = 0;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        const uint8_t* row = src + (long long)reflect_101(2 * Y + ky - 2, a.sh) * a.sw * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const uint32_t h = (uint32_t)row[sx[0] + c] + 4u * row[sx[1] + c] + 6u * row[sx[2] + c] + 4u * row[sx[3] + c] + row[sx[4] + c];
+            sum[c] += wv[ky] * h;  // h <= 4080 fits the reference's u16 intermediate
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = (uint8_t)min((sum[c] + 128u) >> 8, 255u);
+}
+
+// pyrup_u8 (:656-840): horizontal pass to a u8 intermediate, then the same taps vertically
+template <int C>
+__device__ __forceinline__ uint32_t pyrup_h_u8(const uint8_t* __restrict__ row, int sw, int X, int c) {
+    const int x = X >> 1;
+    const uint32_t pc = row[x * C + c], pn = row[reflect_101(x + 1, sw) * C + c];
+    if (X & 1) return (pc + pn + 1u) >> 1;
+    const uint32_t pp = row[reflect_101(x - 1, sw) * C + c];
+    return ((pp + 6u * pc + pn + 4u) >> 3) & 0xffu;
+}
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void pyrup_u8_kernel(Pyr<uint8_t> a) {
+    KH_PYR_PROLOGUE(uint8_t)
+    const int y = Y >> 1;
+    const long long stride = (long long)a.sw * C;
+    const uint8_t* rc = src + y * stride;
+    const uint8_t* rn = src + reflect_101(y + 1, a.sh) * stride;
+    const uint8_t* rp = src + reflect_101(y - 1, a.sh) * stride;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const uint32_t pc = pyrup_h_u8<C>(rc, a.sw, X, c), pn = pyrup_h_u8<C>(rn, a.sw, X, c);
+        uint32_t v;
+        if (Y & 1) v = (pc + pn + 1u) >> 1;
+        else v = (pyrup_h_u8<C>(rp, a.sw, X, c) + 6u * pc + pn + 4u) >> 3;
+        o[c] = (uint8_t)v;
+    }
+}
+
+// ---- morphology ------------------------------------------------------------------------------------------
+struct Morph {
+    const uint8_t* src;
+    uint8_t* dst;
+    int w, h, kw, kh, border, op;
+    long long ss, ds;
+    uint32_t rows[32];  // bit kx of rows[ky] = tap (ky, kx) active
+    uint32_t cval[4];
+    XcdTiles tiles;
+};
+
+__device__ __forceinline__ int map_index(int mode, int i, int len) {  // PaddingMode::map_index, padding.rs:32-80
+    if (i >= 0 && i < len) return i;
+    switch (mode) {
+        case 1: return i < 0 ? 0 : len - 1;
+        case 2:
+            if (len == 1) return 0;
+            while (i < 0 || i >= len) i = i < 0 ? -i : 2 * len - i - 2;
+            return i;
+        case 3:
+            if (len == 1) return 0;
+            while (i < 0 || i >= len) i = i < 0 ? -i - 1 : 2 * len - i - 1;
+            return i;
+        case 4: return ((i % len) + len) % len;
+        default: return -1;  // constant
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void morphology_u8_kernel(Morph a) {
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int x = bx_ * kBx + threadIdx.x, y = by_ * kBy + threadIdx.y;
+    if (x >= a.w || y >= a.h) return;
+    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
+    const int pad_h = a.kh / 2, pad_w = a.kw / 2;
+    const bool dilate = a.op == 0;
+    int acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = dilate ? 0 : 256;  // dilate starts from T::default(), ops.rs:88
+    bool any = false;
+    for (int ky = 0; ky < a.kh; ++ky) {
+        const uint32_t bits = a.rows[ky];
+        if (!bits) continue;
+        const int sy = map_index(a.border, y + ky - pad_h, a.h);
+        for (int kx = 0; kx < a.kw; ++kx) {
+            if (!((bits >> kx) & 1u)) continue;
+            any = true;
+            const int sx = map_index(a.border, x + kx - pad_w, a.w);
+            const bool outside = sy < 0 || sx < 0;
+            const uint8_t* p = src + ((long long)max(sy, 0) * a.w + max(sx, 0)) * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int v = outside ? (int)a.cval[c] : (int)p[c];
+                acc[c] = dilate ? max(acc[c], v) : min(acc[c], v);
+            }
+        }
+    }
+    uint8_t* o = a.dst + (long long)bz_ * a.ds + ((long long)y * a.w + x) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = (uint8_t)(any ? acc[c] : 0);  // erode with no active tap: unwrap_or_default
+}
+
+template <typename T>
+int32_t check_pyr(const char* what, const T* src, T* dst, int sw, int sh, int channels, int batch, int64_t ss, int64_t ds,
+                  int dw, int dh) {
+    KH_REQUIRE(sw > 0 && sh > 0, KH_ERR_INVALID_ARG, "%s: zero-sized image %dx%d", what, sw, sh);
+    KH_REQUIRE(channels == 1 || channels == 3 || channels == 4, KH_ERR_UNSUPPORTED,
+               "%s: no device kernel for %d channels (supported: 1, 3, 4)", what, channels);
+    KH_REQUIRE(batch >= 0 && batch <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, batch);
+    KH_REQUIRE((int64_t)sw * sh * channels <= kI32Max && (int64_t)dw * dh * channels <= kI32Max, KH_ERR_TOO_LARGE,
+               "%s: image exceeds 32-bit indexing", what);
+    KH_REQUIRE(ss >= 0 && ds >= 0, KH_ERR_INVALID_ARG, "%s: negative batch stride", what);
+    if (batch > 0) KH_REQUIRE(src && dst, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
+    return KH_OK;
+}
+
+#define KH_PYR_ENTRY(NAME, T, KERNEL, DW, DH)                                                                     \
+    int32_t NAME(kh_stream_t stream, const T* src, T* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch, \
+                 int64_t ss, int64_t ds) {                                                                        \
+        const int dw = (DW), dh = (DH);                                                                           \
+        if (int32_t rc = check_pyr(#NAME, src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;          \
+        if (batch == 0) return KH_OK;                                                                             \
+        Pyr<T> a{src, dst, sw, sh, dw, dh, ss, ds,                                                                \
+                 xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)batch, cdiv(dw, kBx) * 8)};                    \
+        KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, #NAME ": batch x tiles exceeds one launch");              \
+        const dim3 blk(kBx, kBy), grid = xcd_grid(a.tiles);                                                       \
+        hipStream_t st = as_hip(stream);                                                                          \
+        if (channels == 1) hipLaunchKernelGGL(KERNEL<1>, grid, blk, 0, st, a);                                    \
+        else if (channels == 3) hipLaunchKernelGGL(KERNEL<3>, grid, blk, 0, st, a);                               \
+        else hipLaunchKernelGGL(KERNEL<4>, grid, blk, 0, st, a);                                                  \
+        return check_launch(#NAME);                                                                               \
+    }
+
+}  // namespace
+
+extern "C" {
+
+KH_PYR_ENTRY(kh_pyrdown_f32, float, pyrdown_f32_kernel, (sw + 1) / 2, (sh + 1) / 2)
+KH_PYR_ENTRY(kh_pyrup_f32, float, pyrup_f32_kernel, sw * 2, sh * 2)
+KH_PYR_ENTRY(kh_pyrdown_u8, uint8_t, pyrdown_u8_kernel, (sw + 1) / 2, (sh + 1) / 2)
+KH_PYR_ENTRY(kh_pyrup_u8, uint8_t, pyrup_u8_kernel, sw * 2, sh * 2)
+
+// Kernel::new (P/morphology/kernels.rs:113-185): shape 0 box, 1 cross, 2 ellipse; out = width*height bytes
+int32_t kh_morph_kernel(int32_t shape, int32_t width, int32_t height, uint8_t* out) {
+    KH_REQUIRE(out && width > 0 && height > 0, KH_ERR_INVALID_ARG, "kh_morph_kernel: bad arguments");
+    KH_REQUIRE(shape >= 0 && shape <= 2, KH_ERR_INVALID_ARG, "kh_morph_kernel: unknown shape %d", shape);
+    KH_REQUIRE(shape == 2 || width == height, KH_ERR_INVALID_ARG, "kh_morph_kernel: box / cross kernels are square");
+    for (int i = 0; i < width * height; ++i) out[i] = shape == 0 ? 1 : 0;
+    if (shape == 1) {
+        const int mid = width / 2;
+        for (int j = 0; j < width; ++j) out[mid * width + j] = 1;
+        for (int i = 0; i < width; ++i) out[i * width + mid] = 1;
+    } else if (shape == 2) {
+        const float cx = (float)width / 2.0f, cy = (float)height / 2.0f, rx = cx, ry = cy;
+        for (int i = 0; i < height; ++i)
+            for (int j = 0; j < width; ++j) {
+                const float x = (float)j - cx, y = (float)i - cy;
+                if ((x * x) / (rx * rx) + (y * y) / (ry * ry) <= 1.0f) out[i * width + j] = 1;
+            }
+    }
+    return KH_OK;
+}
+
+int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t w, int32_t h, int32_t channels,
+                         int32_t op, const uint8_t* mask, int32_t kw, int32_t kh_, int32_t border, const uint8_t* cval,
+                         int32_t batch, int64_t ss, int64_t ds) {
+    const char* what = "kh_morphology_u8";
+    if (int32_t rc = check_pyr(what, src, dst, w, h, channels, batch, ss, ds, w, h)) return rc;
+    KH_REQUIRE(op == KH_MORPH_DILATE || op == KH_MORPH_ERODE, KH_ERR_INVALID_ARG, "%s: unknown op %d", what, op);
+    KH_REQUIRE(mask && kw > 0 && kh_ > 0, KH_ERR_INVALID_ARG, "%s: empty structuring element", what);
+    KH_REQUIRE(kw <= 32 && kh_ <= 32, KH_ERR_UNSUPPORTED, "%s: structuring element %dx%d larger than 32x32", what, kw, kh_);
+    KH_REQUIRE(border >= KH_BORDER_CONSTANT && border <= KH_BORDER_WRAP, KH_ERR_INVALID_ARG, "%s: unknown border mode %d", what, border);
+    KH_REQUIRE(border != KH_BORDER_CONSTANT || cval, KH_ERR_INVALID_ARG, "%s: constant border needs a value", what);
+    KH_REQUIRE(src != dst || batch == 0, KH_ERR_INVALID_ARG, "%s: in-place morphology is not supported", what);
+    if (batch == 0) return KH_OK;
+    Morph a;
+    a.src = src; a.dst = dst; a.w = w; a.h = h; a.kw = kw; a.kh = kh_; a.border = border; a.op = op; a.ss = ss; a.ds = ds;
+    for (int ky = 0; ky < 32; ++ky) {
+        a.rows[ky] = 0;
+        if (ky < kh_)
+            for (int kx = 0; kx < kw; ++kx)
+                if (mask[ky * kw + kx] == 1) a.rows[ky] |= 1u << kx;
+    }
+    for (int c = 0; c < 4; ++c) a.cval[c] = (cval && c < channels) ? cval[c] : 0;
+    a.tiles = xcd_tiles(cdiv(w, kBx), cdiv(h, kBy), (unsigned)batch, cdiv(w, kBx) * 8);
+    KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+    const dim3 blk(kBx, kBy), grid = xcd_grid(a.tiles);
+    hipStream_t st = as_hip(stream);
+    if (channels == 1) hipLaunchKernelGGL(morphology_u8_kernel<1>, grid, blk, 0, st, a);
+    else if (channels == 3) hipLaunchKernelGGL(morphology_u8_kernel<3>, grid, blk, 0, st, a);
+    else hipLaunchKernelGGL(morphology_u8_kernel<4>, grid, blk, 0, st, a);
+    return check_launch(what);
+}
+
+}  // extern "C"

@@ -30,6 +30,9 @@ KH_OUT_F32, KH_OUT_F16 = 0, 1
 KH_PRE_FORCE_GENERIC = 1
 KH_YCC_YCRCB, KH_YCC_YUV = 0, 1
 KH_INTERP_NEAREST, KH_INTERP_BILINEAR, KH_INTERP_BICUBIC, KH_INTERP_LANCZOS = 0, 1, 2, 3
+KH_MORPH_DILATE, KH_MORPH_ERODE = 0, 1
+KH_BORDER = {"constant": 0, "replicate": 1, "reflect101": 2, "reflect": 3, "wrap": 4}
+KH_MORPH_SHAPE = {"box": 0, "cross": 1, "ellipse": 2}
 KH_GRAD_SOBEL, KH_GRAD_SCHARR = 0, 1
 
 
@@ -134,6 +137,12 @@ SIGNATURES = {
     "kh_resize_normalize_to_chw_u8_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _P(_f32), _P(_f32), _i32, _i32, _i32, _i64, _i64]),
     "kh_resize_opencv_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
     "kh_resize_opencv_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    # pyramid + morphology
+    **{n: (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64]) for n in (
+        "kh_pyrdown_f32", "kh_pyrup_f32", "kh_pyrdown_u8", "kh_pyrup_u8")},
+    "kh_morph_kernel": (_i32, [_i32, _i32, _i32, _P(C.c_uint8)]),
+    "kh_morphology_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _P(C.c_uint8), _i32, _i32, _i32, _P(C.c_uint8),
+                                _i32, _i64, _i64]),
     # pointwise
     "kh_normalize_mean_std_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _P(_f32), _P(_f32)]),
     "kh_normalize_rgb_u8_f32": (_i32, [_vp, _vp, _vp, _i64, _P(_f32), _P(_f32)]),

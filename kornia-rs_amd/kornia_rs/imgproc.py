@@ -592,3 +592,101 @@ warp_perspective_u8 = _u8_only(warp_perspective, "warp_perspective_u8")
 remap_u8 = _u8_only(remap, "remap_u8")
 gaussian_blur_u8 = _u8_only(gaussian_blur, "gaussian_blur_u8")
 box_blur_u8 = _u8_only(box_blur, "box_blur_u8")
+
+
+# ---- pyramid + morphology -----------------------------------------------------------------------------------
+
+def _pyr(src: Image, dst: Optional[Image], up: bool, what: str) -> Image:
+    if src.dtype not in ("float32", "uint8"):
+        raise ImageError("NoDeviceKernel", f"{what}: no device kernel for {src.dtype}")
+    _require(src, src.dtype, (1, 3, 4), what)
+    w, h = (src.width * 2, src.height * 2) if up else ((src.width + 1) // 2, (src.height + 1) // 2)
+    out = dst if dst is not None else _new_like(src, size=(w, h))
+    _require(out, src.dtype, (src.channels,), what)
+    if out.size != (w, h):  # P/pyramid.rs:216-224, 318-326
+        raise ImageError("InvalidImageSize", f"{what}: expected a {w}x{h} destination, got {out.width}x{out.height}")
+    stream = _pair_residency(src, out)
+    fn = getattr(lib, f"kh_{'pyrup' if up else 'pyrdown'}_{'f32' if src.dtype == 'float32' else 'u8'}")
+    _check(fn(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels, 1, 0, 0))
+    return out
+
+
+def pyrdown(src: Image, dst: Optional[Image] = None) -> Image:
+    """pyrdown_f32 / pyrdown_u8 (P/pyramid.rs:312, 469): 5x5 Gaussian + 2x decimation, reflect-101."""
+    return _pyr(src, dst, False, "pyrdown")
+
+
+def pyrup(src: Image, dst: Optional[Image] = None) -> Image:
+    """pyrup_f32 / pyrup_u8 (P/pyramid.rs:210, 804): 2x Gaussian upsampling."""
+    return _pyr(src, dst, True, "pyrup")
+
+
+def build_pyramid(src: Image, max_level: int) -> list:
+    """build_pyramid (P/pyramid.rs:431-452): [src, pyrdown(src), ...] with max_level + 1 entries."""
+    levels = [src]
+    for _ in range(max_level):
+        levels.append(pyrdown(levels[-1]))
+    return levels
+
+
+class Kernel:
+    """Morphological structuring element (P/morphology/kernels.rs:60-110): ``Kernel("box", 3)``,
+    ``Kernel("cross", 5)``, ``Kernel("ellipse", (w, h))`` or ``Kernel.from_mask(array)``."""
+
+    def __init__(self, shape: str, size):
+        code = _ffi.KH_MORPH_SHAPE.get(str(shape).lower())
+        if code is None:
+            raise ImageError("InvalidKernelShape", f"unknown kernel shape {shape!r} (box, cross, ellipse)")
+        w, h = (size, size) if np.isscalar(size) else size
+        self.width, self.height = int(w), int(h)
+        buf = (C.c_uint8 * (self.width * self.height))()
+        _check(lib.kh_morph_kernel(code, self.width, self.height, buf))
+        self.data = np.frombuffer(buf, np.uint8).reshape(self.height, self.width).copy()
+
+    @staticmethod
+    def from_mask(mask: np.ndarray) -> "Kernel":
+        k = Kernel.__new__(Kernel)
+        k.data = np.ascontiguousarray(mask, np.uint8)
+        k.height, k.width = k.data.shape
+        return k
+
+    def pad(self) -> Tuple[int, int]:
+        return self.height // 2, self.width // 2
+
+
+def _morph(src: Image, kernel: Kernel, op: int, padding_mode: str, constant_value, dst: Optional[Image], what: str) -> Image:
+    _require(src, "uint8", (1, 3, 4), what)  # only u8 has a device kernel (P/morphology/cuda.rs:62-64)
+    out = dst if dst is not None else _new_like(src)
+    _require(out, "uint8", (src.channels,), what)
+    if out.size != src.size:
+        raise ImageError("InvalidImageSize", f"{what}: image sizes differ: {src.width}x{src.height} vs {out.width}x{out.height}")
+    border = _ffi.KH_BORDER.get(str(padding_mode).lower())
+    if border is None:
+        raise ImageError("InvalidPaddingMode", f"unknown padding mode {padding_mode!r}")
+    cv = np.zeros(4, np.uint8)
+    vals = np.atleast_1d(np.asarray(constant_value if constant_value is not None else 0))
+    cv[: src.channels] = np.broadcast_to(vals, (src.channels,)) if vals.size == 1 else vals[: src.channels]
+    stream = _pair_residency(src, out)
+    mask = np.ascontiguousarray(kernel.data, np.uint8)
+    _check(lib.kh_morphology_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels, op,
+                                mask.ctypes.data_as(C.POINTER(C.c_uint8)), kernel.width, kernel.height, border,
+                                cv.ctypes.data_as(C.POINTER(C.c_uint8)), 1, 0, 0))
+    return out
+
+
+def dilate(src: Image, kernel: Kernel, padding_mode: str = "constant", constant_value=0, dst: Optional[Image] = None) -> Image:
+    return _morph(src, kernel, _ffi.KH_MORPH_DILATE, padding_mode, constant_value, dst, "dilate")
+
+
+def erode(src: Image, kernel: Kernel, padding_mode: str = "constant", constant_value=0, dst: Optional[Image] = None) -> Image:
+    return _morph(src, kernel, _ffi.KH_MORPH_ERODE, padding_mode, constant_value, dst, "erode")
+
+
+def morph_open(src: Image, kernel: Kernel, padding_mode: str = "constant", constant_value=0, dst: Optional[Image] = None) -> Image:
+    """open (P/morphology/ops.rs:227-240): erode into a temporary, then dilate."""
+    return dilate(erode(src, kernel, padding_mode, constant_value), kernel, padding_mode, constant_value, dst)
+
+
+def morph_close(src: Image, kernel: Kernel, padding_mode: str = "constant", constant_value=0, dst: Optional[Image] = None) -> Image:
+    """close (P/morphology/ops.rs:255-268): dilate into a temporary, then erode."""
+    return erode(dilate(src, kernel, padding_mode, constant_value), kernel, padding_mode, constant_value, dst)

@@ -130,6 +130,15 @@ void ko_normalize_params(const float mean[3], const float std[3], float scale[3]
 int ko_resize_normalize_to_chw(const uint8_t* src, int sw, int sh, float* dst, int dw, int dh, const float scale[3],
                                const float bias[3], int mode, int antialias);
 
+/* ---- pyramid + morphology (ko_pyramid_morph.c) ------------------------------------------------------- */
+void ko_pyrdown_f32(const float* src, int sw, int sh, float* dst, int C);
+void ko_pyrup_f32(const float* src, int sw, int sh, float* dst, int C);
+void ko_pyrdown_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int C);
+void ko_pyrup_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int C);
+void ko_morph_kernel(int shape, int width, int height, uint8_t* out);
+void ko_morphology_u8(const uint8_t* src, int w, int h, int C, uint8_t* dst, int op, const uint8_t* mask, int kw, int kh,
+                      int border, const uint8_t* cval);
+
 #ifdef __cplusplus
 }
 #endif

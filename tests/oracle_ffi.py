@@ -474,3 +474,53 @@ def resize_normalize_to_chw(src, dw, dh, scale, bias, mode="bilinear", antialias
     path = ko.ko_resize_normalize_to_chw(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, C.byref(sc), C.byref(bi),
                                          MODE[mode], int(antialias))
     return out, FUSED_PATHS[path]
+
+
+# ---- pyramid + morphology (ko_pyramid_morph.c) ------------------------------------------------------------------
+for _n, _p in (("ko_pyrdown_f32", _f32p), ("ko_pyrup_f32", _f32p), ("ko_pyrdown_u8", _u8p), ("ko_pyrup_u8", _u8p)):
+    getattr(ko, _n).argtypes = [_p, C.c_int, C.c_int, _p, C.c_int]
+ko.ko_morph_kernel.argtypes = [C.c_int, C.c_int, C.c_int, _u8p]
+ko.ko_morphology_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _u8p]
+BORDER = {"constant": 0, "replicate": 1, "reflect101": 2, "reflect": 3, "wrap": 4}
+
+
+def _pyr(src, up):
+    src = np.ascontiguousarray(src)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    sh, sw, c = src.shape
+    dh, dw = (2 * sh, 2 * sw) if up else ((sh + 1) // 2, (sw + 1) // 2)
+    out = np.empty((dh, dw, c), src.dtype)
+    fn = getattr(ko, f"ko_{'pyrup' if up else 'pyrdown'}_{'u8' if src.dtype == np.uint8 else 'f32'}")
+    fn(src.reshape(-1), sw, sh, out.reshape(-1), c)
+    return out
+
+
+def pyrdown(src):
+    return _pyr(src, False)
+
+
+def pyrup(src):
+    return _pyr(src, True)
+
+
+def morph_kernel(shape, width, height=None):
+    height = width if height is None else height
+    out = np.empty(width * height, np.uint8)
+    ko.ko_morph_kernel({"box": 0, "cross": 1, "ellipse": 2}[shape], width, height, out)
+    return out.reshape(height, width)
+
+
+def morphology_u8(src, op, mask, border="constant", cval=None):
+    src = np.ascontiguousarray(src, np.uint8)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    h, w, c = src.shape
+    out = np.empty_like(src)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    cv = np.zeros(4, np.uint8)
+    if cval is not None:
+        cv[:c] = cval
+    ko.ko_morphology_u8(src.reshape(-1), w, h, c, out.reshape(-1), {"dilate": 0, "erode": 1}[op], mask.reshape(-1),
+                        mask.shape[1], mask.shape[0], BORDER[border], cv)
+    return out

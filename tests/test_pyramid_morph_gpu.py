@@ -1,0 +1,115 @@
+"""GPU parity for the Gaussian pyramid (f32 / u8) and u8 morphology: bit-exact against the CPU oracle
+(shapes after P/cuda/pyramid.rs and P/morphology/cuda.rs device==host tests)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from gpu_util import assert_same_bits, dev, out_buf
+
+pytestmark = pytest.mark.gpu
+SHAPES = [(129, 97), (64, 48), (63, 41), (2, 2), (1, 1), (1, 7), (7, 1), (3, 2), (300, 5)]
+
+
+def make(w, h, c, dtype, seed=0):
+    if dtype == np.uint8:
+        return np.roll(O.pattern_u8(w * h * c + seed), -seed)[: w * h * c].reshape(h, w, c).copy()
+    return np.roll(O.pattern_f32(w * h * c + seed), -seed)[: w * h * c].reshape(h, w, c).copy()
+
+
+def pyr_gpu(gpu_stream, src, up, batch=1):
+    from kornia_rs import _ffi
+    h, w, c = src.shape[-3:]
+    dh, dw = (2 * h, 2 * w) if up else ((h + 1) // 2, (w + 1) // 2)
+    es = src.dtype.itemsize
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, batch * dh * dw * c * es)
+    fn = getattr(_ffi.lib, f"kh_{'pyrup' if up else 'pyrdown'}_{'u8' if src.dtype == np.uint8 else 'f32'}")
+    _ffi.check(fn(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, w, h, c, batch, h * w * c, dh * dw * c))
+    return d_dst.to_numpy(src.dtype, (batch, dh, dw, c))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("up", [False, True])
+def test_pyramid_matches_oracle(gpu_stream, dtype, c, up):
+    for w, h in SHAPES:
+        src = make(w, h, c, dtype)
+        got = pyr_gpu(gpu_stream, src, up)[0]
+        assert_same_bits(got, O.pyrup(src) if up else O.pyrdown(src), f"{'pyrup' if up else 'pyrdown'} {dtype.__name__} c{c} {w}x{h}")
+
+
+def test_pyramid_batch_and_host_api(gpu_stream):
+    from kornia_rs import Image, ImageError, imgproc
+    n = 3
+    for dtype in (np.float32, np.uint8):
+        src = np.stack([make(640, 360, 3, dtype, seed=31 * k) for k in range(n)])
+        down, up = pyr_gpu(gpu_stream, src, False, batch=n), pyr_gpu(gpu_stream, src, True, batch=n)
+        for k in range(n):
+            assert_same_bits(down[k], O.pyrdown(src[k]), f"pyrdown frame {k}")
+            assert_same_bits(up[k], O.pyrup(src[k]), f"pyrup frame {k}")
+    img = Image.from_numpy(make(37, 29, 1, np.float32)).to_hip(gpu_stream)
+    levels = imgproc.build_pyramid(img, 3)  # pyramid.rs:845-885
+    assert [(l.height, l.width) for l in levels] == [(29, 37), (15, 19), (8, 10), (4, 5)]
+    ref = make(37, 29, 1, np.float32)
+    for l in levels[1:]:
+        ref = O.pyrdown(ref)
+        assert_same_bits(l.cpu().numpy(), ref, "build_pyramid level")
+    with pytest.raises(ImageError) as e:
+        imgproc.pyrup(img, dst=Image.uninit(10, 10, 1, "float32", gpu_stream))
+    assert e.value.kind == "InvalidImageSize"
+
+
+def morph_gpu(gpu_stream, src, op, mask, border, cval, batch=1):
+    from kornia_rs import _ffi
+    h, w, c = src.shape[-3:]
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, batch * h * w * c)
+    m = np.ascontiguousarray(mask, np.uint8)
+    cv = (C.c_uint8 * 4)(*([int(v) for v in cval] + [0] * (4 - len(cval))))
+    rc = _ffi.lib.kh_morphology_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, w, h, c, {"dilate": 0, "erode": 1}[op],
+                                   m.ctypes.data_as(C.POINTER(C.c_uint8)), m.shape[1], m.shape[0], O.BORDER[border], cv, batch,
+                                   h * w * c, h * w * c)
+    if rc != 0:
+        return rc
+    return d_dst.to_numpy(np.uint8, (batch, h, w, c))
+
+
+@pytest.mark.parametrize("border", ["constant", "replicate", "reflect101", "reflect", "wrap"])
+@pytest.mark.parametrize("kshape", [("box", 3, 3), ("cross", 5, 5), ("ellipse", 7, 5), ("box", 4, 4), ("ellipse", 2, 6), ("box", 15, 15), ("box", 1, 1)])
+def test_morphology_matches_oracle(gpu_stream, border, kshape):
+    mask = O.morph_kernel(*kshape)
+    for (w, h), c in [((129, 97), 3), ((33, 21), 1), ((5, 3), 4), ((1, 1), 1)]:
+        src = make(w, h, c, np.uint8, seed=5)
+        for op, cval in (("dilate", [7] * c), ("erode", [200] * c)):
+            got = morph_gpu(gpu_stream, src, op, mask, border, cval)[0]
+            assert_same_bits(got, O.morphology_u8(src, op, mask, border, cval), f"{op} {kshape} {border} {w}x{h} c{c}")
+
+
+def test_morphology_unit_tests_batch_and_errors(gpu_stream):  # ops.rs:326-400
+    from kornia_rs import Image, _ffi, imgproc
+    box3 = O.morph_kernel("box", 3)
+    src = np.zeros((3, 3, 1), np.uint8); src[1, 1] = 255
+    assert (morph_gpu(gpu_stream, src, "dilate", box3, "constant", [0]) == 255).all()
+    er = morph_gpu(gpu_stream, np.full((3, 3, 1), 255, np.uint8), "erode", box3, "constant", [0])[0].reshape(3, 3)
+    assert er[1, 1] == 255 and er[0, 0] == 0
+    empty = np.zeros((3, 3), np.uint8)  # no active tap: dilate -> 0, erode -> unwrap_or_default = 0
+    img = make(20, 10, 3, np.uint8)
+    for op in ("dilate", "erode"):
+        assert (morph_gpu(gpu_stream, img, op, empty, "replicate", [0, 0, 0]) == 0).all()
+    n = 4
+    batch = np.stack([make(320, 180, 3, np.uint8, seed=31 * k) for k in range(n)])
+    ell = O.morph_kernel("ellipse", 9, 9)
+    got = morph_gpu(gpu_stream, batch, "erode", ell, "reflect101", [0, 0, 0], batch=n)
+    for k in range(n):
+        assert_same_bits(got[k], O.morphology_u8(batch[k], "erode", ell, "reflect101"), f"frame {k}")
+    assert morph_gpu(gpu_stream, img, "dilate", np.ones((33, 3), np.uint8), "constant", [0, 0, 0]) == _ffi.KH_ERR_UNSUPPORTED
+    # host API: open removes an isolated pixel, close fills a hole (ops.rs:345-400)
+    noise = np.zeros((5, 5, 1), np.uint8); noise[1, 1] = 255
+    k3 = imgproc.Kernel("box", 3)
+    assert np.array_equal(k3.data, box3) and k3.pad() == (1, 1)
+    opened = imgproc.morph_open(Image.from_numpy(noise).to_hip(gpu_stream), k3).cpu().numpy()
+    assert (opened == 0).all()
+    hole = np.zeros((5, 5, 1), np.uint8); hole[1:4, 1:4] = 255; hole[2, 2] = 0
+    closed = imgproc.morph_close(Image.from_numpy(hole).to_hip(gpu_stream), k3).cpu().numpy().reshape(5, 5)
+    assert closed[2, 2] == 255 and closed[1, 1] == 255 and closed[3, 3] == 255
+    assert np.array_equal(imgproc.Kernel("ellipse", (7, 5)).data, O.morph_kernel("ellipse", 7, 5))
