@@ -332,12 +332,169 @@ class UndistortWarp4K(F32Images):
                 f"(restatement, not the upstream Rust binary), OpenMP x{threads} over rows"}
 
 
+
+class U8Images(Workload):
+    """Shared setup for the u8 HWC workloads (SURVEY 8f.1 twins): image k = LCG base shifted by 31*k bytes."""
+
+    dtype = "u8"
+    W, H, C = 3840, 2160, 3
+
+    def _make_src(self, stream, w, h, c, batch):
+        from kornia_rs.hip import DeviceBuffer, lib, check
+        n = w * h * c
+        base = lcg_bytes(n + 31 * batch)
+        dbase = DeviceBuffer.from_numpy(base, stream)
+        src = DeviceBuffer(n * batch, stream, zeroed=False)
+        for k in range(batch):
+            check(lib.kh_memcpy_d2d_async(src.ptr + k * n, dbase.ptr + 31 * k, n, stream.cuda_stream_ptr))
+        stream.synchronize()
+        self.base = base
+        return src
+
+    def _oracle(self):
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
+        return O
+
+    def _time_cpu(self, fn, what):
+        O = self._oracle()
+        threads = O.ko.ko_max_threads()
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            fn(O)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > 8.0 or reps >= 64:
+                break
+        return {"value": round(reps * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+                "sample": f"{reps} images in {dt:.1f} s; C oracle of {what} (not the upstream Rust binary), OpenMP x{threads}"}
+
+
+class GaussianU8_4K(U8Images):
+    """gaussian_blur_u8 7x7 sigma 1.5 (Q8 general path) on 3840x2160 RGB8, batch 256."""
+
+    name, kernel = "gaussian_blur_u8_7x7_4k_b256", "blur_u8_roll_kernel<7,3>"
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C  # 1R + 1W
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.W * self.H * self.C, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        n = self.W * self.H * self.C
+        check(lib.kh_gaussian_blur_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.C, 7, 7,
+                                      1.5, 1.5, self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::filter::gaussian_blur_u8 (7,7) sigma (1.5,1.5), Q8, fused H+V",
+                "src": "3840x2160x3 u8", "dst": "same", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        return self._time_cpu(lambda O: O.gaussian_blur_u8(img, (7, 7), (1.5, 1.5)), "gaussian_blur_u8")
+
+
+class WarpAffineU8_4K(U8Images):
+    """warp_affine_u8 (rotation 12 deg about the centre, scale 0.9) on 3840x2160 RGB8, batch 256."""
+
+    name, kernel = "warp_affine_u8_4k_b256", "warp_affine_u8_kernel<3>"
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C
+
+    def setup(self, stream):
+        import ctypes as C
+        from kornia_rs.hip import DeviceBuffer
+        from kornia_rs._ffi import lib
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.W * self.H * self.C, stream, zeroed=False)
+        self.m = (C.c_float * 6)()
+        lib.kh_get_rotation_matrix2d(self.W / 2.0, self.H / 2.0, 12.0, 0.9, self.m)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        n = self.W * self.H * self.C
+        check(lib.kh_warp_affine_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.W, self.H,
+                                    self.C, self.m, self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::warp::warp_affine_u8 (rot 12 deg, scale 0.9), Q16 span + Q10 bilinear",
+                "src": "3840x2160x3 u8", "dst": "same", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        m = list(self.m)
+        return self._time_cpu(lambda O: O.warp_affine_u8(img, m, self.W, self.H), "warp_affine_u8")
+
+
+class FusedRgb640(U8Images):
+    """fused pipeline read_u8rgb_bilinear -> normalize -> write_chw_f32, 1920x1080 RGB8 -> 640x640
+    (the reference's own `probe_fused_1080p` configuration, P/cuda/fusion.rs:849-885), batch 1024."""
+
+    name, kernel = "fused_rgb8_1080p_to_chw640_f32_b1024", "fused_pipeline_kernel<chw>"
+    W, H, C, D = 1920, 1080, 3, 640
+    dtype = "f32"
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * (self.D * self.D * 12 + self.W * self.H * 3)  # write + whole source once
+
+    def setup(self, stream):
+        import ctypes as C
+        from kornia_rs.hip import DeviceBuffer
+        from kornia_rs import _ffi
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * 3 * self.D * self.D * 4, stream, zeroed=False)
+        st = (_ffi.FusedStage * 3)()
+        st[0].kind = _ffi.KH_FUSE_READ_U8RGB_BILINEAR
+        st[0].u[0], st[0].u[1], st[0].u[2], st[0].u[3] = self.W, self.H, self.D, self.D
+        st[1].kind = _ffi.KH_FUSE_NORMALIZE
+        for i in range(3):
+            st[1].f[i], st[1].f[3 + i] = 1.0 / 255.0, 0.0
+        st[2].kind = _ffi.KH_FUSE_WRITE_CHW_F32
+        self.h = C.c_void_p()
+        _ffi.check(_ffi.lib.kh_fused_pipeline_build(C.cast(st, C.c_void_p), 3, self.D, self.D, self.N, 3 * self.D * self.D,
+                                                     C.byref(self.h)))
+        n = self.W * self.H * 3
+        self.ptrs = (C.c_void_p * self.N)(*[self.src.ptr + k * n for k in range(self.N)])
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        check(lib.kh_fused_pipeline_launch(self.h, self.stream.cuda_stream_ptr, self.ptrs, self.N, self.W * self.H * 3,
+                                           self.dst.ptr, self.N * 3 * self.D * self.D))
+
+    def describe(self):
+        return {"workload": self.name, "op": "cuda::fusion FusedPipeline [read_u8rgb_bilinear, normalize, write_chw_f32]",
+                "src": "1920x1080x3 u8", "dst": "3x640x640 f32", "batch_per_gpu": self.N,
+                "parallelism": "batch-sharded, no collective", "launches_per_step": (self.N + 31) // 32}
+
+    def cpu_baseline(self):
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        return self._time_cpu(lambda O: O.fused_pipeline(img, self.D, self.D, [("normalize", [1 / 255.0] * 3, [0.0] * 3)], "chw"),
+                              "the fused pipeline")
+
+
 WORKLOADS = {
     "nv12_chw": lambda a: NorthStarNV12(a.batch or 1024, 0),
     "nv12_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640),
     "resize_224": lambda a: ResizeBilinear(a.batch or 256),
     "gaussian_4k": lambda a: Gaussian4K(a.batch or 256),
     "undistort_warp_4k": lambda a: UndistortWarp4K(a.batch or 256),
+    "gaussian_u8_4k": lambda a: GaussianU8_4K(a.batch or 256),
+    "warp_affine_u8_4k": lambda a: WarpAffineU8_4K(a.batch or 256),
+    "fused_rgb_640": lambda a: FusedRgb640(a.batch or 1024),
 }
 
 

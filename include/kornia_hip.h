@@ -381,6 +381,34 @@ KH_API int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t*
                                 int64_t dst_stride);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Fused per-pixel pipelines — replaces FusedPipeline::{build, build_batched, launch,
+ * launch_batched, generated_source} and the v1 stage library (P/cuda/fusion.rs:196-690): a source
+ * stage produces an f32 RGB value for each destination pixel, map stages transform it in registers,
+ * a sink stage writes it.  No run-time compiler: the stage program travels in the kernel arguments.
+ * Stage parameters:  READ_U8RGB_BILINEAR u = {src_w, src_h, dst_w, dst_h} (half-pixel grid, value in
+ * [0, 255]);  NORMALIZE f = {scale r,g,b, bias r,g,b};  RGB_TO_GRAY, WRITE_CHW_F32 (3 planes),
+ * WRITE_C1_F32 (lane x): none.  `batch` images are read through per-image pointers and written
+ * `out_elems_per_image` floats apart (ignored for batch == 1).  Errors follow FusionError: shape
+ * problems -> KH_ERR_INVALID_ARG ("invalid pipeline: ..."), too many stages -> KH_ERR_TOO_LARGE,
+ * short buffers at launch -> KH_ERR_SLICE_TOO_SMALL (pass 0 to skip a length check).           */
+enum { KH_FUSE_READ_U8RGB_BILINEAR = 1, KH_FUSE_NORMALIZE = 16, KH_FUSE_RGB_TO_GRAY = 17, KH_FUSE_WRITE_CHW_F32 = 32,
+       KH_FUSE_WRITE_C1_F32 = 33 };
+typedef struct kh_fused_stage {
+    int32_t kind;
+    int32_t u[4];
+    float f[6];
+} kh_fused_stage;
+typedef struct kh_fused_pipeline_s* kh_fused_pipeline_t;
+KH_API int32_t kh_fused_pipeline_build(const kh_fused_stage* stages, int32_t nstages, int32_t dst_w, int32_t dst_h,
+                                       int32_t batch, int64_t out_elems_per_image, kh_fused_pipeline_t* out);
+/* srcs: HOST array of `nsrcs` device pointers (== the built batch)                              */
+KH_API int32_t kh_fused_pipeline_launch(kh_fused_pipeline_t pipeline, kh_stream_t stream, const uint8_t* const* srcs,
+                                        int32_t nsrcs, int64_t src_bytes_each, float* dst, int64_t dst_elems);
+/* the stage program as text (analogue of generated_source); returns its length                 */
+KH_API int32_t kh_fused_pipeline_describe(kh_fused_pipeline_t pipeline, char* buf, size_t n);
+KH_API void kh_fused_pipeline_destroy(kh_fused_pipeline_t pipeline);
+
+/* ------------------------------------------------------------------------------------------ */
 /* normalize / crop / flip (P/normalize.rs:56-420, P/crop.rs:187-240, P/flip.rs:39-360).  The
  * reference has no device twin for normalize; these follow its CPU arithmetic: true division
  * in normalize_mean_std, `(x-min_v)*(max-min)/(max_v-min_v)+min` in normalize_min_max, the

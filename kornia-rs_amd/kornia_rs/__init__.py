@@ -12,6 +12,7 @@ from .tensor import Tensor
 from .image import Image, ImageError
 from .preprocess import Preprocessor, PreprocessError, ResizeMode, SourceFormat
 from . import imgproc
+from . import fusion
 from . import sharding
 
 cuda = hip  # reference module name (kornia_rs.cuda.Stream); same objects, HIP underneath
@@ -19,5 +20,5 @@ cuda = hip  # reference module name (kornia_rs.cuda.Stream); same objects, HIP u
 __version__ = "0.1.0"
 __all__ = [
     "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Image", "ImageError", "Preprocessor",
-    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "hip", "cuda", "sharding",
+    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "fusion", "hip", "cuda", "sharding",
 ]

@@ -31,6 +31,12 @@ KH_PRE_FORCE_GENERIC = 1
 KH_YCC_YCRCB, KH_YCC_YUV = 0, 1
 KH_INTERP_NEAREST, KH_INTERP_BILINEAR, KH_INTERP_BICUBIC, KH_INTERP_LANCZOS = 0, 1, 2, 3
 KH_MORPH_DILATE, KH_MORPH_ERODE = 0, 1
+KH_FUSE_READ_U8RGB_BILINEAR, KH_FUSE_NORMALIZE, KH_FUSE_RGB_TO_GRAY, KH_FUSE_WRITE_CHW_F32, KH_FUSE_WRITE_C1_F32 = 1, 16, 17, 32, 33
+
+
+class FusedStage(C.Structure):
+    """kh_fused_stage (include/kornia_hip.h)."""
+    _fields_ = [("kind", C.c_int32), ("u", C.c_int32 * 4), ("f", C.c_float * 6)]
 KH_BORDER = {"constant": 0, "replicate": 1, "reflect101": 2, "reflect": 3, "wrap": 4}
 KH_MORPH_SHAPE = {"box": 0, "cross": 1, "ellipse": 2}
 KH_GRAD_SOBEL, KH_GRAD_SCHARR = 0, 1
@@ -143,6 +149,11 @@ SIGNATURES = {
     "kh_morph_kernel": (_i32, [_i32, _i32, _i32, _P(C.c_uint8)]),
     "kh_morphology_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _P(C.c_uint8), _i32, _i32, _i32, _P(C.c_uint8),
                                 _i32, _i64, _i64]),
+    # fused pipelines
+    "kh_fused_pipeline_build": (_i32, [_vp, _i32, _i32, _i32, _i32, _i64, _P(_vp)]),
+    "kh_fused_pipeline_launch": (_i32, [_vp, _vp, _P(_vp), _i32, _i64, _vp, _i64]),
+    "kh_fused_pipeline_describe": (_i32, [_vp, C.c_char_p, C.c_size_t]),
+    "kh_fused_pipeline_destroy": (None, [_vp]),
     # pointwise
     "kh_normalize_mean_std_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _P(_f32), _P(_f32)]),
     "kh_normalize_rgb_u8_f32": (_i32, [_vp, _vp, _vp, _i64, _P(_f32), _P(_f32)]),

@@ -130,6 +130,9 @@ void ko_normalize_params(const float mean[3], const float std[3], float scale[3]
 int ko_resize_normalize_to_chw(const uint8_t* src, int sw, int sh, float* dst, int dw, int dh, const float scale[3],
                                const float bias[3], int mode, int antialias);
 
+void ko_fused_pipeline(const uint8_t* src, int sw, int sh, int rdw, int rdh, int dw, int dh, const int* map_kinds,
+                       const float* map_params, int nmaps, int sink, float* dst);
+
 /* ---- pyramid + morphology (ko_pyramid_morph.c) ------------------------------------------------------- */
 void ko_pyrdown_f32(const float* src, int sw, int sh, float* dst, int C);
 void ko_pyrup_f32(const float* src, int sw, int sh, float* dst, int C);

@@ -402,3 +402,42 @@ int ko_resize_normalize_to_chw(const uint8_t* src, int sw, int sh, float* dst, i
     free(hbuf); free(xofs); free(xw); free(yofs); free(yw);
     return 4;
 }
+
+/* ---- fused per-pixel pipelines (P/cuda/fusion.rs) ---------------------------------------------------
+ * source ReadU8RgbBilinear (:545-585) -> maps Normalize (kind 16, :610-616) / RgbToGray (kind 17,
+ * :636-640) -> sink WriteChwF32 (kind 32) / WriteC1F32 (kind 33).  rdw/rdh = the source stage's own
+ * dst size (the half-pixel coefficients are built from it, :538-543).  f32, uncontracted. */
+void ko_fused_pipeline(const uint8_t* src, int sw, int sh, int rdw, int rdh, int dw, int dh, const int* map_kinds,
+                       const float* map_params /* [nmaps][6] */, int nmaps, int sink, float* dst) {
+    const float axv = (float)sw / (float)rdw, ayv = (float)sh / (float)rdh;
+    const float ax = axv, bx = 0.5f * axv - 0.5f, ay = ayv, by = 0.5f * ayv - 0.5f;
+    const size_t plane = (size_t)dw * dh;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            float sxf = ax * (float)x + bx; sxf = sxf > 0.0f ? sxf : 0.0f;
+            float syf = ay * (float)y + by; syf = syf > 0.0f ? syf : 0.0f;
+            unsigned sx0 = (unsigned)sxf; if (sx0 > (unsigned)sw - 1u) sx0 = (unsigned)sw - 1u;
+            unsigned sy0 = (unsigned)syf; if (sy0 > (unsigned)sh - 1u) sy0 = (unsigned)sh - 1u;
+            const unsigned sx1 = sx0 + 1u < (unsigned)sw - 1u ? sx0 + 1u : (unsigned)sw - 1u;
+            const unsigned sy1 = sy0 + 1u < (unsigned)sh - 1u ? sy0 + 1u : (unsigned)sh - 1u;
+            const float wx = sxf - (float)sx0, wy = syf - (float)sy0;
+            const uint8_t *r0 = src + (size_t)sy0 * sw * 3, *r1 = src + (size_t)sy1 * sw * 3;
+            const float w00 = (1.0f - wy) * (1.0f - wx), w01 = (1.0f - wy) * wx, w10 = wy * (1.0f - wx), w11 = wy * wx;
+            float v[3];
+            for (int c = 0; c < 3; ++c)
+                v[c] = w00 * (float)r0[sx0 * 3 + c] + w01 * (float)r0[sx1 * 3 + c] + w10 * (float)r1[sx0 * 3 + c] + w11 * (float)r1[sx1 * 3 + c];
+            for (int i = 0; i < nmaps; ++i) {
+                const float* f = map_params + (size_t)i * 6;
+                if (map_kinds[i] == 16) {
+                    v[0] = v[0] * f[0] + f[3]; v[1] = v[1] * f[1] + f[4]; v[2] = v[2] * f[2] + f[5];
+                } else {
+                    const float g = 0.299f * v[0] + 0.587f * v[1] + 0.114f * v[2];
+                    v[0] = g; v[1] = g; v[2] = g;
+                }
+            }
+            const size_t di = (size_t)y * dw + x;
+            dst[di] = v[0];
+            if (sink == 32) { dst[di + plane] = v[1]; dst[di + 2 * plane] = v[2]; }
+        }
+}

@@ -524,3 +524,23 @@ def morphology_u8(src, op, mask, border="constant", cval=None):
     ko.ko_morphology_u8(src.reshape(-1), w, h, c, out.reshape(-1), {"dilate": 0, "erode": 1}[op], mask.reshape(-1),
                         mask.shape[1], mask.shape[0], BORDER[border], cv)
     return out
+
+
+# ---- fused per-pixel pipelines (P/cuda/fusion.rs) -------------------------------------------------------------
+ko.ko_fused_pipeline.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _f32p]
+
+
+def fused_pipeline(src, dw, dh, maps, sink, read_dst=None):
+    """maps: list of ("normalize", scale, bias) | ("gray",); sink: "chw" | "c1"."""
+    src = np.ascontiguousarray(src, np.uint8)
+    sh, sw, _ = src.shape
+    rdw, rdh = read_dst or (dw, dh)
+    kinds = np.array([16 if m[0] == "normalize" else 17 for m in maps] or [0], np.int32)
+    params = np.zeros((max(len(maps), 1), 6), np.float32)
+    for i, m in enumerate(maps):
+        if m[0] == "normalize":
+            params[i, :3], params[i, 3:] = m[1], m[2]
+    out = np.empty((3 if sink == "chw" else 1, dh, dw), np.float32)
+    ko.ko_fused_pipeline(src.reshape(-1), sw, sh, rdw, rdh, dw, dh, kinds, params.reshape(-1), len(maps),
+                         32 if sink == "chw" else 33, out.reshape(-1))
+    return out
