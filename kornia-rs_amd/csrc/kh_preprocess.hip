@@ -35,6 +35,8 @@ struct PreArgs {
     float pad_value;
     long long src_frame_stride;  // bytes
     long long dst_frame_stride;  // elements
+    float rc_x, rc_y;            // 1 / scale_x, 1 / scale_y
+    int fast_div;                // host-verified: the 3-op quotient equals IEEE division on this grid
 };
 
 // BT.601 limited-range Q20 decode, constants of P/color/yuv/kernels.rs:696-702 and the fused
@@ -59,7 +61,7 @@ template <int FMT, bool WIDE>
 __device__ __forceinline__ void fetch_px(const uint8_t* __restrict__ src, int x, int y,
                                          const PreArgs& a, float px[3]) {
     if constexpr (FMT == KH_FMT_RGB || FMT == KH_FMT_BGR) {
-        const uint8_t* p = src + (long long)y * a.src_pitch + x * a.src_bpp;
+        const uint8_t* p = src + (unsigned)(y * a.src_pitch + x * a.src_bpp);  // < 2^31, host-checked
         int c0, c1, c2;
         if (WIDE && a.src_bpp == 4) {
             const uint32_t q = *reinterpret_cast<const uint32_t*>(p);
@@ -73,12 +75,11 @@ __device__ __forceinline__ void fetch_px(const uint8_t* __restrict__ src, int x,
             px[0] = (float)c2; px[1] = (float)c1; px[2] = (float)c0;
         }
     } else if constexpr (FMT == KH_FMT_GRAY) {
-        float v = (float)src[(long long)y * a.src_pitch + x];
+        float v = (float)src[(unsigned)(y * a.src_pitch + x)];
         px[0] = v; px[1] = v; px[2] = v;
     } else if constexpr (FMT == KH_FMT_NV12) {
-        int yv = src[(long long)y * a.src_w + x];
-        const uint8_t* uv =
-            src + (long long)a.src_w * a.src_h + (long long)(y >> 1) * a.src_w + (x >> 1) * 2;
+        int yv = src[(unsigned)(y * a.src_w + x)];
+        const uint8_t* uv = src + (unsigned)(a.src_w * a.src_h + (y >> 1) * a.src_w + (x >> 1) * 2);
         if constexpr (WIDE) {
             const uint32_t q = *reinterpret_cast<const uint16_t*>(uv);
             yuv_to_rgbf(yv, q & 0xFF, q >> 8, px);
@@ -86,7 +87,7 @@ __device__ __forceinline__ void fetch_px(const uint8_t* __restrict__ src, int x,
             yuv_to_rgbf(yv, uv[0], uv[1], px);
         }
     } else {  // YUYV
-        const uint8_t* grp = src + (long long)y * a.src_pitch + (x >> 1) * 4;
+        const uint8_t* grp = src + (unsigned)(y * a.src_pitch + (x >> 1) * 4);
         if constexpr (WIDE) {
             const uint32_t q = *reinterpret_cast<const uint32_t*>(grp);
             yuv_to_rgbf((x & 1) ? (q >> 16) & 0xFF : q & 0xFF, (q >> 8) & 0xFF, q >> 24, px);
@@ -181,6 +182,27 @@ __device__ __forceinline__ float to_out<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ unsigned short to_out<unsigned short>(float v) { return f2h_bits(v); }
 
+// The generic kernel is VALU-issue bound (about 250 instructions per pixel for NV12 bilinear, 17
+// IEEE divisions of ~10 instructions each per 4-pixel thread), so its divisions use the 3-operation
+// quotient q = n*rc; r = fma(-q, d, n); q' = fma(r, rc, q) wherever that is PROVEN equal to IEEE
+// division:
+//  * x / 255: exhaustively equal for every finite float (tests/test_host_math.py sweeps all 2^32
+//    patterns through the host twin with the same IEEE fma); `r == 0 ? q : ...` keeps -0 -> -0.
+//  * (o - pad) / scale (plan_pixel, P/preprocess.rs:437-448): the host evaluates both forms for every
+//    destination column and row of the launch (dst_w + dst_h values) and sets `fast_div` only if all
+//    agree bit for bit; otherwise the kernel divides.
+__device__ __forceinline__ float div255_any(float x) {
+    const float rc = 1.0f / 255.0f;
+    const float q = x * rc;
+    const float r = __builtin_fmaf(-q, 255.0f, x);
+    return r == 0.0f ? q : __builtin_fmaf(r, rc, q);
+}
+__host__ __device__ __forceinline__ float quot3(float n, float d, float rc) {
+    const float q = n * rc;
+    const float r = __builtin_fmaf(-q, d, n);
+    return __builtin_fmaf(r, rc, q);
+}
+
 // 64x4-thread blocks; a thread owns kGenPx destination pixels of one row, 64 apart, so every
 // load / store instruction of a wave still covers 64 consecutive pixels while kGenPx independent
 // tap gathers are in flight per lane (the kernel is latency-bound: 8 waves/SIMD x 1 pixel measured
@@ -196,14 +218,16 @@ __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __re
     if (ox0 >= a.dst_w || oy >= a.dst_h) return;
     const uint8_t* src = src_base + (long long)blockIdx.z * a.src_frame_stride;
     OutT* dst = dst_base + (long long)blockIdx.z * a.dst_frame_stride;
-    const float sy = ((float)oy - a.pad_y) / a.scale_y;
+    const float ny = (float)oy - a.pad_y;
+    const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
 
     float px[kGenPx][3];
 #pragma unroll
     for (int j = 0; j < kGenPx; ++j) {
         const int ox = ox0 + 64 * j;
         // plan_pixel (P/preprocess.rs:437-448)
-        const float sx = ((float)ox - a.pad_x) / a.scale_x;
+        const float nx = (float)ox - a.pad_x;
+        const float sx = a.fast_div ? quot3(nx, a.scale_x, a.rc_x) : nx / a.scale_x;
         const bool inside = ox < a.dst_w &&
                             !(sx < 0.0f || sy < 0.0f || sx >= (float)a.src_w || sy >= (float)a.src_h);
         if (inside) {
@@ -219,9 +243,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __re
         const int ox = ox0 + 64 * j;
         if (ox >= a.dst_w) break;
         const int i = oy * a.dst_w + ox;
-        dst[i] = to_out<OutT>((px[j][0] / 255.0f - a.m0) * a.is0);
-        dst[pixels + i] = to_out<OutT>((px[j][1] / 255.0f - a.m1) * a.is1);
-        dst[2 * pixels + i] = to_out<OutT>((px[j][2] / 255.0f - a.m2) * a.is2);
+        dst[i] = to_out<OutT>((div255_any(px[j][0]) - a.m0) * a.is0);
+        dst[pixels + i] = to_out<OutT>((div255_any(px[j][1]) - a.m1) * a.is1);
+        dst[2 * pixels + i] = to_out<OutT>((div255_any(px[j][2]) - a.m2) * a.is2);
     }
 }
 
@@ -301,6 +325,28 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
         store4<NT>(dst + c * plane + off, o[c][0], o[c][1], o[c][2], o[c][3]);
 }
 
+// Does quot3 reproduce IEEE division for every (o - pad) / scale the launch will evaluate?  dst_w +
+// dst_h host evaluations (microseconds), memoised on the last geometry.
+bool plan_division_is_exact(const PreArgs& a) {
+    struct Key { float sx, sy, px, py; int w, h; bool ok; };
+    static thread_local Key last = {0, 0, 0, 0, 0, 0, false};
+    if (last.w == a.dst_w && last.h == a.dst_h && last.sx == a.scale_x && last.sy == a.scale_y && last.px == a.pad_x &&
+        last.py == a.pad_y)
+        return last.ok;
+    auto same = [](float u, float v) { return __builtin_bit_cast(uint32_t, u) == __builtin_bit_cast(uint32_t, v); };
+    bool ok = a.scale_x != 0.0f && a.scale_y != 0.0f;
+    for (int o = 0; ok && o < a.dst_w; ++o) {
+        const float n = (float)o - a.pad_x;
+        ok = same(quot3(n, a.scale_x, a.rc_x), n / a.scale_x);
+    }
+    for (int o = 0; ok && o < a.dst_h; ++o) {
+        const float n = (float)o - a.pad_y;
+        ok = same(quot3(n, a.scale_y, a.rc_y), n / a.scale_y);
+    }
+    last = Key{a.scale_x, a.scale_y, a.pad_x, a.pad_y, a.dst_w, a.dst_h, ok};
+    return ok;
+}
+
 bool identity_fast_path(const kh_preprocess_params* p, const uint8_t* src, const void* dst) {
     return !(p->flags & KH_PRE_FORCE_GENERIC) && p->fmt == KH_FMT_NV12 &&
            p->out_dtype == KH_OUT_F32 &&
@@ -338,7 +384,8 @@ int32_t validate(const kh_preprocess_params* p, const uint8_t* src, const void* 
                "preprocess: pitch %d shorter than a %d-px row", p->src_pitch, p->src_w);
     // 32-bit kernel indexing guard (P/preprocess.rs:1336-1339).
     KH_REQUIRE((int64_t)p->dst_w * p->dst_h <= kI32Max / 4 &&
-                   (int64_t)p->src_pitch * p->src_h <= kI32Max,
+                   (int64_t)p->src_pitch * p->src_h <= kI32Max &&
+                   (p->fmt != KH_FMT_NV12 || (int64_t)p->src_w * p->src_h * 3 / 2 <= kI32Max),
                KH_ERR_TOO_LARGE, "preprocess: dimensions exceed the 32-bit kernel index limit");
     KH_REQUIRE(p->nframes <= 65535, KH_ERR_TOO_LARGE,
                "preprocess: at most 65535 frames per launch, got %d", p->nframes);
@@ -409,6 +456,9 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
     a.pad_value = p->pad_value;
     a.src_frame_stride = p->src_frame_stride;
     a.dst_frame_stride = p->dst_frame_stride;
+    a.rc_x = 1.0f / a.scale_x;
+    a.rc_y = 1.0f / a.scale_y;
+    a.fast_div = plan_division_is_exact(a) ? 1 : 0;
     hipStream_t s = as_hip(stream);
 
     if (identity_fast_path(p, src, dst)) {

@@ -56,6 +56,8 @@ void ko_preprocess_affine(int mode, int sw, int sh, int dw, int dh, float out[4]
 uint16_t ko_f2h(float f);
 /* see ko_preprocess.c: exhaustively-checked x/255 shortcut used by the device fast path */
 float ko_div255_fma(float x);
+long long ko_div255_fma_mismatches(uint32_t lo_bits, uint32_t hi_bits);
+int ko_plan_div_mismatches(float pad, float scale, int count);
 
 /* ---- colour: gray (P/color/gray/kernels.rs) ----------------------------------------------- */
 void ko_gray_from_rgb_u8(const uint8_t* src, uint8_t* dst, size_t npixels);

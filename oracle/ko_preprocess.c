@@ -247,3 +247,50 @@ float ko_div255_fma(float x) {
     const float r = fmaf(-q, 255.0f, x);
     return fmaf(r, rc, q);
 }
+
+/* Exhaustive check of the same sequence against IEEE division for EVERY float whose bit pattern lies
+ * in [lo_bits, hi_bits] (and its negation): returns the number of inputs where the two differ.
+ * tests/test_host_math.py sweeps all floats of magnitude < 65536, which covers every value the
+ * generic preprocess kernel can feed it (blended / Lanczos-filtered bytes). */
+/* the generic kernel's form: `r == 0 ? q : fma(r, rc, q)` (keeps -0 -> -0) */
+float ko_div255_any(float x) {
+    const float rc = 1.0f / 255.0f;
+    const float q = x * rc;
+    const float r = fmaf(-q, 255.0f, x);
+    return r == 0.0f ? q : fmaf(r, rc, q);
+}
+
+long long ko_div255_fma_mismatches(uint32_t lo_bits, uint32_t hi_bits) {
+    long long bad = 0;
+#pragma omp parallel for schedule(dynamic, 1 << 20) reduction(+ : bad)
+    for (long long b = (long long)lo_bits; b <= (long long)hi_bits; ++b) {
+        union { uint32_t u; float f; } v;
+        v.u = (uint32_t)b;
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const float x = sgn ? -v.f : v.f;
+            union { uint32_t u; float f; } a, c;
+            a.f = ko_div255_any(x);
+            c.f = x / 255.0f;
+            bad += a.u != c.u;
+        }
+    }
+    return bad;
+}
+
+/* The generic kernel's plan_pixel division (o - pad) / scale done as q = n*rc; r = fma(-q, scale, n);
+ * fma(r, rc, q) with rc = 1/scale: number of destination indices o in [0, count) for which that differs
+ * from IEEE division.  The product checks this on the host per (pad, scale, count) before trusting the
+ * short sequence; this twin lets the tests cross-check that decision. */
+int ko_plan_div_mismatches(float pad, float scale, int count) {
+    const float rc = 1.0f / scale;
+    int bad = 0;
+    for (int o = 0; o < count; ++o) {
+        const float n = (float)o - pad;
+        const float q = n * rc, r = fmaf(-q, scale, n);
+        union { uint32_t u; float f; } a, c;
+        a.f = fmaf(r, rc, q);
+        c.f = n / scale;
+        bad += a.u != c.u;
+    }
+    return bad;
+}
