@@ -320,19 +320,49 @@ __device__ __forceinline__ void put_zero_u8(uint8_t* o) {
     put_u8<C>(o, z);
 }
 
+// Two horizontally adjacent pixels of one row: 2*C contiguous bytes fetched with one or two unaligned
+// loads instead of 2*C byte loads (the gathers were issue-bound on byte loads).  At the last column
+// the reference replicates the pixel (xi1 == xi), taken on the byte path.
+typedef uint16_t u16u __attribute__((aligned(1)));
+typedef uint64_t u64u __attribute__((aligned(1)));
+template <int C>
+__device__ __forceinline__ void load_pair(const uint8_t* __restrict__ row, int xi, bool has_next, uint32_t p0[C], uint32_t p1[C]) {
+    const uint8_t* p = row + xi * C;
+    if (!has_next) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) p0[c] = p1[c] = p[c];
+        return;
+    }
+    if constexpr (C == 1) {
+        const uint32_t v = *reinterpret_cast<const u16u*>(p);
+        p0[0] = v & 0xffu; p1[0] = v >> 8;
+    } else if constexpr (C == 3) {
+        const uint32_t lo = *reinterpret_cast<const u32u*>(p);
+        const uint32_t hi = *reinterpret_cast<const u16u*>(p + 4);
+        p0[0] = lo & 0xffu; p0[1] = (lo >> 8) & 0xffu; p0[2] = (lo >> 16) & 0xffu;
+        p1[0] = lo >> 24; p1[1] = hi & 0xffu; p1[2] = hi >> 8;
+    } else {
+        const uint64_t v = *reinterpret_cast<const u64u*>(p);
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { p0[c] = (lo >> (8 * c)) & 0xffu; p1[c] = (hi >> (8 * c)) & 0xffu; }
+    }
+}
+
 // bilinear_sample_u8_valid (P/warp/common.rs:79-165): xi, yi in range; fx, fy in Q10
 template <int C>
 __device__ __forceinline__ void sample_q10(const uint8_t* __restrict__ src, int sw, int sh, int xi, int yi, uint32_t fx,
                                            uint32_t fy, uint8_t* o) {
     const uint32_t fx1 = 1024u - fx, fy1 = 1024u - fy;
-    const int xi1 = xi + 1 < sw ? xi + 1 : xi, yi1 = yi + 1 < sh ? yi + 1 : yi;
-    const uint8_t* r0 = src + (long long)yi * sw * C;
-    const uint8_t* r1 = src + (long long)yi1 * sw * C;
+    const bool has_next = xi + 1 < sw;
+    const int yi1 = yi + 1 < sh ? yi + 1 : yi;
+    uint32_t p00[C], p01[C], p10[C], p11[C];
+    load_pair<C>(src + (unsigned)(yi * sw) * C, xi, has_next, p00, p01);   // < 2^31 bytes, host-checked
+    load_pair<C>(src + (unsigned)(yi1 * sw) * C, xi, has_next, p10, p11);
     uint32_t v[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const uint32_t p00 = r0[xi * C + c], p01 = r0[xi1 * C + c], p10 = r1[xi * C + c], p11 = r1[xi1 * C + c];
-        const uint32_t top = p00 * fx1 + p01 * fx, bot = p10 * fx1 + p11 * fx;
+        const uint32_t top = p00[c] * fx1 + p01[c] * fx, bot = p10[c] * fx1 + p11[c] * fx;
         v[c] = ((top * fy1 + bot * fy + (1u << 19)) >> 20) & 0xffu;
     }
     put_u8<C>(o, v);
@@ -419,30 +449,46 @@ struct Mat9 { float m[9]; };
 // warp_affine_u8 (P/warp/affine.rs:373-445): per-row valid span (P/warp/span.rs:61-85), Q16
 // coordinates stepped from the span start with wrapping adds (P/warp/kernels.rs:386-415) — here
 // sx_q_lo + (x - x_lo) * dsx_q in wrapping arithmetic, the same value.
-template <int C>
-__global__ __launch_bounds__(kBx* kBy) void warp_affine_u8_kernel(ImgU8 im, Mat6 mi, int dsx_q, int dsy_q) {
-    KH_U8_PROLOGUE
-    const uint8_t* src = im.src + (long long)bz_ * im.src_stride;
-    uint8_t* o = im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C;
+//
+// The span algebra (4 IEEE divisions, saturating i64 conversions) depends on the row only; doing it per
+// pixel made the gather VALU-bound (r01m: 16.7 ms / 256 4K images, slower than the f32 warp).  A
+// dst_h-thread pre-kernel writes one RowSpan per row into stream-ordered scratch shared by the batch.
+struct AffineRow { int lo, hi; uint32_t sx_lo, sy_lo; };
+__global__ __launch_bounds__(kBlock) void affine_rows_kernel(AffineRow* __restrict__ rows, int dw, int dh, int sw, int sh, Mat6 mi) {
+    const int y = blockIdx.x * kBlock + threadIdx.x;
+    if (y >= dh) return;
     const float dsx = mi.m[0], dsy = mi.m[3];
     const float sx0 = mi.m[1] * (float)y + mi.m[2], sy0 = mi.m[4] * (float)y + mi.m[5];
-    long long lo = 0, hi = im.dw;
+    long long lo = 0, hi = dw;
     constrain_span(dsx, sx0, true, 1e-12f, lo, hi);
-    constrain_span(dsx, sx0 - (float)im.sw, false, 1e-12f, lo, hi);
+    constrain_span(dsx, sx0 - (float)sw, false, 1e-12f, lo, hi);
     bool empty = lo >= hi;
     if (!empty) {
         constrain_span(dsy, sy0, true, 1e-12f, lo, hi);
-        constrain_span(dsy, sy0 - (float)im.sh, false, 1e-12f, lo, hi);
+        constrain_span(dsy, sy0 - (float)sh, false, 1e-12f, lo, hi);
         empty = lo >= hi;
     }
-    lo = min(max(lo, 0ll), (long long)im.dw);
-    hi = min(max(hi, 0ll), (long long)im.dw);
-    if (empty || lo >= hi || x < lo || x >= hi) { put_zero_u8<C>(o); return; }
-    const int x_lo = (int)lo;
-    const uint32_t sx_lo = (uint32_t)f2i_sat((sx0 + dsx * (float)x_lo) * 65536.0f);
-    const uint32_t sy_lo = (uint32_t)f2i_sat((sy0 + dsy * (float)x_lo) * 65536.0f);
-    const int sx_q = (int)(sx_lo + (uint32_t)(x - x_lo) * (uint32_t)dsx_q);
-    const int sy_q = (int)(sy_lo + (uint32_t)(x - x_lo) * (uint32_t)dsy_q);
+    lo = min(max(lo, 0ll), (long long)dw);
+    hi = min(max(hi, 0ll), (long long)dw);
+    AffineRow r{0, 0, 0u, 0u};
+    if (!empty && lo < hi) {
+        r.lo = (int)lo;
+        r.hi = (int)hi;
+        r.sx_lo = (uint32_t)f2i_sat((sx0 + dsx * (float)r.lo) * 65536.0f);
+        r.sy_lo = (uint32_t)f2i_sat((sy0 + dsy * (float)r.lo) * 65536.0f);
+    }
+    rows[y] = r;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void warp_affine_u8_kernel(ImgU8 im, const AffineRow* __restrict__ rows, int dsx_q, int dsy_q) {
+    KH_U8_PROLOGUE
+    const uint8_t* src = im.src + (long long)bz_ * im.src_stride;
+    uint8_t* o = im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C;
+    const AffineRow r = rows[y];
+    if (x < r.lo || x >= r.hi) { put_zero_u8<C>(o); return; }
+    const int sx_q = (int)(r.sx_lo + (uint32_t)(x - r.lo) * (uint32_t)dsx_q);
+    const int sy_q = (int)(r.sy_lo + (uint32_t)(x - r.lo) * (uint32_t)dsy_q);
     // The span keeps the indices in range in exact arithmetic; the clamp only matters where Q16
     // rounding drift would take the reference's unchecked sampler outside the image.
     const int xi = min(max(sx_q >> 16, 0), im.sw - 1), yi = min(max(sy_q >> 16, 0), im.sh - 1);
@@ -451,30 +497,44 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_u8_kernel(ImgU8 im, Mat6
 
 // warp_perspective_u8 (P/warp/perspective.rs:179-322): rows whose denominator keeps one sign get
 // the analytic span, other rows the bounds-checked sampler on every column; coordinates are
-// evaluated directly per column (perspective_coord_at, P/warp/kernels.rs:107-122).
+// evaluated directly per column (perspective_coord_at, P/warp/kernels.rs:107-122).  Row terms come
+// from the same kind of pre-kernel as the affine warp.
+struct PerspRow { float nx0, ny0, nd0, dnx, dny, dnd; int lo, hi; };
+__global__ __launch_bounds__(kBlock) void persp_rows_kernel(PerspRow* __restrict__ rows, int dw, int dh, int sw, int sh, Mat9 inv) {
+    const int y = blockIdx.x * kBlock + threadIdx.x;
+    if (y >= dh) return;
+    const float yf = (float)y, swf = (float)sw, shf = (float)sh;
+    PerspRow r;
+    r.nx0 = inv.m[1] * yf + inv.m[2]; r.ny0 = inv.m[4] * yf + inv.m[5]; r.nd0 = inv.m[7] * yf + inv.m[8];
+    r.dnx = inv.m[0]; r.dny = inv.m[3]; r.dnd = inv.m[6];
+    r.lo = 0; r.hi = dw;
+    const float nd_end = r.nd0 + r.dnd * ((float)dw - 1.0f);
+    const bool pos = r.nd0 > 1e-6f && nd_end > 1e-6f, neg = r.nd0 < -1e-6f && nd_end < -1e-6f;
+    if (pos || neg) {
+        if (neg) { r.nx0 = -r.nx0; r.ny0 = -r.ny0; r.nd0 = -r.nd0; r.dnx = -r.dnx; r.dny = -r.dny; r.dnd = -r.dnd; }
+        long long lo = 0, hi = dw;
+        constrain_span(r.dnx, r.nx0, true, 0.0f, lo, hi);
+        constrain_span(r.dnx - swf * r.dnd, r.nx0 - swf * r.nd0, false, 0.0f, lo, hi);
+        constrain_span(r.dny, r.ny0, true, 0.0f, lo, hi);
+        constrain_span(r.dny - shf * r.dnd, r.ny0 - shf * r.nd0, false, 0.0f, lo, hi);
+        lo = min(max(lo, 0ll), (long long)dw);
+        hi = min(max(hi, 0ll), (long long)dw);
+        if (lo >= hi) { lo = 0; hi = 0; }
+        r.lo = (int)lo;
+        r.hi = (int)hi;
+    }
+    rows[y] = r;
+}
+
 template <int C>
-__global__ __launch_bounds__(kBx* kBy) void warp_perspective_u8_kernel(ImgU8 im, Mat9 inv) {
+__global__ __launch_bounds__(kBx* kBy) void warp_perspective_u8_kernel(ImgU8 im, const PerspRow* __restrict__ rows) {
     KH_U8_PROLOGUE
     const uint8_t* src = im.src + (long long)bz_ * im.src_stride;
     uint8_t* o = im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C;
-    const float yf = (float)y, swf = (float)im.sw, shf = (float)im.sh;
-    float nx0 = inv.m[1] * yf + inv.m[2], ny0 = inv.m[4] * yf + inv.m[5], nd0 = inv.m[7] * yf + inv.m[8];
-    float dnx = inv.m[0], dny = inv.m[3], dnd = inv.m[6];
-    const float nd_end = nd0 + dnd * ((float)im.dw - 1.0f);
-    const bool pos = nd0 > 1e-6f && nd_end > 1e-6f, neg = nd0 < -1e-6f && nd_end < -1e-6f;
-    if (pos || neg) {
-        if (neg) { nx0 = -nx0; ny0 = -ny0; nd0 = -nd0; dnx = -dnx; dny = -dny; dnd = -dnd; }
-        long long lo = 0, hi = im.dw;
-        constrain_span(dnx, nx0, true, 0.0f, lo, hi);
-        constrain_span(dnx - swf * dnd, nx0 - swf * nd0, false, 0.0f, lo, hi);
-        constrain_span(dny, ny0, true, 0.0f, lo, hi);
-        constrain_span(dny - shf * dnd, ny0 - shf * nd0, false, 0.0f, lo, hi);
-        lo = min(max(lo, 0ll), (long long)im.dw);
-        hi = min(max(hi, 0ll), (long long)im.dw);
-        if (lo >= hi || x < lo || x >= hi) { put_zero_u8<C>(o); return; }
-    }
+    const PerspRow r = rows[y];
+    if (x < r.lo || x >= r.hi) { put_zero_u8<C>(o); return; }
     const float xf_ = (float)x;
-    const float nx = nx0 + dnx * xf_, ny = ny0 + dny * xf_, nd = nd0 + dnd * xf_;
+    const float nx = r.nx0 + r.dnx * xf_, ny = r.ny0 + r.dny * xf_, nd = r.nd0 + r.dnd * xf_;
     const float inv_nd = 1.0f / nd;
     sample_q10_checked<C>(src, im.sw, im.sh, nx * inv_nd, ny * inv_nd, o);
 }
@@ -591,8 +651,13 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     const int dsx_q = f2i_sat(mi.m[0] * 65536.0f), dsy_q = f2i_sat(mi.m[3] * 65536.0f);
     const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
     KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_affine_u8: batch x tiles exceeds one launch");
-    KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, mi, dsx_q, dsy_q);
-    return check_launch("kh_warp_affine_u8");
+    AffineRow* rows = nullptr;  // per-row spans, stream-ordered scratch shared by the batch
+    if (int32_t rc = kh_malloc_async((void**)&rows, sizeof(AffineRow) * (size_t)dh, 0, stream)) return rc;
+    hipLaunchKernelGGL(affine_rows_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, as_hip(stream), rows, dw, dh, sw, sh, mi);
+    KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const AffineRow*)rows, dsx_q, dsy_q);
+    const int32_t rc = check_launch("kh_warp_affine_u8");
+    (void)kh_free_async(rows, stream);
+    return rc;
 }
 
 int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh,
@@ -606,8 +671,13 @@ int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, uint8_t* 
     if (batch == 0) return KH_OK;
     const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
     KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_perspective_u8: batch x tiles exceeds one launch");
-    KH_DISPATCH_C(warp_perspective_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, inv);
-    return check_launch("kh_warp_perspective_u8");
+    PerspRow* rows = nullptr;
+    if (int32_t rc = kh_malloc_async((void**)&rows, sizeof(PerspRow) * (size_t)dh, 0, stream)) return rc;
+    hipLaunchKernelGGL(persp_rows_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, as_hip(stream), rows, dw, dh, sw, sh, inv);
+    KH_DISPATCH_C(warp_perspective_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const PerspRow*)rows);
+    const int32_t rc = check_launch("kh_warp_perspective_u8");
+    (void)kh_free_async(rows, stream);
+    return rc;
 }
 
 }  // extern "C"
