@@ -238,121 +238,10 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
     }
 }
 
-// ---- rolling-column kernel, two columns per lane ---------------------------------------------------
-// Same walk, but a lane owns TWO adjacent flat columns (a wave 128): main loads / stores are 8 bytes
-// per lane, the horizontal halo (unchanged, <= 32 floats a side) is amortised over twice the columns,
-// and the arithmetic is written on 2-vectors so it issues as packed v_pk_mul_f32 / v_pk_add_f32 — the
-// 7x7 f32 case was within ~25 % of the VALU issue limit with one column per lane (28 mul/add + 7 LDS
-// reads per element).  Per element the operations and their order are exactly those of
-// sep_roll_kernel (mul then add, ascending taps), so results are bit-identical.  C is a template
-// parameter here so every LDS tap offset is an immediate.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef f32x2 f32x2_u __attribute__((aligned(4)));
-constexpr int kTF2 = 512;  // flat floats per 256-thread block row
-
-template <int K, int C, bool GRAD>
-__global__ __launch_bounds__(kBlock) void sep_roll2_kernel(FilterArgs a, TapsK kx, TapsK ky) {
-    __shared__ float rowbuf[4][196];  // 128 + 2*32 floats + a dummy slot
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    constexpr int H = K / 2, halo = H * C;
-    static_assert(halo <= 32, "halo does not fit");
-    unsigned tx, ty, bz;
-    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
-    const int gx0 = tx * kTF2 + wv * 128;
-    if (gx0 >= a.rowlen) return;
-    const int y0 = ty * a.th;
-    const float* __restrict__ src = a.src + (long long)bz * a.src_stride;
-    float* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
-    float* buf = rowbuf[wv];
-
-    const int gx = gx0 + 2 * lane;  // first of this lane's two columns
-    const bool ok0 = gx < a.rowlen, ok1 = gx + 1 < a.rowlen;
-    // Unconditional clamped loads (see sep_roll_kernel).  A pair that straddles the end of the row is
-    // fetched from rowlen-2 and shifted; rowlen >= 2 is checked on the host.
-    const int cx_m = min(gx, a.rowlen - 2);
-    const bool shifted = gx > cx_m;  // gx == rowlen-1 (or beyond): element 0 of the pair is loaded.y
-    const bool is_halo = lane < 2 * halo;
-    const int hgx = lane < halo ? gx0 - halo + lane : gx0 + 128 + (lane - halo);
-    const bool hgx_ok = is_halo && hgx >= 0 && hgx < a.rowlen;
-    const int cx_h = is_halo ? min(max(hgx, 0), a.rowlen - 1) : min(gx, a.rowlen - 1);
-    const int hs = is_halo ? (lane < halo ? lane : 128 + lane) : 195;
-    const int nrows = min(a.th, a.rows - y0) + 2 * H;
-    int pf_row = y0 - H;
-
-    f32x2 qm[K];
-    float qh[K];
-    auto prefetch = [&](f32x2& m, float& hv) {
-        const int base = min(max(pf_row, 0), a.rows - 1) * a.rowlen;
-        m = *reinterpret_cast<const f32x2_u*>(src + base + cx_m);
-        hv = src[base + cx_h];
-        ++pf_row;
-    };
-#pragma unroll
-    for (int p = 0; p < K; ++p) prefetch(qm[p], qh[p]);
-
-    f32x2 ring[K], ring2[GRAD ? K : 1];
-#pragma unroll
-    for (int i = 0; i < K; ++i) { ring[i] = f32x2{0.0f, 0.0f}; if constexpr (GRAD) ring2[i] = f32x2{0.0f, 0.0f}; }
-
-    int out_off = (y0 - 2 * H) * a.rowlen + gx;
-    const float* tap = buf + 2 * lane;  // tap i of column j: tap[i*C + j]
-    for (int rb = 0; rb < nrows; rb += K) {
-#pragma unroll
-        for (int p = 0; p < K; ++p) {
-            const int r = rb + p;
-            const int row = y0 - H + r;
-            const bool row_ok = row >= 0 && row < a.rows;
-            const f32x2 raw = qm[p];
-            const float m0 = (row_ok && ok0) ? (shifted ? raw.y : raw.x) : 0.0f;
-            const float m1 = (row_ok && ok1) ? raw.y : 0.0f;
-            const float hv = (row_ok && hgx_ok) ? qh[p] : 0.0f;
-            prefetch(qm[p], qh[p]);
-            buf[halo + 2 * lane] = m0;
-            buf[halo + 2 * lane + 1] = m1;
-            buf[hs] = hv;
-            __builtin_amdgcn_wave_barrier();
-            f32x2 h1 = {0.0f, 0.0f}, h2 = {0.0f, 0.0f};
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const f32x2 v = {tap[i * C], tap[i * C + 1]};
-                h1 = h1 + v * kx.k[i];
-                if constexpr (GRAD) h2 = h2 + v * ky.k[i];
-            }
-            __builtin_amdgcn_wave_barrier();
-            ring[p] = h1;
-            if constexpr (GRAD) ring2[p] = h2;
-            f32x2 o = {0.0f, 0.0f}, o2 = {0.0f, 0.0f};
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                o = o + ring[(p + 1 + i) % K] * ky.k[i];
-                if constexpr (GRAD) o2 = o2 + ring2[(p + 1 + i) % K] * kx.k[i];
-            }
-            if constexpr (GRAD) {
-                o.x = sqrtf(o.x * o.x + o2.x * o2.x);
-                o.y = sqrtf(o.y * o.y + o2.y * o2.y);
-            }
-            if (r >= 2 * H && r < nrows) {
-                if (ok1) *reinterpret_cast<f32x2_u*>(dst + out_off) = o;
-                else if (ok0) dst[out_off] = o.x;
-            }
-            out_off += a.rowlen;
-        }
-    }
-}
-
-template <int K, int C>
-void launch_roll2_c(hipStream_t st, dim3 grid, bool grad, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
-    if constexpr ((K / 2) * C <= 32) {
-        if (grad) hipLaunchKernelGGL((sep_roll2_kernel<K, C, true>), grid, dim3(kBlock), 0, st, a, kx, ky);
-        else hipLaunchKernelGGL((sep_roll2_kernel<K, C, false>), grid, dim3(kBlock), 0, st, a, kx, ky);
-    }
-}
-template <int K>
-void launch_roll2(hipStream_t st, dim3 grid, bool grad, int C, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
-    if (C == 1) launch_roll2_c<K, 1>(st, grid, grad, a, kx, ky);
-    else if (C == 3) launch_roll2_c<K, 3>(st, grid, grad, a, kx, ky);
-    else launch_roll2_c<K, 4>(st, grid, grad, a, kx, ky);
-}
+// (A two-columns-per-lane variant — 8-byte loads/stores, packed v_pk_mul_f32 / v_pk_add_f32 arithmetic,
+// halo amortised over 128 columns — was built, bit-identical, and measured 2 % SLOWER on C4 (9.95 vs
+// 9.75 ms on the same box, profiles/r01n_ab.log): the kernel is bound by memory traffic and latency, not
+// by VALU issue, so it was dropped.)
 
 // tuning knob (dev): KH_FILTER_STRIP = output rows per strip
 int env_int(const char* name, int dflt) {
@@ -409,9 +298,7 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         TapsK px, py;
         pad_taps(px, kx, K);
         pad_taps(py, ky, K);
-        // two columns per lane for the common channel counts (KH_FILTER_ROLL2=0, dev knob: one column)
-        const bool roll2 = (C == 1 || C == 3 || C == 4) && a.rowlen >= 2 && env_int("KH_FILTER_ROLL2", 1) != 0;
-        const unsigned tiles_x = cdiv(a.rowlen, roll2 ? kTF2 : kTF);
+        const unsigned tiles_x = cdiv(a.rowlen, kTF);
         // Strip height: tall strips amortise the ky-1 warm-up rows (4K x 256 images: 360 rows is
         // 5 % faster than 90), short strips keep a small launch wide enough to fill 256 CUs.
         {
@@ -425,18 +312,6 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const dim3 grid = xcd_grid(a.tiles);
         hipStream_t st = as_hip(stream);
-        if (roll2) {
-            switch (K) {
-                case 3: launch_roll2<3>(st, grid, grad, C, a, px, py); break;
-                case 5: launch_roll2<5>(st, grid, grad, C, a, px, py); break;
-                case 7: launch_roll2<7>(st, grid, grad, C, a, px, py); break;
-                case 9: launch_roll2<9>(st, grid, grad, C, a, px, py); break;
-                case 11: launch_roll2<11>(st, grid, grad, C, a, px, py); break;
-                case 13: launch_roll2<13>(st, grid, grad, C, a, px, py); break;
-                default: launch_roll2<15>(st, grid, grad, C, a, px, py); break;
-            }
-            return check_launch(what);
-        }
         switch (K) {
             case 3: launch_roll<3>(st, grid, grad, a, px, py); break;
             case 5: launch_roll<5>(st, grid, grad, a, px, py); break;

@@ -24,6 +24,9 @@ constexpr int kBx = 64, kBy = 4;
 constexpr int kMaxMaps = 12;
 constexpr int kMaxBatchPerLaunch = 32;  // per-image source pointers travel in the kernel arguments
 
+typedef uint16_t u16u __attribute__((aligned(1)));
+typedef uint32_t u32u __attribute__((aligned(1)));
+
 struct MapStage { int kind; float f[6]; };
 
 struct FusedProgram {
@@ -55,11 +58,24 @@ __global__ __launch_bounds__(kBx* kBy) void fused_pipeline_kernel(FusedProgram P
     const uint8_t* r0 = src + (size_t)sy0 * P.sw * 3u;
     const uint8_t* r1 = src + (size_t)sy1 * P.sw * 3u;
     const float w00 = (1.0f - wy) * (1.0f - wx), w01 = (1.0f - wy) * wx, w10 = wy * (1.0f - wx), w11 = wy * wx;
+    // the two taps of a row are adjacent: 6 bytes = one dword + one ushort load instead of six byte loads
+    // (gathers are bound by vector-memory instructions per pixel)
+    uint32_t t[4][3];
+    if (sx1 != sx0) {
+        const uint32_t a0 = *reinterpret_cast<const u32u*>(r0 + sx0 * 3u), a1 = *reinterpret_cast<const u16u*>(r0 + sx0 * 3u + 4u);
+        const uint32_t b0 = *reinterpret_cast<const u32u*>(r1 + sx0 * 3u), b1 = *reinterpret_cast<const u16u*>(r1 + sx0 * 3u + 4u);
+        t[0][0] = a0 & 0xFF; t[0][1] = (a0 >> 8) & 0xFF; t[0][2] = (a0 >> 16) & 0xFF;
+        t[1][0] = a0 >> 24; t[1][1] = a1 & 0xFF; t[1][2] = a1 >> 8;
+        t[2][0] = b0 & 0xFF; t[2][1] = (b0 >> 8) & 0xFF; t[2][2] = (b0 >> 16) & 0xFF;
+        t[3][0] = b0 >> 24; t[3][1] = b1 & 0xFF; t[3][2] = b1 >> 8;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { t[0][c] = t[1][c] = r0[sx0 * 3u + c]; t[2][c] = t[3][c] = r1[sx0 * 3u + c]; }
+    }
     float v[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        v[c] = w00 * (float)r0[sx0 * 3u + c] + w01 * (float)r0[sx1 * 3u + c] + w10 * (float)r1[sx0 * 3u + c] +
-               w11 * (float)r1[sx1 * 3u + c];
+        v[c] = w00 * (float)t[0][c] + w01 * (float)t[1][c] + w10 * (float)t[2][c] + w11 * (float)t[3][c];
 
     // maps (wave-uniform program walk)
     for (int i = 0; i < P.nmaps; ++i) {
