@@ -115,60 +115,56 @@ typedef uint16_t u16u __attribute__((aligned(1)));
 typedef uint32_t u32u __attribute__((aligned(1)));
 typedef uint64_t u64u __attribute__((aligned(1)));
 
+// Branch-free: the wide load is taken from a base clamped so that it stays inside the row, then shifted;
+// a parity- or edge-dependent branch here would diverge in every wave and serialise the loads (measured:
+// 2.69 vs 2.31 ms on 1080p->640).  Needs rows of at least 2 pixels (4 for the 4:2:x formats) — narrower
+// sources take the per-tap path.
 template <int FMT>
 __device__ __forceinline__ void fetch_pair(const uint8_t* __restrict__ src, int x0, bool has_next, int y, const PreArgs& a,
                                            float l[3], float r[3]) {
     if constexpr (FMT == KH_FMT_RGB || FMT == KH_FMT_BGR) {
-        const uint8_t* p = src + (unsigned)(y * a.src_pitch + x0 * a.src_bpp);
+        const int xb = min(x0, a.src_w - 2);                 // pixels xb, xb + 1 are in the row
+        const bool second = x0 != xb;                         // x0 is the last column
+        const uint8_t* p = src + (unsigned)(y * a.src_pitch + xb * a.src_bpp);
         uint32_t c[6];
-        if (!has_next) {
-            c[0] = c[3] = p[0]; c[1] = c[4] = p[1]; c[2] = c[5] = p[2];
-        } else if (a.src_bpp == 4) {
+        if (a.src_bpp == 4) {                                 // uniform
             const uint64_t v = *reinterpret_cast<const u64u*>(p);
-            c[0] = (uint32_t)v & 0xFF; c[1] = ((uint32_t)v >> 8) & 0xFF; c[2] = ((uint32_t)v >> 16) & 0xFF;
-            const uint32_t h = (uint32_t)(v >> 32);
-            c[3] = h & 0xFF; c[4] = (h >> 8) & 0xFF; c[5] = (h >> 16) & 0xFF;
+            const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+            c[0] = lo & 0xFF; c[1] = (lo >> 8) & 0xFF; c[2] = (lo >> 16) & 0xFF;
+            c[3] = hi & 0xFF; c[4] = (hi >> 8) & 0xFF; c[5] = (hi >> 16) & 0xFF;
         } else {
             const uint32_t lo = *reinterpret_cast<const u32u*>(p);
             const uint32_t hi = *reinterpret_cast<const u16u*>(p + 4);
             c[0] = lo & 0xFF; c[1] = (lo >> 8) & 0xFF; c[2] = (lo >> 16) & 0xFF;
             c[3] = lo >> 24; c[4] = hi & 0xFF; c[5] = hi >> 8;
         }
-        if constexpr (FMT == KH_FMT_RGB) {
-            l[0] = (float)c[0]; l[1] = (float)c[1]; l[2] = (float)c[2];
-            r[0] = (float)c[3]; r[1] = (float)c[4]; r[2] = (float)c[5];
-        } else {
-            l[0] = (float)c[2]; l[1] = (float)c[1]; l[2] = (float)c[0];
-            r[0] = (float)c[5]; r[1] = (float)c[4]; r[2] = (float)c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t lv = second ? c[3 + k] : c[k], rv = has_next ? c[3 + k] : lv;
+            const int o = (FMT == KH_FMT_RGB) ? k : 2 - k;
+            l[o] = (float)lv;
+            r[o] = (float)rv;
         }
     } else if constexpr (FMT == KH_FMT_GRAY) {
-        const uint8_t* p = src + (unsigned)(y * a.src_pitch + x0);
-        uint32_t g0, g1;
-        if (has_next) { const uint32_t v = *reinterpret_cast<const u16u*>(p); g0 = v & 0xFF; g1 = v >> 8; }
-        else { g0 = g1 = p[0]; }
+        const int xb = min(x0, a.src_w - 2);
+        const uint32_t v = (uint32_t)*reinterpret_cast<const u16u*>(src + (unsigned)(y * a.src_pitch + xb)) >> ((x0 - xb) * 8);
+        const uint32_t g0 = v & 0xFF, g1 = has_next ? v >> 8 : g0;
         l[0] = l[1] = l[2] = (float)g0;
         r[0] = r[1] = r[2] = (float)g1;
     } else if constexpr (FMT == KH_FMT_NV12) {
-        const uint8_t* py = src + (unsigned)(y * a.src_w + x0);
-        const int c0 = x0 >> 1;
-        const uint8_t* puv = src + (unsigned)(a.src_w * a.src_h + (y >> 1) * a.src_w + c0 * 2);
-        uint32_t y0v, y1v, uv0, uv1;
-        if (has_next) { const uint32_t v = *reinterpret_cast<const u16u*>(py); y0v = v & 0xFF; y1v = v >> 8; }
-        else { y0v = y1v = py[0]; }
-        if (has_next && (x0 & 1)) {  // taps straddle two chroma pairs (the second one exists: x0 + 1 < src_w)
-            const uint32_t q = *reinterpret_cast<const u32u*>(puv);
-            uv0 = q & 0xFFFF; uv1 = q >> 16;
-        } else {
-            uv0 = uv1 = *reinterpret_cast<const u16u*>(puv);
-        }
+        const int xb = min(x0, a.src_w - 2);
+        const uint32_t yv = (uint32_t)*reinterpret_cast<const u16u*>(src + (unsigned)(y * a.src_w + xb)) >> ((x0 - xb) * 8);
+        const uint32_t y0v = yv & 0xFF, y1v = has_next ? yv >> 8 : y0v;
+        const int c0 = x0 >> 1, cb = min(c0, (a.src_w >> 1) - 2);  // chroma pairs cb, cb + 1 are in the row
+        const uint32_t q = *reinterpret_cast<const u32u*>(src + (unsigned)(a.src_w * a.src_h + (y >> 1) * a.src_w + cb * 2)) >>
+                           ((c0 - cb) * 16);
+        const uint32_t uv0 = q & 0xFFFF, uv1 = (has_next && (x0 & 1)) ? q >> 16 : uv0;
         yuv_to_rgbf((int)y0v, (int)(uv0 & 0xFF), (int)(uv0 >> 8), l);
         yuv_to_rgbf((int)y1v, (int)(uv1 & 0xFF), (int)(uv1 >> 8), r);
     } else {  // YUYV: groups of 4 bytes Y0 U Y1 V per 2 pixels
-        const int g0 = x0 >> 1;
-        const uint8_t* p = src + (unsigned)(y * a.src_pitch + g0 * 4);
-        uint32_t q0, q1;
-        if (has_next && (x0 & 1)) { const uint64_t v = *reinterpret_cast<const u64u*>(p); q0 = (uint32_t)v; q1 = (uint32_t)(v >> 32); }
-        else { q0 = q1 = *reinterpret_cast<const u32u*>(p); }
+        const int g0 = x0 >> 1, gb = min(g0, (a.src_w >> 1) - 2);
+        const uint64_t v = *reinterpret_cast<const u64u*>(src + (unsigned)(y * a.src_pitch + gb * 4)) >> ((g0 - gb) * 32);
+        const uint32_t q0 = (uint32_t)v, q1 = (has_next && (x0 & 1)) ? (uint32_t)(v >> 32) : q0;
         const int x1 = has_next ? x0 + 1 : x0;
         yuv_to_rgbf((int)((x0 & 1) ? (q0 >> 16) & 0xFF : q0 & 0xFF), (int)((q0 >> 8) & 0xFF), (int)(q0 >> 24), l);
         yuv_to_rgbf((int)((x1 & 1) ? (q1 >> 16) & 0xFF : q1 & 0xFF), (int)((q1 >> 8) & 0xFF), (int)(q1 >> 24), r);
@@ -186,8 +182,17 @@ __device__ __forceinline__ void sample_bilinear(const uint8_t* __restrict__ src,
     x0 = max(x0, 0);
     y0 = max(y0, 0);
     float t00[3], t10[3], t01[3], t11[3];
-    fetch_pair<FMT>(src, x0, has_next, y0, a, t00, t10);
-    fetch_pair<FMT>(src, x0, has_next, y1, a, t01, t11);
+    constexpr int kMinW = (FMT == KH_FMT_NV12 || FMT == KH_FMT_YUYV) ? 4 : 2;
+    if (a.src_w >= kMinW) {  // uniform
+        fetch_pair<FMT>(src, x0, has_next, y0, a, t00, t10);
+        fetch_pair<FMT>(src, x0, has_next, y1, a, t01, t11);
+    } else {
+        const int x1 = has_next ? x0 + 1 : x0;
+        fetch_px<FMT, WIDE>(src, x0, y0, a, t00);
+        fetch_px<FMT, WIDE>(src, x1, y0, a, t10);
+        fetch_px<FMT, WIDE>(src, x0, y1, a, t01);
+        fetch_px<FMT, WIDE>(src, x1, y1, a, t11);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float top = t00[c] + (t10[c] - t00[c]) * ax;
