@@ -81,6 +81,51 @@ __device__ __forceinline__ bool xcd_tile(const XcdTiles& t, unsigned& bx, unsign
     return true;
 }
 
+// Unaligned 2/4/8-byte global accesses (fine on gfx950; the compiler emits single dword/dwordx2 ops).
+typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+
+// The two horizontally adjacent u8 pixels x0 and x1 = min(x0 + 1, w - 1) of one row, C channels each,
+// with one or two wide loads instead of 2*C byte loads.  Gathers on this chip are bound by the number of
+// vector-memory instructions per pixel, and the two bilinear taps of a row are adjacent in memory.
+// Branch-free: the load base is clamped so that both pixels are inside the row (needs w >= 2; a 1-pixel
+// row replicates its pixel), then the halves are selected.
+template <int C>
+__device__ __forceinline__ void load_pair_u8(const uint8_t* __restrict__ row, int x0, int w, uint32_t p0[C], uint32_t p1[C]) {
+    if (w < 2) {  // uniform
+#pragma unroll
+        for (int c = 0; c < C; ++c) p0[c] = p1[c] = row[c];
+        return;
+    }
+    const int xb = min(x0, w - 2);
+    const bool second = x0 != xb;  // x0 is the last column: both taps are the pair's second pixel
+    const uint8_t* p = row + (unsigned)(xb * C);
+    uint32_t a[C], b[C];
+    if constexpr (C == 1) {
+        const uint32_t v = *reinterpret_cast<const u16_unaligned*>(p);
+        a[0] = v & 0xffu; b[0] = v >> 8;
+    } else if constexpr (C == 2) {
+        const uint32_t v = *reinterpret_cast<const u32_unaligned*>(p);
+        a[0] = v & 0xffu; a[1] = (v >> 8) & 0xffu; b[0] = (v >> 16) & 0xffu; b[1] = v >> 24;
+    } else if constexpr (C == 3) {
+        const uint32_t lo = *reinterpret_cast<const u32_unaligned*>(p);
+        const uint32_t hi = *reinterpret_cast<const u16_unaligned*>(p + 4);
+        a[0] = lo & 0xffu; a[1] = (lo >> 8) & 0xffu; a[2] = (lo >> 16) & 0xffu;
+        b[0] = lo >> 24; b[1] = hi & 0xffu; b[2] = hi >> 8;
+    } else {
+        const uint64_t v = *reinterpret_cast<const u64_unaligned*>(p);
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a[c] = (lo >> (8 * c)) & 0xffu; b[c] = (hi >> (8 * c)) & 0xffu; }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        p0[c] = second ? b[c] : a[c];
+        p1[c] = b[c];
+    }
+}
+
 }  // namespace kh
 
 #define KH_HIP(call)                                           \

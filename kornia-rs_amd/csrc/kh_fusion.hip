@@ -24,9 +24,6 @@ constexpr int kBx = 64, kBy = 4;
 constexpr int kMaxMaps = 12;
 constexpr int kMaxBatchPerLaunch = 32;  // per-image source pointers travel in the kernel arguments
 
-typedef uint16_t u16u __attribute__((aligned(1)));
-typedef uint32_t u32u __attribute__((aligned(1)));
-
 struct MapStage { int kind; float f[6]; };
 
 struct FusedProgram {
@@ -53,25 +50,15 @@ __global__ __launch_bounds__(kBx* kBy) void fused_pipeline_kernel(FusedProgram P
     const float sxf = fmaxf(P.ax * (float)x + P.bx, 0.0f);
     const float syf = fmaxf(P.ay * (float)y + P.by, 0.0f);
     const unsigned sx0 = min((unsigned)sxf, (unsigned)P.sw - 1u), sy0 = min((unsigned)syf, (unsigned)P.sh - 1u);
-    const unsigned sx1 = min(sx0 + 1u, (unsigned)P.sw - 1u), sy1 = min(sy0 + 1u, (unsigned)P.sh - 1u);
+    const unsigned sy1 = min(sy0 + 1u, (unsigned)P.sh - 1u);  // sx1 = min(sx0 + 1, sw - 1) is load_pair_u8's second pixel
     const float wx = sxf - (float)sx0, wy = syf - (float)sy0;
     const uint8_t* r0 = src + (size_t)sy0 * P.sw * 3u;
     const uint8_t* r1 = src + (size_t)sy1 * P.sw * 3u;
     const float w00 = (1.0f - wy) * (1.0f - wx), w01 = (1.0f - wy) * wx, w10 = wy * (1.0f - wx), w11 = wy * wx;
-    // the two taps of a row are adjacent: 6 bytes = one dword + one ushort load instead of six byte loads
-    // (gathers are bound by vector-memory instructions per pixel)
+    // the two taps of a row are adjacent: one dword + one ushort load instead of six byte loads
     uint32_t t[4][3];
-    if (sx1 != sx0) {
-        const uint32_t a0 = *reinterpret_cast<const u32u*>(r0 + sx0 * 3u), a1 = *reinterpret_cast<const u16u*>(r0 + sx0 * 3u + 4u);
-        const uint32_t b0 = *reinterpret_cast<const u32u*>(r1 + sx0 * 3u), b1 = *reinterpret_cast<const u16u*>(r1 + sx0 * 3u + 4u);
-        t[0][0] = a0 & 0xFF; t[0][1] = (a0 >> 8) & 0xFF; t[0][2] = (a0 >> 16) & 0xFF;
-        t[1][0] = a0 >> 24; t[1][1] = a1 & 0xFF; t[1][2] = a1 >> 8;
-        t[2][0] = b0 & 0xFF; t[2][1] = (b0 >> 8) & 0xFF; t[2][2] = (b0 >> 16) & 0xFF;
-        t[3][0] = b0 >> 24; t[3][1] = b1 & 0xFF; t[3][2] = b1 >> 8;
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { t[0][c] = t[1][c] = r0[sx0 * 3u + c]; t[2][c] = t[3][c] = r1[sx0 * 3u + c]; }
-    }
+    load_pair_u8<3>(r0, (int)sx0, P.sw, t[0], t[1]);
+    load_pair_u8<3>(r1, (int)sx0, P.sw, t[2], t[3]);
     float v[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)

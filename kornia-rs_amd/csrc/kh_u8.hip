@@ -320,45 +320,15 @@ __device__ __forceinline__ void put_zero_u8(uint8_t* o) {
     put_u8<C>(o, z);
 }
 
-// Two horizontally adjacent pixels of one row: 2*C contiguous bytes fetched with one or two unaligned
-// loads instead of 2*C byte loads (the gathers were issue-bound on byte loads).  At the last column
-// the reference replicates the pixel (xi1 == xi), taken on the byte path.
-typedef uint16_t u16u __attribute__((aligned(1)));
-typedef uint64_t u64u __attribute__((aligned(1)));
-template <int C>
-__device__ __forceinline__ void load_pair(const uint8_t* __restrict__ row, int xi, bool has_next, uint32_t p0[C], uint32_t p1[C]) {
-    const uint8_t* p = row + xi * C;
-    if (!has_next) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) p0[c] = p1[c] = p[c];
-        return;
-    }
-    if constexpr (C == 1) {
-        const uint32_t v = *reinterpret_cast<const u16u*>(p);
-        p0[0] = v & 0xffu; p1[0] = v >> 8;
-    } else if constexpr (C == 3) {
-        const uint32_t lo = *reinterpret_cast<const u32u*>(p);
-        const uint32_t hi = *reinterpret_cast<const u16u*>(p + 4);
-        p0[0] = lo & 0xffu; p0[1] = (lo >> 8) & 0xffu; p0[2] = (lo >> 16) & 0xffu;
-        p1[0] = lo >> 24; p1[1] = hi & 0xffu; p1[2] = hi >> 8;
-    } else {
-        const uint64_t v = *reinterpret_cast<const u64u*>(p);
-        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { p0[c] = (lo >> (8 * c)) & 0xffu; p1[c] = (hi >> (8 * c)) & 0xffu; }
-    }
-}
-
 // bilinear_sample_u8_valid (P/warp/common.rs:79-165): xi, yi in range; fx, fy in Q10
 template <int C>
 __device__ __forceinline__ void sample_q10(const uint8_t* __restrict__ src, int sw, int sh, int xi, int yi, uint32_t fx,
                                            uint32_t fy, uint8_t* o) {
     const uint32_t fx1 = 1024u - fx, fy1 = 1024u - fy;
-    const bool has_next = xi + 1 < sw;
     const int yi1 = yi + 1 < sh ? yi + 1 : yi;
-    uint32_t p00[C], p01[C], p10[C], p11[C];
-    load_pair<C>(src + (unsigned)(yi * sw) * C, xi, has_next, p00, p01);   // < 2^31 bytes, host-checked
-    load_pair<C>(src + (unsigned)(yi1 * sw) * C, xi, has_next, p10, p11);
+    uint32_t p00[C], p01[C], p10[C], p11[C];  // xi1 = xi + 1 < sw ? xi + 1 : xi  ==  load_pair_u8's second pixel
+    load_pair_u8<C>(src + (unsigned)(yi * sw) * C, xi, sw, p00, p01);   // < 2^31 bytes, host-checked
+    load_pair_u8<C>(src + (unsigned)(yi1 * sw) * C, xi, sw, p10, p11);
     uint32_t v[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
