@@ -146,16 +146,15 @@ constexpr int kRollStripMax = 360;  // tallest strip (output rows)
 
 struct TapsK { float k[16]; };
 
-constexpr int kRollMaxBlock = 1024;
 template <int K, bool GRAD>
-__global__ __launch_bounds__(kRollMaxBlock) void sep_roll_kernel(FilterArgs a, TapsK kx, TapsK ky) {
-    __shared__ float rowbuf[kRollMaxBlock / 64][160];
+__global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx, TapsK ky) {
+    __shared__ float rowbuf[4][160];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int H = K / 2;
     const int halo = H * a.C;  // <= 32 (checked on the host)
     unsigned tx, ty, bz;
     if (!xcd_tile(a.tiles, tx, ty, bz)) return;
-    const int gx0 = tx * blockDim.x + wv * 64;  // first flat column of this wave
+    const int gx0 = tx * kTF + wv * 64;  // first flat column of this wave
     if (gx0 >= a.rowlen) return;         // whole wave idle (no block barrier below)
     const int y0 = ty * a.th;
     const float* __restrict__ src = a.src + (long long)bz * a.src_stride;
@@ -251,9 +250,9 @@ int env_int(const char* name, int dflt) {
 }
 
 template <int K>
-void launch_roll(hipStream_t st, dim3 grid, int block, bool grad, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
-    if (grad) hipLaunchKernelGGL((sep_roll_kernel<K, true>), grid, dim3(block), 0, st, a, kx, ky);
-    else hipLaunchKernelGGL((sep_roll_kernel<K, false>), grid, dim3(block), 0, st, a, kx, ky);
+void launch_roll(hipStream_t st, dim3 grid, bool grad, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
+    if (grad) hipLaunchKernelGGL((sep_roll_kernel<K, true>), grid, dim3(kBlock), 0, st, a, kx, ky);
+    else hipLaunchKernelGGL((sep_roll_kernel<K, false>), grid, dim3(kBlock), 0, st, a, kx, ky);
 }
 
 // Centre an n-tap kernel inside K taps.  The zero pad taps contribute (+-0) to the accumulator,
@@ -299,11 +298,7 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         TapsK px, py;
         pad_taps(px, kx, K);
         pad_taps(py, ky, K);
-        // waves of a block share nothing but their halo cache lines; wider blocks = fewer block-edge
-        // lines fetched twice (KH_FILTER_BLOCK: dev knob, 256 / 512 / 1024)
-        int block = env_int("KH_FILTER_BLOCK", kBlock);
-        if (block != 256 && block != 512 && block != 1024) block = kBlock;
-        const unsigned tiles_x = cdiv(a.rowlen, block);
+        const unsigned tiles_x = cdiv(a.rowlen, kTF);  // 256-thread blocks: 512 measured +1 %, 1024 +9 % (r01q)
         // Strip height: tall strips amortise the ky-1 warm-up rows (4K x 256 images: 360 rows is
         // 5 % faster than 90), short strips keep a small launch wide enough to fill 256 CUs.
         {
@@ -318,13 +313,13 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         const dim3 grid = xcd_grid(a.tiles);
         hipStream_t st = as_hip(stream);
         switch (K) {
-            case 3: launch_roll<3>(st, grid, block, grad, a, px, py); break;
-            case 5: launch_roll<5>(st, grid, block, grad, a, px, py); break;
-            case 7: launch_roll<7>(st, grid, block, grad, a, px, py); break;
-            case 9: launch_roll<9>(st, grid, block, grad, a, px, py); break;
-            case 11: launch_roll<11>(st, grid, block, grad, a, px, py); break;
-            case 13: launch_roll<13>(st, grid, block, grad, a, px, py); break;
-            default: launch_roll<15>(st, grid, block, grad, a, px, py); break;
+            case 3: launch_roll<3>(st, grid, grad, a, px, py); break;
+            case 5: launch_roll<5>(st, grid, grad, a, px, py); break;
+            case 7: launch_roll<7>(st, grid, grad, a, px, py); break;
+            case 9: launch_roll<9>(st, grid, grad, a, px, py); break;
+            case 11: launch_roll<11>(st, grid, grad, a, px, py); break;
+            case 13: launch_roll<13>(st, grid, grad, a, px, py); break;
+            default: launch_roll<15>(st, grid, grad, a, px, py); break;
         }
         return check_launch(what);
     }

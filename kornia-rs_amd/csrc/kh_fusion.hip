@@ -50,15 +50,14 @@ __global__ __launch_bounds__(kBx* kBy) void fused_pipeline_kernel(FusedProgram P
     const float sxf = fmaxf(P.ax * (float)x + P.bx, 0.0f);
     const float syf = fmaxf(P.ay * (float)y + P.by, 0.0f);
     const unsigned sx0 = min((unsigned)sxf, (unsigned)P.sw - 1u), sy0 = min((unsigned)syf, (unsigned)P.sh - 1u);
-    const unsigned sy1 = min(sy0 + 1u, (unsigned)P.sh - 1u);  // sx1 = min(sx0 + 1, sw - 1) is load_pair_u8's second pixel
+    const unsigned sy1 = min(sy0 + 1u, (unsigned)P.sh - 1u);  // sx1 = min(sx0 + 1, sw - 1) is load_quad_u8's second pixel
     const float wx = sxf - (float)sx0, wy = syf - (float)sy0;
     const uint8_t* r0 = src + (size_t)sy0 * P.sw * 3u;
     const uint8_t* r1 = src + (size_t)sy1 * P.sw * 3u;
     const float w00 = (1.0f - wy) * (1.0f - wx), w01 = (1.0f - wy) * wx, w10 = wy * (1.0f - wx), w11 = wy * wx;
     // the two taps of a row are adjacent: one dword + one ushort load instead of six byte loads
     uint32_t t[4][3];
-    load_pair_u8<3>(r0, (int)sx0, P.sw, t[0], t[1]);
-    load_pair_u8<3>(r1, (int)sx0, P.sw, t[2], t[3]);
+    load_quad_u8<3>(r0, r1, (int)sx0, P.sw, t[0], t[1], t[2], t[3]);
     float v[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)

@@ -121,8 +121,7 @@ __global__ __launch_bounds__(kBx* kBy) void bilinear_u8_kernel(Rz a) {
     bilinear_tap(y, a.scale_y, a.sh, yi, fy);
     const uint64_t fx1 = 16384u - fx, fy1 = 16384u - fy;
     uint32_t p00[C], p01[C], p10[C], p11[C];  // xi <= sw - 2, yi <= sh - 2: both neighbours exist
-    load_pair_u8<C>(src + (unsigned)(yi * a.sw) * C, xi, a.sw, p00, p01);
-    load_pair_u8<C>(src + (unsigned)((yi + 1) * a.sw) * C, xi, a.sw, p10, p11);
+    load_quad_u8<C>(src + (unsigned)(yi * a.sw) * C, src + (unsigned)((yi + 1) * a.sw) * C, xi, a.sw, p00, p01, p10, p11);
     uint8_t* o = dst + ((long long)y * a.dw + x) * C;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) {  // bilinear_row_u8_scalar, kernels.rs:1141-1165 (u64 accumulate)
@@ -205,9 +204,8 @@ __global__ __launch_bounds__(kBx* kBy) void fused_rgb_chw_kernel(Rz a, Norm3 n, 
         const int y0 = min((int)fy, a.sh - 1), y1 = min(y0 + 1, a.sh - 1);
         const int x0 = min((int)fx, a.sw - 1), x1 = min(x0 + 1, a.sw - 1);
         const float wy = fy - (float)y0, w = fx - (float)x0;
-        uint32_t t00[3], t01[3], t10[3], t11[3];  // x1 = min(x0 + 1, sw - 1): load_pair_u8's second pixel
-        load_pair_u8<3>(src + (unsigned)(y0 * a.sw) * 3, x0, a.sw, t00, t01);
-        load_pair_u8<3>(src + (unsigned)(y1 * a.sw) * 3, x0, a.sw, t10, t11);
+        uint32_t t00[3], t01[3], t10[3], t11[3];  // x1 = min(x0 + 1, sw - 1): load_quad_u8's second pixel
+        load_quad_u8<3>(src + (unsigned)(y0 * a.sw) * 3, src + (unsigned)(y1 * a.sw) * 3, x0, a.sw, t00, t01, t10, t11);
         (void)x1;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -282,8 +280,7 @@ __global__ __launch_bounds__(kBx* kBy) void cv_linear_u8_kernel(Rz a) {  // resi
     const LinTap tx = linear_tap(x, a.scale_x, a.sw), ty = linear_tap(y, a.scale_y, a.sh);
     const int sy1 = min(ty.ofs + 1, a.sh - 1);
     uint32_t p00[C], p01[C], p10[C], p11[C];  // border columns (ofs == sw - 1) only use the first pixel
-    load_pair_u8<C>(src + (unsigned)(ty.ofs * a.sw) * C, tx.ofs, a.sw, p00, p01);
-    load_pair_u8<C>(src + (unsigned)(sy1 * a.sw) * C, tx.ofs, a.sw, p10, p11);
+    load_quad_u8<C>(src + (unsigned)(ty.ofs * a.sw) * C, src + (unsigned)(sy1 * a.sw) * C, tx.ofs, a.sw, p00, p01, p10, p11);
     uint8_t* o = dst + ((long long)y * a.dw + x) * C;
 #pragma unroll
     for (int k = 0; k < C; ++k) {

@@ -326,9 +326,8 @@ __device__ __forceinline__ void sample_q10(const uint8_t* __restrict__ src, int 
                                            uint32_t fy, uint8_t* o) {
     const uint32_t fx1 = 1024u - fx, fy1 = 1024u - fy;
     const int yi1 = yi + 1 < sh ? yi + 1 : yi;
-    uint32_t p00[C], p01[C], p10[C], p11[C];  // xi1 = xi + 1 < sw ? xi + 1 : xi  ==  load_pair_u8's second pixel
-    load_pair_u8<C>(src + (unsigned)(yi * sw) * C, xi, sw, p00, p01);   // < 2^31 bytes, host-checked
-    load_pair_u8<C>(src + (unsigned)(yi1 * sw) * C, xi, sw, p10, p11);
+    uint32_t p00[C], p01[C], p10[C], p11[C];  // xi1 = xi + 1 < sw ? xi + 1 : xi  ==  load_quad_u8's second pixel
+    load_quad_u8<C>(src + (unsigned)(yi * sw) * C, src + (unsigned)(yi1 * sw) * C, xi, sw, p00, p01, p10, p11);  // < 2^31 B
     uint32_t v[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
