@@ -93,45 +93,52 @@ typedef uint64_t u64_unaligned __attribute__((aligned(1)));
 // afterwards), and BOTH rows are fetched under ONE uniform width test: a load inside its own branch, even
 // a uniform one, makes the compiler wait for it before issuing the next (measured 3x on the fused
 // pipeline: 2.2 vs 6.4 ms).
+// Pixels come back PACKED (channel c of a pixel = bits [8c, 8c+8) of its word): passing small arrays
+// through the helper made the compiler park them in LDS (promote-alloca) in some kernels — 2.3x slower
+// than the byte loads it replaced (profiles/r01s_ab.log).
+struct QuadU8 { uint32_t p00, p01, p10, p11; };
+__device__ __forceinline__ uint32_t chan_u8(uint32_t px, int c) { return (px >> (8 * c)) & 0xffu; }
+
 template <int C>
-__device__ __forceinline__ void load_pair_u8_wide(const uint8_t* __restrict__ row, int x0, int w, uint32_t p0[C], uint32_t p1[C]) {
+__device__ __forceinline__ void load_pair_u8_wide(const uint8_t* __restrict__ row, int x0, int w, uint32_t& p0, uint32_t& p1) {
     const int xb = min(x0, w - 2);   // w >= 2
-    const bool second = x0 != xb;    // x0 is the last column: both taps are the pair's second pixel
     const uint8_t* p = row + (unsigned)(xb * C);
-    uint32_t a[C], b[C];
+    uint32_t a, b;
     if constexpr (C == 1) {
         const uint32_t v = *reinterpret_cast<const u16_unaligned*>(p);
-        a[0] = v & 0xffu; b[0] = v >> 8;
+        a = v & 0xffu; b = v >> 8;
     } else if constexpr (C == 2) {
         const uint32_t v = *reinterpret_cast<const u32_unaligned*>(p);
-        a[0] = v & 0xffu; a[1] = (v >> 8) & 0xffu; b[0] = (v >> 16) & 0xffu; b[1] = v >> 24;
+        a = v & 0xffffu; b = v >> 16;
     } else if constexpr (C == 3) {
         const uint32_t lo = *reinterpret_cast<const u32_unaligned*>(p);
         const uint32_t hi = *reinterpret_cast<const u16_unaligned*>(p + 4);
-        a[0] = lo & 0xffu; a[1] = (lo >> 8) & 0xffu; a[2] = (lo >> 16) & 0xffu;
-        b[0] = lo >> 24; b[1] = hi & 0xffu; b[2] = hi >> 8;
+        a = lo & 0xffffffu; b = (lo >> 24) | (hi << 8);
     } else {
         const uint64_t v = *reinterpret_cast<const u64_unaligned*>(p);
-        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { a[c] = (lo >> (8 * c)) & 0xffu; b[c] = (hi >> (8 * c)) & 0xffu; }
+        a = (uint32_t)v; b = (uint32_t)(v >> 32);
     }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        p0[c] = second ? b[c] : a[c];
-        p1[c] = b[c];
-    }
+    p0 = x0 != xb ? b : a;  // x0 is the last column: both taps are the pair's second pixel
+    p1 = b;
 }
 template <int C>
-__device__ __forceinline__ void load_quad_u8(const uint8_t* __restrict__ row0, const uint8_t* __restrict__ row1, int x0, int w,
-                                             uint32_t p00[C], uint32_t p01[C], uint32_t p10[C], uint32_t p11[C]) {
-    if (w >= 2) {  // uniform
-        load_pair_u8_wide<C>(row0, x0, w, p00, p01);
-        load_pair_u8_wide<C>(row1, x0, w, p10, p11);
-    } else {       // a 1-pixel row replicates its pixel
+__device__ __forceinline__ uint32_t load_px_u8(const uint8_t* __restrict__ p) {
+    uint32_t v = 0;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { p00[c] = p01[c] = row0[c]; p10[c] = p11[c] = row1[c]; }
+    for (int c = 0; c < C; ++c) v |= (uint32_t)p[c] << (8 * c);
+    return v;
+}
+template <int C>
+__device__ __forceinline__ QuadU8 load_quad_u8(const uint8_t* __restrict__ row0, const uint8_t* __restrict__ row1, int x0, int w) {
+    QuadU8 q;
+    if (w >= 2) {  // uniform
+        load_pair_u8_wide<C>(row0, x0, w, q.p00, q.p01);
+        load_pair_u8_wide<C>(row1, x0, w, q.p10, q.p11);
+    } else {       // a 1-pixel row replicates its pixel
+        q.p00 = q.p01 = load_px_u8<C>(row0);
+        q.p10 = q.p11 = load_px_u8<C>(row1);
     }
+    return q;
 }
 
 }  // namespace kh

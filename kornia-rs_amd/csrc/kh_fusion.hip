@@ -59,7 +59,9 @@ __global__ __launch_bounds__(kBx* kBy) void fused_pipeline_kernel(FusedProgram P
     // the two taps of a row are adjacent: one dword + one ushort load instead of six byte loads
     uint32_t t[4][3];
     if constexpr (LOADS == 2) {
-        load_quad_u8<3>(r0, r1, (int)sx0, P.sw, t[0], t[1], t[2], t[3]);
+        const QuadU8 q = load_quad_u8<3>(r0, r1, (int)sx0, P.sw);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { t[0][c] = chan_u8(q.p00, c); t[1][c] = chan_u8(q.p01, c); t[2][c] = chan_u8(q.p10, c); t[3][c] = chan_u8(q.p11, c); }
     } else {
         const unsigned sx1 = min(sx0 + 1u, (unsigned)P.sw - 1u);
         if (LOADS == 1 && sx1 != sx0) {

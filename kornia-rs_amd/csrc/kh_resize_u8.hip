@@ -120,13 +120,13 @@ __global__ __launch_bounds__(kBx* kBy) void bilinear_u8_kernel(Rz a) {
     bilinear_tap(x, a.scale_x, a.sw, xi, fx);
     bilinear_tap(y, a.scale_y, a.sh, yi, fy);
     const uint64_t fx1 = 16384u - fx, fy1 = 16384u - fy;
-    uint32_t p00[C], p01[C], p10[C], p11[C];  // xi <= sw - 2, yi <= sh - 2: both neighbours exist
-    load_quad_u8<C>(src + (unsigned)(yi * a.sw) * C, src + (unsigned)((yi + 1) * a.sw) * C, xi, a.sw, p00, p01, p10, p11);
+    // xi <= sw - 2, yi <= sh - 2: both neighbours exist
+    const QuadU8 q = load_quad_u8<C>(src + (unsigned)(yi * a.sw) * C, src + (unsigned)((yi + 1) * a.sw) * C, xi, a.sw);
     uint8_t* o = dst + ((long long)y * a.dw + x) * C;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) {  // bilinear_row_u8_scalar, kernels.rs:1141-1165 (u64 accumulate)
-        const uint64_t top = (uint64_t)p00[ch] * fx1 + (uint64_t)p01[ch] * fx;
-        const uint64_t bot = (uint64_t)p10[ch] * fx1 + (uint64_t)p11[ch] * fx;
+        const uint64_t top = (uint64_t)chan_u8(q.p00, ch) * fx1 + (uint64_t)chan_u8(q.p01, ch) * fx;
+        const uint64_t bot = (uint64_t)chan_u8(q.p10, ch) * fx1 + (uint64_t)chan_u8(q.p11, ch) * fx;
         o[ch] = (uint8_t)((top * fy1 + bot * fy + (1ull << 27)) >> 28);
     }
 }
@@ -204,12 +204,12 @@ __global__ __launch_bounds__(kBx* kBy) void fused_rgb_chw_kernel(Rz a, Norm3 n, 
         const int y0 = min((int)fy, a.sh - 1), y1 = min(y0 + 1, a.sh - 1);
         const int x0 = min((int)fx, a.sw - 1), x1 = min(x0 + 1, a.sw - 1);
         const float wy = fy - (float)y0, w = fx - (float)x0;
-        uint32_t t00[3], t01[3], t10[3], t11[3];  // x1 = min(x0 + 1, sw - 1): load_quad_u8's second pixel
-        load_quad_u8<3>(src + (unsigned)(y0 * a.sw) * 3, src + (unsigned)(y1 * a.sw) * 3, x0, a.sw, t00, t01, t10, t11);
+        // x1 = min(x0 + 1, sw - 1): load_quad_u8's second pixel
+        const QuadU8 t = load_quad_u8<3>(src + (unsigned)(y0 * a.sw) * 3, src + (unsigned)(y1 * a.sw) * 3, x0, a.sw);
         (void)x1;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float p = (float)t00[c], q = (float)t01[c], r = (float)t10[c], s = (float)t11[c];
+            const float p = (float)chan_u8(t.p00, c), q = (float)chan_u8(t.p01, c), r = (float)chan_u8(t.p10, c), s = (float)chan_u8(t.p11, c);
             const float top = p + w * (q - p), bot = r + w * (s - r);
             v[c] = (top + wy * (bot - top)) * n.scale[c] + n.bias[c];
         }
@@ -279,14 +279,15 @@ __global__ __launch_bounds__(kBx* kBy) void cv_linear_u8_kernel(Rz a) {  // resi
     KH_RZ_PROLOGUE
     const LinTap tx = linear_tap(x, a.scale_x, a.sw), ty = linear_tap(y, a.scale_y, a.sh);
     const int sy1 = min(ty.ofs + 1, a.sh - 1);
-    uint32_t p00[C], p01[C], p10[C], p11[C];  // border columns (ofs == sw - 1) only use the first pixel
-    load_quad_u8<C>(src + (unsigned)(ty.ofs * a.sw) * C, src + (unsigned)(sy1 * a.sw) * C, tx.ofs, a.sw, p00, p01, p10, p11);
+    // border columns (ofs == sw - 1) only use the first pixel
+    const QuadU8 q = load_quad_u8<C>(src + (unsigned)(ty.ofs * a.sw) * C, src + (unsigned)(sy1 * a.sw) * C, tx.ofs, a.sw);
     uint8_t* o = dst + ((long long)y * a.dw + x) * C;
 #pragma unroll
     for (int k = 0; k < C; ++k) {
+        const int32_t p00 = (int32_t)chan_u8(q.p00, k), p01 = (int32_t)chan_u8(q.p01, k), p10 = (int32_t)chan_u8(q.p10, k), p11 = (int32_t)chan_u8(q.p11, k);
         int32_t s0, s1;
-        if (tx.border) { s0 = (int32_t)p00[k] << 11; s1 = (int32_t)p10[k] << 11; }
-        else { s0 = (int32_t)p00[k] * tx.i0 + (int32_t)p01[k] * tx.i1; s1 = (int32_t)p10[k] * tx.i0 + (int32_t)p11[k] * tx.i1; }
+        if (tx.border) { s0 = p00 << 11; s1 = p10 << 11; }
+        else { s0 = p00 * tx.i0 + p01 * tx.i1; s1 = p10 * tx.i0 + p11 * tx.i1; }
         o[k] = (uint8_t)((((ty.i0 * (s0 >> 4)) >> 16) + ((ty.i1 * (s1 >> 4)) >> 16) + 2) >> 2);
     }
 }

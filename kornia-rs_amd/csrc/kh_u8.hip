@@ -326,12 +326,12 @@ __device__ __forceinline__ void sample_q10(const uint8_t* __restrict__ src, int 
                                            uint32_t fy, uint8_t* o) {
     const uint32_t fx1 = 1024u - fx, fy1 = 1024u - fy;
     const int yi1 = yi + 1 < sh ? yi + 1 : yi;
-    uint32_t p00[C], p01[C], p10[C], p11[C];  // xi1 = xi + 1 < sw ? xi + 1 : xi  ==  load_quad_u8's second pixel
-    load_quad_u8<C>(src + (unsigned)(yi * sw) * C, src + (unsigned)(yi1 * sw) * C, xi, sw, p00, p01, p10, p11);  // < 2^31 B
+    // xi1 = xi + 1 < sw ? xi + 1 : xi  ==  load_quad_u8's second pixel; offsets < 2^31 B (host-checked)
+    const QuadU8 q = load_quad_u8<C>(src + (unsigned)(yi * sw) * C, src + (unsigned)(yi1 * sw) * C, xi, sw);
     uint32_t v[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const uint32_t top = p00[c] * fx1 + p01[c] * fx, bot = p10[c] * fx1 + p11[c] * fx;
+        const uint32_t top = chan_u8(q.p00, c) * fx1 + chan_u8(q.p01, c) * fx, bot = chan_u8(q.p10, c) * fx1 + chan_u8(q.p11, c) * fx;
         v[c] = ((top * fy1 + bot * fy + (1u << 19)) >> 20) & 0xffu;
     }
     put_u8<C>(o, v);
