@@ -37,8 +37,7 @@ struct FusedProgram {
     XcdTiles tiles;
 };
 
-// LOADS (dev A/B, KH_FUSE_LOADS): 0 = twelve byte loads, 1 = paired loads behind an edge test, 2 = load_quad_u8
-template <int SINK, int LOADS>
+template <int SINK>
 __global__ __launch_bounds__(kBx* kBy) void fused_pipeline_kernel(FusedProgram P) {
     unsigned bx_, by_, bz_;
     if (!xcd_tile(P.tiles, bx_, by_, bz_)) return;
@@ -57,31 +56,14 @@ __global__ __launch_bounds__(kBx* kBy) void fused_pipeline_kernel(FusedProgram P
     const uint8_t* r1 = src + (size_t)sy1 * P.sw * 3u;
     const float w00 = (1.0f - wy) * (1.0f - wx), w01 = (1.0f - wy) * wx, w10 = wy * (1.0f - wx), w11 = wy * wx;
     // the two taps of a row are adjacent: one dword + one ushort load instead of six byte loads
-    uint32_t t[4][3];
-    if constexpr (LOADS == 2) {
-        const QuadU8 q = load_quad_u8<3>(r0, r1, (int)sx0, P.sw);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { t[0][c] = chan_u8(q.p00, c); t[1][c] = chan_u8(q.p01, c); t[2][c] = chan_u8(q.p10, c); t[3][c] = chan_u8(q.p11, c); }
-    } else {
-        const unsigned sx1 = min(sx0 + 1u, (unsigned)P.sw - 1u);
-        if (LOADS == 1 && sx1 != sx0) {
-            const uint32_t a0 = *reinterpret_cast<const u32_unaligned*>(r0 + sx0 * 3u), a1 = *reinterpret_cast<const u16_unaligned*>(r0 + sx0 * 3u + 4u);
-            const uint32_t b0 = *reinterpret_cast<const u32_unaligned*>(r1 + sx0 * 3u), b1 = *reinterpret_cast<const u16_unaligned*>(r1 + sx0 * 3u + 4u);
-            t[0][0] = a0 & 0xFF; t[0][1] = (a0 >> 8) & 0xFF; t[0][2] = (a0 >> 16) & 0xFF;
-            t[1][0] = a0 >> 24; t[1][1] = a1 & 0xFF; t[1][2] = a1 >> 8;
-            t[2][0] = b0 & 0xFF; t[2][1] = (b0 >> 8) & 0xFF; t[2][2] = (b0 >> 16) & 0xFF;
-            t[3][0] = b0 >> 24; t[3][1] = b1 & 0xFF; t[3][2] = b1 >> 8;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                t[0][c] = r0[sx0 * 3u + c]; t[1][c] = r0[sx1 * 3u + c]; t[2][c] = r1[sx0 * 3u + c]; t[3][c] = r1[sx1 * 3u + c];
-            }
-        }
-    }
+    // sx1 = min(sx0 + 1, sw - 1) is load_quad_u8's second pixel (12 byte loads: 3.9 ms, 4 paired loads: 2.2 ms on
+    // the 1080p -> 640 x 1024 probe, profiles/r01s_ab.log)
+    const QuadU8 q = load_quad_u8<3>(r0, r1, (int)sx0, P.sw);
     float v[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        v[c] = w00 * (float)t[0][c] + w01 * (float)t[1][c] + w10 * (float)t[2][c] + w11 * (float)t[3][c];
+        v[c] = w00 * (float)chan_u8(q.p00, c) + w01 * (float)chan_u8(q.p01, c) + w10 * (float)chan_u8(q.p10, c) +
+               w11 * (float)chan_u8(q.p11, c);
 
     // maps (wave-uniform program walk)
     for (int i = 0; i < P.nmaps; ++i) {
@@ -210,17 +192,10 @@ int32_t kh_fused_pipeline_launch(kh_fused_pipeline_t p, kh_stream_t stream, cons
         g.dst = dst + (long long)base * g.dst_stride;
         g.tiles = xcd_tiles(cdiv(g.dw, kBx), cdiv(g.dh, kBy), (unsigned)n, cdiv(g.dw, kBx) * 8);
         KH_REQUIRE(g.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-        static const int loads = [] { const char* e = getenv("KH_FUSE_LOADS"); return e && *e ? atoi(e) : 2; }();
-        const dim3 grid = xcd_grid(g.tiles);
-#define KH_FUSE_LAUNCH(SINK)                                                                          \
-    do {                                                                                              \
-        if (loads == 0) hipLaunchKernelGGL((fused_pipeline_kernel<SINK, 0>), grid, blk, 0, st, g);    \
-        else if (loads == 1) hipLaunchKernelGGL((fused_pipeline_kernel<SINK, 1>), grid, blk, 0, st, g); \
-        else hipLaunchKernelGGL((fused_pipeline_kernel<SINK, 2>), grid, blk, 0, st, g);               \
-    } while (0)
-        if (p->sink == KH_FUSE_WRITE_CHW_F32) KH_FUSE_LAUNCH(KH_FUSE_WRITE_CHW_F32);
-        else KH_FUSE_LAUNCH(KH_FUSE_WRITE_C1_F32);
-#undef KH_FUSE_LAUNCH
+        if (p->sink == KH_FUSE_WRITE_CHW_F32)
+            hipLaunchKernelGGL(fused_pipeline_kernel<KH_FUSE_WRITE_CHW_F32>, xcd_grid(g.tiles), blk, 0, st, g);
+        else
+            hipLaunchKernelGGL(fused_pipeline_kernel<KH_FUSE_WRITE_C1_F32>, xcd_grid(g.tiles), blk, 0, st, g);
     }
     return check_launch(what);
 }

@@ -305,49 +305,57 @@ struct ImgU8 {
     XcdTiles tiles;
 };
 
+// A destination pixel as a packed word (channel c = bits [8c, 8c+8)).  RGB8 rows are written with dword
+// stores: in a full wave the 64 pixels are 192 contiguous bytes = 48 dwords, assembled with two
+// cross-lane reads per lane instead of three byte-granular store instructions per pixel (the gathers are
+// bound by vector-memory instructions).  `wave_full` must be wave-uniform and all 64 lanes must call.
 template <int C>
-__device__ __forceinline__ void put_u8(uint8_t* o, const uint32_t v[C]) {
+__device__ __forceinline__ void store_px_u8(uint8_t* o, uint32_t px, bool wave_full) {
     if constexpr (C == 4) {
-        *reinterpret_cast<uint32_t*>(o) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);  // pixel-aligned
+        *reinterpret_cast<uint32_t*>(o) = px;  // pixel-aligned
+    } else if constexpr (C == 3) {
+        if (wave_full) {
+            const int lane = threadIdx.x;  // kBx == 64: one wave per tile row
+            const int a = (4 * lane) / 3, off = (4 * lane) % 3;
+            const uint32_t pa = (uint32_t)__shfl((int)px, a), pb = (uint32_t)__shfl((int)px, min(a + 1, 63));
+            const uint64_t w = (uint64_t)pa | ((uint64_t)pb << 24);
+            if (lane < 48) *reinterpret_cast<u32_unaligned*>(o + lane) = (uint32_t)(w >> (8 * off));  // row base + 4*lane
+        } else {
+            o[0] = (uint8_t)px; o[1] = (uint8_t)(px >> 8); o[2] = (uint8_t)(px >> 16);
+        }
     } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) o[c] = (uint8_t)v[c];
+        for (int c = 0; c < C; ++c) o[c] = (uint8_t)(px >> (8 * c));
     }
-}
-template <int C>
-__device__ __forceinline__ void put_zero_u8(uint8_t* o) {
-    const uint32_t z[4] = {0, 0, 0, 0};
-    put_u8<C>(o, z);
 }
 
 // bilinear_sample_u8_valid (P/warp/common.rs:79-165): xi, yi in range; fx, fy in Q10
 template <int C>
-__device__ __forceinline__ void sample_q10(const uint8_t* __restrict__ src, int sw, int sh, int xi, int yi, uint32_t fx,
-                                           uint32_t fy, uint8_t* o) {
+__device__ __forceinline__ uint32_t sample_q10(const uint8_t* __restrict__ src, int sw, int sh, int xi, int yi, uint32_t fx,
+                                               uint32_t fy) {
     const uint32_t fx1 = 1024u - fx, fy1 = 1024u - fy;
     const int yi1 = yi + 1 < sh ? yi + 1 : yi;
     // xi1 = xi + 1 < sw ? xi + 1 : xi  ==  load_quad_u8's second pixel; offsets < 2^31 B (host-checked)
     const QuadU8 q = load_quad_u8<C>(src + (unsigned)(yi * sw) * C, src + (unsigned)(yi1 * sw) * C, xi, sw);
-    uint32_t v[C];
+    uint32_t px = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const uint32_t top = chan_u8(q.p00, c) * fx1 + chan_u8(q.p01, c) * fx, bot = chan_u8(q.p10, c) * fx1 + chan_u8(q.p11, c) * fx;
-        v[c] = ((top * fy1 + bot * fy + (1u << 19)) >> 20) & 0xffu;
+        px |= (((top * fy1 + bot * fy + (1u << 19)) >> 20) & 0xffu) << (8 * c);
     }
-    put_u8<C>(o, v);
+    return px;
 }
 
 // bilinear_sample_u8 (P/warp/common.rs:16-70): zeros when non-finite or outside
 template <int C>
-__device__ __forceinline__ void sample_q10_checked(const uint8_t* __restrict__ src, int sw, int sh, float xf, float yf,
-                                                   uint8_t* o) {
+__device__ __forceinline__ uint32_t sample_q10_checked(const uint8_t* __restrict__ src, int sw, int sh, float xf, float yf) {
     bool ok = __builtin_isfinite(xf) && __builtin_isfinite(yf);
     // floor(..) as i32 saturates in the reference; clamping first keeps the range test identical
     const int xi = (int)fminf(fmaxf(floorf(xf), -1.0f), 2147483520.0f);
     const int yi = (int)fminf(fmaxf(floorf(yf), -1.0f), 2147483520.0f);
     ok = ok && xi >= 0 && xi < sw && yi >= 0 && yi < sh;
-    if (!ok) { put_zero_u8<C>(o); return; }
-    sample_q10<C>(src, sw, sh, xi, yi, (uint32_t)((xf - (float)xi) * 1024.0f), (uint32_t)((yf - (float)yi) * 1024.0f), o);
+    if (!ok) return 0u;
+    return sample_q10<C>(src, sw, sh, xi, yi, (uint32_t)((xf - (float)xi) * 1024.0f), (uint32_t)((yf - (float)yi) * 1024.0f));
 }
 
 #define KH_U8_PROLOGUE                                          \
@@ -355,7 +363,8 @@ __device__ __forceinline__ void sample_q10_checked(const uint8_t* __restrict__ s
     if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;             \
     const int x = bx_ * kBx + threadIdx.x;                      \
     const int y = by_ * kBy + threadIdx.y;                      \
-    if (x >= im.dw || y >= im.dh) return;
+    if (x >= im.dw || y >= im.dh) return;                       \
+    const bool wave_full = (int)(bx_ * kBx) + kBx <= im.dw; /* uniform: all 64 lanes of this row are inside */
 
 // remap_u8 (P/interpolation/remap.rs:157-300); maps shared by the batch, kU8RemapNB images per thread
 constexpr int kU8RemapNB = 4;
@@ -372,20 +381,16 @@ __global__ __launch_bounds__(kBx* kBy) void remap_u8_kernel(ImgU8 im, const floa
         if (z >= batch) break;
         const uint8_t* src = im.src + (long long)z * im.src_stride;
         uint8_t* o = im.dst + (long long)z * im.dst_stride + i * C;
+        uint32_t px = 0;
         if constexpr (MODE == KH_INTERP_BILINEAR) {
-            sample_q10_checked<C>(src, im.sw, im.sh, xf, yf, o);
+            px = sample_q10_checked<C>(src, im.sw, im.sh, xf, yf);
         } else {  // nearest, :268-298
             if (xf >= 0.0f && xf < (float)im.sw && yf >= 0.0f && yf < (float)im.sh) {
                 const int xi = min(max((int)roundf(xf), 0), im.sw - 1), yi = min(max((int)roundf(yf), 0), im.sh - 1);
-                const uint8_t* p = src + ((long long)yi * im.sw + xi) * C;
-                uint32_t v[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) v[c] = p[c];
-                put_u8<C>(o, v);
-            } else {
-                put_zero_u8<C>(o);
+                px = load_px_u8<C>(src + ((long long)yi * im.sw + xi) * C);
             }
         }
+        store_px_u8<C>(o, px, wave_full);
     }
 }
 
@@ -455,13 +460,16 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_u8_kernel(ImgU8 im, cons
     const uint8_t* src = im.src + (long long)bz_ * im.src_stride;
     uint8_t* o = im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C;
     const AffineRow r = rows[y];
-    if (x < r.lo || x >= r.hi) { put_zero_u8<C>(o); return; }
-    const int sx_q = (int)(r.sx_lo + (uint32_t)(x - r.lo) * (uint32_t)dsx_q);
-    const int sy_q = (int)(r.sy_lo + (uint32_t)(x - r.lo) * (uint32_t)dsy_q);
-    // The span keeps the indices in range in exact arithmetic; the clamp only matters where Q16
-    // rounding drift would take the reference's unchecked sampler outside the image.
-    const int xi = min(max(sx_q >> 16, 0), im.sw - 1), yi = min(max(sy_q >> 16, 0), im.sh - 1);
-    sample_q10<C>(src, im.sw, im.sh, xi, yi, ((uint32_t)(sx_q & 0xFFFF)) >> 6, ((uint32_t)(sy_q & 0xFFFF)) >> 6, o);
+    uint32_t px = 0;
+    if (x >= r.lo && x < r.hi) {
+        const int sx_q = (int)(r.sx_lo + (uint32_t)(x - r.lo) * (uint32_t)dsx_q);
+        const int sy_q = (int)(r.sy_lo + (uint32_t)(x - r.lo) * (uint32_t)dsy_q);
+        // The span keeps the indices in range in exact arithmetic; the clamp only matters where Q16
+        // rounding drift would take the reference's unchecked sampler outside the image.
+        const int xi = min(max(sx_q >> 16, 0), im.sw - 1), yi = min(max(sy_q >> 16, 0), im.sh - 1);
+        px = sample_q10<C>(src, im.sw, im.sh, xi, yi, ((uint32_t)(sx_q & 0xFFFF)) >> 6, ((uint32_t)(sy_q & 0xFFFF)) >> 6);
+    }
+    store_px_u8<C>(o, px, wave_full);
 }
 
 // warp_perspective_u8 (P/warp/perspective.rs:179-322): rows whose denominator keeps one sign get
@@ -501,11 +509,14 @@ __global__ __launch_bounds__(kBx* kBy) void warp_perspective_u8_kernel(ImgU8 im,
     const uint8_t* src = im.src + (long long)bz_ * im.src_stride;
     uint8_t* o = im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C;
     const PerspRow r = rows[y];
-    if (x < r.lo || x >= r.hi) { put_zero_u8<C>(o); return; }
-    const float xf_ = (float)x;
-    const float nx = r.nx0 + r.dnx * xf_, ny = r.ny0 + r.dny * xf_, nd = r.nd0 + r.dnd * xf_;
-    const float inv_nd = 1.0f / nd;
-    sample_q10_checked<C>(src, im.sw, im.sh, nx * inv_nd, ny * inv_nd, o);
+    uint32_t px = 0;
+    if (x >= r.lo && x < r.hi) {
+        const float xf_ = (float)x;
+        const float nx = r.nx0 + r.dnx * xf_, ny = r.ny0 + r.dny * xf_, nd = r.nd0 + r.dnd * xf_;
+        const float inv_nd = 1.0f / nd;
+        px = sample_q10_checked<C>(src, im.sw, im.sh, nx * inv_nd, ny * inv_nd);
+    }
+    store_px_u8<C>(o, px, wave_full);
 }
 
 ImgU8 make_img_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int64_t ss, int64_t ds, int groups) {
