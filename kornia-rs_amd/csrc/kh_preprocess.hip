@@ -21,6 +21,8 @@
 //     At scale 1 the bilinear weights are exactly 0 (`ax == ay == 0.0f`), hence
 //     `t00 + (t10 - t00) * 0 == t00` for the finite 0..255 taps and the result equals the
 //     generic kernel bit for bit; tests assert that equality.
+#include <stdlib.h>
+
 #include "kh_common.h"
 
 using namespace kh;
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
 // Does quot3 reproduce IEEE division for every (o - pad) / scale the launch will evaluate?  dst_w +
 // dst_h host evaluations (microseconds), memoised on the last geometry.
 bool plan_division_is_exact(const PreArgs& a) {
+    if (const char* e = getenv("KH_PRE_IEEE_DIV"); e && e[0] == '1') return false;  // dev/test knob: always divide
     struct Key { float sx, sy, px, py; int w, h; bool ok; };
     static thread_local Key last = {0, 0, 0, 0, 0, 0, false};
     if (last.w == a.dst_w && last.h == a.dst_h && last.sx == a.scale_x && last.sy == a.scale_y && last.px == a.pad_x &&

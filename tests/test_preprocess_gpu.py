@@ -246,3 +246,19 @@ def test_python_run_api(gpu_stream):
     assert np.array_equal(outs.numpy()[0], want[0])
     cai = out.__cuda_array_interface__
     assert cai["shape"] == (1, 3, 24, 24) and cai["typestr"] == "<f4" and cai["data"][0] == out.data_ptr
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "rgb", "yuyv"])
+def test_quotient_shortcut_equals_ieee_division_path(gpu_stream, fmt, monkeypatch):
+    """The generic kernel replaces (o - pad) / scale by a host-verified 3-op quotient; KH_PRE_IEEE_DIV=1
+    forces the plain divisions.  Both must give the oracle's bits on awkward scales."""
+    for (w, h), (dw, dh), mode in [((1920, 1080), (640, 640), "letterbox"), ((130, 98), (97, 55), "stretch"),
+                                   ((64, 48), (333, 171), "letterbox"), ((258, 194), (224, 224), "stretch")]:
+        raw = _raw_for(fmt, w, h, seed=5)
+        kw = dict(fmt=fmt, mode=mode, sampling="bilinear", **IMAGENET)
+        want = O.preprocess(raw, w, h, dw, dh, **kw)
+        monkeypatch.delenv("KH_PRE_IEEE_DIV", raising=False)
+        _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), want, f"{fmt} {w}x{h}->{dw}x{dh} shortcut")
+        monkeypatch.setenv("KH_PRE_IEEE_DIV", "1")
+        _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), want, f"{fmt} {w}x{h}->{dw}x{dh} ieee")
+    monkeypatch.delenv("KH_PRE_IEEE_DIV", raising=False)
