@@ -284,6 +284,17 @@ KH_API int32_t kh_box_blur_kernel_1d(int32_t n, float* out);
 KH_API int32_t kh_gaussian_kernel_1d(int32_t n, float sigma, float* out);
 KH_API int32_t kh_gaussian_resolve(int32_t ksize_xy[2], float sigma_xy[2]);
 
+/* CIE colour spaces — replaces the 16 NVRTC kernels of P/cuda/color/cie.rs (adapters
+ * P/color/cuda_dispatch.rs) == linear_rgb_from_rgb, rgb_from_linear_rgb, xyz_from_rgb, rgb_from_xyz,
+ * lab_from_rgb, rgb_from_lab, luv_from_rgb, rgb_from_luv (P/color/cie/mod.rs:58-130): f32 RGB in [0, 1],
+ * D65, OpenCV coefficients; XYZ is the bare 3x3 matrix (no gamma), Lab / Luv linearise first.  The
+ * matrix conversions are bit-identical to the reference's scalar path; the transfer / cube-root stages
+ * are held to its own tolerances against the f64 formulas (powf / cbrtf differ in the last bits between
+ * math libraries, as they do between the reference's NEON and scalar paths).                    */
+enum { KH_CIE_LINEAR_RGB_FROM_RGB = 0, KH_CIE_RGB_FROM_LINEAR_RGB = 1, KH_CIE_XYZ_FROM_RGB = 2, KH_CIE_RGB_FROM_XYZ = 3,
+       KH_CIE_LAB_FROM_RGB = 4, KH_CIE_RGB_FROM_LAB = 5, KH_CIE_LUV_FROM_RGB = 6, KH_CIE_RGB_FROM_LUV = 7 };
+KH_API int32_t kh_cie_convert_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels, int32_t conversion);
+
 /* ------------------------------------------------------------------------------------------ */
 /* u8 fixed-point twins.  Byte-identical to the reference CPU ops they replace the
  * device launchers of; HWC u8, channels in {1, 3, 4}, `batch` images `*_stride` BYTES apart.

@@ -518,6 +518,92 @@ int32_t check_wh(const void* src, const void* dst, int w, int h, bool even_w, bo
     return KH_OK;
 }
 
+
+// ---- CIE colour spaces (P/color/cie: kernels.rs:21-340, transfer.rs:14-45) -------------------------------
+// f32 per-pixel formulas of the reference's scalar path.  The matrix-only conversions are plain mul/add
+// and bit-identical; the sRGB transfer and Lab / Luv stages call powf / cbrtf, whose last bits differ
+// between libm implementations (the reference's own NEON path uses ~4e-4 polynomials), so those are held
+// to the reference's tolerances against its f64 formulas instead (tests/test_cie.py).
+constexpr float kM_RGB2XYZ[9] = {0.412453f, 0.357580f, 0.180423f, 0.212671f, 0.715160f, 0.072169f, 0.019334f, 0.119193f, 0.950227f};
+constexpr float kM_XYZ2RGB[9] = {3.240479f, -1.537150f, -0.498535f, -0.969256f, 1.875991f, 0.041556f, 0.055648f, -0.204043f, 1.057311f};
+constexpr float kXN = 0.950456f, kZN = 1.088754f, kInvXN = 1.0f / kXN, kInvZN = 1.0f / kZN;
+constexpr float kLabDelta = 0.008856f, kLabFSlope = 1.0f / 0.12841855f, kLabFOffset = 0.13793103f;
+constexpr float kLabFinvThresh = 0.20689655f, kLabFinvSlope = 0.12841855f;
+constexpr float kLuvUn = 0.19793943f, kLuvVn = 0.46831096f, kLuvKappa = 903.3f;
+
+__device__ __forceinline__ float srgb_to_linear(float x) {  // transfer.rs:27-35
+    x = fmaxf(x, 0.0f);
+    return x <= 0.04045f ? x * (1.0f / 12.92f) : powf((x + 0.055f) * (1.0f / 1.055f), 2.4f);
+}
+__device__ __forceinline__ float linear_to_srgb(float l) {  // transfer.rs:37-45
+    l = fmaxf(l, 0.0f);
+    return l <= 0.0031308f ? l * 12.92f : 1.055f * powf(l, 1.0f / 2.4f) - 0.055f;
+}
+__device__ __forceinline__ void matvec32(const float m[9], float a, float b, float c, float o[3]) {
+    o[0] = m[0] * a + m[1] * b + m[2] * c;
+    o[1] = m[3] * a + m[4] * b + m[5] * c;
+    o[2] = m[6] * a + m[7] * b + m[8] * c;
+}
+__device__ __forceinline__ float lab_f(float t) { return t > kLabDelta ? cbrtf(t) : t * kLabFSlope + kLabFOffset; }
+__device__ __forceinline__ float lab_finv(float f) { return f > kLabFinvThresh ? f * f * f : kLabFinvSlope * (f - kLabFOffset); }
+__device__ __forceinline__ void lin_xyz_from_rgb(const float in[3], float o[3]) {
+    matvec32(kM_RGB2XYZ, srgb_to_linear(in[0]), srgb_to_linear(in[1]), srgb_to_linear(in[2]), o);
+}
+__device__ __forceinline__ void rgb_from_lin_xyz(float x, float y, float z, float out[3]) {
+    float l[3];
+    matvec32(kM_XYZ2RGB, x, y, z, l);
+    out[0] = linear_to_srgb(l[0]); out[1] = linear_to_srgb(l[1]); out[2] = linear_to_srgb(l[2]);
+}
+struct CieF32 {
+    int conv;
+    __device__ void operator()(const float in[3], float out[3]) const {
+        switch (conv) {  // wave-uniform
+            case KH_CIE_LINEAR_RGB_FROM_RGB:
+                out[0] = srgb_to_linear(in[0]); out[1] = srgb_to_linear(in[1]); out[2] = srgb_to_linear(in[2]);
+                break;
+            case KH_CIE_RGB_FROM_LINEAR_RGB:
+                out[0] = linear_to_srgb(in[0]); out[1] = linear_to_srgb(in[1]); out[2] = linear_to_srgb(in[2]);
+                break;
+            case KH_CIE_XYZ_FROM_RGB: matvec32(kM_RGB2XYZ, in[0], in[1], in[2], out); break;  // no gamma, kernels.rs:124-131
+            case KH_CIE_RGB_FROM_XYZ: matvec32(kM_XYZ2RGB, in[0], in[1], in[2], out); break;
+            case KH_CIE_LAB_FROM_RGB: {  // kernels.rs:277-283
+                float q[3];
+                lin_xyz_from_rgb(in, q);
+                const float fx = lab_f(q[0] * kInvXN), fy = lab_f(q[1]), fz = lab_f(q[2] * kInvZN);
+                out[0] = 116.0f * fy - 16.0f; out[1] = 500.0f * (fx - fy); out[2] = 200.0f * (fy - fz);
+                break;
+            }
+            case KH_CIE_RGB_FROM_LAB: {  // :286-294
+                const float fy = (in[0] + 16.0f) / 116.0f, fx = fy + in[1] / 500.0f, fz = fy - in[2] / 200.0f;
+                rgb_from_lin_xyz(kXN * lab_finv(fx), 1.0f * lab_finv(fy), kZN * lab_finv(fz), out);
+                break;
+            }
+            case KH_CIE_LUV_FROM_RGB: {  // :297-312
+                float q[3];
+                lin_xyz_from_rgb(in, q);
+                const float yr = q[1];
+                const float l = yr > kLabDelta ? 116.0f * cbrtf(yr) - 16.0f : kLuvKappa * yr;
+                const float d = q[0] + 15.0f * q[1] + 3.0f * q[2];
+                const float up = d == 0.0f ? 0.0f : 4.0f * q[0] / d, vp = d == 0.0f ? 0.0f : 9.0f * q[1] / d;
+                out[0] = l; out[1] = 13.0f * l * (up - kLuvUn); out[2] = 13.0f * l * (vp - kLuvVn);
+                break;
+            }
+            default: {  // KH_CIE_RGB_FROM_LUV, :315-337
+                const float l = in[0];
+                if (l <= 0.0f) { rgb_from_lin_xyz(0.0f, 0.0f, 0.0f, out); break; }
+                float y;
+                if (l > 8.0f) { const float t = (l + 16.0f) / 116.0f; y = 1.0f * t * t * t; }
+                else y = 1.0f * l / kLuvKappa;
+                const float inv13l = 1.0f / (13.0f * l);
+                const float up = in[1] * inv13l + kLuvUn, vp = in[2] * inv13l + kLuvVn;
+                const float x = y * 9.0f * up / (4.0f * vp);
+                const float z = y * (12.0f - 3.0f * up - 20.0f * vp) / (4.0f * vp);
+                rgb_from_lin_xyz(x, y, z, out);
+            }
+        }
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -526,6 +612,12 @@ extern "C" {
     int32_t NAME(kh_stream_t s, const uint8_t* src, uint8_t* dst, int64_t n) { return launch_u8<CIN, COUT>(s, src, dst, n, OP, #NAME); }
 #define KH_MAP_F32(NAME, CIN, COUT, OP) \
     int32_t NAME(kh_stream_t s, const float* src, float* dst, int64_t n) { return launch_f32<CIN, COUT>(s, src, dst, n, OP, #NAME); }
+
+int32_t kh_cie_convert_f32(kh_stream_t s, const float* src, float* dst, int64_t n, int32_t conv) {
+    KH_REQUIRE(conv >= KH_CIE_LINEAR_RGB_FROM_RGB && conv <= KH_CIE_RGB_FROM_LUV, KH_ERR_INVALID_ARG,
+               "kh_cie_convert_f32: unknown conversion %d", conv);
+    return launch_f32<3, 3>(s, src, dst, n, CieF32{conv}, "kh_cie_convert_f32");
+}
 
 KH_MAP_U8(kh_gray_from_rgb_u8, 3, 1, GrayFromRgbU8{})
 KH_MAP_F32(kh_gray_from_rgb_f32, 3, 1, GrayFromRgbF32{})

@@ -31,6 +31,8 @@ KH_PRE_FORCE_GENERIC = 1
 KH_YCC_YCRCB, KH_YCC_YUV = 0, 1
 KH_INTERP_NEAREST, KH_INTERP_BILINEAR, KH_INTERP_BICUBIC, KH_INTERP_LANCZOS = 0, 1, 2, 3
 KH_MORPH_DILATE, KH_MORPH_ERODE = 0, 1
+KH_CIE = {"linear_rgb_from_rgb": 0, "rgb_from_linear_rgb": 1, "xyz_from_rgb": 2, "rgb_from_xyz": 3, "lab_from_rgb": 4,
+          "rgb_from_lab": 5, "luv_from_rgb": 6, "rgb_from_luv": 7}
 KH_FUSE_READ_U8RGB_BILINEAR, KH_FUSE_NORMALIZE, KH_FUSE_RGB_TO_GRAY, KH_FUSE_WRITE_CHW_F32, KH_FUSE_WRITE_C1_F32 = 1, 16, 17, 32, 33
 
 
@@ -109,6 +111,7 @@ SIGNATURES = {
     **{n: (_i32, [_vp, _vp, _vp, _i64, _i32]) for n in (
         "kh_rgba_from_rgb_u8", "kh_rgba_from_rgb_f32", "kh_ycc_from_rgb_u8", "kh_rgb_from_ycc_u8",
         "kh_ycc_from_rgb_f32", "kh_rgb_from_ycc_f32")},
+    "kh_cie_convert_f32": (_i32, [_vp, _vp, _vp, _i64, _i32]),
     "kh_rgb_from_rgba_u8": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "kh_apply_colormap_u8": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "kh_rgb_from_planar420_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),

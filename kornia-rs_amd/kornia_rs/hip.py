@@ -165,6 +165,31 @@ def _stream_handle(stream: Optional[Stream]) -> int:
     return 0 if stream is None else stream.cuda_stream_ptr
 
 
+class PinnedBuffer:
+    """Page-locked host memory (``PinnedAllocator`` / ``zeros_pinned``, T/cuda.rs:355-380): the source
+    of true stream-ordered DMA uploads.  ``view()`` is a writable uint8 numpy view."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib.kh_host_alloc(C.byref(p), max(self.nbytes, 1)))
+        self.ptr = p.value
+
+    def view(self) -> np.ndarray:
+        return np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr))[: self.nbytes]
+
+    def free(self) -> None:
+        p, self.ptr = self.ptr, None
+        if p:
+            lib.kh_host_free(p)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class DeviceBuffer:
     """An owned, stream-ordered device allocation (``CudaResource`` with ``Backing::Device`` in
     crates/kornia-tensor/src/cuda.rs:89-169): carries its stream, freed on that stream."""

@@ -690,3 +690,32 @@ def morph_open(src: Image, kernel: Kernel, padding_mode: str = "constant", const
 def morph_close(src: Image, kernel: Kernel, padding_mode: str = "constant", constant_value=0, dst: Optional[Image] = None) -> Image:
     """close (P/morphology/ops.rs:255-268): dilate into a temporary, then erode."""
     return erode(dilate(src, kernel, padding_mode, constant_value), kernel, padding_mode, constant_value, dst)
+
+
+# ---- CIE colour spaces (P/color/cie/mod.rs:58-160) ---------------------------------------------------------
+
+def _cie(name: str):
+    code = _ffi.KH_CIE[name]
+
+    def conv(src: Image, dst: Optional[Image] = None) -> Image:
+        _require(src, "float32", (3,), name)
+        out = dst if dst is not None else _new_like(src)
+        _require(out, "float32", (3,), name)
+        _same_size(src, out)
+        stream = _pair_residency(src, out)
+        _check(lib.kh_cie_convert_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height, code))
+        return out
+
+    conv.__name__ = name
+    conv.__doc__ = f"``{name}`` on float32 RGB in [0, 1] (D65, OpenCV coefficients)."
+    return conv
+
+
+linear_rgb_from_rgb = _cie("linear_rgb_from_rgb")
+rgb_from_linear_rgb = _cie("rgb_from_linear_rgb")
+xyz_from_rgb = _cie("xyz_from_rgb")
+rgb_from_xyz = _cie("rgb_from_xyz")
+lab_from_rgb = _cie("lab_from_rgb")
+rgb_from_lab = _cie("rgb_from_lab")
+luv_from_rgb = _cie("luv_from_rgb")
+rgb_from_luv = _cie("rgb_from_luv")

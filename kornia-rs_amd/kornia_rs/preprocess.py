@@ -116,7 +116,7 @@ RawSource = Union[DeviceBuffer, Tensor, int]
 
 
 def _ptr_len(src: Any) -> Tuple[int, Optional[int]]:
-    if isinstance(src, DeviceBuffer):
+    if isinstance(src, (DeviceBuffer, _DeviceView)):
         return src.ptr, src.nbytes
     if isinstance(src, Tensor):
         if not src.is_device:
@@ -131,6 +131,50 @@ def _ptr_len(src: Any) -> Tuple[int, Optional[int]]:
         raise PreprocessError("NotDeviceImage",
                               "HIP preprocessor requires a device-resident source image")
     return int(src), None
+
+
+class _Staging:
+    """Persistent upload staging for host frames (``Staging``, PY/cuda_ext/mod.rs:688-745): ONE page-locked
+    host buffer holding the frames of a call back to back and one device buffer, both grown on demand and
+    reused across calls.  Page-locking is far too expensive for a frame loop, and pinned memory makes the
+    H2D copy a stream-ordered DMA.  The event recorded after each upload is host-waited before the pinned
+    bytes are overwritten by the next call (the plain host copy is not stream-ordered)."""
+
+    def __init__(self):
+        self.pinned = None
+        self.device = None
+        self.upload_done = None
+        self.allocations = 0  # grows only; exposed for the tests
+
+    def upload(self, stream: Stream, frames):
+        from .hip import Event, PinnedBuffer
+        frame_len = int(frames[0].size)
+        stride = (frame_len + 255) // 256 * 256  # keep every frame 256-byte aligned on the device
+        total = stride * len(frames)
+        if self.upload_done is not None:  # wait_prev_upload: BEFORE touching (or re-allocating) the pinned buffer
+            self.upload_done.synchronize()
+            self.upload_done = None
+        if self.pinned is None or self.pinned.nbytes < total:
+            self.pinned = PinnedBuffer(total)
+            self.allocations += 1
+        if self.device is None or self.device.nbytes < total:
+            self.device = DeviceBuffer(total, stream, zeroed=False)
+            self.allocations += 1
+        view = self.pinned.view()
+        for k, fr in enumerate(frames):
+            view[k * stride: k * stride + frame_len] = fr
+        check(lib.kh_memcpy_h2d_async(self.device.ptr, self.pinned.ptr, total, stream.cuda_stream_ptr))
+        ev = Event(timing=False)
+        ev.record(stream)  # mark_upload
+        self.upload_done = ev
+        return _DeviceView(self.device, frame_len if len(frames) == 1 else total), stride
+
+
+class _DeviceView:
+    """A (ptr, nbytes) view of the staging device buffer, accepted by ``_ptr_len``."""
+
+    def __init__(self, buf: DeviceBuffer, nbytes: int):
+        self._buf, self.ptr, self.nbytes = buf, buf.ptr, nbytes
 
 
 class Preprocessor:
@@ -161,6 +205,7 @@ class Preprocessor:
         self.mean, self.inv_std = mean_inv_std(mean, std)
         self.pad_value = f32(pad_value)
         self.stream = stream
+        self._staging = _Staging()
 
     # -- helpers ------------------------------------------------------------------------------
     def _params(self, sw: int, sh: int, pitch: int, bpp: int, fmt_code: int, dw: int, dh: int,
@@ -350,19 +395,29 @@ class Preprocessor:
             raise PreprocessError("BadOutputShape",
                                   f"out= is {list(dst.shape)}, expected [*, 3, {out_height}, {out_width}]")
 
-        def upload(a):
+        def host(a):
             if isinstance(a, np.ndarray):
                 if a.dtype != np.uint8:
                     raise TypeError("raw frames must be uint8")
-                return DeviceBuffer.from_numpy(a.reshape(-1), self.stream)
-            return a
+                return True
+            return False
 
-        if frames is not None:
-            self.run_raw_batch([upload(a) for a in frames], width, height, dst)
+        if frames is not None and frames and all(host(a) for a in frames):
+            sizes = {a.size for a in frames}
+            if len(sizes) != 1:
+                raise PreprocessError("InvalidRawSource", "batched frames must have the same length")
+            dev, stride = self._staging.upload(self.stream, [a.reshape(-1) for a in frames])
+            self.run_raw_batch(dev, width, height, dst, frame_stride=stride)
+        elif frames is not None:
+            self.run_raw_batch([DeviceBuffer.from_numpy(a.reshape(-1), self.stream) if host(a) else a for a in frames],
+                               width, height, dst)
         elif hasattr(frame, "channels") and hasattr(frame, "is_device"):
             self.run_image(frame, dst)
+        elif host(frame):
+            dev, _ = self._staging.upload(self.stream, [frame.reshape(-1)])
+            self.run_raw(dev, width, height, dst)
         else:
-            self.run_raw(upload(frame), width, height, dst)
+            self.run_raw(frame, width, height, dst)
         if consumer_stream is not None:
             cs = Stream.from_cuda_stream(consumer_stream)
             check(lib.kh_stream_fence(self.stream.cuda_stream_ptr, cs.cuda_stream_ptr))

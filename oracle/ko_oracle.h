@@ -135,6 +135,10 @@ int ko_resize_normalize_to_chw(const uint8_t* src, int sw, int sh, float* dst, i
 void ko_fused_pipeline(const uint8_t* src, int sw, int sh, int rdw, int rdh, int dw, int dh, const int* map_kinds,
                        const float* map_params, int nmaps, int sink, float* dst);
 
+/* ---- CIE colour spaces (ko_cie.c) -------------------------------------------------------------------- */
+void ko_cie_f32(const float* src, float* dst, size_t npixels, int conv);
+void ko_cie_f64(const double* src, double* dst, size_t npixels, int conv);
+
 /* ---- pyramid + morphology (ko_pyramid_morph.c) ------------------------------------------------------- */
 void ko_pyrdown_f32(const float* src, int sw, int sh, float* dst, int C);
 void ko_pyrup_f32(const float* src, int sw, int sh, float* dst, int C);

@@ -544,3 +544,19 @@ def fused_pipeline(src, dw, dh, maps, sink, read_dst=None):
     ko.ko_fused_pipeline(src.reshape(-1), sw, sh, rdw, rdh, dw, dh, kinds, params.reshape(-1), len(maps),
                          32 if sink == "chw" else 33, out.reshape(-1))
     return out
+
+
+# ---- CIE colour spaces (ko_cie.c) ---------------------------------------------------------------------------
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
+ko.ko_cie_f32.argtypes = [_f32p, _f32p, C.c_size_t, C.c_int]
+ko.ko_cie_f64.argtypes = [_f64p, _f64p, C.c_size_t, C.c_int]
+CIE = {"linear_rgb_from_rgb": 0, "rgb_from_linear_rgb": 1, "xyz_from_rgb": 2, "rgb_from_xyz": 3, "lab_from_rgb": 4,
+       "rgb_from_lab": 5, "luv_from_rgb": 6, "rgb_from_luv": 7}
+
+
+def cie(name, src):
+    """f32 input -> the reference's f32 scalar path; f64 input -> its f64 exact-formula functions."""
+    src = np.ascontiguousarray(src)
+    out = np.empty_like(src)
+    (ko.ko_cie_f32 if src.dtype == np.float32 else ko.ko_cie_f64)(src.reshape(-1), out.reshape(-1), src.size // 3, CIE[name])
+    return out

@@ -262,3 +262,25 @@ def test_quotient_shortcut_equals_ieee_division_path(gpu_stream, fmt, monkeypatc
         monkeypatch.setenv("KH_PRE_IEEE_DIV", "1")
         _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), want, f"{fmt} {w}x{h}->{dw}x{dh} ieee")
     monkeypatch.delenv("KH_PRE_IEEE_DIV", raising=False)
+
+
+def test_python_run_reuses_pinned_staging_in_a_frame_loop(gpu_stream):
+    """PY/cuda_ext/mod.rs:647-745: host frames go through ONE persistent page-locked buffer + device buffer
+    (grown on demand, never per call); the previous upload is waited before the pinned bytes are reused,
+    so back-to-back calls with different frames stay correct."""
+    w, h = 64, 32
+    pre = _pre(gpu_stream, mode="letterbox", format="nv12", **IMAGENET)
+    frames = [_raw_for("nv12", w, h, seed=7 * k) for k in range(6)]
+    outs = [pre.run(fr, w, h, 24, 40) for fr in frames]          # no sync between calls
+    assert pre._staging.allocations == 2                          # one pinned + one device allocation in total
+    for fr, out in zip(frames, outs):
+        want = O.preprocess(fr, w, h, 40, 24, fmt="nv12", mode="letterbox", sampling="bilinear", **IMAGENET)
+        _assert_bits_equal(out.numpy()[0], want[0] if want.ndim == 4 else want, "frame loop")
+    batch = pre.run(frames[:4], w, h, 24, 40)                     # grows both buffers once
+    assert pre._staging.allocations == 4 and batch.shape == (4, 3, 24, 40)
+    for k in range(4):
+        want = O.preprocess(frames[k], w, h, 40, 24, fmt="nv12", mode="letterbox", sampling="bilinear", **IMAGENET)
+        _assert_bits_equal(batch.numpy()[k], want[0] if want.ndim == 4 else want, f"batch frame {k}")
+    again = pre.run(frames[:4], w, h, 24, 40)
+    assert pre._staging.allocations == 4
+    _assert_bits_equal(again.numpy(), batch.numpy(), "staging reuse")
