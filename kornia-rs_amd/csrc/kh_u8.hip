@@ -41,8 +41,15 @@ typedef uint32_t u32u __attribute__((aligned(1)));  // unaligned dword access (g
 
 __device__ __forceinline__ uint32_t rhadd(uint32_t a, uint32_t b) { return (a + b + 1u) >> 1; }
 
-template <int K, int C, bool BINOMIAL>
+// MODE 0: one u32 accumulator per byte (any taps).  MODE 1: 3x3 binomial of rounding halving adds.
+// MODE 2: two bytes per register in 16-bit lanes — valid when the taps of each pass sum to <= 256, which
+// quantize_kernel_256 guarantees for every gaussian / box kernel: a lane never exceeds 255*256 + 128 <
+// 2^16, so `(b0 | b2 << 16) * k` accumulates both bytes with one 24-bit multiply-add and no carry.  The
+// kernel is VALU-bound (r01m: 5.5 ms on 4K x 256 against a 1.6 ms memory floor); MODE 2 halves its
+// arithmetic.  v_perm_b32 pulls the even / odd bytes of a tap's unaligned 4-byte window straight into lanes.
+template <int K, int C, int MODE>
 __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky) {
+    constexpr bool BINOMIAL = MODE == 1;
     __shared__ uint32_t rowbuf[4][84];  // 80 dwords of row + a dummy slot
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int H = K / 2;
@@ -125,6 +132,31 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
 #pragma unroll
             for (int i = 0; i < 2 * D + 1; ++i) d[i] = tap[i];
             __builtin_amdgcn_wave_barrier();  // row consumed before the next one overwrites it
+            uint32_t packed = 0;
+            if constexpr (MODE == 2) {
+                uint32_t accE = 0, accO = 0;  // bytes (0, 2) and (1, 3) of this lane's dword, 16-bit lanes
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    constexpr int base = 4 * D - H * C;       // byte offset of tap 0's window in d[]
+                    const int rel = base + t * C, i = rel / 4, sft = rel % 4;  // compile-time after unrolling
+                    const uint32_t lo = d[i], hi = d[i + 1 < 2 * D + 1 ? i + 1 : i];
+                    const uint32_t selE = (uint32_t)sft | 0x0c00u | ((uint32_t)(sft + 2) << 16) | 0x0c000000u;
+                    const uint32_t selO = (uint32_t)(sft + 1) | 0x0c00u | ((uint32_t)(sft + 3) << 16) | 0x0c000000u;
+                    accE += __umul24(__builtin_amdgcn_perm(hi, lo, selE), kx.k[t]);
+                    accO += __umul24(__builtin_amdgcn_perm(hi, lo, selO), kx.k[t]);
+                }
+                ring[p][0] = ((accE + 0x00800080u) >> 8) & 0x00ff00ffu;
+                ring[p][1] = ((accO + 0x00800080u) >> 8) & 0x00ff00ffu;
+                uint32_t oE = 0, oO = 0;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {  // oldest row first
+                    oE += __umul24(ring[(p + 1 + i) % K][0], ky.k[i]);
+                    oO += __umul24(ring[(p + 1 + i) % K][1], ky.k[i]);
+                }
+                oE = ((oE + 0x00800080u) >> 8) & 0x00ff00ffu;
+                oO = ((oO + 0x00800080u) >> 8) & 0x00ff00ffu;
+                packed = oE | (oO << 8);
+            } else {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 auto byte_at = [&](int t) -> uint32_t {  // tap t of output byte b; offsets are compile-time
@@ -140,7 +172,6 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
                     ring[p][b] = ((acc + 128u) >> 8) & 0xffu;  // `as u8`
                 }
             }
-            uint32_t packed = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 uint32_t o;
@@ -154,6 +185,7 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
                 }
                 packed |= o << (8 * b);
             }
+            }  // MODE != 2
             if (r >= 2 * H && r < nrows) {
                 if (full) {
                     *reinterpret_cast<u32u*>(dst + out_off) = packed;
@@ -203,11 +235,15 @@ void launch_blur_kc(hipStream_t st, bool binomial, const U8FilterArgs& a, const 
     const dim3 grid = xcd_grid(a.tiles);
     if constexpr (K == 3) {
         if (binomial) {
-            hipLaunchKernelGGL((blur_u8_roll_kernel<3, C, true>), grid, dim3(kBlock), 0, st, a, kx, ky);
+            hipLaunchKernelGGL((blur_u8_roll_kernel<3, C, 1>), grid, dim3(kBlock), 0, st, a, kx, ky);
             return;
         }
     }
-    hipLaunchKernelGGL((blur_u8_roll_kernel<K, C, false>), grid, dim3(kBlock), 0, st, a, kx, ky);
+    unsigned sx = 0, sy = 0;
+    for (int i = 0; i < 16; ++i) { sx += kx.k[i]; sy += ky.k[i]; }
+    static const bool no_swar = [] { const char* e = getenv("KH_U8_BLUR_SWAR"); return e && e[0] == '0'; }();  // dev knob
+    if (sx <= 256 && sy <= 256 && !no_swar) hipLaunchKernelGGL((blur_u8_roll_kernel<K, C, 2>), grid, dim3(kBlock), 0, st, a, kx, ky);
+    else hipLaunchKernelGGL((blur_u8_roll_kernel<K, C, 0>), grid, dim3(kBlock), 0, st, a, kx, ky);
 }
 template <int K>
 void launch_blur_k(hipStream_t st, int C, bool binomial, const U8FilterArgs& a, const TapsQ& kx, const TapsQ& ky) {
