@@ -58,6 +58,8 @@ KH_API size_t kh_last_error(char* buf, size_t cap);
 
 /* Library version string, e.g. "kornia-hip 0.1.0 (gfx950)".                                    */
 KH_API const char* kh_version(void);
+/* test hook: floor(n / d) through the multiply-shift division the kernels use for tile ids (n < 2^31)   */
+KH_API uint32_t kh_debug_fast_quot(uint32_t n, uint32_t d);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Device runtime: replaces cudarc's CudaContext/CudaStream/CudaEvent use in T/cuda.rs and

@@ -41,7 +41,26 @@ inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b);
 // gathers are neutral with short runs and resize 1080p->224 LOSES 13 % with eighths, so gathers use
 // runs of 8 tile rows.  KH_XCD_TILES=0 (dev knob) restores the plain order.
 constexpr unsigned kXcdEighth = ~0u;
-struct XcdTiles { unsigned tiles_x, tiles_y, total, run; };
+// Division of a block id (< 2^31) by a launch constant without the ~8-instruction-per-quotient float
+// reciprocal sequence the compiler emits for a run-time divisor (three of them were ~20 % of the VALU work
+// of a gather wave).  Granlund-Montgomery: for n < 2^31 and l = ceil(log2 d), m = ceil(2^(31+l) / d) fits
+// 32 bits and floor(n / d) == (n * m) >> (31 + l) == umulhi(n, m) >> (l - 1).  d == 1 is encoded as m == 0.
+// The operands are wave-uniform, so this is two scalar instructions.  tests/test_abi.py sweeps it.
+struct FastDiv { uint32_t d, m, sh; };
+inline FastDiv fast_div(uint32_t d) {
+    FastDiv f{d, 0u, 0u};
+    if (d <= 1) return f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;  // ceil(log2 d), >= 1
+    f.m = (uint32_t)(((1ull << (31 + l)) + d - 1) / d);
+    f.sh = l - 1;
+    return f;
+}
+__host__ __device__ __forceinline__ uint32_t fast_quot(uint32_t n, const FastDiv& f) {
+    return f.m ? (uint32_t)(((uint64_t)n * f.m) >> 32) >> f.sh : n;
+}
+
+struct XcdTiles { unsigned tiles_x, tiles_y, total, run; FastDiv by_run, by_img, by_row; };
 constexpr int kXcds = 8;
 inline bool xcd_tiles_enabled() {
     static const bool on = [] { const char* e = getenv("KH_XCD_TILES"); return !(e && e[0] == '0'); }();
@@ -49,7 +68,7 @@ inline bool xcd_tiles_enabled() {
 }
 inline XcdTiles xcd_tiles(unsigned tiles_x, unsigned tiles_y, unsigned images, unsigned run) {
     const uint64_t total = (uint64_t)tiles_x * tiles_y * images;
-    XcdTiles t{tiles_x, tiles_y, (unsigned)total, 0};
+    XcdTiles t{tiles_x, tiles_y, (unsigned)total, 0, FastDiv{1, 0, 0}, fast_div(tiles_x * tiles_y), fast_div(tiles_x)};
     if (total > 0x7ff00000ull) t.total = 0;  // caller rejects (KH_ERR_TOO_LARGE)
     else if (xcd_tiles_enabled()) {
         // KH_XCD_RUN (dev knob): n > 0 = run length, -1 = one contiguous eighth of the launch per XCD
@@ -57,7 +76,7 @@ inline XcdTiles xcd_tiles(unsigned tiles_x, unsigned tiles_y, unsigned images, u
         if (env_run > 0) run = (unsigned)env_run;
         if (env_run < 0) run = (unsigned)((total + kXcds - 1) / kXcds);
         if (run == kXcdEighth) run = (unsigned)((total + kXcds - 1) / kXcds);
-        if (run > 1 && total > run) t.run = run;
+        if (run > 1 && total > run) { t.run = run; t.by_run = fast_div(run); }
     }
     return t;
 }
@@ -70,14 +89,14 @@ __device__ __forceinline__ bool xcd_tile(const XcdTiles& t, unsigned& bx, unsign
     const unsigned b = blockIdx.x;
     unsigned id = b;
     if (t.run) {
-        const unsigned xcd = b % kXcds, slot = b / kXcds;
-        id = (slot / t.run * kXcds + xcd) * t.run + slot % t.run;
+        const unsigned xcd = b % kXcds, slot = b / kXcds, grp = fast_quot(slot, t.by_run);
+        id = (grp * kXcds + xcd) * t.run + (slot - grp * t.run);
     }
     if (id >= t.total) return false;
-    const unsigned per_img = t.tiles_x * t.tiles_y, r = id % per_img;
-    bz = id / per_img;
-    by = r / t.tiles_x;
-    bx = r % t.tiles_x;
+    bz = fast_quot(id, t.by_img);
+    const unsigned r = id - bz * (t.tiles_x * t.tiles_y);
+    by = fast_quot(r, t.by_row);
+    bx = r - by * t.tiles_x;
     return true;
 }
 

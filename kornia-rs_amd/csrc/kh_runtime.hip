@@ -52,6 +52,9 @@ size_t kh_last_error(char* buf, size_t cap) {
 
 const char* kh_version(void) { return "kornia-hip 0.1.0 (gfx950)"; }
 
+// test hook: the launch-constant division used to decode tile ids (kh_common.h::FastDiv), on the host
+uint32_t kh_debug_fast_quot(uint32_t n, uint32_t d) { return kh::fast_quot(n, kh::fast_div(d)); }
+
 int32_t kh_device_count(int32_t* count) {
     KH_REQUIRE(count, KH_ERR_INVALID_ARG, "kh_device_count: null out pointer");
     int n = 0;

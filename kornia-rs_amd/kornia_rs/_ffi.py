@@ -74,6 +74,7 @@ _P = C.POINTER
 # (tests/test_abi.py cross-checks the header against this table and the built library).
 SIGNATURES = {
     "kh_last_error": (_sz, [C.c_char_p, _sz]),
+    "kh_debug_fast_quot": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "kh_version": (C.c_char_p, []),
     "kh_device_count": (_i32, [_P(_i32)]),
     "kh_set_device": (_i32, [_i32]),

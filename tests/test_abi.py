@@ -111,3 +111,21 @@ def test_no_device_fails_loudly_not_silently():
     assert rc == _ffi.KH_ERR_HIP and "HIP error" in _ffi.last_error()
     with pytest.raises(_ffi.KorniaHipError):
         hip.DeviceBuffer(16)
+
+
+def test_tile_id_division_is_exact():
+    """kh_common.h::FastDiv (multiply-shift division of block ids by launch constants): exact for every
+    divisor up to 4096 plus large / awkward ones, at all multiples' boundaries and the top of the id range."""
+    import numpy as np
+    from kornia_rs import _ffi
+    q = _ffi.lib.kh_debug_fast_quot
+    rng = np.random.default_rng(0)
+    divisors = list(range(1, 4097)) + [4800, 8640, 69120, 65535, 65537, 1 << 20, (1 << 20) + 1, 3 * 5 * 7 * 11 * 13 * 17, (1 << 30) - 1,
+                                       (1 << 30) + 1, 0x7fefffff]
+    top = 0x7ff00000
+    for d in divisors:
+        ns = {0, 1, d - 1, d, d + 1, top - 1, top, top // d * d, top // d * d - 1}
+        ns.update(int(k) * d + o for k in rng.integers(0, top // d + 1, 6) for o in (-1, 0, 1))
+        for n in ns:
+            if 0 <= n <= top:
+                assert q(n, d) == n // d, (n, d)
