@@ -13,6 +13,8 @@ from .image import Image, ImageError
 from .preprocess import Preprocessor, PreprocessError, ResizeMode, SourceFormat
 from . import imgproc
 from . import fusion
+from . import color_spaces
+from .color_spaces import ColorSpace
 from . import sharding
 
 cuda = hip  # reference module name (kornia_rs.cuda.Stream); same objects, HIP underneath
@@ -20,5 +22,5 @@ cuda = hip  # reference module name (kornia_rs.cuda.Stream); same objects, HIP u
 __version__ = "0.1.0"
 __all__ = [
     "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Image", "ImageError", "Preprocessor",
-    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "fusion", "hip", "cuda", "sharding",
+    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "fusion", "color_spaces", "ColorSpace", "hip", "cuda", "sharding",
 ]

@@ -185,7 +185,9 @@ def apply_colormap(src: Image, lut: np.ndarray, dst: Optional[Image] = None) -> 
 # ---- video formats (raw buffers <-> RGB8) ----------------------------------------------------------
 
 def _raw_ptr(buf, need: int, what: str) -> Tuple[int, Stream]:
-    if isinstance(buf, (Tensor, Image)):
+    if hasattr(buf, "layout") and hasattr(buf, "as_slice"):  # color_spaces.Nv12 / Yuyv8 ... typed buffers
+        n, ptr, st = buf.nbytes, buf.data_ptr, buf.stream    # .data_ptr raises for host-resident buffers
+    elif isinstance(buf, (Tensor, Image)):
         if not buf.is_device:
             raise ImageError("HostPathUnavailable", f"{what}: host buffer; upload it first (DeviceBuffer.from_numpy)")
         n, ptr, st = buf.nbytes, buf.data_ptr, buf.stream
@@ -207,6 +209,15 @@ def _decode(kind: str, layout: int, data, width: int, height: int, dst: Optional
         raise ImageError("InvalidImageSize", f"destination is {out.width}x{out.height}, expected {width}x{height}")
     _check(getattr(lib, f"kh_rgb_from_{kind}_u8")(st.cuda_stream_ptr, ptr, out.data_ptr, width, height, layout))
     return out
+
+
+def rgb_from_video(buf, dst: Optional[Image] = None) -> Image:
+    """Decode a typed camera buffer (``color_spaces.Nv12`` / ``Nv21`` / ``I420`` / ``Yv12`` / ``Yuyv8`` / ``Uyvy8`` /
+    ``Yvyu8``) to RGB8 — the typed entry points of P/color/yuv/mod.rs:209-273."""
+    kinds = {"nv12": ("planar420", 0), "nv21": ("planar420", 1), "i420": ("planar420", 2), "yv12": ("planar420", 3),
+             "yuyv": ("packed422", 0), "uyvy": ("packed422", 1), "yvyu": ("packed422", 2)}
+    kind, layout = kinds[buf.layout]
+    return _decode(kind, layout, buf, buf.width, buf.height, dst)
 
 
 def rgb_from_nv12(data, width, height, dst=None): return _decode("planar420", 0, data, width, height, dst)

@@ -172,3 +172,35 @@ def test_preprocessor_host_validation():
     assert K.preprocess.SourceFormat.from_name("NV12").buffer_len(8, 6) == 72
     assert K.preprocess.SourceFormat.from_name("yuyv").buffer_len(8, 6) == 96
     assert K.preprocess.SourceFormat.from_name("nope") is None
+
+
+def test_color_space_tags_and_typed_constructors():  # I/color_spaces.rs:19-80, 269-620
+    from kornia_rs import ColorSpace, ImageError, color_spaces as cs
+    assert ColorSpace.GRAY.channels == 1 and ColorSpace.BGRA.channels == 4 and ColorSpace.LAB.channels == 3
+    assert ColorSpace.LAB.float_only and not ColorSpace.RGB.float_only
+    img = cs.Rgb8(np.zeros((4, 6, 3), np.uint8))
+    assert img.color_space is ColorSpace.RGB and (img.width, img.height, img.channels) == (6, 4, 3)
+    assert cs.Gray8(np.zeros((4, 6), np.uint8)).channels == 1
+    assert cs.Labf32(np.zeros((2, 2, 3), np.float32)).color_space is ColorSpace.LAB
+    for bad in (np.zeros((4, 6, 4), np.uint8), np.zeros((4, 6, 3), np.float32)):
+        with pytest.raises(ImageError) as e:
+            cs.Rgb8(bad)
+        assert e.value.kind == "InvalidChannelShape"
+
+
+def test_video_buffer_types_validate_layout():  # I/color_spaces.rs:630-830
+    from kornia_rs import ImageError, color_spaces as cs, imgproc
+    nv = cs.Nv12(8, 4, np.arange(48, dtype=np.uint8))
+    assert nv.size == (8, 4) and nv.nbytes == 48 and not nv.is_device and nv.as_slice().shape == (48,)
+    assert cs.I420.from_size_vec((8, 4), np.zeros(48, np.uint8)).layout == "i420"
+    yu = cs.Yuyv8(8, 3, np.zeros(48, np.uint8))  # packed 4:2:2 allows an odd height
+    assert yu.nbytes == 48 and yu.layout == "yuyv"
+    for ctor, args in [(cs.Nv12, (8, 4, np.zeros(47, np.uint8))), (cs.Nv21, (7, 4, np.zeros(42, np.uint8))),
+                       (cs.Yv12, (8, 3, np.zeros(36, np.uint8))), (cs.Uyvy8, (7, 2, np.zeros(28, np.uint8))),
+                       (cs.Yvyu8, (8, 2, np.zeros(31, np.uint8)))]:
+        with pytest.raises(ImageError) as e:
+            ctor(*args)
+        assert e.value.kind == "InvalidImageSize"
+    with pytest.raises(ImageError) as e:  # host buffers never reach a device decoder implicitly
+        imgproc.rgb_from_video(nv)
+    assert e.value.kind == "HostPathUnavailable"

@@ -92,3 +92,19 @@ def test_torch_rocm_zero_copy_interop(gpu_stream):
     ptr = x.data_ptr()
     del x
     assert img.data_ptr == ptr and np.array_equal(imgproc.gray_from_rgb(img).numpy(), want)
+
+
+def test_typed_video_buffers_decode_on_device(gpu_stream):
+    import oracle_ffi as O
+    from kornia_rs import color_spaces as cs, imgproc
+    w, h = 64, 32
+    raw = O.pattern_u8(w * h * 3 // 2)
+    for cls, layout in ((cs.Nv12, 0), (cs.Nv21, 1), (cs.I420, 2), (cs.Yv12, 3)):
+        got = imgproc.rgb_from_video(cls(w, h, raw).to_hip(gpu_stream)).cpu().numpy()
+        assert np.array_equal(got, O.rgb_from_nv12(raw, w, h, layout))
+    raw2 = O.pattern_u8(w * h * 2)
+    for cls, layout in ((cs.Yuyv8, 0), (cs.Uyvy8, 1), (cs.Yvyu8, 2)):
+        buf = cls(w, h, raw2).to_hip(gpu_stream)
+        assert buf.is_device and np.array_equal(buf.cpu().as_slice(), raw2)
+        got = imgproc.rgb_from_video(buf).cpu().numpy()
+        assert np.array_equal(got, O.rgb_from_yuyv(raw2, w, h, layout))
