@@ -498,6 +498,25 @@ WORKLOADS = {
 }
 
 
+def measured_d2d_ceiling(hip, stream, nbytes: int = 2 << 30, reps: int = 5):
+    """record the measured device-to-device copy rate next to the datasheet peak."""
+    try:
+        from kornia_rs._ffi import lib, check
+        a, b = hip.DeviceBuffer(nbytes, stream, zeroed=True), hip.DeviceBuffer(nbytes, stream, zeroed=False)
+        check(lib.kh_memcpy_d2d_async(b.ptr, a.ptr, nbytes, stream.cuda_stream_ptr))  # warm-up
+        e0, e1 = hip.Event(timing=True), hip.Event(timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            check(lib.kh_memcpy_d2d_async(b.ptr, a.ptr, nbytes, stream.cuda_stream_ptr))
+        e1.record(stream)
+        stream.synchronize()
+        ms = e0.elapsed_ms(e1) / reps
+        a.free(); b.free()
+        return round(2 * nbytes / (ms * 1e-3) / 1e9, 1)
+    except Exception:  # never let the side measurement break the bench line
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -566,6 +585,7 @@ def main():
         if tfile.exists():
             traffic = json.loads(tfile.read_text()).get(wl.name)
         name, cus, mem = hip.device_info(local_rank)
+        d2d = measured_d2d_ceiling(hip, stream)
         line = {
             "metric": ("Mpixels/s, fused 1080p NV12->normalized CHW f32 (achieved HBM GB/s in roofline)"
                        if args.workload.startswith("nv12") else f"Mpixels/s (source pixels), {wl.name}"),
@@ -579,7 +599,9 @@ def main():
                          "kernel": wl.kernel, "alg_bytes_per_launch": wl.alg_bytes_per_launch,
                          "mean_launch_ms": round(mean_kernel_s * 1e3, 4),
                          "min_launch_ms": round(float(np.min(kernel_ms)), 4)},
-            "device": {"name": name, "cus": cus, "hbm_bytes": mem},
+            "device": {"name": name, "cus": cus, "hbm_bytes": mem, "measured_d2d_copy_GBps": d2d,
+                       "note": "d2d = (read + write) bytes / time of a 2 GiB hipMemcpyDtoD, the practical HBM ceiling "
+                               "next to the 8000 GB/s datasheet peak used for roofline.frac"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl.cpu_baseline()
