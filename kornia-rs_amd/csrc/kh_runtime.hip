@@ -175,30 +175,6 @@ static int32_t pin_pool_once() {
     return KH_OK;
 }
 
-// Fills run as an ordinary kernel on the caller's stream.  hipMemsetAsync was observed (ROCm 7.2 / gfx950,
-// r01z: order-dependent, after other streams had been active in the process) to land one 4 MiB chunk of a
-// zero-fill AFTER a kernel queued behind it on the same stream — a zeroed destination came back with a
-// 4 MiB hole of zeros.  A kernel launch has no such reordering.
-__global__ __launch_bounds__(kh::kBlock) void fill_kernel(uint8_t* __restrict__ p, size_t bytes, uint32_t pattern) {
-    const size_t head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;  // bytes before the first 16-B boundary
-    const size_t h = head < bytes ? head : bytes;
-    const size_t vec = (bytes - h) / 16;
-    const size_t tid = (size_t)blockIdx.x * kh::kBlock + threadIdx.x, nthreads = (size_t)gridDim.x * kh::kBlock;
-    uint4* q = reinterpret_cast<uint4*>(p + h);
-    const uint4 v = {pattern, pattern, pattern, pattern};
-    for (size_t i = tid; i < vec; i += nthreads) q[i] = v;
-    const size_t tail0 = h + vec * 16;
-    if (tid < h) p[tid] = (uint8_t)pattern;
-    if (tid < bytes - tail0) p[tail0 + tid] = (uint8_t)pattern;
-}
-static int32_t fill_async(void* dst, int value, size_t bytes, hipStream_t st) {
-    const uint32_t b = (uint32_t)value & 0xffu, pattern = b * 0x01010101u;
-    size_t blocks = (bytes / 16 + kh::kBlock - 1) / kh::kBlock;
-    blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(kh::kBlock), 0, st, (uint8_t*)dst, bytes, pattern);
-    return kh::check_launch("fill_kernel");
-}
-
 int32_t kh_malloc_async(void** out, size_t bytes, int32_t zeroed, kh_stream_t stream) {
     KH_REQUIRE(out, KH_ERR_INVALID_ARG, "kh_malloc_async: null out pointer");
     *out = nullptr;
@@ -207,9 +183,10 @@ int32_t kh_malloc_async(void** out, size_t bytes, int32_t zeroed, kh_stream_t st
     void* p = nullptr;
     KH_HIP(hipMallocAsync(&p, bytes, as_hip(stream)));
     if (zeroed) {
-        if (int32_t rc = fill_async(p, 0, bytes, as_hip(stream))) {
+        hipError_t e = hipMemsetAsync(p, 0, bytes, as_hip(stream));
+        if (e != hipSuccess) {
             (void)hipFreeAsync(p, as_hip(stream));
-            return rc;
+            return fail_hip(e, "hipMemsetAsync (zeroed allocation)");
         }
     }
     *out = p;
@@ -292,7 +269,8 @@ int32_t kh_memcpy_d2d_async(void* dst, const void* src, size_t bytes, kh_stream_
 int32_t kh_memset_async(void* dst, int32_t value, size_t bytes, kh_stream_t stream) {
     if (bytes == 0) return KH_OK;
     KH_REQUIRE(dst, KH_ERR_INVALID_ARG, "kh_memset_async: null pointer");
-    return fill_async(dst, value, bytes, as_hip(stream));
+    KH_HIP(hipMemsetAsync(dst, value, bytes, as_hip(stream)));
+    return KH_OK;
 }
 
 int32_t kh_pointer_domain(const void* ptr, int32_t* domain, int32_t* device) {

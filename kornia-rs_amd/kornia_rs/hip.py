@@ -10,7 +10,6 @@ they are the protocol names torch-ROCm and cupy-ROCm speak.
 from __future__ import annotations
 
 import ctypes as C
-import threading
 from typing import Any, Optional, Tuple
 
 import numpy as np
@@ -150,53 +149,16 @@ class Event:
             self._handle = None
 
 
-_BOUNCE_BYTES = 32 << 20
-_bounce = None  # one page-locked staging buffer for pageable <-> device copies, created on first use
-_bounce_lock = threading.Lock()
-
-
-def _bounce_buffer() -> "PinnedBuffer":
-    global _bounce
-    if _bounce is None:
-        _bounce = PinnedBuffer(_BOUNCE_BYTES)
-    return _bounce
-
-
 def d2h(out: np.ndarray, device_ptr: int, stream: Stream) -> None:
-    """Device -> host copy into a numpy array (to_host, crates/kornia-tensor/src/cuda.rs:1258-1300).
-
-    Goes through a page-locked staging buffer in chunks, so every transfer is a true stream-ordered DMA:
-    pageable destinations let the runtime service copies from the host side, and on ROCm 7.2 / gfx950 we
-    observed such copies overtaking kernels still queued on the stream (stale reads).  The stream is
-    drained before the first chunk as well (the producer must be complete) and after each chunk."""
+    """Device -> pageable host copy (to_host, crates/kornia-tensor/src/cuda.rs:1258-1300).
+    The stream is drained BEFORE the copy as well as after it: a pageable destination lets the
+    runtime service small copies from the host side, and we observed such copies overtaking
+    kernels still queued on the stream (stale reads) on ROCm 7.2 / gfx950."""
     if out.nbytes == 0:
         return
-    flat = out.reshape(-1).view(np.uint8)
     stream.synchronize()
-    with _bounce_lock:
-        pin = _bounce_buffer()
-        view = pin.view()
-        for off in range(0, flat.size, _BOUNCE_BYTES):
-            n = min(_BOUNCE_BYTES, flat.size - off)
-            check(lib.kh_memcpy_d2h_async(pin.ptr, device_ptr + off, n, stream.cuda_stream_ptr))
-            stream.synchronize()
-            flat[off:off + n] = view[:n]
-
-
-def h2d(device_ptr: int, a: np.ndarray, stream: Stream) -> None:
-    """Host numpy array -> device, through the same page-locked staging buffer (see d2h)."""
-    if a.nbytes == 0:
-        return
-    flat = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+    check(lib.kh_memcpy_d2h_async(out.ctypes.data, device_ptr, out.nbytes, stream.cuda_stream_ptr))
     stream.synchronize()
-    with _bounce_lock:
-        pin = _bounce_buffer()
-        view = pin.view()
-        for off in range(0, flat.size, _BOUNCE_BYTES):
-            n = min(_BOUNCE_BYTES, flat.size - off)
-            view[:n] = flat[off:off + n]
-            check(lib.kh_memcpy_h2d_async(device_ptr + off, pin.ptr, n, stream.cuda_stream_ptr))
-            stream.synchronize()  # the staging bytes are reused by the next chunk
 
 
 def _stream_handle(stream: Optional[Stream]) -> int:
@@ -257,7 +219,12 @@ class DeviceBuffer:
         assert offset + a.nbytes <= self.nbytes
         if a.nbytes == 0:
             return
-        h2d(self.ptr + offset, a, self.stream)  # page-locked staging, drained before and after
+        # Pageable source: drain first (a host-serviced copy must not overtake a queued memset /
+        # kernel on this stream, see d2h) and after (the runtime may still be reading `a`).
+        self.stream.synchronize()
+        check(lib.kh_memcpy_h2d_async(self.ptr + offset, a.ctypes.data, a.nbytes,
+                                      self.stream.cuda_stream_ptr))
+        self.stream.synchronize()
 
     def to_numpy(self, dtype, shape, offset: int = 0) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
