@@ -168,7 +168,19 @@ SIGNATURES = {
 }
 
 
+def _prefer_shader_copies() -> None:
+    """ROCm 7.2 / gfx950 workaround, applied only if the variable is unset and only effective when the HIP
+    runtime has not been initialised yet: with the SDMA copy engines enabled we observed host<->device copies
+    (pageable AND page-locked) that had not fully landed when ``hipStreamSynchronize`` returned — 4 MiB / 16 MiB
+    holes of stale bytes, dependent on what the process had done before (profiles/r01zy_sdma.log).  With
+    ``HSA_ENABLE_SDMA=0`` the runtime copies with shader kernels, which order like any other kernel; every
+    variant of the failing sequence passes.  Kernels (the measured path) are unaffected."""
+    import os
+    os.environ.setdefault("HSA_ENABLE_SDMA", "0")
+
+
 def _load() -> C.CDLL:
+    _prefer_shader_copies()
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} not found — build it with `make -C kornia-rs_amd` "
