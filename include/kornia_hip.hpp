@@ -1,0 +1,401 @@
+// kornia_hip.hpp — header-only C++17 host mirror of the reference's Rust API for the imgproc hot path,
+// layered on the C ABI of include/kornia_hip.h (link with -lkornia_hip).
+//
+// The reference is compiled Rust (crates/kornia-tensor, kornia-image, kornia-imgproc); this header keeps its
+// host-side contract for non-Python hosts: `Image<T, C>` whose residency (Host / Device) is a run-time
+// property of the storage (I/image.rs:138, T/storage.rs:53, T/resource.rs:19), explicit transfers only
+// (`to_hip` / `to_host`, I/cuda.rs:53-221), host access to device memory is an error (T/storage.rs:102-110),
+// and every operator classifies its operands first (pair_residency, P/cuda/dispatch.rs:105-130): mixed
+// host/device pairs, different devices and unsupported dtype / channel combinations are TYPED errors, never
+// a silent transfer or a CPU fallback.  A host/host pair has no implementation here — this build is the
+// device backend only — and says so.
+//
+//   kornia::Stream s = kornia::Stream::create(0);
+//   auto img  = kornia::Image<float, 3>::from_size_val({1920, 1080}, 0.5f);
+//   auto dimg = img.to_hip(s);
+//   auto out  = kornia::Image<float, 3>::zeros_hip({224, 224}, s);
+//   kornia::imgproc::resize(dimg, out, kornia::InterpolationMode::Bilinear);
+//   auto host = out.to_host();
+#pragma once
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "kornia_hip.h"
+
+namespace kornia {
+
+// ---- errors (I/error.rs:3-80, P/cuda/dispatch.rs:166-211) ------------------------------------------------
+class ImageError : public std::runtime_error {
+public:
+    enum class Kind {
+        InvalidImageSize, InvalidChannelShape, MixedResidency, DeviceMismatch, UnsupportedDevice, HostPathUnavailable,
+        NoDeviceKernel, CannotComputeDeterminant, InvalidSigmaValue, InvalidNormalize, DimensionsTooLarge, SliceTooSmall, Hip
+    };
+    ImageError(Kind k, const std::string& what) : std::runtime_error(what), kind(k) {}
+    Kind kind;
+};
+
+namespace detail {
+inline std::string last_error() {
+    char buf[512];
+    kh_last_error(buf, sizeof buf);
+    return buf;
+}
+// status codes -> the reference's typed errors
+inline void check(int32_t rc) {
+    if (rc == KH_OK) return;
+    using K = ImageError::Kind;
+    K k = K::Hip;
+    switch (rc) {
+        case KH_ERR_INVALID_ARG: k = K::InvalidImageSize; break;
+        case KH_ERR_UNSUPPORTED: k = K::NoDeviceKernel; break;
+        case KH_ERR_TOO_LARGE: k = K::DimensionsTooLarge; break;
+        case KH_ERR_SINGULAR: k = K::CannotComputeDeterminant; break;
+        case KH_ERR_SLICE_TOO_SMALL: k = K::SliceTooSmall; break;
+        default: break;
+    }
+    throw ImageError(k, last_error());
+}
+}  // namespace detail
+
+// ---- streams / events (T/cuda.rs cuda_stream, PY/cuda_ext/mod.rs:61-120) ----------------------------------
+class Stream {
+public:
+    // a new non-blocking stream on `device`
+    static Stream create(int device = 0) {
+        int prev = 0;
+        detail::check(kh_get_device(&prev));
+        detail::check(kh_set_device(device));
+        kh_stream_t h = nullptr;
+        const int32_t rc = kh_stream_create(&h);
+        kh_set_device(prev);
+        detail::check(rc);
+        return Stream(std::shared_ptr<Handle>(new Handle{h, device, true}));
+    }
+    // borrow a caller-owned hipStream_t (never destroyed here)
+    static Stream from_handle(void* hip_stream, int device) {
+        return Stream(std::shared_ptr<Handle>(new Handle{static_cast<kh_stream_t>(hip_stream), device, false}));
+    }
+    void synchronize() const { detail::check(kh_stream_synchronize(h_->h)); }
+    kh_stream_t handle() const { return h_->h; }
+    int device() const { return h_->device; }
+    bool same_as(const Stream& o) const { return h_->h == o.h_->h; }
+
+private:
+    struct Handle {
+        kh_stream_t h;
+        int device;
+        bool owned;
+        ~Handle() { if (owned && h) kh_stream_destroy(h); }
+    };
+    explicit Stream(std::shared_ptr<Handle> h) : h_(std::move(h)) {}
+    std::shared_ptr<Handle> h_;
+};
+
+// ---- storage: residency is a run-time property (T/resource.rs:19-60) --------------------------------------
+enum class MemoryDomain { Host, Device };
+
+struct ImageSize {
+    size_t width, height;
+    bool operator==(const ImageSize& o) const { return width == o.width && height == o.height; }
+    bool operator!=(const ImageSize& o) const { return !(*this == o); }
+};
+
+enum class InterpolationMode { Nearest = KH_INTERP_NEAREST, Bilinear = KH_INTERP_BILINEAR, Bicubic = KH_INTERP_BICUBIC,
+                               Lanczos = KH_INTERP_LANCZOS };
+
+namespace detail {
+template <typename T>
+struct Storage {
+    MemoryDomain domain = MemoryDomain::Host;
+    std::vector<T> host;            // Host
+    T* dev = nullptr;               // Device (stream-ordered allocation, freed on its stream)
+    size_t len = 0;
+    std::unique_ptr<Stream> stream; // Device only
+    Storage() = default;
+    Storage(const Storage&) = delete;
+    Storage& operator=(const Storage&) = delete;
+    ~Storage() {
+        if (dev) kh_free_async(dev, stream ? stream->handle() : nullptr);
+    }
+};
+}  // namespace detail
+
+// ---- Image<T, C> (I/image.rs:138-420, I/cuda.rs:53-221) ----------------------------------------------------
+template <typename T, int C>
+class Image {
+    static_assert(C >= 1 && C <= 4, "1..4 channels");
+
+public:
+    static Image from_size_vec(ImageSize size, std::vector<T> data) {
+        if (data.size() != size.width * size.height * C)
+            throw ImageError(ImageError::Kind::InvalidChannelShape,
+                             "data length " + std::to_string(data.size()) + " does not match the image shape " +
+                                 std::to_string(size.height) + "x" + std::to_string(size.width) + "x" + std::to_string(C));
+        Image img(size);
+        img.s_->host = std::move(data);
+        img.s_->len = img.s_->host.size();
+        return img;
+    }
+    static Image from_size_val(ImageSize size, T val) { return from_size_vec(size, std::vector<T>(size.width * size.height * C, val)); }
+
+    // zeros_cuda / uninit_cuda (I/cuda.rs:96-121): device-resident, allocated on `stream`
+    static Image zeros_hip(ImageSize size, const Stream& stream) { return alloc_hip(size, stream, true); }
+    static Image uninit_hip(ImageSize size, const Stream& stream) { return alloc_hip(size, stream, false); }
+
+    ImageSize size() const { return size_; }
+    size_t width() const { return size_.width; }
+    size_t height() const { return size_.height; }
+    size_t cols() const { return size_.width; }
+    size_t rows() const { return size_.height; }
+    static constexpr int num_channels() { return C; }
+    size_t numel() const { return size_.width * size_.height * C; }
+    MemoryDomain domain() const { return s_->domain; }
+    bool is_device() const { return s_->domain == MemoryDomain::Device; }
+    // the stream a device image is ordered on (TensorStorage::cuda_stream, T/cuda.rs:1010); nullptr for host
+    const Stream* stream() const { return s_->stream.get(); }
+
+    // host access only — refuses device memory like TensorStorage::as_slice (T/storage.rs:102-110)
+    const std::vector<T>& as_slice() const {
+        if (is_device()) throw ImageError(ImageError::Kind::UnsupportedDevice, "host access to device-resident image data; call to_host() first");
+        return s_->host;
+    }
+    std::vector<T>& as_slice_mut() { return const_cast<std::vector<T>&>(static_cast<const Image&>(*this).as_slice()); }
+    // raw device pointer (as_cudaslice, I/cuda.rs:200-221); host images have none
+    const T* device_ptr() const {
+        if (!is_device()) throw ImageError(ImageError::Kind::UnsupportedDevice, "device pointer of a host-resident image; call to_hip(stream) first");
+        return s_->dev;
+    }
+    T* device_ptr_mut() { return const_cast<T*>(static_cast<const Image&>(*this).device_ptr()); }
+
+    // explicit transfers (to_cuda, to_host_owned: I/cuda.rs:53-95, 122-160)
+    Image to_hip(const Stream& stream) const {
+        if (is_device()) throw ImageError(ImageError::Kind::UnsupportedDevice, "to_hip: the image is already device-resident");
+        Image out = alloc_hip(size_, stream, false);
+        if (numel()) {
+            detail::check(kh_memcpy_h2d_async(out.s_->dev, s_->host.data(), numel() * sizeof(T), stream.handle()));
+            stream.synchronize();  // the pageable source may be released by the caller right after
+        }
+        return out;
+    }
+    Image to_host() const {
+        if (!is_device()) throw ImageError(ImageError::Kind::UnsupportedDevice, "to_host: the image is already host-resident");
+        Image out(size_);
+        out.s_->host.resize(numel());
+        out.s_->len = numel();
+        if (numel()) {
+            s_->stream->synchronize();
+            detail::check(kh_memcpy_d2h_async(out.s_->host.data(), s_->dev, numel() * sizeof(T), s_->stream->handle()));
+            s_->stream->synchronize();
+        }
+        return out;
+    }
+
+private:
+    explicit Image(ImageSize size) : size_(size), s_(std::make_shared<detail::Storage<T>>()) {}
+    static Image alloc_hip(ImageSize size, const Stream& stream, bool zeroed) {
+        Image img(size);
+        img.s_->domain = MemoryDomain::Device;
+        img.s_->stream.reset(new Stream(stream));
+        img.s_->len = size.width * size.height * C;
+        void* p = nullptr;
+        int prev = 0;
+        detail::check(kh_get_device(&prev));
+        detail::check(kh_set_device(stream.device()));
+        const int32_t rc = kh_malloc_async(&p, img.s_->len * sizeof(T), zeroed ? 1 : 0, stream.handle());
+        kh_set_device(prev);
+        detail::check(rc);
+        img.s_->dev = static_cast<T*>(p);
+        return img;
+    }
+    ImageSize size_;
+    std::shared_ptr<detail::Storage<T>> s_;
+};
+
+// ---- residency dispatch (pair_residency / DeviceExec::for_streams, P/cuda/dispatch.rs:50-130) ---------------
+namespace detail {
+// Returns the stream to launch on (the SOURCE image's stream) after fencing the destination's stream in.
+template <typename TS, int CS, typename TD, int CD>
+inline const Stream& device_exec_for(const Image<TS, CS>& src, const Image<TD, CD>& dst, const char* what) {
+    if (src.is_device() != dst.is_device())
+        throw ImageError(ImageError::Kind::MixedResidency, std::string(what) + ": src and dst must both be host-resident or both device-resident "
+                                                                                  "(no implicit transfers)");
+    if (!src.is_device())
+        throw ImageError(ImageError::Kind::HostPathUnavailable, std::string(what) + ": host images — this build provides the HIP device backend only; "
+                                                                                       "move the images with to_hip(stream)");
+    const Stream& ss = *src.stream();
+    const Stream& ds = *dst.stream();
+    if (ss.device() != ds.device())
+        throw ImageError(ImageError::Kind::DeviceMismatch, std::string(what) + ": src is on device " + std::to_string(ss.device()) +
+                                                               ", dst on device " + std::to_string(ds.device()));
+    if (!ss.same_as(ds)) check(kh_stream_fence(ds.handle(), ss.handle()));  // dst's pending work first
+    return ss;
+}
+template <typename T, int C>
+inline void same_size(const Image<T, C>& a, const Image<T, C>& b, const char* what) {
+    if (a.size() != b.size())
+        throw ImageError(ImageError::Kind::InvalidImageSize, std::string(what) + ": image sizes differ: " + std::to_string(a.width()) + "x" +
+                                                                 std::to_string(a.height()) + " vs " + std::to_string(b.width()) + "x" + std::to_string(b.height()));
+}
+inline int32_t i32(size_t v) { return static_cast<int32_t>(v); }
+}  // namespace detail
+
+// ---- operators: one call per reference launcher (names and argument meaning of kornia_imgproc) --------------
+namespace imgproc {
+
+// color::gray_from_rgb (P/color/gray/mod.rs:104-147)
+inline void gray_from_rgb(const Image<uint8_t, 3>& src, Image<uint8_t, 1>& dst) {
+    const Stream& s = detail::device_exec_for(src, dst, "gray_from_rgb");
+    if (src.size() != dst.size()) throw ImageError(ImageError::Kind::InvalidImageSize, "gray_from_rgb: image sizes differ");
+    detail::check(kh_gray_from_rgb_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), (int64_t)(src.width() * src.height())));
+}
+inline void gray_from_rgb(const Image<float, 3>& src, Image<float, 1>& dst) {
+    const Stream& s = detail::device_exec_for(src, dst, "gray_from_rgb");
+    if (src.size() != dst.size()) throw ImageError(ImageError::Kind::InvalidImageSize, "gray_from_rgb: image sizes differ");
+    detail::check(kh_gray_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), (int64_t)(src.width() * src.height())));
+}
+
+// resize::resize (P/resize/mod.rs:114-238); f32, C in {1, 3, 4}
+template <int C>
+inline void resize(const Image<float, C>& src, Image<float, C>& dst, InterpolationMode interpolation) {
+    const Stream& s = detail::device_exec_for(src, dst, "resize");
+    detail::check(kh_resize_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
+                                detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, 1, 0, 0));
+}
+// resize::resize_fast_u8_aa (P/resize/mod.rs:348)
+template <int C>
+inline void resize_fast(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, InterpolationMode interpolation, bool antialias = true) {
+    const Stream& s = detail::device_exec_for(src, dst, "resize_fast");
+    detail::check(kh_resize_fast_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
+                                    detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, antialias ? 1 : 0, 1, 0, 0));
+}
+
+// filter::gaussian_blur / box_blur (P/filter/ops.rs:116, 39; u8: :639, :59)
+template <int C>
+inline void gaussian_blur(const Image<float, C>& src, Image<float, C>& dst, std::pair<int, int> kernel_size, std::pair<float, float> sigma) {
+    const Stream& s = detail::device_exec_for(src, dst, "gaussian_blur");
+    detail::same_size(src, dst, "gaussian_blur");
+    detail::check(kh_gaussian_blur_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
+                                       kernel_size.first, kernel_size.second, sigma.first, sigma.second, 1, 0, 0));
+}
+template <int C>
+inline void gaussian_blur(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, std::pair<int, int> kernel_size, std::pair<float, float> sigma) {
+    const Stream& s = detail::device_exec_for(src, dst, "gaussian_blur_u8");
+    detail::same_size(src, dst, "gaussian_blur_u8");
+    detail::check(kh_gaussian_blur_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
+                                      kernel_size.first, kernel_size.second, sigma.first, sigma.second, 1, 0, 0));
+}
+template <int C>
+inline void box_blur(const Image<float, C>& src, Image<float, C>& dst, std::pair<int, int> kernel_size) {
+    const Stream& s = detail::device_exec_for(src, dst, "box_blur");
+    detail::same_size(src, dst, "box_blur");
+    detail::check(kh_box_blur_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
+                                  kernel_size.first, kernel_size.second, 1, 0, 0));
+}
+
+// warp::warp_affine / warp_perspective (P/warp/affine.rs:123, P/warp/perspective.rs:115); m = FORWARD transform
+template <int C>
+inline void warp_affine(const Image<float, C>& src, Image<float, C>& dst, const std::array<float, 6>& m, InterpolationMode interpolation) {
+    const Stream& s = detail::device_exec_for(src, dst, "warp_affine");
+    detail::check(kh_warp_affine_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
+                                     detail::i32(dst.width()), detail::i32(dst.height()), C, m.data(), (int32_t)interpolation, 1, 0, 0));
+}
+template <int C>
+inline void warp_perspective(const Image<float, C>& src, Image<float, C>& dst, const std::array<float, 9>& m, InterpolationMode interpolation) {
+    const Stream& s = detail::device_exec_for(src, dst, "warp_perspective");
+    detail::check(kh_warp_perspective_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
+                                          detail::i32(dst.width()), detail::i32(dst.height()), C, m.data(), (int32_t)interpolation, 1, 0, 0));
+}
+template <int C>
+inline void warp_affine_u8(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const std::array<float, 6>& m) {
+    const Stream& s = detail::device_exec_for(src, dst, "warp_affine_u8");
+    detail::check(kh_warp_affine_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
+                                    detail::i32(dst.width()), detail::i32(dst.height()), C, m.data(), 1, 0, 0));
+}
+
+// interpolation::remap (P/interpolation/remap.rs:43): maps are single-channel f32 images of the destination size
+template <int C>
+inline void remap(const Image<float, C>& src, Image<float, C>& dst, const Image<float, 1>& map_x, const Image<float, 1>& map_y,
+                  InterpolationMode interpolation) {
+    const Stream& s = detail::device_exec_for(src, dst, "remap");
+    if (map_x.size() != dst.size() || map_y.size() != dst.size())
+        throw ImageError(ImageError::Kind::InvalidImageSize, "remap: map_x, map_y and dst must have the same size");
+    if (!map_x.is_device() || !map_y.is_device())
+        throw ImageError(ImageError::Kind::MixedResidency, "remap: map_x and map_y must be device-resident when src/dst are on the GPU");
+    for (const Image<float, 1>* mp : {&map_x, &map_y})
+        if (!mp->stream()->same_as(s)) detail::check(kh_stream_fence(mp->stream()->handle(), s.handle()));
+    detail::check(kh_remap_f32(s.handle(), src.device_ptr(), map_x.device_ptr(), map_y.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()),
+                               detail::i32(src.height()), detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, 1, 0, 0));
+}
+
+// normalize::normalize_mean_std (P/normalize.rs:56)
+template <int C>
+inline void normalize_mean_std(const Image<float, C>& src, Image<float, C>& dst, const std::array<float, C>& mean, const std::array<float, C>& std_) {
+    const Stream& s = detail::device_exec_for(src, dst, "normalize_mean_std");
+    detail::same_size(src, dst, "normalize_mean_std");
+    detail::check(kh_normalize_mean_std_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), (int64_t)(src.width() * src.height()), C, mean.data(),
+                                            std_.data()));
+}
+
+}  // namespace imgproc
+
+// ---- fused camera preprocess (Preprocessor / PreprocessorBuilder, P/preprocess.rs:654-1282) ------------------
+enum class ResizeMode { Stretch, Letterbox };
+enum class SourceFormat { Rgb8 = KH_FMT_RGB, Bgr8 = KH_FMT_BGR, Gray8 = KH_FMT_GRAY, Nv12 = KH_FMT_NV12, Yuyv = KH_FMT_YUYV };
+
+class Preprocessor {
+public:
+    Preprocessor(const Stream& stream, ResizeMode mode, SourceFormat format, std::array<float, 3> mean = {0, 0, 0}, std::array<float, 3> std_ = {1, 1, 1},
+                 float pad_value = 114.0f, int sampling = KH_SAMPLE_BILINEAR)
+        : stream_(stream), mode_(mode), format_(format), mean_(mean), pad_value_(pad_value), sampling_(sampling) {
+        // Normalize::mean_inv_std (P/preprocess.rs:107-121): finite mean, finite std > 0
+        for (int c = 0; c < 3; ++c) {
+            if (!(std_[c] > 0.0f) || !(std_[c] <= 3.4028234e38f) || !(mean[c] == mean[c]) || !(mean[c] >= -3.4028234e38f && mean[c] <= 3.4028234e38f))
+                throw ImageError(ImageError::Kind::InvalidNormalize, "invalid normalize: mean must be finite, std must be finite and > 0");
+            inv_std_[c] = 1.0f / std_[c];
+        }
+    }
+    // run_raw (P/preprocess.rs:1184-1222): one raw device frame -> dst [1, 3, dst_h, dst_w] f32 (device pointers)
+    void run_raw(const uint8_t* src_device, size_t src_bytes, int src_w, int src_h, float* dst_device, int dst_w, int dst_h, int nframes = 1,
+                 int64_t src_frame_stride = 0) const {
+        // SourceFormat::{bpp, pitch, buffer_len, dims_ok} (P/preprocess.rs:131-250)
+        const bool nv12 = format_ == SourceFormat::Nv12, yuyv = format_ == SourceFormat::Yuyv;
+        const int bpp = (format_ == SourceFormat::Rgb8 || format_ == SourceFormat::Bgr8) ? 3 : (yuyv ? 2 : 1);
+        const size_t need = (size_t)src_w * bpp * src_h + (nv12 ? (size_t)src_w * src_h / 2 : 0);
+        if (src_w <= 0 || src_h <= 0 || src_bytes < need || (nv12 && ((src_w | src_h) & 1)) || (yuyv && (src_w & 1)))
+            throw ImageError(ImageError::Kind::InvalidImageSize, "preprocess: invalid raw source (need " + std::to_string(need) + " bytes, even dimensions for 4:2:x)");
+        kh_preprocess_params p{};
+        // Affine (P/preprocess.rs:350-369), f32 arithmetic: letterbox s = min(dw/sw, dh/sh), pad = (d - src*s) * 0.5
+        if (mode_ == ResizeMode::Stretch) {
+            p.scale_x = (float)dst_w / (float)src_w; p.scale_y = (float)dst_h / (float)src_h; p.pad_x = 0.0f; p.pad_y = 0.0f;
+        } else {
+            const float sx = (float)dst_w / (float)src_w, sy = (float)dst_h / (float)src_h, sc = sx < sy ? sx : sy;
+            p.scale_x = sc; p.scale_y = sc;
+            p.pad_x = ((float)dst_w - (float)src_w * sc) * 0.5f; p.pad_y = ((float)dst_h - (float)src_h * sc) * 0.5f;
+        }
+        p.src_w = src_w; p.src_h = src_h; p.src_pitch = src_w * bpp; p.src_bpp = bpp; p.fmt = (int32_t)format_;
+        p.dst_w = dst_w; p.dst_h = dst_h;
+        for (int c = 0; c < 3; ++c) { p.mean[c] = mean_[c]; p.inv_std[c] = inv_std_[c]; }
+        p.pad_value = pad_value_; p.sampling = sampling_; p.out_dtype = KH_OUT_F32; p.nframes = nframes; p.flags = 0;
+        p.src_frame_stride = src_frame_stride; p.dst_frame_stride = (int64_t)3 * dst_w * dst_h;
+        detail::check(kh_preprocess_to_chw(stream_.handle(), src_device, dst_device, &p));
+    }
+    const Stream& stream() const { return stream_; }
+
+private:
+    Stream stream_;
+    ResizeMode mode_;
+    SourceFormat format_;
+    std::array<float, 3> mean_, inv_std_;
+    float pad_value_;
+    int sampling_;
+};
+
+}  // namespace kornia

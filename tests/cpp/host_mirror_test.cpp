@@ -1,0 +1,95 @@
+// Exercises include/kornia_hip.hpp.  `host` mode (no GPU): residency rules and typed errors only — no compute
+// entry is reached.  `gpu` mode: the reference's own known answers through the C++ mirror on a device.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "kornia_hip.hpp"
+
+using namespace kornia;
+using K = ImageError::Kind;
+
+static int failures = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+template <typename F>
+static bool throws(K kind, F&& f) {
+    try { f(); } catch (const ImageError& e) { return e.kind == kind; } catch (...) { return false; }
+    return false;
+}
+
+static void host_only() {
+    auto a = Image<float, 3>::from_size_val({4, 5}, 0.25f);
+    EXPECT(a.width() == 4 && a.height() == 5 && a.numel() == 60 && !a.is_device() && a.domain() == MemoryDomain::Host);
+    EXPECT(a.as_slice().size() == 60 && a.as_slice()[7] == 0.25f && a.stream() == nullptr);
+    EXPECT(throws(K::InvalidChannelShape, [] { Image<float, 3>::from_size_vec({4, 5}, std::vector<float>(59)); }));
+    EXPECT(throws(K::UnsupportedDevice, [&] { (void)a.device_ptr(); }));
+    EXPECT(throws(K::UnsupportedDevice, [&] { (void)a.to_host(); }));
+    auto b = Image<float, 3>::from_size_val({2, 3}, 0.0f);
+    // host/host pair: this build has no CPU path and says so — never a silent fallback (P/cuda/dispatch.rs:203-211)
+    EXPECT(throws(K::HostPathUnavailable, [&] { imgproc::resize(a, b, InterpolationMode::Bilinear); }));
+    EXPECT(throws(K::HostPathUnavailable, [&] { imgproc::gaussian_blur(a, a, {3, 3}, {1.0f, 1.0f}); }));
+    Stream borrowed = Stream::from_handle(nullptr, 0);  // no runtime call: a borrowed handle is only recorded
+    EXPECT(borrowed.device() == 0 && borrowed.handle() == nullptr);
+    EXPECT(throws(K::InvalidNormalize, [&] { Preprocessor(borrowed, ResizeMode::Letterbox, SourceFormat::Rgb8, {0, 0, 0}, {1, 0, 1}); }));
+    EXPECT(throws(K::InvalidNormalize, [&] { Preprocessor(borrowed, ResizeMode::Letterbox, SourceFormat::Rgb8, {0, NAN, 0}, {1, 1, 1}); }));
+    // raw-frame validation happens before any launch (SourceFormat::dims_ok / buffer_len, P/preprocess.rs:131-250)
+    Preprocessor pre(borrowed, ResizeMode::Letterbox, SourceFormat::Nv12);
+    EXPECT(throws(K::InvalidImageSize, [&] { pre.run_raw(nullptr, 1 << 20, 15, 8, nullptr, 8, 8); }));  // odd width
+    EXPECT(throws(K::InvalidImageSize, [&] { pre.run_raw(nullptr, 16 * 8, 16, 8, nullptr, 8, 8); }));  // luma only: chroma plane missing
+    Preprocessor yuyv(borrowed, ResizeMode::Stretch, SourceFormat::Yuyv);
+    EXPECT(throws(K::InvalidImageSize, [&] { yuyv.run_raw(nullptr, 16 * 8 * 2 - 1, 16, 8, nullptr, 8, 8); }));
+}
+
+static void on_device() {
+    Stream s = Stream::create(0), other = Stream::create(0);
+    // gray [0,128,255],[128,0,128] -> [104, 53]  (P/color/gray/mod.rs:395-412)
+    auto rgb = Image<uint8_t, 3>::from_size_vec({2, 1}, {0, 128, 255, 128, 0, 128}).to_hip(s);
+    auto gray = Image<uint8_t, 1>::zeros_hip({2, 1}, s);
+    imgproc::gray_from_rgb(rgb, gray);
+    auto g = gray.to_host();
+    EXPECT(g.as_slice()[0] == 104 && g.as_slice()[1] == 53);
+    EXPECT(throws(K::UnsupportedDevice, [&] { (void)gray.as_slice(); }));
+    // resize smoke (P/resize/mod.rs:447-490): 4x3x3 ramp -> 3x2, expected 18 values
+    std::vector<float> ramp(36);
+    for (int i = 0; i < 36; ++i) ramp[i] = (float)i;
+    auto src = Image<float, 3>::from_size_vec({3, 4}, ramp).to_hip(s);
+    auto dst = Image<float, 3>::zeros_hip({2, 3}, other);  // allocated + zero-filled on ANOTHER stream: must be fenced in
+    imgproc::resize(src, dst, InterpolationMode::Bilinear);
+    const float want[18] = {2.25f, 3.25f, 4.25f, 6.75f, 7.75f, 8.75f, 14.25f, 15.25f, 16.25f, 18.75f, 19.75f, 20.75f, 26.25f, 27.25f, 28.25f,
+                            30.75f, 31.75f, 32.75f};
+    s.synchronize();
+    auto out = dst.to_host();
+    for (int i = 0; i < 18; ++i) EXPECT(std::fabs(out.as_slice()[i] - want[i]) < 1e-4f);
+    // mixed residency and singular homography are typed errors (P/warp/cuda.rs:369-400, P/warp/perspective.rs:41-60)
+    auto host_dst = Image<float, 3>::from_size_val({2, 3}, 0.0f);
+    EXPECT(throws(K::MixedResidency, [&] { imgproc::resize(src, host_dst, InterpolationMode::Bilinear); }));
+    auto same = Image<float, 3>::zeros_hip({3, 4}, s);
+    EXPECT(throws(K::CannotComputeDeterminant, [&] { imgproc::warp_perspective(src, same, {1, 2, 3, 2, 4, 6, 3, 6, 9}, InterpolationMode::Bilinear); }));
+    // horizontal flip through warp_affine lands every column (P/warp/affine.rs:471-495)
+    auto row = Image<float, 1>::from_size_vec({4, 2}, {1, 2, 3, 4, 5, 6, 7, 8}).to_hip(s);
+    auto flipped = Image<float, 1>::zeros_hip({4, 2}, s);
+    imgproc::warp_affine(row, flipped, {-1, 0, 3, 0, 1, 0}, InterpolationMode::Nearest);
+    auto f = flipped.to_host();
+    const float wf[8] = {4, 3, 2, 1, 8, 7, 6, 5};
+    for (int i = 0; i < 8; ++i) EXPECT(f.as_slice()[i] == wf[i]);
+    // fused preprocess: a solid NV12 frame (Y=235,U=V=128 -> white) stretched, unit normalisation -> all 1.0 (P/preprocess.rs:1429)
+    const int w = 16, h = 8;
+    std::vector<uint8_t> nv(w * h * 3 / 2, 128);
+    std::memset(nv.data(), 235, w * h);
+    auto frame = Image<uint8_t, 1>::from_size_vec({(size_t)w * h * 3 / 2, 1}, nv).to_hip(s);
+    auto chw = Image<float, 1>::zeros_hip({(size_t)3 * 12 * 6, 1}, s);
+    Preprocessor pre(s, ResizeMode::Stretch, SourceFormat::Nv12);
+    pre.run_raw(frame.device_ptr(), nv.size(), w, h, chw.device_ptr_mut(), 12, 6);
+    auto t = chw.to_host();
+    for (float v : t.as_slice()) EXPECT(std::fabs(v - 1.0f) < 1e-6f);
+    EXPECT(throws(K::InvalidImageSize, [&] { pre.run_raw(frame.device_ptr(), nv.size() - 1, w, h, chw.device_ptr_mut(), 12, 6); }));
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "host";
+    host_only();
+    if (mode == "gpu") on_device();
+    std::printf("%s: %d failure(s) [%s]\n", mode.c_str(), failures, kh_version());
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,38 @@
+"""include/kornia_hip.hpp — the C++17 host mirror of the reference's Rust API — compiled with g++ against the
+C ABI.  CPU leg: residency rules, typed errors and raw-frame validation (no compute entry is reached).  GPU leg:
+the reference's own known answers (gray, resize smoke, flip, solid NV12 frame) through the mirror."""
+import os
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB = ROOT / "kornia-rs_amd" / "lib"
+
+
+@pytest.fixture(scope="module")
+def binary(tmp_path_factory):
+    out = tmp_path_factory.mktemp("cpp") / "host_mirror_test"
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", f"-I{ROOT / 'include'}",
+           str(ROOT / "tests" / "cpp" / "host_mirror_test.cpp"), "-o", str(out), f"-L{LIB}", "-lkornia_hip",
+           f"-Wl,-rpath,{LIB}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+def _run(binary, mode):
+    env = dict(os.environ, HSA_ENABLE_SDMA=os.environ.get("HSA_ENABLE_SDMA", "0"))
+    r = subprocess.run([str(binary), mode], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failure(s)" in r.stdout
+
+
+def test_cpp_mirror_host_contract(binary):
+    _run(binary, "host")
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_known_answers_on_device(binary):
+    _run(binary, "gpu")
