@@ -14,6 +14,7 @@ from .preprocess import Preprocessor, PreprocessError, ResizeMode, SourceFormat
 from . import imgproc
 from . import fusion
 from . import color_spaces
+from . import calibration
 from .color_spaces import ColorSpace
 from . import sharding
 
@@ -22,5 +23,5 @@ cuda = hip  # reference module name (kornia_rs.cuda.Stream); same objects, HIP u
 __version__ = "0.1.0"
 __all__ = [
     "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Image", "ImageError", "Preprocessor",
-    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "fusion", "color_spaces", "ColorSpace", "hip", "cuda", "sharding",
+    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "fusion", "color_spaces", "ColorSpace", "calibration", "hip", "cuda", "sharding",
 ]

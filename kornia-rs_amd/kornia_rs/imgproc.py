@@ -555,7 +555,7 @@ def normalize_min_max(src: Image, min: float, max: float, dst: Optional[Image] =
     return out
 
 
-def crop(src: Image, x: int, y: int, width: int, height: int, dst: Optional[Image] = None) -> Image:
+def crop_image(src: Image, x: int, y: int, width: int, height: int, dst: Optional[Image] = None) -> Image:
     out = dst if dst is not None else _new_like(src, size=(width, height))
     if out.dtype != src.dtype or out.channels != src.channels or out.size != (width, height):
         raise ImageError("InvalidImageSize", "crop destination must be width x height with the source's type")
@@ -730,3 +730,6 @@ lab_from_rgb = _cie("lab_from_rgb")
 rgb_from_lab = _cie("rgb_from_lab")
 luv_from_rgb = _cie("luv_from_rgb")
 rgb_from_luv = _cie("rgb_from_luv")
+
+
+crop = crop_image  # short name used by the Python stubs; `crop_image` is the Rust name (P/crop.rs:187)

@@ -48,3 +48,41 @@ def test_plan_division_shortcut_is_checked_not_assumed():
     worst = np.array([0x3FFFFFFF], np.uint32).view(np.float32)[0]
     total = sum(g(float(p), float(worst), 4096) for p in (0.0, 0.25, 7.5))
     assert total >= 0  # informational: the kernel falls back to IEEE division whenever this is non-zero
+
+
+# ---- calibration (P/calibration/distortion.rs) -------------------------------------------------------
+
+def _ref_camera():
+    from kornia_rs.calibration import CameraIntrinsic, PolynomialDistortion
+    intr = CameraIntrinsic(fx=577.48583984375, fy=652.8748779296875, cx=577.48583984375, cy=386.1428833007813)
+    dist = PolynomialDistortion(k1=1.7547749280929563, k2=0.0097926277667284, k3=-0.027250492945313457,
+                                k4=2.1092164516448975, k5=0.462927520275116, k6=-0.08215277642011642,
+                                p1=-0.00005457743463921361, p2=0.00003006766564794816)
+    return intr, dist
+
+
+def test_distort_point_polynomial_reference_known_answer():  # distortion.rs:604-628
+    from kornia_rs.calibration import distort_point_polynomial
+    intr, dist = _ref_camera()
+    x, y = distort_point_polynomial(100.0, 20.0, intr, dist)
+    assert y == 98.83006704526377  # the reference asserts f64 equality on y
+    assert x != 194.24656721843076  # ... and (sic) inequality on x: cx == fx in this fixture moves it
+
+
+def test_distort_point_matches_the_map_restatement_everywhere():
+    """The per-point host model and the map builder the device kernel is checked against are the same function."""
+    from dataclasses import astuple
+    from kornia_rs.calibration import distort_point_polynomial
+    intr, dist = _ref_camera()
+    mx, my = O.correction_map(astuple(intr), astuple(dist), 160, 120)
+    for (x, y) in [(0, 0), (100, 20), (159, 119), (37, 91), (80, 60)]:
+        px, py = distort_point_polynomial(x, y, intr, dist)
+        assert mx[y, x] == np.float32(px) and my[y, x] == np.float32(py)
+
+
+def test_polynomial_distortion_defaults_to_identity():
+    from kornia_rs.calibration import CameraIntrinsic, PolynomialDistortion, distort_point_polynomial
+    intr = CameraIntrinsic(500.0, 500.0, 320.0, 240.0)
+    for (x, y) in [(0.0, 0.0), (320.0, 240.0), (639.0, 479.0)]:
+        px, py = distort_point_polynomial(x, y, intr, PolynomialDistortion())
+        assert abs(px - x) < 1e-9 and abs(py - y) < 1e-9
