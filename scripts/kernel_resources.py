@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Static per-kernel resource table (VGPRs, scratch, LDS, occupancy) for every gfx950 kernel in csrc/ — no GPU
+needed.  Catches register spills and private arrays the compiler moved to scratch / LDS before they cost a GPU run.
+
+    python scripts/kernel_resources.py > profiles/<round>_static_kernel_resources.txt
+"""
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "kornia-rs_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fvisibility=hidden", "-Wno-unused-function",
+         "-Wno-pass-failed", f"-I{ROOT}/include", f"-I{CSRC}", "--cuda-device-only",
+         "-Rpass-analysis=kernel-resource-usage", "-c"]
+FIELDS = [("vgpr", r" VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("sgpr", r"TotalSGPRs: (\d+)"),
+          ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("occ", r"Occupancy \[waves/SIMD\]: (\d+)"),
+          ("lds", r"LDS Size \[bytes/block\]: (\d+)"), ("spill", r"VGPRs Spill: (\d+)")]
+
+
+def main():
+    rows = []
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
+            out = os.path.join(tmp, os.path.basename(src) + ".co")
+            procs.append((src, subprocess.Popen(["/opt/rocm/bin/hipcc", *FLAGS, src, "-o", out], stderr=subprocess.PIPE, text=True)))
+        for src, p in procs:
+            _, err = p.communicate()
+            if p.returncode:
+                sys.exit(err)
+            cur = None
+            for line in err.splitlines():
+                m = re.search(r"Function Name: (\S+)", line)
+                if m:
+                    cur = {"file": os.path.basename(src), "name": m.group(1)}
+                    rows.append(cur)
+                    continue
+                for key, pat in FIELDS:
+                    m = re.search(pat, line)
+                    if m and cur is not None:
+                        cur[key] = int(m.group(1))
+    dem = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
+    print(f"# {len(rows)} kernels, gfx950, flags: {' '.join(FLAGS[:9])}")
+    print(f"# kernels with scratch: {sum(1 for r in rows if r.get('scratch', 0))}, with VGPR spills: {sum(1 for r in rows if r.get('spill', 0))}")
+    print(f"{'file':22s} {'vgpr':>4s} {'sgpr':>4s} {'scr':>4s} {'lds':>5s} {'occ':>3s}  kernel")
+    for r, d in sorted(zip(rows, dem), key=lambda t: (t[0]["file"], t[1])):
+        d = d.replace("(anonymous namespace)::", "")
+        d = re.sub(r"\(.*", "", d)
+        print(f"{r['file']:22s} {r.get('vgpr', 0):4d} {r.get('sgpr', 0):4d} {r.get('scratch', 0):4d} {r.get('lds', 0):5d} {r.get('occ', 0):3d}  {d}")
+
+
+if __name__ == "__main__":
+    main()
