@@ -7,6 +7,10 @@ are ``Image`` factories that check dtype and channel count.  ``Nv12`` / ``Nv21``
 ``Yuyv8`` / ``Uyvy8`` / ``Yvyu8`` carry one byte buffer with a sub-sampled layout and validate its length
 and the even-dimension rules on construction; ``to_hip`` uploads the buffer for the device decoders
 (``imgproc.rgb_from_*`` accept them directly).
+
+``convert(src, to)`` is the ``ConvertColor`` trait (crates/kornia-imgproc/src/color/convert.rs:31-273): the source's
+colour-space tag, its dtype and the requested space select ONE conversion from the same table of impls; a pair
+without an impl is an error, never a multi-hop route.
 """
 from __future__ import annotations
 
@@ -40,9 +44,7 @@ def _typed(name: str, dtype: str, space: ColorSpace):
         if a.ndim != 3 or a.shape[2] != space.channels or a.dtype != np.dtype(dtype):
             raise ImageError("InvalidChannelShape",
                              f"{name} needs a [H, W, {space.channels}] {dtype} array, got {a.shape} {a.dtype}")
-        img = Image.from_numpy(np.ascontiguousarray(a))
-        img.color_space = space
-        return img
+        return Image(Image.from_numpy(np.ascontiguousarray(a)).tensor, space)
     make.__name__ = name
     make.color_space = space
     return make
@@ -126,3 +128,63 @@ class _Packed422(_VideoBuffer):
 class Yuyv8(_Packed422): layout = "yuyv"
 class Uyvy8(_Packed422): layout = "uyvy"
 class Yvyu8(_Packed422): layout = "yvyu"
+
+
+# ---- ConvertColor (P/color/convert.rs:101-273) -------------------------------------------------------------
+# (source space, destination space) -> (imgproc function, dtypes the reference implements for a device pair)
+_U8, _F32, _BOTH = ("uint8",), ("float32",), ("uint8", "float32")
+_CONVERSIONS = {
+    (ColorSpace.RGB, ColorSpace.GRAY): ("gray_from_rgb", _BOTH), (ColorSpace.GRAY, ColorSpace.RGB): ("rgb_from_gray", _BOTH),
+    (ColorSpace.RGB, ColorSpace.BGR): ("bgr_from_rgb", _BOTH), (ColorSpace.BGR, ColorSpace.RGB): ("bgr_from_rgb", _BOTH),
+    (ColorSpace.RGB, ColorSpace.HSV): ("hsv_from_rgb", _F32), (ColorSpace.HSV, ColorSpace.RGB): ("rgb_from_hsv", _F32),
+    (ColorSpace.RGB, ColorSpace.HLS): ("hls_from_rgb", _F32), (ColorSpace.HLS, ColorSpace.RGB): ("rgb_from_hls", _F32),
+    (ColorSpace.RGB, ColorSpace.LINEAR_RGB): ("linear_rgb_from_rgb", _F32),
+    (ColorSpace.LINEAR_RGB, ColorSpace.RGB): ("rgb_from_linear_rgb", _F32),
+    (ColorSpace.RGB, ColorSpace.XYZ): ("xyz_from_rgb", _F32), (ColorSpace.XYZ, ColorSpace.RGB): ("rgb_from_xyz", _F32),
+    (ColorSpace.RGB, ColorSpace.LAB): ("lab_from_rgb", _F32), (ColorSpace.LAB, ColorSpace.RGB): ("rgb_from_lab", _F32),
+    (ColorSpace.RGB, ColorSpace.LUV): ("luv_from_rgb", _F32), (ColorSpace.LUV, ColorSpace.RGB): ("rgb_from_luv", _F32),
+    (ColorSpace.RGB, ColorSpace.YCBCR): ("ycbcr_from_rgb", _BOTH), (ColorSpace.YCBCR, ColorSpace.RGB): ("rgb_from_ycbcr", _BOTH),
+    (ColorSpace.RGB, ColorSpace.YUV): ("yuv_from_rgb", _BOTH), (ColorSpace.YUV, ColorSpace.RGB): ("rgb_from_yuv", _BOTH),
+    (ColorSpace.RGBA, ColorSpace.RGB): ("rgb_from_rgba", _U8), (ColorSpace.BGRA, ColorSpace.RGB): ("rgb_from_bgra", _U8),
+    (ColorSpace.RGB, ColorSpace.RGBA): ("rgba_from_rgb", _BOTH), (ColorSpace.RGB, ColorSpace.BGRA): ("bgra_from_rgb", _BOTH),
+}
+
+
+def _space_of(to) -> ColorSpace:
+    if isinstance(to, ColorSpace):
+        return to
+    space = getattr(to, "color_space", None)  # a typed constructor (Gray8, Hsvf32 ...) or a tagged image
+    if isinstance(space, ColorSpace):
+        return space
+    raise ImageError("InvalidChannelShape", f"convert: {to!r} does not name a colour space")
+
+
+def convert(src, to, dst: Optional[Image] = None, background=None) -> Image:
+    """``src.convert(&mut dst)`` (P/color/convert.rs:31-40).  ``src`` is a tagged image (``Rgb8(...)``, possibly moved with
+    ``to_hip``) or a camera buffer (``Nv12`` ... decode to RGB8, :245-261); ``to`` a ``ColorSpace`` or a typed
+    constructor.  ``background`` is ``convert_with_bg``'s optional RGB triple for RGBA/BGRA sources (:266-274).
+    The result carries the destination tag."""
+    from . import imgproc
+    want = _space_of(to)
+    if isinstance(src, _VideoBuffer):
+        if want is not ColorSpace.RGB:
+            raise ImageError("NoDeviceKernel", f"convert: camera buffers decode to RGB8 only (asked for {want.name})")
+        out = imgproc.rgb_from_video(src, dst)
+        out.color_space = want
+        return out
+    have = getattr(src, "color_space", None)
+    if have is None:
+        raise ImageError("InvalidChannelShape", "convert: the source image carries no colour-space tag; build it with a typed "
+                                                 "constructor (Rgb8, Bgrf32 ...) or call the imgproc function directly")
+    entry = _CONVERSIONS.get((have, want))
+    if entry is None or src.dtype not in entry[1]:
+        raise ImageError("NoDeviceKernel", f"convert: no {have.name} -> {want.name} conversion for {src.dtype} images")
+    fn = getattr(imgproc, entry[0])
+    if background is not None:
+        if have not in (ColorSpace.RGBA, ColorSpace.BGRA):
+            raise ImageError("NoDeviceKernel", "convert: a background applies to RGBA / BGRA sources only")
+        out = fn(src, dst, background)
+    else:
+        out = fn(src, dst)
+    out.color_space = want
+    return out

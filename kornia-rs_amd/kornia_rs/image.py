@@ -32,10 +32,13 @@ class ImageError(ValueError):
 
 
 class Image:
-    def __init__(self, tensor: Tensor):
+    def __init__(self, tensor: Tensor, color_space=None):
         if len(tensor.shape) != 3:
             raise ImageError("InvalidChannelShape", f"an image is [H, W, C], got shape {tensor.shape}")
         self._t = tensor
+        # what the channels mean (color_spaces.ColorSpace) when the image came from a typed constructor
+        # (Rgb8, Hsvf32 ... — the newtypes of I/color_spaces.rs:269-620); None = untyped.  Travels with transfers.
+        self.color_space = color_space
 
     # -- constructors -------------------------------------------------------------------------
     @staticmethod
@@ -98,14 +101,14 @@ class Image:
 
     def to_hip(self, stream: Optional[Stream] = None) -> "Image":
         """H2D copy onto ``stream``'s device (to_cuda, I/cuda.rs:53-70); a device image is returned as is."""
-        return self if self.is_device else Image(self._t.to_hip(stream))
+        return self if self.is_device else Image(self._t.to_hip(stream), self.color_space)
 
     to_cuda = to_hip  # reference spelling (kornia_rs/image.pyi:199)
 
     def cpu(self, stream: Optional[Stream] = None) -> "Image":
         if self.is_device:
-            return Image(self._t.cpu())
-        return Image(Tensor.from_numpy(self._t.numpy_raw().copy()))
+            return Image(self._t.cpu(), self.color_space)
+        return Image(Tensor.from_numpy(self._t.numpy_raw().copy()), self.color_space)
 
     def numpy(self) -> np.ndarray:
         """Host: zero-copy view.  Device: D2H copy, returned read-only (image.pyi:179-184)."""

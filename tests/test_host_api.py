@@ -204,3 +204,36 @@ def test_video_buffer_types_validate_layout():  # I/color_spaces.rs:630-830
     with pytest.raises(ImageError) as e:  # host buffers never reach a device decoder implicitly
         imgproc.rgb_from_video(nv)
     assert e.value.kind == "HostPathUnavailable"
+
+
+# ---- ConvertColor dispatch (P/color/convert.rs) --------------------------------------------------------
+
+def test_convert_color_table_covers_the_reference_impls_and_rejects_the_rest():
+    from kornia_rs import ImageError, color_spaces as cs, imgproc
+    CS = cs.ColorSpace
+    # every impl_convert! of convert.rs:108-238 that has a device arm resolves to an imgproc entry
+    for (have, want), (name, dtypes) in cs._CONVERSIONS.items():
+        assert callable(getattr(imgproc, name)), name
+        assert have.channels in (1, 3, 4) and want.channels in (1, 3, 4) and dtypes
+    assert len(cs._CONVERSIONS) == 24
+    rgb = cs.Rgb8(np.zeros((4, 6, 3), np.uint8))
+    assert rgb.color_space is CS.RGB and rgb.cpu().color_space is CS.RGB  # the tag travels with copies
+    # host operands: classified, then refused (device backend only) — the table lookup itself succeeded
+    with pytest.raises(ImageError) as e:
+        cs.convert(rgb, cs.Gray8)
+    assert e.value.kind == "HostPathUnavailable"
+    with pytest.raises(ImageError) as e:  # float-only space from a u8 image: no impl (convert.rs:134-190)
+        cs.convert(rgb, CS.HSV)
+    assert e.value.kind == "NoDeviceKernel"
+    with pytest.raises(ImageError) as e:  # no multi-hop routes: HSV -> LAB is not an impl
+        cs.convert(cs.Hsvf32(np.zeros((2, 2, 3), np.float32)), CS.LAB)
+    assert e.value.kind == "NoDeviceKernel"
+    with pytest.raises(ImageError) as e:  # untyped image
+        cs.convert(__import__("kornia_rs").Image.from_numpy(np.zeros((2, 2, 3), np.uint8)), CS.GRAY)
+    assert e.value.kind == "InvalidChannelShape"
+    with pytest.raises(ImageError) as e:  # background only for RGBA / BGRA sources
+        cs.convert(rgb, CS.GRAY, background=(1, 2, 3))
+    assert e.value.kind == "NoDeviceKernel"
+    with pytest.raises(ImageError) as e:  # camera buffers decode to RGB8 only
+        cs.convert(cs.Nv12(4, 2, np.zeros(12, np.uint8)), CS.GRAY)
+    assert e.value.kind == "NoDeviceKernel"

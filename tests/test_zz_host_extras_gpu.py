@@ -1,0 +1,75 @@
+"""Host conveniences on a device — ``kornia_rs.calibration`` (typed camera parameters -> correction maps -> remap;
+P/calibration/distortion.rs:135-152, examples/undistort) and ``color_spaces.convert`` (the ConvertColor trait,
+P/color/convert.rs).  Sorted last on purpose: both chain entry points the earlier files already pin individually."""
+from dataclasses import astuple
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_undistort_image_matches_maps_then_remap(gpu_stream):
+    from kornia_rs import Image, ImageError, calibration, imgproc
+    intr = calibration.CameraIntrinsic(300.0, 300.0, 64.0, 48.0)
+    dist = calibration.PolynomialDistortion(k1=0.1, k2=0.01, p1=1e-4, p2=1e-4)
+    host = O.pattern_f32(129 * 97 * 3).reshape(97, 129, 3)
+    src = Image.from_numpy(host).to_hip(gpu_stream)
+    wx, wy = O.correction_map(astuple(intr), astuple(dist), 129, 97)
+    want = O.remap(host, wx, wy)
+    got = calibration.undistort_image(src, intr, dist)
+    assert got.is_device and np.array_equal(got.numpy(), want)
+    # cached maps + nearest, and the u8 twin through the same maps
+    maps = calibration.generate_correction_map_polynomial(intr, dist, (129, 97), gpu_stream)
+    assert np.array_equal(maps[0].numpy()[:, :, 0], wx) and np.array_equal(maps[1].numpy()[:, :, 0], wy)
+    near = calibration.undistort_image(src, intr, dist, "nearest", maps=maps)
+    assert np.array_equal(near.numpy(), O.remap(host, wx, wy, "nearest"))
+    rgb = O.pattern_u8(129 * 97 * 3).reshape(97, 129, 3)
+    und8 = calibration.undistort_image(Image.from_numpy(rgb).to_hip(gpu_stream), intr, dist, maps=maps)
+    assert np.array_equal(und8.numpy(), O.remap_u8(rgb, wx, wy))
+    with pytest.raises(ImageError) as e:
+        calibration.undistort_image(Image.from_numpy(host), intr, dist)
+    assert e.value.kind == "HostPathUnavailable"
+    assert imgproc.crop is imgproc.crop_image
+
+
+def test_convert_color_reference_cases(gpu_stream):  # P/color/convert.rs:280-560
+    from kornia_rs import color_spaces as cs
+    CS = cs.ColorSpace
+    up = lambda img: img.to_hip(gpu_stream)
+    # test_bgr_from_rgb / test_rgb_from_bgr
+    bgr = cs.convert(up(cs.Rgb8(np.array([[[255, 128, 64]]], np.uint8))), cs.Bgr8)
+    assert bgr.color_space is CS.BGR and bgr.numpy().reshape(-1).tolist() == [64, 128, 255]
+    assert cs.convert(bgr, CS.RGB).numpy().reshape(-1).tolist() == [255, 128, 64]
+    # test_gray_from_rgb_{f32,u8}, test_rgb_from_gray: shapes + values against the restatement
+    rgbf = np.array([1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.5, 0.5, 0.5], np.float32).reshape(2, 2, 3)
+    gray = cs.convert(up(cs.Rgbf32(rgbf)), cs.Grayf32)
+    assert gray.shape == (2, 2, 1) and np.array_equal(gray.numpy().reshape(-1), O.color_map("gray_from_rgb_f32", rgbf, 1))
+    g8 = cs.convert(up(cs.Rgb8(np.array([[[255, 0, 0], [0, 255, 0]]], np.uint8))), cs.Gray8)
+    assert g8.shape == (1, 2, 1) and g8.numpy().reshape(-1).tolist() == [76, 150]
+    back = cs.convert(up(cs.Grayf32(np.array([[0.0, 0.5], [1.0, 0.25]], np.float32))), cs.Rgbf32)
+    assert back.shape == (2, 2, 3) and np.array_equal(back.numpy()[:, :, 1], np.array([[0.0, 0.5], [1.0, 0.25]], np.float32))
+    # test_ycbcr_and_yuv_round_trip_u8
+    data = ((np.arange(4 * 2 * 3) * 7 + 11) % 256).astype(np.uint8).reshape(2, 4, 3)
+    rgb = up(cs.Rgb8(data))
+    ycc = cs.convert(rgb, cs.YCbCr8)
+    assert np.abs(cs.convert(ycc, cs.Rgb8).numpy().astype(int) - data.astype(int)).max() <= 3
+    yuv = cs.convert(rgb, cs.Yuv8)
+    assert yuv.color_space is CS.YUV and ycc.numpy()[0, 0, 0] == yuv.numpy()[0, 0, 0]
+    assert np.abs(cs.convert(yuv, cs.Rgb8).numpy().astype(int) - data.astype(int)).max() <= 3
+    # test_yuyv_decode_to_rgb: Y=16, U=V=128 -> black (limited range)
+    black = cs.convert(cs.Yuyv8(2, 1, np.array([16, 128, 16, 128], np.uint8)).to_hip(gpu_stream), cs.Rgb8)
+    assert black.color_space is CS.RGB and black.numpy().reshape(-1).tolist() == [0] * 6
+    # test_hsv_from_rgb + float-only CIE spaces resolve; test_rgb_from_rgba{,_with_background}, test_rgba_from_rgb
+    hsv = cs.convert(up(cs.Rgbf32(np.array([[[255.0, 0.0, 0.0]]], np.float32))), cs.Hsvf32)
+    assert hsv.shape == (1, 1, 3) and hsv.color_space is CS.HSV
+    lab = cs.convert(up(cs.Rgbf32(rgbf)), CS.LAB)
+    assert np.abs(cs.convert(lab, CS.RGB).numpy() - rgbf).max() < 1e-4
+    rgba = up(cs.Rgba8(np.array([[[255, 0, 0, 128], [0, 255, 0, 255]]], np.uint8)))
+    assert cs.convert(rgba, cs.Rgb8).numpy().reshape(-1).tolist() == [255, 0, 0, 0, 255, 0]
+    blended = cs.convert(rgba, cs.Rgb8, background=(100, 100, 100)).numpy().reshape(-1)
+    assert blended.tolist() == [178, 50, 50, 0, 255, 0]  # convert.rs:498-520: 50% red over (100, 100, 100)
+    again = cs.convert(up(cs.Rgb8(np.array([[[1, 2, 3]]], np.uint8))), cs.Rgba8)
+    assert again.numpy().reshape(-1).tolist() == [1, 2, 3, 255]
