@@ -322,7 +322,8 @@ KH_API int32_t kh_box_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* d
  * (P/warp/affine.rs:373: per-row valid span, Q16 stepped coordinates) and warp_perspective_u8
  * (P/warp/perspective.rs:179: analytic span on constant-sign rows, direct per-column coordinates).
  * Sampler: P/warp/common.rs:16-165, `(top*fy1 + bot*fy + 2^19) >> 20`, zeros outside.  Matrices
- * are FORWARD (src -> dst), host memory.                                                          */
+ * are FORWARD (src -> dst), host memory.  These three also take 2-channel images (the reference
+ * instantiates them per channel count and tests C = 2, P/warp/cuda.rs:458-494).                  */
 KH_API int32_t kh_remap_u8(kh_stream_t stream, const uint8_t* src, const float* map_x, const float* map_y,
                            uint8_t* dst, int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h, int32_t channels,
                            int32_t mode, int32_t batch, int64_t src_stride, int64_t dst_stride);

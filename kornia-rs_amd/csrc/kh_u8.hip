@@ -315,12 +315,14 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
     return rc;
 }
 
+// `two_ok`: the Q10 gathers take 2-channel images too (the reference instantiates them per channel count,
+// P/cuda/warp_affine_u8.rs:36-60, and tests C = 2: P/warp/cuda.rs:458-494); the blurs are built for 1, 3, 4.
 int32_t check_u8_img(const char* what, const void* src, const void* dst, int sw, int sh, int dw, int dh, int channels,
-                     int batch, int64_t ss, int64_t ds) {
+                     int batch, int64_t ss, int64_t ds, bool two_ok = false) {
     KH_REQUIRE(sw > 0 && sh > 0 && dw > 0 && dh > 0, KH_ERR_INVALID_ARG, "%s: zero-sized image (src %dx%d, dst %dx%d)",
                what, sw, sh, dw, dh);
-    KH_REQUIRE(channels == 1 || channels == 3 || channels == 4, KH_ERR_UNSUPPORTED,
-               "%s: no device kernel for %d channels (supported: 1, 3, 4)", what, channels);
+    KH_REQUIRE(channels == 1 || channels == 3 || channels == 4 || (two_ok && channels == 2), KH_ERR_UNSUPPORTED,
+               "%s: no device kernel for %d channels (supported: %s)", what, channels, two_ok ? "1, 2, 3, 4" : "1, 3, 4");
     KH_REQUIRE(batch >= 0 && batch <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, batch);
     KH_REQUIRE((int64_t)sw * sh * channels <= kI32Max && (int64_t)dw * dh * channels <= kI32Max, KH_ERR_TOO_LARGE,
                "%s: image exceeds 32-bit indexing", what);
@@ -359,9 +361,10 @@ __device__ __forceinline__ void store_px_u8(uint8_t* o, uint32_t px, bool wave_f
         } else {
             o[0] = (uint8_t)px; o[1] = (uint8_t)(px >> 8); o[2] = (uint8_t)(px >> 16);
         }
+    } else if constexpr (C == 2) {
+        *reinterpret_cast<u16_unaligned*>(o) = (uint16_t)px;
     } else {
-#pragma unroll
-        for (int c = 0; c < C; ++c) o[c] = (uint8_t)(px >> (8 * c));
+        o[0] = (uint8_t)px;
     }
 }
 
@@ -563,6 +566,7 @@ ImgU8 make_img_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int 
     do {                                                                                                \
         const dim3 blk(kBx, kBy);                                                                       \
         if ((channels) == 1) hipLaunchKernelGGL((KERNEL<1>), grid, blk, 0, stream, __VA_ARGS__);        \
+        else if ((channels) == 2) hipLaunchKernelGGL((KERNEL<2>), grid, blk, 0, stream, __VA_ARGS__);   \
         else if ((channels) == 3) hipLaunchKernelGGL((KERNEL<3>), grid, blk, 0, stream, __VA_ARGS__);   \
         else hipLaunchKernelGGL((KERNEL<4>), grid, blk, 0, stream, __VA_ARGS__);                        \
     } while (0)
@@ -634,7 +638,7 @@ int32_t kh_box_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
 int32_t kh_remap_u8(kh_stream_t stream, const uint8_t* src, const float* map_x, const float* map_y, uint8_t* dst,
                     int32_t sw, int32_t sh, int32_t dw, int32_t dh, int32_t channels, int32_t mode, int32_t batch,
                     int64_t src_stride, int64_t dst_stride) {
-    if (int32_t rc = check_u8_img("kh_remap_u8", src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride)) return rc;
+    if (int32_t rc = check_u8_img("kh_remap_u8", src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, true)) return rc;
     // P/interpolation/remap.rs:171-178: only nearest and bilinear exist for u8
     KH_REQUIRE(mode == KH_INTERP_NEAREST || mode == KH_INTERP_BILINEAR, KH_ERR_UNSUPPORTED,
                "kh_remap_u8: interpolation mode %d is not supported for u8 (nearest, bilinear)", mode);
@@ -647,6 +651,8 @@ int32_t kh_remap_u8(kh_stream_t stream, const uint8_t* src, const float* map_x, 
     switch (channels * 10 + mode) {
         case 10: hipLaunchKernelGGL((remap_u8_kernel<1, 0>), grid, blk, 0, st, im, map_x, map_y, batch); break;
         case 11: hipLaunchKernelGGL((remap_u8_kernel<1, 1>), grid, blk, 0, st, im, map_x, map_y, batch); break;
+        case 20: hipLaunchKernelGGL((remap_u8_kernel<2, 0>), grid, blk, 0, st, im, map_x, map_y, batch); break;
+        case 21: hipLaunchKernelGGL((remap_u8_kernel<2, 1>), grid, blk, 0, st, im, map_x, map_y, batch); break;
         case 30: hipLaunchKernelGGL((remap_u8_kernel<3, 0>), grid, blk, 0, st, im, map_x, map_y, batch); break;
         case 31: hipLaunchKernelGGL((remap_u8_kernel<3, 1>), grid, blk, 0, st, im, map_x, map_y, batch); break;
         case 40: hipLaunchKernelGGL((remap_u8_kernel<4, 0>), grid, blk, 0, st, im, map_x, map_y, batch); break;
@@ -658,7 +664,7 @@ int32_t kh_remap_u8(kh_stream_t stream, const uint8_t* src, const float* map_x, 
 int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t dw,
                           int32_t dh, int32_t channels, const float* m, int32_t batch, int64_t src_stride,
                           int64_t dst_stride) {
-    if (int32_t rc = check_u8_img("kh_warp_affine_u8", src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride))
+    if (int32_t rc = check_u8_img("kh_warp_affine_u8", src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, true))
         return rc;
     KH_REQUIRE(m, KH_ERR_INVALID_ARG, "kh_warp_affine_u8: null matrix");
     if (batch == 0) return KH_OK;
@@ -679,7 +685,7 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
 int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh,
                                int32_t dw, int32_t dh, int32_t channels, const float* m, int32_t batch,
                                int64_t src_stride, int64_t dst_stride) {
-    if (int32_t rc = check_u8_img("kh_warp_perspective_u8", src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride))
+    if (int32_t rc = check_u8_img("kh_warp_perspective_u8", src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, true))
         return rc;
     KH_REQUIRE(m, KH_ERR_INVALID_ARG, "kh_warp_perspective_u8: null matrix");
     Mat9 inv;

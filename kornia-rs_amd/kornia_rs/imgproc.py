@@ -257,7 +257,8 @@ def _interp(name: str) -> int:
 
 def _geom_pair(src: Image, dst: Optional[Image], new_size: Optional[Tuple[int, int]], what: str,
                dtype: str = "float32") -> Tuple[Image, Stream]:
-    _require(src, dtype, (1, 3, 4), what)
+    # the Q10 u8 gathers exist for 2-channel images as well (P/warp/cuda.rs:458-494)
+    _require(src, dtype, (1, 2, 3, 4) if dtype == "uint8" else (1, 3, 4), what)
     if dst is None:
         h, w = new_size  # the Python API takes (height, width)
         dst = _new_like(src, size=(w, h))

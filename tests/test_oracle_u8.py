@@ -126,3 +126,19 @@ def test_warp_affine_u8_tracks_the_f32_warp():
     ref = O.warp_affine(smooth.astype(np.float32), m, 129, 97, "bilinear")
     inner = (slice(2, -2), slice(2, -2))
     assert np.abs(got[inner] - ref[inner]).max() <= 3.0
+
+
+def test_two_channel_gathers_are_per_channel_independent():
+    """C = 2 (P/warp/cuda.rs:458-494): the Q10 sampler treats channels independently, so a 2-channel warp equals
+    the two 1-channel warps interleaved — pins the restatement's channel indexing for the odd channel count."""
+    src = O.pattern_u8(37 * 29 * 2).reshape(29, 37, 2)
+    m = np.array([0.9, 0.1, 2.0, -0.05, 1.05, -1.0], np.float32)
+    hm = np.array([1.02, 0.04, -1.5, -0.03, 0.97, 2.0, 2e-4, -1e-4, 1.0], np.float32)
+    ys, xs = np.mgrid[0:23, 0:31].astype(np.float32)
+    mx, my = (xs * 1.17 - 0.4).astype(np.float32), (ys * 1.21 + 0.3).astype(np.float32)
+    for got, one in [(O.warp_affine_u8(src, m, 31, 23), lambda c: O.warp_affine_u8(src[:, :, c:c + 1].copy(), m, 31, 23)),
+                     (O.warp_perspective_u8(src, hm, 31, 23), lambda c: O.warp_perspective_u8(src[:, :, c:c + 1].copy(), hm, 31, 23)),
+                     (O.remap_u8(src, mx, my), lambda c: O.remap_u8(src[:, :, c:c + 1].copy(), mx, my))]:
+        assert got.shape == (23, 31, 2) and got.any()
+        for c in range(2):
+            assert np.array_equal(got[:, :, c], one(c)[:, :, 0])

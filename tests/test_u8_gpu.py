@@ -113,7 +113,7 @@ AFFINES = {"flip": [-1.0, 0.0, 128.0, 0.0, 1.0, 0.0], "half": [1.0, 0.0, 0.5, 0.
            "degenerate_x": [0.0, 1.0, 3.0, 1.0, 1e-13, 0.0], "zoom": [3.7, 0.0, -100.0, 0.0, 3.7, -80.0]}
 
 
-@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
 @pytest.mark.parametrize("name", list(AFFINES) + ["rot37", "rot90"])
 def test_warp_affine_u8_matches_oracle(gpu_stream, c, name):  # P/warp/cuda.rs:174-222
     m = AFFINES.get(name) or {"rot37": rotation(64.0, 48.0, 37.0, 1.3), "rot90": rotation(64.0, 48.0, 90.0, 1.0)}[name]
@@ -130,7 +130,7 @@ HOMOGRAPHIES = {"proj": PROJ, "affine_h": [1.1, 0.1, -3.0, -0.05, 0.95, 2.0, 0.0
                 "horizon": [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.02, 0.0, -1.0]}  # denominator changes sign inside rows
 
 
-@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
 @pytest.mark.parametrize("name", list(HOMOGRAPHIES))
 def test_warp_perspective_u8_matches_oracle(gpu_stream, c, name):  # P/warp/cuda.rs:224-300
     m = HOMOGRAPHIES[name]
@@ -148,7 +148,7 @@ def test_warp_u8_known_answers_batch_and_errors(gpu_stream):
     assert warp_u8_gpu(gpu_stream, "affine", src, flip[:6], 4, 2)[0].reshape(-1).tolist() == [40, 30, 20, 10, 80, 70, 60, 50]
     rc = warp_u8_gpu(gpu_stream, "perspective", src, [1, 2, 3, 2, 4, 6, 3, 6, 9], 4, 2)
     assert rc == _ffi.KH_ERR_SINGULAR
-    assert warp_u8_gpu(gpu_stream, "affine", pat(8, 8, 2), flip[:6], 8, 8) == _ffi.KH_ERR_UNSUPPORTED
+    assert warp_u8_gpu(gpu_stream, "affine", pat(8, 8, 5), flip[:6], 8, 8) == _ffi.KH_ERR_UNSUPPORTED
     n = 5
     batch = np.stack([pat(640, 360, 3, seed=31 * k) for k in range(n)])
     m = rotation(320.0, 180.0, 12.0, 0.9)
@@ -159,7 +159,7 @@ def test_warp_u8_known_answers_batch_and_errors(gpu_stream):
         assert_same_bits(gotp[k], O.warp_perspective_u8(batch[k], PROJ, 640, 360), f"perspective frame {k}")
 
 
-@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
 @pytest.mark.parametrize("mode", ["nearest", "bilinear"])
 def test_remap_u8_matches_oracle(gpu_stream, c, mode):  # P/interpolation/remap.rs:833-870
     from kornia_rs import _ffi

@@ -73,3 +73,24 @@ def test_convert_color_reference_cases(gpu_stream):  # P/color/convert.rs:280-56
     assert blended.tolist() == [178, 50, 50, 0, 255, 0]  # convert.rs:498-520: 50% red over (100, 100, 100)
     again = cs.convert(up(cs.Rgb8(np.array([[[1, 2, 3]]], np.uint8))), cs.Rgba8)
     assert again.numpy().reshape(-1).tolist() == [1, 2, 3, 255]
+
+
+def test_u8_gathers_two_channels(gpu_stream):  # warp_u8_c2_device_matches_cpu, P/warp/cuda.rs:458-494
+    from kornia_rs import Image, imgproc
+    src = O.pattern_u8(37 * 29 * 2).reshape(29, 37, 2)
+    dev = Image.from_numpy(src).to_hip(gpu_stream)
+    m = [0.9, 0.1, 2.0, -0.05, 1.05, -1.0]
+    got = imgproc.warp_affine(dev, m, (23, 31), "bilinear")
+    assert got.shape == (23, 31, 2) and np.array_equal(got.numpy(), O.warp_affine_u8(src, np.array(m, np.float32), 31, 23))
+    hm = [1.02, 0.04, -1.5, -0.03, 0.97, 2.0, 2e-4, -1e-4, 1.0]
+    got = imgproc.warp_perspective(dev, hm, (23, 31), "bilinear")
+    assert np.array_equal(got.numpy(), O.warp_perspective_u8(src, np.array(hm, np.float32), 31, 23))
+    ys, xs = np.mgrid[0:23, 0:31].astype(np.float32)
+    mx, my = (xs * 1.17 - 0.4).astype(np.float32), (ys * 1.21 + 0.3).astype(np.float32)
+    dmx, dmy = Image.from_numpy(mx).to_hip(gpu_stream), Image.from_numpy(my).to_hip(gpu_stream)
+    for mode in ("bilinear", "nearest"):
+        assert np.array_equal(imgproc.remap(dev, dmx, dmy, mode).numpy(), O.remap_u8(src, mx, my, mode)), mode
+    # wide rows too: full-wave store path, odd width tail
+    wide = O.pattern_u8(131 * 17 * 2).reshape(17, 131, 2)
+    got = imgproc.warp_affine(Image.from_numpy(wide).to_hip(gpu_stream), [1.0, 0.02, 0.5, -0.01, 1.0, 0.25], (17, 131))
+    assert np.array_equal(got.numpy(), O.warp_affine_u8(wide, np.array([1.0, 0.02, 0.5, -0.01, 1.0, 0.25], np.float32), 131, 17))
