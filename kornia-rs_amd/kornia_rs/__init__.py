@@ -15,6 +15,8 @@ from . import imgproc
 from . import fusion
 from . import color_spaces
 from . import calibration
+from . import colormap
+from .colormap import ColormapType
 from .color_spaces import ColorSpace
 from . import sharding
 
@@ -23,5 +25,5 @@ cuda = hip  # reference module name (kornia_rs.cuda.Stream); same objects, HIP u
 __version__ = "0.1.0"
 __all__ = [
     "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Image", "ImageError", "Preprocessor",
-    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "fusion", "color_spaces", "ColorSpace", "calibration", "hip", "cuda", "sharding",
+    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "fusion", "color_spaces", "ColorSpace", "calibration", "colormap", "ColormapType", "hip", "cuda", "sharding",
 ]

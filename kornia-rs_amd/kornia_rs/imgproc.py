@@ -26,6 +26,7 @@ from . import _ffi
 from ._ffi import lib
 from .hip import DeviceBuffer, Stream
 from .image import Image, ImageError
+from . import colormap as _colormap
 from .tensor import Tensor
 
 _INTERP = {"nearest": 0, "bilinear": 1, "bicubic": 2, "lanczos": 3}
@@ -168,9 +169,11 @@ def sepia_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
     return _map("sepia_from_rgb", src, dst, 3, 3, ("uint8", "float32"))
 
 
-def apply_colormap(src: Image, lut: np.ndarray, dst: Optional[Image] = None) -> Image:
-    """``lut``: uint8 array of shape (3, 256) = r[256], g[256], b[256] (the reference's
-    ``ColormapLut``, P/color/colormap.rs).  Named OpenCV tables are not bundled."""
+def apply_colormap(src: Image, lut, dst: Optional[Image] = None) -> Image:
+    """``lut``: a colour-map name / ``colormap.ColormapType`` (P/color/colormap.rs:49-100) or a uint8 array of shape
+    (3, 256) = r[256], g[256], b[256] (the reference's ``ColormapLut``)."""
+    if isinstance(lut, (str, _colormap.ColormapType)):
+        lut = _colormap.lut(lut)
     lut = np.ascontiguousarray(lut, np.uint8).reshape(-1)
     if lut.size != 768:
         raise ImageError("InvalidArgument", "colormap LUT must hold 3 x 256 bytes")

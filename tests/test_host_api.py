@@ -237,3 +237,27 @@ def test_convert_color_table_covers_the_reference_impls_and_rejects_the_rest():
     with pytest.raises(ImageError) as e:  # camera buffers decode to RGB8 only
         cs.convert(cs.Nv12(4, 2, np.zeros(12, np.uint8)), CS.GRAY)
     assert e.value.kind == "NoDeviceKernel"
+
+
+# ---- named colour maps (P/color/colormap.rs) -----------------------------------------------------------
+
+def test_named_colormaps_match_the_reference_digests():
+    """The bundled tables are rebuilt from public definitions (scripts/gen_colormaps.py); their SHA-256 must equal the
+    digests of the reference's tables (tests/golden/colormaps/reference_sha256.json, taken from colormap_luts.rs)."""
+    import hashlib
+    import json
+    from pathlib import Path
+    from kornia_rs import ColormapType, ImageError, colormap
+    digests = json.loads((Path(__file__).parent / "golden" / "colormaps" / "reference_sha256.json").read_text())
+    assert sorted(digests) == sorted(k.value for k in ColormapType) and len(digests) == 21  # colormap.rs:49-73
+    assert len(colormap.bundled()) == 10
+    for name in colormap.bundled():
+        table = colormap.lut(name)
+        assert table.shape == (3, 256) and table.dtype == np.uint8
+        assert hashlib.sha256(table.tobytes()).hexdigest() == digests[name], name
+    assert ColormapType.from_name("ViRiDiS") is ColormapType.VIRIDIS and ColormapType.from_name("nope") is None  # :78-84
+    assert np.array_equal(colormap.lut(ColormapType.AUTUMN)[:, [0, 255]], [[255, 255], [0, 255], [0, 0]])
+    for name, kind in (("jet", "not bundled"), ("nope", "unknown")):
+        with pytest.raises(ImageError) as e:
+            colormap.lut(name)
+        assert kind in str(e.value)

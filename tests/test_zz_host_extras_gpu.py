@@ -94,3 +94,15 @@ def test_u8_gathers_two_channels(gpu_stream):  # warp_u8_c2_device_matches_cpu, 
     wide = O.pattern_u8(131 * 17 * 2).reshape(17, 131, 2)
     got = imgproc.warp_affine(Image.from_numpy(wide).to_hip(gpu_stream), [1.0, 0.02, 0.5, -0.01, 1.0, 0.25], (17, 131))
     assert np.array_equal(got.numpy(), O.warp_affine_u8(wide, np.array([1.0, 0.02, 0.5, -0.01, 1.0, 0.25], np.float32), 131, 17))
+
+
+def test_apply_colormap_by_name(gpu_stream):  # P/color/colormap.rs:252-300
+    from kornia_rs import ColormapType, Image, colormap, imgproc
+    gray = O.pattern_u8(131 * 17).reshape(17, 131, 1)
+    dev = Image.from_numpy(gray).to_hip(gpu_stream)
+    for name in ("viridis", ColormapType.TURBO, "Winter"):
+        table = colormap.lut(name)
+        got = imgproc.apply_colormap(dev, name).numpy()
+        assert got.shape == (17, 131, 3) and np.array_equal(got, table.T[gray[:, :, 0]])
+    ramp = Image.from_numpy(np.arange(256, dtype=np.uint8).reshape(1, 256, 1)).to_hip(gpu_stream)
+    assert np.array_equal(imgproc.apply_colormap(ramp, "autumn").numpy()[0], colormap.lut("autumn").T)
