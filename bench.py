@@ -486,6 +486,185 @@ class FusedRgb640(U8Images):
                               "the fused pipeline")
 
 
+class ResizeU8_224(U8Images):
+    """resize_fast_u8_aa Lanczos-3 (antialiased Q14 separable cascade) 1920x1080 RGB8 -> 224x224, batch 256."""
+
+    name, kernel = "resize_fast_u8_lanczos_1080p_to_224_b256", "sep_h_u8_kernel<3> + sep_v_u8_kernel"
+    W, H, C, D = 1920, 1080, 3, 224
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * (self.W * self.H * self.C + self.D * self.D * self.C)  # source once + dst
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.D * self.D * self.C, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs import _ffi
+        _ffi.check(_ffi.lib.kh_resize_fast_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.D, self.D,
+                                              self.C, _ffi.KH_INTERP_LANCZOS, 1, self.N, self.W * self.H * self.C,
+                                              self.D * self.D * self.C))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::resize::resize_fast_u8_aa(Lanczos, antialias) — two passes, i16 scratch",
+                "src": "1920x1080x3 u8", "dst": "224x224x3 u8", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        return self._time_cpu(lambda O: O.resize_fast_u8(img, self.D, self.D, "lanczos", True), "resize_fast_u8_aa")
+
+
+class ResizeNormChw224(U8Images):
+    """resize_normalize_to_tensor_u8_to_f32 (bilinear) 1920x1080 RGB8 -> [3,224,224] f32, batch 256 — the reference's
+    CPU timing twin of the camera preprocess (P/resize/fused.rs:57)."""
+
+    name, kernel = "resize_normalize_chw_1080p_to_224_b256", "fused_rgb_chw_kernel<bilinear>"
+    W, H, C, D = 1920, 1080, 3, 224
+    dtype = "f32"
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        # 4 source taps x 3 B per destination pixel + 12 B written (the source is sub-sampled 8.6x / 4.8x: most of it is never read)
+        self.alg_bytes_per_launch = self.N * self.D * self.D * (4 * 3 + 12)
+
+    def setup(self, stream):
+        import ctypes as C
+        from kornia_rs.hip import DeviceBuffer
+        from kornia_rs.hip import IMAGENET_MEAN, IMAGENET_STD
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * 3 * self.D * self.D * 4, stream, zeroed=False)
+        f = np.float32
+        self.scale_np = (f(1.0) / (np.asarray(IMAGENET_STD, f) * f(255.0))).astype(f)
+        self.bias_np = (-np.asarray(IMAGENET_MEAN, f) / np.asarray(IMAGENET_STD, f)).astype(f)
+        self.scale, self.bias = (C.c_float * 3)(*self.scale_np), (C.c_float * 3)(*self.bias_np)
+
+    def step(self):
+        from kornia_rs import _ffi
+        _ffi.check(_ffi.lib.kh_resize_normalize_to_chw_u8_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H,
+                                                              self.D, self.D, self.scale, self.bias, _ffi.KH_INTERP_BILINEAR, 1,
+                                                              self.N, self.W * self.H * 3, 3 * self.D * self.D))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::resize::resize_normalize_to_tensor_u8_to_f32 (bilinear, ImageNet mean/std)",
+                "src": "1920x1080x3 u8", "dst": "3x224x224 f32", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        return self._time_cpu(lambda O: O.resize_normalize_to_chw(img, self.D, self.D, self.scale_np, self.bias_np, "bilinear", True),
+                              "resize_normalize_to_tensor_u8_to_f32")
+
+
+class PyrDownU8_4K(U8Images):
+    """pyrdown_u8 (5x5 Gaussian + 2x decimation, one launch) on 3840x2160 RGB8, batch 256."""
+
+    name, kernel = "pyrdown_u8_4k_b256", "pyrdown_u8_kernel<3>"
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * (self.W * self.H * self.C + (self.W // 2) * (self.H // 2) * self.C)
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * (self.W // 2) * (self.H // 2) * self.C, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        check(lib.kh_pyrdown_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.C, self.N,
+                                self.W * self.H * self.C, (self.W // 2) * (self.H // 2) * self.C))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::pyramid::pyrdown_u8 (fused 5x5 Gaussian, reflect-101, 2x decimation)",
+                "src": "3840x2160x3 u8", "dst": "1920x1080x3 u8", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        return self._time_cpu(lambda O: O.pyrdown(img), "pyrdown_u8")
+
+
+class DilateU8_4K(U8Images):
+    """u8 dilate, 5x5 box structuring element, constant border, on 3840x2160 RGB8, batch 256."""
+
+    name, kernel = "dilate_u8_box5_4k_b256", "morphology_u8_kernel<3>"
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C
+
+    def setup(self, stream):
+        import ctypes as C
+        from kornia_rs.hip import DeviceBuffer
+        from kornia_rs import _ffi
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.W * self.H * self.C, stream, zeroed=False)
+        self.mask = (C.c_uint8 * 25)()
+        _ffi.check(_ffi.lib.kh_morph_kernel(_ffi.KH_MORPH_SHAPE["box"], 5, 5, self.mask))
+        self.cval = (C.c_uint8 * 4)(0, 0, 0, 0)
+
+    def step(self):
+        from kornia_rs import _ffi
+        n = self.W * self.H * self.C
+        _ffi.check(_ffi.lib.kh_morphology_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.C,
+                                             _ffi.KH_MORPH_DILATE, self.mask, 5, 5, _ffi.KH_BORDER["constant"], self.cval, self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::morphology::dilate (5x5 box, constant border)", "src": "3840x2160x3 u8",
+                "dst": "same", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        return self._time_cpu(lambda O: O.morphology_u8(img, "dilate", O.morph_kernel("box", 5)), "dilate")
+
+
+class LabFromRgb4K(U8Images):
+    """lab_from_rgb f32 on 3840x2160x3, batch 64 (6.4 GB in + 6.4 GB out)."""
+
+    name, kernel = "lab_from_rgb_f32_4k_b64", "map_kernel<CieF32>"
+    dtype = "f32"
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * 12
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        from kornia_rs._ffi import lib, check
+        self.stream = stream
+        n = self.W * self.H * 3
+        x = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761)) >> np.uint32(8)  # values in [0, 1)
+        self.host = (x.astype(np.float32) / np.float32(1 << 24)).astype(np.float32)
+        one = DeviceBuffer.from_numpy(self.host, stream)
+        self.src = DeviceBuffer(self.N * n * 4, stream, zeroed=False)
+        for k in range(self.N):
+            check(lib.kh_memcpy_d2d_async(self.src.ptr + k * n * 4, one.ptr, n * 4, stream.cuda_stream_ptr))
+        stream.synchronize()
+        self.dst = DeviceBuffer(self.N * n * 4, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs import _ffi
+        _ffi.check(_ffi.lib.kh_cie_convert_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.N * self.W * self.H,
+                                               _ffi.KH_CIE["lab_from_rgb"]))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::color::lab_from_rgb (f32)", "src": "3840x2160x3 f32", "dst": "same",
+                "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        img = self.host.reshape(self.H, self.W, 3)
+        return self._time_cpu(lambda O: O.cie("lab_from_rgb", img), "lab_from_rgb")
+
+
 WORKLOADS = {
     "nv12_chw": lambda a: NorthStarNV12(a.batch or 1024, 0),
     "nv12_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640),
@@ -495,6 +674,11 @@ WORKLOADS = {
     "gaussian_u8_4k": lambda a: GaussianU8_4K(a.batch or 256),
     "warp_affine_u8_4k": lambda a: WarpAffineU8_4K(a.batch or 256),
     "fused_rgb_640": lambda a: FusedRgb640(a.batch or 1024),
+    "resize_u8_224": lambda a: ResizeU8_224(a.batch or 256),
+    "resize_norm_chw_224": lambda a: ResizeNormChw224(a.batch or 256),
+    "pyrdown_u8_4k": lambda a: PyrDownU8_4K(a.batch or 256),
+    "dilate_u8_4k": lambda a: DilateU8_4K(a.batch or 256),
+    "lab_from_rgb_4k": lambda a: LabFromRgb4K(a.batch or 64),
 }
 
 
