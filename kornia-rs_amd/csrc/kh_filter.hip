@@ -264,8 +264,9 @@ void pad_taps(TapsK& out, const Taps& in, int K) {
 }
 
 int32_t set_taps(Taps& t, const float* k, int n, const char* what) {
-    KH_REQUIRE(k && n >= 1 && n <= kMaxTaps, KH_ERR_UNSUPPORTED, "%s: kernel length %d outside [1, %d]", what, n,
-               kMaxTaps);
+    // an empty kernel is the reference's InvalidKernelLength (P/filter/separable_filter.rs:175-180)
+    KH_REQUIRE(k && n >= 1, KH_ERR_INVALID_ARG, "%s: invalid kernel length %d (null or empty kernel)", what, k ? n : 0);
+    KH_REQUIRE(n <= kMaxTaps, KH_ERR_UNSUPPORTED, "%s: kernel length %d exceeds %d taps", what, n, kMaxTaps);
     for (int i = 0; i < 64; ++i) t.k[i] = i < n ? k[i] : 0.0f;
     t.n = n;
     return KH_OK;
@@ -421,8 +422,9 @@ int32_t kh_gaussian_blur_f32(kh_stream_t stream, const float* src, float* dst, i
 
 int32_t kh_box_blur_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows, int32_t channels,
                         int32_t ksize_x, int32_t ksize_y, int32_t batch, int64_t src_stride, int64_t dst_stride) {
-    KH_REQUIRE(ksize_x >= 1 && ksize_y >= 1 && ksize_x <= kMaxTaps && ksize_y <= kMaxTaps, KH_ERR_UNSUPPORTED,
-               "kh_box_blur_f32: kernel (%d, %d) outside [1, %d]", ksize_x, ksize_y, kMaxTaps);
+    KH_REQUIRE(ksize_x >= 1 && ksize_y >= 1, KH_ERR_INVALID_ARG, "kh_box_blur_f32: invalid kernel length (%d, %d)", ksize_x, ksize_y);
+    KH_REQUIRE(ksize_x <= kMaxTaps && ksize_y <= kMaxTaps, KH_ERR_UNSUPPORTED, "kh_box_blur_f32: kernel (%d, %d) exceeds %d taps",
+               ksize_x, ksize_y, kMaxTaps);
     float tx[64], ty[64];
     kh_box_blur_kernel_1d(ksize_x, tx);
     kh_box_blur_kernel_1d(ksize_y, ty);
