@@ -129,3 +129,23 @@ def test_tile_id_division_is_exact():
         for n in ns:
             if 0 <= n <= top:
                 assert q(n, d) == n // d, (n, d)
+
+
+def test_rust_sys_crate_is_in_step_with_the_header():
+    """integration/kornia-hip-sys/src/lib.rs is generated from include/kornia_hip.h (no rustc in this image, so it
+    is kept correct mechanically): regenerating must reproduce the committed file, and every exported symbol, status
+    code and #[repr(C)] field must be bound."""
+    import importlib.util
+    from kornia_rs import _ffi
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", ROOT / "scripts" / "gen_rust_ffi.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = (ROOT / "integration" / "kornia-hip-sys" / "src" / "lib.rs").read_text()
+    assert gen.generate() == committed, "run scripts/gen_rust_ffi.py"
+    bound = set(re.findall(r"pub fn (kh_\w+)\(", committed))
+    assert bound == set(_ffi.SIGNATURES)
+    for const in ("KH_OK", "KH_ERR_HIP", "KH_ERR_SINGULAR", "KH_FMT_NV12", "KH_INTERP_LANCZOS", "KH_FUSE_WRITE_CHW_F32"):
+        assert re.search(rf"pub const {const}: i32 = -?\d+;", committed), const
+    fields = re.search(r"pub struct kh_preprocess_params \{(.*?)\}", committed, re.S).group(1)
+    assert [f.split(":")[0].strip().replace("pub ", "") for f in fields.strip().splitlines()] == \
+        [name for name, _ in _ffi.PreprocessParams._fields_]
