@@ -121,3 +121,29 @@ def test_morphology_against_scipy(border, mode, kshape):
             wins = [pad[ky:ky + 19, kx:kx + 23] for ky in range(kh) for kx in range(kw) if mask[ky, kx]]
             ref = np.max(wins, axis=0) if op == "dilate" else np.min(wins, axis=0)
             assert np.array_equal(got, ref), (op, border, kshape)
+
+
+def test_pyramid_reference_known_answers():
+    """P/pyramid.rs:885-1290 — the reference's own vectors ("verified with opencv")."""
+    ramp = np.arange(16, dtype=np.float32).reshape(4, 4, 1)
+    assert np.abs(O.pyrdown(ramp).reshape(-1) - [3.75, 4.875, 8.25, 9.375]).max() < 1e-4            # test_pyrdown
+    ramp3 = np.arange(48, dtype=np.float32).reshape(4, 4, 3)
+    want = [11.25, 12.25, 13.25, 14.625, 15.625, 16.625, 24.75, 25.75, 26.75, 28.125, 29.125, 30.125]
+    assert np.abs(O.pyrdown(ramp3).reshape(-1) - want).max() < 1e-4                                  # test_pyrdown_3c
+    up = O.pyrup(np.array([[0.0, 1.0], [2.0, 3.0]], np.float32))                                     # test_pyrup
+    assert up.shape == (4, 4, 1) and np.isfinite(up).all()
+    odd = O.pyrdown(np.arange(35, dtype=np.float32).reshape(7, 5, 1))                                # test_pyrdown_odd_dims
+    assert odd.shape == (4, 3, 1) and np.isfinite(odd).all()
+    for img in (np.array([[42.0]], np.float32), np.array([[1.0], [2.0]], np.float32), np.array([[1.0, 2.0]], np.float32)):
+        out = O.pyrdown(img)                                                                         # test_pyrdown_min_sizes
+        assert out.shape == (1, 1, 1) and np.isfinite(out).all()
+    assert O.pyrdown(np.array([[42.0]], np.float32))[0, 0, 0] == 42.0
+    big = O.pyrdown(np.full((4, 4, 1), 1e9, np.float32))                                             # test_pyrdown_numeric_extremes
+    assert np.isfinite(big).all() and (np.abs(big) <= 1e9).all()
+    small = O.pyrdown(np.arange(16, dtype=np.uint8).reshape(4, 4, 1))                                # test_pyrdown_u8_smoke
+    assert small.shape == (2, 2, 1) and (small < 255).all()
+    assert np.array_equal(small.reshape(-1), np.floor(np.array([3.75, 4.875, 8.25, 9.375]) + 0.5).astype(np.uint8))
+    up8 = O.pyrup(np.array([[0, 10], [20, 30]], np.uint8))                                           # test_pyrup_u8_smoke
+    assert up8.shape == (4, 4, 1) and up8.min() >= 0 and up8.max() <= 30
+    for val in (0, 1, 127, 200, 255):                                                                # test_pyrdown_u8_flat
+        assert np.array_equal(O.pyrdown(np.full((16, 16, 1), val, np.uint8)), np.full((8, 8, 1), val, np.uint8))
