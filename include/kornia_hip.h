@@ -297,6 +297,18 @@ enum { KH_CIE_LINEAR_RGB_FROM_RGB = 0, KH_CIE_RGB_FROM_LINEAR_RGB = 1, KH_CIE_XY
        KH_CIE_LAB_FROM_RGB = 4, KH_CIE_RGB_FROM_LAB = 5, KH_CIE_LUV_FROM_RGB = 6, KH_CIE_RGB_FROM_LUV = 7 };
 KH_API int32_t kh_cie_convert_f32(kh_stream_t stream, const float* src, float* dst, int64_t npixels, int32_t conversion);
 
+/* f64 colour conversions — replace the 18 f64 launchers of P/color/cuda_dispatch.rs:48-61,111-135
+ * (gray::launch_{gray_from_rgb,rgb_from_gray}_f64, hsv_hls::launch_*_f64, cie::launch_*_f64,
+ * yuv::launch_{ycc_from_rgb,rgb_from_ycc}_f64) == the f64 arms of gray_from_rgb (P/color/gray/mod.rs:41),
+ * hsv/hls (P/color/hsv/mod.rs:64-113, P/color/hls/mod.rs:64-130; [0,255] domain), YCbCr / YUV
+ * (P/color/yuv/mod.rs:95-145) and the CIE `*_scalar64` formulas (P/color/cie/kernels.rs:64-215), CPU
+ * arithmetic operation for operation.  Interleaved f64 pixels, 3 -> 3 channels except GRAY_FROM_RGB
+ * (3 -> 1) and RGB_FROM_GRAY (1 -> 3); codes 0..7 equal KH_CIE_*.                                  */
+enum { KH_F64_GRAY_FROM_RGB = 8, KH_F64_RGB_FROM_GRAY = 9, KH_F64_HSV_FROM_RGB = 10, KH_F64_RGB_FROM_HSV = 11,
+       KH_F64_HLS_FROM_RGB = 12, KH_F64_RGB_FROM_HLS = 13, KH_F64_YCBCR_FROM_RGB = 14, KH_F64_RGB_FROM_YCBCR = 15,
+       KH_F64_YUV_FROM_RGB = 16, KH_F64_RGB_FROM_YUV = 17 };
+KH_API int32_t kh_color_convert_f64(kh_stream_t stream, const double* src, double* dst, int64_t npixels, int32_t conversion);
+
 /* ------------------------------------------------------------------------------------------ */
 /* u8 fixed-point twins.  Byte-identical to the reference CPU ops they replace the
  * device launchers of; HWC u8, channels in {1, 3, 4}, `batch` images `*_stride` BYTES apart.

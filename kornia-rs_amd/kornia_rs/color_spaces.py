@@ -57,6 +57,11 @@ Rgbf32, Bgrf32, Grayf32 = _typed("Rgbf32", "float32", ColorSpace.RGB), _typed("B
 Hsvf32, Hlsf32, Labf32 = _typed("Hsvf32", "float32", ColorSpace.HSV), _typed("Hlsf32", "float32", ColorSpace.HLS), _typed("Labf32", "float32", ColorSpace.LAB)
 Luvf32, Xyzf32, LinearRgbf32 = _typed("Luvf32", "float32", ColorSpace.LUV), _typed("Xyzf32", "float32", ColorSpace.XYZ), _typed("LinearRgbf32", "float32", ColorSpace.LINEAR_RGB)
 YCbCrf32, Yuvf32 = _typed("YCbCrf32", "float32", ColorSpace.YCBCR), _typed("Yuvf32", "float32", ColorSpace.YUV)
+# f64 newtypes (color_spaces.rs:269-620; device conversions: P/color/convert.rs:110-218 f64 impls)
+Rgbf64, Grayf64 = _typed("Rgbf64", "float64", ColorSpace.RGB), _typed("Grayf64", "float64", ColorSpace.GRAY)
+Hsvf64, Hlsf64, Labf64 = _typed("Hsvf64", "float64", ColorSpace.HSV), _typed("Hlsf64", "float64", ColorSpace.HLS), _typed("Labf64", "float64", ColorSpace.LAB)
+Luvf64, Xyzf64, LinearRgbf64 = _typed("Luvf64", "float64", ColorSpace.LUV), _typed("Xyzf64", "float64", ColorSpace.XYZ), _typed("LinearRgbf64", "float64", ColorSpace.LINEAR_RGB)
+YCbCrf64, Yuvf64 = _typed("YCbCrf64", "float64", ColorSpace.YCBCR), _typed("Yuvf64", "float64", ColorSpace.YUV)
 
 
 class _VideoBuffer:
@@ -133,18 +138,19 @@ class Yvyu8(_Packed422): layout = "yvyu"
 # ---- ConvertColor (P/color/convert.rs:101-273) -------------------------------------------------------------
 # (source space, destination space) -> (imgproc function, dtypes the reference implements for a device pair)
 _U8, _F32, _BOTH = ("uint8",), ("float32",), ("uint8", "float32")
+_FLT, _ALL = ("float32", "float64"), ("uint8", "float32", "float64")
 _CONVERSIONS = {
-    (ColorSpace.RGB, ColorSpace.GRAY): ("gray_from_rgb", _BOTH), (ColorSpace.GRAY, ColorSpace.RGB): ("rgb_from_gray", _BOTH),
+    (ColorSpace.RGB, ColorSpace.GRAY): ("gray_from_rgb", _ALL), (ColorSpace.GRAY, ColorSpace.RGB): ("rgb_from_gray", _ALL),
     (ColorSpace.RGB, ColorSpace.BGR): ("bgr_from_rgb", _BOTH), (ColorSpace.BGR, ColorSpace.RGB): ("bgr_from_rgb", _BOTH),
-    (ColorSpace.RGB, ColorSpace.HSV): ("hsv_from_rgb", _F32), (ColorSpace.HSV, ColorSpace.RGB): ("rgb_from_hsv", _F32),
-    (ColorSpace.RGB, ColorSpace.HLS): ("hls_from_rgb", _F32), (ColorSpace.HLS, ColorSpace.RGB): ("rgb_from_hls", _F32),
-    (ColorSpace.RGB, ColorSpace.LINEAR_RGB): ("linear_rgb_from_rgb", _F32),
-    (ColorSpace.LINEAR_RGB, ColorSpace.RGB): ("rgb_from_linear_rgb", _F32),
-    (ColorSpace.RGB, ColorSpace.XYZ): ("xyz_from_rgb", _F32), (ColorSpace.XYZ, ColorSpace.RGB): ("rgb_from_xyz", _F32),
-    (ColorSpace.RGB, ColorSpace.LAB): ("lab_from_rgb", _F32), (ColorSpace.LAB, ColorSpace.RGB): ("rgb_from_lab", _F32),
-    (ColorSpace.RGB, ColorSpace.LUV): ("luv_from_rgb", _F32), (ColorSpace.LUV, ColorSpace.RGB): ("rgb_from_luv", _F32),
-    (ColorSpace.RGB, ColorSpace.YCBCR): ("ycbcr_from_rgb", _BOTH), (ColorSpace.YCBCR, ColorSpace.RGB): ("rgb_from_ycbcr", _BOTH),
-    (ColorSpace.RGB, ColorSpace.YUV): ("yuv_from_rgb", _BOTH), (ColorSpace.YUV, ColorSpace.RGB): ("rgb_from_yuv", _BOTH),
+    (ColorSpace.RGB, ColorSpace.HSV): ("hsv_from_rgb", _FLT), (ColorSpace.HSV, ColorSpace.RGB): ("rgb_from_hsv", _FLT),
+    (ColorSpace.RGB, ColorSpace.HLS): ("hls_from_rgb", _FLT), (ColorSpace.HLS, ColorSpace.RGB): ("rgb_from_hls", _FLT),
+    (ColorSpace.RGB, ColorSpace.LINEAR_RGB): ("linear_rgb_from_rgb", _FLT),
+    (ColorSpace.LINEAR_RGB, ColorSpace.RGB): ("rgb_from_linear_rgb", _FLT),
+    (ColorSpace.RGB, ColorSpace.XYZ): ("xyz_from_rgb", _FLT), (ColorSpace.XYZ, ColorSpace.RGB): ("rgb_from_xyz", _FLT),
+    (ColorSpace.RGB, ColorSpace.LAB): ("lab_from_rgb", _FLT), (ColorSpace.LAB, ColorSpace.RGB): ("rgb_from_lab", _FLT),
+    (ColorSpace.RGB, ColorSpace.LUV): ("luv_from_rgb", _FLT), (ColorSpace.LUV, ColorSpace.RGB): ("rgb_from_luv", _FLT),
+    (ColorSpace.RGB, ColorSpace.YCBCR): ("ycbcr_from_rgb", _ALL), (ColorSpace.YCBCR, ColorSpace.RGB): ("rgb_from_ycbcr", _ALL),
+    (ColorSpace.RGB, ColorSpace.YUV): ("yuv_from_rgb", _ALL), (ColorSpace.YUV, ColorSpace.RGB): ("rgb_from_yuv", _ALL),
     (ColorSpace.RGBA, ColorSpace.RGB): ("rgb_from_rgba", _U8), (ColorSpace.BGRA, ColorSpace.RGB): ("rgb_from_bgra", _U8),
     (ColorSpace.RGB, ColorSpace.RGBA): ("rgba_from_rgb", _BOTH), (ColorSpace.RGB, ColorSpace.BGRA): ("bgra_from_rgb", _BOTH),
 }

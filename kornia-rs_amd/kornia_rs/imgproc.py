@@ -83,7 +83,22 @@ def _new_like(src: Image, channels: Optional[int] = None, dtype: Optional[str] =
 
 # ---- colour maps --------------------------------------------------------------------------------
 
-def _map(name: str, src: Image, dst: Optional[Image], cin: int, cout: int, dtypes: Sequence[str], *extra) -> Image:
+def _map_f64(code_name: str, src: Image, dst: Optional[Image], cin: int, cout: int) -> Image:
+    """float64 images: the f64 launchers of P/color/cuda_dispatch.rs:48-61,111-135 == kh_color_convert_f64."""
+    _require(src, "float64", (cin,), code_name)
+    out = dst if dst is not None else _new_like(src, channels=cout)
+    _require(out, "float64", (cout,), code_name)
+    _same_size(src, out)
+    stream = _pair_residency(src, out)
+    _check(lib.kh_color_convert_f64(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height,
+                                    _ffi.KH_F64[code_name]))
+    return out
+
+
+def _map(name: str, src: Image, dst: Optional[Image], cin: int, cout: int, dtypes: Sequence[str], *extra,
+         f64: Optional[str] = None) -> Image:
+    if f64 is not None and src.dtype == "float64":
+        return _map_f64(f64, src, dst, cin, cout)
     if src.dtype not in dtypes:
         raise ImageError("NoDeviceKernel", f"{name}: no device kernel for dtype {src.dtype} (supported: {tuple(dtypes)})")
     _require(src, src.dtype, (cin,), name)
@@ -98,11 +113,11 @@ def _map(name: str, src: Image, dst: Optional[Image], cin: int, cout: int, dtype
 
 
 def gray_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
-    return _map("gray_from_rgb", src, dst, 3, 1, ("uint8", "float32"))
+    return _map("gray_from_rgb", src, dst, 3, 1, ("uint8", "float32"), f64="gray_from_rgb")
 
 
 def rgb_from_gray(src: Image, dst: Optional[Image] = None) -> Image:
-    return _map("rgb_from_gray", src, dst, 1, 3, ("uint8", "float32"))
+    return _map("rgb_from_gray", src, dst, 1, 3, ("uint8", "float32"), f64="rgb_from_gray")
 
 
 def bgr_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
@@ -134,35 +149,35 @@ def rgb_from_bgra(src: Image, dst: Optional[Image] = None, background: Optional[
 
 
 def ycbcr_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
-    return _map("ycc_from_rgb", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YCRCB)
+    return _map("ycc_from_rgb", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YCRCB, f64="ycbcr_from_rgb")
 
 
 def rgb_from_ycbcr(src: Image, dst: Optional[Image] = None) -> Image:
-    return _map("rgb_from_ycc", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YCRCB)
+    return _map("rgb_from_ycc", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YCRCB, f64="rgb_from_ycbcr")
 
 
 def yuv_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
-    return _map("ycc_from_rgb", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YUV)
+    return _map("ycc_from_rgb", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YUV, f64="yuv_from_rgb")
 
 
 def rgb_from_yuv(src: Image, dst: Optional[Image] = None) -> Image:
-    return _map("rgb_from_ycc", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YUV)
+    return _map("rgb_from_ycc", src, dst, 3, 3, ("uint8", "float32"), _ffi.KH_YCC_YUV, f64="rgb_from_yuv")
 
 
 def hsv_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
-    return _map("hsv_from_rgb", src, dst, 3, 3, ("float32",))
+    return _map("hsv_from_rgb", src, dst, 3, 3, ("float32",), f64="hsv_from_rgb")
 
 
 def rgb_from_hsv(src: Image, dst: Optional[Image] = None) -> Image:
-    return _map("rgb_from_hsv", src, dst, 3, 3, ("float32",))
+    return _map("rgb_from_hsv", src, dst, 3, 3, ("float32",), f64="rgb_from_hsv")
 
 
 def hls_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
-    return _map("hls_from_rgb", src, dst, 3, 3, ("float32",))
+    return _map("hls_from_rgb", src, dst, 3, 3, ("float32",), f64="hls_from_rgb")
 
 
 def rgb_from_hls(src: Image, dst: Optional[Image] = None) -> Image:
-    return _map("rgb_from_hls", src, dst, 3, 3, ("float32",))
+    return _map("rgb_from_hls", src, dst, 3, 3, ("float32",), f64="rgb_from_hls")
 
 
 def sepia_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
@@ -713,6 +728,8 @@ def _cie(name: str):
     code = _ffi.KH_CIE[name]
 
     def conv(src: Image, dst: Optional[Image] = None) -> Image:
+        if src.dtype == "float64":  # the `*_scalar64` formulas (P/color/cie/kernels.rs:64-215)
+            return _map_f64(name, src, dst, 3, 3)
         _require(src, "float32", (3,), name)
         out = dst if dst is not None else _new_like(src)
         _require(out, "float32", (3,), name)
@@ -722,7 +739,7 @@ def _cie(name: str):
         return out
 
     conv.__name__ = name
-    conv.__doc__ = f"``{name}`` on float32 RGB in [0, 1] (D65, OpenCV coefficients)."
+    conv.__doc__ = f"``{name}`` on float32 / float64 RGB in [0, 1] (D65, OpenCV coefficients)."
     return conv
 
 

@@ -138,6 +138,8 @@ void ko_fused_pipeline(const uint8_t* src, int sw, int sh, int rdw, int rdh, int
 /* ---- CIE colour spaces (ko_cie.c) -------------------------------------------------------------------- */
 void ko_cie_f32(const float* src, float* dst, size_t npixels, int conv);
 void ko_cie_f64(const double* src, double* dst, size_t npixels, int conv);
+/* f64 colour family (ko_color_f64.c): conv 0..7 = ko_cie_f64, 8..17 gray / hsv / hls / ycbcr / yuv; -1 on an unknown code */
+int ko_color_f64(const double* src, double* dst, size_t npixels, int conv);
 
 /* ---- pyramid + morphology (ko_pyramid_morph.c) ------------------------------------------------------- */
 void ko_pyrdown_f32(const float* src, int sw, int sh, float* dst, int C);

@@ -560,3 +560,23 @@ def cie(name, src):
     out = np.empty_like(src)
     (ko.ko_cie_f32 if src.dtype == np.float32 else ko.ko_cie_f64)(src.reshape(-1), out.reshape(-1), src.size // 3, CIE[name])
     return out
+
+
+# ---- f64 colour family (P/color/{gray,hsv,hls,yuv}/mod.rs f64 arms + the CIE scalar64 formulas) -------------------
+F64_CONV = {"linear_rgb_from_rgb": 0, "rgb_from_linear_rgb": 1, "xyz_from_rgb": 2, "rgb_from_xyz": 3, "lab_from_rgb": 4,
+            "rgb_from_lab": 5, "luv_from_rgb": 6, "rgb_from_luv": 7, "gray_from_rgb": 8, "rgb_from_gray": 9, "hsv_from_rgb": 10,
+            "rgb_from_hsv": 11, "hls_from_rgb": 12, "rgb_from_hls": 13, "ycbcr_from_rgb": 14, "rgb_from_ycbcr": 15,
+            "yuv_from_rgb": 16, "rgb_from_yuv": 17}
+ko.ko_color_f64.argtypes = [_f64p, _f64p, C.c_size_t, C.c_int]
+ko.ko_color_f64.restype = C.c_int
+
+
+def color_f64(name, src):
+    """src: float64 [..., cin] -> float64 [..., cout] through the reference's f64 arms."""
+    src = np.ascontiguousarray(src, np.float64)
+    conv = F64_CONV[name]
+    cin, cout = (1 if conv == 9 else 3), (1 if conv == 8 else 3)
+    n = src.size // cin
+    out = np.empty(n * cout, np.float64)
+    assert ko.ko_color_f64(src.reshape(-1), out, n, conv) == 0
+    return out.reshape(src.shape[:-1] + (cout,)) if src.ndim > 1 else out

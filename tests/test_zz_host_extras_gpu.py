@@ -106,3 +106,52 @@ def test_apply_colormap_by_name(gpu_stream):  # P/color/colormap.rs:252-300
         assert got.shape == (17, 131, 3) and np.array_equal(got, table.T[gray[:, :, 0]])
     ramp = Image.from_numpy(np.arange(256, dtype=np.uint8).reshape(1, 256, 1)).to_hip(gpu_stream)
     assert np.array_equal(imgproc.apply_colormap(ramp, "autumn").numpy()[0], colormap.lut("autumn").T)
+
+
+# ---- f64 colour family (P/color/cuda_dispatch.rs:48-61, 111-135) ---------------------------------------------
+
+def _f64_samples(name):
+    from test_color_f64 import samples
+    return samples(name, n=20000, seed=3)
+
+
+@pytest.mark.parametrize("name", sorted(O.F64_CONV, key=O.F64_CONV.get))
+def test_color_f64_matches_cpu_arithmetic(gpu_stream, name):
+    """The +,-,*,/ conversions (gray, hsv, hls, YCbCr, YUV, XYZ) must equal the CPU f64 path bit for bit; the ones through
+    pow / cbrt (sRGB transfer, Lab, Luv) within 1e-9 of it — the reference holds its own f64 device twins to 1e-3 / 1e-4
+    (P/cuda/color/cie.rs:554-620, hsv_hls.rs:466)."""
+    from kornia_rs import _ffi
+    from kornia_rs.hip import DeviceBuffer
+    x = _f64_samples(name)
+    want = O.color_f64(name, x)
+    d_src = DeviceBuffer.from_numpy(x.reshape(-1), gpu_stream)
+    d_dst = DeviceBuffer(want.nbytes, gpu_stream, zeroed=False)
+    _ffi.check(_ffi.lib.kh_color_convert_f64(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, x.shape[0], O.F64_CONV[name]))
+    got = d_dst.to_numpy(np.float64, want.shape)
+    libm = name in ("linear_rgb_from_rgb", "rgb_from_linear_rgb", "lab_from_rgb", "rgb_from_lab", "luv_from_rgb", "rgb_from_luv")
+    if libm:
+        ok = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), ok)
+        err = np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))
+        assert err.max() < 1e-9, f"{name}: {err.max()}"
+    else:
+        assert got.tobytes() == want.tobytes(), f"{name}: max |diff| {np.nanmax(np.abs(got - want))}"
+
+
+def test_color_f64_through_the_host_api(gpu_stream):
+    from kornia_rs import Image, ImageError, color_spaces as cs, imgproc
+    rgb = (O.pattern_u8(3 * 33 * 17).astype(np.float64) / 255.0).reshape(17, 33, 3)
+    dev = cs.Rgbf64(rgb).to_hip(gpu_stream)
+    gray = cs.convert(dev, cs.Grayf64)
+    assert gray.dtype == "float64" and gray.shape == (17, 33, 1)
+    assert np.array_equal(gray.numpy(), O.color_f64("gray_from_rgb", rgb))
+    assert np.array_equal(cs.convert(gray, cs.Rgbf64).numpy(), np.repeat(gray.numpy(), 3, axis=2))
+    hsv = imgproc.hsv_from_rgb(Image.from_numpy(rgb * 255.0).to_hip(gpu_stream))
+    assert np.array_equal(hsv.numpy(), O.color_f64("hsv_from_rgb", rgb * 255.0))
+    yuv = cs.convert(dev, cs.Yuvf64)
+    assert np.array_equal(yuv.numpy(), O.color_f64("yuv_from_rgb", rgb))
+    lab = cs.convert(dev, cs.ColorSpace.LAB)
+    assert lab.dtype == "float64" and np.abs(lab.numpy() - O.color_f64("lab_from_rgb", rgb)).max() < 1e-9
+    with pytest.raises(ImageError) as e:  # no f64 BGR swizzle in the reference either (convert.rs:124-131)
+        imgproc.bgr_from_rgb(dev)
+    assert e.value.kind == "NoDeviceKernel"
