@@ -309,6 +309,14 @@ enum { KH_F64_GRAY_FROM_RGB = 8, KH_F64_RGB_FROM_GRAY = 9, KH_F64_HSV_FROM_RGB =
        KH_F64_YUV_FROM_RGB = 16, KH_F64_RGB_FROM_YUV = 17 };
 KH_API int32_t kh_color_convert_f64(kh_stream_t stream, const double* src, double* dst, int64_t npixels, int32_t conversion);
 
+/* YUYV -> RGB8 with a selectable matrix — replaces the yuyv_to_rgb_{bt601_full,bt709_full,bt601_limited}_u8
+ * launchers (P/cuda/color/video.rs:128-190) == convert_yuyv_to_rgb_u8 (P/color/yuv/mod.rs:342-410; Q10
+ * integer, one (U,V) per pixel pair).  src: width*height*2 bytes `Y0 U Y1 V`; an odd width leaves the
+ * last pixel of each row untouched, as the reference does.                                         */
+enum { KH_YUV_BT601_FULL = 0, KH_YUV_BT709_FULL = 1, KH_YUV_BT601_LIMITED = 2 };
+KH_API int32_t kh_yuyv_to_rgb_mode_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t width, int32_t height,
+                                      int32_t mode);
+
 /* ------------------------------------------------------------------------------------------ */
 /* u8 fixed-point twins.  Byte-identical to the reference CPU ops they replace the
  * device launchers of; HWC u8, channels in {1, 3, 4}, `batch` images `*_stride` BYTES apart.

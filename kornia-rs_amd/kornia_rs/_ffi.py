@@ -41,6 +41,7 @@ class FusedStage(C.Structure):
     _fields_ = [("kind", C.c_int32), ("u", C.c_int32 * 4), ("f", C.c_float * 6)]
 KH_BORDER = {"constant": 0, "replicate": 1, "reflect101": 2, "reflect": 3, "wrap": 4}
 KH_MORPH_SHAPE = {"box": 0, "cross": 1, "ellipse": 2}
+KH_YUV_MODE = {"bt601_full": 0, "bt709_full": 1, "bt601_limited": 2}  # YuvToRgbMode, P/color/yuv/mod.rs:319-327
 # kh_color_convert_f64 codes: 0..7 = KH_CIE, then the gray / hsv / hls / YCbCr / YUV f64 twins
 KH_F64 = {**KH_CIE, "gray_from_rgb": 8, "rgb_from_gray": 9, "hsv_from_rgb": 10, "rgb_from_hsv": 11, "hls_from_rgb": 12,
           "rgb_from_hls": 13, "ycbcr_from_rgb": 14, "rgb_from_ycbcr": 15, "yuv_from_rgb": 16, "rgb_from_yuv": 17}
@@ -117,6 +118,7 @@ SIGNATURES = {
         "kh_ycc_from_rgb_f32", "kh_rgb_from_ycc_f32")},
     "kh_cie_convert_f32": (_i32, [_vp, _vp, _vp, _i64, _i32]),
     "kh_color_convert_f64": (_i32, [_vp, _vp, _vp, _i64, _i32]),
+    "kh_yuyv_to_rgb_mode_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),
     "kh_rgb_from_rgba_u8": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "kh_apply_colormap_u8": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "kh_rgb_from_planar420_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),

@@ -247,6 +247,22 @@ def rgb_from_uyvy(data, width, height, dst=None): return _decode("packed422", 1,
 def rgb_from_yvyu(data, width, height, dst=None): return _decode("packed422", 2, data, width, height, dst)
 
 
+def convert_yuyv_to_rgb_u8(data, width: int, height: int, mode: str = "bt601_limited", dst: Optional[Image] = None) -> Image:
+    """YUYV -> RGB8 with a selectable matrix: ``mode`` in ``bt601_full`` | ``bt709_full`` | ``bt601_limited``
+    (``YuvToRgbMode``, P/color/yuv/mod.rs:319-410).  ``data``: a device buffer / ``color_spaces.Yuyv8`` of
+    ``width * height * 2`` bytes.  An odd width leaves the last pixel of each row as it was, like the reference."""
+    code = _ffi.KH_YUV_MODE.get(str(mode).lower())
+    if code is None:
+        raise ImageError("InvalidArgument", f"convert_yuyv_to_rgb_u8: unknown mode {mode!r} ({', '.join(_ffi.KH_YUV_MODE)})")
+    ptr, st = _raw_ptr(data, width * height * 2, "convert_yuyv_to_rgb_u8")
+    out = dst if dst is not None else Image.uninit(width, height, 3, "uint8", st)
+    _require(out, "uint8", (3,), "convert_yuyv_to_rgb_u8")
+    if out.size != (width, height):
+        raise ImageError("InvalidImageSize", f"destination is {out.width}x{out.height}, expected {width}x{height}")
+    _check(lib.kh_yuyv_to_rgb_mode_u8(st.cuda_stream_ptr, ptr, out.data_ptr, width, height, code))
+    return out
+
+
 def _encode(name: str, src: Image, nbytes: int) -> Tensor:
     _require(src, "uint8", (3,), name)
     if not src.is_device:

@@ -384,3 +384,44 @@ void ko_apply_colormap_u8(const uint8_t* src, uint8_t* dst, size_t n, const uint
         dst[3 * i] = lut[src[i]]; dst[3 * i + 1] = lut[256 + src[i]]; dst[3 * i + 2] = lut[512 + src[i]];
     }
 }
+
+/* ---- convert_yuyv_to_rgb_u8 (P/color/yuv/mod.rs:319-480): YUYV -> RGB8 with a selectable Q10 matrix -------------
+ * mode 0 = Bt601Full, 1 = Bt709Full, 2 = Bt601Limited.  The row is walked in whole 6-byte RGB chunks (:374-376): with
+ * an odd width the last pixel of every row is left as it was.  Rust `>>` on i32 is arithmetic; so is gcc's.         */
+static inline uint8_t sat8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+static inline void yuv_px_mode(int mode, uint8_t y, uint8_t u, uint8_t v, uint8_t* rgb) {
+    int y_val = (int)y, u_val = (int)u - 128, v_val = (int)v - 128, r, g, b;
+    switch (mode) {
+        case 0:
+            r = y_val + ((1436 * v_val + 512) >> 10);
+            g = y_val - ((352 * u_val + 731 * v_val + 512) >> 10);
+            b = y_val + ((1815 * u_val + 512) >> 10);
+            break;
+        case 1:
+            r = y_val + ((1612 * v_val + 512) >> 10);
+            g = y_val - ((192 * u_val + 479 * v_val + 512) >> 10);
+            b = y_val + ((1900 * u_val + 512) >> 10);
+            break;
+        default:
+            y_val = (((int)y - 16) * 1192 + 512) >> 10;
+            r = y_val + ((1634 * v_val + 512) >> 10);
+            g = y_val - ((401 * u_val + 832 * v_val + 512) >> 10);
+            b = y_val + ((2066 * u_val + 512) >> 10);
+    }
+    rgb[0] = sat8(r); rgb[1] = sat8(g); rgb[2] = sat8(b);
+}
+
+int ko_yuyv_to_rgb_mode(const uint8_t* src, uint8_t* dst, int w, int h, int mode) {
+    if (mode < 0 || mode > 2 || w < 0 || h < 0) return -1;
+    for (int row = 0; row < h; ++row) {
+        const uint8_t* s = src + (size_t)row * w * 2;
+        uint8_t* d = dst + (size_t)row * w * 3;
+        for (int col = 0; col < (w * 3) / 6; ++col) {
+            const uint8_t* q = s + 4 * col;
+            yuv_px_mode(mode, q[0], q[1], q[3], d + 6 * col);
+            yuv_px_mode(mode, q[2], q[1], q[3], d + 6 * col + 3);
+        }
+    }
+    return 0;
+}

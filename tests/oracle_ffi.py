@@ -580,3 +580,15 @@ def color_f64(name, src):
     out = np.empty(n * cout, np.float64)
     assert ko.ko_color_f64(src.reshape(-1), out, n, conv) == 0
     return out.reshape(src.shape[:-1] + (cout,)) if src.ndim > 1 else out
+
+
+YUV_MODE = {"bt601_full": 0, "bt709_full": 1, "bt601_limited": 2}
+ko.ko_yuyv_to_rgb_mode.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+ko.ko_yuyv_to_rgb_mode.restype = C.c_int
+
+
+def yuyv_to_rgb_mode(buf, w, h, mode, fill=0):
+    """convert_yuyv_to_rgb_u8; pixels the reference leaves untouched (odd widths) keep `fill`."""
+    out = np.full((h, w, 3), fill, np.uint8)
+    assert ko.ko_yuyv_to_rgb_mode(np.ascontiguousarray(buf, np.uint8).reshape(-1), out.reshape(-1), w, h, YUV_MODE[mode]) == 0
+    return out

@@ -70,6 +70,9 @@ CASES = [
     ("color f64: unknown conversion", lambda: L.kh_color_convert_f64(S, P, Q, 10, 18), INVALID, "conversion 18"),
     ("color f64: null", lambda: L.kh_color_convert_f64(S, None, Q, 10, 8), INVALID, "null"),
     ("color f64: negative count", lambda: L.kh_color_convert_f64(S, P, Q, -3, 8), INVALID, "negative"),
+    ("yuyv mode decode: unknown mode", lambda: L.kh_yuyv_to_rgb_mode_u8(S, P, Q, 8, 4, 3), INVALID, "mode 3"),
+    ("yuyv mode decode: null", lambda: L.kh_yuyv_to_rgb_mode_u8(S, None, Q, 8, 4, 0), INVALID, "null"),
+    ("yuyv mode decode: > 2^31 bytes", lambda: L.kh_yuyv_to_rgb_mode_u8(S, P, Q, 40000, 40000, 0), TOO_LARGE, "32-bit"),
     ("planar 4:2:0: odd width", lambda: L.kh_rgb_from_planar420_u8(S, P, Q, 7, 4, 0), INVALID, "even"),
     ("planar 4:2:0: unknown layout", lambda: L.kh_rgb_from_planar420_u8(S, P, Q, 8, 4, 9), INVALID, "layout 9"),
     ("packed 4:2:2: odd width", lambda: L.kh_rgb_from_packed422_u8(S, P, Q, 7, 4, 0), INVALID, "even"),
@@ -105,4 +108,5 @@ def test_empty_batches_and_images_are_no_ops_without_a_device():
     assert L.kh_pyrdown_u8(S, None, None, 8, 8, 3, 0, 0, 0) == 0
     assert L.kh_gray_from_rgb_u8(S, None, None, 0) == 0
     assert L.kh_color_convert_f64(S, None, None, 0, 12) == 0
+    assert L.kh_yuyv_to_rgb_mode_u8(S, None, None, 1, 9, 0) == 0  # width 1: no whole pixel pair
     assert L.kh_flip(S, P, Q, 0, 8, 3, 1) == 0

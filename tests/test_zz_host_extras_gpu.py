@@ -155,3 +155,25 @@ def test_color_f64_through_the_host_api(gpu_stream):
     with pytest.raises(ImageError) as e:  # no f64 BGR swizzle in the reference either (convert.rs:124-131)
         imgproc.bgr_from_rgb(dev)
     assert e.value.kind == "NoDeviceKernel"
+
+
+# ---- YUYV mode decode (P/cuda/color/video.rs:128-190, yuyv_mode_decode_bit_exact_vs_cpu) --------------------------
+
+@pytest.mark.parametrize("mode", sorted(O.YUV_MODE))
+def test_yuyv_mode_decode_bit_exact(gpu_stream, mode):
+    from kornia_rs import Image, ImageError, imgproc
+    from kornia_rs.hip import DeviceBuffer
+    for w, h in [(640, 37), (38, 7), (2, 1), (5, 3)]:  # (5, 3): odd width, last column untouched
+        buf = O.pattern_u8(w * h * 2)
+        dst = Image.from_numpy(np.full((h, w, 3), 77, np.uint8)).to_hip(gpu_stream)
+        got = imgproc.convert_yuyv_to_rgb_u8(DeviceBuffer.from_numpy(buf, gpu_stream), w, h, mode, dst)
+        assert got is dst and np.array_equal(got.numpy(), O.yuyv_to_rgb_mode(buf, w, h, mode, fill=77)), (mode, w, h)
+    # every (Y, U, V) once: 256 rows of (u, v) pairs for each y would be 2^24 pairs = 64 MiB in, 96 MiB out
+    yy, uu, vv = np.meshgrid(np.arange(0, 256, 1, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    buf = np.stack([yy, uu, yy, vv], -1).reshape(-1)
+    got = imgproc.convert_yuyv_to_rgb_u8(DeviceBuffer.from_numpy(buf, gpu_stream), 512, 65536, mode)
+    assert np.array_equal(got.numpy(), O.yuyv_to_rgb_mode(buf, 512, 65536, mode))
+    with pytest.raises(ImageError):
+        imgproc.convert_yuyv_to_rgb_u8(DeviceBuffer.from_numpy(buf[:16], gpu_stream), 4, 2, "bt2020")
+    with pytest.raises(ImageError):  # buffer shorter than width * height * 2
+        imgproc.convert_yuyv_to_rgb_u8(DeviceBuffer.from_numpy(buf[:15], gpu_stream), 4, 2, mode)
