@@ -217,6 +217,41 @@ class ResizeBilinear(F32Images):
                 f"resize, not the upstream Rust binary), OpenMP x{threads} over output rows"}
 
 
+class ResizeNormalizeF32(ResizeBilinear):
+    """The reference's own fused launcher on the configs[1] shape: bilinear resize 1920x1080 -> 224x224 f32x3 fused with
+    (px - mean) * (1 / std) (launch_resize_bilinear_normalize_cuda, bench_cuda_resize.rs:456), batch 256."""
+
+    name, kernel = "resize_bilinear_normalize_1080p_to_224_f32_b256", "resize_normalize_kernel"
+
+    def step(self):
+        import ctypes as C
+        from kornia_rs._ffi import lib, check
+        from kornia_rs.hip import IMAGENET_MEAN, IMAGENET_STD
+        check(lib.kh_resize_bilinear_normalize_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.SW, self.SH,
+                                                   self.DW, self.DH, (C.c_float * 3)(*IMAGENET_MEAN), (C.c_float * 3)(*IMAGENET_STD),
+                                                   0, self.N, self.SW * self.SH * self.C, self.DW * self.DH * self.C))
+
+    def describe(self):
+        d = super().describe()
+        d.update(workload=self.name, op="cuda::resize::launch_resize_bilinear_normalize (half-pixel, ImageNet mean/std)")
+        return d
+
+    def cpu_baseline(self):
+        O = self._oracle()
+        from kornia_rs.hip import IMAGENET_MEAN, IMAGENET_STD
+        threads, n = O.ko.ko_max_threads(), self.SW * self.SH * self.C
+        frames, t0 = 0, time.perf_counter()
+        while True:
+            O.resize_bilinear_normalize(self.base[31 * frames: 31 * frames + n].reshape(self.SH, self.SW, self.C), self.DW, self.DH,
+                                        IMAGENET_MEAN, IMAGENET_STD)
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt > 10.0 or frames >= 256:
+                break
+        return {"value": round(frames * self.SW * self.SH / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                "sample": f"{frames} images in {dt:.1f} s; C restatement of the fused launcher, single thread"}
+
+
 class Gaussian4K(F32Images):
     """configs[3]: separable gaussian_blur 7x7 sigma 1.5 f32x3, 3840x2160, batch 256 (LDS stencil)."""
 
@@ -669,6 +704,7 @@ WORKLOADS = {
     "nv12_chw": lambda a: NorthStarNV12(a.batch or 1024, 0),
     "nv12_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640),
     "resize_224": lambda a: ResizeBilinear(a.batch or 256),
+    "resize_normalize_f32_224": lambda a: ResizeNormalizeF32(a.batch or 256),
     "gaussian_4k": lambda a: Gaussian4K(a.batch or 256),
     "undistort_warp_4k": lambda a: UndistortWarp4K(a.batch or 256),
     "gaussian_u8_4k": lambda a: GaussianU8_4K(a.batch or 256),

@@ -236,6 +236,22 @@ enum { KH_INTERP_NEAREST = 0, KH_INTERP_BILINEAR = 1, KH_INTERP_BICUBIC = 2, KH_
 KH_API int32_t kh_resize_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w, int32_t src_h,
                              int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode, int32_t batch,
                              int64_t src_stride, int64_t dst_stride);
+/* The reference's resize launchers take a PixelMapping (P/cuda/resize.rs:433-473): HalfPixel — the public
+ * `resize` and the default everywhere — or AlignCorners (`src = dst * (src_len-1)/(dst_len-1)`, a 1-wide
+ * destination axis pins to 0).  kh_resize_mapped_f32 == launch_resize_{bilinear_downscale,nearest_downscale,
+ * bicubic,lanczos}_cuda(.., mapping) (:490-930); kh_resize_f32 is the HalfPixel case.
+ * kh_resize_bilinear_normalize_f32 == launch_resize_bilinear_normalize_cuda (:580-650, kernel :184-236):
+ * 3-channel bilinear resize fused with `(px - mean[c]) * (1 / std[c])`, HWC f32 out; mean / std are HOST
+ * pointers to 3 floats; a zero std is an error.                                                      */
+enum { KH_MAP_HALF_PIXEL = 0, KH_MAP_ALIGN_CORNERS = 1 };
+KH_API int32_t kh_pixel_mapping_coeffs(int32_t mapping, int32_t src_len, int32_t dst_len, float out_a_b[2]);
+KH_API int32_t kh_resize_mapped_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w, int32_t src_h,
+                                    int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode, int32_t mapping,
+                                    int32_t batch, int64_t src_stride, int64_t dst_stride);
+KH_API int32_t kh_resize_bilinear_normalize_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w,
+                                                int32_t src_h, int32_t dst_w, int32_t dst_h, const float* mean,
+                                                const float* std_dev, int32_t mapping, int32_t batch,
+                                                int64_t src_stride, int64_t dst_stride);
 KH_API int32_t kh_warp_affine_f32(kh_stream_t stream, const float* src, float* dst, int32_t src_w, int32_t src_h,
                                   int32_t dst_w, int32_t dst_h, int32_t channels, const float* m2x3, int32_t mode,
                                   int32_t batch, int64_t src_stride, int64_t dst_stride);

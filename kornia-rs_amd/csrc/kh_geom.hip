@@ -221,6 +221,21 @@ __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, floa
     put<C>(o, v);
 }
 
+// resize_bilinear_normalize_3c (P/cuda/resize.rs:184-236): bilinear resize fused with `(px - mean) * inv_std`, HWC in,
+// HWC out — the sample is the same bilinear sampler as `resize`, the epilogue the reference kernel's expression.
+struct Norm3f { float mean[3], inv_std[3]; };
+__global__ __launch_bounds__(kBx* kBy) void resize_normalize_kernel(Img im, float ax, float bx, float ay, float by, Norm3f n) {
+    constexpr int C = 3;
+    KH_PIXEL_PROLOGUE
+    const float sx = clampf(ax * (float)x + bx, 0.0f, (float)(im.sw - 1));
+    const float sy = clampf(ay * (float)y + by, 0.0f, (float)(im.sh - 1));
+    float v[C];
+    sample<C, KH_INTERP_BILINEAR>(src, im.sh, im.sw, sx, sy, v);
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = (v[c] - n.mean[c]) * n.inv_std[c];
+    put<C>(o, v);
+}
+
 // Lanczos resize is separable in the reference (resize_lanczos_separable, lanczos.rs:189-245): an H
 // pass into a dst_w x src_h f32 intermediate, then a V pass, both fmaf chains over six host-built
 // table weights.  Here the two passes run fused per destination pixel — the row value `rx` IS the
@@ -460,14 +475,39 @@ int32_t kh_invert_homography(const float m[9], float inv[9]) {
     return KH_OK;
 }
 
+// PixelMapping::coeffs (P/cuda/resize.rs:456-473): src = a * dst + b per axis.  HalfPixel is exactly the CPU LUT's
+// expression (P/resize/mod.rs:169-171); AlignCorners pins a 1-wide destination axis to source coordinate 0.
+int32_t kh_pixel_mapping_coeffs(int32_t mapping, int32_t src_len, int32_t dst_len, float out[2]) {
+    KH_REQUIRE(out, KH_ERR_INVALID_ARG, "kh_pixel_mapping_coeffs: null output");
+    KH_REQUIRE(mapping == KH_MAP_HALF_PIXEL || mapping == KH_MAP_ALIGN_CORNERS, KH_ERR_INVALID_ARG,
+               "kh_pixel_mapping_coeffs: unknown pixel mapping %d", mapping);
+    KH_REQUIRE(src_len > 0 && dst_len > 0, KH_ERR_INVALID_ARG, "kh_pixel_mapping_coeffs: lengths must be positive (%d, %d)", src_len, dst_len);
+    if (mapping == KH_MAP_HALF_PIXEL) {
+        const float a = (float)src_len / (float)dst_len;
+        out[0] = a; out[1] = 0.5f * a - 0.5f;
+    } else if (dst_len > 1) {
+        out[0] = (float)(src_len - 1) / (float)(dst_len - 1); out[1] = 0.0f;
+    } else {
+        out[0] = 0.0f; out[1] = 0.0f;
+    }
+    return KH_OK;
+}
+
 int32_t kh_resize_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw, int32_t dh,
                       int32_t channels, int32_t mode, int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    return kh_resize_mapped_f32(stream, src, dst, sw, sh, dw, dh, channels, mode, KH_MAP_HALF_PIXEL, batch, src_stride, dst_stride);
+}
+
+int32_t kh_resize_mapped_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw, int32_t dh,
+                             int32_t channels, int32_t mode, int32_t mapping, int32_t batch, int64_t src_stride,
+                             int64_t dst_stride) {
     if (int32_t rc = check_img("kh_resize_f32", src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride, dst_stride))
         return rc;
+    float cx[2], cy[2];
+    if (int32_t rc = kh_pixel_mapping_coeffs(mapping, sw, dw, cx)) return rc;
+    if (int32_t rc = kh_pixel_mapping_coeffs(mapping, sh, dh, cy)) return rc;
     if (batch == 0) return KH_OK;
-    // PixelMapping::HalfPixel coefficients, exactly the CPU LUT's expression (P/resize/mod.rs:169-171)
-    const float ax = (float)sw / (float)dw, bx = 0.5f * ax - 0.5f;
-    const float ay = (float)sh / (float)dh, by = 0.5f * ay - 0.5f;
+    const float ax = cx[0], bx = cx[1], ay = cy[0], by = cy[1];
     const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
     KH_REQUIRE_TILES("kh_resize_f32", im);
     if (mode == KH_INTERP_LANCZOS) {  // P/resize/mod.rs:139-146
@@ -492,6 +532,27 @@ int32_t kh_resize_f32(kh_stream_t stream, const float* src, float* dst, int32_t 
     }
     KH_DISPATCH_C_MODE(resize_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, ax, bx, ay, by);
     return check_launch("kh_resize_f32");
+}
+
+int32_t kh_resize_bilinear_normalize_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw,
+                                         int32_t dh, const float* mean, const float* std_dev, int32_t mapping, int32_t batch,
+                                         int64_t src_stride, int64_t dst_stride) {
+    const char* what = "kh_resize_bilinear_normalize_f32";
+    if (int32_t rc = check_img(what, src, dst, sw, sh, dw, dh, 3, KH_INTERP_BILINEAR, batch, src_stride, dst_stride)) return rc;
+    KH_REQUIRE(mean && std_dev, KH_ERR_INVALID_ARG, "%s: null mean / std", what);
+    // launch_resize_bilinear_normalize_cuda, P/cuda/resize.rs:606-610
+    KH_REQUIRE(std_dev[0] != 0.0f && std_dev[1] != 0.0f && std_dev[2] != 0.0f, KH_ERR_INVALID_ARG,
+               "%s: std must be non-zero for all channels", what);
+    float cx[2], cy[2];
+    if (int32_t rc = kh_pixel_mapping_coeffs(mapping, sw, dw, cx)) return rc;
+    if (int32_t rc = kh_pixel_mapping_coeffs(mapping, sh, dh, cy)) return rc;
+    if (batch == 0) return KH_OK;
+    Norm3f n;
+    for (int c = 0; c < 3; ++c) { n.mean[c] = mean[c]; n.inv_std[c] = 1.0f / std_dev[c]; }
+    const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
+    KH_REQUIRE_TILES(what, im);
+    hipLaunchKernelGGL(resize_normalize_kernel, xcd_grid(im.tiles), dim3(kBx, kBy), 0, as_hip(stream), im, cx[0], cx[1], cy[0], cy[1], n);
+    return check_launch(what);
 }
 
 int32_t kh_warp_affine_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw,

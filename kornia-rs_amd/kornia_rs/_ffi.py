@@ -41,6 +41,7 @@ class FusedStage(C.Structure):
     _fields_ = [("kind", C.c_int32), ("u", C.c_int32 * 4), ("f", C.c_float * 6)]
 KH_BORDER = {"constant": 0, "replicate": 1, "reflect101": 2, "reflect": 3, "wrap": 4}
 KH_MORPH_SHAPE = {"box": 0, "cross": 1, "ellipse": 2}
+KH_PIXEL_MAPPING = {"half_pixel": 0, "align_corners": 1}  # PixelMapping, P/cuda/resize.rs:438-454
 KH_YUV_MODE = {"bt601_full": 0, "bt709_full": 1, "bt601_limited": 2}  # YuvToRgbMode, P/color/yuv/mod.rs:319-327
 # kh_color_convert_f64 codes: 0..7 = KH_CIE, then the gray / hsv / hls / YCbCr / YUV f64 twins
 KH_F64 = {**KH_CIE, "gray_from_rgb": 8, "rgb_from_gray": 9, "hsv_from_rgb": 10, "rgb_from_hsv": 11, "hls_from_rgb": 12,
@@ -127,6 +128,9 @@ SIGNATURES = {
     "kh_yuyv_from_rgb_u8": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     # geometry
     "kh_resize_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_pixel_mapping_coeffs": (_i32, [_i32, _i32, _i32, _P(_f32)]),
+    "kh_resize_mapped_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_resize_bilinear_normalize_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _P(_f32), _P(_f32), _i32, _i32, _i64, _i64]),
     "kh_warp_affine_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i32, _i64, _i64]),
     "kh_warp_perspective_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i32, _i64, _i64]),
     "kh_remap_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),

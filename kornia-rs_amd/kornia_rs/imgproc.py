@@ -319,6 +319,36 @@ def resize(src: Image, new_size: Optional[Tuple[int, int]] = None, interpolation
     return dst
 
 
+def _mapping(name: str) -> int:
+    code = _ffi.KH_PIXEL_MAPPING.get(str(name).lower())
+    if code is None:
+        raise ImageError("InvalidArgument", f"unknown pixel mapping {name!r} (half_pixel, align_corners)")
+    return code
+
+
+def resize_mapped(src: Image, new_size: Tuple[int, int], interpolation: str = "bilinear", mapping: str = "half_pixel",
+                  out: Optional[Image] = None) -> Image:
+    """The resize LAUNCHERS with their ``PixelMapping`` argument (launch_resize_*_cuda, P/cuda/resize.rs:433-930):
+    ``half_pixel`` is what ``resize`` does; ``align_corners`` maps ``src = dst * (src_len-1)/(dst_len-1)``."""
+    mode = _interp(interpolation)
+    dst, stream = _geom_pair(src, out, new_size, "resize")
+    _check(lib.kh_resize_mapped_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
+                                    dst.height, src.channels, mode, _mapping(mapping), 1, 0, 0))
+    return dst
+
+
+def resize_bilinear_normalize(src: Image, new_size: Tuple[int, int], mean: Sequence[float], std: Sequence[float],
+                              mapping: str = "half_pixel", out: Optional[Image] = None) -> Image:
+    """launch_resize_bilinear_normalize_cuda (P/cuda/resize.rs:580-650): float32 RGB bilinear resize fused with
+    ``(px - mean) * (1 / std)``, HWC float32 out (one pass over HBM instead of resize + normalize_mean_std)."""
+    _require(src, "float32", (3,), "resize_bilinear_normalize")
+    dst, stream = _geom_pair(src, out, new_size, "resize_bilinear_normalize")
+    m, s_ = _matrix(mean, 3, "resize_bilinear_normalize"), _matrix(std, 3, "resize_bilinear_normalize")
+    _check(lib.kh_resize_bilinear_normalize_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height,
+                                                dst.width, dst.height, m, s_, _mapping(mapping), 1, 0, 0))
+    return dst
+
+
 def _matrix(m: Sequence[float], n: int, what: str):
     m = [float(v) for v in np.asarray(m, dtype=np.float32).reshape(-1)]
     if len(m) != n:

@@ -94,8 +94,13 @@ float ko_lanczos3(float x) {
 }
 
 /* lanczos_axis, lanczos.rs:59-101: tap base + six normalised weights per destination index */
+static void lanczos_axis_ab(int src_len, int dst_len, float a, float b, int32_t* x0s, float* weights);
 void ko_lanczos_axis(int src_len, int dst_len, int32_t* x0s, float* weights) {
-    const float a = (float)src_len / (float)dst_len, b = 0.5f * a - 0.5f, max = (float)(src_len - 1);
+    const float a = (float)src_len / (float)dst_len, b = 0.5f * a - 0.5f;
+    lanczos_axis_ab(src_len, dst_len, a, b, x0s, weights);
+}
+static void lanczos_axis_ab(int src_len, int dst_len, float a, float b, int32_t* x0s, float* weights) {
+    const float max = (float)(src_len - 1);
     for (int i = 0; i < dst_len; ++i) {
         float s = a * (float)i + b;
         s = s < 0.0f ? 0.0f : (s > max ? max : s);
@@ -165,13 +170,19 @@ static inline float sample(int mode, const float* img, int rows, int cols, int C
 }
 
 /* resize_lanczos_separable, lanczos.rs:189-245: H pass into a dst_w x src_h f32 intermediate, then V */
+static void resize_lanczos_separable_ab(const float* s, int sw, int sh, float* d, int dw, int dh, int C, const float cx[2], const float cy[2]);
 static void resize_lanczos_separable(const float* s, int sw, int sh, float* d, int dw, int dh, int C) {
+    const float ax = (float)sw / (float)dw, ay = (float)sh / (float)dh;
+    const float cx[2] = {ax, 0.5f * ax - 0.5f}, cy[2] = {ay, 0.5f * ay - 0.5f};
+    resize_lanczos_separable_ab(s, sw, sh, d, dw, dh, C, cx, cy);
+}
+static void resize_lanczos_separable_ab(const float* s, int sw, int sh, float* d, int dw, int dh, int C, const float cx[2], const float cy[2]) {
     int32_t* x0s = (int32_t*)malloc(sizeof(int32_t) * (size_t)(dw + dh));
     int32_t* y0s = x0s + dw;
     float* wx = (float*)malloc(sizeof(float) * 6 * (size_t)(dw + dh));
     float* wy = wx + 6 * (size_t)dw;
-    ko_lanczos_axis(sw, dw, x0s, wx);
-    ko_lanczos_axis(sh, dh, y0s, wy);
+    lanczos_axis_ab(sw, dw, cx[0], cx[1], x0s, wx);
+    lanczos_axis_ab(sh, dh, cy[0], cy[1], y0s, wy);
     float* inter = (float*)malloc(sizeof(float) * (size_t)dw * sh * C);
 #pragma omp parallel for schedule(static)
     for (int sy = 0; sy < sh; ++sy)
@@ -221,6 +232,56 @@ void ko_resize_f32(const float* src, int sw, int sh, float* dst, int dw, int dh,
             for (int c = 0; c < C; ++c) dst[((size_t)y * dw + x) * C + c] = sample(mode, src, sh, sw, C, sx, sy, c);
         }
     }
+}
+
+/* ---- the resize LAUNCHERS' PixelMapping (P/cuda/resize.rs:433-473) and the fused resize + normalise kernel
+ * (resize_bilinear_normalize_3c, :184-236; launcher :580-650).  mapping 0 = HalfPixel, 1 = AlignCorners.  The
+ * launchers have no same-size short circuit; the sample is the bilinear sampler of `resize`, the epilogue the
+ * kernel's `(ch - mean) * inv_std` with inv_std = 1.0f / std computed by the launcher (:621-623).            */
+int ko_pixel_mapping_coeffs(int mapping, int src_len, int dst_len, float out[2]) {
+    if (src_len <= 0 || dst_len <= 0) return -1;
+    if (mapping == 0) {
+        float a = (float)src_len / (float)dst_len;
+        out[0] = a; out[1] = 0.5f * a - 0.5f;
+    } else if (mapping == 1) {
+        if (dst_len > 1) { out[0] = (float)(src_len - 1) / (float)(dst_len - 1); out[1] = 0.0f; }
+        else { out[0] = 0.0f; out[1] = 0.0f; }
+    } else return -1;
+    return 0;
+}
+
+int ko_resize_mapped_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int C, int mode, int mapping) {
+    float cx[2], cy[2];
+    if (ko_pixel_mapping_coeffs(mapping, sw, dw, cx) || ko_pixel_mapping_coeffs(mapping, sh, dh, cy)) return -1;
+    if (mode == 3) { resize_lanczos_separable_ab(src, sw, sh, dst, dw, dh, C, cx, cy); return 0; }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; ++y) {
+        float sy = fclamp(cy[0] * (float)y + cy[1], 0.0f, (float)(sh - 1));
+        for (int x = 0; x < dw; ++x) {
+            float sx = fclamp(cx[0] * (float)x + cx[1], 0.0f, (float)(sw - 1));
+            for (int c = 0; c < C; ++c) dst[((size_t)y * dw + x) * C + c] = sample(mode, src, sh, sw, C, sx, sy, c);
+        }
+    }
+    return 0;
+}
+
+int ko_resize_bilinear_normalize_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, const float mean[3],
+                                     const float std_dev[3], int mapping) {
+    float cx[2], cy[2];
+    if (ko_pixel_mapping_coeffs(mapping, sw, dw, cx) || ko_pixel_mapping_coeffs(mapping, sh, dh, cy)) return -1;
+    if (std_dev[0] == 0.0f || std_dev[1] == 0.0f || std_dev[2] == 0.0f) return -2;
+    const float inv_std[3] = {1.0f / std_dev[0], 1.0f / std_dev[1], 1.0f / std_dev[2]};
+    for (int y = 0; y < dh; ++y) {
+        float sy = fclamp(cy[0] * (float)y + cy[1], 0.0f, (float)(sh - 1));
+        for (int x = 0; x < dw; ++x) {
+            float sx = fclamp(cx[0] * (float)x + cx[1], 0.0f, (float)(sw - 1));
+            for (int c = 0; c < 3; ++c) {
+                float ch = sample(1, src, sh, sw, 3, sx, sy, c);
+                dst[((size_t)y * dw + x) * 3 + c] = (ch - mean[c]) * inv_std[c];
+            }
+        }
+    }
+    return 0;
 }
 
 /* ---- affine (P/warp/affine.rs:18-38 invert; :123-372 warp) ----------------------------------- */

@@ -93,6 +93,11 @@ void ko_apply_colormap_u8(const uint8_t* src, uint8_t* dst, size_t n, const uint
 
 /* ---- geometry, f32 (ko_geom.c): mode 0 nearest, 1 bilinear, 2 bicubic --------------------- */
 void ko_resize_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int C, int mode);
+/* the launchers' PixelMapping (0 HalfPixel, 1 AlignCorners) and the fused resize + normalise kernel; -1 / -2 on bad arguments */
+int ko_pixel_mapping_coeffs(int mapping, int src_len, int dst_len, float out[2]);
+int ko_resize_mapped_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int C, int mode, int mapping);
+int ko_resize_bilinear_normalize_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, const float mean[3],
+                                     const float std_dev[3], int mapping);
 void ko_invert_affine_transform(const float m[6], float out[6]);
 void ko_warp_affine_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int C, const float m[6], int mode);
 int ko_invert_homography(const float m[9], float inv[9]);

@@ -592,3 +592,40 @@ def yuyv_to_rgb_mode(buf, w, h, mode, fill=0):
     out = np.full((h, w, 3), fill, np.uint8)
     assert ko.ko_yuyv_to_rgb_mode(np.ascontiguousarray(buf, np.uint8).reshape(-1), out.reshape(-1), w, h, YUV_MODE[mode]) == 0
     return out
+
+
+# ---- resize launchers' PixelMapping + fused resize/normalise (P/cuda/resize.rs:184-236, 433-473, 580-650) -----------
+PIXEL_MAPPING = {"half_pixel": 0, "align_corners": 1}
+ko.ko_pixel_mapping_coeffs.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+ko.ko_pixel_mapping_coeffs.restype = C.c_int
+ko.ko_resize_mapped_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+ko.ko_resize_mapped_f32.restype = C.c_int
+ko.ko_resize_bilinear_normalize_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                                C.POINTER(C.c_float), C.c_int]
+ko.ko_resize_bilinear_normalize_f32.restype = C.c_int
+
+
+def pixel_mapping_coeffs(mapping, src_len, dst_len):
+    out = (C.c_float * 2)()
+    assert ko.ko_pixel_mapping_coeffs(PIXEL_MAPPING[mapping], src_len, dst_len, out) == 0
+    return float(out[0]), float(out[1])
+
+
+def resize_mapped(src, dw, dh, mode="bilinear", mapping="half_pixel"):
+    src = _img(src)
+    sh, sw, c = src.shape
+    out = np.empty((dh, dw, c), np.float32)
+    assert ko.ko_resize_mapped_f32(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, c, MODE[mode], PIXEL_MAPPING[mapping]) == 0
+    return out
+
+
+def resize_bilinear_normalize(src, dw, dh, mean, std, mapping="half_pixel"):
+    src = _img(src)
+    sh, sw, c = src.shape
+    assert c == 3
+    out = np.empty((dh, dw, 3), np.float32)
+    rc = ko.ko_resize_bilinear_normalize_f32(src.reshape(-1), sw, sh, out.reshape(-1), dw, dh, (C.c_float * 3)(*mean),
+                                             (C.c_float * 3)(*std), PIXEL_MAPPING[mapping])
+    if rc:
+        raise ValueError(f"ko_resize_bilinear_normalize_f32 -> {rc}")
+    return out

@@ -28,6 +28,10 @@ CASES = [
     ("resize: negative stride", lambda: L.kh_resize_f32(S, P, Q, 8, 8, 4, 4, 3, 1, 2, -1, 0), INVALID, "stride"),
     ("resize: batch > 65535", lambda: L.kh_resize_f32(S, P, Q, 8, 8, 4, 4, 3, 1, 70000, 0, 0), TOO_LARGE, "batch"),
     ("resize: > 2^31 elements", lambda: L.kh_resize_f32(S, P, Q, 8, 8, 50000, 50000, 3, 1, 1, 0, 0), TOO_LARGE, "32-bit"),
+    ("resize_mapped: unknown mapping", lambda: L.kh_resize_mapped_f32(S, P, Q, 8, 8, 4, 4, 3, 1, 5, 1, 0, 0), INVALID, "mapping 5"),
+    ("resize_normalize_f32: zero std", lambda: L.kh_resize_bilinear_normalize_f32(S, P, Q, 8, 8, 4, 4, K3, (C.c_float * 3)(1, 0, 1), 0, 1, 0, 0), INVALID, "non-zero"),
+    ("resize_normalize_f32: null mean", lambda: L.kh_resize_bilinear_normalize_f32(S, P, Q, 8, 8, 4, 4, None, K3, 0, 1, 0, 0), INVALID, "mean"),
+    ("resize_normalize_f32: unknown mapping", lambda: L.kh_resize_bilinear_normalize_f32(S, P, Q, 8, 8, 4, 4, K3, K3, 2, 1, 0, 0), INVALID, "mapping 2"),
     ("warp_affine: null matrix", lambda: L.kh_warp_affine_f32(S, P, Q, 8, 8, 8, 8, 3, None, 1, 1, 0, 0), INVALID, "matrix"),
     ("warp_perspective: singular", lambda: L.kh_warp_perspective_f32(S, P, Q, 8, 8, 8, 8, 3, SING, 1, 1, 0, 0), SINGULAR, "determinant"),
     ("remap: null map", lambda: L.kh_remap_f32(S, P, None, P, Q, 8, 8, 8, 8, 3, 1, 1, 0, 0), INVALID, "map"),

@@ -10,6 +10,7 @@
   cuda/remap.rs:770-804            remap_identity_*, remap_oob_writes_zero
 """
 import numpy as np
+import pytest
 
 import oracle_ffi as O
 
@@ -171,3 +172,46 @@ def test_lanczos_resize_and_warps_reproduce_constants_and_identity():
     inter = np.einsum("yxtc,xt->yxc", src[:, xi, :].astype(np.float64), wx)
     want = np.einsum("ytxc,yt->yxc", inter[yi, :, :], wy)
     assert np.abs(O.resize(src, 20, 30, "lanczos") - want).max() < 1e-5
+
+
+# ---- PixelMapping + fused resize / normalise launchers (P/cuda/resize.rs) -----------------------------------------------
+
+REF_COEFFS = [("half_pixel", 640, 320, (2.0, 0.5)), ("half_pixel", 320, 640, (0.5, -0.25)), ("half_pixel", 9, 1, (9.0, 4.0)),
+              ("align_corners", 641, 321, (2.0, 0.0)), ("align_corners", 9, 1, (0.0, 0.0))]
+
+
+def test_pixel_mapping_coeffs_reference_vector():  # cuda/resize.rs:931-940, restatement AND the product's host function
+    import ctypes as C
+    from kornia_rs import _ffi
+    for mapping, s, d, want in REF_COEFFS:
+        assert O.pixel_mapping_coeffs(mapping, s, d) == want
+        out = (C.c_float * 2)()
+        assert _ffi.lib.kh_pixel_mapping_coeffs(_ffi.KH_PIXEL_MAPPING[mapping], s, d, out) == 0
+        assert (float(out[0]), float(out[1])) == want
+    assert _ffi.lib.kh_pixel_mapping_coeffs(2, 8, 8, (C.c_float * 2)()) == _ffi.KH_ERR_INVALID_ARG
+    assert _ffi.lib.kh_pixel_mapping_coeffs(0, 0, 8, (C.c_float * 2)()) == _ffi.KH_ERR_INVALID_ARG
+
+
+def test_mapped_resize_half_pixel_is_resize_and_align_corners_hits_corners():
+    src = O.pattern_f32(23 * 17 * 3).reshape(17, 23, 3)
+    for mode in ("nearest", "bilinear", "bicubic", "lanczos"):
+        assert np.array_equal(O.resize_mapped(src, 11, 9, mode, "half_pixel"), O.resize(src, 11, 9, mode)), mode
+        ac = O.resize_mapped(src, 12, 9, mode, "align_corners")  # (23-1)/(12-1) = 2, (17-1)/(9-1) = 2: every sample on a pixel
+        assert np.array_equal(ac, src[::2, ::2]), mode
+        assert np.array_equal(O.resize_mapped(src, 23, 17, mode, "align_corners"), src), mode
+    one = O.resize_mapped(src, 1, 1, "bilinear", "align_corners")  # a 1-wide destination axis pins to source 0
+    assert np.array_equal(one[0, 0], src[0, 0])
+
+
+def test_fused_resize_normalize_is_resize_then_the_kernel_epilogue():
+    src = O.pattern_f32(37 * 29 * 3).reshape(29, 37, 3)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for mapping in ("half_pixel", "align_corners"):
+        got = O.resize_bilinear_normalize(src, 16, 12, mean, std, mapping)
+        inv = (np.float32(1.0) / np.asarray(std, np.float32)).astype(np.float32)
+        want = ((O.resize_mapped(src, 16, 12, "bilinear", mapping) - np.asarray(mean, np.float32)) * inv).astype(np.float32)
+        assert np.array_equal(got, want), mapping
+    ident = O.resize_bilinear_normalize(src, 16, 12, (0, 0, 0), (1, 1, 1))
+    assert np.array_equal(ident, O.resize(src, 16, 12, "bilinear"))
+    with pytest.raises(ValueError):
+        O.resize_bilinear_normalize(src, 16, 12, mean, (0.2, 0.0, 0.2))  # "std must be non-zero" (resize.rs:606-610)

@@ -177,3 +177,37 @@ def test_yuyv_mode_decode_bit_exact(gpu_stream, mode):
         imgproc.convert_yuyv_to_rgb_u8(DeviceBuffer.from_numpy(buf[:16], gpu_stream), 4, 2, "bt2020")
     with pytest.raises(ImageError):  # buffer shorter than width * height * 2
         imgproc.convert_yuyv_to_rgb_u8(DeviceBuffer.from_numpy(buf[:15], gpu_stream), 4, 2, mode)
+
+
+# ---- PixelMapping launchers + fused resize / normalise (P/cuda/resize.rs:184-236, 433-473, 580-650) ------------------
+
+@pytest.mark.parametrize("mapping", ["half_pixel", "align_corners"])
+def test_resize_mapped_matches_cpu_arithmetic(gpu_stream, mapping):
+    from kornia_rs import Image, imgproc
+    for c in (1, 3, 4):
+        src = O.pattern_f32(131 * 77 * c).reshape(77, 131, c)
+        dev = Image.from_numpy(src).to_hip(gpu_stream)
+        for mode in ("nearest", "bilinear", "bicubic", "lanczos"):
+            for dw, dh in [(64, 48), (200, 150), (131, 77), (1, 1)]:
+                got = imgproc.resize_mapped(dev, (dh, dw), mode, mapping).numpy()
+                assert np.array_equal(got, O.resize_mapped(src, dw, dh, mode, mapping)), (c, mode, mapping, dw, dh)
+    src = O.pattern_f32(23 * 17 * 3).reshape(17, 23, 3)
+    ac = imgproc.resize_mapped(Image.from_numpy(src).to_hip(gpu_stream), (9, 12), "bicubic", "align_corners").numpy()
+    assert np.array_equal(ac, src[::2, ::2])  # every sample lands on a source pixel
+
+
+def test_resize_bilinear_normalize_fused(gpu_stream):
+    from kornia_rs import Image, ImageError, imgproc
+    src = O.pattern_f32(1920 * 270 * 3).reshape(270, 1920, 3)
+    dev = Image.from_numpy(src).to_hip(gpu_stream)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for mapping in ("half_pixel", "align_corners"):
+        for dw, dh in [(224, 224), (960, 135), (37, 11)]:
+            got = imgproc.resize_bilinear_normalize(dev, (dh, dw), mean, std, mapping).numpy()
+            assert np.array_equal(got, O.resize_bilinear_normalize(src, dw, dh, mean, std, mapping)), (mapping, dw, dh)
+    # == resize then the separate normalisation pass up to the (x - m) * (1/s) vs (x - m) / s rounding
+    two_pass = imgproc.normalize_mean_std(imgproc.resize(dev, (224, 224), "bilinear"), mean, std).numpy()
+    fused = imgproc.resize_bilinear_normalize(dev, (224, 224), mean, std).numpy()
+    assert np.abs(fused - two_pass).max() <= 1e-6 * np.abs(two_pass).max()
+    with pytest.raises(ImageError):
+        imgproc.resize_bilinear_normalize(dev, (8, 8), mean, (0.2, 0.0, 0.2))
