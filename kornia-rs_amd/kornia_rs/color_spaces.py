@@ -135,6 +135,68 @@ class Uyvy8(_Packed422): layout = "uyvy"
 class Yvyu8(_Packed422): layout = "yvyu"
 
 
+
+# ---- DeviceVideoFrame (P/cuda/color/video.rs:470-640) -------------------------------------------------------------
+VIDEO_FORMATS = {"nv12": Nv12, "nv21": Nv21, "i420": I420, "yv12": Yv12, "yuyv": Yuyv8, "uyvy": Uyvy8, "yvyu": Yvyu8}
+
+
+class DeviceVideoFrame:
+    """A device-resident camera frame tagged with its layout — ``VideoFormat::{Packed422, Planar420}`` by name
+    (``nv12`` ... ``yvyu``).  ``from_host`` uploads exactly ``buffer_len`` bytes (longer inputs are truncated, shorter ones
+    rejected: video.rs:516-537); ``to_rgb`` / ``convert`` decode into an RGB8 image of the frame's size."""
+
+    def __init__(self, buffer: _VideoBuffer):
+        if not buffer.is_device:
+            raise ImageError("UnsupportedDevice", "video frame is not device-backed")
+        self._buf = buffer
+
+    @staticmethod
+    def buffer_len(fmt: str, width: int, height: int) -> int:  # VideoFormat::buffer_len, :485-492
+        cls = DeviceVideoFrame._cls(fmt)
+        return width * height * cls._num // cls._den
+
+    @staticmethod
+    def _cls(fmt: str):
+        cls = VIDEO_FORMATS.get(str(fmt).lower())
+        if cls is None:
+            raise ImageError("InvalidArgument", f"unknown video format {fmt!r} ({', '.join(VIDEO_FORMATS)})")
+        return cls
+
+    @classmethod
+    def from_host(cls, data, width: int, height: int, fmt: str, stream: Stream) -> "DeviceVideoFrame":
+        need = cls.buffer_len(fmt, width, height)
+        flat = np.ascontiguousarray(np.asarray(data, np.uint8)).reshape(-1)
+        if flat.size < need:
+            raise ImageError("InvalidImageSize", f"src holds {flat.size} bytes, a {width}x{height} {fmt} frame needs {need}")
+        return cls(cls._cls(fmt)(width, height, flat[:need]).to_hip(stream))
+
+    @classmethod
+    def from_device_buffer(cls, buf: DeviceBuffer, width: int, height: int, fmt: str) -> "DeviceVideoFrame":
+        """``from_cudaslice``: adopt device memory that already holds the frame (exactly ``buffer_len`` bytes)."""
+        frame = cls._cls(fmt)(width, height, None, _device=buf)
+        frame.stream = buf.stream
+        return cls(frame)
+
+    @property
+    def width(self) -> int: return self._buf.width
+    @property
+    def height(self) -> int: return self._buf.height
+    @property
+    def format(self) -> str: return self._buf.layout
+    @property
+    def buffer(self) -> _VideoBuffer: return self._buf
+
+    def to_rgb(self, dst: Optional[Image] = None) -> Image:
+        from . import imgproc
+        if dst is not None and dst.size != (self.width, self.height):
+            raise ImageError("InvalidImageSize", f"destination is {dst.width}x{dst.height}, the frame {self.width}x{self.height}")
+        out = imgproc.rgb_from_video(self._buf, dst)
+        out.color_space = ColorSpace.RGB
+        return out
+
+    convert = to_rgb  # ConvertColor<Rgb8> for DeviceVideoFrame, video.rs:630-638
+
+
 # ---- ConvertColor (P/color/convert.rs:101-273) -------------------------------------------------------------
 # (source space, destination space) -> (imgproc function, dtypes the reference implements for a device pair)
 _U8, _F32, _BOTH = ("uint8",), ("float32",), ("uint8", "float32")

@@ -261,3 +261,18 @@ def test_named_colormaps_match_the_reference_digests():
         with pytest.raises(ImageError) as e:
             colormap.lut(name)
         assert kind in str(e.value)
+
+
+def test_device_video_frame_contract_without_a_device():  # P/cuda/color/video.rs:470-560
+    from kornia_rs import ImageError
+    from kornia_rs.color_spaces import DeviceVideoFrame, Nv12
+    assert DeviceVideoFrame.buffer_len("yuyv", 64, 48) == 64 * 48 * 2 and DeviceVideoFrame.buffer_len("NV12", 64, 48) == 64 * 48 * 3 // 2
+    with pytest.raises(ImageError) as e:
+        DeviceVideoFrame.buffer_len("h264", 64, 48)
+    assert e.value.kind == "InvalidArgument"
+    with pytest.raises(ImageError) as e:  # short source: check_len before any upload
+        DeviceVideoFrame.from_host(np.zeros(10, np.uint8), 4, 2, "nv12", None)
+    assert e.value.kind == "InvalidImageSize"
+    with pytest.raises(ImageError) as e:  # a host-resident buffer is not a device frame
+        DeviceVideoFrame(Nv12(4, 2, np.zeros(12, np.uint8)))
+    assert e.value.kind == "UnsupportedDevice"

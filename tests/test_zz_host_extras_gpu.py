@@ -211,3 +211,21 @@ def test_resize_bilinear_normalize_fused(gpu_stream):
     assert np.abs(fused - two_pass).max() <= 1e-6 * np.abs(two_pass).max()
     with pytest.raises(ImageError):
         imgproc.resize_bilinear_normalize(dev, (8, 8), mean, (0.2, 0.0, 0.2))
+
+
+def test_device_video_frame_convert_matches_cpu(gpu_stream):  # P/cuda/color/video.rs:647-690
+    from kornia_rs import Image, ImageError
+    from kornia_rs.color_spaces import ColorSpace, DeviceVideoFrame
+    from kornia_rs.hip import DeviceBuffer
+    w, h = 64, 48
+    for fmt, decode, layout in [("yuyv", O.rgb_from_yuyv, 0), ("nv12", O.rgb_from_nv12, 0), ("yv12", O.rgb_from_nv12, 3), ("uyvy", O.rgb_from_yuyv, 1)]:
+        raw = O.pattern_u8(DeviceVideoFrame.buffer_len(fmt, w, h) + 5)  # longer than needed: exactly buffer_len bytes go up
+        frame = DeviceVideoFrame.from_host(raw, w, h, fmt, gpu_stream)
+        assert (frame.width, frame.height, frame.format) == (w, h, fmt)
+        rgb = frame.convert()
+        assert rgb.color_space is ColorSpace.RGB and np.array_equal(rgb.numpy(), decode(raw[:DeviceVideoFrame.buffer_len(fmt, w, h)], w, h, layout))
+        adopted = DeviceVideoFrame.from_device_buffer(DeviceBuffer.from_numpy(raw[:DeviceVideoFrame.buffer_len(fmt, w, h)], gpu_stream), w, h, fmt)
+        dst = Image.zeros(w, h, 3, "uint8", gpu_stream)
+        assert adopted.to_rgb(dst) is dst and np.array_equal(dst.numpy(), rgb.numpy())
+    with pytest.raises(ImageError):
+        frame.to_rgb(Image.zeros(w + 2, h, 3, "uint8", gpu_stream))
