@@ -116,6 +116,12 @@ def gray_from_rgb(src: Image, dst: Optional[Image] = None) -> Image:
     return _map("gray_from_rgb", src, dst, 3, 1, ("uint8", "float32"), f64="gray_from_rgb")
 
 
+def gray_from_rgb_f32(src: Image, dst: Optional[Image] = None) -> Image:
+    """float32-only spelling kept by the Python stubs (imgproc.pyi:25)."""
+    _require(src, "float32", (3,), "gray_from_rgb_f32")
+    return gray_from_rgb(src, dst)
+
+
 def rgb_from_gray(src: Image, dst: Optional[Image] = None) -> Image:
     return _map("rgb_from_gray", src, dst, 1, 3, ("uint8", "float32"), f64="rgb_from_gray")
 
@@ -307,11 +313,12 @@ def _u8_bilinear_only(interpolation: str, what: str) -> None:
 
 
 def resize(src: Image, new_size: Optional[Tuple[int, int]] = None, interpolation: str = "bilinear",
-           out: Optional[Image] = None) -> Image:
-    """``new_size`` = (height, width) as in kornia_rs (imgproc.pyi:80-93).  uint8 images take the
-    antialiased u8 cascade (resize_fast_u8, P/resize/mod.rs:254), float32 the per-pixel resize."""
+           antialias: bool = True, out: Optional[Image] = None) -> Image:
+    """``resize(image, new_size, interpolation, antialias=True, out=None)`` with ``new_size`` = (height, width), as in
+    kornia_rs (imgproc.pyi:80-93).  uint8 images take the u8 cascade (resize_fast_u8_aa, P/resize/mod.rs:348; ``antialias``
+    shapes its bicubic / lanczos kernels), float32 the per-pixel resize (``antialias`` is ignored there, as in the reference)."""
     if src.dtype == "uint8":
-        return resize_fast(src, new_size, interpolation, True, out)
+        return resize_fast(src, new_size, interpolation, bool(antialias), out)
     mode = _interp(interpolation)
     dst, stream = _geom_pair(src, out, new_size, "resize")
     _check(lib.kh_resize_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
@@ -591,6 +598,18 @@ def normalize_mean_std(src: Image, mean: Sequence[float], std: Sequence[float], 
     return out
 
 
+def normalize_rgb_u8(src: Image, scale: Sequence[float], offset: Sequence[float], dst: Optional[Image] = None) -> Image:
+    """uint8 RGB -> float32 RGB, ``x * scale[c] + offset[c]`` (normalize_rgb_u8, P/normalize.rs:235-260)."""
+    _require(src, "uint8", (3,), "normalize_rgb_u8")
+    out = dst if dst is not None else _new_like(src, dtype="float32")
+    _require(out, "float32", (3,), "normalize_rgb_u8")
+    _same_size(src, out)
+    stream = _pair_residency(src, out)
+    _check(lib.kh_normalize_rgb_u8_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height,
+                                       _matrix(scale, 3, "normalize_rgb_u8"), _matrix(offset, 3, "normalize_rgb_u8")))
+    return out
+
+
 def find_min_max(src: Image) -> Tuple[float, float]:
     _require(src, "float32", tuple(range(1, 9)), "find_min_max")
     if not src.is_device:
@@ -750,12 +769,32 @@ def _morph(src: Image, kernel: Kernel, op: int, padding_mode: str, constant_valu
     return out
 
 
-def dilate(src: Image, kernel: Kernel, padding_mode: str = "constant", constant_value=0, dst: Optional[Image] = None) -> Image:
-    return _morph(src, kernel, _ffi.KH_MORPH_DILATE, padding_mode, constant_value, dst, "dilate")
+def _kernel_arg(kernel, size) -> Kernel:
+    """``Kernel`` object (Rust API, P/morphology/ops.rs:120) or the kornia-py spelling: a shape name plus ``size`` =
+    (height, width) (imgproc.pyi:127-147)."""
+    if isinstance(kernel, Kernel):
+        return kernel
+    h, w = size
+    if str(kernel).lower() in ("box", "cross") and h != w:  # parse_kernel, kornia-py/src/morphology.rs:9-27
+        raise ImageError("InvalidArgument", f"{kernel} kernel requires a square size")
+    return Kernel(kernel, (w, h))
 
 
-def erode(src: Image, kernel: Kernel, padding_mode: str = "constant", constant_value=0, dst: Optional[Image] = None) -> Image:
-    return _morph(src, kernel, _ffi.KH_MORPH_ERODE, padding_mode, constant_value, dst, "erode")
+def _border_arg(kernel, padding_mode: Optional[str], border: Optional[str]) -> str:
+    """The Rust API always names its PaddingMode; the Python stubs default ``border`` to "replicate" (morphology.rs:60)."""
+    return border or padding_mode or ("constant" if isinstance(kernel, Kernel) else "replicate")
+
+
+def dilate(src: Image, kernel="box", padding_mode: Optional[str] = None, constant_value=0, dst: Optional[Image] = None, *,
+           size: Tuple[int, int] = (3, 3), border: Optional[str] = None) -> Image:
+    return _morph(src, _kernel_arg(kernel, size), _ffi.KH_MORPH_DILATE, _border_arg(kernel, padding_mode, border), constant_value,
+                  dst, "dilate")
+
+
+def erode(src: Image, kernel="box", padding_mode: Optional[str] = None, constant_value=0, dst: Optional[Image] = None, *,
+          size: Tuple[int, int] = (3, 3), border: Optional[str] = None) -> Image:
+    return _morph(src, _kernel_arg(kernel, size), _ffi.KH_MORPH_ERODE, _border_arg(kernel, padding_mode, border), constant_value,
+                  dst, "erode")
 
 
 def morph_open(src: Image, kernel: Kernel, padding_mode: str = "constant", constant_value=0, dst: Optional[Image] = None) -> Image:

@@ -276,3 +276,39 @@ def test_device_video_frame_contract_without_a_device():  # P/cuda/color/video.r
     with pytest.raises(ImageError) as e:  # a host-resident buffer is not a device frame
         DeviceVideoFrame(Nv12(4, 2, np.zeros(12, np.uint8)))
     assert e.value.kind == "UnsupportedDevice"
+
+
+def test_kornia_py_spellings_resolve_before_the_residency_check():
+    """imgproc.pyi:80-160: resize(image, new_size, interpolation, antialias, out), dilate / erode(image, kernel="box",
+    size=(h, w), border=...), gray_from_rgb_f32, apply_colormap(image, name).  On host images each call must get past its
+    argument handling and stop at the typed residency error."""
+    from kornia_rs import Image, ImageError, imgproc
+    u8 = Image.from_numpy(np.zeros((8, 10, 3), np.uint8))
+    f32 = Image.from_numpy(np.zeros((8, 10, 3), np.float32))
+    calls = [lambda: imgproc.resize(u8, (4, 5), "lanczos", False), lambda: imgproc.resize(f32, (4, 5), "bicubic", True, None),
+             lambda: imgproc.dilate(u8, "cross", size=(5, 5), border="reflect101"), lambda: imgproc.erode(u8, kernel="ellipse", size=(5, 5)),
+             lambda: imgproc.dilate(u8, imgproc.Kernel("box", 3), "replicate"), lambda: imgproc.gray_from_rgb_f32(f32),
+             lambda: imgproc.normalize_rgb_u8(u8, (1, 1, 1), (0, 0, 0)),
+             lambda: imgproc.apply_colormap(Image.from_numpy(np.zeros((4, 4, 1), np.uint8)), "viridis"),
+             lambda: imgproc.resize_mapped(f32, (4, 5), "bilinear", "align_corners"),
+             lambda: imgproc.resize_bilinear_normalize(f32, (4, 5), (0, 0, 0), (1, 1, 1))]
+    for call in calls:
+        with pytest.raises(ImageError) as e:
+            call()
+        assert e.value.kind == "HostPathUnavailable", e.value
+    k = imgproc._kernel_arg("ellipse", (3, 5))  # size is (height, width) in the Python API
+    assert (k.height, k.width) == (3, 5)
+    with pytest.raises(ImageError) as e:  # parse_kernel (kornia-py/src/morphology.rs:9-27): box / cross are square
+        imgproc.dilate(u8, "cross", size=(3, 5))
+    assert "square" in str(e.value)
+    assert imgproc._border_arg("box", None, None) == "replicate" and imgproc._border_arg(k, None, None) == "constant"
+    assert imgproc._border_arg("box", None, "wrap") == "wrap" and imgproc._border_arg(k, "reflect", None) == "reflect"
+    with pytest.raises(ImageError) as e:
+        imgproc.gray_from_rgb_f32(u8)
+    assert e.value.kind == "NoDeviceKernel"
+    with pytest.raises(ImageError) as e:
+        imgproc.dilate(u8, "star")
+    assert e.value.kind == "InvalidKernelShape"
+    with pytest.raises(ImageError) as e:
+        imgproc.resize_mapped(f32, (4, 5), "bilinear", "corner")
+    assert e.value.kind in ("InvalidArgument", "HostPathUnavailable")

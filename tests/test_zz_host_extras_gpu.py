@@ -229,3 +229,23 @@ def test_device_video_frame_convert_matches_cpu(gpu_stream):  # P/cuda/color/vid
         assert adopted.to_rgb(dst) is dst and np.array_equal(dst.numpy(), rgb.numpy())
     with pytest.raises(ImageError):
         frame.to_rgb(Image.zeros(w + 2, h, 3, "uint8", gpu_stream))
+
+
+def test_kornia_py_spellings_on_device(gpu_stream):  # imgproc.pyi:80-160
+    from kornia_rs import Image, imgproc
+    rgb = O.pattern_u8(3 * 61 * 47).reshape(47, 61, 3)
+    dev = Image.from_numpy(rgb).to_hip(gpu_stream)
+    # resize(image, new_size, interpolation, antialias): antialias reaches the u8 separable kernels
+    for aa in (True, False):
+        got = imgproc.resize(dev, (20, 25), "lanczos", aa).numpy()
+        assert np.array_equal(got, O.resize_fast_u8(rgb, 25, 20, "lanczos", aa)[0]), aa
+    # dilate / erode(image, kernel="box", size=(h, w), border="replicate")
+    assert np.array_equal(imgproc.dilate(dev).numpy(), O.morphology_u8(rgb, "dilate", O.morph_kernel("box", 3), "replicate"))
+    got = imgproc.erode(dev, "ellipse", size=(3, 5), border="reflect101").numpy()
+    assert np.array_equal(got, O.morphology_u8(rgb, "erode", O.morph_kernel("ellipse", 5, 3), "reflect101"))
+    # normalize_rgb_u8: x * scale + offset (plain mul-add, the scalar expression)
+    scale, offset = np.array([0.5, 0.25, 2.0], np.float32), np.array([-1.0, 0.5, 3.0], np.float32)
+    got = imgproc.normalize_rgb_u8(dev, scale, offset).numpy()
+    assert got.dtype == np.float32 and np.array_equal(got, (rgb.astype(np.float32) * scale + offset).astype(np.float32))
+    f = Image.from_numpy(O.pattern_f32(3 * 61 * 47).reshape(47, 61, 3)).to_hip(gpu_stream)
+    assert np.array_equal(imgproc.gray_from_rgb_f32(f).numpy().reshape(-1), O.color_map("gray_from_rgb_f32", f.numpy(), 1))
