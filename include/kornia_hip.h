@@ -72,10 +72,24 @@ KH_API int32_t kh_get_device(int32_t* device);
 KH_API int32_t kh_device_info(int32_t device, char* name, size_t name_cap, int32_t* cu_count,
                               uint64_t* total_mem_bytes);
 
+/* free / total bytes of the current device (cuMemGetInfo; kornia_rs.cuda.mem_get_info).            */
+KH_API int32_t kh_mem_get_info(uint64_t* free_bytes, uint64_t* total_bytes);
+
 KH_API int32_t kh_stream_create(kh_stream_t* out);            /* non-blocking stream on the current device */
 KH_API int32_t kh_stream_destroy(kh_stream_t stream);
 KH_API int32_t kh_stream_synchronize(kh_stream_t stream);     /* T/cuda.rs:1258 to_host sync */
 KH_API int32_t kh_stream_wait_event(kh_stream_t stream, kh_event_t event);
+
+/* Stream capture -> executable graph: replaces kornia_rs.cuda.Graph.{capture, replay}
+ * (PY/cuda_ext/mod.rs:1684-1790: cudarc begin_capture(THREAD_LOCAL) / end_capture / launch).  Everything
+ * enqueued on `stream` between begin and end is recorded instead of run; kh_graph_launch replays it.  The
+ * recorded work must be allocation-free (preallocated outputs), as the reference requires; an empty
+ * capture is an error.  kh_graph_capture_end always ends the capture, also when it fails.           */
+typedef struct kh_graph_s* kh_graph_t;
+KH_API int32_t kh_graph_capture_begin(kh_stream_t stream);
+KH_API int32_t kh_graph_capture_end(kh_stream_t stream, kh_graph_t* out);
+KH_API int32_t kh_graph_launch(kh_graph_t graph, kh_stream_t stream);
+KH_API int32_t kh_graph_destroy(kh_graph_t graph);
 
 KH_API int32_t kh_event_create(kh_event_t* out, int32_t enable_timing);
 KH_API int32_t kh_event_destroy(kh_event_t event);

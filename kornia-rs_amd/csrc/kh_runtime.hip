@@ -157,6 +157,64 @@ int32_t kh_stream_fence(kh_stream_t producer, kh_stream_t consumer) {
     return KH_OK;
 }
 
+// cuMemGetInfo twin (kornia_rs.cuda.mem_get_info, PY/cuda_ext/mod.rs): free / total bytes of the current device.
+int32_t kh_mem_get_info(uint64_t* free_bytes, uint64_t* total_bytes) {
+    KH_REQUIRE(free_bytes && total_bytes, KH_ERR_INVALID_ARG, "kh_mem_get_info: null output");
+    size_t f = 0, t = 0;
+    KH_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes = f; *total_bytes = t;
+    return KH_OK;
+}
+
+// ---- stream capture -> executable graph (kornia_rs.cuda.Graph, PY/cuda_ext/mod.rs:1684-1790) -------------------
+// Record the launches a caller enqueues on `stream` between begin and end into a hipGraph and replay them at the
+// cost of one launch.  Thread-local capture mode, as the reference uses.  The captured work must be allocation-free
+// (preallocated outputs): the launchers that take stream-ordered scratch say so in the header.
+struct kh_graph_s { hipGraph_t graph; hipGraphExec_t exec; };
+
+int32_t kh_graph_capture_begin(kh_stream_t stream) {
+    KH_REQUIRE(stream, KH_ERR_INVALID_ARG, "kh_graph_capture_begin: capture needs a non-default stream");
+    KH_HIP(hipStreamBeginCapture(as_hip(stream), hipStreamCaptureModeThreadLocal));
+    return KH_OK;
+}
+
+int32_t kh_graph_capture_end(kh_stream_t stream, kh_graph_t* out) {
+    KH_REQUIRE(stream && out, KH_ERR_INVALID_ARG, "kh_graph_capture_end: null argument");
+    *out = nullptr;
+    hipGraph_t g = nullptr;
+    KH_HIP(hipStreamEndCapture(as_hip(stream), &g));  // always ends the capture, so the stream is usable again
+    KH_REQUIRE(g, KH_ERR_INVALID_ARG, "kh_graph_capture_end: nothing was captured (no device work was enqueued on this stream)");
+    size_t nodes = 0;
+    hipError_t r = hipGraphGetNodes(g, nullptr, &nodes);
+    if (r == hipSuccess && nodes == 0) {
+        (void)hipGraphDestroy(g);
+        return fail(KH_ERR_INVALID_ARG, "kh_graph_capture_end: nothing was captured (no device work was enqueued on this stream)");
+    }
+    hipGraphExec_t exec = nullptr;
+    if (r == hipSuccess) r = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    if (r != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return fail_hip(r, "kh_graph_capture_end");
+    }
+    *out = new kh_graph_s{g, exec};
+    return KH_OK;
+}
+
+int32_t kh_graph_launch(kh_graph_t graph, kh_stream_t stream) {
+    KH_REQUIRE(graph, KH_ERR_INVALID_ARG, "kh_graph_launch: null graph");
+    KH_HIP(hipGraphLaunch(graph->exec, as_hip(stream)));
+    return KH_OK;
+}
+
+int32_t kh_graph_destroy(kh_graph_t graph) {
+    if (!graph) return KH_OK;
+    hipError_t a = hipGraphExecDestroy(graph->exec), b = hipGraphDestroy(graph->graph);
+    delete graph;
+    if (a != hipSuccess) return fail_hip(a, "kh_graph_destroy");
+    if (b != hipSuccess) return fail_hip(b, "kh_graph_destroy");
+    return KH_OK;
+}
+
 // The default mem-pool trims itself to the release threshold (0) at every synchronisation point.
 // The reference raises the threshold so steady-state alloc/free never goes back to the driver
 // (crates/kornia-tensor/src/cuda.rs:238-262); here it is also a correctness matter: on ROCm 7.2 /

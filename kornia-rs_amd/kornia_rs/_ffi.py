@@ -85,6 +85,11 @@ SIGNATURES = {
     "kh_set_device": (_i32, [_i32]),
     "kh_get_device": (_i32, [_P(_i32)]),
     "kh_device_info": (_i32, [_i32, C.c_char_p, _sz, _P(_i32), _P(_u64)]),
+    "kh_mem_get_info": (_i32, [_P(_u64), _P(_u64)]),
+    "kh_graph_capture_begin": (_i32, [_vp]),
+    "kh_graph_capture_end": (_i32, [_vp, _P(_vp)]),
+    "kh_graph_launch": (_i32, [_vp, _vp]),
+    "kh_graph_destroy": (_i32, [_vp]),
     "kh_stream_create": (_i32, [_P(_vp)]),
     "kh_stream_destroy": (_i32, [_vp]),
     "kh_stream_synchronize": (_i32, [_vp]),

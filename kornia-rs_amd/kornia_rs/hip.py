@@ -51,6 +51,15 @@ def device_info(device: int = 0) -> Tuple[str, int, int]:
     return name.value.decode(), int(cu.value), int(mem.value)
 
 
+def mem_get_info() -> Tuple[int, int]:
+    """``(free, total)`` bytes of the current device (cuda.pyi:64-70; the default stream is synchronised first, so a
+    loop can be bracketed with it to assert that no device memory leaked)."""
+    check(lib.kh_stream_synchronize(None))
+    free, total = C.c_uint64(0), C.c_uint64(0)
+    check(lib.kh_mem_get_info(C.byref(free), C.byref(total)))
+    return int(free.value), int(total.value)
+
+
 class Stream:
     """A HIP stream handle.  The stream's device selects where ``Image.to_hip(stream)`` /
     ``Image.zeros(..., stream=stream)`` place data."""
@@ -147,6 +156,47 @@ class Event:
             except Exception:
                 pass
             self._handle = None
+
+
+class Graph:
+    """A captured graph: record once, replay per frame at the cost of one launch (``kornia_rs.cuda.Graph``,
+    cuda.pyi:80-90, PY/cuda_ext/mod.rs:1684-1790).  Capture requires allocation-free ops — pass preallocated ``out=`` /
+    ``dst=`` device images — on a non-default stream (``Stream.new()``), with the operands allocated on that same
+    stream.  ``retain`` keeps the operand objects (and their device memory) alive as long as the graph."""
+
+    def __init__(self, handle: int, stream: Stream, retain):
+        self._handle, self.stream, self._retained = handle, stream, list(retain)
+
+    @staticmethod
+    def capture(f, retain, stream: Optional[Stream] = None) -> "Graph":
+        if stream is None or not stream.cuda_stream_ptr:
+            raise _ffi.KorniaHipError(_ffi.KH_ERR_INVALID_ARG, "Graph.capture: capture needs a non-default stream (Stream.new())")
+        check(lib.kh_graph_capture_begin(stream.cuda_stream_ptr))
+        error = None
+        try:
+            f()
+        except BaseException as e:  # always end the capture so the stream is usable again, then surface the error
+            error = e
+        handle = C.c_void_p()
+        rc = lib.kh_graph_capture_end(stream.cuda_stream_ptr, C.byref(handle))
+        if error is not None:
+            if rc == _ffi.KH_OK:
+                lib.kh_graph_destroy(handle)
+            raise error
+        if rc != _ffi.KH_OK:
+            msg = _ffi.last_error()
+            if "nothing was captured" in msg:
+                raise ValueError("Graph.capture: nothing was captured (the callable enqueued no device work on this stream)")
+            check(rc)
+        return Graph(handle.value, stream, retain)
+
+    def replay(self) -> None:
+        check(lib.kh_graph_launch(self._handle, self.stream.cuda_stream_ptr))
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            lib.kh_graph_destroy(h)
 
 
 def d2h(out: np.ndarray, device_ptr: int, stream: Stream) -> None:

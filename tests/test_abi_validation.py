@@ -90,6 +90,11 @@ CASES = [
     ("crop: window outside", lambda: L.kh_crop(S, P, Q, 8, 8, 4, 4, 6, 6, 3), INVALID, "out of bounds"),
     ("crop: negative origin", lambda: L.kh_crop(S, P, Q, 8, 8, 4, 4, -1, 0, 3), INVALID, "negative"),
     ("flip: negative width", lambda: L.kh_flip(S, P, Q, -1, 8, 3, 1), INVALID, "geometry"),
+    # ---- runtime: graphs
+    ("graph capture: default stream", lambda: L.kh_graph_capture_begin(None), INVALID, "non-default stream"),
+    ("graph capture end: null out", lambda: L.kh_graph_capture_end(C.c_void_p(P), None), INVALID, "null"),
+    ("graph launch: null graph", lambda: L.kh_graph_launch(None, None), INVALID, "null graph"),
+    ("mem_get_info: null outputs", lambda: L.kh_mem_get_info(None, None), INVALID, "null"),
     # ---- fused pipelines
     ("fused pipeline: no stages", lambda: L.kh_fused_pipeline_build(None, 3, 8, 8, 1, 0, C.byref(C.c_void_p())), INVALID, "stage"),
 ]
@@ -114,3 +119,4 @@ def test_empty_batches_and_images_are_no_ops_without_a_device():
     assert L.kh_color_convert_f64(S, None, None, 0, 12) == 0
     assert L.kh_yuyv_to_rgb_mode_u8(S, None, None, 1, 9, 0) == 0  # width 1: no whole pixel pair
     assert L.kh_flip(S, P, Q, 0, 8, 3, 1) == 0
+    assert L.kh_graph_destroy(None) == 0

@@ -312,3 +312,14 @@ def test_kornia_py_spellings_resolve_before_the_residency_check():
     with pytest.raises(ImageError) as e:
         imgproc.resize_mapped(f32, (4, 5), "bilinear", "corner")
     assert e.value.kind in ("InvalidArgument", "HostPathUnavailable")
+
+
+def test_graph_and_mem_info_fail_loudly_without_a_device():  # cuda.pyi:64-90
+    from kornia_rs import _ffi, hip
+    if hip.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_ffi.KorniaHipError):
+        hip.mem_get_info()
+    with pytest.raises(_ffi.KorniaHipError) as e:  # the default stream cannot be captured
+        hip.Graph.capture(lambda: None, [], None)
+    assert e.value.code == _ffi.KH_ERR_INVALID_ARG

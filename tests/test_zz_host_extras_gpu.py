@@ -249,3 +249,51 @@ def test_kornia_py_spellings_on_device(gpu_stream):  # imgproc.pyi:80-160
     assert got.dtype == np.float32 and np.array_equal(got, (rgb.astype(np.float32) * scale + offset).astype(np.float32))
     f = Image.from_numpy(O.pattern_f32(3 * 61 * 47).reshape(47, 61, 3)).to_hip(gpu_stream)
     assert np.array_equal(imgproc.gray_from_rgb_f32(f).numpy().reshape(-1), O.color_map("gray_from_rgb_f32", f.numpy(), 1))
+
+
+# ---- kornia_rs.cuda.Graph / mem_get_info (cuda.pyi:64-90, PY/cuda_ext/mod.rs:1684-1790) ------------------------------
+
+def test_graph_capture_and_replay(gpu_stream):
+    from kornia_rs import Image, hip, imgproc
+    stream = hip.Stream.new(0)  # capture needs a non-default stream; operands live on it
+    w, h = 64, 48
+    rgb0 = O.pattern_u8(3 * w * h).reshape(h, w, 3)
+    src = Image.from_numpy(rgb0).to_hip(stream)
+    gray, small, blur = Image.zeros(w, h, 1, "uint8", stream), Image.zeros(32, 24, 3, "uint8", stream), Image.zeros(w, h, 3, "uint8", stream)
+    stream.synchronize()
+
+    def frame():  # allocation-free: every op writes into a preallocated destination
+        imgproc.gray_from_rgb(src, gray)
+        imgproc.resize(src, (24, 32), "nearest", True, small)
+        imgproc.gaussian_blur(src, (5, 5), (1.2, 1.2), blur)
+
+    free0, total = hip.mem_get_info()
+    assert 0 < free0 <= total
+    graph = hip.Graph.capture(frame, [src, gray, small, blur], stream)
+    stream.synchronize()
+    assert not gray.numpy().any()  # capture records, it does not run
+    for k in range(3):  # new pixels in the same device memory, one launch per frame
+        rgb = np.roll(rgb0, 7 * k + 1, axis=1).copy()
+        _upload(src, rgb)
+        graph.replay()
+        stream.synchronize()
+        assert np.array_equal(gray.numpy().reshape(-1), O.color_map("gray_from_rgb_u8", rgb, 1)), k
+        assert np.array_equal(small.numpy(), O.resize_fast_u8(rgb, 32, 24, "nearest", True)[0]), k
+        assert np.array_equal(blur.numpy(), O.gaussian_blur_u8(rgb, (5, 5), (1.2, 1.2))), k
+    with pytest.raises(ValueError):
+        hip.Graph.capture(lambda: None, [], stream)  # nothing enqueued
+    with pytest.raises(ZeroDivisionError):  # the callable's own error surfaces, and the stream is usable afterwards
+        hip.Graph.capture(lambda: 1 / 0, [], stream)
+    imgproc.gray_from_rgb(src, gray)
+    stream.synchronize()
+    free1, _ = hip.mem_get_info()
+    assert abs(free1 - free0) <= 64 << 20  # no per-replay allocations
+
+
+def _upload(img, array):
+    """Overwrite a device image's pixels in place (same allocation, so a captured graph sees the new frame)."""
+    from kornia_rs import _ffi
+    a = np.ascontiguousarray(array)
+    img.stream.synchronize()
+    _ffi.check(_ffi.lib.kh_memcpy_h2d_async(img.data_ptr, a.ctypes.data, a.nbytes, img.stream.cuda_stream_ptr))
+    img.stream.synchronize()
