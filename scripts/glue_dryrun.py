@@ -4,7 +4,8 @@
 
 The mock is generated from kornia_rs/_ffi.py::SIGNATURES: "device" memory is host malloc, copies are memcpy, streams /
 events / graphs are dummy handles, host-only helpers (matrix inversion, kernel taps, ...) forward to the REAL library,
-and every compute entry returns KH_OK WITHOUT computing anything.  So value assertions are expected to fail; what must
+and every compute entry runs the REAL library's argument validation (which stops with KH_ERR_HIP once it reaches the missing
+device — reported as KH_OK) WITHOUT computing anything.  So value assertions are expected to fail; what must
 not happen is any other exception.  Nothing here touches the product: a copy of the tree with the mock in place of the
 library is made under a temporary directory and pytest runs there.
 
@@ -29,10 +30,10 @@ sys.path.insert(0, os.path.join(ROOT, "kornia-rs_amd"))
 # host-only entries: forwarded to the real library (they never touch the HIP runtime)
 FORWARD = {"kh_invert_affine_transform", "kh_get_rotation_matrix2d", "kh_invert_homography", "kh_box_blur_kernel_1d",
            "kh_gaussian_kernel_1d", "kh_gaussian_resolve", "kh_quantize_kernel_256", "kh_morph_kernel", "kh_pixel_mapping_coeffs",
-           "kh_debug_fast_quot", "kh_preprocess_variant", "kh_version"}
+           "kh_debug_fast_quot", "kh_preprocess_variant", "kh_version", "kh_last_error", "kh_fused_pipeline_build",
+           "kh_fused_pipeline_describe", "kh_fused_pipeline_destroy"}
 
 SPECIAL = {
-    "kh_last_error": "{ const char* m = \"mock: no message\"; size_t n = strlen(m); if (a0 && a1) { strncpy((char*)a0, m, a1 - 1); ((char*)a0)[a1 - 1] = 0; } return n; }",
     "kh_device_count": "{ if (a0) *(int32_t*)a0 = 1; return 0; }",
     "kh_get_device": "{ if (a0) *(int32_t*)a0 = 0; return 0; }",
     "kh_device_info": "{ if (a1 && a2) { strncpy((char*)a1, \"mock gfx950\", a2 - 1); ((char*)a1)[a2 - 1] = 0; } if (a3) *(int32_t*)a3 = 256; if (a4) *(uint64_t*)a4 = 288ull << 30; return 0; }",
@@ -53,11 +54,10 @@ SPECIAL = {
     "kh_memset_async": "{ if (a2) memset(a0, a1, a2); return 0; }",
     "kh_pointer_domain": "{ if (a1) *(int32_t*)a1 = 1; if (a2) *(int32_t*)a2 = 0; return 0; }",
     "kh_mem_get_info": "{ if (a0) *(uint64_t*)a0 = 200ull << 30; if (a1) *(uint64_t*)a1 = 288ull << 30; return 0; }",
+    "kh_graph_capture_begin": "{ return a0 ? 0 : -1; }",
+    "kh_graph_launch": "{ return a0 ? 0 : -1; }",
     "kh_graph_capture_end": "{ *(void**)a1 = malloc(8); return 0; }",
     "kh_graph_destroy": "{ free(a0); return 0; }",
-    "kh_fused_pipeline_build": "{ *(void**)a6 = malloc(8); return 0; }",
-    "kh_fused_pipeline_describe": "{ const char* m = \"mock pipeline\"; if (a1 && a2) { strncpy((char*)a1, m, a2 - 1); ((char*)a1)[a2 - 1] = 0; } return (int32_t)strlen(m); }",
-    "kh_fused_pipeline_destroy": "{ free(a0); }",
     "kh_find_min_max_f32": "{ if (a3) *(float*)a3 = 0.0f; if (a4) *(float*)a4 = 1.0f; return 0; }",
 }
 
@@ -83,14 +83,64 @@ def generate(signatures, real_lib):
             body = "{ " + ("" if rt == "void" else "return ") + call + "; }"
         elif name in SPECIAL:
             body = SPECIAL[name]
+        elif rt == "int32_t":
+            # compute entry: let the REAL library validate the arguments (it fails with KH_ERR_HIP = -2 only once it reaches
+            # the device, i.e. after validation passed) and report success in its place — nothing is computed
+            types = ", ".join(ctype(a) for a in args) or "void"
+            call = f"((int32_t (*)({types}))real(\"{name}\"))({', '.join(f'a{i}' for i in range(len(args)))})"
+            body = "{ int32_t rc = " + call + "; return rc == -2 ? 0 : rc; }"
         else:
             body = "{ " + ("" if rt == "void" else "return 0;") + " }"
         out.append(f"{rt} {name}({params}) {body}")
     return "\n".join(out) + "\n"
 
 
+BENCH_SNIPPET = r"""
+import importlib.util, sys
+sys.path.insert(0, "kornia-rs_amd")
+spec = importlib.util.spec_from_file_location("bench", "bench.py")
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+from kornia_rs import hip
+class Args: batch = 2
+stream = hip.Stream.new(0)
+for name, make in bench.WORKLOADS.items():
+    wl = make(Args)
+    wl.setup(stream)
+    wl.step(); wl.step()
+    stream.synchronize()
+    d = wl.describe()
+    assert d["workload"] == wl.name and wl.alg_bytes_per_launch > 0 and wl.units_per_step > 0, name
+    print("ok", name, flush=True)
+"""
+
+
+def mock_tree(tmp):
+    from kornia_rs import _ffi
+    tree = os.path.join(tmp, "repo")
+    shutil.copytree(ROOT, tree, ignore=shutil.ignore_patterns(".git", "gpurun_out", "profiles", "__pycache__", "build", ".pytest_cache"))
+    real = os.path.join(tmp, "libkornia_hip_real.so")
+    shutil.copy(_ffi.LIB_PATH, real)
+    src = os.path.join(tmp, "mock.c")
+    open(src, "w").write(generate(_ffi.SIGNATURES, real))
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-w", src, "-o", os.path.join(tree, "kornia-rs_amd", "lib", "libkornia_hip.so"), "-ldl"])
+    return tree
+
+
+def bench_dryrun():
+    """Every bench workload: setup / step / describe at batch 2 against the mock (no torch, no timing)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        tree = mock_tree(tmp)
+        r = subprocess.run([sys.executable, "-c", BENCH_SNIPPET], cwd=tree, capture_output=True, text=True)
+    print(r.stdout, end="")
+    if r.returncode:
+        print(r.stderr[-2000:])
+    return r.returncode
+
+
 def main():
     from kornia_rs import _ffi
+    if "--bench" in sys.argv[1:]:
+        return bench_dryrun()
     no_asserts = "--no-asserts" in sys.argv[1:]
     args = [a for a in sys.argv[1:] if a != "--no-asserts"] or ["tests", "-m", "gpu"]
     with tempfile.TemporaryDirectory() as tmp:
