@@ -344,6 +344,358 @@ inline void normalize_mean_std(const Image<float, C>& src, Image<float, C>& dst,
                                             std_.data()));
 }
 
+
+// ---- the rest of the operator surface (same residency rules; every call cites the Rust function it mirrors) ------
+
+namespace helpers {
+template <typename TS, int CS, typename TD, int CD>
+inline const Stream& map_pair(const Image<TS, CS>& src, const Image<TD, CD>& dst, const char* what) {
+    const Stream& s = detail::device_exec_for(src, dst, what);
+    if (src.size() != dst.size()) throw ImageError(ImageError::Kind::InvalidImageSize, std::string(what) + ": image sizes differ");
+    return s;
+}
+template <typename T, int C>
+inline int64_t npixels(const Image<T, C>& im) { return (int64_t)(im.width() * im.height()); }
+}  // namespace helpers
+
+// color::rgb_from_gray / bgr_from_rgb / rgba_from_rgb / bgra_from_rgb / rgb_from_rgba / rgb_from_bgra (P/color/gray/mod.rs:241,
+// P/color/rgb/mod.rs:60-330)
+inline void rgb_from_gray(const Image<uint8_t, 1>& src, Image<uint8_t, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "rgb_from_gray");  // classify operands BEFORE touching device pointers
+    detail::check(kh_rgb_from_gray_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
+}
+inline void rgb_from_gray(const Image<float, 1>& src, Image<float, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "rgb_from_gray");  // classify operands BEFORE touching device pointers
+    detail::check(kh_rgb_from_gray_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
+}
+inline void bgr_from_rgb(const Image<uint8_t, 3>& src, Image<uint8_t, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "bgr_from_rgb");  // classify operands BEFORE touching device pointers
+    detail::check(kh_bgr_from_rgb_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
+}
+inline void bgr_from_rgb(const Image<float, 3>& src, Image<float, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "bgr_from_rgb");  // classify operands BEFORE touching device pointers
+    detail::check(kh_bgr_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
+}
+inline void rgba_from_rgb(const Image<uint8_t, 3>& src, Image<uint8_t, 4>& dst, bool bgra = false) {
+    const Stream& s = helpers::map_pair(src, dst, "rgba_from_rgb");  // classify operands BEFORE touching device pointers
+    detail::check(kh_rgba_from_rgb_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), bgra ? 1 : 0));
+}
+inline void rgba_from_rgb(const Image<float, 3>& src, Image<float, 4>& dst, bool bgra = false) {
+    const Stream& s = helpers::map_pair(src, dst, "rgba_from_rgb");  // classify operands BEFORE touching device pointers
+    detail::check(kh_rgba_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), bgra ? 1 : 0));
+}
+// `background` = nullptr drops alpha, else blends over the RGB triple (rgb_from_rgba, P/color/rgb/mod.rs:60-126); `bgra` swaps R and B
+inline void rgb_from_rgba(const Image<uint8_t, 4>& src, Image<uint8_t, 3>& dst, const std::array<uint8_t, 3>* background = nullptr, bool bgra = false) {
+    const Stream& s = helpers::map_pair(src, dst, "rgb_from_rgba");  // classify operands BEFORE touching device pointers
+    detail::check(kh_rgb_from_rgba_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src),
+                                      bgra ? 1 : 0, background ? background->data() : nullptr));
+}
+
+// color::ycbcr_from_rgb / yuv_from_rgb and inverses (P/color/yuv/mod.rs:150-185)
+enum class ChromaOrder { YCrCb = KH_YCC_YCRCB, YuvCbCr = KH_YCC_YUV };
+inline void ycc_from_rgb(const Image<uint8_t, 3>& src, Image<uint8_t, 3>& dst, ChromaOrder order) {
+    const Stream& s = helpers::map_pair(src, dst, "ycc_from_rgb");  // classify operands BEFORE touching device pointers
+    detail::check(kh_ycc_from_rgb_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), (int32_t)order));
+}
+inline void rgb_from_ycc(const Image<uint8_t, 3>& src, Image<uint8_t, 3>& dst, ChromaOrder order) {
+    const Stream& s = helpers::map_pair(src, dst, "rgb_from_ycc");  // classify operands BEFORE touching device pointers
+    detail::check(kh_rgb_from_ycc_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), (int32_t)order));
+}
+inline void ycc_from_rgb(const Image<float, 3>& src, Image<float, 3>& dst, ChromaOrder order) {
+    const Stream& s = helpers::map_pair(src, dst, "ycc_from_rgb");  // classify operands BEFORE touching device pointers
+    detail::check(kh_ycc_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), (int32_t)order));
+}
+inline void rgb_from_ycc(const Image<float, 3>& src, Image<float, 3>& dst, ChromaOrder order) {
+    const Stream& s = helpers::map_pair(src, dst, "rgb_from_ycc");  // classify operands BEFORE touching device pointers
+    detail::check(kh_rgb_from_ycc_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), (int32_t)order));
+}
+
+// color::{hsv,hls}_from_rgb and inverses, sepia_from_rgb (P/color/hsv/mod.rs, P/color/hls/mod.rs, P/color/sepia.rs); [0, 255] domain
+inline void hsv_from_rgb(const Image<float, 3>& src, Image<float, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "hsv_from_rgb");  // classify operands BEFORE touching device pointers
+    detail::check(kh_hsv_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
+}
+inline void rgb_from_hsv(const Image<float, 3>& src, Image<float, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "rgb_from_hsv");  // classify operands BEFORE touching device pointers
+    detail::check(kh_rgb_from_hsv_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
+}
+inline void hls_from_rgb(const Image<float, 3>& src, Image<float, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "hls_from_rgb");  // classify operands BEFORE touching device pointers
+    detail::check(kh_hls_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
+}
+inline void rgb_from_hls(const Image<float, 3>& src, Image<float, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "rgb_from_hls");  // classify operands BEFORE touching device pointers
+    detail::check(kh_rgb_from_hls_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
+}
+inline void sepia_from_rgb(const Image<uint8_t, 3>& src, Image<uint8_t, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "sepia_from_rgb");  // classify operands BEFORE touching device pointers
+    detail::check(kh_sepia_from_rgb_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
+}
+inline void sepia_from_rgb(const Image<float, 3>& src, Image<float, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "sepia_from_rgb");  // classify operands BEFORE touching device pointers
+    detail::check(kh_sepia_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
+}
+
+// CIE family (P/color/cie/mod.rs:58-160) for f32, and every f64 colour conversion (gray, hsv / hls, ycbcr / yuv, CIE:
+// P/color/cuda_dispatch.rs:48-61,111-135).  `conversion` is a KH_CIE_* (both) or KH_F64_* (f64) code.
+inline void cie_convert(const Image<float, 3>& src, Image<float, 3>& dst, int conversion) {
+    const Stream& s = helpers::map_pair(src, dst, "cie_convert");  // classify operands BEFORE touching device pointers
+    detail::check(kh_cie_convert_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), conversion));
+}
+template <int CS, int CD>
+inline void color_convert_f64(const Image<double, CS>& src, Image<double, CD>& dst, int conversion) {
+    const int want_in = conversion == KH_F64_RGB_FROM_GRAY ? 1 : 3, want_out = conversion == KH_F64_GRAY_FROM_RGB ? 1 : 3;
+    if (CS != want_in || CD != want_out)
+        throw ImageError(ImageError::Kind::InvalidChannelShape, "color_convert_f64: conversion " + std::to_string(conversion) + " maps " +
+                                                                     std::to_string(want_in) + " -> " + std::to_string(want_out) + " channels");
+    const Stream& s = helpers::map_pair(src, dst, "color_convert_f64");  // classify operands BEFORE touching device pointers
+    detail::check(kh_color_convert_f64(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), conversion));
+}
+
+// color::apply_colormap with a caller-provided table r[256] g[256] b[256] (P/color/colormap.rs:252-300)
+inline void apply_colormap(const Image<uint8_t, 1>& src, Image<uint8_t, 3>& dst, const std::array<uint8_t, 768>& lut) {
+    const Stream& s = helpers::map_pair(src, dst, "apply_colormap");
+    void* dlut = nullptr;
+    detail::check(kh_malloc_async(&dlut, 768, 0, s.handle()));
+    int32_t rc = kh_memcpy_h2d_async(dlut, lut.data(), 768, s.handle());
+    if (rc == KH_OK) rc = kh_stream_synchronize(s.handle());  // the table is caller memory: land it before returning
+    if (rc == KH_OK) rc = kh_apply_colormap_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), static_cast<const uint8_t*>(dlut));
+    kh_free_async(dlut, s.handle());
+    detail::check(rc);
+}
+
+// camera formats <-> RGB8 (P/color/yuv/mod.rs:209-310, 342): raw device buffers in, RGB8 image out (or back)
+enum class Planar420 { Nv12 = 0, Nv21 = 1, I420 = 2, Yv12 = 3 };
+enum class Packed422 { Yuyv = 0, Uyvy = 1, Yvyu = 2 };
+enum class YuvToRgbMode { Bt601Full = KH_YUV_BT601_FULL, Bt709Full = KH_YUV_BT709_FULL, Bt601Limited = KH_YUV_BT601_LIMITED };
+namespace helpers {
+inline const Stream& raw_to_image(const Image<uint8_t, 3>& dst, const uint8_t* raw, size_t have, size_t need, const char* what) {
+    if (!dst.is_device()) throw ImageError(ImageError::Kind::HostPathUnavailable, std::string(what) + ": host image — device backend only");
+    if (!raw || have < need) throw ImageError(ImageError::Kind::InvalidImageSize, std::string(what) + ": buffer holds " + std::to_string(have) + " bytes, the format needs " + std::to_string(need));
+    return *dst.stream();
+}
+}  // namespace helpers
+inline void rgb_from_planar420(const uint8_t* raw_device, size_t raw_bytes, Image<uint8_t, 3>& dst, Planar420 layout) {
+    const Stream& s = helpers::raw_to_image(dst, raw_device, raw_bytes, dst.width() * dst.height() * 3 / 2, "rgb_from_planar420");
+    detail::check(kh_rgb_from_planar420_u8(s.handle(), raw_device, dst.device_ptr_mut(), detail::i32(dst.width()), detail::i32(dst.height()), (int32_t)layout));
+}
+inline void rgb_from_packed422(const uint8_t* raw_device, size_t raw_bytes, Image<uint8_t, 3>& dst, Packed422 layout) {
+    const Stream& s = helpers::raw_to_image(dst, raw_device, raw_bytes, dst.width() * dst.height() * 2, "rgb_from_packed422");
+    detail::check(kh_rgb_from_packed422_u8(s.handle(), raw_device, dst.device_ptr_mut(), detail::i32(dst.width()), detail::i32(dst.height()), (int32_t)layout));
+}
+inline void convert_yuyv_to_rgb_u8(const uint8_t* raw_device, size_t raw_bytes, Image<uint8_t, 3>& dst, YuvToRgbMode mode) {
+    const Stream& s = helpers::raw_to_image(dst, raw_device, raw_bytes, dst.width() * dst.height() * 2, "convert_yuyv_to_rgb_u8");
+    detail::check(kh_yuyv_to_rgb_mode_u8(s.handle(), raw_device, dst.device_ptr_mut(), detail::i32(dst.width()), detail::i32(dst.height()), (int32_t)mode));
+}
+// encoders write width*height*3/2 (NV12) or width*height*2 (YUYV) bytes at `out_device`
+inline void nv12_from_rgb(const Image<uint8_t, 3>& src, uint8_t* out_device) {
+    if (!src.is_device()) throw ImageError(ImageError::Kind::HostPathUnavailable, "nv12_from_rgb: host image — device backend only");
+    detail::check(kh_nv12_from_rgb_u8(src.stream()->handle(), src.device_ptr(), out_device, detail::i32(src.width()), detail::i32(src.height())));
+}
+inline void yuyv_from_rgb(const Image<uint8_t, 3>& src, uint8_t* out_device) {
+    if (!src.is_device()) throw ImageError(ImageError::Kind::HostPathUnavailable, "yuyv_from_rgb: host image — device backend only");
+    detail::check(kh_yuyv_from_rgb_u8(src.stream()->handle(), src.device_ptr(), out_device, detail::i32(src.width()), detail::i32(src.height())));
+}
+
+// resize launchers with their PixelMapping, the fused resize + normalise, cv2-compatible resize (P/cuda/resize.rs:433-930,
+// P/resize/opencv_compat.rs:76-250)
+enum class PixelMapping { HalfPixel = KH_MAP_HALF_PIXEL, AlignCorners = KH_MAP_ALIGN_CORNERS };
+template <int C>
+inline void resize_mapped(const Image<float, C>& src, Image<float, C>& dst, InterpolationMode interpolation, PixelMapping mapping) {
+    const Stream& s = detail::device_exec_for(src, dst, "resize");
+    detail::check(kh_resize_mapped_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
+                                       detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, (int32_t)mapping, 1, 0, 0));
+}
+inline void resize_bilinear_normalize(const Image<float, 3>& src, Image<float, 3>& dst, const std::array<float, 3>& mean,
+                                      const std::array<float, 3>& std_, PixelMapping mapping = PixelMapping::HalfPixel) {
+    const Stream& s = detail::device_exec_for(src, dst, "resize_bilinear_normalize");
+    detail::check(kh_resize_bilinear_normalize_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
+                                                   detail::i32(dst.width()), detail::i32(dst.height()), mean.data(), std_.data(), (int32_t)mapping, 1, 0, 0));
+}
+template <int C>
+inline void resize_opencv(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, InterpolationMode interpolation) {
+    const Stream& s = detail::device_exec_for(src, dst, "resize_opencv");
+    detail::check(kh_resize_opencv_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
+                                      detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, 1, 0, 0));
+}
+template <int C>
+inline void resize_opencv(const Image<float, C>& src, Image<float, C>& dst, InterpolationMode interpolation) {
+    const Stream& s = detail::device_exec_for(src, dst, "resize_opencv");
+    detail::check(kh_resize_opencv_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
+                                       detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, 1, 0, 0));
+}
+
+// u8 gathers / filters (P/interpolation/remap.rs:157, P/warp/perspective.rs:179, P/filter/ops.rs:59)
+template <int C>
+inline void remap(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const Image<float, 1>& map_x, const Image<float, 1>& map_y,
+                  InterpolationMode interpolation) {
+    const Stream& s = detail::device_exec_for(src, dst, "remap_u8");
+    if (map_x.size() != dst.size() || map_y.size() != dst.size())
+        throw ImageError(ImageError::Kind::InvalidImageSize, "remap: map_x, map_y and dst must have the same size");
+    if (!map_x.is_device() || !map_y.is_device())
+        throw ImageError(ImageError::Kind::MixedResidency, "remap: map_x and map_y must be device-resident when src/dst are on the GPU");
+    for (const Image<float, 1>* mp : {&map_x, &map_y})
+        if (!mp->stream()->same_as(s)) detail::check(kh_stream_fence(mp->stream()->handle(), s.handle()));
+    detail::check(kh_remap_u8(s.handle(), src.device_ptr(), map_x.device_ptr(), map_y.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()),
+                              detail::i32(src.height()), detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, 1, 0, 0));
+}
+template <int C>
+inline void warp_perspective_u8(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const std::array<float, 9>& m) {
+    const Stream& s = detail::device_exec_for(src, dst, "warp_perspective_u8");
+    detail::check(kh_warp_perspective_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
+                                         detail::i32(dst.width()), detail::i32(dst.height()), C, m.data(), 1, 0, 0));
+}
+template <int C>
+inline void box_blur(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, std::pair<int, int> kernel_size) {
+    const Stream& s = detail::device_exec_for(src, dst, "box_blur_u8");
+    detail::same_size(src, dst, "box_blur_u8");
+    detail::check(kh_box_blur_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
+                                 kernel_size.first, kernel_size.second, 1, 0, 0));
+}
+
+// filter::separable_filter, sobel, scharr (P/filter/separable_filter.rs:166, P/filter/ops.rs:174, 214)
+template <int C>
+inline void separable_filter(const Image<float, C>& src, Image<float, C>& dst, const std::vector<float>& kernel_x, const std::vector<float>& kernel_y) {
+    const Stream& s = detail::device_exec_for(src, dst, "separable_filter");
+    detail::same_size(src, dst, "separable_filter");
+    detail::check(kh_separable_filter_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
+                                          kernel_x.data(), detail::i32(kernel_x.size()), kernel_y.data(), detail::i32(kernel_y.size()), 1, 0, 0));
+}
+template <int C>
+inline void sobel(const Image<float, C>& src, Image<float, C>& dst, int kernel_size) {
+    const Stream& s = detail::device_exec_for(src, dst, "sobel");
+    detail::same_size(src, dst, "sobel");
+    detail::check(kh_gradient_magnitude_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
+                                            KH_GRAD_SOBEL, kernel_size, 1, 0, 0));
+}
+template <int C>
+inline void scharr(const Image<float, C>& src, Image<float, C>& dst) {
+    const Stream& s = detail::device_exec_for(src, dst, "scharr");
+    detail::same_size(src, dst, "scharr");
+    detail::check(kh_gradient_magnitude_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
+                                            KH_GRAD_SCHARR, 3, 1, 0, 0));
+}
+
+// pyramid::pyrdown / pyrup (P/pyramid.rs:180-520): dst is ceil(src / 2) resp. 2 * src
+namespace helpers {
+template <typename T, int C>
+inline const Stream& pyr_pair(const Image<T, C>& src, const Image<T, C>& dst, bool up, const char* what) {
+    const Stream& s = detail::device_exec_for(src, dst, what);
+    const size_t w = up ? src.width() * 2 : (src.width() + 1) / 2, h = up ? src.height() * 2 : (src.height() + 1) / 2;
+    if (dst.width() != w || dst.height() != h)
+        throw ImageError(ImageError::Kind::InvalidImageSize, std::string(what) + ": destination must be " + std::to_string(w) + "x" + std::to_string(h));
+    return s;
+}
+}  // namespace helpers
+template <int C>
+inline void pyrdown(const Image<float, C>& src, Image<float, C>& dst) {
+    const Stream& s = helpers::pyr_pair(src, dst, false, "pyrdown");  // classify operands BEFORE touching device pointers
+    detail::check(kh_pyrdown_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, 1, 0, 0));
+}
+template <int C>
+inline void pyrdown(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst) {
+    const Stream& s = helpers::pyr_pair(src, dst, false, "pyrdown");  // classify operands BEFORE touching device pointers
+    detail::check(kh_pyrdown_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, 1, 0, 0));
+}
+template <int C>
+inline void pyrup(const Image<float, C>& src, Image<float, C>& dst) {
+    const Stream& s = helpers::pyr_pair(src, dst, true, "pyrup");  // classify operands BEFORE touching device pointers
+    detail::check(kh_pyrup_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, 1, 0, 0));
+}
+template <int C>
+inline void pyrup(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst) {
+    const Stream& s = helpers::pyr_pair(src, dst, true, "pyrup");  // classify operands BEFORE touching device pointers
+    detail::check(kh_pyrup_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, 1, 0, 0));
+}
+
+// morphology::{Kernel, dilate, erode} (P/morphology/kernels.rs:60-185, ops.rs:120-268)
+enum class KernelShape { Box = KH_MORPH_BOX, Cross = KH_MORPH_CROSS, Ellipse = KH_MORPH_ELLIPSE };
+enum class PaddingMode { Constant = KH_BORDER_CONSTANT, Replicate = KH_BORDER_REPLICATE, Reflect101 = KH_BORDER_REFLECT101,
+                         Reflect = KH_BORDER_REFLECT, Wrap = KH_BORDER_WRAP };
+struct Kernel {
+    int width = 0, height = 0;
+    std::vector<uint8_t> mask;  // row-major, 1 = active tap; anchor (height/2, width/2)
+    Kernel(KernelShape shape, int w, int h) : width(w), height(h), mask((size_t)(w > 0 && h > 0 ? w * h : 0)) {
+        detail::check(kh_morph_kernel((int32_t)shape, w, h, mask.data()));
+    }
+    Kernel(KernelShape shape, int size) : Kernel(shape, size, size) {}
+};
+namespace helpers {
+template <int C>
+inline void morph(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const Kernel& k, int op, PaddingMode mode, const std::array<uint8_t, C>& constant, const char* what) {
+    const Stream& s = detail::device_exec_for(src, dst, what);
+    detail::same_size(src, dst, what);
+    detail::check(kh_morphology_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, op, k.mask.data(), k.width, k.height,
+                           (int32_t)mode, constant.data(), 1, 0, 0));
+}
+}  // namespace helpers
+template <int C>
+inline void dilate(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const Kernel& kernel, PaddingMode mode, const std::array<uint8_t, C>& constant_value = {}) {
+    helpers::morph<C>(src, dst, kernel, KH_MORPH_DILATE, mode, constant_value, "dilate");
+}
+template <int C>
+inline void erode(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const Kernel& kernel, PaddingMode mode, const std::array<uint8_t, C>& constant_value = {}) {
+    helpers::morph<C>(src, dst, kernel, KH_MORPH_ERODE, mode, constant_value, "erode");
+}
+
+// crop::crop_image, flip::{horizontal,vertical}_flip (P/crop.rs:187, P/flip.rs:39, 305)
+template <typename T, int C>
+inline void crop_image(const Image<T, C>& src, Image<T, C>& dst, size_t x, size_t y) {
+    const Stream& s = detail::device_exec_for(src, dst, "crop_image");
+    detail::check(kh_crop(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), detail::i32(dst.width()),
+                          detail::i32(dst.height()), detail::i32(x), detail::i32(y), (int32_t)(C * sizeof(T))));
+}
+template <typename T, int C>
+inline void horizontal_flip(const Image<T, C>& src, Image<T, C>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "horizontal_flip");  // classify operands BEFORE touching device pointers
+    detail::check(kh_flip(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()),
+                          detail::i32(src.height()), (int32_t)(C * sizeof(T)), 1));
+}
+template <typename T, int C>
+inline void vertical_flip(const Image<T, C>& src, Image<T, C>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "vertical_flip");  // classify operands BEFORE touching device pointers
+    detail::check(kh_flip(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()),
+                          detail::i32(src.height()), (int32_t)(C * sizeof(T)), 0));
+}
+
+// normalize::find_min_max / normalize_min_max (P/normalize.rs:123, 191): the reduction stays on the device, the pair is read back
+template <int C>
+inline std::pair<float, float> find_min_max(const Image<float, C>& src) {
+    if (!src.is_device()) throw ImageError(ImageError::Kind::HostPathUnavailable, "find_min_max: host image — device backend only");
+    const Stream& s = *src.stream();
+    void* scratch = nullptr;
+    detail::check(kh_malloc_async(&scratch, 16, 1, s.handle()));
+    float* mm = static_cast<float*>(scratch);
+    float out[2] = {0.0f, 0.0f};
+    int32_t rc = kh_find_min_max_f32(s.handle(), src.device_ptr(), (int64_t)src.numel(), mm, reinterpret_cast<uint32_t*>(mm + 2));
+    if (rc == KH_OK) rc = kh_stream_synchronize(s.handle());
+    if (rc == KH_OK) rc = kh_memcpy_d2h_async(out, mm, sizeof out, s.handle());
+    if (rc == KH_OK) rc = kh_stream_synchronize(s.handle());
+    kh_free_async(scratch, s.handle());
+    detail::check(rc);
+    return {out[0], out[1]};
+}
+template <int C>
+inline void normalize_min_max(const Image<float, C>& src, Image<float, C>& dst, float min, float max) {
+    const Stream& s = helpers::map_pair(src, dst, "normalize_min_max");
+    void* scratch = nullptr;
+    detail::check(kh_malloc_async(&scratch, 16, 1, s.handle()));
+    float* mm = static_cast<float*>(scratch);
+    const int32_t rc = kh_normalize_min_max_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), (int64_t)src.numel(), min, max, mm,
+                                                reinterpret_cast<uint32_t*>(mm + 2));
+    kh_free_async(scratch, s.handle());  // stream-ordered: released after the kernels that use it
+    detail::check(rc);
+}
+
+// calibration::distortion::generate_correction_map_polynomial (P/calibration/distortion.rs:135-152): intrinsic = {fx, fy, cx, cy},
+// distortion = {k1..k6, p1, p2}
+inline void generate_correction_map_polynomial(Image<float, 1>& map_x, Image<float, 1>& map_y, const std::array<double, 4>& intrinsic,
+                                               const std::array<double, 8>& distortion) {
+    const Stream& s = helpers::map_pair(map_x, map_y, "generate_correction_map_polynomial");
+    detail::check(kh_correction_map_polynomial_f32(s.handle(), map_x.device_ptr_mut(), map_y.device_ptr_mut(), detail::i32(map_x.width()),
+                                                   detail::i32(map_x.height()), intrinsic.data(), distortion.data()));
+}
+
 }  // namespace imgproc
 
 // ---- fused camera preprocess (Preprocessor / PreprocessorBuilder, P/preprocess.rs:654-1282) ------------------
@@ -396,6 +748,32 @@ private:
     std::array<float, 3> mean_, inv_std_;
     float pad_value_;
     int sampling_;
+};
+
+
+// ---- captured graph (kornia_rs.cuda.Graph, PY/cuda_ext/mod.rs:1684-1790): record allocation-free work once, replay per frame ----
+class Graph {
+public:
+    // f() enqueues the work on `stream` (preallocated outputs only); the capture is always ended, also when f throws
+    template <typename F>
+    static Graph capture(const Stream& stream, F&& f) {
+        detail::check(kh_graph_capture_begin(stream.handle()));
+        kh_graph_t g = nullptr;
+        try {
+            f();
+        } catch (...) {
+            if (kh_graph_capture_end(stream.handle(), &g) == KH_OK) kh_graph_destroy(g);
+            throw;
+        }
+        detail::check(kh_graph_capture_end(stream.handle(), &g));
+        return Graph(g, stream);
+    }
+    void replay() const { detail::check(kh_graph_launch(g_.get(), stream_.handle())); }
+
+private:
+    Graph(kh_graph_t g, const Stream& s) : g_(g, [](kh_graph_t p) { kh_graph_destroy(p); }), stream_(s) {}
+    std::shared_ptr<kh_graph_s> g_;
+    Stream stream_;
 };
 
 }  // namespace kornia

@@ -137,10 +137,32 @@ def bench_dryrun():
     return r.returncode
 
 
+def cpp_dryrun():
+    """The C++ mirror's device legs against the mock: value checks print FAIL (expected), exceptions print THROW (glue bugs)."""
+    status = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        tree = mock_tree(tmp)
+        lib = os.path.join(tree, "kornia-rs_amd", "lib")
+        for name in ("host_mirror_test", "host_mirror_ops_test"):
+            exe = os.path.join(tmp, name)
+            subprocess.check_call(["g++", "-std=c++17", "-O1", f"-I{os.path.join(tree, 'include')}", os.path.join(tree, "tests", "cpp", name + ".cpp"),
+                                   "-o", exe, f"-L{lib}", "-lkornia_hip", f"-Wl,-rpath,{lib}", "-ldl"])
+            r = subprocess.run([exe, "gpu"], capture_output=True, text=True)
+            lines = r.stdout.splitlines()
+            thrown = [ln for ln in lines if ln.startswith("THROW")] + ([f"crashed with status {r.returncode}: {r.stderr[-300:]}"] if r.returncode not in (0, 1) else [])
+            print(f"{name}: {sum(ln.startswith('FAIL') for ln in lines)} value failures (expected), {len(thrown)} exceptions; {lines[-1] if lines else ''}")
+            for ln in thrown:
+                print("  GLUE ", ln)
+            status |= bool(thrown)
+    return status
+
+
 def main():
     from kornia_rs import _ffi
     if "--bench" in sys.argv[1:]:
         return bench_dryrun()
+    if "--cpp" in sys.argv[1:]:
+        return cpp_dryrun()
     no_asserts = "--no-asserts" in sys.argv[1:]
     args = [a for a in sys.argv[1:] if a != "--no-asserts"] or ["tests", "-m", "gpu"]
     with tempfile.TemporaryDirectory() as tmp:

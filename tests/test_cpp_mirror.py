@@ -11,15 +11,24 @@ ROOT = Path(__file__).resolve().parent.parent
 LIB = ROOT / "kornia-rs_amd" / "lib"
 
 
-@pytest.fixture(scope="module")
-def binary(tmp_path_factory):
-    out = tmp_path_factory.mktemp("cpp") / "host_mirror_test"
+def build(tmp_path_factory, name):
+    out = tmp_path_factory.mktemp("cpp") / name
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", f"-I{ROOT / 'include'}",
-           str(ROOT / "tests" / "cpp" / "host_mirror_test.cpp"), "-o", str(out), f"-L{LIB}", "-lkornia_hip",
+           str(ROOT / "tests" / "cpp" / f"{name}.cpp"), "-o", str(out), f"-L{LIB}", "-lkornia_hip",
            f"-Wl,-rpath,{LIB}", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return out
+
+
+@pytest.fixture(scope="module")
+def binary(tmp_path_factory):
+    return build(tmp_path_factory, "host_mirror_test")
+
+
+@pytest.fixture(scope="module")
+def ops_binary(tmp_path_factory):
+    return build(tmp_path_factory, "host_mirror_ops_test")
 
 
 def _run(binary, mode):
@@ -31,6 +40,12 @@ def _run(binary, mode):
 
 def test_cpp_mirror_host_contract(binary):
     _run(binary, "host")
+
+
+def test_cpp_mirror_full_surface_host_contract(ops_binary):
+    """Every remaining wrapper (colour, camera formats, u8 twins, pyramid, morphology, crop / flip, min-max, maps, graphs)
+    classifies host operands first and throws the typed error; host-side helpers (morphology kernels) work without a device."""
+    _run(ops_binary, "host")
 
 
 @pytest.mark.gpu

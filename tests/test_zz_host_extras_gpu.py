@@ -297,3 +297,9 @@ def _upload(img, array):
     img.stream.synchronize()
     _ffi.check(_ffi.lib.kh_memcpy_h2d_async(img.data_ptr, a.ctypes.data, a.nbytes, img.stream.cuda_stream_ptr))
     img.stream.synchronize()
+
+
+def test_cpp_mirror_full_surface_on_device(tmp_path_factory):
+    """tests/cpp/host_mirror_ops_test.cpp `gpu`: the reference's known answers through every remaining C++ wrapper."""
+    import test_cpp_mirror as T
+    T._run(T.build(tmp_path_factory, "host_mirror_ops_test"), "gpu")
