@@ -61,7 +61,8 @@ __global__ __launch_bounds__(kBlock) void minmax_partial_kernel(const float* __r
     for (int off = 32; off > 0; off >>= 1) {
         mn = fminf(mn, __shfl_xor(mn, off));
         mx = fmaxf(mx, __shfl_xor(mx, off));
-        any = any || __shfl_xor((int)any, off);
+        const int other = __shfl_xor((int)any, off);  // every lane takes part: `any || __shfl_xor(..)` would skip the
+        any = any || other;                            // exchange in the lanes that already hold data (a divergent shuffle)
     }
     if ((threadIdx.x & 63) == 0 && any) {
         atomicMin(&keys[0], f2key(mn));

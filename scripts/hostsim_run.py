@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Run `-m gpu` tests on a GPU-less box against the HOST SIMULATOR build of the product (tests/hostsim/): the real
+kernels and host entries compiled for x86, HIP threads as fibers.  A copy of the tree with that library in place of
+libkornia_hip.so is made under a temporary directory and pytest runs there; nothing in the product changes.
+
+    python scripts/hostsim_run.py tests/test_geom_gpu.py -x -q
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
+
+
+def main():
+    import build as hostsim_build
+    args = sys.argv[1:] or ["tests", "-q"]
+    with tempfile.TemporaryDirectory() as tmp:
+        tree = os.path.join(tmp, "repo")
+        shutil.copytree(ROOT, tree, ignore=shutil.ignore_patterns(".git", "gpurun_out", "profiles", "__pycache__", "build", ".pytest_cache"))
+        hostsim_build.build(os.path.join(tree, "kornia-rs_amd", "lib", "libkornia_hip.so"))
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", KH_HOSTSIM="1")
+        return subprocess.run([sys.executable, "-m", "pytest", *args, "-m", "gpu", "-p", "no:cacheprovider"], cwd=tree, env=env).returncode
+
+
+if __name__ == "__main__":
+    sys.exit(main())

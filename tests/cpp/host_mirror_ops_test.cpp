@@ -153,7 +153,8 @@ static void on_device() {
         imgproc::nv12_from_rgb(solid, nv12.device_ptr_mut());
         auto round = Image<uint8_t, 3>::zeros_hip({4, 2}, s);
         imgproc::rgb_from_planar420(nv12.device_ptr(), 12, round, imgproc::Planar420::Nv12);
-        for (uint8_t v : round.to_host().as_slice()) EXPECT(std::abs((int)v - 200) <= 2);  // encode_decode_constant_is_exact
+        const auto host1 = round.to_host();  // keep the copy alive for the loop (a range-for over a temporary's member dangles)
+        for (uint8_t v : host1.as_slice()) EXPECT(std::abs((int)v - 200) <= 2);  // encode_decode_constant_is_exact
         EXPECT(throws_kind(K::InvalidImageSize, [&] { imgproc::rgb_from_planar420(nv12.device_ptr(), 11, round, imgproc::Planar420::Nv12); }));
     });
     section("resize family", [&] {
@@ -185,7 +186,8 @@ static void on_device() {
         auto flat = Image<uint8_t, 3>::from_size_val({9, 7}, 77).to_hip(s);
         auto blur = Image<uint8_t, 3>::zeros_hip({9, 7}, s);
         imgproc::box_blur(flat, blur, {3, 3});
-        for (uint8_t v : blur.to_host().as_slice()) EXPECT(v == 77);
+        const auto host2 = blur.to_host();  // keep the copy alive for the loop (a range-for over a temporary's member dangles)
+        for (uint8_t v : host2.as_slice()) EXPECT(v == 77);
         std::vector<float> imp(25, 0.0f);
         imp[12] = 9.0f;
         auto f = up<float, 1>(s, 5, 5, imp);
@@ -212,7 +214,8 @@ static void on_device() {
         auto flat = Image<uint8_t, 3>::from_size_val({3, 2}, 200).to_hip(s);
         auto upi = Image<uint8_t, 3>::zeros_hip({6, 4}, s);
         imgproc::pyrup(flat, upi);
-        for (uint8_t v : upi.to_host().as_slice()) EXPECT(v == 200);
+        const auto host3 = upi.to_host();  // keep the copy alive for the loop (a range-for over a temporary's member dangles)
+        for (uint8_t v : host3.as_slice()) EXPECT(v == 200);
         EXPECT(throws_kind(K::InvalidImageSize, [&] { imgproc::pyrdown(src, src); }));
         std::vector<uint8_t> dot(25, 0);
         dot[12] = 255;
@@ -225,7 +228,8 @@ static void on_device() {
         EXPECT(lit == 9 && d.as_slice()[6] == 255 && d.as_slice()[0] == 0);  // test_dilate_3x3
         imgproc::erode(out, img, imgproc::Kernel(imgproc::KernelShape::Box, 3), imgproc::PaddingMode::Constant);
         lit = 0;
-        for (uint8_t v : img.to_host().as_slice()) lit += v == 255;
+        const auto host4 = img.to_host();  // keep the copy alive for the loop (a range-for over a temporary's member dangles)
+        for (uint8_t v : host4.as_slice()) lit += v == 255;
         EXPECT(lit == 1);
     });
     section("crop, flip, min / max, maps", [&] {

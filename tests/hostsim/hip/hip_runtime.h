@@ -1,0 +1,153 @@
+// TEST INFRASTRUCTURE — a host stand-in for <hip/hip_runtime.h> so that the product's .hip sources (kernels AND host
+// entries, unmodified) compile with clang++ for x86 and run on a GPU-less box: tests/hostsim/build.py.
+// Never part of the product: libkornia_hip.so is always built by hipcc for gfx950 (kornia-rs_amd/Makefile).
+//
+// Execution model: a launch runs its blocks one after another; inside a block every HIP thread is a fiber (ucontext) on
+// one OS thread.  __syncthreads() and the wave-level operations (__shfl*, __builtin_amdgcn_wave_barrier) are fiber
+// barriers, so LDS hand-offs and cross-lane reads see the lock-step semantics a 64-wide wave gives them on the GPU.
+// `__shared__` is static storage (one block at a time).  Streams are synchronous, device memory is host memory.
+#pragma once
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace hostsim {
+struct Lane { dim3 tid, bid, bdim, gdim; };
+extern Lane* cur;                       // the fiber that is running
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void block_barrier();
+void wave_barrier();
+uint32_t shfl_bits(uint32_t v, int src_lane);  // value of `v` in lane `src_lane` of the caller's wave
+int lane_id();
+}  // namespace hostsim
+
+#define threadIdx (hostsim::cur->tid)
+#define blockIdx (hostsim::cur->bid)
+#define blockDim (hostsim::cur->bdim)
+#define gridDim (hostsim::cur->gdim)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hostsim::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+
+// ---- device intrinsics used by the kernels -------------------------------------------------------------------------
+inline void __syncthreads() { hostsim::block_barrier(); }
+#define __builtin_amdgcn_wave_barrier() hostsim::wave_barrier()
+inline int __shfl(int v, int lane) { return (int)hostsim::shfl_bits((uint32_t)v, lane); }
+inline int __shfl_xor(int v, int mask) { return (int)hostsim::shfl_bits((uint32_t)v, hostsim::lane_id() ^ mask); }
+inline float __shfl_xor(float v, int mask) {
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    b = hostsim::shfl_bits(b, hostsim::lane_id() ^ mask);
+    memcpy(&v, &b, 4);
+    return v;
+}
+inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+// v_perm_b32: the selector's byte i picks a byte of the 64-bit value {s0 (high dword), s1 (low dword)}: 0..3 -> s1, 4..7 -> s0,
+// 8..11 -> sign of bytes 1 / 3 of s1 / s0 replicated, 12 -> 0x00, 13.. -> 0xff
+inline uint32_t hostsim_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+    const uint64_t v = ((uint64_t)s0 << 32) | s1;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t k = (sel >> (8 * i)) & 0xffu;
+        uint32_t b;
+        if (k <= 7) b = (uint32_t)(v >> (8 * k)) & 0xffu;
+        else if (k <= 11) b = ((v >> (16 * (k - 8) + 15)) & 1u) ? 0xffu : 0x00u;
+        else b = k == 12 ? 0x00u : 0xffu;
+        out |= b << (8 * i);
+    }
+    return out;
+}
+#define __builtin_amdgcn_perm(a, b, sel) hostsim_perm((a), (b), (sel))
+
+// one block, one fiber at a time: plain read-modify-write is atomic here
+template <typename T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <typename T> inline T atomicMax(T* p, T v) { T o = *p; if (o < v) *p = v; return o; }
+template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+
+template <typename T> inline T min(T a, T b) { return b < a ? b : a; }
+template <typename T> inline T max(T a, T b) { return a < b ? b : a; }
+inline long long min(long long a, int b) { return a < b ? a : b; }
+inline long long max(long long a, int b) { return a > b ? a : b; }
+inline long long min(int a, long long b) { return a < b ? a : b; }
+inline long long max(int a, long long b) { return a > b ? a : b; }
+inline unsigned min(unsigned a, int b) { return a < (unsigned)b ? a : (unsigned)b; }
+inline unsigned min(int a, unsigned b) { return (unsigned)a < b ? (unsigned)a : b; }
+inline unsigned max(unsigned a, int b) { return a > (unsigned)b ? a : (unsigned)b; }
+inline unsigned max(int a, unsigned b) { return (unsigned)a > b ? (unsigned)a : b; }
+
+// ---- runtime API (tests/hostsim/hostsim.cpp) ---------------------------------------------------------------------------
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801 };
+typedef struct hostsim_stream* hipStream_t;
+typedef struct hostsim_event* hipEvent_t;
+typedef struct hostsim_pool* hipMemPool_t;
+typedef struct hostsim_graph* hipGraph_t;
+typedef struct hostsim_graph_exec* hipGraphExec_t;
+typedef struct hostsim_graph_node* hipGraphNode_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+enum { hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipMemAttachGlobal = 1 };
+enum hipMemPoolAttr { hipMemPoolAttrReleaseThreshold = 4 };
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeManaged = 3 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; };
+struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; };
+
+const char* hipGetErrorString(hipError_t e);
+hipError_t hipGetLastError();
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipMemGetInfo(size_t* f, size_t* t);
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);
+hipError_t hipGraphGetNodes(hipGraph_t g, hipGraphNode_t* nodes, size_t* n);
+hipError_t hipGraphDestroy(hipGraph_t g);
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t* err, char* log, size_t n);
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s);
+hipError_t hipGraphExecDestroy(hipGraphExec_t e);
+hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t* p, int d);
+hipError_t hipMemPoolSetAttribute(hipMemPool_t p, hipMemPoolAttr a, void* v);
+hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipMallocAsync(void** p, size_t n, hipStream_t s);
+hipError_t hipFree(void* p);
+hipError_t hipFreeAsync(void* p, hipStream_t s);
+hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
+hipError_t hipHostFree(void* p);
+hipError_t hipMallocManaged(void** p, size_t n, unsigned flags);
+hipError_t hipMemset(void* p, int v, size_t n);
+hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t s);
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t w, size_t h, hipMemcpyKind k, hipStream_t st);
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p);
+hipError_t hipFuncSetAttribute(const void* f, hipFuncAttribute a, int v);

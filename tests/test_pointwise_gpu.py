@@ -69,8 +69,8 @@ def test_min_max_and_normalize_min_max(gpu_stream):
     assert_same_bits(got[ok], want[ok], "normalize_min_max")
     # reference doc example: [0,1,0,1,2,3,...] -> min 0, max 3
     ex = np.array([0, 1, 0, 1, 2, 3, 0, 1, 0, 1, 2, 3], f32)
-    _ffi.check(lib.kh_find_min_max_f32(s, dev(gpu_stream, ex).ptr, ex.size, d_mm.ptr, d_scr.ptr))
-    # (temporary device buffer above is freed after the call is enqueued: stream-ordered, safe)
+    d_ex = dev(gpu_stream, ex)  # named: a temporary would be released (stream-ordered free) BEFORE the launch is enqueued
+    _ffi.check(lib.kh_find_min_max_f32(s, d_ex.ptr, ex.size, d_mm.ptr, d_scr.ptr))
     assert d_mm.to_numpy(f32, (2,)).tolist() == [0.0, 3.0]
     assert lib.kh_find_min_max_f32(s, d_src.ptr, 0, d_mm.ptr, d_scr.ptr) == _ffi.KH_ERR_INVALID_ARG  # ImageDataNotInitialized
 
@@ -96,6 +96,6 @@ def test_crop_and_flip(gpu_stream, dtype, c):
 def test_crop_reference_example(gpu_stream):  # crop.rs doc example
     _ffi, lib, s = lib_s(gpu_stream)
     src = np.arange(16, dtype=np.uint8)
-    d_dst = out_buf(gpu_stream, 4)
-    _ffi.check(lib.kh_crop(s, dev(gpu_stream, src).ptr, d_dst.ptr, 4, 4, 2, 2, 1, 1, 1))
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, 4)
+    _ffi.check(lib.kh_crop(s, d_src.ptr, d_dst.ptr, 4, 4, 2, 2, 1, 1, 1))
     assert d_dst.to_numpy(np.uint8, (4,)).tolist() == [5, 6, 9, 10]

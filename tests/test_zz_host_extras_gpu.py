@@ -279,7 +279,7 @@ def test_graph_capture_and_replay(gpu_stream):
         stream.synchronize()
         assert np.array_equal(gray.numpy().reshape(-1), O.color_map("gray_from_rgb_u8", rgb, 1)), k
         assert np.array_equal(small.numpy(), O.resize_fast_u8(rgb, 32, 24, "nearest", True)[0]), k
-        assert np.array_equal(blur.numpy(), O.gaussian_blur_u8(rgb, (5, 5), (1.2, 1.2))), k
+        assert np.array_equal(blur.numpy(), O.gaussian_blur_u8(rgb, (5, 5), (1.2, 1.2))[0]), k
     with pytest.raises(ValueError):
         hip.Graph.capture(lambda: None, [], stream)  # nothing enqueued
     with pytest.raises(ZeroDivisionError):  # the callable's own error surfaces, and the stream is usable afterwards
@@ -303,3 +303,19 @@ def test_cpp_mirror_full_surface_on_device(tmp_path_factory):
     """tests/cpp/host_mirror_ops_test.cpp `gpu`: the reference's known answers through every remaining C++ wrapper."""
     import test_cpp_mirror as T
     T._run(T.build(tmp_path_factory, "host_mirror_ops_test"), "gpu")
+
+
+def test_min_max_ignores_nan_in_any_lane(gpu_stream):
+    """find_min_max (P/normalize.rs:123-146): a NaN never wins a comparison.  A NaN in the FIRST lane of a wave whose other
+    lanes hold the extremes used to drop that wave's contribution (the `any` flag was exchanged with a divergent shuffle)."""
+    from kornia_rs import Image, imgproc
+    x = np.linspace(1.0, 2.0, 64 * 5, dtype=np.float32)
+    x[64] = np.nan          # lane 0 of wave 1
+    x[70], x[100] = -7.5, 99.25  # ... whose other lanes hold the minimum and the maximum
+    x[200] = np.nan
+    lo, hi = imgproc.find_min_max(Image.from_numpy(x.reshape(1, -1, 1)).to_hip(gpu_stream))
+    assert (lo, hi) == (-7.5, 99.25)
+    y = x.copy()
+    y[0] = np.nan           # a NaN FIRST element poisons both, as the reference loop does
+    lo, hi = imgproc.find_min_max(Image.from_numpy(y.reshape(1, -1, 1)).to_hip(gpu_stream))
+    assert np.isnan(lo) and np.isnan(hi)
