@@ -1,0 +1,24 @@
+"""The whole `-m gpu` parity suite on a GPU-less box: the product's .hip sources (kernels AND host entries) are compiled for
+x86 against tests/hostsim/hip/hip_runtime.h — every HIP thread a fiber, __syncthreads / wave barriers / shuffles real
+barriers, device memory host memory — and the GPU tests run against that build in a temporary copy of the tree
+(scripts/hostsim_run.py).  TEST INFRASTRUCTURE: the product library is always the hipcc / gfx950 build and never loads this.
+
+What it proves: indexing, tiling, border handling, integer and IEEE arithmetic of the real kernel source equal the CPU
+restatement.  What it cannot: device-compiler code generation, device libm, launch limits, performance — the GPU run does.
+Sorted last so that a failure here does not hide the faster CPU tests."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_gpu_suite_passes_on_the_host_simulator():
+    workers = str(max(1, min(16, (os.cpu_count() or 2) // 2)))
+    cmd = [sys.executable, str(ROOT / "scripts" / "hostsim_run.py"), "tests", "-q", "-n", workers, "-x",
+           "--deselect", "tests/test_host_api_gpu.py::test_torch_rocm_zero_copy_interop"]  # needs torch to see a real device
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3000)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
