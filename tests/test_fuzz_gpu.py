@@ -1,0 +1,150 @@
+"""Seeded random differential sweep — ragged shapes, tiny images, extreme scales — of the operators against the CPU
+restatement.  Every case is small, so the file costs seconds on the device and runs in the host simulator on a GPU-less box."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+import os
+
+pytestmark = pytest.mark.gpu
+EXTRA = int(os.environ.get("KH_FUZZ_SEEDS", "0"))  # e.g. KH_FUZZ_SEEDS=50 python scripts/hostsim_run.py tests/test_fuzz_gpu.py -n 16
+MODES = ("nearest", "bilinear", "bicubic", "lanczos")
+
+
+def _f32(rng, h, w, c):
+    return rng.uniform(-2.0, 2.0, (h, w, c)).astype(np.float32)
+
+
+def _u8(rng, h, w, c):
+    return rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+
+
+def _up(img, stream):
+    from kornia_rs import Image
+    return Image.from_numpy(img).to_hip(stream)
+
+
+def _shape(rng, lo=1, hi=70):
+    return int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))
+
+
+@pytest.mark.parametrize("seed", range(6 + EXTRA))
+def test_fuzz_f32_resize_and_warps(gpu_stream, seed):
+    from kornia_rs import imgproc
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(10):
+        (sh, sw), (dh, dw), c = _shape(rng), _shape(rng), int(rng.choice([1, 3, 4]))
+        src = _f32(rng, sh, sw, c)
+        dev, mode = _up(src, gpu_stream), str(rng.choice(MODES))
+        mapping = str(rng.choice(["half_pixel", "align_corners"]))
+        assert np.array_equal(imgproc.resize_mapped(dev, (dh, dw), mode, mapping).numpy(), O.resize_mapped(src, dw, dh, mode, mapping)), \
+            ("resize", sw, sh, dw, dh, c, mode, mapping)
+        m = [float(v) for v in (rng.uniform(0.5, 1.5), rng.uniform(-0.5, 0.5), rng.uniform(-8, 8), rng.uniform(-0.5, 0.5), rng.uniform(0.5, 1.5),
+                                rng.uniform(-8, 8))]
+        assert np.array_equal(imgproc.warp_affine(dev, m, (dh, dw), mode).numpy(), O.warp_affine(src, m, dw, dh, mode)), ("affine", sw, sh, dw, dh, c, mode, m)
+        hm = m + [float(rng.uniform(-2e-3, 2e-3)), float(rng.uniform(-2e-3, 2e-3)), 1.0]
+        assert np.array_equal(imgproc.warp_perspective(dev, hm, (dh, dw), mode).numpy(), O.warp_perspective(src, hm, dw, dh, mode)), \
+            ("perspective", sw, sh, dw, dh, c, mode, hm)
+        mx = rng.uniform(-2, sw + 1, (dh, dw)).astype(np.float32)
+        my = rng.uniform(-2, sh + 1, (dh, dw)).astype(np.float32)
+        got = imgproc.remap(dev, _up(mx, gpu_stream), _up(my, gpu_stream), mode).numpy()
+        assert np.array_equal(got, O.remap(src, mx, my, mode)), ("remap", sw, sh, dw, dh, c, mode)
+
+
+@pytest.mark.parametrize("seed", range(6 + EXTRA))
+def test_fuzz_filters(gpu_stream, seed):
+    from kornia_rs import imgproc
+    rng = np.random.default_rng(2000 + seed)
+    for _ in range(8):
+        (h, w), c = _shape(rng), int(rng.choice([1, 3, 4]))
+        src = _f32(rng, h, w, c)
+        dev = _up(src, gpu_stream)
+        k = (int(rng.choice([1, 3, 5, 7, 9, 11, 15, 17, 21])), int(rng.choice([1, 3, 5, 7, 9, 13, 15, 19])))
+        s = (float(rng.uniform(0.3, 4.0)), float(rng.uniform(0.3, 4.0)))
+        assert np.array_equal(imgproc.gaussian_blur(dev, k, s).numpy(), O.gaussian_blur(src, k, s)), ("gaussian", w, h, c, k, s)
+        u = _u8(rng, h, w, c)
+        udev = _up(u, gpu_stream)
+        assert np.array_equal(imgproc.gaussian_blur(udev, k, s).numpy(), O.gaussian_blur_u8(u, k, s)[0]), ("gaussian_u8", w, h, c, k, s)
+        assert np.array_equal(imgproc.box_blur(udev, k).numpy(), O.box_blur_u8(u, k)[0] if isinstance(O.box_blur_u8(u, k), tuple) else O.box_blur_u8(u, k)), \
+            ("box_u8", w, h, c, k)
+
+
+@pytest.mark.parametrize("seed", range(6 + EXTRA))
+def test_fuzz_u8_gathers_and_resize(gpu_stream, seed):
+    from kornia_rs import ImageError, imgproc
+    rng = np.random.default_rng(3000 + seed)
+    for _ in range(10):
+        (sh, sw), (dh, dw), c = _shape(rng), _shape(rng), int(rng.choice([1, 2, 3, 4]))
+        src = _u8(rng, sh, sw, c)
+        dev = _up(src, gpu_stream)
+        m = [float(v) for v in (rng.uniform(0.5, 1.5), rng.uniform(-0.5, 0.5), rng.uniform(-8, 8), rng.uniform(-0.5, 0.5), rng.uniform(0.5, 1.5),
+                                rng.uniform(-8, 8))]
+        assert np.array_equal(imgproc.warp_affine(dev, m, (dh, dw)).numpy(), O.warp_affine_u8(src, np.array(m, np.float32), dw, dh)), ("affine_u8", sw, sh, dw, dh, c, m)
+        hm = m + [float(rng.uniform(-2e-3, 2e-3)), float(rng.uniform(-2e-3, 2e-3)), 1.0]
+        assert np.array_equal(imgproc.warp_perspective(dev, hm, (dh, dw)).numpy(), O.warp_perspective_u8(src, np.array(hm, np.float32), dw, dh)), \
+            ("perspective_u8", sw, sh, dw, dh, c, hm)
+        mx = rng.uniform(-2, sw + 1, (dh, dw)).astype(np.float32)
+        my = rng.uniform(-2, sh + 1, (dh, dw)).astype(np.float32)
+        for mode in ("nearest", "bilinear"):
+            got = imgproc.remap(dev, _up(mx, gpu_stream), _up(my, gpu_stream), mode).numpy()
+            assert np.array_equal(got, O.remap_u8(src, mx, my, mode)), ("remap_u8", sw, sh, dw, dh, c, mode)
+        mode, aa = str(rng.choice(MODES)), bool(rng.integers(0, 2))
+        try:
+            want = O.resize_fast_u8(src, dw, dh, mode, aa)[0]
+        except ValueError:  # the reference's typed errors (2 channels beyond nearest, 1-px-wide bilinear source): same on the device
+            with pytest.raises(ImageError):
+                imgproc.resize_fast(dev, (dh, dw), mode, aa)
+            continue
+        assert np.array_equal(imgproc.resize_fast(dev, (dh, dw), mode, aa).numpy(), want), ("resize_fast", sw, sh, dw, dh, c, mode, aa)
+
+
+@pytest.mark.parametrize("seed", range(4 + EXTRA))
+def test_fuzz_pyramid_morphology_pointwise(gpu_stream, seed):
+    from kornia_rs import imgproc
+    rng = np.random.default_rng(4000 + seed)
+    for _ in range(8):
+        (h, w), c = _shape(rng), int(rng.choice([1, 3, 4]))
+        u, f = _u8(rng, h, w, c), _f32(rng, h, w, c)
+        ud, fd = _up(u, gpu_stream), _up(f, gpu_stream)
+        assert np.array_equal(imgproc.pyrdown(ud).numpy(), O.pyrdown(u)) and np.array_equal(imgproc.pyrdown(fd).numpy(), O.pyrdown(f)), ("pyrdown", w, h, c)
+        assert np.array_equal(imgproc.pyrup(ud).numpy(), O.pyrup(u)) and np.array_equal(imgproc.pyrup(fd).numpy(), O.pyrup(f)), ("pyrup", w, h, c)
+        shape = str(rng.choice(["box", "cross", "ellipse"]))
+        kh_, kw_ = (int(rng.integers(1, 8)),) * 2 if shape != "ellipse" else (int(rng.integers(1, 8)), int(rng.integers(1, 8)))
+        border = str(rng.choice(["constant", "replicate", "reflect101", "reflect", "wrap"]))
+        if border in ("reflect101", "reflect", "wrap") and (kh_ // 2 >= h or kw_ // 2 >= w):
+            border = "replicate"  # the mirrored / wrapped index needs the pad smaller than the image, as in the reference
+        for op, fn in (("dilate", imgproc.dilate), ("erode", imgproc.erode)):
+            got = fn(ud, shape, size=(kh_, kw_), border=border, constant_value=9).numpy()
+            assert np.array_equal(got, O.morphology_u8(u, op, O.morph_kernel(shape, kw_, kh_), border, [9] * c)), (op, w, h, c, shape, kh_, kw_, border)
+        assert np.array_equal(imgproc.horizontal_flip(ud).numpy(), u[:, ::-1]) and np.array_equal(imgproc.vertical_flip(fd).numpy(), f[::-1])
+        lo, hi = imgproc.find_min_max(fd)
+        assert (lo, hi) == (float(f.min()), float(f.max()))
+
+
+@pytest.mark.parametrize("seed", range(6 + EXTRA))
+def test_fuzz_fused_preprocess(gpu_stream, seed):
+    """The north-star family: every source format x resize mode x sampler x f32 / f16 at random (even where 4:2:x needs it)
+    geometries, including 1:1 (the specialised kernel), up- and down-scales.  Lanczos goes through device sinf: 2e-4."""
+    from test_preprocess_gpu import _run, _raw_for
+    rng = np.random.default_rng(5000 + seed)
+    for _ in range(10):
+        fmt = str(rng.choice(["rgb", "bgr", "rgba", "bgra", "gray", "nv12", "yuyv"]))
+        w, h = 2 * int(rng.integers(1, 40)), 2 * int(rng.integers(1, 30))
+        if rng.integers(0, 4) == 0:
+            dw, dh = w, h  # scale 1: the identity-geometry variant
+        else:
+            dw, dh = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        mode, sampling = str(rng.choice(["letterbox", "stretch"])), str(rng.choice(["nearest", "bilinear", "lanczos"]))
+        f16 = bool(rng.integers(0, 2))
+        norm = dict(mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) if rng.integers(0, 2) else {}
+        raw = _raw_for(fmt, w, h, seed=int(rng.integers(0, 1000)))
+        got = _run(gpu_stream, raw, w, h, dw, dh, fmt=fmt, mode=mode, sampling=sampling, f16=f16, **norm)
+        want = O.preprocess(raw, w, h, dw, dh, fmt=fmt, mode=mode, sampling=sampling, f16=f16, **norm)
+        what = (fmt, w, h, dw, dh, mode, sampling, f16, bool(norm))
+        if sampling == "lanczos":
+            a = got.view(np.float16).astype(np.float32) if f16 else got
+            b = want.view(np.float16).astype(np.float32) if f16 else want
+            assert np.abs(a - b).max() <= (2e-4 if not f16 else 4e-3) * max(1.0, float(np.abs(b).max())), what
+        else:
+            assert np.array_equal(got, want), what
