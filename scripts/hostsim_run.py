@@ -4,6 +4,7 @@ kernels and host entries compiled for x86, HIP threads as fibers.  A copy of the
 libkornia_hip.so is made under a temporary directory and pytest runs there; nothing in the product changes.
 
     python scripts/hostsim_run.py tests/test_geom_gpu.py -x -q
+    KH_HOSTSIM_SANITIZE=address python scripts/hostsim_run.py tests -q -n 16     # AddressSanitizer: out-of-bounds kernel accesses
 """
 import os
 import shutil
@@ -23,6 +24,10 @@ def main():
         shutil.copytree(ROOT, tree, ignore=shutil.ignore_patterns(".git", "gpurun_out", "profiles", "__pycache__", "build", ".pytest_cache"))
         hostsim_build.build(os.path.join(tree, "kornia-rs_amd", "lib", "libkornia_hip.so"))
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", KH_HOSTSIM="1")
+        if os.environ.get("KH_HOSTSIM_SANITIZE") == "address":  # the sanitizer runtime must be loaded before python's allocator is used
+            rt = subprocess.check_output([hostsim_build.CXX, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+            env["LD_PRELOAD"] = rt
+            env["ASAN_OPTIONS"] = "detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0:halt_on_error=1:" + os.environ.get("ASAN_OPTIONS", "")
         return subprocess.run([sys.executable, "-m", "pytest", *args, "-m", "gpu", "-p", "no:cacheprovider"], cwd=tree, env=env).returncode
 
 

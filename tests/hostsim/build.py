@@ -21,7 +21,11 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-fno-f
          f"-I{HERE}", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 
 
-def build(out):
+def build(out, sanitize=None):
+    """sanitize="address": AddressSanitizer build (KH_HOSTSIM_SANITIZE=address scripts/hostsim_run.py ...): device buffers are
+    plain heap blocks here, so a kernel that reads or writes one byte past an image is reported with its source line."""
+    sanitize = sanitize or os.environ.get("KH_HOSTSIM_SANITIZE")
+    extra = [f"-fsanitize={sanitize}", "-shared-libasan", "-fno-omit-frame-pointer", "-g"] if sanitize else []
     objs = []
     with tempfile.TemporaryDirectory() as tmp:
         procs = []
@@ -34,12 +38,12 @@ def build(out):
             open(patched, "w").write(f'#line 1 "{src}"\n' + text)
             obj = os.path.join(tmp, os.path.basename(src) + ".o")
             objs.append(obj)
-            procs.append((src, subprocess.Popen([CXX, *FLAGS, "-c", patched, "-o", obj], stderr=subprocess.PIPE, text=True)))
+            procs.append((src, subprocess.Popen([CXX, *FLAGS, *extra, "-c", patched, "-o", obj], stderr=subprocess.PIPE, text=True)))
         for src, p in procs:
             _, err = p.communicate()
             if p.returncode:
                 sys.exit(f"{src}:\n{err[-4000:]}")
-        subprocess.check_call([CXX, "-shared", "-o", out, *objs, "-lm", "-lpthread"])
+        subprocess.check_call([CXX, "-shared", *extra, "-o", out, *objs, "-lm", "-lpthread"])
     return out
 
 
