@@ -24,6 +24,10 @@ def main():
         shutil.copytree(ROOT, tree, ignore=shutil.ignore_patterns(".git", "gpurun_out", "profiles", "__pycache__", "build", ".pytest_cache"))
         hostsim_build.build(os.path.join(tree, "kornia-rs_amd", "lib", "libkornia_hip.so"))
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", KH_HOSTSIM="1")
+        if os.environ.get("KH_HOSTSIM_SANITIZE") == "undefined":
+            rt = subprocess.check_output([hostsim_build.CXX, "-print-file-name=libclang_rt.ubsan_standalone-x86_64.so"], text=True).strip()
+            env["LD_PRELOAD"] = rt
+            env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=0:log_path=/tmp/kh_ubsan:" + os.environ.get("UBSAN_OPTIONS", "")
         if os.environ.get("KH_HOSTSIM_SANITIZE") == "address":  # the sanitizer runtime must be loaded before python's allocator is used
             rt = subprocess.check_output([hostsim_build.CXX, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
             env["LD_PRELOAD"] = rt

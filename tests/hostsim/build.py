@@ -25,7 +25,11 @@ def build(out, sanitize=None):
     """sanitize="address": AddressSanitizer build (KH_HOSTSIM_SANITIZE=address scripts/hostsim_run.py ...): device buffers are
     plain heap blocks here, so a kernel that reads or writes one byte past an image is reported with its source line."""
     sanitize = sanitize or os.environ.get("KH_HOSTSIM_SANITIZE")
-    extra = [f"-fsanitize={sanitize}", "-shared-libasan", "-fno-omit-frame-pointer", "-g"] if sanitize else []
+    extra = []
+    if sanitize == "address":
+        extra = ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g"]
+    elif sanitize == "undefined":  # signed overflow, bad shifts, misaligned typed accesses, out-of-range float -> int casts
+        extra = ["-fsanitize=undefined,float-cast-overflow", "-fno-sanitize=vptr,function", "-shared-libsan", "-fno-omit-frame-pointer", "-g"]
     objs = []
     with tempfile.TemporaryDirectory() as tmp:
         procs = []
