@@ -339,6 +339,13 @@ enum { KH_F64_GRAY_FROM_RGB = 8, KH_F64_RGB_FROM_GRAY = 9, KH_F64_HSV_FROM_RGB =
        KH_F64_YUV_FROM_RGB = 16, KH_F64_RGB_FROM_YUV = 17 };
 KH_API int32_t kh_color_convert_f64(kh_stream_t stream, const double* src, double* dst, int64_t npixels, int32_t conversion);
 
+/* Bayer mosaic -> RGB8, bilinear, cv2-compatible — replaces launch_rgb_from_bayer_u8 (P/cuda/color/bayer.rs) ==
+ * rgb_from_bayer (P/color/bayer/mod.rs:37-70, kernels.rs:30-200): rounded integer averages over
+ * replicate-clamped neighbours; the 1-pixel frame takes its interior neighbour's result.            */
+enum { KH_BAYER_RGGB = 0, KH_BAYER_BGGR = 1, KH_BAYER_GRBG = 2, KH_BAYER_GBRG = 3 };
+KH_API int32_t kh_rgb_from_bayer_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t width, int32_t height,
+                                    int32_t pattern);
+
 /* YUYV -> RGB8 with a selectable matrix — replaces the yuyv_to_rgb_{bt601_full,bt709_full,bt601_limited}_u8
  * launchers (P/cuda/color/video.rs:128-190) == convert_yuyv_to_rgb_u8 (P/color/yuv/mod.rs:342-410; Q10
  * integer, one (U,V) per pixel pair).  src: width*height*2 bytes `Y0 U Y1 V`; an odd width leaves the

@@ -497,6 +497,13 @@ inline void yuyv_from_rgb(const Image<uint8_t, 3>& src, uint8_t* out_device) {
     detail::check(kh_yuyv_from_rgb_u8(src.stream()->handle(), src.device_ptr(), out_device, detail::i32(src.width()), detail::i32(src.height())));
 }
 
+// color::rgb_from_bayer (P/color/bayer/mod.rs:37-70): bilinear, cv2-compatible demosaic
+enum class BayerPattern { Rggb = KH_BAYER_RGGB, Bggr = KH_BAYER_BGGR, Grbg = KH_BAYER_GRBG, Gbrg = KH_BAYER_GBRG };
+inline void rgb_from_bayer(const Image<uint8_t, 1>& src, BayerPattern pattern, Image<uint8_t, 3>& dst) {
+    const Stream& s = helpers::map_pair(src, dst, "rgb_from_bayer");
+    detail::check(kh_rgb_from_bayer_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), (int32_t)pattern));
+}
+
 // resize launchers with their PixelMapping, the fused resize + normalise, cv2-compatible resize (P/cuda/resize.rs:433-930,
 // P/resize/opencv_compat.rs:76-250)
 enum class PixelMapping { HalfPixel = KH_MAP_HALF_PIXEL, AlignCorners = KH_MAP_ALIGN_CORNERS };

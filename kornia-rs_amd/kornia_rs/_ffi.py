@@ -42,6 +42,7 @@ class FusedStage(C.Structure):
 KH_BORDER = {"constant": 0, "replicate": 1, "reflect101": 2, "reflect": 3, "wrap": 4}
 KH_MORPH_SHAPE = {"box": 0, "cross": 1, "ellipse": 2}
 KH_PIXEL_MAPPING = {"half_pixel": 0, "align_corners": 1}  # PixelMapping, P/cuda/resize.rs:438-454
+KH_BAYER = {"rggb": 0, "bggr": 1, "grbg": 2, "gbrg": 3}  # BayerPattern, I/color_spaces.rs:853-862
 KH_YUV_MODE = {"bt601_full": 0, "bt709_full": 1, "bt601_limited": 2}  # YuvToRgbMode, P/color/yuv/mod.rs:319-327
 # kh_color_convert_f64 codes: 0..7 = KH_CIE, then the gray / hsv / hls / YCbCr / YUV f64 twins
 KH_F64 = {**KH_CIE, "gray_from_rgb": 8, "rgb_from_gray": 9, "hsv_from_rgb": 10, "rgb_from_hsv": 11, "hls_from_rgb": 12,
@@ -125,6 +126,7 @@ SIGNATURES = {
     "kh_cie_convert_f32": (_i32, [_vp, _vp, _vp, _i64, _i32]),
     "kh_color_convert_f64": (_i32, [_vp, _vp, _vp, _i64, _i32]),
     "kh_yuyv_to_rgb_mode_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),
+    "kh_rgb_from_bayer_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),
     "kh_rgb_from_rgba_u8": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "kh_apply_colormap_u8": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "kh_rgb_from_planar420_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),

@@ -136,6 +136,42 @@ class Yvyu8(_Packed422): layout = "yvyu"
 
 
 
+
+class Bayer8:
+    """Single-channel 8-bit mosaic tagged with its ``BayerPattern`` (color_spaces.rs:853-900): ``rggb`` | ``bggr`` | ``grbg`` |
+    ``gbrg``.  ``convert(bayer, Rgb8)`` / ``imgproc.rgb_from_bayer(bayer)`` demosaic it."""
+    PATTERNS = ("rggb", "bggr", "grbg", "gbrg")
+
+    def __init__(self, data, pattern: str):
+        self.pattern = str(pattern).lower()
+        if self.pattern not in self.PATTERNS:
+            raise ImageError("InvalidArgument", f"Bayer8: unknown pattern {pattern!r} ({', '.join(self.PATTERNS)})")
+        if isinstance(data, Image):
+            img = data
+        else:
+            a = np.asarray(data)
+            if a.ndim == 2:
+                a = a[:, :, None]
+            if a.ndim != 3 or a.shape[2] != 1 or a.dtype != np.uint8:
+                raise ImageError("InvalidChannelShape", f"Bayer8 needs a [H, W] or [H, W, 1] uint8 array, got {a.shape} {a.dtype}")
+            img = Image.from_numpy(np.ascontiguousarray(a))
+        if img.channels != 1 or img.dtype != "uint8":
+            raise ImageError("InvalidChannelShape", "Bayer8 wraps a single-channel uint8 image")
+        self._image = img
+
+    def as_image(self) -> Image: return self._image
+    @property
+    def size(self): return self._image.size
+    @property
+    def is_device(self) -> bool: return self._image.is_device
+
+    def to_hip(self, stream: Stream) -> "Bayer8":
+        return Bayer8(self._image.to_hip(stream), self.pattern)
+
+    def cpu(self) -> "Bayer8":
+        return Bayer8(self._image.cpu(), self.pattern)
+
+
 # ---- DeviceVideoFrame (P/cuda/color/video.rs:470-640) -------------------------------------------------------------
 VIDEO_FORMATS = {"nv12": Nv12, "nv21": Nv21, "i420": I420, "yv12": Yv12, "yuyv": Yuyv8, "uyvy": Uyvy8, "yvyu": Yvyu8}
 
@@ -234,6 +270,12 @@ def convert(src, to, dst: Optional[Image] = None, background=None) -> Image:
     The result carries the destination tag."""
     from . import imgproc
     want = _space_of(to)
+    if isinstance(src, Bayer8):  # impl ConvertColor<Rgb8> for Bayer8 (convert.rs:101-106)
+        if want is not ColorSpace.RGB:
+            raise ImageError("NoDeviceKernel", f"convert: a Bayer mosaic demosaics to RGB8 only (asked for {want.name})")
+        out = imgproc.rgb_from_bayer(src, None, dst)
+        out.color_space = want
+        return out
     if isinstance(src, _VideoBuffer):
         if want is not ColorSpace.RGB:
             raise ImageError("NoDeviceKernel", f"convert: camera buffers decode to RGB8 only (asked for {want.name})")

@@ -253,6 +253,24 @@ def rgb_from_uyvy(data, width, height, dst=None): return _decode("packed422", 1,
 def rgb_from_yvyu(data, width, height, dst=None): return _decode("packed422", 2, data, width, height, dst)
 
 
+def rgb_from_bayer(src, pattern: Optional[str] = None, dst: Optional[Image] = None) -> Image:
+    """Bilinear, cv2-compatible demosaic of a single-channel uint8 mosaic (``rgb_from_bayer``, P/color/bayer/mod.rs:37-70;
+    imgproc.pyi:58).  ``src``: a 1-channel image plus ``pattern`` in ``rggb`` | ``bggr`` | ``grbg`` | ``gbrg``, or a
+    ``color_spaces.Bayer8`` that carries its pattern."""
+    if hasattr(src, "pattern") and hasattr(src, "as_image"):
+        pattern, src = pattern or src.pattern, src.as_image()
+    code = _ffi.KH_BAYER.get(str(pattern).lower())
+    if code is None:
+        raise ImageError("InvalidArgument", f"rgb_from_bayer: unknown pattern {pattern!r} ({', '.join(_ffi.KH_BAYER)})")
+    _require(src, "uint8", (1,), "rgb_from_bayer")
+    out = dst if dst is not None else _new_like(src, channels=3)
+    _require(out, "uint8", (3,), "rgb_from_bayer")
+    _same_size(src, out)
+    stream = _pair_residency(src, out)
+    _check(lib.kh_rgb_from_bayer_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, code))
+    return out
+
+
 def convert_yuyv_to_rgb_u8(data, width: int, height: int, mode: str = "bt601_limited", dst: Optional[Image] = None) -> Image:
     """YUYV -> RGB8 with a selectable matrix: ``mode`` in ``bt601_full`` | ``bt709_full`` | ``bt601_limited``
     (``YuvToRgbMode``, P/color/yuv/mod.rs:319-410).  ``data``: a device buffer / ``color_spaces.Yuyv8`` of

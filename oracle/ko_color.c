@@ -425,3 +425,65 @@ int ko_yuyv_to_rgb_mode(const uint8_t* src, uint8_t* dst, int w, int h, int mode
     }
     return 0;
 }
+
+/* ---- rgb_from_bayer (P/color/bayer/mod.rs:37-70; kernels.rs:30-200): bilinear demosaic, u8 -------------------------
+ * pattern 0 RGGB, 1 BGGR, 2 GRBG, 3 GBRG.  demosaic_px over replicate-clamped neighbours for every pixel, then
+ * bayer_border_replicate: row 0 <- row 1 and last row <- the row above it (when rows >= 3), then column 0 <- column 1 and
+ * last column <- the one before it (when cols >= 3).                                                                  */
+enum { CELL_R = 0, CELL_G_ON_R = 1, CELL_G_ON_B = 2, CELL_B = 3 };
+static const int BAYER_PHASE[4][2][2] = {
+    {{CELL_R, CELL_G_ON_R}, {CELL_G_ON_B, CELL_B}},   /* Rggb */
+    {{CELL_B, CELL_G_ON_B}, {CELL_G_ON_R, CELL_R}},   /* Bggr */
+    {{CELL_G_ON_R, CELL_R}, {CELL_B, CELL_G_ON_B}},   /* Grbg */
+    {{CELL_G_ON_B, CELL_B}, {CELL_R, CELL_G_ON_R}},   /* Gbrg */
+};
+static inline uint8_t bayer_at(const uint8_t* src, long r, long c, int rows, int cols) {
+    long rr = r < 0 ? 0 : (r > rows - 1 ? rows - 1 : r), cc = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
+    return src[rr * cols + cc];
+}
+static inline uint8_t avg2u(uint8_t a, uint8_t b) { return (uint8_t)(((unsigned)a + b + 1u) >> 1); }
+static inline uint8_t avg4u(uint8_t a, uint8_t b, uint8_t c, uint8_t d) { return (uint8_t)(((unsigned)a + b + c + d + 2u) >> 2); }
+
+int ko_rgb_from_bayer(const uint8_t* src, uint8_t* dst, int cols, int rows, int pattern) {
+    if (pattern < 0 || pattern > 3 || rows < 0 || cols < 0) return -1;
+    if (rows == 0 || cols == 0) return 0;
+    for (long r = 0; r < rows; ++r)
+        for (long c = 0; c < cols; ++c) {
+            uint8_t center = src[r * cols + c], red, green, blue;
+            switch (BAYER_PHASE[pattern][r & 1][c & 1]) {
+                case CELL_R:
+                    green = avg4u(bayer_at(src, r - 1, c, rows, cols), bayer_at(src, r + 1, c, rows, cols), bayer_at(src, r, c - 1, rows, cols), bayer_at(src, r, c + 1, rows, cols));
+                    blue = avg4u(bayer_at(src, r - 1, c - 1, rows, cols), bayer_at(src, r - 1, c + 1, rows, cols), bayer_at(src, r + 1, c - 1, rows, cols), bayer_at(src, r + 1, c + 1, rows, cols));
+                    red = center;
+                    break;
+                case CELL_B:
+                    green = avg4u(bayer_at(src, r - 1, c, rows, cols), bayer_at(src, r + 1, c, rows, cols), bayer_at(src, r, c - 1, rows, cols), bayer_at(src, r, c + 1, rows, cols));
+                    red = avg4u(bayer_at(src, r - 1, c - 1, rows, cols), bayer_at(src, r - 1, c + 1, rows, cols), bayer_at(src, r + 1, c - 1, rows, cols), bayer_at(src, r + 1, c + 1, rows, cols));
+                    blue = center;
+                    break;
+                case CELL_G_ON_R:
+                    red = avg2u(bayer_at(src, r, c - 1, rows, cols), bayer_at(src, r, c + 1, rows, cols));
+                    blue = avg2u(bayer_at(src, r - 1, c, rows, cols), bayer_at(src, r + 1, c, rows, cols));
+                    green = center;
+                    break;
+                default:
+                    blue = avg2u(bayer_at(src, r, c - 1, rows, cols), bayer_at(src, r, c + 1, rows, cols));
+                    red = avg2u(bayer_at(src, r - 1, c, rows, cols), bayer_at(src, r + 1, c, rows, cols));
+                    green = center;
+            }
+            uint8_t* o = dst + (r * cols + c) * 3;
+            o[0] = red; o[1] = green; o[2] = blue;
+        }
+    size_t w = (size_t)cols * 3;
+    if (rows >= 3) {
+        memcpy(dst, dst + w, w);
+        memcpy(dst + (size_t)(rows - 1) * w, dst + (size_t)(rows - 2) * w, w);
+    }
+    if (cols >= 3)
+        for (long r = 0; r < rows; ++r) {
+            uint8_t* row = dst + (size_t)r * w;
+            memcpy(row, row + 3, 3);
+            memcpy(row + (size_t)(cols - 1) * 3, row + (size_t)(cols - 2) * 3, 3);
+        }
+    return 0;
+}

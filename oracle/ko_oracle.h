@@ -143,6 +143,8 @@ void ko_fused_pipeline(const uint8_t* src, int sw, int sh, int rdw, int rdh, int
 /* ---- CIE colour spaces (ko_cie.c) -------------------------------------------------------------------- */
 void ko_cie_f32(const float* src, float* dst, size_t npixels, int conv);
 void ko_cie_f64(const double* src, double* dst, size_t npixels, int conv);
+/* rgb_from_bayer (P/color/bayer/mod.rs:37): pattern 0 RGGB, 1 BGGR, 2 GRBG, 3 GBRG; -1 on a bad argument */
+int ko_rgb_from_bayer(const uint8_t* src, uint8_t* dst, int cols, int rows, int pattern);
 /* convert_yuyv_to_rgb_u8 (P/color/yuv/mod.rs:342): mode 0 Bt601Full, 1 Bt709Full, 2 Bt601Limited; -1 on a bad argument */
 int ko_yuyv_to_rgb_mode(const uint8_t* src, uint8_t* dst, int w, int h, int mode);
 /* f64 colour family (ko_color_f64.c): conv 0..7 = ko_cie_f64, 8..17 gray / hsv / hls / ycbcr / yuv; -1 on an unknown code */

@@ -56,6 +56,7 @@ static void host_only() {
     EXPECT(throws_kind(H, [&] { imgproc::rgb_from_planar420(nullptr, 0, u3, imgproc::Planar420::Nv12); }));
     EXPECT(throws_kind(H, [&] { imgproc::rgb_from_packed422(nullptr, 0, u3, imgproc::Packed422::Uyvy); }));
     EXPECT(throws_kind(H, [&] { imgproc::convert_yuyv_to_rgb_u8(nullptr, 0, u3, imgproc::YuvToRgbMode::Bt709Full); }));
+    EXPECT(throws_kind(H, [&] { imgproc::rgb_from_bayer(u1, imgproc::BayerPattern::Grbg, u3); }));
     EXPECT(throws_kind(H, [&] { imgproc::nv12_from_rgb(u3, nullptr); }));
     EXPECT(throws_kind(H, [&] { imgproc::yuyv_from_rgb(u3, nullptr); }));
     EXPECT(throws_kind(H, [&] { imgproc::resize_mapped(f3, f3s, InterpolationMode::Bicubic, imgproc::PixelMapping::AlignCorners); }));
@@ -148,6 +149,11 @@ static void on_device() {
         EXPECT(rgb.to_host().as_slice() == std::vector<uint8_t>(6, 0));
         imgproc::convert_yuyv_to_rgb_u8(yuyv.device_ptr(), 4, rgb, imgproc::YuvToRgbMode::Bt601Full);
         EXPECT(rgb.to_host().as_slice() == std::vector<uint8_t>(6, 16));  // full range: Y passes through at neutral chroma
+        auto mosaic = up<uint8_t, 1>(s, 4, 4, {10, 20, 30, 40, 50, 60, 70, 80, 90, 100, 110, 120, 130, 140, 150, 160});
+        auto demo = Image<uint8_t, 3>::zeros_hip({4, 4}, s);
+        imgproc::rgb_from_bayer(mosaic, imgproc::BayerPattern::Rggb, demo);  // rggb_interior_known_value, corners_use_replicate_border
+        const auto dm = demo.to_host();
+        EXPECT(dm.as_slice()[(4 + 1) * 3] == 60 && dm.as_slice()[(4 + 1) * 3 + 1] == 60 && dm.as_slice()[(4 + 2) * 3 + 2] == 70 && dm.as_slice()[0] == 60);
         auto solid = Image<uint8_t, 3>::from_size_val({4, 2}, 200).to_hip(s);
         auto nv12 = Image<uint8_t, 1>::zeros_hip({4 * 2 * 3 / 2, 1}, s);
         imgproc::nv12_from_rgb(solid, nv12.device_ptr_mut());

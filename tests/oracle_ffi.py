@@ -629,3 +629,18 @@ def resize_bilinear_normalize(src, dw, dh, mean, std, mapping="half_pixel"):
     if rc:
         raise ValueError(f"ko_resize_bilinear_normalize_f32 -> {rc}")
     return out
+
+
+BAYER = {"rggb": 0, "bggr": 1, "grbg": 2, "gbrg": 3}
+ko.ko_rgb_from_bayer.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+ko.ko_rgb_from_bayer.restype = C.c_int
+
+
+def rgb_from_bayer(mosaic, pattern):
+    m = np.ascontiguousarray(mosaic, np.uint8)
+    if m.ndim == 3:
+        m = m[:, :, 0]
+    h, w = m.shape
+    out = np.empty((h, w, 3), np.uint8)
+    assert ko.ko_rgb_from_bayer(np.ascontiguousarray(m).reshape(-1), out.reshape(-1), w, h, BAYER[pattern]) == 0
+    return out

@@ -77,6 +77,8 @@ CASES = [
     ("yuyv mode decode: unknown mode", lambda: L.kh_yuyv_to_rgb_mode_u8(S, P, Q, 8, 4, 3), INVALID, "mode 3"),
     ("yuyv mode decode: null", lambda: L.kh_yuyv_to_rgb_mode_u8(S, None, Q, 8, 4, 0), INVALID, "null"),
     ("yuyv mode decode: > 2^31 bytes", lambda: L.kh_yuyv_to_rgb_mode_u8(S, P, Q, 40000, 40000, 0), TOO_LARGE, "32-bit"),
+    ("bayer: unknown pattern", lambda: L.kh_rgb_from_bayer_u8(S, P, Q, 8, 4, 4), INVALID, "pattern 4"),
+    ("bayer: null", lambda: L.kh_rgb_from_bayer_u8(S, P, None, 8, 4, 0), INVALID, "null"),
     ("planar 4:2:0: odd width", lambda: L.kh_rgb_from_planar420_u8(S, P, Q, 7, 4, 0), INVALID, "even"),
     ("planar 4:2:0: unknown layout", lambda: L.kh_rgb_from_planar420_u8(S, P, Q, 8, 4, 9), INVALID, "layout 9"),
     ("packed 4:2:2: odd width", lambda: L.kh_rgb_from_packed422_u8(S, P, Q, 7, 4, 0), INVALID, "even"),
@@ -120,3 +122,4 @@ def test_empty_batches_and_images_are_no_ops_without_a_device():
     assert L.kh_yuyv_to_rgb_mode_u8(S, None, None, 1, 9, 0) == 0  # width 1: no whole pixel pair
     assert L.kh_flip(S, P, Q, 0, 8, 3, 1) == 0
     assert L.kh_graph_destroy(None) == 0
+    assert L.kh_rgb_from_bayer_u8(S, None, None, 0, 7, 1) == 0

@@ -72,3 +72,47 @@ def test_rgba_swizzles():
     a = np.float32(128) / np.float32(255)
     mid = [int(np.round(np.float32(c) * a + np.float32(b) * (np.float32(1) - a))) for c, b in zip((10, 20, 30), (100, 50, 200))]
     assert got == [100, 50, 200, 10, 20, 30] + mid
+
+
+# ---- Bayer demosaic (P/color/bayer/mod.rs:100-203) -----------------------------------------------------
+
+RAMP4 = np.array([10, 20, 30, 40, 50, 60, 70, 80, 90, 100, 110, 120, 130, 140, 150, 160], np.uint8).reshape(4, 4)
+
+
+def _numpy_demosaic(m, pattern):
+    """Independent form: replicate-pad, per-colour-plane bilinear fill with rounded means, then the cv2 frame rule."""
+    h, w = m.shape
+    p = np.pad(m.astype(np.int64), 1, mode="edge")
+    n, s, wv, e = p[:-2, 1:-1], p[2:, 1:-1], p[1:-1, :-2], p[1:-1, 2:]
+    nw, ne, sw_, se = p[:-2, :-2], p[:-2, 2:], p[2:, :-2], p[2:, 2:]
+    cross, diag, horiz, vert = (n + s + wv + e + 2) >> 2, (nw + ne + sw_ + se + 2) >> 2, (wv + e + 1) >> 1, (n + s + 1) >> 1
+    rr, cc = np.mgrid[0:h, 0:w]
+    r0, c0 = {"rggb": (0, 0), "bggr": (1, 1), "grbg": (0, 1), "gbrg": (1, 0)}[pattern]  # where the red sensel sits in the 2x2 cell
+    is_r = ((rr & 1) == r0) & ((cc & 1) == c0)
+    is_b = ((rr & 1) == 1 - r0) & ((cc & 1) == 1 - c0)
+    g_on_r_row = ((rr & 1) == r0) & ~is_r
+    c = m.astype(np.int64)
+    red = np.where(is_r, c, np.where(is_b, diag, np.where(g_on_r_row, horiz, vert)))
+    blue = np.where(is_b, c, np.where(is_r, diag, np.where(g_on_r_row, vert, horiz)))
+    green = np.where(is_r | is_b, cross, c)
+    out = np.stack([red, green, blue], -1).astype(np.uint8)
+    if h >= 3:
+        out[0], out[-1] = out[1], out[-2]
+    if w >= 3:
+        out[:, 0], out[:, -1] = out[:, 1], out[:, -2]
+    return out
+
+
+def test_bayer_reference_known_answers():
+    for p in O.BAYER:  # flat_mosaic_is_flat
+        assert (O.rgb_from_bayer(np.full((6, 6), 200, np.uint8), p) == 200).all(), p
+    out = O.rgb_from_bayer(RAMP4, "rggb")
+    assert out[1, 1].tolist() == [60, 60, 60] and out[1, 2].tolist() == [70, 70, 70]  # rggb_interior_known_value
+    assert out[0, 0].tolist() == [60, 60, 60] and np.array_equal(out[0, 2], out[1, 2])  # corners_use_replicate_border
+
+
+def test_bayer_matches_independent_numpy_form():
+    for (w, h) in [(4, 4), (5, 5), (7, 6), (33, 4), (40, 9), (3, 3), (2, 2), (1, 5), (6, 1), (1, 1), (2, 7)]:  # mod.rs:107-119 sizes + degenerate ones
+        data = ((np.arange(w * h) * 37 + 11) % 256).astype(np.uint8).reshape(h, w)
+        for p in O.BAYER:
+            assert np.array_equal(O.rgb_from_bayer(data, p), _numpy_demosaic(data, p)), (p, w, h)

@@ -319,3 +319,21 @@ def test_min_max_ignores_nan_in_any_lane(gpu_stream):
     y[0] = np.nan           # a NaN FIRST element poisons both, as the reference loop does
     lo, hi = imgproc.find_min_max(Image.from_numpy(y.reshape(1, -1, 1)).to_hip(gpu_stream))
     assert np.isnan(lo) and np.isnan(hi)
+
+
+# ---- Bayer demosaic (P/cuda/color/bayer.rs, P/color/bayer/mod.rs) -------------------------------------------------------------
+
+@pytest.mark.parametrize("pattern", sorted(O.BAYER))
+def test_bayer_demosaic_bit_exact(gpu_stream, pattern):
+    from kornia_rs import Image, ImageError, color_spaces as cs, imgproc
+    for (w, h) in [(4, 4), (5, 5), (7, 6), (33, 4), (40, 9), (3, 3), (2, 2), (1, 5), (6, 1), (1, 1), (131, 67), (640, 37)]:
+        data = ((np.arange(w * h) * 37 + 11) % 256).astype(np.uint8).reshape(h, w, 1)
+        got = imgproc.rgb_from_bayer(Image.from_numpy(data).to_hip(gpu_stream), pattern)
+        assert got.shape == (h, w, 3) and np.array_equal(got.numpy(), O.rgb_from_bayer(data, pattern)), (pattern, w, h)
+    mosaic = cs.Bayer8(O.pattern_u8(48 * 36).reshape(36, 48), pattern).to_hip(gpu_stream)
+    rgb = cs.convert(mosaic, cs.Rgb8)
+    assert rgb.color_space is cs.ColorSpace.RGB and np.array_equal(rgb.numpy(), O.rgb_from_bayer(mosaic.cpu().as_image().numpy(), pattern))
+    with pytest.raises(ImageError):  # size_mismatch_errors
+        imgproc.rgb_from_bayer(mosaic, None, Image.zeros(49, 36, 3, "uint8", gpu_stream))
+    with pytest.raises(ImageError):
+        imgproc.rgb_from_bayer(mosaic.as_image(), "rgbg")
