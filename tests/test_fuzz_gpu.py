@@ -148,3 +148,43 @@ def test_fuzz_fused_preprocess(gpu_stream, seed):
             assert np.abs(a - b).max() <= (2e-4 if not f16 else 4e-3) * max(1.0, float(np.abs(b).max())), what
         else:
             assert np.array_equal(got, want), what
+
+
+@pytest.mark.parametrize("seed", range(4 + EXTRA))
+def test_fuzz_colour_and_camera_formats(gpu_stream, seed):
+    """Pointwise colour maps at odd pixel counts (quad / tail paths of the u8 map kernel), camera-format decode / encode at
+    random even sizes, Bayer at any size."""
+    from kornia_rs import imgproc
+    from kornia_rs.hip import DeviceBuffer
+    rng = np.random.default_rng(6000 + seed)
+    for _ in range(6):
+        h, w = _shape(rng, 1, 50)
+        u = _u8(rng, h, w, 3)
+        ud = _up(u, gpu_stream)
+        for name, cout, extra in (("gray_from_rgb_u8", 1, ()), ("bgr_from_rgb_u8", 3, ()), ("sepia_from_rgb_u8", 3, ()),
+                                  ("ycc_from_rgb_u8", 3, (int(rng.integers(0, 2)),))):
+            fn = {"gray_from_rgb_u8": imgproc.gray_from_rgb, "bgr_from_rgb_u8": imgproc.bgr_from_rgb, "sepia_from_rgb_u8": imgproc.sepia_from_rgb,
+                  "ycc_from_rgb_u8": (imgproc.ycbcr_from_rgb if extra == (0,) else imgproc.yuv_from_rgb)}[name]
+            assert np.array_equal(fn(ud).numpy().reshape(-1), O.color_map(name, u, cout, *extra)), (name, w, h)
+        f = (u.astype(np.float32))
+        fd = _up(f, gpu_stream)
+        for name, fn in (("hsv_from_rgb_f32", imgproc.hsv_from_rgb), ("hls_from_rgb_f32", imgproc.hls_from_rgb)):
+            assert np.array_equal(fn(fd).numpy().reshape(-1), O.color_map(name, f, 3)), (name, w, h)
+        w2, h2 = 2 * int(rng.integers(1, 30)), 2 * int(rng.integers(1, 20))
+        rgb = _u8(rng, h2, w2, 3)
+        rd = _up(rgb, gpu_stream)
+        nv12 = imgproc.nv12_from_rgb(rd)
+        assert np.array_equal(nv12.numpy_raw().reshape(-1), O.nv12_from_rgb(rgb)), ("nv12_from_rgb", w2, h2)
+        yuyv = imgproc.yuyv_from_rgb(rd)
+        assert np.array_equal(yuyv.numpy_raw().reshape(-1), O.yuyv_from_rgb(rgb)), ("yuyv_from_rgb", w2, h2)
+        for layout, decode in enumerate((imgproc.rgb_from_nv12, imgproc.rgb_from_nv21, imgproc.rgb_from_i420, imgproc.rgb_from_yv12)):
+            raw = rng.integers(0, 256, w2 * h2 * 3 // 2, dtype=np.uint8)
+            got = decode(DeviceBuffer.from_numpy(raw, gpu_stream), w2, h2).numpy()
+            assert np.array_equal(got, O.rgb_from_nv12(raw, w2, h2, layout)), ("planar420", layout, w2, h2)
+        for layout, decode in enumerate((imgproc.rgb_from_yuyv, imgproc.rgb_from_uyvy, imgproc.rgb_from_yvyu)):
+            raw = rng.integers(0, 256, w2 * h2 * 2, dtype=np.uint8)
+            got = decode(DeviceBuffer.from_numpy(raw, gpu_stream), w2, h2).numpy()
+            assert np.array_equal(got, O.rgb_from_yuyv(raw, w2, h2, layout)), ("packed422", layout, w2, h2)
+        mosaic = _u8(rng, h, w, 1)
+        pattern = str(rng.choice(sorted(O.BAYER)))
+        assert np.array_equal(imgproc.rgb_from_bayer(_up(mosaic, gpu_stream), pattern).numpy(), O.rgb_from_bayer(mosaic, pattern)), ("bayer", pattern, w, h)
