@@ -18,6 +18,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Files whose GPU tests were written after this round's last device run (they pass on the host simulator of the kernels,
+# tests/hostsim; a device run is pending).  `pytest -x` stops at the first failure, so they are collected AFTER the
+# device-verified files: a surprise in a new test must not hide the verdict on the ~700 tests that already ran on MI355X.
+# Empty this list once a device run has covered them.
+DEVICE_RUN_PENDING = ("test_bench_workloads_gpu.py", "test_color_f64.py", "test_video_modes.py", "test_fuzz_gpu.py",
+                      "test_cpp_mirror.py", "test_zz_host_extras_gpu.py")
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: Path(str(it.fspath)).name in DEVICE_RUN_PENDING)  # stable: keeps file / definition order
+
+
 def _ensure_built():
     """Build the HIP library and the oracle if a fresh checkout has neither (cross-compiles on CPU)."""
     import subprocess
