@@ -700,6 +700,130 @@ class LabFromRgb4K(U8Images):
         return self._time_cpu(lambda O: O.cie("lab_from_rgb", img), "lab_from_rgb")
 
 
+class SpatialGradient1080p(F32Images):
+    """spatial_gradient_float (normalised 3x3 Sobel, dx + dy) on 1920x1080 f32x3, batch 256."""
+
+    name, kernel = "spatial_gradient_sobel_1080p_f32_b256", "spatial_gradient_kernel"
+    W, H, C = 1920, 1080, 3
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * 3 * self.W * self.H * self.C * 4  # 1R + 2W
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.W * self.H * self.C * 4, stream, zeroed=False)
+        self.dst_y = DeviceBuffer(self.N * self.W * self.H * self.C * 4, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        n = self.W * self.H * self.C
+        check(lib.kh_spatial_gradient_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.dst_y.ptr, self.W, self.H, self.C, 0,
+                                          self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::filter::spatial_gradient_float (3x3 Sobel, dx and dy)", "src": "1920x1080x3 f32",
+                "dst": "2 x same", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        O = self._oracle()
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        threads = O.ko.ko_max_threads()
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 8.0 and reps < 64:
+            O.spatial_gradient(img, "sobel")
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": round(reps * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+                "sample": f"{reps} images in {dt:.1f} s; C oracle of spatial_gradient_float_parallel_row (not the upstream Rust binary), OpenMP x{threads}"}
+
+
+class BoxBlurFast1080p(SpatialGradient1080p):
+    """box_blur_fast sigma (2, 2): six running-sum passes through a transposed scratch, 1920x1080 f32x3, batch 64."""
+
+    name, kernel = "box_blur_fast_sigma2_1080p_f32_b64", "fast_hfilter_kernel"
+
+    def __init__(self, batch):
+        super().__init__(batch)
+        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C * 4  # per pass (six launches per step): 1R + 1W
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        n = self.W * self.H * self.C
+        check(lib.kh_box_blur_fast_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.dst_y.ptr, self.W, self.H, self.C, 2.0, 2.0,
+                                       self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::filter::box_blur_fast sigma (2,2): 3 x (row pass -> transposed scratch -> row pass)",
+                "src": "1920x1080x3 f32", "dst": "same", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        O = self._oracle()
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        threads = O.ko.ko_max_threads()
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 8.0 and reps < 64:
+            O.box_blur_fast(img, (2.0, 2.0))
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": round(reps * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+                "sample": f"{reps} images in {dt:.1f} s; C oracle of box_blur_fast (single-threaded in the reference), OpenMP x{threads} over rows"}
+
+
+class Median5U8_1080p(U8Images):
+    """median_blur 5x5 on 1920x1080 RGB8, batch 256 (compute-bound: packed min/max selection network)."""
+
+    name, kernel = "median_blur_5x5_1080p_rgb8_b256", "median_kernel<5,3>"
+    W, H, C = 1920, 1080, 3
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.W * self.H * self.C, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        n = self.W * self.H * self.C
+        check(lib.kh_median_blur_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.C, 5, self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::filter::median_blur ksize 5 (replicate border)", "src": "1920x1080x3 u8", "dst": "same",
+                "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        return self._time_cpu(lambda O: O.median_blur(img, 5), "median_blur (counting form)")
+
+
+class Bilateral1080p(Median5U8_1080p):
+    """bilateral_filter d=5 sigma (50, 50) on 1920x1080 gray u8, batch 256 — the reference's probe shape (median.rs:1143-1178)."""
+
+    name, kernel = "bilateral_d5_1080p_gray8_b256", "bilateral_kernel"
+    C = 1
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        n = self.W * self.H
+        check(lib.kh_bilateral_filter_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, 5, 50.0, 50.0, self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::filter::bilateral_filter d=5 sigma_color=50 sigma_space=50 (cv2-compatible)",
+                "src": "1920x1080x1 u8", "dst": "same", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        img = self.base[: self.W * self.H].reshape(self.H, self.W, 1)
+        return self._time_cpu(lambda O: O.bilateral_filter(img, 5, 50.0, 50.0), "bilateral_filter")
+
+
 WORKLOADS = {
     "nv12_chw": lambda a: NorthStarNV12(a.batch or 1024, 0),
     "nv12_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640),
@@ -715,6 +839,10 @@ WORKLOADS = {
     "pyrdown_u8_4k": lambda a: PyrDownU8_4K(a.batch or 256),
     "dilate_u8_4k": lambda a: DilateU8_4K(a.batch or 256),
     "lab_from_rgb_4k": lambda a: LabFromRgb4K(a.batch or 64),
+    "spatial_gradient_1080p": lambda a: SpatialGradient1080p(a.batch or 256),
+    "box_blur_fast_1080p": lambda a: BoxBlurFast1080p(a.batch or 64),
+    "median5_u8_1080p": lambda a: Median5U8_1080p(a.batch or 256),
+    "bilateral_1080p": lambda a: Bilateral1080p(a.batch or 256),
 }
 
 

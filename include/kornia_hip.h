@@ -316,6 +316,50 @@ KH_API int32_t kh_box_blur_kernel_1d(int32_t n, float* out);
 KH_API int32_t kh_gaussian_kernel_1d(int32_t n, float sigma, float* out);
 KH_API int32_t kh_gaussian_resolve(int32_t ksize_xy[2], float sigma_xy[2]);
 
+/* ------------------------------------------------------------------------------------------ */
+/* The rest of the reference's filter module.  Strides in ELEMENTS between batch images.
+ *
+ * spatial_gradient_float / scharr_spatial_gradient_float (P/filter/ops.rs:287-590; the _parallel
+ * variants share the arithmetic): normalised 3x3 Sobel / Scharr cross-correlation
+ * (P/filter/kernels.rs:107-140), replicate border, nine products added in row-major tap order.
+ * kind = KH_GRAD_SOBEL | KH_GRAD_SCHARR; src, dx, dy distinct images of the same shape.        */
+KH_API int32_t kh_spatial_gradient_f32(kh_stream_t stream, const float* src, float* dx, float* dy, int32_t cols,
+                                       int32_t rows, int32_t channels, int32_t kind, int32_t batch, int64_t src_stride,
+                                       int64_t dst_stride);
+/* box_blur_fast (P/filter/ops.rs:252-285): three rounds of a running-sum box per axis with the
+ * sizes of box_blur_fast_kernels_1d (P/filter/kernels.rs:151-170) used as half widths, exactly as
+ * the reference does.  `scratch` = batch images of cols*rows*channels floats (the transposed
+ * intermediate, caller-provided like the reference's low-level filter launcher's scratch,
+ * P/cuda/filter.rs:361).  A half width that does not fit the image is KH_ERR_INVALID_ARG (the
+ * reference indexes out of bounds there).  kh_fast_horizontal_filter_f32 is one pass
+ * (fast_horizontal_filter, P/filter/separable_filter.rs:202-257): dst is rows-wide, cols-tall.   */
+KH_API int32_t kh_box_blur_fast_kernels_1d(float sigma, int32_t kernels, int32_t* out);
+KH_API int32_t kh_fast_horizontal_filter_f32(kh_stream_t stream, const float* src, float* dst_transposed, int32_t cols,
+                                             int32_t rows, int32_t channels, int32_t half, int32_t batch,
+                                             int64_t src_stride, int64_t dst_stride);
+KH_API int32_t kh_box_blur_fast_f32(kh_stream_t stream, const float* src, float* dst, float* scratch, int32_t cols,
+                                    int32_t rows, int32_t channels, float sigma_x, float sigma_y, int32_t batch,
+                                    int64_t src_stride, int64_t dst_stride);
+/* median_blur == launch_median_u8 (P/filter/median.rs:174-250, P/cuda/median.rs:95-138): exact
+ * median of the replicate-bordered ksize x ksize window per channel; ksize 3 | 5 (else
+ * KH_ERR_INVALID_ARG, the reference's InvalidKernelLength), 1..4 channels.                        */
+KH_API int32_t kh_median_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t cols, int32_t rows,
+                                 int32_t channels, int32_t ksize, int32_t batch, int64_t src_stride,
+                                 int64_t dst_stride);
+/* bilateral_filter == launch_bilateral_u8 (P/filter/bilateral.rs:172-300, P/cuda/bilateral.rs:33-135):
+ * single-channel u8, byte-for-byte cv2.bilateralFilter semantics — circular window of radius d/2
+ * (or round(1.5 sigma_space) for d <= 0), reflect-101 border, cv2's colour table (its SIMD exp
+ * polynomial + scalar-expf tail) and its position-dependent tap order; sigma <= 1e-6 copies the
+ * source through.  Tables are built on the host and cached on the device per (d, sigmas).
+ * kh_bilateral_tables returns them (build_tables, bilateral.rs:110-170): *ntaps always; the
+ * arrays (color_weight: 256 entries) only when capacity >= *ntaps.                                */
+KH_API int32_t kh_bilateral_filter_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t cols, int32_t rows,
+                                      int32_t d, double sigma_color, double sigma_space, int32_t batch,
+                                      int64_t src_stride, int64_t dst_stride);
+KH_API int32_t kh_bilateral_tables(int32_t d, double sigma_color, double sigma_space, int32_t capacity, int32_t* radius,
+                                   int32_t* ntaps, int32_t* tap_dy, int32_t* tap_dx, float* space_weight,
+                                   float* color_weight, int32_t* simd_order);
+
 /* CIE colour spaces — replaces the 16 NVRTC kernels of P/cuda/color/cie.rs (adapters
  * P/color/cuda_dispatch.rs) == linear_rgb_from_rgb, rgb_from_linear_rgb, xyz_from_rgb, rgb_from_xyz,
  * lab_from_rgb, rgb_from_lab, luv_from_rgb, rgb_from_luv (P/color/cie/mod.rs:58-130): f32 RGB in [0, 1],

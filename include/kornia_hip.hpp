@@ -583,6 +583,49 @@ inline void scharr(const Image<float, C>& src, Image<float, C>& dst) {
                                             KH_GRAD_SCHARR, 3, 1, 0, 0));
 }
 
+// filter::spatial_gradient_float / scharr_spatial_gradient_float (P/filter/ops.rs:287, 511): normalised 3x3 derivatives
+template <int C>
+inline void spatial_gradient_float(const Image<float, C>& src, Image<float, C>& dx, Image<float, C>& dy) {
+    const Stream& s = detail::device_exec_for(src, dx, "spatial_gradient_float");
+    detail::device_exec_for(src, dy, "spatial_gradient_float");
+    detail::same_size(src, dx, "spatial_gradient_float");
+    detail::same_size(src, dy, "spatial_gradient_float");
+    detail::check(kh_spatial_gradient_f32(s.handle(), src.device_ptr(), dx.device_ptr_mut(), dy.device_ptr_mut(), detail::i32(src.width()),
+                                          detail::i32(src.height()), C, KH_GRAD_SOBEL, 1, 0, 0));
+}
+template <int C>
+inline void scharr_spatial_gradient_float(const Image<float, C>& src, Image<float, C>& dx, Image<float, C>& dy) {
+    const Stream& s = detail::device_exec_for(src, dx, "scharr_spatial_gradient_float");
+    detail::device_exec_for(src, dy, "scharr_spatial_gradient_float");
+    detail::same_size(src, dx, "scharr_spatial_gradient_float");
+    detail::same_size(src, dy, "scharr_spatial_gradient_float");
+    detail::check(kh_spatial_gradient_f32(s.handle(), src.device_ptr(), dx.device_ptr_mut(), dy.device_ptr_mut(), detail::i32(src.width()),
+                                          detail::i32(src.height()), C, KH_GRAD_SCHARR, 1, 0, 0));
+}
+// filter::box_blur_fast (P/filter/ops.rs:252): the transposed intermediate is a scratch image on the source's stream
+template <int C>
+inline void box_blur_fast(const Image<float, C>& src, Image<float, C>& dst, std::pair<float, float> sigma) {
+    const Stream& s = detail::device_exec_for(src, dst, "box_blur_fast");
+    detail::same_size(src, dst, "box_blur_fast");
+    auto scratch = Image<float, C>::uninit_hip(src.size(), s);
+    detail::check(kh_box_blur_fast_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), scratch.device_ptr_mut(), detail::i32(src.width()),
+                                       detail::i32(src.height()), C, sigma.first, sigma.second, 1, 0, 0));
+}
+// filter::median_blur (P/filter/median.rs:174), filter::bilateral_filter (P/filter/bilateral.rs:172)
+template <int C>
+inline void median_blur(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, int ksize) {
+    const Stream& s = detail::device_exec_for(src, dst, "median_blur");
+    detail::same_size(src, dst, "median_blur");
+    detail::check(kh_median_blur_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, ksize,
+                                    1, 0, 0));
+}
+inline void bilateral_filter(const Image<uint8_t, 1>& src, Image<uint8_t, 1>& dst, int d, double sigma_color, double sigma_space) {
+    const Stream& s = detail::device_exec_for(src, dst, "bilateral_filter");
+    detail::same_size(src, dst, "bilateral_filter");
+    detail::check(kh_bilateral_filter_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), d,
+                                         sigma_color, sigma_space, 1, 0, 0));
+}
+
 // pyramid::pyrdown / pyrup (P/pyramid.rs:180-520): dst is ceil(src / 2) resp. 2 * src
 namespace helpers {
 template <typename T, int C>

@@ -74,6 +74,7 @@ class PreprocessParams(C.Structure):
 
 _vp, _i32, _u64, _sz, _f32 = C.c_void_p, C.c_int32, C.c_uint64, C.c_size_t, C.c_float
 _i64 = C.c_int64
+_f64 = C.c_double
 _P = C.POINTER
 
 # name -> (restype, argtypes); every symbol kornia_hip.h declares must appear here
@@ -150,6 +151,13 @@ SIGNATURES = {
     "kh_gaussian_blur_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i64, _i64]),
     "kh_box_blur_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
     "kh_gradient_magnitude_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_spatial_gradient_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_box_blur_fast_kernels_1d": (_i32, [_f32, _i32, _P(_i32)]),
+    "kh_fast_horizontal_filter_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_box_blur_fast_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _i64, _i64]),
+    "kh_median_blur_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_bilateral_filter_u8": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f64, _f64, _i32, _i64, _i64]),
+    "kh_bilateral_tables": (_i32, [_i32, _f64, _f64, _i32, _P(_i32), _P(_i32), _vp, _vp, _vp, _vp, _vp]),
     "kh_box_blur_kernel_1d": (_i32, [_i32, _P(_f32)]),
     "kh_gaussian_kernel_1d": (_i32, [_i32, _f32, _P(_f32)]),
     "kh_gaussian_resolve": (_i32, [_P(_i32), _P(_f32)]),

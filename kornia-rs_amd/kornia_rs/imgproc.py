@@ -601,6 +601,87 @@ def separable_filter(src: Image, kernel_x: Sequence[float], kernel_y: Sequence[f
     return out
 
 
+def _spatial_gradient(src: Image, kind: int, dx: Optional[Image], dy: Optional[Image], what: str) -> Tuple[Image, Image]:
+    _require(src, "float32", tuple(range(1, 9)), what)
+    gx = dx if dx is not None else _new_like(src)
+    gy = dy if dy is not None else _new_like(src)
+    for g in (gx, gy):
+        _require(g, "float32", (src.channels,), what)
+        _same_size(src, g)
+    stream = _pair_residency(src, gx)
+    _pair_residency(src, gy)
+    _check(lib.kh_spatial_gradient_f32(stream.cuda_stream_ptr, src.data_ptr, gx.data_ptr, gy.data_ptr, src.width, src.height,
+                                       src.channels, kind, 1, 0, 0))
+    return gx, gy
+
+
+def spatial_gradient_float(src: Image, dx: Optional[Image] = None, dy: Optional[Image] = None) -> Tuple[Image, Image]:
+    """First-order derivatives with the normalised 3x3 Sobel operator (spatial_gradient_float and its _parallel twins,
+    P/filter/ops.rs:287-509).  Returns ``(dx, dy)``."""
+    return _spatial_gradient(src, _ffi.KH_GRAD_SOBEL, dx, dy, "spatial_gradient_float")
+
+
+def scharr_spatial_gradient_float(src: Image, dx: Optional[Image] = None, dy: Optional[Image] = None) -> Tuple[Image, Image]:
+    """The Scharr twin (scharr_spatial_gradient_float, P/filter/ops.rs:511-590)."""
+    return _spatial_gradient(src, _ffi.KH_GRAD_SCHARR, dx, dy, "scharr_spatial_gradient_float")
+
+
+def box_blur_fast_kernels_1d(sigma: float, kernels: int):
+    out = (C.c_int32 * max(int(kernels), 1))()
+    _check(lib.kh_box_blur_fast_kernels_1d(sigma, kernels, out))
+    return [int(v) for v in out[:kernels]]
+
+
+def box_blur_fast(src: Image, sigma: Tuple[float, float], dst: Optional[Image] = None) -> Image:
+    """Three running-sum box passes per axis approximating a gaussian of ``sigma`` (box_blur_fast, P/filter/ops.rs:252-285).
+    The transposed intermediate is a stream-ordered scratch image, released on the stream after the last pass."""
+    out, stream = _filter_pair(src, dst, "box_blur_fast")
+    scratch = _new_like(src)
+    _check(lib.kh_box_blur_fast_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, scratch.data_ptr, src.width, src.height,
+                                    src.channels, sigma[0], sigma[1], 1, 0, 0))
+    return out
+
+
+def median_blur(image: Image, kernel_size: int = 3, dst: Optional[Image] = None) -> Image:
+    """cv2.medianBlur-compatible median (replicate border), kernel 3 or 5, uint8 x 1..4 channels (median_blur,
+    P/filter/median.rs:174; kornia-py imgproc.pyi:169)."""
+    if kernel_size not in (3, 5):
+        raise ImageError("InvalidKernelLength", f"median_blur: invalid kernel length ({kernel_size}, {kernel_size})")
+    _require(image, "uint8", (1, 2, 3, 4), "median_blur")
+    out = dst if dst is not None else _new_like(image)
+    _require(out, "uint8", (image.channels,), "median_blur")
+    _same_size(image, out)
+    stream = _pair_residency(image, out)
+    _check(lib.kh_median_blur_u8(stream.cuda_stream_ptr, image.data_ptr, out.data_ptr, image.width, image.height, image.channels,
+                                 kernel_size, 1, 0, 0))
+    return out
+
+
+def bilateral_filter(image: Image, d: int = 5, sigma_color: float = 50.0, sigma_space: float = 50.0, dst: Optional[Image] = None) -> Image:
+    """cv2.bilateralFilter-compatible bilateral filter for single-channel uint8 (bilateral_filter, P/filter/bilateral.rs:172;
+    kornia-py imgproc.pyi:174)."""
+    _require(image, "uint8", (1,), "bilateral_filter")
+    out = dst if dst is not None else _new_like(image)
+    _require(out, "uint8", (1,), "bilateral_filter")
+    _same_size(image, out)
+    stream = _pair_residency(image, out)
+    _check(lib.kh_bilateral_filter_u8(stream.cuda_stream_ptr, image.data_ptr, out.data_ptr, image.width, image.height, int(d),
+                                      float(sigma_color), float(sigma_space), 1, 0, 0))
+    return out
+
+
+def bilateral_tables(d: int, sigma_color: float, sigma_space: float) -> dict:
+    """The tables cv2 would build (BilateralTables / build_tables, P/filter/bilateral.rs:80-170); host-only."""
+    radius, n = C.c_int32(0), C.c_int32(0)
+    _check(lib.kh_bilateral_tables(d, sigma_color, sigma_space, 0, C.byref(radius), C.byref(n), None, None, None, None, None))
+    dy, dx, order = (np.empty(n.value, np.int32) for _ in range(3))
+    space, color = np.empty(n.value, np.float32), np.empty(256, np.float32)
+    _check(lib.kh_bilateral_tables(d, sigma_color, sigma_space, n.value, C.byref(radius), C.byref(n), dy.ctypes.data, dx.ctypes.data,
+                                   space.ctypes.data, color.ctypes.data, order.ctypes.data))
+    return {"radius": radius.value, "taps": list(zip(dy.tolist(), dx.tolist())), "space_weight": space, "color_weight": color,
+            "simd_order": order.tolist()}
+
+
 # ---- normalize / crop / flip ----------------------------------------------------------------------------
 
 def normalize_mean_std(src: Image, mean: Sequence[float], std: Sequence[float], dst: Optional[Image] = None) -> Image:

@@ -159,6 +159,21 @@ void ko_morph_kernel(int shape, int width, int height, uint8_t* out);
 void ko_morphology_u8(const uint8_t* src, int w, int h, int C, uint8_t* dst, int op, const uint8_t* mask, int kw, int kh,
                       int border, const uint8_t* cval);
 
+/* ---- the rest of the filter module (ko_filter_extra.c) ------------------------------------------------ */
+/* spatial_gradient_float / scharr_spatial_gradient_float (P/filter/ops.rs:287-590): kind 0 = Sobel, 1 = Scharr */
+void ko_spatial_gradient_f32(const float* src, float* gx, float* gy, int cols, int rows, int C, int kind);
+void ko_box_blur_fast_kernels_1d(float sigma, int kernels, int* out);
+/* -1 where the reference would index out of bounds (half >= cols); dst is the TRANSPOSED image */
+int ko_fast_horizontal_filter(const float* src, float* dst, int cols, int rows, int C, int half);
+int ko_box_blur_fast_f32(const float* src, float* dst, int cols, int rows, int C, float sigma_x, float sigma_y);
+/* median_blur (P/filter/median.rs:174): ksize 3 | 5, else -1 */
+int ko_median_blur_u8(const uint8_t* src, uint8_t* dst, int cols, int rows, int C, int ksize);
+/* bilateral_filter (P/filter/bilateral.rs): cv2's tables and accumulation order, single-channel u8 */
+float ko_v_exp_f32(float x);
+int ko_bilateral_tables(int d, double sigma_color, double sigma_space, int capacity, int* radius_out, int* tap_dy, int* tap_dx,
+                        float* space_weight, float* color_weight, int* simd_order);
+int ko_bilateral_filter_u8(const uint8_t* src, uint8_t* dst, int cols, int rows, int d, double sigma_color, double sigma_space);
+
 #ifdef __cplusplus
 }
 #endif

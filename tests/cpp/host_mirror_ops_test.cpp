@@ -70,6 +70,11 @@ static void host_only() {
     EXPECT(throws_kind(H, [&] { imgproc::separable_filter(f3, f3b, {0.25f, 0.5f, 0.25f}, {1.0f}); }));
     EXPECT(throws_kind(H, [&] { imgproc::sobel(f3, f3b, 3); }));
     EXPECT(throws_kind(H, [&] { imgproc::scharr(f3, f3b); }));
+    EXPECT(throws_kind(H, [&] { imgproc::spatial_gradient_float(f3, f3b, f3b); }));
+    EXPECT(throws_kind(H, [&] { imgproc::scharr_spatial_gradient_float(f3, f3b, f3b); }));
+    EXPECT(throws_kind(H, [&] { imgproc::box_blur_fast(f3, f3b, {1.0f, 1.0f}); }));
+    EXPECT(throws_kind(H, [&] { imgproc::median_blur(u3, u3b, 3); }));
+    EXPECT(throws_kind(H, [&] { imgproc::bilateral_filter(u1, u1, 5, 50.0, 50.0); }));
     EXPECT(throws_kind(H, [&] { imgproc::pyrdown(f3, f3s); }));
     EXPECT(throws_kind(H, [&] { imgproc::pyrup(u3s, u3); }));
     imgproc::Kernel cross(imgproc::KernelShape::Cross, 3);  // host helper: no device needed
@@ -207,6 +212,26 @@ static void on_device() {
         EXPECT(mag.to_host().as_slice()[14] == 0.0f);  // no gradient inside a constant image
         imgproc::scharr(cst, mag);
         EXPECT(mag.to_host().as_slice()[21] == 0.0f);
+        std::vector<float> ramp25(25);
+        for (int i = 0; i < 25; ++i) ramp25[i] = (float)i;
+        auto rsrc = up<float, 1>(s, 5, 5, ramp25);
+        auto gx = Image<float, 1>::zeros_hip({5, 5}, s), gy = Image<float, 1>::zeros_hip({5, 5}, s);
+        imgproc::spatial_gradient_float(rsrc, gx, gy);  // test_spatial_gradient: 1 per x step, 5 per y step, halved on the border
+        EXPECT(gx.to_host().as_slice()[12] == 1.0f && gx.to_host().as_slice()[10] == 0.5f && gy.to_host().as_slice()[12] == 5.0f && gy.to_host().as_slice()[2] == 2.5f);
+        imgproc::scharr_spatial_gradient_float(rsrc, gx, gy);  // test_scharr_spatial_gradient
+        EXPECT(gx.to_host().as_slice()[12] == 1.0f && gy.to_host().as_slice()[12] == 5.0f);
+        auto fast = Image<float, 1>::zeros_hip({5, 5}, s);
+        imgproc::box_blur_fast(rsrc, fast, {0.5f, 0.5f});  // test_box_blur_fast: exact floats
+        EXPECT(fast.to_host().as_slice()[0] == 4.444444f && fast.to_host().as_slice()[12] == 12.0f && fast.to_host().as_slice()[24] == 19.555555f);
+        auto flat8 = Image<uint8_t, 1>::from_size_val({16, 12}, 200).to_hip(s);
+        auto out8 = Image<uint8_t, 1>::zeros_hip({16, 12}, s);
+        imgproc::median_blur(flat8, out8, 5);  // constant_image_unchanged (median.rs, bilateral.rs)
+        const auto m8 = out8.to_host();
+        for (uint8_t v : m8.as_slice()) EXPECT(v == 200);
+        imgproc::bilateral_filter(flat8, out8, 5, 50.0, 50.0);
+        const auto b8 = out8.to_host();
+        for (uint8_t v : b8.as_slice()) EXPECT(v == 200);
+        EXPECT(throws_kind(K::InvalidImageSize, [&] { imgproc::median_blur(flat8, out8, 4); }));  // rejects_bad_ksize_and_size_mismatch
     });
     section("pyramid, morphology", [&] {
         std::vector<float> ramp(16);

@@ -644,3 +644,74 @@ def rgb_from_bayer(mosaic, pattern):
     out = np.empty((h, w, 3), np.uint8)
     assert ko.ko_rgb_from_bayer(np.ascontiguousarray(m).reshape(-1), out.reshape(-1), w, h, BAYER[pattern]) == 0
     return out
+
+
+# ---- the rest of the filter module (oracle/ko_filter_extra.c) ------------------------------------------------------------
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+ko.ko_spatial_gradient_f32.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]
+ko.ko_box_blur_fast_kernels_1d.argtypes = [C.c_float, C.c_int, _i32p]
+ko.ko_fast_horizontal_filter.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]
+ko.ko_box_blur_fast_f32.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+ko.ko_median_blur_u8.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+ko.ko_v_exp_f32.argtypes = [C.c_float]
+ko.ko_v_exp_f32.restype = C.c_float
+ko.ko_bilateral_tables.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+ko.ko_bilateral_filter_u8.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+
+GRADIENT_KINDS = {"sobel": 0, "scharr": 1}
+
+
+def spatial_gradient(src, kind="sobel"):
+    src = _img(src)
+    h, w, c = src.shape
+    gx, gy = np.empty_like(src), np.empty_like(src)
+    ko.ko_spatial_gradient_f32(src.reshape(-1), gx.reshape(-1), gy.reshape(-1), w, h, c, GRADIENT_KINDS[kind])
+    return gx, gy
+
+
+def box_blur_fast_kernels_1d(sigma, kernels):
+    out = np.empty(kernels, np.int32)
+    ko.ko_box_blur_fast_kernels_1d(sigma, kernels, out)
+    return [int(v) for v in out]
+
+
+def fast_horizontal_filter(src, half):
+    """Returns the TRANSPOSED image (W, H, C), or None where the reference would index out of bounds."""
+    src = _img(src)
+    h, w, c = src.shape
+    out = np.empty((w, h, c), np.float32)
+    return out if ko.ko_fast_horizontal_filter(src.reshape(-1), out.reshape(-1), w, h, c, half) == 0 else None
+
+
+def box_blur_fast(src, sigma):
+    src = _img(src)
+    h, w, c = src.shape
+    out = np.empty_like(src)
+    return out if ko.ko_box_blur_fast_f32(src.reshape(-1), out.reshape(-1), w, h, c, sigma[0], sigma[1]) == 0 else None
+
+
+def median_blur(src, ksize):
+    src = _img8(src)
+    h, w, c = src.shape
+    out = np.empty_like(src)
+    return out if ko.ko_median_blur_u8(src.reshape(-1), out.reshape(-1), w, h, c, ksize) == 0 else None
+
+
+def bilateral_tables(d, sigma_color, sigma_space):
+    radius = C.c_int(0)
+    n = ko.ko_bilateral_tables(d, sigma_color, sigma_space, 0, C.byref(radius), None, None, None, None, None)
+    dy, dx, order = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32)
+    sw, cw = np.empty(n, np.float32), np.empty(256, np.float32)
+    ko.ko_bilateral_tables(d, sigma_color, sigma_space, n, C.byref(radius), dy.ctypes.data, dx.ctypes.data, sw.ctypes.data, cw.ctypes.data,
+                           order.ctypes.data)
+    return {"radius": radius.value, "dy": dy, "dx": dx, "space_weight": sw, "color_weight": cw, "simd_order": order}
+
+
+def bilateral_filter(src, d, sigma_color, sigma_space):
+    src = _img8(src)
+    h, w, c = src.shape
+    assert c == 1
+    out = np.empty_like(src)
+    assert ko.ko_bilateral_filter_u8(src.reshape(-1), out.reshape(-1), w, h, d, sigma_color, sigma_space) == 0
+    return out

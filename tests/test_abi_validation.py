@@ -11,7 +11,7 @@ from kornia_rs import _ffi
 
 L = _ffi.lib
 S = None
-P, Q = 0x10000, 0x2000000  # fake device addresses (distinct: src != dst)
+P, Q, R3 = 0x10000, 0x2000000, 0x3000000  # fake device addresses (distinct: src != dst)
 M6 = (C.c_float * 6)(1, 0, 0, 0, 1, 0)
 SING = (C.c_float * 9)(1, 2, 3, 2, 4, 6, 3, 6, 9)
 K3 = (C.c_float * 3)(0.25, 0.5, 0.25)
@@ -47,6 +47,21 @@ CASES = [
     ("separable: empty kernel", lambda: L.kh_separable_filter_f32(S, P, Q, 8, 8, 3, K3, 3, K3, 0, 1, 0, 0), INVALID, "kernel length"),
     ("gradient: unknown kind", lambda: L.kh_gradient_magnitude_f32(S, P, Q, 8, 8, 3, 9, 3, 1, 0, 0), INVALID, "kind 9"),
     ("gradient: sobel size 4", lambda: L.kh_gradient_magnitude_f32(S, P, Q, 8, 8, 3, 0, 4, 1, 0, 0), INVALID, "kernel length"),
+    # ---- the rest of the filter module
+    ("spatial_gradient: unknown kind", lambda: L.kh_spatial_gradient_f32(S, P, Q, R3, 8, 8, 3, 4, 1, 0, 0), INVALID, "kind 4"),
+    ("spatial_gradient: dx aliases src", lambda: L.kh_spatial_gradient_f32(S, P, P, Q, 8, 8, 3, 0, 1, 0, 0), INVALID, "distinct"),
+    ("spatial_gradient: zero-sized", lambda: L.kh_spatial_gradient_f32(S, P, Q, R3, 0, 8, 3, 0, 1, 0, 0), INVALID, "zero-sized"),
+    ("fast_horizontal_filter: half >= cols", lambda: L.kh_fast_horizontal_filter_f32(S, P, Q, 8, 8, 3, 8, 1, 0, 0), INVALID, "does not fit"),
+    ("box_blur_fast: sigma too wide", lambda: L.kh_box_blur_fast_f32(S, P, Q, R3, 8, 8, 3, 6.0, 0.5, 1, 0, 0), INVALID, "do not fit"),
+    ("box_blur_fast: null scratch", lambda: L.kh_box_blur_fast_f32(S, P, Q, None, 8, 8, 3, 0.5, 0.5, 1, 0, 0), INVALID, "null"),
+    ("box_blur_fast_kernels: null out", lambda: L.kh_box_blur_fast_kernels_1d(1.0, 3, None), INVALID, "bad argument"),
+    ("median: ksize 4", lambda: L.kh_median_blur_u8(S, P, Q, 8, 8, 3, 4, 1, 0, 0), INVALID, "kernel length 4"),
+    ("median: ksize 7", lambda: L.kh_median_blur_u8(S, P, Q, 8, 8, 3, 7, 1, 0, 0), INVALID, "kernel length 7"),
+    ("median: 5 channels", lambda: L.kh_median_blur_u8(S, P, Q, 8, 8, 5, 3, 1, 0, 0), UNSUPPORTED, "5 channels"),
+    ("median: in place", lambda: L.kh_median_blur_u8(S, P, P, 8, 8, 3, 3, 1, 0, 0), INVALID, "aliased"),
+    ("bilateral: zero-sized", lambda: L.kh_bilateral_filter_u8(S, P, Q, 0, 8, 5, 50.0, 50.0, 1, 0, 0), INVALID, "zero-sized"),
+    ("bilateral: null dst", lambda: L.kh_bilateral_filter_u8(S, P, None, 8, 8, 5, 50.0, 50.0, 1, 0, 0), INVALID, "null"),
+    ("bilateral_tables: null ntaps", lambda: L.kh_bilateral_tables(5, 50.0, 50.0, 0, None, None, None, None, None, None, None), INVALID, "ntaps"),
     # ---- u8 fixed-point twins
     ("gaussian_u8: 2 channels", lambda: L.kh_gaussian_blur_u8(S, P, Q, 8, 8, 2, 3, 3, 1.0, 1.0, 1, 0, 0), UNSUPPORTED, "2 channels"),
     ("box_u8: even kernel", lambda: L.kh_box_blur_u8(S, P, Q, 8, 8, 3, 2, 3, 1, 0, 0), INVALID, "odd"),
@@ -123,3 +138,7 @@ def test_empty_batches_and_images_are_no_ops_without_a_device():
     assert L.kh_flip(S, P, Q, 0, 8, 3, 1) == 0
     assert L.kh_graph_destroy(None) == 0
     assert L.kh_rgb_from_bayer_u8(S, None, None, 0, 7, 1) == 0
+    assert L.kh_spatial_gradient_f32(S, None, None, None, 8, 8, 3, 1, 0, 0, 0) == 0
+    assert L.kh_median_blur_u8(S, None, None, 8, 8, 3, 5, 0, 0, 0) == 0
+    assert L.kh_bilateral_filter_u8(S, None, None, 8, 8, 5, 50.0, 50.0, 0, 0, 0) == 0
+    assert L.kh_box_blur_fast_f32(S, None, None, None, 8, 8, 3, 0.5, 0.5, 0, 0, 0) == 0

@@ -125,7 +125,29 @@ def test_lab_workload_4k(gpu_stream, bench):
         assert np.abs(got[k] - want).max() < 2e-2, k
 
 
+def test_filter_extra_workloads_1080p(gpu_stream, bench):
+    wl = _run(bench, "spatial_gradient_1080p", gpu_stream)
+    n = wl.W * wl.H * wl.C
+    gx, gy = _out(wl, np.float32, (wl.H, wl.W, wl.C)), wl.dst_y.to_numpy(np.float32, (wl.N, wl.H, wl.W, wl.C))
+    for k in range(wl.N):
+        wx, wy = O.spatial_gradient(_frame(wl, k, n, (wl.H, wl.W, wl.C)), "sobel")
+        assert np.array_equal(gx[k], wx) and np.array_equal(gy[k], wy), k
+    wl = _run(bench, "box_blur_fast_1080p", gpu_stream)
+    got = _out(wl, np.float32, (wl.H, wl.W, wl.C))
+    for k in range(wl.N):
+        assert np.array_equal(got[k], O.box_blur_fast(_frame(wl, k, n, (wl.H, wl.W, wl.C)), (2.0, 2.0))), k
+    wl = _run(bench, "median5_u8_1080p", gpu_stream)
+    got = _out(wl, np.uint8, (wl.H, wl.W, wl.C))
+    for k in range(wl.N):
+        assert np.array_equal(got[k], O.median_blur(_frame(wl, k, n, (wl.H, wl.W, wl.C)), 5)), k
+    wl = _run(bench, "bilateral_1080p", gpu_stream)
+    got = _out(wl, np.uint8, (wl.H, wl.W, 1))
+    for k in range(wl.N):
+        assert np.array_equal(got[k], O.bilateral_filter(_frame(wl, k, wl.W * wl.H, (wl.H, wl.W, 1)), 5, 50.0, 50.0)), k
+
+
 def test_every_workload_is_covered(bench):
     covered = {"nv12_chw", "nv12_chw_640", "resize_224", "resize_normalize_f32_224", "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640",
-               "gaussian_4k", "gaussian_u8_4k", "pyrdown_u8_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_u8_4k", "lab_from_rgb_4k"}
+               "gaussian_4k", "gaussian_u8_4k", "pyrdown_u8_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_u8_4k", "lab_from_rgb_4k",
+               "spatial_gradient_1080p", "box_blur_fast_1080p", "median5_u8_1080p", "bilateral_1080p"}
     assert covered == set(bench.WORKLOADS)

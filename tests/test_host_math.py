@@ -86,3 +86,14 @@ def test_polynomial_distortion_defaults_to_identity():
     for (x, y) in [(0.0, 0.0), (320.0, 240.0), (639.0, 479.0)]:
         px, py = distort_point_polynomial(x, y, intr, PolynomialDistortion())
         assert abs(px - x) < 1e-9 and abs(py - y) < 1e-9
+
+
+def test_median_networks_are_the_generated_and_proved_ones():
+    """kh_median_net.h is what scripts/gen_median_net.py generates — pruned odd-even merge sort, proved to select the median of
+    all 2^9 / 2^25 binary inputs (0-1 principle) every time it is generated, this test included."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "scripts" / "gen_median_net.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
