@@ -10,7 +10,7 @@ from . import hip
 from .hip import IMAGENET_MEAN, IMAGENET_STD, Stream
 from .tensor import Tensor
 from .image import Image, ImageError
-from .preprocess import Preprocessor, PreprocessError, ResizeMode, SourceFormat
+from .preprocess import Normalize, Preprocessor, PreprocessorBuilder, PreprocessError, ResizeMode, SourceFormat
 from . import imgproc
 from . import fusion
 from . import color_spaces
@@ -24,6 +24,6 @@ cuda = hip  # reference module name (kornia_rs.cuda.Stream); same objects, HIP u
 
 __version__ = "0.1.0"
 __all__ = [
-    "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Image", "ImageError", "Preprocessor",
+    "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Image", "ImageError", "Preprocessor", "PreprocessorBuilder", "Normalize",
     "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "fusion", "color_spaces", "ColorSpace", "calibration", "colormap", "ColormapType", "hip", "cuda", "sharding",
 ]

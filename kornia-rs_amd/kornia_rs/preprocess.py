@@ -115,6 +115,73 @@ def mean_inv_std(mean, std) -> Tuple[np.ndarray, np.ndarray]:
 RawSource = Union[DeviceBuffer, Tensor, int]
 
 
+class Normalize:
+    """``Normalize`` (P/preprocess.rs:78-121): ``unit_scale()`` (divide by 255, the default), ``mean_std(mean, std)`` in the
+    [0, 1] domain, ``imagenet()`` = torchvision's constants."""
+
+    def __init__(self, mean: Optional[Sequence[float]] = None, std: Optional[Sequence[float]] = None):
+        self.mean, self.std = (None, None) if mean is None and std is None else (tuple(mean), tuple(std))
+
+    @staticmethod
+    def unit_scale() -> "Normalize":
+        return Normalize()
+
+    @staticmethod
+    def mean_std(mean: Sequence[float], std: Sequence[float]) -> "Normalize":
+        return Normalize(mean, std)
+
+    @staticmethod
+    def imagenet() -> "Normalize":
+        return Normalize(IMAGENET_MEAN, IMAGENET_STD)
+
+    def __eq__(self, other):
+        return isinstance(other, Normalize) and (self.mean, self.std) == (other.mean, other.std)
+
+
+class PreprocessorBuilder:
+    """``PreprocessorBuilder`` (P/preprocess.rs:654-785): chainable configuration with the reference's defaults (letterbox,
+    unit scale, pad 114, bilinear, RGB8).  ``build_hip(stream)`` is ``build_cuda(stream)``; ``build()`` — the reference's CPU
+    preprocessor — does not exist in this backend and says so."""
+
+    def __init__(self):
+        self._mode, self._normalize, self._pad_value = ResizeMode.LETTERBOX, Normalize.unit_scale(), 114
+        self._sampling, self._format = "bilinear", "rgb"
+
+    @staticmethod
+    def new() -> "PreprocessorBuilder":
+        return PreprocessorBuilder()
+
+    def source_format(self, format) -> "PreprocessorBuilder":
+        self._format = format.name if isinstance(format, SourceFormat) else format
+        return self
+
+    def mode(self, mode: str) -> "PreprocessorBuilder":
+        self._mode = mode
+        return self
+
+    def normalize(self, normalize: Normalize) -> "PreprocessorBuilder":
+        self._normalize = normalize
+        return self
+
+    def pad_value(self, pad_value: int) -> "PreprocessorBuilder":
+        if not 0 <= int(pad_value) <= 255:
+            raise ValueError("pad_value is a u8")
+        self._pad_value = int(pad_value)
+        return self
+
+    def sampling(self, sampling: str) -> "PreprocessorBuilder":
+        self._sampling = sampling
+        return self
+
+    def build(self) -> "Preprocessor":
+        raise PreprocessError("NotDeviceImage", "PreprocessorBuilder.build(): the CPU preprocessor lives in the reference crate; this backend "
+                                                "builds device preprocessors only — build_hip(stream)")
+
+    def build_hip(self, stream: Stream, f16: bool = False) -> "Preprocessor":
+        return Preprocessor(self._mode, self._format, self._sampling, f16, self._normalize.mean, self._normalize.std, self._pad_value, stream)
+
+
+
 def _ptr_len(src: Any) -> Tuple[int, Optional[int]]:
     if isinstance(src, (DeviceBuffer, _DeviceView)):
         return src.ptr, src.nbytes
@@ -374,6 +441,46 @@ class Preprocessor:
         w, h = int(image.width), int(image.height)
         p = self._params(w, h, w * c, c, f.fmt_code, dst.shape[3], dst.shape[2], 1, 0, want_f16, False)
         self._launch(image.data_ptr, dst, p)
+
+    # f16 twins (run_f16 / run_surface_f16 / run_raw_f16 / run_raw_batch_f16, P/preprocess.rs:1086-1282): the same launch into a
+    # float16 destination; a float32 tensor is the reference's dtype mismatch, rejected before any device work
+    @staticmethod
+    def _need_f16(dst: Tensor, what: str) -> None:
+        if not isinstance(dst, Tensor) or dst.dtype != "float16":
+            raise PreprocessError("BadOutputShape", f"{what}: destination must be a float16 device tensor")
+
+    def run_f16(self, image: Any, dst: Tensor) -> None:
+        self._need_f16(dst, "run_f16")
+        self.run_image(image, dst)
+
+    def run_surface_f16(self, data: RawSource, width: int, height: int, row_pitch: int, channels: int, dst: Tensor) -> None:
+        self._need_f16(dst, "run_surface_f16")
+        self.run_surface(data, width, height, row_pitch, channels, dst)
+
+    def run_raw_f16(self, src: RawSource, src_w: int, src_h: int, dst: Tensor) -> None:
+        self._need_f16(dst, "run_raw_f16")
+        self.run_raw(src, src_w, src_h, dst)
+
+    def run_raw_batch_f16(self, frames, src_w: int, src_h: int, dst: Tensor, *, frame_stride: Optional[int] = None) -> None:
+        self._need_f16(dst, "run_raw_batch_f16")
+        self.run_raw_batch(frames, src_w, src_h, dst, frame_stride=frame_stride)
+
+    # constructors of the Rust API (P/preprocess.rs:838-880)
+    @staticmethod
+    def builder() -> "PreprocessorBuilder":
+        return PreprocessorBuilder()
+
+    @staticmethod
+    def letterbox(stream: Stream) -> "Preprocessor":
+        return Preprocessor.with_mode(stream, ResizeMode.LETTERBOX)
+
+    @staticmethod
+    def stretch(stream: Stream) -> "Preprocessor":
+        return Preprocessor.with_mode(stream, ResizeMode.STRETCH)
+
+    @staticmethod
+    def with_mode(stream: Stream, mode: str) -> "Preprocessor":
+        return PreprocessorBuilder().mode(mode).build_hip(stream)
 
     # -- Python-shaped entry points (kornia_rs/__init__.pyi:88-111) ------------------------------
     def alloc_output(self, out_height: int, out_width: int, batch: int = 1) -> Tensor:

@@ -323,3 +323,34 @@ def test_graph_and_mem_info_fail_loudly_without_a_device():  # cuda.pyi:64-90
     with pytest.raises(_ffi.KorniaHipError) as e:  # the default stream cannot be captured
         hip.Graph.capture(lambda: None, [], None)
     assert e.value.code == _ffi.KH_ERR_INVALID_ARG
+
+
+def test_preprocessor_builder_mirrors_the_rust_api():
+    """PreprocessorBuilder / Normalize / Preprocessor::{builder, letterbox, stretch, with_mode} (P/preprocess.rs:654-880): defaults,
+    chaining and the validation `build_cuda` performs, all before any device work."""
+    from kornia_rs import IMAGENET_MEAN, IMAGENET_STD, Normalize, PreprocessError, Preprocessor, PreprocessorBuilder, ResizeMode, SourceFormat
+    s = Stream.default(0)
+    pre = PreprocessorBuilder.new().build_hip(s)  # defaults: letterbox, unit scale, pad 114, bilinear, rgb8
+    assert (pre.mode, pre.sampling, pre.source_format.name, float(pre.pad_value)) == (ResizeMode.LETTERBOX, "bilinear", "rgb8", 114.0)
+    assert pre.mean.tolist() == [0, 0, 0] and pre.inv_std.tolist() == [1, 1, 1]
+    pre = (Preprocessor.builder().source_format(SourceFormat.from_name("nv12")).mode(ResizeMode.STRETCH).normalize(Normalize.imagenet())
+           .pad_value(0).sampling("lanczos").build_hip(s))
+    assert (pre.mode, pre.sampling, pre.source_format.name, float(pre.pad_value)) == (ResizeMode.STRETCH, "lanczos", "nv12", 0.0)
+    assert np.array_equal(pre.mean, np.asarray(IMAGENET_MEAN, np.float32))
+    assert np.array_equal(pre.inv_std, (np.float32(1.0) / np.asarray(IMAGENET_STD, np.float32)).astype(np.float32))
+    assert Normalize.imagenet() == Normalize.mean_std(IMAGENET_MEAN, IMAGENET_STD) and Normalize.unit_scale() != Normalize.imagenet()
+    assert Preprocessor.letterbox(s).mode == ResizeMode.LETTERBOX and Preprocessor.stretch(s).mode == ResizeMode.STRETCH
+    assert Preprocessor.with_mode(s, ResizeMode.STRETCH).mode == ResizeMode.STRETCH
+    with pytest.raises(PreprocessError) as e:  # UnsupportedSampling (preprocess.rs:717-722)
+        PreprocessorBuilder().sampling("bicubic").build_hip(s)
+    assert e.value.kind == "UnsupportedSampling"
+    with pytest.raises(PreprocessError) as e:  # InvalidNormalize (preprocess.rs:110-116)
+        PreprocessorBuilder().normalize(Normalize.mean_std((0.5, 0.5, 0.5), (0.2, 0.0, 0.2))).build_hip(s)
+    assert e.value.kind == "InvalidNormalize"
+    with pytest.raises(PreprocessError):  # the CPU preprocessor is the reference crate's, not this backend's
+        PreprocessorBuilder().build()
+    with pytest.raises(ValueError):
+        PreprocessorBuilder().pad_value(300)
+    with pytest.raises(PreprocessError) as e:  # the _f16 twins take float16 destinations only
+        Preprocessor.letterbox(s).run_raw_f16(0x1000, 8, 8, object())
+    assert e.value.kind == "BadOutputShape"

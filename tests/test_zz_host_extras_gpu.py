@@ -337,3 +337,32 @@ def test_bayer_demosaic_bit_exact(gpu_stream, pattern):
         imgproc.rgb_from_bayer(mosaic, None, Image.zeros(49, 36, 3, "uint8", gpu_stream))
     with pytest.raises(ImageError):
         imgproc.rgb_from_bayer(mosaic.as_image(), "rgbg")
+
+
+# ---- the Rust-shaped Preprocessor constructors and _f16 twins (P/preprocess.rs:654-880, 1086-1282) -----------------------
+
+def test_preprocessor_builder_and_f16_twins_on_device(gpu_stream):
+    from kornia_rs import Normalize, PreprocessError, Preprocessor, SourceFormat, Tensor
+    from kornia_rs.hip import DeviceBuffer
+    w, h, dw, dh = 46, 30, 20, 16
+    raw = O.pattern_u8(w * h * 3 // 2)
+    pre = (Preprocessor.builder().source_format(SourceFormat.from_name("nv12")).normalize(Normalize.imagenet()).pad_value(114)
+           .sampling("bilinear").build_hip(gpu_stream))
+    src = DeviceBuffer.from_numpy(raw, gpu_stream)
+    f32 = Tensor.uninit((1, 3, dh, dw), "float32", gpu_stream)
+    f16 = Tensor.uninit((1, 3, dh, dw), "float16", gpu_stream)
+    pre.run_raw(src, w, h, f32)
+    pre.run_raw_f16(src, w, h, f16)
+    want = O.preprocess(raw, w, h, dw, dh, fmt="nv12", mode="letterbox", mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225))
+    assert np.array_equal(f32.numpy_raw(), want)
+    assert np.array_equal(f16.numpy_raw().view(np.uint16), want.astype(np.float16).view(np.uint16))
+    two = Tensor.uninit((2, 3, dh, dw), "float16", gpu_stream)
+    Preprocessor.builder().source_format("nv12").normalize(Normalize.imagenet()).build_hip(gpu_stream).run_raw_batch_f16([src, src], w, h, two)
+    assert np.array_equal(two.numpy_raw()[1].view(np.uint16), f16.numpy_raw()[0].view(np.uint16))
+    with pytest.raises(PreprocessError):  # an f32 destination is not an _f16 launch
+        pre.run_raw_f16(src, w, h, f32)
+    stretch = Preprocessor.stretch(gpu_stream)  # rgb8, unit scale
+    rgb = O.pattern_u8(w * h * 3)
+    out = Tensor.uninit((1, 3, dh, dw), "float32", gpu_stream)
+    stretch.run_surface(DeviceBuffer.from_numpy(rgb, gpu_stream), w, h, w * 3, 3, out)
+    assert np.array_equal(out.numpy_raw(), O.preprocess(rgb, w, h, dw, dh, fmt="rgb", mode="stretch"))
