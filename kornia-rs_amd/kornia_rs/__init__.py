@@ -19,11 +19,12 @@ from . import colormap
 from .colormap import ColormapType
 from .color_spaces import ColorSpace
 from . import sharding
+from . import rust_api
 
 cuda = hip  # reference module name (kornia_rs.cuda.Stream); same objects, HIP underneath
 
 __version__ = "0.1.0"
 __all__ = [
     "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Image", "ImageError", "Preprocessor", "PreprocessorBuilder", "Normalize",
-    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "fusion", "color_spaces", "ColorSpace", "calibration", "colormap", "ColormapType", "hip", "cuda", "sharding",
+    "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "rust_api", "fusion", "color_spaces", "ColorSpace", "calibration", "colormap", "ColormapType", "hip", "cuda", "sharding",
 ]

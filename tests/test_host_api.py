@@ -354,3 +354,36 @@ def test_preprocessor_builder_mirrors_the_rust_api():
     with pytest.raises(PreprocessError) as e:  # the _f16 twins take float16 destinations only
         Preprocessor.letterbox(s).run_raw_f16(0x1000, 8, 8, object())
     assert e.value.kind == "BadOutputShape"
+
+
+def test_rust_api_names_tables_and_type_checks():
+    """kornia_rs.rust_api: the Rust crate's free-function names.  Host-side tables equal the reference's
+    (filter/kernels.rs tests :180-226, morphology/kernels.rs) and a wrong element type is a typed error before any device work."""
+    from kornia_rs import Image, ImageError, rust_api as R
+    assert R.sobel_kernel_1d(3) == ([-1.0, 0.0, 1.0], [1.0, 2.0, 1.0])  # test_sobel_kernel_1d
+    assert R.sobel_kernel_1d(5) == ([-1.0, -2.0, 0.0, 2.0, 1.0], [1.0, 4.0, 6.0, 4.0, 1.0])
+    assert R.scharr_kernel_1d(3) == ([-1.0, 0.0, 1.0], [3.0, 10.0, 3.0])  # test_scharr_kernel_1d
+    for bad in (lambda: R.sobel_kernel_1d(7), lambda: R.scharr_kernel_1d(5), lambda: R.scharr_kernel_1d(7)):
+        with pytest.raises(ImageError):
+            bad()
+    want = np.array([0.00026386508, 0.10645077, 0.78657067, 0.10645077, 0.00026386508], np.float32)  # test_gaussian_kernel_1d (assert_eq!)
+    assert np.array_equal(np.array(R.gaussian_kernel_1d(5, 0.5), np.float32), want)
+    assert R.box_blur_kernel_1d(4) == [0.25] * 4
+    assert R.box_blur_fast_kernels_1d(1.0, 5) == [1, 1, 1, 1, 3]  # test_box_blur_fast_kernels_1d
+    sx, sy = R.normalized_sobel_kernel3()
+    assert sx[1] == [-0.25, 0.0, 0.25] and sy[2] == [0.125, 0.25, 0.125] and sum(map(sum, sx)) == 0
+    cx, cy = R.normalized_scharr_kernel3()
+    assert cx[0] == [-0.09375, 0.0, 0.09375] and cy[0] == [-0.09375, -0.3125, -0.09375]
+    assert R.cross_kernel(3).data.tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]] and R.box_kernel(2).data.tolist() == [[1, 1], [1, 1]]
+    assert R.ellipse_kernel(5, 5).data.shape == (5, 5)
+    f = Image.from_numpy(np.zeros((4, 4, 3), np.float32))
+    u = Image.from_numpy(np.zeros((4, 4, 3), np.uint8))
+    for call in (lambda: R.gray_from_rgb_u8(f, u), lambda: R.gray_from_rgb_f32(u, f), lambda: R.hsv_from_rgb_f32(u, f),
+                 lambda: R.ycc_from_rgb_u8(f, u), lambda: R.resize_fast_rgb(f, u, "bilinear"), lambda: R.resize_opencv_f32(u, u, "nearest"),
+                 lambda: R.resize_fast_mono(u, u, "bilinear")):
+        with pytest.raises(ImageError) as e:
+            call()
+        assert e.value.kind == "NoDeviceKernel"
+    with pytest.raises(ImageError):
+        R.ycc_from_rgb_u8(u, u, "xyz")
+    assert R.spatial_gradient_float_parallel is R.spatial_gradient_float

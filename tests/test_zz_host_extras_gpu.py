@@ -366,3 +366,33 @@ def test_preprocessor_builder_and_f16_twins_on_device(gpu_stream):
     out = Tensor.uninit((1, 3, dh, dw), "float32", gpu_stream)
     stretch.run_surface(DeviceBuffer.from_numpy(rgb, gpu_stream), w, h, w * 3, 3, out)
     assert np.array_equal(out.numpy_raw(), O.preprocess(rgb, w, h, dw, dh, fmt="rgb", mode="stretch"))
+
+
+def test_rust_api_spellings_on_device(gpu_stream):
+    """kornia_rs.rust_api: (src, dst, params) order, typed suffixes — same bytes as the restatement."""
+    from kornia_rs import Image, rust_api as R
+    w, h = 37, 23
+    rgb = O.pattern_u8(w * h * 3).reshape(h, w, 3)
+    src = Image.from_numpy(rgb).to_hip(gpu_stream)
+    gray = Image.zeros(w, h, 1, "uint8", gpu_stream)
+    assert R.gray_from_rgb_u8(src, gray) is None
+    assert np.array_equal(gray.numpy().reshape(-1), O.color_map("gray_from_rgb_u8", rgb, 1))
+    ycc = Image.zeros(w, h, 3, "uint8", gpu_stream)
+    R.ycc_from_rgb_u8(src, ycc, "yuv")
+    from kornia_rs import imgproc
+    assert np.array_equal(ycc.numpy(), imgproc.yuv_from_rgb(src).numpy())
+    small = Image.zeros(16, 12, 3, "uint8", gpu_stream)
+    R.resize_fast_rgb_aa(src, small, "lanczos", False)
+    assert np.array_equal(small.numpy(), O.resize_fast_u8(rgb, 16, 12, "lanczos", False)[0])
+    R.resize_opencv_u8(src, small, "bilinear")
+    assert np.array_equal(small.numpy(), O.resize_opencv(rgb, 16, 12, "bilinear"))
+    f = Image.from_numpy(O.pattern_f32(w * h * 3).reshape(h, w, 3)).to_hip(gpu_stream)
+    gx, gy = Image.zeros(w, h, 3, "float32", gpu_stream), Image.zeros(w, h, 3, "float32", gpu_stream)
+    R.spatial_gradient_float_parallel_row(f, gx, gy)
+    wx, wy = O.spatial_gradient(f.numpy(), "sobel")
+    assert np.array_equal(gx.numpy(), wx) and np.array_equal(gy.numpy(), wy)
+    nv12 = O.nv12_from_rgb(O.pattern_u8(32 * 16 * 3).reshape(16, 32, 3))
+    out = Image.zeros(32, 16, 3, "uint8", gpu_stream)
+    from kornia_rs.hip import DeviceBuffer
+    R.rgb_from_planar420(DeviceBuffer.from_numpy(nv12, gpu_stream), 32, 16, out, "nv12")
+    assert np.array_equal(out.numpy(), O.rgb_from_nv12(nv12, 32, 16))
