@@ -95,6 +95,58 @@ __global__ __launch_bounds__(kBlock) void fast_hfilter_kernel(const float* __res
     }
 }
 
+// The same chain with the row reads staged through LDS.  In the direct kernel a wave's 64 lanes read 64 different rows —
+// 64 cache lines per load instruction — so it is bound by vector-memory requests, not bytes.  Here a 256-thread block owns
+// 256 consecutive (row, channel) chains (~256 / C rows) and walks the image in chunks of T columns: the block loads, for each of
+// its rows, the (T + 2 * half + 1) * C contiguous floats the chunk needs (one coalesced 256-byte request per wave instruction)
+// into LDS, then every thread runs T steps of its chain out of LDS (two ds_read_b32 per step; row pitch odd in dwords so the
+// rows of a wave spread over the banks) and stores transposed (256 contiguous bytes per wave store).  Same operations in the
+// same order per chain: bit-identical to the direct kernel.
+extern __shared__ __attribute__((aligned(16))) float hfilter_lds[];
+
+__global__ __launch_bounds__(kBlock) void fast_hfilter_lds_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols,
+                                                                  int C, int half, int T, int pitch, long long ss, long long ds) {
+    const int t0 = blockIdx.x * kBlock, t = t0 + threadIdx.x, total = rows * C;
+    const bool live = t < total;
+    const int r_first = t0 / C, r_last = min(t0 + kBlock - 1, total - 1) / C, nrows = r_last - r_first + 1;
+    const int r = live ? t / C : r_first, ch = live ? t - r * C : 0, rl = r - r_first;
+    const float* img = src + (long long)blockIdx.y * ss;
+    const float* row = img + (long long)r * cols * C + ch;
+    float* out = dst + (long long)blockIdx.y * ds + t;
+    const long long ostep = (long long)rows * C;
+    const float leftmost = live ? row[0] : 0.0f, rightmost = live ? row[(long long)(cols - 1) * C] : 0.0f;
+    const float norm = (float)(half * 2 + 1);
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const float* mine = hfilter_lds + rl * pitch + ch;
+    float acc = 0.0f;
+    for (int c0 = 0; c0 < cols; c0 += T) {
+        const int lo = max(c0 - half - 1, 0), hi = min(c0 + T - 1 + half, cols - 1), seg = (hi - lo + 1) * C;
+        __syncthreads();  // the previous chunk has been consumed
+        for (int k = wave; k < nrows; k += kBlock / kWave) {
+            const float* g = img + ((long long)(r_first + k) * cols + lo) * C;
+            for (int e = lane; e < seg; e += kWave) hfilter_lds[k * pitch + e] = g[e];
+        }
+        __syncthreads();
+        if (live) {
+            const int cend = min(c0 + T, cols);
+            int c = c0;
+            if (c0 == 0) {
+                acc = leftmost * (float)(half + 1);
+                for (int p = 0; p < half; ++p) acc += mine[(p + 1 - lo) * C];
+                out[0] = acc / norm;
+                c = 1;
+            }
+            for (; c < cend; ++c) {
+                const float leaving = c >= half + 1 ? mine[(c - half - 1 - lo) * C] : leftmost;
+                const float entering = c + half < cols ? mine[(c + half - lo) * C] : rightmost;
+                acc -= leaving;
+                acc += entering;
+                out[(long long)c * ostep] = acc / norm;
+            }
+        }
+    }
+}
+
 // ---- median_blur (P/filter/median.rs:174-250, cuda/median.rs) ---------------------------------------------------------
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
@@ -321,8 +373,26 @@ int32_t kh_fast_horizontal_filter_f32(kh_stream_t stream, const float* src, floa
     KH_REQUIRE(half >= 0 && half < cols, KH_ERR_INVALID_ARG, "%s: half kernel %d does not fit a %d-pixel row", what, half, cols);
     if (batch == 0) return KH_OK;
     KH_REQUIRE(src && dst_transposed && src != dst_transposed, KH_ERR_INVALID_ARG, "%s: null or aliased device pointer", what);
-    hipLaunchKernelGGL(fast_hfilter_kernel, dim3(cdiv((int64_t)rows * channels, kBlock), batch), dim3(kBlock), 0, as_hip(stream), src,
-                       dst_transposed, (int)rows, (int)cols, (int)channels, (int)half, (long long)src_stride, (long long)dst_stride);
+    const dim3 grid(cdiv((int64_t)rows * channels, kBlock), batch);
+    // LDS-staged rows when a useful chunk fits: ~(256 / C + 2) rows x (T + 2 * half + 1) columns.  64 KiB keeps two blocks per CU;
+    // wide boxes may take up to 150 KiB; beyond that the direct kernel runs.  KH_HFILTER_DIRECT=1 (dev knob) forces it for A/B.
+    static const bool force_direct = [] { const char* e = getenv("KH_HFILTER_DIRECT"); return e && e[0] == '1'; }();
+    const int nrows_max = (kBlock + channels - 1) / channels + 1;
+    auto chunk_for = [&](size_t budget) { return (int)(budget / (sizeof(float) * (size_t)nrows_max * channels)) - (2 * half + 1) - 1; };
+    int T = chunk_for(64 * 1024);
+    if (T < 16) T = chunk_for(150 * 1024);
+    if (T > cols) T = cols;
+    if (!force_direct && T >= 8 && channels <= kBlock) {
+        const int pitch = ((T + 2 * half + 1) * channels) | 1;  // odd dword pitch: consecutive rows start on different banks
+        const size_t bytes = sizeof(float) * (size_t)nrows_max * pitch;
+        if (bytes > 48 * 1024)
+            KH_HIP(hipFuncSetAttribute((const void*)fast_hfilter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(fast_hfilter_lds_kernel, grid, dim3(kBlock), bytes, as_hip(stream), src, dst_transposed, (int)rows, (int)cols,
+                           (int)channels, (int)half, T, pitch, (long long)src_stride, (long long)dst_stride);
+        return check_launch(what);
+    }
+    hipLaunchKernelGGL(fast_hfilter_kernel, grid, dim3(kBlock), 0, as_hip(stream), src, dst_transposed, (int)rows, (int)cols, (int)channels,
+                       (int)half, (long long)src_stride, (long long)dst_stride);
     return check_launch(what);
 }
 

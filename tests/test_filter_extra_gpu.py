@@ -74,7 +74,7 @@ def test_spatial_gradient_python_mirror_and_known_answer(gpu_stream):
 
 
 @pytest.mark.parametrize("shape,half", [((9, 14, 3), 0), ((9, 14, 3), 1), ((9, 14, 3), 13), ((1, 1, 1), 0), ((70, 3, 1), 2), ((5, 300, 4), 17),
-                                        ((130, 33, 2), 5)])
+                                        ((130, 33, 2), 5), ((300, 200, 3), 4), ((20, 120, 3), 30), ((4, 200, 3), 80), ((260, 70, 1), 9)])
 def test_fast_horizontal_filter_bit_exact(gpu_stream, shape, half):
     F = _lib()
     h, w, c = shape
