@@ -352,15 +352,27 @@ __device__ __forceinline__ float div255_u8(float x) {
 // profiles/r01b_ubench_nv12.txt).  The chroma dword is read by both rows of a pair; the second
 // read is an L2 / Infinity-Cache hit.
 constexpr int kIdBlock = 512;  // 8 KiB contiguous per plane per block; +2 % over 256 (profiles/r01b_ubench_nv12.txt)
-template <bool NT>
+// XCDF (dev knob KH_NV12_XCD_FRAMES=1, off by default until measured): a 1-D launch in which XCD k — workgroups go to the 8
+// XCDs round-robin by linear id — walks frames k, k + 8, ... chunk by chunk, so one L2 sees a frame's chunks in address order
+// (both rows of a chroma pair hit the same L2; the default order puts neighbouring 8 KiB chunks on different XCDs and the
+// second chroma read, 1.06 GB of the 29.66 GB measured, goes back to the fabric).
+struct XcdFrames { FastDiv by_bpf; unsigned bpf, nframes; };
+template <bool NT, bool XCDF>
 __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
-    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a) {
+    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a, XcdFrames xf) {
     const int wq = a.src_w >> 2;     // 4-pixel groups per row
     const int groups = wq * a.src_h;
-    const int g = blockIdx.x * kIdBlock + threadIdx.x;
+    unsigned chunk = blockIdx.x, frame = blockIdx.y;
+    if constexpr (XCDF) {
+        const unsigned xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds, fgrp = fast_quot(slot, xf.by_bpf);
+        chunk = slot - fgrp * xf.bpf;
+        frame = fgrp * kXcds + xcd;
+        if (frame >= xf.nframes) return;
+    }
+    const int g = chunk * kIdBlock + threadIdx.x;
     if (g >= groups) return;
-    const uint8_t* src = src_base + (long long)blockIdx.y * a.src_frame_stride;
-    float* dst = dst_base + (long long)blockIdx.y * a.dst_frame_stride;
+    const uint8_t* src = src_base + (long long)frame * a.src_frame_stride;
+    float* dst = dst_base + (long long)frame * a.dst_frame_stride;
 
     const int r = g / wq;
     const int xq = g - r * wq;
@@ -540,9 +552,16 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
 
     if (identity_fast_path(p, src, dst)) {
         const int groups = (p->src_w / 4) * p->src_h;
-        dim3 grid(cdiv(groups, kIdBlock), (unsigned)p->nframes);
-        hipLaunchKernelGGL((preprocess_nv12_identity<true>), grid, dim3(kIdBlock), 0, s, src,
-                           (float*)dst, a);
+        const unsigned bpf = cdiv(groups, kIdBlock);
+        static const bool xcd_frames = [] { const char* e = getenv("KH_NV12_XCD_FRAMES"); return e && e[0] == '1'; }();
+        const uint64_t remapped = (uint64_t)bpf * kXcds * cdiv(p->nframes, kXcds);
+        if (xcd_frames && remapped < 0x7ff00000ull) {
+            const XcdFrames xf{fast_div(bpf), bpf, (unsigned)p->nframes};
+            hipLaunchKernelGGL((preprocess_nv12_identity<true, true>), dim3((unsigned)remapped), dim3(kIdBlock), 0, s, src, (float*)dst, a, xf);
+        } else {
+            hipLaunchKernelGGL((preprocess_nv12_identity<true, false>), dim3(bpf, (unsigned)p->nframes), dim3(kIdBlock), 0, s, src, (float*)dst, a,
+                               XcdFrames{});
+        }
         return check_launch("preprocess_nv12_identity");
     }
 
