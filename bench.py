@@ -748,7 +748,7 @@ class BoxBlurFast1080p(SpatialGradient1080p):
 
     def __init__(self, batch):
         super().__init__(batch)
-        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C * 4  # per pass (six launches per step): 1R + 1W
+        self.alg_bytes_per_launch = 6 * self.N * 2 * self.W * self.H * self.C * 4  # six passes per step (the events bracket the step), each 1R + 1W
 
     def step(self):
         from kornia_rs._ffi import lib, check
