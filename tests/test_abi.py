@@ -149,3 +149,17 @@ def test_rust_sys_crate_is_in_step_with_the_header():
     fields = re.search(r"pub struct kh_preprocess_params \{(.*?)\}", committed, re.S).group(1)
     assert [f.split(":")[0].strip().replace("pub ", "") for f in fields.strip().splitlines()] == \
         [name for name, _ in _ffi.PreprocessParams._fields_]
+
+
+def test_header_is_plain_c_and_a_c_consumer_links(tmp_path):
+    """include/kornia_hip.h is the boundary a cgo / JNI / Rust binding compiles against: it must be valid C99 (-pedantic), and a
+    C program linked with libkornia_hip.so must be able to call the host-only entries and read the error text."""
+    import subprocess
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "abi_consumer"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{root / 'include'}", str(root / "tests" / "c" / "abi_consumer.c"),
+           "-o", str(exe), f"-L{root / 'kornia-rs_amd' / 'lib'}", "-lkornia_hip", f"-Wl,-rpath,{root / 'kornia-rs_amd' / 'lib'}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c-abi ok" in r.stdout, r.stdout + r.stderr
