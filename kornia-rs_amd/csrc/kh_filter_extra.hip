@@ -150,10 +150,16 @@ __global__ __launch_bounds__(kBlock) void fast_hfilter_lds_kernel(const float* _
 // ---- median_blur (P/filter/median.rs:174-250, cuda/median.rs) ---------------------------------------------------------
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
-template <int K, int C>
+// Window loads: the two pixels' windows span K + 1 columns = (K + 1) * C contiguous bytes per row.  Away from the left / right
+// border a thread fetches them as ceil((K + 1) * C / 4) unaligned dwords and picks the bytes out with constant-index bit-field
+// extracts — 2..6 vector-memory instructions per row instead of (K + 1) * C byte loads (these kernels are otherwise bound by
+// load instructions, like the u8 gathers: DESIGN.md section 5).  The dword run may cover up to 3 bytes more than the window; it
+// is taken only when those bytes are still inside the row, so nothing is read outside the image.  WIDE = false (dev knob
+// KH_MEDIAN_BYTES=1) keeps the byte loads everywhere for A/B.
+template <int K, int C, bool WIDE>
 __global__ __launch_bounds__(kBx* kBy) void median_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int cols,
                                                           long long ss, long long ds) {
-    constexpr int R = K / 2;
+    constexpr int R = K / 2, NB = (K + 1) * C, NW = (NB + 3) / 4;
     const int x0 = 2 * (blockIdx.x * kBx + threadIdx.x), y = blockIdx.y * kBy + threadIdx.y;  // this thread: pixels x0 and x0 + 1
     if (x0 >= cols || y >= rows) return;
     const uint8_t* s = src + (long long)blockIdx.z * ss;
@@ -162,15 +168,30 @@ __global__ __launch_bounds__(kBx* kBy) void median_kernel(const uint8_t* __restr
 #pragma unroll
     for (int j = 0; j <= K; ++j) sx[j] = min(max(x0 + j - R, 0), cols - 1) * C;  // replicate border (cv2.medianBlur's)
     const bool second = x0 + 1 < cols;
+    const bool wide = WIDE && x0 >= R && (x0 - R) * C + 4 * NW <= cols * C;  // no clamped column, dword run inside the row
+    uint32_t words[K][NW];
+    if (wide) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const uint8_t* row = s + (long long)min(max(y + i - R, 0), rows - 1) * cols * C + (x0 - R) * C;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) words[i][w] = *reinterpret_cast<const u32_unaligned*>(row + 4 * w);
+        }
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         us2 v[K * K];
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            const uint8_t* row = s + (long long)min(max(y + i - R, 0), rows - 1) * cols * C + c;
             unsigned short col[K + 1];
+            if (wide) {
 #pragma unroll
-            for (int j = 0; j <= K; ++j) col[j] = row[sx[j]];
+                for (int j = 0; j <= K; ++j) col[j] = (unsigned short)((words[i][(j * C + c) >> 2] >> (8 * ((j * C + c) & 3))) & 0xffu);
+            } else {
+                const uint8_t* row = s + (long long)min(max(y + i - R, 0), rows - 1) * cols * C + c;
+#pragma unroll
+                for (int j = 0; j <= K; ++j) col[j] = row[sx[j]];
+            }
 #pragma unroll
             for (int j = 0; j < K; ++j) v[i * K + j] = us2{col[j], col[j + 1]};  // .x: window of x0, .y: window of x0 + 1
         }
@@ -433,16 +454,23 @@ int32_t kh_median_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     const dim3 grid(cdiv(cdiv(cols, 2), kBx), cdiv(rows, kBy), batch), blk(kBx, kBy);
     hipStream_t st = as_hip(stream);
     const long long ss = src_stride, ds = dst_stride;
+    static const bool bytes_only = [] { const char* e = getenv("KH_MEDIAN_BYTES"); return e && e[0] == '1'; }();
+#define KH_MEDIAN_LAUNCH(K, CH)                                                                                                   \
+    do {                                                                                                                          \
+        if (bytes_only) hipLaunchKernelGGL((median_kernel<K, CH, false>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); \
+        else hipLaunchKernelGGL((median_kernel<K, CH, true>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds);          \
+    } while (0)
     switch (ksize * 10 + channels) {
-        case 31: hipLaunchKernelGGL((median_kernel<3, 1>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); break;
-        case 32: hipLaunchKernelGGL((median_kernel<3, 2>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); break;
-        case 33: hipLaunchKernelGGL((median_kernel<3, 3>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); break;
-        case 34: hipLaunchKernelGGL((median_kernel<3, 4>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); break;
-        case 51: hipLaunchKernelGGL((median_kernel<5, 1>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); break;
-        case 52: hipLaunchKernelGGL((median_kernel<5, 2>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); break;
-        case 53: hipLaunchKernelGGL((median_kernel<5, 3>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); break;
-        default: hipLaunchKernelGGL((median_kernel<5, 4>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); break;
+        case 31: KH_MEDIAN_LAUNCH(3, 1); break;
+        case 32: KH_MEDIAN_LAUNCH(3, 2); break;
+        case 33: KH_MEDIAN_LAUNCH(3, 3); break;
+        case 34: KH_MEDIAN_LAUNCH(3, 4); break;
+        case 51: KH_MEDIAN_LAUNCH(5, 1); break;
+        case 52: KH_MEDIAN_LAUNCH(5, 2); break;
+        case 53: KH_MEDIAN_LAUNCH(5, 3); break;
+        default: KH_MEDIAN_LAUNCH(5, 4); break;
     }
+#undef KH_MEDIAN_LAUNCH
     return check_launch(what);
 }
 

@@ -27,6 +27,12 @@ for i in 1 2; do
   echo " direct" | tee -a "$LOG"; KH_HFILTER_DIRECT=1 timeout 300 python bench.py --workload box_blur_fast_1080p --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | line | tee -a "$LOG"
 done
 
+echo "== 3b. median 5x5: dword window loads vs byte loads (KH_MEDIAN_BYTES)" | tee -a "$LOG"
+for i in 1 2; do
+  echo " wide" | tee -a "$LOG"; timeout 300 python bench.py --workload median5_u8_1080p --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | line | tee -a "$LOG"
+  echo " bytes" | tee -a "$LOG"; KH_MEDIAN_BYTES=1 timeout 300 python bench.py --workload median5_u8_1080p --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | line | tee -a "$LOG"
+done
+
 echo "== 4. first numbers for the workloads added without GPU time" | tee -a "$LOG"
 for wl in spatial_gradient_1080p median5_u8_1080p bilateral_1080p resize_normalize_f32_224 resize_u8_224 resize_norm_chw_224 pyrdown_u8_4k dilate_u8_4k lab_from_rgb_4k; do
   timeout 300 python bench.py --workload $wl --steps 10 --warmup 2 2>&1 | grep '^{' | tee -a "$OUT/bench_new.log" | line | tee -a "$LOG"

@@ -182,3 +182,15 @@ def test_bilateral_batch_tables_and_degenerate_sigma(gpu_stream):
         assert_same_bits(t["space_weight"], want["space_weight"], "space")
         assert_same_bits(t["color_weight"], want["color_weight"], "color")
     assert imgproc.bilateral_tables(5, 50.0, 50.0)["radius"] == 2 and len(imgproc.bilateral_tables(5, 50.0, 50.0)["taps"]) == 13
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+def test_median_width_sweep_exact_allocations(gpu_stream, c):
+    """Every width 1..41 with tightly sized device images: the wide (dword) window loads must hand over to byte loads exactly
+    where a dword would leave the row (the host simulator's AddressSanitizer build turns a 1-byte overrun into a failure)."""
+    from kornia_rs import Image, imgproc
+    for w in list(range(1, 42)) + [127, 128, 129]:
+        img = O.pattern_u8(3 * w * c + w).reshape(-1)[: 3 * w * c].reshape(3, w, c)
+        src = Image.from_numpy(img).to_hip(gpu_stream)
+        for k in (3, 5):
+            assert np.array_equal(imgproc.median_blur(src, k).numpy(), O.median_blur(img, k)), (w, c, k)
