@@ -350,7 +350,9 @@ KH_API int32_t kh_median_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t
  * single-channel u8, byte-for-byte cv2.bilateralFilter semantics — circular window of radius d/2
  * (or round(1.5 sigma_space) for d <= 0), reflect-101 border, cv2's colour table (its SIMD exp
  * polynomial + scalar-expf tail) and its position-dependent tap order; sigma <= 1e-6 copies the
- * source through.  Tables are built on the host and cached on the device per (d, sigmas).
+ * source through.  Tables are built on the host and cached on the device per (d, sigmas): the
+ * FIRST call with a new parameter set uploads them with a blocking copy, so warm it up once
+ * before capturing the call into a graph (kh_graph_capture_begin).
  * kh_bilateral_tables returns them (build_tables, bilateral.rs:110-170): *ntaps always; the
  * arrays (color_weight: 256 entries) only when capacity >= *ntaps.                                */
 KH_API int32_t kh_bilateral_filter_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t cols, int32_t rows,
