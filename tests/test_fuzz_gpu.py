@@ -188,3 +188,35 @@ def test_fuzz_colour_and_camera_formats(gpu_stream, seed):
         mosaic = _u8(rng, h, w, 1)
         pattern = str(rng.choice(sorted(O.BAYER)))
         assert np.array_equal(imgproc.rgb_from_bayer(_up(mosaic, gpu_stream), pattern).numpy(), O.rgb_from_bayer(mosaic, pattern)), ("bayer", pattern, w, h)
+
+
+@pytest.mark.parametrize("seed", range(6 + EXTRA))
+def test_fuzz_filter_extra(gpu_stream, seed):
+    """Spatial gradients, box_blur_fast, median and bilateral at random ragged sizes / parameters."""
+    from kornia_rs import ImageError, imgproc
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(8):
+        (h, w), c = _shape(rng), int(rng.choice([1, 2, 3, 4]))
+        f = _f32(rng, h, w, c)
+        dev = _up(f, gpu_stream)
+        for kind, fn in (("sobel", imgproc.spatial_gradient_float), ("scharr", imgproc.scharr_spatial_gradient_float)):
+            gx, gy = fn(dev)
+            wx, wy = O.spatial_gradient(f, kind)
+            assert np.array_equal(gx.numpy(), wx) and np.array_equal(gy.numpy(), wy), (kind, w, h, c)
+        sigma = (float(rng.uniform(0.3, 4.0)), float(rng.uniform(0.3, 4.0)))
+        want = O.box_blur_fast(f, sigma)
+        if want is None:  # a box wider than the image: the reference indexes out of bounds, the entry refuses
+            with pytest.raises(ImageError):
+                imgproc.box_blur_fast(dev, sigma)
+        else:
+            assert np.array_equal(imgproc.box_blur_fast(dev, sigma).numpy(), want), ("box_blur_fast", w, h, c, sigma)
+        u = _u8(rng, h, w, c)
+        if rng.random() < 0.3:
+            u[:] = rng.integers(0, 256)  # flat images: every window element equal
+        udev, k = _up(u, gpu_stream), int(rng.choice([3, 5]))
+        assert np.array_equal(imgproc.median_blur(udev, k).numpy(), O.median_blur(u, k)), ("median", w, h, c, k)
+        g = _u8(rng, h, w, 1)
+        d = int(rng.choice([-1, 0, 3, 5, 7, 9]))
+        sc, ss = float(rng.uniform(5.0, 120.0)), float(rng.uniform(0.8, 6.0))
+        assert np.array_equal(imgproc.bilateral_filter(_up(g, gpu_stream), d, sc, ss).numpy(), O.bilateral_filter(g, d, sc, ss)), \
+            ("bilateral", w, h, d, sc, ss)
