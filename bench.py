@@ -703,7 +703,7 @@ class LabFromRgb4K(U8Images):
 class SpatialGradient1080p(F32Images):
     """spatial_gradient_float (normalised 3x3 Sobel, dx + dy) on 1920x1080 f32x3, batch 256."""
 
-    name, kernel = "spatial_gradient_sobel_1080p_f32_b256", "spatial_gradient_kernel"
+    name, kernel = "spatial_gradient_sobel_1080p_f32_b256", "spatial_gradient_x4_kernel<3>"
     W, H, C = 1920, 1080, 3
 
     def __init__(self, batch):

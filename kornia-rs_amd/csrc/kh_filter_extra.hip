@@ -70,6 +70,68 @@ __global__ __launch_bounds__(kBx* kBy) void spatial_gradient_kernel(const float*
     gy[o] = sy;
 }
 
+// Four consecutive elements per thread (C <= 4, row length a multiple of 4, 16-byte-aligned images): the 3 x 12-float window
+// of a thread is nine aligned dwordx4 loads and the two results go out as dwordx4 stores — 1 KiB contiguous per wave store
+// instead of 256 B (on this chip the store segment size is what separates 5.2 from 6+ TB/s on streaming maps, profiles/r01b),
+// and 2.25 load instructions per element instead of 9.  Same nine products in the same order per element.  Threads whose window
+// leaves the row (first / last 4 elements of a row) take clamped scalar loads; the values they clamp are never used (the
+// replicate rule substitutes the centre column there).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int C>  // compile-time channel count: every window index below is a constant, so the window stays in registers
+__global__ __launch_bounds__(kBx* kBy) void spatial_gradient_x4_kernel(const float* __restrict__ src, float* __restrict__ gx,
+                                                                       float* __restrict__ gy, int rows, int cols, float a, float b,
+                                                                       long long ss, long long ds) {
+    const int rowlen = cols * C;
+    const int i = 4 * (blockIdx.x * kBx + threadIdx.x), r = blockIdx.y * kBy + threadIdx.y;
+    if (i >= rowlen || r >= rows) return;
+    const float* s = src + (long long)blockIdx.z * ss;
+    const bool inside = i >= 4 && i + 8 <= rowlen;
+    float w[3][12];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int rr = k == 0 ? max(r - 1, 0) : (k == 1 ? r : min(r + 1, rows - 1));
+        const float* row = s + (long long)rr * rowlen;
+        if (inside) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f32x4v v = *reinterpret_cast<const f32x4v*>(row + i - 4 + 4 * q);
+                w[k][4 * q] = v.x; w[k][4 * q + 1] = v.y; w[k][4 * q + 2] = v.z; w[k][4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) w[k][q] = row[min(max(i - 4 + q, 0), rowlen - 1)];
+        }
+    }
+    float ox[4], oy[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool has_left = i + e >= C, has_right = i + e < rowlen - C;  // else replicate: the centre column
+        float l[3], m[3], rt[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            m[k] = w[k][4 + e];
+            l[k] = has_left ? w[k][4 + e - C] : m[k];
+            rt[k] = has_right ? w[k][4 + e + C] : m[k];
+        }
+        float sx = 0.0f, sy = 0.0f;
+        sx += l[0] * -a;    sy += l[0] * -a;
+        sx += m[0] * 0.0f;  sy += m[0] * -b;
+        sx += rt[0] * a;    sy += rt[0] * -a;
+        sx += l[1] * -b;    sy += l[1] * 0.0f;
+        sx += m[1] * 0.0f;  sy += m[1] * 0.0f;
+        sx += rt[1] * b;    sy += rt[1] * 0.0f;
+        sx += l[2] * -a;    sy += l[2] * a;
+        sx += m[2] * 0.0f;  sy += m[2] * b;
+        sx += rt[2] * a;    sy += rt[2] * a;
+        ox[e] = sx;
+        oy[e] = sy;
+    }
+    const long long o = (long long)blockIdx.z * ds + (long long)r * rowlen + i;
+    *reinterpret_cast<f32x4v*>(gx + o) = f32x4v{ox[0], ox[1], ox[2], ox[3]};
+    *reinterpret_cast<f32x4v*>(gy + o) = f32x4v{oy[0], oy[1], oy[2], oy[3]};
+}
+
 // ---- fast_horizontal_filter (P/filter/separable_filter.rs:202-257) ----------------------------------------------------
 // acc = x0 * (half + 1) + sum of the next `half` pixels at column 0, then acc -= leaving, acc += entering (ends replicated);
 // out = acc / (2 * half + 1), stored transposed.  One thread per (row, channel); the chain is sequential by definition.
@@ -362,8 +424,24 @@ int32_t kh_spatial_gradient_f32(kh_stream_t stream, const float* src, float* dx,
     KH_REQUIRE(src && dx && dy, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
     KH_REQUIRE(src != dx && src != dy && dx != dy, KH_ERR_INVALID_ARG, "%s: src, dx and dy must be distinct images", what);
     const float a = kind == KH_GRAD_SOBEL ? 0.125f : 0.09375f, b = kind == KH_GRAD_SOBEL ? 0.25f : 0.3125f;
-    hipLaunchKernelGGL(spatial_gradient_kernel, dim3(cdiv((int64_t)cols * channels, kBx), cdiv(rows, kBy), batch), dim3(kBx, kBy), 0,
-                       as_hip(stream), src, dx, dy, (int)rows, (int)cols, (int)channels, a, b, (long long)src_stride, (long long)dst_stride);
+    const int64_t rowlen = (int64_t)cols * channels;
+    static const bool force_scalar = [] { const char* e = getenv("KH_GRAD_SCALAR"); return e && e[0] == '1'; }();  // dev knob for A/B
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dy)) % 16) == 0 &&
+                         rowlen % 4 == 0 && (batch == 1 || (src_stride % 4 == 0 && dst_stride % 4 == 0));
+    if (!force_scalar && aligned && channels <= 4) {
+        const dim3 grid(cdiv(rowlen / 4, kBx), cdiv(rows, kBy), batch), blk(kBx, kBy);
+        hipStream_t st = as_hip(stream);
+        const long long ss = src_stride, ds = dst_stride;
+        switch (channels) {
+            case 1: hipLaunchKernelGGL(spatial_gradient_x4_kernel<1>, grid, blk, 0, st, src, dx, dy, (int)rows, (int)cols, a, b, ss, ds); break;
+            case 2: hipLaunchKernelGGL(spatial_gradient_x4_kernel<2>, grid, blk, 0, st, src, dx, dy, (int)rows, (int)cols, a, b, ss, ds); break;
+            case 3: hipLaunchKernelGGL(spatial_gradient_x4_kernel<3>, grid, blk, 0, st, src, dx, dy, (int)rows, (int)cols, a, b, ss, ds); break;
+            default: hipLaunchKernelGGL(spatial_gradient_x4_kernel<4>, grid, blk, 0, st, src, dx, dy, (int)rows, (int)cols, a, b, ss, ds); break;
+        }
+        return check_launch(what);
+    }
+    hipLaunchKernelGGL(spatial_gradient_kernel, dim3(cdiv(rowlen, kBx), cdiv(rows, kBy), batch), dim3(kBx, kBy), 0, as_hip(stream), src, dx, dy,
+                       (int)rows, (int)cols, (int)channels, a, b, (long long)src_stride, (long long)dst_stride);
     return check_launch(what);
 }
 

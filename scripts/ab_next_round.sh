@@ -33,6 +33,12 @@ for i in 1 2; do
   echo " bytes" | tee -a "$LOG"; KH_MEDIAN_BYTES=1 timeout 300 python bench.py --workload median5_u8_1080p --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | line | tee -a "$LOG"
 done
 
+echo "== 3c. spatial gradient: four elements per thread vs one (KH_GRAD_SCALAR)" | tee -a "$LOG"
+for i in 1 2; do
+  echo " x4" | tee -a "$LOG"; timeout 300 python bench.py --workload spatial_gradient_1080p --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | line | tee -a "$LOG"
+  echo " scalar" | tee -a "$LOG"; KH_GRAD_SCALAR=1 timeout 300 python bench.py --workload spatial_gradient_1080p --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | line | tee -a "$LOG"
+done
+
 echo "== 4. first numbers for the workloads added without GPU time" | tee -a "$LOG"
 for wl in spatial_gradient_1080p median5_u8_1080p bilateral_1080p resize_normalize_f32_224 resize_u8_224 resize_norm_chw_224 pyrdown_u8_4k dilate_u8_4k lab_from_rgb_4k; do
   timeout 300 python bench.py --workload $wl --steps 10 --warmup 2 2>&1 | grep '^{' | tee -a "$OUT/bench_new.log" | line | tee -a "$LOG"

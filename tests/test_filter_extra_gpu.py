@@ -17,7 +17,9 @@ def _lib():
     return _ffi
 
 
-SHAPES_F32 = [(5, 5, 2), (1, 1, 1), (1, 9, 3), (7, 1, 1), (2, 2, 4), (37, 131, 3), (64, 200, 1), (19, 70, 5)]
+SHAPES_F32 = [(5, 5, 2), (1, 1, 1), (1, 9, 3), (7, 1, 1), (2, 2, 4), (37, 131, 3), (64, 200, 1), (19, 70, 5),
+              # row length a multiple of 4 (with the 4-aligned batch stride below: the four-elements-per-thread kernel)
+              (5, 8, 1), (7, 4, 1), (12, 6, 2), (9, 16, 3), (33, 100, 4), (3, 2, 2), (6, 1, 4), (17, 268, 3)]
 
 
 @pytest.mark.parametrize("kind", ["sobel", "scharr"])
@@ -29,7 +31,7 @@ def test_spatial_gradient_bit_exact(gpu_stream, kind, shape):
     imgs = O.pattern_f32(batch * h * w * c).reshape(batch, h, w, c)
     imgs[0].reshape(-1)[::7] *= -3.5  # mixed signs
     n = h * w * c
-    stride = n + 5  # padded batch stride
+    stride = n + (8 if (w * c) % 4 == 0 else 5)  # padded batch stride; 4-aligned where the vector kernel can run
     src = np.zeros(batch * stride, np.float32)
     for k in range(batch):
         src[k * stride:k * stride + n] = imgs[k].reshape(-1)
