@@ -353,6 +353,7 @@ KH_API int32_t kh_median_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t
  * source through.  Tables are built on the host and cached on the device per (d, sigmas): the
  * FIRST call with a new parameter set uploads them with a blocking copy, so warm it up once
  * before capturing the call into a graph (kh_graph_capture_begin).
+ * A window radius above 512 (d > 1025 or sigma_space > ~341 with d <= 0) is KH_ERR_TOO_LARGE.
  * kh_bilateral_tables returns them (build_tables, bilateral.rs:110-170): *ntaps always; the
  * arrays (color_weight: 256 entries) only when capacity >= *ntaps.                                */
 KH_API int32_t kh_bilateral_filter_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t cols, int32_t rows,

@@ -286,7 +286,7 @@ struct BilateralTab {           // one device allocation: [colour 256 f32][space
     const float* space;
     const Tap* taps;
     const int* order;
-    int n;
+    int n, radius;
 };
 
 __global__ __launch_bounds__(kBx* kBy) void bilateral_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int cols,
@@ -300,14 +300,28 @@ __global__ __launch_bounds__(kBx* kBy) void bilateral_kernel(const uint8_t* __re
     const int val0 = s[(long long)y * cols + x];
     const bool in_simd = x < simd_end;  // cv2's 16-pixel SIMD loop uses a permuted tap order when ntaps == 13
     float wsum = 0.0f, sum = 0.0f;
-    for (int kk = 0; kk < t.n; ++kk) {
-        const int k = in_simd ? t.order[kk] : kk;
-        const Tap tap = t.taps[k];
-        const int sy = reflect101(y + tap.dy, rows), sx = reflect101(x + tap.dx, cols);
-        const int val = s[(long long)sy * cols + sx];
-        const float wgt = t.space[k] * color_w[abs(val - val0)];
-        wsum += wgt;
-        sum = fmaf((float)val, wgt, sum);
+    // Pixels at least `radius` away from every border need no reflection: two integer modulos per tap (~80 VALU instructions)
+    // are skipped for all but a frame of the image.  Same taps, same order, same arithmetic.
+    if (x >= t.radius && x + t.radius < cols && y >= t.radius && y + t.radius < rows) {
+        const uint8_t* centre = s + (long long)y * cols + x;
+        for (int kk = 0; kk < t.n; ++kk) {
+            const int k = in_simd ? t.order[kk] : kk;
+            const Tap tap = t.taps[k];
+            const int val = centre[tap.dy * cols + tap.dx];
+            const float wgt = t.space[k] * color_w[abs(val - val0)];
+            wsum += wgt;
+            sum = fmaf((float)val, wgt, sum);
+        }
+    } else {
+        for (int kk = 0; kk < t.n; ++kk) {
+            const int k = in_simd ? t.order[kk] : kk;
+            const Tap tap = t.taps[k];
+            const int sy = reflect101(y + tap.dy, rows), sx = reflect101(x + tap.dx, cols);
+            const int val = s[(long long)sy * cols + sx];
+            const float wgt = t.space[k] * color_w[abs(val - val0)];
+            wsum += wgt;
+            sum = fmaf((float)val, wgt, sum);
+        }
     }
     dst[(long long)blockIdx.z * ds + (long long)y * cols + x] = (uint8_t)(int)rintf(sum / wsum);
 }
@@ -335,17 +349,23 @@ float v_exp_f32(float x) {
 
 struct HostTables { int radius = 1; std::vector<int32_t> dy, dx, order; std::vector<float> space, color; };
 
-// build_tables (bilateral.rs:110-170)
-void build_tables(int d, double sigma_color, double sigma_space, HostTables& t) {
-    const float color_coeff = (float)(-0.5 / (sigma_color * sigma_color)), space_coeff = (float)(-0.5 / (sigma_space * sigma_space));
+// radius = d / 2, or round-half-even(1.5 sigma_space) through Rust's saturating cast when d <= 0; at least 1 (bilateral.rs:114-121)
+int bilateral_radius(int d, double sigma_space) {
     int radius;
-    if (d <= 0) {  // round-half-even, then Rust's saturating cast
+    if (d <= 0) {
         const double r = nearbyint(sigma_space * 1.5);
         radius = r != r ? 0 : (r >= 2147483647.0 ? 2147483647 : (r <= -2147483648.0 ? INT32_MIN : (int)r));
     } else {
         radius = d / 2;
     }
-    t.radius = radius < 1 ? 1 : radius;
+    return radius < 1 ? 1 : radius;
+}
+constexpr int kMaxBilateralRadius = 512;  // ~824 000 taps per pixel; beyond this the tap tables alone run to gigabytes
+
+// build_tables (bilateral.rs:110-170)
+void build_tables(int d, double sigma_color, double sigma_space, HostTables& t) {
+    const float color_coeff = (float)(-0.5 / (sigma_color * sigma_color)), space_coeff = (float)(-0.5 / (sigma_space * sigma_space));
+    t.radius = bilateral_radius(d, sigma_space);
     t.color.assign(256, 0.0f);
     int i = 0;
     for (; i < 256 - 4; ++i) { const float fi = (float)i; t.color[i] = v_exp_f32(fi * fi * color_coeff); }  // cv2's SIMD polynomial ...
@@ -365,7 +385,7 @@ void build_tables(int d, double sigma_color, double sigma_space, HostTables& t) 
 
 // Device tables are cached per (device, d, sigma bits) like the resize contribution tables: uploaded with a blocking copy
 // into a fresh allocation BEFORE they are published (the reference re-uploads five small arrays on every call).
-struct DevTab { void* dev = nullptr; int n = 0; };
+struct DevTab { void* dev = nullptr; int n = 0, radius = 1; };
 std::mutex g_bil_mu;
 std::map<std::tuple<int, int, uint64_t, uint64_t>, DevTab> g_bil;
 
@@ -393,6 +413,7 @@ int32_t get_bilateral_tab(int d, double sigma_color, double sigma_space, Bilater
         memcpy(&blob[256 + 3 * n], t.order.data(), n * 4);
         DevTab e;
         e.n = (int)n;
+        e.radius = t.radius;
         KH_HIP(hipMalloc(&e.dev, blob.size() * 4));
         const hipError_t err = hipMemcpy(e.dev, blob.data(), blob.size() * 4, hipMemcpyHostToDevice);
         if (err != hipSuccess) {
@@ -408,6 +429,7 @@ int32_t get_bilateral_tab(int d, double sigma_color, double sigma_space, Bilater
     out.taps = (const Tap*)(base + 256 + n);
     out.order = (const int*)(base + 256 + 3 * n);
     out.n = (int)n;
+    out.radius = it->second.radius;
     return KH_OK;
 }
 
@@ -557,6 +579,8 @@ int32_t kh_median_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
 int32_t kh_bilateral_tables(int32_t d, double sigma_color, double sigma_space, int32_t capacity, int32_t* radius, int32_t* ntaps,
                             int32_t* tap_dy, int32_t* tap_dx, float* space_weight, float* color_weight, int32_t* simd_order) {
     KH_REQUIRE(ntaps, KH_ERR_INVALID_ARG, "kh_bilateral_tables: null ntaps");
+    KH_REQUIRE(bilateral_radius(d, sigma_space) <= kMaxBilateralRadius, KH_ERR_TOO_LARGE, "kh_bilateral_tables: window radius %d exceeds %d",
+               bilateral_radius(d, sigma_space), kMaxBilateralRadius);
     HostTables t;
     build_tables(d, sigma_color, sigma_space, t);
     const int n = (int)t.dy.size();
@@ -584,6 +608,8 @@ int32_t kh_bilateral_filter_u8(kh_stream_t stream, const uint8_t* src, uint8_t* 
         else KH_HIP(hipMemcpy2DAsync(dst, (size_t)dst_stride, src, (size_t)src_stride, image, (size_t)batch, hipMemcpyDeviceToDevice, as_hip(stream)));
         return KH_OK;
     }
+    KH_REQUIRE(bilateral_radius(d, sigma_space) <= kMaxBilateralRadius, KH_ERR_TOO_LARGE, "%s: window radius %d exceeds %d", what,
+               bilateral_radius(d, sigma_space), kMaxBilateralRadius);
     BilateralTab t;
     if (int32_t rc = get_bilateral_tab(d, sigma_color, sigma_space, t)) return rc;
     const int simd_end = cols >= 16 ? ((cols - 16) / 16) * 16 + 16 : 0;  // simd_region_end, bilateral.rs:99-106

@@ -61,6 +61,8 @@ CASES = [
     ("median: in place", lambda: L.kh_median_blur_u8(S, P, P, 8, 8, 3, 3, 1, 0, 0), INVALID, "aliased"),
     ("bilateral: zero-sized", lambda: L.kh_bilateral_filter_u8(S, P, Q, 0, 8, 5, 50.0, 50.0, 1, 0, 0), INVALID, "zero-sized"),
     ("bilateral: null dst", lambda: L.kh_bilateral_filter_u8(S, P, None, 8, 8, 5, 50.0, 50.0, 1, 0, 0), INVALID, "null"),
+    ("bilateral: absurd radius", lambda: L.kh_bilateral_filter_u8(S, P, Q, 8, 8, 0, 50.0, 1e9, 1, 0, 0), TOO_LARGE, "radius"),
+    ("bilateral_tables: absurd radius", lambda: L.kh_bilateral_tables(4000, 50.0, 50.0, 0, None, C.byref(C.c_int32()), None, None, None, None, None), TOO_LARGE, "radius"),
     ("bilateral_tables: null ntaps", lambda: L.kh_bilateral_tables(5, 50.0, 50.0, 0, None, None, None, None, None, None, None), INVALID, "ntaps"),
     # ---- u8 fixed-point twins
     ("gaussian_u8: 2 channels", lambda: L.kh_gaussian_blur_u8(S, P, Q, 8, 8, 2, 3, 3, 1.0, 1.0, 1, 0, 0), UNSUPPORTED, "2 channels"),
