@@ -2,16 +2,20 @@
 // blur and the cv2-compatible bilateral filter (crates/kornia-imgproc/src/filter/{ops,median,bilateral}.rs and their
 // device twins cuda/{median,bilateral}.rs).  All four are per-pixel maps over a small replicated / reflected window:
 //
-//   spatial_gradient   4 B in, 8 B out per element: HBM-bound.  One thread per (pixel, channel) element along the
-//                      HWC row so a wave reads three 256-byte row segments (neighbours come from L1/L2) and writes two.
+//   spatial_gradient   4 B in, 8 B out per element: HBM-bound.  Four consecutive elements of the HWC row per thread: nine
+//                      aligned dwordx4 window loads, two dwordx4 stores (1 KiB contiguous per wave store); a one-element
+//                      form covers unaligned images, C > 4 and row lengths not divisible by 4.
 //   fast_hfilter       the running row sum is a serial f32 chain per (row, channel) — that order IS the result — so
 //                      the parallelism is rows x channels x batch; lanes are consecutive (row, channel) pairs, which
-//                      makes the TRANSPOSED store of the reference's layout the coalesced one.
-//   median             exact order statistic, compute-bound (k*k loads, ~2 * |network| min/max per pixel): two
-//                      horizontally adjacent pixels ride in the 16-bit halves of one register through a proved
-//                      selection network (kh_median_net.h), so every v_pk_min_u16 / v_pk_max_u16 serves two pixels.
+//                      makes the TRANSPOSED store of the reference's layout the coalesced one; the row reads are staged
+//                      through LDS in column chunks so that they are coalesced too.
+//   median             exact order statistic, compute-bound (~2 * |network| min/max per pixel): two horizontally adjacent
+//                      pixels ride in the 16-bit halves of one register through a proved selection network
+//                      (kh_median_net.h), so every v_pk_min_u16 / v_pk_max_u16 serves two pixels; window bytes arrive as
+//                      a few unaligned dwords per row.
 //   bilateral          per pixel ntaps x (byte load, LDS colour-weight lookup, mul, add, fma) with the host-built
-//                      cv2 tables; the 1 KiB colour table lives in LDS, taps stream through the scalar/vector cache.
+//                      cv2 tables; the 1 KiB colour table lives in LDS, taps stream through the scalar/vector cache;
+//                      interior pixels skip the border reflection.
 #include <math.h>
 #include <string.h>
 
