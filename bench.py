@@ -875,7 +875,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    os.environ.setdefault("HSA_ENABLE_SDMA", "0")  # shader copies: see kornia_rs/_ffi.py::_prefer_shader_copies
     import torch  # first: one HIP runtime (torch's bundled libamdhip64) for the whole process
     import torch.distributed as dist
 

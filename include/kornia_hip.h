@@ -65,6 +65,13 @@ KH_API uint32_t kh_debug_fast_quot(uint32_t n, uint32_t d);
 /* Device runtime: replaces cudarc's CudaContext/CudaStream/CudaEvent use in T/cuda.rs and
  * P/cuda/dispatch.rs:50-82 (DeviceExec::for_streams — same-device check + event fence).       */
 
+/* Number of HIP runtime images (libamdhip64*) mapped into this process; their paths, newline-separated, go to `buf`
+ * (may be NULL).  The reference never faces this (cudarc dlopens the one driver library, T/cuda.rs:170-212); on
+ * ROCm a Python wheel may bundle its own runtime, and two runtimes in one process do not order copies or stream
+ * waits against each other.  A result above 1 means device work through this library is unsafe — make every HIP
+ * user of the process resolve to one image (INTEGRATION.md "One HIP runtime per process").                        */
+KH_API int32_t kh_hip_runtime_images(char* buf, size_t cap);
+
 KH_API int32_t kh_device_count(int32_t* count);
 KH_API int32_t kh_set_device(int32_t device);
 KH_API int32_t kh_get_device(int32_t* device);

@@ -100,7 +100,9 @@ private:
 };
 
 // ---- storage: residency is a run-time property (T/resource.rs:19-60) --------------------------------------
-enum class MemoryDomain { Host, Device };
+// Host / Device / Unified — where the bytes can be legally dereferenced (MemoryDomain, T/resource.rs:19-60).  Unified = managed
+// memory (kh_malloc_managed): host slices AND device kernels work on the same allocation; dispatch treats it as device-resident.
+enum class MemoryDomain { Host, Device, Unified };
 
 struct ImageSize {
     size_t width, height;
@@ -116,14 +118,20 @@ template <typename T>
 struct Storage {
     MemoryDomain domain = MemoryDomain::Host;
     std::vector<T> host;            // Host
-    T* dev = nullptr;               // Device (stream-ordered allocation, freed on its stream)
+    T* dev = nullptr;               // Device (stream-ordered allocation, freed on its stream) or Unified (managed, kh_free)
     size_t len = 0;
-    std::unique_ptr<Stream> stream; // Device only
+    std::unique_ptr<Stream> stream; // Device / Unified
     Storage() = default;
     Storage(const Storage&) = delete;
     Storage& operator=(const Storage&) = delete;
     ~Storage() {
-        if (dev) kh_free_async(dev, stream ? stream->handle() : nullptr);
+        if (!dev) return;
+        if (domain == MemoryDomain::Unified) {  // Backing::Managed (T/cuda.rs:139-169): drain the carried stream, then hipFree
+            if (stream) kh_stream_synchronize(stream->handle());
+            kh_free(dev);
+        } else {
+            kh_free_async(dev, stream ? stream->handle() : nullptr);
+        }
     }
 };
 }  // namespace detail
@@ -149,6 +157,23 @@ public:
     // zeros_cuda / uninit_cuda (I/cuda.rs:96-121): device-resident, allocated on `stream`
     static Image zeros_hip(ImageSize size, const Stream& stream) { return alloc_hip(size, stream, true); }
     static Image uninit_hip(ImageSize size, const Stream& stream) { return alloc_hip(size, stream, false); }
+    // zeros_cuda_unified (I/cuda.rs:144-160): zero-filled managed memory carrying `stream`
+    static Image zeros_hip_unified(ImageSize size, const Stream& stream) {
+        Image img(size);
+        img.s_->domain = MemoryDomain::Unified;
+        img.s_->stream.reset(new Stream(stream));
+        img.s_->len = size.width * size.height * C;
+        void* p = nullptr;
+        int prev = 0;
+        detail::check(kh_get_device(&prev));
+        detail::check(kh_set_device(stream.device()));
+        const size_t bytes = img.s_->len * sizeof(T);
+        const int32_t rc = kh_malloc_managed(&p, bytes ? bytes : 1);  // the driver rejects a zero-size request
+        kh_set_device(prev);
+        detail::check(rc);
+        img.s_->dev = static_cast<T*>(p);
+        return img;
+    }
 
     ImageSize size() const { return size_; }
     size_t width() const { return size_.width; }
@@ -158,16 +183,28 @@ public:
     static constexpr int num_channels() { return C; }
     size_t numel() const { return size_.width * size_.height * C; }
     MemoryDomain domain() const { return s_->domain; }
-    bool is_device() const { return s_->domain == MemoryDomain::Device; }
+    // device- OR unified-resident: what residency dispatch asks (is_device, P/cuda/dispatch.rs:90-96)
+    bool is_device() const { return s_->domain != MemoryDomain::Host; }
+    bool is_unified() const { return s_->domain == MemoryDomain::Unified; }
+    bool is_host_accessible() const { return s_->domain != MemoryDomain::Device; }
     // the stream a device image is ordered on (TensorStorage::cuda_stream, T/cuda.rs:1010); nullptr for host
     const Stream* stream() const { return s_->stream.get(); }
 
     // host access only — refuses device memory like TensorStorage::as_slice (T/storage.rs:102-110)
     const std::vector<T>& as_slice() const {
-        if (is_device()) throw ImageError(ImageError::Kind::UnsupportedDevice, "host access to device-resident image data; call to_host() first");
+        if (is_device()) throw ImageError(ImageError::Kind::UnsupportedDevice, is_unified() ? "managed image: use unified_data() (a pointer, not a vector)"
+                                                                                           : "host access to device-resident image data; call to_host() first");
         return s_->host;
     }
     std::vector<T>& as_slice_mut() { return const_cast<std::vector<T>&>(static_cast<const Image&>(*this).as_slice()); }
+    // host view of a MANAGED image (as_slice on MemoryDomain::Unified, T/storage.rs:102-125): the carried stream is drained
+    // first, so kernels that wrote the image have finished.  numel() elements.
+    T* unified_data() {
+        if (!is_unified()) throw ImageError(ImageError::Kind::UnsupportedDevice, "unified_data: the image is not in managed memory");
+        s_->stream->synchronize();
+        return s_->dev;
+    }
+    const T* unified_data() const { return const_cast<Image*>(this)->unified_data(); }
     // raw device pointer (as_cudaslice, I/cuda.rs:200-221); host images have none
     const T* device_ptr() const {
         if (!is_device()) throw ImageError(ImageError::Kind::UnsupportedDevice, "device pointer of a host-resident image; call to_hip(stream) first");
@@ -183,6 +220,13 @@ public:
             detail::check(kh_memcpy_h2d_async(out.s_->dev, s_->host.data(), numel() * sizeof(T), stream.handle()));
             stream.synchronize();  // the pageable source may be released by the caller right after
         }
+        return out;
+    }
+    // to_cuda_unified (I/cuda.rs:62-75): copy a HOST image into a new managed image carrying `stream`
+    Image to_hip_unified(const Stream& stream) const {
+        if (is_device()) throw ImageError(ImageError::Kind::UnsupportedDevice, "to_hip_unified: the image is not host-resident");
+        Image out = zeros_hip_unified(size_, stream);
+        if (numel()) std::copy(s_->host.begin(), s_->host.end(), out.s_->dev);  // managed memory is host-writable
         return out;
     }
     Image to_host() const {
@@ -221,9 +265,31 @@ private:
 
 // ---- residency dispatch (pair_residency / DeviceExec::for_streams, P/cuda/dispatch.rs:50-130) ---------------
 namespace detail {
-// Returns the stream to launch on (the SOURCE image's stream) after fencing the destination's stream in.
+// DeviceExec (P/cuda/dispatch.rs:28-82): the stream an op launches on — the SOURCE image's — with the destination's
+// stream fenced IN before the launch (for_streams) and the launch stream fenced BACK into it when the exec goes out of
+// scope, i.e. right after the launch in every operator below (run): dst's own stream — its to_host(), the next op that
+// reads it, its stream-ordered free — is ordered after the kernel that writes it.  Same-stream pairs cost nothing.
+class DeviceExec {
+public:
+    DeviceExec(const Stream& launch, const Stream& dst) : launch_(launch), dst_(dst), cross_(!launch.same_as(dst)) {
+        if (cross_) check(kh_stream_fence(dst_.handle(), launch_.handle()));  // dst's pending work first
+    }
+    DeviceExec(const DeviceExec&) = delete;
+    DeviceExec& operator=(const DeviceExec&) = delete;
+    DeviceExec(DeviceExec&& o) noexcept : launch_(o.launch_), dst_(o.dst_), cross_(o.cross_) { o.cross_ = false; }
+    ~DeviceExec() {
+        if (cross_) kh_stream_fence(launch_.handle(), dst_.handle());  // best effort in a destructor; a failed launch has already thrown
+    }
+    kh_stream_t handle() const { return launch_.handle(); }
+    const Stream& stream() const { return launch_; }
+    operator const Stream&() const { return launch_; }
+
+private:
+    Stream launch_, dst_;
+    bool cross_;
+};
 template <typename TS, int CS, typename TD, int CD>
-inline const Stream& device_exec_for(const Image<TS, CS>& src, const Image<TD, CD>& dst, const char* what) {
+inline DeviceExec device_exec_for(const Image<TS, CS>& src, const Image<TD, CD>& dst, const char* what) {
     if (src.is_device() != dst.is_device())
         throw ImageError(ImageError::Kind::MixedResidency, std::string(what) + ": src and dst must both be host-resident or both device-resident "
                                                                                   "(no implicit transfers)");
@@ -235,8 +301,7 @@ inline const Stream& device_exec_for(const Image<TS, CS>& src, const Image<TD, C
     if (ss.device() != ds.device())
         throw ImageError(ImageError::Kind::DeviceMismatch, std::string(what) + ": src is on device " + std::to_string(ss.device()) +
                                                                ", dst on device " + std::to_string(ds.device()));
-    if (!ss.same_as(ds)) check(kh_stream_fence(ds.handle(), ss.handle()));  // dst's pending work first
-    return ss;
+    return DeviceExec(ss, ds);
 }
 template <typename T, int C>
 inline void same_size(const Image<T, C>& a, const Image<T, C>& b, const char* what) {
@@ -252,12 +317,12 @@ namespace imgproc {
 
 // color::gray_from_rgb (P/color/gray/mod.rs:104-147)
 inline void gray_from_rgb(const Image<uint8_t, 3>& src, Image<uint8_t, 1>& dst) {
-    const Stream& s = detail::device_exec_for(src, dst, "gray_from_rgb");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "gray_from_rgb");
     if (src.size() != dst.size()) throw ImageError(ImageError::Kind::InvalidImageSize, "gray_from_rgb: image sizes differ");
     detail::check(kh_gray_from_rgb_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), (int64_t)(src.width() * src.height())));
 }
 inline void gray_from_rgb(const Image<float, 3>& src, Image<float, 1>& dst) {
-    const Stream& s = detail::device_exec_for(src, dst, "gray_from_rgb");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "gray_from_rgb");
     if (src.size() != dst.size()) throw ImageError(ImageError::Kind::InvalidImageSize, "gray_from_rgb: image sizes differ");
     detail::check(kh_gray_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), (int64_t)(src.width() * src.height())));
 }
@@ -265,14 +330,14 @@ inline void gray_from_rgb(const Image<float, 3>& src, Image<float, 1>& dst) {
 // resize::resize (P/resize/mod.rs:114-238); f32, C in {1, 3, 4}
 template <int C>
 inline void resize(const Image<float, C>& src, Image<float, C>& dst, InterpolationMode interpolation) {
-    const Stream& s = detail::device_exec_for(src, dst, "resize");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "resize");
     detail::check(kh_resize_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
                                 detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, 1, 0, 0));
 }
 // resize::resize_fast_u8_aa (P/resize/mod.rs:348)
 template <int C>
 inline void resize_fast(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, InterpolationMode interpolation, bool antialias = true) {
-    const Stream& s = detail::device_exec_for(src, dst, "resize_fast");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "resize_fast");
     detail::check(kh_resize_fast_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
                                     detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, antialias ? 1 : 0, 1, 0, 0));
 }
@@ -280,21 +345,21 @@ inline void resize_fast(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, In
 // filter::gaussian_blur / box_blur (P/filter/ops.rs:116, 39; u8: :639, :59)
 template <int C>
 inline void gaussian_blur(const Image<float, C>& src, Image<float, C>& dst, std::pair<int, int> kernel_size, std::pair<float, float> sigma) {
-    const Stream& s = detail::device_exec_for(src, dst, "gaussian_blur");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "gaussian_blur");
     detail::same_size(src, dst, "gaussian_blur");
     detail::check(kh_gaussian_blur_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
                                        kernel_size.first, kernel_size.second, sigma.first, sigma.second, 1, 0, 0));
 }
 template <int C>
 inline void gaussian_blur(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, std::pair<int, int> kernel_size, std::pair<float, float> sigma) {
-    const Stream& s = detail::device_exec_for(src, dst, "gaussian_blur_u8");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "gaussian_blur_u8");
     detail::same_size(src, dst, "gaussian_blur_u8");
     detail::check(kh_gaussian_blur_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
                                       kernel_size.first, kernel_size.second, sigma.first, sigma.second, 1, 0, 0));
 }
 template <int C>
 inline void box_blur(const Image<float, C>& src, Image<float, C>& dst, std::pair<int, int> kernel_size) {
-    const Stream& s = detail::device_exec_for(src, dst, "box_blur");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "box_blur");
     detail::same_size(src, dst, "box_blur");
     detail::check(kh_box_blur_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
                                   kernel_size.first, kernel_size.second, 1, 0, 0));
@@ -303,19 +368,19 @@ inline void box_blur(const Image<float, C>& src, Image<float, C>& dst, std::pair
 // warp::warp_affine / warp_perspective (P/warp/affine.rs:123, P/warp/perspective.rs:115); m = FORWARD transform
 template <int C>
 inline void warp_affine(const Image<float, C>& src, Image<float, C>& dst, const std::array<float, 6>& m, InterpolationMode interpolation) {
-    const Stream& s = detail::device_exec_for(src, dst, "warp_affine");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "warp_affine");
     detail::check(kh_warp_affine_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
                                      detail::i32(dst.width()), detail::i32(dst.height()), C, m.data(), (int32_t)interpolation, 1, 0, 0));
 }
 template <int C>
 inline void warp_perspective(const Image<float, C>& src, Image<float, C>& dst, const std::array<float, 9>& m, InterpolationMode interpolation) {
-    const Stream& s = detail::device_exec_for(src, dst, "warp_perspective");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "warp_perspective");
     detail::check(kh_warp_perspective_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
                                           detail::i32(dst.width()), detail::i32(dst.height()), C, m.data(), (int32_t)interpolation, 1, 0, 0));
 }
 template <int C>
 inline void warp_affine_u8(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const std::array<float, 6>& m) {
-    const Stream& s = detail::device_exec_for(src, dst, "warp_affine_u8");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "warp_affine_u8");
     detail::check(kh_warp_affine_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
                                     detail::i32(dst.width()), detail::i32(dst.height()), C, m.data(), 1, 0, 0));
 }
@@ -324,13 +389,13 @@ inline void warp_affine_u8(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst,
 template <int C>
 inline void remap(const Image<float, C>& src, Image<float, C>& dst, const Image<float, 1>& map_x, const Image<float, 1>& map_y,
                   InterpolationMode interpolation) {
-    const Stream& s = detail::device_exec_for(src, dst, "remap");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "remap");
     if (map_x.size() != dst.size() || map_y.size() != dst.size())
         throw ImageError(ImageError::Kind::InvalidImageSize, "remap: map_x, map_y and dst must have the same size");
     if (!map_x.is_device() || !map_y.is_device())
         throw ImageError(ImageError::Kind::MixedResidency, "remap: map_x and map_y must be device-resident when src/dst are on the GPU");
     for (const Image<float, 1>* mp : {&map_x, &map_y})
-        if (!mp->stream()->same_as(s)) detail::check(kh_stream_fence(mp->stream()->handle(), s.handle()));
+        if (!mp->stream()->same_as(s.stream())) detail::check(kh_stream_fence(mp->stream()->handle(), s.handle()));
     detail::check(kh_remap_f32(s.handle(), src.device_ptr(), map_x.device_ptr(), map_y.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()),
                                detail::i32(src.height()), detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, 1, 0, 0));
 }
@@ -338,7 +403,7 @@ inline void remap(const Image<float, C>& src, Image<float, C>& dst, const Image<
 // normalize::normalize_mean_std (P/normalize.rs:56)
 template <int C>
 inline void normalize_mean_std(const Image<float, C>& src, Image<float, C>& dst, const std::array<float, C>& mean, const std::array<float, C>& std_) {
-    const Stream& s = detail::device_exec_for(src, dst, "normalize_mean_std");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "normalize_mean_std");
     detail::same_size(src, dst, "normalize_mean_std");
     detail::check(kh_normalize_mean_std_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), (int64_t)(src.width() * src.height()), C, mean.data(),
                                             std_.data()));
@@ -349,8 +414,8 @@ inline void normalize_mean_std(const Image<float, C>& src, Image<float, C>& dst,
 
 namespace helpers {
 template <typename TS, int CS, typename TD, int CD>
-inline const Stream& map_pair(const Image<TS, CS>& src, const Image<TD, CD>& dst, const char* what) {
-    const Stream& s = detail::device_exec_for(src, dst, what);
+inline detail::DeviceExec map_pair(const Image<TS, CS>& src, const Image<TD, CD>& dst, const char* what) {
+    detail::DeviceExec s = detail::device_exec_for(src, dst, what);
     if (src.size() != dst.size()) throw ImageError(ImageError::Kind::InvalidImageSize, std::string(what) + ": image sizes differ");
     return s;
 }
@@ -361,32 +426,32 @@ inline int64_t npixels(const Image<T, C>& im) { return (int64_t)(im.width() * im
 // color::rgb_from_gray / bgr_from_rgb / rgba_from_rgb / bgra_from_rgb / rgb_from_rgba / rgb_from_bgra (P/color/gray/mod.rs:241,
 // P/color/rgb/mod.rs:60-330)
 inline void rgb_from_gray(const Image<uint8_t, 1>& src, Image<uint8_t, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "rgb_from_gray");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "rgb_from_gray");  // classify operands BEFORE touching device pointers
     detail::check(kh_rgb_from_gray_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
 }
 inline void rgb_from_gray(const Image<float, 1>& src, Image<float, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "rgb_from_gray");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "rgb_from_gray");  // classify operands BEFORE touching device pointers
     detail::check(kh_rgb_from_gray_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
 }
 inline void bgr_from_rgb(const Image<uint8_t, 3>& src, Image<uint8_t, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "bgr_from_rgb");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "bgr_from_rgb");  // classify operands BEFORE touching device pointers
     detail::check(kh_bgr_from_rgb_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
 }
 inline void bgr_from_rgb(const Image<float, 3>& src, Image<float, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "bgr_from_rgb");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "bgr_from_rgb");  // classify operands BEFORE touching device pointers
     detail::check(kh_bgr_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
 }
 inline void rgba_from_rgb(const Image<uint8_t, 3>& src, Image<uint8_t, 4>& dst, bool bgra = false) {
-    const Stream& s = helpers::map_pair(src, dst, "rgba_from_rgb");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "rgba_from_rgb");  // classify operands BEFORE touching device pointers
     detail::check(kh_rgba_from_rgb_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), bgra ? 1 : 0));
 }
 inline void rgba_from_rgb(const Image<float, 3>& src, Image<float, 4>& dst, bool bgra = false) {
-    const Stream& s = helpers::map_pair(src, dst, "rgba_from_rgb");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "rgba_from_rgb");  // classify operands BEFORE touching device pointers
     detail::check(kh_rgba_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), bgra ? 1 : 0));
 }
 // `background` = nullptr drops alpha, else blends over the RGB triple (rgb_from_rgba, P/color/rgb/mod.rs:60-126); `bgra` swaps R and B
 inline void rgb_from_rgba(const Image<uint8_t, 4>& src, Image<uint8_t, 3>& dst, const std::array<uint8_t, 3>* background = nullptr, bool bgra = false) {
-    const Stream& s = helpers::map_pair(src, dst, "rgb_from_rgba");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "rgb_from_rgba");  // classify operands BEFORE touching device pointers
     detail::check(kh_rgb_from_rgba_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src),
                                       bgra ? 1 : 0, background ? background->data() : nullptr));
 }
@@ -394,52 +459,52 @@ inline void rgb_from_rgba(const Image<uint8_t, 4>& src, Image<uint8_t, 3>& dst, 
 // color::ycbcr_from_rgb / yuv_from_rgb and inverses (P/color/yuv/mod.rs:150-185)
 enum class ChromaOrder { YCrCb = KH_YCC_YCRCB, YuvCbCr = KH_YCC_YUV };
 inline void ycc_from_rgb(const Image<uint8_t, 3>& src, Image<uint8_t, 3>& dst, ChromaOrder order) {
-    const Stream& s = helpers::map_pair(src, dst, "ycc_from_rgb");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "ycc_from_rgb");  // classify operands BEFORE touching device pointers
     detail::check(kh_ycc_from_rgb_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), (int32_t)order));
 }
 inline void rgb_from_ycc(const Image<uint8_t, 3>& src, Image<uint8_t, 3>& dst, ChromaOrder order) {
-    const Stream& s = helpers::map_pair(src, dst, "rgb_from_ycc");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "rgb_from_ycc");  // classify operands BEFORE touching device pointers
     detail::check(kh_rgb_from_ycc_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), (int32_t)order));
 }
 inline void ycc_from_rgb(const Image<float, 3>& src, Image<float, 3>& dst, ChromaOrder order) {
-    const Stream& s = helpers::map_pair(src, dst, "ycc_from_rgb");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "ycc_from_rgb");  // classify operands BEFORE touching device pointers
     detail::check(kh_ycc_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), (int32_t)order));
 }
 inline void rgb_from_ycc(const Image<float, 3>& src, Image<float, 3>& dst, ChromaOrder order) {
-    const Stream& s = helpers::map_pair(src, dst, "rgb_from_ycc");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "rgb_from_ycc");  // classify operands BEFORE touching device pointers
     detail::check(kh_rgb_from_ycc_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), (int32_t)order));
 }
 
 // color::{hsv,hls}_from_rgb and inverses, sepia_from_rgb (P/color/hsv/mod.rs, P/color/hls/mod.rs, P/color/sepia.rs); [0, 255] domain
 inline void hsv_from_rgb(const Image<float, 3>& src, Image<float, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "hsv_from_rgb");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "hsv_from_rgb");  // classify operands BEFORE touching device pointers
     detail::check(kh_hsv_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
 }
 inline void rgb_from_hsv(const Image<float, 3>& src, Image<float, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "rgb_from_hsv");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "rgb_from_hsv");  // classify operands BEFORE touching device pointers
     detail::check(kh_rgb_from_hsv_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
 }
 inline void hls_from_rgb(const Image<float, 3>& src, Image<float, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "hls_from_rgb");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "hls_from_rgb");  // classify operands BEFORE touching device pointers
     detail::check(kh_hls_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
 }
 inline void rgb_from_hls(const Image<float, 3>& src, Image<float, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "rgb_from_hls");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "rgb_from_hls");  // classify operands BEFORE touching device pointers
     detail::check(kh_rgb_from_hls_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
 }
 inline void sepia_from_rgb(const Image<uint8_t, 3>& src, Image<uint8_t, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "sepia_from_rgb");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "sepia_from_rgb");  // classify operands BEFORE touching device pointers
     detail::check(kh_sepia_from_rgb_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
 }
 inline void sepia_from_rgb(const Image<float, 3>& src, Image<float, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "sepia_from_rgb");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "sepia_from_rgb");  // classify operands BEFORE touching device pointers
     detail::check(kh_sepia_from_rgb_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src)));
 }
 
 // CIE family (P/color/cie/mod.rs:58-160) for f32, and every f64 colour conversion (gray, hsv / hls, ycbcr / yuv, CIE:
 // P/color/cuda_dispatch.rs:48-61,111-135).  `conversion` is a KH_CIE_* (both) or KH_F64_* (f64) code.
 inline void cie_convert(const Image<float, 3>& src, Image<float, 3>& dst, int conversion) {
-    const Stream& s = helpers::map_pair(src, dst, "cie_convert");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "cie_convert");  // classify operands BEFORE touching device pointers
     detail::check(kh_cie_convert_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), conversion));
 }
 template <int CS, int CD>
@@ -448,13 +513,13 @@ inline void color_convert_f64(const Image<double, CS>& src, Image<double, CD>& d
     if (CS != want_in || CD != want_out)
         throw ImageError(ImageError::Kind::InvalidChannelShape, "color_convert_f64: conversion " + std::to_string(conversion) + " maps " +
                                                                      std::to_string(want_in) + " -> " + std::to_string(want_out) + " channels");
-    const Stream& s = helpers::map_pair(src, dst, "color_convert_f64");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "color_convert_f64");  // classify operands BEFORE touching device pointers
     detail::check(kh_color_convert_f64(s.handle(), src.device_ptr(), dst.device_ptr_mut(), helpers::npixels(src), conversion));
 }
 
 // color::apply_colormap with a caller-provided table r[256] g[256] b[256] (P/color/colormap.rs:252-300)
 inline void apply_colormap(const Image<uint8_t, 1>& src, Image<uint8_t, 3>& dst, const std::array<uint8_t, 768>& lut) {
-    const Stream& s = helpers::map_pair(src, dst, "apply_colormap");
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "apply_colormap");
     void* dlut = nullptr;
     detail::check(kh_malloc_async(&dlut, 768, 0, s.handle()));
     int32_t rc = kh_memcpy_h2d_async(dlut, lut.data(), 768, s.handle());
@@ -500,7 +565,7 @@ inline void yuyv_from_rgb(const Image<uint8_t, 3>& src, uint8_t* out_device) {
 // color::rgb_from_bayer (P/color/bayer/mod.rs:37-70): bilinear, cv2-compatible demosaic
 enum class BayerPattern { Rggb = KH_BAYER_RGGB, Bggr = KH_BAYER_BGGR, Grbg = KH_BAYER_GRBG, Gbrg = KH_BAYER_GBRG };
 inline void rgb_from_bayer(const Image<uint8_t, 1>& src, BayerPattern pattern, Image<uint8_t, 3>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "rgb_from_bayer");
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "rgb_from_bayer");
     detail::check(kh_rgb_from_bayer_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), (int32_t)pattern));
 }
 
@@ -509,25 +574,25 @@ inline void rgb_from_bayer(const Image<uint8_t, 1>& src, BayerPattern pattern, I
 enum class PixelMapping { HalfPixel = KH_MAP_HALF_PIXEL, AlignCorners = KH_MAP_ALIGN_CORNERS };
 template <int C>
 inline void resize_mapped(const Image<float, C>& src, Image<float, C>& dst, InterpolationMode interpolation, PixelMapping mapping) {
-    const Stream& s = detail::device_exec_for(src, dst, "resize");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "resize");
     detail::check(kh_resize_mapped_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
                                        detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, (int32_t)mapping, 1, 0, 0));
 }
 inline void resize_bilinear_normalize(const Image<float, 3>& src, Image<float, 3>& dst, const std::array<float, 3>& mean,
                                       const std::array<float, 3>& std_, PixelMapping mapping = PixelMapping::HalfPixel) {
-    const Stream& s = detail::device_exec_for(src, dst, "resize_bilinear_normalize");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "resize_bilinear_normalize");
     detail::check(kh_resize_bilinear_normalize_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
                                                    detail::i32(dst.width()), detail::i32(dst.height()), mean.data(), std_.data(), (int32_t)mapping, 1, 0, 0));
 }
 template <int C>
 inline void resize_opencv(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, InterpolationMode interpolation) {
-    const Stream& s = detail::device_exec_for(src, dst, "resize_opencv");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "resize_opencv");
     detail::check(kh_resize_opencv_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
                                       detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, 1, 0, 0));
 }
 template <int C>
 inline void resize_opencv(const Image<float, C>& src, Image<float, C>& dst, InterpolationMode interpolation) {
-    const Stream& s = detail::device_exec_for(src, dst, "resize_opencv");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "resize_opencv");
     detail::check(kh_resize_opencv_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
                                        detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, 1, 0, 0));
 }
@@ -536,25 +601,25 @@ inline void resize_opencv(const Image<float, C>& src, Image<float, C>& dst, Inte
 template <int C>
 inline void remap(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const Image<float, 1>& map_x, const Image<float, 1>& map_y,
                   InterpolationMode interpolation) {
-    const Stream& s = detail::device_exec_for(src, dst, "remap_u8");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "remap_u8");
     if (map_x.size() != dst.size() || map_y.size() != dst.size())
         throw ImageError(ImageError::Kind::InvalidImageSize, "remap: map_x, map_y and dst must have the same size");
     if (!map_x.is_device() || !map_y.is_device())
         throw ImageError(ImageError::Kind::MixedResidency, "remap: map_x and map_y must be device-resident when src/dst are on the GPU");
     for (const Image<float, 1>* mp : {&map_x, &map_y})
-        if (!mp->stream()->same_as(s)) detail::check(kh_stream_fence(mp->stream()->handle(), s.handle()));
+        if (!mp->stream()->same_as(s.stream())) detail::check(kh_stream_fence(mp->stream()->handle(), s.handle()));
     detail::check(kh_remap_u8(s.handle(), src.device_ptr(), map_x.device_ptr(), map_y.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()),
                               detail::i32(src.height()), detail::i32(dst.width()), detail::i32(dst.height()), C, (int32_t)interpolation, 1, 0, 0));
 }
 template <int C>
 inline void warp_perspective_u8(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const std::array<float, 9>& m) {
-    const Stream& s = detail::device_exec_for(src, dst, "warp_perspective_u8");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "warp_perspective_u8");
     detail::check(kh_warp_perspective_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()),
                                          detail::i32(dst.width()), detail::i32(dst.height()), C, m.data(), 1, 0, 0));
 }
 template <int C>
 inline void box_blur(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, std::pair<int, int> kernel_size) {
-    const Stream& s = detail::device_exec_for(src, dst, "box_blur_u8");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "box_blur_u8");
     detail::same_size(src, dst, "box_blur_u8");
     detail::check(kh_box_blur_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
                                  kernel_size.first, kernel_size.second, 1, 0, 0));
@@ -563,21 +628,21 @@ inline void box_blur(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, std::
 // filter::separable_filter, sobel, scharr (P/filter/separable_filter.rs:166, P/filter/ops.rs:174, 214)
 template <int C>
 inline void separable_filter(const Image<float, C>& src, Image<float, C>& dst, const std::vector<float>& kernel_x, const std::vector<float>& kernel_y) {
-    const Stream& s = detail::device_exec_for(src, dst, "separable_filter");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "separable_filter");
     detail::same_size(src, dst, "separable_filter");
     detail::check(kh_separable_filter_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
                                           kernel_x.data(), detail::i32(kernel_x.size()), kernel_y.data(), detail::i32(kernel_y.size()), 1, 0, 0));
 }
 template <int C>
 inline void sobel(const Image<float, C>& src, Image<float, C>& dst, int kernel_size) {
-    const Stream& s = detail::device_exec_for(src, dst, "sobel");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "sobel");
     detail::same_size(src, dst, "sobel");
     detail::check(kh_gradient_magnitude_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
                                             KH_GRAD_SOBEL, kernel_size, 1, 0, 0));
 }
 template <int C>
 inline void scharr(const Image<float, C>& src, Image<float, C>& dst) {
-    const Stream& s = detail::device_exec_for(src, dst, "scharr");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "scharr");
     detail::same_size(src, dst, "scharr");
     detail::check(kh_gradient_magnitude_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C,
                                             KH_GRAD_SCHARR, 3, 1, 0, 0));
@@ -586,7 +651,7 @@ inline void scharr(const Image<float, C>& src, Image<float, C>& dst) {
 // filter::spatial_gradient_float / scharr_spatial_gradient_float (P/filter/ops.rs:287, 511): normalised 3x3 derivatives
 template <int C>
 inline void spatial_gradient_float(const Image<float, C>& src, Image<float, C>& dx, Image<float, C>& dy) {
-    const Stream& s = detail::device_exec_for(src, dx, "spatial_gradient_float");
+    const detail::DeviceExec s = detail::device_exec_for(src, dx, "spatial_gradient_float");
     detail::device_exec_for(src, dy, "spatial_gradient_float");
     detail::same_size(src, dx, "spatial_gradient_float");
     detail::same_size(src, dy, "spatial_gradient_float");
@@ -595,7 +660,7 @@ inline void spatial_gradient_float(const Image<float, C>& src, Image<float, C>& 
 }
 template <int C>
 inline void scharr_spatial_gradient_float(const Image<float, C>& src, Image<float, C>& dx, Image<float, C>& dy) {
-    const Stream& s = detail::device_exec_for(src, dx, "scharr_spatial_gradient_float");
+    const detail::DeviceExec s = detail::device_exec_for(src, dx, "scharr_spatial_gradient_float");
     detail::device_exec_for(src, dy, "scharr_spatial_gradient_float");
     detail::same_size(src, dx, "scharr_spatial_gradient_float");
     detail::same_size(src, dy, "scharr_spatial_gradient_float");
@@ -605,22 +670,22 @@ inline void scharr_spatial_gradient_float(const Image<float, C>& src, Image<floa
 // filter::box_blur_fast (P/filter/ops.rs:252): the transposed intermediate is a scratch image on the source's stream
 template <int C>
 inline void box_blur_fast(const Image<float, C>& src, Image<float, C>& dst, std::pair<float, float> sigma) {
-    const Stream& s = detail::device_exec_for(src, dst, "box_blur_fast");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "box_blur_fast");
     detail::same_size(src, dst, "box_blur_fast");
-    auto scratch = Image<float, C>::uninit_hip(src.size(), s);
+    auto scratch = Image<float, C>::uninit_hip(src.size(), s.stream());
     detail::check(kh_box_blur_fast_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), scratch.device_ptr_mut(), detail::i32(src.width()),
                                        detail::i32(src.height()), C, sigma.first, sigma.second, 1, 0, 0));
 }
 // filter::median_blur (P/filter/median.rs:174), filter::bilateral_filter (P/filter/bilateral.rs:172)
 template <int C>
 inline void median_blur(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, int ksize) {
-    const Stream& s = detail::device_exec_for(src, dst, "median_blur");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "median_blur");
     detail::same_size(src, dst, "median_blur");
     detail::check(kh_median_blur_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, ksize,
                                     1, 0, 0));
 }
 inline void bilateral_filter(const Image<uint8_t, 1>& src, Image<uint8_t, 1>& dst, int d, double sigma_color, double sigma_space) {
-    const Stream& s = detail::device_exec_for(src, dst, "bilateral_filter");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "bilateral_filter");
     detail::same_size(src, dst, "bilateral_filter");
     detail::check(kh_bilateral_filter_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), d,
                                          sigma_color, sigma_space, 1, 0, 0));
@@ -629,8 +694,8 @@ inline void bilateral_filter(const Image<uint8_t, 1>& src, Image<uint8_t, 1>& ds
 // pyramid::pyrdown / pyrup (P/pyramid.rs:180-520): dst is ceil(src / 2) resp. 2 * src
 namespace helpers {
 template <typename T, int C>
-inline const Stream& pyr_pair(const Image<T, C>& src, const Image<T, C>& dst, bool up, const char* what) {
-    const Stream& s = detail::device_exec_for(src, dst, what);
+inline detail::DeviceExec pyr_pair(const Image<T, C>& src, const Image<T, C>& dst, bool up, const char* what) {
+    detail::DeviceExec s = detail::device_exec_for(src, dst, what);
     const size_t w = up ? src.width() * 2 : (src.width() + 1) / 2, h = up ? src.height() * 2 : (src.height() + 1) / 2;
     if (dst.width() != w || dst.height() != h)
         throw ImageError(ImageError::Kind::InvalidImageSize, std::string(what) + ": destination must be " + std::to_string(w) + "x" + std::to_string(h));
@@ -639,22 +704,22 @@ inline const Stream& pyr_pair(const Image<T, C>& src, const Image<T, C>& dst, bo
 }  // namespace helpers
 template <int C>
 inline void pyrdown(const Image<float, C>& src, Image<float, C>& dst) {
-    const Stream& s = helpers::pyr_pair(src, dst, false, "pyrdown");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::pyr_pair(src, dst, false, "pyrdown");  // classify operands BEFORE touching device pointers
     detail::check(kh_pyrdown_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, 1, 0, 0));
 }
 template <int C>
 inline void pyrdown(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst) {
-    const Stream& s = helpers::pyr_pair(src, dst, false, "pyrdown");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::pyr_pair(src, dst, false, "pyrdown");  // classify operands BEFORE touching device pointers
     detail::check(kh_pyrdown_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, 1, 0, 0));
 }
 template <int C>
 inline void pyrup(const Image<float, C>& src, Image<float, C>& dst) {
-    const Stream& s = helpers::pyr_pair(src, dst, true, "pyrup");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::pyr_pair(src, dst, true, "pyrup");  // classify operands BEFORE touching device pointers
     detail::check(kh_pyrup_f32(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, 1, 0, 0));
 }
 template <int C>
 inline void pyrup(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst) {
-    const Stream& s = helpers::pyr_pair(src, dst, true, "pyrup");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::pyr_pair(src, dst, true, "pyrup");  // classify operands BEFORE touching device pointers
     detail::check(kh_pyrup_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, 1, 0, 0));
 }
 
@@ -673,7 +738,7 @@ struct Kernel {
 namespace helpers {
 template <int C>
 inline void morph(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const Kernel& k, int op, PaddingMode mode, const std::array<uint8_t, C>& constant, const char* what) {
-    const Stream& s = detail::device_exec_for(src, dst, what);
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, what);
     detail::same_size(src, dst, what);
     detail::check(kh_morphology_u8(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), C, op, k.mask.data(), k.width, k.height,
                            (int32_t)mode, constant.data(), 1, 0, 0));
@@ -691,19 +756,19 @@ inline void erode(const Image<uint8_t, C>& src, Image<uint8_t, C>& dst, const Ke
 // crop::crop_image, flip::{horizontal,vertical}_flip (P/crop.rs:187, P/flip.rs:39, 305)
 template <typename T, int C>
 inline void crop_image(const Image<T, C>& src, Image<T, C>& dst, size_t x, size_t y) {
-    const Stream& s = detail::device_exec_for(src, dst, "crop_image");
+    const detail::DeviceExec s = detail::device_exec_for(src, dst, "crop_image");
     detail::check(kh_crop(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()), detail::i32(src.height()), detail::i32(dst.width()),
                           detail::i32(dst.height()), detail::i32(x), detail::i32(y), (int32_t)(C * sizeof(T))));
 }
 template <typename T, int C>
 inline void horizontal_flip(const Image<T, C>& src, Image<T, C>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "horizontal_flip");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "horizontal_flip");  // classify operands BEFORE touching device pointers
     detail::check(kh_flip(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()),
                           detail::i32(src.height()), (int32_t)(C * sizeof(T)), 1));
 }
 template <typename T, int C>
 inline void vertical_flip(const Image<T, C>& src, Image<T, C>& dst) {
-    const Stream& s = helpers::map_pair(src, dst, "vertical_flip");  // classify operands BEFORE touching device pointers
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "vertical_flip");  // classify operands BEFORE touching device pointers
     detail::check(kh_flip(s.handle(), src.device_ptr(), dst.device_ptr_mut(), detail::i32(src.width()),
                           detail::i32(src.height()), (int32_t)(C * sizeof(T)), 0));
 }
@@ -727,7 +792,7 @@ inline std::pair<float, float> find_min_max(const Image<float, C>& src) {
 }
 template <int C>
 inline void normalize_min_max(const Image<float, C>& src, Image<float, C>& dst, float min, float max) {
-    const Stream& s = helpers::map_pair(src, dst, "normalize_min_max");
+    const detail::DeviceExec s = helpers::map_pair(src, dst, "normalize_min_max");
     void* scratch = nullptr;
     detail::check(kh_malloc_async(&scratch, 16, 1, s.handle()));
     float* mm = static_cast<float*>(scratch);
@@ -741,7 +806,7 @@ inline void normalize_min_max(const Image<float, C>& src, Image<float, C>& dst, 
 // distortion = {k1..k6, p1, p2}
 inline void generate_correction_map_polynomial(Image<float, 1>& map_x, Image<float, 1>& map_y, const std::array<double, 4>& intrinsic,
                                                const std::array<double, 8>& distortion) {
-    const Stream& s = helpers::map_pair(map_x, map_y, "generate_correction_map_polynomial");
+    const detail::DeviceExec s = helpers::map_pair(map_x, map_y, "generate_correction_map_polynomial");
     detail::check(kh_correction_map_polynomial_f32(s.handle(), map_x.device_ptr_mut(), map_y.device_ptr_mut(), detail::i32(map_x.width()),
                                                    detail::i32(map_x.height()), intrinsic.data(), distortion.data()));
 }

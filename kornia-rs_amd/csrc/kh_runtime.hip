@@ -8,6 +8,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <atomic>
+#include <set>
+#include <string>
+
 #include "kh_common.h"
 
 namespace kh {
@@ -54,6 +58,37 @@ const char* kh_version(void) { return "kornia-hip 0.1.0 (gfx950)"; }
 
 // test hook: the launch-constant division used to decode tile ids (kh_common.h::FastDiv), on the host
 uint32_t kh_debug_fast_quot(uint32_t n, uint32_t d) { return kh::fast_quot(n, kh::fast_div(d)); }
+
+// How many HIP runtime images (libamdhip64*) are mapped into this process, and which.  More than one is unsafe: each
+// brings its own HSA runtime, and copies / stream waits issued through one do not order against the other (the
+// round-1 "incomplete copy at hipStreamSynchronize" finding: libkornia_hip.so bound to /opt/rocm's runtime, then
+// `import torch` mapped the wheel's bundled copy beside it — profiles/r02*_runtimes.log).  A host that mixes this
+// library with another HIP user must make both resolve to ONE runtime image (load order / RPATH); this entry lets it
+// check.  `buf` receives the paths separated by newlines.  Linux only (/proc/self/maps); returns 0 images elsewhere.
+int32_t kh_hip_runtime_images(char* buf, size_t cap) {
+    std::set<std::string> images;
+    if (FILE* f = fopen("/proc/self/maps", "r")) {
+        char line[4352];
+        while (fgets(line, sizeof(line), f)) {
+            const char* path = strchr(line, '/');
+            if (!path) continue;
+            const char* base = strrchr(path, '/');
+            if (strncmp(base + 1, "libamdhip64", 11) != 0) continue;
+            std::string p(path);
+            while (!p.empty() && (p.back() == '\n' || p.back() == ' ')) p.pop_back();
+            images.insert(p);
+        }
+        fclose(f);
+    }
+    if (buf && cap) {
+        std::string all;
+        for (const auto& p : images) { all += p; all += '\n'; }
+        const size_t m = all.size() < cap - 1 ? all.size() : cap - 1;
+        memcpy(buf, all.data(), m);
+        buf[m] = 0;
+    }
+    return (int32_t)images.size();
+}
 
 int32_t kh_device_count(int32_t* count) {
     KH_REQUIRE(count, KH_ERR_INVALID_ARG, "kh_device_count: null out pointer");
@@ -221,15 +256,16 @@ int32_t kh_graph_destroy(kh_graph_t graph) {
 // gfx950 we observed a trim of a large freed block invalidate a small block re-allocated from it
 // (reads came back as zeros).  Keep everything cached; kh_mempool_set_release_threshold can lower it.
 static int32_t pin_pool_once() {
-    static bool done[64] = {false};
+    // 0 = not done, 1 = done.  Racing first calls may both set the attribute (idempotent); nobody reads a torn flag.
+    static std::atomic<uint8_t> done[64];
     int dev = 0;
     KH_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || done[dev]) return KH_OK;
+    if (dev < 0 || dev >= 64 || done[dev].load(std::memory_order_acquire)) return KH_OK;
     hipMemPool_t pool = nullptr;
     KH_HIP(hipDeviceGetDefaultMemPool(&pool, dev));
     uint64_t v = UINT64_MAX;
     KH_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &v));
-    done[dev] = true;
+    done[dev].store(1, std::memory_order_release);
     return KH_OK;
 }
 

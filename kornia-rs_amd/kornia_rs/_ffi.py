@@ -83,6 +83,7 @@ SIGNATURES = {
     "kh_last_error": (_sz, [C.c_char_p, _sz]),
     "kh_debug_fast_quot": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "kh_version": (C.c_char_p, []),
+    "kh_hip_runtime_images": (_i32, [C.c_char_p, C.c_size_t]),
     "kh_device_count": (_i32, [_P(_i32)]),
     "kh_set_device": (_i32, [_i32]),
     "kh_get_device": (_i32, [_P(_i32)]),
@@ -193,28 +194,92 @@ SIGNATURES = {
 }
 
 
-def _prefer_shader_copies() -> None:
-    """ROCm 7.2 / gfx950 workaround, applied only if the variable is unset and only effective when the HIP
-    runtime has not been initialised yet: with the SDMA copy engines enabled we observed host<->device copies
-    (pageable AND page-locked) that had not fully landed when ``hipStreamSynchronize`` returned — 4 MiB / 16 MiB
-    holes of stale bytes, dependent on what the process had done before (profiles/r01zy_sdma.log).  With
-    ``HSA_ENABLE_SDMA=0`` the runtime copies with shader kernels, which order like any other kernel; every
-    variant of the failing sequence passes.  Kernels (the measured path) are unaffected."""
-    import os
-    os.environ.setdefault("HSA_ENABLE_SDMA", "0")
+def mapped_hip_runtimes() -> dict:
+    """{"libamdhip64": [paths], "libhsa-runtime64": [paths]} of the HIP / HSA runtime images mapped into this process
+    (from /proc/self/maps).  More than one of either is the root cause of the round-1 "SDMA" finding: two HSA runtimes
+    in one process share the process's single KFD event page / copy-engine queues, and a host<->device copy of runtime A
+    was seen incomplete at ``hipStreamSynchronize`` once runtime B had initialised (profiles/r01zy_sdma.log,
+    profiles/r02*_runtimes.log)."""
+    import re
+    found = {"libamdhip64": set(), "libhsa-runtime64": set()}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                m = re.search(r"(/\S*/(libamdhip64|libhsa-runtime64)[^/\s]*)", line)
+                if m:
+                    found[m.group(2)].add(os.path.realpath(m.group(1)))
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in found.items()}
+
+
+class MultipleHipRuntimes(RuntimeError):
+    """Two HIP (or HSA) runtime images are mapped into the process; device work through either is unsafe."""
+
+
+def assert_single_runtime() -> None:
+    """Raise if the process holds more than one HIP or HSA runtime image.  Called wherever device memory crosses to
+    or from another library (DLPack / ``__cuda_array_interface__`` import and export): that is the only way a second
+    runtime can enter a process that loaded this package first with ``KORNIA_HIP_RUNTIME=system``."""
+    rt = mapped_hip_runtimes()
+    dup = {k: v for k, v in rt.items() if len(v) > 1}
+    if dup:
+        raise MultipleHipRuntimes(
+            f"two HIP/HSA runtimes are mapped into this process: {dup}.  Copies and stream waits issued through one do not "
+            "order against the other (observed: host<->device copies incomplete at hipStreamSynchronize).  Import torch "
+            "before kornia_rs, or leave KORNIA_HIP_RUNTIME unset so that kornia_rs binds to torch's bundled runtime.")
+
+
+def _preload_hip_runtime() -> str:
+    """Make sure the process ends up with ONE HIP runtime, whatever the import order.
+
+    ``libkornia_hip.so`` needs ``libamdhip64.so.7`` (RUNPATH /opt/rocm/lib).  torch-ROCm wheels bundle their own copy as
+    ``torch/lib/libamdhip64.so`` (same SONAME) and ``libtorch_hip.so`` asks for it by FILE name — so if this package is
+    loaded first the system runtime is mapped, and a later ``import torch`` maps a second HIP + HSA runtime beside it
+    (verified from /proc/self/maps on CPU and on the GPU box).  Policy (``KORNIA_HIP_RUNTIME``):
+      * unset / ``auto``: a runtime already mapped is used as is; otherwise, if a torch-ROCm wheel is installed, its
+        bundled runtime is loaded first (by path, RTLD_GLOBAL) so that both libraries bind to that one image; otherwise
+        the system runtime.
+      * ``system``: never touch torch's copy (C / Rust hosts, torch-free deployments).
+      * a path: load that ``libamdhip64`` image.
+    Returns a short description of the choice (``hip.runtime_info()``)."""
+    choice = os.environ.get("KORNIA_HIP_RUNTIME", "auto")
+    already = mapped_hip_runtimes()["libamdhip64"]
+    if already:
+        return f"already mapped: {already[0]}"
+    if choice == "system":
+        return "system (KORNIA_HIP_RUNTIME=system)"
+    if choice not in ("", "auto"):
+        C.CDLL(choice, mode=C.RTLD_GLOBAL)
+        return f"explicit: {choice}"
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")  # locates the wheel without importing it
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = Path(spec.origin).resolve().parent / "lib" / "libamdhip64.so"
+        if cand.exists():
+            try:
+                C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+                return f"torch bundle: {cand}"
+            except OSError:
+                pass
+    return "system"
+
+
+RUNTIME_CHOICE = ""
 
 
 def _load() -> C.CDLL:
-    _prefer_shader_copies()
+    global RUNTIME_CHOICE
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} not found — build it with `make -C kornia-rs_amd` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "There is no CPU fallback for the device path."
         )
-    # If torch is already in the process, its bundled libamdhip64.so.7 is the HIP runtime in
-    # use; loading ours afterwards binds to that same runtime (same SONAME).  Importing torch
-    # first keeps one runtime when both are wanted.
+    RUNTIME_CHOICE = _preload_hip_runtime()
     lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly

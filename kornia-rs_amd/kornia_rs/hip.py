@@ -240,6 +240,42 @@ class PinnedBuffer:
             pass
 
 
+class ManagedBuffer:
+    """Managed (unified) memory: ONE allocation dereferenceable from the host and from kernels on any stream of the
+    process (``CudaUnifiedAllocator`` / ``Backing::Managed``, T/cuda.rs:440-511: ``cuMemAllocManaged(ATTACH_GLOBAL)``,
+    zero-filled).  It carries a stream like every device-accessible buffer so residency dispatch can launch on it;
+    ``view()`` is a writable uint8 numpy view of the same bytes.  The host side must not touch the bytes while a kernel
+    that uses them is in flight: ``Tensor.numpy()`` / ``as_slice`` drain the carried stream first.  Freed with
+    ``hipFree`` (which waits for the device) after draining the stream."""
+
+    def __init__(self, nbytes: int, stream: Optional[Stream] = None):
+        self.stream = stream if stream is not None else Stream.default(current_device())
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        prev = current_device()
+        set_device(self.stream.device)
+        try:
+            check(lib.kh_malloc_managed(C.byref(p), max(self.nbytes, 1)))  # the driver rejects a zero-size request (T/cuda.rs:468)
+        finally:
+            set_device(prev)
+        self.ptr = p.value or 0
+
+    def view(self) -> np.ndarray:
+        return np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr))[: self.nbytes]
+
+    def free(self) -> None:
+        p, self.ptr = self.ptr, 0
+        if p:
+            lib.kh_stream_synchronize(self.stream.cuda_stream_ptr)
+            lib.kh_free(p)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class DeviceBuffer:
     """An owned, stream-ordered device allocation (``CudaResource`` with ``Backing::Device`` in
     crates/kornia-tensor/src/cuda.rs:89-169): carries its stream, freed on that stream."""
@@ -292,6 +328,11 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def runtime_info() -> dict:
+    """Which HIP runtime image this process uses and how it was chosen (``_ffi._preload_hip_runtime``)."""
+    return {"choice": _ffi.RUNTIME_CHOICE, **_ffi.mapped_hip_runtimes()}
 
 
 def pointer_domain(ptr: int) -> Tuple[int, int]:

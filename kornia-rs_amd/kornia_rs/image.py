@@ -62,11 +62,25 @@ class Image:
         return Image(Tensor.uninit((height, width, channels), dtype, stream))
 
     @staticmethod
+    def zeros_hip_unified(width: int, height: int, channels: int, dtype: str, stream: Stream) -> "Image":
+        """Zero-filled MANAGED memory carrying ``stream`` (``zeros_cuda_unified``, I/cuda.rs:144-160): host slices and
+        device kernels both work on it; residency dispatch routes it to the device kernels without an upload."""
+        return Image(Tensor.zeros_unified((height, width, channels), dtype, stream))
+
+    zeros_cuda_unified = zeros_hip_unified  # reference spelling
+
+    @staticmethod
+    def zeros_pinned(width: int, height: int, channels: int, dtype: str = "uint8") -> "Image":
+        """A HOST image in page-locked memory (``zeros_pinned``, I/cuda.rs:122-142): uploads from it are direct DMA."""
+        return Image(Tensor.zeros_pinned((height, width, channels), dtype))
+
+    @staticmethod
     def from_dlpack(obj: Any, stream: Optional[Stream] = None) -> "Image":
         t = Tensor.from_dlpack(obj, stream)
         if len(t.shape) == 2:
             t = Tensor(t.shape + (1,), t._dtype, host=None if t.is_device else t._host.reshape(t.shape + (1,)),
-                       device_ptr=t.data_ptr if t.is_device else 0, device=t.device_id, stream=t.stream, keepalive=t)
+                       device_ptr=t.data_ptr if t.is_device else 0, device=t.device_id, stream=t.stream, keepalive=t,
+                       unified=t.is_unified, pinned=t.is_pinned)
         return Image(t)
 
     # -- geometry / type ------------------------------------------------------------------------
@@ -89,6 +103,10 @@ class Image:
     @property
     def is_device(self) -> bool: return self._t.is_device
     @property
+    def domain(self) -> str: return self._t.domain
+    @property
+    def is_unified(self) -> bool: return self._t.is_unified
+    @property
     def device(self) -> str: return self._t.device
     @property
     def device_id(self) -> int: return self._t.device_id
@@ -105,6 +123,14 @@ class Image:
 
     to_cuda = to_hip  # reference spelling (kornia_rs/image.pyi:199)
 
+    def to_hip_unified(self, stream: Stream) -> "Image":
+        """Copy this HOST image into a new managed-memory image carrying ``stream`` (``to_cuda_unified``, I/cuda.rs:62-75)."""
+        if self.is_device:
+            raise ImageError("UnsupportedDevice", "to_hip_unified: the image is not host-resident")
+        return Image(self._t.to_hip_unified(stream), self.color_space)
+
+    to_cuda_unified = to_hip_unified
+
     def cpu(self, stream: Optional[Stream] = None) -> "Image":
         if self.is_device:
             return Image(self._t.cpu(), self.color_space)
@@ -113,13 +139,13 @@ class Image:
     def numpy(self) -> np.ndarray:
         """Host: zero-copy view.  Device: D2H copy, returned read-only (image.pyi:179-184)."""
         a = self._t.numpy_raw()
-        if self.is_device:
+        if self.is_device and not self.is_unified:  # a managed image IS its host view: writable, like as_slice_mut
             a.flags.writeable = False
         return a
 
     def as_slice(self) -> np.ndarray:
         """Host access only — like ``TensorStorage::as_slice`` it refuses device memory (T/storage.rs:102-110)."""
-        if self.is_device:
+        if not self._t.is_host_accessible:
             raise ImageError("UnsupportedDevice", "host access to device-resident image data; call .cpu() first")
         return self._t.numpy_raw().reshape(-1)
 

@@ -41,24 +41,51 @@ def _check(rc: int) -> None:
     raise ImageError(kind, msg)
 
 
-def _pair_residency(src: Image, dst: Image) -> Stream:
-    """Host/Device/Mixed classification + same-device check + cross-stream fence.  Returns the
-    stream to launch on (the source image's)."""
-    if src.is_device != dst.is_device:
-        raise ImageError("MixedResidency", "source and destination images must both be on the host or both on the "
-                                           "device; there is no implicit transfer")
+class _DeviceExec(Stream):
+    """``DeviceExec`` (P/cuda/dispatch.rs:28-82): the stream a device op launches on — the source image's — plus the other
+    streams its operands carry.  ``for_streams`` fences those INTO the launch stream before the launch; ``check`` is the
+    reference's ``run``: it takes the status of the launch that has just been enqueued and then fences the launch stream
+    BACK into every other stream, so a destination's own stream (its ``numpy()``, the next op that reads it, its
+    stream-ordered free) is ordered after the kernel that writes it.  Same-stream operands cost nothing."""
+
+    def __init__(self, launch: Stream, others: Sequence[Stream] = ()):
+        super().__init__(launch.cuda_stream_ptr, launch.device, owned=False)
+        self._launch = launch  # keeps an owned stream alive for as long as the exec
+        self._others = []
+        for o in others:
+            self.join(o)
+
+    def join(self, other: Optional[Stream]) -> None:
+        """Order ``other``'s queued work before the launch, and remember it for the fence back."""
+        if other is None or other.cuda_stream_ptr == self.cuda_stream_ptr:
+            return
+        if all(o.cuda_stream_ptr != other.cuda_stream_ptr for o in self._others):
+            _check(lib.kh_stream_fence(other.cuda_stream_ptr, self.cuda_stream_ptr))
+            self._others.append(other)
+
+    def check(self, rc: int) -> None:
+        _check(rc)
+        for o in self._others:
+            _check(lib.kh_stream_fence(self.cuda_stream_ptr, o.cuda_stream_ptr))
+
+
+def _pair_residency(src: Image, *dsts: Image) -> _DeviceExec:
+    """Host/Device/Mixed classification + same-device check + cross-stream fences (pair_residency, P/cuda/dispatch.rs:105-133).
+    Returns the ``_DeviceExec`` to launch on: ``exec.check(lib.kh_...(exec.cuda_stream_ptr, ...))``."""
+    for dst in dsts:
+        if src.is_device != dst.is_device:
+            raise ImageError("MixedResidency", "source and destination images must both be on the host or both on the "
+                                               "device; there is no implicit transfer")
     if not src.is_device:
         raise ImageError("HostPathUnavailable", "host images: this build provides the HIP device backend only — move "
                                                 "the image with .to_hip(stream) (the CPU path lives in the reference crate)")
-    if src.device_id != dst.device_id:
-        raise ImageError("DeviceMismatch", f"images live on different devices ({src.device} vs {dst.device})")
-    s_src, s_dst = src.stream, dst.stream
-    if s_src is None or s_dst is None:
+    for dst in dsts:
+        if src.device_id != dst.device_id:
+            raise ImageError("DeviceMismatch", f"images live on different devices ({src.device} vs {dst.device})")
+    if src.stream is None or any(dst.stream is None for dst in dsts):
         raise ImageError("UnsupportedDevice", "device image without a stream (untyped foreign memory); re-wrap it "
                                               "with Image.from_dlpack(obj, stream=...)")
-    if s_src.cuda_stream_ptr != s_dst.cuda_stream_ptr:
-        _check(lib.kh_stream_fence(s_dst.cuda_stream_ptr, s_src.cuda_stream_ptr))
-    return s_src
+    return _DeviceExec(src.stream, [dst.stream for dst in dsts])
 
 
 def _require(img: Image, dtype: str, channels: Tuple[int, ...], what: str) -> None:
@@ -90,8 +117,8 @@ def _map_f64(code_name: str, src: Image, dst: Optional[Image], cin: int, cout: i
     _require(out, "float64", (cout,), code_name)
     _same_size(src, out)
     stream = _pair_residency(src, out)
-    _check(lib.kh_color_convert_f64(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height,
-                                    _ffi.KH_F64[code_name]))
+    stream.check(lib.kh_color_convert_f64(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height,
+                                          _ffi.KH_F64[code_name]))
     return out
 
 
@@ -108,7 +135,7 @@ def _map(name: str, src: Image, dst: Optional[Image], cin: int, cout: int, dtype
     stream = _pair_residency(src, out)
     suffix = {"uint8": "u8", "float32": "f32"}[src.dtype]
     fn = getattr(lib, f"kh_{name}_{suffix}")
-    _check(fn(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height, *extra))
+    stream.check(fn(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height, *extra))
     return out
 
 
@@ -231,7 +258,8 @@ def _decode(kind: str, layout: int, data, width: int, height: int, dst: Optional
     _require(out, "uint8", (3,), f"rgb_from_{kind}")
     if out.size != (width, height):
         raise ImageError("InvalidImageSize", f"destination is {out.width}x{out.height}, expected {width}x{height}")
-    _check(getattr(lib, f"kh_rgb_from_{kind}_u8")(st.cuda_stream_ptr, ptr, out.data_ptr, width, height, layout))
+    ex = _DeviceExec(st, [out.stream])  # device_exec_for (P/cuda/dispatch.rs:150-162): raw source stream + destination image
+    ex.check(getattr(lib, f"kh_rgb_from_{kind}_u8")(ex.cuda_stream_ptr, ptr, out.data_ptr, width, height, layout))
     return out
 
 
@@ -267,7 +295,7 @@ def rgb_from_bayer(src, pattern: Optional[str] = None, dst: Optional[Image] = No
     _require(out, "uint8", (3,), "rgb_from_bayer")
     _same_size(src, out)
     stream = _pair_residency(src, out)
-    _check(lib.kh_rgb_from_bayer_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, code))
+    stream.check(lib.kh_rgb_from_bayer_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, code))
     return out
 
 
@@ -283,7 +311,8 @@ def convert_yuyv_to_rgb_u8(data, width: int, height: int, mode: str = "bt601_lim
     _require(out, "uint8", (3,), "convert_yuyv_to_rgb_u8")
     if out.size != (width, height):
         raise ImageError("InvalidImageSize", f"destination is {out.width}x{out.height}, expected {width}x{height}")
-    _check(lib.kh_yuyv_to_rgb_mode_u8(st.cuda_stream_ptr, ptr, out.data_ptr, width, height, code))
+    ex = _DeviceExec(st, [out.stream])
+    ex.check(lib.kh_yuyv_to_rgb_mode_u8(ex.cuda_stream_ptr, ptr, out.data_ptr, width, height, code))
     return out
 
 
@@ -339,8 +368,8 @@ def resize(src: Image, new_size: Optional[Tuple[int, int]] = None, interpolation
         return resize_fast(src, new_size, interpolation, bool(antialias), out)
     mode = _interp(interpolation)
     dst, stream = _geom_pair(src, out, new_size, "resize")
-    _check(lib.kh_resize_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
-                             dst.height, src.channels, mode, 1, 0, 0))
+    stream.check(lib.kh_resize_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
+                                   dst.height, src.channels, mode, 1, 0, 0))
     return dst
 
 
@@ -357,8 +386,8 @@ def resize_mapped(src: Image, new_size: Tuple[int, int], interpolation: str = "b
     ``half_pixel`` is what ``resize`` does; ``align_corners`` maps ``src = dst * (src_len-1)/(dst_len-1)``."""
     mode = _interp(interpolation)
     dst, stream = _geom_pair(src, out, new_size, "resize")
-    _check(lib.kh_resize_mapped_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
-                                    dst.height, src.channels, mode, _mapping(mapping), 1, 0, 0))
+    stream.check(lib.kh_resize_mapped_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
+                                          dst.height, src.channels, mode, _mapping(mapping), 1, 0, 0))
     return dst
 
 
@@ -369,8 +398,8 @@ def resize_bilinear_normalize(src: Image, new_size: Tuple[int, int], mean: Seque
     _require(src, "float32", (3,), "resize_bilinear_normalize")
     dst, stream = _geom_pair(src, out, new_size, "resize_bilinear_normalize")
     m, s_ = _matrix(mean, 3, "resize_bilinear_normalize"), _matrix(std, 3, "resize_bilinear_normalize")
-    _check(lib.kh_resize_bilinear_normalize_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height,
-                                                dst.width, dst.height, m, s_, _mapping(mapping), 1, 0, 0))
+    stream.check(lib.kh_resize_bilinear_normalize_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height,
+                                                      dst.width, dst.height, m, s_, _mapping(mapping), 1, 0, 0))
     return dst
 
 
@@ -396,8 +425,8 @@ def resize_fast(src: Image, new_size: Optional[Tuple[int, int]] = None, interpol
         raise ImageError("UnsupportedChannelCount", "resize_fast: 2-channel images support nearest only")
     if mode == _ffi.KH_INTERP_BILINEAR and (src.width < 2 or src.height < 2):
         raise ImageError("InvalidImageSize", f"resize_fast: bilinear needs a source of at least 2x2, got {src.width}x{src.height}")
-    _check(lib.kh_resize_fast_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, out.width,
-                                 out.height, src.channels, mode, int(bool(antialias)), 1, 0, 0))
+    stream.check(lib.kh_resize_fast_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, out.width,
+                                       out.height, src.channels, mode, int(bool(antialias)), 1, 0, 0))
     return out
 
 
@@ -426,8 +455,9 @@ def resize_normalize_to_tensor(src: Image, width: int, height: int, mean: Sequen
         out = Tensor.uninit((3, height, width), "float32", src.stream)
     elif tuple(out.shape) != (3, height, width) or out.dtype != "float32" or not out.is_device:
         raise ImageError("InvalidChannelShape", f"out must be a device float32 tensor of shape (3, {height}, {width})")
-    _check(lib.kh_resize_normalize_to_chw_u8_f32(
-        src.stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, width, height,
+    ex = _DeviceExec(src.stream, [out.stream])
+    ex.check(lib.kh_resize_normalize_to_chw_u8_f32(
+        ex.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, width, height,
         scale.ctypes.data_as(C.POINTER(C.c_float)), bias.ctypes.data_as(C.POINTER(C.c_float)), mode, int(bool(antialias)),
         1, 0, 0))
     return out
@@ -449,8 +479,8 @@ def resize_opencv(src: Image, new_size: Optional[Tuple[int, int]] = None, interp
     _require(out, src.dtype, (src.channels,), "resize_opencv")
     stream = _pair_residency(src, out)
     fn = lib.kh_resize_opencv_u8 if src.dtype == "uint8" else lib.kh_resize_opencv_f32
-    _check(fn(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, out.width, out.height,
-              src.channels, mode, 1, 0, 0))
+    stream.check(fn(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, out.width, out.height,
+                    src.channels, mode, 1, 0, 0))
     return out
 
 
@@ -459,13 +489,13 @@ def warp_affine(src: Image, m: Sequence[float], new_size: Optional[Tuple[int, in
     if src.dtype == "uint8":  # warp_affine_u8, P/warp/affine.rs:373
         _u8_bilinear_only(interpolation, "warp_affine")
         dst, stream = _geom_pair(src, out, new_size, "warp_affine_u8", "uint8")
-        _check(lib.kh_warp_affine_u8(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
-                                     dst.height, src.channels, _matrix(m, 6, "warp_affine"), 1, 0, 0))
+        stream.check(lib.kh_warp_affine_u8(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
+                                           dst.height, src.channels, _matrix(m, 6, "warp_affine"), 1, 0, 0))
         return dst
     mode = _interp(interpolation)
     dst, stream = _geom_pair(src, out, new_size, "warp_affine")
-    _check(lib.kh_warp_affine_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
-                                  dst.height, src.channels, _matrix(m, 6, "warp_affine"), mode, 1, 0, 0))
+    stream.check(lib.kh_warp_affine_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height, dst.width,
+                                        dst.height, src.channels, _matrix(m, 6, "warp_affine"), mode, 1, 0, 0))
     return dst
 
 
@@ -478,12 +508,12 @@ def warp_perspective(src: Image, m: Sequence[float], new_size: Optional[Tuple[in
     if src.dtype == "uint8":  # warp_perspective_u8, P/warp/perspective.rs:179
         _u8_bilinear_only(interpolation, "warp_perspective")
         dst, stream = _geom_pair(src, out, new_size, "warp_perspective_u8", "uint8")
-        _check(lib.kh_warp_perspective_u8(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height,
-                                          dst.width, dst.height, src.channels, mm, 1, 0, 0))
+        stream.check(lib.kh_warp_perspective_u8(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height,
+                                                dst.width, dst.height, src.channels, mm, 1, 0, 0))
         return dst
     dst, stream = _geom_pair(src, out, new_size, "warp_perspective")
-    _check(lib.kh_warp_perspective_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height,
-                                       dst.width, dst.height, src.channels, mm, mode, 1, 0, 0))
+    stream.check(lib.kh_warp_perspective_f32(stream.cuda_stream_ptr, src.data_ptr, dst.data_ptr, src.width, src.height,
+                                             dst.width, dst.height, src.channels, mm, mode, 1, 0, 0))
     return dst
 
 
@@ -502,12 +532,11 @@ def remap(src: Image, map_x: Image, map_y: Image, interpolation: str = "bilinear
         raise ImageError("InvalidImageSize", "dst must have the size of the maps")
     if not (map_x.is_device and map_y.is_device):
         raise ImageError("Hip", "remap: map_x and map_y must be device-resident when src/dst are on GPU")
-    for mp in (map_x, map_y):
-        if mp.stream is not None and mp.stream.cuda_stream_ptr != stream.cuda_stream_ptr:
-            _check(lib.kh_stream_fence(mp.stream.cuda_stream_ptr, stream.cuda_stream_ptr))
+    for mp in (map_x, map_y):  # inputs on their own streams: fenced in, and fenced back so a later rewrite of a map waits for this read
+        stream.join(mp.stream)
     fn = lib.kh_remap_u8 if u8 else lib.kh_remap_f32
-    _check(fn(stream.cuda_stream_ptr, src.data_ptr, map_x.data_ptr, map_y.data_ptr, dst.data_ptr,
-              src.width, src.height, dst.width, dst.height, src.channels, mode, 1, 0, 0))
+    stream.check(fn(stream.cuda_stream_ptr, src.data_ptr, map_x.data_ptr, map_y.data_ptr, dst.data_ptr,
+                    src.width, src.height, dst.width, dst.height, src.channels, mode, 1, 0, 0))
     return dst
 
 
@@ -551,12 +580,12 @@ def gaussian_blur(src: Image, kernel_size: Tuple[int, int], sigma: Tuple[float, 
         raise ImageError("InvalidSigmaValue", _ffi.last_error())
     if src.dtype == "uint8":  # gaussian_blur_u8, P/filter/ops.rs:639
         out, stream = _filter_pair(src, dst, "gaussian_blur_u8", "uint8")
-        _check(lib.kh_gaussian_blur_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
-                                       src.channels, kernel_size[0], kernel_size[1], sigma[0], sigma[1], 1, 0, 0))
+        stream.check(lib.kh_gaussian_blur_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
+                                             src.channels, kernel_size[0], kernel_size[1], sigma[0], sigma[1], 1, 0, 0))
         return out
     out, stream = _filter_pair(src, dst, "gaussian_blur")
-    _check(lib.kh_gaussian_blur_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
-                                    src.channels, kernel_size[0], kernel_size[1], sigma[0], sigma[1], 1, 0, 0))
+    stream.check(lib.kh_gaussian_blur_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
+                                          src.channels, kernel_size[0], kernel_size[1], sigma[0], sigma[1], 1, 0, 0))
     return out
 
 
@@ -565,12 +594,12 @@ def box_blur(src: Image, kernel_size: Tuple[int, int], dst: Optional[Image] = No
         if not all(int(k) > 0 and int(k) % 2 == 1 for k in kernel_size):
             raise ImageError("InvalidKernelLength", f"box_blur: invalid kernel length {tuple(kernel_size)} (u8 needs odd sizes)")
         out, stream = _filter_pair(src, dst, "box_blur_u8", "uint8")
-        _check(lib.kh_box_blur_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels,
-                                  kernel_size[0], kernel_size[1], 1, 0, 0))
+        stream.check(lib.kh_box_blur_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels,
+                                        kernel_size[0], kernel_size[1], 1, 0, 0))
         return out
     out, stream = _filter_pair(src, dst, "box_blur")
-    _check(lib.kh_box_blur_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels,
-                               kernel_size[0], kernel_size[1], 1, 0, 0))
+    stream.check(lib.kh_box_blur_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels,
+                                     kernel_size[0], kernel_size[1], 1, 0, 0))
     return out
 
 
@@ -579,8 +608,8 @@ def _gradient(src: Image, kind: int, kernel_size: int, dst: Optional[Image], wha
     if not ok:
         raise ImageError("InvalidKernelLength", f"{what}: invalid kernel length ({kernel_size}, {kernel_size})")
     out, stream = _filter_pair(src, dst, what)
-    _check(lib.kh_gradient_magnitude_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
-                                         src.channels, kind, kernel_size, 1, 0, 0))
+    stream.check(lib.kh_gradient_magnitude_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
+                                               src.channels, kind, kernel_size, 1, 0, 0))
     return out
 
 
@@ -595,9 +624,9 @@ def scharr(src: Image, kernel_size: int = 3, dst: Optional[Image] = None) -> Ima
 def separable_filter(src: Image, kernel_x: Sequence[float], kernel_y: Sequence[float], dst: Optional[Image] = None) -> Image:
     kx, ky = np.asarray(kernel_x, np.float32), np.asarray(kernel_y, np.float32)
     out, stream = _filter_pair(src, dst, "separable_filter")
-    _check(lib.kh_separable_filter_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
-                                       src.channels, (C.c_float * kx.size)(*kx), kx.size, (C.c_float * ky.size)(*ky),
-                                       ky.size, 1, 0, 0))
+    stream.check(lib.kh_separable_filter_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height,
+                                             src.channels, (C.c_float * kx.size)(*kx), kx.size, (C.c_float * ky.size)(*ky),
+                                             ky.size, 1, 0, 0))
     return out
 
 
@@ -608,10 +637,9 @@ def _spatial_gradient(src: Image, kind: int, dx: Optional[Image], dy: Optional[I
     for g in (gx, gy):
         _require(g, "float32", (src.channels,), what)
         _same_size(src, g)
-    stream = _pair_residency(src, gx)
-    _pair_residency(src, gy)
-    _check(lib.kh_spatial_gradient_f32(stream.cuda_stream_ptr, src.data_ptr, gx.data_ptr, gy.data_ptr, src.width, src.height,
-                                       src.channels, kind, 1, 0, 0))
+    stream = _pair_residency(src, gx, gy)
+    stream.check(lib.kh_spatial_gradient_f32(stream.cuda_stream_ptr, src.data_ptr, gx.data_ptr, gy.data_ptr, src.width, src.height,
+                                             src.channels, kind, 1, 0, 0))
     return gx, gy
 
 
@@ -637,8 +665,8 @@ def box_blur_fast(src: Image, sigma: Tuple[float, float], dst: Optional[Image] =
     The transposed intermediate is a stream-ordered scratch image, released on the stream after the last pass."""
     out, stream = _filter_pair(src, dst, "box_blur_fast")
     scratch = _new_like(src)
-    _check(lib.kh_box_blur_fast_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, scratch.data_ptr, src.width, src.height,
-                                    src.channels, sigma[0], sigma[1], 1, 0, 0))
+    stream.check(lib.kh_box_blur_fast_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, scratch.data_ptr, src.width, src.height,
+                                          src.channels, sigma[0], sigma[1], 1, 0, 0))
     return out
 
 
@@ -652,8 +680,8 @@ def median_blur(image: Image, kernel_size: int = 3, dst: Optional[Image] = None)
     _require(out, "uint8", (image.channels,), "median_blur")
     _same_size(image, out)
     stream = _pair_residency(image, out)
-    _check(lib.kh_median_blur_u8(stream.cuda_stream_ptr, image.data_ptr, out.data_ptr, image.width, image.height, image.channels,
-                                 kernel_size, 1, 0, 0))
+    stream.check(lib.kh_median_blur_u8(stream.cuda_stream_ptr, image.data_ptr, out.data_ptr, image.width, image.height, image.channels,
+                                       kernel_size, 1, 0, 0))
     return out
 
 
@@ -665,8 +693,8 @@ def bilateral_filter(image: Image, d: int = 5, sigma_color: float = 50.0, sigma_
     _require(out, "uint8", (1,), "bilateral_filter")
     _same_size(image, out)
     stream = _pair_residency(image, out)
-    _check(lib.kh_bilateral_filter_u8(stream.cuda_stream_ptr, image.data_ptr, out.data_ptr, image.width, image.height, int(d),
-                                      float(sigma_color), float(sigma_space), 1, 0, 0))
+    stream.check(lib.kh_bilateral_filter_u8(stream.cuda_stream_ptr, image.data_ptr, out.data_ptr, image.width, image.height, int(d),
+                                            float(sigma_color), float(sigma_space), 1, 0, 0))
     return out
 
 
@@ -692,8 +720,8 @@ def normalize_mean_std(src: Image, mean: Sequence[float], std: Sequence[float], 
     _require(out, "float32", (src.channels,), "normalize_mean_std")
     _same_size(src, out)
     stream = _pair_residency(src, out)
-    _check(lib.kh_normalize_mean_std_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height,
-                                         src.channels, (C.c_float * src.channels)(*mean), (C.c_float * src.channels)(*std)))
+    stream.check(lib.kh_normalize_mean_std_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height,
+                                               src.channels, (C.c_float * src.channels)(*mean), (C.c_float * src.channels)(*std)))
     return out
 
 
@@ -704,8 +732,8 @@ def normalize_rgb_u8(src: Image, scale: Sequence[float], offset: Sequence[float]
     _require(out, "float32", (3,), "normalize_rgb_u8")
     _same_size(src, out)
     stream = _pair_residency(src, out)
-    _check(lib.kh_normalize_rgb_u8_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height,
-                                       _matrix(scale, 3, "normalize_rgb_u8"), _matrix(offset, 3, "normalize_rgb_u8")))
+    stream.check(lib.kh_normalize_rgb_u8_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height,
+                                             _matrix(scale, 3, "normalize_rgb_u8"), _matrix(offset, 3, "normalize_rgb_u8")))
     return out
 
 
@@ -732,8 +760,8 @@ def normalize_min_max(src: Image, min: float, max: float, dst: Optional[Image] =
     if n == 0:
         raise ImageError("ImageDataNotInitialized", "image data is not initialized")
     mm, scratch = Tensor.uninit((2,), "float32", stream), Tensor.uninit((2,), "int32", stream)
-    _check(lib.kh_normalize_min_max_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, n, min, max, mm.data_ptr,
-                                        scratch.data_ptr))
+    stream.check(lib.kh_normalize_min_max_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, n, min, max, mm.data_ptr,
+                                              scratch.data_ptr))
     out._scratch_keepalive = (mm, scratch)
     return out
 
@@ -747,7 +775,7 @@ def crop_image(src: Image, x: int, y: int, width: int, height: int, dst: Optiona
                                                   f"{src.width}x{src.height}")
     stream = _pair_residency(src, out)
     pb = src.channels * np.dtype(src.dtype).itemsize
-    _check(lib.kh_crop(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, width, height, x, y, pb))
+    stream.check(lib.kh_crop(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, width, height, x, y, pb))
     return out
 
 
@@ -758,7 +786,7 @@ def _flip(src: Image, dst: Optional[Image], horizontal: int) -> Image:
     _same_size(src, out)
     stream = _pair_residency(src, out)
     pb = src.channels * np.dtype(src.dtype).itemsize
-    _check(lib.kh_flip(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, pb, horizontal))
+    stream.check(lib.kh_flip(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, pb, horizontal))
     return out
 
 
@@ -801,7 +829,7 @@ def _pyr(src: Image, dst: Optional[Image], up: bool, what: str) -> Image:
         raise ImageError("InvalidImageSize", f"{what}: expected a {w}x{h} destination, got {out.width}x{out.height}")
     stream = _pair_residency(src, out)
     fn = getattr(lib, f"kh_{'pyrup' if up else 'pyrdown'}_{'f32' if src.dtype == 'float32' else 'u8'}")
-    _check(fn(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels, 1, 0, 0))
+    stream.check(fn(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels, 1, 0, 0))
     return out
 
 
@@ -862,9 +890,9 @@ def _morph(src: Image, kernel: Kernel, op: int, padding_mode: str, constant_valu
     cv[: src.channels] = np.broadcast_to(vals, (src.channels,)) if vals.size == 1 else vals[: src.channels]
     stream = _pair_residency(src, out)
     mask = np.ascontiguousarray(kernel.data, np.uint8)
-    _check(lib.kh_morphology_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels, op,
-                                mask.ctypes.data_as(C.POINTER(C.c_uint8)), kernel.width, kernel.height, border,
-                                cv.ctypes.data_as(C.POINTER(C.c_uint8)), 1, 0, 0))
+    stream.check(lib.kh_morphology_u8(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width, src.height, src.channels, op,
+                                      mask.ctypes.data_as(C.POINTER(C.c_uint8)), kernel.width, kernel.height, border,
+                                      cv.ctypes.data_as(C.POINTER(C.c_uint8)), 1, 0, 0))
     return out
 
 
@@ -919,7 +947,7 @@ def _cie(name: str):
         _require(out, "float32", (3,), name)
         _same_size(src, out)
         stream = _pair_residency(src, out)
-        _check(lib.kh_cie_convert_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height, code))
+        stream.check(lib.kh_cie_convert_f32(stream.cuda_stream_ptr, src.data_ptr, out.data_ptr, src.width * src.height, code))
         return out
 
     conv.__name__ = name

@@ -273,6 +273,9 @@ class Preprocessor:
         self.pad_value = f32(pad_value)
         self.stream = stream
         self._staging = _Staging()
+        # what a per-device replica is built from (ShardedPreprocessor; kernel parameters are replicated)
+        self._config = dict(mode=mode, format=format, sampling=sampling, f16=bool(f16), mean=mean, std=std, pad_value=pad_value)
+        self._sharders: dict = {}
 
     # -- helpers ------------------------------------------------------------------------------
     def _params(self, sw: int, sh: int, pitch: int, bpp: int, fmt_code: int, dw: int, dh: int,
@@ -328,11 +331,15 @@ class Preprocessor:
                 format=f.name, width=w, height=h, got=got, need=need)
 
     def _launch(self, src_ptr: int, dst: Tensor, p: PreprocessParams) -> None:
-        # Launch on the preprocessor's stream; if dst was produced on another stream, fence it
-        # in first (DeviceExec::for_streams, P/cuda/dispatch.rs:50-67).
-        if dst.stream is not None and dst.stream.cuda_stream_ptr != self.stream.cuda_stream_ptr:
+        # Launch on the preprocessor's stream.  If dst carries another stream it is fenced in before the launch and the
+        # launch stream is fenced back into it afterwards (DeviceExec::for_streams + run, P/cuda/dispatch.rs:50-82), so
+        # dst's own stream — its numpy(), the next op that reads it, its stream-ordered free — is ordered after the kernel.
+        other = dst.stream is not None and dst.stream.cuda_stream_ptr != self.stream.cuda_stream_ptr
+        if other:
             check(lib.kh_stream_fence(dst.stream.cuda_stream_ptr, self.stream.cuda_stream_ptr))
         check(lib.kh_preprocess_to_chw(self.stream.cuda_stream_ptr, src_ptr, dst.data_ptr, C.byref(p)))
+        if other:
+            check(lib.kh_stream_fence(self.stream.cuda_stream_ptr, dst.stream.cuda_stream_ptr))
 
     # -- Rust-shaped entry points ---------------------------------------------------------------
     def run_raw(self, src: RawSource, src_w: int, src_h: int, dst: Tensor, *,
@@ -347,15 +354,40 @@ class Preprocessor:
                          1, 0, want_f16, _force_generic)
         self._launch(ptr, dst, p)
 
+    def sharded(self, devices: Sequence[int]):
+        """This configuration replicated over ``devices`` — one stream, one worker thread and one ``Preprocessor`` per
+        ordinal (``kornia_rs.sharding.ShardedPreprocessor``; cached per device list)."""
+        from .sharding import ShardedPreprocessor
+        key = tuple(int(d) for d in devices)
+        if key not in self._sharders:
+            self._sharders[key] = ShardedPreprocessor(key, **self._config)
+        return self._sharders[key]
+
     def run_raw_batch(self, frames: Union[Sequence[RawSource], RawSource], src_w: int, src_h: int,
-                      dst: Tensor, *, frame_stride: Optional[int] = None,
-                      _force_generic: bool = False) -> None:
+                      dst: Any, *, frame_stride: Optional[int] = None, devices: Optional[Sequence[int]] = None,
+                      _force_generic: bool = False) -> Any:
         """``N`` same-sized raw frames -> ``[N, 3, H, W]`` (P/preprocess.rs:1234-1282).
 
         ``frames`` is either a sequence of per-frame device buffers (the reference signature) or
         ONE device buffer holding ``N`` frames ``frame_stride`` bytes apart.  Equally-spaced
         frames go out as a single batched launch; otherwise one launch per frame, like the
-        reference."""
+        reference.
+
+        ``devices=[g0, g1, ...]`` shards the batch across GPUs in this process (contiguous slices, one
+        host thread + one stream per device, no collective): ``frames`` is then a host ``[N, frame_bytes]`` uint8 array /
+        list of host frames, or one ``(device_buffer, n_frames)`` pair per device; ``dst`` is a list with one
+        ``[n_g, 3, H, W]`` tensor per device, or an ``(out_height, out_width)`` pair to have them allocated.  Returns a
+        ``sharding.ShardedBatch``."""
+        if devices is not None:
+            sp = self.sharded(devices)
+            if isinstance(dst, (tuple, list)) and len(dst) == 2 and all(isinstance(v, int) for v in dst):
+                return sp.run_raw_batch(frames, src_w, src_h, dst[0], dst[1], frame_stride=frame_stride)
+            outs = list(dst)
+            if not outs or len(outs) != sp.world:
+                raise PreprocessError("BatchMismatch", f"devices={list(devices)} needs one destination tensor per device, got {len(outs)}",
+                                      dst_n=len(outs), frames=sp.world)
+            first = next(t for t in outs if t is not None)
+            return sp.run_raw_batch(frames, src_w, src_h, first.shape[2], first.shape[3], frame_stride=frame_stride, out=outs)
         f = self.source_format
         need = f.buffer_len(src_w, src_h)
         if frame_stride is not None:

@@ -15,7 +15,22 @@ from typing import Any, Optional, Sequence, Tuple
 import numpy as np
 
 from . import hip
-from .hip import DeviceBuffer, Stream
+from .hip import DeviceBuffer, ManagedBuffer, PinnedBuffer, Stream
+
+
+class MemoryDomain:
+    """Where a buffer can be legally dereferenced (``MemoryDomain``, T/resource.rs:19-60): ``HOST``, ``DEVICE`` or
+    ``UNIFIED`` (managed memory: host AND device accessible)."""
+
+    HOST, DEVICE, UNIFIED = "host", "device", "unified"
+
+    @staticmethod
+    def is_host_accessible(domain: str) -> bool:
+        return domain in (MemoryDomain.HOST, MemoryDomain.UNIFIED)
+
+    @staticmethod
+    def is_device_accessible(domain: str) -> bool:
+        return domain in (MemoryDomain.DEVICE, MemoryDomain.UNIFIED)
 
 _DTYPES = {
     "uint8": np.uint8, "uint16": np.uint16, "int32": np.int32, "int64": np.int64,
@@ -36,15 +51,29 @@ class Tensor:
 
     def __init__(self, shape: Sequence[int], dtype, *, host: Optional[np.ndarray] = None,
                  device_buf: Optional[DeviceBuffer] = None, device_ptr: int = 0,
-                 device: int = 0, stream: Optional[Stream] = None, keepalive: Any = None):
+                 device: int = 0, stream: Optional[Stream] = None, keepalive: Any = None,
+                 managed_buf: Optional[ManagedBuffer] = None, unified: bool = False, pinned: bool = False):
         self._shape = tuple(int(s) for s in shape)
         self._dtype = _np_dtype(dtype)
-        self._host = host
-        self._buf = device_buf
-        self._ptr = device_buf.ptr if device_buf is not None else int(device_ptr)
-        self._device = device_buf.stream.device if device_buf is not None else int(device)
-        self._stream = device_buf.stream if device_buf is not None else stream
+        self._buf = device_buf if device_buf is not None else managed_buf
+        self._ptr = self._buf.ptr if self._buf is not None else int(device_ptr)
+        self._device = self._buf.stream.device if self._buf is not None else int(device)
+        self._stream = self._buf.stream if self._buf is not None else stream
         self._keepalive = keepalive  # foreign memory owner (Backing::Foreign, cuda.rs:139-169)
+        self._pinned = bool(pinned)  # host domain, page-locked (zeros_pinned): exported as kDLROCMHost
+        if managed_buf is not None or unified:
+            # Unified: the SAME bytes seen from the host (a numpy view) and from kernels (the pointer).
+            self._domain = MemoryDomain.UNIFIED
+            n = int(np.prod(self._shape, dtype=np.int64))
+            if host is None:
+                raw = (C.c_uint8 * max(n * self._dtype.itemsize, 1)).from_address(self._ptr)
+                host = np.frombuffer(raw, dtype=self._dtype, count=n).reshape(self._shape)
+            self._host = None
+            self._uview = host
+        else:
+            self._domain = MemoryDomain.HOST if host is not None else MemoryDomain.DEVICE
+            self._host = host
+            self._uview = None
         if host is not None:
             assert host.flags["C_CONTIGUOUS"] and tuple(host.shape) == self._shape
 
@@ -68,6 +97,27 @@ class Tensor:
         return Tensor(shape, dt, device_buf=DeviceBuffer(n, stream, zeroed=False))
 
     @staticmethod
+    def zeros_unified(shape: Sequence[int], dtype, stream: Stream) -> "Tensor":
+        """Zero-filled managed memory carrying ``stream`` (``zeros_cuda_unified``, T/cuda.rs:513-560): host slices AND
+        device kernels work on it without a copy; dispatch treats it as device-resident (P/cuda/dispatch.rs:90-96)."""
+        dt = _np_dtype(dtype)
+        n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        return Tensor(shape, dt, managed_buf=ManagedBuffer(n, stream))
+
+    zeros_hip_unified = zeros_unified
+    zeros_cuda_unified = zeros_unified  # reference spelling
+
+    @staticmethod
+    def zeros_pinned(shape: Sequence[int], dtype="uint8") -> "Tensor":
+        """A HOST tensor in page-locked memory (``zeros_pinned``, T/cuda.rs:382-410): an ordinary host tensor for every
+        host path, but copies against it are direct, stream-ordered DMA.  Allocate once and reuse."""
+        dt = _np_dtype(dtype)
+        n = int(np.prod(shape, dtype=np.int64))
+        pin = PinnedBuffer(n * dt.itemsize)
+        host = pin.view().view(dt)[:n].reshape(tuple(int(s) for s in shape)) if n else np.zeros(shape, dt)
+        return Tensor(shape, dt, host=host, keepalive=pin, pinned=True)
+
+    @staticmethod
     def from_numpy(a: np.ndarray) -> "Tensor":
         a = np.ascontiguousarray(a)
         return Tensor(a.shape, a.dtype, host=a)
@@ -82,14 +132,32 @@ class Tensor:
         return self._dtype.name
 
     @property
+    def domain(self) -> str:
+        """``MemoryDomain.HOST`` / ``DEVICE`` / ``UNIFIED`` (TensorStorage::domain, T/storage.rs:86-100)."""
+        return self._domain
+
+    @property
     def is_device(self) -> bool:
-        return self._host is None
+        """Device- OR unified-resident: what residency dispatch asks (``is_device``, P/cuda/dispatch.rs:90-96)."""
+        return self._domain != MemoryDomain.HOST
+
+    @property
+    def is_unified(self) -> bool:
+        return self._domain == MemoryDomain.UNIFIED
+
+    @property
+    def is_host_accessible(self) -> bool:
+        return MemoryDomain.is_host_accessible(self._domain)
+
+    @property
+    def is_pinned(self) -> bool:
+        return self._pinned
 
     @property
     def device(self) -> str:
         # torch-ROCm names HIP devices "cuda:N"; keep that spelling so `torch.device(t.device)`
         # and reference user code keep working.
-        return "cpu" if self._host is not None else f"cuda:{self._device}"
+        return "cpu" if self._domain == MemoryDomain.HOST else f"cuda:{self._device}"
 
     @property
     def device_id(self) -> int:
@@ -134,12 +202,28 @@ class Tensor:
         return out.astype(np.float32) if self._dtype == np.float16 else out
 
     def numpy_raw(self) -> np.ndarray:
-        """Like numpy() but never widens (binary16 stays binary16)."""
+        """Like numpy() but never widens (binary16 stays binary16).  Unified memory: the carried stream is drained, then
+        the managed bytes themselves are returned as a no-copy view (``as_slice`` on ``MemoryDomain::Unified``)."""
         if self._host is not None:
             return self._host
+        if self._uview is not None:
+            if self._stream is not None:
+                self._stream.synchronize()
+            return self._uview
         out = np.empty(self._shape, dtype=self._dtype)
         hip.d2h(out, self._ptr, self._stream if self._stream is not None else Stream.default(self._device))
         return out
+
+    def to_hip_unified(self, stream: Stream) -> "Tensor":
+        """Copy this HOST tensor into a new managed allocation carrying ``stream`` (``to_cuda_unified``, T/cuda.rs:1302-1340)."""
+        if self._host is None:
+            raise ValueError("to_hip_unified: the tensor is not host-resident")
+        out = Tensor.zeros_unified(self._shape, self._dtype, stream)
+        if self.nbytes:
+            out._uview[...] = self._host  # managed memory is host-writable; first device touch migrates the pages
+        return out
+
+    to_cuda_unified = to_hip_unified
 
     def to_hip(self, stream: Optional[Stream] = None) -> "Tensor":
         if self._host is None:
@@ -150,12 +234,15 @@ class Tensor:
     def cpu(self) -> "Tensor":
         if self._host is not None:
             return self
-        return Tensor(self._shape, self._dtype, host=self.numpy_raw())
+        raw = self.numpy_raw()
+        return Tensor(self._shape, self._dtype, host=raw.copy() if self._uview is not None else raw)
 
     # -- DLPack (T/dlpack.rs:72-290, PY/cuda_ext/mod.rs:196-216) ---------------------------------
     def __dlpack_device__(self) -> Tuple[int, int]:
         from . import dlpack
-        return (dlpack.kDLCPU, 0) if self._host is not None else (dlpack.kDLROCM, self._device)
+        if self._host is not None:  # Host -> kDLCPU, page-locked host -> kDLROCMHost (T/dlpack.rs:76-84)
+            return (dlpack.kDLROCMHost, 0) if self._pinned else (dlpack.kDLCPU, 0)
+        return (dlpack.kDLCUDAManaged, self._device) if self._uview is not None else (dlpack.kDLROCM, self._device)
 
     def __dlpack__(self, *, stream: Any = None, max_version: Any = None, dl_device: Any = None,
                    copy: Any = None) -> Any:
@@ -166,11 +253,28 @@ class Tensor:
         if copy:
             raise BufferError("DLPack export never copies")
         if self._host is not None:
-            return dlpack.export(self, int(self._host.ctypes.data), self._shape, self._dtype, dlpack.kDLCPU, 0)
+            return dlpack.export(self, int(self._host.ctypes.data), self._shape, self._dtype,
+                                 dlpack.kDLROCMHost if self._pinned else dlpack.kDLCPU, 0)
+        hip._ffi.assert_single_runtime()  # device memory is about to cross to another library
+        dev_code = dlpack.kDLCUDAManaged if self._uview is not None else dlpack.kDLROCM
+        if dl_device is not None and self._uview is not None:
+            # Managed memory is legal on both sides: a consumer that cannot take kDLCUDAManaged (torch-ROCm) may ask for
+            # the device view, (kDLROCM, id), or the host view, (kDLCPU, 0) — same pointer, no copy.
+            want = (int(dl_device[0]), int(dl_device[1]))
+            if want == (dlpack.kDLCPU, 0):
+                if self._stream is not None:
+                    self._stream.synchronize()
+                return dlpack.export(self, self._ptr, self._shape, self._dtype, dlpack.kDLCPU, 0)
+            if want not in ((dlpack.kDLROCM, self._device), (dlpack.kDLCUDAManaged, self._device)):
+                raise BufferError(f"cannot export managed memory of device {self._device} as DLPack device {want}")
+            dev_code = want[0]
+        elif dl_device is not None and (int(dl_device[0]), int(dl_device[1])) != (dev_code, self._device):
+            raise BufferError(f"DLPack export never copies: the tensor lives on {(dev_code, self._device)}, not {tuple(dl_device)}")
         if stream is not None and stream != -1 and self._stream is not None:
             consumer = 0 if stream in (0, 1, 2) else int(stream)  # 0/1/2 = default-stream aliases
             hip.check(hip.lib.kh_stream_fence(self._stream.cuda_stream_ptr, consumer))
-        return dlpack.export(self, self._ptr, self._shape, self._dtype, dlpack.kDLROCM, self._device)
+        # DLPack has no ROCm-specific managed code: kDLCUDAManaged (13) is THE managed type, as in the reference
+        return dlpack.export(self, self._ptr, self._shape, self._dtype, dev_code, self._device)
 
     @staticmethod
     def from_dlpack(obj: Any, stream: Optional[Stream] = None) -> "Tensor":
@@ -186,9 +290,11 @@ class Tensor:
             n = int(np.prod(shape, dtype=np.int64))
             buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr) if n else b""
             host = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
-            return Tensor(shape, dtype, host=host, keepalive=keep)
+            return Tensor(shape, dtype, host=host, keepalive=keep, pinned=dev_type != dlpack.kDLCPU)
+        hip._ffi.assert_single_runtime()  # a foreign exporter of device memory: both sides must share one HIP runtime
         st = stream if stream is not None else Stream.default(dev_id)
-        return Tensor(shape, dtype, device_ptr=ptr, device=dev_id, stream=st, keepalive=keep)
+        return Tensor(shape, dtype, device_ptr=ptr, device=dev_id, stream=st, keepalive=keep,
+                      unified=dev_type == dlpack.kDLCUDAManaged)
 
     def __repr__(self) -> str:
         return f"Tensor(shape={self._shape}, dtype={self.dtype}, device={self.device})"

@@ -18,7 +18,6 @@ import statistics
 import sys
 from pathlib import Path
 
-os.environ.setdefault("HSA_ENABLE_SDMA", "0")
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "kornia-rs_amd"))
 

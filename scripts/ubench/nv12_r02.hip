@@ -1,0 +1,375 @@
+// Dev micro-benchmark (round 2, not shipped): what is left between the production NV12->CHW kernel (6.0-6.2 TB/s)
+// and a flat fill (6.9-7.2 TB/s)?  Round 1 showed reads are additive (R+W = W-only + read-only time) and that a block
+// writing ONE plane (fill 3-stream rotate) loses 5 % against a flat fill while a wave writing THREE planes loses 15 %.
+// Variants here keep the production store shape (1 KiB per wave-store, block-contiguous) and change what surrounds it:
+//   prod        the production mapping (4 px x 1 row per thread, 512-thread blocks, 2-D grid)
+//   staged      block stages a flat chunk of Y + its chroma rows in LDS with 16-B loads, then K rounds of
+//               {ds_read, decode, 3 stores}: one global-load latency per K store rounds, no vmcnt wait between rounds
+//   hoist       same K rounds, loads issued up front into registers (no LDS)
+//   persist     grid = CUs x occupancy, block-stride loop with the next chunk's loads issued before the stores
+//   tstore      results transposed through LDS so each wave stores 3 KiB of ONE plane
+//   F0..F3      fills isolating the store granularity (flat / 3 planes per thread / 3 KiB of one plane per wave / per block)
+// Every decode variant is compared word for word with `prod`.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kCY = 1220542, kCUB = 2116026, kCUG = -409993, kCVG = -852492, kCVR = 1673527, kHalf20 = 1 << 19;
+__device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }
+struct Args { int w, h; float m0, m1, m2, is0, is1, is2; long long sfs, dfs; };
+template <bool NT> __device__ __forceinline__ void st4(float* p, f32x4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, (f32x4*)p); else *(f32x4*)p = v;
+}
+extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+
+__device__ __forceinline__ float norm1(int v, float m, float is) {
+    const float x = (float)v, rc = 1.0f / 255.0f;
+    float q = x * rc, r = __builtin_fmaf(-q, 255.0f, x);
+    q = __builtin_fmaf(r, rc, q);
+    return (q - m) * is;
+}
+__device__ __forceinline__ void decode4(uint32_t y4, uint32_t uv4, const Args& a, f32x4 o[3]) {
+    int tb[2], tg[2], tr[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = (int)((uv4 >> (16 * k)) & 0xFFu) - 128, v = (int)((uv4 >> (16 * k + 8)) & 0xFFu) - 128;
+        tb[k] = kCUB * u + kHalf20; tg[k] = kCUG * u + kCVG * v + kHalf20; tr[k] = kCVR * v + kHalf20;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int yy = max((int)((y4 >> (8 * j)) & 0xFFu) - 16, 0) * kCY;
+        const int k = j >> 1;
+        o[0][j] = norm1(clamp255((yy + tr[k]) >> 20), a.m0, a.is0);
+        o[1][j] = norm1(clamp255((yy + tg[k]) >> 20), a.m1, a.is1);
+        o[2][j] = norm1(clamp255((yy + tb[k]) >> 20), a.m2, a.is2);
+    }
+}
+
+// ---- prod: production mapping.  XF: XCD k walks frames k, k+8, ... (1-D launch)
+template <int BLOCK, bool NT, bool XF>
+__global__ __launch_bounds__(BLOCK) void k_prod(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a, int bpf, int nframes) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    unsigned chunk = blockIdx.x, frame = blockIdx.y;
+    if constexpr (XF) {
+        const unsigned xcd = blockIdx.x % 8, slot = blockIdx.x / 8, fg = slot / bpf;
+        chunk = slot - fg * bpf; frame = fg * 8 + xcd;
+        if ((int)frame >= nframes) return;
+    }
+    const int g = chunk * BLOCK + threadIdx.x;
+    if (g >= groups) return;
+    const uint8_t* src = sb + (long long)frame * a.sfs;
+    float* dst = db + (long long)frame * a.dfs;
+    const int r = g / wq, xq = g - r * wq;
+    const long long plane = (long long)a.w * a.h;
+    const uint32_t y4 = *(const uint32_t*)(src + 4ll * g);
+    const uint32_t uv4 = *(const uint32_t*)(src + plane + (long long)(r >> 1) * a.w + 4 * xq);
+    f32x4 o[3];
+    decode4(y4, uv4, a, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st4<NT>(dst + c * plane + 4ll * g, o[c]);
+}
+
+// ---- staged: flat chunk of BLOCK*K quads per block; Y + chroma rows through LDS with 16-byte loads
+template <int BLOCK, int K, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_staged(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a, int uv_dwords_max) {
+    uint32_t* ly = (uint32_t*)dyn_lds;
+    uint32_t* luv = ly + BLOCK * K;
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int g0 = blockIdx.x * (BLOCK * K), gend = min(g0 + BLOCK * K, groups);
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const long long plane = (long long)a.w * a.h;
+    const int r0 = g0 / wq, r1 = (gend - 1) / wq, c0 = r0 >> 1, c1 = r1 >> 1;
+    {
+        // all loads issued before the first LDS write (a rolled loop would wait for every load in turn)
+        constexpr int NY = (K + 3) / 4, NU = (K + 3) / 4 + 1;   // uv_dwords_max / 4 / BLOCK <= NU (host-checked)
+        const u32x4* gy = (const u32x4*)(src + 4ll * g0);
+        const int ny = (gend - g0) >> 2;
+        const u32x4* gu = (const u32x4*)(src + plane + (long long)c0 * a.w);
+        const int nu = ((c1 - c0 + 1) * wq) >> 2;
+        u32x4 vy[NY], vu[NU];
+#pragma unroll
+        for (int i = 0; i < NY; ++i) { const int j = threadIdx.x + i * BLOCK; vy[i] = gy[min(j, ny - 1)]; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { const int j = threadIdx.x + i * BLOCK; vu[i] = gu[min(j, nu - 1)]; }
+#pragma unroll
+        for (int i = 0; i < NY; ++i) { const int j = threadIdx.x + i * BLOCK; if (j < ny) ((u32x4*)ly)[j] = vy[i]; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { const int j = threadIdx.x + i * BLOCK; if (j < nu) ((u32x4*)luv)[j] = vu[i]; }
+    }
+    __syncthreads();
+    int g = g0 + threadIdx.x;
+    int r = g / wq, xq = g - r * wq;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (g < gend) {
+            const uint32_t y4 = ly[g - g0];
+            const uint32_t uv4 = luv[((r >> 1) - c0) * wq + xq];
+            f32x4 o[3];
+            decode4(y4, uv4, a, o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) st4<NT>(dst + c * plane + 4ll * g, o[c]);
+        }
+        g += BLOCK; xq += BLOCK;
+        while (xq >= wq) { xq -= wq; ++r; }
+    }
+}
+
+// ---- hoist: K rounds per thread, all 2K dword loads issued before the first store (no LDS)
+template <int BLOCK, int K, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_hoist(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int g0 = blockIdx.x * (BLOCK * K) + threadIdx.x;
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const long long plane = (long long)a.w * a.h;
+    uint32_t y4[K], uv4[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int g = min(g0 + k * BLOCK, groups - 1);
+        const int r = g / wq, xq = g - r * wq;
+        y4[k] = *(const uint32_t*)(src + 4ll * g);
+        uv4[k] = *(const uint32_t*)(src + plane + (long long)(r >> 1) * a.w + 4 * xq);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int g = g0 + k * BLOCK;
+        if (g < groups) {
+            f32x4 o[3];
+            decode4(y4[k], uv4[k], a, o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) st4<NT>(dst + c * plane + 4ll * g, o[c]);
+        }
+    }
+}
+
+// ---- persist: block-stride loop over (frame, chunk), next loads issued before the current stores
+template <int BLOCK, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_persist(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a, int bpf, int total) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const long long plane = (long long)a.w * a.h;
+    int c = blockIdx.x;
+    if (c >= total) return;
+    auto addr = [&](int cc, int& g, int& frame) { frame = cc / bpf; g = min((cc - frame * bpf) * BLOCK + (int)threadIdx.x, groups - 1); };
+    int g, frame;
+    addr(c, g, frame);
+    int r = g / wq, xq = g - r * wq;
+    uint32_t y4 = *(const uint32_t*)(sb + (long long)frame * a.sfs + 4ll * g);
+    uint32_t uv4 = *(const uint32_t*)(sb + (long long)frame * a.sfs + plane + (long long)(r >> 1) * a.w + 4 * xq);
+    while (true) {
+        const int cn = c + gridDim.x;
+        int gn = 0, fn = 0; uint32_t yn = 0, un = 0;
+        if (cn < total) {
+            addr(cn, gn, fn);
+            const int rn = gn / wq, xn = gn - rn * wq;
+            yn = *(const uint32_t*)(sb + (long long)fn * a.sfs + 4ll * gn);
+            un = *(const uint32_t*)(sb + (long long)fn * a.sfs + plane + (long long)(rn >> 1) * a.w + 4 * xn);
+        }
+        if ((c - frame * bpf) * BLOCK + (int)threadIdx.x < groups) {
+            f32x4 o[3];
+            decode4(y4, uv4, a, o);
+            float* dst = db + (long long)frame * a.dfs;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) st4<NT>(dst + p * plane + 4ll * g, o[p]);
+        }
+        if (cn >= total) break;
+        c = cn; g = gn; frame = fn; y4 = yn; uv4 = un;
+    }
+}
+
+// ---- tstore: 768-thread block; results go through LDS so every wave stores 3 KiB of ONE plane (12 waves = 3 planes x 4 segments)
+template <bool NT>
+__global__ __launch_bounds__(768) void k_tstore(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    f32x4* l = (f32x4*)dyn_lds;  // [3][768]
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int g0 = blockIdx.x * 768, t = threadIdx.x, g = min(g0 + t, groups - 1);
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const long long plane = (long long)a.w * a.h;
+    const int r = g / wq, xq = g - r * wq;
+    const uint32_t y4 = *(const uint32_t*)(src + 4ll * g);
+    const uint32_t uv4 = *(const uint32_t*)(src + plane + (long long)(r >> 1) * a.w + 4 * xq);
+    f32x4 o[3];
+    decode4(y4, uv4, a, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) l[c * 768 + t] = o[c];
+    __syncthreads();
+    const int wv = t >> 6, lane = t & 63, c = wv >> 2, seg = wv & 3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int idx = seg * 192 + j * 64 + lane;
+        if (g0 + idx < groups) st4<NT>(dst + c * plane + 4ll * (g0 + idx), l[c * 768 + idx]);
+    }
+}
+
+// ---- fills
+template <bool NT>
+__global__ __launch_bounds__(256) void f_flat(float* __restrict__ db, long long n4) {
+    long long i = (long long)blockIdx.y * gridDim.x * 256 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) st4<NT>(db + 4 * i, f32x4{1.f, 2.f, 3.f, 4.f});
+}
+template <int BLOCK, bool NT>  // F1: thread = 16 B in each of the 3 planes (the production store shape, no loads / decode)
+__global__ __launch_bounds__(BLOCK) void f_3plane(float* __restrict__ db, Args a) {
+    const int groups = (a.w >> 2) * a.h, g = blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= groups) return;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const long long plane = (long long)a.w * a.h;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st4<NT>(dst + c * plane + 4ll * g, f32x4{1.f, 2.f, 3.f, (float)c});
+}
+template <int BLOCK, bool NT>  // F2: wave = 3 KiB contiguous of ONE plane; block = 3*BLOCK*16 B of one plane; consecutive blocks rotate planes
+__global__ __launch_bounds__(BLOCK) void f_wave3k(float* __restrict__ db, Args a) {
+    const int groups = (a.w >> 2) * a.h;
+    const int c = blockIdx.x % 3, chunk = blockIdx.x / 3;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* dst = db + (long long)blockIdx.y * a.dfs + c * (long long)a.w * a.h;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int g = chunk * (3 * BLOCK) + wv * 192 + j * 64 + lane;
+        if (g < groups) st4<NT>(dst + 4ll * g, f32x4{1.f, 2.f, 3.f, (float)c});
+    }
+}
+template <bool NT>  // F3: the tstore shape without loads / decode / LDS: 768 threads, wave -> (plane, segment), 3 KiB per wave
+__global__ __launch_bounds__(768) void f_tstore(float* __restrict__ db, Args a) {
+    const int groups = (a.w >> 2) * a.h, g0 = blockIdx.x * 768;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = wv >> 2, seg = wv & 3;
+    float* dst = db + (long long)blockIdx.y * a.dfs + c * (long long)a.w * a.h;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int idx = seg * 192 + j * 64 + lane;
+        if (g0 + idx < groups) st4<NT>(dst + 4ll * (g0 + idx), f32x4{1.f, 2.f, 3.f, (float)c});
+    }
+}
+// F4: W-only with the staged loop shape: K rounds of 3 plane stores per thread, block-contiguous
+template <int BLOCK, int K, bool NT>
+__global__ __launch_bounds__(BLOCK) void f_3plane_k(float* __restrict__ db, Args a) {
+    const int groups = (a.w >> 2) * a.h;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const long long plane = (long long)a.w * a.h;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int g = blockIdx.x * (BLOCK * K) + k * BLOCK + threadIdx.x;
+        if (g < groups) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) st4<NT>(dst + c * plane + 4ll * g, f32x4{1.f, 2.f, 3.f, (float)c});
+        }
+    }
+}
+// read-only, 16 B per lane
+__global__ __launch_bounds__(256) void r_wide(const uint8_t* __restrict__ sb, float* __restrict__ out, long long n16) {
+    long long i = (long long)blockIdx.y * gridDim.x * 256 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    u32x4 v = ((const u32x4*)sb)[i];
+    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345677u) out[0] = 1.0f;
+}
+
+__global__ void k_diff(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, long long n, unsigned long long* out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (; i < n; i += stride) bad += a[i] != b[i];
+    if (bad) atomicAdd(out, bad);
+}
+
+int main(int argc, char** argv) {
+    const int W = 1920, H = 1080, N = argc > 1 ? atoi(argv[1]) : 1024, ROUNDS = argc > 2 ? atoi(argv[2]) : 5;
+    const int NCHK = std::min(N, 16);  // frames compared against prod
+    const size_t fb = (size_t)W * H * 3 / 2, ob = (size_t)W * H * 3;
+    uint8_t* src; float *dst, *ref;
+    CK(hipMalloc(&src, fb * N)); CK(hipMalloc(&dst, ob * N * 4)); CK(hipMalloc(&ref, ob * NCHK * 4));
+    {
+        std::vector<uint8_t> h(fb + 31 * 64); uint32_t s = 0x12345678u;
+        for (auto& b : h) { s = s * 1664525u + 1013904223u; b = (uint8_t)(s >> 24); }
+        for (int k = 0; k < N; ++k) CK(hipMemcpy(src + k * fb, h.data() + 31 * (k % 64), fb, hipMemcpyHostToDevice));
+    }
+    Args a{W, H, 0.485f, 0.456f, 0.406f, 1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f, (long long)fb, (long long)ob};
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    unsigned long long* dbad; CK(hipMalloc(&dbad, 8));
+    const int groups = (W / 4) * H;
+    const long long n4 = (long long)ob * N / 4;
+    const double full = (double)(fb + ob * 4) * N, wonly = (double)ob * 4 * N, ronly = (double)fb * N;
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    struct V { std::string name; double bytes; bool check; std::function<void()> run; std::vector<float> ms; long long bad; };
+    std::vector<V> vs;
+    auto G = [&](int per_block) { return dim3((groups + per_block - 1) / per_block, N); };
+    auto bpf = [&](int blk) { return (groups + blk - 1) / blk; };
+
+    vs.push_back({"prod 4x1 NT b512 (production)", full, false, [&] { hipLaunchKernelGGL((k_prod<512, true, false>), G(512), dim3(512), 0, st, src, dst, a, 0, N); }, {}, 0});
+    vs.push_back({"prod 4x1 st b512", full, true, [&] { hipLaunchKernelGGL((k_prod<512, false, false>), G(512), dim3(512), 0, st, src, dst, a, 0, N); }, {}, 0});
+    vs.push_back({"prod 4x1 NT b256", full, true, [&] { hipLaunchKernelGGL((k_prod<256, true, false>), G(256), dim3(256), 0, st, src, dst, a, 0, N); }, {}, 0});
+    vs.push_back({"prod 4x1 NT b512 XCD-per-frame", full, true, [&] { int b = bpf(512); hipLaunchKernelGGL((k_prod<512, true, true>), dim3(b * 8 * ((N + 7) / 8)), dim3(512), 0, st, src, dst, a, b, N); }, {}, 0});
+    vs.push_back({"prod 4x1 NT b256 XCD-per-frame", full, true, [&] { int b = bpf(256); hipLaunchKernelGGL((k_prod<256, true, true>), dim3(b * 8 * ((N + 7) / 8)), dim3(256), 0, st, src, dst, a, b, N); }, {}, 0});
+
+    auto uvmax = [&](int quads) { int rows = (quads + W / 4 - 2) / (W / 4) + 1; return (rows / 2 + 1) * (W / 4); };
+#define STAGED(B, K, NT, EXTRA)                                                                                          \
+    {                                                                                                                    \
+        const int uvd = uvmax(B * K);                                                                                    \
+        if (uvd / 4 > ((K + 3) / 4 + 1) * B) { printf("staged b%d K%d: chroma window does not fit the unrolled loader\n", B, K); exit(1); } \
+        const int lds = (B * K + uvd) * 4 + EXTRA;                                                                       \
+        CK(hipFuncSetAttribute((const void*)k_staged<B, K, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        vs.push_back({std::string("staged b" #B " K" #K) + (NT ? " NT" : " st") + " lds=" + std::to_string(lds / 1024) + "K", full, true, \
+                      [&, lds, uvd] { hipLaunchKernelGGL((k_staged<B, K, NT>), G(B * K), dim3(B), lds, st, src, dst, a, uvd); }, {}, 0}); \
+    }
+    STAGED(256, 4, true, 0) STAGED(256, 8, true, 0) STAGED(256, 16, true, 0)
+    STAGED(512, 4, true, 0) STAGED(512, 8, true, 0) STAGED(512, 16, true, 0)
+    STAGED(256, 8, false, 0) STAGED(512, 8, false, 0)
+    STAGED(256, 8, true, 24 * 1024) STAGED(512, 8, true, 40 * 1024)
+    STAGED(1024, 4, true, 0) STAGED(1024, 8, true, 0)
+#define HOIST(B, K, NT) vs.push_back({std::string("hoist b" #B " K" #K) + (NT ? " NT" : " st"), full, true, [&] { hipLaunchKernelGGL((k_hoist<B, K, NT>), G(B * K), dim3(B), 0, st, src, dst, a); }, {}, 0});
+    HOIST(256, 2, true) HOIST(256, 4, true) HOIST(512, 2, true) HOIST(512, 4, true) HOIST(512, 8, true) HOIST(512, 4, false)
+#define PERSIST(B, OCC) vs.push_back({"persist b" #B " x" #OCC "/CU NT", full, true, [&] { int b = bpf(B); hipLaunchKernelGGL((k_persist<B, true>), dim3(cus * OCC), dim3(B), 0, st, src, dst, a, b, b * N); }, {}, 0});
+    PERSIST(512, 2) PERSIST(512, 4) PERSIST(256, 4) PERSIST(256, 8) PERSIST(512, 8) PERSIST(256, 16)
+    CK(hipFuncSetAttribute((const void*)k_tstore<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_tstore<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    vs.push_back({"tstore b768 NT (wave = 3 KiB of one plane)", full, true, [&] { hipLaunchKernelGGL((k_tstore<true>), G(768), dim3(768), 3 * 768 * 16, st, src, dst, a); }, {}, 0});
+    vs.push_back({"tstore b768 st", full, true, [&] { hipLaunchKernelGGL((k_tstore<false>), G(768), dim3(768), 3 * 768 * 16, st, src, dst, a); }, {}, 0});
+
+    vs.push_back({"F0 fill flat NT", wonly, false, [&] { hipLaunchKernelGGL((f_flat<true>), dim3(65536, (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), 0, st, dst, n4); }, {}, 0});
+    vs.push_back({"F0 fill flat st", wonly, false, [&] { hipLaunchKernelGGL((f_flat<false>), dim3(65536, (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), 0, st, dst, n4); }, {}, 0});
+    vs.push_back({"F1 W-only 3 planes/thread b512 NT", wonly, false, [&] { hipLaunchKernelGGL((f_3plane<512, true>), G(512), dim3(512), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F1 W-only 3 planes/thread b512 st", wonly, false, [&] { hipLaunchKernelGGL((f_3plane<512, false>), G(512), dim3(512), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F2 W-only wave=3KiB one plane, block rotates NT", wonly, false, [&] { hipLaunchKernelGGL((f_wave3k<512, true>), dim3(3 * bpf(3 * 512), N), dim3(512), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F2 W-only wave=3KiB one plane, block rotates st", wonly, false, [&] { hipLaunchKernelGGL((f_wave3k<512, false>), dim3(3 * bpf(3 * 512), N), dim3(512), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F3 W-only tstore shape b768 NT", wonly, false, [&] { hipLaunchKernelGGL((f_tstore<true>), G(768), dim3(768), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F3 W-only tstore shape b768 st", wonly, false, [&] { hipLaunchKernelGGL((f_tstore<false>), G(768), dim3(768), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F4 W-only 3 planes/thread b512 K8 NT", wonly, false, [&] { hipLaunchKernelGGL((f_3plane_k<512, 8, true>), G(512 * 8), dim3(512), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F4 W-only 3 planes/thread b256 K8 NT", wonly, false, [&] { hipLaunchKernelGGL((f_3plane_k<256, 8, true>), G(256 * 8), dim3(256), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"R read-only src 16 B/lane", ronly, false, [&] { long long n16 = (long long)fb * N / 16; hipLaunchKernelGGL(r_wide, dim3(65536, (unsigned)((n16 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), 0, st, src, dst, n16); }, {}, 0});
+
+    // reference output of the first NCHK frames from prod
+    vs[0].run(); CK(hipGetLastError()); CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(ref, dst, ob * NCHK * 4, hipMemcpyDeviceToDevice));
+    for (auto& v : vs) {
+        if (!v.check) continue;
+        CK(hipMemsetAsync(dst, 0xCD, ob * NCHK * 4, st));
+        v.run(); CK(hipGetLastError());
+        CK(hipMemsetAsync(dbad, 0, 8, st));
+        hipLaunchKernelGGL(k_diff, dim3(4096), dim3(256), 0, st, (const uint32_t*)ref, (const uint32_t*)dst, (long long)ob * NCHK, dbad);
+        unsigned long long bad; CK(hipMemcpyAsync(&bad, dbad, 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+        v.bad = (long long)bad;
+    }
+    for (int r = 0; r < ROUNDS + 1; ++r)
+        for (auto& v : vs) {
+            CK(hipEventRecord(e0, st)); v.run(); CK(hipGetLastError()); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) v.ms.push_back(ms);
+        }
+    printf("# N=%d frames of 1920x1080, %d rounds interleaved, %d CUs; GB/s = algorithmic bytes (R+W 28.67 GB, W-only 25.48 GB, R 3.19 GB at N=1024) / median\n", N, ROUNDS, cus);
+    printf("%-52s %9s %9s %9s  %s\n", "variant", "med ms", "min ms", "GB/s@med", "vs prod");
+    for (auto& v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        float med = v.ms[v.ms.size() / 2];
+        printf("%-52s %9.3f %9.3f %9.0f  %s\n", v.name.c_str(), med, v.ms[0], v.bytes / med / 1e6,
+               !v.check ? "-" : (v.bad ? ("MISMATCH " + std::to_string(v.bad)).c_str() : "bit-equal"));
+    }
+    return 0;
+}

@@ -1,7 +1,3 @@
-import os as _os
-
-_os.environ.setdefault("HSA_ENABLE_SDMA", "0")  # before any HIP runtime initialises (see kornia_rs/_ffi.py)
-
 import os
 import sys
 from pathlib import Path

@@ -34,7 +34,7 @@ def ops_binary(tmp_path_factory):
 
 
 def _run(binary, mode):
-    env = dict(os.environ, HSA_ENABLE_SDMA=os.environ.get("HSA_ENABLE_SDMA", "0"))
+    env = dict(os.environ)
     r = subprocess.run([str(binary), mode], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 failure(s)" in r.stdout

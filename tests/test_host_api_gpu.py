@@ -50,16 +50,31 @@ def test_image_to_hip_roundtrip_and_ops(gpu_stream):
 
 
 def test_cross_stream_destination_is_fenced(gpu_stream):
-    """dst allocated (and zero-filled) on another stream: the dispatch must fence it into the
-    source's stream before launching (P/cuda/dispatch.rs:50-67)."""
-    from kornia_rs import Image, Stream, imgproc
+    """dst allocated (and zero-filled) on another stream: the dispatch fences it into the source's stream before the launch
+    AND fences the launch stream back into dst's stream afterwards (DeviceExec::for_streams + run, P/cuda/dispatch.rs:50-82).
+    The launch stream is kept busy with 4K blurs and nothing here synchronises it: ``dst.numpy()`` drains only dst's own
+    stream, so without the fence back it would read the memset's zeros."""
+    from kornia_rs import Image, Preprocessor, Stream, Tensor, imgproc
+    from kornia_rs.hip import DeviceBuffer
     other = Stream.new(0)
     src = Image.from_numpy(O.pattern_f32(300 * 200 * 3).reshape(200, 300, 3)).to_hip(gpu_stream)
-    for _ in range(5):
+    want = O.gaussian_blur(src.numpy(), (5, 5), (1.0, 1.0))
+    big = Image.from_numpy(O.pattern_f32(2160 * 3840 * 3).reshape(2160, 3840, 3)).to_hip(gpu_stream)
+    big_dst = Image.uninit(3840, 2160, 3, "float32", gpu_stream)
+    raw = O.pattern_u8(64 * 32 * 3 // 2)
+    dev_raw = DeviceBuffer.from_numpy(raw, gpu_stream)
+    pre = Preprocessor(mode="stretch", format="nv12", stream=gpu_stream)
+    want_pre = O.preprocess(raw, 64, 32, 64, 32, fmt="nv12", mode="stretch")
+    for _ in range(4):
+        for _ in range(6):
+            imgproc.gaussian_blur(big, (7, 7), (1.5, 1.5), dst=big_dst)  # a few ms of queued work ahead of the op under test
         dst = Image.zeros(300, 200, 3, "float32", stream=other)  # memset queued on `other`
         imgproc.gaussian_blur(src, (5, 5), (1.0, 1.0), dst=dst)
-        gpu_stream.synchronize()
-        assert np.array_equal(dst.numpy(), O.gaussian_blur(src.numpy(), (5, 5), (1.0, 1.0)))
+        t = Tensor.zeros((1, 3, 32, 64), "float32", stream=other)
+        pre.run_raw(dev_raw, 64, 32, t)
+        assert np.array_equal(dst.numpy(), want)
+        assert np.array_equal(t.numpy().view(np.uint32), want_pre.view(np.uint32))
+    gpu_stream.synchronize()
 
 
 def test_torch_rocm_zero_copy_interop(gpu_stream):

@@ -426,6 +426,6 @@ for k in range(n):
     assert np.array_equal(got[k], want), k
 print("xcd-frames ok")
 '''.replace("{root}", str(root))
-    env = dict(os.environ, KH_NV12_XCD_FRAMES="1", HSA_ENABLE_SDMA=os.environ.get("HSA_ENABLE_SDMA", "0"))
+    env = dict(os.environ, KH_NV12_XCD_FRAMES="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "xcd-frames ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
