@@ -131,9 +131,9 @@ class NorthStarNV12(Workload):
         import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
         threads = O.ko.ko_max_threads()
         oh, ow = (self.H, self.W) if self.out == 0 else (self.out, self.out)
-        frames, t0, budget = 0, time.perf_counter(), 12.0
+        frames, t0, budget = 0, time.perf_counter(), 12.0 * CPU_BUDGET_SCALE
         while True:
-            raw = self.base[31 * frames: 31 * frames + self.frame_bytes]
+            raw = self.base[31 * (frames % self.N): 31 * (frames % self.N) + self.frame_bytes]
             rgb = O.rgb_from_nv12(raw, self.W, self.H)
             O.preprocess(rgb, self.W, self.H, ow, oh, fmt="rgb",
                          mode="stretch" if self.out == 0 else "letterbox",
@@ -207,10 +207,10 @@ class ResizeBilinear(F32Images):
         n = self.SW * self.SH * self.C
         frames, t0 = 0, time.perf_counter()
         while True:
-            O.resize(self.base[31 * frames: 31 * frames + n].reshape(self.SH, self.SW, self.C), self.DW, self.DH)
+            O.resize(self.base[31 * (frames % self.N): 31 * (frames % self.N) + n].reshape(self.SH, self.SW, self.C), self.DW, self.DH)
             frames += 1
             dt = time.perf_counter() - t0
-            if dt > 10.0 or frames >= 256:
+            if dt > 10.0 * CPU_BUDGET_SCALE or frames >= 256:
                 break
         return {"value": round(frames * self.SW * self.SH / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads,
                 "kind": "port", "sample": f"{frames} images in {dt:.1f} s; C oracle (restatement of kornia-imgproc "
@@ -242,11 +242,11 @@ class ResizeNormalizeF32(ResizeBilinear):
         threads, n = O.ko.ko_max_threads(), self.SW * self.SH * self.C
         frames, t0 = 0, time.perf_counter()
         while True:
-            O.resize_bilinear_normalize(self.base[31 * frames: 31 * frames + n].reshape(self.SH, self.SW, self.C), self.DW, self.DH,
+            O.resize_bilinear_normalize(self.base[31 * (frames % self.N): 31 * (frames % self.N) + n].reshape(self.SH, self.SW, self.C), self.DW, self.DH,
                                         IMAGENET_MEAN, IMAGENET_STD)
             frames += 1
             dt = time.perf_counter() - t0
-            if dt > 10.0 or frames >= 256:
+            if dt > 10.0 * CPU_BUDGET_SCALE or frames >= 256:
                 break
         return {"value": round(frames * self.SW * self.SH / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
                 "sample": f"{frames} images in {dt:.1f} s; C restatement of the fused launcher, single thread"}
@@ -292,7 +292,7 @@ class Gaussian4K(F32Images):
         threads = O.ko.ko_max_threads()
         t0 = time.perf_counter()
         reps = 0
-        while time.perf_counter() - t0 < 5.0 and reps < 16:
+        while time.perf_counter() - t0 < 5.0 * CPU_BUDGET_SCALE and reps < 16:
             O.gaussian_blur(img, (7, 7), (1.5, 1.5))
             reps += 1
         dtn = (time.perf_counter() - t0) / max(reps, 1)
@@ -356,11 +356,11 @@ class UndistortWarp4K(F32Images):
         mx, my = O.correction_map(self.INTR, self.DIST, self.W, self.H)
         frames, t0 = 0, time.perf_counter()
         while True:
-            img = self.base[31 * frames: 31 * frames + n].reshape(self.H, self.W, self.C)
+            img = self.base[31 * (frames % self.N): 31 * (frames % self.N) + n].reshape(self.H, self.W, self.C)
             O.warp_perspective(O.remap(img, mx, my), self.hm, self.W, self.H)
             frames += 1
             dt = time.perf_counter() - t0
-            if dt > 10.0 or frames >= 64:
+            if dt > 10.0 * CPU_BUDGET_SCALE or frames >= 64:
                 break
         return {"value": round(frames * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads,
                 "kind": "port", "sample": f"{frames} images in {dt:.1f} s; C oracle remap+warp_perspective "
@@ -399,7 +399,7 @@ class U8Images(Workload):
             fn(O)
             reps += 1
             dt = time.perf_counter() - t0
-            if dt > 8.0 or reps >= 64:
+            if dt > 8.0 * CPU_BUDGET_SCALE or reps >= 64:
                 break
         return {"value": round(reps * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
                 "sample": f"{reps} images in {dt:.1f} s; C oracle of {what} (not the upstream Rust binary), OpenMP x{threads}"}
@@ -733,7 +733,7 @@ class SpatialGradient1080p(F32Images):
         img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
         threads = O.ko.ko_max_threads()
         reps, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 8.0 and reps < 64:
+        while time.perf_counter() - t0 < 8.0 * CPU_BUDGET_SCALE and reps < 64:
             O.spatial_gradient(img, "sobel")
             reps += 1
         dt = time.perf_counter() - t0
@@ -765,7 +765,7 @@ class BoxBlurFast1080p(SpatialGradient1080p):
         img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
         threads = O.ko.ko_max_threads()
         reps, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 8.0 and reps < 64:
+        while time.perf_counter() - t0 < 8.0 * CPU_BUDGET_SCALE and reps < 64:
             O.box_blur_fast(img, (2.0, 2.0))
             reps += 1
         dt = time.perf_counter() - t0
@@ -824,6 +824,117 @@ class Bilateral1080p(Median5U8_1080p):
         return self._time_cpu(lambda O: O.bilateral_filter(img, 5, 50.0, 50.0), "bilateral_filter")
 
 
+
+class ColorMap1080p(Workload):
+    """Pointwise colour maps on 1920x1080 images, batch 1024 (one launch over N*W*H pixels): the reference's own headline
+    GPU claim is gray_from_rgb f32 at 87 % of its part's peak (crates/kornia-imgproc/benchmarks.md:72)."""
+
+    W, H = 1920, 1080
+    SPECS = {  # name -> (entry, dtype, src channels, dst channels, oracle call)
+        "gray_u8": ("kh_gray_from_rgb_u8", "u8", 3, 1, "map_u8_quads<Gray>"),
+        "gray_f32": ("kh_gray_from_rgb_f32", "f32", 3, 1, "map_f32<Gray>"),
+        "hsv_f32": ("kh_hsv_from_rgb_f32", "f32", 3, 3, "map_f32<Hsv>"),
+        "bgr_u8": ("kh_bgr_from_rgb_u8", "u8", 3, 3, "map_u8_quads<Swizzle>"),
+    }
+
+    def __init__(self, which, batch):
+        self.which, self.N = which, batch
+        self.entry, self.dtype, self.cin, self.cout, self.kernel = self.SPECS[which]
+        self.item = 1 if self.dtype == "u8" else 4
+        self.name = f"{self.entry[3:]}_1080p_b{batch}"
+        px = self.W * self.H
+        self.units_per_step = self.N * px / 1e6
+        self.alg_bytes_per_launch = self.N * px * (self.cin + self.cout) * self.item
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer, lib, check
+        self.stream = stream
+        n = self.W * self.H * self.cin
+        raw = lcg_bytes(n + 31 * self.N)
+        base = raw if self.dtype == "u8" else (raw.astype(np.float32) / np.float32(255.0))
+        dbase = DeviceBuffer.from_numpy(base, stream)
+        self.src = DeviceBuffer(n * self.item * self.N, stream, zeroed=False)
+        for k in range(self.N):
+            check(lib.kh_memcpy_d2d_async(self.src.ptr + k * n * self.item, dbase.ptr + 31 * k * self.item, n * self.item,
+                                          stream.cuda_stream_ptr))
+        stream.synchronize()
+        self.base = base
+        self.dst = DeviceBuffer(self.N * self.W * self.H * self.cout * self.item, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        check(getattr(lib, self.entry)(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.N * self.W * self.H))
+
+    def describe(self):
+        return {"workload": self.name, "op": f"imgproc::color::{self.entry[3:]}", "src": f"1920x1080x{self.cin} {self.dtype}",
+                "dst": f"1920x1080x{self.cout} {self.dtype}", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
+        img = self.base[: self.W * self.H * self.cin].reshape(self.H, self.W, self.cin)
+        threads = O.ko.ko_max_threads()
+        name = self.entry[3:]
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            O.color_map(name, img, self.cout)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > 6.0 * CPU_BUDGET_SCALE or reps >= 64:
+                break
+        return {"value": round(reps * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+                "sample": f"{reps} images in {dt:.1f} s; C oracle of {name} (not the upstream Rust binary), OpenMP x{threads}, "
+                          "row-parallel above 1 Mpx like par_strip_dispatch"}
+
+
+class GrayPlumbing258x195(Workload):
+    """BASELINE configs[0]: color::gray_from_rgb on ONE 258x195 RGB8 image — the reference's CPU Rayon plumbing case
+    (tests/data/dog-rgb8.png's size, P/color/gray/mod.rs:254-269).  Not a GPU workload: 50 310 pixels is far below the
+    reference's PAR_THRESHOLD of 1 Mpx (P/color/kernel_common.rs:40), so its CPU path runs SERIALLY — and that is what
+    is timed here beside the device path (one launch per image, launch-latency bound).  Reported for completeness of the
+    five configs; 201 240 algorithmic bytes per image say nothing about HBM."""
+
+    name, kernel, dtype = "gray_from_rgb_u8_258x195_plumbing", "map_u8_quads<Gray>", "u8"
+    W, H = 258, 195
+
+    def __init__(self, batch=1):
+        self.N = 1
+        self.units_per_step = self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.W * self.H * 4
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        self.base = lcg_bytes(self.W * self.H * 3)
+        self.src = DeviceBuffer.from_numpy(self.base, stream)
+        self.dst = DeviceBuffer(self.W * self.H, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        check(lib.kh_gray_from_rgb_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W * self.H))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::color::gray_from_rgb (u8), one image", "src": "258x195x3 u8", "dst": "258x195x1 u8",
+                "batch_per_gpu": 1, "parallelism": "none (BASELINE configs[0]: CPU plumbing; the device line is launch-latency bound)"}
+
+    def cpu_baseline(self):
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
+        img = self.base.reshape(self.H, self.W, 3)
+        O.ko.ko_set_threads(1)  # below PAR_THRESHOLD (1 Mpx) the reference's par_strip_dispatch runs the kernel serially
+        try:
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 1.0:
+                O.gray_from_rgb_u8(img)
+                reps += 1
+            dt = time.perf_counter() - t0
+        finally:
+            O.ko.ko_set_threads(0)
+        return {"value": round(reps * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                "sample": f"{reps} calls in {dt:.1f} s incl. the Python/ctypes call overhead (~{dt / reps * 1e6:.0f} us per call); C oracle of "
+                          "gray_from_rgb_u8, serial as the reference's par_strip_dispatch is below 1 Mpx"}
+
+
 WORKLOADS = {
     "nv12_chw": lambda a: NorthStarNV12(a.batch or 1024, 0),
     "nv12_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640),
@@ -843,7 +954,19 @@ WORKLOADS = {
     "box_blur_fast_1080p": lambda a: BoxBlurFast1080p(a.batch or 64),
     "median5_u8_1080p": lambda a: Median5U8_1080p(a.batch or 256),
     "bilateral_1080p": lambda a: Bilateral1080p(a.batch or 256),
+    "gray_u8_1080p": lambda a: ColorMap1080p("gray_u8", a.batch or 1024),
+    "gray_f32_1080p": lambda a: ColorMap1080p("gray_f32", a.batch or 1024),
+    "hsv_f32_1080p": lambda a: ColorMap1080p("hsv_f32", a.batch or 512),
+    "bgr_u8_1080p": lambda a: ColorMap1080p("bgr_u8", a.batch or 1024),
+    "gray_258x195": lambda a: GrayPlumbing258x195(),
 }
+
+# What the default run measures after the headline workload, in the same process ("put C2 / C4 / C5 and the
+# 640 secondary into the driver's single run"): the other BASELINE configs, the north star's letterbox secondary, the
+# pointwise colour maps and the two weakest kernels of round 1.  Each entry is a full roofline record.
+ALSO_DEFAULT = ["nv12_chw_640", "resize_224", "gaussian_4k", "undistort_warp_4k", "gray_258x195", "gray_u8_1080p",
+                "gray_f32_1080p", "hsv_f32_1080p", "warp_affine_u8_4k", "gaussian_u8_4k"]
+CPU_BUDGET_SCALE = 1.0  # lowered for the `also` entries so the default run stays within a few minutes
 
 
 def measured_d2d_ceiling(hip, stream, nbytes: int = 2 << 30, reps: int = 5):
@@ -865,7 +988,151 @@ def measured_d2d_ceiling(hip, stream, nbytes: int = 2 << 30, reps: int = 5):
         return None
 
 
+def make_workload(name: str, args) -> Workload:
+    """Instantiate a workload; its name always carries the batch it actually runs (`..._b<N>`), which is also what keys the
+    replayed PMC traffic — a non-default batch never inherits the default batch's counters."""
+    import re
+    wl = WORKLOADS[name](args)
+    n = getattr(wl, "N", None)
+    if n is not None and re.search(r"_b\d+$", wl.name):
+        wl.name = re.sub(r"_b\d+$", f"_b{n}", wl.name)
+    return wl
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def respawn_under_torchrun(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves — one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 — and pass their single JSON line through."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.call(cmd, env=env)
+
+
+class Runner:
+    """Times workloads on this rank's device: K steps bracketed by barrier + sync, per-step HIP events on the launch stream."""
+
+    def __init__(self, hip, torch, dist, stream, rank, local_rank, world):
+        self.hip, self.torch, self.dist, self.stream = hip, torch, dist, stream
+        self.rank, self.local_rank, self.world = rank, local_rank, world
+
+    def barrier(self):
+        self.stream.synchronize()
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier(device_ids=[self.local_rank])
+
+    def time(self, wl, steps, warmup):
+        hip, stream = self.hip, self.stream
+        for _ in range(warmup):
+            wl.step()
+        starts = [hip.Event(timing=True) for _ in range(steps)]
+        stops = [hip.Event(timing=True) for _ in range(steps)]
+        self.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            starts[k].record(stream)   # HIP events on the stream the kernel is launched on
+            wl.step()
+            stops[k].record(stream)
+        stream.synchronize()
+        self.torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            self.dist.barrier(device_ids=[self.local_rank])
+        kernel_ms = [starts[k].elapsed_ms(stops[k]) for k in range(steps)]
+        return elapsed, kernel_ms
+
+    def record(self, wl, steps, warmup, elapsed, kernel_ms, key):
+        """The measured part of a JSON record for `wl` (rank 0)."""
+        mean_kernel_s = float(np.mean(kernel_ms)) / 1e3 if kernel_ms else 0.0
+        if not mean_kernel_s > 0.0:  # events without a resolution (host simulator): fall back to the wall clock per step
+            mean_kernel_s = elapsed / steps
+        achieved = wl.alg_bytes_per_launch / mean_kernel_s / 1e9
+        traffic, source = None, None
+        tfile = ROOT / "profiles" / "pmc_traffic.json"  # per-launch HBM bytes from separate rocprofv3 --pmc passes
+        if tfile.exists():
+            tj = json.loads(tfile.read_text())
+            traffic = tj.get(wl.name)
+            if traffic is not None:
+                source = f"profiles/pmc_traffic.json ({tj.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')}); replayed from that profile, not counted in this run"
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source, "kernel": wl.kernel,
+                "alg_bytes_per_launch": wl.alg_bytes_per_launch, "mean_launch_ms": round(mean_kernel_s * 1e3, 4),
+                "min_launch_ms": round(float(np.min(kernel_ms)), 4)}
+        if traffic:
+            # Where the algorithmic figure counts only the taps a gather needs (C2) the kernel really moves whole 128-B
+            # lines: report the HBM rate of the counted traffic next to the algorithmic one.
+            roof["traffic_GBps"] = round(traffic / mean_kernel_s / 1e9, 1)
+            roof["traffic_frac"] = round(traffic / mean_kernel_s / 1e9 / HBM_PEAK_GBS, 4)
+        extra = getattr(wl, "roofline_extra", None)
+        if extra:
+            roof.update(extra(mean_kernel_s))
+        return {"value": round(self.world * wl.units_per_step * steps / elapsed, 1), "unit": "Mpixels/s", "steps": steps, "warmup": warmup,
+                "ms_per_step": round(elapsed / steps * 1e3, 4), "dtype": wl.dtype, "config": wl.describe(), "roofline": roof}
+
+
+def in_process_sharded(args) -> int:
+    """`--in-process`: the north star sharded across `--gpus` devices INSIDE one process (one host thread +
+    one non-default stream per device, contiguous batch slices, no collective) through
+    kornia_rs.sharding.ShardedPreprocessor — the deployment shape of a batch server.  The driver's scaling runs use the
+    process-per-GPU path; this mode exists to measure the thread-per-GPU one beside it."""
+    import torch  # noqa: F401  one HIP runtime for the process
+    from kornia_rs import hip
+    from kornia_rs.sharding import ShardedPreprocessor
+    n_dev = hip.device_count()
+    devices = [g % max(n_dev, 1) for g in range(args.gpus)]
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    per = args.batch or 1024
+    W, H = 1920, 1080
+    fb = W * H * 3 // 2
+    sp = ShardedPreprocessor(devices, mode="stretch", format="nv12", sampling="bilinear", mean=IMAGENET_MEAN, std=IMAGENET_STD)
+    base = lcg_bytes(fb + 31 * per)
+    srcs, dsts = [None] * len(devices), [None] * len(devices)
+
+    def setup(g):
+        from kornia_rs import Tensor
+        from kornia_rs.hip import DeviceBuffer, check, lib
+        st = sp.streams[g]
+        dbase = DeviceBuffer.from_numpy(base, st)
+        src = DeviceBuffer(fb * per, st, zeroed=False)
+        for k in range(per):
+            check(lib.kh_memcpy_d2d_async(src.ptr + k * fb, dbase.ptr + 31 * k, fb, st.cuda_stream_ptr))
+        st.synchronize()
+        srcs[g], dsts[g] = src, Tensor.uninit((per, 3, H, W), "float32", st)
+
+    sp._each(setup)
+    elapsed = sp.timed_steps(lambda g: sp.shards[g].run_raw_batch(srcs[g], W, H, dsts[g], frame_stride=fb), args.steps, args.warmup)
+    mpx = len(devices) * per * W * H / 1e6
+    alg = per * (fb + 12 * W * H)
+    per_dev_s = elapsed / args.steps
+    name, cus, mem = hip.device_info(0)
+    print(json.dumps({
+        "metric": "Mpixels/s, fused 1080p NV12->normalized CHW f32 (achieved HBM GB/s in roofline)", "value": round(mpx * args.steps / elapsed, 1),
+        "unit": "Mpixels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_dev_s * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (LCG bytes, reference pattern_u8; frame k shifted by 31k)",
+        "config": {"workload": f"nv12_1080p_to_chw_f32_b{per}", "launcher": "in-process: one host thread + one stream per device (kornia_rs.sharding)",
+                   "devices": devices, "batch_per_gpu": per, "parallelism": "batch-sharded, no collective"},
+        "roofline": {"bound": "hbm", "achieved": round(alg / per_dev_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / per_dev_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "preprocess_nv12_identity",
+                     "note": "per device, from the wall clock of the slowest shard thread (no per-launch events in this mode)"},
+        "device": {"name": name, "cus": cus, "hbm_bytes": mem, "visible_devices": n_dev}}), flush=True)
+    return 0
+
+
 def main():
+    global CPU_BUDGET_SCALE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -873,7 +1140,16 @@ def main():
     ap.add_argument("--workload", default="nv12_chw", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also", default=None, help="comma-separated workloads measured after the headline one and reported under "
+                                                 "\"also\" (default: the other BASELINE configs etc. when the headline is the north star; 'none' disables)")
+    ap.add_argument("--also-batch", type=int, default=0, help="batch override for the --also workloads (quick checks)")
+    ap.add_argument("--in-process", action="store_true", help="shard across --gpus devices inside ONE process (a thread + stream per device)")
     args = ap.parse_args()
+
+    if args.in_process:
+        return in_process_sharded(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return respawn_under_torchrun(args)  # bare `python bench.py --gpus N`: start the ranks ourselves
 
     import torch  # first: one HIP runtime (torch's bundled libamdhip64) for the whole process
     import torch.distributed as dist
@@ -882,7 +1158,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -893,71 +1169,67 @@ def main():
     from kornia_rs import hip
     hip.set_device(local_rank)
     stream = hip.Stream.new(local_rank)
-    wl = WORKLOADS[args.workload](args)
+    run = Runner(hip, torch, dist, stream, rank, local_rank, world)
+
+    wl = make_workload(args.workload, args)
     wl.setup(stream)
-
-    def barrier():
-        stream.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-
-    for _ in range(args.warmup):
-        wl.step()
-    starts = [hip.Event(timing=True) for _ in range(args.steps)]
-    stops = [hip.Event(timing=True) for _ in range(args.steps)]
-
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        starts[k].record(stream)   # HIP events on the stream the kernel is launched on
-        wl.step()
-        stops[k].record(stream)
-    stream.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier(device_ids=[local_rank])
-
-    kernel_ms = [starts[k].elapsed_ms(stops[k]) for k in range(args.steps)]
-    mean_kernel_s = float(np.mean(kernel_ms)) / 1e3 if kernel_ms else float("nan")
-
+    elapsed, kernel_ms = run.time(wl, args.steps, args.warmup)
+    line = None
     if rank == 0:
-        value = world * wl.units_per_step * args.steps / elapsed
-        achieved = wl.alg_bytes_per_launch / mean_kernel_s / 1e9
-        traffic = None
-        tfile = ROOT / "profiles" / "pmc_traffic.json"  # written from a rocprofv3 --pmc run
-        if tfile.exists():
-            traffic = json.loads(tfile.read_text()).get(wl.name)
+        rec = run.record(wl, args.steps, args.warmup, elapsed, kernel_ms, args.workload)
         name, cus, mem = hip.device_info(local_rank)
-        d2d = measured_d2d_ceiling(hip, stream)
-        line = {
-            "metric": ("Mpixels/s, fused 1080p NV12->normalized CHW f32 (achieved HBM GB/s in roofline)"
-                       if args.workload.startswith("nv12") else f"Mpixels/s (source pixels), {wl.name}"),
-            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,
-            "data": "synthetic (LCG bytes, reference pattern_u8; frame k shifted by 31k)",
-            "config": wl.describe(),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": wl.kernel, "alg_bytes_per_launch": wl.alg_bytes_per_launch,
-                         "mean_launch_ms": round(mean_kernel_s * 1e3, 4),
-                         "min_launch_ms": round(float(np.min(kernel_ms)), 4)},
-            "device": {"name": name, "cus": cus, "hbm_bytes": mem, "measured_d2d_copy_GBps": d2d,
-                       "note": "d2d = (read + write) bytes / time of a 2 GiB hipMemcpyDtoD, the practical HBM ceiling "
-                               "next to the 8000 GB/s datasheet peak used for roofline.frac"},
-        }
+        line = {"metric": ("Mpixels/s, fused 1080p NV12->normalized CHW f32 (achieved HBM GB/s in roofline)"
+                           if args.workload.startswith("nv12") else f"Mpixels/s (source pixels), {wl.name}"),
+                "value": rec["value"], "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,
+                "data": "synthetic (LCG bytes, reference pattern_u8; frame k shifted by 31k)", "config": rec["config"],
+                "roofline": rec["roofline"]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl.cpu_baseline()
+
+    also = args.also
+    if also is None:
+        also = ",".join(ALSO_DEFAULT) if args.workload == "nv12_chw" and not args.batch else "none"
+    names = [n for n in also.split(",") if n and n != "none"]
+    if names:
+        del wl  # frees the headline batch (28.7 GB) before the 4K configs allocate theirs
+        import gc
+        gc.collect()
+        stream.synchronize()
+        records = []
+        CPU_BUDGET_SCALE = 0.25
+        a_steps, a_warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+        for n in names:
+            if n not in WORKLOADS:
+                raise SystemExit(f"--also: unknown workload {n!r}")
+            w2 = make_workload(n, argparse.Namespace(batch=args.also_batch))
+            w2.setup(stream)
+            steps2 = 200 if n == "gray_258x195" else a_steps  # a 7 us launch needs more samples than a 10 ms one
+            e2, k2 = run.time(w2, steps2, a_warm)
+            if rank == 0:
+                r2 = run.record(w2, steps2, a_warm, e2, k2, n)
+                r2["n_gpus"] = world
+                if world == 1 and not args.no_cpu_baseline:
+                    r2["cpu_baseline"] = w2.cpu_baseline()
+                records.append(r2)
+            del w2
+            gc.collect()
+            stream.synchronize()
+        if rank == 0:
+            line["also"] = records
+
+    if rank == 0:
+        name, cus, mem = hip.device_info(local_rank)
+        line["device"] = {"name": name, "cus": cus, "hbm_bytes": mem, "measured_d2d_copy_GBps": measured_d2d_ceiling(hip, stream),
+                          "hip_runtime": hip.runtime_info().get("choice"),
+                          "note": "d2d = (read + write) bytes / time of a 2 GiB hipMemcpyDtoD, the practical HBM ceiling "
+                                  "next to the 8000 GB/s datasheet peak used for roofline.frac"}
         print(json.dumps(line), flush=True)
 
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -58,9 +58,26 @@ static void on_device() {
     imgproc::resize(src, dst, InterpolationMode::Bilinear);
     const float want[18] = {2.25f, 3.25f, 4.25f, 6.75f, 7.75f, 8.75f, 14.25f, 15.25f, 16.25f, 18.75f, 19.75f, 20.75f, 26.25f, 27.25f, 28.25f,
                             30.75f, 31.75f, 32.75f};
-    s.synchronize();
+    // no s.synchronize() here: the DeviceExec fenced the launch stream back into dst's stream, and to_host() drains that one
     auto out = dst.to_host();
     for (int i = 0; i < 18; ++i) EXPECT(std::fabs(out.as_slice()[i] - want[i]) < 1e-4f);
+    // managed memory (MemoryDomain::Unified, I/cuda.rs:144-160): host writes reach the kernel, its result reaches the host view
+    {
+        auto uni = Image<uint8_t, 3>::zeros_hip_unified({2, 1}, s);
+        EXPECT(uni.domain() == MemoryDomain::Unified && uni.is_device() && uni.is_unified() && uni.is_host_accessible());
+        int32_t dom = -1, dev = -1;
+        EXPECT(kh_pointer_domain(uni.device_ptr(), &dom, &dev) == KH_OK && dom == KH_DOMAIN_UNIFIED && dev == 0);
+        const uint8_t px[6] = {0, 128, 255, 128, 0, 128};
+        std::memcpy(uni.unified_data(), px, 6);
+        auto ugray = Image<uint8_t, 1>::zeros_hip_unified({2, 1}, other);
+        imgproc::gray_from_rgb(uni, ugray);
+        const uint8_t* r = ugray.unified_data();  // drains ugray's stream, which was fenced behind the launch
+        EXPECT(r[0] == 104 && r[1] == 53);
+        auto up = Image<uint8_t, 3>::from_size_vec({2, 1}, {0, 128, 255, 128, 0, 128}).to_hip_unified(s);
+        EXPECT(up.is_unified() && std::memcmp(up.unified_data(), px, 6) == 0);
+        EXPECT(throws(K::UnsupportedDevice, [&] { (void)up.to_hip_unified(s); }));
+        EXPECT(throws(K::UnsupportedDevice, [&] { (void)rgb.unified_data(); }));
+    }
     // mixed residency and singular homography are typed errors (P/warp/cuda.rs:369-400, P/warp/perspective.rs:41-60)
     auto host_dst = Image<float, 3>::from_size_val({2, 3}, 0.0f);
     EXPECT(throws(K::MixedResidency, [&] { imgproc::resize(src, host_dst, InterpolationMode::Bilinear); }));

@@ -146,8 +146,25 @@ def test_filter_extra_workloads_1080p(gpu_stream, bench):
         assert np.array_equal(got[k], O.bilateral_filter(_frame(wl, k, wl.W * wl.H, (wl.H, wl.W, 1)), 5, 50.0, 50.0)), k
 
 
+def test_colour_map_workloads_1080p(gpu_stream, bench):
+    for name in ("gray_u8_1080p", "gray_f32_1080p", "hsv_f32_1080p", "bgr_u8_1080p"):
+        wl = _run(bench, name, gpu_stream)
+        np_dt = np.uint8 if wl.dtype == "u8" else np.float32
+        n = wl.W * wl.H * wl.cin
+        got = _out(wl, np_dt, (wl.H, wl.W, wl.cout))
+        for k in range(wl.N):
+            want = O.color_map(wl.entry[3:], _frame(wl, k, n, (wl.H, wl.W, wl.cin)), wl.cout)
+            assert np.array_equal(got[k].view(np.uint32 if np_dt == np.float32 else np.uint8),
+                                  want.reshape(got[k].shape).view(np.uint32 if np_dt == np.float32 else np.uint8)), (name, k)
+    wl = _run(bench, "gray_258x195", gpu_stream)  # BASELINE configs[0]
+    got = wl.dst.to_numpy(np.uint8, (wl.H, wl.W))
+    assert np.array_equal(got, O.gray_from_rgb_u8(wl.base.reshape(wl.H, wl.W, 3)).reshape(wl.H, wl.W))
+
+
 def test_every_workload_is_covered(bench):
     covered = {"nv12_chw", "nv12_chw_640", "resize_224", "resize_normalize_f32_224", "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640",
                "gaussian_4k", "gaussian_u8_4k", "pyrdown_u8_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_u8_4k", "lab_from_rgb_4k",
-               "spatial_gradient_1080p", "box_blur_fast_1080p", "median5_u8_1080p", "bilateral_1080p"}
+               "spatial_gradient_1080p", "box_blur_fast_1080p", "median5_u8_1080p", "bilateral_1080p",
+               "gray_u8_1080p", "gray_f32_1080p", "hsv_f32_1080p", "bgr_u8_1080p", "gray_258x195"}
+    assert set(bench.ALSO_DEFAULT) <= set(bench.WORKLOADS)
     assert covered == set(bench.WORKLOADS)
