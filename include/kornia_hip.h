@@ -58,6 +58,9 @@ KH_API size_t kh_last_error(char* buf, size_t cap);
 
 /* Library version string, e.g. "kornia-hip 0.1.0 (gfx950)".                                    */
 KH_API const char* kh_version(void);
+/* A no-op `void (*deleter)(DLManagedTensor*)`: hosts swap it into tensors still exported through DLPack when their own
+ * deleter callback is about to become uncallable (interpreter shutdown).  T/dlpack.rs:72-170 relies on Rust's Box for this. */
+KH_API void kh_dlpack_noop_deleter(void* managed_tensor);
 /* test hook: floor(n / d) through the multiply-shift division the kernels use for tile ids (n < 2^31)   */
 KH_API uint32_t kh_debug_fast_quot(uint32_t n, uint32_t d);
 
@@ -97,6 +100,16 @@ KH_API int32_t kh_graph_capture_begin(kh_stream_t stream);
 KH_API int32_t kh_graph_capture_end(kh_stream_t stream, kh_graph_t* out);
 KH_API int32_t kh_graph_launch(kh_graph_t graph, kh_stream_t stream);
 KH_API int32_t kh_graph_destroy(kh_graph_t graph);
+
+/* Caller scratch for the operators that need an intermediate (kh_resize_fast_u8 / kh_resize_normalize_to_chw_u8_f32 in their
+ * separable modes, kh_gaussian_blur_u8 / kh_box_blur_u8 beyond 15 taps, kh_warp_affine_u8, kh_warp_perspective_u8,
+ * kh_resize_f32 Lanczos): the reference's low-level launchers take it from the caller (P/cuda/filter.rs:361) while its adapters
+ * allocate per call (P/filter/cuda.rs:119).  Here an operator uses the workspace registered for its stream when it is large
+ * enough — then it allocates nothing and may be captured — and the stream-ordered pool otherwise (refused under capture,
+ * with the byte count in the message).  One workspace serves ONE host thread's calls on that stream.  kh_last_workspace_bytes:
+ * scratch the last compute call on this thread asked for (0 = none) — run once eagerly, read it, register, capture.            */
+KH_API int32_t kh_stream_set_workspace(kh_stream_t stream, void* device_ptr, size_t bytes);
+KH_API int32_t kh_last_workspace_bytes(size_t* bytes);
 
 KH_API int32_t kh_event_create(kh_event_t* out, int32_t enable_timing);
 KH_API int32_t kh_event_destroy(kh_event_t event);

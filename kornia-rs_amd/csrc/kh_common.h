@@ -24,6 +24,23 @@ inline int32_t check_launch(const char* what) {
     return e == hipSuccess ? KH_OK : fail_hip(e, what);
 }
 
+// Scratch for the few operators that need an intermediate (separable u8 resize, wide u8 blurs, per-row warp spans, Lanczos axis
+// tables).  Taken from the workspace the caller registered for this stream (kh_stream_set_workspace) when it is large enough —
+// then the call allocates nothing and can be captured into a graph — otherwise from the stream-ordered pool, as the reference's
+// adapters do per call (P/filter/cuda.rs:119, P/resize/cuda.rs:262); under stream capture the pool path is refused with the
+// number of bytes to register.  Releases pool scratch (stream-ordered) when it goes out of scope.
+struct Scratch {
+    void* ptr = nullptr;
+    kh_stream_t stream = nullptr;
+    bool pooled = false;
+    Scratch() = default;
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+    ~Scratch();
+    template <typename T> T* as() const { return static_cast<T*>(ptr); }
+};
+int32_t get_scratch(kh_stream_t stream, size_t bytes, const char* what, Scratch& out);
+
 constexpr int kWave = 64;       // gfx950 wavefront
 constexpr int kBlock = 256;     // 4 waves: one per SIMD of a CU
 constexpr int64_t kI32Max = 2147483647LL;
@@ -98,6 +115,22 @@ __device__ __forceinline__ bool xcd_tile(const XcdTiles& t, unsigned& bx, unsign
     by = fast_quot(r, t.by_row);
     bx = r - by * t.tiles_x;
     return true;
+}
+
+// Streaming stores through the buffer path.  The gfx940-family cache-policy bits travel in the `aux` operand of the raw buffer
+// builtins (1 = sc0, 2 = nt, 16 = sc1), so the COMPILER sees the store and handles hazards / waitcnts — unlike inline asm, where a
+// missing wait state between a 16-byte store and the next VALU write of its data registers corrupted 15 % of the output
+// (profiles/r02c_ubench_nv12.txt).  `sc0 sc1 nt` = write-through at system scope + non-temporal: the lines leave the L2 for memory
+// in arrival order instead of waiting for an LRU eviction.  Measured on the north-star store pattern: 4.44-4.51 ms against 4.70-4.80
+// with the plain non-temporal global store, +4 % on a flat fill (profiles/r02f_ubench_nv12.txt).
+// Offsets are 32-bit and range-checked by the hardware against `bytes` (out-of-range lanes are dropped, not faulted); keep the
+// per-plane offset in the VECTOR offset: with an SGPR soffset ROCm 7.2 schedules a packed VALU write of the data registers into
+// the slot right after the store — a gfx9 hazard — and 2 % of one plane came out wrong (profiles/r02d_ubench_nv12.txt).
+constexpr int kAuxSc0 = 1, kAuxNt = 2, kAuxSc1 = 16;
+constexpr int kAuxStream = kAuxSc0 | kAuxSc1 | kAuxNt;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);  // raw buffer, 32-bit data format
 }
 
 // Unaligned 2/4/8-byte global accesses (fine on gfx950; the compiler emits single dword/dwordx2 ops).

@@ -293,8 +293,12 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
 
     // Fast path: rolling-column kernel for odd kernels up to 15 taps whose horizontal halo fits
     // the 32-float side buffers; everything else takes the LDS-tile kernel below.
+    // Equal tap counts only: padding the shorter kernel with zero taps would multiply pixels OUTSIDE the reference's n-tap window
+    // by 0, and 0 * Inf = NaN — a non-finite pixel would poison a wider neighbourhood than separable_filter.rs does.
+    // Unequal odd sizes (rare: e.g. gaussian (3, 7)) take the tile kernel, which walks exactly kx.n / ky.n taps.  3 is the
+    // smallest rolling instantiation, so a 1-tap pair goes to the tile kernel as well.
     const int kmax = kx.n > ky.n ? kx.n : ky.n;
-    if ((kx.n & 1) && (ky.n & 1) && kmax <= 15 && (kmax / 2) * C <= 32 && !force_tile_kernel()) {
+    if (kx.n == ky.n && (kx.n & 1) && kmax >= 3 && kmax <= 15 && (kmax / 2) * C <= 32 && !force_tile_kernel()) {
         const int K = kmax < 3 ? 3 : kmax;
         TapsK px, py;
         pad_taps(px, kx, K);

@@ -26,6 +26,7 @@
 
 #include "kh_common.h"
 #include "kh_median_net.h"
+#include "kh_table_cache.h"
 
 using namespace kh;
 
@@ -388,25 +389,19 @@ void build_tables(int d, double sigma_color, double sigma_space, HostTables& t) 
 }
 
 // Device tables are cached per (device, d, sigma bits) like the resize contribution tables: uploaded with a blocking copy
-// into a fresh allocation BEFORE they are published (the reference re-uploads five small arrays on every call).
-struct DevTab { void* dev = nullptr; int n = 0, radius = 1; };
-std::mutex g_bil_mu;
-std::map<std::tuple<int, int, uint64_t, uint64_t>, DevTab> g_bil;
+// into a fresh allocation BEFORE they are published (the reference re-uploads five small arrays on every call); LRU beyond
+// 64 parameter sets, never freeing a table a launch may still read (kh_table_cache.h).
+// never destroyed: at process exit the HIP runtime may already be gone when static destructors run
+TableCache<std::tuple<int, int, uint64_t, uint64_t>>& g_bil = *new TableCache<std::tuple<int, int, uint64_t, uint64_t>>(64);
 
-int32_t get_bilateral_tab(int d, double sigma_color, double sigma_space, BilateralTab& out) {
+int32_t get_bilateral_tab(int d, double sigma_color, double sigma_space, hipStream_t stream, const char* what, BilateralTab& out, TableLease& lease) {
     int dev = 0;
     KH_HIP(hipGetDevice(&dev));
     uint64_t cb, sb;
     memcpy(&cb, &sigma_color, 8);
     memcpy(&sb, &sigma_space, 8);
     const auto key = std::make_tuple(dev, d, cb, sb);
-    std::lock_guard<std::mutex> lock(g_bil_mu);
-    auto it = g_bil.find(key);
-    if (it == g_bil.end()) {
-        if (g_bil.size() >= 64) {  // bounded: drop everything (hipFree waits for the device)
-            for (auto& kv : g_bil) (void)hipFree(kv.second.dev);
-            g_bil.clear();
-        }
+    const int32_t rc = g_bil.lookup(key, stream, what, [&](DevTable& e) -> int32_t {
         HostTables t;
         build_tables(d, sigma_color, sigma_space, t);
         const size_t n = t.dy.size();
@@ -415,25 +410,23 @@ int32_t get_bilateral_tab(int d, double sigma_color, double sigma_space, Bilater
         memcpy(&blob[256], t.space.data(), n * 4);
         for (size_t k = 0; k < n; ++k) { blob[256 + n + 2 * k] = (uint32_t)t.dy[k]; blob[256 + n + 2 * k + 1] = (uint32_t)t.dx[k]; }
         memcpy(&blob[256 + 3 * n], t.order.data(), n * 4);
-        DevTab e;
-        e.n = (int)n;
-        e.radius = t.radius;
-        KH_HIP(hipMalloc(&e.dev, blob.size() * 4));
-        const hipError_t err = hipMemcpy(e.dev, blob.data(), blob.size() * 4, hipMemcpyHostToDevice);
-        if (err != hipSuccess) {
-            (void)hipFree(e.dev);
-            return fail_hip(err, "hipMemcpy (bilateral tables)");
-        }
-        it = g_bil.emplace(key, e).first;
-    }
-    const uint32_t* base = (const uint32_t*)it->second.dev;
-    const size_t n = (size_t)it->second.n;
+        e.meta[0] = (int)n;
+        e.meta[1] = t.radius;
+        e.bytes = blob.size() * 4;
+        KH_HIP(hipMalloc(&e.dev, e.bytes));
+        const hipError_t err = hipMemcpy(e.dev, blob.data(), e.bytes, hipMemcpyHostToDevice);
+        if (err != hipSuccess) return fail_hip(err, "hipMemcpy (bilateral tables)");  // ~DevTable frees the allocation
+        return KH_OK;
+    }, lease);
+    if (rc != KH_OK) return rc;
+    const uint32_t* base = (const uint32_t*)lease->dev;
+    const size_t n = (size_t)lease->meta[0];
     out.color = (const float*)base;
     out.space = (const float*)(base + 256);
     out.taps = (const Tap*)(base + 256 + n);
     out.order = (const int*)(base + 256 + 3 * n);
     out.n = (int)n;
-    out.radius = it->second.radius;
+    out.radius = lease->meta[1];
     return KH_OK;
 }
 
@@ -615,11 +608,14 @@ int32_t kh_bilateral_filter_u8(kh_stream_t stream, const uint8_t* src, uint8_t* 
     KH_REQUIRE(bilateral_radius(d, sigma_space) <= kMaxBilateralRadius, KH_ERR_TOO_LARGE, "%s: window radius %d exceeds %d", what,
                bilateral_radius(d, sigma_space), kMaxBilateralRadius);
     BilateralTab t;
-    if (int32_t rc = get_bilateral_tab(d, sigma_color, sigma_space, t)) return rc;
+    TableLease lease;  // keeps the table alive until the launch that reads it is enqueued and recorded
+    if (int32_t rc = get_bilateral_tab(d, sigma_color, sigma_space, as_hip(stream), what, t, lease)) return rc;
     const int simd_end = cols >= 16 ? ((cols - 16) / 16) * 16 + 16 : 0;  // simd_region_end, bilateral.rs:99-106
     hipLaunchKernelGGL(bilateral_kernel, dim3(cdiv(cols, kBx), cdiv(rows, kBy), batch), dim3(kBx, kBy), 0, as_hip(stream), src, dst, (int)rows,
                        (int)cols, t, simd_end, (long long)src_stride, (long long)dst_stride);
-    return check_launch(what);
+    const int32_t rc = check_launch(what);
+    lease->used_on(as_hip(stream));
+    return rc;
 }
 
 }  // extern "C"

@@ -513,8 +513,9 @@ int32_t kh_resize_mapped_f32(kh_stream_t stream, const float* src, float* dst, i
     if (mode == KH_INTERP_LANCZOS) {  // P/resize/mod.rs:139-146
         // (dw + dh) x 28 B of stream-ordered scratch for the axis tables, as the reference adapter
         // allocates its tables/intermediate per call (P/resize/cuda.rs:151-190)
-        LzTap* tab = nullptr;
-        if (int32_t rc = kh_malloc_async((void**)&tab, sizeof(LzTap) * ((size_t)dw + dh), 0, stream)) return rc;
+        Scratch scratch;
+        if (int32_t rc = get_scratch(stream, sizeof(LzTap) * ((size_t)dw + dh), "kh_resize_f32 (lanczos)", scratch)) return rc;
+        LzTap* tab = scratch.as<LzTap>();
         hipStream_t st = as_hip(stream);
         hipLaunchKernelGGL(lanczos_axis_kernel, dim3(cdiv(dw, kBlock)), dim3(kBlock), 0, st, tab, dw, ax, bx,
                            (float)(sw - 1));
@@ -526,9 +527,7 @@ int32_t kh_resize_mapped_f32(kh_stream_t stream, const float* src, float* dst, i
             case 3: hipLaunchKernelGGL(resize_lanczos_kernel<3>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw); break;
             default: hipLaunchKernelGGL(resize_lanczos_kernel<4>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw); break;
         }
-        const int32_t rc = check_launch("kh_resize_f32 (lanczos)");
-        (void)kh_free_async(tab, stream);
-        return rc;
+        return check_launch("kh_resize_f32 (lanczos)");
     }
     KH_DISPATCH_C_MODE(resize_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, ax, bx, ay, by);
     return check_launch("kh_resize_f32");

@@ -347,19 +347,26 @@ __device__ __forceinline__ float div255_u8(float x) {
     return __builtin_fmaf(r, rc, q);
 }
 
-// One thread = 4 pixels of ONE row, all three planes: a wave writes three 1 KiB-contiguous
-// segments (3 store streams; the 4x2 variant's 6 streams measured ~8 % slower, see
-// profiles/r01b_ubench_nv12.txt).  The chroma dword is read by both rows of a pair; the second
-// read is an L2 / Infinity-Cache hit.
-constexpr int kIdBlock = 512;  // 8 KiB contiguous per plane per block; +2 % over 256 (profiles/r01b_ubench_nv12.txt)
-// XCDF (dev knob KH_NV12_XCD_FRAMES=1, off by default until measured): a 1-D launch in which XCD k — workgroups go to the 8
-// XCDs round-robin by linear id — walks frames k, k + 8, ... chunk by chunk, so one L2 sees a frame's chunks in address order
-// (both rows of a chroma pair hit the same L2; the default order puts neighbouring 8 KiB chunks on different XCDs and the
-// second chroma read, 1.06 GB of the 29.66 GB measured, goes back to the fabric).
+// One thread = 4 pixels of ONE row, all three planes: a wave writes three 1 KiB-contiguous segments (3 store streams; the 4x2
+// variant's 6 streams measured ~8 % slower, profiles/r01b_ubench_nv12.txt; two rows per thread with write-through stores 12 %
+// slower, profiles/r02f_ubench_nv12.txt).  The chroma dword is read by both rows of a pair; the second read is an L2 /
+// Infinity-Cache hit (putting the two readers on one XCD changes nothing: r02g `adj` variants).
+//
+// Round 2: loads and stores go through the buffer path with the stores write-through + non-temporal (kAuxStream, kh_common.h):
+// -5.6 % time against the non-temporal global stores of round 1.  What was measured around it on MI355X and is NOT used
+// (profiles/r02a..r02g_ubench_nv12.txt, every variant bit-identical to this kernel): staging the source through LDS with
+// 16-byte loads (block-wide K rounds -1..-17 %, wave-private +12 %), K rounds per thread with hoisted loads (+2 % at best, -12 %
+// typical), persistent block-stride loops (-25..-48 %), one plane per wave through an LDS transpose (-19 %), one store per
+// thread with the planes on different waves (-33 %), XCD-per-frame block order (-4 %), frame-stride / base-offset padding
+// (+-0.5 %), non-temporal LOADS (-16 %), limiting occupancy through LDS (0..-25 %).  Ceilings on the same boxes: the same three
+// plane stores with no loads or decode 4.04 ms, a flat fill of the same bytes 3.55-3.63 ms, this kernel 4.44-4.51 ms.
+constexpr int kIdBlock = 512;  // 8 KiB contiguous per plane per block; 256 / 384 / 640 / 768 / 1024 are 2-11 % slower (r02e, r02f)
+// XCDF (dev knob KH_NV12_XCD_FRAMES=1): a 1-D launch in which XCD k walks frames k, k + 8, ... chunk by chunk.  Measured in
+// round 2: 4.84 ms against 4.65 ms for the default order (profiles/r02a_ab.log) — kept only as the A/B it was, off by default.
 struct XcdFrames { FastDiv by_bpf; unsigned bpf, nframes; };
-template <bool NT, bool XCDF>
+template <bool XCDF>
 __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
-    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a, XcdFrames xf) {
+    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a, XcdFrames xf, FastDiv by_wq) {
     const int wq = a.src_w >> 2;     // 4-pixel groups per row
     const int groups = wq * a.src_h;
     unsigned chunk = blockIdx.x, frame = blockIdx.y;
@@ -371,18 +378,15 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
     }
     const int g = chunk * kIdBlock + threadIdx.x;
     if (g >= groups) return;
-    const uint8_t* src = src_base + (long long)frame * a.src_frame_stride;
-    float* dst = dst_base + (long long)frame * a.dst_frame_stride;
+    const int plane = a.src_w * a.src_h;           // host-checked: 12 * plane < 2^31
+    // one V# per frame: source = plane * 3 / 2 bytes, destination = 3 planes of f32
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(src_base + (long long)frame * a.src_frame_stride, (uint32_t)(plane + plane / 2));
+    const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_base + (long long)frame * a.dst_frame_stride, (uint32_t)(12 * plane));
 
-    const int r = g / wq;
+    const int r = (int)fast_quot((uint32_t)g, by_wq);
     const int xq = g - r * wq;
-    const int w = a.src_w;
-    const long long plane = (long long)w * a.src_h;
-    const long long off = (long long)r * w + 4 * xq;
-
-    const uint32_t y4 = *reinterpret_cast<const uint32_t*>(src + off);
-    const uint32_t uv4 =
-        *reinterpret_cast<const uint32_t*>(src + plane + (long long)(r >> 1) * w + 4 * xq);
+    const uint32_t y4 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, 4 * g, 0, 0);
+    const uint32_t uv4 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, plane + (r >> 1) * a.src_w + 4 * xq, 0, 0);
 
     // Chroma terms shared by each pixel pair; integer adds are exact, so hoisting the rounding
     // constant gives the same value as (yy + c*u + half).
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
         tr[k] = kCVR * v + kHalf20;
     }
 
-    float o[3][4];
+    f32x4 o[3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int yy = max((int)((y4 >> (8 * j)) & 0xFFu) - 16, 0) * kCY;
@@ -409,8 +413,8 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
         o[2][j] = (div255_u8(bb) - a.m2) * a.is2;
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        store4<NT>(dst + c * plane + off, o[c][0], o[c][1], o[c][2], o[c][3]);
+    for (int c = 0; c < 3; ++c)  // plane offset in the vector offset, never in an SGPR soffset (kh_common.h)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[c]), rdst, 16 * g + c * (4 * plane), 0, kAuxStream);
 }
 
 // Does quot3 reproduce IEEE division for every (o - pad) / scale the launch will evaluate?  dst_w +
@@ -442,6 +446,7 @@ bool identity_fast_path(const kh_preprocess_params* p, const uint8_t* src, const
            (p->sampling == KH_SAMPLE_BILINEAR || p->sampling == KH_SAMPLE_NEAREST) &&
            p->scale_x == 1.0f && p->scale_y == 1.0f && p->pad_x == 0.0f && p->pad_y == 0.0f &&
            p->dst_w == p->src_w && p->dst_h == p->src_h && (p->src_w % 4) == 0 &&
+           (int64_t)p->src_w * p->src_h * 12 <= kI32Max &&  // 32-bit buffer offsets within one frame's three planes
            (reinterpret_cast<uintptr_t>(src) % 4) == 0 && (p->src_frame_stride % 4) == 0 &&
            (reinterpret_cast<uintptr_t>(dst) % 16) == 0 && (p->dst_frame_stride % 4) == 0;
 }
@@ -557,10 +562,11 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
         const uint64_t remapped = (uint64_t)bpf * kXcds * cdiv(p->nframes, kXcds);
         if (xcd_frames && remapped < 0x7ff00000ull) {
             const XcdFrames xf{fast_div(bpf), bpf, (unsigned)p->nframes};
-            hipLaunchKernelGGL((preprocess_nv12_identity<true, true>), dim3((unsigned)remapped), dim3(kIdBlock), 0, s, src, (float*)dst, a, xf);
+            hipLaunchKernelGGL((preprocess_nv12_identity<true>), dim3((unsigned)remapped), dim3(kIdBlock), 0, s, src, (float*)dst, a, xf,
+                               fast_div((uint32_t)(p->src_w / 4)));
         } else {
-            hipLaunchKernelGGL((preprocess_nv12_identity<true, false>), dim3(bpf, (unsigned)p->nframes), dim3(kIdBlock), 0, s, src, (float*)dst, a,
-                               XcdFrames{});
+            hipLaunchKernelGGL((preprocess_nv12_identity<false>), dim3(bpf, (unsigned)p->nframes), dim3(kIdBlock), 0, s, src, (float*)dst, a,
+                               XcdFrames{}, fast_div((uint32_t)(p->src_w / 4)));
         }
         return check_launch("preprocess_nv12_identity");
     }

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "kh_common.h"
+#include "kh_table_cache.h"
 
 using namespace kh;
 
@@ -368,42 +369,33 @@ int build_contribs(int src_size, int dst_size, int filt, bool antialias, std::ve
     return ksize;
 }
 
-// Contribution tables live on the device for the life of the process, keyed like the reference's
-// per-(device, geometry) cache.  A table is uploaded with a blocking copy into a fresh allocation
-// BEFORE it is published, so no stream ever observes a half-written table.
-struct TabEntry { void* dev = nullptr; int k = 0; int dst = 0; };
-std::mutex g_tab_mu;
-std::map<std::tuple<int, int, int, int, int>, TabEntry> g_tabs;
+// Contribution tables live on the device, keyed like the reference's per-(device, geometry) cache (P/resize/cuda.rs:151-190).
+// A table is uploaded with a blocking copy into a fresh allocation BEFORE it is published, so no stream ever observes a
+// half-written table; eviction (LRU beyond 256 geometries) never frees a table a launch may still read — kh_table_cache.h.
+// never destroyed: at process exit the HIP runtime may already be gone when static destructors run
+TableCache<std::tuple<int, int, int, int, int>>& g_tabs = *new TableCache<std::tuple<int, int, int, int, int>>(256);
 
-int32_t get_tab(int src_size, int dst_size, int filt, bool aa, SepTab& out) {
+int32_t get_tab(int src_size, int dst_size, int filt, bool aa, hipStream_t stream, const char* what, SepTab& out, TableLease& lease) {
     int dev = 0;
     KH_HIP(hipGetDevice(&dev));
     const auto key = std::make_tuple(dev, src_size, dst_size, filt, (int)aa);
-    std::lock_guard<std::mutex> lock(g_tab_mu);
-    auto it = g_tabs.find(key);
-    if (it == g_tabs.end()) {
-        if (g_tabs.size() >= 256) {  // bounded: drop everything (hipFree waits for the device)
-            for (auto& kv : g_tabs) (void)hipFree(kv.second.dev);
-            g_tabs.clear();
-        }
+    const int32_t rc = g_tabs.lookup(key, stream, what, [&](DevTable& t) -> int32_t {
         std::vector<int32_t> ofs;
         std::vector<int16_t> w;
-        TabEntry e;
-        e.k = build_contribs(src_size, dst_size, filt, aa, ofs, w);
-        e.dst = dst_size;
+        t.meta[0] = build_contribs(src_size, dst_size, filt, aa, ofs, w);
+        t.meta[1] = dst_size;
         const size_t ofs_bytes = sizeof(int32_t) * ofs.size(), w_bytes = sizeof(int16_t) * w.size();
-        KH_HIP(hipMalloc(&e.dev, ofs_bytes + w_bytes));
-        hipError_t err = hipMemcpy(e.dev, ofs.data(), ofs_bytes, hipMemcpyHostToDevice);
-        if (err == hipSuccess) err = hipMemcpy((char*)e.dev + ofs_bytes, w.data(), w_bytes, hipMemcpyHostToDevice);
-        if (err != hipSuccess) {
-            (void)hipFree(e.dev);
-            return fail_hip(err, "hipMemcpy (resize contribution table)");
-        }
-        it = g_tabs.emplace(key, e).first;
-    }
-    out.ofs = (const int32_t*)it->second.dev;
-    out.w = (const int16_t*)((const char*)it->second.dev + sizeof(int32_t) * (size_t)it->second.dst);
-    out.k = it->second.k;
+        t.bytes = ofs_bytes + w_bytes;
+        KH_HIP(hipMalloc(&t.dev, t.bytes));
+        hipError_t err = hipMemcpy(t.dev, ofs.data(), ofs_bytes, hipMemcpyHostToDevice);
+        if (err == hipSuccess) err = hipMemcpy((char*)t.dev + ofs_bytes, w.data(), w_bytes, hipMemcpyHostToDevice);
+        if (err != hipSuccess) return fail_hip(err, "hipMemcpy (resize contribution table)");  // ~DevTable frees the allocation
+        return KH_OK;
+    }, lease);
+    if (rc != KH_OK) return rc;
+    out.ofs = (const int32_t*)lease->dev;
+    out.w = (const int16_t*)((const char*)lease->dev + sizeof(int32_t) * (size_t)lease->meta[1]);
+    out.k = lease->meta[0];
     return KH_OK;
 }
 
@@ -480,17 +472,16 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     } else {
         const int filt = mode == KH_INTERP_BICUBIC ? 0 : 1;
         SepTab tx, ty;
-        if (int32_t rc = get_tab(sw, dw, filt, antialias != 0, tx)) return rc;
-        if (int32_t rc = get_tab(sh, dh, filt, antialias != 0, ty)) return rc;
+        TableLease lx, ly;  // keep both tables alive until the launches that read them are enqueued (and recorded below)
+        if (int32_t rc = get_tab(sw, dw, filt, antialias != 0, st, what, tx, lx)) return rc;
+        if (int32_t rc = get_tab(sh, dh, filt, antialias != 0, st, what, ty, ly)) return rc;
         const int hrow = dw * channels;
-        int16_t* hbuf = nullptr;  // dst_w x src_h i16 intermediate, stream-ordered (P/resize/cuda.rs:262)
-        if (int32_t rc = kh_malloc_async((void**)&hbuf, sizeof(int16_t) * (size_t)hrow * sh * batch, 0, stream)) return rc;
+        Scratch scratch;  // dst_w x src_h i16 intermediate (P/resize/cuda.rs:262): caller workspace or stream-ordered pool
+        if (int32_t rc = get_scratch(stream, sizeof(int16_t) * (size_t)hrow * sh * batch, what, scratch)) return rc;
+        int16_t* hbuf = scratch.as<int16_t>();
         Rz ah = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, dw, sh);
         Rz av = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, hrow, dh);
-        if (ah.tiles.total == 0 || av.tiles.total == 0) {
-            (void)kh_free_async(hbuf, stream);
-            return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-        }
+        if (ah.tiles.total == 0 || av.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         switch (channels) {
             case 1: hipLaunchKernelGGL(sep_h_u8_kernel<1>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
             case 3: hipLaunchKernelGGL(sep_h_u8_kernel<3>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
@@ -498,7 +489,7 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
         }
         hipLaunchKernelGGL(sep_v_u8_kernel, xcd_grid(av.tiles), blk, 0, st, av, (const int16_t*)hbuf, ty, hrow);
         const int32_t rc = check_launch(what);
-        (void)kh_free_async(hbuf, stream);
+        lx->used_on(st); ly->used_on(st);
         return rc;
     }
     return check_launch(what);
@@ -529,19 +520,18 @@ int32_t kh_resize_normalize_to_chw_u8_f32(kh_stream_t stream, const uint8_t* src
     } else {
         const int filt = mode == KH_INTERP_BICUBIC ? 0 : 1;
         SepTab tx, ty;
-        if (int32_t rc = get_tab(sw, dw, filt, antialias != 0, tx)) return rc;
-        if (int32_t rc = get_tab(sh, dh, filt, antialias != 0, ty)) return rc;
-        int16_t* hbuf = nullptr;
-        if (int32_t rc = kh_malloc_async((void**)&hbuf, sizeof(int16_t) * (size_t)dw * 3 * sh * batch, 0, stream)) return rc;
+        TableLease lx, ly;  // keep both tables alive until the launches that read them are enqueued (and recorded below)
+        if (int32_t rc = get_tab(sw, dw, filt, antialias != 0, st, what, tx, lx)) return rc;
+        if (int32_t rc = get_tab(sh, dh, filt, antialias != 0, st, what, ty, ly)) return rc;
+        Scratch scratch;
+        if (int32_t rc = get_scratch(stream, sizeof(int16_t) * (size_t)dw * 3 * sh * batch, what, scratch)) return rc;
+        int16_t* hbuf = scratch.as<int16_t>();
         Rz ah = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, dw, sh);
-        if (ah.tiles.total == 0) {
-            (void)kh_free_async(hbuf, stream);
-            return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-        }
+        if (ah.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         hipLaunchKernelGGL(sep_h_u8_kernel<3>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx);
         hipLaunchKernelGGL(fused_sep_v_kernel, grid, blk, 0, st, a, (const int16_t*)hbuf, ty, n);
         const int32_t rc = check_launch(what);
-        (void)kh_free_async(hbuf, stream);
+        lx->used_on(st); ly->used_on(st);
         return rc;
     }
     return check_launch(what);

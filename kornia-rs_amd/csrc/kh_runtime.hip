@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <set>
 #include <string>
 
@@ -38,6 +40,38 @@ int32_t fail_hip(hipError_t e, const char* what) {
     return KH_ERR_HIP;
 }
 
+namespace {
+struct Workspace { void* ptr; size_t bytes; };
+std::mutex g_ws_mu;
+std::map<kh_stream_t, Workspace>& workspaces() { static auto& m = *new std::map<kh_stream_t, Workspace>(); return m; }
+thread_local size_t g_last_scratch = 0;
+}  // namespace
+
+Scratch::~Scratch() {
+    if (pooled && ptr) (void)hipFreeAsync(ptr, as_hip(stream));
+}
+
+int32_t get_scratch(kh_stream_t stream, size_t bytes, const char* what, Scratch& out) {
+    g_last_scratch = bytes;
+    out.stream = stream;
+    if (bytes == 0) return KH_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mu);
+        auto it = workspaces().find(stream);
+        if (it != workspaces().end() && it->second.bytes >= bytes) {
+            out.ptr = it->second.ptr;  // caller-owned: nothing to allocate, nothing to free
+            return KH_OK;
+        }
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(as_hip(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(KH_ERR_INVALID_ARG, "%s needs %zu bytes of scratch and the stream is being captured: captured work must not allocate — "
+                                        "register a device buffer of at least that size with kh_stream_set_workspace before the capture", what, bytes);
+    if (int32_t rc = kh_malloc_async(&out.ptr, bytes, 0, stream)) return rc;
+    out.pooled = true;
+    return KH_OK;
+}
+
 }  // namespace kh
 
 using namespace kh;
@@ -55,6 +89,11 @@ size_t kh_last_error(char* buf, size_t cap) {
 }
 
 const char* kh_version(void) { return "kornia-hip 0.1.0 (gfx950)"; }
+
+// A DLManagedTensor deleter that does nothing.  The Python host swaps it into every still-exported tensor when the
+// interpreter starts to finalise: a consumer (e.g. a torch tensor destroyed during shutdown) may call the deleter after the
+// Python callback it was exported with can no longer run; the process is exiting, so the memory is simply not released.
+void kh_dlpack_noop_deleter(void* managed_tensor) { (void)managed_tensor; }
 
 // test hook: the launch-constant division used to decode tile ids (kh_common.h::FastDiv), on the host
 uint32_t kh_debug_fast_quot(uint32_t n, uint32_t d) { return kh::fast_quot(n, kh::fast_div(d)); }
@@ -298,6 +337,20 @@ int32_t kh_mempool_set_release_threshold(int32_t device, uint64_t bytes) {
     KH_HIP(hipDeviceGetDefaultMemPool(&pool, device));
     uint64_t v = bytes;
     KH_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &v));
+    return KH_OK;
+}
+
+int32_t kh_stream_set_workspace(kh_stream_t stream, void* device_ptr, size_t bytes) {
+    KH_REQUIRE((device_ptr != nullptr) == (bytes != 0), KH_ERR_INVALID_ARG, "kh_stream_set_workspace: pointer and size must both be set, or both zero to unregister");
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    if (!device_ptr) workspaces().erase(stream);
+    else workspaces()[stream] = Workspace{device_ptr, bytes};
+    return KH_OK;
+}
+
+int32_t kh_last_workspace_bytes(size_t* bytes) {
+    KH_REQUIRE(bytes, KH_ERR_INVALID_ARG, "kh_last_workspace_bytes: null out pointer");
+    *bytes = g_last_scratch;
     return KH_OK;
 }
 

@@ -292,8 +292,9 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
     }
     // two passes through stream-ordered scratch (P/filter/cuda.rs:119)
     const size_t img = (size_t)rows * rowlen;
-    uint8_t* tmp = nullptr;
-    if (int32_t rc = kh_malloc_async((void**)&tmp, img * batch, 0, stream)) return rc;
+    Scratch scratch;
+    if (int32_t rc = get_scratch(stream, img * batch, what, scratch)) return rc;
+    uint8_t* tmp = scratch.as<uint8_t>();
     Taps64 tx{}, tyv{};
     tx.n = nx; tyv.n = ny;
     for (int i = 0; i < nx; ++i) tx.k[i] = qx[i];
@@ -310,9 +311,7 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         hipLaunchKernelGGL((blur_u8_pass_kernel<false, false>), grid, dim3(kBlock), 0, st, (const uint8_t*)tmp, dst, cols,
                            rows, C, (long long)img, (long long)ds, tyv);
     }
-    const int32_t rc = check_launch(what);
-    (void)kh_free_async(tmp, stream);
-    return rc;
+    return check_launch(what);
 }
 
 // `two_ok`: the Q10 gathers take 2-channel images too (the reference instantiates them per channel count,
@@ -673,13 +672,12 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     const int dsx_q = f2i_sat(mi.m[0] * 65536.0f), dsy_q = f2i_sat(mi.m[3] * 65536.0f);
     const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
     KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_affine_u8: batch x tiles exceeds one launch");
-    AffineRow* rows = nullptr;  // per-row spans, stream-ordered scratch shared by the batch
-    if (int32_t rc = kh_malloc_async((void**)&rows, sizeof(AffineRow) * (size_t)dh, 0, stream)) return rc;
+    Scratch scratch;  // per-row spans shared by the batch: caller workspace or stream-ordered pool
+    if (int32_t rc = get_scratch(stream, sizeof(AffineRow) * (size_t)dh, "kh_warp_affine_u8", scratch)) return rc;
+    AffineRow* rows = scratch.as<AffineRow>();
     hipLaunchKernelGGL(affine_rows_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, as_hip(stream), rows, dw, dh, sw, sh, mi);
     KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const AffineRow*)rows, dsx_q, dsy_q);
-    const int32_t rc = check_launch("kh_warp_affine_u8");
-    (void)kh_free_async(rows, stream);
-    return rc;
+    return check_launch("kh_warp_affine_u8");
 }
 
 int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh,
@@ -693,13 +691,12 @@ int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, uint8_t* 
     if (batch == 0) return KH_OK;
     const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
     KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_perspective_u8: batch x tiles exceeds one launch");
-    PerspRow* rows = nullptr;
-    if (int32_t rc = kh_malloc_async((void**)&rows, sizeof(PerspRow) * (size_t)dh, 0, stream)) return rc;
+    Scratch scratch;
+    if (int32_t rc = get_scratch(stream, sizeof(PerspRow) * (size_t)dh, "kh_warp_perspective_u8", scratch)) return rc;
+    PerspRow* rows = scratch.as<PerspRow>();
     hipLaunchKernelGGL(persp_rows_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, as_hip(stream), rows, dw, dh, sw, sh, inv);
     KH_DISPATCH_C(warp_perspective_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const PerspRow*)rows);
-    const int32_t rc = check_launch("kh_warp_perspective_u8");
-    (void)kh_free_async(rows, stream);
-    return rc;
+    return check_launch("kh_warp_perspective_u8");
 }
 
 }  // extern "C"

@@ -84,6 +84,7 @@ SIGNATURES = {
     "kh_debug_fast_quot": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "kh_version": (C.c_char_p, []),
     "kh_hip_runtime_images": (_i32, [C.c_char_p, C.c_size_t]),
+    "kh_dlpack_noop_deleter": (None, [_vp]),
     "kh_device_count": (_i32, [_P(_i32)]),
     "kh_set_device": (_i32, [_i32]),
     "kh_get_device": (_i32, [_P(_i32)]),
@@ -97,6 +98,8 @@ SIGNATURES = {
     "kh_stream_destroy": (_i32, [_vp]),
     "kh_stream_synchronize": (_i32, [_vp]),
     "kh_stream_wait_event": (_i32, [_vp, _vp]),
+    "kh_stream_set_workspace": (_i32, [_vp, _vp, _sz]),
+    "kh_last_workspace_bytes": (_i32, [_P(_sz)]),
     "kh_event_create": (_i32, [_P(_vp), _i32]),
     "kh_event_destroy": (_i32, [_vp]),
     "kh_event_record": (_i32, [_vp, _vp]),

@@ -75,6 +75,23 @@ def _deleter(mt_ptr):
         release_count += 1
 
 
+def _neutralise_live_exports():
+    """atexit: a consumer may release an exported tensor AFTER the interpreter has begun to finalise (a torch tensor that is
+    still alive at shutdown was seen to crash the process with SIGSEGV in the deleter callback, profiles/r02a_runtimes.log).
+    Every tensor still exported gets the C no-op deleter, and its struct / shape / owner are deliberately leaked so the
+    consumer's pointer stays valid until the process ends."""
+    from ._ffi import lib
+    noop = C.cast(lib.kh_dlpack_noop_deleter, _DELETER)
+    for mt, shp, owner in list(_live.values()):
+        mt.deleter = noop
+        for obj in (mt, shp, owner):
+            C.pythonapi.Py_IncRef(C.py_object(obj))
+
+
+import atexit  # noqa: E402
+
+atexit.register(_neutralise_live_exports)
+
 _CAPSULE_DTOR = C.CFUNCTYPE(None, C.c_void_p)
 
 

@@ -111,6 +111,16 @@ class Stream:
     def synchronize(self) -> None:
         check(lib.kh_stream_synchronize(self._handle))
 
+    def set_workspace(self, buf: Optional["DeviceBuffer"]) -> None:
+        """Register ``buf`` as the scratch the operators with an intermediate (separable u8 resize, wide u8 blurs, u8 warps,
+        Lanczos resize) use on this stream instead of allocating — what makes them capturable (``kh_stream_set_workspace``).
+        ``None`` unregisters.  The stream keeps the buffer alive."""
+        if buf is None:
+            check(lib.kh_stream_set_workspace(self._handle, None, 0))
+        else:
+            check(lib.kh_stream_set_workspace(self._handle, buf.ptr, buf.nbytes))
+        self._workspace = buf
+
     @property
     def cuda_stream_ptr(self) -> int:
         return self._handle
@@ -328,6 +338,13 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def last_workspace_bytes() -> int:
+    """Scratch the last compute call on this thread asked for (0 = none): size ``Stream.set_workspace`` with it."""
+    n = C.c_size_t(0)
+    check(lib.kh_last_workspace_bytes(C.byref(n)))
+    return int(n.value)
 
 
 def runtime_info() -> dict:

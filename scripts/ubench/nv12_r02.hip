@@ -53,6 +53,25 @@ __device__ __forceinline__ void decode4(uint32_t y4, uint32_t uv4, const Args& a
     }
 }
 
+// one channel of decode4 (C: 0 = R, 1 = G, 2 = B)
+template <int C>
+__device__ __forceinline__ f32x4 decode1(uint32_t y4, uint32_t uv4, const Args& a) {
+    int t[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = (int)((uv4 >> (16 * k)) & 0xFFu) - 128, v = (int)((uv4 >> (16 * k + 8)) & 0xFFu) - 128;
+        t[k] = C == 0 ? kCVR * v + kHalf20 : (C == 1 ? kCUG * u + kCVG * v + kHalf20 : kCUB * u + kHalf20);
+    }
+    const float m = C == 0 ? a.m0 : (C == 1 ? a.m1 : a.m2), is = C == 0 ? a.is0 : (C == 1 ? a.is1 : a.is2);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int yy = max((int)((y4 >> (8 * j)) & 0xFFu) - 16, 0) * kCY;
+        o[j] = norm1(clamp255((yy + t[j >> 1]) >> 20), m, is);
+    }
+    return o;
+}
+
 // ---- prod: production mapping.  XF: XCD k walks frames k, k+8, ... (1-D launch)
 template <int BLOCK, bool NT, bool XF>
 __global__ __launch_bounds__(BLOCK) void k_prod(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a, int bpf, int nframes) {
@@ -210,6 +229,209 @@ __global__ __launch_bounds__(768) void k_tstore(const uint8_t* __restrict__ sb, 
     }
 }
 
+
+// ---- wstage: a WAVE stages K*64 contiguous quads: one 16-byte Y load + one 16-byte UV load per lane (1 KiB per wave-load,
+// 4x fewer and 4x larger read requests than prod), transposed through a wave-private LDS slice (no block barrier), then K
+// rounds of {2 ds_read_b32, decode, 3 stores}: the wave writes K KiB CONTIGUOUS per plane.  K == 4 only (16 B = 4 quads per lane).
+template <int BLOCK, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_wstage(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    __shared__ uint32_t lds[BLOCK / 64][2][256];
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * (BLOCK / 64) + wv) * 256;          // first quad of this wave
+    if (g0 >= groups) return;
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const long long plane = (long long)a.w * a.h;
+    {
+        const int g = min(g0 + 4 * lane, groups - 4);               // 4 quads per lane, never straddling a row (wq % 4 == 0)
+        const int r = g / wq, xq = g - r * wq;
+        const u32x4 y16 = *(const u32x4*)(src + 4ll * g);
+        const u32x4 uv16 = *(const u32x4*)(src + plane + (long long)(r >> 1) * a.w + 4 * xq);
+        *(u32x4*)&lds[wv][0][4 * lane] = y16;
+        *(u32x4*)&lds[wv][1][4 * lane] = uv16;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = 64 * k + lane, g = g0 + q;
+        if (g < groups) {
+            f32x4 o[3];
+            decode4(lds[wv][0][q], lds[wv][1][q], a, o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) st4<NT>(dst + c * plane + 4ll * g, o[c]);
+        }
+    }
+}
+
+// ---- plane1: ONE store per thread.  768-thread blocks: wave w decodes plane (w % 3) of pixel group (w / 3); the three waves of a
+// group read the same 512 source bytes (L1 hits) and each keeps only its own channel.
+template <bool NT>
+__global__ __launch_bounds__(768) void k_plane1(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c = wv % 3, grp = wv / 3;
+    const int g = blockIdx.x * 256 + grp * 64 + lane;
+    if (g >= groups) return;
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const long long plane = (long long)a.w * a.h;
+    const int r = g / wq, xq = g - r * wq;
+    const uint32_t y4 = *(const uint32_t*)(src + 4ll * g);
+    const uint32_t uv4 = *(const uint32_t*)(src + plane + (long long)(r >> 1) * a.w + 4 * xq);
+    f32x4 v;
+    if (c == 0) v = decode1<0>(y4, uv4, a); else if (c == 1) v = decode1<1>(y4, uv4, a); else v = decode1<2>(y4, uv4, a);  // wave-uniform branch
+    st4<NT>(dst + c * plane + 4ll * g, v);
+}
+
+// ---- prod with explicit cache-policy bits on the stores (inline asm; LLVM's nontemporal store emits "nt" only)
+// s_nop: the compiler cannot see the store inside the asm, so it does not insert the wait state gfx9 needs between a >64-bit VMEM
+// store and a VALU write of its data registers (r02c: 15 % of the elements came out wrong without it)
+#define ASM_STORE(FLAGS) asm volatile("global_store_dwordx4 %0, %1, off " FLAGS "\n\ts_nop 2" :: "v"(p), "v"(v) : "memory")
+template <int FLAV> __device__ __forceinline__ void st4_flav(float* p, f32x4 v) {
+    if constexpr (FLAV == 0) ASM_STORE("");
+    else if constexpr (FLAV == 1) ASM_STORE("nt");
+    else if constexpr (FLAV == 2) ASM_STORE("sc1");
+    else if constexpr (FLAV == 3) ASM_STORE("sc0 sc1");
+    else if constexpr (FLAV == 4) ASM_STORE("sc1 nt");
+    else if constexpr (FLAV == 5) ASM_STORE("sc0 sc1 nt");
+    else ASM_STORE("sc0 nt");
+}
+template <int BLOCK, int FLAV>
+__global__ __launch_bounds__(BLOCK) void k_prod_flav(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int g = blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= groups) return;
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const int r = g / wq, xq = g - r * wq;
+    const long long plane = (long long)a.w * a.h;
+    const uint32_t y4 = *(const uint32_t*)(src + 4ll * g);
+    const uint32_t uv4 = *(const uint32_t*)(src + plane + (long long)(r >> 1) * a.w + 4 * xq);
+    f32x4 o[3];
+    decode4(y4, uv4, a, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st4_flav<FLAV>(dst + c * plane + 4ll * g, o[c]);
+}
+template <int FLAV>
+__global__ __launch_bounds__(256) void f_flat_flav(float* __restrict__ db, long long n4) {
+    long long i = (long long)blockIdx.y * gridDim.x * 256 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) st4_flav<FLAV>(db + 4 * i, f32x4{1.f, 2.f, 3.f, 4.f});
+}
+// F5: the plane1 store shape without loads / decode: one store per thread, wave -> plane (w % 3)
+template <bool NT>
+__global__ __launch_bounds__(768) void f_plane1(float* __restrict__ db, Args a) {
+    const int groups = (a.w >> 2) * a.h;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = wv % 3, grp = wv / 3;
+    const int g = blockIdx.x * 256 + grp * 64 + lane;
+    if (g >= groups) return;
+    st4<NT>(db + (long long)blockIdx.y * a.dfs + c * (long long)a.w * a.h + 4ll * g, f32x4{1.f, 2.f, 3.f, (float)c});
+}
+template <int BLOCK, bool NT>  // F6: flat fill at another block size
+__global__ __launch_bounds__(BLOCK) void f_flat_b(float* __restrict__ db, long long n4) {
+    long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
+    if (i < n4) st4<NT>(db + 4 * i, f32x4{1.f, 2.f, 3.f, 4.f});
+}
+
+
+// ---- prod with raw buffer stores: the cache-policy bits go through the compiler (aux: 1 = sc0, 2 = nt, 16 = sc1), hazards and
+// waitcnts handled; one V# per frame (24.9 MB < 4 GiB), out-of-range lanes are dropped by the hardware range check.
+template <int BLOCK, int AUX, int K>
+__global__ __launch_bounds__(BLOCK) void k_prod_buf(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const long long plane = (long long)a.w * a.h;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(3 * plane * 4), 0x00020000);
+    uint32_t y4[K], uv4[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int g = min((int)(blockIdx.x * (BLOCK * K) + k * BLOCK + threadIdx.x), groups - 1);
+        const int r = g / wq, xq = g - r * wq;
+        y4[k] = *(const uint32_t*)(src + 4ll * g);
+        uv4[k] = *(const uint32_t*)(src + plane + (long long)(r >> 1) * a.w + 4 * xq);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int g = blockIdx.x * (BLOCK * K) + k * BLOCK + threadIdx.x;
+        f32x4 o[3];
+        decode4(y4[k], uv4[k], a, o);
+        const int off = g < groups ? 16 * g : 0x7fffffff - 2 * (int)(plane * 4);  // out of range: dropped
+        // The plane offset goes into the VECTOR offset: with an SGPR soffset the compiler (ROCm 7.2) lets a packed VALU write the
+        // store's data registers in the very next slot — a gfx9 hazard for > 64-bit MUBUF stores with an SGPR offset — and 2 % of
+        // the G plane came out wrong (r02d).
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[c]), rs, off + (int)(c * plane * 4), 0, AUX);
+    }
+}
+
+// ---- prod with buffer stores AND buffer loads with their own cache policy (LAUX), optionally two rows per thread (ROWS = 2: the
+// chroma dword is loaded once for both rows; 6 stores per thread)
+template <int BLOCK, int AUX, int LAUX, int ROWS>
+__global__ __launch_bounds__(BLOCK) void k_prod_buf2(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    const int wq = a.w >> 2, groups = wq * (a.h / ROWS);
+    const int g = blockIdx.x * BLOCK + threadIdx.x;
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const int plane = a.w * a.h;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 3 * plane * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, plane * 3 / 2, 0x00020000);
+    const int gc = min(g, groups - 1);
+    const int rp = gc / wq, xq = gc - rp * wq;
+    uint32_t y4[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) y4[r] = __builtin_amdgcn_raw_buffer_load_b32(rl, (ROWS * rp + r) * a.w + 4 * xq, 0, LAUX);
+    const uint32_t uv4 = __builtin_amdgcn_raw_buffer_load_b32(rl, plane + ((ROWS * rp) >> 1) * a.w + 4 * xq, 0, LAUX);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        f32x4 o[3];
+        decode4(y4[r], uv4, a, o);
+        const int off = g < groups ? 4 * ((ROWS * rp + r) * a.w + 4 * xq) : 0x7fffffff - 2 * plane * 4;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[c]), rs, off + c * plane * 4, 0, AUX);
+    }
+}
+template <int BLOCK, int AUX>  // F1 with buffer stores + cache policy
+__global__ __launch_bounds__(BLOCK) void f_3plane_buf(float* __restrict__ db, Args a) {
+    const int groups = (a.w >> 2) * a.h, g = blockIdx.x * BLOCK + threadIdx.x;
+    const int plane = a.w * a.h;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(db + (long long)blockIdx.y * a.dfs, 0, 3 * plane * 4, 0x00020000);
+    const int off = g < groups ? 16 * g : 0x7fffffff - 2 * plane * 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{1u, 2u, 3u, (unsigned)c}, rs, off + c * plane * 4, 0, AUX);
+}
+
+// ---- k_prod_buf3: k_prod_buf2 (1 row) + chunk permutation so that ADJ adjacent chunks (which share chroma rows) run on the
+// same XCD at about the same time: blocks go to XCDs round-robin, so block b = (ADJ*8)*q + x + 8*p (x = XCD, p < ADJ) takes
+// chunk (ADJ*8)*q + ADJ*x + p.  ADJ = 1 is the identity.  Dynamic LDS (unused) limits occupancy for the A/B.
+template <int BLOCK, int AUX, int ADJ>
+__global__ __launch_bounds__(BLOCK) void k_prod_buf3(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a, int nchunks) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    int chunk = blockIdx.x;
+    if constexpr (ADJ > 1) {
+        const int grp = chunk / (8 * ADJ), rem = chunk - grp * (8 * ADJ), x = rem & 7, p = rem >> 3;
+        const int c2 = grp * (8 * ADJ) + ADJ * x + p;
+        chunk = (grp + 1) * (8 * ADJ) <= nchunks ? c2 : chunk;   // the ragged tail keeps the identity order
+    }
+    const int g = chunk * BLOCK + threadIdx.x;
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const int plane = a.w * a.h;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 3 * plane * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, plane * 3 / 2, 0x00020000);
+    const int gc = min(g, groups - 1);
+    const int r = gc / wq, xq = gc - r * wq;
+    const uint32_t y4 = __builtin_amdgcn_raw_buffer_load_b32(rl, 4 * gc, 0, 0);
+    const uint32_t uv4 = __builtin_amdgcn_raw_buffer_load_b32(rl, plane + (r >> 1) * a.w + 4 * xq, 0, 0);
+    f32x4 o[3];
+    decode4(y4, uv4, a, o);
+    const int off = g < groups ? 16 * g : 0x7fffffff - 2 * plane * 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[c]), rs, off + c * plane * 4, 0, AUX);
+}
 // ---- fills
 template <bool NT>
 __global__ __launch_bounds__(256) void f_flat(float* __restrict__ db, long long n4) {
@@ -273,9 +495,9 @@ __global__ __launch_bounds__(256) void r_wide(const uint8_t* __restrict__ sb, fl
 
 __global__ void k_diff(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, long long n, unsigned long long* out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
-    unsigned long long bad = 0;
-    for (; i < n; i += stride) bad += a[i] != b[i];
-    if (bad) atomicAdd(out, bad);
+    unsigned long long bad = 0, first = ~0ull;
+    for (; i < n; i += stride) if (a[i] != b[i]) { ++bad; if ((unsigned long long)i < first) first = i; }
+    if (bad) { atomicAdd(out, bad); atomicMin(out + 1, first); }
 }
 
 int main(int argc, char** argv) {
@@ -292,7 +514,7 @@ int main(int argc, char** argv) {
     Args a{W, H, 0.485f, 0.456f, 0.406f, 1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f, (long long)fb, (long long)ob};
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    unsigned long long* dbad; CK(hipMalloc(&dbad, 8));
+    unsigned long long* dbad; CK(hipMalloc(&dbad, 16));
     const int groups = (W / 4) * H;
     const long long n4 = (long long)ob * N / 4;
     const double full = (double)(fb + ob * 4) * N, wonly = (double)ob * 4 * N, ronly = (double)fb * N;
@@ -333,6 +555,39 @@ int main(int argc, char** argv) {
     vs.push_back({"tstore b768 NT (wave = 3 KiB of one plane)", full, true, [&] { hipLaunchKernelGGL((k_tstore<true>), G(768), dim3(768), 3 * 768 * 16, st, src, dst, a); }, {}, 0});
     vs.push_back({"tstore b768 st", full, true, [&] { hipLaunchKernelGGL((k_tstore<false>), G(768), dim3(768), 3 * 768 * 16, st, src, dst, a); }, {}, 0});
 
+
+#define WSTAGE(B, NT) vs.push_back({std::string("wstage b" #B) + (NT ? " NT" : " st") + " (wave: 2x16B loads, 4 KiB contiguous per plane)", full, true, [&] { hipLaunchKernelGGL((k_wstage<B, NT>), G(B * 4), dim3(B), 0, st, src, dst, a); }, {}, 0});
+    WSTAGE(64, true) WSTAGE(128, true) WSTAGE(256, true) WSTAGE(512, true) WSTAGE(256, false)
+    vs.push_back({"plane1 b768 NT (one store per thread)", full, true, [&] { hipLaunchKernelGGL((k_plane1<true>), G(256), dim3(768), 0, st, src, dst, a); }, {}, 0});
+    vs.push_back({"plane1 b768 st", full, true, [&] { hipLaunchKernelGGL((k_plane1<false>), G(256), dim3(768), 0, st, src, dst, a); }, {}, 0});
+#define FLAV(F, NAME) vs.push_back({"prod b512 asm store [" NAME "]", full, true, [&] { hipLaunchKernelGGL((k_prod_flav<512, F>), G(512), dim3(512), 0, st, src, dst, a); }, {}, 0}); \
+    vs.push_back({"F0 fill flat asm store [" NAME "]", wonly, false, [&] { hipLaunchKernelGGL((f_flat_flav<F>), dim3(65536, (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), 0, st, dst, n4); }, {}, 0});
+    FLAV(0, "plain") FLAV(1, "nt") FLAV(2, "sc1") FLAV(3, "sc0 sc1") FLAV(4, "sc1 nt") FLAV(5, "sc0 sc1 nt") FLAV(6, "sc0 nt")
+    vs.push_back({"F5 W-only plane1 shape b768 NT", wonly, false, [&] { hipLaunchKernelGGL((f_plane1<true>), G(256), dim3(768), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F5 W-only plane1 shape b768 st", wonly, false, [&] { hipLaunchKernelGGL((f_plane1<false>), G(256), dim3(768), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F6 fill flat b512 st", wonly, false, [&] { hipLaunchKernelGGL((f_flat_b<512, false>), dim3(65536, (unsigned)((n4 + 65536LL * 512 - 1) / (65536LL * 512))), dim3(512), 0, st, dst, n4); }, {}, 0});
+    vs.push_back({"F6 fill flat b1024 st", wonly, false, [&] { hipLaunchKernelGGL((f_flat_b<1024, false>), dim3(65536, (unsigned)((n4 + 65536LL * 1024 - 1) / (65536LL * 1024))), dim3(1024), 0, st, dst, n4); }, {}, 0});
+    vs.push_back({"F6 fill flat b64 st", wonly, false, [&] { hipLaunchKernelGGL((f_flat_b<64, false>), dim3(65536, (unsigned)((n4 + 65536LL * 64 - 1) / (65536LL * 64))), dim3(64), 0, st, dst, n4); }, {}, 0});
+
+#define PBUF(B, AUX, K, NAME) vs.push_back({"prod buffer_store b" #B " K" #K " [" NAME "]", full, true, [&] { hipLaunchKernelGGL((k_prod_buf<B, AUX, K>), G(B * K), dim3(B), 0, st, src, dst, a); }, {}, 0});
+    PBUF(512, 0, 1, "plain") PBUF(512, 2, 1, "nt") PBUF(512, 16, 1, "sc1") PBUF(512, 17, 1, "sc0 sc1") PBUF(512, 18, 1, "sc1 nt") PBUF(512, 19, 1, "sc0 sc1 nt")
+    PBUF(256, 18, 1, "sc1 nt") PBUF(1024, 18, 1, "sc1 nt") PBUF(256, 19, 1, "sc0 sc1 nt") PBUF(1024, 19, 1, "sc0 sc1 nt")
+    PBUF(512, 18, 2, "sc1 nt") PBUF(512, 19, 2, "sc0 sc1 nt") PBUF(256, 18, 2, "sc1 nt") PBUF(256, 18, 4, "sc1 nt") PBUF(256, 19, 4, "sc0 sc1 nt")
+
+#define PBUF2(B, AUX, LAUX, ROWS, NAME) vs.push_back({"prod buf b" #B " rows" #ROWS " [" NAME "]", full, true, [&] { hipLaunchKernelGGL((k_prod_buf2<B, AUX, LAUX, ROWS>), dim3(((W / 4) * (H / ROWS) + B - 1) / B, N), dim3(B), 0, st, src, dst, a); }, {}, 0});
+    PBUF2(512, 19, 0, 1, "st sc0 sc1 nt | ld plain") PBUF2(512, 19, 2, 1, "st sc0 sc1 nt | ld nt") PBUF2(512, 19, 16, 1, "st sc0 sc1 nt | ld sc1") PBUF2(512, 19, 18, 1, "st sc0 sc1 nt | ld sc1 nt")
+    PBUF2(512, 19, 19, 1, "st sc0 sc1 nt | ld sc0 sc1 nt") PBUF2(512, 19, 1, 1, "st sc0 sc1 nt | ld sc0")
+    PBUF2(512, 19, 0, 2, "st sc0 sc1 nt | ld plain") PBUF2(512, 19, 2, 2, "st sc0 sc1 nt | ld nt") PBUF2(256, 19, 0, 2, "st sc0 sc1 nt | ld plain") PBUF2(256, 19, 2, 1, "st sc0 sc1 nt | ld nt")
+    PBUF2(512, 18, 2, 1, "st sc1 nt | ld nt") PBUF2(384, 19, 0, 1, "st sc0 sc1 nt | ld plain") PBUF2(768, 19, 0, 1, "st sc0 sc1 nt | ld plain") PBUF2(640, 19, 0, 1, "st sc0 sc1 nt | ld plain")
+    vs.push_back({"F1 W-only 3 planes/thread b512 buffer [plain]", wonly, false, [&] { hipLaunchKernelGGL((f_3plane_buf<512, 0>), G(512), dim3(512), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F1 W-only 3 planes/thread b512 buffer [sc1]", wonly, false, [&] { hipLaunchKernelGGL((f_3plane_buf<512, 16>), G(512), dim3(512), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F1 W-only 3 planes/thread b512 buffer [sc0 sc1 nt]", wonly, false, [&] { hipLaunchKernelGGL((f_3plane_buf<512, 19>), G(512), dim3(512), 0, st, dst, a); }, {}, 0});
+    vs.push_back({"F1 W-only 3 planes/thread b256 buffer [sc0 sc1 nt]", wonly, false, [&] { hipLaunchKernelGGL((f_3plane_buf<256, 19>), G(256), dim3(256), 0, st, dst, a); }, {}, 0});
+
+#define PBUF3(B, ADJ, LDS) { CK(hipFuncSetAttribute((const void*)k_prod_buf3<B, 19, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    vs.push_back({"prod buf3 b" #B " adj" #ADJ " lds=" #LDS "K [st sc0 sc1 nt]", full, true, [&] { int nc = bpf(B); hipLaunchKernelGGL((k_prod_buf3<B, 19, ADJ>), dim3(nc, N), dim3(B), LDS * 1024, st, src, dst, a, nc); }, {}, 0}); }
+    PBUF3(512, 1, 0) PBUF3(512, 2, 0) PBUF3(512, 4, 0) PBUF3(512, 8, 0) PBUF3(256, 2, 0) PBUF3(256, 4, 0) PBUF3(256, 8, 0)
+    PBUF3(512, 1, 30) PBUF3(512, 1, 40) PBUF3(512, 1, 60) PBUF3(512, 2, 40) PBUF3(256, 1, 20) PBUF3(256, 1, 30)
     vs.push_back({"F0 fill flat NT", wonly, false, [&] { hipLaunchKernelGGL((f_flat<true>), dim3(65536, (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), 0, st, dst, n4); }, {}, 0});
     vs.push_back({"F0 fill flat st", wonly, false, [&] { hipLaunchKernelGGL((f_flat<false>), dim3(65536, (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), 0, st, dst, n4); }, {}, 0});
     vs.push_back({"F1 W-only 3 planes/thread b512 NT", wonly, false, [&] { hipLaunchKernelGGL((f_3plane<512, true>), G(512), dim3(512), 0, st, dst, a); }, {}, 0});
@@ -352,10 +607,17 @@ int main(int argc, char** argv) {
         if (!v.check) continue;
         CK(hipMemsetAsync(dst, 0xCD, ob * NCHK * 4, st));
         v.run(); CK(hipGetLastError());
-        CK(hipMemsetAsync(dbad, 0, 8, st));
+        CK(hipMemsetAsync(dbad, 0, 8, st)); CK(hipMemsetAsync(dbad + 1, 0xFF, 8, st));
         hipLaunchKernelGGL(k_diff, dim3(4096), dim3(256), 0, st, (const uint32_t*)ref, (const uint32_t*)dst, (long long)ob * NCHK, dbad);
-        unsigned long long bad; CK(hipMemcpyAsync(&bad, dbad, 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
-        v.bad = (long long)bad;
+        unsigned long long bad[2]; CK(hipMemcpyAsync(bad, dbad, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+        v.bad = (long long)bad[0];
+        if (bad[0]) {
+            uint32_t got[8], want[8];
+            CK(hipMemcpy(got, (uint32_t*)dst + bad[1], 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(want, (uint32_t*)ref + bad[1], 32, hipMemcpyDeviceToHost));
+            const long long e = (long long)bad[1], fr = e / (long long)ob, pl = (e % (long long)ob) / ((long long)W * H), px = e % ((long long)W * H);
+            printf("  [%s] first bad element %lld: frame %lld plane %lld row %lld col %lld; got %08x %08x %08x %08x want %08x %08x %08x %08x\n", v.name.c_str(), e, fr, pl,
+                   px / W, px % W, got[0], got[1], got[2], got[3], want[0], want[1], want[2], want[3]);
+        }
     }
     for (int r = 0; r < ROUNDS + 1; ++r)
         for (auto& v : vs) {

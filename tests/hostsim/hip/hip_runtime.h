@@ -76,6 +76,21 @@ inline uint32_t hostsim_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
     return out;
 }
 #define __builtin_amdgcn_perm(a, b, sel) hostsim_perm((a), (b), (sel))
+// raw buffer accesses: base + soffset + voffset, dropped / zero when voffset + size runs past num_records (the hardware range check)
+struct hostsim_rsrc { char* base; uint32_t n; };
+typedef hostsim_rsrc __amdgpu_buffer_rsrc_t;
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) hostsim_rsrc{(char*)(p), (uint32_t)(n)}
+template <typename V>
+inline void hostsim_buf_store(V v, hostsim_rsrc r, int voff, int soff) {
+    if ((uint64_t)(uint32_t)voff + sizeof(V) <= r.n) memcpy(r.base + soff + (uint32_t)voff, &v, sizeof(V));
+}
+inline uint32_t hostsim_buf_load32(hostsim_rsrc r, int voff, int soff) {
+    uint32_t v = 0;
+    if ((uint64_t)(uint32_t)voff + 4 <= r.n) memcpy(&v, r.base + soff + (uint32_t)voff, 4);
+    return v;
+}
+#define __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, so, aux) hostsim_buf_store((v), (r), (vo), (so))
+#define __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, aux) hostsim_buf_load32((r), (vo), (so))
 
 // one block, one fiber at a time: plain read-modify-write is atomic here
 template <typename T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
@@ -107,6 +122,7 @@ enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemc
 enum { hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipMemAttachGlobal = 1 };
 enum hipMemPoolAttr { hipMemPoolAttrReleaseThreshold = 4 };
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1 };
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1, hipStreamCaptureStatusInvalidated = 2 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeManaged = 3 };
 struct hipPointerAttribute_t { hipMemoryType type; int device; };
@@ -130,6 +146,7 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipMemGetInfo(size_t* f, size_t* t);
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
 hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* status);
 hipError_t hipGraphGetNodes(hipGraph_t g, hipGraphNode_t* nodes, size_t* n);
 hipError_t hipGraphDestroy(hipGraph_t g);
 hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t* err, char* log, size_t n);

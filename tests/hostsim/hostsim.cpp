@@ -180,6 +180,10 @@ hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
     hostsim::g_capture = nullptr;
     return hipSuccess;
 }
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* status) {
+    *status = hostsim::g_capture ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone;
+    return hipSuccess;
+}
 hipError_t hipGraphGetNodes(hipGraph_t g, hipGraphNode_t*, size_t* n) { *n = g->nodes.size(); return hipSuccess; }
 hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
 hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t*, char*, size_t) { *e = new hostsim_graph_exec{g->nodes}; return hipSuccess; }

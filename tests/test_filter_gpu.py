@@ -52,6 +52,20 @@ def test_gaussian_matches_oracle(gpu_stream, c, shape, ks):
     assert_same_bits(got, O.gaussian_blur(src, (kx, ky), (sx, sy)), f"gaussian {shape} c{c} k{kx}x{ky}")
 
 
+@pytest.mark.parametrize("ks", [((3, 7), (0.8, 1.5)), ((9, 5), (2.0, 1.0)), ((7, 7), (1.5, 1.5)), ((5, 5), (1.0, 1.0))])
+def test_non_finite_pixels_poison_only_their_own_window(gpu_stream, ks):
+    """An Inf / NaN pixel reaches exactly the outputs whose n-tap windows contain it — also when kx and ky differ in length
+    (a kernel padded with zero taps would compute 0 * Inf = NaN outside the reference's window)."""
+    img = O.pattern_f32(61 * 47 * 3).reshape(47, 61, 3).copy()  # noqa: F811 (local image)
+    img[20, 30, 1] = np.inf
+    img[5, 7, 0] = np.nan
+    img[40, 50, 2] = -np.inf
+    (kx, ky), (sx, sy) = ks
+    got, want = run(gpu_stream, "kh_gaussian_blur_f32", img, kx, ky, sx, sy), O.gaussian_blur(img, (kx, ky), (sx, sy))
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+    assert_same_bits(np.nan_to_num(got, nan=7.0, posinf=8.0, neginf=9.0), np.nan_to_num(want, nan=7.0, posinf=8.0, neginf=9.0), f"non-finite {ks}")
+
+
 @pytest.fixture(params=["roll", "tile"])
 def kernel_path(request, monkeypatch):
     """Both device kernels behind the filter entry points: the rolling-column fast path and the
