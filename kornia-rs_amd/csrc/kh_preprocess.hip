@@ -352,21 +352,30 @@ __device__ __forceinline__ float div255_u8(float x) {
 // slower, profiles/r02f_ubench_nv12.txt).  The chroma dword is read by both rows of a pair; the second read is an L2 /
 // Infinity-Cache hit (putting the two readers on one XCD changes nothing: r02g `adj` variants).
 //
-// Round 2: loads and stores go through the buffer path with the stores write-through + non-temporal (kAuxStream, kh_common.h):
-// -5.6 % time against the non-temporal global stores of round 1.  What was measured around it on MI355X and is NOT used
-// (profiles/r02a..r02g_ubench_nv12.txt, every variant bit-identical to this kernel): staging the source through LDS with
-// 16-byte loads (block-wide K rounds -1..-17 %, wave-private +12 %), K rounds per thread with hoisted loads (+2 % at best, -12 %
-// typical), persistent block-stride loops (-25..-48 %), one plane per wave through an LDS transpose (-19 %), one store per
-// thread with the planes on different waves (-33 %), XCD-per-frame block order (-4 %), frame-stride / base-offset padding
-// (+-0.5 %), non-temporal LOADS (-16 %), limiting occupancy through LDS (0..-25 %).  Ceilings on the same boxes: the same three
-// plane stores with no loads or decode 4.04 ms, a flat fill of the same bytes 3.55-3.63 ms, this kernel 4.44-4.51 ms.
+// Round 2 (profiles/r02a..r02l_ubench_nv12.txt; every variant bit-identical to this kernel, same box, interleaved):
+//   * loads and stores go through the buffer path, the stores write-through + non-temporal (kAuxStream, kh_common.h): -4..-6 % time
+//     against the non-temporal global stores of round 1;
+//   * all twelve results are computed BEFORE the first store (the empty asm below pins that), so the three plane stores issue back to
+//     back instead of being interleaved with the decode by the scheduler: another -3.5 %;
+//   * the row index comes from a plain integer division and BOTH loads depend on it.  Replacing it with the 2-instruction multiply-shift
+//     used elsewhere in this library makes the kernel 3.5 % SLOWER (4.42 vs 4.27 ms), and a sleep of the same length does not give the
+//     time back: WHEN and how densely a wave touches memory matters more than its instruction count here.
+// Together: 4.27-4.30 ms per 1024 frames against 4.69-4.74 ms for the round-1 kernel on the same boxes (6.7 TB/s, 0.84 of 8 TB/s).
+// Measured and NOT used: staging the source through LDS with 16-byte loads (block-wide K rounds -1..-17 %, wave-private -12 %), K
+// chunks per thread with hoisted loads (+2 % at best, -12 % typical, -18 % with back-to-back stores), persistent block-stride loops
+// (-25..-48 %), one plane per wave through an LDS transpose (-19 %), one store per thread with the planes on different waves
+// (-33 %), two rows per thread (-12 %), XCD-per-frame block order (-4 %), pairing chroma-sharing chunks on one XCD (0 %),
+// frame-stride / base-offset padding (+-0.5 %), non-temporal LOADS (-16 %), s_setprio before the stores (-2 %), sleeps before the
+// loads or the stores (0..-6 %), limiting occupancy through LDS (0..-25 %), other block sizes (256 -13 %, 384 -4 %, 448 -3 %, 576 -7 %,
+// 640 -12 %, 1024 -18 %).  Ceilings on the same boxes: these three plane stores with no loads or decode 4.04 ms, a flat fill of the
+// same bytes 3.55-3.63 ms.
 constexpr int kIdBlock = 512;  // 8 KiB contiguous per plane per block; 256 / 384 / 640 / 768 / 1024 are 2-11 % slower (r02e, r02f)
 // XCDF (dev knob KH_NV12_XCD_FRAMES=1): a 1-D launch in which XCD k walks frames k, k + 8, ... chunk by chunk.  Measured in
 // round 2: 4.84 ms against 4.65 ms for the default order (profiles/r02a_ab.log) — kept only as the A/B it was, off by default.
 struct XcdFrames { FastDiv by_bpf; unsigned bpf, nframes; };
 template <bool XCDF>
 __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
-    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a, XcdFrames xf, FastDiv by_wq) {
+    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a, XcdFrames xf) {
     const int wq = a.src_w >> 2;     // 4-pixel groups per row
     const int groups = wq * a.src_h;
     unsigned chunk = blockIdx.x, frame = blockIdx.y;
@@ -383,9 +392,9 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
     const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(src_base + (long long)frame * a.src_frame_stride, (uint32_t)(plane + plane / 2));
     const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_base + (long long)frame * a.dst_frame_stride, (uint32_t)(12 * plane));
 
-    const int r = (int)fast_quot((uint32_t)g, by_wq);
+    const int r = g / wq;  // deliberately NOT fast_quot(g, by_wq): see the header comment (the division paces the loads)
     const int xq = g - r * wq;
-    const uint32_t y4 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, 4 * g, 0, 0);
+    const uint32_t y4 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, r * a.src_w + 4 * xq, 0, 0);
     const uint32_t uv4 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, plane + (r >> 1) * a.src_w + 4 * xq, 0, 0);
 
     // Chroma terms shared by each pixel pair; integer adds are exact, so hoisting the rounding
@@ -412,6 +421,7 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
         o[1][j] = (div255_u8(gg) - a.m1) * a.is1;
         o[2][j] = (div255_u8(bb) - a.m2) * a.is2;
     }
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));  // all twelve values exist here: the stores below issue back to back
 #pragma unroll
     for (int c = 0; c < 3; ++c)  // plane offset in the vector offset, never in an SGPR soffset (kh_common.h)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[c]), rdst, 16 * g + c * (4 * plane), 0, kAuxStream);
@@ -562,11 +572,10 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
         const uint64_t remapped = (uint64_t)bpf * kXcds * cdiv(p->nframes, kXcds);
         if (xcd_frames && remapped < 0x7ff00000ull) {
             const XcdFrames xf{fast_div(bpf), bpf, (unsigned)p->nframes};
-            hipLaunchKernelGGL((preprocess_nv12_identity<true>), dim3((unsigned)remapped), dim3(kIdBlock), 0, s, src, (float*)dst, a, xf,
-                               fast_div((uint32_t)(p->src_w / 4)));
+            hipLaunchKernelGGL((preprocess_nv12_identity<true>), dim3((unsigned)remapped), dim3(kIdBlock), 0, s, src, (float*)dst, a, xf);
         } else {
             hipLaunchKernelGGL((preprocess_nv12_identity<false>), dim3(bpf, (unsigned)p->nframes), dim3(kIdBlock), 0, s, src, (float*)dst, a,
-                               XcdFrames{}, fast_div((uint32_t)(p->src_w / 4)));
+                               XcdFrames{});
         }
         return check_launch("preprocess_nv12_identity");
     }

@@ -432,6 +432,119 @@ __global__ __launch_bounds__(BLOCK) void k_prod_buf3(const uint8_t* __restrict__
     for (int c = 0; c < 3; ++c)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[c]), rs, off + c * plane * 4, 0, AUX);
 }
+
+// ---- k_lib: the production kernel as shipped in round 2 (early return, multiply-shift row division, plane offsets in voffset),
+// to find why the library does not show the gain k_prod_buf2 shows.  DIVMODE 0 = multiply-shift, 1 = integer division;
+// EARLY 1 = `if (g >= groups) return`, 0 = clamped loads + hardware-dropped stores.
+struct FastDivU { uint32_t d, m, sh; };
+static FastDivU fast_div_u(uint32_t d) {
+    FastDivU f{d, 0u, 0u};
+    if (d <= 1) return f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.m = (uint32_t)(((1ull << (31 + l)) + d - 1) / d);
+    f.sh = l - 1;
+    return f;
+}
+template <int BLOCK, int DIVMODE, int EARLY, int AUX>
+__global__ __launch_bounds__(BLOCK) void k_lib(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a, FastDivU by_wq) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int g0 = blockIdx.x * BLOCK + threadIdx.x;
+    if constexpr (EARLY) { if (g0 >= groups) return; }
+    const int g = EARLY ? g0 : min(g0, groups - 1);
+    const int plane = a.w * a.h;
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sb + (long long)blockIdx.y * a.sfs), 0, plane + plane / 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(db + (long long)blockIdx.y * a.dfs, 0, 12 * plane, 0x00020000);
+    const int r = DIVMODE ? g / wq : (by_wq.m ? (int)((uint32_t)(((uint64_t)(uint32_t)g * by_wq.m) >> 32) >> by_wq.sh) : g);
+    const int xq = g - r * wq;
+    const uint32_t y4 = __builtin_amdgcn_raw_buffer_load_b32(rl, 4 * g, 0, 0);
+    const uint32_t uv4 = __builtin_amdgcn_raw_buffer_load_b32(rl, plane + (r >> 1) * a.w + 4 * xq, 0, 0);
+    f32x4 o[3];
+    decode4(y4, uv4, a, o);
+    const int off = (EARLY || g0 < groups) ? 16 * g : 0x7fffffff - 2 * plane * 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[c]), rs, off + c * (4 * plane), 0, AUX);
+}
+
+// ---- k_pace: k_prod_buf2-shaped (both loads after the integer division) with extra pacing: s_sleep(S0) before the loads and
+// s_sleep(S1) between the loads' return and the stores.  r02i: replacing the ~40-instruction division by a 2-instruction
+// multiply-shift made the kernel 1.6 % SLOWER, i.e. WHEN a wave touches memory matters.
+template <int BLOCK, int S0, int S1, int AUX>
+__global__ __launch_bounds__(BLOCK) void k_pace(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int g0 = blockIdx.x * BLOCK + threadIdx.x;
+    const int g = min(g0, groups - 1);
+    const int plane = a.w * a.h;
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sb + (long long)blockIdx.y * a.sfs), 0, plane + plane / 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(db + (long long)blockIdx.y * a.dfs, 0, 12 * plane, 0x00020000);
+    if constexpr (S0 > 0) __builtin_amdgcn_s_sleep(S0);
+    const int r = g / wq, xq = g - r * wq;
+    const uint32_t y4 = __builtin_amdgcn_raw_buffer_load_b32(rl, r * a.w + 4 * xq, 0, 0);
+    const uint32_t uv4 = __builtin_amdgcn_raw_buffer_load_b32(rl, plane + (r >> 1) * a.w + 4 * xq, 0, 0);
+    f32x4 o[3];
+    decode4(y4, uv4, a, o);
+    // S1 < 0: only force all twelve values to exist before the first store (stores issue back to back), no sleep
+    if constexpr (S1 != 0) { asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2])); if constexpr (S1 > 0) __builtin_amdgcn_s_sleep(S1); }
+    const int off = g0 < groups ? 16 * g : 0x7fffffff - 2 * plane * 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[c]), rs, off + c * (4 * plane), 0, AUX);
+}
+
+// ---- k_b2b: all twelve values are computed before the first store, so the three plane stores issue back to back (r02j: 4.356 ms
+// against 4.512 with the compiler's interleaving of decode and stores).  DIV: 0 multiply-shift / 1 integer division (both loads
+// after it) / 2 integer division, luma load before it.  K chunks per thread (BLOCK apart), all loads first, then 3K stores.
+template <int BLOCK, int DIV, int AUX, int K, int PRIO>
+__global__ __launch_bounds__(BLOCK) void k_b2b(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a, FastDivU by_wq) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int plane = a.w * a.h;
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sb + (long long)blockIdx.y * a.sfs), 0, plane + plane / 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(db + (long long)blockIdx.y * a.dfs, 0, 12 * plane, 0x00020000);
+    uint32_t y4[K], uv4[K];
+    int off[K];
+    if constexpr (PRIO >= 10) __builtin_amdgcn_s_sleep(PRIO - 10);   // pre-load delay in units of 64 clocks
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int g0 = blockIdx.x * (BLOCK * K) + k * BLOCK + threadIdx.x;
+        const int g = min(g0, groups - 1);
+        if constexpr (DIV == 2) y4[k] = __builtin_amdgcn_raw_buffer_load_b32(rl, 4 * g, 0, 0);
+        const int r = DIV == 0 ? (int)((uint32_t)(((uint64_t)(uint32_t)g * by_wq.m) >> 32) >> by_wq.sh) : g / wq;
+        const int xq = g - r * wq;
+        if constexpr (DIV != 2) y4[k] = __builtin_amdgcn_raw_buffer_load_b32(rl, DIV == 0 ? 4 * g : r * a.w + 4 * xq, 0, 0);
+        uv4[k] = __builtin_amdgcn_raw_buffer_load_b32(rl, plane + (r >> 1) * a.w + 4 * xq, 0, 0);
+        off[k] = g0 < groups ? 16 * g : 0x7fffffff - 2 * plane * 4;
+    }
+    f32x4 o[K][3];
+#pragma unroll
+    for (int k = 0; k < K; ++k) decode4(y4[k], uv4[k], a, o[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) asm volatile("" : "+v"(o[k][0]), "+v"(o[k][1]), "+v"(o[k][2]));
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[k][c]), rs, off[k] + c * (4 * plane), 0, AUX);
+}
+// global (flat-family) NT stores, back to back
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_b2b_global(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
+    const int wq = a.w >> 2, groups = wq * a.h;
+    const int g = blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= groups) return;
+    const uint8_t* src = sb + (long long)blockIdx.y * a.sfs;
+    float* dst = db + (long long)blockIdx.y * a.dfs;
+    const int r = g / wq, xq = g - r * wq;
+    const long long plane = (long long)a.w * a.h;
+    const uint32_t y4 = *(const uint32_t*)(src + 4ll * g);
+    const uint32_t uv4 = *(const uint32_t*)(src + plane + (long long)(r >> 1) * a.w + 4 * xq);
+    f32x4 o[3];
+    decode4(y4, uv4, a, o);
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st4<true>(dst + c * plane + 4ll * g, o[c]);
+}
 // ---- fills
 template <bool NT>
 __global__ __launch_bounds__(256) void f_flat(float* __restrict__ db, long long n4) {
@@ -505,7 +618,13 @@ int main(int argc, char** argv) {
     const int NCHK = std::min(N, 16);  // frames compared against prod
     const size_t fb = (size_t)W * H * 3 / 2, ob = (size_t)W * H * 3;
     uint8_t* src; float *dst, *ref;
-    CK(hipMalloc(&src, fb * N)); CK(hipMalloc(&dst, ob * N * 4)); CK(hipMalloc(&ref, ob * NCHK * 4));
+    const bool pool = argc > 3 && std::string(argv[3]) == "pool";   // stream-ordered pool memory, as the library's DeviceBuffer uses
+    if (pool) {
+        hipMemPool_t mp; CK(hipDeviceGetDefaultMemPool(&mp, 0)); uint64_t thr = UINT64_MAX; CK(hipMemPoolSetAttribute(mp, hipMemPoolAttrReleaseThreshold, &thr));
+        CK(hipMallocAsync((void**)&src, fb * N, 0)); CK(hipMallocAsync((void**)&dst, ob * N * 4, 0)); CK(hipDeviceSynchronize());
+    } else { CK(hipMalloc(&src, fb * N)); CK(hipMalloc(&dst, ob * N * 4)); }
+    CK(hipMalloc(&ref, ob * NCHK * 4));
+    printf("# buffers: %s  src %p dst %p\n", pool ? "hipMallocAsync (default pool)" : "hipMalloc", (void*)src, (void*)dst);
     {
         std::vector<uint8_t> h(fb + 31 * 64); uint32_t s = 0x12345678u;
         for (auto& b : h) { s = s * 1664525u + 1013904223u; b = (uint8_t)(s >> 24); }
@@ -588,6 +707,26 @@ int main(int argc, char** argv) {
     vs.push_back({"prod buf3 b" #B " adj" #ADJ " lds=" #LDS "K [st sc0 sc1 nt]", full, true, [&] { int nc = bpf(B); hipLaunchKernelGGL((k_prod_buf3<B, 19, ADJ>), dim3(nc, N), dim3(B), LDS * 1024, st, src, dst, a, nc); }, {}, 0}); }
     PBUF3(512, 1, 0) PBUF3(512, 2, 0) PBUF3(512, 4, 0) PBUF3(512, 8, 0) PBUF3(256, 2, 0) PBUF3(256, 4, 0) PBUF3(256, 8, 0)
     PBUF3(512, 1, 30) PBUF3(512, 1, 40) PBUF3(512, 1, 60) PBUF3(512, 2, 40) PBUF3(256, 1, 20) PBUF3(256, 1, 30)
+
+#define KLIB(B, DM, EARLY, AUX, NAME) vs.push_back({"lib-shaped b" #B " " NAME, full, true, [&] { hipLaunchKernelGGL((k_lib<B, DM, EARLY, AUX>), G(B), dim3(B), 0, st, src, dst, a, fast_div_u(W / 4)); }, {}, 0});
+    KLIB(512, 0, 1, 19, "fastdiv early-return [sc0 sc1 nt]") KLIB(512, 1, 1, 19, "intdiv early-return [sc0 sc1 nt]") KLIB(512, 0, 0, 19, "fastdiv clamped [sc0 sc1 nt]")
+    KLIB(512, 1, 0, 19, "intdiv clamped [sc0 sc1 nt]") KLIB(512, 0, 1, 2, "fastdiv early-return [nt]") KLIB(512, 1, 0, 2, "intdiv clamped [nt]")
+
+#define PACE(B, S0, S1) vs.push_back({"pace b" #B " sleep " #S0 "/" #S1 " [sc0 sc1 nt]", full, true, [&] { hipLaunchKernelGGL((k_pace<B, S0, S1, 19>), G(B), dim3(B), 0, st, src, dst, a); }, {}, 0});
+    PACE(512, 0, 0) PACE(512, 1, 0) PACE(512, 2, 0) PACE(512, 4, 0) PACE(512, 8, 0) PACE(512, 16, 0) PACE(512, 32, 0)
+    PACE(512, 0, -1) PACE(512, 0, 1) PACE(512, 0, 2) PACE(512, 0, 4) PACE(512, 0, 8) PACE(512, 2, 2) PACE(512, 4, 4) PACE(256, 4, 0) PACE(256, 0, 4)
+
+#define B2B(B, DIV, AUX, K, PRIO, NAME) vs.push_back({"b2b b" #B " K" #K " " NAME, full, true, [&] { hipLaunchKernelGGL((k_b2b<B, DIV, AUX, K, PRIO>), G(B * K), dim3(B), 0, st, src, dst, a, fast_div_u(W / 4)); }, {}, 0});
+    B2B(512, 1, 19, 1, 0, "intdiv [sc0 sc1 nt]") B2B(512, 0, 19, 1, 0, "fastdiv [sc0 sc1 nt]") B2B(512, 2, 19, 1, 0, "intdiv, luma load first [sc0 sc1 nt]")
+    B2B(512, 1, 18, 1, 0, "intdiv [sc1 nt]") B2B(512, 1, 2, 1, 0, "intdiv [nt]") B2B(512, 1, 0, 1, 0, "intdiv [plain]") B2B(512, 1, 17, 1, 0, "intdiv [sc0 sc1]")
+    B2B(512, 1, 19, 1, 1, "intdiv setprio [sc0 sc1 nt]")
+    B2B(512, 0, 19, 1, 11, "fastdiv sleep1 [sc0 sc1 nt]") B2B(512, 0, 19, 1, 12, "fastdiv sleep2 [sc0 sc1 nt]") B2B(512, 0, 19, 1, 13, "fastdiv sleep3 [sc0 sc1 nt]")
+    B2B(512, 0, 19, 1, 14, "fastdiv sleep4 [sc0 sc1 nt]") B2B(512, 0, 19, 1, 16, "fastdiv sleep6 [sc0 sc1 nt]") B2B(512, 0, 19, 1, 18, "fastdiv sleep8 [sc0 sc1 nt]")
+    B2B(512, 1, 19, 1, 11, "intdiv sleep1 [sc0 sc1 nt]") B2B(512, 1, 19, 1, 12, "intdiv sleep2 [sc0 sc1 nt]") B2B(512, 1, 19, 1, 14, "intdiv sleep4 [sc0 sc1 nt]")
+    B2B(448, 1, 19, 1, 0, "intdiv [sc0 sc1 nt]") B2B(576, 1, 19, 1, 0, "intdiv [sc0 sc1 nt]")
+    B2B(256, 1, 19, 1, 0, "intdiv [sc0 sc1 nt]") B2B(384, 1, 19, 1, 0, "intdiv [sc0 sc1 nt]") B2B(640, 1, 19, 1, 0, "intdiv [sc0 sc1 nt]") B2B(1024, 1, 19, 1, 0, "intdiv [sc0 sc1 nt]")
+    B2B(512, 1, 19, 2, 0, "intdiv [sc0 sc1 nt]") B2B(256, 1, 19, 2, 0, "intdiv [sc0 sc1 nt]") B2B(256, 1, 19, 4, 0, "intdiv [sc0 sc1 nt]")
+    vs.push_back({"b2b b512 global NT stores", full, true, [&] { hipLaunchKernelGGL((k_b2b_global<512>), G(512), dim3(512), 0, st, src, dst, a); }, {}, 0});
     vs.push_back({"F0 fill flat NT", wonly, false, [&] { hipLaunchKernelGGL((f_flat<true>), dim3(65536, (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), 0, st, dst, n4); }, {}, 0});
     vs.push_back({"F0 fill flat st", wonly, false, [&] { hipLaunchKernelGGL((f_flat<false>), dim3(65536, (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), 0, st, dst, n4); }, {}, 0});
     vs.push_back({"F1 W-only 3 planes/thread b512 NT", wonly, false, [&] { hipLaunchKernelGGL((f_3plane<512, true>), G(512), dim3(512), 0, st, dst, a); }, {}, 0});
