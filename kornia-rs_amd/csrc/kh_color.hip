@@ -44,7 +44,9 @@ __global__ __launch_bounds__(kBlock) void map_u8_quads(const uint8_t* __restrict
                 out.w[b >> 2] |= ((uint32_t)po[c] & 0xFFu) << (8 * (b & 3));
             }
         }
-        *reinterpret_cast<Words<COUT>*>(dst + q * 4 * COUT) = out;
+        // block-local streaming window: write-through non-temporal store of COUT dwords (kh_common.h::stream_store)
+        const long long q0 = (long long)blockIdx.x * kBlock;
+        stream_store<COUT>(stream_window(dst + q0 * 4 * COUT, (nq - q0) * 4 * COUT), (int)threadIdx.x * 4 * COUT, out.w);
     } else if (q == nq) {
         for (long long p = nq * 4; p < npx; ++p) {
             int pi[CIN], po[COUT];
@@ -76,7 +78,11 @@ __global__ __launch_bounds__(kBlock) void map_f32(const float* __restrict__ src,
     const Floats<CIN> in = *reinterpret_cast<const Floats<CIN>*>(src + p * CIN);
     Floats<COUT> out;
     op(in.v, out.v);
-    *reinterpret_cast<Floats<COUT>*>(dst + p * COUT) = out;
+    uint32_t w[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) w[c] = __float_as_uint(out.v[c]);
+    const long long p0 = (long long)blockIdx.x * kBlock;
+    stream_store<COUT>(stream_window(dst + p0 * COUT, (npx - p0) * COUT * 4), (int)threadIdx.x * COUT * 4, w);
 }
 
 int32_t check_map(const void* src, const void* dst, int64_t npx, const char* what) {

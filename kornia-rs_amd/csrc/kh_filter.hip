@@ -197,7 +197,11 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
     // partial group of K) recompute clamped rows and store nothing; the first 2H steps are the
     // ring warm-up and store nothing either.
     const int hs = is_halo ? hslot : 159;  // non-halo lanes park their duplicate in a slot nobody reads
-    int out_off = (y0 - 2 * H) * a.rowlen + gx;  // destination offset of walk step 0's (virtual) output row
+    // Output: a streaming window (kh_common.h) over this strip's rows of the destination — wave-uniform base, write-through
+    // non-temporal dword stores (same-box A/B on C4: 9.11 vs 9.34 ms, profiles/r02o_ab_stores.txt); the offsets of the 2H warm-up
+    // steps are negative and never stored.
+    const __amdgpu_buffer_rsrc_t ow = stream_window(dst + (long long)y0 * a.rowlen, (long long)(a.rows - y0) * a.rowlen * 4);
+    int out_off = (gx - 2 * H * a.rowlen) * 4;  // byte offset of walk step 0's (virtual) output row inside the window
     const float* tap = buf + halo + lane - H * a.C;
     for (int rb = 0; rb < nrows; rb += K) {
 #pragma unroll
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
                 if constexpr (GRAD) o2 += ring2[(p + 1 + i) % K] * kx.k[i];
             }
             if constexpr (GRAD) o = sqrtf(o * o + o2 * o2);
-            if (gx_ok && r >= 2 * H && r < nrows) dst[out_off] = o;
-            out_off += a.rowlen;
+            if (gx_ok && r >= 2 * H && r < nrows) { const uint32_t ow_bits = __float_as_uint(o); stream_store<1>(ow, out_off, &ow_bits); }
+            out_off += a.rowlen * 4;
         }
     }
 }
@@ -298,7 +302,8 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
     // Unequal odd sizes (rare: e.g. gaussian (3, 7)) take the tile kernel, which walks exactly kx.n / ky.n taps.  3 is the
     // smallest rolling instantiation, so a 1-tap pair goes to the tile kernel as well.
     const int kmax = kx.n > ky.n ? kx.n : ky.n;
-    if (kx.n == ky.n && (kx.n & 1) && kmax >= 3 && kmax <= 15 && (kmax / 2) * C <= 32 && !force_tile_kernel()) {
+    const bool strip_fits_32bit = (int64_t)(kRollStripMax + 16) * a.rowlen * 4 <= kI32Max;  // byte offsets inside a strip's output window
+    if (kx.n == ky.n && (kx.n & 1) && kmax >= 3 && kmax <= 15 && (kmax / 2) * C <= 32 && strip_fits_32bit && !force_tile_kernel()) {
         const int K = kmax < 3 ? 3 : kmax;
         TapsK px, py;
         pad_taps(px, kx, K);

@@ -84,12 +84,19 @@ template <typename V>
 inline void hostsim_buf_store(V v, hostsim_rsrc r, int voff, int soff) {
     if ((uint64_t)(uint32_t)voff + sizeof(V) <= r.n) memcpy(r.base + soff + (uint32_t)voff, &v, sizeof(V));
 }
+template <int BYTES, typename V>  // a 3-element ext vector is padded to 16 bytes: store its first BYTES only
+inline void hostsim_buf_store_n(V v, hostsim_rsrc r, int voff, int soff) {
+    if ((uint64_t)(uint32_t)voff + BYTES <= r.n) memcpy(r.base + soff + (uint32_t)voff, &v, BYTES);
+}
 inline uint32_t hostsim_buf_load32(hostsim_rsrc r, int voff, int soff) {
     uint32_t v = 0;
     if ((uint64_t)(uint32_t)voff + 4 <= r.n) memcpy(&v, r.base + soff + (uint32_t)voff, 4);
     return v;
 }
 #define __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, so, aux) hostsim_buf_store((v), (r), (vo), (so))
+#define __builtin_amdgcn_raw_buffer_store_b96(v, r, vo, so, aux) hostsim_buf_store_n<12>((v), (r), (vo), (so))
+#define __builtin_amdgcn_raw_buffer_store_b64(v, r, vo, so, aux) hostsim_buf_store((v), (r), (vo), (so))
+#define __builtin_amdgcn_raw_buffer_store_b32(v, r, vo, so, aux) hostsim_buf_store((v), (r), (vo), (so))
 #define __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, aux) hostsim_buf_load32((r), (vo), (so))
 
 // one block, one fiber at a time: plain read-modify-write is atomic here
