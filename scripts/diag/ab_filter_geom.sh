@@ -1,0 +1,3 @@
+for i in 1 2 3; do for v in plain wt; do for w in gaussian_4k undistort_warp_4k resize_224; do
+  KORNIA_HIP_LIB=$PWD//tmp/kh_ab/libkornia_hip_$v.so python bench.py --workload $w --no-cpu-baseline --steps 10 --also none 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('$v', j['config']['workload'], j['ms_per_step'], j['roofline']['frac'])"
+done; done; done
