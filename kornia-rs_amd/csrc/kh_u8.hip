@@ -510,6 +510,139 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_u8_kernel(ImgU8 im, cons
     store_px_u8<C>(o, px, wave_full);
 }
 
+
+// ---- LDS-staged affine warp -----------------------------------------------------------------------------------------------------
+// The per-pixel kernel above is bound by vector-memory INSTRUCTIONS: four scattered sub-dword loads per pixel (r01: 11.3 ms per 256
+// 4K images = 0.14 of the HBM roofline, PMC traffic only 1.11x the algorithmic bytes).  An affine map takes a 64 x kStageRows
+// destination tile to a parallelogram whose bounding box is small (12 deg, scale 0.9: 76 x 35 source pixels for 64 x 16 outputs), so
+// a block stages that box in LDS with wide contiguous loads — four pixels (4*C bytes) per lane per load, one dword per pixel in
+// LDS — and every tap becomes an aligned ds_read_b32.  The arithmetic is the per-pixel kernel's (same row spans, Q16 stepping,
+// clamps and Q10 blend), so the bytes are identical; tests compare both kernels with the restatement.
+//   * box = min / max of the clamped integer source coordinates at both ends of every row's valid span (coordinates are linear in x
+//     along a row, so the ends bound the row), +1 for the second tap, found by the first wave and shared through LDS;
+//   * a block whose box does not fit (strong minification, near-singular maps, tiny sources) samples from global memory exactly as
+//     the per-pixel kernel does — a block-uniform branch, no host-side case analysis;
+//   * the staged row pitch is the box width rounded up to 4 pixels; the box is shifted left inside the row when that would run past
+//     the row end, so quads never leave the image.
+constexpr int kStageRows = 16;          // destination rows per block (4 per thread)
+constexpr int kStageCap = 8192;         // staged pixels per block: 32 KiB of LDS, 5 blocks per CU
+
+template <int C>
+__device__ __forceinline__ void load_quad_px(const uint8_t* __restrict__ p, uint32_t px[4]) {
+    if constexpr (C == 4) {
+        const uint64_t a = *reinterpret_cast<const u64_unaligned*>(p), b = *reinterpret_cast<const u64_unaligned*>(p + 8);
+        px[0] = (uint32_t)a; px[1] = (uint32_t)(a >> 32); px[2] = (uint32_t)b; px[3] = (uint32_t)(b >> 32);
+    } else if constexpr (C == 3) {
+        const uint64_t a = *reinterpret_cast<const u64_unaligned*>(p);
+        const uint32_t b = *reinterpret_cast<const u32_unaligned*>(p + 8);
+        px[0] = (uint32_t)a & 0xffffffu; px[1] = (uint32_t)(a >> 24) & 0xffffffu;
+        px[2] = ((uint32_t)(a >> 48) | (b << 16)) & 0xffffffu; px[3] = b >> 8;
+    } else if constexpr (C == 2) {
+        const uint64_t a = *reinterpret_cast<const u64_unaligned*>(p);
+        px[0] = (uint32_t)a & 0xffffu; px[1] = (uint32_t)(a >> 16) & 0xffffu; px[2] = (uint32_t)(a >> 32) & 0xffffu; px[3] = (uint32_t)(a >> 48);
+    } else {
+        const uint32_t a = *reinterpret_cast<const u32_unaligned*>(p);
+        px[0] = a & 0xffu; px[1] = (a >> 8) & 0xffu; px[2] = (a >> 16) & 0xffu; px[3] = a >> 24;
+    }
+}
+
+// the Q10 blend of sample_q10 on four packed taps
+template <int C>
+__device__ __forceinline__ uint32_t blend_q10(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uint32_t fx, uint32_t fy) {
+    const uint32_t fx1 = 1024u - fx, fy1 = 1024u - fy;
+    uint32_t px = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const uint32_t top = chan_u8(p00, c) * fx1 + chan_u8(p01, c) * fx, bot = chan_u8(p10, c) * fx1 + chan_u8(p11, c) * fx;
+        px |= (((top * fy1 + bot * fy + (1u << 19)) >> 20) & 0xffu) << (8 * c);
+    }
+    return px;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBx * 4) void warp_affine_u8_lds_kernel(ImgU8 im, const AffineRow* __restrict__ rows, int dsx_q, int dsy_q) {
+    __shared__ uint32_t tile[kStageCap];
+    __shared__ int box[4];
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;
+    const int lane = threadIdx.x, ty = threadIdx.y, tid = ty * kBx + lane;
+    const int x = bx_ * kBx + lane, y0 = by_ * kStageRows;
+    const bool wave_full = (int)(bx_ * kBx) + kBx <= im.dw;
+    const uint8_t* src = im.src + (long long)bz_ * im.src_stride;
+    uint8_t* dst = im.dst + (long long)bz_ * im.dst_stride;
+    const int x_first = bx_ * kBx, x_last = min(x_first + kBx, im.dw);  // this tile's columns [x_first, x_last)
+
+    // 1. bounding box of the tile's taps: wave 0, lane = 2 * row + end
+    if (ty == 0) {
+        int xmin = 0x7fffffff, xmax = -1, ymin = 0x7fffffff, ymax = -1;
+        const int row = y0 + (lane >> 1);
+        if (lane < 2 * kStageRows && row < im.dh) {
+            const AffineRow r = rows[row];
+            const int lo = max(r.lo, x_first), hi = min(r.hi, x_last);
+            if (lo < hi) {
+                const int xe = (lane & 1) ? hi - 1 : lo;
+                const int sx_q = (int)(r.sx_lo + (uint32_t)(xe - r.lo) * (uint32_t)dsx_q), sy_q = (int)(r.sy_lo + (uint32_t)(xe - r.lo) * (uint32_t)dsy_q);
+                xmin = xmax = min(max(sx_q >> 16, 0), im.sw - 1);
+                ymin = ymax = min(max(sy_q >> 16, 0), im.sh - 1);
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            xmin = min(xmin, __shfl_xor(xmin, m)); xmax = max(xmax, __shfl_xor(xmax, m));
+            ymin = min(ymin, __shfl_xor(ymin, m)); ymax = max(ymax, __shfl_xor(ymax, m));
+        }
+        if (lane == 0) { box[0] = xmin; box[1] = xmax; box[2] = ymin; box[3] = ymax; }
+    }
+    __syncthreads();
+    const int xmin = box[0], xmax = box[1], ymin = box[2], ymax = box[3];
+    if (xmax < 0) {  // no valid pixel in the tile: zeros
+#pragma unroll
+        for (int k = 0; k < kStageRows / 4; ++k) {
+            const int y = y0 + ty + 4 * k;
+            if (x < im.dw && y < im.dh) store_px_u8<C>(dst + ((long long)y * im.dw + x) * C, 0u, wave_full);
+        }
+        return;
+    }
+    // staged box: columns [bx0, bx0 + pitch), rows [ymin, by1]; the second taps are min(xi + 1, sw - 1) / min(yi + 1, sh - 1)
+    const int by1 = min(ymax + 1, im.sh - 1), bh = by1 - ymin + 1;
+    const int bw = min(xmax + 1, im.sw - 1) - xmin + 1, pitch = (bw + 3) & ~3;
+    const int bx0 = min(xmin, im.sw - pitch);  // keep every quad inside its row
+    const bool staged = bx0 >= 0 && pitch * bh <= kStageCap;   // block-uniform
+    if (staged) {
+        const int qpr = pitch >> 2, nq = qpr * bh;
+        for (int q = tid; q < nq; q += kBx * 4) {
+            const int r = q / qpr, c4 = q - r * qpr;
+            uint32_t px[4];
+            load_quad_px<C>(src + ((long long)(ymin + r) * im.sw + bx0 + 4 * c4) * C, px);
+            *reinterpret_cast<u32x4_t*>(&tile[r * pitch + 4 * c4]) = u32x4_t{px[0], px[1], px[2], px[3]};
+        }
+    }
+    __syncthreads();
+    // 2. sample: thread = column x of rows ty, ty + 4, ...
+#pragma unroll
+    for (int k = 0; k < kStageRows / 4; ++k) {
+        const int y = y0 + ty + 4 * k;
+        if (x >= im.dw || y >= im.dh) continue;   // a whole wave leaves together only when the row is outside (uniform); columns past dw idle
+        const AffineRow r = rows[y];
+        uint32_t px = 0;
+        if (x >= r.lo && x < r.hi) {
+            const int sx_q = (int)(r.sx_lo + (uint32_t)(x - r.lo) * (uint32_t)dsx_q);
+            const int sy_q = (int)(r.sy_lo + (uint32_t)(x - r.lo) * (uint32_t)dsy_q);
+            const int xi = min(max(sx_q >> 16, 0), im.sw - 1), yi = min(max(sy_q >> 16, 0), im.sh - 1);
+            const uint32_t fx = ((uint32_t)(sx_q & 0xFFFF)) >> 6, fy = ((uint32_t)(sy_q & 0xFFFF)) >> 6;
+            if (staged) {
+                const int xi1 = xi + 1 < im.sw ? xi + 1 : xi, yi1 = yi + 1 < im.sh ? yi + 1 : yi;
+                const uint32_t* t0 = tile + (yi - ymin) * pitch - bx0;
+                const uint32_t* t1 = tile + (yi1 - ymin) * pitch - bx0;
+                px = blend_q10<C>(t0[xi], t0[xi1], t1[xi], t1[xi1], fx, fy);
+            } else {
+                px = sample_q10<C>(src, im.sw, im.sh, xi, yi, fx, fy);
+            }
+        }
+        store_px_u8<C>(dst + ((long long)y * im.dw + x) * C, px, wave_full);
+    }
+}
+
 // warp_perspective_u8 (P/warp/perspective.rs:179-322): rows whose denominator keeps one sign get
 // the analytic span, other rows the bounds-checked sampler on every column; coordinates are
 // evaluated directly per column (perspective_coord_at, P/warp/kernels.rs:107-122).  Row terms come
@@ -676,7 +809,15 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     if (int32_t rc = get_scratch(stream, sizeof(AffineRow) * (size_t)dh, "kh_warp_affine_u8", scratch)) return rc;
     AffineRow* rows = scratch.as<AffineRow>();
     hipLaunchKernelGGL(affine_rows_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, as_hip(stream), rows, dw, dh, sw, sh, mi);
-    KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const AffineRow*)rows, dsx_q, dsy_q);
+    static const bool direct = [] { const char* e = getenv("KH_WARP_U8_DIRECT"); return e && e[0] == '1'; }();  // dev / test knob: the per-pixel kernel
+    if (direct) {
+        KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const AffineRow*)rows, dsx_q, dsy_q);
+    } else {
+        ImgU8 ims = im;  // 64 x kStageRows tiles, dealt to the XCDs in runs of 8 tile rows like the other gathers
+        ims.tiles = xcd_tiles(cdiv(dw, kBx), cdiv(dh, kStageRows), (unsigned)batch, cdiv(dw, kBx) * 8);
+        KH_REQUIRE(ims.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_affine_u8: batch x tiles exceeds one launch");
+        KH_DISPATCH_C(warp_affine_u8_lds_kernel, channels, xcd_grid(ims.tiles), as_hip(stream), ims, (const AffineRow*)rows, dsx_q, dsy_q);
+    }
     return check_launch("kh_warp_affine_u8");
 }
 

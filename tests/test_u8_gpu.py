@@ -123,6 +123,49 @@ def test_warp_affine_u8_matches_oracle(gpu_stream, c, name):  # P/warp/cuda.rs:1
         assert_same_bits(got, O.warp_affine_u8(src, m, dw, dh), f"affine_u8 {name} c{c} {w}x{h}->{dw}x{dh}")
 
 
+STAGED_CASES = {  # name -> (forward matrix builder, (w, h), (dw, dh)); sizes span several 64 x 16 tiles and ragged tile edges
+    "rot12_wide": (lambda: rotation(210.0, 75.0, 12.0, 0.9), (421, 150), (421, 150)),
+    "rot77_tall": (lambda: rotation(60.0, 170.0, 77.0, 1.1), (120, 341), (200, 130)),
+    "minify7": (lambda: [1 / 7.0, 0.0, 3.0, 0.0, 1 / 7.0, 2.0], (900, 500), (140, 75)),      # boxes too large for LDS: global fallback
+    "magnify5": (lambda: [5.0, 0.3, -20.0, -0.2, 5.0, 7.0], (70, 45), (330, 215)),
+    "shear_out": (lambda: [1.0, 0.9, -150.0, 0.05, 1.0, 40.0], (300, 120), (257, 129)),           # tiles fully / partly outside the source
+    "tiny_src": (lambda: [1.0, 0.0, 0.4, 0.0, 1.0, 0.3], (3, 5), (70, 20)),                       # source narrower than a quad
+    "last_row": (lambda: [1.0, 0.0, 0.0, 0.0, 1.0, -0.5], (67, 33), (67, 40)),                    # taps on the last source row / column
+}
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+@pytest.mark.parametrize("name", list(STAGED_CASES))
+def test_warp_affine_u8_staged_tiles_match_oracle(gpu_stream, c, name):
+    """The LDS-staged affine kernel: multi-tile images, ragged edges, boxes that do not fit (block-uniform fallback), quads at the
+    end of the last source row — byte for byte the restatement (and therefore the per-pixel kernel)."""
+    build, (w, h), (dw, dh) = STAGED_CASES[name]
+    m = build()
+    src = pat(w, h, c)
+    got = warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0]
+    assert_same_bits(got, O.warp_affine_u8(src, m, dw, dh), f"staged affine_u8 {name} c{c}")
+
+
+def test_warp_affine_u8_both_kernels_agree(gpu_stream, tmp_path):
+    """KH_WARP_U8_DIRECT=1 selects the per-pixel kernel (read once per process): a child process runs it on the same inputs and the
+    bytes must equal this process's LDS-staged result."""
+    import os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    src = pat(421, 150, 3)
+    m = rotation(210.0, 75.0, 12.0, 0.9)
+    staged = warp_u8_gpu(gpu_stream, "affine", np.stack([src, src[::-1].copy()]), m, 421, 150, batch=2)
+    np.save(tmp_path / "src.npy", src)
+    code = (f"import sys, numpy as np; sys.path[:0] = [{str(root / 'kornia-rs_amd')!r}, {str(root / 'tests')!r}]\n"
+            "import conftest, test_u8_gpu as T\nfrom kornia_rs import hip\n"
+            f"src = np.load({str(tmp_path / 'src.npy')!r}); st = hip.Stream.new(0)\n"
+            f"out = T.warp_u8_gpu(st, 'affine', np.stack([src, src[::-1].copy()]), {m!r}, 421, 150, batch=2)\n"
+            f"np.save({str(tmp_path / 'direct.npy')!r}, out)\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KH_WARP_U8_DIRECT="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(tmp_path / "direct.npy"), staged)
+
+
 PROJ = [0.9, 0.12, 4.0, -0.08, 1.05, -2.0, 6.0e-4, -4.5e-4, 1.0]
 HOMOGRAPHIES = {"proj": PROJ, "affine_h": [1.1, 0.1, -3.0, -0.05, 0.95, 2.0, 0.0, 0.0, 1.0], "neg": [-v for v in PROJ],
                 "flip": [-1, 0, 128, 0, 1, 0, 0, 0, 1], "identity": [1, 0, 0, 0, 1, 0, 0, 0, 1],
