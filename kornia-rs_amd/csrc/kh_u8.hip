@@ -14,6 +14,8 @@
 // 1 read + 1 write of HBM per byte instead of the reference's two passes through a scratch image.
 #include <math.h>
 
+#include <algorithm>
+
 #include "kh_common.h"
 
 using namespace kh;
@@ -512,20 +514,23 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_u8_kernel(ImgU8 im, cons
 
 
 // ---- LDS-staged affine warp -----------------------------------------------------------------------------------------------------
-// The per-pixel kernel above is bound by vector-memory INSTRUCTIONS: four scattered sub-dword loads per pixel (r01: 11.3 ms per 256
-// 4K images = 0.14 of the HBM roofline, PMC traffic only 1.11x the algorithmic bytes).  An affine map takes a 64 x kStageRows
-// destination tile to a parallelogram whose bounding box is small (12 deg, scale 0.9: 76 x 35 source pixels for 64 x 16 outputs), so
-// a block stages that box in LDS with wide contiguous loads — four pixels (4*C bytes) per lane per load, one dword per pixel in
-// LDS — and every tap becomes an aligned ds_read_b32.  The arithmetic is the per-pixel kernel's (same row spans, Q16 stepping,
-// clamps and Q10 blend), so the bytes are identical; tests compare both kernels with the restatement.
-//   * box = min / max of the clamped integer source coordinates at both ends of every row's valid span (coordinates are linear in x
-//     along a row, so the ends bound the row), +1 for the second tap, found by the first wave and shared through LDS;
-//   * a block whose box does not fit (strong minification, near-singular maps, tiny sources) samples from global memory exactly as
-//     the per-pixel kernel does — a block-uniform branch, no host-side case analysis;
-//   * the staged row pitch is the box width rounded up to 4 pixels; the box is shifted left inside the row when that would run past
-//     the row end, so quads never leave the image.
-constexpr int kStageRows = 16;          // destination rows per block (4 per thread)
-constexpr int kStageCap = 8192;         // staged pixels per block: 32 KiB of LDS, 5 blocks per CU
+// The per-pixel kernel above costs ~100 VALU instructions and 4 scattered sub-dword loads per pixel and runs at 0.14 of the HBM
+// roofline (11.3 ms per 256 4K images; PMC traffic only 1.11x the algorithmic bytes — it is not over-fetch).  An affine map takes a
+// 64 x 16 destination tile to a parallelogram with a small bounding box (12 deg, scale 0.9: 76 x 35 source pixels), so a block
+//   1. reads that box — min / max of the clamped integer source coordinates at both ends of every row's valid span (coordinates are
+//      linear in x along a row, so the ends bound the row), +1 column / row for the second taps — from a per-tile table one small
+//      launch builds for the whole batch (the boxes depend on the geometry only);
+//   2. stages it in LDS, ONE DWORD PER PIXEL, with wide contiguous loads (4 pixels = 4*C bytes per lane); cells past the last image
+//      column / row replicate the edge, which is exactly the reference's `xi + 1 < sw ? xi + 1 : xi` tap rule, so the sampler reads
+//      its four taps at fixed offsets {0, 1, pitch, pitch + 1} with no edge tests;
+//   3. samples: a thread owns FOUR CONSECUTIVE pixels of one row — coordinates step by adds, the blend uses four shared weights per
+//      pixel (blend_q10), and the 4*C result bytes leave in one store (no cross-lane packing, 4x fewer store instructions).
+// Same row spans, Q16 stepping, clamps and integer blend as the per-pixel kernel: the bytes are identical (tests run both).
+// LDS is sized by the host from the matrix (the box of a 64 x 16 tile, at most 32 KiB): a 12-degree rotation needs 11.5 KiB, so eight
+// blocks share a CU instead of five.  A block whose box does not fit (strong minification, near-singular maps, or a row-quantised box
+// a few pixels larger than the estimate) samples from global memory instead — a block-uniform branch.
+constexpr int kStageW = 64, kStageH = 16;   // destination tile
+constexpr int kStageCap = 8192;             // staged pixels per block: 32 KiB of LDS, 5 blocks per CU
 
 template <int C>
 __device__ __forceinline__ void load_quad_px(const uint8_t* __restrict__ p, uint32_t px[4]) {
@@ -545,102 +550,148 @@ __device__ __forceinline__ void load_quad_px(const uint8_t* __restrict__ p, uint
         px[0] = a & 0xffu; px[1] = (a >> 8) & 0xffu; px[2] = (a >> 16) & 0xffu; px[3] = a >> 24;
     }
 }
+// four packed pixels -> 4*C bytes at `o` (any alignment)
+template <int C>
+__device__ __forceinline__ void store_quad_px(uint8_t* o, const uint32_t px[4]) {
+    if constexpr (C == 4) {
+        *reinterpret_cast<u64_unaligned*>(o) = (uint64_t)px[0] | ((uint64_t)px[1] << 32);
+        *reinterpret_cast<u64_unaligned*>(o + 8) = (uint64_t)px[2] | ((uint64_t)px[3] << 32);
+    } else if constexpr (C == 3) {
+        *reinterpret_cast<u64_unaligned*>(o) = (uint64_t)px[0] | ((uint64_t)px[1] << 24) | ((uint64_t)px[2] << 48);
+        *reinterpret_cast<u32_unaligned*>(o + 8) = (px[2] >> 16) | (px[3] << 8);
+    } else if constexpr (C == 2) {
+        *reinterpret_cast<u64_unaligned*>(o) = (uint64_t)px[0] | ((uint64_t)px[1] << 16) | ((uint64_t)px[2] << 32) | ((uint64_t)px[3] << 48);
+    } else {
+        *reinterpret_cast<u32_unaligned*>(o) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+    }
+}
+template <int C>
+__device__ __forceinline__ void store_one_px(uint8_t* o, uint32_t px) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = (uint8_t)(px >> (8 * c));
+}
 
-// the Q10 blend of sample_q10 on four packed taps
+// The Q10 blend of sample_q10 on four packed taps.  sample_q10 computes ((p00*fx1 + p01*fx)*fy1 + (p10*fx1 + p11*fx)*fy + 2^19) >> 20
+// with exact integer intermediates, so the products distribute: four weights per PIXEL (each <= 2^20, summing to 2^20) and four
+// multiply-adds per channel give the same integer — about a third fewer VALU instructions for RGB.
 template <int C>
 __device__ __forceinline__ uint32_t blend_q10(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uint32_t fx, uint32_t fy) {
     const uint32_t fx1 = 1024u - fx, fy1 = 1024u - fy;
+    const uint32_t w00 = __umul24(fx1, fy1), w01 = __umul24(fx, fy1), w10 = __umul24(fx1, fy), w11 = __umul24(fx, fy);
     uint32_t px = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const uint32_t top = chan_u8(p00, c) * fx1 + chan_u8(p01, c) * fx, bot = chan_u8(p10, c) * fx1 + chan_u8(p11, c) * fx;
-        px |= (((top * fy1 + bot * fy + (1u << 19)) >> 20) & 0xffu) << (8 * c);
+        const uint32_t acc = __umul24(chan_u8(p00, c), w00) + __umul24(chan_u8(p01, c), w01) + __umul24(chan_u8(p10, c), w10) +
+                             __umul24(chan_u8(p11, c), w11) + (1u << 19);
+        px |= ((acc >> 20) & 0xffu) << (8 * c);
     }
     return px;
 }
 
+// Bounding boxes of the tiles' first taps, one per (tile column, tile row): they depend on the geometry only, so ONE small launch
+// computes them for the whole batch and the main kernel reads its box with a scalar load instead of a wave reduction + barrier.
+struct TileBox { int xmin, xmax, ymin, ymax; };
+__global__ __launch_bounds__(64) void affine_boxes_kernel(TileBox* __restrict__ boxes, const AffineRow* __restrict__ rows, int tiles_x, int tiles_y,
+                                                          int dw, int dh, int sw, int sh, int dsx_q, int dsy_q) {
+    const int tile = blockIdx.x, lane = threadIdx.x;   // one wave per tile, lane = 2 * row + end
+    const int bx = tile % tiles_x, by = tile / tiles_x;
+    const int x_first = bx * kStageW, x_last = min(x_first + kStageW, dw), row = by * kStageH + (lane >> 1);
+    int xmin = 0x7fffffff, xmax = -1, ymin = 0x7fffffff, ymax = -1;
+    if (lane < 2 * kStageH && row < dh) {
+        const AffineRow r = rows[row];
+        const int lo = max(r.lo, x_first), hi = min(r.hi, x_last);
+        if (lo < hi) {
+            const int xe = (lane & 1) ? hi - 1 : lo;
+            const int sx_q = (int)(r.sx_lo + (uint32_t)(xe - r.lo) * (uint32_t)dsx_q), sy_q = (int)(r.sy_lo + (uint32_t)(xe - r.lo) * (uint32_t)dsy_q);
+            xmin = xmax = min(max(sx_q >> 16, 0), sw - 1);
+            ymin = ymax = min(max(sy_q >> 16, 0), sh - 1);
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) {
+        xmin = min(xmin, __shfl_xor(xmin, m)); xmax = max(xmax, __shfl_xor(xmax, m));
+        ymin = min(ymin, __shfl_xor(ymin, m)); ymax = max(ymax, __shfl_xor(ymax, m));
+    }
+    if (lane == 0) boxes[tile] = TileBox{xmin, xmax, ymin, ymax};
+}
+
+extern __shared__ __attribute__((aligned(16))) uint32_t kh_warp_tile[];   // dynamic: sized by the host from the matrix (cap_px pixels), at most kStageCap
+
 template <int C>
-__global__ __launch_bounds__(kBx * 4) void warp_affine_u8_lds_kernel(ImgU8 im, const AffineRow* __restrict__ rows, int dsx_q, int dsy_q) {
-    __shared__ uint32_t tile[kStageCap];
-    __shared__ int box[4];
+__global__ __launch_bounds__(256) void warp_affine_u8_lds_kernel(ImgU8 im, const AffineRow* __restrict__ rows, const TileBox* __restrict__ boxes,
+                                                                 int dsx_q, int dsy_q, int cap_px) {
+    uint32_t* tile = kh_warp_tile;
     unsigned bx_, by_, bz_;
     if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;
-    const int lane = threadIdx.x, ty = threadIdx.y, tid = ty * kBx + lane;
-    const int x = bx_ * kBx + lane, y0 = by_ * kStageRows;
-    const bool wave_full = (int)(bx_ * kBx) + kBx <= im.dw;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;   // block (16, 16): 16 four-pixel groups x 16 rows
+    const int x_first = bx_ * kStageW, y0 = by_ * kStageH;
     const uint8_t* src = im.src + (long long)bz_ * im.src_stride;
     uint8_t* dst = im.dst + (long long)bz_ * im.dst_stride;
-    const int x_first = bx_ * kBx, x_last = min(x_first + kBx, im.dw);  // this tile's columns [x_first, x_last)
-
-    // 1. bounding box of the tile's taps: wave 0, lane = 2 * row + end
-    if (ty == 0) {
-        int xmin = 0x7fffffff, xmax = -1, ymin = 0x7fffffff, ymax = -1;
-        const int row = y0 + (lane >> 1);
-        if (lane < 2 * kStageRows && row < im.dh) {
-            const AffineRow r = rows[row];
-            const int lo = max(r.lo, x_first), hi = min(r.hi, x_last);
-            if (lo < hi) {
-                const int xe = (lane & 1) ? hi - 1 : lo;
-                const int sx_q = (int)(r.sx_lo + (uint32_t)(xe - r.lo) * (uint32_t)dsx_q), sy_q = (int)(r.sy_lo + (uint32_t)(xe - r.lo) * (uint32_t)dsy_q);
-                xmin = xmax = min(max(sx_q >> 16, 0), im.sw - 1);
-                ymin = ymax = min(max(sy_q >> 16, 0), im.sh - 1);
-            }
-        }
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
-            xmin = min(xmin, __shfl_xor(xmin, m)); xmax = max(xmax, __shfl_xor(xmax, m));
-            ymin = min(ymin, __shfl_xor(ymin, m)); ymax = max(ymax, __shfl_xor(ymax, m));
-        }
-        if (lane == 0) { box[0] = xmin; box[1] = xmax; box[2] = ymin; box[3] = ymax; }
-    }
-    __syncthreads();
-    const int xmin = box[0], xmax = box[1], ymin = box[2], ymax = box[3];
-    if (xmax < 0) {  // no valid pixel in the tile: zeros
-#pragma unroll
-        for (int k = 0; k < kStageRows / 4; ++k) {
-            const int y = y0 + ty + 4 * k;
-            if (x < im.dw && y < im.dh) store_px_u8<C>(dst + ((long long)y * im.dw + x) * C, 0u, wave_full);
+    const TileBox tb = boxes[by_ * im.tiles.tiles_x + bx_];   // block-uniform index: a scalar load
+    const int xmin = tb.xmin, xmax = tb.xmax, ymin = tb.ymin, ymax = tb.ymax;
+    const int y = y0 + ty, x4 = x_first + 4 * tx;
+    const bool mine = y < im.dh && x4 < im.dw;                  // this thread has pixels
+    const bool whole = x4 + 3 < im.dw;                           // all four are inside the row
+    uint8_t* o = dst + ((long long)y * im.dw + x4) * C;
+    if (xmax < 0) {  // no valid pixel in the tile (block-uniform): zeros
+        if (mine) {
+            const uint32_t z[4] = {0u, 0u, 0u, 0u};
+            if (whole) store_quad_px<C>(o, z);
+            else for (int j = 0; x4 + j < im.dw; ++j) store_one_px<C>(o + j * C, 0u);
         }
         return;
     }
-    // staged box: columns [bx0, bx0 + pitch), rows [ymin, by1]; the second taps are min(xi + 1, sw - 1) / min(yi + 1, sh - 1)
-    const int by1 = min(ymax + 1, im.sh - 1), bh = by1 - ymin + 1;
-    const int bw = min(xmax + 1, im.sw - 1) - xmin + 1, pitch = (bw + 3) & ~3;
-    const int bx0 = min(xmin, im.sw - pitch);  // keep every quad inside its row
-    const bool staged = bx0 >= 0 && pitch * bh <= kStageCap;   // block-uniform
+    // staged box: columns [xmin, xmin + pitch), rows [ymin, ymax + 1]; one column / row more than the first taps reach, cells past
+    // the image edge replicate it
+    const int bh = ymax + 2 - ymin, pitch = (xmax + 2 - xmin + 3) & ~3;
+    const bool staged = pitch * bh <= cap_px;   // block-uniform
     if (staged) {
         const int qpr = pitch >> 2, nq = qpr * bh;
-        for (int q = tid; q < nq; q += kBx * 4) {
-            const int r = q / qpr, c4 = q - r * qpr;
+        const float inv_qpr = 1.0f / (float)qpr;   // q / qpr for q < 8192: the float quotient is within one of the integer one
+        for (int q = tid; q < nq; q += 256) {
+            int r = (int)((float)q * inv_qpr);
+            r -= (r * qpr > q);
+            r += ((r + 1) * qpr <= q);
+            const int c0 = xmin + 4 * (q - r * qpr);
+            const uint8_t* srow = src + (long long)min(ymin + r, im.sh - 1) * im.sw * C;
             uint32_t px[4];
-            load_quad_px<C>(src + ((long long)(ymin + r) * im.sw + bx0 + 4 * c4) * C, px);
-            *reinterpret_cast<u32x4_t*>(&tile[r * pitch + 4 * c4]) = u32x4_t{px[0], px[1], px[2], px[3]};
+            if (c0 + 3 < im.sw) {
+                load_quad_px<C>(srow + (long long)c0 * C, px);
+            } else {  // the quad reaches past the last column: per-pixel, clamped (replicated edge)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) px[j] = load_px_u8<C>(srow + (long long)min(c0 + j, im.sw - 1) * C);
+            }
+            *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = u32x4_t{px[0], px[1], px[2], px[3]};   // q * 4 == r * pitch + 4 * c4
         }
     }
     __syncthreads();
-    // 2. sample: thread = column x of rows ty, ty + 4, ...
+    if (!mine) return;
+    // 2. sample four consecutive pixels of row y
+    const AffineRow r = rows[y];
+    const uint32_t sxb = r.sx_lo + (uint32_t)(x4 - r.lo) * (uint32_t)dsx_q, syb = r.sy_lo + (uint32_t)(x4 - r.lo) * (uint32_t)dsy_q;
+    const uint32_t* tbase = tile - ymin * pitch - xmin;   // tbase[yi * pitch + xi] = source pixel (xi, yi)
+    uint32_t out[4];
 #pragma unroll
-    for (int k = 0; k < kStageRows / 4; ++k) {
-        const int y = y0 + ty + 4 * k;
-        if (x >= im.dw || y >= im.dh) continue;   // a whole wave leaves together only when the row is outside (uniform); columns past dw idle
-        const AffineRow r = rows[y];
+    for (int j = 0; j < 4; ++j) {
+        const int x = x4 + j;
         uint32_t px = 0;
         if (x >= r.lo && x < r.hi) {
-            const int sx_q = (int)(r.sx_lo + (uint32_t)(x - r.lo) * (uint32_t)dsx_q);
-            const int sy_q = (int)(r.sy_lo + (uint32_t)(x - r.lo) * (uint32_t)dsy_q);
+            const int sx_q = (int)(sxb + (uint32_t)j * (uint32_t)dsx_q), sy_q = (int)(syb + (uint32_t)j * (uint32_t)dsy_q);
+            // The span keeps the indices in range in exact arithmetic; the clamp only matters where Q16 rounding drift would take the
+            // reference's unchecked sampler outside the image.
             const int xi = min(max(sx_q >> 16, 0), im.sw - 1), yi = min(max(sy_q >> 16, 0), im.sh - 1);
             const uint32_t fx = ((uint32_t)(sx_q & 0xFFFF)) >> 6, fy = ((uint32_t)(sy_q & 0xFFFF)) >> 6;
             if (staged) {
-                const int xi1 = xi + 1 < im.sw ? xi + 1 : xi, yi1 = yi + 1 < im.sh ? yi + 1 : yi;
-                const uint32_t* t0 = tile + (yi - ymin) * pitch - bx0;
-                const uint32_t* t1 = tile + (yi1 - ymin) * pitch - bx0;
-                px = blend_q10<C>(t0[xi], t0[xi1], t1[xi], t1[xi1], fx, fy);
+                const uint32_t* t0 = tbase + yi * pitch + xi;
+                px = blend_q10<C>(t0[0], t0[1], t0[pitch], t0[pitch + 1], fx, fy);
             } else {
                 px = sample_q10<C>(src, im.sw, im.sh, xi, yi, fx, fy);
             }
         }
-        store_px_u8<C>(dst + ((long long)y * im.dw + x) * C, px, wave_full);
+        out[j] = px;
     }
+    if (whole) store_quad_px<C>(o, out);
+    else for (int j = 0; x4 + j < im.dw; ++j) store_one_px<C>(o + j * C, out[j]);
 }
 
 // warp_perspective_u8 (P/warp/perspective.rs:179-322): rows whose denominator keeps one sign get
@@ -806,17 +857,40 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
     KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_affine_u8: batch x tiles exceeds one launch");
     Scratch scratch;  // per-row spans shared by the batch: caller workspace or stream-ordered pool
-    if (int32_t rc = get_scratch(stream, sizeof(AffineRow) * (size_t)dh, "kh_warp_affine_u8", scratch)) return rc;
+    static_assert(sizeof(AffineRow) == 16 && sizeof(TileBox) == 16, "the tile boxes follow the row records in one scratch block");
+    if (int32_t rc = get_scratch(stream, sizeof(AffineRow) * (size_t)dh + sizeof(TileBox) * (size_t)cdiv(dw, kStageW) * cdiv(dh, kStageH), "kh_warp_affine_u8", scratch))
+        return rc;
     AffineRow* rows = scratch.as<AffineRow>();
     hipLaunchKernelGGL(affine_rows_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, as_hip(stream), rows, dw, dh, sw, sh, mi);
     static const bool direct = [] { const char* e = getenv("KH_WARP_U8_DIRECT"); return e && e[0] == '1'; }();  // dev / test knob: the per-pixel kernel
     if (direct) {
         KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const AffineRow*)rows, dsx_q, dsy_q);
     } else {
-        ImgU8 ims = im;  // 64 x kStageRows tiles, dealt to the XCDs in runs of 8 tile rows like the other gathers
-        ims.tiles = xcd_tiles(cdiv(dw, kBx), cdiv(dh, kStageRows), (unsigned)batch, cdiv(dw, kBx) * 8);
+        ImgU8 ims = im;  // 64 x 16 tiles, dealt to the XCDs in runs of 8 tile rows like the other gathers
+        const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, kStageH);
+        ims.tiles = xcd_tiles(tiles_x, tiles_y, (unsigned)batch, tiles_x * 8);
         KH_REQUIRE(ims.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_affine_u8: batch x tiles exceeds one launch");
-        KH_DISPATCH_C(warp_affine_u8_lds_kernel, channels, xcd_grid(ims.tiles), as_hip(stream), ims, (const AffineRow*)rows, dsx_q, dsy_q);
+        const hipStream_t st = as_hip(stream);
+        TileBox* boxes = reinterpret_cast<TileBox*>(rows + dh);   // same scratch block (sized below)
+        hipLaunchKernelGGL(affine_boxes_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, st, boxes, (const AffineRow*)rows, (int)tiles_x, (int)tiles_y, dw, dh,
+                           sw, sh, dsx_q, dsy_q);
+        // LDS per block: the source box of a 64 x 16 tile under this matrix (+ the second-tap column / row, quad rounding, slack for
+        // the per-row Q16 rounding), capped at kStageCap pixels
+        const double bwf = kStageW * fabs((double)mi.m[0]) + kStageH * fabs((double)mi.m[1]), bhf = kStageW * fabs((double)mi.m[3]) + kStageH * fabs((double)mi.m[4]);
+        int cap_px = kStageCap;
+        if (bwf < 4096.0 && bhf < 4096.0) {
+            const long long want = (long long)(((int)ceil(bwf) + 4 + 3) & ~3) * ((int)ceil(bhf) + 4);
+            cap_px = (int)std::min<long long>(kStageCap, std::max<long long>(want, 256));
+        }
+        const dim3 grid = xcd_grid(ims.tiles), blk(16, 16);
+        const size_t lds = (size_t)cap_px * 4;
+        const AffineRow* rr = rows;
+        switch (channels) {
+            case 1: hipLaunchKernelGGL(warp_affine_u8_lds_kernel<1>, grid, blk, lds, st, ims, rr, (const TileBox*)boxes, dsx_q, dsy_q, cap_px); break;
+            case 2: hipLaunchKernelGGL(warp_affine_u8_lds_kernel<2>, grid, blk, lds, st, ims, rr, (const TileBox*)boxes, dsx_q, dsy_q, cap_px); break;
+            case 3: hipLaunchKernelGGL(warp_affine_u8_lds_kernel<3>, grid, blk, lds, st, ims, rr, (const TileBox*)boxes, dsx_q, dsy_q, cap_px); break;
+            default: hipLaunchKernelGGL(warp_affine_u8_lds_kernel<4>, grid, blk, lds, st, ims, rr, (const TileBox*)boxes, dsx_q, dsy_q, cap_px); break;
+        }
     }
     return check_launch("kh_warp_affine_u8");
 }

@@ -76,6 +76,7 @@ inline uint32_t hostsim_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
     return out;
 }
 #define __builtin_amdgcn_perm(a, b, sel) hostsim_perm((a), (b), (sel))
+#define __builtin_amdgcn_readfirstlane(v) (v)  /* only ever applied to wave-uniform values */
 // raw buffer accesses: base + soffset + voffset, dropped / zero when voffset + size runs past num_records (the hardware range check)
 struct hostsim_rsrc { char* base; uint32_t n; };
 typedef hostsim_rsrc __amdgpu_buffer_rsrc_t;
