@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_u8_kernel(ImgU8 im, cons
 // ---- LDS-staged affine warp -----------------------------------------------------------------------------------------------------
 // The per-pixel kernel above costs ~100 VALU instructions and 4 scattered sub-dword loads per pixel and runs at 0.14 of the HBM
 // roofline (11.3 ms per 256 4K images; PMC traffic only 1.11x the algorithmic bytes — it is not over-fetch).  An affine map takes a
-// 64 x 16 destination tile to a parallelogram with a small bounding box (12 deg, scale 0.9: 76 x 35 source pixels), so a block
+// 64 x 32 destination tile to a parallelogram with a small bounding box (12 deg, scale 0.9: 80 x 53 source pixels), so a block
 //   1. reads that box — min / max of the clamped integer source coordinates at both ends of every row's valid span (coordinates are
 //      linear in x along a row, so the ends bound the row), +1 column / row for the second taps — from a per-tile table one small
 //      launch builds for the whole batch (the boxes depend on the geometry only);
@@ -526,10 +526,10 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_u8_kernel(ImgU8 im, cons
 //   3. samples: a thread owns FOUR CONSECUTIVE pixels of one row — coordinates step by adds, the blend uses four shared weights per
 //      pixel (blend_q10), and the 4*C result bytes leave in one store (no cross-lane packing, 4x fewer store instructions).
 // Same row spans, Q16 stepping, clamps and integer blend as the per-pixel kernel: the bytes are identical (tests run both).
-// LDS is sized by the host from the matrix (the box of a 64 x 16 tile, at most 32 KiB): a 12-degree rotation needs 11.5 KiB, so eight
-// blocks share a CU instead of five.  A block whose box does not fit (strong minification, near-singular maps, or a row-quantised box
+// LDS is sized by the host from the matrix (the box of a 64 x 32 tile, at most 32 KiB): a 12-degree rotation needs 18 KiB, so four
+// 512-thread blocks share a CU (the wave limit) instead of the two a fixed 32 KiB would allow...   A block whose box does not fit (strong minification, near-singular maps, or a row-quantised box
 // a few pixels larger than the estimate) samples from global memory instead — a block-uniform branch.
-constexpr int kStageW = 64, kStageH = 16;   // destination tile
+constexpr int kStageW = 64, kStageH = 32;   // destination tile (same-box A/B on the 4K rotation: 8 rows 5.05 ms, 16 rows 4.60 ms, 32 rows 4.46 ms)
 constexpr int kStageCap = 8192;             // staged pixels per block: 32 KiB of LDS, 5 blocks per CU
 
 template <int C>
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(64) void affine_boxes_kernel(TileBox* __restrict__ 
         }
     }
 #pragma unroll
-    for (int m = 1; m < 32; m <<= 1) {
+    for (int m = 1; m < 64; m <<= 1) {
         xmin = min(xmin, __shfl_xor(xmin, m)); xmax = max(xmax, __shfl_xor(xmax, m));
         ymin = min(ymin, __shfl_xor(ymin, m)); ymax = max(ymax, __shfl_xor(ymax, m));
     }
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64) void affine_boxes_kernel(TileBox* __restrict__ 
 extern __shared__ __attribute__((aligned(16))) uint32_t kh_warp_tile[];   // dynamic: sized by the host from the matrix (cap_px pixels), at most kStageCap
 
 template <int C>
-__global__ __launch_bounds__(256) void warp_affine_u8_lds_kernel(ImgU8 im, const AffineRow* __restrict__ rows, const TileBox* __restrict__ boxes,
+__global__ __launch_bounds__(16 * kStageH) void warp_affine_u8_lds_kernel(ImgU8 im, const AffineRow* __restrict__ rows, const TileBox* __restrict__ boxes,
                                                                  int dsx_q, int dsy_q, int cap_px) {
     uint32_t* tile = kh_warp_tile;
     unsigned bx_, by_, bz_;
@@ -633,6 +633,9 @@ __global__ __launch_bounds__(256) void warp_affine_u8_lds_kernel(ImgU8 im, const
     const bool mine = y < im.dh && x4 < im.dw;                  // this thread has pixels
     const bool whole = x4 + 3 < im.dw;                           // all four are inside the row
     uint8_t* o = dst + ((long long)y * im.dw + x4) * C;
+    // this thread's row record: loaded BEFORE the staging phase so its latency hides behind it (the compiler cannot move a load
+    // across the barrier below)
+    const AffineRow r = rows[min(y, im.dh - 1)];
     if (xmax < 0) {  // no valid pixel in the tile (block-uniform): zeros
         if (mine) {
             const uint32_t z[4] = {0u, 0u, 0u, 0u};
@@ -648,26 +651,32 @@ __global__ __launch_bounds__(256) void warp_affine_u8_lds_kernel(ImgU8 im, const
     if (staged) {
         const int qpr = pitch >> 2, nq = qpr * bh;
         const float inv_qpr = 1.0f / (float)qpr;   // q / qpr for q < 8192: the float quotient is within one of the integer one
-        for (int q = tid; q < nq; q += 256) {
-            int r = (int)((float)q * inv_qpr);
-            r -= (r * qpr > q);
-            r += ((r + 1) * qpr <= q);
-            const int c0 = xmin + 4 * (q - r * qpr);
-            const uint8_t* srow = src + (long long)min(ymin + r, im.sh - 1) * im.sw * C;
-            uint32_t px[4];
+        auto fetch = [&](int q, uint32_t px[4]) {
+            int r_ = (int)((float)q * inv_qpr);
+            r_ -= (r_ * qpr > q);
+            r_ += ((r_ + 1) * qpr <= q);
+            const int c0 = xmin + 4 * (q - r_ * qpr);
+            const uint8_t* srow = src + (long long)min(ymin + r_, im.sh - 1) * im.sw * C;
             if (c0 + 3 < im.sw) {
                 load_quad_px<C>(srow + (long long)c0 * C, px);
             } else {  // the quad reaches past the last column: per-pixel, clamped (replicated edge)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) px[j] = load_px_u8<C>(srow + (long long)min(c0 + j, im.sw - 1) * C);
             }
-            *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = u32x4_t{px[0], px[1], px[2], px[3]};   // q * 4 == r * pitch + 4 * c4
+        };
+        constexpr int kT = 16 * kStageH;
+        for (int q = tid; q < nq; q += 2 * kT) {   // two quads in flight per thread: both loads issue before the first LDS write
+            uint32_t pa[4], pb[4];
+            const bool second = q + kT < nq;
+            fetch(q, pa);
+            fetch(second ? q + kT : q, pb);
+            *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = u32x4_t{pa[0], pa[1], pa[2], pa[3]};   // q * 4 == r * pitch + 4 * c4
+            if (second) *reinterpret_cast<u32x4_t*>(&tile[(q + kT) * 4]) = u32x4_t{pb[0], pb[1], pb[2], pb[3]};
         }
     }
     __syncthreads();
     if (!mine) return;
     // 2. sample four consecutive pixels of row y
-    const AffineRow r = rows[y];
     const uint32_t sxb = r.sx_lo + (uint32_t)(x4 - r.lo) * (uint32_t)dsx_q, syb = r.sy_lo + (uint32_t)(x4 - r.lo) * (uint32_t)dsy_q;
     const uint32_t* tbase = tile - ymin * pitch - xmin;   // tbase[yi * pitch + xi] = source pixel (xi, yi)
     uint32_t out[4];
@@ -866,7 +875,7 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     if (direct) {
         KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const AffineRow*)rows, dsx_q, dsy_q);
     } else {
-        ImgU8 ims = im;  // 64 x 16 tiles, dealt to the XCDs in runs of 8 tile rows like the other gathers
+        ImgU8 ims = im;  // 64 x 32 tiles, dealt to the XCDs in runs of 8 tile rows like the other gathers
         const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, kStageH);
         ims.tiles = xcd_tiles(tiles_x, tiles_y, (unsigned)batch, tiles_x * 8);
         KH_REQUIRE(ims.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_affine_u8: batch x tiles exceeds one launch");
@@ -874,7 +883,7 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
         TileBox* boxes = reinterpret_cast<TileBox*>(rows + dh);   // same scratch block (sized below)
         hipLaunchKernelGGL(affine_boxes_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, st, boxes, (const AffineRow*)rows, (int)tiles_x, (int)tiles_y, dw, dh,
                            sw, sh, dsx_q, dsy_q);
-        // LDS per block: the source box of a 64 x 16 tile under this matrix (+ the second-tap column / row, quad rounding, slack for
+        // LDS per block: the source box of a 64 x 32 tile under this matrix (+ the second-tap column / row, quad rounding, slack for
         // the per-row Q16 rounding), capped at kStageCap pixels
         const double bwf = kStageW * fabs((double)mi.m[0]) + kStageH * fabs((double)mi.m[1]), bhf = kStageW * fabs((double)mi.m[3]) + kStageH * fabs((double)mi.m[4]);
         int cap_px = kStageCap;
@@ -882,7 +891,7 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
             const long long want = (long long)(((int)ceil(bwf) + 4 + 3) & ~3) * ((int)ceil(bhf) + 4);
             cap_px = (int)std::min<long long>(kStageCap, std::max<long long>(want, 256));
         }
-        const dim3 grid = xcd_grid(ims.tiles), blk(16, 16);
+        const dim3 grid = xcd_grid(ims.tiles), blk(16, kStageH);
         const size_t lds = (size_t)cap_px * 4;
         const AffineRow* rr = rows;
         switch (channels) {
