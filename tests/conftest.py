@@ -14,12 +14,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-# Files whose GPU tests were written after this round's last device run (they pass on the host simulator of the kernels,
-# tests/hostsim; a device run is pending).  `pytest -x` stops at the first failure, so they are collected AFTER the
-# device-verified files: a surprise in a new test must not hide the verdict on the ~700 tests that already ran on MI355X.
-# Empty this list once a device run has covered them.
-DEVICE_RUN_PENDING = ("test_bench_workloads_gpu.py", "test_color_f64.py", "test_video_modes.py", "test_fuzz_gpu.py",
-                      "test_cpp_mirror.py", "test_filter_extra_gpu.py", "test_zz_host_extras_gpu.py")
+# Files whose GPU tests were written after the last device run of everything else go here: `pytest -x` stops at the first
+# failure, so they are collected AFTER the device-verified files and a surprise in a new test cannot hide the verdict on the
+# suite that already ran on MI355X.  Empty since round 2: every file has run on the device (GPUTEST_r01.json, profiles/r02h).
+DEVICE_RUN_PENDING = ()
 
 
 def pytest_collection_modifyitems(config, items):
