@@ -10,7 +10,14 @@ for g in "${GROUPS_[@]}"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $g -d "$REPO/$OUT/pmc_$i" -o pmc -- python "$REPO/bench.py" --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --also none > "$REPO/$OUT/pmc_$i.log" 2>&1
   db=$(find "$REPO/$OUT/pmc_$i" -name '*.db' | head -1)
-  [ -n "$db" ] && python "$REPO/scripts/rocpd_summary.py" "$db" | grep -v rocclr | tail -n +1 | grep -E "counter|warp|kernel<|_kernel" | cut -c1-60,150- >> "$REPO/$OUT/pmc_$WL.txt"
+  [ -n "$db" ] && python "$REPO/scripts/rocpd_summary.py" "$db" | grep -v rocclr | sed -n '/counter,mean/,$p' >> "$REPO/$OUT/pmc_$WL.txt"
 done
-cat "$REPO/$OUT/pmc_$WL.txt"
+python - "$REPO/$OUT/pmc_$WL.txt" <<'PY'
+import re, sys
+for line in open(sys.argv[1]):
+    m = re.match(r'"(.*)",(\w+),([\d.]+),(\d+)', line.strip())
+    if m:
+        name = re.sub(r"\(.*", "", m.group(1).replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))
+        print(f"  {name:44s} {m.group(2):24s} {float(m.group(3)):18.1f}")
+PY
 find "$REPO/$OUT" -name '*.db' -delete
