@@ -82,8 +82,9 @@ class NorthStarNV12(Workload):
     kernel = "preprocess_nv12_identity"
     dtype = "f32"
 
-    def __init__(self, batch: int = 1024, out: int = 0):
+    def __init__(self, batch: int = 1024, out: int = 0, sampling: str = "bilinear"):
         self.N = batch
+        self.sampling = sampling
         self.out = out  # 0: same-size (north star); else letterbox to out x out (secondary row)
         self.frame_bytes = self.W * self.H * 3 // 2
         px = self.W * self.H
@@ -92,10 +93,11 @@ class NorthStarNV12(Workload):
             # 1.5 B/px read + 12 B/px written = 27 993 600 B per frame
             self.alg_bytes_per_launch = self.N * (self.frame_bytes + 12 * px)
         else:
-            self.name = f"nv12_1080p_to_chw_f32_letterbox{out}_b{batch}"
+            self.name = f"nv12_1080p_to_chw_f32_letterbox{out}{'' if sampling == 'bilinear' else '_' + sampling}_b{batch}"
             self.kernel = "preprocess_generic"
-            # out*out*12 B written + taps actually required (<= 4 taps * 1.5 B per output pixel)
-            self.alg_bytes_per_launch = self.N * (out * out * 12 + out * out * 4 * 3 // 2)
+            # out*out*12 B written + taps actually required (<= 4 taps * 1.5 B per output pixel; 36 for Lanczos-3)
+            taps = 36 if sampling == "lanczos" else 4
+            self.alg_bytes_per_launch = self.N * (out * out * 12 + out * out * taps * 3 // 2)
 
     def setup(self, stream):
         from kornia_rs import Preprocessor, Tensor
@@ -112,7 +114,7 @@ class NorthStarNV12(Workload):
         oh, ow = (self.H, self.W) if self.out == 0 else (self.out, self.out)
         self.dst = Tensor.uninit((self.N, 3, oh, ow), "float32", stream)
         self.pre = Preprocessor(mode="stretch" if self.out == 0 else "letterbox", format="nv12",
-                                sampling="bilinear", mean=IMAGENET_MEAN, std=IMAGENET_STD,
+                                sampling=self.sampling, mean=IMAGENET_MEAN, std=IMAGENET_STD,
                                 stream=stream)
 
     def step(self):
@@ -136,7 +138,7 @@ class NorthStarNV12(Workload):
             raw = self.base[31 * (frames % self.N): 31 * (frames % self.N) + self.frame_bytes]
             rgb = O.rgb_from_nv12(raw, self.W, self.H)
             O.preprocess(rgb, self.W, self.H, ow, oh, fmt="rgb",
-                         mode="stretch" if self.out == 0 else "letterbox",
+                         mode="stretch" if self.out == 0 else "letterbox", sampling=self.sampling,
                          mean=IMAGENET_MEAN, std=IMAGENET_STD)
             frames += 1
             dt = time.perf_counter() - t0
@@ -146,7 +148,7 @@ class NorthStarNV12(Workload):
                 "cores": threads, "kind": "port",
                 "sample": f"{frames} frames of the same 1080p NV12 workload in {dt:.1f} s; C oracle "
                           "(faithful restatement of kornia-imgproc, not the upstream Rust binary), "
-                          f"chained rgb_from_nv12 -> bilinear/normalize/CHW, OpenMP x{threads}"}
+                          f"chained rgb_from_nv12 -> {self.sampling}/normalize/CHW, OpenMP x{threads}"}
 
 
 class F32Images(Workload):
@@ -938,6 +940,7 @@ class GrayPlumbing258x195(Workload):
 WORKLOADS = {
     "nv12_chw": lambda a: NorthStarNV12(a.batch or 1024, 0),
     "nv12_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640),
+    "nv12_chw_640_lanczos": lambda a: NorthStarNV12(a.batch or 256, 640, "lanczos"),
     "resize_224": lambda a: ResizeBilinear(a.batch or 256),
     "resize_normalize_f32_224": lambda a: ResizeNormalizeF32(a.batch or 256),
     "gaussian_4k": lambda a: Gaussian4K(a.batch or 256),

@@ -211,24 +211,92 @@ __device__ __forceinline__ float lanczos_w(float d) {
     return 3.0f * sinf(pd) * sinf(pd / 3.0f) / (pd * pd);
 }
 
+// One row of the 6-tap Lanczos window, pixels clamp(x0 - 2 + i, 0, w - 1) for i = 0..5, decoded to float RGB.
+// The six taps of a row are adjacent in memory, so they come from ONE or TWO wide loads — NV12: 8 luma bytes + 4 chroma pairs,
+// Gray: 8 bytes, YUYV: 4 groups — taken from a window base clamped into the row; a tap picks its byte / pair by a variable shift,
+// which also implements the border replication (clamped taps index the edge pixel again).  72 loads per destination pixel in the
+// per-tap form (6 x 6 x (luma byte + chroma pair)) become 12.  Interleaved RGB / BGR taps are one unaligned dword each (36 loads
+// instead of 108).  Needs rows of at least 8 pixels; narrower sources take the per-tap path.
+template <int FMT>
+__device__ __forceinline__ void fetch_row6(const uint8_t* __restrict__ src, int x0, int yc, const PreArgs& a, float t[6][3]) {
+    if constexpr (FMT == KH_FMT_NV12 || FMT == KH_FMT_GRAY) {
+        const int pitch = FMT == KH_FMT_NV12 ? a.src_w : a.src_pitch;
+        const int xb = min(max(x0 - 2, 0), a.src_w - 8);                      // bytes xb .. xb + 7 are in the row
+        const uint64_t yw = *reinterpret_cast<const u64u*>(src + (unsigned)(yc * pitch + xb));
+        uint64_t cw = 0;
+        int cb = 0;
+        if constexpr (FMT == KH_FMT_NV12) {
+            cb = min(max((x0 - 2) >> 1, 0), (a.src_w >> 1) - 4);              // chroma pairs cb .. cb + 3 are in the row
+            cw = *reinterpret_cast<const u64u*>(src + (unsigned)(a.src_w * a.src_h + (yc >> 1) * a.src_w + cb * 2));
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int xc = min(max(x0 - 2 + i, 0), a.src_w - 1);
+            const int yv = (int)((yw >> (8 * (xc - xb))) & 0xFF);
+            if constexpr (FMT == KH_FMT_NV12) {
+                const uint32_t uv = (uint32_t)(cw >> (16 * ((xc >> 1) - cb))) & 0xFFFFu;
+                yuv_to_rgbf(yv, (int)(uv & 0xFF), (int)(uv >> 8), t[i]);
+            } else {
+                t[i][0] = t[i][1] = t[i][2] = (float)yv;
+            }
+        }
+    } else if constexpr (FMT == KH_FMT_YUYV) {
+        const int gb = min(max((x0 - 2) >> 1, 0), (a.src_w >> 1) - 4);        // groups gb .. gb + 3 (Y0 U Y1 V) are in the row
+        const uint8_t* p = src + (unsigned)(yc * a.src_pitch + gb * 4);
+        const uint64_t lo = *reinterpret_cast<const u64u*>(p), hi = *reinterpret_cast<const u64u*>(p + 8);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int xc = min(max(x0 - 2 + i, 0), a.src_w - 1);
+            const int g = (xc >> 1) - gb;                                     // 0 .. 3
+            const uint32_t q = (uint32_t)((g & 2 ? hi : lo) >> (32 * (g & 1)));
+            yuv_to_rgbf((int)((xc & 1) ? (q >> 16) & 0xFF : q & 0xFF), (int)((q >> 8) & 0xFF), (int)(q >> 24), t[i]);
+        }
+    } else {  // interleaved RGB / BGR, 3 or 4 bytes per pixel: one unaligned dword per tap, kept inside the surface
+        const unsigned last = (unsigned)((a.src_h - 1) * a.src_pitch + a.src_w * a.src_bpp) - 4u;   // last dword that is inside
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int xc = min(max(x0 - 2 + i, 0), a.src_w - 1);
+            const unsigned off = (unsigned)(yc * a.src_pitch + xc * a.src_bpp), ob = min(off, last);
+            const uint32_t q = *reinterpret_cast<const u32u*>(src + ob) >> (8 * (off - ob));
+            const float c0 = (float)(q & 0xFF), c1 = (float)((q >> 8) & 0xFF), c2 = (float)((q >> 16) & 0xFF);
+            if constexpr (FMT == KH_FMT_RGB) { t[i][0] = c0; t[i][1] = c1; t[i][2] = c2; }
+            else { t[i][0] = c2; t[i][1] = c1; t[i][2] = c0; }
+        }
+    }
+}
+
+// Lanczos-3 over the 6 x 6 window (P/preprocess.rs:566-591).  The twelve axis weights are evaluated once per pixel (the reference
+// kernel re-evaluates the horizontal weight inside the row loop: 42 sinf pairs instead of 12 — same values, same products); rows come
+// in through fetch_row6.  The accumulation order — rows outer, taps inner, w = wy * wx, acc += w * t, wsum += w, one division at the
+// end — is the reference's, so the result is bit-identical to the per-tap form it replaces.
 template <int FMT, bool WIDE>
 __device__ __forceinline__ void sample_lanczos(const uint8_t* __restrict__ src, float sx, float sy,
                                                const PreArgs& a, float px[3]) {
-    int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+    const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+    float wx[6], wy[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        wx[i] = lanczos_w(sx - (float)(x0 - 2 + i));
+        wy[i] = lanczos_w(sy - (float)(y0 - 2 + i));
+    }
     float acc[3] = {0.0f, 0.0f, 0.0f};
     float wsum = 0.0f;
-    for (int j = -2; j <= 3; ++j) {
-        int yj = y0 + j;
-        float wy = lanczos_w(sy - (float)yj);
-        int yc = min(max(yj, 0), a.src_h - 1);
-        for (int i = -2; i <= 3; ++i) {
-            int xi = x0 + i;
-            float w = wy * lanczos_w(sx - (float)xi);
-            int xc = min(max(xi, 0), a.src_w - 1);
-            float t[3];
-            fetch_px<FMT, WIDE>(src, xc, yc, a, t);
+    const bool wide_rows = a.src_w >= 8;  // uniform; narrower sources take the per-tap loads
+#pragma unroll 1
+    for (int j = 0; j < 6; ++j) {
+        const int yc = min(max(y0 - 2 + j, 0), a.src_h - 1);
+        float t[6][3];
+        if (wide_rows) {
+            fetch_row6<FMT>(src, x0, yc, a, t);
+        } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] += w * t[c];
+            for (int i = 0; i < 6; ++i) fetch_px<FMT, WIDE>(src, min(max(x0 - 2 + i, 0), a.src_w - 1), yc, a, t[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float w = wy[j] * wx[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] += w * t[i][c];
             wsum += w;
         }
     }

@@ -56,6 +56,15 @@ def test_north_star_workloads(gpu_stream, bench, name, size):
         assert np.array_equal(got[k], want), (name, k)
 
 
+def test_lanczos_secondary_workload(gpu_stream, bench):
+    wl = _run(bench, "nv12_chw_640_lanczos", gpu_stream)
+    got = _out(wl, np.float32, (3, 640, 640))
+    for k in range(wl.N):
+        raw = wl.base[31 * k: 31 * k + wl.frame_bytes]
+        want = O.preprocess(raw, wl.W, wl.H, 640, 640, fmt="nv12", mode="letterbox", sampling="lanczos", mean=MEAN, std=STD)[0]
+        assert np.abs(got[k] - want).max() <= 2e-4, k
+
+
 def test_resize_workloads(gpu_stream, bench):
     wl = _run(bench, "resize_224", gpu_stream)
     n = wl.SW * wl.SH * wl.C
@@ -165,6 +174,6 @@ def test_every_workload_is_covered(bench):
     covered = {"nv12_chw", "nv12_chw_640", "resize_224", "resize_normalize_f32_224", "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640",
                "gaussian_4k", "gaussian_u8_4k", "pyrdown_u8_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_u8_4k", "lab_from_rgb_4k",
                "spatial_gradient_1080p", "box_blur_fast_1080p", "median5_u8_1080p", "bilateral_1080p",
-               "gray_u8_1080p", "gray_f32_1080p", "hsv_f32_1080p", "bgr_u8_1080p", "gray_258x195"}
+               "gray_u8_1080p", "gray_f32_1080p", "hsv_f32_1080p", "bgr_u8_1080p", "gray_258x195", "nv12_chw_640_lanczos"}
     assert set(bench.ALSO_DEFAULT) <= set(bench.WORKLOADS)
     assert covered == set(bench.WORKLOADS)

@@ -61,14 +61,17 @@ def test_matches_oracle_bit_exact(gpu_stream, fmt, mode, sampling, f16):
         _assert_bits_equal(got, want, f"{fmt}/{mode}/{sampling}/f16={f16} {w}x{h}->{dw}x{dh}")
 
 
-@pytest.mark.parametrize("fmt", ["rgb", "nv12", "yuyv", "gray"])
+@pytest.mark.parametrize("fmt", ["rgb", "bgr", "rgba", "bgra", "nv12", "yuyv", "gray"])
 @pytest.mark.parametrize("mode", ["letterbox", "stretch"])
 def test_lanczos_close_to_oracle(gpu_stream, fmt, mode):
-    w, h, dw, dh = 46, 34, 31, 27
-    raw = _raw_for(fmt, w, h)
-    got = _run(gpu_stream, raw, w, h, dw, dh, fmt=fmt, mode=mode, sampling="lanczos")
-    want = O.preprocess(raw, w, h, dw, dh, fmt=fmt, mode=mode, sampling="lanczos")
-    assert np.abs(got - want).max() <= 2e-4
+    """Lanczos-3 through the row-window loader (rows of >= 8 pixels: one or two wide loads per window row, taps picked by shifts,
+    which is also the border replication) and through the per-tap loads narrower sources take; up- and down-scaling so windows
+    hang over every edge.  Tolerance 2e-4: device sinf vs libm sinf (the reference compares Lanczos loosely as well)."""
+    for (w, h, dw, dh) in [(46, 34, 31, 27), (8, 6, 21, 17), (6, 4, 9, 7), (64, 10, 16, 20)]:
+        raw = _raw_for(fmt, w, h)
+        got = _run(gpu_stream, raw, w, h, dw, dh, fmt=fmt, mode=mode, sampling="lanczos")
+        want = O.preprocess(raw, w, h, dw, dh, fmt=fmt, mode=mode, sampling="lanczos")
+        assert np.abs(got - want).max() <= 2e-4, (fmt, mode, w, h, dw, dh, float(np.abs(got - want).max()))
 
 
 @pytest.mark.parametrize("sampling", ["nearest", "bilinear", "lanczos"])
