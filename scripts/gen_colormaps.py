@@ -8,9 +8,10 @@ mounted (and their SHA-256 digests are committed under tests/golden/colormaps/ s
 * autumn / spring / cool / winter — OpenCV's `linear_colormap` construction (imgproc/src/colormap.cpp): 11 control
   points 0.1 apart, f32 `linspace` + `interp1`, `convertTo(CV_8U, 255)` (round half to even);
 * magma / inferno / plasma / viridis / cividis / turbo — the published 256-entry float tables (matplotlib ships them
-  verbatim), `round(255 * v)`.
+  verbatim), `round(255 * v)`;
+* summer / hsv — 64 Octave control points (`summer(64)`, `hsv(64)`) through the same `linear_colormap` interpolation.
 
-The other eleven (bone, jet, rainbow, ocean, summer, hsv, pink, hot, parula, twilight, deepgreen) need OpenCV's literal
+The other nine (bone, jet, rainbow, ocean, pink, hot, parula, twilight, deepgreen) need OpenCV's literal
 control arrays, which are not available offline; `apply_colormap` names them in its error and still takes any
 caller-provided 3x256 table.
 """
@@ -64,6 +65,12 @@ def build():
         "cool": cv_linear_colormap(t, t[::-1], one),
         "winter": cv_linear_colormap(zero, t, [1.0 - 0.05 * i for i in range(11)]),
     }
+    # summer / hsv — OpenCV interpolates 64 Octave control points: summer(64) = [x, 0.5 + x/2, 0.4], hsv(64) = hsv2rgb(linspace(0, 1, 64), 1, 1)
+    import colorsys
+    x64 = [k / 63.0 for k in range(64)]
+    maps["summer"] = cv_linear_colormap(x64, [0.5 + v / 2 for v in x64], [0.4] * 64)
+    hsv = [colorsys.hsv_to_rgb(v % 1.0, 1.0, 1.0) for v in x64]
+    maps["hsv"] = cv_linear_colormap([c[0] for c in hsv], [c[1] for c in hsv], [c[2] for c in hsv])
     from matplotlib import colormaps
     x = np.arange(256) / 255.0
     for name in ("magma", "inferno", "plasma", "viridis", "cividis", "turbo"):

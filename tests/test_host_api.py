@@ -250,7 +250,7 @@ def test_named_colormaps_match_the_reference_digests():
     from kornia_rs import ColormapType, ImageError, colormap
     digests = json.loads((Path(__file__).parent / "golden" / "colormaps" / "reference_sha256.json").read_text())
     assert sorted(digests) == sorted(k.value for k in ColormapType) and len(digests) == 21  # colormap.rs:49-73
-    assert len(colormap.bundled()) == 10
+    assert len(colormap.bundled()) == 12
     for name in colormap.bundled():
         table = colormap.lut(name)
         assert table.shape == (3, 256) and table.dtype == np.uint8
