@@ -85,6 +85,39 @@ def test_morphology_matches_oracle(gpu_stream, border, kshape):
             assert_same_bits(got, O.morphology_u8(src, op, mask, border, cval), f"{op} {kshape} {border} {w}x{h} c{c}")
 
 
+@pytest.mark.parametrize("kshape", [("box", 5, 5), ("ellipse", 7, 5), ("box", 2, 2), ("box", 1, 1), ("cross", 3, 9), ("box", 31, 3)])
+def test_morphology_tiled_interior_and_ragged_tiles(gpu_stream, kshape):
+    """Sizes with tiles that take the tiled kernel's interior staging path (384 flat bytes x 32 rows per tile), a ragged last tile
+    column / row, and - 2x2 and 1x1 masks have no right / bottom halo - an interior tile that ends on the image's last byte."""
+    mask = O.morph_kernel(*kshape)
+    for (w, h), c, border in [((400, 100), 3, "reflect101"), ((1200, 70), 1, "constant"), ((300, 97), 4, "wrap"), ((257, 64), 3, "replicate"),
+                              ((768, 96), 1, "reflect")]:
+        src = make(w, h, c, np.uint8, seed=11)
+        for op, cval in (("dilate", [3] * c), ("erode", [250] * c)):
+            got = morph_gpu(gpu_stream, src, op, mask, border, cval)[0]
+            assert_same_bits(got, O.morphology_u8(src, op, mask, border, cval), f"{op} {kshape} {border} {w}x{h} c{c}")
+
+
+def test_morphology_both_kernels_agree(gpu_stream, tmp_path):
+    """KH_MORPH_DIRECT=1 selects the per-pixel kernel (read once per process): a child process runs it on the same inputs and the
+    bytes must equal this process's tiled result."""
+    import os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    src = np.stack([make(421, 75, 3, np.uint8, seed=s) for s in (1, 2)])
+    ell = O.morph_kernel("ellipse", 7, 5)
+    tiled = morph_gpu(gpu_stream, src, "dilate", ell, "reflect101", [0, 0, 0], batch=2)
+    np.save(tmp_path / "src.npy", src)
+    code = (f"import sys, numpy as np; sys.path[:0] = [{str(root / 'kornia-rs_amd')!r}, {str(root / 'tests')!r}, {str(root / 'oracle')!r}]\n"
+            "import conftest, test_pyramid_morph_gpu as T\nfrom kornia_rs import hip\n"
+            f"src = np.load({str(tmp_path / 'src.npy')!r}); st = hip.Stream.new(0)\n"
+            "out = T.morph_gpu(st, src, 'dilate', T.O.morph_kernel('ellipse', 7, 5), 'reflect101', [0, 0, 0], batch=2)\n"
+            f"np.save({str(tmp_path / 'direct.npy')!r}, out)\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KH_MORPH_DIRECT="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(tmp_path / "direct.npy"), tiled)
+
+
 def test_morphology_unit_tests_batch_and_errors(gpu_stream):  # ops.rs:326-400
     from kornia_rs import Image, _ffi, imgproc
     box3 = O.morph_kernel("box", 3)
