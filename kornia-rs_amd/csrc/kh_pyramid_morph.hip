@@ -40,6 +40,7 @@ struct Pyr {
     T* __restrict__ o = a.dst + (long long)bz_ * a.ds + ((long long)Y * a.dw + X) * C;
 
 __device__ __forceinline__ int reflect_101(int p, int len) {  // pyramid.rs:252-270
+    if ((unsigned)p < (unsigned)len) return p;  // the common case costs one compare, not a modulo
     if (len == 1) return 0;
     if (p < 0) p = -p;
     const int period = 2 * (len - 1);
@@ -136,6 +137,77 @@ __global__ __launch_bounds__(kBx* kBy) void pyrdown_u8_kernel(Pyr<uint8_t> a) {
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) o[c] = (uint8_t)min((sum[c] + 128u) >> 8, 255u);
+}
+
+// pyrdown_u8, tiled (round 2).  The per-pixel kernel above spends ~940 lane-operations per destination pixel (ten reflect_101
+// modulos, 25 x C byte loads and their addresses): 12.8 ms per 256 4K RGB images, 0.08 of the HBM roofline.  Here a 256-thread block
+// owns kPdTW x kPdTH destination pixels and
+//   1. runs the reference's horizontal pass ([1 4 6 4 1] into u16) once per (source row, destination column) of the tile's
+//      2 * kPdTH + 3 source rows, straight from global memory into LDS: interior tiles load each 5-pixel window as ceil(5C / 4)
+//      unaligned dwords (neighbouring lanes overlap, so the lines come from L1), border tiles reflect per tap;
+//   2. runs the vertical pass from LDS, four destination bytes per item, and stores dwords.
+// Same integer expressions as the per-pixel kernel, so the bytes are identical.
+constexpr int kPdTW = 64, kPdTH = 16, kPdRows = 2 * kPdTH + 3;
+
+template <int C>
+__global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
+    __shared__ __attribute__((aligned(16))) uint16_t H[kPdRows][kPdTW * C];
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int tid = threadIdx.x;
+    const int X0 = bx_ * kPdTW, Y0 = by_ * kPdTH;
+    const int sx0 = 2 * X0 - 2, sy0 = 2 * Y0 - 2;                           // source coordinates of the tile's first tap
+    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
+    uint8_t* __restrict__ dst = a.dst + (long long)bz_ * a.ds;
+    constexpr int ND = (5 * C + 3) / 4;                                      // dwords covering one 5-pixel window
+    // interior (block-uniform): every tap inside the image, and the up to three bytes a window's last dword reads past it too
+    const bool interior = sx0 >= 0 && sy0 >= 0 && sx0 + 2 * kPdTW + 3 + 3 <= a.sw && sy0 + kPdRows <= a.sh;
+    const int rows_needed = 2 * min(kPdTH, a.dh - Y0) + 3, cols_needed = min(kPdTW, a.dw - X0);
+    for (int i = tid; i < rows_needed * kPdTW; i += 256) {
+        const int r = i / kPdTW, lx = i - r * kPdTW;
+        if (lx >= cols_needed) continue;
+        uint32_t B[5 * C];
+        if (interior) {
+            const uint8_t* p = src + ((long long)(sy0 + r) * a.sw + sx0 + 2 * lx) * C;
+            uint32_t wv[ND];
+#pragma unroll
+            for (int k = 0; k < ND; ++k) wv[k] = *reinterpret_cast<const u32_unaligned*>(p + 4 * k);
+#pragma unroll
+            for (int b = 0; b < 5 * C; ++b) B[b] = (wv[b >> 2] >> (8 * (b & 3))) & 0xffu;
+        } else {
+            const uint8_t* row = src + (long long)reflect_101(sy0 + r, a.sh) * a.sw * C;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const uint8_t* p = row + reflect_101(sx0 + 2 * lx + t, a.sw) * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) B[t * C + c] = p[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c)  // <= 4080: the reference's u16 intermediate
+            H[r][lx * C + c] = (uint16_t)(B[c] + 4u * B[C + c] + 6u * B[2 * C + c] + 4u * B[3 * C + c] + B[4 * C + c]);
+    }
+    __syncthreads();
+    constexpr int kQ = kPdTW * C / 4;                                        // four-byte items per destination row of the tile
+    const int row_bytes = a.dw * C;
+    for (int i = tid; i < kPdTH * kQ; i += 256) {
+        const int ry = i / kQ, fb = 4 * (i - ry * kQ);
+        const int Y = Y0 + ry, gb = X0 * C + fb;                             // destination row, flat byte inside it
+        if (Y >= a.dh || gb >= row_bytes) continue;
+        uint32_t s[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+            const uint32_t* hp = reinterpret_cast<const uint32_t*>(&H[2 * ry + ky][fb]);
+            const uint32_t v0 = hp[0], v1 = hp[1], w = ky == 2 ? 6u : (ky == 0 || ky == 4) ? 1u : 4u;
+            s[0] += w * (v0 & 0xffffu); s[1] += w * (v0 >> 16); s[2] += w * (v1 & 0xffffu); s[3] += w * (v1 >> 16);
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) o[b] = min((s[b] + 128u) >> 8, 255u);
+        uint8_t* op = dst + (long long)Y * row_bytes + gb;
+        if (gb + 4 <= row_bytes) *reinterpret_cast<u32_unaligned*>(op) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+        else for (int b = 0; gb + b < row_bytes; ++b) op[b] = (uint8_t)o[b];
+    }
 }
 
 // pyrup_u8 (:656-840): horizontal pass to a u8 intermediate, then the same taps vertically
@@ -381,13 +453,30 @@ int32_t check_pyr(const char* what, const T* src, T* dst, int sw, int sh, int ch
         return check_launch(#NAME);                                                                               \
     }
 
+KH_PYR_ENTRY(kh_pyrdown_u8_direct, uint8_t, pyrdown_u8_kernel, (sw + 1) / 2, (sh + 1) / 2)  // per-pixel kernel: KH_PYR_DIRECT=1 only
+
 }  // namespace
 
 extern "C" {
 
 KH_PYR_ENTRY(kh_pyrdown_f32, float, pyrdown_f32_kernel, (sw + 1) / 2, (sh + 1) / 2)
 KH_PYR_ENTRY(kh_pyrup_f32, float, pyrup_f32_kernel, sw * 2, sh * 2)
-KH_PYR_ENTRY(kh_pyrdown_u8, uint8_t, pyrdown_u8_kernel, (sw + 1) / 2, (sh + 1) / 2)
+int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch,
+                      int64_t ss, int64_t ds) {
+    static const bool direct = [] { const char* e = getenv("KH_PYR_DIRECT"); return e && e[0] == '1'; }();
+    if (direct) return kh_pyrdown_u8_direct(stream, src, dst, sw, sh, channels, batch, ss, ds);
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    if (int32_t rc = check_pyr("kh_pyrdown_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
+    if (batch == 0) return KH_OK;
+    Pyr<uint8_t> a{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kPdTW), cdiv(dh, kPdTH), (unsigned)batch, cdiv(dw, kPdTW) * 4)};
+    KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrdown_u8: batch x tiles exceeds one launch");
+    const dim3 blk(256), grid = xcd_grid(a.tiles);
+    hipStream_t st = as_hip(stream);
+    if (channels == 1) hipLaunchKernelGGL(pyrdown_u8_tile_kernel<1>, grid, blk, 0, st, a);
+    else if (channels == 3) hipLaunchKernelGGL(pyrdown_u8_tile_kernel<3>, grid, blk, 0, st, a);
+    else hipLaunchKernelGGL(pyrdown_u8_tile_kernel<4>, grid, blk, 0, st, a);
+    return check_launch("kh_pyrdown_u8");
+}
 KH_PYR_ENTRY(kh_pyrup_u8, uint8_t, pyrup_u8_kernel, sw * 2, sh * 2)
 
 // Kernel::new (P/morphology/kernels.rs:113-185): shape 0 box, 1 cross, 2 ellipse; out = width*height bytes

@@ -17,6 +17,9 @@
 // (P/resize/cuda.rs:151-190).
 #include <math.h>
 
+#include <stdlib.h>
+
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(kBx* kBy) void bilinear_u8_kernel(Rz a) {
 }
 
 // ---- separable Q14 ------------------------------------------------------------------------------------
-struct SepTab { const int32_t* ofs; const int16_t* w; int k; };
+struct SepTab { const int32_t* ofs; const int16_t* w; int k, kp, span64; };  // k taps; rows of kp = roundup(k, 4) weights (zero padded); span64: see get_tab
 
 // horizontal_row_scalar (kernels.rs:403-425): (x, source row) -> i16
 template <int C>
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(kBx* kBy) void sep_h_u8_kernel(Rz a, int16_t* __res
     if (x >= a.dw || sy >= a.sh) return;
     const uint8_t* __restrict__ row = a.src + (long long)bz_ * a.ss + (long long)sy * a.sw * C;
     const int x0 = tx.ofs[x];
-    const int16_t* w = tx.w + (long long)x * tx.k;
+    const int16_t* w = tx.w + (long long)x * tx.kp;
     int32_t acc[C];
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) acc[ch] = 0;
@@ -159,6 +162,116 @@ __global__ __launch_bounds__(kBx* kBy) void sep_h_u8_kernel(Rz a, int16_t* __res
     for (int ch = 0; ch < C; ++ch) o[ch] = (int16_t)min(max((acc[ch] + 8192) >> 14, -32768), 32767);
 }
 
+// horizontal pass, LDS-staged (round 2).  The kernel above gathers: neighbouring lanes read bytes `scale` pixels apart, k taps x C
+// byte loads per destination sample, each wave-load touching a dozen cache lines — the address path (TA), not HBM, sets its time
+// (8.4 ms per 256 1080p -> 224 Lanczos-3 antialiased frames, 0.02 of the roofline).  Here a 256-thread block owns kSepTX
+// destination columns x kSepRows source rows:
+//   1. the source span those columns tap (table offsets are monotonic: ofs[first] .. ofs[last] + kp) is staged in LDS once per
+//      row with aligned dword copies (edge tiles: per byte, with the reference's clamp to the row);
+//   2. each thread accumulates one destination column for four rows, four taps at a time: one 8-byte weight load serves the four
+//      rows, the 4 x C source bytes come from LDS as C + 1 dwords re-aligned with v_alignbyte, and each channel's four products
+//      are two v_dot2_i32_i16 (pixel pairs x weight pairs) — i32 sums of the same i16 x u8 products, so the same integers.
+constexpr int kSepTX = 64, kSepRows = 16;
+extern __shared__ __attribute__((aligned(16))) uint8_t kh_sep_lds[];
+
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int32_t dot2_i16(uint32_t a, uint32_t b, int32_t c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, a), __builtin_bit_cast(i16x2_t, b), c, false);
+}
+// {byte n1, 0, byte n2, 0} of the byte string e[0], e[1], ...: two pixels' samples of one channel as an i16 pair
+template <int C, int N1>
+__device__ __forceinline__ uint32_t pixel_pair(const uint32_t (&e)[C]) {
+    constexpr int b = N1 >> 2, i1 = N1 - 4 * b, i2 = N1 + C - 4 * b;
+    constexpr uint32_t sel = 0x0c000c00u | (uint32_t)i1 | ((uint32_t)i2 << 16);
+    return __builtin_amdgcn_perm(e[b + 1 < C ? b + 1 : b], e[b], sel);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void sep_h_u8_tile_kernel(Rz a, int16_t* __restrict__ hbuf, SepTab tx, int pitch) {
+    uint8_t* S = kh_sep_lds;  // [kSepRows][pitch]
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int X0 = bx_ * kSepTX, sy0 = by_ * kSepRows;
+    const int p0 = tx.ofs[X0], span = tx.ofs[min(X0 + kSepTX, a.dw) - 1] + tx.kp - p0;   // block-uniform
+    const int nrows = min(kSepRows, a.sh - sy0);
+    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
+    const long long img_bytes = (long long)a.sw * a.sh * C;
+    // per staged row: where its first tapped byte sits in the LDS row (`mis` = the source address modulo 4 when the row is copied
+    // as aligned dwords, which needs the whole aligned window inside the image; 0 when it is staged per byte)
+    auto row_mis = [&](int r, bool& dwords) -> int {
+        const long long g = ((long long)(sy0 + r) * a.sw + p0) * C;
+        const int mis = (int)((uintptr_t)(src + g) & 3);
+        dwords = p0 >= 0 && p0 + span <= a.sw && g - mis >= 0 && g - mis + (((long long)mis + span * C + 3) & ~3ll) <= img_bytes;
+        return dwords ? mis : 0;
+    };
+    for (int r = wave; r < nrows; r += 4) {
+        bool dwords;
+        const int mis = row_mis(r, dwords);
+        uint8_t* row = S + r * pitch;
+        if (dwords) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(src + ((long long)(sy0 + r) * a.sw + p0) * C - mis);
+            const int ndw = (mis + span * C + 3) >> 2;
+            for (int d = lane; d < ndw; d += 64) reinterpret_cast<uint32_t*>(row)[d] = q[d];
+        } else {
+            const uint8_t* grow = src + (long long)(sy0 + r) * a.sw * C;
+            for (int j = lane; j < span * C; j += 64) {
+                const int px = j / C, c = j - px * C;
+                row[j] = grow[min(max(p0 + px, 0), a.sw - 1) * C + c];  // build_xsrc_lut, common.rs:127-137
+            }
+        }
+    }
+    __syncthreads();
+    const int x = X0 + lane;
+    if (x >= a.dw) return;
+    const int rel = (tx.ofs[x] - p0) * C;
+    const uint32_t* wrow = reinterpret_cast<const uint32_t*>(tx.w + (long long)x * tx.kp);
+    const uint8_t* rowp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = min(wave * 4 + i, nrows - 1);  // rows past the image repeat the last one and are not stored
+        bool dwords;
+        rowp[i] = S + r * pitch + row_mis(r, dwords) + rel;
+    }
+    int32_t acc[4][C];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[i][c] = 0;
+    for (int t4 = 0; t4 < tx.kp; t4 += 4) {
+        const uint32_t w01 = wrow[t4 >> 1], w23 = wrow[(t4 >> 1) + 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uintptr_t o = (uintptr_t)(rowp[i] + t4 * C);
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(o & ~(uintptr_t)3);
+            const uint32_t sh = (uint32_t)(o & 3);
+            uint32_t e[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) e[j] = __builtin_amdgcn_alignbyte(p[j + 1], p[j], sh);
+            if constexpr (C == 1) {
+                acc[i][0] = dot2_i16(pixel_pair<1, 2>(e), w23, dot2_i16(pixel_pair<1, 0>(e), w01, acc[i][0]));
+            } else if constexpr (C == 3) {
+                acc[i][0] = dot2_i16(pixel_pair<3, 6>(e), w23, dot2_i16(pixel_pair<3, 0>(e), w01, acc[i][0]));
+                acc[i][1] = dot2_i16(pixel_pair<3, 7>(e), w23, dot2_i16(pixel_pair<3, 1>(e), w01, acc[i][1]));
+                acc[i][2] = dot2_i16(pixel_pair<3, 8>(e), w23, dot2_i16(pixel_pair<3, 2>(e), w01, acc[i][2]));
+            } else {
+                acc[i][0] = dot2_i16(pixel_pair<4, 8>(e), w23, dot2_i16(pixel_pair<4, 0>(e), w01, acc[i][0]));
+                acc[i][1] = dot2_i16(pixel_pair<4, 9>(e), w23, dot2_i16(pixel_pair<4, 1>(e), w01, acc[i][1]));
+                acc[i][2] = dot2_i16(pixel_pair<4, 10>(e), w23, dot2_i16(pixel_pair<4, 2>(e), w01, acc[i][2]));
+                acc[i][3] = dot2_i16(pixel_pair<4, 11>(e), w23, dot2_i16(pixel_pair<4, 3>(e), w01, acc[i][3]));
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 4 + i;
+        if (r >= nrows) break;
+        int16_t* o = hbuf + (((long long)bz_ * a.sh + sy0 + r) * a.dw + x) * C;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) o[ch] = (int16_t)min(max((acc[i][ch] + 8192) >> 14, -32768), 32767);
+    }
+}
+
 // vertical_row_scalar (kernels.rs:699-708): thread = one flat i16 column of the intermediate
 __global__ __launch_bounds__(kBx* kBy) void sep_v_u8_kernel(Rz a, const int16_t* __restrict__ hbuf, SepTab ty, int hrow) {
     unsigned bx_, by_, bz_;
@@ -167,7 +280,7 @@ __global__ __launch_bounds__(kBx* kBy) void sep_v_u8_kernel(Rz a, const int16_t*
     if (i >= hrow || y >= a.dh) return;
     const int16_t* __restrict__ h = hbuf + (long long)bz_ * a.sh * hrow + i;
     const int y0 = ty.ofs[y];
-    const int16_t* w = ty.w + (long long)y * ty.k;
+    const int16_t* w = ty.w + (long long)y * ty.kp;
     int32_t acc = 0;
     for (int k = 0; k < ty.k; ++k) {
         const int sy = min(max(y0 + k, 0), a.sh - 1);
@@ -228,7 +341,7 @@ __global__ __launch_bounds__(kBx* kBy) void fused_sep_v_kernel(Rz a, const int16
     const int hrow = a.dw * 3;
     const int16_t* __restrict__ h = hbuf + (long long)bz_ * a.sh * hrow + x * 3;
     const int y0 = ty.ofs[y];
-    const int16_t* w = ty.w + (long long)y * ty.k;
+    const int16_t* w = ty.w + (long long)y * ty.kp;
     int32_t acc[3] = {0, 0, 0};
     for (int k = 0; k < ty.k; ++k) {
         const int sy = min(max(y0 + k, 0), a.sh - 1);
@@ -381,9 +494,14 @@ int32_t get_tab(int src_size, int dst_size, int filt, bool aa, hipStream_t strea
     const auto key = std::make_tuple(dev, src_size, dst_size, filt, (int)aa);
     const int32_t rc = g_tabs.lookup(key, stream, what, [&](DevTable& t) -> int32_t {
         std::vector<int32_t> ofs;
-        std::vector<int16_t> w;
-        t.meta[0] = build_contribs(src_size, dst_size, filt, aa, ofs, w);
-        t.meta[1] = dst_size;
+        std::vector<int16_t> wk, w;
+        const int k = build_contribs(src_size, dst_size, filt, aa, ofs, wk), kp = (k + 3) & ~3;
+        w.assign((size_t)dst_size * kp, 0);  // rows padded to a multiple of four taps with zero weights (sep_h_u8_tile_kernel)
+        for (int i = 0; i < dst_size; ++i) std::copy(wk.begin() + (size_t)i * k, wk.begin() + (size_t)(i + 1) * k, w.begin() + (size_t)i * kp);
+        int span64 = 0;                      // widest source span (pixels) one tile of kSepTX destination columns taps
+        for (int x0 = 0; x0 < dst_size; x0 += kSepTX) span64 = std::max(span64, ofs[std::min(x0 + kSepTX, dst_size) - 1] + kp - ofs[x0]);
+        t.meta[0] = k; t.meta[1] = dst_size; t.meta[2] = kp; t.meta[3] = span64;
+        ofs.resize((ofs.size() + 3) & ~(size_t)3, 0);  // the weight block starts 16-byte aligned
         const size_t ofs_bytes = sizeof(int32_t) * ofs.size(), w_bytes = sizeof(int16_t) * w.size();
         t.bytes = ofs_bytes + w_bytes;
         KH_HIP(hipMalloc(&t.dev, t.bytes));
@@ -394,8 +512,8 @@ int32_t get_tab(int src_size, int dst_size, int filt, bool aa, hipStream_t strea
     }, lease);
     if (rc != KH_OK) return rc;
     out.ofs = (const int32_t*)lease->dev;
-    out.w = (const int16_t*)((const char*)lease->dev + sizeof(int32_t) * (size_t)lease->meta[1]);
-    out.k = lease->meta[0];
+    out.w = (const int16_t*)((const char*)lease->dev + sizeof(int32_t) * (((size_t)lease->meta[1] + 3) & ~(size_t)3));
+    out.k = lease->meta[0]; out.kp = lease->meta[2]; out.span64 = lease->meta[3];
     return KH_OK;
 }
 
@@ -422,6 +540,35 @@ Rz make_rz(const void* src, void* dst, int sw, int sh, int dw, int dh, int64_t s
     a.scale_y = (double)sh / (double)dh;
     a.tiles = xcd_tiles(cdiv(gw, kBx), cdiv(gh, kBy), (unsigned)batch, cdiv(gw, kBx) * 8);
     return a;
+}
+
+// horizontal pass: the LDS-staged kernel when its tile fits 64 KiB, else (or with KH_RESIZE_U8_GATHER=1, dev / test knob) the gather
+int32_t launch_sep_h(hipStream_t st, const void* src, int sw, int sh, int dw, int dh, int channels, int batch, int64_t ss,
+                     int16_t* hbuf, const SepTab& tx, const char* what) {
+    static const bool gather = [] { const char* e = getenv("KH_RESIZE_U8_GATHER"); return e && e[0] == '1'; }();
+    const int pitch = (((tx.span64 * channels + 3) + 3) & ~3) + 8;
+    const size_t lds = (size_t)pitch * kSepRows;
+    if (!gather && lds <= 64 * 1024) {
+        Rz ah = make_rz(src, nullptr, sw, sh, dw, dh, ss, 0, batch, dw, sh);
+        ah.tiles = xcd_tiles(cdiv(dw, kSepTX), cdiv(sh, kSepRows), (unsigned)batch, cdiv(dw, kSepTX) * 8);
+        if (ah.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        const dim3 grid = xcd_grid(ah.tiles), blk(256);
+        switch (channels) {
+            case 1: hipLaunchKernelGGL(sep_h_u8_tile_kernel<1>, grid, blk, lds, st, ah, hbuf, tx, pitch); break;
+            case 3: hipLaunchKernelGGL(sep_h_u8_tile_kernel<3>, grid, blk, lds, st, ah, hbuf, tx, pitch); break;
+            default: hipLaunchKernelGGL(sep_h_u8_tile_kernel<4>, grid, blk, lds, st, ah, hbuf, tx, pitch); break;
+        }
+        return KH_OK;
+    }
+    Rz ah = make_rz(src, nullptr, sw, sh, dw, dh, ss, 0, batch, dw, sh);
+    if (ah.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+    const dim3 blk(kBx, kBy);
+    switch (channels) {
+        case 1: hipLaunchKernelGGL(sep_h_u8_kernel<1>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
+        case 3: hipLaunchKernelGGL(sep_h_u8_kernel<3>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
+        default: hipLaunchKernelGGL(sep_h_u8_kernel<4>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
+    }
+    return KH_OK;
 }
 
 #define KH_RZ_LAUNCH_C(KERNEL, channels, a, st)                                                           \
@@ -479,14 +626,9 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
         Scratch scratch;  // dst_w x src_h i16 intermediate (P/resize/cuda.rs:262): caller workspace or stream-ordered pool
         if (int32_t rc = get_scratch(stream, sizeof(int16_t) * (size_t)hrow * sh * batch, what, scratch)) return rc;
         int16_t* hbuf = scratch.as<int16_t>();
-        Rz ah = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, dw, sh);
         Rz av = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, hrow, dh);
-        if (ah.tiles.total == 0 || av.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-        switch (channels) {
-            case 1: hipLaunchKernelGGL(sep_h_u8_kernel<1>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
-            case 3: hipLaunchKernelGGL(sep_h_u8_kernel<3>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
-            default: hipLaunchKernelGGL(sep_h_u8_kernel<4>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx); break;
-        }
+        if (av.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        if (int32_t rc = launch_sep_h(st, src, sw, sh, dw, dh, channels, batch, src_stride, hbuf, tx, what)) return rc;
         hipLaunchKernelGGL(sep_v_u8_kernel, xcd_grid(av.tiles), blk, 0, st, av, (const int16_t*)hbuf, ty, hrow);
         const int32_t rc = check_launch(what);
         lx->used_on(st); ly->used_on(st);
@@ -526,9 +668,7 @@ int32_t kh_resize_normalize_to_chw_u8_f32(kh_stream_t stream, const uint8_t* src
         Scratch scratch;
         if (int32_t rc = get_scratch(stream, sizeof(int16_t) * (size_t)dw * 3 * sh * batch, what, scratch)) return rc;
         int16_t* hbuf = scratch.as<int16_t>();
-        Rz ah = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, dw, sh);
-        if (ah.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-        hipLaunchKernelGGL(sep_h_u8_kernel<3>, xcd_grid(ah.tiles), blk, 0, st, ah, hbuf, tx);
+        if (int32_t rc = launch_sep_h(st, src, sw, sh, dw, dh, 3, batch, src_stride, hbuf, tx, what)) return rc;
         hipLaunchKernelGGL(fused_sep_v_kernel, grid, blk, 0, st, a, (const int16_t*)hbuf, ty, n);
         const int32_t rc = check_launch(what);
         lx->used_on(st); ly->used_on(st);

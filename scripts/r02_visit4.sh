@@ -1,16 +1,17 @@
 #!/bin/bash
-# Round-2 visit 4: tiled morphology (parity + timing against the per-pixel kernel), Lanczos sampler before / after.
+# Round-2 visit 4/5: tiled morphology, tiled pyrdown_u8, LDS-staged separable u8 resize (parity + timing against the kernels they
+# replace), Lanczos sampler of the fused preprocess before / after.
 set -u
 TAG=${1:-r02w}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-echo "== morphology parity" | tee "$OUT/log.txt"
-timeout 600 python -m pytest tests/test_pyramid_morph_gpu.py -m gpu -q -x 2>&1 | tail -3 | tee -a "$OUT/log.txt"
-for v in 0 1; do
-  echo "== dilate_u8_4k KH_MORPH_DIRECT=$v" | tee -a "$OUT/log.txt"
-  KH_MORPH_DIRECT=$v timeout 300 python bench.py --workload dilate_u8_4k --no-cpu-baseline --steps 10 --warmup 2 2>&1 | grep '^{' | tee -a "$OUT/log.txt"
-done
-if [ -f gpurun_ab/libkornia_hip_oldlz.so ]; then
-  for lib in "" gpurun_ab/libkornia_hip_oldlz.so; do
-    echo "== nv12_chw_640_lanczos lib=${lib:-HEAD}" | tee -a "$OUT/log.txt"
-    KORNIA_HIP_LIB=${lib:+$(pwd)/$lib} timeout 300 python bench.py --workload nv12_chw_640_lanczos --no-cpu-baseline --steps 10 --warmup 2 2>&1 | grep '^{' | tee -a "$OUT/log.txt"
-  done
-fi
+echo "== parity" | tee "$OUT/log.txt"
+timeout 900 python -m pytest tests/test_pyramid_morph_gpu.py tests/test_resize_u8_gpu.py -m gpu -q -x 2>&1 | tail -3 | tee -a "$OUT/log.txt"
+run() { wl=$1; shift; echo "== $wl $*" | tee -a "$OUT/log.txt"; env "$@" timeout 300 python bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 2 2>&1 | grep '^{' | python -c 'import json,sys
+for l in sys.stdin:
+    j=json.loads(l); r=j["roofline"]; print("   %-50s %8.3f ms/step  frac %.3f  launch %.3f ms" % (j["config"]["workload"], j["ms_per_step"], r["frac"], r["mean_launch_ms"]))' | tee -a "$OUT/log.txt"; }
+run dilate_u8_4k KH_X=0
+run pyrdown_u8_4k KH_X=0
+run pyrdown_u8_4k KH_PYR_DIRECT=1
+run resize_u8_224 KH_X=0
+run resize_u8_224 KH_RESIZE_U8_GATHER=1
+run nv12_chw_640_lanczos KH_X=0
+[ -f gpurun_ab/libkornia_hip_oldlz.so ] && run nv12_chw_640_lanczos KORNIA_HIP_LIB=$(pwd)/gpurun_ab/libkornia_hip_oldlz.so

@@ -39,6 +39,20 @@ def test_pyramid_matches_oracle(gpu_stream, dtype, c, up):
         assert_same_bits(got, O.pyrup(src) if up else O.pyrdown(src), f"{'pyrup' if up else 'pyrdown'} {dtype.__name__} c{c} {w}x{h}")
 
 
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_pyrdown_u8_tiled_interior_and_edge_tiles(gpu_stream, c):
+    """Sizes that give the tiled pyrdown_u8 kernel (64 x 16 destination pixels per block) interior tiles (dword window loads),
+    interior tiles whose last window ends exactly on the image's last bytes, and ragged right / bottom tiles."""
+    for w, h in [(520, 140), (260, 65), (259, 65), (261, 66), (262, 67), (513, 33), (390, 130)]:
+        src = make(w, h, c, np.uint8, seed=w)
+        assert_same_bits(pyr_gpu(gpu_stream, src, False)[0], O.pyrdown(src), f"pyrdown u8 c{c} {w}x{h}")
+    n = 3
+    batch = np.stack([make(300, 70, c, np.uint8, seed=k) for k in range(n)])
+    got = pyr_gpu(gpu_stream, batch, False, batch=n)
+    for k in range(n):
+        assert_same_bits(got[k], O.pyrdown(batch[k]), f"pyrdown u8 batch frame {k}")
+
+
 def test_pyramid_batch_and_host_api(gpu_stream):
     from kornia_rs import Image, ImageError, imgproc
     n = 3

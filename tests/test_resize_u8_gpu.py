@@ -63,6 +63,16 @@ def test_separable_q14(gpu_stream, mode, aa):  # cuda.rs:420-440
         assert check(gpu_stream, s, d, c, mode, aa) == "separable"
 
 
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_separable_staged_horizontal_pass_tiles(gpu_stream, c):
+    """The LDS-staged horizontal pass (64 destination columns x 16 source rows per block): several interior tiles whose rows
+    start at every address alignment (odd widths), ragged last tiles, upsampling (k = 6 padded to 8 taps), and a span too wide
+    for 64 KiB of LDS (falls back to the gather kernel)."""
+    for s, d, mode, aa in [((517, 70), (300, 40), "lanczos", True), ((1001, 37), (230, 37), "lanczos", True), ((333, 50), (700, 50), "lanczos", False),
+                           ((415, 35), (200, 20), "bicubic", True), ((415, 35), (200, 20), "bicubic", False), ((20000, 4), (70, 4), "lanczos", True)]:
+        assert check(gpu_stream, s, d, c, mode, aa) == "separable"
+
+
 def test_separable_extreme_downscale_and_batch(gpu_stream):  # cuda.rs:442-448
     check(gpu_stream, (1024, 64), (50, 40), 3, "lanczos", True)
     check(gpu_stream, (1024, 64), (50, 40), 3, "bicubic", True)
