@@ -163,29 +163,57 @@ __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
     // interior (block-uniform): every tap inside the image, and the up to three bytes a window's last dword reads past it too
     const bool interior = sx0 >= 0 && sy0 >= 0 && sx0 + 2 * kPdTW + 3 + 3 <= a.sw && sy0 + kPdRows <= a.sh;
     const int rows_needed = 2 * min(kPdTH, a.dh - Y0) + 3, cols_needed = min(kPdTW, a.dw - X0);
-    for (int i = tid; i < rows_needed * kPdTW; i += 256) {
-        const int r = i / kPdTW, lx = i - r * kPdTW;
-        if (lx >= cols_needed) continue;
-        uint32_t B[5 * C];
-        if (interior) {
-            const uint8_t* p = src + ((long long)(sy0 + r) * a.sw + sx0 + 2 * lx) * C;
-            uint32_t wv[ND];
+    const int lx = tid & (kPdTW - 1);                                        // kPdTW = 64: one destination column per lane
+    if (interior) {
+        // a batch of rows' windows is loaded before the first LDS write, so the block waits one memory round trip per batch
+        // and not one per row (the same finding as the morphology staging loop)
+        constexpr int kBatch = 5;
+        for (int r0 = tid >> 6; r0 < rows_needed; r0 += 4 * kBatch) {
+            uint32_t wv[kBatch][ND];
 #pragma unroll
-            for (int k = 0; k < ND; ++k) wv[k] = *reinterpret_cast<const u32_unaligned*>(p + 4 * k);
+            for (int k = 0; k < kBatch; ++k) {
+                const int r = min(r0 + 4 * k, rows_needed - 1);
+                const uint8_t* p = src + ((long long)(sy0 + r) * a.sw + sx0 + 2 * lx) * C;
 #pragma unroll
-            for (int b = 0; b < 5 * C; ++b) B[b] = (wv[b >> 2] >> (8 * (b & 3))) & 0xffu;
-        } else {
-            const uint8_t* row = src + (long long)reflect_101(sy0 + r, a.sh) * a.sw * C;
+                for (int j = 0; j < ND; ++j) wv[k][j] = *reinterpret_cast<const u32_unaligned*>(p + 4 * j);
+            }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                const uint8_t* p = row + reflect_101(sx0 + 2 * lx + t, a.sw) * C;
+            for (int k = 0; k < kBatch; ++k) {
+                const int r = r0 + 4 * k;
+                if (r >= rows_needed) break;
+                uint32_t B[5 * C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) B[t * C + c] = p[c];
+                for (int b = 0; b < 5 * C; ++b) B[b] = (wv[k][b >> 2] >> (8 * (b & 3))) & 0xffu;
+#pragma unroll
+                for (int c = 0; c < C; ++c)  // <= 4080: the reference's u16 intermediate
+                    H[r][lx * C + c] = (uint16_t)(B[c] + 4u * B[C + c] + 6u * B[2 * C + c] + 4u * B[3 * C + c] + B[4 * C + c]);
             }
         }
+    } else {
+        constexpr int kBatch = 3;
+        for (int r0 = tid >> 6; r0 < rows_needed; r0 += 4 * kBatch) {
+            if (lx >= cols_needed) continue;
+            uint8_t B[kBatch][5 * C];
 #pragma unroll
-        for (int c = 0; c < C; ++c)  // <= 4080: the reference's u16 intermediate
-            H[r][lx * C + c] = (uint16_t)(B[c] + 4u * B[C + c] + 6u * B[2 * C + c] + 4u * B[3 * C + c] + B[4 * C + c]);
+            for (int k = 0; k < kBatch; ++k) {
+                const int r = min(r0 + 4 * k, rows_needed - 1);
+                const uint8_t* row = src + (long long)reflect_101(sy0 + r, a.sh) * a.sw * C;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    const uint8_t* p = row + reflect_101(sx0 + 2 * lx + t, a.sw) * C;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) B[k][t * C + c] = p[c];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int r = r0 + 4 * k;
+                if (r >= rows_needed) break;
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    H[r][lx * C + c] = (uint16_t)((uint32_t)B[k][c] + 4u * B[k][C + c] + 6u * B[k][2 * C + c] + 4u * B[k][3 * C + c] + B[k][4 * C + c]);
+            }
+        }
     }
     __syncthreads();
     constexpr int kQ = kPdTW * C / 4;                                        // four-byte items per destination row of the tile
@@ -306,35 +334,36 @@ __global__ __launch_bounds__(kBx* kBy) void morphology_u8_kernel(Morph a) {
 // 5x5 box (0.02 of the HBM roofline).  Here a 256-thread block owns an output tile of kMorphFW flat bytes x kMorphTH rows and
 //   1. stages the source window (tile + (kw - 1) x (kh - 1) halo) in LDS as flat byte rows; the border mode is resolved ONCE per
 //      staged pixel (constant mode writes the border value), interior tiles copy dwords;
-//   2. for an all-ones (box) structuring element: a horizontal pass S -> H (max / min over kw taps, 4 output bytes per item: one
-//      ds_read2_b32 + v_alignbyte per tap, then four byte-lane max) and a vertical pass H -> destination (kh dword reads per
-//      item): kw + kh taps per byte instead of kw * kh;
-//      for any other mask: the active taps straight from S (still one LDS read + alignbyte + four byte-lane max per tap per
-//      four output bytes, no global loads, no border arithmetic).
-// max / min are order-independent and exact, so the result equals the per-pixel kernel byte for byte.
+//   2. for an all-ones (box) structuring element: a horizontal pass S -> H (max / min over kw taps) and a vertical pass H ->
+//      destination: kw + kh taps per byte instead of kw * kh; for any other mask: the active taps straight from S.
+// The kernel is bound by vector-ALU issue, not memory (r02w: the first version spent ~190 lane-operations per four output bytes
+// and ran at exactly that rate), so taps work on two bytes per instruction: v_perm_b32 pulls the even / odd bytes of a tap's
+// unaligned four-byte window out of two LDS dwords straight into 16-bit lanes (the selector depends on the tap only, not on the
+// lane) and v_pk_max_u16 / v_pk_min_u16 accumulates them; H holds the lanes unpacked, so a vertical tap is one ds_read_b64 and
+// two packed max.  max / min are order-independent and exact: the bytes equal the per-pixel kernel's.
 constexpr int kMorphFW = 384;   // flat bytes per tile row: a whole number of pixels for C = 1, 2, 3, 4, and of dwords
 constexpr int kMorphTH = 32;    // output rows per tile
 extern __shared__ __attribute__((aligned(16))) uint8_t kh_morph_lds[];
 
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 template <bool DILATE>
-__device__ __forceinline__ void minmax4(uint32_t acc[4], uint32_t t) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const uint32_t v = (t >> (8 * b)) & 0xffu;
-        acc[b] = DILATE ? max(acc[b], v) : min(acc[b], v);
-    }
+__device__ __forceinline__ uint32_t pk_minmax(uint32_t a, uint32_t b) {
+    const u16x2_t x = __builtin_bit_cast(u16x2_t, a), y = __builtin_bit_cast(u16x2_t, b);
+    return __builtin_bit_cast(uint32_t, DILATE ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y));
 }
-__device__ __forceinline__ uint32_t pack4(const uint32_t acc[4]) { return acc[0] | (acc[1] << 8) | (acc[2] << 16) | (acc[3] << 24); }
-// four bytes starting at byte offset `o` of an LDS row whose first byte is 4-byte aligned
-__device__ __forceinline__ uint32_t lds_bytes4(const uint8_t* row, int o) {
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(row + (o & ~3));
-    return __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)(o & 3));
+// one tap on the four output bytes whose window starts `o` bytes into LDS row `row32` (o & 3 is the same for every lane)
+template <bool DILATE>
+__device__ __forceinline__ void tap_pair(const uint32_t* row32, int o, uint32_t& acc_e, uint32_t& acc_o) {
+    const uint32_t lo = row32[o >> 2], hi = row32[(o >> 2) + 1], s = (uint32_t)(o & 3);
+    const uint32_t sel_e = 0x0c000c00u | s | ((s + 2u) << 16);   // {byte s, 0, byte s + 2, 0}
+    acc_e = pk_minmax<DILATE>(acc_e, __builtin_amdgcn_perm(hi, lo, sel_e));
+    acc_o = pk_minmax<DILATE>(acc_o, __builtin_amdgcn_perm(hi, lo, sel_e + 0x00010001u));
 }
 
 template <int C, bool DILATE, bool BOX>
 __global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp, int srows) {
-    uint8_t* S = kh_morph_lds;                 // [srows][sp]: source window, flat bytes
-    uint8_t* H = S + srows * sp;               // [srows][kMorphFW]: horizontal pass (BOX only)
+    uint8_t* S = kh_morph_lds;                                              // [srows][sp]: source window, flat bytes
+    uint32_t* H = reinterpret_cast<uint32_t*>(kh_morph_lds + srows * sp);   // [srows][kDW][2]: horizontal pass, 16-bit lanes (BOX only)
     unsigned bx_, by_, bz_;
     if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
     const int tid = threadIdx.x;
@@ -347,42 +376,72 @@ __global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp
 
     // 1. stage the window
     const bool interior = wx0 >= 0 && wy0 >= 0 && wx0 + spx <= a.w && wy0 + srows <= a.h;   // block-uniform
+    // Both staging loops issue a batch of independent global loads before the first LDS write: one load per loop trip left the
+    // block waiting a full memory round trip per trip (r02z: 18 trips, 12 ms per 256 4K images, slower than the VALU work).
     if (interior) {
-        const int dpr = (spx * C + 3) >> 2;                                  // dwords per staged row (sp >= 4 * dpr)
+        const int dpr = (spx * C + 3) >> 2;                                  // dwords per staged row (sp >= 4 * dpr, dpr <= 128)
         // the last dword of a row may read up to 3 bytes past the window: still inside the image except at its very end
         const long long img_bytes = (long long)a.w * a.h * C;
-        for (int i = tid; i < dpr * srows; i += 256) {
-            const int r = i / dpr, d = i - r * dpr;
-            const long long off = ((long long)(wy0 + r) * a.w + wx0) * C + 4 * d;
-            uint32_t v;
-            if (off + 4 <= img_bytes) v = *reinterpret_cast<const u32_unaligned*>(src + off);
-            else { v = 0; for (int b = 0; off + b < img_bytes; ++b) v |= (uint32_t)src[off + b] << (8 * b); }
-            *reinterpret_cast<uint32_t*>(S + r * sp + 4 * d) = v;
+        const int d = tid & 127;
+        constexpr int kBatch = 10;                                           // rows per thread in flight (two threads-halves interleave rows)
+        for (int r0 = tid >> 7; r0 < srows; r0 += 2 * kBatch) {
+            uint32_t v[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int r = r0 + 2 * k;
+                v[k] = 0;
+                if (r < srows && d < dpr) {
+                    const long long off = ((long long)(wy0 + r) * a.w + wx0) * C + 4 * d;
+                    if (off + 4 <= img_bytes) v[k] = *reinterpret_cast<const u32_unaligned*>(src + off);
+                    else for (int b = 0; off + b < img_bytes; ++b) v[k] |= (uint32_t)src[off + b] << (8 * b);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int r = r0 + 2 * k;
+                if (r < srows && d < dpr) *reinterpret_cast<uint32_t*>(S + r * sp + 4 * d) = v[k];
+            }
         }
     } else {
-        for (int i = tid; i < spx * srows; i += 256) {
-            const int r = i / spx, c = i - r * spx;
-            // cells right of / below every output's window (ragged last tiles) are never consumed: skip their border walk
-            const bool unused = wx0 + c >= a.w + pad_w || wy0 + r >= a.h + pad_h;
-            const int sy = unused ? -1 : map_index(a.border, wy0 + r, a.h), sx = unused ? -1 : map_index(a.border, wx0 + c, a.w);
-            const bool outside = sy < 0 || sx < 0;
-            const uint8_t* p = src + ((long long)max(sy, 0) * a.w + max(sx, 0)) * C;
+        constexpr int kBatch = 4;
+        const int n = spx * srows;
+        for (int i0 = tid; i0 < n; i0 += 256 * kBatch) {
+            uint8_t px[kBatch][C];
 #pragma unroll
-            for (int ch = 0; ch < C; ++ch) S[r * sp + c * C + ch] = outside ? (uint8_t)a.cval[ch] : p[ch];
+            for (int k = 0; k < kBatch; ++k) {
+                const int i = i0 + 256 * k;
+                const int r = i / spx, c = i - r * spx;
+                // cells right of / below every output's window (ragged last tiles) are never consumed: skip their border walk
+                const bool unused = i >= n || wx0 + c >= a.w + pad_w || wy0 + r >= a.h + pad_h;
+                const int sy = unused ? -1 : map_index(a.border, wy0 + r, a.h), sx = unused ? -1 : map_index(a.border, wx0 + c, a.w);
+                const bool outside = sy < 0 || sx < 0;
+                const uint8_t* p = src + ((long long)max(sy, 0) * a.w + max(sx, 0)) * C;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) px[k][ch] = outside ? (uint8_t)a.cval[ch] : p[ch];
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int i = i0 + 256 * k;
+                if (i >= n) break;
+                const int r = i / spx, c = i - r * spx;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) S[r * sp + c * C + ch] = px[k][ch];
+            }
         }
     }
     __syncthreads();
 
-    constexpr int kDW = kMorphFW / 4;   // dword items per row
-    const uint32_t init = DILATE ? 0u : 255u;
+    constexpr int kDW = kMorphFW / 4;   // four-byte items per row
+    const uint32_t init = DILATE ? 0u : 0x00ff00ffu;
     if constexpr (BOX) {
         // 2a. horizontal pass over every staged row
         for (int i = tid; i < kDW * srows; i += 256) {
             const int r = i / kDW, d = i - r * kDW;
-            const uint8_t* row = S + r * sp;
-            uint32_t acc[4] = {init, init, init, init};
-            for (int kx = 0; kx < a.kw; ++kx) minmax4<DILATE>(acc, lds_bytes4(row, 4 * d + kx * C));
-            *reinterpret_cast<uint32_t*>(H + r * kMorphFW + 4 * d) = pack4(acc);
+            const uint32_t* row32 = reinterpret_cast<const uint32_t*>(S + r * sp);
+            uint32_t acc_e = init, acc_o = init;
+            for (int kx = 0; kx < a.kw; ++kx) tap_pair<DILATE>(row32, 4 * d + kx * C, acc_e, acc_o);
+            H[2 * i] = acc_e;
+            H[2 * i + 1] = acc_o;
         }
         __syncthreads();
     }
@@ -393,33 +452,45 @@ __global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp
         const int y = y0 + r;
         const int fb = x0 * C + 4 * d;                                       // flat byte inside the image row
         if (y >= a.h || fb >= row_bytes) continue;
-        uint32_t acc[4] = {init, init, init, init};
+        uint32_t acc_e = init, acc_o = init;
         if constexpr (BOX) {
-            for (int ky = 0; ky < a.kh; ++ky) minmax4<DILATE>(acc, *reinterpret_cast<const uint32_t*>(H + (r + ky) * kMorphFW + 4 * d));
+            for (int ky = 0; ky < a.kh; ++ky) {
+                acc_e = pk_minmax<DILATE>(acc_e, H[2 * (i + ky * kDW)]);
+                acc_o = pk_minmax<DILATE>(acc_o, H[2 * (i + ky * kDW) + 1]);
+            }
         } else {
             for (int ky = 0; ky < a.kh; ++ky) {
                 uint32_t bits = a.rows[ky];
-                const uint8_t* row = S + (r + ky) * sp;
+                const uint32_t* row32 = reinterpret_cast<const uint32_t*>(S + (r + ky) * sp);
                 for (int kx = 0; bits; ++kx, bits >>= 1)
-                    if (bits & 1u) minmax4<DILATE>(acc, lds_bytes4(row, 4 * d + kx * C));
+                    if (bits & 1u) tap_pair<DILATE>(row32, 4 * d + kx * C, acc_e, acc_o);
             }
         }
+        const uint32_t out = __builtin_amdgcn_perm(acc_o, acc_e, 0x06020400u);   // {e.b0, o.b0, e.b2, o.b2}
         uint8_t* o = dst + (long long)y * row_bytes + fb;
-        if (fb + 4 <= row_bytes) *reinterpret_cast<u32_unaligned*>(o) = pack4(acc);
-        else for (int b = 0; fb + b < row_bytes; ++b) o[b] = (uint8_t)acc[b];
+        if (fb + 4 <= row_bytes) *reinterpret_cast<u32_unaligned*>(o) = out;
+        else for (int b = 0; fb + b < row_bytes; ++b) o[b] = (uint8_t)(out >> (8 * b));
     }
 }
 
 template <int C>
-void launch_morph_tile(hipStream_t st, const Morph& a, bool box, int sp, int srows, size_t lds) {
+int32_t launch_morph_tile(hipStream_t st, const Morph& a, bool box, int sp, int srows, size_t lds) {
     const dim3 grid = xcd_grid(a.tiles), blk(256);
+#define KH_MORPH_TILE(D, B)                                                                                                        \
+    do {                                                                                                                          \
+        if (lds > 48 * 1024)                                                                                                      \
+            KH_HIP(hipFuncSetAttribute((const void*)morphology_u8_tile_kernel<C, D, B>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((morphology_u8_tile_kernel<C, D, B>), grid, blk, lds, st, a, sp, srows);                                \
+    } while (0)
     if (a.op == 0) {
-        if (box) hipLaunchKernelGGL((morphology_u8_tile_kernel<C, true, true>), grid, blk, lds, st, a, sp, srows);
-        else hipLaunchKernelGGL((morphology_u8_tile_kernel<C, true, false>), grid, blk, lds, st, a, sp, srows);
+        if (box) KH_MORPH_TILE(true, true);
+        else KH_MORPH_TILE(true, false);
     } else {
-        if (box) hipLaunchKernelGGL((morphology_u8_tile_kernel<C, false, true>), grid, blk, lds, st, a, sp, srows);
-        else hipLaunchKernelGGL((morphology_u8_tile_kernel<C, false, false>), grid, blk, lds, st, a, sp, srows);
+        if (box) KH_MORPH_TILE(false, true);
+        else KH_MORPH_TILE(false, false);
     }
+#undef KH_MORPH_TILE
+    return KH_OK;
 }
 
 template <typename T>
@@ -523,19 +594,18 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     for (int c = 0; c < 4; ++c) a.cval[c] = (cval && c < channels) ? cval[c] : 0;
     hipStream_t st = as_hip(stream);
     // tiled kernel (LDS-staged window; separable for all-ones masks) unless the mask has no active tap (the per-pixel kernel's
-    // "no tap" rule), the window does not fit 64 KiB of LDS, or KH_MORPH_DIRECT=1 (dev / test knob)
+    // "no tap" rule), the window does not fit 150 KiB of LDS, or KH_MORPH_DIRECT=1 (dev / test knob)
     bool any = false, box = true;
     for (int ky = 0; ky < kh_; ++ky) { any = any || a.rows[ky]; box = box && a.rows[ky] == (kw == 32 ? 0xffffffffu : (1u << kw) - 1u); }
     static const bool direct = [] { const char* e = getenv("KH_MORPH_DIRECT"); return e && e[0] == '1'; }();
     const int srows = kMorphTH + kh_ - 1, sp = ((kMorphFW + (kw - 1) * channels + 3) & ~3) + 4;
-    const size_t lds = (size_t)srows * sp + (box ? (size_t)srows * kMorphFW : 0);
-    if (any && !direct && lds <= 64 * 1024 && (int64_t)w * h * channels <= kI32Max - 8) {
+    const size_t lds = (size_t)srows * sp + (box ? (size_t)srows * kMorphFW * 2 : 0);
+    if (any && !direct && lds <= 150 * 1024 && (int64_t)w * h * channels <= kI32Max - 8) {
         a.tiles = xcd_tiles(cdiv((int64_t)w * channels, kMorphFW), cdiv(h, kMorphTH), (unsigned)batch, cdiv((int64_t)w * channels, kMorphFW) * 4);
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-        if (channels == 1) launch_morph_tile<1>(st, a, box, sp, srows, lds);
-        else if (channels == 3) launch_morph_tile<3>(st, a, box, sp, srows, lds);
-        else launch_morph_tile<4>(st, a, box, sp, srows, lds);
-        return check_launch(what);
+        const int32_t rc = channels == 1 ? launch_morph_tile<1>(st, a, box, sp, srows, lds)
+                         : channels == 3 ? launch_morph_tile<3>(st, a, box, sp, srows, lds) : launch_morph_tile<4>(st, a, box, sp, srows, lds);
+        return rc ? rc : check_launch(what);
     }
     a.tiles = xcd_tiles(cdiv(w, kBx), cdiv(h, kBy), (unsigned)batch, cdiv(w, kBx) * 8);
     KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);

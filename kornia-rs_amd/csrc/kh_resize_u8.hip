@@ -212,7 +212,15 @@ __global__ __launch_bounds__(256) void sep_h_u8_tile_kernel(Rz a, int16_t* __res
         if (dwords) {
             const uint32_t* q = reinterpret_cast<const uint32_t*>(src + ((long long)(sy0 + r) * a.sw + p0) * C - mis);
             const int ndw = (mis + span * C + 3) >> 2;
-            for (int d = lane; d < ndw; d += 64) reinterpret_cast<uint32_t*>(row)[d] = q[d];
+            // eight independent loads in flight before the first LDS write (one per trip = one memory round trip per trip)
+            for (int d0 = lane; d0 < ndw; d0 += 64 * 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = q[min(d0 + 64 * k, ndw - 1)];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (d0 + 64 * k < ndw) reinterpret_cast<uint32_t*>(row)[d0 + 64 * k] = v[k];
+            }
         } else {
             const uint8_t* grow = src + (long long)(sy0 + r) * a.sw * C;
             for (int j = lane; j < span * C; j += 64) {
@@ -226,12 +234,13 @@ __global__ __launch_bounds__(256) void sep_h_u8_tile_kernel(Rz a, int16_t* __res
     if (x >= a.dw) return;
     const int rel = (tx.ofs[x] - p0) * C;
     const uint32_t* wrow = reinterpret_cast<const uint32_t*>(tx.w + (long long)x * tx.kp);
-    const uint8_t* rowp[4];
+    int rowo[4];  // byte offsets into the LDS tile (kept as integers: a pointer round trip through uintptr_t would turn the
+                  // ds_read into flat loads)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = min(wave * 4 + i, nrows - 1);  // rows past the image repeat the last one and are not stored
         bool dwords;
-        rowp[i] = S + r * pitch + row_mis(r, dwords) + rel;
+        rowo[i] = r * pitch + row_mis(r, dwords) + rel;
     }
     int32_t acc[4][C];
 #pragma unroll
@@ -242,8 +251,8 @@ __global__ __launch_bounds__(256) void sep_h_u8_tile_kernel(Rz a, int16_t* __res
         const uint32_t w01 = wrow[t4 >> 1], w23 = wrow[(t4 >> 1) + 1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uintptr_t o = (uintptr_t)(rowp[i] + t4 * C);
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(o & ~(uintptr_t)3);
+            const int o = rowo[i] + t4 * C;
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(kh_sep_lds + (o & ~3));
             const uint32_t sh = (uint32_t)(o & 3);
             uint32_t e[C];
 #pragma unroll
