@@ -526,7 +526,7 @@ class FusedRgb640(U8Images):
 class ResizeU8_224(U8Images):
     """resize_fast_u8_aa Lanczos-3 (antialiased Q14 separable cascade) 1920x1080 RGB8 -> 224x224, batch 256."""
 
-    name, kernel = "resize_fast_u8_lanczos_1080p_to_224_b256", "sep_h_u8_kernel<3> + sep_v_u8_kernel"
+    name, kernel = "resize_fast_u8_lanczos_1080p_to_224_b256", "sep_h_u8_tile_kernel<3> + sep_v_u8_kernel"
     W, H, C, D = 1920, 1080, 3, 224
 
     def __init__(self, batch):
@@ -600,7 +600,7 @@ class ResizeNormChw224(U8Images):
 class PyrDownU8_4K(U8Images):
     """pyrdown_u8 (5x5 Gaussian + 2x decimation, one launch) on 3840x2160 RGB8, batch 256."""
 
-    name, kernel = "pyrdown_u8_4k_b256", "pyrdown_u8_kernel<3>"
+    name, kernel = "pyrdown_u8_4k_b256", "pyrdown_u8_tile_kernel<3>"
 
     def __init__(self, batch):
         self.N = batch
@@ -630,7 +630,7 @@ class PyrDownU8_4K(U8Images):
 class DilateU8_4K(U8Images):
     """u8 dilate, 5x5 box structuring element, constant border, on 3840x2160 RGB8, batch 256."""
 
-    name, kernel = "dilate_u8_box5_4k_b256", "morphology_u8_kernel<3>"
+    name, kernel = "dilate_u8_box5_4k_b256", "morphology_u8_tile_kernel<3, dilate, box, 5>"
 
     def __init__(self, batch):
         self.N = batch
@@ -746,7 +746,7 @@ class SpatialGradient1080p(F32Images):
 class BoxBlurFast1080p(SpatialGradient1080p):
     """box_blur_fast sigma (2, 2): six running-sum passes through a transposed scratch, 1920x1080 f32x3, batch 64."""
 
-    name, kernel = "box_blur_fast_sigma2_1080p_f32_b64", "fast_hfilter_kernel"
+    name, kernel = "box_blur_fast_sigma2_1080p_f32_b64", "fast_hfilter_lds_kernel x6"
 
     def __init__(self, batch):
         super().__init__(batch)

@@ -189,24 +189,24 @@ __global__ __launch_bounds__(kBlock) void fast_hfilter_lds_kernel(const float* _
     for (int c0 = 0; c0 < cols; c0 += T) {
         const int lo = max(c0 - half - 1, 0), hi = min(c0 + T - 1 + half, cols - 1), seg = (hi - lo + 1) * C;
         __syncthreads();  // the previous chunk has been consumed
-        // eight independent loads (four rows x two segments) are in flight before the first LDS write: with one load per loop
-        // trip every trip cost a full memory round trip, and the ~66 trips per chunk were the kernel's whole time (r02y: 2.6 ms
-        // per pass of 64 1080p RGB f32 images)
-        constexpr int kWaves = kBlock / kWave;
-        for (int k0 = wave; k0 < nrows; k0 += 4 * kWaves) {
-            const float* g[4];
+        // 32 independent loads (eight rows x four 64-float segments) are in flight before the first LDS write: with one load per
+        // loop trip every trip cost a full memory round trip, and the ~66 trips per chunk were the kernel's whole time (r02y: 2.6 ms
+        // per pass of 64 1080p RGB f32 images; eight in flight: 1.3 ms).  Two blocks of four waves per CU leave 256 VGPRs per lane.
+        constexpr int kWaves = kBlock / kWave, kRowsB = 8, kSegB = 4;
+        for (int k0 = wave; k0 < nrows; k0 += kRowsB * kWaves) {
+            const float* g[kRowsB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = img + ((long long)(r_first + min(k0 + i * kWaves, nrows - 1)) * cols + lo) * C;
-            for (int e0 = lane; e0 < seg; e0 += 2 * kWave) {
-                float v[4][2];
+            for (int i = 0; i < kRowsB; ++i) g[i] = img + ((long long)(r_first + min(k0 + i * kWaves, nrows - 1)) * cols + lo) * C;
+            for (int e0 = lane; e0 < seg; e0 += kSegB * kWave) {
+                float v[kRowsB][kSegB];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < kRowsB; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) v[i][j] = g[i][min(e0 + j * kWave, seg - 1)];
+                    for (int j = 0; j < kSegB; ++j) v[i][j] = g[i][min(e0 + j * kWave, seg - 1)];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < kRowsB; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < kSegB; ++j)
                         if (k0 + i * kWaves < nrows && e0 + j * kWave < seg) hfilter_lds[(k0 + i * kWaves) * pitch + e0 + j * kWave] = v[i][j];
             }
         }

@@ -143,15 +143,28 @@ __global__ __launch_bounds__(kBx* kBy) void pyrdown_u8_kernel(Pyr<uint8_t> a) {
 // modulos, 25 x C byte loads and their addresses): 12.8 ms per 256 4K RGB images, 0.08 of the HBM roofline.  Here a 256-thread block
 // owns kPdTW x kPdTH destination pixels and
 //   1. runs the reference's horizontal pass ([1 4 6 4 1] into u16) once per (source row, destination column) of the tile's
-//      2 * kPdTH + 3 source rows, straight from global memory into LDS: interior tiles load each 5-pixel window as ceil(5C / 4)
-//      unaligned dwords (neighbouring lanes overlap, so the lines come from L1), border tiles reflect per tap;
-//   2. runs the vertical pass from LDS, four destination bytes per item, and stores dwords.
-// Same integer expressions as the per-pixel kernel, so the bytes are identical.
-constexpr int kPdTW = 64, kPdTH = 16, kPdRows = 2 * kPdTH + 3;
+//      2 * kPdTH + 3 source rows, straight from global memory into LDS.  A thread takes two neighbouring destination pixels:
+//      their windows overlap (7 source pixels = ceil(7C / 4) unaligned dwords; border tiles assemble the same dwords from
+//      reflected bytes), v_perm_b32 puts tap t of both pixels into the two 16-bit lanes of a register and the weights are
+//      applied with packed 16-bit adds / shifts / multiplies (the sums are <= 4080).  LDS holds one plane per channel, a dword
+//      = the pixel pair, so the writes are conflict-free (r02zb: the first version's three 2-byte writes per pixel at a 6-byte
+//      lane stride kept the LDS busy 2.2 of 3.3 ms);
+//   2. runs the vertical pass from LDS with the same packed arithmetic (<= 65280 + 128 fits a lane), four destination pixels per
+//      thread, and stores C dwords.
+// Same integers as the per-pixel kernel (exact sums, same final rounding), so the bytes are identical.
+constexpr int kPdTW = 64, kPdTH = 16, kPdRows = 2 * kPdTH + 3, kPdPairs = kPdTW / 2;
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2_t as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2_t, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2_t v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ u16x2_t binomial5(u16x2_t t0, u16x2_t t1, u16x2_t t2, u16x2_t t3, u16x2_t t4) {
+    const u16x2_t two = {2, 2}, six = {6, 6};
+    return (t0 + t4) + ((t1 + t3) << two) + t2 * six;
+}
 
 template <int C>
 __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
-    __shared__ __attribute__((aligned(16))) uint16_t H[kPdRows][kPdTW * C];
+    __shared__ __attribute__((aligned(16))) uint32_t H[kPdRows][C][kPdPairs];
     unsigned bx_, by_, bz_;
     if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
     const int tid = threadIdx.x;
@@ -159,82 +172,92 @@ __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
     const int sx0 = 2 * X0 - 2, sy0 = 2 * Y0 - 2;                           // source coordinates of the tile's first tap
     const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz_ * a.ds;
-    constexpr int ND = (5 * C + 3) / 4;                                      // dwords covering one 5-pixel window
+    constexpr int ND = (7 * C + 3) / 4;                                      // dwords covering a pixel pair's 7-pixel window
     // interior (block-uniform): every tap inside the image, and the up to three bytes a window's last dword reads past it too
     const bool interior = sx0 >= 0 && sy0 >= 0 && sx0 + 2 * kPdTW + 3 + 3 <= a.sw && sy0 + kPdRows <= a.sh;
-    const int rows_needed = 2 * min(kPdTH, a.dh - Y0) + 3, cols_needed = min(kPdTW, a.dw - X0);
-    const int lx = tid & (kPdTW - 1);                                        // kPdTW = 64: one destination column per lane
-    if (interior) {
-        // a batch of rows' windows is loaded before the first LDS write, so the block waits one memory round trip per batch
-        // and not one per row (the same finding as the morphology staging loop)
-        constexpr int kBatch = 5;
-        for (int r0 = tid >> 6; r0 < rows_needed; r0 += 4 * kBatch) {
-            uint32_t wv[kBatch][ND];
+    const int rows_needed = 2 * min(kPdTH, a.dh - Y0) + 3;
+    const int p = tid & (kPdPairs - 1), slot = tid >> 5;                     // pixel pair, row slot (8 rows per trip)
+    const bool pair_live = X0 + 2 * p < a.dw;
+    constexpr int kBatch = 5;                                                // 8 * 5 >= kPdRows: every row's loads are in flight at once
+    uint32_t wv[kBatch][ND];
+    if (interior) {  // one basic block: all kBatch * ND loads issue back to back
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const int r = min(r0 + 4 * k, rows_needed - 1);
-                const uint8_t* p = src + ((long long)(sy0 + r) * a.sw + sx0 + 2 * lx) * C;
+        for (int k = 0; k < kBatch; ++k) {
+            const int r = min(slot + 8 * k, rows_needed - 1);
+            const uint8_t* q = src + ((long long)(sy0 + r) * a.sw + sx0 + 4 * p) * C;
 #pragma unroll
-                for (int j = 0; j < ND; ++j) wv[k][j] = *reinterpret_cast<const u32_unaligned*>(p + 4 * j);
-            }
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const int r = r0 + 4 * k;
-                if (r >= rows_needed) break;
-                uint32_t B[5 * C];
-#pragma unroll
-                for (int b = 0; b < 5 * C; ++b) B[b] = (wv[k][b >> 2] >> (8 * (b & 3))) & 0xffu;
-#pragma unroll
-                for (int c = 0; c < C; ++c)  // <= 4080: the reference's u16 intermediate
-                    H[r][lx * C + c] = (uint16_t)(B[c] + 4u * B[C + c] + 6u * B[2 * C + c] + 4u * B[3 * C + c] + B[4 * C + c]);
-            }
+            for (int j = 0; j < ND; ++j) wv[k][j] = *reinterpret_cast<const u32_unaligned*>(q + 4 * j);
         }
     } else {
-        constexpr int kBatch = 3;
-        for (int r0 = tid >> 6; r0 < rows_needed; r0 += 4 * kBatch) {
-            if (lx >= cols_needed) continue;
-            uint8_t B[kBatch][5 * C];
+        // every tap's address is valid after reflection, so these byte loads are unconditional too (dead pairs read pixel 0)
+        int sx[7];
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const int r = min(r0 + 4 * k, rows_needed - 1);
-                const uint8_t* row = src + (long long)reflect_101(sy0 + r, a.sh) * a.sw * C;
+        for (int t = 0; t < 7; ++t) sx[t] = pair_live ? reflect_101(sx0 + 4 * p + t, a.sw) * C : 0;
 #pragma unroll
-                for (int t = 0; t < 5; ++t) {
-                    const uint8_t* p = row + reflect_101(sx0 + 2 * lx + t, a.sw) * C;
+        for (int k = 0; k < kBatch; ++k) {
+            const int r = min(slot + 8 * k, rows_needed - 1);
+            const uint8_t* row = src + (long long)reflect_101(sy0 + r, a.sh) * a.sw * C;
+            uint32_t bytes[7 * C];
 #pragma unroll
-                    for (int c = 0; c < C; ++c) B[k][t * C + c] = p[c];
+            for (int t = 0; t < 7; ++t)
+#pragma unroll
+                for (int c = 0; c < C; ++c) bytes[t * C + c] = row[sx[t] + c];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) wv[k][j] = 0;
+#pragma unroll
+            for (int n = 0; n < 7 * C; ++n) wv[k][n >> 2] |= bytes[n] << (8 * (n & 3));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+        const int r = slot + 8 * k;
+        if (r < rows_needed && pair_live) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                u16x2_t t[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {  // lanes: tap j of the pair's first pixel, tap j of its second (two source pixels on)
+                    constexpr uint32_t kZero = 0x0c000c00u;
+                    const int n1 = j * C + c, n2 = (j + 2) * C + c;
+                    t[j] = as_u16x2(__builtin_amdgcn_perm(wv[k][n2 >> 2], wv[k][n1 >> 2], kZero | (uint32_t)(n1 & 3) | ((uint32_t)(4 + (n2 & 3)) << 16)));
                 }
-            }
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const int r = r0 + 4 * k;
-                if (r >= rows_needed) break;
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    H[r][lx * C + c] = (uint16_t)((uint32_t)B[k][c] + 4u * B[k][C + c] + 6u * B[k][2 * C + c] + 4u * B[k][3 * C + c] + B[k][4 * C + c]);
+                H[r][c][p] = as_u32(binomial5(t[0], t[1], t[2], t[3], t[4]));  // <= 4080: the reference's u16 intermediate
             }
         }
     }
     __syncthreads();
-    constexpr int kQ = kPdTW * C / 4;                                        // four-byte items per destination row of the tile
-    const int row_bytes = a.dw * C;
-    for (int i = tid; i < kPdTH * kQ; i += 256) {
-        const int ry = i / kQ, fb = 4 * (i - ry * kQ);
-        const int Y = Y0 + ry, gb = X0 * C + fb;                             // destination row, flat byte inside it
-        if (Y >= a.dh || gb >= row_bytes) continue;
-        uint32_t s[4] = {0, 0, 0, 0};
+    // vertical pass: thread = destination row ry, pixels 4q .. 4q + 3 (two pairs)
+    const int ry = tid >> 4, q4 = tid & 15;
+    const int Y = Y0 + ry, X = X0 + 4 * q4;
+    if (Y >= a.dh || X >= a.dw) return;
+    uint32_t o[4][C];  // [pixel][channel]
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        u16x2_t lo[5], hi[5];
 #pragma unroll
         for (int ky = 0; ky < 5; ++ky) {
-            const uint32_t* hp = reinterpret_cast<const uint32_t*>(&H[2 * ry + ky][fb]);
-            const uint32_t v0 = hp[0], v1 = hp[1], w = ky == 2 ? 6u : (ky == 0 || ky == 4) ? 1u : 4u;
-            s[0] += w * (v0 & 0xffffu); s[1] += w * (v0 >> 16); s[2] += w * (v1 & 0xffffu); s[3] += w * (v1 >> 16);
+            const uint32_t* hp = &H[2 * ry + ky][c][2 * q4];
+            lo[ky] = as_u16x2(hp[0]);
+            hi[ky] = as_u16x2(hp[1]);
         }
-        uint32_t o[4];
+        const u16x2_t half = {128, 128}, eight = {8, 8}, top = {255, 255};
+        const u16x2_t v01 = __builtin_elementwise_min((binomial5(lo[0], lo[1], lo[2], lo[3], lo[4]) + half) >> eight, top);
+        const u16x2_t v23 = __builtin_elementwise_min((binomial5(hi[0], hi[1], hi[2], hi[3], hi[4]) + half) >> eight, top);
+        o[0][c] = v01[0]; o[1][c] = v01[1]; o[2][c] = v23[0]; o[3][c] = v23[1];
+    }
+    uint8_t* op = dst + ((long long)Y * a.dw + X) * C;
+    if (X + 4 <= a.dw) {
+        uint32_t w[C];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) o[b] = min((s[b] + 128u) >> 8, 255u);
-        uint8_t* op = dst + (long long)Y * row_bytes + gb;
-        if (gb + 4 <= row_bytes) *reinterpret_cast<u32_unaligned*>(op) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-        else for (int b = 0; gb + b < row_bytes; ++b) op[b] = (uint8_t)o[b];
+        for (int j = 0; j < C; ++j) w[j] = 0;
+#pragma unroll
+        for (int n = 0; n < 4 * C; ++n) w[n >> 2] |= o[n / C][n % C] << (8 * (n & 3));
+#pragma unroll
+        for (int j = 0; j < C; ++j) reinterpret_cast<u32_unaligned*>(op)[j] = w[j];
+    } else {
+        for (int px = 0; X + px < a.dw; ++px)
+#pragma unroll
+            for (int c = 0; c < C; ++c) op[px * C + c] = (uint8_t)o[px][c];
     }
 }
 
@@ -345,7 +368,6 @@ constexpr int kMorphFW = 384;   // flat bytes per tile row: a whole number of pi
 constexpr int kMorphTH = 32;    // output rows per tile
 extern __shared__ __attribute__((aligned(16))) uint8_t kh_morph_lds[];
 
-typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 template <bool DILATE>
 __device__ __forceinline__ uint32_t pk_minmax(uint32_t a, uint32_t b) {
     const u16x2_t x = __builtin_bit_cast(u16x2_t, a), y = __builtin_bit_cast(u16x2_t, b);
@@ -360,8 +382,14 @@ __device__ __forceinline__ void tap_pair(const uint32_t* row32, int o, uint32_t&
     acc_o = pk_minmax<DILATE>(acc_o, __builtin_amdgcn_perm(hi, lo, sel_e + 0x00010001u));
 }
 
-template <int C, bool DILATE, bool BOX>
-__global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp, int srows) {
+// K > 0: a K x K box known at compile time (3, 5, 7): the tap loops unroll, a window's dwords are read once and the tile
+// geometry folds into constants (r02zb: the run-time loops cost 128 lane-operations per four output bytes, 62 % VALU-busy).
+template <int C, bool DILATE, bool BOX, int K>
+__global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp_, int srows_) {
+    static_assert(K == 0 || BOX, "a compile-time size is a box");
+    const int srows = K ? kMorphTH + K - 1 : srows_;
+    const int sp = K ? ((kMorphFW + (K - 1) * C + 3) & ~3) + 4 : sp_;
+    if (K) { a.kw = K; a.kh = K; }
     uint8_t* S = kh_morph_lds;                                              // [srows][sp]: source window, flat bytes
     uint32_t* H = reinterpret_cast<uint32_t*>(kh_morph_lds + srows * sp);   // [srows][kDW][2]: horizontal pass, 16-bit lanes (BOX only)
     unsigned bx_, by_, bz_;
@@ -382,25 +410,21 @@ __global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp
         const int dpr = (spx * C + 3) >> 2;                                  // dwords per staged row (sp >= 4 * dpr, dpr <= 128)
         // the last dword of a row may read up to 3 bytes past the window: still inside the image except at its very end
         const long long img_bytes = (long long)a.w * a.h * C;
-        const int d = tid & 127;
-        constexpr int kBatch = 10;                                           // rows per thread in flight (two threads-halves interleave rows)
+        // Branch-free: every thread loads from a clamped (row, dword) of the window — a load inside its own branch is waited for
+        // before the next one issues — and the duplicate lanes / rows store the same value to the same LDS cell.  The last dword
+        // of the image is fetched from img_bytes - 4 and shifted down.
+        const int d = min(tid & 127, dpr - 1);
+        constexpr int kBatch = 10;                                           // rows per thread in flight (the two 128-thread halves interleave rows)
         for (int r0 = tid >> 7; r0 < srows; r0 += 2 * kBatch) {
             uint32_t v[kBatch];
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
-                const int r = r0 + 2 * k;
-                v[k] = 0;
-                if (r < srows && d < dpr) {
-                    const long long off = ((long long)(wy0 + r) * a.w + wx0) * C + 4 * d;
-                    if (off + 4 <= img_bytes) v[k] = *reinterpret_cast<const u32_unaligned*>(src + off);
-                    else for (int b = 0; off + b < img_bytes; ++b) v[k] |= (uint32_t)src[off + b] << (8 * b);
-                }
+                const int r = min(r0 + 2 * k, srows - 1);
+                const long long off = ((long long)(wy0 + r) * a.w + wx0) * C + 4 * d, offc = min(off, img_bytes - 4);
+                v[k] = *reinterpret_cast<const u32_unaligned*>(src + offc) >> (8 * (int)(off - offc));
             }
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const int r = r0 + 2 * k;
-                if (r < srows && d < dpr) *reinterpret_cast<uint32_t*>(S + r * sp + 4 * d) = v[k];
-            }
+            for (int k = 0; k < kBatch; ++k) *reinterpret_cast<uint32_t*>(S + min(r0 + 2 * k, srows - 1) * sp + 4 * d) = v[k];
         }
     } else {
         constexpr int kBatch = 4;
@@ -435,18 +459,58 @@ __global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp
     const uint32_t init = DILATE ? 0u : 0x00ff00ffu;
     if constexpr (BOX) {
         // 2a. horizontal pass over every staged row
-        for (int i = tid; i < kDW * srows; i += 256) {
-            const int r = i / kDW, d = i - r * kDW;
-            const uint32_t* row32 = reinterpret_cast<const uint32_t*>(S + r * sp);
-            uint32_t acc_e = init, acc_o = init;
-            for (int kx = 0; kx < a.kw; ++kx) tap_pair<DILATE>(row32, 4 * d + kx * C, acc_e, acc_o);
-            H[2 * i] = acc_e;
-            H[2 * i + 1] = acc_o;
+        if constexpr (K > 0) {
+            // eight output bytes per item: the two windows share all but one of their dwords and the index arithmetic
+            for (int i = tid; i < (kDW / 2) * srows; i += 256) {
+                const int r = i / (kDW / 2), j = i - r * (kDW / 2);
+                const uint32_t* row32 = reinterpret_cast<const uint32_t*>(S + r * sp) + 2 * j;
+                uint32_t e0 = init, o0 = init, e1 = init, o1 = init;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    tap_pair<DILATE>(row32, kx * C, e0, o0);
+                    tap_pair<DILATE>(row32 + 1, kx * C, e1, o1);
+                }
+                uint32_t* h = H + 4 * i;
+                h[0] = e0; h[1] = o0; h[2] = e1; h[3] = o1;
+            }
+        } else {
+            for (int i = tid; i < kDW * srows; i += 256) {
+                const int r = i / kDW, d = i - r * kDW;
+                const uint32_t* row32 = reinterpret_cast<const uint32_t*>(S + r * sp);
+                uint32_t acc_e = init, acc_o = init;
+                for (int kx = 0; kx < a.kw; ++kx) tap_pair<DILATE>(row32, 4 * d + kx * C, acc_e, acc_o);
+                H[2 * i] = acc_e;
+                H[2 * i + 1] = acc_o;
+            }
         }
         __syncthreads();
     }
     // 2b / 3. output rows
     const int row_bytes = a.w * C;
+    if constexpr (K > 0) {
+        // two output rows per item: they share K - 1 of their K + 1 rows of H
+        for (int i = tid; i < kDW * (kMorphTH / 2); i += 256) {
+            const int rp = i / kDW, d = i - rp * kDW;
+            const int y = y0 + 2 * rp, fb = x0 * C + 4 * d;
+            if (y >= a.h || fb >= row_bytes) continue;
+            const uint32_t* h = H + 2 * (2 * rp * kDW + d);
+            uint32_t he[K + 1], ho[K + 1];
+#pragma unroll
+            for (int ky = 0; ky <= K; ++ky) { he[ky] = h[2 * ky * kDW]; ho[ky] = h[2 * ky * kDW + 1]; }
+            uint32_t me = he[1], mo = ho[1];   // rows 1 .. K - 1 are common to both outputs
+#pragma unroll
+            for (int ky = 2; ky < K; ++ky) { me = pk_minmax<DILATE>(me, he[ky]); mo = pk_minmax<DILATE>(mo, ho[ky]); }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (y + j >= a.h) break;
+                const uint32_t out = __builtin_amdgcn_perm(pk_minmax<DILATE>(mo, ho[j ? K : 0]), pk_minmax<DILATE>(me, he[j ? K : 0]), 0x06020400u);
+                uint8_t* o = dst + (long long)(y + j) * row_bytes + fb;
+                if (fb + 4 <= row_bytes) *reinterpret_cast<u32_unaligned*>(o) = out;
+                else for (int b = 0; fb + b < row_bytes; ++b) o[b] = (uint8_t)(out >> (8 * b));
+            }
+        }
+        return;
+    }
     for (int i = tid; i < kDW * kMorphTH; i += 256) {
         const int r = i / kDW, d = i - r * kDW;
         const int y = y0 + r;
@@ -476,19 +540,27 @@ __global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp
 template <int C>
 int32_t launch_morph_tile(hipStream_t st, const Morph& a, bool box, int sp, int srows, size_t lds) {
     const dim3 grid = xcd_grid(a.tiles), blk(256);
-#define KH_MORPH_TILE(D, B)                                                                                                        \
+#define KH_MORPH_TILE(D, B, KK)                                                                                                    \
     do {                                                                                                                          \
         if (lds > 48 * 1024)                                                                                                      \
-            KH_HIP(hipFuncSetAttribute((const void*)morphology_u8_tile_kernel<C, D, B>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((morphology_u8_tile_kernel<C, D, B>), grid, blk, lds, st, a, sp, srows);                                \
+            KH_HIP(hipFuncSetAttribute((const void*)morphology_u8_tile_kernel<C, D, B, KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((morphology_u8_tile_kernel<C, D, B, KK>), grid, blk, lds, st, a, sp, srows);                            \
+    } while (0)
+#define KH_MORPH_BOX(D)                                                                                                            \
+    do {                                                                                                                          \
+        if (a.kw == a.kh && a.kw == 3) KH_MORPH_TILE(D, true, 3);                                                                  \
+        else if (a.kw == a.kh && a.kw == 5) KH_MORPH_TILE(D, true, 5);                                                             \
+        else if (a.kw == a.kh && a.kw == 7) KH_MORPH_TILE(D, true, 7);                                                             \
+        else KH_MORPH_TILE(D, true, 0);                                                                                            \
     } while (0)
     if (a.op == 0) {
-        if (box) KH_MORPH_TILE(true, true);
-        else KH_MORPH_TILE(true, false);
+        if (box) KH_MORPH_BOX(true);
+        else KH_MORPH_TILE(true, false, 0);
     } else {
-        if (box) KH_MORPH_TILE(false, true);
-        else KH_MORPH_TILE(false, false);
+        if (box) KH_MORPH_BOX(false);
+        else KH_MORPH_TILE(false, false, 0);
     }
+#undef KH_MORPH_BOX
 #undef KH_MORPH_TILE
     return KH_OK;
 }

@@ -99,7 +99,7 @@ def test_morphology_matches_oracle(gpu_stream, border, kshape):
             assert_same_bits(got, O.morphology_u8(src, op, mask, border, cval), f"{op} {kshape} {border} {w}x{h} c{c}")
 
 
-@pytest.mark.parametrize("kshape", [("box", 5, 5), ("ellipse", 7, 5), ("box", 2, 2), ("box", 1, 1), ("cross", 3, 9), ("box", 31, 3)])
+@pytest.mark.parametrize("kshape", [("box", 3, 3), ("box", 5, 5), ("box", 7, 7), ("ellipse", 7, 5), ("box", 2, 2), ("box", 1, 1), ("cross", 3, 9), ("box", 31, 3)])
 def test_morphology_tiled_interior_and_ragged_tiles(gpu_stream, kshape):
     """Sizes with tiles that take the tiled kernel's interior staging path (384 flat bytes x 32 rows per tile), a ragged last tile
     column / row, and - 2x2 and 1x1 masks have no right / bottom halo - an interior tile that ends on the image's last byte."""
