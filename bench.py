@@ -627,6 +627,58 @@ class PyrDownU8_4K(U8Images):
         return self._time_cpu(lambda O: O.pyrdown(img), "pyrdown_u8")
 
 
+class PyramidLevel(Workload):
+    """One pyramid step between 3840x2160 and 1920x1080 RGB, u8 or f32: `kind` in pyrup_u8 / pyrdown_f32 / pyrup_f32 (pyrdown_u8 has
+    its own class above).  Units = pixels of the LARGER image."""
+
+    def __init__(self, kind, batch):
+        self.kind, self.N = kind, batch
+        self.up, self.f32 = kind.startswith("pyrup"), kind.endswith("f32")
+        self.dtype = "f32" if self.f32 else "u8"
+        self.es = 4 if self.f32 else 1
+        self.C = 3
+        self.sw, self.sh = (1920, 1080) if self.up else (3840, 2160)
+        self.dw, self.dh = (3840, 2160) if self.up else (1920, 1080)
+        self.name = f"{kind}_4k_b{batch}"
+        self.kernel = f"{kind}_kernel<3>"
+        self.units_per_step = self.N * 3840 * 2160 / 1e6
+        self.alg_bytes_per_launch = self.N * (self.sw * self.sh + self.dw * self.dh) * self.C * self.es
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        helper = F32Images() if self.f32 else U8Images()
+        self.src = helper._make_src(stream, self.sw, self.sh, self.C, self.N)
+        self.base = helper.base
+        self.dst = DeviceBuffer(self.N * self.dw * self.dh * self.C * self.es, stream, zeroed=False)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        fn = getattr(lib, f"kh_{self.kind}")
+        check(fn(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.sw, self.sh, self.C, self.N,
+                 self.sw * self.sh * self.C, self.dw * self.dh * self.C))
+
+    def describe(self):
+        return {"workload": self.name, "op": f"imgproc::pyramid::{self.kind} (one launch, both passes)",
+                "src": f"{self.sw}x{self.sh}x3 {self.dtype}", "dst": f"{self.dw}x{self.dh}x3 {self.dtype}", "batch_per_gpu": self.N,
+                "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
+        img = self.base[: self.sw * self.sh * self.C].reshape(self.sh, self.sw, self.C)
+        fn = O.pyrup if self.up else O.pyrdown
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            fn(img)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > 8.0 * CPU_BUDGET_SCALE or reps >= 64:
+                break
+        return {"value": round(reps * 3840 * 2160 / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": O.ko.ko_max_threads(), "kind": "port",
+                "sample": f"{reps} images in {dt:.1f} s; C oracle of {self.kind} (not the upstream Rust binary)"}
+
+
 class DilateU8_4K(U8Images):
     """u8 dilate, 5x5 box structuring element, constant border, on 3840x2160 RGB8, batch 256."""
 
@@ -952,6 +1004,9 @@ WORKLOADS = {
     "resize_norm_chw_224": lambda a: ResizeNormChw224(a.batch or 256),
     "pyrdown_u8_4k": lambda a: PyrDownU8_4K(a.batch or 256),
     "dilate_u8_4k": lambda a: DilateU8_4K(a.batch or 256),
+    "pyrup_u8_4k": lambda a: PyramidLevel("pyrup_u8", a.batch or 256),
+    "pyrdown_f32_4k": lambda a: PyramidLevel("pyrdown_f32", a.batch or 64),
+    "pyrup_f32_4k": lambda a: PyramidLevel("pyrup_f32", a.batch or 64),
     "lab_from_rgb_4k": lambda a: LabFromRgb4K(a.batch or 64),
     "spatial_gradient_1080p": lambda a: SpatialGradient1080p(a.batch or 256),
     "box_blur_fast_1080p": lambda a: BoxBlurFast1080p(a.batch or 64),

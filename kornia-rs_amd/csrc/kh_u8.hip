@@ -699,8 +699,13 @@ __global__ __launch_bounds__(16 * kStageH) void warp_affine_u8_lds_kernel(ImgU8 
         }
         out[j] = px;
     }
-    if (whole) store_quad_px<C>(o, out);
-    else for (int j = 0; x4 + j < im.dw; ++j) store_one_px<C>(o + j * C, out[j]);
+    if (whole) {
+        store_quad_px<C>(o, out);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)  // fixed trip count: a run-time bound indexes out[] dynamically and puts it in scratch
+            if (x4 + j < im.dw) store_one_px<C>(o + j * C, out[j]);
+    }
 }
 
 // warp_perspective_u8 (P/warp/perspective.rs:179-322): rows whose denominator keeps one sign get

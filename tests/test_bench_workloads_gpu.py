@@ -112,6 +112,16 @@ def test_filter_workloads_4k(gpu_stream, bench):
         assert np.array_equal(got[k], O.morphology_u8(_frame(wl, k, n, (wl.H, wl.W, wl.C)), "dilate", O.morph_kernel("box", 5), "constant", [0, 0, 0])), k
 
 
+@pytest.mark.parametrize("name", ["pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k"])
+def test_pyramid_workloads_4k(gpu_stream, bench, name):
+    wl = _run(bench, name, gpu_stream)
+    n = wl.sw * wl.sh * wl.C
+    got = _out(wl, np.float32 if wl.f32 else np.uint8, (wl.dh, wl.dw, wl.C))
+    for k in range(wl.N):
+        src = _frame(wl, k, n, (wl.sh, wl.sw, wl.C))
+        assert np.array_equal(got[k], O.pyrup(src) if wl.up else O.pyrdown(src)), k
+
+
 def test_gather_workloads_4k(gpu_stream, bench):
     wl = _run(bench, "undistort_warp_4k", gpu_stream)
     n = wl.W * wl.H * wl.C
@@ -172,7 +182,7 @@ def test_colour_map_workloads_1080p(gpu_stream, bench):
 
 def test_every_workload_is_covered(bench):
     covered = {"nv12_chw", "nv12_chw_640", "resize_224", "resize_normalize_f32_224", "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640",
-               "gaussian_4k", "gaussian_u8_4k", "pyrdown_u8_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_u8_4k", "lab_from_rgb_4k",
+               "gaussian_4k", "gaussian_u8_4k", "pyrdown_u8_4k", "pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_u8_4k", "lab_from_rgb_4k",
                "spatial_gradient_1080p", "box_blur_fast_1080p", "median5_u8_1080p", "bilateral_1080p",
                "gray_u8_1080p", "gray_f32_1080p", "hsv_f32_1080p", "bgr_u8_1080p", "gray_258x195", "nv12_chw_640_lanczos"}
     assert set(bench.ALSO_DEFAULT) <= set(bench.WORKLOADS)
