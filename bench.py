@@ -441,7 +441,7 @@ class GaussianU8_4K(U8Images):
 class WarpAffineU8_4K(U8Images):
     """warp_affine_u8 (rotation 12 deg about the centre, scale 0.9) on 3840x2160 RGB8, batch 256."""
 
-    name, kernel = "warp_affine_u8_4k_b256", "warp_affine_u8_kernel<3>"
+    name, kernel = "warp_affine_u8_4k_b256", "warp_affine_u8_lds_kernel<3> (+ affine_rows, affine_boxes)"
 
     def __init__(self, batch):
         self.N = batch

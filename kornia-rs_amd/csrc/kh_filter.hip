@@ -251,8 +251,9 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
 // wash, which settles what bounds this kernel: NOT instruction issue (by SQ_INSTS_VALU x 4 cycles the one-column kernel keeps the
 // vector ALUs about 80 % busy, yet halving that changes nothing), but the memory system: 52.7 GB of counted traffic in 9.1 ms = 5.8 TB/s
 // for a 50 % read / 50 % write stream, against 6.2-6.3 TB/s for the best plain copies measured on this part.  Round 1 reached the
-// same conclusion from a similar variant (profiles/r01n_ab.log).  The two-column kernel is the default for even rows of at least
-// 512 floats (fewer instructions for the same time); KH_FILTER_ONE_COLUMN=1 selects the other.
+// same conclusion from a similar variant (profiles/r01n_ab.log).  A second same-box A/B at the end of the round (r02zk, three
+// interleaved runs each) has the one-column kernel 1.5 % ahead (9.17 vs 9.30 ms), so it stays the default; KH_FILTER_TWO_COLUMNS=1
+// selects this kernel (even rows of at least 512 floats; tests/test_filter_gpu.py runs it in a child process).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int kTF2 = 2 * kTF;  // flat columns per 256-thread block
 
@@ -400,10 +401,11 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         TapsK px, py;
         pad_taps(px, kx, K);
         pad_taps(py, ky, K);
-        // two columns per lane (packed f32 math) for rows of even length that fill at least one 512-column block; gradients and
-        // narrow / odd rows keep the one-column kernel.  KH_FILTER_ONE_COLUMN=1 (dev / test knob) forces the one-column kernel.
-        static const bool one_col = [] { const char* e = getenv("KH_FILTER_ONE_COLUMN"); return e && e[0] == '1'; }();
-        const bool two = !grad && !one_col && (a.rowlen % 2 == 0) && a.rowlen >= kTF2 && (reinterpret_cast<uintptr_t>(src) % 8 == 0) &&
+        // KH_FILTER_TWO_COLUMNS=1 (dev / test knob): two columns per lane (packed f32 math) for rows of even length that fill at
+        // least one 512-column block; gradients and narrow / odd rows always take the one-column kernel.
+        const char* two_env = getenv("KH_FILTER_TWO_COLUMNS");  // read per call, like KH_FILTER_FORCE_TILE: the tests flip it
+        const bool two_cols = two_env && two_env[0] == '1';
+        const bool two = !grad && two_cols && (a.rowlen % 2 == 0) && a.rowlen >= kTF2 && (reinterpret_cast<uintptr_t>(src) % 8 == 0) &&
                          (batch == 1 || ss % 2 == 0);
         const unsigned tiles_x = cdiv(a.rowlen, two ? kTF2 : kTF);  // 256-thread blocks: 512 measured +1 %, 1024 +9 % (r01q)
         // Strip height: tall strips amortise the ky-1 warm-up rows (4K x 256 images: 360 rows is

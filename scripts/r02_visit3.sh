@@ -13,7 +13,7 @@ for l in sys.stdin:
 echo "== default bench" | tee "$OUT/bench_table.txt"
 timeout 900 python bench.py 2>&1 | grep '^{' | tee "$OUT/bench.log" | line | tee -a "$OUT/bench_table.txt"
 echo "== opt-in workloads" | tee -a "$OUT/bench_table.txt"
-timeout 1200 python bench.py --no-cpu-baseline --also resize_normalize_f32_224,fused_rgb_640,resize_u8_224,resize_norm_chw_224,pyrdown_u8_4k,dilate_u8_4k,lab_from_rgb_4k,spatial_gradient_1080p,box_blur_fast_1080p,median5_u8_1080p,bilateral_1080p,bgr_u8_1080p 2>&1 | grep '^{' | tee -a "$OUT/bench.log" | line | tee -a "$OUT/bench_table.txt"
+timeout 1200 python bench.py --no-cpu-baseline --also resize_normalize_f32_224,fused_rgb_640,resize_u8_224,resize_norm_chw_224,pyrdown_u8_4k,pyrup_u8_4k,pyrdown_f32_4k,pyrup_f32_4k,dilate_u8_4k,nv12_chw_640_lanczos,lab_from_rgb_4k,spatial_gradient_1080p,box_blur_fast_1080p,median5_u8_1080p,bilateral_1080p,bgr_u8_1080p 2>&1 | grep '^{' | tee -a "$OUT/bench.log" | line | tee -a "$OUT/bench_table.txt"
 echo "== rocprofv3 kernel trace of the default run"
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d "$REPO/$OUT/prof_default" -o kt -- python "$REPO/bench.py" --no-cpu-baseline > "$REPO/$OUT/prof_default.log" 2>&1
