@@ -26,7 +26,7 @@ namespace kh {
 struct DevTable {
     void* dev = nullptr;
     size_t bytes = 0;
-    int meta[4] = {0, 0, 0, 0};   // small per-table facts (tap count, radius ...)
+    int meta[6] = {0, 0, 0, 0, 0, 0};   // small per-table facts (tap count, radius ...)
     hipEvent_t last_use = nullptr;
     bool pinned = false;          // referenced by a captured graph: never evicted
     int device = 0;
