@@ -1,9 +1,9 @@
 """Named colour maps — ``ColormapType`` / ``ColormapLut`` of crates/kornia-imgproc/src/color/colormap.rs:49-100.
 
-All 21 reference names parse (``ColormapType.from_name`` is case-insensitive like the reference's); the twelve tables
+All 21 reference names parse (``ColormapType.from_name`` is case-insensitive like the reference's); the nineteen tables
 that can be rebuilt from their public definitions are bundled (``data/colormaps.npy``, produced and checked by
 ``scripts/gen_colormaps.py``).  Asking for one of the others is an error that says so — ``apply_colormap`` also takes
-any caller-provided 3 x 256 table, so OpenCV's remaining tables can be supplied from ``cv2`` where it is installed.
+any caller-provided 3 x 256 table, so the two literal tables (parula, deepgreen) can be supplied from ``cv2`` where it is installed.
 """
 import enum
 import json

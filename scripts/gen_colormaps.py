@@ -9,11 +9,13 @@ mounted (and their SHA-256 digests are committed under tests/golden/colormaps/ s
   points 0.1 apart, f32 `linspace` + `interp1`, `convertTo(CV_8U, 255)` (round half to even);
 * magma / inferno / plasma / viridis / cividis / turbo — the published 256-entry float tables (matplotlib ships them
   verbatim), `round(255 * v)`;
-* summer / hsv — 64 Octave control points (`summer(64)`, `hsv(64)`) through the same `linear_colormap` interpolation.
+* summer / hsv / bone / pink / hot / rainbow / ocean — 64 Octave control points (`summer(64)`, `hsv(64)`, ... from the
+  piecewise-linear definitions in Octave's scripts/image/*.m) through the same `linear_colormap` interpolation;
+* jet — 256 control points of min(4x - a, -4x + b) clipped to [0, 1] (matplotlib's `jet` segments), x = i / 255;
+* twilight — matplotlib's 510-entry `twilight` table as control points through the same interpolation.
 
-The other nine (bone, jet, rainbow, ocean, pink, hot, parula, twilight, deepgreen) need OpenCV's literal
-control arrays, which are not available offline; `apply_colormap` names them in its error and still takes any
-caller-provided 3x256 table.
+The other two (parula, deepgreen) are literal tables with no public closed form; `apply_colormap` names them in
+its error and still takes any caller-provided 3x256 table.
 """
 import hashlib
 import json
@@ -71,8 +73,30 @@ def build():
     maps["summer"] = cv_linear_colormap(x64, [0.5 + v / 2 for v in x64], [0.4] * 64)
     hsv = [colorsys.hsv_to_rgb(v % 1.0, 1.0, 1.0) for v in x64]
     maps["hsv"] = cv_linear_colormap([c[0] for c in hsv], [c[1] for c in hsv], [c[2] for c in hsv])
-    from matplotlib import colormaps
+    # Octave's piecewise-linear definitions on x = linspace(0, 1, 64)
+    x = np.linspace(0, 1, 64)
+    w = np.where
+    maps["rainbow"] = cv_linear_colormap(w(x < 2 / 5, 1, w(x < 3 / 5, -5 * x + 3, w(x < 4 / 5, 0, 10 / 3 * x - 8 / 3))),
+                                         w(x < 2 / 5, 5 / 2 * x, w(x < 3 / 5, 1, w(x < 4 / 5, -5 * x + 4, 0))),
+                                         w(x < 3 / 5, 0, w(x < 4 / 5, 5 * x - 3, 1)))
+    maps["bone"] = cv_linear_colormap(w(x < 3 / 4, 7 / 8 * x, 11 / 8 * x - 3 / 8),
+                                      w(x < 3 / 8, 7 / 8 * x, w(x < 3 / 4, 29 / 24 * x - 1 / 8, 7 / 8 * x + 1 / 8)),
+                                      w(x < 3 / 8, 29 / 24 * x, 7 / 8 * x + 1 / 8))
+    maps["pink"] = cv_linear_colormap(np.sqrt(w(x < 3 / 8, 14 / 9 * x, 2 / 3 * x + 1 / 3)),
+                                      np.sqrt(w(x < 3 / 8, 2 / 3 * x, w(x < 3 / 4, 14 / 9 * x - 1 / 3, 2 / 3 * x + 1 / 3))),
+                                      np.sqrt(w(x < 3 / 4, 2 / 3 * x, 2 * x - 1)))
+    maps["hot"] = cv_linear_colormap(w(x < 2 / 5, 5 / 2 * x, 1.0), w(x < 2 / 5, 0, w(x < 4 / 5, 5 / 2 * x - 1, 1.0)), w(x < 4 / 5, 0, 5 * x - 4))
+    cutin = 64 // 3
+    ramp = lambda step: np.arange(0, 63 + 1e-9, step)
+    pad = lambda v: np.concatenate([np.zeros(64 - len(v)), v]) / 63
+    maps["ocean"] = cv_linear_colormap(pad(ramp(63 / cutin)), pad(ramp(63 / (2 * cutin))), np.arange(64) / 63)
     x = np.arange(256) / 255.0
+    clip = lambda v: np.clip(v, 0, 1)
+    maps["jet"] = cv_linear_colormap(clip(np.minimum(4 * x - 1.5, -4 * x + 4.5)), clip(np.minimum(4 * x - 0.5, -4 * x + 3.5)),
+                                     clip(np.minimum(4 * x + 0.5, -4 * x + 2.5)))
+    from matplotlib import colormaps
+    tw = np.array(colormaps["twilight"].colors)
+    maps["twilight"] = cv_linear_colormap(tw[:, 0], tw[:, 1], tw[:, 2])
     for name in ("magma", "inferno", "plasma", "viridis", "cividis", "turbo"):
         maps[name] = np.rint(colormaps[name](x)[:, :3] * 255.0).astype(np.uint8).T.copy()
     return maps

@@ -250,14 +250,14 @@ def test_named_colormaps_match_the_reference_digests():
     from kornia_rs import ColormapType, ImageError, colormap
     digests = json.loads((Path(__file__).parent / "golden" / "colormaps" / "reference_sha256.json").read_text())
     assert sorted(digests) == sorted(k.value for k in ColormapType) and len(digests) == 21  # colormap.rs:49-73
-    assert len(colormap.bundled()) == 12
+    assert len(colormap.bundled()) == 19 and set(digests) - set(colormap.bundled()) == {"parula", "deepgreen"}
     for name in colormap.bundled():
         table = colormap.lut(name)
         assert table.shape == (3, 256) and table.dtype == np.uint8
         assert hashlib.sha256(table.tobytes()).hexdigest() == digests[name], name
     assert ColormapType.from_name("ViRiDiS") is ColormapType.VIRIDIS and ColormapType.from_name("nope") is None  # :78-84
     assert np.array_equal(colormap.lut(ColormapType.AUTUMN)[:, [0, 255]], [[255, 255], [0, 255], [0, 0]])
-    for name, kind in (("jet", "not bundled"), ("nope", "unknown")):
+    for name, kind in (("parula", "not bundled"), ("nope", "unknown")):
         with pytest.raises(ImageError) as e:
             colormap.lut(name)
         assert kind in str(e.value)
