@@ -24,6 +24,8 @@
 #include <tuple>
 #include <vector>
 
+#include <type_traits>
+
 #include "kh_common.h"
 #include "kh_median_net.h"
 #include "kh_table_cache.h"
@@ -338,8 +340,44 @@ __global__ __launch_bounds__(kBx* kBy) void bilateral_kernel(const uint8_t* __re
     // simd_end is a multiple of 16 and a block spans 64 columns, so in all but one block column every lane uses the same tap
     // order: then the tap index is block-uniform and the order / (dy, dx) / space-weight reads are scalar loads (one per wave)
     // instead of three vector loads per tap per lane (r02y: 8.4 ms per 256 1080p images, bound by load issue).
-    const int bx0 = blockIdx.x * kBx;
-    if (bx0 + kBx <= simd_end) {
+    const int bx0 = blockIdx.x * kBx, by0 = blockIdx.y * kBy;
+    // Blocks that lie wholly inside the reflection frame and use one tap order take the taps eight at a time: the eight table
+    // reads (scalar), then the eight pixel bytes, then the eight colour weights are each issued together, and only the
+    // accumulation runs in tap order.  One tap per trip was a serial chain of two scalar-load, one vector-load and one LDS
+    // latency per tap — 13 taps x ~1000 cycles per thread, which is what the kernel's 6.3 ms were (r02za).
+    const bool blk_inner = bx0 >= t.radius && bx0 + kBx - 1 + t.radius < cols && by0 >= t.radius && by0 + kBy - 1 + t.radius < rows;
+    auto batched = [&](auto ordered) {
+        constexpr int kB = 8;
+        for (int k0 = 0; k0 < t.n; k0 += kB) {
+            int off[kB], val[kB];
+            float sw[kB], cw[kB];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int kk = min(k0 + j, t.n - 1);
+                int k = kk;
+                if constexpr (decltype(ordered)::value) k = t.order[kk];
+                const Tap tap = t.taps[k];
+                off[j] = tap.dy * cols + tap.dx;
+                sw[j] = t.space[k];
+            }
+#pragma unroll
+            for (int j = 0; j < kB; ++j) val[j] = centre[off[j]];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) cw[j] = color_w[abs(val[j] - val0)];
+#pragma unroll
+            for (int j = 0; j < kB; ++j)
+                if (k0 + j < t.n) {
+                    const float wgt = sw[j] * cw[j];
+                    wsum += wgt;
+                    sum = fmaf((float)val[j], wgt, sum);
+                }
+        }
+    };
+    if (blk_inner && bx0 + kBx <= simd_end) {
+        batched(std::true_type{});
+    } else if (blk_inner && bx0 >= simd_end) {
+        batched(std::false_type{});
+    } else if (bx0 + kBx <= simd_end) {
         for (int kk = 0; kk < t.n; ++kk) accumulate(t.order[kk]);
     } else if (bx0 >= simd_end) {
         for (int kk = 0; kk < t.n; ++kk) accumulate(kk);

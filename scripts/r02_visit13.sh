@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round-2 visit: bilateral with eight taps in flight; parity + timing.
+set -u
+TAG=${1:-r02zo}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+echo "== parity" | tee "$OUT/log.txt"
+timeout 600 python -m pytest tests/test_filter_extra_gpu.py -m gpu -q -x -k "bilateral" 2>&1 | tail -3 | tee -a "$OUT/log.txt"
+run() { wl=$1; shift; echo "== $wl $*" | tee -a "$OUT/log.txt"; env "$@" timeout 300 python bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 2 2>&1 | grep '^{' | python -c 'import json,sys
+for l in sys.stdin:
+    j=json.loads(l); r=j["roofline"]; print("   %-50s %8.3f ms/step  frac %.3f  launch %.3f ms" % (j["config"]["workload"], j["ms_per_step"], r["frac"], r["mean_launch_ms"]))' | tee -a "$OUT/log.txt"; }
+run bilateral_1080p KH_X=0
