@@ -125,8 +125,12 @@ template <int C>
 __global__ __launch_bounds__(kBx* kBy) void pyrup_f32_block_kernel(Pyr<float> a) {
     unsigned bx_, by_, bz_;
     if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
-    const int x = bx_ * kBx + threadIdx.x, y = by_ * kBy + threadIdx.y;  // SOURCE pixel
-    if (x >= a.sw || y >= a.sh) return;
+    // a block is 64 x 4 threads: a wave = 64 consecutive source pixels of one row.  Lanes past the image stay alive (clamped to the
+    // last pixel / row) because their neighbours take values from them; they do not store.
+    const int lane = threadIdx.x;
+    const int xr = bx_ * kBx + lane, yr = by_ * kBy + threadIdx.y;
+    const bool live = xr < a.sw && yr < a.sh;
+    const int x = min(xr, a.sw - 1), y = min(yr, a.sh - 1);  // SOURCE pixel
     const float* __restrict__ src = a.src + (long long)bz_ * a.ss;
     float* __restrict__ dst = a.dst + (long long)bz_ * a.ds;
     int rt, rc, rb;
@@ -137,21 +141,42 @@ __global__ __launch_bounds__(kBx* kBy) void pyrup_f32_block_kernel(Pyr<float> a)
     const int xm = max(x - 1, 0), xp = min(x + 1, a.sw - 1);
     const long long stride = (long long)a.sw * C;
     const int rows[3] = {rt, rc, rb};
-    // The 3 x 3 x C window is loaded first and pinned (the empty asm makes every value live here): left to itself the compiler turns
-    // the edge selects below into branches and sinks each load into the branch that uses it, where it is waited for alone.
+    // Each lane loads ITS pixel of the three rows (lane-consecutive: a wave-load is 768 contiguous bytes) and takes the left / right
+    // neighbours from the adjacent lanes; only lanes 0 and 63 load a neighbour themselves.  Loading all nine pixels per lane cost
+    // ~35 L1 accesses per wave-load x 9 and the L1's access rate was 1.8 of the kernel's 2.7 ms (r02zq).  The values are pinned
+    // (empty asm) so that the edge selects below cannot pull a load into a branch.
     float win[3][3][C];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const float* row = src + rows[r] * stride;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { win[r][0][c] = row[xm * C + c]; win[r][1][c] = row[x * C + c]; win[r][2][c] = row[xp * C + c]; }
+        for (int c = 0; c < C; ++c) win[r][1][c] = row[x * C + c];
+    }
+    float edge[3][C];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < C; ++c) edge[r][c] = 0.0f;
+    if (lane == 0 || lane == kBx - 1) {
+        const int xe = lane == 0 ? xm : xp;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float* row = src + rows[r] * stride;
+#pragma unroll
+            for (int c = 0; c < C; ++c) edge[r][c] = row[xe * C + c];
+        }
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int c = 0; c < C; ++c) asm volatile("" : "+v"(win[r][t][c]));
+        for (int c = 0; c < C; ++c) {
+            asm volatile("" : "+v"(win[r][1][c]));
+            const int bits = __float_as_uint(win[r][1][c]);
+            const float left = __uint_as_float((uint32_t)__shfl(bits, max(lane - 1, 0)));
+            const float right = __uint_as_float((uint32_t)__shfl(bits, min(lane + 1, kBx - 1)));
+            win[r][0][c] = lane == 0 ? edge[r][c] : left;        // pixel xm: lane - 1 holds x - 1 (x >= 1 here)
+            win[r][2][c] = lane == kBx - 1 ? edge[r][c] : right;  // pixel xp: lane + 1 holds min(x + 1, sw - 1)
+        }
     float he[3][C], ho[3][C];  // horizontal pass at columns 2x and 2x + 1 of rows rt, rc, rb
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -183,6 +208,7 @@ __global__ __launch_bounds__(kBx* kBy) void pyrup_f32_block_kernel(Pyr<float> a)
         for (int i = 0; i < 2 * C; ++i) asm volatile("" : "+v"(out[k][i]));
     typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    if (!live) return;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         float* o = dst + ((long long)(2 * y + k) * a.dw + 2 * x) * C;
@@ -223,8 +249,8 @@ __global__ __launch_bounds__(kBx* kBy) void pyrdown_u8_kernel(Pyr<uint8_t> a) {
 // owns kPdTW x kPdTH destination pixels and
 //   1. runs the reference's horizontal pass ([1 4 6 4 1] into u16) once per (source row, destination column) of the tile's
 //      2 * kPdTH + 3 source rows, straight from global memory into LDS.  A thread takes two neighbouring destination pixels:
-//      their windows overlap (7 source pixels = ceil(7C / 4) unaligned dwords; border tiles assemble the same dwords from
-//      reflected bytes), v_perm_b32 puts tap t of both pixels into the two 16-bit lanes of a register and the weights are
+//      their windows overlap (7 source pixels = ceil(7C / 4) dwords, taken out of rows that interior tiles stage in LDS with
+//      aligned dword loads; border tiles assemble the same dwords from reflected bytes), v_perm_b32 puts tap t of both pixels into the two 16-bit lanes of a register and the weights are
 //      applied with packed 16-bit adds / shifts / multiplies (the sums are <= 4080).  LDS holds one plane per channel, a dword
 //      = the pixel pair, so the writes are conflict-free (r02zb: the first version's three 2-byte writes per pixel at a 6-byte
 //      lane stride kept the LDS busy 2.2 of 3.3 ms);
@@ -243,7 +269,14 @@ __device__ __forceinline__ u16x2_t binomial5(u16x2_t t0, u16x2_t t1, u16x2_t t2,
 
 template <int C>
 __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
-    __shared__ __attribute__((aligned(16))) uint32_t H[kPdRows][C][kPdPairs];
+    // One LDS block, used twice: first the staged source rows S[kPdRows][kPitch] (bytes), then — after every thread has taken its
+    // windows out of it — the horizontal pass H[kPdRows][C][kPdPairs] (a dword = a pixel pair's two 16-bit sums).
+    constexpr int kWin = (2 * kPdTW + 3) * C;                                // bytes of a tile row's source window
+    constexpr int kNdw = (kWin + 3 + 3) / 4 + 1;                              // dwords staged per row (any alignment, + the windows' read-ahead)
+    constexpr int kPitch = 4 * kNdw + 8;
+    constexpr int kLdsBytes = kPdRows * kPitch > kPdRows * C * kPdPairs * 4 ? kPdRows * kPitch : kPdRows * C * kPdPairs * 4;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsBytes / 4];
+    uint32_t (*H)[C][kPdPairs] = reinterpret_cast<uint32_t (*)[C][kPdPairs]>(lds);
     unsigned bx_, by_, bz_;
     if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
     const int tid = threadIdx.x;
@@ -252,20 +285,48 @@ __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
     const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz_ * a.ds;
     constexpr int ND = (7 * C + 3) / 4;                                      // dwords covering a pixel pair's 7-pixel window
-    // interior (block-uniform): every tap inside the image, and the up to three bytes a window's last dword reads past it too
-    const bool interior = sx0 >= 0 && sy0 >= 0 && sx0 + 2 * kPdTW + 3 + 3 <= a.sw && sy0 + kPdRows <= a.sh;
+    // interior (block-uniform): every tap inside the image, with a margin for the staged dwords that start up to 3 bytes before
+    // and end up to 10 bytes after a row's window
+    const bool interior = sx0 >= 4 && sy0 >= 0 && sx0 + 2 * kPdTW + 3 + (10 + C - 1) / C <= a.sw && sy0 + kPdRows <= a.sh;
     const int rows_needed = 2 * min(kPdTH, a.dh - Y0) + 3;
     const int p = tid & (kPdPairs - 1), slot = tid >> 5;                     // pixel pair, row slot (8 rows per trip)
     const bool pair_live = X0 + 2 * p < a.dw;
-    constexpr int kBatch = 5;                                                // 8 * 5 >= kPdRows: every row's loads are in flight at once
+    constexpr int kBatch = 5;                                                // 8 * 5 >= kPdRows
     uint32_t wv[kBatch][ND];
-    if (interior) {  // one basic block: all kBatch * ND loads issue back to back
+    if (interior) {
+        // Stage the rows with ALIGNED, lane-consecutive dword loads.  Loading each pair's window straight from global memory
+        // (unaligned dwords, 4 * C bytes apart across lanes) cost ~52 L1 accesses per wave-load, and the L1's access rate was the
+        // kernel's limit (r02zq: 1.7e9 TCP accesses = 2.8 of its 2.9 ms); an aligned 256-byte wave-load costs four.
+        auto row_base = [&](int r, int& mis) -> const uint32_t* {
+            const uint8_t* g = src + ((long long)(sy0 + r) * a.sw + sx0) * C;
+            mis = (int)((uintptr_t)g & 3);
+            return reinterpret_cast<const uint32_t*>(g - mis);
+        };
+        constexpr int kItems = kPdRows * kNdw, kTrips = (kItems + 255) / 256;
+        uint32_t v[kTrips];
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {   // every load unconditional, from a clamped (row, dword): all in flight together
+            const int i = min(tid + 256 * k, kItems - 1), r = min(i / kNdw, rows_needed - 1), d = i - (i / kNdw) * kNdw;
+            int mis;
+            v[k] = row_base(r, mis)[d];
+        }
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {
+            const int i = tid + 256 * k;
+            if (i < kItems) lds[(i / kNdw) * (kPitch / 4) + (i - (i / kNdw) * kNdw)] = v[k];
+        }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
             const int r = min(slot + 8 * k, rows_needed - 1);
-            const uint8_t* q = src + ((long long)(sy0 + r) * a.sw + sx0 + 4 * p) * C;
+            int mis;
+            row_base(r, mis);
+            const uint32_t* q = lds + r * (kPitch / 4) + p * C;              // the pair's window starts mis bytes into this dword
+            uint32_t raw[ND + 1];
 #pragma unroll
-            for (int j = 0; j < ND; ++j) wv[k][j] = *reinterpret_cast<const u32_unaligned*>(q + 4 * j);
+            for (int j = 0; j <= ND; ++j) raw[j] = q[j];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) wv[k][j] = __builtin_amdgcn_alignbyte(raw[j + 1], raw[j], (uint32_t)mis);
         }
     } else {
         // every tap's address is valid after reflection, so these byte loads are unconditional too (dead pairs read pixel 0)
@@ -287,21 +348,27 @@ __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
             for (int n = 0; n < 7 * C; ++n) wv[k][n >> 2] |= bytes[n] << (8 * (n & 3));
         }
     }
+    uint32_t hv[kBatch][C];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            u16x2_t t[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {  // lanes: tap j of the pair's first pixel, tap j of its second (two source pixels on)
+                constexpr uint32_t kZero = 0x0c000c00u;
+                const int n1 = j * C + c, n2 = (j + 2) * C + c;
+                t[j] = as_u16x2(__builtin_amdgcn_perm(wv[k][n2 >> 2], wv[k][n1 >> 2], kZero | (uint32_t)(n1 & 3) | ((uint32_t)(4 + (n2 & 3)) << 16)));
+            }
+            hv[k][c] = as_u32(binomial5(t[0], t[1], t[2], t[3], t[4]));  // <= 4080: the reference's u16 intermediate
+        }
+    __syncthreads();   // the staged rows have been consumed: H takes their place
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
         const int r = slot + 8 * k;
         if (r < rows_needed && pair_live) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                u16x2_t t[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {  // lanes: tap j of the pair's first pixel, tap j of its second (two source pixels on)
-                    constexpr uint32_t kZero = 0x0c000c00u;
-                    const int n1 = j * C + c, n2 = (j + 2) * C + c;
-                    t[j] = as_u16x2(__builtin_amdgcn_perm(wv[k][n2 >> 2], wv[k][n1 >> 2], kZero | (uint32_t)(n1 & 3) | ((uint32_t)(4 + (n2 & 3)) << 16)));
-                }
-                H[r][c][p] = as_u32(binomial5(t[0], t[1], t[2], t[3], t[4]));  // <= 4080: the reference's u16 intermediate
-            }
+            for (int c = 0; c < C; ++c) H[r][c][p] = hv[k][c];
         }
     }
     __syncthreads();
