@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Static per-kernel resource table (VGPRs, scratch, LDS, occupancy) for every gfx950 kernel in csrc/ — no GPU
-needed.  Catches register spills and private arrays the compiler moved to scratch / LDS before they cost a GPU run.
+needed.  Catches register spills, private arrays the compiler moved to scratch / LDS, and FLAT memory instructions (an LDS
+pointer that lost its address space, e.g. through a uintptr_t round trip, is read with flat_load instead of ds_read: measured
+1.9 vs 1.5 ms on the separable u8 resize) before they cost a GPU run.  tests/test_kernel_lint.py asserts the three zeros.
 
     python scripts/kernel_resources.py > profiles/<round>_static_kernel_resources.txt
 """
@@ -23,12 +25,28 @@ FIELDS = [("vgpr", r" VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("sgpr", r"Tota
 
 
 def main():
-    rows = []
+    rows, flat = [], {}
     with tempfile.TemporaryDirectory() as tmp:
         procs = []
         for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
             out = os.path.join(tmp, os.path.basename(src) + ".co")
             procs.append((src, subprocess.Popen(["/opt/rocm/bin/hipcc", *FLAGS, src, "-o", out], stderr=subprocess.PIPE, text=True)))
+        asm = []
+        for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
+            out = os.path.join(tmp, os.path.basename(src) + ".s")
+            asm.append((src, out, subprocess.Popen(["/opt/rocm/bin/hipcc", *[f for f in FLAGS if not f.startswith("-Rpass") and f != "-c"], "-S", src, "-o", out],
+                                                   stderr=subprocess.PIPE, text=True)))
+        for src, out, p in asm:
+            _, err = p.communicate()
+            if p.returncode:
+                sys.exit(err)
+            label = None
+            for line in open(out):
+                m = re.match(r"^(_Z\w+):", line)
+                if m:
+                    label = m.group(1)
+                elif label and re.match(r"\s+flat_(load|store|atomic)", line):
+                    flat[label] = flat.get(label, 0) + 1
         for src, p in procs:
             _, err = p.communicate()
             if p.returncode:
@@ -47,6 +65,7 @@ def main():
     dem = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
     print(f"# {len(rows)} kernels, gfx950, flags: {' '.join(FLAGS[:9])}")
     print(f"# kernels with scratch: {sum(1 for r in rows if r.get('scratch', 0))}, with VGPR spills: {sum(1 for r in rows if r.get('spill', 0))}")
+    print(f"# kernels with flat memory instructions: {len(flat)}" + "".join(f"\n#   {k}: {v}" for k, v in sorted(flat.items())))
     print(f"{'file':22s} {'vgpr':>4s} {'sgpr':>4s} {'scr':>4s} {'lds':>5s} {'occ':>3s}  kernel")
     for r, d in sorted(zip(rows, dem), key=lambda t: (t[0]["file"], t[1])):
         d = d.replace("(anonymous namespace)::", "")
