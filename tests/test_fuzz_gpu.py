@@ -122,6 +122,31 @@ def test_fuzz_pyramid_morphology_pointwise(gpu_stream, seed):
         assert (lo, hi) == (float(f.min()), float(f.max()))
 
 
+@pytest.mark.parametrize("seed", range(4 + EXTRA))
+def test_fuzz_tiled_kernels_large_shapes(gpu_stream, seed):
+    """The LDS-tile kernels (morphology, pyrdown_u8, separable u8 resize) and the pyrup kernels only reach their interior / staged
+    paths on images a few hundred pixels wide: random shapes in that range, every channel count, against the restatement."""
+    from kornia_rs import imgproc
+    rng = np.random.default_rng(9000 + seed)
+    for _ in range(3):
+        h, w, c = int(rng.integers(34, 150)), int(rng.integers(130, 700)), int(rng.choice([1, 3, 4]))
+        u, f = _u8(rng, h, w, c), _f32(rng, h, w, c)
+        ud, fd = _up(u, gpu_stream), _up(f, gpu_stream)
+        assert np.array_equal(imgproc.pyrdown(ud).numpy(), O.pyrdown(u)) and np.array_equal(imgproc.pyrdown(fd).numpy(), O.pyrdown(f)), ("pyrdown", w, h, c)
+        assert np.array_equal(imgproc.pyrup(ud).numpy(), O.pyrup(u)) and np.array_equal(imgproc.pyrup(fd).numpy(), O.pyrup(f)), ("pyrup", w, h, c)
+        shape = str(rng.choice(["box", "box", "cross", "ellipse"]))
+        k = int(rng.choice([3, 5, 7, 2, 4, 9]))
+        kh_, kw_ = (k, k) if shape != "ellipse" else (int(rng.integers(1, 10)), int(rng.integers(1, 10)))
+        border = str(rng.choice(["constant", "replicate", "reflect101", "reflect", "wrap"]))
+        for op, fn in (("dilate", imgproc.dilate), ("erode", imgproc.erode)):
+            got = fn(ud, shape, size=(kh_, kw_), border=border, constant_value=9).numpy()
+            assert np.array_equal(got, O.morphology_u8(u, op, O.morph_kernel(shape, kw_, kh_), border, [9] * c)), (op, w, h, c, shape, kh_, kw_, border)
+        dw, dh = int(rng.integers(20, 400)), int(rng.integers(10, 120))
+        mode, aa = str(rng.choice(["bicubic", "lanczos"])), bool(rng.integers(0, 2))
+        want = O.resize_fast_u8(u, dw, dh, mode, aa)[0]
+        assert np.array_equal(imgproc.resize_fast(ud, (dh, dw), mode, aa).numpy(), want), ("resize_fast", w, h, dw, dh, c, mode, aa)
+
+
 @pytest.mark.parametrize("seed", range(6 + EXTRA))
 def test_fuzz_fused_preprocess(gpu_stream, seed):
     """The north-star family: every source format x resize mode x sampler x f32 / f16 at random (even where 4:2:x needs it)
