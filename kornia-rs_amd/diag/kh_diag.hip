@@ -1,0 +1,54 @@
+// libkornia_hip_diag.so — MEASUREMENT ceilings for bench.py, not part of the product ABI (nothing in kornia_rs/ loads it).
+//
+// Round-2 VERDICT item 1c: the bench line carried a hipMemcpyDtoD rate (4.9 TB/s) as "the practical ceiling" although the headline
+// kernel runs above it.  The ceilings that bound the NV12 -> CHW kernel are (profiles/r02*_ubench_nv12.txt):
+//   khd_flat_fill          a flat 16 B / lane fill of the output bytes with the production store policy (write-through,
+//                          non-temporal buffer stores): the best this part does for a pure write stream;
+//   khd_three_plane_store  the production kernel's STORE SHAPE — 512-thread blocks, a thread stores 16 B into each of the three
+//                          f32 planes of its frame, back to back — with no loads and no decode.
+// bench.py times both in the same process, on the same buffers, with the same HIP events, so "fraction of the achievable" is
+// driver-timed instead of quoted from an earlier box.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAux = 19;  // sc0 sc1 nt: the production policy (kh_common.h::kAuxStream)
+
+namespace {
+
+__global__ __launch_bounds__(256) void flat_fill_kernel(float* __restrict__ db, long long n4) {
+    const long long i = (long long)blockIdx.y * gridDim.x * 256 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const long long base = i & ~((1ll << 26) - 1);  // one V# per 1 GiB window (32-bit buffer offsets)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(db + 4 * base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{1u, 2u, 3u, 4u}, rs, (int)(16 * (i - base)), 0, kAux);
+}
+
+__global__ __launch_bounds__(512) void three_plane_store_kernel(float* __restrict__ db, int w, int h, long long dfs) {
+    const int groups = (w >> 2) * h, g = blockIdx.x * 512 + threadIdx.x, plane = w * h;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(db + (long long)blockIdx.y * dfs, 0, 12 * plane, 0x00020000);
+    const int off = g < groups ? 16 * g : 0x7fffffff - 8 * plane;  // out-of-range lanes are dropped by the range check
+#pragma unroll
+    for (int c = 0; c < 3; ++c) __builtin_amdgcn_raw_buffer_store_b128(u32x4{1u, 2u, 3u, (unsigned)c}, rs, off + c * plane * 4, 0, kAux);
+}
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) int khd_flat_fill(void* stream, float* dst, long long nbytes) {
+    const long long n4 = nbytes / 16;
+    if (n4 <= 0) return 0;
+    const unsigned gy = (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256));
+    hipLaunchKernelGGL(flat_fill_kernel, dim3(65536, gy), dim3(256), 0, (hipStream_t)stream, dst, n4);
+    return (int)hipGetLastError();
+}
+
+__attribute__((visibility("default"))) int khd_three_plane_store(void* stream, float* dst, int w, int h, int nframes, long long dst_frame_stride) {
+    if (nframes <= 0 || w <= 0 || h <= 0 || (w & 3) || (long long)w * h * 12 > 0x7fffffffLL || nframes > 65535) return -1;
+    const int groups = (w >> 2) * h;
+    hipLaunchKernelGGL(three_plane_store_kernel, dim3((groups + 511) / 512, nframes), dim3(512), 0, (hipStream_t)stream, dst, w, h, dst_frame_stride);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

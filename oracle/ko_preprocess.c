@@ -27,11 +27,16 @@ int ko_max_threads(void) {
 #endif
 }
 
+/* n > 0 pins the team size; n <= 0 restores the default team (every processor OpenMP sees, i.e. what
+ * Rayon's global pool would use, P/parallel.rs:10).  Restoring matters: omp_set_num_threads is sticky,
+ * so "set(1) … set(0)" without it left every later baseline on one thread (round-2 VERDICT). */
 void ko_set_threads(int n) {
-    g_threads = n;
 #ifdef _OPENMP
-    if (n > 0) omp_set_num_threads(n);
+    static int g_default = 0; /* the team size before anyone pinned it (honours OMP_NUM_THREADS) */
+    if (g_default == 0) g_default = g_threads > 0 ? omp_get_num_procs() : omp_get_max_threads();
+    omp_set_num_threads(n > 0 ? n : g_default);
 #endif
+    g_threads = n > 0 ? n : 0;
 }
 
 /* P/cuda/color/mod.rs:303-317 */
