@@ -107,9 +107,14 @@ KH_API int32_t kh_graph_destroy(kh_graph_t graph);
  * allocate per call (P/filter/cuda.rs:119).  Here an operator uses the workspace registered for its stream when it is large
  * enough — then it allocates nothing and may be captured — and the stream-ordered pool otherwise (refused under capture,
  * with the byte count in the message).  One workspace serves ONE host thread's calls on that stream.  kh_last_workspace_bytes:
- * scratch the last compute call on this thread asked for (0 = none) — run once eagerly, read it, register, capture.            */
+ * scratch the last compute call on this thread asked for (0 = none) — run once eagerly, read it, register, capture.
+ * Registrations are filed under (current device, stream): handle 0 is the default stream of every device, so select the stream's
+ * device before registering, as before any launch; a buffer that lives on another device is KH_ERR_INVALID_ARG.  kh_stream_destroy
+ * drops the stream's registration; the caller must unregister (pointer and size 0) before freeing a registered buffer.
+ * kh_stream_workspace_bytes: the size registered for `stream` on the current device (0 = none).                                   */
 KH_API int32_t kh_stream_set_workspace(kh_stream_t stream, void* device_ptr, size_t bytes);
 KH_API int32_t kh_last_workspace_bytes(size_t* bytes);
+KH_API int32_t kh_stream_workspace_bytes(kh_stream_t stream, size_t* bytes);
 
 KH_API int32_t kh_event_create(kh_event_t* out, int32_t enable_timing);
 KH_API int32_t kh_event_destroy(kh_event_t event);

@@ -9,7 +9,9 @@
 #include <string.h>
 
 #include <atomic>
+#include <iterator>
 #include <map>
+#include <utility>
 #include <mutex>
 #include <set>
 #include <string>
@@ -41,10 +43,19 @@ int32_t fail_hip(hipError_t e, const char* what) {
 }
 
 namespace {
+// Workspaces are keyed by (device, stream handle): handle 0 is the default stream of EVERY device, so the handle alone would hand a
+// buffer registered for device 0 to work launched on device 1's default stream (round-2 ADVICE).  Entries are erased when their
+// stream is destroyed (a later stream may reuse the handle value) and when the owner unregisters.
 struct Workspace { void* ptr; size_t bytes; };
+using WsKey = std::pair<int, kh_stream_t>;
 std::mutex g_ws_mu;
-std::map<kh_stream_t, Workspace>& workspaces() { static auto& m = *new std::map<kh_stream_t, Workspace>(); return m; }
+std::map<WsKey, Workspace>& workspaces() { static auto& m = *new std::map<WsKey, Workspace>(); return m; }
 thread_local size_t g_last_scratch = 0;
+int current_device_or_zero() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    return d;
+}
 }  // namespace
 
 Scratch::~Scratch() {
@@ -57,7 +68,7 @@ int32_t get_scratch(kh_stream_t stream, size_t bytes, const char* what, Scratch&
     if (bytes == 0) return KH_OK;
     {
         std::lock_guard<std::mutex> lock(g_ws_mu);
-        auto it = workspaces().find(stream);
+        auto it = workspaces().find(WsKey{current_device_or_zero(), stream});  // launches go to the current device
         if (it != workspaces().end() && it->second.bytes >= bytes) {
             out.ptr = it->second.ptr;  // caller-owned: nothing to allocate, nothing to free
             return KH_OK;
@@ -172,6 +183,11 @@ int32_t kh_stream_create(kh_stream_t* out) {
 
 int32_t kh_stream_destroy(kh_stream_t stream) {
     KH_REQUIRE(stream, KH_ERR_INVALID_ARG, "kh_stream_destroy: the default stream is not owned");
+    {   // a workspace registered for this stream dies with it: the handle value may be reused by a later stream
+        std::lock_guard<std::mutex> lock(g_ws_mu);
+        auto& m = workspaces();
+        for (auto it = m.begin(); it != m.end();) it = it->first.second == stream ? m.erase(it) : std::next(it);
+    }
     KH_HIP(hipStreamDestroy(as_hip(stream)));
     return KH_OK;
 }
@@ -342,9 +358,29 @@ int32_t kh_mempool_set_release_threshold(int32_t device, uint64_t bytes) {
 
 int32_t kh_stream_set_workspace(kh_stream_t stream, void* device_ptr, size_t bytes) {
     KH_REQUIRE((device_ptr != nullptr) == (bytes != 0), KH_ERR_INVALID_ARG, "kh_stream_set_workspace: pointer and size must both be set, or both zero to unregister");
+    // The entry belongs to the CURRENT device (the one `stream` was created on; hosts select it before the call, as for every
+    // launch).  A buffer that lives on another device is refused instead of being handed to kernels that cannot reach it.
+    const int dev = current_device_or_zero();
+    if (device_ptr) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, device_ptr) == hipSuccess) {
+            KH_REQUIRE(at.type != hipMemoryTypeDevice || at.device == dev, KH_ERR_INVALID_ARG,
+                       "kh_stream_set_workspace: the buffer lives on device %d but the current device is %d", at.device, dev);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     std::lock_guard<std::mutex> lock(g_ws_mu);
-    if (!device_ptr) workspaces().erase(stream);
-    else workspaces()[stream] = Workspace{device_ptr, bytes};
+    if (!device_ptr) workspaces().erase(WsKey{dev, stream});
+    else workspaces()[WsKey{dev, stream}] = Workspace{device_ptr, bytes};
+    return KH_OK;
+}
+
+int32_t kh_stream_workspace_bytes(kh_stream_t stream, size_t* bytes) {
+    KH_REQUIRE(bytes, KH_ERR_INVALID_ARG, "kh_stream_workspace_bytes: null out pointer");
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    auto it = workspaces().find(WsKey{current_device_or_zero(), stream});
+    *bytes = it == workspaces().end() ? 0 : it->second.bytes;
     return KH_OK;
 }
 

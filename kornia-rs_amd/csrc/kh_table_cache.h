@@ -14,10 +14,12 @@
 //     which is illegal under capture: warm the operator up once before capturing.
 #pragma once
 
+#include <atomic>
 #include <list>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <vector>
 
 #include "kh_common.h"
 
@@ -27,25 +29,41 @@ struct DevTable {
     void* dev = nullptr;
     size_t bytes = 0;
     int meta[6] = {0, 0, 0, 0, 0, 0};   // small per-table facts (tap count, radius ...)
-    hipEvent_t last_use = nullptr;
-    bool pinned = false;          // referenced by a captured graph: never evicted
+    std::atomic<bool> pinned{false};  // referenced by a captured graph: never evicted (read by the evictor, written by users)
     int device = 0;
     DevTable() = default;
     DevTable(const DevTable&) = delete;
     DevTable& operator=(const DevTable&) = delete;
     ~DevTable() {
-        if (last_use) { (void)hipEventSynchronize(last_use); (void)hipEventDestroy(last_use); }
+        // host-wait for the last launch of EVERY stream that used the table, then free it
+        for (auto& kv : last_use_) { (void)hipEventSynchronize(kv.second); (void)hipEventDestroy(kv.second); }
         if (dev) (void)hipFree(dev);
     }
-    // Call after the launch that reads the table has been enqueued on `stream`.
+    // Call after the launch that reads the table has been enqueued on `stream`.  One event PER STREAM: two streams (or threads)
+    // leasing the same table each leave their own fence — a single re-recorded event covered only the latest user.
     void used_on(hipStream_t stream) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-            pinned = true;  // the graph holds the pointer; an event cannot be recorded into a capture for a later host wait
+            pinned.store(true);  // the graph holds the pointer; an event cannot be recorded into a capture for a later host wait
             return;
         }
-        if (last_use) (void)hipEventRecord(last_use, stream);
+        std::lock_guard<std::mutex> lock(use_mu_);
+        auto it = last_use_.find(stream);
+        if (it == last_use_.end()) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {  // no fence possible: make the user wait now
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(stream);
+                return;
+            }
+            it = last_use_.emplace(stream, ev).first;
+        }
+        (void)hipEventRecord(it->second, stream);
     }
+
+private:
+    std::mutex use_mu_;
+    std::map<hipStream_t, hipEvent_t> last_use_;
 };
 using TableLease = std::shared_ptr<DevTable>;
 
@@ -57,6 +75,7 @@ public:
     // `build(table)` fills dev / bytes / meta with a blocking upload into a fresh allocation (sync-before-publish).
     template <typename Build>
     int32_t lookup(const Key& key, hipStream_t stream, const char* what, Build&& build, TableLease& out) {
+        std::vector<TableLease> doomed;  // evicted tables die AFTER the lock is released: their destructor host-waits and hipFrees
         std::lock_guard<std::mutex> lock(mu_);
         auto it = map_.find(key);
         if (it != map_.end()) {
@@ -69,12 +88,10 @@ public:
             return fail(KH_ERR_INVALID_ARG, "%s: the lookup table for this geometry is not on the device yet and cannot be built while the "
                                             "stream is being captured (it needs an allocation and a blocking copy) — run the operator once "
                                             "with these parameters before kh_graph_capture_begin", what);
-        evict_locked();
+        evict_locked(doomed);
         auto tab = std::make_shared<DevTable>();
         (void)hipGetDevice(&tab->device);
         if (int32_t rc = build(*tab)) return rc;
-        hipError_t e = hipEventCreateWithFlags(&tab->last_use, hipEventDisableTiming);
-        if (e != hipSuccess) return fail_hip(e, "hipEventCreate (table cache)");
         lru_.push_front(key);
         map_.emplace(key, Slot{tab, lru_.begin()});
         out = tab;
@@ -87,14 +104,16 @@ public:
 
 private:
     struct Slot { TableLease tab; typename std::list<Key>::iterator pos; };
-    // Drop least-recently-used entries nobody else holds until there is room.  The DevTable destructor (run here, since
-    // the cache held the last reference) host-waits for the last launch that used the table before freeing it.
-    void evict_locked() {
+    // Drop least-recently-used entries nobody else holds until there is room.  The evicted tables are handed to the caller, which
+    // lets go of them outside the cache mutex: the DevTable destructor host-waits for the last launch of every stream that used
+    // the table and calls hipFree (a device-wide sync) — neither may stall other threads' lookups.
+    void evict_locked(std::vector<TableLease>& doomed) {
         if (map_.size() < max_) return;
         for (auto pos = lru_.end(); pos != lru_.begin() && map_.size() >= max_;) {
             --pos;
             auto it = map_.find(*pos);
-            if (it->second.tab.use_count() == 1 && !it->second.tab->pinned) {
+            if (it->second.tab.use_count() == 1 && !it->second.tab->pinned.load()) {
+                doomed.push_back(std::move(it->second.tab));
                 map_.erase(it);
                 pos = lru_.erase(pos);
             }

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
@@ -100,6 +101,7 @@ SIGNATURES = {
     "kh_stream_wait_event": (_i32, [_vp, _vp]),
     "kh_stream_set_workspace": (_i32, [_vp, _vp, _sz]),
     "kh_last_workspace_bytes": (_i32, [_P(_sz)]),
+    "kh_stream_workspace_bytes": (_i32, [_vp, _P(_sz)]),
     "kh_event_create": (_i32, [_P(_vp), _i32]),
     "kh_event_destroy": (_i32, [_vp]),
     "kh_event_record": (_i32, [_vp, _vp]),
@@ -216,6 +218,9 @@ def mapped_hip_runtimes() -> dict:
     return {k: sorted(v) for k, v in found.items()}
 
 
+_RUNTIME_CHECKED_AT = -1  # len(sys.modules) at the last check that found a single runtime
+
+
 class MultipleHipRuntimes(RuntimeError):
     """Two HIP (or HSA) runtime images are mapped into the process; device work through either is unsafe."""
 
@@ -224,13 +229,66 @@ def assert_single_runtime() -> None:
     """Raise if the process holds more than one HIP or HSA runtime image.  Called wherever device memory crosses to
     or from another library (DLPack / ``__cuda_array_interface__`` import and export): that is the only way a second
     runtime can enter a process that loaded this package first with ``KORNIA_HIP_RUNTIME=system``."""
+    # /proc/self/maps has thousands of lines once torch is loaded and this sits on the per-frame zero-copy path: re-parse only
+    # when the set of loaded Python modules could have brought in a new native library (a second runtime can only arrive with
+    # an import), i.e. when sys.modules has grown since the last clean check (ADVICE r02).
+    global _RUNTIME_CHECKED_AT
+    n_mod = len(sys.modules)
+    if _RUNTIME_CHECKED_AT == n_mod:
+        return
     rt = mapped_hip_runtimes()
     dup = {k: v for k, v in rt.items() if len(v) > 1}
+    if not dup:
+        _RUNTIME_CHECKED_AT = n_mod
     if dup:
         raise MultipleHipRuntimes(
             f"two HIP/HSA runtimes are mapped into this process: {dup}.  Copies and stream waits issued through one do not "
             "order against the other (observed: host<->device copies incomplete at hipStreamSynchronize).  Import torch "
             "before kornia_rs, or leave KORNIA_HIP_RUNTIME unset so that kornia_rs binds to torch's bundled runtime.")
+
+
+def elf_dynamic_names(path) -> dict:
+    """{"soname": str | None, "needed": [str]} of an ELF64 little-endian shared object, read from its dynamic section
+    (no subprocess, nothing is loaded).  Used to check that a runtime image about to be preloaded is the one
+    ``libkornia_hip.so`` asks for by DT_NEEDED name."""
+    import struct
+    out = {"soname": None, "needed": []}
+    try:
+        data = Path(path).read_bytes()
+        if data[:6] != b"\x7fELF\x02\x01":
+            return out
+        e_phoff, = struct.unpack_from("<Q", data, 0x20)
+        e_phentsize, e_phnum = struct.unpack_from("<HH", data, 0x36)
+        loads, dyn = [], None
+        for i in range(e_phnum):
+            p_type, _flags, p_offset, p_vaddr, _paddr, p_filesz = struct.unpack_from("<IIQQQQ", data, e_phoff + i * e_phentsize)
+            if p_type == 1:
+                loads.append((p_vaddr, p_offset, p_filesz))
+            elif p_type == 2:
+                dyn = (p_offset, p_filesz)
+        if dyn is None:
+            return out
+        tags = [struct.unpack_from("<qQ", data, dyn[0] + k) for k in range(0, dyn[1], 16)]
+        strtab = next((v for t, v in tags if t == 5), None)
+        if strtab is None:
+            return out
+        off = next((strtab - va + fo for va, fo, sz in loads if va <= strtab < va + sz), None)
+        if off is None:
+            return out
+
+        def name(idx):
+            end = data.index(b"\0", off + idx)
+            return data[off + idx:end].decode("utf-8", "replace")
+        for t, v in tags:
+            if t == 0:
+                break
+            if t == 1:
+                out["needed"].append(name(v))
+            elif t == 14:
+                out["soname"] = name(v)
+    except (OSError, ValueError, IndexError, struct.error):
+        pass
+    return out
 
 
 def _preload_hip_runtime() -> str:
@@ -263,6 +321,13 @@ def _preload_hip_runtime() -> str:
     if spec is not None and spec.origin:
         cand = Path(spec.origin).resolve().parent / "lib" / "libamdhip64.so"
         if cand.exists():
+            # Only a bundle whose SONAME is the name libkornia_hip.so asks for can serve both libraries as ONE image: with a
+            # different SONAME (another ROCm major) the dynamic linker would still load the system runtime for DT_NEEDED and
+            # the preload itself would create the two-runtime process this function exists to prevent (round-2 ADVICE).
+            want = [n for n in elf_dynamic_names(LIB_PATH)["needed"] if n.startswith("libamdhip64")]
+            have = elf_dynamic_names(cand)["soname"]
+            if want and have != want[0]:
+                return f"system (torch bundle {cand} is {have!r}, libkornia_hip.so needs {want[0]!r})"
             try:
                 C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
                 return f"torch bundle: {cand}"
@@ -284,6 +349,18 @@ def _load() -> C.CDLL:
         )
     RUNTIME_CHOICE = _preload_hip_runtime()
     lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    # Whatever was chosen, the process must hold ONE HIP and ONE HSA runtime now.  Checked here, at load, and not only when
+    # device memory crosses a DLPack boundary: a torch-free process can end up with two images through the preload alone.
+    dup = {k: v for k, v in mapped_hip_runtimes().items() if len(v) > 1}
+    if dup:
+        msg = (f"libkornia_hip.so was loaded into a process that now maps two HIP/HSA runtime images: {dup} (choice: {RUNTIME_CHOICE}).  "
+               "Copies and stream waits issued through one do not order against the other.  Set KORNIA_HIP_RUNTIME=system or to the "
+               "path of the one runtime every HIP user of this process should share; KORNIA_HIP_RUNTIME_CHECK=warn downgrades this to a warning.")
+        if os.environ.get("KORNIA_HIP_RUNTIME_CHECK", "raise") == "warn":
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
+        else:
+            raise MultipleHipRuntimes(msg)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res

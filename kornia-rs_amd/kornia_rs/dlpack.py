@@ -173,8 +173,9 @@ def from_object(obj: Any, stream_ptr: Optional[int] = None):
     """Call ``obj.__dlpack__`` the way the array-API protocol prescribes and import the capsule."""
     if hasattr(obj, "__dlpack_device__"):
         dev_type, _ = obj.__dlpack_device__()
-        if dev_type in _DEVICE_TYPES:
-            # ROCm convention: stream 0 = the default stream; we pass our consumer stream handle.
+        if dev_type in _DEVICE_TYPES or dev_type == kDLCUDAManaged:
+            # Managed memory is written by kernels too: its producer needs the consumer stream for the hand-off fence just like a
+            # device producer (ADVICE r02).  ROCm convention: stream 0 = the default stream; we pass our consumer stream handle.
             capsule = obj.__dlpack__(stream=stream_ptr if stream_ptr else None)
         else:
             capsule = obj.__dlpack__()

@@ -114,12 +114,25 @@ class Stream:
     def set_workspace(self, buf: Optional["DeviceBuffer"]) -> None:
         """Register ``buf`` as the scratch the operators with an intermediate (separable u8 resize, wide u8 blurs, u8 warps,
         Lanczos resize) use on this stream instead of allocating — what makes them capturable (``kh_stream_set_workspace``).
-        ``None`` unregisters.  The stream keeps the buffer alive."""
-        if buf is None:
-            check(lib.kh_stream_set_workspace(self._handle, None, 0))
-        else:
-            check(lib.kh_stream_set_workspace(self._handle, buf.ptr, buf.nbytes))
-        self._workspace = buf
+        ``None`` unregisters.  The registration — not this wrapper object — keeps the buffer alive: it lives in a module-level
+        table keyed by (device, handle), like the C registry, so ``Stream.default(0).set_workspace(buf)`` on a temporary wrapper
+        does not free ``buf`` behind the library's back; ``buf.free()`` and destroying an owned stream unregister first."""
+        key = (self.device, self._handle)
+        prev = current_device()
+        set_device(self.device)  # the C registry files the entry under the current device
+        try:
+            if buf is None:
+                check(lib.kh_stream_set_workspace(self._handle, None, 0))
+            else:
+                check(lib.kh_stream_set_workspace(self._handle, buf.ptr, buf.nbytes))
+        finally:
+            set_device(prev)
+        old = _WORKSPACES.pop(key, None)
+        if old is not None:
+            old._ws_keys.discard(key)
+        if buf is not None:
+            _WORKSPACES[key] = buf
+            buf._ws_keys.add(key)
 
     @property
     def cuda_stream_ptr(self) -> int:
@@ -133,6 +146,9 @@ class Stream:
     def __del__(self):
         if getattr(self, "_owned", False) and self._handle:
             try:
+                old = _WORKSPACES.pop((self.device, self._handle), None)  # kh_stream_destroy erases the C entry
+                if old is not None:
+                    old._ws_keys.discard((self.device, self._handle))
                 lib.kh_stream_destroy(self._handle)
             except Exception:
                 pass
@@ -140,6 +156,10 @@ class Stream:
 
     def __repr__(self) -> str:
         return f"Stream(device={self.device}, handle=0x{self._handle:x})"
+
+
+# (device, stream handle) -> the DeviceBuffer registered as that stream's workspace (the keepalive of Stream.set_workspace)
+_WORKSPACES: dict = {}
 
 
 class Event:
@@ -293,6 +313,7 @@ class DeviceBuffer:
     def __init__(self, nbytes: int, stream: Optional[Stream] = None, zeroed: bool = True):
         self.stream = stream if stream is not None else Stream.default(current_device())
         self.nbytes = int(nbytes)
+        self._ws_keys: set = set()  # (device, handle) registrations of this buffer as a stream workspace
         p = C.c_void_p(0)
         prev = current_device()
         set_device(self.stream.device)
@@ -330,6 +351,15 @@ class DeviceBuffer:
 
     def free(self) -> None:
         if self.ptr:
+            for dev, handle in list(getattr(self, "_ws_keys", ())):  # never leave the library pointing at freed memory
+                prev = current_device()
+                try:
+                    set_device(dev)
+                    lib.kh_stream_set_workspace(handle, None, 0)
+                finally:
+                    set_device(prev)
+                _WORKSPACES.pop((dev, handle), None)
+            self._ws_keys = set()
             lib.kh_free_async(self.ptr, self.stream.cuda_stream_ptr)
             self.ptr = 0
 

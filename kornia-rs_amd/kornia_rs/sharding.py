@@ -199,6 +199,12 @@ class ShardedPreprocessor:
                 raise PreprocessError("BatchMismatch", f"shard {g}: destination batch dim {t.shape[0] if len(t.shape) == 4 else t.shape} "
                                                        f"!= frame count {counts[g]}", dst_n=t.shape[0] if t.shape else 0, frames=counts[g])
 
+        for g, t in enumerate(dsts):  # a shard that has frames needs somewhere to put them (typed, not an AttributeError in a worker)
+            if t is None and counts[g] > 0:
+                from .preprocess import PreprocessError
+                raise PreprocessError("BatchMismatch", f"shard {g}: out[{g}] is None but the shard holds {counts[g]} frames",
+                                      dst_n=0, frames=counts[g])
+
         def run(g: int):
             buf, k = parts[g]
             if k == 0:
@@ -220,10 +226,17 @@ class ShardedPreprocessor:
         spans: List[Tuple[float, float]] = [(0.0, 0.0)] * self.world
 
         def body(g: int):
-            for _ in range(warmup):
-                step(g)
-            self.streams[g].synchronize()
-            barrier.wait()
+            try:
+                for _ in range(warmup):
+                    step(g)
+                self.streams[g].synchronize()
+            except BaseException:
+                barrier.abort()  # a shard that failed in warm-up must not leave the others waiting for it forever
+                raise
+            try:
+                barrier.wait(timeout=600.0)
+            except threading.BrokenBarrierError:
+                raise RuntimeError(f"shard {g}: another shard failed (or hung for 10 min) before the timed region; see its error") from None
             t0 = time.perf_counter()
             for _ in range(steps):
                 step(g)

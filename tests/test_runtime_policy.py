@@ -102,3 +102,64 @@ def test_sharder_rejects_bad_device_lists_without_a_device():
         assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [hi - lo for lo, hi in spans]
         assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_elf_names_of_the_library_and_the_bundle():
+    sys.path.insert(0, str(ROOT / "kornia-rs_amd"))
+    from kornia_rs import _ffi
+    names = _ffi.elf_dynamic_names(_ffi.LIB_PATH)
+    assert any(n.startswith("libamdhip64.so") for n in names["needed"])
+    assert _ffi.elf_dynamic_names(__file__) == {"soname": None, "needed": []}  # not an ELF: empty, no exception
+
+
+LOAD_CHILD = r'''
+import sys, os, ctypes
+sys.path.insert(0, %r)
+mode = os.environ["KH_TEST_MODE"]
+if mode == "two_runtimes":           # a second HIP runtime image is already in the process when the package loads
+    import importlib.util, pathlib
+    ctypes.CDLL("/opt/rocm/lib/libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+    cand = pathlib.Path(importlib.util.find_spec("torch").origin).resolve().parent / "lib" / "libamdhip64.so"
+    ctypes.CDLL(str(cand), mode=ctypes.RTLD_GLOBAL)
+try:
+    if mode == "soname_mismatch":    # the bundle claims another ROCm major: it must not be preloaded
+        import importlib.util, types
+        origin = os.path.join(sys.path[0], "kornia_rs", "_ffi.py")   # by path: importing the package would load the library
+        src = open(origin).read().replace('have = elf_dynamic_names(cand)["soname"]', 'have = "libamdhip64.so.6"')
+        mod = types.ModuleType("kornia_rs._ffi"); mod.__file__ = origin
+        exec(compile(src, origin, "exec"), mod.__dict__)
+        print("CHOICE", mod.RUNTIME_CHOICE); print("MAPPED", len(mod.mapped_hip_runtimes()["libamdhip64"]))
+    else:
+        from kornia_rs import _ffi
+        print("LOADED", _ffi.RUNTIME_CHOICE)
+except Exception as e:
+    print("RAISED", type(e).__name__, str(e)[:200])
+'''
+
+
+def _load_child(mode, extra=None):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("KORNIA_HIP_RUNTIME")}
+    env.update({"KH_TEST_MODE": mode, **(extra or {})})
+    r = subprocess.run([sys.executable, "-c", LOAD_CHILD % str(ROOT / "kornia-rs_amd")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_loading_into_a_two_runtime_process_fails_loudly():
+    """ADVICE r02: the single-runtime check ran only on DLPack hand-overs; a process that already maps two images (or ends up with
+    two through the preload) now fails at load — or warns with KORNIA_HIP_RUNTIME_CHECK=warn."""
+    pytest.importorskip("torch")
+    if not Path("/opt/rocm/lib/libamdhip64.so").exists():
+        pytest.skip("no system HIP runtime to map beside torch's")
+    out = _load_child("two_runtimes")
+    if "LOADED" in out:
+        pytest.skip("this torch build shares the system HIP runtime")
+    assert "RAISED MultipleHipRuntimes" in out, out
+    out = _load_child("two_runtimes", {"KORNIA_HIP_RUNTIME_CHECK": "warn"})
+    assert "LOADED already mapped" in out, out
+
+
+def test_a_bundle_with_another_soname_is_not_preloaded():
+    pytest.importorskip("torch")
+    out = _load_child("soname_mismatch")
+    assert "CHOICE system (torch bundle" in out and "MAPPED 1" in out, out

@@ -106,3 +106,59 @@ def test_workspace_argument_errors():
     assert _ffi.lib.kh_stream_set_workspace(None, 4096, 0) == _ffi.KH_ERR_INVALID_ARG
     assert _ffi.lib.kh_stream_set_workspace(None, None, 0) == _ffi.KH_OK
     assert _ffi.lib.kh_last_workspace_bytes(None) == _ffi.KH_ERR_INVALID_ARG
+
+
+def _registered(stream) -> int:
+    from kornia_rs import _ffi
+    n = C.c_size_t(0)
+    _ffi.check(_ffi.lib.kh_stream_workspace_bytes(stream.cuda_stream_ptr, C.byref(n)))
+    return int(n.value)
+
+
+def test_workspace_outlives_a_temporary_stream_wrapper():
+    """`Stream.from_handle(h).set_workspace(buf)` on a temporary wrapper used to drop the only reference to `buf`
+    while the C registry still pointed at it.  The registration itself now keeps the buffer alive."""
+    import gc
+    from kornia_rs import hip
+    from kornia_rs.hip import DeviceBuffer
+    stream = hip.Stream.new(0)
+    hip.Stream.from_handle(stream.cuda_stream_ptr, 0).set_workspace(DeviceBuffer(4096, stream, zeroed=False))
+    gc.collect()
+    key = (0, stream.cuda_stream_ptr)
+    assert key in hip._WORKSPACES and hip._WORKSPACES[key].ptr != 0  # still allocated
+    assert _registered(stream) == 4096
+    stream.set_workspace(None)
+    assert key not in hip._WORKSPACES and _registered(stream) == 0
+
+
+def test_freeing_a_registered_workspace_unregisters_it():
+    from kornia_rs import hip
+    from kornia_rs.hip import DeviceBuffer
+    stream = hip.Stream.new(0)
+    ws = DeviceBuffer(8192, stream, zeroed=False)
+    stream.set_workspace(ws)
+    assert _registered(stream) == 8192
+    ws.free()  # the library must not keep a pointer to freed memory
+    assert _registered(stream) == 0 and (0, stream.cuda_stream_ptr) not in hip._WORKSPACES
+    # replacing a registration releases the old buffer's bookkeeping
+    a, b = DeviceBuffer(1024, stream, zeroed=False), DeviceBuffer(2048, stream, zeroed=False)
+    stream.set_workspace(a)
+    stream.set_workspace(b)
+    assert _registered(stream) == 2048 and not a._ws_keys and b._ws_keys
+    stream.set_workspace(None)
+
+
+def test_destroying_a_stream_drops_its_workspace():
+    """A later stream may reuse the handle value: it must not inherit the stale entry."""
+    from kornia_rs import _ffi, hip
+    from kornia_rs.hip import DeviceBuffer
+    h = C.c_void_p(0)
+    _ffi.check(_ffi.lib.kh_stream_create(C.byref(h)))
+    ws = DeviceBuffer(4096, hip.Stream.default(0), zeroed=False)
+    _ffi.check(_ffi.lib.kh_stream_set_workspace(h, ws.ptr, 4096))
+    n = C.c_size_t(0)
+    _ffi.check(_ffi.lib.kh_stream_workspace_bytes(h, C.byref(n)))
+    assert n.value == 4096
+    _ffi.check(_ffi.lib.kh_stream_destroy(h))
+    _ffi.check(_ffi.lib.kh_stream_workspace_bytes(h, C.byref(n)))  # a map lookup by value; the handle is not dereferenced
+    assert n.value == 0
