@@ -21,9 +21,14 @@
 //     At scale 1 the bilinear weights are exactly 0 (`ax == ay == 0.0f`), hence
 //     `t00 + (t10 - t00) * 0 == t00` for the finite 0..255 taps and the result equals the
 //     generic kernel bit for bit; tests assert that equality.
+#include <math.h>
 #include <stdlib.h>
 
+#include <tuple>
+#include <vector>
+
 #include "kh_common.h"
+#include "kh_table_cache.h"
 
 using namespace kh;
 
@@ -39,6 +44,8 @@ struct PreArgs {
     long long dst_frame_stride;  // elements
     float rc_x, rc_y;            // 1 / scale_x, 1 / scale_y
     int fast_div;                // host-verified: the 3-op quotient equals IEEE division on this grid
+    const float* lz_wx;          // Lanczos only: 6 axis weights per destination column / row, built on the host (see lanczos_tables)
+    const float* lz_wy;
 };
 
 // BT.601 limited-range Q20 decode, constants of P/color/yuv/kernels.rs:696-702 and the fused
@@ -203,7 +210,13 @@ __device__ __forceinline__ void sample_bilinear(const uint8_t* __restrict__ src,
     }
 }
 
-__device__ __forceinline__ float lanczos_w(float d) {
+// 1-D Lanczos-3 weight, the reference's expression (P/preprocess.rs:481-487).  It runs on the HOST: the six horizontal weights of a
+// destination column depend only on the column, the six vertical ones only on the row, so a launch needs 6 * (dst_w + dst_h) of
+// them and they are built once per geometry with the host's libm `sinf` — the function the reference's CPU side (`f32::sin`) and
+// the restatement call.  Round 2 evaluated them per pixel with the device `sinf`, whose last-bit differences from libm left the
+// fused Lanczos output within 2e-4 of the restatement instead of north_star's 1e-6; with the tables it is bit-identical, and the
+// kernel loses 24 sinf evaluations per pixel.
+inline float lanczos_w(float d) {
     float ad = fabsf(d);
     if (ad < 1e-6f) return 1.0f;
     if (ad >= 3.0f) return 0.0f;
@@ -270,14 +283,18 @@ __device__ __forceinline__ void fetch_row6(const uint8_t* __restrict__ src, int 
 // in through fetch_row6.  The accumulation order — rows outer, taps inner, w = wy * wx, acc += w * t, wsum += w, one division at the
 // end — is the reference's, so the result is bit-identical to the per-tap form it replaces.
 template <int FMT, bool WIDE>
-__device__ __forceinline__ void sample_lanczos(const uint8_t* __restrict__ src, float sx, float sy,
+__device__ __forceinline__ void sample_lanczos(const uint8_t* __restrict__ src, float sx, float sy, int ox, int oy,
                                                const PreArgs& a, float px[3]) {
     const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
     float wx[6], wy[6];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2* wxp = reinterpret_cast<const f32x2*>(a.lz_wx + 6 * ox);   // lanczos_w(sx - (x0 - 2 + i)), i = 0..5 (24-byte rows)
+    const f32x2* wyp = reinterpret_cast<const f32x2*>(a.lz_wy + 6 * oy);   // wave-uniform: one row per wave
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        wx[i] = lanczos_w(sx - (float)(x0 - 2 + i));
-        wy[i] = lanczos_w(sy - (float)(y0 - 2 + i));
+    for (int i = 0; i < 3; ++i) {
+        const f32x2 u = wxp[i], v = wyp[i];
+        wx[2 * i] = u[0]; wx[2 * i + 1] = u[1];
+        wy[2 * i] = v[0]; wy[2 * i + 1] = v[1];
     }
     float acc[3] = {0.0f, 0.0f, 0.0f};
     float wsum = 0.0f;
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __re
         if (inside) {
             if constexpr (SAMPLER == KH_SAMPLE_NEAREST) sample_nearest<FMT, WIDE>(src, sx, sy, a, px[j]);
             else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) sample_bilinear<FMT, WIDE>(src, sx, sy, a, px[j]);
-            else sample_lanczos<FMT, WIDE>(src, sx, sy, a, px[j]);
+            else sample_lanczos<FMT, WIDE>(src, sx, sy, ox, oy, a, px[j]);
         } else {
             px[j][0] = a.pad_value; px[j][1] = a.pad_value; px[j][2] = a.pad_value;
         }
@@ -493,6 +510,41 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
 #pragma unroll
     for (int c = 0; c < 3; ++c)  // plane offset in the vector offset, never in an SGPR soffset (kh_common.h)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[c]), rdst, 16 * g + c * (4 * plane), 0, kAuxStream);
+}
+
+// Lanczos axis-weight tables: wx[dst_w][6] then wy[dst_h][6], cached per (device, geometry) like the reference's tap tables
+// (P/resize/cuda.rs:151-190): blocking upload before publication, leased until the launch is recorded, a cold table under stream
+// capture is a typed error (kh_table_cache.h).  `s` is evaluated exactly as the kernel's plan_pixel does ((o - pad) / scale, IEEE).
+using LzKey = std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t, int, int>;
+TableCache<LzKey>& g_lz_tabs = *new TableCache<LzKey>(64);  // never destroyed (the runtime may be gone at static destruction)
+
+int32_t lanczos_tables(PreArgs& a, hipStream_t stream, TableLease& lease) {
+    int dev = 0;
+    KH_HIP(hipGetDevice(&dev));
+    auto bits = [](float f) { return __builtin_bit_cast(uint32_t, f); };
+    const LzKey key{dev, bits(a.scale_x), bits(a.pad_x), bits(a.scale_y), bits(a.pad_y), a.dst_w, a.dst_h};
+    const int32_t rc = g_lz_tabs.lookup(key, stream, "preprocess (Lanczos weights)", [&](DevTable& t) -> int32_t {
+        std::vector<float> w((size_t)6 * (a.dst_w + a.dst_h));
+        auto axis = [](float* out, int n, float pad, float scale) {
+            for (int o = 0; o < n; ++o) {
+                const float s = ((float)o - pad) / scale;
+                const int i0 = (int)floorf(s);
+                for (int i = 0; i < 6; ++i) out[6 * o + i] = lanczos_w(s - (float)(i0 - 2 + i));
+            }
+        };
+        axis(w.data(), a.dst_w, a.pad_x, a.scale_x);
+        axis(w.data() + (size_t)6 * a.dst_w, a.dst_h, a.pad_y, a.scale_y);
+        t.bytes = w.size() * sizeof(float);
+        t.meta[0] = a.dst_w;
+        KH_HIP(hipMalloc(&t.dev, t.bytes));
+        const hipError_t err = hipMemcpy(t.dev, w.data(), t.bytes, hipMemcpyHostToDevice);
+        if (err != hipSuccess) return fail_hip(err, "hipMemcpy (Lanczos weight table)");  // ~DevTable frees the allocation
+        return KH_OK;
+    }, lease);
+    if (rc != KH_OK) return rc;
+    a.lz_wx = static_cast<const float*>(lease->dev);
+    a.lz_wy = a.lz_wx + (size_t)6 * a.dst_w;
+    return KH_OK;
 }
 
 // Does quot3 reproduce IEEE division for every (o - pad) / scale the launch will evaluate?  dst_w +
@@ -631,6 +683,7 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
     a.rc_x = 1.0f / a.scale_x;
     a.rc_y = 1.0f / a.scale_y;
     a.fast_div = plan_division_is_exact(a) ? 1 : 0;
+    a.lz_wx = a.lz_wy = nullptr;
     hipStream_t s = as_hip(stream);
 
     if (identity_fast_path(p, src, dst)) {
@@ -648,6 +701,11 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
         return check_launch("preprocess_nv12_identity");
     }
 
+    TableLease lz;  // keeps the weight table alive until the launch that reads it is enqueued and recorded
+    if (p->sampling == KH_SAMPLE_LANCZOS) {
+        rc = lanczos_tables(a, s, lz);
+        if (rc != KH_OK) return rc;
+    }
     dim3 grid(cdiv(p->dst_w, 64 * kGenPx), cdiv(p->dst_h, 4), (unsigned)p->nframes);
     switch (p->fmt) {
         case KH_FMT_RGB: launch_generic_fmt<KH_FMT_RGB>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
@@ -656,6 +714,7 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
         case KH_FMT_NV12: launch_generic_fmt<KH_FMT_NV12>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
         default: launch_generic_fmt<KH_FMT_YUYV>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
     }
+    if (lz) lz->used_on(s);
     return check_launch("preprocess_generic");
 }
 
