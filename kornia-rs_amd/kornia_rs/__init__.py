@@ -8,6 +8,8 @@ Importing the package loads the shared library and fails loudly if it is missing
 from . import _ffi
 from . import hip
 from .hip import IMAGENET_MEAN, IMAGENET_STD, Stream
+from . import allocator
+from .allocator import CpuAllocator, HipAllocator, HipUnifiedAllocator, Layout, PinnedAllocator, TensorAllocator, TensorAllocatorError, host_alloc
 from .tensor import Tensor
 from .image import Image, ImageError
 from .preprocess import Normalize, Preprocessor, PreprocessorBuilder, PreprocessError, ResizeMode, SourceFormat
@@ -27,4 +29,5 @@ __version__ = "0.1.0"
 __all__ = [
     "IMAGENET_MEAN", "IMAGENET_STD", "Stream", "Tensor", "Image", "ImageError", "Preprocessor", "PreprocessorBuilder", "Normalize",
     "PreprocessError", "ResizeMode", "SourceFormat", "imgproc", "rust_api", "fusion", "color_spaces", "ColorSpace", "calibration", "colormap", "ColormapType", "hip", "cuda", "sharding",
+    "allocator", "TensorAllocator", "TensorAllocatorError", "CpuAllocator", "PinnedAllocator", "HipAllocator", "HipUnifiedAllocator", "Layout", "host_alloc",
 ]

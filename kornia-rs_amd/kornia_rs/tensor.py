@@ -14,6 +14,7 @@ from typing import Any, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import allocator as _alloc
 from . import hip
 from .hip import DeviceBuffer, ManagedBuffer, PinnedBuffer, Stream
 
@@ -52,7 +53,11 @@ class Tensor:
     def __init__(self, shape: Sequence[int], dtype, *, host: Optional[np.ndarray] = None,
                  device_buf: Optional[DeviceBuffer] = None, device_ptr: int = 0,
                  device: int = 0, stream: Optional[Stream] = None, keepalive: Any = None,
-                 managed_buf: Optional[ManagedBuffer] = None, unified: bool = False, pinned: bool = False):
+                 managed_buf: Optional[ManagedBuffer] = None, unified: bool = False, pinned: bool = False,
+                 alloc: Optional["_alloc.TensorAllocator"] = None):
+        # the allocator handle this tensor's memory came from (TensorStorage.alloc, T/storage.rs:53-70); memory the tensor did
+        # not allocate (from_numpy of a caller's array, DLPack / array-interface imports) carries the handle that cannot allocate
+        self._alloc = alloc if alloc is not None else _alloc.foreign_alloc()
         self._shape = tuple(int(s) for s in shape)
         self._dtype = _np_dtype(dtype)
         self._buf = device_buf if device_buf is not None else managed_buf
@@ -82,27 +87,41 @@ class Tensor:
     def zeros(shape: Sequence[int], dtype="float32", stream: Optional[Stream] = None) -> "Tensor":
         """Host zeros when ``stream`` is None, else a zeroed stream-ordered device allocation
         (zeros_cuda, cuda.rs:860)."""
+        return Tensor.zeros_in(shape, dtype, _alloc.host_alloc() if stream is None else _alloc.HipAllocator(stream, zeroed=True))
+
+    @staticmethod
+    def zeros_in(shape: Sequence[int], dtype, allocator: "_alloc.TensorAllocator") -> "Tensor":
+        """``Tensor::zeros(shape, alloc)`` (T/tensor.rs:300-330): the allocator decides where the tensor lives — ``CpuAllocator``
+        / ``PinnedAllocator`` give a host tensor, ``HipAllocator`` a device tensor on its stream, ``HipUnifiedAllocator`` a
+        unified one.  The tensor keeps the handle (``Tensor.alloc``)."""
         dt = _np_dtype(dtype)
-        if stream is None:
-            return Tensor(shape, dt, host=np.zeros(shape, dtype=dt))
-        n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
-        return Tensor(shape, dt, device_buf=DeviceBuffer(n, stream, zeroed=True))
+        shape = tuple(int(s) for s in shape)
+        n = int(np.prod(shape, dtype=np.int64))
+        res = allocator.allocate(_alloc.Layout.array(dt, n))
+        if res.len_bytes() != n * dt.itemsize:
+            raise _alloc.TensorAllocatorError("NullPointer", f"allocator returned {res.len_bytes()} bytes for a {n * dt.itemsize}-byte tensor")
+        back = res.as_any()
+        if res.domain == MemoryDomain.DEVICE:
+            return Tensor(shape, dt, device_buf=back, alloc=allocator)
+        if res.domain == MemoryDomain.UNIFIED:
+            return Tensor(shape, dt, managed_buf=back, alloc=allocator)
+        if isinstance(back, PinnedBuffer):
+            host = back.view().view(dt)[:n].reshape(shape) if n else np.zeros(shape, dt)
+            return Tensor(shape, dt, host=host, keepalive=back, pinned=True, alloc=allocator)
+        host = back.view(dt)[:n].reshape(shape) if n else np.zeros(shape, dt)
+        return Tensor(shape, dt, host=host, keepalive=res, alloc=allocator)
 
     @staticmethod
     def uninit(shape: Sequence[int], dtype, stream: Stream) -> "Tensor":
         """Device allocation without the memset (uninit_cuda, cuda.rs:891): the producer kernel
         must overwrite every element."""
-        dt = _np_dtype(dtype)
-        n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
-        return Tensor(shape, dt, device_buf=DeviceBuffer(n, stream, zeroed=False))
+        return Tensor.zeros_in(shape, dtype, _alloc.HipAllocator(stream, zeroed=False))
 
     @staticmethod
     def zeros_unified(shape: Sequence[int], dtype, stream: Stream) -> "Tensor":
         """Zero-filled managed memory carrying ``stream`` (``zeros_cuda_unified``, T/cuda.rs:513-560): host slices AND
         device kernels work on it without a copy; dispatch treats it as device-resident (P/cuda/dispatch.rs:90-96)."""
-        dt = _np_dtype(dtype)
-        n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
-        return Tensor(shape, dt, managed_buf=ManagedBuffer(n, stream))
+        return Tensor.zeros_in(shape, dtype, _alloc.HipUnifiedAllocator(stream))
 
     zeros_hip_unified = zeros_unified
     zeros_cuda_unified = zeros_unified  # reference spelling
@@ -111,16 +130,12 @@ class Tensor:
     def zeros_pinned(shape: Sequence[int], dtype="uint8") -> "Tensor":
         """A HOST tensor in page-locked memory (``zeros_pinned``, T/cuda.rs:382-410): an ordinary host tensor for every
         host path, but copies against it are direct, stream-ordered DMA.  Allocate once and reuse."""
-        dt = _np_dtype(dtype)
-        n = int(np.prod(shape, dtype=np.int64))
-        pin = PinnedBuffer(n * dt.itemsize)
-        host = pin.view().view(dt)[:n].reshape(tuple(int(s) for s in shape)) if n else np.zeros(shape, dt)
-        return Tensor(shape, dt, host=host, keepalive=pin, pinned=True)
+        return Tensor.zeros_in(shape, dtype, _alloc.PinnedAllocator())
 
     @staticmethod
     def from_numpy(a: np.ndarray) -> "Tensor":
         a = np.ascontiguousarray(a)
-        return Tensor(a.shape, a.dtype, host=a)
+        return Tensor(a.shape, a.dtype, host=a, alloc=_alloc.host_alloc())  # from_shape_vec(shape, data, CpuAllocator)
 
     # -- properties ---------------------------------------------------------------------------
     @property
@@ -130,6 +145,11 @@ class Tensor:
     @property
     def dtype(self) -> str:
         return self._dtype.name
+
+    @property
+    def alloc(self) -> "_alloc.TensorAllocator":
+        """The allocator handle the storage was created with (``TensorStorage::alloc``); ``ForeignAllocator`` for wrapped memory."""
+        return self._alloc
 
     @property
     def domain(self) -> str:
@@ -229,13 +249,13 @@ class Tensor:
         if self._host is None:
             return self
         stream = stream if stream is not None else Stream.default(hip.current_device())
-        return Tensor(self._shape, self._dtype, device_buf=DeviceBuffer.from_numpy(self._host, stream))
+        return Tensor(self._shape, self._dtype, device_buf=DeviceBuffer.from_numpy(self._host, stream), alloc=_alloc.HipAllocator(stream, zeroed=False))
 
     def cpu(self) -> "Tensor":
         if self._host is not None:
             return self
         raw = self.numpy_raw()
-        return Tensor(self._shape, self._dtype, host=raw.copy() if self._uview is not None else raw)
+        return Tensor(self._shape, self._dtype, host=raw.copy() if self._uview is not None else raw, alloc=_alloc.host_alloc())
 
     # -- DLPack (T/dlpack.rs:72-290, PY/cuda_ext/mod.rs:196-216) ---------------------------------
     def __dlpack_device__(self) -> Tuple[int, int]:

@@ -387,3 +387,47 @@ def test_rust_api_names_tables_and_type_checks():
     with pytest.raises(ImageError):
         R.ycc_from_rgb_u8(u, u, "xyz")
     assert R.spatial_gradient_float_parallel is R.spatial_gradient_float
+
+
+# ---- allocator abstraction (a3: T/allocator.rs:73-144) ---------------------------------------------------------------------
+def test_cpu_allocator_zeroed_aligned_and_shared_handle():
+    """`cpu_allocate_zeroed_and_aligned` (T/allocator.rs:150-160) + the process-global handle."""
+    import kornia_rs as K
+    from kornia_rs.allocator import CpuAllocator, Layout, TensorAllocatorError, host_alloc
+    r = CpuAllocator().allocate(Layout(64, 1))
+    assert r.len_bytes() == 64 and r.domain == "host" and not r.is_readonly()
+    assert not r.as_any().any()
+    for align in (8, 64, 4096):
+        r = host_alloc().allocate(Layout(1024, align))
+        assert r.len_bytes() == 1024 and r.as_ptr() % align == 0
+    assert host_alloc() is host_alloc()  # one shared, stateless handle
+    assert host_alloc().allocate(Layout(0, 8)).len_bytes() == 0  # zero-size layouts are legal
+    for bad in ((-1, 1), (8, 0), (8, 3)):
+        with pytest.raises(TensorAllocatorError) as e:
+            Layout(*bad)
+        assert e.value.kind == "LayoutError"
+    assert Layout.array("float32", 10).size == 40 and Layout.array("float64", 1).align == 8
+    assert K.host_alloc() is host_alloc()
+
+
+def test_tensors_remember_their_allocator():
+    import kornia_rs as K
+    from kornia_rs.allocator import CpuAllocator, ForeignAllocator, TensorAllocator, TensorAllocatorError
+    t = K.Tensor.zeros((2, 3), "float32")
+    assert isinstance(t.alloc, CpuAllocator) and t.alloc is K.host_alloc() and not t.numpy().any()
+    assert isinstance(K.Tensor.from_numpy(np.ones((2, 2), np.uint8)).alloc, CpuAllocator)
+
+    class Counting(TensorAllocator):  # a user allocator: the trait is open (object-safe, one method)
+        calls = 0
+
+        def allocate(self, layout):
+            Counting.calls += 1
+            return CpuAllocator().allocate(layout)
+    a = Counting()
+    t = K.Tensor.zeros_in((4, 5), "int32", a)
+    assert t.alloc is a and Counting.calls == 1 and t.shape == (4, 5) and t.dtype == "int32" and not t.numpy().any()
+    t.numpy()[1, 2] = 7  # host tensors are writable views of the resource
+    assert t.numpy()[1, 2] == 7
+    with pytest.raises(TensorAllocatorError) as e:
+        ForeignAllocator().allocate(K.Layout(8, 1))
+    assert e.value.kind == "CannotAllocateForeign"

@@ -125,3 +125,23 @@ def test_typed_video_buffers_decode_on_device(gpu_stream):
         assert buf.is_device and np.array_equal(buf.cpu().as_slice(), raw2)
         got = imgproc.rgb_from_video(buf).cpu().numpy()
         assert np.array_equal(got, O.rgb_from_yuyv(raw2, w, h, layout))
+
+
+def test_hip_allocators_place_tensors(gpu_stream):
+    """a3 / a4: the HIP allocators behind `TensorAllocator` — device (zeroed / uninit), pinned host, unified — and the handle each
+    tensor keeps (T/allocator.rs:73-144, T/cuda.rs:214-262, 355-380, 440-511)."""
+    import kornia_rs as K
+    from kornia_rs.allocator import HipAllocator, HipUnifiedAllocator, Layout, PinnedAllocator
+    dev = HipAllocator(gpu_stream)
+    r = dev.allocate(Layout(4096, 256))
+    assert r.domain == "device" and r.len_bytes() == 4096 and r.as_ptr() % 256 == 0 and r.stream is gpu_stream
+    t = K.Tensor.zeros_in((3, 5), "float32", dev)
+    assert t.is_device and t.alloc is dev and not t.cpu().numpy().any()
+    assert isinstance(K.Tensor.zeros((2, 2), "uint8", gpu_stream).alloc, HipAllocator)
+    u = K.Tensor.uninit((2, 2), "uint8", gpu_stream)
+    assert isinstance(u.alloc, HipAllocator) and not u.alloc.zeroed
+    p = K.Tensor.zeros_in((16,), "uint8", PinnedAllocator())
+    assert not p.is_device and p.is_pinned and not p.numpy().any()
+    m = K.Tensor.zeros_in((4, 4), "float32", HipUnifiedAllocator(gpu_stream))
+    assert m.is_unified and m.is_host_accessible and not m.numpy().any()
+    assert isinstance(K.Tensor.from_numpy(np.ones(4, np.float32)).to_hip(gpu_stream).alloc, HipAllocator)
