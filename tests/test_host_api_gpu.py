@@ -133,8 +133,8 @@ def test_hip_allocators_place_tensors(gpu_stream):
     import kornia_rs as K
     from kornia_rs.allocator import HipAllocator, HipUnifiedAllocator, Layout, PinnedAllocator
     dev = HipAllocator(gpu_stream)
-    r = dev.allocate(Layout(4096, 256))
-    assert r.domain == "device" and r.len_bytes() == 4096 and r.as_ptr() % 256 == 0 and r.stream is gpu_stream
+    r = dev.allocate(Layout(4096, 16))
+    assert r.domain == "device" and r.len_bytes() == 4096 and r.as_ptr() % 16 == 0 and r.stream is gpu_stream
     t = K.Tensor.zeros_in((3, 5), "float32", dev)
     assert t.is_device and t.alloc is dev and not t.cpu().numpy().any()
     assert isinstance(K.Tensor.zeros((2, 2), "uint8", gpu_stream).alloc, HipAllocator)
