@@ -1178,11 +1178,33 @@ def in_process_sharded(args) -> int:
     process-per-GPU path; this mode exists to measure the thread-per-GPU one beside it."""
     import torch  # noqa: F401  one HIP runtime for the process
     from kornia_rs import hip
-    from kornia_rs.sharding import ShardedPreprocessor
+    from kornia_rs.sharding import ShardedPreprocessor, ShardPool
     n_dev = hip.device_count()
     devices = [g % max(n_dev, 1) for g in range(args.gpus)]
     if n_dev == 0:
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    if args.workload != "nv12_chw":
+        # Any other workload (e.g. BASELINE configs[4], --workload undistort_warp_4k): one instance per device, each set up and
+        # stepped on its shard's own thread + stream (kornia_rs.sharding.ShardPool — the pool ShardedImgproc runs on), common
+        # start barrier, slowest shard's end.  Weak scaling: every device owns a full per-GPU batch.
+        pool = ShardPool(devices)
+        wls = [make_workload(args.workload, args) for _ in devices]
+        pool._each(lambda g: wls[g].setup(pool.streams[g]))
+        elapsed = pool.timed_steps(lambda g: wls[g].step(), args.steps, args.warmup)
+        per_dev_s = elapsed / args.steps
+        name, cus, mem = hip.device_info(0)
+        w0 = wls[0]
+        print(json.dumps({
+            "metric": f"Mpixels/s (source pixels), {w0.name}", "value": round(len(devices) * w0.units_per_step * args.steps / elapsed, 1),
+            "unit": "Mpixels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_dev_s * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": w0.dtype,
+            "data": "synthetic (LCG bytes, reference pattern_u8; image k shifted by 31k)",
+            "config": {**w0.describe(), "launcher": "in-process: one host thread + one stream per device (kornia_rs.sharding.ShardPool)", "devices": devices},
+            "roofline": {"bound": "hbm", "achieved": round(w0.alg_bytes_per_launch / per_dev_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(w0.alg_bytes_per_launch / per_dev_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "kernel": w0.kernel,
+                         "note": "per device, from the wall clock of the slowest shard thread (no per-launch events in this mode)"},
+            "device": {"name": name, "cus": cus, "hbm_bytes": mem, "visible_devices": n_dev}}, separators=(",", ":")), flush=True)
+        return 0
     per = args.batch or 1024
     W, H = 1920, 1080
     fb = W * H * 3 // 2

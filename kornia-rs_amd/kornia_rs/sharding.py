@@ -9,6 +9,11 @@ per-ordinal streams (kornia-py/src/cuda_ext/mod.rs:61-84) — this module is the
 * ``ShardedPreprocessor``    in-process sharder for the fused camera preprocess: one ``Preprocessor`` + ``Stream`` per
                              device, one worker thread per device (``hipSetDevice`` is per-thread state; ctypes calls drop
                              the GIL, so uploads and launches of different devices overlap);
+* ``ShardedImgproc``         the same sharder for ANY ``imgproc`` operator (round 3): ``scatter`` a host batch into per-device
+                             images, ``replicate`` shared operands (undistortion maps, homographies, LUTs), ``map`` an operator
+                             over every image on its owner's stream, ``gather``; ``undistort_warp`` is BASELINE configs[4]
+                             (remap with Brown-Conrady maps, then warp_perspective) on top of it; ``plan`` is the pure
+                             partition both launchers (threads here, ranks under torchrun) use;
 * ``aggregate_throughput``   the process-per-GPU reduction used under ``torch.distributed`` (RCCL / gloo): slowest rank's
                              time, sum of units — the only collective anywhere, and it is not on the data path.
 
@@ -72,31 +77,19 @@ class ShardedBatch:
         return sum(hi - lo for lo, hi in self.ranges)
 
 
-class ShardedPreprocessor:
-    """One ``Preprocessor`` per device behind the single-device call shape.
+class ShardPool:
+    """Devices, one non-default stream and one worker thread per shard: what every in-process sharder shares."""
 
-    ``run_raw_batch(frames, src_w, src_h, out_h, out_w)`` takes either
-      * a host array ``[N, frame_bytes]`` uint8 (or a list of N 1-D uint8 arrays): slice ``g`` is staged through shard
-        ``g``'s persistent page-locked buffer and uploaded on shard ``g``'s stream, or
-      * a list with ONE entry per shard, each a device buffer on that shard's device holding its slice back to back
-        (``frame_stride`` bytes apart) together with the slice length: ``[(buf0, n0), (buf1, n1), ...]``
-    and returns a ``ShardedBatch``.  Every shard runs on its own worker thread: device selection, upload, launch.
-    """
-
-    def __init__(self, devices: Sequence[int], **preprocessor_kwargs: Any):
+    def __init__(self, devices: Sequence[int]):
         from . import hip
-        from .preprocess import Preprocessor
         if not devices:
-            raise ValueError("ShardedPreprocessor needs at least one device ordinal")
+            raise ValueError(f"{type(self).__name__} needs at least one device ordinal")
         n_dev = hip.device_count()
         for d in devices:
             if not (0 <= int(d) < n_dev):
                 raise ValueError(f"device ordinal {d} out of range (this process sees {n_dev} HIP device(s))")
-        if "stream" in preprocessor_kwargs:
-            raise ValueError("ShardedPreprocessor creates one stream per device; do not pass stream=")
         self.devices = [int(d) for d in devices]
         self.streams = [hip.Stream.new(d) for d in self.devices]
-        self.shards = [Preprocessor(stream=s, **preprocessor_kwargs) for s in self.streams]
         self._pool = ThreadPoolExecutor(max_workers=len(self.devices), thread_name_prefix="kornia-shard")
 
     @property
@@ -122,6 +115,56 @@ class ShardedPreprocessor:
 
         futures = [self._pool.submit(task, g) for g in range(self.world)]
         return [f.result() for f in futures]
+
+    def synchronize(self) -> None:
+        for s in self.streams:
+            s.synchronize()
+
+    def timed_steps(self, step: Callable[[int], None], steps: int, warmup: int = 0) -> float:
+        """Run ``step(g)`` ``warmup + steps`` times on every shard thread; the timed part starts behind a common barrier
+        (every shard's stream drained) and ends when the slowest shard has drained its stream.  Returns seconds."""
+        barrier = threading.Barrier(self.world)
+        spans: List[Tuple[float, float]] = [(0.0, 0.0)] * self.world
+
+        def body(g: int):
+            try:
+                for _ in range(warmup):
+                    step(g)
+                self.streams[g].synchronize()
+            except BaseException:
+                barrier.abort()  # a shard that failed in warm-up must not leave the others waiting for it forever
+                raise
+            try:
+                barrier.wait(timeout=600.0)
+            except threading.BrokenBarrierError:
+                raise RuntimeError(f"shard {g}: another shard failed (or hung for 10 min) before the timed region; see its error") from None
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(g)
+            self.streams[g].synchronize()
+            spans[g] = (t0, time.perf_counter())
+
+        self._each(body)
+        return max(t1 for _, t1 in spans) - min(t0 for t0, _ in spans)
+
+
+class ShardedPreprocessor(ShardPool):
+    """One ``Preprocessor`` per device behind the single-device call shape.
+
+    ``run_raw_batch(frames, src_w, src_h, out_h, out_w)`` takes either
+      * a host array ``[N, frame_bytes]`` uint8 (or a list of N 1-D uint8 arrays): slice ``g`` is staged through shard
+        ``g``'s persistent page-locked buffer and uploaded on shard ``g``'s stream, or
+      * a list with ONE entry per shard, each a device buffer on that shard's device holding its slice back to back
+        (``frame_stride`` bytes apart) together with the slice length: ``[(buf0, n0), (buf1, n1), ...]``
+    and returns a ``ShardedBatch``.  Every shard runs on its own worker thread: device selection, upload, launch.
+    """
+
+    def __init__(self, devices: Sequence[int], **preprocessor_kwargs: Any):
+        from .preprocess import Preprocessor
+        if "stream" in preprocessor_kwargs:
+            raise ValueError("ShardedPreprocessor creates one stream per device; do not pass stream=")
+        super().__init__(devices)
+        self.shards = [Preprocessor(stream=s, **preprocessor_kwargs) for s in self.streams]
 
     def alloc_output(self, n_frames: int, out_height: int, out_width: int, zeroed: bool = False) -> List[Any]:
         """Per-shard destination tensors for a batch of ``n_frames`` (uninitialised by default: the kernel writes every element)."""
@@ -219,29 +262,111 @@ class ShardedPreprocessor:
         self._each(run)
         return ShardedBatch(dsts, ranges, list(self.devices))
 
-    def timed_steps(self, step: Callable[[int], None], steps: int, warmup: int = 0) -> float:
-        """Run ``step(g)`` ``warmup + steps`` times on every shard thread; the timed part starts behind a common barrier
-        (every shard's stream drained) and ends when the slowest shard has drained its stream.  Returns seconds."""
-        barrier = threading.Barrier(self.world)
-        spans: List[Tuple[float, float]] = [(0.0, 0.0)] * self.world
 
-        def body(g: int):
-            try:
-                for _ in range(warmup):
-                    step(g)
-                self.streams[g].synchronize()
-            except BaseException:
-                barrier.abort()  # a shard that failed in warm-up must not leave the others waiting for it forever
-                raise
-            try:
-                barrier.wait(timeout=600.0)
-            except threading.BrokenBarrierError:
-                raise RuntimeError(f"shard {g}: another shard failed (or hung for 10 min) before the timed region; see its error") from None
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step(g)
-            self.streams[g].synchronize()
-            spans[g] = (t0, time.perf_counter())
+class Replicated:
+    """An operand every shard needs its own copy of (maps, LUTs, matrices): ``per_shard[g]`` lives on ``devices[g]``."""
 
-        self._each(body)
-        return max(t1 for _, t1 in spans) - min(t0 for t0, _ in spans)
+    def __init__(self, per_shard: List[Any]):
+        self.per_shard = per_shard
+
+
+class ShardedImages:
+    """A batch of device images spread over shards: ``shards[g]`` is the list of ``Image`` of slice ``ranges[g]`` on
+    ``devices[g]``, each ordered on that shard's stream.  Nothing has been synchronised."""
+
+    def __init__(self, shards: List[List[Any]], ranges: List[Tuple[int, int]], devices: List[int]):
+        self.shards, self.ranges, self.devices = shards, ranges, devices
+
+    def __len__(self) -> int:
+        return sum(len(s) for s in self.shards)
+
+    def numpy(self) -> List[np.ndarray]:
+        """Host copies in batch order (one D2H copy per image, on its owner's stream)."""
+        return [img.cpu().numpy() if hasattr(img, "cpu") else img.numpy() for shard in self.shards for img in shard]
+
+
+def plan(n_items: int, world: int) -> List[Tuple[int, int]]:
+    """The partition of ``n_items`` independent units over ``world`` shards / ranks: contiguous, balanced, in order, covering
+    ``[0, n_items)`` exactly once.  BASELINE configs[4]: ``plan(2048, 8)`` = 256 images per GPU."""
+    return [shard_range(n_items, g, world) for g in range(world)]
+
+
+class ShardedImgproc(ShardPool):
+    """Any ``kornia_rs.imgproc`` operator over a batch of independent images, sharded across devices.
+
+        sp = ShardedImgproc([0, 1, 2, 3])
+        batch = sp.scatter(host_images)                                   # slice g -> device g, on stream g
+        mx, my = sp.replicate_fn(lambda st: imgproc.generate_correction_map_polynomial(K, D, (w, h), st))
+        out = sp.map(imgproc.remap, batch, mx, my)                        # every image on its owner's thread + stream
+        out = sp.map(imgproc.warp_perspective, out, H)
+        host = out.numpy()
+
+    Operands wrapped in ``Replicated`` are resolved to the shard's own copy; everything else is passed through.  There is no
+    collective and no cross-device access: an image is only ever touched by the device that owns its slice (the reference's
+    same-device rule, P/cuda/dispatch.rs:51-53, holds per shard by construction)."""
+
+    def scatter(self, images: Sequence[Any]) -> ShardedImages:
+        """Upload a host batch: images ``[lo_g, hi_g)`` to device ``devices[g]`` on ``streams[g]``.  Accepts numpy HWC arrays or
+        host ``Image`` objects."""
+        from .image import Image
+        imgs = list(images)
+        ranges = plan(len(imgs), self.world)
+
+        def up(g: int):
+            lo, hi = ranges[g]
+            out = []
+            for k in range(lo, hi):
+                im = imgs[k] if isinstance(imgs[k], Image) else Image.from_numpy(np.asarray(imgs[k]))
+                if im.is_device:
+                    raise ValueError("scatter takes host images; device images already have an owner")
+                out.append(im.to_hip(self.streams[g]))
+            return out
+
+        return ShardedImages(self._each(up), ranges, list(self.devices))
+
+    def replicate(self, value: Any) -> Replicated:
+        """One device copy per shard of a host ``Image`` / numpy array (maps, LUT images)."""
+        from .image import Image
+
+        def up(g: int):
+            im = value if isinstance(value, Image) else Image.from_numpy(np.asarray(value))
+            return im.to_hip(self.streams[g])
+
+        return Replicated(self._each(up))
+
+    def replicate_fn(self, make: Callable[[Any], Any]):
+        """Build a replicated operand ON each device: ``make(stream_g)`` runs on shard ``g``'s thread (e.g. the undistortion maps,
+        generated in f64 on the device — 66 MB per camera never cross PCIe).  A tuple result becomes a tuple of ``Replicated``."""
+        made = self._each(lambda g: make(self.streams[g]))
+        if made and isinstance(made[0], tuple):
+            return tuple(Replicated([m[i] for m in made]) for i in range(len(made[0])))
+        return Replicated(made)
+
+    def map(self, fn: Callable[..., Any], batch: ShardedImages, *args: Any, **kwargs: Any) -> ShardedImages:
+        """``fn(image, *args, **kwargs)`` for every image of the batch, on the worker thread and stream of the shard that owns it."""
+        if batch.devices != self.devices:
+            raise ValueError(f"batch was scattered over devices {batch.devices}, this sharder runs on {self.devices}")
+
+        def run(g: int):
+            a = [x.per_shard[g] if isinstance(x, Replicated) else x for x in args]
+            kw = {k: (v.per_shard[g] if isinstance(v, Replicated) else v) for k, v in kwargs.items()}
+            return [fn(img, *a, **kw) for img in batch.shards[g]]
+
+        return ShardedImages(self._each(run), list(batch.ranges), list(batch.devices))
+
+    def undistort_warp(self, batch: ShardedImages, intrinsic: Sequence[float], distortion: Sequence[float],
+                       homography: Sequence[float], interpolation: str = "bilinear", maps: Optional[Tuple[Replicated, Replicated]] = None
+                       ) -> ShardedImages:
+        """BASELINE configs[4]: ``remap`` with the Brown-Conrady correction maps of (intrinsic, distortion), then
+        ``warp_perspective`` with ``homography``; maps replicated per device (built there unless ``maps`` is given), ``H``
+        replicated by value."""
+        from . import imgproc
+        first = next((s[0] for s in batch.shards if s), None)
+        if first is None:
+            return ShardedImages([[] for _ in self.devices], list(batch.ranges), list(batch.devices))
+        size = (first.width, first.height)
+        if maps is None:
+            maps = self.replicate_fn(lambda st: imgproc.generate_correction_map_polynomial(intrinsic, distortion, size, st))
+        mx, my = maps
+        und = self.map(imgproc.remap, batch, mx, my, interpolation)
+        return self.map(imgproc.warp_perspective, und, homography, (size[1], size[0]), interpolation)  # the Python API takes (height, width)

@@ -139,3 +139,73 @@ def test_timed_steps_common_barrier(gpu_stream):
     assert calls == [7, 7] and dt > 0
     got = np.concatenate([t.numpy() for t in outs])
     assert_same_bits(got, _want(frames, W, H, "stretch"), "timed_steps")
+
+
+# ---- ShardedImgproc: any imgproc operator, sharded (round 3) ----------------------------------------------
+INTR = (60.0, 62.0, 48.5, 30.25)
+DIST = (1.7547749280929563, 0.0097926277667284, -0.027250492945313457, 2.1092164516448975, 0.462927520275116,
+        -0.08215277642011642, -0.00005535508171073161, 0.00003768636770639569)   # examples/undistort_image/src/main.rs:30-50
+IW, IH = 97, 61
+HM = [1.03, 0.05, -3.0 * IW / 129.0, -0.02, 0.97, 4.0 * IH / 97.0, 2.0 / (IH * IW), 1.5 / (IW * IH), 1.0]  # the projective H of bench C5
+
+
+def _images_f32(n):
+    base = O.pattern_f32(IW * IH * 3 + 31 * n)
+    return [base[31 * k: 31 * k + IW * IH * 3].reshape(IH, IW, 3).copy() for k in range(n)]
+
+
+@pytest.mark.parametrize("n_images", [1, 5])
+def test_sharded_undistort_warp_equals_oracle(gpu_stream, n_images):
+    """BASELINE configs[4] through the product sharder: remap (device-built Brown-Conrady maps, replicated) then warp_perspective,
+    every image of every shard bit-equal to the restatement."""
+    from kornia_rs.sharding import ShardedImgproc, plan
+    imgs = _images_f32(n_images)
+    mx, my = O.correction_map(INTR, DIST, IW, IH)
+    want = [O.warp_perspective(O.remap(im, mx, my), HM, IW, IH) for im in imgs]
+    for devices in _device_lists():
+        sp = ShardedImgproc(devices)
+        batch = sp.scatter(imgs)
+        assert batch.ranges == plan(n_images, len(devices)) and len(batch) == n_images
+        out = sp.undistort_warp(batch, INTR, DIST, HM)
+        for g, shard in enumerate(out.shards):
+            assert all(im.is_device and im.device_id == devices[g] and im.stream is sp.streams[g] for im in shard)
+        got = out.numpy()
+        assert len(got) == n_images
+        for k in range(n_images):
+            assert_same_bits(got[k], want[k], f"devices={devices} image {k}")
+        sp.close()
+
+
+def test_sharded_map_of_other_operators(gpu_stream):
+    """`map` takes any imgproc operator: a colour map, a separable filter, a u8 gather with a replicated host operand."""
+    from kornia_rs import imgproc
+    from kornia_rs.sharding import ShardedImgproc
+    n = 4
+    base = O.pattern_u8(IW * IH * 3 + 31 * n)
+    u8 = [base[31 * k: 31 * k + IW * IH * 3].reshape(IH, IW, 3).copy() for k in range(n)]
+    f32 = _images_f32(n)
+    mx, my = O.correction_map(INTR, DIST, IW, IH)
+    sp = ShardedImgproc([0, 0, 0])
+    gray = sp.map(imgproc.gray_from_rgb, sp.scatter(u8)).numpy()
+    blur = sp.map(imgproc.gaussian_blur, sp.scatter(f32), (7, 7), (1.5, 1.5)).numpy()
+    rm = sp.map(imgproc.remap, sp.scatter(u8), sp.replicate(mx.reshape(IH, IW, 1)), sp.replicate(my.reshape(IH, IW, 1))).numpy()
+    for k in range(n):
+        assert np.array_equal(gray[k].reshape(IH, IW), O.gray_from_rgb_u8(u8[k]).reshape(IH, IW)), k
+        assert_same_bits(blur[k], O.gaussian_blur(f32[k], (7, 7), (1.5, 1.5)), f"blur {k}")
+        assert np.array_equal(rm[k], O.remap_u8(u8[k], mx, my)), k
+    with pytest.raises(ValueError, match="scattered over devices"):
+        ShardedImgproc([0]).map(imgproc.gray_from_rgb, sp.scatter(u8))
+    sp.close()
+
+
+def test_a_failing_shard_surfaces_its_error_and_never_hangs_the_timer(gpu_stream):
+    from kornia_rs.sharding import ShardedImgproc
+    sp = ShardedImgproc([0, 0])
+
+    def step(g):
+        if g == 1:
+            raise RuntimeError("boom on shard 1")
+    with pytest.raises(RuntimeError, match="boom on shard 1|another shard failed"):
+        sp.timed_steps(step, steps=2, warmup=1)
+    assert sp.timed_steps(lambda g: None, steps=2, warmup=1) >= 0.0  # the pool is still usable
+    sp.close()
