@@ -49,13 +49,13 @@ struct PreArgs {
 };
 
 // BT.601 limited-range Q20 decode, constants of P/color/yuv/kernels.rs:696-702 and the fused
-// kernel's yuv_to_rgbf (P/preprocess.rs:501-508).
+// kernel's bt601_q20_to_rgb (P/preprocess.rs:501-508).
 constexpr int kCY = 1220542, kCUB = 2116026, kCUG = -409993, kCVG = -852492, kCVR = 1673527;
 constexpr int kHalf20 = 1 << 19;
 
 __device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }
 
-__device__ __forceinline__ void yuv_to_rgbf(int yv, int u, int v, float px[3]) {
+__device__ __forceinline__ void bt601_q20_to_rgb(int yv, int u, int v, float px[3]) {
     int yy = max(yv - 16, 0) * kCY;
     u -= 128;
     v -= 128;
@@ -67,7 +67,7 @@ __device__ __forceinline__ void yuv_to_rgbf(int yv, int u, int v, float px[3]) {
 // WIDE: the frame base / pitch alignment lets a tap's chroma pair (NV12, 2 B), YUYV group (4 B) or
 // RGBA pixel (4 B) come in with ONE load instead of 2-3 byte loads (checked on the host).
 template <int FMT, bool WIDE>
-__device__ __forceinline__ void fetch_px(const uint8_t* __restrict__ src, int x, int y,
+__device__ __forceinline__ void tap_rgb(const uint8_t* __restrict__ src, int x, int y,
                                          const PreArgs& a, float px[3]) {
     if constexpr (FMT == KH_FMT_RGB || FMT == KH_FMT_BGR) {
         const uint8_t* p = src + (unsigned)(y * a.src_pitch + x * a.src_bpp);  // < 2^31, host-checked
@@ -91,28 +91,28 @@ __device__ __forceinline__ void fetch_px(const uint8_t* __restrict__ src, int x,
         const uint8_t* uv = src + (unsigned)(a.src_w * a.src_h + (y >> 1) * a.src_w + (x >> 1) * 2);
         if constexpr (WIDE) {
             const uint32_t q = *reinterpret_cast<const uint16_t*>(uv);
-            yuv_to_rgbf(yv, q & 0xFF, q >> 8, px);
+            bt601_q20_to_rgb(yv, q & 0xFF, q >> 8, px);
         } else {
-            yuv_to_rgbf(yv, uv[0], uv[1], px);
+            bt601_q20_to_rgb(yv, uv[0], uv[1], px);
         }
     } else {  // YUYV
         const uint8_t* grp = src + (unsigned)(y * a.src_pitch + (x >> 1) * 4);
         if constexpr (WIDE) {
             const uint32_t q = *reinterpret_cast<const uint32_t*>(grp);
-            yuv_to_rgbf((x & 1) ? (q >> 16) & 0xFF : q & 0xFF, (q >> 8) & 0xFF, q >> 24, px);
+            bt601_q20_to_rgb((x & 1) ? (q >> 16) & 0xFF : q & 0xFF, (q >> 8) & 0xFF, q >> 24, px);
         } else {
             int yv = grp[(x & 1) ? 2 : 0];
-            yuv_to_rgbf(yv, grp[1], grp[3], px);
+            bt601_q20_to_rgb(yv, grp[1], grp[3], px);
         }
     }
 }
 
 template <int FMT, bool WIDE>
-__device__ __forceinline__ void sample_nearest(const uint8_t* __restrict__ src, float sx, float sy,
+__device__ __forceinline__ void nearest_tap(const uint8_t* __restrict__ src, float sx, float sy,
                                                const PreArgs& a, float px[3]) {
     int xn = min(max((int)roundf(sx), 0), a.src_w - 1);
     int yn = min(max((int)roundf(sy), 0), a.src_h - 1);
-    fetch_px<FMT, WIDE>(src, xn, yn, a, px);
+    tap_rgb<FMT, WIDE>(src, xn, yn, a, px);
 }
 
 // The two horizontal taps of a bilinear sample, (x0, y) and (x1, y) with x1 = x0 + 1 (or x0 at the last
@@ -168,20 +168,20 @@ __device__ __forceinline__ void fetch_pair(const uint8_t* __restrict__ src, int 
         const uint32_t q = *reinterpret_cast<const u32u*>(src + (unsigned)(a.src_w * a.src_h + (y >> 1) * a.src_w + cb * 2)) >>
                            ((c0 - cb) * 16);
         const uint32_t uv0 = q & 0xFFFF, uv1 = (has_next && (x0 & 1)) ? q >> 16 : uv0;
-        yuv_to_rgbf((int)y0v, (int)(uv0 & 0xFF), (int)(uv0 >> 8), l);
-        yuv_to_rgbf((int)y1v, (int)(uv1 & 0xFF), (int)(uv1 >> 8), r);
+        bt601_q20_to_rgb((int)y0v, (int)(uv0 & 0xFF), (int)(uv0 >> 8), l);
+        bt601_q20_to_rgb((int)y1v, (int)(uv1 & 0xFF), (int)(uv1 >> 8), r);
     } else {  // YUYV: groups of 4 bytes Y0 U Y1 V per 2 pixels
         const int g0 = x0 >> 1, gb = min(g0, (a.src_w >> 1) - 2);
         const uint64_t v = *reinterpret_cast<const u64u*>(src + (unsigned)(y * a.src_pitch + gb * 4)) >> ((g0 - gb) * 32);
         const uint32_t q0 = (uint32_t)v, q1 = (has_next && (x0 & 1)) ? (uint32_t)(v >> 32) : q0;
         const int x1 = has_next ? x0 + 1 : x0;
-        yuv_to_rgbf((int)((x0 & 1) ? (q0 >> 16) & 0xFF : q0 & 0xFF), (int)((q0 >> 8) & 0xFF), (int)(q0 >> 24), l);
-        yuv_to_rgbf((int)((x1 & 1) ? (q1 >> 16) & 0xFF : q1 & 0xFF), (int)((q1 >> 8) & 0xFF), (int)(q1 >> 24), r);
+        bt601_q20_to_rgb((int)((x0 & 1) ? (q0 >> 16) & 0xFF : q0 & 0xFF), (int)((q0 >> 8) & 0xFF), (int)(q0 >> 24), l);
+        bt601_q20_to_rgb((int)((x1 & 1) ? (q1 >> 16) & 0xFF : q1 & 0xFF), (int)((q1 >> 8) & 0xFF), (int)(q1 >> 24), r);
     }
 }
 
 template <int FMT, bool WIDE>
-__device__ __forceinline__ void sample_bilinear(const uint8_t* __restrict__ src, float sx, float sy,
+__device__ __forceinline__ void bilinear_quad(const uint8_t* __restrict__ src, float sx, float sy,
                                                 const PreArgs& a, float px[3]) {
     int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
     float ax = sx - (float)x0, ay = sy - (float)y0;
@@ -197,10 +197,10 @@ __device__ __forceinline__ void sample_bilinear(const uint8_t* __restrict__ src,
         fetch_pair<FMT>(src, x0, has_next, y1, a, t01, t11);
     } else {
         const int x1 = has_next ? x0 + 1 : x0;
-        fetch_px<FMT, WIDE>(src, x0, y0, a, t00);
-        fetch_px<FMT, WIDE>(src, x1, y0, a, t10);
-        fetch_px<FMT, WIDE>(src, x0, y1, a, t01);
-        fetch_px<FMT, WIDE>(src, x1, y1, a, t11);
+        tap_rgb<FMT, WIDE>(src, x0, y0, a, t00);
+        tap_rgb<FMT, WIDE>(src, x1, y0, a, t10);
+        tap_rgb<FMT, WIDE>(src, x0, y1, a, t01);
+        tap_rgb<FMT, WIDE>(src, x1, y1, a, t11);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -231,7 +231,7 @@ inline float lanczos_w(float d) {
 // per-tap form (6 x 6 x (luma byte + chroma pair)) become 12.  Interleaved RGB / BGR taps are one unaligned dword each (36 loads
 // instead of 108).  Needs rows of at least 8 pixels; narrower sources take the per-tap path.
 template <int FMT>
-__device__ __forceinline__ void fetch_row6(const uint8_t* __restrict__ src, int x0, int yc, const PreArgs& a, float t[6][3]) {
+__device__ __forceinline__ void window_row6(const uint8_t* __restrict__ src, int x0, int yc, const PreArgs& a, float t[6][3]) {
     if constexpr (FMT == KH_FMT_NV12 || FMT == KH_FMT_GRAY) {
         const int pitch = FMT == KH_FMT_NV12 ? a.src_w : a.src_pitch;
         const int xb = min(max(x0 - 2, 0), a.src_w - 8);                      // bytes xb .. xb + 7 are in the row
@@ -248,7 +248,7 @@ __device__ __forceinline__ void fetch_row6(const uint8_t* __restrict__ src, int 
             const int yv = (int)((yw >> (8 * (xc - xb))) & 0xFF);
             if constexpr (FMT == KH_FMT_NV12) {
                 const uint32_t uv = (uint32_t)(cw >> (16 * ((xc >> 1) - cb))) & 0xFFFFu;
-                yuv_to_rgbf(yv, (int)(uv & 0xFF), (int)(uv >> 8), t[i]);
+                bt601_q20_to_rgb(yv, (int)(uv & 0xFF), (int)(uv >> 8), t[i]);
             } else {
                 t[i][0] = t[i][1] = t[i][2] = (float)yv;
             }
@@ -262,7 +262,7 @@ __device__ __forceinline__ void fetch_row6(const uint8_t* __restrict__ src, int 
             const int xc = min(max(x0 - 2 + i, 0), a.src_w - 1);
             const int g = (xc >> 1) - gb;                                     // 0 .. 3
             const uint32_t q = (uint32_t)((g & 2 ? hi : lo) >> (32 * (g & 1)));
-            yuv_to_rgbf((int)((xc & 1) ? (q >> 16) & 0xFF : q & 0xFF), (int)((q >> 8) & 0xFF), (int)(q >> 24), t[i]);
+            bt601_q20_to_rgb((int)((xc & 1) ? (q >> 16) & 0xFF : q & 0xFF), (int)((q >> 8) & 0xFF), (int)(q >> 24), t[i]);
         }
     } else {  // interleaved RGB / BGR, 3 or 4 bytes per pixel: one unaligned dword per tap, kept inside the surface
         const unsigned last = (unsigned)((a.src_h - 1) * a.src_pitch + a.src_w * a.src_bpp) - 4u;   // last dword that is inside
@@ -280,10 +280,10 @@ __device__ __forceinline__ void fetch_row6(const uint8_t* __restrict__ src, int 
 
 // Lanczos-3 over the 6 x 6 window (P/preprocess.rs:566-591).  The twelve axis weights are evaluated once per pixel (the reference
 // kernel re-evaluates the horizontal weight inside the row loop: 42 sinf pairs instead of 12 — same values, same products); rows come
-// in through fetch_row6.  The accumulation order — rows outer, taps inner, w = wy * wx, acc += w * t, wsum += w, one division at the
+// in through window_row6.  The accumulation order — rows outer, taps inner, w = wy * wx, acc += w * t, wsum += w, one division at the
 // end — is the reference's, so the result is bit-identical to the per-tap form it replaces.
 template <int FMT, bool WIDE>
-__device__ __forceinline__ void sample_lanczos(const uint8_t* __restrict__ src, float sx, float sy, int ox, int oy,
+__device__ __forceinline__ void lanczos_window(const uint8_t* __restrict__ src, float sx, float sy, int ox, int oy,
                                                const PreArgs& a, float px[3]) {
     const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
     float wx[6], wy[6];
@@ -304,10 +304,10 @@ __device__ __forceinline__ void sample_lanczos(const uint8_t* __restrict__ src, 
         const int yc = min(max(y0 - 2 + j, 0), a.src_h - 1);
         float t[6][3];
         if (wide_rows) {
-            fetch_row6<FMT>(src, x0, yc, a, t);
+            window_row6<FMT>(src, x0, yc, a, t);
         } else {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) fetch_px<FMT, WIDE>(src, min(max(x0 - 2 + i, 0), a.src_w - 1), yc, a, t[i]);
+            for (int i = 0; i < 6; ++i) tap_rgb<FMT, WIDE>(src, min(max(x0 - 2 + i, 0), a.src_w - 1), yc, a, t[i]);
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -392,9 +392,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __re
         const bool inside = ox < a.dst_w &&
                             !(sx < 0.0f || sy < 0.0f || sx >= (float)a.src_w || sy >= (float)a.src_h);
         if (inside) {
-            if constexpr (SAMPLER == KH_SAMPLE_NEAREST) sample_nearest<FMT, WIDE>(src, sx, sy, a, px[j]);
-            else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) sample_bilinear<FMT, WIDE>(src, sx, sy, a, px[j]);
-            else sample_lanczos<FMT, WIDE>(src, sx, sy, ox, oy, a, px[j]);
+            if constexpr (SAMPLER == KH_SAMPLE_NEAREST) nearest_tap<FMT, WIDE>(src, sx, sy, a, px[j]);
+            else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) bilinear_quad<FMT, WIDE>(src, sx, sy, a, px[j]);
+            else lanczos_window<FMT, WIDE>(src, sx, sy, ox, oy, a, px[j]);
         } else {
             px[j][0] = a.pad_value; px[j][1] = a.pad_value; px[j][2] = a.pad_value;
         }

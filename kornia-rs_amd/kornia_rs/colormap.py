@@ -1,9 +1,10 @@
 """Named colour maps — ``ColormapType`` / ``ColormapLut`` of crates/kornia-imgproc/src/color/colormap.rs:49-100.
 
-All 21 reference names parse (``ColormapType.from_name`` is case-insensitive like the reference's); the nineteen tables
-that can be rebuilt from their public definitions are bundled (``data/colormaps.npy``, produced and checked by
-``scripts/gen_colormaps.py``).  Asking for one of the others is an error that says so — ``apply_colormap`` also takes
-any caller-provided 3 x 256 table, so the two literal tables (parula, deepgreen) can be supplied from ``cv2`` where it is installed.
+All 21 reference names parse (``ColormapType.from_name`` is case-insensitive like the reference's) and all 21 tables are bundled
+in ``data/colormaps.npy``: nineteen are rebuilt from their public definitions by ``scripts/gen_colormaps.py``; parula and
+deepgreen have no public closed form and are shipped as the constant 3 x 256 byte tables they are (the same bytes as
+``colormap_luts.rs``; every table's SHA-256 is checked against the reference's, ``tests/golden/colormaps/``).
+``apply_colormap`` also takes any caller-provided 3 x 256 table.
 """
 import enum
 import json
