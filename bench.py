@@ -441,7 +441,7 @@ class GaussianU8_4K(U8Images):
 class WarpAffineU8_4K(U8Images):
     """warp_affine_u8 (rotation 12 deg about the centre, scale 0.9) on 3840x2160 RGB8, batch 256."""
 
-    name, kernel = "warp_affine_u8_4k_b256", "warp_affine_u8_lds_kernel<3> (+ affine_rows, affine_boxes)"
+    name, kernel = "warp_affine_u8_4k_b256", "gather_u8_staged_kernel<3,affine> (+ affine_rows)"
 
     def __init__(self, batch):
         self.N = batch
@@ -472,6 +472,81 @@ class WarpAffineU8_4K(U8Images):
         img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
         m = list(self.m)
         return self._time_cpu(lambda O: O.warp_affine_u8(img, m, self.W, self.H), "warp_affine_u8")
+
+
+class WarpPerspectiveU8_4K(U8Images):
+    """warp_perspective_u8 (the projective H of the C5 workload) on 3840x2160 RGB8, batch 256 (P/cuda/warp_perspective_u8.rs:59)."""
+
+    name, kernel = "warp_perspective_u8_4k_b256", "gather_u8_staged_kernel<3,perspective> (+ persp_rows)"
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C
+        w, h = float(self.W), float(self.H)
+        self.hm = [1.03, 0.05, -3.0 * w / 129.0, -0.02, 0.97, 4.0 * h / 97.0, 2.0 / (h * w), 1.5 / (w * h), 1.0]
+
+    def setup(self, stream):
+        import ctypes as C
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.W * self.H * self.C, stream, zeroed=False)
+        self.m = (C.c_float * 9)(*self.hm)
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        n = self.W * self.H * self.C
+        check(lib.kh_warp_perspective_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.W, self.H,
+                                         self.C, self.m, self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::warp::warp_perspective_u8 (projective H), row spans + Q10 bilinear",
+                "src": "3840x2160x3 u8", "dst": "same", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        return self._time_cpu(lambda O: O.warp_perspective_u8(img, self.hm, self.W, self.H), "warp_perspective_u8")
+
+
+class RemapU8_4K(U8Images):
+    """remap_u8 bilinear with the Brown-Conrady undistortion maps of the C5 workload on 3840x2160 RGB8, batch 256
+    (P/cuda/remap.rs:381,444).  Algorithmic bytes: 1R + 1W of the image + the two f32 maps ONCE per batch (they are shared)."""
+
+    name, kernel = "remap_u8_undistort_4k_b256", "gather_u8_staged_kernel<3,remap>"
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C + 2 * self.W * self.H * 4
+
+    def setup(self, stream):
+        import ctypes as C
+        from kornia_rs.hip import DeviceBuffer
+        from kornia_rs._ffi import lib, check
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.W * self.H * self.C, stream, zeroed=False)
+        self.mx = DeviceBuffer(self.W * self.H * 4, stream, zeroed=False)
+        self.my = DeviceBuffer(self.W * self.H * 4, stream, zeroed=False)
+        check(lib.kh_correction_map_polynomial_f32(stream.cuda_stream_ptr, self.mx.ptr, self.my.ptr, self.W, self.H,
+                                                   (C.c_double * 4)(*UndistortWarp4K.INTR), (C.c_double * 8)(*UndistortWarp4K.DIST)))
+
+    def step(self):
+        from kornia_rs._ffi import lib, check
+        n = self.W * self.H * self.C
+        check(lib.kh_remap_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.mx.ptr, self.my.ptr, self.dst.ptr, self.W, self.H,
+                              self.W, self.H, self.C, 1, self.N, n, n))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::interpolation::remap_u8 bilinear (Brown-Conrady undistortion maps), Q10",
+                "src": "3840x2160x3 u8 + 2 f32 maps", "dst": "same", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        O = self._oracle()
+        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
+        mx, my = O.correction_map(UndistortWarp4K.INTR, UndistortWarp4K.DIST, self.W, self.H)
+        return self._time_cpu(lambda O_: O_.remap_u8(img, mx, my, "bilinear"), "remap_u8")
 
 
 class FusedRgb640(U8Images):
@@ -999,6 +1074,8 @@ WORKLOADS = {
     "undistort_warp_4k": lambda a: UndistortWarp4K(a.batch or 256),
     "gaussian_u8_4k": lambda a: GaussianU8_4K(a.batch or 256),
     "warp_affine_u8_4k": lambda a: WarpAffineU8_4K(a.batch or 256),
+    "warp_perspective_u8_4k": lambda a: WarpPerspectiveU8_4K(a.batch or 256),
+    "remap_u8_4k": lambda a: RemapU8_4K(a.batch or 256),
     "fused_rgb_640": lambda a: FusedRgb640(a.batch or 1024),
     "resize_u8_224": lambda a: ResizeU8_224(a.batch or 256),
     "resize_norm_chw_224": lambda a: ResizeNormChw224(a.batch or 256),
@@ -1023,7 +1100,7 @@ WORKLOADS = {
 # 640 secondary into the driver's single run"): the other BASELINE configs, the north star's letterbox secondary, the
 # pointwise colour maps and the two weakest kernels of round 1.  Each entry is a full roofline record.
 ALSO_DEFAULT = ["nv12_chw_640", "resize_224", "gaussian_4k", "undistort_warp_4k", "gray_258x195", "gray_u8_1080p",
-                "gray_f32_1080p", "hsv_f32_1080p", "warp_affine_u8_4k", "gaussian_u8_4k"]
+                "gray_f32_1080p", "hsv_f32_1080p", "warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k", "gaussian_u8_4k"]
 CPU_BUDGET_SCALE = 1.0  # lowered for the `also` entries so the default run stays within a few minutes
 
 

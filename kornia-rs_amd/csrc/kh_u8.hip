@@ -369,21 +369,52 @@ __device__ __forceinline__ void store_px_u8(uint8_t* o, uint32_t px, bool wave_f
     }
 }
 
+// The Q10 blend of bilinear_sample_u8_valid (P/warp/common.rs:79-165) on four packed taps (channel c of a tap = bits [8c, 8c + 8)):
+//     ((p00*fx1 + p01*fx) * fy1 + (p10*fx1 + p11*fx) * fy + 2^19) >> 20,     fx1 = 1024 - fx, fy1 = 1024 - fy
+// with exact integer intermediates (< 2^28).  Round 2 spent ~12 VALU instructions per channel on it (four byte extracts, four
+// 24-bit multiply-adds, shift, mask, insert) and the staged affine warp was VALU-bound at 67.6 instructions per pixel
+// (profiles/r02q).  Now, per channel:
+//   * ONE v_perm_b32 per tap row puts the row's two taps into the 16-bit halves of a dword (selector bytes 0x0c = constant zero);
+//   * ONE v_dot2_u32_u16 with (fx1, fx) gives the horizontal sum  top = p00*fx1 + p01*fx  (<= 255 * 1024);
+//   * two v_mad_u32_u24 do the vertical sum with the weights pre-multiplied by 16, so the result byte lands in bits [31:24]:
+//     (X * 16) >> 24 == X >> 20 for X < 2^28;
+// and the channels' top bytes are gathered by one or two more v_perm_b32 — six instructions per channel plus two to pack.  The
+// integer is the reference's, operand for operand, so every caller stays byte-exact.
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+// fxp_bits = (1024 - fx) | fx << 16, fy16 = 16 * fy: prepared by the caller (the staged gather keeps them per pixel across images)
+template <int C>
+__device__ __forceinline__ uint32_t blend_q10_w(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uint32_t fxp_bits, uint32_t fy16) {
+    const u16x2_t fxp = __builtin_bit_cast(u16x2_t, fxp_bits);
+    const uint32_t fy1_16 = 16384u - fy16;
+    uint32_t acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const uint32_t sel = 0x0c000c00u | (uint32_t)c | ((uint32_t)(4 + c) << 16);   // (low tap . c, 0, high tap . c, 0)
+        const u16x2_t tp = __builtin_bit_cast(u16x2_t, __builtin_amdgcn_perm(p01, p00, sel));
+        const u16x2_t bp = __builtin_bit_cast(u16x2_t, __builtin_amdgcn_perm(p11, p10, sel));
+        const uint32_t top = __builtin_amdgcn_udot2(tp, fxp, 0u, false), bot = __builtin_amdgcn_udot2(bp, fxp, 0u, false);
+        acc[c] = __umul24(top, fy1_16) + (__umul24(bot, fy16) + (1u << 23));
+    }
+    if constexpr (C == 1) return acc[0] >> 24;
+    const uint32_t lo = __builtin_amdgcn_perm(acc[C > 1 ? 1 : 0], acc[0], 0x0c0c0703u);         // (acc0.b3, acc1.b3, 0, 0)
+    if constexpr (C == 2) return lo;
+    if constexpr (C == 3) return __builtin_amdgcn_perm(acc[C > 2 ? 2 : 0], lo, 0x0c070100u);    // (lo.b0, lo.b1, acc2.b3, 0)
+    const uint32_t hi = __builtin_amdgcn_perm(acc[C > 3 ? 3 : 0], acc[C > 2 ? 2 : 0], 0x0c0c0703u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+template <int C>
+__device__ __forceinline__ uint32_t blend_q10(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uint32_t fx, uint32_t fy) {
+    return blend_q10_w<C>(p00, p01, p10, p11, (1024u - fx) | (fx << 16), fy << 4);
+}
+
 // bilinear_sample_u8_valid (P/warp/common.rs:79-165): xi, yi in range; fx, fy in Q10
 template <int C>
 __device__ __forceinline__ uint32_t sample_q10(const uint8_t* __restrict__ src, int sw, int sh, int xi, int yi, uint32_t fx,
                                                uint32_t fy) {
-    const uint32_t fx1 = 1024u - fx, fy1 = 1024u - fy;
     const int yi1 = yi + 1 < sh ? yi + 1 : yi;
     // xi1 = xi + 1 < sw ? xi + 1 : xi  ==  load_quad_u8's second pixel; offsets < 2^31 B (host-checked)
     const QuadU8 q = load_quad_u8<C>(src + (unsigned)(yi * sw) * C, src + (unsigned)(yi1 * sw) * C, xi, sw);
-    uint32_t px = 0;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const uint32_t top = chan_u8(q.p00, c) * fx1 + chan_u8(q.p01, c) * fx, bot = chan_u8(q.p10, c) * fx1 + chan_u8(q.p11, c) * fx;
-        px |= (((top * fy1 + bot * fy + (1u << 19)) >> 20) & 0xffu) << (8 * c);
-    }
-    return px;
+    return blend_q10<C>(q.p00, q.p01, q.p10, q.p11, fx, fy);
 }
 
 // bilinear_sample_u8 (P/warp/common.rs:16-70): zeros when non-finite or outside
@@ -513,25 +544,7 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_u8_kernel(ImgU8 im, cons
 }
 
 
-// ---- LDS-staged affine warp -----------------------------------------------------------------------------------------------------
-// The per-pixel kernel above costs ~100 VALU instructions and 4 scattered sub-dword loads per pixel and runs at 0.14 of the HBM
-// roofline (11.3 ms per 256 4K images; PMC traffic only 1.11x the algorithmic bytes — it is not over-fetch).  An affine map takes a
-// 64 x 32 destination tile to a parallelogram with a small bounding box (12 deg, scale 0.9: 80 x 53 source pixels), so a block
-//   1. reads that box — min / max of the clamped integer source coordinates at both ends of every row's valid span (coordinates are
-//      linear in x along a row, so the ends bound the row), +1 column / row for the second taps — from a per-tile table one small
-//      launch builds for the whole batch (the boxes depend on the geometry only);
-//   2. stages it in LDS, ONE DWORD PER PIXEL, with wide contiguous loads (4 pixels = 4*C bytes per lane); cells past the last image
-//      column / row replicate the edge, which is exactly the reference's `xi + 1 < sw ? xi + 1 : xi` tap rule, so the sampler reads
-//      its four taps at fixed offsets {0, 1, pitch, pitch + 1} with no edge tests;
-//   3. samples: a thread owns FOUR CONSECUTIVE pixels of one row — coordinates step by adds, the blend uses four shared weights per
-//      pixel (blend_q10), and the 4*C result bytes leave in one store (no cross-lane packing, 4x fewer store instructions).
-// Same row spans, Q16 stepping, clamps and integer blend as the per-pixel kernel: the bytes are identical (tests run both).
-// LDS is sized by the host from the matrix (the box of a 64 x 32 tile, at most 32 KiB): a 12-degree rotation needs 18 KiB, so four
-// 512-thread blocks share a CU (the wave limit) instead of the two a fixed 32 KiB would allow...   A block whose box does not fit (strong minification, near-singular maps, or a row-quantised box
-// a few pixels larger than the estimate) samples from global memory instead — a block-uniform branch.
-constexpr int kStageW = 64, kStageH = 32;   // destination tile (same-box A/B on the 4K rotation: 8 rows 5.05 ms, 16 rows 4.60 ms, 32 rows 4.46 ms)
-constexpr int kStageCap = 8192;             // staged pixels per block: 32 KiB of LDS, 5 blocks per CU
-
+// ---- helpers of the staged gather (below): four packed pixels <-> 4*C bytes ------------------------------------------------------
 template <int C>
 __device__ __forceinline__ void load_quad_px(const uint8_t* __restrict__ p, uint32_t px[4]) {
     if constexpr (C == 4) {
@@ -569,143 +582,6 @@ template <int C>
 __device__ __forceinline__ void store_one_px(uint8_t* o, uint32_t px) {
 #pragma unroll
     for (int c = 0; c < C; ++c) o[c] = (uint8_t)(px >> (8 * c));
-}
-
-// The Q10 blend of sample_q10 on four packed taps.  sample_q10 computes ((p00*fx1 + p01*fx)*fy1 + (p10*fx1 + p11*fx)*fy + 2^19) >> 20
-// with exact integer intermediates, so the products distribute: four weights per PIXEL (each <= 2^20, summing to 2^20) and four
-// multiply-adds per channel give the same integer — about a third fewer VALU instructions for RGB.
-template <int C>
-__device__ __forceinline__ uint32_t blend_q10(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uint32_t fx, uint32_t fy) {
-    const uint32_t fx1 = 1024u - fx, fy1 = 1024u - fy;
-    const uint32_t w00 = __umul24(fx1, fy1), w01 = __umul24(fx, fy1), w10 = __umul24(fx1, fy), w11 = __umul24(fx, fy);
-    uint32_t px = 0;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const uint32_t acc = __umul24(chan_u8(p00, c), w00) + __umul24(chan_u8(p01, c), w01) + __umul24(chan_u8(p10, c), w10) +
-                             __umul24(chan_u8(p11, c), w11) + (1u << 19);
-        px |= ((acc >> 20) & 0xffu) << (8 * c);
-    }
-    return px;
-}
-
-// Bounding boxes of the tiles' first taps, one per (tile column, tile row): they depend on the geometry only, so ONE small launch
-// computes them for the whole batch and the main kernel reads its box with a scalar load instead of a wave reduction + barrier.
-struct TileBox { int xmin, xmax, ymin, ymax; };
-__global__ __launch_bounds__(64) void affine_boxes_kernel(TileBox* __restrict__ boxes, const AffineRow* __restrict__ rows, int tiles_x, int tiles_y,
-                                                          int dw, int dh, int sw, int sh, int dsx_q, int dsy_q) {
-    const int tile = blockIdx.x, lane = threadIdx.x;   // one wave per tile, lane = 2 * row + end
-    const int bx = tile % tiles_x, by = tile / tiles_x;
-    const int x_first = bx * kStageW, x_last = min(x_first + kStageW, dw), row = by * kStageH + (lane >> 1);
-    int xmin = 0x7fffffff, xmax = -1, ymin = 0x7fffffff, ymax = -1;
-    if (lane < 2 * kStageH && row < dh) {
-        const AffineRow r = rows[row];
-        const int lo = max(r.lo, x_first), hi = min(r.hi, x_last);
-        if (lo < hi) {
-            const int xe = (lane & 1) ? hi - 1 : lo;
-            const int sx_q = (int)(r.sx_lo + (uint32_t)(xe - r.lo) * (uint32_t)dsx_q), sy_q = (int)(r.sy_lo + (uint32_t)(xe - r.lo) * (uint32_t)dsy_q);
-            xmin = xmax = min(max(sx_q >> 16, 0), sw - 1);
-            ymin = ymax = min(max(sy_q >> 16, 0), sh - 1);
-        }
-    }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        xmin = min(xmin, __shfl_xor(xmin, m)); xmax = max(xmax, __shfl_xor(xmax, m));
-        ymin = min(ymin, __shfl_xor(ymin, m)); ymax = max(ymax, __shfl_xor(ymax, m));
-    }
-    if (lane == 0) boxes[tile] = TileBox{xmin, xmax, ymin, ymax};
-}
-
-extern __shared__ __attribute__((aligned(16))) uint32_t kh_warp_tile[];   // dynamic: sized by the host from the matrix (cap_px pixels), at most kStageCap
-
-template <int C>
-__global__ __launch_bounds__(16 * kStageH) void warp_affine_u8_lds_kernel(ImgU8 im, const AffineRow* __restrict__ rows, const TileBox* __restrict__ boxes,
-                                                                 int dsx_q, int dsy_q, int cap_px) {
-    uint32_t* tile = kh_warp_tile;
-    unsigned bx_, by_, bz_;
-    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;   // block (16, 16): 16 four-pixel groups x 16 rows
-    const int x_first = bx_ * kStageW, y0 = by_ * kStageH;
-    const uint8_t* src = im.src + (long long)bz_ * im.src_stride;
-    uint8_t* dst = im.dst + (long long)bz_ * im.dst_stride;
-    const TileBox tb = boxes[by_ * im.tiles.tiles_x + bx_];   // block-uniform index: a scalar load
-    const int xmin = tb.xmin, xmax = tb.xmax, ymin = tb.ymin, ymax = tb.ymax;
-    const int y = y0 + ty, x4 = x_first + 4 * tx;
-    const bool mine = y < im.dh && x4 < im.dw;                  // this thread has pixels
-    const bool whole = x4 + 3 < im.dw;                           // all four are inside the row
-    uint8_t* o = dst + ((long long)y * im.dw + x4) * C;
-    // this thread's row record: loaded BEFORE the staging phase so its latency hides behind it (the compiler cannot move a load
-    // across the barrier below)
-    const AffineRow r = rows[min(y, im.dh - 1)];
-    if (xmax < 0) {  // no valid pixel in the tile (block-uniform): zeros
-        if (mine) {
-            const uint32_t z[4] = {0u, 0u, 0u, 0u};
-            if (whole) store_quad_px<C>(o, z);
-            else for (int j = 0; x4 + j < im.dw; ++j) store_one_px<C>(o + j * C, 0u);
-        }
-        return;
-    }
-    // staged box: columns [xmin, xmin + pitch), rows [ymin, ymax + 1]; one column / row more than the first taps reach, cells past
-    // the image edge replicate it
-    const int bh = ymax + 2 - ymin, pitch = (xmax + 2 - xmin + 3) & ~3;
-    const bool staged = pitch * bh <= cap_px;   // block-uniform
-    if (staged) {
-        const int qpr = pitch >> 2, nq = qpr * bh;
-        const float inv_qpr = 1.0f / (float)qpr;   // q / qpr for q < 8192: the float quotient is within one of the integer one
-        auto fetch = [&](int q, uint32_t px[4]) {
-            int r_ = (int)((float)q * inv_qpr);
-            r_ -= (r_ * qpr > q);
-            r_ += ((r_ + 1) * qpr <= q);
-            const int c0 = xmin + 4 * (q - r_ * qpr);
-            const uint8_t* srow = src + (long long)min(ymin + r_, im.sh - 1) * im.sw * C;
-            if (c0 + 3 < im.sw) {
-                load_quad_px<C>(srow + (long long)c0 * C, px);
-            } else {  // the quad reaches past the last column: per-pixel, clamped (replicated edge)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) px[j] = load_px_u8<C>(srow + (long long)min(c0 + j, im.sw - 1) * C);
-            }
-        };
-        constexpr int kT = 16 * kStageH;
-        for (int q = tid; q < nq; q += 2 * kT) {   // two quads in flight per thread: both loads issue before the first LDS write
-            uint32_t pa[4], pb[4];
-            const bool second = q + kT < nq;
-            fetch(q, pa);
-            fetch(second ? q + kT : q, pb);
-            *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = u32x4_t{pa[0], pa[1], pa[2], pa[3]};   // q * 4 == r * pitch + 4 * c4
-            if (second) *reinterpret_cast<u32x4_t*>(&tile[(q + kT) * 4]) = u32x4_t{pb[0], pb[1], pb[2], pb[3]};
-        }
-    }
-    __syncthreads();
-    if (!mine) return;
-    // 2. sample four consecutive pixels of row y
-    const uint32_t sxb = r.sx_lo + (uint32_t)(x4 - r.lo) * (uint32_t)dsx_q, syb = r.sy_lo + (uint32_t)(x4 - r.lo) * (uint32_t)dsy_q;
-    const uint32_t* tbase = tile - ymin * pitch - xmin;   // tbase[yi * pitch + xi] = source pixel (xi, yi)
-    uint32_t out[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int x = x4 + j;
-        uint32_t px = 0;
-        if (x >= r.lo && x < r.hi) {
-            const int sx_q = (int)(sxb + (uint32_t)j * (uint32_t)dsx_q), sy_q = (int)(syb + (uint32_t)j * (uint32_t)dsy_q);
-            // The span keeps the indices in range in exact arithmetic; the clamp only matters where Q16 rounding drift would take the
-            // reference's unchecked sampler outside the image.
-            const int xi = min(max(sx_q >> 16, 0), im.sw - 1), yi = min(max(sy_q >> 16, 0), im.sh - 1);
-            const uint32_t fx = ((uint32_t)(sx_q & 0xFFFF)) >> 6, fy = ((uint32_t)(sy_q & 0xFFFF)) >> 6;
-            if (staged) {
-                const uint32_t* t0 = tbase + yi * pitch + xi;
-                px = blend_q10<C>(t0[0], t0[1], t0[pitch], t0[pitch + 1], fx, fy);
-            } else {
-                px = sample_q10<C>(src, im.sw, im.sh, xi, yi, fx, fy);
-            }
-        }
-        out[j] = px;
-    }
-    if (whole) {
-        store_quad_px<C>(o, out);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)  // fixed trip count: a run-time bound indexes out[] dynamically and puts it in scratch
-            if (x4 + j < im.dw) store_one_px<C>(o + j * C, out[j]);
-    }
 }
 
 // warp_perspective_u8 (P/warp/perspective.rs:179-322): rows whose denominator keeps one sign get
@@ -755,6 +631,222 @@ __global__ __launch_bounds__(kBx* kBy) void warp_perspective_u8_kernel(ImgU8 im,
     store_px_u8<C>(o, px, wave_full);
 }
 
+
+// ---- staged Q10 gather: ONE kernel for warp_affine_u8 / warp_perspective_u8 / remap_u8 (bilinear) -------------------------------
+// The per-pixel kernels above cost ~100 VALU instructions and four scattered sub-dword loads per pixel (0.14 of the HBM roofline on
+// the 4K rotation, r01); round 2's staged affine kernel got to 0.38 and was VALU-bound at 67.6 instructions per pixel (r02q).
+// What an output pixel needs splits into a part that depends on the GEOMETRY only — its coordinates, validity, blend weights, the
+// source box of its tile — and a part that depends on the image: four taps and the blend.  A batch shares the geometry (one matrix,
+// one pair of maps), so a 512-thread block owns a 64 x 32 destination tile of kStageNB CONSECUTIVE IMAGES and
+//   A. evaluates the coordinates of its pixels ONCE (a thread = four consecutive pixels of a row), in the op's own arithmetic —
+//      Q16 stepping along the row span (affine), per-column projective division inside the row span (perspective), the two map
+//      reads (remap; they are the largest stream of remap_u8, 8 of 14 bytes per pixel, now read once per kStageNB images) — and
+//      keeps the first-tap position, the packed horizontal weights (fx1, fx) and 16 * fy in registers;
+//   B. reduces the tile's source bounding box in-block (packed 16-bit min / max: v_pk_min_u16 / v_pk_max_u16 through wave
+//      shuffles, then eight partials through LDS) — exact by construction, it is the min / max of the very tap indices that will
+//      be used, so no pre-pass, no margins, no analytic bound per op;
+//   C. derives from the box, once: every pixel's LDS tap address and the (source offset, LDS slot) of the up-to-four 4-pixel
+//      groups the thread stages;
+//   D. per image: stages the box (one dword per pixel, 4*C-byte contiguous loads, cells past the last image column / row replicate
+//      the edge = the reference's `xi + 1 < sw ? xi + 1 : xi` tap rule), barrier, then per pixel two ds_read2_b32 and blend_q10 —
+//      about 25 VALU instructions per pixel and image — and one 4*C-byte store per thread.
+// A tile whose box does not fit 32 KiB of LDS (strong minification, wild maps) samples from global memory with the same registers
+// (a block-uniform branch); images wider or taller than 65535 (16-bit box fields) keep the per-pixel kernels.  Same spans, clamps,
+// floors and integer blend as those kernels: byte-identical (tests run both).
+constexpr int kStageW = 64, kStageH = 32;   // destination tile (same-box A/B on the 4K rotation, r02p: 8 rows 5.05 ms, 16 rows 4.60, 32 rows 4.46)
+constexpr int kStageCap = 8192;             // staged pixels per block: 32 KiB of LDS; four 512-thread blocks per CU (the wave limit)
+constexpr int kStageNB = 4;                 // images per block
+enum { kOpAffine = 0, kOpPersp = 1, kOpRemap = 2 };
+struct GatherOp {
+    const void* rows;                         // AffineRow* (affine) / PerspRow* (perspective)
+    const float* map_x; const float* map_y;   // remap
+    int dsx_q, dsy_q;                         // affine: Q16 column steps
+    int batch;
+};
+
+// bilinear_sample_u8's admission rule (P/warp/common.rs:16-70), as in sample_q10_checked: non-finite or outside -> not sampled
+__device__ __forceinline__ bool checked_tap(float xf, float yf, int sw, int sh, int& xi, int& yi, uint32_t& fx, uint32_t& fy) {
+    bool ok = __builtin_isfinite(xf) && __builtin_isfinite(yf);
+    xi = (int)fminf(fmaxf(floorf(ok ? xf : 0.0f), -1.0f), 2147483520.0f);
+    yi = (int)fminf(fmaxf(floorf(ok ? yf : 0.0f), -1.0f), 2147483520.0f);
+    ok = ok && xi >= 0 && xi < sw && yi >= 0 && yi < sh;
+    fx = (uint32_t)(ok ? (xf - (float)xi) * 1024.0f : 0.0f);
+    fy = (uint32_t)(ok ? (yf - (float)yi) * 1024.0f : 0.0f);
+    return ok;
+}
+
+template <int C, int OP>
+__global__ __launch_bounds__(16 * kStageH) void gather_u8_staged_kernel(ImgU8 im, GatherOp op) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kStageCap];
+    __shared__ uint32_t red[16];
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;   // block-uniform
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;   // block (16, 32): 16 four-pixel groups x 32 rows
+    const int x4 = bx_ * kStageW + 4 * tx, y = by_ * kStageH + ty;
+    const bool row_in = y < im.dh;
+    const int yc = min(y, im.dh - 1);
+
+    // A. coordinates of this thread's four pixels (geometry only)
+    uint32_t xy[4], fxp[4], fy16[4];
+    unsigned valid = 0;
+    if constexpr (OP == kOpAffine) {
+        const AffineRow r = static_cast<const AffineRow*>(op.rows)[yc];
+        uint32_t sx = r.sx_lo + (uint32_t)(x4 - r.lo) * (uint32_t)op.dsx_q, sy = r.sy_lo + (uint32_t)(x4 - r.lo) * (uint32_t)op.dsy_q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x4 + j;
+            if (row_in && x >= r.lo && x < r.hi) valid |= 1u << j;   // hi <= dw
+            // The span keeps the indices in range in exact arithmetic; the clamp only matters where Q16 rounding drift would take the
+            // reference's unchecked sampler outside the image.
+            const int xi = min(max((int)sx >> 16, 0), im.sw - 1), yi = min(max((int)sy >> 16, 0), im.sh - 1);
+            const uint32_t fx = (sx & 0xFFFFu) >> 6, fy = (sy & 0xFFFFu) >> 6;
+            xy[j] = (uint32_t)xi | ((uint32_t)yi << 16);
+            fxp[j] = (1024u - fx) | (fx << 16);
+            fy16[j] = fy << 4;
+            sx += (uint32_t)op.dsx_q; sy += (uint32_t)op.dsy_q;
+        }
+    } else {
+        PerspRow r{};
+        if constexpr (OP == kOpPersp) r = static_cast<const PerspRow*>(op.rows)[yc];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x4 + j;
+            float xf, yf;
+            bool in;
+            if constexpr (OP == kOpPersp) {
+                in = row_in && x >= r.lo && x < r.hi;
+                const float xf_ = (float)x;
+                const float nx = r.nx0 + r.dnx * xf_, ny = r.ny0 + r.dny * xf_, nd = r.nd0 + r.dnd * xf_;
+                const float inv_nd = 1.0f / nd;
+                xf = nx * inv_nd; yf = ny * inv_nd;
+            } else {
+                in = row_in && x < im.dw;
+                const int i = yc * im.dw + min(x, im.dw - 1);   // unconditional, clamped loads (dw * dh < 2^31: host-checked)
+                xf = op.map_x[i]; yf = op.map_y[i];
+            }
+            int xi, yi;
+            uint32_t fx, fy;
+            const bool ok = checked_tap(xf, yf, im.sw, im.sh, xi, yi, fx, fy) && in;
+            if (ok) valid |= 1u << j;
+            xy[j] = ok ? ((uint32_t)xi | ((uint32_t)yi << 16)) : 0u;
+            fxp[j] = (1024u - fx) | (fx << 16);
+            fy16[j] = fy << 4;
+        }
+    }
+
+    // B. the tile's source box: packed (x, y) minima and maxima of the valid first taps
+    u16x2_t lo2 = __builtin_bit_cast(u16x2_t, 0xFFFFFFFFu), hi2 = __builtin_bit_cast(u16x2_t, 0u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool v = (valid >> j) & 1u;
+        lo2 = __builtin_elementwise_min(lo2, __builtin_bit_cast(u16x2_t, v ? xy[j] : 0xFFFFFFFFu));
+        hi2 = __builtin_elementwise_max(hi2, __builtin_bit_cast(u16x2_t, v ? xy[j] : 0u));
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        lo2 = __builtin_elementwise_min(lo2, __builtin_bit_cast(u16x2_t, (uint32_t)__shfl_xor((int)__builtin_bit_cast(uint32_t, lo2), m)));
+        hi2 = __builtin_elementwise_max(hi2, __builtin_bit_cast(u16x2_t, (uint32_t)__shfl_xor((int)__builtin_bit_cast(uint32_t, hi2), m)));
+    }
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = __builtin_bit_cast(uint32_t, lo2); red[2 * (tid >> 6) + 1] = __builtin_bit_cast(uint32_t, hi2); }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        lo2 = __builtin_elementwise_min(lo2, __builtin_bit_cast(u16x2_t, red[2 * w]));
+        hi2 = __builtin_elementwise_max(hi2, __builtin_bit_cast(u16x2_t, red[2 * w + 1]));
+    }
+    const int xmin = lo2[0], ymin = lo2[1], xmax = hi2[0], ymax = hi2[1];
+    const bool any = xmax >= xmin;                              // block-uniform: some pixel of the tile is sampled
+    const bool mine = row_in && x4 < im.dw, whole = x4 + 3 < im.dw;
+    const int z0 = bz_ * kStageNB, nimg = min(kStageNB, op.batch - z0);
+    const long long dst_off = ((long long)y * im.dw + x4) * C;
+
+    // staged box: columns [xmin, xmin + pitch), rows [ymin, ymax + 1]: one column / row more than the first taps reach
+    const int bh = ymax + 2 - ymin, pitch = (xmax + 2 - xmin + 3) & ~3;
+    const bool staged = any && pitch * bh <= kStageCap;         // block-uniform
+
+    // C. per-thread plan, from the box: LDS tap index per pixel; (source byte offset, edge flag) of the quads this thread stages
+    int la[4];
+    uint32_t soff[4];
+    unsigned edge = 0;
+    if (staged) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            la[j] = ((valid >> j) & 1u) ? (int)__umul24((xy[j] >> 16) - (uint32_t)ymin, (uint32_t)pitch) + (int)((xy[j] & 0xFFFFu) - (uint32_t)xmin) : 0;
+        const int qpr = pitch >> 2, nq = qpr * bh;
+        const float inv_qpr = 1.0f / (float)qpr;   // q / qpr for q < 2048: the float quotient is within one of the integer one
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = tid + k * (16 * kStageH);
+            int r_ = (int)((float)q * inv_qpr);
+            r_ -= (r_ * qpr > q);
+            r_ += ((r_ + 1) * qpr <= q);
+            const int c0 = xmin + 4 * (q - r_ * qpr);
+            soff[k] = q < nq ? __umul24((uint32_t)min(ymin + r_, im.sh - 1), (uint32_t)(im.sw * C)) + (uint32_t)(min(c0, im.sw - 1) * C) : 0xFFFFFFFFu;
+            if (q < nq && c0 + 3 >= im.sw) edge |= 1u << k;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) la[j] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) soff[k] = 0xFFFFFFFFu;
+    }
+
+    // D. the images of this block
+    for (int b = 0; b < nimg; ++b) {
+        const uint8_t* src = im.src + (long long)(z0 + b) * im.src_stride;
+        uint8_t* o = im.dst + (long long)(z0 + b) * im.dst_stride + dst_off;
+        uint32_t out[4] = {0u, 0u, 0u, 0u};
+        if (staged) {
+            if (b > 0) __syncthreads();   // every thread has sampled the previous image before its box is overwritten
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2 += 2) {   // two quads in flight per thread: both loads issue before the first LDS write
+                uint32_t pq[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = k2 + h;
+                    if (soff[k] == 0xFFFFFFFFu) continue;
+                    const uint8_t* sp = src + soff[k];
+                    if (!((edge >> k) & 1u)) {
+                        load_quad_px<C>(sp, pq[h]);
+                    } else {  // the quad reaches past the last column: per pixel, clamped (replicated edge).  soff already holds min(c0, sw - 1).
+                        const int q = tid + k * (16 * kStageH), qpr = pitch >> 2;
+                        const int c0 = xmin + 4 * (q % qpr);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pq[h][j] = load_px_u8<C>(sp + (min(c0 + j, im.sw - 1) - min(c0, im.sw - 1)) * C);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = k2 + h;
+                    if (soff[k] == 0xFFFFFFFFu) continue;
+                    *reinterpret_cast<u32x4_t*>(&tile[(tid + k * (16 * kStageH)) * 4]) = u32x4_t{pq[h][0], pq[h][1], pq[h][2], pq[h][3]};   // q * 4 == r * pitch + 4 * c4
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t* t0 = tile + la[j];
+                const uint32_t px = blend_q10_w<C>(t0[0], t0[1], t0[pitch], t0[pitch + 1], fxp[j], fy16[j]);
+                out[j] = ((valid >> j) & 1u) ? px : 0u;
+            }
+        } else if (any) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((valid >> j) & 1u)
+                    out[j] = sample_q10<C>(src, im.sw, im.sh, (int)(xy[j] & 0xFFFFu), (int)(xy[j] >> 16), fxp[j] >> 16, fy16[j] >> 4);
+        }
+        if (mine) {
+            if (whole) {
+                store_quad_px<C>(o, out);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)  // fixed trip count: a run-time bound indexes out[] dynamically and puts it in scratch
+                    if (x4 + j < im.dw) store_one_px<C>(o + j * C, out[j]);
+            }
+        }
+    }
+}
+
 ImgU8 make_img_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int64_t ss, int64_t ds, int groups) {
     return ImgU8{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups, cdiv(dw, kBx) * 8)};
 }
@@ -767,6 +859,30 @@ ImgU8 make_img_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int 
         else if ((channels) == 3) hipLaunchKernelGGL((KERNEL<3>), grid, blk, 0, stream, __VA_ARGS__);   \
         else hipLaunchKernelGGL((KERNEL<4>), grid, blk, 0, stream, __VA_ARGS__);                        \
     } while (0)
+
+
+// The staged gather serves images up to 65535 x 65535 (16-bit box fields); KH_WARP_U8_DIRECT=1 (dev / test knob, read once) keeps
+// the per-pixel kernels for all three operators.
+bool use_staged_gather(int sw, int sh) {
+    static const bool direct = [] { const char* e = getenv("KH_WARP_U8_DIRECT"); return e && e[0] == '1'; }();
+    return !direct && sw <= 65535 && sh <= 65535;
+}
+template <int OP>
+int32_t launch_staged_gather(hipStream_t st, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int channels, int batch,
+                             int64_t ss, int64_t ds, const GatherOp& op, const char* what) {
+    const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, kStageH), groups = cdiv(batch, kStageNB);
+    // 64 x 32 tiles, dealt to the XCDs in runs of 8 tile rows like the other gathers
+    const ImgU8 im{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(tiles_x, tiles_y, groups, tiles_x * 8)};
+    KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+    const dim3 grid = xcd_grid(im.tiles), blk(16, kStageH);
+    switch (channels) {
+        case 1: hipLaunchKernelGGL((gather_u8_staged_kernel<1, OP>), grid, blk, 0, st, im, op); break;
+        case 2: hipLaunchKernelGGL((gather_u8_staged_kernel<2, OP>), grid, blk, 0, st, im, op); break;
+        case 3: hipLaunchKernelGGL((gather_u8_staged_kernel<3, OP>), grid, blk, 0, st, im, op); break;
+        default: hipLaunchKernelGGL((gather_u8_staged_kernel<4, OP>), grid, blk, 0, st, im, op); break;
+    }
+    return check_launch(what);
+}
 
 }  // namespace
 
@@ -841,6 +957,10 @@ int32_t kh_remap_u8(kh_stream_t stream, const uint8_t* src, const float* map_x, 
                "kh_remap_u8: interpolation mode %d is not supported for u8 (nearest, bilinear)", mode);
     if (batch == 0) return KH_OK;
     KH_REQUIRE(map_x && map_y, KH_ERR_INVALID_ARG, "kh_remap_u8: null map pointer");
+    if (mode == KH_INTERP_BILINEAR && use_staged_gather(sw, sh)) {
+        const GatherOp op{nullptr, map_x, map_y, 0, 0, batch};
+        return launch_staged_gather<kOpRemap>(as_hip(stream), src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, op, "kh_remap_u8");
+    }
     const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, (batch + kU8RemapNB - 1) / kU8RemapNB);
     KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_remap_u8: batch x tiles exceeds one launch");
     const dim3 blk(kBx, kBy), grid = xcd_grid(im.tiles);
@@ -871,41 +991,14 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
     KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_affine_u8: batch x tiles exceeds one launch");
     Scratch scratch;  // per-row spans shared by the batch: caller workspace or stream-ordered pool
-    static_assert(sizeof(AffineRow) == 16 && sizeof(TileBox) == 16, "the tile boxes follow the row records in one scratch block");
-    if (int32_t rc = get_scratch(stream, sizeof(AffineRow) * (size_t)dh + sizeof(TileBox) * (size_t)cdiv(dw, kStageW) * cdiv(dh, kStageH), "kh_warp_affine_u8", scratch))
-        return rc;
+    if (int32_t rc = get_scratch(stream, sizeof(AffineRow) * (size_t)dh, "kh_warp_affine_u8", scratch)) return rc;
     AffineRow* rows = scratch.as<AffineRow>();
     hipLaunchKernelGGL(affine_rows_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, as_hip(stream), rows, dw, dh, sw, sh, mi);
-    static const bool direct = [] { const char* e = getenv("KH_WARP_U8_DIRECT"); return e && e[0] == '1'; }();  // dev / test knob: the per-pixel kernel
-    if (direct) {
-        KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const AffineRow*)rows, dsx_q, dsy_q);
-    } else {
-        ImgU8 ims = im;  // 64 x 32 tiles, dealt to the XCDs in runs of 8 tile rows like the other gathers
-        const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, kStageH);
-        ims.tiles = xcd_tiles(tiles_x, tiles_y, (unsigned)batch, tiles_x * 8);
-        KH_REQUIRE(ims.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_warp_affine_u8: batch x tiles exceeds one launch");
-        const hipStream_t st = as_hip(stream);
-        TileBox* boxes = reinterpret_cast<TileBox*>(rows + dh);   // same scratch block (sized below)
-        hipLaunchKernelGGL(affine_boxes_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, st, boxes, (const AffineRow*)rows, (int)tiles_x, (int)tiles_y, dw, dh,
-                           sw, sh, dsx_q, dsy_q);
-        // LDS per block: the source box of a 64 x 32 tile under this matrix (+ the second-tap column / row, quad rounding, slack for
-        // the per-row Q16 rounding), capped at kStageCap pixels
-        const double bwf = kStageW * fabs((double)mi.m[0]) + kStageH * fabs((double)mi.m[1]), bhf = kStageW * fabs((double)mi.m[3]) + kStageH * fabs((double)mi.m[4]);
-        int cap_px = kStageCap;
-        if (bwf < 4096.0 && bhf < 4096.0) {
-            const long long want = (long long)(((int)ceil(bwf) + 4 + 3) & ~3) * ((int)ceil(bhf) + 4);
-            cap_px = (int)std::min<long long>(kStageCap, std::max<long long>(want, 256));
-        }
-        const dim3 grid = xcd_grid(ims.tiles), blk(16, kStageH);
-        const size_t lds = (size_t)cap_px * 4;
-        const AffineRow* rr = rows;
-        switch (channels) {
-            case 1: hipLaunchKernelGGL(warp_affine_u8_lds_kernel<1>, grid, blk, lds, st, ims, rr, (const TileBox*)boxes, dsx_q, dsy_q, cap_px); break;
-            case 2: hipLaunchKernelGGL(warp_affine_u8_lds_kernel<2>, grid, blk, lds, st, ims, rr, (const TileBox*)boxes, dsx_q, dsy_q, cap_px); break;
-            case 3: hipLaunchKernelGGL(warp_affine_u8_lds_kernel<3>, grid, blk, lds, st, ims, rr, (const TileBox*)boxes, dsx_q, dsy_q, cap_px); break;
-            default: hipLaunchKernelGGL(warp_affine_u8_lds_kernel<4>, grid, blk, lds, st, ims, rr, (const TileBox*)boxes, dsx_q, dsy_q, cap_px); break;
-        }
+    if (use_staged_gather(sw, sh)) {
+        const GatherOp op{rows, nullptr, nullptr, dsx_q, dsy_q, batch};
+        return launch_staged_gather<kOpAffine>(as_hip(stream), src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, op, "kh_warp_affine_u8");
     }
+    KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const AffineRow*)rows, dsx_q, dsy_q);
     return check_launch("kh_warp_affine_u8");
 }
 
@@ -924,6 +1017,10 @@ int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, uint8_t* 
     if (int32_t rc = get_scratch(stream, sizeof(PerspRow) * (size_t)dh, "kh_warp_perspective_u8", scratch)) return rc;
     PerspRow* rows = scratch.as<PerspRow>();
     hipLaunchKernelGGL(persp_rows_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, as_hip(stream), rows, dw, dh, sw, sh, inv);
+    if (use_staged_gather(sw, sh)) {
+        const GatherOp op{rows, nullptr, nullptr, 0, 0, batch};
+        return launch_staged_gather<kOpPersp>(as_hip(stream), src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, op, "kh_warp_perspective_u8");
+    }
     KH_DISPATCH_C(warp_perspective_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const PerspRow*)rows);
     return check_launch("kh_warp_perspective_u8");
 }

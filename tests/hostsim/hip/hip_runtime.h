@@ -78,6 +78,7 @@ inline uint32_t hostsim_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
 #define __builtin_amdgcn_perm(a, b, sel) hostsim_perm((a), (b), (sel))
 #define __builtin_amdgcn_alignbyte(hi, lo, s) ((uint32_t)(((((uint64_t)(uint32_t)(hi)) << 32) | (uint32_t)(lo)) >> (8 * ((s) & 3))))
 #define __builtin_amdgcn_sdot2(a, b, c, clamp) ((int)((c) + (int)(a)[0] * (int)(b)[0] + (int)(a)[1] * (int)(b)[1]))
+#define __builtin_amdgcn_udot2(a, b, c, clamp) ((uint32_t)((c) + (uint32_t)(a)[0] * (uint32_t)(b)[0] + (uint32_t)(a)[1] * (uint32_t)(b)[1]))
 #define __builtin_amdgcn_readfirstlane(v) (v)  /* only ever applied to wave-uniform values */
 // raw buffer accesses: base + soffset + voffset, dropped / zero when voffset + size runs past num_records (the hardware range check)
 struct hostsim_rsrc { char* base; uint32_t n; };

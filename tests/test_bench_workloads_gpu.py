@@ -134,6 +134,14 @@ def test_gather_workloads_4k(gpu_stream, bench):
     got = _out(wl, np.uint8, (wl.H, wl.W, wl.C))
     for k in range(wl.N):
         assert np.array_equal(got[k], O.warp_affine_u8(_frame(wl, k, n, (wl.H, wl.W, wl.C)), np.array(list(wl.m), np.float32), wl.W, wl.H)), k
+    wl = _run(bench, "warp_perspective_u8_4k", gpu_stream)
+    got = _out(wl, np.uint8, (wl.H, wl.W, wl.C))
+    for k in range(wl.N):
+        assert np.array_equal(got[k], O.warp_perspective_u8(_frame(wl, k, n, (wl.H, wl.W, wl.C)), wl.hm, wl.W, wl.H)), k
+    wl = _run(bench, "remap_u8_4k", gpu_stream)
+    got = _out(wl, np.uint8, (wl.H, wl.W, wl.C))
+    for k in range(wl.N):
+        assert np.array_equal(got[k], O.remap_u8(_frame(wl, k, n, (wl.H, wl.W, wl.C)), mx, my, "bilinear")), k
 
 
 def test_lab_workload_4k(gpu_stream, bench):
@@ -182,7 +190,7 @@ def test_colour_map_workloads_1080p(gpu_stream, bench):
 
 def test_every_workload_is_covered(bench):
     covered = {"nv12_chw", "nv12_chw_640", "resize_224", "resize_normalize_f32_224", "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640",
-               "gaussian_4k", "gaussian_u8_4k", "pyrdown_u8_4k", "pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_u8_4k", "lab_from_rgb_4k",
+               "gaussian_4k", "gaussian_u8_4k", "pyrdown_u8_4k", "pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k", "lab_from_rgb_4k",
                "spatial_gradient_1080p", "box_blur_fast_1080p", "median5_u8_1080p", "bilateral_1080p",
                "gray_u8_1080p", "gray_f32_1080p", "hsv_f32_1080p", "bgr_u8_1080p", "gray_258x195", "nv12_chw_640_lanczos"}
     assert set(bench.ALSO_DEFAULT) <= set(bench.WORKLOADS)

@@ -246,3 +246,46 @@ def test_remap_u8_known_answers_and_identity(gpu_stream):  # remap.rs:552-672
     xs, ys = np.meshgrid(np.arange(65, dtype=np.float32), np.arange(33, dtype=np.float32))
     for mode in ("bilinear", "nearest"):
         assert np.array_equal(run(img, xs, ys, mode), img)
+
+
+# ---- the staged gather (round 3) on the other two operators: multi-tile images, partial image groups, tiles whose box does not fit ----
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("name", ["proj", "strong", "horizon", "neg"])
+def test_warp_perspective_u8_staged_tiles_match_oracle(gpu_stream, c, name):
+    m = HOMOGRAPHIES[name]
+    for (w, h), (dw, dh), n in [((421, 150), (421, 150), 5), ((900, 500), (140, 75), 2), ((70, 45), (330, 215), 1)]:
+        src = np.stack([pat(w, h, c, seed=31 * k) for k in range(n)])
+        got = warp_u8_gpu(gpu_stream, "perspective", src, m, dw, dh, batch=n)
+        for k in range(n):
+            assert_same_bits(got[k], O.warp_perspective_u8(src[k], m, dw, dh), f"staged perspective_u8 {name} c{c} {w}x{h}->{dw}x{dh} frame {k}")
+
+
+@pytest.mark.parametrize("c", [1, 3])
+@pytest.mark.parametrize("kind", ["smooth", "magnify", "minify", "wild", "all_outside"])
+def test_remap_u8_staged_tiles_match_oracle(gpu_stream, c, kind):
+    """Bilinear remap_u8 through the staged gather: smooth maps (boxes fit), magnification, strong minification and random maps (boxes do
+    not fit: block-uniform global fallback), maps that leave the image everywhere (zero tiles); 5 images = one full group + 1."""
+    from kornia_rs import _ffi
+    w, h, dw, dh, n = 300, 170, 257, 131, 5
+    src = np.stack([pat(w, h, c, seed=31 * k) for k in range(n)])
+    rng = np.random.default_rng(11)
+    xs, ys = np.meshgrid(np.arange(dw, dtype=np.float32), np.arange(dh, dtype=np.float32))
+    if kind == "smooth":
+        mx = xs * np.float32(1.1) + np.float32(4.0) * np.sin(ys / np.float32(17.0)) + np.float32(2.5)
+        my = ys * np.float32(1.2) + np.float32(3.0) * np.cos(xs / np.float32(23.0)) - np.float32(1.25)
+    elif kind == "magnify":
+        mx, my = xs * np.float32(0.21) + np.float32(240.3), ys * np.float32(0.19) + np.float32(140.7)   # reaches the last column / row
+    elif kind == "minify":
+        mx, my = xs * np.float32(9.0) - np.float32(900.0), ys * np.float32(7.0) - np.float32(300.0)
+    elif kind == "wild":
+        mx, my = rng.uniform(-20, w + 20, xs.shape), rng.uniform(-20, h + 20, ys.shape)
+    else:
+        mx, my = xs + np.float32(1000.0), ys - np.float32(1000.0)
+    mx, my = np.ascontiguousarray(mx, np.float32), np.ascontiguousarray(my, np.float32)
+    d_src, d_mx, d_my = dev(gpu_stream, src), dev(gpu_stream, mx), dev(gpu_stream, my)
+    d_dst = out_buf(gpu_stream, n * dh * dw * c)
+    _ffi.check(_ffi.lib.kh_remap_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_mx.ptr, d_my.ptr, d_dst.ptr, w, h, dw, dh, c,
+                                    O.MODE["bilinear"], n, h * w * c, dh * dw * c))
+    got = d_dst.to_numpy(np.uint8, (n, dh, dw, c))
+    for k in range(n):
+        assert_same_bits(got[k], O.remap_u8(src[k], mx, my, "bilinear"), f"staged remap_u8 {kind} c{c} frame {k}")
