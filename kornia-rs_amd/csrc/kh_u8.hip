@@ -675,6 +675,42 @@ __device__ __forceinline__ bool checked_tap(float xf, float yf, int sw, int sh, 
     return ok;
 }
 
+// KM staging rounds of one thread, straight-line: KM 4*C-byte loads in flight, then the LDS writes (lanes past the end of the box
+// skip the write; their load was a duplicate of the box's first quad).
+template <int C, int KM>
+__device__ __forceinline__ void stage_rounds(uint32_t* __restrict__ tile, const uint8_t* __restrict__ src, const uint32_t (&soff)[4], int tid, int nq) {
+    uint32_t pq[KM][4];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) load_quad_px<C>(src + soff[k], pq[k]);
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        const int q = tid + k * (16 * kStageH);
+        if (q < nq) *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = u32x4_t{pq[k][0], pq[k][1], pq[k][2], pq[k][3]};   // q * 4 == r * pitch + 4 * c4
+    }
+}
+// The same for a box that reaches past the last image column (tiles at the right border only; a rolled loop, one quad at a time):
+// such a quad was loaded from the row's last four columns and is re-indexed so that cells past the edge replicate it.
+template <int C>
+__device__ __forceinline__ void stage_rounds_edge(uint32_t* __restrict__ tile, const uint8_t* __restrict__ src, const uint32_t (&soff)[4], int tid, int nq,
+                                               int kmax, int xmin, int pitch, int sw) {
+    const int qpr = pitch >> 2;
+#pragma unroll 1
+    for (int k = 0; k < kmax; ++k) {
+        const int q = tid + k * (16 * kStageH);
+        if (q >= nq) break;
+        uint32_t a[4];
+        load_quad_px<C>(src + soff[k], a);
+        const int c0 = xmin + 4 * (q % qpr), d = c0 - min(c0, sw - 4);   // 0 for the quads inside the row
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = min(d + j, 3);
+            o[j] = t == 0 ? a[0] : (t == 1 ? a[1] : (t == 2 ? a[2] : a[3]));
+        }
+        *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = u32x4_t{o[0], o[1], o[2], o[3]};
+    }
+}
+
 template <int C, int OP>
 __global__ __launch_bounds__(16 * kStageH) void gather_u8_staged_kernel(ImgU8 im, GatherOp op) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kStageCap];
@@ -764,85 +800,90 @@ __global__ __launch_bounds__(16 * kStageH) void gather_u8_staged_kernel(ImgU8 im
     const int bh = ymax + 2 - ymin, pitch = (xmax + 2 - xmin + 3) & ~3;
     const bool staged = any && pitch * bh <= kStageCap;         // block-uniform
 
-    // C. per-thread plan, from the box: LDS tap index per pixel; (source byte offset, edge flag) of the quads this thread stages
+    // C. per-thread plan, from the box: LDS tap index per pixel; source byte offset of the (up to four) quads this thread stages.
     int la[4];
     uint32_t soff[4];
-    unsigned edge = 0;
+    int kmax = 0, nq = 0;    // block-uniform: staging rounds (512 quads each), quads in the box
+    bool at_edge = false;    // block-uniform: the box reaches past the last image column (replicated cells)
     if (staged) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             la[j] = ((valid >> j) & 1u) ? (int)__umul24((xy[j] >> 16) - (uint32_t)ymin, (uint32_t)pitch) + (int)((xy[j] & 0xFFFFu) - (uint32_t)xmin) : 0;
-        const int qpr = pitch >> 2, nq = qpr * bh;
+        const int qpr = pitch >> 2;
+        nq = qpr * bh;
+        kmax = (nq + 16 * kStageH - 1) / (16 * kStageH);
+        at_edge = xmin + pitch > im.sw;
         const float inv_qpr = 1.0f / (float)qpr;   // q / qpr for q < 2048: the float quotient is within one of the integer one
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int q = tid + k * (16 * kStageH);
+            const int q0 = tid + k * (16 * kStageH), q = q0 < nq ? q0 : 0;   // idle lanes re-load the box's first quad (and do not write it)
             int r_ = (int)((float)q * inv_qpr);
             r_ -= (r_ * qpr > q);
             r_ += ((r_ + 1) * qpr <= q);
             const int c0 = xmin + 4 * (q - r_ * qpr);
-            soff[k] = q < nq ? __umul24((uint32_t)min(ymin + r_, im.sh - 1), (uint32_t)(im.sw * C)) + (uint32_t)(min(c0, im.sw - 1) * C) : 0xFFFFFFFFu;
-            if (q < nq && c0 + 3 >= im.sw) edge |= 1u << k;
+            // an edge quad is loaded from the last four columns of its row and re-indexed afterwards (sw >= 4: host-checked)
+            const int cl = at_edge ? min(c0, im.sw - 4) : c0;
+            soff[k] = __umul24((uint32_t)min(ymin + r_, im.sh - 1), (uint32_t)(im.sw * C)) + (uint32_t)(cl * C);
         }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) la[j] = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) soff[k] = 0xFFFFFFFFu;
+        for (int k = 0; k < 4; ++k) soff[k] = 0u;
     }
 
-    // D. the images of this block
-    for (int b = 0; b < nimg; ++b) {
-        const uint8_t* src = im.src + (long long)(z0 + b) * im.src_stride;
-        uint8_t* o = im.dst + (long long)(z0 + b) * im.dst_stride + dst_off;
-        uint32_t out[4] = {0u, 0u, 0u, 0u};
-        if (staged) {
-            if (b > 0) __syncthreads();   // every thread has sampled the previous image before its box is overwritten
+    // D. the images of this block: stage the box, barrier, sample, store; the second barrier keeps the next image's staging off a box
+    // that is still being read.  Latency is hidden by the other blocks of the CU.  Two separate loops (staged / not) so that the
+    // fallback's operands are dead in the staged loop (registers decide how many blocks share a CU).
+    auto emit = [&](uint8_t* o, const uint32_t (&out)[4]) {
+        if (!mine) return;
+        if (whole) {
+            store_quad_px<C>(o, out);
+        } else {
 #pragma unroll
-            for (int k2 = 0; k2 < 4; k2 += 2) {   // two quads in flight per thread: both loads issue before the first LDS write
-                uint32_t pq[2][4];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int k = k2 + h;
-                    if (soff[k] == 0xFFFFFFFFu) continue;
-                    const uint8_t* sp = src + soff[k];
-                    if (!((edge >> k) & 1u)) {
-                        load_quad_px<C>(sp, pq[h]);
-                    } else {  // the quad reaches past the last column: per pixel, clamped (replicated edge).  soff already holds min(c0, sw - 1).
-                        const int q = tid + k * (16 * kStageH), qpr = pitch >> 2;
-                        const int c0 = xmin + 4 * (q % qpr);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) pq[h][j] = load_px_u8<C>(sp + (min(c0 + j, im.sw - 1) - min(c0, im.sw - 1)) * C);
-                    }
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int k = k2 + h;
-                    if (soff[k] == 0xFFFFFFFFu) continue;
-                    *reinterpret_cast<u32x4_t*>(&tile[(tid + k * (16 * kStageH)) * 4]) = u32x4_t{pq[h][0], pq[h][1], pq[h][2], pq[h][3]};   // q * 4 == r * pitch + 4 * c4
-                }
+            for (int j = 0; j < 4; ++j)  // fixed trip count: a run-time bound indexes out[] dynamically and puts it in scratch
+                if (x4 + j < im.dw) store_one_px<C>(o + j * C, out[j]);
+        }
+    };
+    if (staged) {
+#pragma unroll 1
+        for (int b = 0; b < nimg; ++b) {
+            const uint8_t* src = im.src + (long long)(z0 + b) * im.src_stride;
+            if (b > 0) __syncthreads();
+            if (at_edge) stage_rounds_edge<C>(tile, src, soff, tid, nq, kmax, xmin, pitch, im.sw);   // block-uniform
+            else switch (kmax) {   // block-uniform; each case is straight-line: all loads of the rounds issue before the first LDS write
+                case 1: stage_rounds<C, 1>(tile, src, soff, tid, nq); break;
+                case 2: stage_rounds<C, 2>(tile, src, soff, tid, nq); break;
+                case 3: stage_rounds<C, 3>(tile, src, soff, tid, nq); break;
+                default: stage_rounds<C, 4>(tile, src, soff, tid, nq); break;
             }
             __syncthreads();
+            uint32_t t[4][4];   // all sixteen taps first: eight LDS reads in flight instead of two
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t* t0 = tile + la[j];
-                const uint32_t px = blend_q10_w<C>(t0[0], t0[1], t0[pitch], t0[pitch + 1], fxp[j], fy16[j]);
+                t[j][0] = t0[0]; t[j][1] = t0[1]; t[j][2] = t0[pitch]; t[j][3] = t0[pitch + 1];
+            }
+            uint32_t out[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t px = blend_q10_w<C>(t[j][0], t[j][1], t[j][2], t[j][3], fxp[j], fy16[j]);
                 out[j] = ((valid >> j) & 1u) ? px : 0u;
             }
-        } else if (any) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if ((valid >> j) & 1u)
-                    out[j] = sample_q10<C>(src, im.sw, im.sh, (int)(xy[j] & 0xFFFFu), (int)(xy[j] >> 16), fxp[j] >> 16, fy16[j] >> 4);
+            emit(im.dst + (long long)(z0 + b) * im.dst_stride + dst_off, out);
         }
-        if (mine) {
-            if (whole) {
-                store_quad_px<C>(o, out);
-            } else {
+    } else {
+#pragma unroll 1
+        for (int b = 0; b < nimg; ++b) {
+            const uint8_t* src = im.src + (long long)(z0 + b) * im.src_stride;
+            uint32_t out[4] = {0u, 0u, 0u, 0u};
+            if (any) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)  // fixed trip count: a run-time bound indexes out[] dynamically and puts it in scratch
-                    if (x4 + j < im.dw) store_one_px<C>(o + j * C, out[j]);
+                for (int j = 0; j < 4; ++j)
+                    if ((valid >> j) & 1u)
+                        out[j] = sample_q10<C>(src, im.sw, im.sh, (int)(xy[j] & 0xFFFFu), (int)(xy[j] >> 16), fxp[j] >> 16, fy16[j] >> 4);
             }
+            emit(im.dst + (long long)(z0 + b) * im.dst_stride + dst_off, out);
         }
     }
 }
@@ -865,7 +906,7 @@ ImgU8 make_img_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int 
 // the per-pixel kernels for all three operators.
 bool use_staged_gather(int sw, int sh) {
     static const bool direct = [] { const char* e = getenv("KH_WARP_U8_DIRECT"); return e && e[0] == '1'; }();
-    return !direct && sw <= 65535 && sh <= 65535;
+    return !direct && sw <= 65535 && sh <= 65535 && sw >= 4;   // 16-bit box fields; a staged quad is four pixels of one row
 }
 template <int OP>
 int32_t launch_staged_gather(hipStream_t st, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int channels, int batch,
