@@ -381,6 +381,17 @@ __device__ __forceinline__ void store_px_u8(uint8_t* o, uint32_t px, bool wave_f
 // and the channels' top bytes are gathered by one or two more v_perm_b32 — six instructions per channel plus two to pack.  The
 // integer is the reference's, operand for operand, so every caller stays byte-exact.
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+// a * b + c on 24-bit operands in ONE v_mad_u32_u24.  Written as `__umul24(a, b) + c` the compiler merges the two multiply-adds of a
+// channel into mul + mul + add3 (three instructions instead of two): the blend is the inner loop of a VALU-bound kernel.
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef KH_HOSTSIM
+    return __umul24(a, b) + c;
+#else
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
+}
 // fxp_bits = (1024 - fx) | fx << 16, fy16 = 16 * fy: prepared by the caller (the staged gather keeps them per pixel across images)
 template <int C>
 __device__ __forceinline__ uint32_t blend_q10_w(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uint32_t fxp_bits, uint32_t fy16) {
@@ -393,7 +404,7 @@ __device__ __forceinline__ uint32_t blend_q10_w(uint32_t p00, uint32_t p01, uint
         const u16x2_t tp = __builtin_bit_cast(u16x2_t, __builtin_amdgcn_perm(p01, p00, sel));
         const u16x2_t bp = __builtin_bit_cast(u16x2_t, __builtin_amdgcn_perm(p11, p10, sel));
         const uint32_t top = __builtin_amdgcn_udot2(tp, fxp, 0u, false), bot = __builtin_amdgcn_udot2(bp, fxp, 0u, false);
-        acc[c] = __umul24(top, fy1_16) + (__umul24(bot, fy16) + (1u << 23));
+        acc[c] = mad24(top, fy1_16, mad24(bot, fy16, 1u << 23));
     }
     if constexpr (C == 1) return acc[0] >> 24;
     const uint32_t lo = __builtin_amdgcn_perm(acc[C > 1 ? 1 : 0], acc[0], 0x0c0c0703u);         // (acc0.b3, acc1.b3, 0, 0)
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(kBx* kBy) void warp_perspective_u8_kernel(ImgU8 im,
 // floors and integer blend as those kernels: byte-identical (tests run both).
 constexpr int kStageW = 64, kStageH = 32;   // destination tile (same-box A/B on the 4K rotation, r02p: 8 rows 5.05 ms, 16 rows 4.60, 32 rows 4.46)
 constexpr int kStageCap = 8192;             // staged pixels per block: 32 KiB of LDS; four 512-thread blocks per CU (the wave limit)
-constexpr int kStageNB = 4;                 // images per block
+constexpr int kStageNB = 8;                 // images per block (4 -> 8: the geometry phase was still ~15 of 43 VALU instructions per pixel and image, r03f)
 enum { kOpAffine = 0, kOpPersp = 1, kOpRemap = 2 };
 struct GatherOp {
     const void* rows;                         // AffineRow* (affine) / PerspRow* (perspective)
@@ -675,19 +686,36 @@ __device__ __forceinline__ bool checked_tap(float xf, float yf, int sw, int sh, 
     return ok;
 }
 
-// KM staging rounds of one thread, straight-line: KM 4*C-byte loads in flight, then the LDS writes (lanes past the end of the box
-// skip the write; their load was a duplicate of the box's first quad).
-template <int C, int KM>
-__device__ __forceinline__ void stage_rounds(uint32_t* __restrict__ tile, const uint8_t* __restrict__ src, const uint32_t (&soff)[4], int tid, int nq) {
-    uint32_t pq[KM][4];
-#pragma unroll
-    for (int k = 0; k < KM; ++k) load_quad_px<C>(src + soff[k], pq[k]);
-#pragma unroll
-    for (int k = 0; k < KM; ++k) {
-        const int q = tid + k * (16 * kStageH);
-        if (q < nq) *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = u32x4_t{pq[k][0], pq[k][1], pq[k][2], pq[k][3]};   // q * 4 == r * pitch + 4 * c4
+// Raw staging loads: a quad = 4 * C contiguous bytes = kRawDw<C> dwords, kept as loaded (unpacked into one dword per pixel only
+// when they are written to LDS), so the quads of image b + 1 can sit in few registers while image b is sampled.
+template <int C> struct RawQuad { uint32_t d[C]; };
+template <int C>
+__device__ __forceinline__ RawQuad<C> load_raw_quad(const uint8_t* __restrict__ p) {
+    RawQuad<C> r;
+    if constexpr (C == 4) {
+        const uint64_t a = *reinterpret_cast<const u64_unaligned*>(p), b = *reinterpret_cast<const u64_unaligned*>(p + 8);
+        r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32); r.d[2] = (uint32_t)b; r.d[3] = (uint32_t)(b >> 32);
+    } else if constexpr (C == 3) {
+        const uint64_t a = *reinterpret_cast<const u64_unaligned*>(p);
+        r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32); r.d[2] = *reinterpret_cast<const u32_unaligned*>(p + 8);
+    } else if constexpr (C == 2) {
+        const uint64_t a = *reinterpret_cast<const u64_unaligned*>(p);
+        r.d[0] = (uint32_t)a; r.d[1] = (uint32_t)(a >> 32);
+    } else {
+        r.d[0] = *reinterpret_cast<const u32_unaligned*>(p);
     }
+    return r;
 }
+// four pixels, one dword each (channel c = bits [8c, 8c + 8); bits above 8C are don't-care: the blend's byte selectors never read them)
+template <int C>
+__device__ __forceinline__ u32x4_t unpack_raw_quad(const RawQuad<C>& r) {
+    if constexpr (C == 4) return u32x4_t{r.d[0], r.d[1], r.d[2], r.d[3]};
+    else if constexpr (C == 3)
+        return u32x4_t{r.d[0], __builtin_amdgcn_alignbyte(r.d[1], r.d[0], 3), __builtin_amdgcn_alignbyte(r.d[2], r.d[1], 2), r.d[2] >> 8};
+    else if constexpr (C == 2) return u32x4_t{r.d[0], r.d[0] >> 16, r.d[1], r.d[1] >> 16};
+    else return u32x4_t{r.d[0], r.d[0] >> 8, r.d[0] >> 16, r.d[0] >> 24};
+}
+
 // The same for a box that reaches past the last image column (tiles at the right border only; a rolled loop, one quad at a time):
 // such a quad was loaded from the row's last four columns and is re-indexed so that cells past the edge replicate it.
 template <int C>
@@ -708,6 +736,56 @@ __device__ __forceinline__ void stage_rounds_edge(uint32_t* __restrict__ tile, c
             o[j] = t == 0 ? a[0] : (t == 1 ? a[1] : (t == 2 ? a[2] : a[3]));
         }
         *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = u32x4_t{o[0], o[1], o[2], o[3]};
+    }
+}
+
+// The staged images of one block, KM staging rounds per image (block-uniform, a template so that the raw quads are registers).
+// Software-pipelined: the loads of image b + 1 are issued right after the barrier that publishes image b's box and complete while
+// image b is sampled — a block hides its own load latency instead of relying on its neighbours (three blocks share a CU).
+template <int C, int KM>
+__device__ __forceinline__ void staged_images(uint32_t* __restrict__ tile, const ImgU8& im, int z0, int nimg, const uint32_t (&soff)[4], int tid, int nq,
+                                              const int (&la)[4], int pitch, const uint32_t (&fxp)[4], const uint32_t (&fy16)[4], unsigned valid,
+                                              long long dst_off, bool mine, bool whole, int x4) {
+    const uint8_t* src = im.src + (long long)z0 * im.src_stride;
+    RawQuad<C> raw[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) raw[k] = load_raw_quad<C>(src + soff[k]);
+#pragma unroll 1
+    for (int b = 0; b < nimg; ++b) {
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            const int q = tid + k * (16 * kStageH);
+            if (q < nq) *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = unpack_raw_quad<C>(raw[k]);   // q * 4 == r * pitch + 4 * c4
+        }
+        __syncthreads();
+        if (b + 1 < nimg) {   // block-uniform
+            src += im.src_stride;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) raw[k] = load_raw_quad<C>(src + soff[k]);
+        }
+        uint32_t t[4][4];   // all sixteen taps first: eight LDS reads in flight
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t* t0 = tile + la[j];
+            t[j][0] = t0[0]; t[j][1] = t0[1]; t[j][2] = t0[pitch]; t[j][3] = t0[pitch + 1];
+        }
+        uint32_t out[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t px = blend_q10_w<C>(t[j][0], t[j][1], t[j][2], t[j][3], fxp[j], fy16[j]);
+            out[j] = ((valid >> j) & 1u) ? px : 0u;
+        }
+        uint8_t* o = im.dst + (long long)(z0 + b) * im.dst_stride + dst_off;
+        if (mine) {
+            if (whole) {
+                store_quad_px<C>(o, out);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)  // fixed trip count: a run-time bound indexes out[] dynamically and puts it in scratch
+                    if (x4 + j < im.dw) store_one_px<C>(o + j * C, out[j]);
+            }
+        }
+        __syncthreads();   // every thread has read this image's taps before the next box is written
     }
 }
 
@@ -845,29 +923,25 @@ __global__ __launch_bounds__(16 * kStageH) void gather_u8_staged_kernel(ImgU8 im
                 if (x4 + j < im.dw) store_one_px<C>(o + j * C, out[j]);
         }
     };
-    if (staged) {
+    if (staged && !at_edge) {
+        switch (kmax) {   // block-uniform
+            case 1: staged_images<C, 1>(tile, im, z0, nimg, soff, tid, nq, la, pitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
+            case 2: staged_images<C, 2>(tile, im, z0, nimg, soff, tid, nq, la, pitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
+            case 3: staged_images<C, 3>(tile, im, z0, nimg, soff, tid, nq, la, pitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
+            default: staged_images<C, 4>(tile, im, z0, nimg, soff, tid, nq, la, pitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
+        }
+    } else if (staged) {   // tiles whose box reaches past the last image column: rolled staging loop, no pipelining
 #pragma unroll 1
         for (int b = 0; b < nimg; ++b) {
             const uint8_t* src = im.src + (long long)(z0 + b) * im.src_stride;
             if (b > 0) __syncthreads();
-            if (at_edge) stage_rounds_edge<C>(tile, src, soff, tid, nq, kmax, xmin, pitch, im.sw);   // block-uniform
-            else switch (kmax) {   // block-uniform; each case is straight-line: all loads of the rounds issue before the first LDS write
-                case 1: stage_rounds<C, 1>(tile, src, soff, tid, nq); break;
-                case 2: stage_rounds<C, 2>(tile, src, soff, tid, nq); break;
-                case 3: stage_rounds<C, 3>(tile, src, soff, tid, nq); break;
-                default: stage_rounds<C, 4>(tile, src, soff, tid, nq); break;
-            }
+            stage_rounds_edge<C>(tile, src, soff, tid, nq, kmax, xmin, pitch, im.sw);
             __syncthreads();
-            uint32_t t[4][4];   // all sixteen taps first: eight LDS reads in flight instead of two
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t* t0 = tile + la[j];
-                t[j][0] = t0[0]; t[j][1] = t0[1]; t[j][2] = t0[pitch]; t[j][3] = t0[pitch + 1];
-            }
             uint32_t out[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t px = blend_q10_w<C>(t[j][0], t[j][1], t[j][2], t[j][3], fxp[j], fy16[j]);
+                const uint32_t* t0 = tile + la[j];
+                const uint32_t px = blend_q10_w<C>(t0[0], t0[1], t0[pitch], t0[pitch + 1], fxp[j], fy16[j]);
                 out[j] = ((valid >> j) & 1u) ? px : 0u;
             }
             emit(im.dst + (long long)(z0 + b) * im.dst_stride + dst_off, out);

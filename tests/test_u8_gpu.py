@@ -192,7 +192,7 @@ def test_warp_u8_known_answers_batch_and_errors(gpu_stream):
     rc = warp_u8_gpu(gpu_stream, "perspective", src, [1, 2, 3, 2, 4, 6, 3, 6, 9], 4, 2)
     assert rc == _ffi.KH_ERR_SINGULAR
     assert warp_u8_gpu(gpu_stream, "affine", pat(8, 8, 5), flip[:6], 8, 8) == _ffi.KH_ERR_UNSUPPORTED
-    n = 5
+    n = 11  # one full group of kStageNB = 8 images + a partial one
     batch = np.stack([pat(640, 360, 3, seed=31 * k) for k in range(n)])
     m = rotation(320.0, 180.0, 12.0, 0.9)
     got = warp_u8_gpu(gpu_stream, "affine", batch, m, 640, 360, batch=n)
@@ -253,7 +253,7 @@ def test_remap_u8_known_answers_and_identity(gpu_stream):  # remap.rs:552-672
 @pytest.mark.parametrize("name", ["proj", "strong", "horizon", "neg"])
 def test_warp_perspective_u8_staged_tiles_match_oracle(gpu_stream, c, name):
     m = HOMOGRAPHIES[name]
-    for (w, h), (dw, dh), n in [((421, 150), (421, 150), 5), ((900, 500), (140, 75), 2), ((70, 45), (330, 215), 1)]:
+    for (w, h), (dw, dh), n in [((421, 150), (421, 150), 9), ((900, 500), (140, 75), 2), ((70, 45), (330, 215), 1)]:
         src = np.stack([pat(w, h, c, seed=31 * k) for k in range(n)])
         got = warp_u8_gpu(gpu_stream, "perspective", src, m, dw, dh, batch=n)
         for k in range(n):
@@ -266,7 +266,7 @@ def test_remap_u8_staged_tiles_match_oracle(gpu_stream, c, kind):
     """Bilinear remap_u8 through the staged gather: smooth maps (boxes fit), magnification, strong minification and random maps (boxes do
     not fit: block-uniform global fallback), maps that leave the image everywhere (zero tiles); 5 images = one full group + 1."""
     from kornia_rs import _ffi
-    w, h, dw, dh, n = 300, 170, 257, 131, 5
+    w, h, dw, dh, n = 300, 170, 257, 131, 10   # 10 images = one full group of kStageNB = 8 + a partial one
     src = np.stack([pat(w, h, c, seed=31 * k) for k in range(n)])
     rng = np.random.default_rng(11)
     xs, ys = np.meshgrid(np.arange(dw, dtype=np.float32), np.arange(dh, dtype=np.float32))
