@@ -166,6 +166,17 @@ typedef uint64_t u64_unaligned __attribute__((aligned(1)));
 // Pixels come back PACKED (channel c of a pixel = bits [8c, 8c+8) of its word): passing small arrays
 // through the helper made the compiler park them in LDS (promote-alloca) in some kernels — 2.3x slower
 // than the byte loads it replaced (profiles/r01s_ab.log).
+// a * b + c on 24-bit operands in ONE v_mad_u32_u24.  Written as `__umul24(a, b) + c` the compiler merges the two multiply-adds of a
+// channel into mul + mul + add3 (three instructions instead of two): the blend is the inner loop of a VALU-bound kernel.
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef KH_HOSTSIM
+    return __umul24(a, b) + c;
+#else
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
+}
 struct QuadU8 { uint32_t p00, p01, p10, p11; };
 __device__ __forceinline__ uint32_t chan_u8(uint32_t px, int c) { return (px >> (8 * c)) & 0xffu; }
 

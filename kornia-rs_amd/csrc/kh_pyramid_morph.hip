@@ -267,6 +267,12 @@ __device__ __forceinline__ u16x2_t binomial5(u16x2_t t0, u16x2_t t1, u16x2_t t2,
     return (t0 + t4) + ((t1 + t3) << two) + t2 * six;
 }
 
+constexpr bool pd_div_exact(int d, uint32_t m, int limit) {
+    for (int i = 0; i < limit; ++i)
+        if ((int)(((uint32_t)i * m) >> 20) != i / d) return false;
+    return true;
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
     // One LDS block, used twice: first the staged source rows S[kPdRows][kPitch] (bytes), then — after every thread has taken its
@@ -297,30 +303,33 @@ __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
         // Stage the rows with ALIGNED, lane-consecutive dword loads.  Loading each pair's window straight from global memory
         // (unaligned dwords, 4 * C bytes apart across lanes) cost ~52 L1 accesses per wave-load, and the L1's access rate was the
         // kernel's limit (r02zq: 1.7e9 TCP accesses = 2.8 of its 2.9 ms); an aligned 256-byte wave-load costs four.
-        auto row_base = [&](int r, int& mis) -> const uint32_t* {
-            const uint8_t* g = src + ((long long)(sy0 + r) * a.sw + sx0) * C;
-            mis = (int)((uintptr_t)g & 3);
-            return reinterpret_cast<const uint32_t*>(g - mis);
-        };
+        // Addresses: one 64-bit window base per block (wave-uniform) + 32-bit offsets, and the item -> (row, dword) split by an
+        // exact 24-bit multiply-shift.  Round 2 did both in 64-bit / with a run-time division per load: ~8 quarter-rate
+        // multiplies per staged dword in a kernel that is latency-bound to begin with (r03 ISA review).
+        const uint8_t* g0 = src + ((long long)sy0 * a.sw + sx0) * C;      // first byte of the window's first row
+        const uint32_t g0lo = (uint32_t)(uintptr_t)g0 & 3u, rowb = (uint32_t)(a.sw * C);   // row bytes < 2^24 (host-checked)
+        auto row_mis = [&](int r) -> int { return (int)((g0lo + __umul24((uint32_t)r, rowb)) & 3u); };
         constexpr int kItems = kPdRows * kNdw, kTrips = (kItems + 255) / 256;
+        constexpr uint32_t kDivM = ((1u << 20) + kNdw - 1) / kNdw;        // i / kNdw == (i * kDivM) >> 20 on the staging range (checked below)
+        static_assert(pd_div_exact(kNdw, kDivM, kTrips * 256), "multiply-shift division by kNdw is not exact on the staging range");
         uint32_t v[kTrips];
 #pragma unroll
         for (int k = 0; k < kTrips; ++k) {   // every load unconditional, from a clamped (row, dword): all in flight together
-            const int i = min(tid + 256 * k, kItems - 1), r = min(i / kNdw, rows_needed - 1), d = i - (i / kNdw) * kNdw;
-            int mis;
-            v[k] = row_base(r, mis)[d];
+            const int i = min(tid + 256 * k, kItems - 1), ri = (int)(__umul24((uint32_t)i, kDivM) >> 20);
+            const int r = min(ri, rows_needed - 1), d = i - ri * kNdw;
+            const int off = (int)__umul24((uint32_t)r, rowb) - row_mis(r) + 4 * d;   // >= -3: the aligned dword holding the row's first byte
+            v[k] = *reinterpret_cast<const uint32_t*>(g0 + off);
         }
 #pragma unroll
         for (int k = 0; k < kTrips; ++k) {
-            const int i = tid + 256 * k;
-            if (i < kItems) lds[(i / kNdw) * (kPitch / 4) + (i - (i / kNdw) * kNdw)] = v[k];
+            const int i = tid + 256 * k, ri = (int)(__umul24((uint32_t)i, kDivM) >> 20);
+            if (i < kItems) lds[ri * (kPitch / 4) + (i - ri * kNdw)] = v[k];
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
             const int r = min(slot + 8 * k, rows_needed - 1);
-            int mis;
-            row_base(r, mis);
+            const int mis = row_mis(r);
             const uint32_t* q = lds + r * (kPitch / 4) + p * C;              // the pair's window starts mis bytes into this dword
             uint32_t raw[ND + 1];
 #pragma unroll
@@ -647,16 +656,23 @@ __global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp
         // of the image is fetched from img_bytes - 4 and shifted down.
         const int d = min(tid & 127, dpr - 1);
         constexpr int kBatch = 10;                                           // rows per thread in flight (the two 128-thread halves interleave rows)
+        // Addresses: ONE 64-bit window base per block (wave-uniform, scalar registers) plus a 32-bit offset per load — the offset of a
+        // staged cell from the window's first byte is < 64 rows x 2^24 bytes.  Round 2 evaluated `((wy0 + r) * w + wx0) * C` in 64 bits
+        // per load: three quarter-rate v_mad_u64_u32 each, about a quarter of the kernel's vector-ALU time (r03 ISA review).
+        const uint8_t* wbase = src + ((long long)wy0 * a.w + wx0) * C;
+        const uint32_t rowb = (uint32_t)(a.w * C);                           // < 2^24 for any image this kernel takes (host-checked)
+        const long long lim64 = img_bytes - 4 - ((long long)wy0 * a.w + wx0) * C;
+        const uint32_t lim = (uint32_t)(lim64 > 0x7fffffffLL ? 0x7fffffffLL : lim64);   // last in-image dword, relative to the window (>= 0)
         for (int r0 = tid >> 7; r0 < srows; r0 += 2 * kBatch) {
             uint32_t v[kBatch];
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
                 const int r = min(r0 + 2 * k, srows - 1);
-                const long long off = ((long long)(wy0 + r) * a.w + wx0) * C + 4 * d, offc = min(off, img_bytes - 4);
-                v[k] = *reinterpret_cast<const u32_unaligned*>(src + offc) >> (8 * (int)(off - offc));
+                const uint32_t off = __umul24((uint32_t)r, rowb) + 4u * (uint32_t)d, offc = min(off, lim);
+                v[k] = *reinterpret_cast<const u32_unaligned*>(wbase + offc) >> (8 * (int)(off - offc));
             }
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) *reinterpret_cast<uint32_t*>(S + min(r0 + 2 * k, srows - 1) * sp + 4 * d) = v[k];
+            for (int k = 0; k < kBatch; ++k) *reinterpret_cast<uint32_t*>(S + __umul24((uint32_t)min(r0 + 2 * k, srows - 1), (uint32_t)sp) + 4 * d) = v[k];
         }
     } else {
         constexpr int kBatch = 4;
@@ -693,9 +709,10 @@ __global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp
         // 2a. horizontal pass over every staged row
         if constexpr (K > 0) {
             // eight output bytes per item: the two windows share all but one of their dwords and the index arithmetic
+            static_assert(kDW / 2 == 48, "the multiply-shift below divides by 48");
             for (int i = tid; i < (kDW / 2) * srows; i += 256) {
-                const int r = i / (kDW / 2), j = i - r * (kDW / 2);
-                const uint32_t* row32 = reinterpret_cast<const uint32_t*>(S + r * sp) + 2 * j;
+                const int r = (int)(__umul24((uint32_t)i, 1366u) >> 16), j = i - r * (kDW / 2);   // i / 48, exact for i < 2048 (srows <= 38)
+                const uint32_t* row32 = reinterpret_cast<const uint32_t*>(S + __umul24((uint32_t)r, (uint32_t)sp)) + 2 * j;
                 uint32_t e0 = init, o0 = init, e1 = init, o1 = init;
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
@@ -721,8 +738,10 @@ __global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp
     const int row_bytes = a.w * C;
     if constexpr (K > 0) {
         // two output rows per item: they share K - 1 of their K + 1 rows of H
+        static_assert(kDW == 96, "the multiply-shift below divides by 96");
+        uint8_t* tile_dst = dst + (long long)y0 * row_bytes + (long long)x0 * C;   // wave-uniform 64-bit base; per-item offsets are 32-bit
         for (int i = tid; i < kDW * (kMorphTH / 2); i += 256) {
-            const int rp = i / kDW, d = i - rp * kDW;
+            const int rp = (int)(__umul24((uint32_t)i, 683u) >> 16), d = i - rp * kDW;   // i / 96, exact for i < 2048
             const int y = y0 + 2 * rp, fb = x0 * C + 4 * d;
             if (y >= a.h || fb >= row_bytes) continue;
             const uint32_t* h = H + 2 * (2 * rp * kDW + d);
@@ -736,7 +755,7 @@ __global__ __launch_bounds__(256) void morphology_u8_tile_kernel(Morph a, int sp
             for (int j = 0; j < 2; ++j) {
                 if (y + j >= a.h) break;
                 const uint32_t out = __builtin_amdgcn_perm(pk_minmax<DILATE>(mo, ho[j ? K : 0]), pk_minmax<DILATE>(me, he[j ? K : 0]), 0x06020400u);
-                uint8_t* o = dst + (long long)(y + j) * row_bytes + fb;
+                uint8_t* o = tile_dst + (__umul24((uint32_t)(2 * rp + j), (uint32_t)row_bytes) + 4u * (uint32_t)d);
                 if (fb + 4 <= row_bytes) *reinterpret_cast<u32_unaligned*>(o) = out;
                 else for (int b = 0; fb + b < row_bytes; ++b) o[b] = (uint8_t)(out >> (8 * b));
             }
@@ -840,7 +859,8 @@ KH_PYR_ENTRY(kh_pyrdown_f32, float, pyrdown_f32_kernel, (sw + 1) / 2, (sh + 1) /
 int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch,
                       int64_t ss, int64_t ds) {
     static const bool direct = [] { const char* e = getenv("KH_PYR_DIRECT"); return e && e[0] == '1'; }();
-    if (direct) return kh_pyrdown_u8_direct(stream, src, dst, sw, sh, channels, batch, ss, ds);
+    // (rows of 2^24 bytes or more: the tile kernel forms its 32-bit offsets with 24-bit multiplies)
+    if (direct || (int64_t)sw * channels >= (1 << 24)) return kh_pyrdown_u8_direct(stream, src, dst, sw, sh, channels, batch, ss, ds);
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     if (int32_t rc = check_pyr("kh_pyrdown_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
@@ -926,7 +946,8 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     static const bool direct = [] { const char* e = getenv("KH_MORPH_DIRECT"); return e && e[0] == '1'; }();
     const int srows = kMorphTH + kh_ - 1, sp = ((kMorphFW + (kw - 1) * channels + 3) & ~3) + 4;
     const size_t lds = (size_t)srows * sp + (box ? (size_t)srows * kMorphFW * 2 : 0);
-    if (any && !direct && lds <= 150 * 1024 && (int64_t)w * h * channels <= kI32Max - 8) {
+    // (row bytes < 2^24: the tile kernel forms its 32-bit offsets with 24-bit multiplies)
+    if (any && !direct && lds <= 150 * 1024 && (int64_t)w * h * channels <= kI32Max - 8 && (int64_t)w * channels < (1 << 24)) {
         a.tiles = xcd_tiles(cdiv((int64_t)w * channels, kMorphFW), cdiv(h, kMorphTH), (unsigned)batch, cdiv((int64_t)w * channels, kMorphFW) * 4);
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const int32_t rc = channels == 1 ? launch_morph_tile<1>(st, a, box, sp, srows, lds)

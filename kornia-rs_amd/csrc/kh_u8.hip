@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
             __builtin_amdgcn_wave_barrier();  // row consumed before the next one overwrites it
             uint32_t packed = 0;
             if constexpr (MODE == 2) {
-                uint32_t accE = 0, accO = 0;  // bytes (0, 2) and (1, 3) of this lane's dword, 16-bit lanes
+                uint32_t accE = 0x00800080u, accO = 0x00800080u;  // bytes (0, 2) and (1, 3) of this lane's dword, 16-bit lanes; + the rounding halves
 #pragma unroll
                 for (int t = 0; t < K; ++t) {
                     constexpr int base = 4 * D - H * C;       // byte offset of tap 0's window in d[]
@@ -144,19 +144,21 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
                     const uint32_t lo = d[i], hi = d[i + 1 < 2 * D + 1 ? i + 1 : i];
                     const uint32_t selE = (uint32_t)sft | 0x0c00u | ((uint32_t)(sft + 2) << 16) | 0x0c000000u;
                     const uint32_t selO = (uint32_t)(sft + 1) | 0x0c00u | ((uint32_t)(sft + 3) << 16) | 0x0c000000u;
-                    accE += __umul24(__builtin_amdgcn_perm(hi, lo, selE), kx.k[t]);
-                    accO += __umul24(__builtin_amdgcn_perm(hi, lo, selO), kx.k[t]);
+                    accE = mad24(__builtin_amdgcn_perm(hi, lo, selE), kx.k[t], accE);
+                    accO = mad24(__builtin_amdgcn_perm(hi, lo, selO), kx.k[t], accO);
                 }
-                ring[p][0] = ((accE + 0x00800080u) >> 8) & 0x00ff00ffu;
-                ring[p][1] = ((accO + 0x00800080u) >> 8) & 0x00ff00ffu;
-                uint32_t oE = 0, oO = 0;
+                ring[p][0] = (accE >> 8) & 0x00ff00ffu;
+                ring[p][1] = (accO >> 8) & 0x00ff00ffu;
+                // every product goes through mad24 (one v_mad_u32_u24): left as `__umul24(..) + acc` the compiler turned four of the
+                // fourteen vertical products into quarter-rate v_mul_lo_u32 and the rest into mul + add3 (r03 ISA review)
+                uint32_t oE = 0x00800080u, oO = 0x00800080u;
 #pragma unroll
                 for (int i = 0; i < K; ++i) {  // oldest row first
-                    oE += __umul24(ring[(p + 1 + i) % K][0], ky.k[i]);
-                    oO += __umul24(ring[(p + 1 + i) % K][1], ky.k[i]);
+                    oE = mad24(ring[(p + 1 + i) % K][0], ky.k[i], oE);
+                    oO = mad24(ring[(p + 1 + i) % K][1], ky.k[i], oO);
                 }
-                oE = ((oE + 0x00800080u) >> 8) & 0x00ff00ffu;
-                oO = ((oO + 0x00800080u) >> 8) & 0x00ff00ffu;
+                oE = (oE >> 8) & 0x00ff00ffu;
+                oO = (oO >> 8) & 0x00ff00ffu;
                 packed = oE | (oO << 8);
             } else {
 #pragma unroll
@@ -168,10 +170,10 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
                 if constexpr (BINOMIAL) {
                     ring[p][b] = rhadd(rhadd(byte_at(0), byte_at(1)), rhadd(byte_at(1), byte_at(2)));
                 } else {
-                    uint32_t acc = 0;
+                    uint32_t acc = 128u;
 #pragma unroll
-                    for (int t = 0; t < K; ++t) acc += byte_at(t) * kx.k[t];
-                    ring[p][b] = ((acc + 128u) >> 8) & 0xffu;  // `as u8`
+                    for (int t = 0; t < K; ++t) acc = mad24(byte_at(t), kx.k[t], acc);   // byte x u8 tap: 24-bit operands
+                    ring[p][b] = (acc >> 8) & 0xffu;  // `as u8`
                 }
             }
 #pragma unroll
@@ -180,10 +182,10 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
                 if constexpr (BINOMIAL) {
                     o = rhadd(rhadd(ring[(p + 1) % K][b], ring[(p + 2) % K][b]), rhadd(ring[(p + 2) % K][b], ring[p][b]));
                 } else {
-                    uint32_t acc = 0;
+                    uint32_t acc = 128u;
 #pragma unroll
-                    for (int i = 0; i < K; ++i) acc += ring[(p + 1 + i) % K][b] * ky.k[i];  // oldest row first
-                    o = ((acc + 128u) >> 8) & 0xffu;
+                    for (int i = 0; i < K; ++i) acc = mad24(ring[(p + 1 + i) % K][b], ky.k[i], acc);  // oldest row first
+                    o = (acc >> 8) & 0xffu;
                 }
                 packed |= o << (8 * b);
             }
@@ -381,17 +383,6 @@ __device__ __forceinline__ void store_px_u8(uint8_t* o, uint32_t px, bool wave_f
 // and the channels' top bytes are gathered by one or two more v_perm_b32 — six instructions per channel plus two to pack.  The
 // integer is the reference's, operand for operand, so every caller stays byte-exact.
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
-// a * b + c on 24-bit operands in ONE v_mad_u32_u24.  Written as `__umul24(a, b) + c` the compiler merges the two multiply-adds of a
-// channel into mul + mul + add3 (three instructions instead of two): the blend is the inner loop of a VALU-bound kernel.
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
-#ifdef KH_HOSTSIM
-    return __umul24(a, b) + c;
-#else
-    uint32_t d;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-#endif
-}
 // fxp_bits = (1024 - fx) | fx << 16, fy16 = 16 * fy: prepared by the caller (the staged gather keeps them per pixel across images)
 template <int C>
 __device__ __forceinline__ uint32_t blend_q10_w(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uint32_t fxp_bits, uint32_t fy16) {
