@@ -256,6 +256,7 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
 // selects this kernel (even rows of at least 512 floats; tests/test_filter_gpu.py runs it in a child process).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int kTF2 = 2 * kTF;  // flat columns per 256-thread block
+constexpr bool kFourColumnsDefault = true;   // sep_roll4_kernel where it applies: 2-7 % faster than one column per lane on C4, same box, interleaved (profiles/r03k, r03l); KH_FILTER_FOUR_COLUMNS=0 turns it off
 
 template <int K>
 __global__ __launch_bounds__(kBlock) void sep_roll2_kernel(FilterArgs a, TapsK kx, TapsK ky) {
@@ -335,6 +336,105 @@ __global__ __launch_bounds__(kBlock) void sep_roll2_kernel(FilterArgs a, TapsK k
     }
 }
 
+
+// ---- rolling-column kernel, FOUR columns per lane (round 3) -------------------------------------------------------------------
+// A lane owns four adjacent flat columns as a float4: ONE 16-byte global load and ONE 16-byte store per row (1 KiB contiguous per
+// wave instruction — the store granularity that mattered on the north star — and a quarter of the vector-memory instructions of
+// the one-column kernel), the row parked in LDS with one ds_write_b128, the horizontal taps cut out of 2 * ceil(H*C / 4) + 1
+// aligned ds_read_b128 at COMPILE-TIME register offsets (C is a template parameter here), both passes in packed f32 math.  Same
+// IEEE operations in the same order per element as the one-column kernel.  A wave covers 256 columns, a 256-thread block 1024;
+// rows must be a multiple of four floats and 16-byte aligned (host-checked), gradients keep the one-column kernel.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kTF4 = 4 * kTF;  // flat columns per 256-thread block
+
+template <int K, int C>
+__global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK kx, TapsK ky) {
+    constexpr int H = K / 2, HALO = H * C;       // <= 32 (checked on the host)
+    constexpr int HQ = (HALO + 3) / 4;           // halo in float4 chunks
+    constexpr int NCH = 2 * HQ + 1;              // chunks a lane reads per row
+    __shared__ __attribute__((aligned(16))) float rowbuf[4][32 + 256 + 32 + 4];  // left halo | main | right halo | parking slot
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int gx0 = tx * kTF4 + wv * 256;   // first flat column of this wave
+    if (gx0 >= a.rowlen) return;             // whole wave idle (no block barrier below)
+    const int y0 = ty * a.th;
+    const float* __restrict__ src = a.src + (long long)bz * a.src_stride;
+    float* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
+    float* buf = rowbuf[wv];
+
+    const int gx = gx0 + 4 * lane;           // this lane's columns gx .. gx + 3 (rowlen % 4 == 0: all four in or all four out)
+    const bool is_halo = lane < 2 * HALO;    // lanes [0, HALO) fetch the left neighbours, [HALO, 2 HALO) the right ones
+    const int hgx = lane < HALO ? gx0 - HALO + lane : gx0 + 256 + (lane - HALO);
+    const int hslot = lane < HALO ? 32 - HALO + lane : 288 + (lane - HALO);
+    const bool gx_ok = gx < a.rowlen, hgx_ok = is_halo && hgx >= 0 && hgx < a.rowlen;
+    const int nrows = min(a.th, a.rows - y0) + 2 * H;
+    const int cx_m = min(gx, a.rowlen - 4);
+    const int cx_h = is_halo ? min(max(hgx, 0), a.rowlen - 1) : cx_m;
+    int pf_row = y0 - H;
+
+    f32x4_t qm[K];
+    float qh[K];
+    auto prefetch = [&](f32x4_t& m, float& hv) {
+        const int base = min(max(pf_row, 0), a.rows - 1) * a.rowlen;  // 32-bit: host-checked
+        m = *reinterpret_cast<const f32x4_t*>(src + base + cx_m);
+        hv = src[base + cx_h];
+        ++pf_row;
+    };
+#pragma unroll
+    for (int p = 0; p < K; ++p) prefetch(qm[p], qh[p]);
+
+    f32x2_t ring[K][2];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { ring[i][0] = f32x2_t{0.0f, 0.0f}; ring[i][1] = f32x2_t{0.0f, 0.0f}; }
+
+    const int hs = is_halo ? hslot : 320;  // non-halo lanes park their duplicate in a slot nobody reads
+    const __amdgpu_buffer_rsrc_t ow = stream_window(dst + (long long)y0 * a.rowlen, (long long)(a.rows - y0) * a.rowlen * 4);
+    int out_off = (gx - 2 * H * a.rowlen) * 4;
+    const f32x4_t* span_p = reinterpret_cast<const f32x4_t*>(buf + 32 + 4 * lane - 4 * HQ);   // 16-byte aligned
+    constexpr int kOff = 4 * HQ - HALO;       // float index of tap 0 of column 0 inside the span
+    for (int rb = 0; rb < nrows; rb += K) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            const int r = rb + p;
+            const int row = y0 - H + r;
+            const bool row_ok = row >= 0 && row < a.rows;  // wave-uniform
+            const f32x4_t m = (row_ok && gx_ok) ? qm[p] : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            const float hv = (row_ok && hgx_ok) ? qh[p] : 0.0f;
+            prefetch(qm[p], qh[p]);
+            *reinterpret_cast<f32x4_t*>(buf + 32 + 4 * lane) = m;
+            buf[hs] = hv;
+            __builtin_amdgcn_wave_barrier();
+            float span[4 * NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const f32x4_t v = span_p[c];
+                span[4 * c] = v.x; span[4 * c + 1] = v.y; span[4 * c + 2] = v.z; span[4 * c + 3] = v.w;
+            }
+            __builtin_amdgcn_wave_barrier();  // every lane has read the row before it is overwritten
+            f32x2_t h01 = {0.0f, 0.0f}, h23 = {0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const f32x2_t v01 = {span[kOff + i * C], span[kOff + i * C + 1]}, v23 = {span[kOff + i * C + 2], span[kOff + i * C + 3]};
+                h01 += v01 * kx.k[i];   // v_pk_mul_f32 then v_pk_add_f32: two roundings per element, as the reference
+                h23 += v23 * kx.k[i];
+            }
+            ring[p][0] = h01; ring[p][1] = h23;
+            f32x2_t o01 = {0.0f, 0.0f}, o23 = {0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < K; ++i) {  // oldest row first: ascending vertical taps
+                o01 += ring[(p + 1 + i) % K][0] * ky.k[i];
+                o23 += ring[(p + 1 + i) % K][1] * ky.k[i];
+            }
+            if (gx_ok && r >= 2 * H && r < nrows) {
+                const uint32_t bits[4] = {__float_as_uint(o01.x), __float_as_uint(o01.y), __float_as_uint(o23.x), __float_as_uint(o23.y)};
+                stream_store<4>(ow, out_off, bits);
+            }
+            out_off += a.rowlen * 4;
+        }
+    }
+}
+
 // tuning knob (dev): KH_FILTER_STRIP = output rows per strip
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -344,6 +444,16 @@ int env_int(const char* name, int dflt) {
 template <int K>
 void launch_roll2(hipStream_t st, dim3 grid, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
     hipLaunchKernelGGL((sep_roll2_kernel<K>), grid, dim3(kBlock), 0, st, a, kx, ky);
+}
+
+template <int K>
+bool launch_roll4(hipStream_t st, dim3 grid, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
+    switch (a.C) {
+        case 1: hipLaunchKernelGGL((sep_roll4_kernel<K, 1>), grid, dim3(kBlock), 0, st, a, kx, ky); return true;
+        case 3: hipLaunchKernelGGL((sep_roll4_kernel<K, 3>), grid, dim3(kBlock), 0, st, a, kx, ky); return true;
+        case 4: hipLaunchKernelGGL((sep_roll4_kernel<K, 4>), grid, dim3(kBlock), 0, st, a, kx, ky); return true;
+        default: return false;
+    }
 }
 
 template <int K>
@@ -407,7 +517,14 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         const bool two_cols = two_env && two_env[0] == '1';
         const bool two = !grad && two_cols && (a.rowlen % 2 == 0) && a.rowlen >= kTF2 && (reinterpret_cast<uintptr_t>(src) % 8 == 0) &&
                          (batch == 1 || ss % 2 == 0);
-        const unsigned tiles_x = cdiv(a.rowlen, two ? kTF2 : kTF);  // 256-thread blocks: 512 measured +1 %, 1024 +9 % (r01q)
+        // KH_FILTER_FOUR_COLUMNS (dev / test knob, read per call): four columns per lane (sep_roll4_kernel) for K <= 9, C in {1, 3, 4},
+        // rows that are a multiple of four floats and fill one 1024-column block, 16-byte aligned images.
+        const char* four_env = getenv("KH_FILTER_FOUR_COLUMNS");
+        const bool four_cols = four_env ? four_env[0] == '1' : kFourColumnsDefault;
+        const bool four = !grad && !two && four_cols && K <= 9 && (C == 1 || C == 3 || C == 4) && (a.rowlen % 4 == 0) && a.rowlen >= kTF4 &&
+                          (reinterpret_cast<uintptr_t>(src) % 16 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
+                          (batch == 1 || (ss % 4 == 0 && ds % 4 == 0));
+        const unsigned tiles_x = cdiv(a.rowlen, four ? kTF4 : (two ? kTF2 : kTF));  // 256-thread blocks: 512 measured +1 %, 1024 +9 % (r01q)
         // Strip height: tall strips amortise the ky-1 warm-up rows (4K x 256 images: 360 rows is
         // 5 % faster than 90), short strips keep a small launch wide enough to fill 256 CUs.
         {
@@ -421,6 +538,15 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const dim3 grid = xcd_grid(a.tiles);
         hipStream_t st = as_hip(stream);
+        if (four) {
+            switch (K) {
+                case 3: launch_roll4<3>(st, grid, a, px, py); break;
+                case 5: launch_roll4<5>(st, grid, a, px, py); break;
+                case 7: launch_roll4<7>(st, grid, a, px, py); break;
+                default: launch_roll4<9>(st, grid, a, px, py); break;
+            }
+            return check_launch(what);
+        }
         if (two) {
             switch (K) {
                 case 3: launch_roll2<3>(st, grid, a, px, py); break;

@@ -66,12 +66,14 @@ def test_non_finite_pixels_poison_only_their_own_window(gpu_stream, ks):
     assert_same_bits(np.nan_to_num(got, nan=7.0, posinf=8.0, neginf=9.0), np.nan_to_num(want, nan=7.0, posinf=8.0, neginf=9.0), f"non-finite {ks}")
 
 
-@pytest.fixture(params=["roll", "roll2", "tile"])
+@pytest.fixture(params=["roll", "roll2", "roll4", "tile"])
 def kernel_path(request, monkeypatch):
-    """The three device kernels behind the filter entry points: the rolling-column fast path, its two-columns-per-lane variant
-    (KH_FILTER_TWO_COLUMNS=1; rows of even length >= 512 floats) and the LDS-tile kernel (KH_FILTER_FORCE_TILE=1)."""
+    """The device kernels behind the filter entry points: the rolling-column fast path, its two- and four-columns-per-lane variants
+    (KH_FILTER_TWO_COLUMNS=1: rows of even length >= 512 floats; KH_FILTER_FOUR_COLUMNS=1: rows of a multiple of four floats >= 1024,
+    kernels up to 9 taps) and the LDS-tile kernel (KH_FILTER_FORCE_TILE=1)."""
     monkeypatch.delenv("KH_FILTER_FORCE_TILE", raising=False)
     monkeypatch.delenv("KH_FILTER_TWO_COLUMNS", raising=False)
+    monkeypatch.setenv("KH_FILTER_FOUR_COLUMNS", "1" if request.param == "roll4" else "0")
     if request.param == "tile":
         monkeypatch.setenv("KH_FILTER_FORCE_TILE", "1")
     elif request.param == "roll2":
@@ -84,7 +86,7 @@ def kernel_path(request, monkeypatch):
                                 ((13, 3), (2.5, 0.0)), ((17, 17), (3.0, 3.0)), ((31, 5), (6.0, 1.0))])
 def test_both_kernels_match_oracle(gpu_stream, kernel_path, c, ks):
     (kx, ky), (sx, sy) = ks
-    for (w, h) in [(67, 43), (300, 200), (64, 91), (1030, 37)]:
+    for (w, h) in [(67, 43), (300, 200), (64, 91), (1030, 37), (1028, 37), (344, 50), (2052, 9)]:
         src = img(w, h, c, seed=3)
         got = run(gpu_stream, "kh_gaussian_blur_f32", src, kx, ky, sx, sy)
         assert_same_bits(got, O.gaussian_blur(src, (kx, ky), (sx, sy)), f"{kernel_path} {w}x{h} c{c} k{kx}x{ky}")
