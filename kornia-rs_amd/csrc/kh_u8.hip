@@ -204,6 +204,146 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
     }
 }
 
+
+// ---- RGB8 blur, planar in registers (round 3) --------------------------------------------------------------------------------
+// blur_u8_roll_kernel above is completely VALU-bound (r03h: 72 vector instructions per 4 bytes, the vector ALUs 101 % busy): with
+// interleaved RGB the horizontal taps of a byte sit 3 bytes apart, so every (two-byte, tap) product costs a v_perm_b32 to gather the
+// bytes and a multiply-add — 7 instructions per byte for a 7-tap row pass.  De-interleaved, the taps of a channel are ADJACENT bytes
+// and v_dot4_u32_u8 takes four of them per instruction:
+//   * a lane owns FOUR PIXELS (12 bytes = 3 dwords, one 768-byte contiguous wave-load per row), de-interleaves them into one dword
+//     per channel (6 v_perm_b32) and gets its left / right neighbours' channel dwords by two wave shifts per channel (ds_bpermute:
+//     an LDS-crossbar instruction, not a vector-ALU one) — no LDS row buffer at all; lanes 0 and 63 are halo lanes (248 output
+//     pixels per wave);
+//   * horizontal pass per channel: the (up to 9) taps of output pixel j are bytes j + 4 - H ... of the 12-byte (prev, cur, next)
+//     string, taken four at a time: 6 v_alignbyte_b32 + 8 v_dot4_u32_u8 per 4 outputs for K = 7 (3.5 instructions per byte
+//     instead of 7), the rounding half in the accumulator operand;
+//   * the four sums of a channel go into the 16-bit-lane pair form ((s0 >> 8) | (s2 >> 8) << 16 — one v_perm_b32 each, the sums are
+//     < 2^16) that the vertical pass of the old kernel uses: K single-instruction 24-bit multiply-adds per pair;
+//   * results are re-interleaved with 9 v_perm_b32 and leave as one 12-byte store.
+// Replicate borders: rows by clamping the row index; columns (waves that touch the first / last pixel only, wave-uniform) by
+// loading the quad from a clamped position and re-indexing its pixels with ONE per-lane byte selector per channel.
+// Same integers as the reference's two u8 passes ((acc + 128) >> 8 after each): byte-identical to the old kernel (tests run both).
+// For 3-channel images, 3..9 taps per axis whose quantised taps sum to <= 256 (every gaussian / box kernel), rows of >= 4 pixels.
+constexpr int kRgbWavePx = 248;                 // output pixels per wave (62 lanes x 4)
+constexpr int kRgbTilePx = 4 * kRgbWavePx;      // per 256-thread block
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void blur_u8_rgb_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky) {
+    constexpr int H = K / 2, G = (K + 3) / 4;   // taps are consumed four at a time
+    static_assert(K >= 3 && K <= 9 && (K & 1), "3..9 taps: one neighbour quad on each side covers the window");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int p0 = (int)tx * kRgbTilePx + wv * kRgbWavePx;   // first output pixel of this wave
+    if (p0 >= a.cols) return;                               // whole wave idle (no block barrier below)
+    const int y0 = ty * a.th;
+    const uint8_t* __restrict__ src = a.src + (long long)bz * a.src_stride;
+    uint8_t* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
+    const int p = p0 - 4 + 4 * lane;                        // this lane's quad: pixels p .. p + 3 (lane 0 / 63: halo quads)
+    const bool edge = p0 < 4 || p0 + kRgbWavePx + 4 > a.cols;   // wave-uniform: some quad of the wave needs clamping
+    const int pc = min(max(p, 0), a.cols - 4);              // where the quad is loaded from (cols >= 4: host-checked)
+    // per-lane byte selector that re-indexes the loaded quad's pixels when the quad was clamped: pixel j <- loaded pixel
+    // clamp(p + j, 0, cols - 1) - pc  (0x03020100 = identity)
+    uint32_t esel = 0x03020100u;
+    if (edge) {
+        esel = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) esel |= (uint32_t)(min(max(p + j, 0), a.cols - 1) - pc) << (8 * j);
+    }
+    const bool writer = lane >= 1 && lane <= 62 && p < a.cols;
+    const bool full = p + 3 < a.cols;
+    const int nrows = min(a.th, a.rows - y0) + 2 * H;
+    int pf_row = y0 - H;
+
+    uint32_t wq[3];   // horizontal taps as bytes, four per dword (zero padded): tap t = byte t & 3 of wq[t >> 2]
+#pragma unroll
+    for (int g = 0; g < 3; ++g) wq[g] = kx.k[4 * g] | (kx.k[4 * g + 1] << 8) | (kx.k[4 * g + 2] << 16) | (kx.k[4 * g + 3] << 24);
+
+    uint32_t q[K][3];  // K rows of raw loads in flight per lane
+    auto prefetch = [&](uint32_t (&d)[3]) {
+        const uint8_t* rp = src + (long long)min(max(pf_row, 0), a.rows - 1) * a.rowlen + 3 * pc;   // replicate rows
+        d[0] = *reinterpret_cast<const u32u*>(rp); d[1] = *reinterpret_cast<const u32u*>(rp + 4); d[2] = *reinterpret_cast<const u32u*>(rp + 8);
+        ++pf_row;
+    };
+#pragma unroll
+    for (int i = 0; i < K; ++i) prefetch(q[i]);
+
+    uint32_t ring[K][3][2];  // [row][channel][even / odd pixel pair], 16-bit lanes
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ring[i][c][0] = 0; ring[i][c][1] = 0; }
+
+    long long out_off = (long long)(y0 - 2 * H) * a.rowlen + 3 * p;
+    for (int rb = 0; rb < nrows; rb += K) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const int r = rb + s;
+            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2];
+            prefetch(q[s]);
+            // de-interleave: [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3] -> one dword per channel, pixel j = byte j
+            uint32_t cur[3];
+            cur[0] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c060300u), 0x05020100u);   // d0.b0 d0.b3 d1.b2 d2.b1
+            cur[1] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);   // d0.b1 d1.b0 d1.b3 d2.b2
+            cur[2] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);   // d0.b2 d1.b1 d2.b0 d2.b3
+            if (edge) {   // wave-uniform
+#pragma unroll
+                for (int c = 0; c < 3; ++c) cur[c] = __builtin_amdgcn_perm(0u, cur[c], esel);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t prev = (uint32_t)__shfl_up((int)cur[c], 1), next = (uint32_t)__shfl_down((int)cur[c], 1);
+                const uint32_t str[4] = {prev, cur[c], next, next};   // bytes 0..11 = pixels p - 4 .. p + 7 of this channel (+ a don't-care dword)
+                uint32_t sum[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t acc = 128u;   // the reference's rounding half
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        constexpr int kBase = 4 - H;
+                        const int off = kBase + j + 4 * g;   // compile-time after unrolling: first byte of this group of four taps
+                        const uint32_t win = (off & 3) == 0 ? str[off >> 2] : __builtin_amdgcn_alignbyte(str[(off >> 2) + 1], str[off >> 2], (uint32_t)(off & 3));
+                        acc = __builtin_amdgcn_udot4(win, wq[g], acc, false);
+                    }
+                    sum[j] = acc;   // < 2^16: the taps sum to <= 256
+                }
+                // (sum >> 8) of pixels (0, 2) and (1, 3) into 16-bit lanes: byte 1 of each sum
+                ring[s][c][0] = __builtin_amdgcn_perm(sum[2], sum[0], 0x0c050c01u);
+                ring[s][c][1] = __builtin_amdgcn_perm(sum[3], sum[1], 0x0c050c01u);
+            }
+            uint32_t pl[3];   // vertical pass, then one dword per channel again (pixel j = byte j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                uint32_t oe = 0x00800080u, oo = 0x00800080u;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {   // oldest row first
+                    oe = mad24(ring[(s + 1 + i) % K][c][0], ky.k[i], oe);
+                    oo = mad24(ring[(s + 1 + i) % K][c][1], ky.k[i], oo);
+                }
+                pl[c] = __builtin_amdgcn_perm(oo, oe, 0x07030501u);   // (oe.b1, oo.b1, oe.b3, oo.b3) = pixels 0, 1, 2, 3
+            }
+            if (writer && r >= 2 * H && r < nrows) {
+                // re-interleave: [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3]
+                const uint32_t rg = __builtin_amdgcn_perm(pl[1], pl[0], 0x05010400u);   // R0 G0 R1 G1
+                const uint32_t rg2 = __builtin_amdgcn_perm(pl[1], pl[0], 0x07030602u); // R2 G2 R3 G3
+                const uint32_t w0 = __builtin_amdgcn_perm(pl[2], rg, 0x02040100u);      // R0 G0 B0 R1
+                const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2], rg, 0x0c0c0503u), rg2, 0x01000504u);   // G1 B1 | R2 G2
+                const uint32_t w2 = __builtin_amdgcn_perm(pl[2], rg2, 0x07030206u);     // B2 R3 G3 B3
+                uint8_t* o = dst + out_off;
+                if (full) {
+                    *reinterpret_cast<u32u*>(o) = w0; *reinterpret_cast<u32u*>(o + 4) = w1; *reinterpret_cast<u32u*>(o + 8) = w2;
+                } else {
+                    const uint32_t w[3] = {w0, w1, w2};
+#pragma unroll
+                    for (int b = 0; b < 9; ++b)   // at most three pixels of a quad that reaches past the last column
+                        if (p + b / 3 < a.cols) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                }
+            }
+            out_off += a.rowlen;
+        }
+    }
+}
+
 // Fallback for what the rolling kernel does not take (kernels wider than 15 taps, halos beyond 32
 // bytes, rows shorter than 4 bytes): one Q8 pass per launch through a scratch image, one thread per
 // byte — the reference's own structure (P/cuda/filter.rs:116-165).
@@ -275,7 +415,11 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         U8FilterArgs a;
         a.src = src; a.dst = dst; a.rows = rows; a.rowlen = rowlen; a.cols = cols;
         a.src_stride = ss; a.dst_stride = ds;
-        const unsigned tiles_x = cdiv(rowlen, kU8Tile);
+        unsigned sxq = 0, syq = 0;
+        for (int i = 0; i < 16; ++i) { sxq += px.k[i]; syq += py.k[i]; }
+        static const bool rgb_off = [] { const char* e = getenv("KH_U8_BLUR_RGB"); return e && e[0] == '0'; }();   // dev / test knob: the interleaved kernel
+        const bool rgb = C == 3 && K <= 9 && !binomial && sxq <= 256 && syq <= 256 && cols >= 4 && !rgb_off;
+        const unsigned tiles_x = rgb ? cdiv(cols, kRgbTilePx) : cdiv(rowlen, kU8Tile);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;  // >= 8 blocks per CU
         const long long min_strips = cdiv(rows, kU8StripMax), max_strips = cdiv(rows, 32);
@@ -283,6 +427,16 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         a.th = (int)cdiv(rows, strips);
         a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch, kXcdEighth);
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        if (rgb) {
+            const dim3 grid = xcd_grid(a.tiles);
+            switch (K) {
+                case 3: hipLaunchKernelGGL(blur_u8_rgb_kernel<3>, grid, dim3(kBlock), 0, st, a, px, py); break;
+                case 5: hipLaunchKernelGGL(blur_u8_rgb_kernel<5>, grid, dim3(kBlock), 0, st, a, px, py); break;
+                case 7: hipLaunchKernelGGL(blur_u8_rgb_kernel<7>, grid, dim3(kBlock), 0, st, a, px, py); break;
+                default: hipLaunchKernelGGL(blur_u8_rgb_kernel<9>, grid, dim3(kBlock), 0, st, a, px, py); break;
+            }
+            return check_launch(what);
+        }
         switch (K) {
             case 3: launch_blur_k<3>(st, C, binomial, a, px, py); break;
             case 5: launch_blur_k<5>(st, C, false, a, px, py); break;

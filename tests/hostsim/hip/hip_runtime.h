@@ -50,6 +50,9 @@ inline void __syncthreads() { hostsim::block_barrier(); }
 #define __builtin_amdgcn_wave_barrier() hostsim::wave_barrier()
 inline int __shfl(int v, int lane) { return (int)hostsim::shfl_bits((uint32_t)v, lane); }
 inline int __shfl_xor(int v, int mask) { return (int)hostsim::shfl_bits((uint32_t)v, hostsim::lane_id() ^ mask); }
+// HIP: lanes whose source falls outside the wave keep their own value
+inline int __shfl_up(int v, unsigned delta) { const int l = hostsim::lane_id(), s = l - (int)delta; return (int)hostsim::shfl_bits((uint32_t)v, s >= 0 ? s : l); }
+inline int __shfl_down(int v, unsigned delta) { const int l = hostsim::lane_id(), s = l + (int)delta; return (int)hostsim::shfl_bits((uint32_t)v, s < 64 ? s : l); }
 inline float __shfl_xor(float v, int mask) {
     uint32_t b;
     memcpy(&b, &v, 4);
@@ -78,6 +81,8 @@ inline uint32_t hostsim_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
 #define __builtin_amdgcn_perm(a, b, sel) hostsim_perm((a), (b), (sel))
 #define __builtin_amdgcn_alignbyte(hi, lo, s) ((uint32_t)(((((uint64_t)(uint32_t)(hi)) << 32) | (uint32_t)(lo)) >> (8 * ((s) & 3))))
 #define __builtin_amdgcn_sdot2(a, b, c, clamp) ((int)((c) + (int)(a)[0] * (int)(b)[0] + (int)(a)[1] * (int)(b)[1]))
+#define __builtin_amdgcn_udot4(a, b, c, clamp) ((uint32_t)((c) + ((uint32_t)(a) & 0xffu) * ((uint32_t)(b) & 0xffu) + (((uint32_t)(a) >> 8) & 0xffu) * (((uint32_t)(b) >> 8) & 0xffu) + \
+                                                          (((uint32_t)(a) >> 16) & 0xffu) * (((uint32_t)(b) >> 16) & 0xffu) + ((uint32_t)(a) >> 24) * ((uint32_t)(b) >> 24)))
 #define __builtin_amdgcn_udot2(a, b, c, clamp) ((uint32_t)((c) + (uint32_t)(a)[0] * (uint32_t)(b)[0] + (uint32_t)(a)[1] * (uint32_t)(b)[1]))
 #define __builtin_amdgcn_readfirstlane(v) (v)  /* only ever applied to wave-uniform values */
 // raw buffer accesses: base + soffset + voffset, dropped / zero when voffset + size runs past num_records (the hardware range check)

@@ -53,7 +53,11 @@ def test_north_star_workloads(gpu_stream, bench, name, size):
     for k in range(wl.N):
         raw = wl.base[31 * k: 31 * k + wl.frame_bytes]
         want = O.preprocess(raw, wl.W, wl.H, ow, oh, fmt="nv12", mode="stretch" if size == 0 else "letterbox", mean=MEAN, std=STD)[0]
-        assert np.array_equal(got[k], want), (name, k)
+        if not np.array_equal(got[k], want):   # say where: a hole of zeros / stale bytes (a copy problem) looks different from wrong arithmetic
+            bad = np.argwhere(got[k].view(np.uint32) != want.view(np.uint32))
+            flat = np.flatnonzero(got[k].view(np.uint32).reshape(-1) != want.view(np.uint32).reshape(-1))
+            raise AssertionError(f"{name} frame {k}: {len(bad)} of {want.size} words differ; first {bad[0].tolist()} last {bad[-1].tolist()}; flat span "
+                                 f"[{flat[0]}, {flat[-1]}]; got {got[k].reshape(-1)[flat[:4]].tolist()} want {want.reshape(-1)[flat[:4]].tolist()}")
 
 
 def test_lanczos_secondary_workload(gpu_stream, bench):
