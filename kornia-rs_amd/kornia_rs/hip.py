@@ -10,6 +10,7 @@ they are the protocol names torch-ROCm and cupy-ROCm speak.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Any, Optional, Tuple
 
 import numpy as np
@@ -229,16 +230,59 @@ class Graph:
             lib.kh_graph_destroy(h)
 
 
+_STAGE_BYTES = 16 << 20
+_stage_local = threading.local()
+
+
+def _stage() -> "PinnedBuffer":
+    """This thread's page-locked bounce buffer for pageable host <-> device copies (16 MiB, allocated on first use, freed with the
+    thread).  Per thread: the sharders upload from one worker thread per device at the same time."""
+    buf = getattr(_stage_local, "buf", None)
+    if buf is None:
+        buf = _stage_local.buf = PinnedBuffer(_STAGE_BYTES)
+    return buf
+
+
 def d2h(out: np.ndarray, device_ptr: int, stream: Stream) -> None:
-    """Device -> pageable host copy (to_host, crates/kornia-tensor/src/cuda.rs:1258-1300).
-    The stream is drained BEFORE the copy as well as after it: a pageable destination lets the
-    runtime service small copies from the host side, and we observed such copies overtaking
-    kernels still queued on the stream (stale reads) on ROCm 7.2 / gfx950."""
+    """Device -> pageable host copy (to_host, crates/kornia-tensor/src/cuda.rs:1258-1300), staged through page-locked memory in
+    16 MiB pieces: every transfer the runtime sees is a true stream-ordered DMA into pinned memory, followed by a host memcpy.
+    Handing the runtime a large PAGEABLE destination instead was seen to complete `hipStreamSynchronize` with a hole in the data
+    (round 1: a 4 - 16 MiB run of stale bytes in a 48 MiB copy; once more in round 3 under four concurrent processes, r03m, with a
+    single HIP runtime mapped) and small pageable copies were seen overtaking kernels queued on the stream — neither can happen to
+    a pinned DMA.  The stream is drained before the first piece (the producer kernels) and after every piece (the bounce buffer is
+    reused)."""
     if out.nbytes == 0:
         return
+    flat = out.reshape(-1).view(np.uint8) if out.flags["C_CONTIGUOUS"] else None
+    if flat is None:
+        tmp = np.empty(out.shape, out.dtype)
+        d2h(tmp, device_ptr, stream)
+        out[...] = tmp
+        return
+    stage = _stage()
+    view = stage.view()
     stream.synchronize()
-    check(lib.kh_memcpy_d2h_async(out.ctypes.data, device_ptr, out.nbytes, stream.cuda_stream_ptr))
-    stream.synchronize()
+    for off in range(0, flat.size, _STAGE_BYTES):
+        n = min(_STAGE_BYTES, flat.size - off)
+        check(lib.kh_memcpy_d2h_async(stage.ptr, device_ptr + off, n, stream.cuda_stream_ptr))
+        stream.synchronize()
+        flat[off:off + n] = view[:n]
+
+
+def h2d(device_ptr: int, a: np.ndarray, stream: Stream) -> None:
+    """Pageable host -> device copy through the same page-locked bounce buffer (see d2h)."""
+    a = np.ascontiguousarray(a)
+    if a.nbytes == 0:
+        return
+    flat = a.reshape(-1).view(np.uint8)
+    stage = _stage()
+    view = stage.view()
+    stream.synchronize()   # a queued memset / kernel on this stream must not be overtaken
+    for off in range(0, flat.size, _STAGE_BYTES):
+        n = min(_STAGE_BYTES, flat.size - off)
+        view[:n] = flat[off:off + n]
+        check(lib.kh_memcpy_h2d_async(device_ptr + off, stage.ptr, n, stream.cuda_stream_ptr))
+        stream.synchronize()   # the bounce buffer is reused by the next piece / the next call
 
 
 def _stream_handle(stream: Optional[Stream]) -> int:
@@ -336,12 +380,7 @@ class DeviceBuffer:
         assert offset + a.nbytes <= self.nbytes
         if a.nbytes == 0:
             return
-        # Pageable source: drain first (a host-serviced copy must not overtake a queued memset /
-        # kernel on this stream, see d2h) and after (the runtime may still be reading `a`).
-        self.stream.synchronize()
-        check(lib.kh_memcpy_h2d_async(self.ptr + offset, a.ctypes.data, a.nbytes,
-                                      self.stream.cuda_stream_ptr))
-        self.stream.synchronize()
+        h2d(self.ptr + offset, a, self.stream)   # pageable source: through the page-locked bounce buffer
 
     def to_numpy(self, dtype, shape, offset: int = 0) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
