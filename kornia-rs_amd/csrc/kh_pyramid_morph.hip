@@ -13,6 +13,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "kh_common.h"
 
 using namespace kh;
@@ -413,6 +415,133 @@ __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
         for (int px = 0; X + px < a.dw; ++px)
 #pragma unroll
             for (int c = 0; c < C; ++c) op[px * C + c] = (uint8_t)o[px][c];
+    }
+}
+
+
+// ---- pyrdown_u8 for RGB8, rolling wave, planar in registers (round 3) -----------------------------------------------------------
+// pyrdown_u8_tile_kernel above is latency-bound (r02zp: vector ALUs 34 - 40 % busy, LDS 11 %, every wave slot taken, ~3 TB/s): its
+// blocks load, barrier, compute, barrier, store.  This kernel has the structure of the round-3 u8 blur (kh_u8.hip,
+// blur_u8_rgb_kernel): a WAVE walks down a strip with five source rows of loads in flight and no barrier at all; a lane owns EIGHT
+// source pixels (24 bytes = two 12-byte quads; a 1.5 KB contiguous wave-load per row), de-interleaves them into two dwords per
+// channel, takes the two border pixels of its neighbours by wave shifts, and runs the reference's [1 4 6 4 1] row pass on ADJACENT
+// bytes with v_dot4_u32_u8 — 8 dot4 + 2 alignbyte per channel for its four destination pixels — into 16-bit lanes (<= 4080, the
+// reference's u16 intermediate); the column pass is the same packed 16-bit arithmetic as the tile kernel (binomial5) on a five-row
+// register ring, every second source row; four destination pixels leave as one 12-byte store.  reflect-101 borders: rows by
+// reflecting the row index, columns (edge waves only) by loading the eight pixels from a clamped position and re-indexing them with
+// one per-lane byte selector pair.  Same integers as the per-pixel kernel: byte-identical (tests run both).  RGB8, sw >= 8.
+constexpr int kPdRollWaveDst = 248;                  // destination pixels per wave (62 lanes x 4)
+constexpr int kPdRollTileDst = 4 * kPdRollWaveDst;   // per 256-thread block
+struct PyrRoll {
+    const uint8_t* src;
+    uint8_t* dst;
+    int sw, sh, dw, dh, th;   // th = destination rows per strip
+    long long ss, ds;
+    XcdTiles tiles;
+};
+
+__global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int X0 = (int)tx * kPdRollTileDst + wv * kPdRollWaveDst;   // first destination pixel of this wave
+    if (X0 >= a.dw) return;                                           // whole wave idle (no block barrier below)
+    const int Y0 = ty * a.th, thr = min(a.th, a.dh - Y0);
+    const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
+    uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
+    const int p = 2 * X0 - 8 + 8 * lane;                              // this lane's source pixels p .. p + 7 (lanes 0 / 63: halos)
+    const bool edge = 2 * X0 < 8 || 2 * X0 + 2 * kPdRollWaveDst + 8 > a.sw;   // wave-uniform: some lane's pixels need re-indexing
+    const int pc = min(max(p, 0), a.sw - 8);                          // where the eight pixels are loaded from (sw >= 8: host-checked)
+    uint32_t selA = 0x03020100u, selB = 0x07060504u;                  // pixel j <- loaded pixel reflect_101(p + j) - pc (identity inside)
+    if (edge) {
+        selA = selB = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            selA |= (uint32_t)min(max(reflect_101(p + j, a.sw) - pc, 0), 7) << (8 * j);
+            selB |= (uint32_t)min(max(reflect_101(p + 4 + j, a.sw) - pc, 0), 7) << (8 * j);
+        }
+    }
+    const int X = X0 - 4 + 4 * lane;                                  // this lane's destination pixels X .. X + 3
+    const bool writer = lane >= 1 && lane <= 62 && X < a.dw;
+    const bool full = X + 3 < a.dw;
+    const int rowb = a.sw * 3;
+    const int n = 2 * thr + 3;                                        // source rows walked: 2 Y0 - 2 .. 2 (Y0 + thr - 1) + 2
+    int pf = 2 * Y0 - 2;
+
+    uint32_t q[5][6];  // five rows of raw loads in flight per lane
+    auto prefetch = [&](uint32_t (&d)[6]) {
+        const uint8_t* rp = src + (long long)reflect_101(pf, a.sh) * rowb + 3 * pc;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = *reinterpret_cast<const u32_unaligned*>(rp + 4 * k);
+        ++pf;
+    };
+#pragma unroll
+    for (int i = 0; i < 5; ++i) prefetch(q[i]);
+
+    u16x2_t ring[5][3][2];   // [row][channel][destination pixel pair]: the row pass, 16-bit lanes
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ring[i][c][0] = u16x2_t{0, 0}; ring[i][c][1] = u16x2_t{0, 0}; }
+
+    long long out_off = (long long)Y0 * a.dw * 3 + 3 * X;
+    for (int ib = 0; ib < n; ib += 10) {   // 10 = lcm(ring depth, row parity): ring slots and the emit test are compile-time
+#pragma unroll
+        for (int s = 0; s < 10; ++s) {
+            const int i = ib + s, slot = s % 5;
+            uint32_t d[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d[k] = q[slot][k];
+            prefetch(q[slot]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                // de-interleave: quad [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3] -> one dword per channel (pixel j = byte j), twice
+                constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
+                uint32_t A = __builtin_amdgcn_perm(d[2], __builtin_amdgcn_perm(d[1], d[0], in1[c]), in2[c]);
+                uint32_t B = __builtin_amdgcn_perm(d[5], __builtin_amdgcn_perm(d[4], d[3], in1[c]), in2[c]);
+                if (edge) {   // wave-uniform
+                    const uint32_t a0 = A, b0 = B;
+                    A = __builtin_amdgcn_perm(b0, a0, selA);
+                    B = __builtin_amdgcn_perm(b0, a0, selB);
+                }
+                const uint32_t prevB = (uint32_t)__shfl_up((int)B, 1), nextA = (uint32_t)__shfl_down((int)A, 1);
+                constexpr uint32_t kW = 0x04060401u;   // taps 1 4 6 4 on four adjacent bytes; the fifth tap (1) is a second dot4
+                const uint32_t h0 = __builtin_amdgcn_udot4(A, 0x00010000u, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A, prevB, 2), kW, 0u, false), false);
+                const uint32_t h1 = __builtin_amdgcn_udot4(B, 0x00000001u, __builtin_amdgcn_udot4(A, kW, 0u, false), false);
+                const uint32_t h2 = __builtin_amdgcn_udot4(B, 0x00010000u, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 2), kW, 0u, false), false);
+                const uint32_t h3 = __builtin_amdgcn_udot4(nextA, 0x00000001u, __builtin_amdgcn_udot4(B, kW, 0u, false), false);
+                ring[slot][c][0] = as_u16x2(h0 | (h1 << 16));   // <= 4080 each
+                ring[slot][c][1] = as_u16x2(h2 | (h3 << 16));
+            }
+            if ((s & 1) == 0 && i >= 4 && i < n) {   // source row 2 Y + 2 is in: destination row Y = Y0 + (i - 4) / 2
+                uint32_t v[3][2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u16x2_t half = {128, 128}, eight = {8, 8}, top = {255, 255};
+                        const u16x2_t b5 = binomial5(ring[(s + 1) % 5][c][h], ring[(s + 2) % 5][c][h], ring[(s + 3) % 5][c][h], ring[(s + 4) % 5][c][h], ring[slot][c][h]);
+                        v[c][h] = as_u32(__builtin_elementwise_min((b5 + half) >> eight, top));   // pixels (2h, 2h + 1) in bytes 0 and 2
+                    }
+                if (writer) {
+                    const uint32_t rg01 = __builtin_amdgcn_perm(v[1][0], v[0][0], 0x06020400u);   // R0 G0 R1 G1
+                    const uint32_t rg23 = __builtin_amdgcn_perm(v[1][1], v[0][1], 0x06020400u);   // R2 G2 R3 G3
+                    const uint32_t w0 = __builtin_amdgcn_perm(v[2][0], rg01, 0x02040100u);        // R0 G0 B0 R1
+                    const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[2][0], rg01, 0x0c0c0603u), rg23, 0x01000504u);   // G1 B1 | R2 G2
+                    const uint32_t w2 = __builtin_amdgcn_perm(v[2][1], rg23, 0x06030204u);        // B2 R3 G3 B3
+                    uint8_t* o = dst + out_off;
+                    if (full) {
+                        *reinterpret_cast<u32_unaligned*>(o) = w0; *reinterpret_cast<u32_unaligned*>(o + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + 8) = w2;
+                    } else {
+                        const uint32_t w[3] = {w0, w1, w2};
+#pragma unroll
+                        for (int b = 0; b < 9; ++b)   // at most three pixels of a quad that reaches past the last destination column
+                            if (X + b / 3 < a.dw) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                    }
+                }
+                out_off += (long long)a.dw * 3;
+            }
+        }
     }
 }
 
@@ -864,6 +993,21 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     if (int32_t rc = check_pyr("kh_pyrdown_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
+    static const bool no_roll = [] { const char* e = getenv("KH_PYR_ROLL"); return e && e[0] == '0'; }();   // dev / test knob: the tile kernel
+    if (channels == 3 && sw >= 8 && !no_roll) {   // RGB8: the rolling planar kernel
+        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
+        const unsigned tiles_x = cdiv(dw, kPdRollTileDst);
+        const long long cols_blocks = (long long)tiles_x * batch;
+        long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
+        const long long min_strips = cdiv(dh, 360), max_strips = cdiv(dh, 16);
+        strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
+        r.th = (int)cdiv(dh, strips);
+        if (const char* e = getenv("KH_PYR_STRIP"); e && *e) r.th = std::max(1, atoi(e));   // dev knob: destination rows per strip
+        r.tiles = xcd_tiles(tiles_x, cdiv(dh, r.th), (unsigned)batch, kXcdEighth);
+        KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrdown_u8: batch x tiles exceeds one launch");
+        hipLaunchKernelGGL(pyrdown_u8_rgb_roll_kernel, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+        return check_launch("kh_pyrdown_u8");
+    }
     Pyr<uint8_t> a{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kPdTW), cdiv(dh, kPdTH), (unsigned)batch, cdiv(dw, kPdTW) * 4)};
     KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrdown_u8: batch x tiles exceeds one launch");
     const dim3 blk(256), grid = xcd_grid(a.tiles);

@@ -43,7 +43,7 @@ def test_pyramid_matches_oracle(gpu_stream, dtype, c, up):
 def test_pyrdown_u8_tiled_interior_and_edge_tiles(gpu_stream, c):
     """Sizes that give the tiled pyrdown_u8 kernel (64 x 16 destination pixels per block) interior tiles (dword window loads),
     interior tiles whose last window ends exactly on the image's last bytes, and ragged right / bottom tiles."""
-    for w, h in [(520, 140), (260, 65), (259, 65), (261, 66), (262, 67), (265, 66), (267, 65), (513, 33), (390, 130)]:
+    for w, h in [(520, 140), (260, 65), (259, 65), (261, 66), (262, 67), (265, 66), (267, 65), (513, 33), (390, 130), (2101, 21), (1990, 37), (8, 9), (9, 8), (497, 12), (503, 75)]:  # + widths around the rolling RGB kernel's 496-source-pixel waves and 1984-pixel blocks
         src = make(w, h, c, np.uint8, seed=w)
         assert_same_bits(pyr_gpu(gpu_stream, src, False)[0], O.pyrdown(src), f"pyrdown u8 c{c} {w}x{h}")
     n = 3
