@@ -545,6 +545,149 @@ __global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
     }
 }
 
+
+// ---- pyrup_u8 for RGB8, rolling wave, planar in registers (round 3) ---------------------------------------------------------------
+// pyrup_u8_pair_kernel above is VALU-bound (r02zp: 71 % busy, 1.06 G instructions per 256 4K outputs).  Same structure as the rolling
+// pyrdown above: a WAVE walks down a strip of SOURCE rows with three rows of loads in flight; a lane owns four source pixels (12
+// bytes), de-interleaves them into one dword per channel and takes the neighbouring pixels by wave shifts.  Row pass per channel:
+//   even destination columns  (p[x-1] + 6 p[x] + p[x+1] + 4) >> 3 : v_dot4_u32_u8 of the four-byte window with the taps pre-multiplied by
+//                             32 — (32 t) has t >> 3 in byte 1 for t < 2048 — so the four results are gathered by three v_perm_b32;
+//   odd destination columns   (p[x] + p[x+1] + 1) >> 1            : a bytewise rounding average of two dwords, (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7f),
+//                             four pixels in five instructions;
+// column pass on the three-row ring: odd destination rows are the same bytewise average of two packed rows, even rows the [1 6 1] sum
+// in 16-bit lanes (rows kept unpacked in the ring).  Eight destination pixels per row leave as three 8-byte stores, two destination rows
+// per source row.  reflect-101 columns on edge waves by re-indexing a clamped quad (one byte selector per lane).  Same integers as the
+// per-pixel kernel: byte-identical (tests run both).  RGB8, sw >= 4.
+constexpr int kPuRollWaveSrc = 248;                  // source pixels per wave (62 lanes x 4)
+constexpr int kPuRollTileSrc = 4 * kPuRollWaveSrc;
+
+__device__ __forceinline__ uint32_t avg_round_u8x4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
+
+__global__ __launch_bounds__(256) void pyrup_u8_rgb_roll_kernel(PyrRoll a) {   // th = SOURCE rows per strip here
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int x0 = (int)tx * kPuRollTileSrc + wv * kPuRollWaveSrc;   // first source pixel of this wave
+    if (x0 >= a.sw) return;
+    const int y0 = ty * a.th, thr = min(a.th, a.sh - y0);
+    const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
+    uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
+    const int p = x0 - 4 + 4 * lane;                                  // this lane's source pixels p .. p + 3 (lanes 0 / 63: halos)
+    const bool edge = x0 < 4 || x0 + kPuRollWaveSrc + 4 > a.sw;       // wave-uniform
+    const int pc = min(max(p, 0), a.sw - 4);                          // sw >= 4: host-checked
+    uint32_t esel = 0x03020100u;
+    if (edge) {
+        esel = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) esel |= (uint32_t)min(max(reflect_101(p + j, a.sw) - pc, 0), 3) << (8 * j);
+    }
+    const int rowb = a.sw * 3;
+    const long long drow = (long long)a.dw * 3;
+    const int seg_bytes = 6 * min(kPuRollWaveSrc, a.sw - x0);        // destination bytes of this wave per row (wave-uniform)
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[4][2][6 * 64];   // per wave, per destination row of a step: 64 lanes x 24 bytes
+    const int n = thr + 2;                                            // source rows walked: y0 - 1 .. y0 + thr
+    int pf = y0 - 1;
+
+    uint32_t q[3][3];
+    auto prefetch = [&](uint32_t (&d)[3]) {
+        const uint8_t* rp = src + (long long)reflect_101(pf, a.sh) * rowb + 3 * pc;
+        d[0] = *reinterpret_cast<const u32_unaligned*>(rp); d[1] = *reinterpret_cast<const u32_unaligned*>(rp + 4); d[2] = *reinterpret_cast<const u32_unaligned*>(rp + 8);
+        ++pf;
+    };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prefetch(q[i]);
+
+    // the row pass of three source rows: [row][channel][even / odd destination columns], packed bytes, and unpacked 16-bit lanes
+    uint32_t hp_[3][3][2], hl[3][3][2], hh[3][3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { hp_[i][c][e] = 0; hl[i][c][e] = 0; hh[i][c][e] = 0; }
+
+    long long row_off = (long long)(2 * y0) * drow + 6 * (long long)x0;   // destination pixel 2 x0 of destination row 2 y0
+    for (int ib = 0; ib < n; ib += 3) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int i = ib + s;
+            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2];
+            prefetch(q[s]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
+                uint32_t A = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, in1[c]), in2[c]);   // this channel's four pixels
+                if (edge) A = __builtin_amdgcn_perm(0u, A, esel);
+                const uint32_t prev = (uint32_t)__shfl_up((int)A, 1), next = (uint32_t)__shfl_down((int)A, 1);
+                const uint32_t w2 = __builtin_amdgcn_alignbyte(next, A, 1);                 // p[x+1] for the four pixels
+                constexpr uint32_t kT = 0x0020c020u;   // taps (1, 6, 1, 0) x 32; accumulator 4 x 32
+                const uint32_t t0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A, prev, 3), kT, 128u, false);
+                const uint32_t t1 = __builtin_amdgcn_udot4(A, kT, 128u, false);
+                const uint32_t t2 = __builtin_amdgcn_udot4(w2, kT, 128u, false);
+                const uint32_t t3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(next, A, 2), kT, 128u, false);
+                const uint32_t ev = __builtin_amdgcn_perm(__builtin_amdgcn_perm(t3, t2, 0x0c0c0501u), __builtin_amdgcn_perm(t1, t0, 0x0c0c0501u), 0x05040100u);
+                const uint32_t od = avg_round_u8x4(A, w2);
+                hp_[s][c][0] = ev; hp_[s][c][1] = od;
+                hl[s][c][0] = ev & 0x00ff00ffu; hh[s][c][0] = (ev >> 8) & 0x00ff00ffu;
+                hl[s][c][1] = od & 0x00ff00ffu; hh[s][c][1] = (od >> 8) & 0x00ff00ffu;
+            }
+            if (i >= 2 && i < n) {   // rows y - 1, y, y + 1 are in: destination rows 2 y and 2 y + 1 (y = y0 + i - 2)
+                const int sp = (s + 1) % 3, sc = (s + 2) % 3, sn = s;   // compile-time after unrolling
+                uint32_t ve[3][2], vo[3][2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint32_t lo = ((mad24(hl[sc][c][e], 6u, hl[sp][c][e]) + hl[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
+                        const uint32_t hi = ((mad24(hh[sc][c][e], 6u, hh[sp][c][e]) + hh[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
+                        ve[c][e] = lo | (hi << 8);
+                        vo[c][e] = avg_round_u8x4(hp_[sc][c][e], hp_[sn][c][e]);
+                    }
+                // Every lane re-interleaves its eight destination pixels (24 bytes) of both rows; the bytes then go through a wave-private
+                // LDS row so that a store INSTRUCTION covers contiguous memory — lane j writes 16-byte chunk j of the wave's row segment.
+                // Written straight from the owning lanes (three 8-byte pieces at a 24-byte lane stride) every store touched every cache line
+                // of the segment with a third of its bytes: 2.63 ms per 256 4K outputs, the vector ALUs 28 % busy (r03r).
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    uint32_t pl[3][2];   // per channel: destination pixels 0..3 and 4..7 (even / odd columns merged)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const uint32_t ee = r ? vo[c][0] : ve[c][0], oo = r ? vo[c][1] : ve[c][1];
+                        pl[c][0] = __builtin_amdgcn_perm(oo, ee, 0x05010400u);   // e0 o0 e1 o1
+                        pl[c][1] = __builtin_amdgcn_perm(oo, ee, 0x07030602u);   // e2 o2 e3 o3
+                    }
+                    uint32_t* xr = xpose[wv][r];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {   // re-interleave four pixels: [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3]
+                        const uint32_t rg = __builtin_amdgcn_perm(pl[1][h], pl[0][h], 0x05010400u), rg2 = __builtin_amdgcn_perm(pl[1][h], pl[0][h], 0x07030602u);
+                        xr[6 * lane + 3 * h] = __builtin_amdgcn_perm(pl[2][h], rg, 0x02040100u);
+                        xr[6 * lane + 3 * h + 1] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2][h], rg, 0x0c0c0503u), rg2, 0x01000504u);
+                        xr[6 * lane + 3 * h + 2] = __builtin_amdgcn_perm(pl[2][h], rg2, 0x07030206u);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint8_t* xb = reinterpret_cast<const uint8_t*>(xpose[wv][r]) + 24;   // lane 1's first byte = destination pixel 2 x0
+                    uint8_t* o = dst + row_off + r * drow;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int off = 16 * (lane + 64 * t);
+                        if (off + 16 <= seg_bytes) {
+                            const uint64_t lo = *reinterpret_cast<const uint64_t*>(xb + off), hi = *reinterpret_cast<const uint64_t*>(xb + off + 8);
+                            *reinterpret_cast<u64_unaligned*>(o + off) = lo; *reinterpret_cast<u64_unaligned*>(o + off + 8) = hi;
+                        } else if (off < seg_bytes) {   // the segment's last, partial chunk (one lane)
+                            for (int b = off; b < seg_bytes; ++b) o[b] = xb[b];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();   // the rows are out before the next step overwrites them (DS operations of a wave are ordered)
+                row_off += 2 * drow;
+            }
+        }
+    }
+}
+
 // pyrup_u8 (:656-840): horizontal pass to a u8 intermediate, then the same taps vertically
 template <int C>
 __device__ __forceinline__ uint32_t pyrup_h_u8(const uint8_t* __restrict__ row, int sw, int X, int c) {
@@ -1038,7 +1181,31 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
         return check_launch(#NAME);                                                                                                \
     }
 KH_PYRUP_ENTRY(kh_pyrup_f32, float, pyrup_f32_block_kernel, 1)
-KH_PYRUP_ENTRY(kh_pyrup_u8, uint8_t, pyrup_u8_pair_kernel, 2)
+static int32_t kh_pyrup_u8_pairs_direct(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch,
+                                        int64_t ss, int64_t ds) {
+    return kh_pyrup_u8_direct(stream, src, dst, sw, sh, channels, batch, ss, ds);
+}
+static KH_PYRUP_ENTRY(kh_pyrup_u8_pairs, uint8_t, pyrup_u8_pair_kernel, 2)   // every channel count; RGB8 takes the rolling kernel below
+int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch, int64_t ss,
+                    int64_t ds) {
+    static const bool direct = [] { const char* e = getenv("KH_PYR_DIRECT"); return e && e[0] == '1'; }();
+    static const bool no_roll = [] { const char* e = getenv("KH_PYR_ROLL"); return e && e[0] == '0'; }();
+    if (direct || no_roll || channels != 3 || sw < 4 || (int64_t)sw * 6 >= (1 << 24)) return kh_pyrup_u8_pairs(stream, src, dst, sw, sh, channels, batch, ss, ds);
+    const int dw = sw * 2, dh = sh * 2;
+    if (int32_t rc = check_pyr("kh_pyrup_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
+    if (batch == 0) return KH_OK;
+    PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
+    const unsigned tiles_x = cdiv(sw, kPuRollTileSrc);
+    const long long cols_blocks = (long long)tiles_x * batch;
+    long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
+    const long long min_strips = cdiv(sh, 360), max_strips = cdiv(sh, 16);
+    strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
+    r.th = (int)cdiv(sh, strips);
+    r.tiles = xcd_tiles(tiles_x, cdiv(sh, r.th), (unsigned)batch, kXcdEighth);
+    KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrup_u8: batch x tiles exceeds one launch");
+    hipLaunchKernelGGL(pyrup_u8_rgb_roll_kernel, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+    return check_launch("kh_pyrup_u8");
+}
 
 // Kernel::new (P/morphology/kernels.rs:113-185): shape 0 box, 1 cross, 2 ellipse; out = width*height bytes
 int32_t kh_morph_kernel(int32_t shape, int32_t width, int32_t height, uint8_t* out) {

@@ -160,3 +160,17 @@ def test_morphology_unit_tests_batch_and_errors(gpu_stream):  # ops.rs:326-400
     closed = imgproc.morph_close(Image.from_numpy(hole).to_hip(gpu_stream), k3).cpu().numpy().reshape(5, 5)
     assert closed[2, 2] == 255 and closed[1, 1] == 255 and closed[3, 3] == 255
     assert np.array_equal(imgproc.Kernel("ellipse", (7, 5)).data, O.morph_kernel("ellipse", 7, 5))
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_pyrup_u8_rolling_wave_boundaries(gpu_stream, c):
+    """Source widths around the rolling RGB kernel's 248-source-pixel waves and 992-pixel blocks, partial last quads, rows shorter than
+    a quad (the pair kernel), strips of a few rows, a batch; the other channel counts take the pair kernel on the same shapes."""
+    for w, h in [(4, 3), (5, 2), (7, 9), (247, 5), (248, 17), (249, 33), (251, 4), (253, 6), (992, 3), (993, 5), (1003, 18), (3, 40), (500, 47)]:
+        src = make(w, h, c, np.uint8, seed=w + h)
+        assert_same_bits(pyr_gpu(gpu_stream, src, True)[0], O.pyrup(src), f"pyrup u8 c{c} {w}x{h}")
+    n = 3
+    batch = np.stack([make(301, 70, c, np.uint8, seed=k) for k in range(n)])
+    got = pyr_gpu(gpu_stream, batch, True, batch=n)
+    for k in range(n):
+        assert_same_bits(got[k], O.pyrup(batch[k]), f"pyrup u8 batch frame {k}")
