@@ -131,7 +131,6 @@ __global__ __launch_bounds__(kBx* kBy) void pyrup_f32_block_kernel(Pyr<float> a)
     // last pixel / row) because their neighbours take values from them; they do not store.
     const int lane = threadIdx.x;
     const int xr = bx_ * kBx + lane, yr = by_ * kBy + threadIdx.y;
-    const bool live = xr < a.sw && yr < a.sh;
     const int x = min(xr, a.sw - 1), y = min(yr, a.sh - 1);  // SOURCE pixel
     const float* __restrict__ src = a.src + (long long)bz_ * a.ss;
     float* __restrict__ dst = a.dst + (long long)bz_ * a.ds;
@@ -203,22 +202,32 @@ __global__ __launch_bounds__(kBx* kBy) void pyrup_f32_block_kernel(Pyr<float> a)
             out[1][k * C + c] = (y != 0 && y == a.sh - 1) ? cen : v_odd;   // sh == 1: y == 0 wins, as in the per-pixel kernel
         }
     }
-    // both rows' 2 * C floats are contiguous: two (C = 3: dwordx4 + dwordx2) stores per row, issued together
+    // A lane holds 2 * C contiguous floats of each of its two destination rows.  Stored straight from the lane (C = 3: a dwordx4 and a
+    // dwordx2 at a 24-byte lane stride) every store instruction touches every cache line of the wave's 1.5 KB row segment with part of
+    // its bytes; the same pattern cost pyrup_u8 a third of its time (r03r -> r03s).  So the rows go through a wave-private LDS row
+    // and leave as contiguous 16-byte chunks: lane j stores chunk j (and chunk 64 + j) of the segment.
+    __shared__ __attribute__((aligned(16))) float xpose[kBy][2][2 * C * kBx];
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int wv = threadIdx.y;
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int i = 0; i < 2 * C; ++i) asm volatile("" : "+v"(out[k][i]));
-    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    if (!live) return;
+        for (int i = 0; i < 2 * C; ++i) xpose[wv][k][2 * C * lane + i] = out[k][i];
+    __builtin_amdgcn_wave_barrier();
+    if (yr >= a.sh) return;                                            // wave-uniform (one source row per wave)
+    const int x0 = bx_ * kBx, nlive = min(kBx, a.sw - x0);            // live lanes of this wave: their floats are the valid segment
+    const int seg = 2 * C * nlive;                                     // floats per destination row
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        float* o = dst + ((long long)(2 * y + k) * a.dw + 2 * x) * C;
-        int i = 0;
+        float* o = dst + ((long long)(2 * y + k) * a.dw + 2 * x0) * C;
+        const float* xr = xpose[wv][k];
 #pragma unroll
-        for (; i + 4 <= 2 * C; i += 4) *reinterpret_cast<f32x4u*>(o + i) = f32x4u{out[k][i], out[k][i + 1], out[k][i + 2], out[k][i + 3]};
-#pragma unroll
-        for (; i + 2 <= 2 * C; i += 2) *reinterpret_cast<f32x2u*>(o + i) = f32x2u{out[k][i], out[k][i + 1]};
+        for (int t = 0; t < (2 * C * kBx + 255) / 256; ++t) {
+            const int f = 4 * (lane + kBx * t);
+            typedef float f32x4a __attribute__((ext_vector_type(4)));   // LDS side: 16-byte aligned (ds_read_b128)
+            if (f + 4 <= seg) { const f32x4a v = *reinterpret_cast<const f32x4a*>(xr + f); *reinterpret_cast<f32x4u*>(o + f) = f32x4u{v.x, v.y, v.z, v.w}; }
+            else for (int i = f; i < seg; ++i) o[i] = xr[i];         // the segment's last, partial chunk (2 * C * nlive is even: at most 2 floats)
+        }
     }
 }
 
