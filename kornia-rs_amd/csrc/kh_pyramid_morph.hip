@@ -445,6 +445,7 @@ struct PyrRoll {
     const uint8_t* src;
     uint8_t* dst;
     int sw, sh, dw, dh, th;   // th = destination rows per strip
+    int dense;                // pyrdown: destination rows leave as contiguous chunks through LDS (1) or straight from the owning lanes (0)
     long long ss, ds;
     XcdTiles tiles;
 };
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
     const int p = 2 * X0 - 8 + 8 * lane;                              // this lane's source pixels p .. p + 7 (lanes 0 / 63: halos)
     const bool edge = 2 * X0 < 8 || 2 * X0 + 2 * kPdRollWaveDst + 8 > a.sw;   // wave-uniform: some lane's pixels need re-indexing
+    constexpr bool kDenseLoads = false;   // chunked loads through LDS measured SLOWER than six strided dword loads per lane (1.91 vs 1.54 ms, r03v vs r03p): the L1 absorbs strided reads; it is strided STORES that hurt
     const int pc = min(max(p, 0), a.sw - 8);                          // where the eight pixels are loaded from (sw >= 8: host-checked)
     uint32_t selA = 0x03020100u, selB = 0x07060504u;                  // pixel j <- loaded pixel reflect_101(p + j) - pc (identity inside)
     if (edge) {
@@ -470,18 +472,34 @@ __global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
             selB |= (uint32_t)min(max(reflect_101(p + 4 + j, a.sw) - pc, 0), 7) << (8 * j);
         }
     }
-    const int X = X0 - 4 + 4 * lane;                                  // this lane's destination pixels X .. X + 3
-    const bool writer = lane >= 1 && lane <= 62 && X < a.dw;
-    const bool full = X + 3 < a.dw;
+    const int seg_bytes = 3 * min(kPdRollWaveDst, a.dw - X0);         // destination bytes of this wave per row (wave-uniform)
     const int rowb = a.sw * 3;
     const int n = 2 * thr + 3;                                        // source rows walked: 2 Y0 - 2 .. 2 (Y0 + thr - 1) + 2
     int pf = 2 * Y0 - 2;
 
-    uint32_t q[5][6];  // five rows of raw loads in flight per lane
-    auto prefetch = [&](uint32_t (&d)[6]) {
-        const uint8_t* rp = src + (long long)reflect_101(pf, a.sh) * rowb + 3 * pc;
+    // Loads.  A lane needs 24 contiguous bytes of the row, the wave 1536: read as six dwords at a 24-byte lane stride every load
+    // instruction touches every cache line of the segment with a sixth of its bytes.  Interior waves (no clamped lane) therefore load
+    // the segment as 96 contiguous 16-byte chunks — lane j takes chunk j and, for j < 32, chunk 64 + j — and redistribute through a
+    // wave-private LDS row; edge waves keep the per-lane loads (their lanes' windows are shifted by the clamp).
+    __shared__ __attribute__((aligned(16))) uint32_t lrow[4][96 * 4];      // one source row segment per wave
+    __shared__ __attribute__((aligned(16))) uint32_t orow[4][64 * 3];      // one destination row segment per wave (12 bytes per lane)
+    const int seg0 = 3 * (2 * X0 - 8);                                      // byte offset of lane 0's first pixel in a row (interior waves)
+    const int c1 = 16 * min(64 + lane, 95);                                 // this lane's second chunk (lanes >= 32 repeat chunk 95)
+    uint32_t q[5][8];  // five rows of raw loads in flight per lane: six dwords (edge) / two 16-byte chunks (interior)
+    auto prefetch = [&](uint32_t (&d)[8]) {
+        const uint8_t* row = src + (long long)reflect_101(pf, a.sh) * rowb;
+        if (edge || !kDenseLoads) {
+            const uint8_t* rp = row + 3 * pc;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] = *reinterpret_cast<const u32_unaligned*>(rp + 4 * k);
+            for (int k = 0; k < 6; ++k) d[k] = *reinterpret_cast<const u32_unaligned*>(rp + 4 * k);
+        } else {
+            // two 8-byte loads per chunk: a 16-byte vector type with byte alignment is split into dword / byte accesses by the compiler
+            const uint8_t* g0 = row + seg0 + 16 * lane, *g1 = row + seg0 + c1;
+            const uint64_t a0 = *reinterpret_cast<const u64_unaligned*>(g0), a1 = *reinterpret_cast<const u64_unaligned*>(g0 + 8);
+            const uint64_t b0 = *reinterpret_cast<const u64_unaligned*>(g1), b1 = *reinterpret_cast<const u64_unaligned*>(g1 + 8);
+            d[0] = (uint32_t)a0; d[1] = (uint32_t)(a0 >> 32); d[2] = (uint32_t)a1; d[3] = (uint32_t)(a1 >> 32);
+            d[4] = (uint32_t)b0; d[5] = (uint32_t)(b0 >> 32); d[6] = (uint32_t)b1; d[7] = (uint32_t)(b1 >> 32);
+        }
         ++pf;
     };
 #pragma unroll
@@ -493,14 +511,23 @@ __global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { ring[i][c][0] = u16x2_t{0, 0}; ring[i][c][1] = u16x2_t{0, 0}; }
 
-    long long out_off = (long long)Y0 * a.dw * 3 + 3 * X;
+    long long out_off = (long long)Y0 * a.dw * 3 + 3 * (long long)X0;   // destination pixel X0 of destination row Y0
     for (int ib = 0; ib < n; ib += 10) {   // 10 = lcm(ring depth, row parity): ring slots and the emit test are compile-time
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
             const int i = ib + s, slot = s % 5;
             uint32_t d[6];
+            if (edge || !kDenseLoads) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) d[k] = q[slot][k];
+                for (int k = 0; k < 6; ++k) d[k] = q[slot][k];
+            } else {   // chunks -> LDS -> this lane's 24 bytes
+                *reinterpret_cast<u32x4_t*>(&lrow[wv][4 * lane]) = u32x4_t{q[slot][0], q[slot][1], q[slot][2], q[slot][3]};
+                *reinterpret_cast<u32x4_t*>(&lrow[wv][c1 >> 2]) = u32x4_t{q[slot][4], q[slot][5], q[slot][6], q[slot][7]};
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 6; ++k) d[k] = lrow[wv][6 * lane + k];
+                __builtin_amdgcn_wave_barrier();   // read before the next row overwrites it (DS operations of a wave are ordered)
+            }
             prefetch(q[slot]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -532,20 +559,36 @@ __global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
                         const u16x2_t b5 = binomial5(ring[(s + 1) % 5][c][h], ring[(s + 2) % 5][c][h], ring[(s + 3) % 5][c][h], ring[(s + 4) % 5][c][h], ring[slot][c][h]);
                         v[c][h] = as_u32(__builtin_elementwise_min((b5 + half) >> eight, top));   // pixels (2h, 2h + 1) in bytes 0 and 2
                     }
-                if (writer) {
+                {   // re-interleave
                     const uint32_t rg01 = __builtin_amdgcn_perm(v[1][0], v[0][0], 0x06020400u);   // R0 G0 R1 G1
                     const uint32_t rg23 = __builtin_amdgcn_perm(v[1][1], v[0][1], 0x06020400u);   // R2 G2 R3 G3
                     const uint32_t w0 = __builtin_amdgcn_perm(v[2][0], rg01, 0x02040100u);        // R0 G0 B0 R1
                     const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[2][0], rg01, 0x0c0c0603u), rg23, 0x01000504u);   // G1 B1 | R2 G2
                     const uint32_t w2 = __builtin_amdgcn_perm(v[2][1], rg23, 0x06030204u);        // B2 R3 G3 B3
                     uint8_t* o = dst + out_off;
-                    if (full) {
-                        *reinterpret_cast<u32_unaligned*>(o) = w0; *reinterpret_cast<u32_unaligned*>(o + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + 8) = w2;
-                    } else {
-                        const uint32_t w[3] = {w0, w1, w2};
+                    if (a.dense) {   // park the 12 bytes in the wave's LDS row, store contiguous 16-byte chunks (wave-uniform choice)
+                        orow[wv][3 * lane] = w0; orow[wv][3 * lane + 1] = w1; orow[wv][3 * lane + 2] = w2;
+                        __builtin_amdgcn_wave_barrier();
+                        const uint8_t* xb = reinterpret_cast<const uint8_t*>(orow[wv]) + 12;       // lane 1's first byte = destination pixel X0
+                        const int off = 16 * lane;
+                        if (off + 16 <= seg_bytes) {
+                            const uint32_t* xw = reinterpret_cast<const uint32_t*>(xb + off);
+                            *reinterpret_cast<u64_unaligned*>(o + off) = (uint64_t)xw[0] | ((uint64_t)xw[1] << 32);
+                            *reinterpret_cast<u64_unaligned*>(o + off + 8) = (uint64_t)xw[2] | ((uint64_t)xw[3] << 32);
+                        } else if (off < seg_bytes) {   // the segment's last, partial chunk (one lane)
+                            for (int b = off; b < seg_bytes; ++b) o[b] = xb[b];
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    } else if (lane >= 1 && lane <= 62) {   // straight from the owning lane: 12 bytes at 12 (lane - 1)
+                        const int off = 12 * (lane - 1);
+                        if (off + 12 <= seg_bytes) {
+                            *reinterpret_cast<u32_unaligned*>(o + off) = w0; *reinterpret_cast<u32_unaligned*>(o + off + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + off + 8) = w2;
+                        } else {
+                            const uint32_t w[3] = {w0, w1, w2};
 #pragma unroll
-                        for (int b = 0; b < 9; ++b)   // at most three pixels of a quad that reaches past the last destination column
-                            if (X + b / 3 < a.dw) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                            for (int b = 0; b < 9; ++b)   // at most three pixels of a quad that reaches past the last destination column
+                                if (off + b < seg_bytes) o[off + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                        }
                     }
                 }
                 out_off += (long long)a.dw * 3;
@@ -1147,7 +1190,8 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
     if (batch == 0) return KH_OK;
     static const bool no_roll = [] { const char* e = getenv("KH_PYR_ROLL"); return e && e[0] == '0'; }();   // dev / test knob: the tile kernel
     if (channels == 3 && sw >= 8 && !no_roll) {   // RGB8: the rolling planar kernel
-        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
+        PyrRoll r{src, dst, sw, sh, dw, dh, 0, 0, ss, ds, XcdTiles{}};
+        { const char* e = getenv("KH_PYR_DENSE_STORES"); r.dense = e && e[0] == '1'; }   // dev knob (A/B r03x)
         const unsigned tiles_x = cdiv(dw, kPdRollTileDst);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
@@ -1203,7 +1247,7 @@ int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_
     const int dw = sw * 2, dh = sh * 2;
     if (int32_t rc = check_pyr("kh_pyrup_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
-    PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
+    PyrRoll r{src, dst, sw, sh, dw, dh, 0, 1, ss, ds, XcdTiles{}};
     const unsigned tiles_x = cdiv(sw, kPuRollTileSrc);
     const long long cols_blocks = (long long)tiles_x * batch;
     long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
