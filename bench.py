@@ -757,7 +757,7 @@ class PyramidLevel(Workload):
 class DilateU8_4K(U8Images):
     """u8 dilate, 5x5 box structuring element, constant border, on 3840x2160 RGB8, batch 256."""
 
-    name, kernel = "dilate_u8_box5_4k_b256", "morphology_u8_tile_kernel<3, dilate, box, 5>"
+    name, kernel = "dilate_u8_box5_4k_b256", "morph_u8_rgb_roll_kernel<5, dilate>"
 
     def __init__(self, batch):
         self.N = batch

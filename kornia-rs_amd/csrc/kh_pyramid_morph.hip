@@ -881,6 +881,144 @@ __device__ __forceinline__ int map_index(int mode, int i, int len) {  // Padding
     }
 }
 
+
+// ---- box dilate / erode for RGB8, rolling wave, planar in registers (round 3) --------------------------------------------------
+// morphology_u8_tile_kernel below is vector-ALU-bound (r02zp: 74 % busy; ~19 instructions per byte for a 5 x 5 box): with interleaved
+// RGB every (byte pair, tap) costs a v_perm_b32 to gather it and a packed max, in both passes, plus the LDS tile traffic and three
+// barriers.  Here, as in the round-3 u8 blur and pyramids: a WAVE walks down a strip with K rows of loads in flight and no barrier;
+// a lane owns four pixels (12 bytes), de-interleaves them into one dword per channel and takes its neighbours' by wave shifts; the
+// twelve bytes (prev | cur | next) of a channel are split once into even / odd bytes in 16-bit lanes (6 perms), after which the byte
+// pair (b[i], b[i+2]) is either a register or one v_alignbyte_b32 away, and the K-wide row maxima of the four pixels are K packed
+// max (the two pairs share all but one term).  Column pass: K - 1 packed max per register on a K-row ring.  Re-interleave, one
+// 12-byte store.  Borders: the row index through map_index (constant: the whole row is the border value); columns on edge waves by
+// loading the quad from a clamped position and re-indexing it — and substituting the border value — with ONE v_perm_b32 per channel
+// whose per-lane selector is computed once.  max / min are exact and order-independent: byte-identical to the other kernels.
+// For square all-ones masks of 3 / 5 / 7, 3 channels, every border mode but wrap, images at least 4 pixels wide.
+template <bool DILATE>
+__device__ __forceinline__ uint32_t pk_minmax(uint32_t a, uint32_t b) {
+    const u16x2_t x = __builtin_bit_cast(u16x2_t, a), y = __builtin_bit_cast(u16x2_t, b);
+    return __builtin_bit_cast(uint32_t, DILATE ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y));
+}
+struct MorphRoll {
+    const uint8_t* src;
+    uint8_t* dst;
+    int w, h, th, border;
+    long long ss, ds;
+    uint32_t cval[3];
+    XcdTiles tiles;
+};
+constexpr int kMrWavePx = 248, kMrTilePx = 4 * kMrWavePx;
+
+template <int K, bool DILATE>
+__global__ __launch_bounds__(256) void morph_u8_rgb_roll_kernel(MorphRoll a) {
+    constexpr int H = K / 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int p0 = (int)tx * kMrTilePx + wv * kMrWavePx;    // first output pixel of this wave
+    if (p0 >= a.w) return;                                  // whole wave idle (no block barrier below)
+    const int y0 = ty * a.th;
+    const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
+    uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
+    const int p = p0 - 4 + 4 * lane;                        // this lane's quad (lanes 0 / 63: halo quads)
+    const bool edge = p0 < 4 || p0 + kMrWavePx + 4 > a.w;   // wave-uniform
+    const int pc = min(max(p, 0), a.w - 4);
+    uint32_t esel = 0x03020100u;   // byte j: 0..3 = loaded pixel, 4 = the constant border value
+    if (edge) {
+        esel = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = map_index(a.border, p + j, a.w);
+            esel |= (uint32_t)(m < 0 ? 4 : min(max(m - pc, 0), 3)) << (8 * j);
+        }
+    }
+    const bool writer = lane >= 1 && lane <= 62 && p < a.w;
+    const bool full = p + 3 < a.w;
+    const int rowb = a.w * 3;
+    const int nrows = min(a.th, a.h - y0) + 2 * H;
+    int pf_row = y0 - H;
+    const uint32_t cv[3] = {a.cval[0] * 0x01010101u, a.cval[1] * 0x01010101u, a.cval[2] * 0x01010101u};
+
+    uint32_t q[K][3];
+    auto prefetch = [&](uint32_t (&d)[3]) {
+        const uint8_t* rp = src + (long long)max(map_index(a.border, pf_row, a.h), 0) * rowb + 3 * pc;
+        d[0] = *reinterpret_cast<const u32_unaligned*>(rp); d[1] = *reinterpret_cast<const u32_unaligned*>(rp + 4); d[2] = *reinterpret_cast<const u32_unaligned*>(rp + 8);
+        ++pf_row;
+    };
+#pragma unroll
+    for (int i = 0; i < K; ++i) prefetch(q[i]);
+
+    constexpr uint32_t kInit = DILATE ? 0u : 0x00ff00ffu;
+    uint32_t ring[K][3][2];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ring[i][c][0] = kInit; ring[i][c][1] = kInit; }
+
+    long long out_off = (long long)(y0 - 2 * H) * rowb + 3 * p;
+    for (int rb = 0; rb < nrows; rb += K) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const int r = rb + s, row = y0 - H + r;
+            const bool row_out = a.border == KH_BORDER_CONSTANT && (row < 0 || row >= a.h);   // wave-uniform: the whole row is the border value
+            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2];
+            prefetch(q[s]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
+                uint32_t cur = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, in1[c]), in2[c]);
+                if (edge) cur = __builtin_amdgcn_perm(cv[c], cur, esel);
+                if (row_out) cur = cv[c];
+                const uint32_t prev = (uint32_t)__shfl_up((int)cur, 1), next = (uint32_t)__shfl_down((int)cur, 1);
+                // even / odd bytes of the 12-byte string prev | cur | next in 16-bit lanes
+                const uint32_t e0 = __builtin_amdgcn_perm(0u, prev, 0x0c020c00u), o0 = __builtin_amdgcn_perm(0u, prev, 0x0c030c01u);
+                const uint32_t e1 = __builtin_amdgcn_perm(0u, cur, 0x0c020c00u), o1 = __builtin_amdgcn_perm(0u, cur, 0x0c030c01u);
+                const uint32_t e2 = __builtin_amdgcn_perm(0u, next, 0x0c020c00u), o2 = __builtin_amdgcn_perm(0u, next, 0x0c030c01u);
+                // P(i) = (b[i], b[i + 2]) in 16-bit lanes, i = 0 .. 9
+                auto P = [&](int i) -> uint32_t {   // i is a compile-time constant after unrolling
+                    switch (i) {
+                        case 0: return e0;  case 1: return o0;
+                        case 2: return __builtin_amdgcn_alignbyte(e1, e0, 2);  case 3: return __builtin_amdgcn_alignbyte(o1, o0, 2);
+                        case 4: return e1;  case 5: return o1;
+                        case 6: return __builtin_amdgcn_alignbyte(e2, e1, 2);  case 7: return __builtin_amdgcn_alignbyte(o2, o1, 2);
+                        case 8: return e2;  default: return o2;
+                    }
+                };
+                // pixels (0, 2) take P(4 - H .. 4 + H), pixels (1, 3) P(5 - H .. 5 + H): K - 1 terms in common
+                uint32_t m = P(5 - H);
+#pragma unroll
+                for (int i = 6 - H; i <= 4 + H; ++i) m = pk_minmax<DILATE>(m, P(i));
+                ring[s][c][0] = pk_minmax<DILATE>(m, P(4 - H));
+                ring[s][c][1] = pk_minmax<DILATE>(m, P(5 + H));
+            }
+            if (writer && r >= 2 * H && r < nrows) {
+                uint32_t pl[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    uint32_t ve = ring[0][c][0], vo = ring[0][c][1];
+#pragma unroll
+                    for (int i = 1; i < K; ++i) { ve = pk_minmax<DILATE>(ve, ring[i][c][0]); vo = pk_minmax<DILATE>(vo, ring[i][c][1]); }
+                    pl[c] = __builtin_amdgcn_perm(vo, ve, 0x06020400u);   // pixels 0, 1, 2, 3 of this channel
+                }
+                const uint32_t rg = __builtin_amdgcn_perm(pl[1], pl[0], 0x05010400u), rg2 = __builtin_amdgcn_perm(pl[1], pl[0], 0x07030602u);
+                const uint32_t w0 = __builtin_amdgcn_perm(pl[2], rg, 0x02040100u);
+                const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2], rg, 0x0c0c0503u), rg2, 0x01000504u);
+                const uint32_t w2 = __builtin_amdgcn_perm(pl[2], rg2, 0x07030206u);
+                uint8_t* o = dst + out_off;
+                if (full) {
+                    *reinterpret_cast<u32_unaligned*>(o) = w0; *reinterpret_cast<u32_unaligned*>(o + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + 8) = w2;
+                } else {
+                    const uint32_t w[3] = {w0, w1, w2};
+#pragma unroll
+                    for (int b = 0; b < 9; ++b)
+                        if (p + b / 3 < a.w) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                }
+            }
+            out_off += rowb;
+        }
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(kBx* kBy) void morphology_u8_kernel(Morph a) {
     unsigned bx_, by_, bz_;
@@ -933,11 +1071,6 @@ constexpr int kMorphFW = 384;   // flat bytes per tile row: a whole number of pi
 constexpr int kMorphTH = 32;    // output rows per tile
 extern __shared__ __attribute__((aligned(16))) uint8_t kh_morph_lds[];
 
-template <bool DILATE>
-__device__ __forceinline__ uint32_t pk_minmax(uint32_t a, uint32_t b) {
-    const u16x2_t x = __builtin_bit_cast(u16x2_t, a), y = __builtin_bit_cast(u16x2_t, b);
-    return __builtin_bit_cast(uint32_t, DILATE ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y));
-}
 // one tap on the four output bytes whose window starts `o` bytes into LDS row `row32` (o & 3 is the same for every lane)
 template <bool DILATE>
 __device__ __forceinline__ void tap_pair(const uint32_t* row32, int o, uint32_t& acc_e, uint32_t& acc_o) {
@@ -1308,6 +1441,31 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     bool any = false, box = true;
     for (int ky = 0; ky < kh_; ++ky) { any = any || a.rows[ky]; box = box && a.rows[ky] == (kw == 32 ? 0xffffffffu : (1u << kw) - 1u); }
     static const bool direct = [] { const char* e = getenv("KH_MORPH_DIRECT"); return e && e[0] == '1'; }();
+    static const bool no_roll = [] { const char* e = getenv("KH_MORPH_ROLL"); return e && e[0] == '0'; }();   // dev / test knob: the tile kernel
+    if (any && box && !direct && !no_roll && channels == 3 && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && w >= 4 &&
+        (int64_t)w * 3 < (1 << 24)) {   // RGB8, square box of 3 / 5 / 7: the rolling planar kernel
+        MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], a.cval[1], a.cval[2]}, XcdTiles{}};
+        const unsigned tiles_x = cdiv(w, kMrTilePx);
+        const long long cols_blocks = (long long)tiles_x * batch;
+        long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
+        const long long min_strips = cdiv(h, 360), max_strips = cdiv(h, 32);
+        strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
+        r.th = (int)cdiv(h, strips);
+        r.tiles = xcd_tiles(tiles_x, cdiv(h, r.th), (unsigned)batch, kXcdEighth);
+        KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        const dim3 grid = xcd_grid(r.tiles);
+        const bool dil = op == KH_MORPH_DILATE;
+#define KH_MR(KK)                                                                                       \
+    do {                                                                                                \
+        if (dil) hipLaunchKernelGGL((morph_u8_rgb_roll_kernel<KK, true>), grid, dim3(256), 0, st, r);   \
+        else hipLaunchKernelGGL((morph_u8_rgb_roll_kernel<KK, false>), grid, dim3(256), 0, st, r);      \
+    } while (0)
+        if (kw == 3) KH_MR(3);
+        else if (kw == 5) KH_MR(5);
+        else KH_MR(7);
+#undef KH_MR
+        return check_launch(what);
+    }
     const int srows = kMorphTH + kh_ - 1, sp = ((kMorphFW + (kw - 1) * channels + 3) & ~3) + 4;
     const size_t lds = (size_t)srows * sp + (box ? (size_t)srows * kMorphFW * 2 : 0);
     // (row bytes < 2^24: the tile kernel forms its 32-bit offsets with 24-bit multiplies)

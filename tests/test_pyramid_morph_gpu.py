@@ -112,6 +112,27 @@ def test_morphology_tiled_interior_and_ragged_tiles(gpu_stream, kshape):
             assert_same_bits(got, O.morphology_u8(src, op, mask, border, cval), f"{op} {kshape} {border} {w}x{h} c{c}")
 
 
+@pytest.mark.parametrize("border", ["constant", "replicate", "reflect101", "reflect"])
+@pytest.mark.parametrize("k", [3, 5, 7])
+def test_morphology_rgb_rolling_wave_boundaries(gpu_stream, k, border):
+    """The rolling planar RGB kernel (square boxes of 3 / 5 / 7): a wave owns 248 pixels and a block 992, the image is cut into
+    row strips, edge waves re-index their clamped quads — widths either side of every one of those seams, the narrowest
+    images the kernel takes (4 .. 7 pixels; narrower ones stay on the tile kernel), heights below the mask's, per-channel
+    border values and a batch."""
+    mask = O.morph_kernel("box", k, k)
+    cval = [9, 130, 251]
+    for (w, h) in [(4, 9), (5, 2), (6, 1), (7, 40), (3, 8), (247, 5), (248, 3), (249, 11), (251, 7), (252, 4), (496, 6), (991, 3), (992, 9), (993, 4),
+                   (996, 5), (1241, 3), (1988, 2), (131, 400)]:
+        src = make(w, h, 3, np.uint8, seed=w + h)
+        for op in ("dilate", "erode"):
+            got = morph_gpu(gpu_stream, src, op, mask, border, cval)[0]
+            assert_same_bits(got, O.morphology_u8(src, op, mask, border, cval), f"{op} box{k} {border} {w}x{h}")
+    src = np.stack([make(1000, 75, 3, np.uint8, seed=s) for s in (4, 5, 6)])
+    got = morph_gpu(gpu_stream, src, "erode", mask, border, cval, batch=3)
+    for i in range(3):
+        assert_same_bits(got[i], O.morphology_u8(src[i], "erode", mask, border, cval), f"batch frame {i}")
+
+
 def test_morphology_both_kernels_agree(gpu_stream, tmp_path):
     """KH_MORPH_DIRECT=1 selects the per-pixel kernel (read once per process): a child process runs it on the same inputs and the
     bytes must equal this process's tiled result."""
