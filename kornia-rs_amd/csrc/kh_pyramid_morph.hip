@@ -886,10 +886,15 @@ __device__ __forceinline__ int map_index(int mode, int i, int len) {  // Padding
 // morphology_u8_tile_kernel below is vector-ALU-bound (r02zp: 74 % busy; ~19 instructions per byte for a 5 x 5 box): with interleaved
 // RGB every (byte pair, tap) costs a v_perm_b32 to gather it and a packed max, in both passes, plus the LDS tile traffic and three
 // barriers.  Here, as in the round-3 u8 blur and pyramids: a WAVE walks down a strip with K rows of loads in flight and no barrier;
-// a lane owns four pixels (12 bytes), de-interleaves them into one dword per channel and takes its neighbours' by wave shifts; the
-// twelve bytes (prev | cur | next) of a channel are split once into even / odd bytes in 16-bit lanes (6 perms), after which the byte
-// pair (b[i], b[i+2]) is either a register or one v_alignbyte_b32 away, and the K-wide row maxima of the four pixels are K packed
-// max (the two pairs share all but one term).  Column pass: K - 1 packed max per register on a K-row ring.  Re-interleave, one
+// a lane owns four pixels (12 bytes), de-interleaves them into one dword per channel and takes its neighbours' by wave shifts.
+// ALL 64 lanes store, so a wave's row segment is 768 bytes = whole 128-byte lines: with 62 storing lanes (744 bytes, the shape of
+// the round-3 blur and pyramid kernels) every segment boundary splits a line between two waves, and a pure copy in that shape
+// runs at 3.05 ms against 2.47 ms for this one (r03_rollcopy: stores alone 1.59 vs 1.16 ms).  The pixels either side of the
+// wave come from one extra load per row — the lower half's lanes all load the quad before the wave's first, the upper's the quad
+// after its last — de-interleaved the same way and handed to the end lanes as the DPP wave shift's fill value.  The
+// byte pair (b[i], b[i+2]) of a channel's twelve bytes (prev | cur | next) in 16-bit lanes is ONE v_perm_b32 of two neighbouring
+// dwords (K + 1 of them per channel), and the K-wide row maxima of the four pixels are K + 1 packed max (the pairs (0, 2) and
+// (1, 3) share all but one term).  Column pass: on pair maxima of consecutive rows, 1 + K / 2 packed max per register.  Re-interleave, one
 // 12-byte store.  Borders: the row index through map_index (constant: the whole row is the border value); columns on edge waves by
 // loading the quad from a clamped position and re-indexing it — and substituting the border value — with ONE v_perm_b32 per channel
 // whose per-lane selector is computed once.  max / min are exact and order-independent: byte-identical to the other kernels.
@@ -907,7 +912,12 @@ struct MorphRoll {
     uint32_t cval[3];
     XcdTiles tiles;
 };
-constexpr int kMrWavePx = 248, kMrTilePx = 4 * kMrWavePx;
+constexpr int kMrWavePx = 256, kMrTilePx = 4 * kMrWavePx;
+
+// prev / next lane's value by DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1): lane i takes lane i -/+ 1 and the END lane,
+// which has no source, keeps `end` — where the halo quad's value is waiting.  Checked on gfx950 by scripts/ubench/dpp_wave_shift.hip.
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t end) { return (uint32_t)__builtin_amdgcn_update_dpp((int)end, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v, uint32_t end) { return (uint32_t)__builtin_amdgcn_update_dpp((int)end, (int)v, 0x130, 0xf, 0xf, false); }
 
 template <int K, bool DILATE>
 __global__ __launch_bounds__(256) void morph_u8_rgb_roll_kernel(MorphRoll a) {
@@ -920,40 +930,48 @@ __global__ __launch_bounds__(256) void morph_u8_rgb_roll_kernel(MorphRoll a) {
     const int y0 = ty * a.th;
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
-    const int p = p0 - 4 + 4 * lane;                        // this lane's quad (lanes 0 / 63: halo quads)
+    const int p = p0 + 4 * lane;                            // this lane's quad
+    const int ph = lane < 32 ? p0 - 4 : p0 + kMrWavePx;     // the wave's halo quads: left in the lower half's lanes, right in the upper's
     const bool edge = p0 < 4 || p0 + kMrWavePx + 4 > a.w;   // wave-uniform
-    const int pc = min(max(p, 0), a.w - 4);
-    uint32_t esel = 0x03020100u;   // byte j: 0..3 = loaded pixel, 4 = the constant border value
+    const int pc = min(p, a.w - 4), phc = min(max(ph, 0), a.w - 4);
+    uint32_t esel = 0x03020100u, hsel = 0x03020100u;   // byte j: 0..3 = loaded pixel, 4 = the constant border value
     if (edge) {
-        esel = 0;
+        esel = hsel = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int m = map_index(a.border, p + j, a.w);
+            const int m = map_index(a.border, p + j, a.w), mh = map_index(a.border, ph + j, a.w);
             esel |= (uint32_t)(m < 0 ? 4 : min(max(m - pc, 0), 3)) << (8 * j);
+            hsel |= (uint32_t)(mh < 0 ? 4 : min(max(mh - phc, 0), 3)) << (8 * j);
         }
     }
-    const bool writer = lane >= 1 && lane <= 62 && p < a.w;
+    const bool writer = p < a.w;
     const bool full = p + 3 < a.w;
     const int rowb = a.w * 3;
     const int nrows = min(a.th, a.h - y0) + 2 * H;
     int pf_row = y0 - H;
     const uint32_t cv[3] = {a.cval[0] * 0x01010101u, a.cval[1] * 0x01010101u, a.cval[2] * 0x01010101u};
 
-    uint32_t q[K][3];
-    auto prefetch = [&](uint32_t (&d)[3]) {
-        const uint8_t* rp = src + (long long)max(map_index(a.border, pf_row, a.h), 0) * rowb + 3 * pc;
-        d[0] = *reinterpret_cast<const u32_unaligned*>(rp); d[1] = *reinterpret_cast<const u32_unaligned*>(rp + 4); d[2] = *reinterpret_cast<const u32_unaligned*>(rp + 8);
+    uint32_t q[K][6];   // the lane's quad and its half-wave's halo quad
+    auto prefetch = [&](uint32_t (&d)[6]) {
+        const uint8_t* rp = src + (long long)max(map_index(a.border, pf_row, a.h), 0) * rowb;
+        const uint8_t *rq = rp + 3 * pc, *rh = rp + 3 * phc;
+        d[0] = *reinterpret_cast<const u32_unaligned*>(rq); d[1] = *reinterpret_cast<const u32_unaligned*>(rq + 4); d[2] = *reinterpret_cast<const u32_unaligned*>(rq + 8);
+        d[3] = *reinterpret_cast<const u32_unaligned*>(rh); d[4] = *reinterpret_cast<const u32_unaligned*>(rh + 4); d[5] = *reinterpret_cast<const u32_unaligned*>(rh + 8);
         ++pf_row;
     };
 #pragma unroll
     for (int i = 0; i < K; ++i) prefetch(q[i]);
 
     constexpr uint32_t kInit = DILATE ? 0u : 0x00ff00ffu;
-    uint32_t ring[K][3][2];
+    // column pass on pair maxima: pr[t] = max(row t - 1, row t), so the K-row maximum ending at row t is row t with pr[t - 1], pr[t - 3] ...:
+    // 1 + K / 2 packed max per register instead of K - 1
+    uint32_t pr[K][3][2], last[3][2];
 #pragma unroll
-    for (int i = 0; i < K; ++i)
+    for (int c = 0; c < 3; ++c) {
+        last[c][0] = kInit; last[c][1] = kInit;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { ring[i][c][0] = kInit; ring[i][c][1] = kInit; }
+        for (int i = 0; i < K; ++i) { pr[i][c][0] = kInit; pr[i][c][1] = kInit; }
+    }
 
     long long out_off = (long long)(y0 - 2 * H) * rowb + 3 * p;
     for (int rb = 0; rb < nrows; rb += K) {
@@ -961,45 +979,38 @@ __global__ __launch_bounds__(256) void morph_u8_rgb_roll_kernel(MorphRoll a) {
         for (int s = 0; s < K; ++s) {
             const int r = rb + s, row = y0 - H + r;
             const bool row_out = a.border == KH_BORDER_CONSTANT && (row < 0 || row >= a.h);   // wave-uniform: the whole row is the border value
-            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2];
+            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2], h0 = q[s][3], h1 = q[s][4], h2 = q[s][5];
             prefetch(q[s]);
+            uint32_t pl[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
                 uint32_t cur = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, in1[c]), in2[c]);
-                if (edge) cur = __builtin_amdgcn_perm(cv[c], cur, esel);
-                if (row_out) cur = cv[c];
-                const uint32_t prev = (uint32_t)__shfl_up((int)cur, 1), next = (uint32_t)__shfl_down((int)cur, 1);
-                // even / odd bytes of the 12-byte string prev | cur | next in 16-bit lanes
-                const uint32_t e0 = __builtin_amdgcn_perm(0u, prev, 0x0c020c00u), o0 = __builtin_amdgcn_perm(0u, prev, 0x0c030c01u);
-                const uint32_t e1 = __builtin_amdgcn_perm(0u, cur, 0x0c020c00u), o1 = __builtin_amdgcn_perm(0u, cur, 0x0c030c01u);
-                const uint32_t e2 = __builtin_amdgcn_perm(0u, next, 0x0c020c00u), o2 = __builtin_amdgcn_perm(0u, next, 0x0c030c01u);
-                // P(i) = (b[i], b[i + 2]) in 16-bit lanes, i = 0 .. 9
+                uint32_t halo = __builtin_amdgcn_perm(h2, __builtin_amdgcn_perm(h1, h0, in1[c]), in2[c]);
+                if (edge) { cur = __builtin_amdgcn_perm(cv[c], cur, esel); halo = __builtin_amdgcn_perm(cv[c], halo, hsel); }
+                if (row_out) { cur = cv[c]; halo = cv[c]; }
+                const uint32_t prev = from_lane_below(cur, halo), next = from_lane_above(cur, halo);
+                // P(i) = (b[i], b[i + 2]) of the 12-byte string prev | cur | next in 16-bit lanes: one v_perm_b32 of two neighbouring dwords
                 auto P = [&](int i) -> uint32_t {   // i is a compile-time constant after unrolling
-                    switch (i) {
-                        case 0: return e0;  case 1: return o0;
-                        case 2: return __builtin_amdgcn_alignbyte(e1, e0, 2);  case 3: return __builtin_amdgcn_alignbyte(o1, o0, 2);
-                        case 4: return e1;  case 5: return o1;
-                        case 6: return __builtin_amdgcn_alignbyte(e2, e1, 2);  case 7: return __builtin_amdgcn_alignbyte(o2, o1, 2);
-                        case 8: return e2;  default: return o2;
-                    }
+                    return i <= 5 ? __builtin_amdgcn_perm(cur, prev, 0x0c000c00u | (uint32_t)i | ((uint32_t)(i + 2) << 16))
+                                  : __builtin_amdgcn_perm(next, cur, 0x0c000c00u | (uint32_t)(i - 4) | ((uint32_t)(i - 2) << 16));
                 };
                 // pixels (0, 2) take P(4 - H .. 4 + H), pixels (1, 3) P(5 - H .. 5 + H): K - 1 terms in common
                 uint32_t m = P(5 - H);
 #pragma unroll
                 for (int i = 6 - H; i <= 4 + H; ++i) m = pk_minmax<DILATE>(m, P(i));
-                ring[s][c][0] = pk_minmax<DILATE>(m, P(4 - H));
-                ring[s][c][1] = pk_minmax<DILATE>(m, P(5 + H));
+                const uint32_t re = pk_minmax<DILATE>(m, P(4 - H)), ro = pk_minmax<DILATE>(m, P(5 + H));
+                uint32_t ve = re, vo = ro;
+#pragma unroll
+                for (int j = 1; j <= H; ++j) {
+                    ve = pk_minmax<DILATE>(ve, pr[(s + K - (2 * j - 1)) % K][c][0]);
+                    vo = pk_minmax<DILATE>(vo, pr[(s + K - (2 * j - 1)) % K][c][1]);
+                }
+                pr[s][c][0] = pk_minmax<DILATE>(re, last[c][0]); pr[s][c][1] = pk_minmax<DILATE>(ro, last[c][1]);
+                last[c][0] = re; last[c][1] = ro;
+                pl[c] = __builtin_amdgcn_perm(vo, ve, 0x06020400u);   // pixels 0, 1, 2, 3 of this channel
             }
             if (writer && r >= 2 * H && r < nrows) {
-                uint32_t pl[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    uint32_t ve = ring[0][c][0], vo = ring[0][c][1];
-#pragma unroll
-                    for (int i = 1; i < K; ++i) { ve = pk_minmax<DILATE>(ve, ring[i][c][0]); vo = pk_minmax<DILATE>(vo, ring[i][c][1]); }
-                    pl[c] = __builtin_amdgcn_perm(vo, ve, 0x06020400u);   // pixels 0, 1, 2, 3 of this channel
-                }
                 const uint32_t rg = __builtin_amdgcn_perm(pl[1], pl[0], 0x05010400u), rg2 = __builtin_amdgcn_perm(pl[1], pl[0], 0x07030602u);
                 const uint32_t w0 = __builtin_amdgcn_perm(pl[2], rg, 0x02040100u);
                 const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2], rg, 0x0c0c0503u), rg2, 0x01000504u);

@@ -53,6 +53,12 @@ inline int __shfl_xor(int v, int mask) { return (int)hostsim::shfl_bits((uint32_
 // HIP: lanes whose source falls outside the wave keep their own value
 inline int __shfl_up(int v, unsigned delta) { const int l = hostsim::lane_id(), s = l - (int)delta; return (int)hostsim::shfl_bits((uint32_t)v, s >= 0 ? s : l); }
 inline int __shfl_down(int v, unsigned delta) { const int l = hostsim::lane_id(), s = l + (int)delta; return (int)hostsim::shfl_bits((uint32_t)v, s < 64 ? s : l); }
+// v_mov_b32_dpp wave_shr:1 (0x138) / wave_shl:1 (0x130): lane i takes lane i -/+ 1, the end lane keeps `old`
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+    const int l = hostsim::lane_id(), s = ctrl == 0x138 ? l - 1 : l + 1;
+    const int v = (int)hostsim::shfl_bits((uint32_t)src, s >= 0 && s < 64 ? s : l);
+    return s >= 0 && s < 64 ? v : old;
+}
 inline float __shfl_xor(float v, int mask) {
     uint32_t b;
     memcpy(&b, &v, 4);

@@ -115,14 +115,15 @@ def test_morphology_tiled_interior_and_ragged_tiles(gpu_stream, kshape):
 @pytest.mark.parametrize("border", ["constant", "replicate", "reflect101", "reflect"])
 @pytest.mark.parametrize("k", [3, 5, 7])
 def test_morphology_rgb_rolling_wave_boundaries(gpu_stream, k, border):
-    """The rolling planar RGB kernel (square boxes of 3 / 5 / 7): a wave owns 248 pixels and a block 992, the image is cut into
-    row strips, edge waves re-index their clamped quads — widths either side of every one of those seams, the narrowest
+    """The rolling planar RGB kernel (square boxes of 3 / 5 / 7): a wave owns 256 pixels and a block 1024, the image is cut into
+    row strips, edge waves re-index their clamped quads and halo quads — widths either side of every one of those seams, the narrowest
     images the kernel takes (4 .. 7 pixels; narrower ones stay on the tile kernel), heights below the mask's, per-channel
     border values and a batch."""
     mask = O.morph_kernel("box", k, k)
     cval = [9, 130, 251]
     for (w, h) in [(4, 9), (5, 2), (6, 1), (7, 40), (3, 8), (247, 5), (248, 3), (249, 11), (251, 7), (252, 4), (496, 6), (991, 3), (992, 9), (993, 4),
-                   (996, 5), (1241, 3), (1988, 2), (131, 400)]:
+                   (996, 5), (1241, 3), (1988, 2), (131, 400), (253, 6), (255, 3), (256, 8), (257, 5), (259, 4), (260, 3), (261, 9), (512, 4), (1023, 3), (1024, 6),
+                   (1025, 4), (1027, 3), (1028, 5), (1029, 2), (1285, 4)]:
         src = make(w, h, 3, np.uint8, seed=w + h)
         for op in ("dilate", "erode"):
             got = morph_gpu(gpu_stream, src, op, mask, border, cval)[0]
