@@ -177,6 +177,12 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
     return d;
 #endif
 }
+
+// prev / next lane's value by DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1): lane i takes lane i -/+ 1 and the END lane,
+// which has no source, keeps `end` — where a wave's halo value can be waiting.  A vector-ALU move, not an LDS-crossbar
+// instruction like ds_bpermute.  Checked on gfx950 by scripts/ubench/dpp_wave_shift.hip.
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t end) { return (uint32_t)__builtin_amdgcn_update_dpp((int)end, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v, uint32_t end) { return (uint32_t)__builtin_amdgcn_update_dpp((int)end, (int)v, 0x130, 0xf, 0xf, false); }
 struct QuadU8 { uint32_t p00, p01, p10, p11; };
 __device__ __forceinline__ uint32_t chan_u8(uint32_t px, int c) { return (px >> (8 * c)) & 0xffu; }
 

@@ -914,13 +914,8 @@ struct MorphRoll {
 };
 constexpr int kMrWavePx = 256, kMrTilePx = 4 * kMrWavePx;
 
-// prev / next lane's value by DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1): lane i takes lane i -/+ 1 and the END lane,
-// which has no source, keeps `end` — where the halo quad's value is waiting.  Checked on gfx950 by scripts/ubench/dpp_wave_shift.hip.
-__device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t end) { return (uint32_t)__builtin_amdgcn_update_dpp((int)end, (int)v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ uint32_t from_lane_above(uint32_t v, uint32_t end) { return (uint32_t)__builtin_amdgcn_update_dpp((int)end, (int)v, 0x130, 0xf, 0xf, false); }
-
 template <int K, bool DILATE>
-__global__ __launch_bounds__(256) void morph_u8_rgb_roll_kernel(MorphRoll a) {
+__global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_rgb_roll_kernel(MorphRoll a) {   // a register target for the scheduler: 5 x 5 105 -> <= 96, 7 x 7 137 -> <= 128 VGPRs
     constexpr int H = K / 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;

@@ -211,9 +211,12 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
 // bytes and a multiply-add — 7 instructions per byte for a 7-tap row pass.  De-interleaved, the taps of a channel are ADJACENT bytes
 // and v_dot4_u32_u8 takes four of them per instruction:
 //   * a lane owns FOUR PIXELS (12 bytes = 3 dwords, one 768-byte contiguous wave-load per row), de-interleaves them into one dword
-//     per channel (6 v_perm_b32) and gets its left / right neighbours' channel dwords by two wave shifts per channel (ds_bpermute:
-//     an LDS-crossbar instruction, not a vector-ALU one) — no LDS row buffer at all; lanes 0 and 63 are halo lanes (248 output
-//     pixels per wave);
+//     per channel (6 v_perm_b32) and gets its left / right neighbours' channel dwords by two wave shifts per channel — no LDS
+//     row buffer at all.  ALL 64 lanes store: a wave's row segment is 256 pixels = 768 bytes = whole 128-byte lines (the first
+//     version kept lanes 0 / 63 as halo lanes: 744-byte segments, every boundary splitting a line between two waves — a pure
+//     copy in that shape is 19 % slower, r03_rollcopy).  The quads either side of the wave come from one more load per row
+//     (the lower half's lanes all load the quad before the wave's first, the upper's the quad after its last), de-interleaved the
+//     same way and handed to the end lanes as the fill value of the DPP wave shifts;
 //   * horizontal pass per channel: the (up to 9) taps of output pixel j are bytes j + 4 - H ... of the 12-byte (prev, cur, next)
 //     string, taken four at a time: 6 v_alignbyte_b32 + 8 v_dot4_u32_u8 per 4 outputs for K = 7 (3.5 instructions per byte
 //     instead of 7), the rounding half in the accumulator operand;
@@ -224,11 +227,11 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
 // loading the quad from a clamped position and re-indexing its pixels with ONE per-lane byte selector per channel.
 // Same integers as the reference's two u8 passes ((acc + 128) >> 8 after each): byte-identical to the old kernel (tests run both).
 // For 3-channel images, 3..9 taps per axis whose quantised taps sum to <= 256 (every gaussian / box kernel), rows of >= 4 pixels.
-constexpr int kRgbWavePx = 248;                 // output pixels per wave (62 lanes x 4)
+constexpr int kRgbWavePx = 256;                 // output pixels per wave (64 lanes x 4)
 constexpr int kRgbTilePx = 4 * kRgbWavePx;      // per 256-thread block
 
 template <int K>
-__global__ __launch_bounds__(kBlock) void blur_u8_rgb_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky) {
+__global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky) {   // K = 7: 131 -> 128 VGPRs keeps 4 waves per SIMD
     constexpr int H = K / 2, G = (K + 3) / 4;   // taps are consumed four at a time
     static_assert(K >= 3 && K <= 9 && (K & 1), "3..9 taps: one neighbour quad on each side covers the window");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -239,18 +242,22 @@ __global__ __launch_bounds__(kBlock) void blur_u8_rgb_kernel(U8FilterArgs a, Tap
     const int y0 = ty * a.th;
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.src_stride;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
-    const int p = p0 - 4 + 4 * lane;                        // this lane's quad: pixels p .. p + 3 (lane 0 / 63: halo quads)
+    const int p = p0 + 4 * lane;                            // this lane's quad: pixels p .. p + 3
+    const int ph = lane < 32 ? p0 - 4 : p0 + kRgbWavePx;    // the wave's halo quads: left in the lower half's lanes, right in the upper's
     const bool edge = p0 < 4 || p0 + kRgbWavePx + 4 > a.cols;   // wave-uniform: some quad of the wave needs clamping
-    const int pc = min(max(p, 0), a.cols - 4);              // where the quad is loaded from (cols >= 4: host-checked)
+    const int pc = min(p, a.cols - 4), phc = min(max(ph, 0), a.cols - 4);   // where the quads are loaded from (cols >= 4: host-checked)
     // per-lane byte selector that re-indexes the loaded quad's pixels when the quad was clamped: pixel j <- loaded pixel
     // clamp(p + j, 0, cols - 1) - pc  (0x03020100 = identity)
-    uint32_t esel = 0x03020100u;
+    uint32_t esel = 0x03020100u, hsel = 0x03020100u;
     if (edge) {
-        esel = 0;
+        esel = hsel = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) esel |= (uint32_t)(min(max(p + j, 0), a.cols - 1) - pc) << (8 * j);
+        for (int j = 0; j < 4; ++j) {
+            esel |= (uint32_t)min(max(min(p + j, a.cols - 1) - pc, 0), 3) << (8 * j);
+            hsel |= (uint32_t)min(max(min(max(ph + j, 0), a.cols - 1) - phc, 0), 3) << (8 * j);
+        }
     }
-    const bool writer = lane >= 1 && lane <= 62 && p < a.cols;
+    const bool writer = p < a.cols;
     const bool full = p + 3 < a.cols;
     const int nrows = min(a.th, a.rows - y0) + 2 * H;
     int pf_row = y0 - H;
@@ -259,10 +266,12 @@ __global__ __launch_bounds__(kBlock) void blur_u8_rgb_kernel(U8FilterArgs a, Tap
 #pragma unroll
     for (int g = 0; g < 3; ++g) wq[g] = kx.k[4 * g] | (kx.k[4 * g + 1] << 8) | (kx.k[4 * g + 2] << 16) | (kx.k[4 * g + 3] << 24);
 
-    uint32_t q[K][3];  // K rows of raw loads in flight per lane
-    auto prefetch = [&](uint32_t (&d)[3]) {
-        const uint8_t* rp = src + (long long)min(max(pf_row, 0), a.rows - 1) * a.rowlen + 3 * pc;   // replicate rows
-        d[0] = *reinterpret_cast<const u32u*>(rp); d[1] = *reinterpret_cast<const u32u*>(rp + 4); d[2] = *reinterpret_cast<const u32u*>(rp + 8);
+    uint32_t q[K][6];  // K rows of raw loads in flight per lane: its quad and its half-wave's halo quad
+    auto prefetch = [&](uint32_t (&d)[6]) {
+        const uint8_t* rp = src + (long long)min(max(pf_row, 0), a.rows - 1) * a.rowlen;   // replicate rows
+        const uint8_t *rq = rp + 3 * pc, *rh = rp + 3 * phc;
+        d[0] = *reinterpret_cast<const u32u*>(rq); d[1] = *reinterpret_cast<const u32u*>(rq + 4); d[2] = *reinterpret_cast<const u32u*>(rq + 8);
+        d[3] = *reinterpret_cast<const u32u*>(rh); d[4] = *reinterpret_cast<const u32u*>(rh + 4); d[5] = *reinterpret_cast<const u32u*>(rh + 8);
         ++pf_row;
     };
 #pragma unroll
@@ -279,20 +288,23 @@ __global__ __launch_bounds__(kBlock) void blur_u8_rgb_kernel(U8FilterArgs a, Tap
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             const int r = rb + s;
-            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2];
+            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2], h0 = q[s][3], h1 = q[s][4], h2 = q[s][5];
             prefetch(q[s]);
             // de-interleave: [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3] -> one dword per channel, pixel j = byte j
-            uint32_t cur[3];
+            uint32_t cur[3], halo[3];
             cur[0] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c060300u), 0x05020100u);   // d0.b0 d0.b3 d1.b2 d2.b1
             cur[1] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);   // d0.b1 d1.b0 d1.b3 d2.b2
             cur[2] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);   // d0.b2 d1.b1 d2.b0 d2.b3
+            halo[0] = __builtin_amdgcn_perm(h2, __builtin_amdgcn_perm(h1, h0, 0x0c060300u), 0x05020100u);
+            halo[1] = __builtin_amdgcn_perm(h2, __builtin_amdgcn_perm(h1, h0, 0x0c070401u), 0x06020100u);
+            halo[2] = __builtin_amdgcn_perm(h2, __builtin_amdgcn_perm(h1, h0, 0x0c0c0502u), 0x07040100u);
             if (edge) {   // wave-uniform
 #pragma unroll
-                for (int c = 0; c < 3; ++c) cur[c] = __builtin_amdgcn_perm(0u, cur[c], esel);
+                for (int c = 0; c < 3; ++c) { cur[c] = __builtin_amdgcn_perm(0u, cur[c], esel); halo[c] = __builtin_amdgcn_perm(0u, halo[c], hsel); }
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const uint32_t prev = (uint32_t)__shfl_up((int)cur[c], 1), next = (uint32_t)__shfl_down((int)cur[c], 1);
+                const uint32_t prev = from_lane_below(cur[c], halo[c]), next = from_lane_above(cur[c], halo[c]);
                 const uint32_t str[4] = {prev, cur[c], next, next};   // bytes 0..11 = pixels p - 4 .. p + 7 of this channel (+ a don't-care dword)
                 uint32_t sum[4];
 #pragma unroll

@@ -66,6 +66,20 @@ def test_blur_u8_edge_shapes(gpu_stream, shape):
         assert_same_bits(got, O.gaussian_blur_u8(src, ksize, sigma)[0], f"{shape} {ksize}")
 
 
+@pytest.mark.parametrize("k", [3, 5, 7, 9])
+def test_blur_u8_rgb_wave_and_block_seams(gpu_stream, k):
+    """The planar RGB kernel: a wave owns 256 pixels (all 64 lanes store), a block 1024; the quads either side of a wave come from
+    its halo load, clamped and re-indexed at the image's edges.  Widths either side of every seam, the narrowest rows the kernel
+    takes (4 pixels), a last quad of 1 / 2 / 3 pixels, fewer rows than taps."""
+    for w, h in [(4, 5), (5, 1), (6, 2), (7, 11), (252, 3), (253, 4), (255, 2), (256, 9), (257, 3), (259, 5), (260, 4), (261, 2), (511, 3), (513, 6),
+                 (1023, 2), (1024, 5), (1025, 3), (1027, 4), (1028, 2), (1029, 7), (1281, 3), (2050, 2), (130, 300)]:
+        src = pat(w, h, 3, seed=w * 7 + h)
+        got = blur_gpu(gpu_stream, "gaussian", src, (k, k), (0.3 * k, 0.2 * k + 0.5))[0]
+        assert_same_bits(got, O.gaussian_blur_u8(src, (k, k), (0.3 * k, 0.2 * k + 0.5))[0], f"gaussian {k} {w}x{h}")
+    src = pat(1030, 40, 3, seed=5)
+    assert_same_bits(blur_gpu(gpu_stream, "box", src, (k, k))[0], O.box_blur_u8(src, (k, k)), f"box {k}")
+
+
 def test_blur_u8_batch_4k_strip_and_errors(gpu_stream):
     from kornia_rs import _ffi
     n = 3
