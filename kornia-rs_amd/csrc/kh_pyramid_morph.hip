@@ -436,21 +436,25 @@ __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
 // channel, takes the two border pixels of its neighbours by wave shifts, and runs the reference's [1 4 6 4 1] row pass on ADJACENT
 // bytes with v_dot4_u32_u8 — 8 dot4 + 2 alignbyte per channel for its four destination pixels — into 16-bit lanes (<= 4080, the
 // reference's u16 intermediate); the column pass is the same packed 16-bit arithmetic as the tile kernel (binomial5) on a five-row
-// register ring, every second source row; four destination pixels leave as one 12-byte store.  reflect-101 borders: rows by
-// reflecting the row index, columns (edge waves only) by loading the eight pixels from a clamped position and re-indexing them with
-// one per-lane byte selector pair.  Same integers as the per-pixel kernel: byte-identical (tests run both).  RGB8, sw >= 8.
-constexpr int kPdRollWaveDst = 248;                  // destination pixels per wave (62 lanes x 4)
+// register ring, every second source row; four destination pixels leave as one 12-byte store.  ALL 64 lanes store — a wave's
+// destination row segment is 256 pixels = 768 bytes = whole 128-byte lines (r03_rollcopy: 744-byte segments, with lanes 0 / 63
+// as halo lanes, split a line between two waves at every boundary and cost 19 % on a pure copy) — and the pixels either side of
+// the wave come from one more quad load per row: the lower half's lanes load the quad before the wave's first pixel, the upper's
+// the quad after its last, de-interleaved the same way and handed to the end lanes as the fill value of the DPP wave shifts.
+// (Tried and dropped: chunked loads and stores through LDS, r03v / r03x — the L1 absorbs the 24-byte-stride loads.)
+// reflect-101 borders: rows by reflecting the row index, columns (edge waves only) by loading from a clamped position and
+// re-indexing with per-lane byte selectors.  Same integers as the per-pixel kernel: byte-identical (tests run both).  RGB8, sw >= 8.
+constexpr int kPdRollWaveDst = 256;                  // destination pixels per wave (64 lanes x 4)
 constexpr int kPdRollTileDst = 4 * kPdRollWaveDst;   // per 256-thread block
 struct PyrRoll {
     const uint8_t* src;
     uint8_t* dst;
-    int sw, sh, dw, dh, th;   // th = destination rows per strip
-    int dense;                // pyrdown: destination rows leave as contiguous chunks through LDS (1) or straight from the owning lanes (0)
+    int sw, sh, dw, dh, th;   // th = destination rows (pyrdown) / source rows (pyrup) per strip
     long long ss, ds;
     XcdTiles tiles;
 };
 
-__global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
+__global__ __launch_bounds__(256, 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
     if (!xcd_tile(a.tiles, tx, ty, bz)) return;
@@ -459,17 +463,18 @@ __global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
     const int Y0 = ty * a.th, thr = min(a.th, a.dh - Y0);
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
-    const int p = 2 * X0 - 8 + 8 * lane;                              // this lane's source pixels p .. p + 7 (lanes 0 / 63: halos)
-    const bool edge = 2 * X0 < 8 || 2 * X0 + 2 * kPdRollWaveDst + 8 > a.sw;   // wave-uniform: some lane's pixels need re-indexing
-    constexpr bool kDenseLoads = false;   // chunked loads through LDS measured SLOWER than six strided dword loads per lane (1.91 vs 1.54 ms, r03v vs r03p): the L1 absorbs strided reads; it is strided STORES that hurt
-    const int pc = min(max(p, 0), a.sw - 8);                          // where the eight pixels are loaded from (sw >= 8: host-checked)
-    uint32_t selA = 0x03020100u, selB = 0x07060504u;                  // pixel j <- loaded pixel reflect_101(p + j) - pc (identity inside)
+    const int p = 2 * X0 + 8 * lane;                                  // this lane's source pixels p .. p + 7
+    const int ph = lane < 32 ? 2 * X0 - 4 : 2 * X0 + 2 * kPdRollWaveDst;   // the wave's halo quads: left in the lower half's lanes, right in the upper's
+    const bool edge = 2 * X0 < 4 || 2 * X0 + 2 * kPdRollWaveDst + 4 > a.sw;   // wave-uniform: some lane's pixels need re-indexing
+    const int pc = min(p, a.sw - 8), phc = min(max(ph, 0), a.sw - 4);  // where the pixels are loaded from (sw >= 8: host-checked)
+    uint32_t selA = 0x03020100u, selB = 0x07060504u, selH = 0x03020100u;   // pixel j <- loaded pixel reflect_101(p + j) - pc (identity inside)
     if (edge) {
-        selA = selB = 0;
+        selA = selB = selH = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             selA |= (uint32_t)min(max(reflect_101(p + j, a.sw) - pc, 0), 7) << (8 * j);
             selB |= (uint32_t)min(max(reflect_101(p + 4 + j, a.sw) - pc, 0), 7) << (8 * j);
+            selH |= (uint32_t)min(max(reflect_101(ph + j, a.sw) - phc, 0), 3) << (8 * j);
         }
     }
     const int seg_bytes = 3 * min(kPdRollWaveDst, a.dw - X0);         // destination bytes of this wave per row (wave-uniform)
@@ -477,29 +482,14 @@ __global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
     const int n = 2 * thr + 3;                                        // source rows walked: 2 Y0 - 2 .. 2 (Y0 + thr - 1) + 2
     int pf = 2 * Y0 - 2;
 
-    // Loads.  A lane needs 24 contiguous bytes of the row, the wave 1536: read as six dwords at a 24-byte lane stride every load
-    // instruction touches every cache line of the segment with a sixth of its bytes.  Interior waves (no clamped lane) therefore load
-    // the segment as 96 contiguous 16-byte chunks — lane j takes chunk j and, for j < 32, chunk 64 + j — and redistribute through a
-    // wave-private LDS row; edge waves keep the per-lane loads (their lanes' windows are shifted by the clamp).
-    __shared__ __attribute__((aligned(16))) uint32_t lrow[4][96 * 4];      // one source row segment per wave
-    __shared__ __attribute__((aligned(16))) uint32_t orow[4][64 * 3];      // one destination row segment per wave (12 bytes per lane)
-    const int seg0 = 3 * (2 * X0 - 8);                                      // byte offset of lane 0's first pixel in a row (interior waves)
-    const int c1 = 16 * min(64 + lane, 95);                                 // this lane's second chunk (lanes >= 32 repeat chunk 95)
-    uint32_t q[5][8];  // five rows of raw loads in flight per lane: six dwords (edge) / two 16-byte chunks (interior)
-    auto prefetch = [&](uint32_t (&d)[8]) {
+    uint32_t q[5][9];  // five rows of raw loads in flight per lane: its eight pixels (six dwords) and its half-wave's halo quad
+    auto prefetch = [&](uint32_t (&d)[9]) {
         const uint8_t* row = src + (long long)reflect_101(pf, a.sh) * rowb;
-        if (edge || !kDenseLoads) {
-            const uint8_t* rp = row + 3 * pc;
+        const uint8_t *rp = row + 3 * pc, *rh = row + 3 * phc;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) d[k] = *reinterpret_cast<const u32_unaligned*>(rp + 4 * k);
-        } else {
-            // two 8-byte loads per chunk: a 16-byte vector type with byte alignment is split into dword / byte accesses by the compiler
-            const uint8_t* g0 = row + seg0 + 16 * lane, *g1 = row + seg0 + c1;
-            const uint64_t a0 = *reinterpret_cast<const u64_unaligned*>(g0), a1 = *reinterpret_cast<const u64_unaligned*>(g0 + 8);
-            const uint64_t b0 = *reinterpret_cast<const u64_unaligned*>(g1), b1 = *reinterpret_cast<const u64_unaligned*>(g1 + 8);
-            d[0] = (uint32_t)a0; d[1] = (uint32_t)(a0 >> 32); d[2] = (uint32_t)a1; d[3] = (uint32_t)(a1 >> 32);
-            d[4] = (uint32_t)b0; d[5] = (uint32_t)(b0 >> 32); d[6] = (uint32_t)b1; d[7] = (uint32_t)(b1 >> 32);
-        }
+        for (int k = 0; k < 6; ++k) d[k] = *reinterpret_cast<const u32_unaligned*>(rp + 4 * k);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[6 + k] = *reinterpret_cast<const u32_unaligned*>(rh + 4 * k);
         ++pf;
     };
 #pragma unroll
@@ -516,31 +506,24 @@ __global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
             const int i = ib + s, slot = s % 5;
-            uint32_t d[6];
-            if (edge || !kDenseLoads) {
+            uint32_t d[9];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) d[k] = q[slot][k];
-            } else {   // chunks -> LDS -> this lane's 24 bytes
-                *reinterpret_cast<u32x4_t*>(&lrow[wv][4 * lane]) = u32x4_t{q[slot][0], q[slot][1], q[slot][2], q[slot][3]};
-                *reinterpret_cast<u32x4_t*>(&lrow[wv][c1 >> 2]) = u32x4_t{q[slot][4], q[slot][5], q[slot][6], q[slot][7]};
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int k = 0; k < 6; ++k) d[k] = lrow[wv][6 * lane + k];
-                __builtin_amdgcn_wave_barrier();   // read before the next row overwrites it (DS operations of a wave are ordered)
-            }
+            for (int k = 0; k < 9; ++k) d[k] = q[slot][k];
             prefetch(q[slot]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                // de-interleave: quad [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3] -> one dword per channel (pixel j = byte j), twice
+                // de-interleave: quad [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3] -> one dword per channel (pixel j = byte j), three times
                 constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
                 uint32_t A = __builtin_amdgcn_perm(d[2], __builtin_amdgcn_perm(d[1], d[0], in1[c]), in2[c]);
                 uint32_t B = __builtin_amdgcn_perm(d[5], __builtin_amdgcn_perm(d[4], d[3], in1[c]), in2[c]);
+                uint32_t Hq = __builtin_amdgcn_perm(d[8], __builtin_amdgcn_perm(d[7], d[6], in1[c]), in2[c]);
                 if (edge) {   // wave-uniform
                     const uint32_t a0 = A, b0 = B;
                     A = __builtin_amdgcn_perm(b0, a0, selA);
                     B = __builtin_amdgcn_perm(b0, a0, selB);
+                    Hq = __builtin_amdgcn_perm(0u, Hq, selH);
                 }
-                const uint32_t prevB = (uint32_t)__shfl_up((int)B, 1), nextA = (uint32_t)__shfl_down((int)A, 1);
+                const uint32_t prevB = from_lane_below(B, Hq), nextA = from_lane_above(A, Hq);
                 constexpr uint32_t kW = 0x04060401u;   // taps 1 4 6 4 on four adjacent bytes; the fifth tap (1) is a second dot4
                 const uint32_t h0 = __builtin_amdgcn_udot4(A, 0x00010000u, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A, prevB, 2), kW, 0u, false), false);
                 const uint32_t h1 = __builtin_amdgcn_udot4(B, 0x00000001u, __builtin_amdgcn_udot4(A, kW, 0u, false), false);
@@ -559,37 +542,21 @@ __global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
                         const u16x2_t b5 = binomial5(ring[(s + 1) % 5][c][h], ring[(s + 2) % 5][c][h], ring[(s + 3) % 5][c][h], ring[(s + 4) % 5][c][h], ring[slot][c][h]);
                         v[c][h] = as_u32(__builtin_elementwise_min((b5 + half) >> eight, top));   // pixels (2h, 2h + 1) in bytes 0 and 2
                     }
-                {   // re-interleave
-                    const uint32_t rg01 = __builtin_amdgcn_perm(v[1][0], v[0][0], 0x06020400u);   // R0 G0 R1 G1
-                    const uint32_t rg23 = __builtin_amdgcn_perm(v[1][1], v[0][1], 0x06020400u);   // R2 G2 R3 G3
-                    const uint32_t w0 = __builtin_amdgcn_perm(v[2][0], rg01, 0x02040100u);        // R0 G0 B0 R1
-                    const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[2][0], rg01, 0x0c0c0603u), rg23, 0x01000504u);   // G1 B1 | R2 G2
-                    const uint32_t w2 = __builtin_amdgcn_perm(v[2][1], rg23, 0x06030204u);        // B2 R3 G3 B3
-                    uint8_t* o = dst + out_off;
-                    if (a.dense) {   // park the 12 bytes in the wave's LDS row, store contiguous 16-byte chunks (wave-uniform choice)
-                        orow[wv][3 * lane] = w0; orow[wv][3 * lane + 1] = w1; orow[wv][3 * lane + 2] = w2;
-                        __builtin_amdgcn_wave_barrier();
-                        const uint8_t* xb = reinterpret_cast<const uint8_t*>(orow[wv]) + 12;       // lane 1's first byte = destination pixel X0
-                        const int off = 16 * lane;
-                        if (off + 16 <= seg_bytes) {
-                            const uint32_t* xw = reinterpret_cast<const uint32_t*>(xb + off);
-                            *reinterpret_cast<u64_unaligned*>(o + off) = (uint64_t)xw[0] | ((uint64_t)xw[1] << 32);
-                            *reinterpret_cast<u64_unaligned*>(o + off + 8) = (uint64_t)xw[2] | ((uint64_t)xw[3] << 32);
-                        } else if (off < seg_bytes) {   // the segment's last, partial chunk (one lane)
-                            for (int b = off; b < seg_bytes; ++b) o[b] = xb[b];
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    } else if (lane >= 1 && lane <= 62) {   // straight from the owning lane: 12 bytes at 12 (lane - 1)
-                        const int off = 12 * (lane - 1);
-                        if (off + 12 <= seg_bytes) {
-                            *reinterpret_cast<u32_unaligned*>(o + off) = w0; *reinterpret_cast<u32_unaligned*>(o + off + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + off + 8) = w2;
-                        } else {
-                            const uint32_t w[3] = {w0, w1, w2};
+                // re-interleave; 12 bytes straight from the owning lane
+                const uint32_t rg01 = __builtin_amdgcn_perm(v[1][0], v[0][0], 0x06020400u);   // R0 G0 R1 G1
+                const uint32_t rg23 = __builtin_amdgcn_perm(v[1][1], v[0][1], 0x06020400u);   // R2 G2 R3 G3
+                const uint32_t w0 = __builtin_amdgcn_perm(v[2][0], rg01, 0x02040100u);        // R0 G0 B0 R1
+                const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[2][0], rg01, 0x0c0c0603u), rg23, 0x01000504u);   // G1 B1 | R2 G2
+                const uint32_t w2 = __builtin_amdgcn_perm(v[2][1], rg23, 0x06030204u);        // B2 R3 G3 B3
+                uint8_t* o = dst + out_off;
+                const int off = 12 * lane;
+                if (off + 12 <= seg_bytes) {
+                    *reinterpret_cast<u32_unaligned*>(o + off) = w0; *reinterpret_cast<u32_unaligned*>(o + off + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + off + 8) = w2;
+                } else {
+                    const uint32_t w[3] = {w0, w1, w2};
 #pragma unroll
-                            for (int b = 0; b < 9; ++b)   // at most three pixels of a quad that reaches past the last destination column
-                                if (off + b < seg_bytes) o[off + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
-                        }
-                    }
+                    for (int b = 0; b < 9; ++b)   // at most three pixels of a quad that reaches past the last destination column
+                        if (off + b < seg_bytes) o[off + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
                 }
                 out_off += (long long)a.dw * 3;
             }
@@ -607,15 +574,19 @@ __global__ __launch_bounds__(256) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
 //   odd destination columns   (p[x] + p[x+1] + 1) >> 1            : a bytewise rounding average of two dwords, (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7f),
 //                             four pixels in five instructions;
 // column pass on the three-row ring: odd destination rows are the same bytewise average of two packed rows, even rows the [1 6 1] sum
-// in 16-bit lanes (rows kept unpacked in the ring).  Eight destination pixels per row leave as three 8-byte stores, two destination rows
-// per source row.  reflect-101 columns on edge waves by re-indexing a clamped quad (one byte selector per lane).  Same integers as the
-// per-pixel kernel: byte-identical (tests run both).  RGB8, sw >= 4.
-constexpr int kPuRollWaveSrc = 248;                  // source pixels per wave (62 lanes x 4)
+// in 16-bit lanes (rows kept unpacked in the ring).  Two destination rows per source row; a wave's destination row segment is 512 pixels
+// = 1536 bytes = whole 128-byte lines, written as 96 contiguous 16-byte chunks through a wave-private LDS row (below).  All 64 lanes
+// produce output: the source pixels either side of the wave come from one more quad load per row (lower half's lanes: the quad before
+// the wave's first pixel, upper half's: the quad after its last) handed to the end lanes as the fill value of the DPP wave shifts
+// (the first version kept lanes 0 / 63 as halo lanes: 1488-byte segments that split a line between two waves at every boundary).
+// reflect-101 columns on edge waves by re-indexing clamped quads (one byte selector per lane).  Same integers as the per-pixel kernel:
+// byte-identical (tests run both).  RGB8, sw >= 4.
+constexpr int kPuRollWaveSrc = 256;                  // source pixels per wave (64 lanes x 4)
 constexpr int kPuRollTileSrc = 4 * kPuRollWaveSrc;
 
 __device__ __forceinline__ uint32_t avg_round_u8x4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
 
-__global__ __launch_bounds__(256) void pyrup_u8_rgb_roll_kernel(PyrRoll a) {   // th = SOURCE rows per strip here
+__global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) {   // th = SOURCE rows per strip here
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
     if (!xcd_tile(a.tiles, tx, ty, bz)) return;
@@ -624,14 +595,18 @@ __global__ __launch_bounds__(256) void pyrup_u8_rgb_roll_kernel(PyrRoll a) {   /
     const int y0 = ty * a.th, thr = min(a.th, a.sh - y0);
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
-    const int p = x0 - 4 + 4 * lane;                                  // this lane's source pixels p .. p + 3 (lanes 0 / 63: halos)
+    const int p = x0 + 4 * lane;                                      // this lane's source pixels p .. p + 3
+    const int ph = lane < 32 ? x0 - 4 : x0 + kPuRollWaveSrc;          // the wave's halo quads: left in the lower half's lanes, right in the upper's
     const bool edge = x0 < 4 || x0 + kPuRollWaveSrc + 4 > a.sw;       // wave-uniform
-    const int pc = min(max(p, 0), a.sw - 4);                          // sw >= 4: host-checked
-    uint32_t esel = 0x03020100u;
+    const int pc = min(p, a.sw - 4), phc = min(max(ph, 0), a.sw - 4); // sw >= 4: host-checked
+    uint32_t esel = 0x03020100u, hsel = 0x03020100u;
     if (edge) {
-        esel = 0;
+        esel = hsel = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) esel |= (uint32_t)min(max(reflect_101(p + j, a.sw) - pc, 0), 3) << (8 * j);
+        for (int j = 0; j < 4; ++j) {
+            esel |= (uint32_t)min(max(reflect_101(p + j, a.sw) - pc, 0), 3) << (8 * j);
+            hsel |= (uint32_t)min(max(reflect_101(ph + j, a.sw) - phc, 0), 3) << (8 * j);
+        }
     }
     const int rowb = a.sw * 3;
     const long long drow = (long long)a.dw * 3;
@@ -640,10 +615,12 @@ __global__ __launch_bounds__(256) void pyrup_u8_rgb_roll_kernel(PyrRoll a) {   /
     const int n = thr + 2;                                            // source rows walked: y0 - 1 .. y0 + thr
     int pf = y0 - 1;
 
-    uint32_t q[3][3];
-    auto prefetch = [&](uint32_t (&d)[3]) {
-        const uint8_t* rp = src + (long long)reflect_101(pf, a.sh) * rowb + 3 * pc;
+    uint32_t q[3][6];   // the lane's quad and its half-wave's halo quad
+    auto prefetch = [&](uint32_t (&d)[6]) {
+        const uint8_t* row = src + (long long)reflect_101(pf, a.sh) * rowb;
+        const uint8_t *rp = row + 3 * pc, *rh = row + 3 * phc;
         d[0] = *reinterpret_cast<const u32_unaligned*>(rp); d[1] = *reinterpret_cast<const u32_unaligned*>(rp + 4); d[2] = *reinterpret_cast<const u32_unaligned*>(rp + 8);
+        d[3] = *reinterpret_cast<const u32_unaligned*>(rh); d[4] = *reinterpret_cast<const u32_unaligned*>(rh + 4); d[5] = *reinterpret_cast<const u32_unaligned*>(rh + 8);
         ++pf;
     };
 #pragma unroll
@@ -663,14 +640,15 @@ __global__ __launch_bounds__(256) void pyrup_u8_rgb_roll_kernel(PyrRoll a) {   /
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int i = ib + s;
-            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2];
+            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2], g0 = q[s][3], g1 = q[s][4], g2 = q[s][5];
             prefetch(q[s]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
                 uint32_t A = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, in1[c]), in2[c]);   // this channel's four pixels
-                if (edge) A = __builtin_amdgcn_perm(0u, A, esel);
-                const uint32_t prev = (uint32_t)__shfl_up((int)A, 1), next = (uint32_t)__shfl_down((int)A, 1);
+                uint32_t Hq = __builtin_amdgcn_perm(g2, __builtin_amdgcn_perm(g1, g0, in1[c]), in2[c]);  // and the halo quad's
+                if (edge) { A = __builtin_amdgcn_perm(0u, A, esel); Hq = __builtin_amdgcn_perm(0u, Hq, hsel); }
+                const uint32_t prev = from_lane_below(A, Hq), next = from_lane_above(A, Hq);
                 const uint32_t w2 = __builtin_amdgcn_alignbyte(next, A, 1);                 // p[x+1] for the four pixels
                 constexpr uint32_t kT = 0x0020c020u;   // taps (1, 6, 1, 0) x 32; accumulator 4 x 32
                 const uint32_t t0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A, prev, 3), kT, 128u, false);
@@ -720,7 +698,7 @@ __global__ __launch_bounds__(256) void pyrup_u8_rgb_roll_kernel(PyrRoll a) {   /
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const uint8_t* xb = reinterpret_cast<const uint8_t*>(xpose[wv][r]) + 24;   // lane 1's first byte = destination pixel 2 x0
+                    const uint8_t* xb = reinterpret_cast<const uint8_t*>(xpose[wv][r]);        // lane 0's first byte = destination pixel 2 x0
                     uint8_t* o = dst + row_off + r * drow;
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -1329,8 +1307,7 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
     if (batch == 0) return KH_OK;
     static const bool no_roll = [] { const char* e = getenv("KH_PYR_ROLL"); return e && e[0] == '0'; }();   // dev / test knob: the tile kernel
     if (channels == 3 && sw >= 8 && !no_roll) {   // RGB8: the rolling planar kernel
-        PyrRoll r{src, dst, sw, sh, dw, dh, 0, 0, ss, ds, XcdTiles{}};
-        { const char* e = getenv("KH_PYR_DENSE_STORES"); r.dense = e && e[0] == '1'; }   // dev knob (A/B r03x)
+        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
         const unsigned tiles_x = cdiv(dw, kPdRollTileDst);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
@@ -1386,7 +1363,7 @@ int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_
     const int dw = sw * 2, dh = sh * 2;
     if (int32_t rc = check_pyr("kh_pyrup_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
-    PyrRoll r{src, dst, sw, sh, dw, dh, 0, 1, ss, ds, XcdTiles{}};
+    PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
     const unsigned tiles_x = cdiv(sw, kPuRollTileSrc);
     const long long cols_blocks = (long long)tiles_x * batch;
     long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU

@@ -43,7 +43,7 @@ def test_pyramid_matches_oracle(gpu_stream, dtype, c, up):
 def test_pyrdown_u8_tiled_interior_and_edge_tiles(gpu_stream, c):
     """Sizes that give the tiled pyrdown_u8 kernel (64 x 16 destination pixels per block) interior tiles (dword window loads),
     interior tiles whose last window ends exactly on the image's last bytes, and ragged right / bottom tiles."""
-    for w, h in [(520, 140), (260, 65), (259, 65), (261, 66), (262, 67), (265, 66), (267, 65), (513, 33), (390, 130), (2101, 21), (1990, 37), (8, 9), (9, 8), (497, 12), (503, 75)]:  # + widths around the rolling RGB kernel's 496-source-pixel waves and 1984-pixel blocks
+    for w, h in [(520, 140), (260, 65), (259, 65), (261, 66), (262, 67), (265, 66), (267, 65), (513, 33), (390, 130), (2101, 21), (1990, 37), (8, 9), (9, 8), (497, 12), (503, 75), (511, 9), (512, 7), (514, 8), (519, 5), (520, 6), (521, 4), (2047, 5), (2049, 6), (2056, 4), (2057, 3)]:  # + widths around the rolling RGB kernel's 512-source-pixel waves and 2048-pixel blocks
         src = make(w, h, c, np.uint8, seed=w)
         assert_same_bits(pyr_gpu(gpu_stream, src, False)[0], O.pyrdown(src), f"pyrdown u8 c{c} {w}x{h}")
     n = 3
@@ -186,9 +186,9 @@ def test_morphology_unit_tests_batch_and_errors(gpu_stream):  # ops.rs:326-400
 
 @pytest.mark.parametrize("c", [1, 3, 4])
 def test_pyrup_u8_rolling_wave_boundaries(gpu_stream, c):
-    """Source widths around the rolling RGB kernel's 248-source-pixel waves and 992-pixel blocks, partial last quads, rows shorter than
+    """Source widths around the rolling RGB kernel's 256-source-pixel waves and 1024-pixel blocks, partial last quads, rows shorter than
     a quad (the pair kernel), strips of a few rows, a batch; the other channel counts take the pair kernel on the same shapes."""
-    for w, h in [(4, 3), (5, 2), (7, 9), (247, 5), (248, 17), (249, 33), (251, 4), (253, 6), (992, 3), (993, 5), (1003, 18), (3, 40), (500, 47)]:
+    for w, h in [(4, 3), (5, 2), (7, 9), (247, 5), (248, 17), (249, 33), (251, 4), (253, 6), (992, 3), (993, 5), (1003, 18), (3, 40), (500, 47), (255, 4), (256, 6), (257, 5), (259, 3), (260, 7), (261, 2), (1023, 3), (1024, 4), (1025, 5), (1028, 2), (1029, 3)]:
         src = make(w, h, c, np.uint8, seed=w + h)
         assert_same_bits(pyr_gpu(gpu_stream, src, True)[0], O.pyrup(src), f"pyrup u8 c{c} {w}x{h}")
     n = 3
