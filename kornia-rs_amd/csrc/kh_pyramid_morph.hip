@@ -50,7 +50,10 @@ __device__ __forceinline__ int reflect_101(int p, int len) {  // pyramid.rs:252-
     return p >= len ? period - p : p;
 }
 
-// pyrdown_f32 (:312-430): 5x5 outer-product taps, ky-major accumulation, reflect-101 border
+// pyrdown_f32 (:312-430): 5x5 outer-product taps, ky-major accumulation, reflect-101 border.
+// (Round 3 tried sharing source pixels along the wave — a lane loads only its own pair and takes the other three pixels from the
+// lanes either side by DPP shifts, 10 full-wave loads per pixel instead of 25: 2.53 ms against this kernel's 2.22 on one box,
+// r03_wl7 — the row-by-row load / shift dependency costs more than the loads it saves.  The kernel is not addresser-bound.)
 template <int C>
 __global__ __launch_bounds__(kBx* kBy) void pyrdown_f32_kernel(Pyr<float> a) {
     KH_PYR_PROLOGUE(float)

@@ -91,6 +91,36 @@ __global__ __launch_bounds__(64 * WAVES) void roll16(A a) {
     }
     if (MODE == 2 && acc == 0x12345u) dst[0] = 1;
 }
+// the staged gather's store shape: a 512-thread block owns a TW x TH pixel tile of NB consecutive images, a thread 4 pixels (12 bytes),
+// threads row-major in the tile: a wave's store instruction covers 256 / TW row segments of 3 TW bytes
+template <int TW, int NB>
+__global__ __launch_bounds__(512) void tile_store(A a, int copy) {
+    constexpr int TH = 2048 / TW, TXN = TW / 4;
+    const int tx = threadIdx.x % TXN, ty = threadIdx.x / TXN;
+    const int x4 = blockIdx.x * TW + 4 * tx, y = blockIdx.y * TH + ty;
+    if (x4 >= a.w || y >= a.h) return;
+    const long long off = (long long)y * a.w * 3 + 3 * x4;
+    for (int b = 0; b < NB; ++b) {
+        const long long f = ((long long)blockIdx.z * NB + b) * a.fs + off;
+        uint32_t d0 = threadIdx.x, d1 = b, d2 = 7;
+        if (copy) { d0 = *(const u32u*)(a.src + f); d1 = *(const u32u*)(a.src + f + 4); d2 = *(const u32u*)(a.src + f + 8); }
+        *(u32u*)(a.dst + f) = d0; *(u32u*)(a.dst + f + 4) = d1; *(u32u*)(a.dst + f + 8) = d2;
+    }
+}
+// a 64-px-wide tile PAIR per block: ORDER 0 = per image, left tile then right tile; 1 = all images of the left tile, then of the right
+template <int ORDER>
+__global__ __launch_bounds__(512) void tile_pair_store(A a) {
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    const int y = blockIdx.y * 32 + ty;
+    if (y >= a.h) return;
+    for (int i = 0; i < 16; ++i) {
+        const int b = ORDER == 0 ? i >> 1 : i & 7, half = ORDER == 0 ? i & 1 : i >> 3;
+        const int x4 = blockIdx.x * 128 + half * 64 + 4 * tx;
+        if (x4 >= a.w) continue;
+        const long long f = ((long long)blockIdx.z * 8 + b) * a.fs + (long long)y * a.w * 3 + 3 * x4;
+        *(u32u*)(a.dst + f) = threadIdx.x; *(u32u*)(a.dst + f + 4) = b; *(u32u*)(a.dst + f + 8) = 7;
+    }
+}
 __global__ __launch_bounds__(256) void flat16(const u32x4* __restrict__ s, u32x4* __restrict__ d, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) d[i] = s[i];
 }
@@ -131,6 +161,16 @@ int main(int argc, char** argv) {
     R16(5, 8, 360, 0, "roll16 K5 8 waves per block")
     R16(5, 4, 360, 2, "roll16 K5 LOAD only")
     R16(5, 4, 360, 3, "roll16 K5 STORE only")
+#define TS(TW, COPY, NAME) vs.push_back({NAME, [&] { A a{src, dst, W, H, 0, (long long)fb}; hipLaunchKernelGGL((tile_store<TW, 8>), dim3(cd(W, TW), cd(H, 2048 / TW), N / 8), dim3(512), 0, st, a, COPY); }, {}});
+    TS(64, 0, "tile 64 x 32 px x 8 images STORE only (the staged gather's shape: 192-byte segments)")
+    TS(128, 0, "tile 128 x 16 STORE only (384-byte segments)")
+    TS(256, 0, "tile 256 x 8 STORE only (768-byte segments)")
+    TS(512, 0, "tile 512 x 4 STORE only")
+    vs.push_back({"tile pair 2 x (64 x 32) per block, per image left then right, STORE only", [&] { A a{src, dst, W, H, 0, (long long)fb}; hipLaunchKernelGGL((tile_pair_store<0>), dim3(cd(W, 128), cd(H, 32), N / 8), dim3(512), 0, st, a); }, {}});
+    vs.push_back({"tile pair 2 x (64 x 32) per block, 8 images left then 8 images right, STORE only", [&] { A a{src, dst, W, H, 0, (long long)fb}; hipLaunchKernelGGL((tile_pair_store<1>), dim3(cd(W, 128), cd(H, 32), N / 8), dim3(512), 0, st, a); }, {}});
+    TS(64, 1, "tile 64 x 32 copy")
+    TS(128, 1, "tile 128 x 16 copy")
+    TS(256, 1, "tile 256 x 8 copy")
     vs.push_back({"flat16 grid-stride copy", [&] { hipLaunchKernelGGL(flat16, dim3(256 * 32), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, (long long)(fb * N / 16)); }, {}});
     for (int r = 0; r < ROUNDS + 1; ++r)
         for (auto& v : vs) {

@@ -40,6 +40,20 @@ def test_pyramid_matches_oracle(gpu_stream, dtype, c, up):
 
 
 @pytest.mark.parametrize("c", [1, 3, 4])
+def test_pyrdown_f32_wave_seams(gpu_stream, c):
+    """Destination widths either side of one / two / four waves (a wave = 64 destination pixels of one row), odd and even source
+    widths (the last destination pixel has one source pixel or two), one- to five-row images and a batch."""
+    for w, h in [(1, 1), (2, 3), (3, 1), (4, 2), (5, 5), (126, 4), (127, 3), (128, 5), (129, 2), (130, 7), (131, 3), (254, 3), (255, 2), (256, 4), (257, 3), (258, 2),
+                 (259, 5), (511, 2), (512, 3), (513, 2), (514, 9), (700, 33)]:
+        src = make(w, h, c, np.float32, seed=3 * w + h)
+        assert_same_bits(pyr_gpu(gpu_stream, src, False)[0], O.pyrdown(src), f"pyrdown f32 c{c} {w}x{h}")
+    batch = np.stack([make(261, 19, c, np.float32, seed=k) for k in range(3)])
+    got = pyr_gpu(gpu_stream, batch, False, batch=3)
+    for k in range(3):
+        assert_same_bits(got[k], O.pyrdown(batch[k]), f"pyrdown f32 batch frame {k}")
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
 def test_pyrdown_u8_tiled_interior_and_edge_tiles(gpu_stream, c):
     """Sizes that give the tiled pyrdown_u8 kernel (64 x 16 destination pixels per block) interior tiles (dword window loads),
     interior tiles whose last window ends exactly on the image's last bytes, and ragged right / bottom tiles."""
