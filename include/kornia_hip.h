@@ -200,7 +200,8 @@ KH_API int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void
                                     const kh_preprocess_params* p);
 
 /* Name of the kernel variant kh_preprocess_to_chw would launch for `p` (for profiles/benches):
- * "generic" or "nv12_identity".  Returns NULL and sets the error on invalid params.           */
+ * "generic", "generic_bilinear_on_grid" (bilinear whose source coordinates all fall on whole pixels: one tap per
+ * pixel, same bits) or "nv12_identity".  Returns NULL and sets the error on invalid params.                       */
 KH_API const char* kh_preprocess_variant(const kh_preprocess_params* p);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -369,6 +369,7 @@ __host__ __device__ __forceinline__ float quot3(float n, float d, float rc) {
 // tap gathers are in flight per lane (the kernel is latency-bound: 8 waves/SIMD x 1 pixel measured
 // 2.46 ms on 1080p -> 640x640 x 1024; no per-pixel integer division either).  grid.z = frame.
 constexpr int kGenPx = 4;
+constexpr int kSampleBilinearOnGrid = 100;   // internal sampler id: bilinear whose taps all sit on whole source pixels (bilinear_taps_on_grid below)
 template <int FMT, int SAMPLER, typename OutT, bool WIDE>
 __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __restrict__ src_base,
                                                              OutT* __restrict__ dst_base,
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __re
         if (inside) {
             if constexpr (SAMPLER == KH_SAMPLE_NEAREST) nearest_tap<FMT, WIDE>(src, sx, sy, a, px[j]);
             else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) bilinear_quad<FMT, WIDE>(src, sx, sy, a, px[j]);
+            else if constexpr (SAMPLER == kSampleBilinearOnGrid) tap_rgb<FMT, WIDE>(src, (int)sx, (int)sy, a, px[j]);   // sx, sy whole and in range (host-checked)
             else lanczos_window<FMT, WIDE>(src, sx, sy, ox, oy, a, px[j]);
         } else {
             px[j][0] = a.pad_value; px[j][1] = a.pad_value; px[j][2] = a.pad_value;
@@ -570,6 +572,32 @@ bool plan_division_is_exact(const PreArgs& a) {
     return ok;
 }
 
+// Do ALL the source coordinates this launch evaluates fall on whole pixels?  (1080p -> a 640-wide letterbox: scale 1/3, sx = 3 ox
+// exactly, in f32.)  Then both bilinear weights are 0 for every destination pixel and the reference's blend
+// t00 + (t10 - t00) * 0 ... returns the first tap bit for bit: the kernel decodes ONE tap per pixel instead of four — the generic
+// bilinear path is bound by its vector ALUs (four exact BT.601 decodes + blend: ~103 instructions per pixel, r02t), not by memory.
+// Decided by evaluating the kernel's own coordinate expression for every column and row (dst_w + dst_h host evaluations,
+// memoised on the last geometry) — not by looking at the scale.  KH_PRE_GRID=0 (dev / test knob) keeps the four-tap kernel.
+bool bilinear_taps_on_grid(const PreArgs& a) {
+    if (const char* e = getenv("KH_PRE_GRID"); e && e[0] == '0') return false;
+    struct Key { float sx, sy, px, py; int w, h, sw, sh; bool ok; };
+    static thread_local Key last = {0, 0, 0, 0, 0, 0, 0, 0, false};
+    if (last.w == a.dst_w && last.h == a.dst_h && last.sw == a.src_w && last.sh == a.src_h && last.sx == a.scale_x && last.sy == a.scale_y &&
+        last.px == a.pad_x && last.py == a.pad_y)
+        return last.ok;
+    auto axis = [](int n, float pad, float scale, int len) {
+        for (int o = 0; o < n; ++o) {
+            const float s = ((float)o - pad) / scale;   // plan_pixel; the kernel's quotient equals this one or takes the division itself
+            if (s < 0.0f || s >= (float)len) continue;  // padding: no tap
+            if (!(s == floorf(s))) return false;        // (also false for NaN)
+        }
+        return true;
+    };
+    const bool ok = a.scale_x != 0.0f && a.scale_y != 0.0f && axis(a.dst_w, a.pad_x, a.scale_x, a.src_w) && axis(a.dst_h, a.pad_y, a.scale_y, a.src_h);
+    last = Key{a.scale_x, a.scale_y, a.pad_x, a.pad_y, a.dst_w, a.dst_h, a.src_w, a.src_h, ok};
+    return ok;
+}
+
 bool identity_fast_path(const kh_preprocess_params* p, const uint8_t* src, const void* dst) {
     return !(p->flags & KH_PRE_FORCE_GENERIC) && p->fmt == KH_FMT_NV12 &&
            p->out_dtype == KH_OUT_F32 &&
@@ -644,7 +672,8 @@ void launch_generic_fmt(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
             launch_generic_out<FMT, KH_SAMPLE_NEAREST>(s, grid, src, dst, a, out_dtype);
             break;
         case KH_SAMPLE_BILINEAR:
-            launch_generic_out<FMT, KH_SAMPLE_BILINEAR>(s, grid, src, dst, a, out_dtype);
+            if (bilinear_taps_on_grid(a)) launch_generic_out<FMT, kSampleBilinearOnGrid>(s, grid, src, dst, a, out_dtype);
+            else launch_generic_out<FMT, KH_SAMPLE_BILINEAR>(s, grid, src, dst, a, out_dtype);
             break;
         default:
             launch_generic_out<FMT, KH_SAMPLE_LANCZOS>(s, grid, src, dst, a, out_dtype);
@@ -660,9 +689,14 @@ const char* kh_preprocess_variant(const kh_preprocess_params* p) {
     // Alignment of the actual buffers is only known at launch; report for aligned buffers.
     if (validate(p, reinterpret_cast<const uint8_t*>(16), reinterpret_cast<void*>(16)) != KH_OK)
         return nullptr;
-    return identity_fast_path(p, reinterpret_cast<const uint8_t*>(16), reinterpret_cast<void*>(16))
-               ? "nv12_identity"
-               : "generic";
+    if (identity_fast_path(p, reinterpret_cast<const uint8_t*>(16), reinterpret_cast<void*>(16))) return "nv12_identity";
+    if (p->sampling == KH_SAMPLE_BILINEAR) {
+        PreArgs a{};
+        a.scale_x = p->scale_x; a.scale_y = p->scale_y; a.pad_x = p->pad_x; a.pad_y = p->pad_y;
+        a.src_w = p->src_w; a.src_h = p->src_h; a.dst_w = p->dst_w; a.dst_h = p->dst_h;
+        if (bilinear_taps_on_grid(a)) return "generic_bilinear_on_grid";
+    }
+    return "generic";
 }
 
 int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,

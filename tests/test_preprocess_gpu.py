@@ -200,8 +200,8 @@ def test_nv12_identity_fast_path_equals_generic_and_oracle(gpu_stream, w, h, sam
     pre = _pre(gpu_stream, mode="stretch", format="nv12", sampling=sampling, **IMAGENET)
     p = pre._params(w, h, w, 1, _ffi.KH_FMT_NV12, w, h, 1, 0, False, False)
     assert _ffi.lib.kh_preprocess_variant(C.byref(p)) == b"nv12_identity"
-    p.flags = _ffi.KH_PRE_FORCE_GENERIC
-    assert _ffi.lib.kh_preprocess_variant(C.byref(p)) == b"generic"
+    p.flags = _ffi.KH_PRE_FORCE_GENERIC   # (scale 1: every bilinear tap sits on a whole pixel — the generic kernel's one-tap form)
+    assert _ffi.lib.kh_preprocess_variant(C.byref(p)) == (b"generic_bilinear_on_grid" if sampling == "bilinear" else b"generic")
 
 
 def test_nv12_identity_batch_1080p(gpu_stream):
@@ -266,6 +266,32 @@ def test_quotient_shortcut_equals_ieee_division_path(gpu_stream, fmt, monkeypatc
         monkeypatch.setenv("KH_PRE_IEEE_DIV", "1")
         _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), want, f"{fmt} {w}x{h}->{dw}x{dh} ieee")
     monkeypatch.delenv("KH_PRE_IEEE_DIV", raising=False)
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "rgb", "bgra", "yuyv", "gray"])
+@pytest.mark.parametrize("f16", [False, True])
+def test_bilinear_on_whole_pixel_grid_equals_the_four_tap_kernel_and_the_oracle(gpu_stream, fmt, f16, monkeypatch):
+    """When every source coordinate of a launch is a whole number (1080p -> 640 letterbox: sx = 3 ox exactly) the bilinear weights are 0
+    and the kernel decodes one tap per pixel; KH_PRE_GRID=0 keeps the four-tap kernel.  Both must give the restatement's bits — on
+    such geometries, on near misses (a fractional pad, scale 1/5 whose f32 quotients are not all whole) and on an upscale."""
+    import ctypes as C
+    from kornia_rs import _ffi
+    cases = [((1920, 1080), (640, 640), "letterbox", True), ((96, 64), (48, 32), "stretch", True), ((90, 60), (30, 20), "stretch", True),
+             ((96, 64), (48, 40), "letterbox", True), ((90, 60), (31, 20), "letterbox", False), ((100, 50), (20, 10), "stretch", None),
+             ((20, 10), (40, 20), "stretch", False), ((46, 34), (31, 27), "stretch", False)]
+    for (w, h), (dw, dh), mode, on_grid in cases:
+        raw = _raw_for(fmt, w, h, seed=3)
+        kw = dict(fmt=fmt, mode=mode, sampling="bilinear", f16=f16, **IMAGENET)
+        want = O.preprocess(raw, w, h, dw, dh, **kw)
+        monkeypatch.delenv("KH_PRE_GRID", raising=False)
+        if on_grid is not None and fmt == "nv12" and not f16:
+            pre = _pre(gpu_stream, mode=mode, format=fmt, sampling="bilinear", **IMAGENET)
+            p = pre._params(w, h, w, 1, _ffi.KH_FMT_NV12, dw, dh, 1, 0, False, False)
+            assert _ffi.lib.kh_preprocess_variant(C.byref(p)) == (b"generic_bilinear_on_grid" if on_grid else b"generic"), (w, h, dw, dh, mode)
+        _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), want, f"{fmt} {w}x{h}->{dw}x{dh} {mode} default")
+        monkeypatch.setenv("KH_PRE_GRID", "0")
+        _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), want, f"{fmt} {w}x{h}->{dw}x{dh} {mode} four taps")
+    monkeypatch.delenv("KH_PRE_GRID", raising=False)
 
 
 def test_python_run_reuses_pinned_staging_in_a_frame_loop(gpu_stream):
