@@ -97,7 +97,10 @@ def test_preprocess_null_and_empty():
     p.nframes = 0  # empty batch: nothing to do, no device needed
     assert _ffi.lib.kh_preprocess_to_chw(None, None, None, C.byref(p)) == 0
     assert _ffi.lib.kh_preprocess_variant(C.byref(_params())) == b"nv12_identity"
-    assert _ffi.lib.kh_preprocess_variant(C.byref(_params(dst_w=7, dst_h=5))) == b"generic"
+    # scale 1 into a smaller grid: every bilinear tap sits on a whole source pixel -> the generic kernel's one-tap form
+    assert _ffi.lib.kh_preprocess_variant(C.byref(_params(dst_w=7, dst_h=5))) == b"generic_bilinear_on_grid"
+    assert _ffi.lib.kh_preprocess_variant(C.byref(_params(dst_w=7, dst_h=5, scale_x=0.7))) == b"generic"
+    assert _ffi.lib.kh_preprocess_variant(C.byref(_params(dst_w=7, dst_h=5, sampling=_ffi.KH_SAMPLE_NEAREST))) == b"generic"
 
 
 def test_no_device_fails_loudly_not_silently():
