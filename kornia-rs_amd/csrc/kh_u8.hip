@@ -830,6 +830,7 @@ struct GatherOp {
     const float* map_x; const float* map_y;   // remap
     int dsx_q, dsy_q;                         // affine: Q16 column steps
     int batch;
+    int nb = kStageNB;                        // images per block (set by launch_staged_gather)
 };
 
 // bilinear_sample_u8's admission rule (P/warp/common.rs:16-70), as in sample_q10_checked: non-finite or outside -> not sampled
@@ -899,6 +900,8 @@ __device__ __forceinline__ void stage_rounds_edge(uint32_t* __restrict__ tile, c
 // The staged images of one block, KM staging rounds per image (block-uniform, a template so that the raw quads are registers).
 // Software-pipelined: the loads of image b + 1 are issued right after the barrier that publishes image b's box and complete while
 // image b is sampled — a block hides its own load latency instead of relying on its neighbours (three blocks share a CU).
+// (Tried, r03ze: boxes of at most half the tile alternating between its two halves — ONE barrier per image instead of two: no change
+// in time on any of the three operators; the barriers are not what bounds the kernel.)
 template <int C, int KM>
 __device__ __forceinline__ void staged_images(uint32_t* __restrict__ tile, const ImgU8& im, int z0, int nimg, const uint32_t (&soff)[4], int tid, int nq,
                                               const int (&la)[4], int pitch, const uint32_t (&fxp)[4], const uint32_t (&fy16)[4], unsigned valid,
@@ -909,7 +912,7 @@ __device__ __forceinline__ void staged_images(uint32_t* __restrict__ tile, const
     for (int k = 0; k < KM; ++k) raw[k] = load_raw_quad<C>(src + soff[k]);
 #pragma unroll 1
     for (int b = 0; b < nimg; ++b) {
-#pragma unroll
+        #pragma unroll
         for (int k = 0; k < KM; ++k) {
             const int q = tid + k * (16 * kStageH);
             if (q < nq) *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = unpack_raw_quad<C>(raw[k]);   // q * 4 == r * pitch + 4 * c4
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(16 * kStageH) void gather_u8_staged_kernel(ImgU8 im
     const int xmin = lo2[0], ymin = lo2[1], xmax = hi2[0], ymax = hi2[1];
     const bool any = xmax >= xmin;                              // block-uniform: some pixel of the tile is sampled
     const bool mine = row_in && x4 < im.dw, whole = x4 + 3 < im.dw;
-    const int z0 = bz_ * kStageNB, nimg = min(kStageNB, op.batch - z0);
+    const int z0 = bz_ * op.nb, nimg = min(op.nb, op.batch - z0);
     const long long dst_off = ((long long)y * im.dw + x4) * C;
 
     // staged box: columns [xmin, xmin + pitch), rows [ymin, ymax + 1]: one column / row more than the first taps reach
@@ -1141,8 +1144,14 @@ bool use_staged_gather(int sw, int sh) {
 }
 template <int OP>
 int32_t launch_staged_gather(hipStream_t st, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int channels, int batch,
-                             int64_t ss, int64_t ds, const GatherOp& op, const char* what) {
-    const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, kStageH), groups = cdiv(batch, kStageNB);
+                             int64_t ss, int64_t ds, const GatherOp& op_, const char* what) {
+    // images per block: 16 for batches of 128 and more — the geometry phase (perspective divisions, the remap's map reads) is paid once
+    // per block: perspective 3.50-3.60 -> 3.27 ms, remap 3.53-3.64 -> 3.11-3.13 ms, affine unchanged; 32 and 64 are slower (r03ze) —
+    // 8 otherwise.  KH_GATHER_NB: dev knob for A/Bs.
+    static const int env_nb = [] { const char* e = getenv("KH_GATHER_NB"); return e && *e ? atoi(e) : 0; }();
+    GatherOp op = op_;
+    op.nb = env_nb > 0 ? env_nb : (batch >= 128 ? 2 * kStageNB : kStageNB);
+    const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, kStageH), groups = cdiv(batch, op.nb);
     // 64 x 32 tiles, dealt to the XCDs in runs of 8 tile rows like the other gathers
     const ImgU8 im{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(tiles_x, tiles_y, groups, tiles_x * 8)};
     KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);

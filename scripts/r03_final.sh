@@ -36,4 +36,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   [ -n "$db" ] && python scripts/rocpd_summary.py "$db" | grep -v rocclr | sed -n '/counter,mean/,$p' > "$OUT/default_pmc_$c.csv" && cat "$OUT/default_pmc_$c.csv" | cut -c1-60,140-
 done
 find "$OUT" -name '*.db' -delete
+if [ "${COUNTERS:-1}" = "1" ]; then
+  echo "== SQ counters of the round-3 rolling RGB8 kernels (VERDICT r02 item 4)"
+  for wl in gaussian_u8_4k dilate_u8_4k pyrdown_u8_4k pyrup_u8_4k; do
+    bash scripts/diag/pmc_workload.sh $wl $TAG/sq "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE" 2>&1 | tail -12 | tee -a "$OUT/sq_counters.txt"
+  done
+fi
 du -sh "$OUT"

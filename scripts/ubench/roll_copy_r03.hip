@@ -49,7 +49,9 @@ __global__ __launch_bounds__(64 * WAVES) void roll12(A a) {
             d0 ^= (uint32_t)__shfl_up((int)d1, 1) & 0u;
             if (MODE == 2) { acc ^= d0 ^ d1 ^ d2; }   // load-only
             else if (r >= K - 1 && r < nrows) {
-                if (MODE == 0 || MODE == 3) {
+                if (MODE == 4) {   // non-temporal stores
+                    if (writer) { uint8_t* o = dst + off; __builtin_nontemporal_store(d0, (u32u*)o); __builtin_nontemporal_store(d1, (u32u*)(o + 4)); __builtin_nontemporal_store(d2, (u32u*)(o + 8)); }
+                } else if (MODE == 0 || MODE == 3) {
                     if (writer) { uint8_t* o = dst + off; *(u32u*)o = d0; *(u32u*)(o + 4) = d1; *(u32u*)(o + 8) = d2; }
                 } else {
                     uint32_t* x = xp[wv][s & 1];
@@ -149,6 +151,13 @@ int main(int argc, char** argv) {
     R12(5, 240, 1, 4, 135, "roll12 K5 240px LDS -> 16-B chunk stores th135")
     R12(5, 248, 0, 8, 360, "roll12 K5 248px 8 waves per block")
     R12(5, 256, 0, 4, 360, "roll12 K5 256px no halo (768 B per wave row)")
+    R12(5, 256, 4, 4, 360, "roll12 K5 256px no halo, NON-TEMPORAL stores")
+    R12(5, 256, 4, 4, 135, "roll12 K5 256px no halo, NON-TEMPORAL stores th135")
+    R12(5, 256, 0, 4, 135, "roll12 K5 256px no halo th135")
+    R12(5, 256, 0, 8, 360, "roll12 K5 256px no halo 8 waves per block")
+    R12(5, 256, 0, 2, 360, "roll12 K5 256px no halo 2 waves per block")
+    R12(3, 256, 0, 4, 360, "roll12 K3 256px no halo")
+    R12(7, 256, 0, 4, 360, "roll12 K7 256px no halo")
     R12(5, 248, 2, 4, 360, "roll12 K5 248px LOAD only")
     R12(5, 256, 2, 4, 360, "roll12 K5 256px no halo LOAD only")
     R12(5, 248, 3, 4, 360, "roll12 K5 248px STORE only")

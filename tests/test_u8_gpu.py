@@ -303,3 +303,26 @@ def test_remap_u8_staged_tiles_match_oracle(gpu_stream, c, kind):
     got = d_dst.to_numpy(np.uint8, (n, dh, dw, c))
     for k in range(n):
         assert_same_bits(got[k], O.remap_u8(src[k], mx, my, "bilinear"), f"staged remap_u8 {kind} c{c} frame {k}")
+
+
+@pytest.mark.parametrize("kind", ["affine", "perspective"])
+def test_staged_gather_sixteen_images_per_block(gpu_stream, kind):
+    """Batches of 128 and more put 16 consecutive images in a block (8 below that).  130 images = eight full groups + a group of
+    two; a mild rotation (boxes of ~3 000 pixels, two staging rounds), 30 degrees (~5 200, three) and 45 degrees at magnification
+    1 / 0.6 (~12 800: no staging, the block-uniform global fallback)."""
+    n, w, h, c = 130, 150, 70, 3
+    src = np.stack([pat(w, h, c, seed=7 * k + 1) for k in range(n)])
+    for ang, scale in [(9.0, 0.95), (30.0, 0.9), (45.0, 0.6)]:
+        if kind == "affine":
+            m = O.rotation_matrix(w / 2.0, h / 2.0, ang, scale) if hasattr(O, "rotation_matrix") else None
+            if m is None:
+                a, b = scale * np.cos(np.deg2rad(ang)), scale * np.sin(np.deg2rad(ang))
+                m = [float(a), float(b), float((1 - a) * w / 2 - b * h / 2), float(-b), float(a), float(b * w / 2 + (1 - a) * h / 2)]
+            want = [O.warp_affine_u8(src[k], m, w, h) for k in (0, 1, 15, 16, 127, 128, 129)]
+        else:
+            a, b = scale * np.cos(np.deg2rad(ang)), scale * np.sin(np.deg2rad(ang))
+            m = [float(a), float(b), float((1 - a) * w / 2 - b * h / 2), float(-b), float(a), float(b * w / 2 + (1 - a) * h / 2), 1e-4, -2e-4, 1.0]
+            want = [O.warp_perspective_u8(src[k], m, w, h) for k in (0, 1, 15, 16, 127, 128, 129)]
+        got = warp_u8_gpu(gpu_stream, kind, src, m, w, h, batch=n)
+        for i, k in enumerate((0, 1, 15, 16, 127, 128, 129)):
+            assert_same_bits(got[k], want[i], f"{kind} {ang} deg frame {k} of {n}")
