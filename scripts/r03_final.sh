@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-3 reference visit: the whole device suite (4 xdist workers share the GPU; failures re-run serially), smoke, the default bench line
+# Round-3 reference visit: the whole device suite (serial, as the driver runs it: four xdist workers with a 256-thread OpenMP team each were SLOWER; failures re-run), smoke, the default bench line
 # (headline + also + summary), the opt-in workloads, one kernel-trace profile of the default run and the HBM PMC passes bench.py replays.
 set -u
 TAG=${1:-r03z}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp; REPO=$(pwd)
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  ( time timeout 1500 python -m pytest tests -m gpu -q -n 4 ) > "$OUT/pytest_full.log" 2>&1
+  ( time timeout 1500 python -m pytest tests -m gpu -q ) > "$OUT/pytest_full.log" 2>&1
   tail -5 "$OUT/pytest_full.log"
   if ! grep -q " passed" "$OUT/pytest_full.log" || grep -q "failed\|error" "$OUT/pytest_full.log"; then
     echo "== serial re-run of failures" | tee -a "$OUT/pytest_full.log"

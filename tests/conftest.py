@@ -4,6 +4,13 @@ from pathlib import Path
 
 import pytest
 
+# The restatement's OpenMP team, for TESTS only (bench.py times it in its own process with every core): the parity tests call it
+# thousands of times on images of a few thousand pixels, where a 256-thread team (the GPU box) costs more in fork / spin than it
+# computes — two morphology tests 0.73 s with the default team, 0.32 s with 16 threads — and four xdist workers with 256 spinning
+# threads each turned an 18-minute suite out of what runs serially in a fraction of that (r03zz).  Set before libgomp loads.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "kornia-rs_amd"))
 sys.path.insert(0, str(ROOT / "tests"))
