@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a finished A/B: the environment knob it flips was removed from the library with the variant that lost — see profiles/README.md)
 # Round-3: staged u8 gather — one barrier per image (two-box layout) and 16 images per block against the previous configuration, one box.
 set -u
 TAG=${1:-r03_gather2}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a finished A/B: the environment knob it flips was removed from the library with the variant that lost — see profiles/README.md)
 set -u
 TAG=${1:-r03x}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 for i in 1 2 3; do for v in 0 1; do
