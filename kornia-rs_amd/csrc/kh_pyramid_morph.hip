@@ -53,7 +53,7 @@ __device__ __forceinline__ int reflect_101(int p, int len) {  // pyramid.rs:252-
 // pyrdown_f32 (:312-430): 5x5 outer-product taps, ky-major accumulation, reflect-101 border.
 // (Round 3 tried sharing source pixels along the wave — a lane loads only its own pair and takes the other three pixels from the
 // lanes either side by DPP shifts, 10 full-wave loads per pixel instead of 25: 2.53 ms against this kernel's 2.22 on one box,
-// r03_wl7 — the row-by-row load / shift dependency costs more than the loads it saves.  The kernel is not addresser-bound.)
+// profiles/r03zc — the row-by-row load / shift dependency costs more than the loads it saves.  The kernel is not addresser-bound.)
 template <int C>
 __global__ __launch_bounds__(kBx* kBy) void pyrdown_f32_kernel(Pyr<float> a) {
     KH_PYR_PROLOGUE(float)
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void pyrdown_u8_tile_kernel(Pyr<uint8_t> a) {
 // bytes with v_dot4_u32_u8 — 8 dot4 + 2 alignbyte per channel for its four destination pixels — into 16-bit lanes (<= 4080, the
 // reference's u16 intermediate); the column pass is the same packed 16-bit arithmetic as the tile kernel (binomial5) on a five-row
 // register ring, every second source row; four destination pixels leave as one 12-byte store.  ALL 64 lanes store — a wave's
-// destination row segment is 256 pixels = 768 bytes = whole 128-byte lines (r03_rollcopy: 744-byte segments, with lanes 0 / 63
+// destination row segment is 256 pixels = 768 bytes = whole 128-byte lines (profiles/r03za: 744-byte segments, with lanes 0 / 63
 // as halo lanes, split a line between two waves at every boundary and cost 19 % on a pure copy) — and the pixels either side of
 // the wave come from one more quad load per row: the lower half's lanes load the quad before the wave's first pixel, the upper's
 // the quad after its last, de-interleaved the same way and handed to the end lanes as the fill value of the DPP wave shifts.
@@ -870,7 +870,7 @@ __device__ __forceinline__ int map_index(int mode, int i, int len) {  // Padding
 // a lane owns four pixels (12 bytes), de-interleaves them into one dword per channel and takes its neighbours' by wave shifts.
 // ALL 64 lanes store, so a wave's row segment is 768 bytes = whole 128-byte lines: with 62 storing lanes (744 bytes, the shape of
 // the round-3 blur and pyramid kernels) every segment boundary splits a line between two waves, and a pure copy in that shape
-// runs at 3.05 ms against 2.47 ms for this one (r03_rollcopy: stores alone 1.59 vs 1.16 ms).  The pixels either side of the
+// runs at 3.05 ms against 2.47 ms for this one (profiles/r03za: stores alone 1.59 vs 1.16 ms).  The pixels either side of the
 // wave come from one extra load per row — the lower half's lanes all load the quad before the wave's first, the upper's the quad
 // after its last — de-interleaved the same way and handed to the end lanes as the DPP wave shift's fill value.  The
 // byte pair (b[i], b[i+2]) of a channel's twelve bytes (prev | cur | next) in 16-bit lanes is ONE v_perm_b32 of two neighbouring

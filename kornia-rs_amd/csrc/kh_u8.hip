@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
 //     per channel (6 v_perm_b32) and gets its left / right neighbours' channel dwords by two wave shifts per channel — no LDS
 //     row buffer at all.  ALL 64 lanes store: a wave's row segment is 256 pixels = 768 bytes = whole 128-byte lines (the first
 //     version kept lanes 0 / 63 as halo lanes: 744-byte segments, every boundary splitting a line between two waves — a pure
-//     copy in that shape is 19 % slower, r03_rollcopy).  The quads either side of the wave come from one more load per row
+//     copy in that shape is 19 % slower, profiles/r03za).  The quads either side of the wave come from one more load per row
 //     (the lower half's lanes all load the quad before the wave's first, the upper's the quad after its last), de-interleaved the
 //     same way and handed to the end lanes as the fill value of the DPP wave shifts;
 //   * horizontal pass per channel: the (up to 9) taps of output pixel j are bytes j + 4 - H ... of the 12-byte (prev, cur, next)
