@@ -21,6 +21,8 @@
 #include <array>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -103,6 +105,163 @@ private:
 // Host / Device / Unified — where the bytes can be legally dereferenced (MemoryDomain, T/resource.rs:19-60).  Unified = managed
 // memory (kh_malloc_managed): host slices AND device kernels work on the same allocation; dispatch treats it as device-resident.
 enum class MemoryDomain { Host, Device, Unified };
+
+// ---- allocators (T/allocator.rs:20-146; T/cuda.rs:214-262, 355-380, 440-511) ------------------------------
+// `TensorAllocator` turns a `Layout` (size + power-of-two alignment, std::alloc::Layout) into an owning `MemoryResource`
+// (as_ptr / len_bytes / domain, T/resource.rs:73-101).  CpuAllocator + host_alloc() are the reference's host side; HipAllocator,
+// PinnedAllocator and HipUnifiedAllocator replace CudaAllocator / PinnedAllocator / CudaUnifiedAllocator over the C ABI
+// (kh_malloc_async, kh_host_alloc, kh_malloc_managed).  Allocations are zero-filled unless the allocator says otherwise;
+// a zero-size layout is legal and owns nothing.
+class TensorAllocatorError : public std::runtime_error {
+public:
+    enum class Kind { LayoutError, NullPointer, CannotAllocateForeign };
+    TensorAllocatorError(Kind k, const std::string& msg) : std::runtime_error(msg), kind_(k) {}
+    Kind kind() const { return kind_; }
+
+private:
+    Kind kind_;
+};
+
+struct Layout {
+    size_t size, align;
+    Layout(size_t size_, size_t align_ = 1) : size(size_), align(align_) {
+        if (align == 0 || (align & (align - 1)) || size > (static_cast<size_t>(1) << 63) - align)
+            throw TensorAllocatorError(TensorAllocatorError::Kind::LayoutError,
+                                       "invalid layout (size " + std::to_string(size) + ", align " + std::to_string(align) + ")");
+    }
+    template <typename T>
+    static Layout array(size_t count) { return Layout(sizeof(T) * count, alignof(T)); }   // Layout::array::<T>(n)
+};
+
+// An owning, move-only block of memory.  Dropping it returns the block to where it came from (the stream-ordered pool on its
+// stream, the pinned / managed heap after draining its stream, the process heap).
+class MemoryResource {
+public:
+    MemoryResource(const MemoryResource&) = delete;
+    MemoryResource& operator=(const MemoryResource&) = delete;
+    MemoryResource(MemoryResource&& o) noexcept : ptr_(o.ptr_), bytes_(o.bytes_), domain_(o.domain_), how_(o.how_), stream_(std::move(o.stream_)) { o.ptr_ = nullptr; }
+    MemoryResource& operator=(MemoryResource&& o) noexcept {
+        if (this != &o) { release(); ptr_ = o.ptr_; bytes_ = o.bytes_; domain_ = o.domain_; how_ = o.how_; stream_ = std::move(o.stream_); o.ptr_ = nullptr; }
+        return *this;
+    }
+    ~MemoryResource() { release(); }
+    void* as_ptr() const { return ptr_; }
+    size_t len_bytes() const { return bytes_; }
+    MemoryDomain domain() const { return domain_; }
+    bool is_readonly() const { return false; }
+    const Stream* stream() const { return stream_.get(); }   // Device / Unified: the stream the block is ordered on
+
+private:
+    friend class CpuAllocator;
+    friend class PinnedAllocator;
+    friend class HipAllocator;
+    friend class HipUnifiedAllocator;
+    enum class How { Heap, Pinned, Pool, Managed };
+    MemoryResource(void* p, size_t n, MemoryDomain d, How h, std::unique_ptr<Stream> s) : ptr_(p), bytes_(n), domain_(d), how_(h), stream_(std::move(s)) {}
+    void release() {
+        if (!ptr_) return;
+        switch (how_) {
+            case How::Heap: std::free(ptr_); break;
+            case How::Pinned: kh_host_free(ptr_); break;
+            case How::Pool: kh_free_async(ptr_, stream_ ? stream_->handle() : nullptr); break;
+            case How::Managed:
+                if (stream_) kh_stream_synchronize(stream_->handle());
+                kh_free(ptr_);
+                break;
+        }
+        ptr_ = nullptr;
+    }
+    void* ptr_ = nullptr;
+    size_t bytes_ = 0;
+    MemoryDomain domain_ = MemoryDomain::Host;
+    How how_ = How::Heap;
+    std::unique_ptr<Stream> stream_;
+};
+
+class TensorAllocator {   // trait TensorAllocator (T/allocator.rs:73-90)
+public:
+    virtual ~TensorAllocator() = default;
+    virtual MemoryResource allocate(const Layout& layout) const = 0;
+    virtual MemoryDomain domain() const = 0;
+};
+
+class CpuAllocator final : public TensorAllocator {   // zeroed, aligned process-heap memory (T/allocator.rs:107-130)
+public:
+    MemoryResource allocate(const Layout& l) const override {
+        if (l.size == 0) return MemoryResource(nullptr, 0, MemoryDomain::Host, MemoryResource::How::Heap, nullptr);
+        const size_t al = l.align < sizeof(void*) ? sizeof(void*) : l.align;
+        void* p = std::aligned_alloc(al, (l.size + al - 1) / al * al);
+        if (!p) throw TensorAllocatorError(TensorAllocatorError::Kind::NullPointer, "the host allocator returned null");
+        std::memset(p, 0, l.size);
+        return MemoryResource(p, l.size, MemoryDomain::Host, MemoryResource::How::Heap, nullptr);
+    }
+    MemoryDomain domain() const override { return MemoryDomain::Host; }
+};
+inline const CpuAllocator& host_alloc() {   // the process-global host allocator handle (T/allocator.rs:136-146)
+    static const CpuAllocator a;
+    return a;
+}
+
+class PinnedAllocator final : public TensorAllocator {   // zeroed page-locked host memory (T/cuda.rs:355-380)
+public:
+    MemoryResource allocate(const Layout& l) const override {
+        if (l.size == 0) return MemoryResource(nullptr, 0, MemoryDomain::Host, MemoryResource::How::Pinned, nullptr);
+        void* p = nullptr;
+        detail::check(kh_host_alloc(&p, l.size));
+        if (!p) throw TensorAllocatorError(TensorAllocatorError::Kind::NullPointer, "kh_host_alloc returned null");
+        std::memset(p, 0, l.size);
+        return MemoryResource(p, l.size, MemoryDomain::Host, MemoryResource::How::Pinned, nullptr);
+    }
+    MemoryDomain domain() const override { return MemoryDomain::Host; }
+};
+
+// replaces CudaAllocator (T/cuda.rs:214-262): stream-ordered pool memory on `stream`'s device, zero-filled on that stream
+// (zeroed = false: uninit_cuda — the producer must overwrite every byte)
+class HipAllocator final : public TensorAllocator {
+public:
+    explicit HipAllocator(const Stream& stream, bool zeroed = true) : stream_(stream), zeroed_(zeroed) {}
+    MemoryResource allocate(const Layout& l) const override {
+        void* p = nullptr;
+        int prev = 0;
+        detail::check(kh_get_device(&prev));
+        detail::check(kh_set_device(stream_.device()));
+        const int32_t rc = kh_malloc_async(&p, l.size, zeroed_ ? 1 : 0, stream_.handle());
+        kh_set_device(prev);
+        detail::check(rc);
+        if (l.size && !p) throw TensorAllocatorError(TensorAllocatorError::Kind::NullPointer, "kh_malloc_async returned null");
+        if (l.size && reinterpret_cast<uintptr_t>(p) % l.align) {
+            kh_free_async(p, stream_.handle());
+            throw TensorAllocatorError(TensorAllocatorError::Kind::LayoutError, "the device pool returned a pointer not aligned to " + std::to_string(l.align));
+        }
+        return MemoryResource(p, l.size, MemoryDomain::Device, MemoryResource::How::Pool, std::unique_ptr<Stream>(new Stream(stream_)));
+    }
+    MemoryDomain domain() const override { return MemoryDomain::Device; }
+
+private:
+    Stream stream_;
+    bool zeroed_;
+};
+
+class HipUnifiedAllocator final : public TensorAllocator {   // managed memory carrying `stream` (CudaUnifiedAllocator, T/cuda.rs:440-511)
+public:
+    explicit HipUnifiedAllocator(const Stream& stream) : stream_(stream) {}
+    MemoryResource allocate(const Layout& l) const override {
+        void* p = nullptr;
+        int prev = 0;
+        detail::check(kh_get_device(&prev));
+        detail::check(kh_set_device(stream_.device()));
+        const int32_t rc = kh_malloc_managed(&p, l.size ? l.size : 1);   // the driver rejects a zero-size request
+        kh_set_device(prev);
+        detail::check(rc);
+        if (!p) throw TensorAllocatorError(TensorAllocatorError::Kind::NullPointer, "kh_malloc_managed returned null");
+        if (l.size) std::memset(p, 0, l.size);   // managed memory is host-writable
+        return MemoryResource(p, l.size, MemoryDomain::Unified, MemoryResource::How::Managed, std::unique_ptr<Stream>(new Stream(stream_)));
+    }
+    MemoryDomain domain() const override { return MemoryDomain::Unified; }
+
+private:
+    Stream stream_;
+};
 
 struct ImageSize {
     size_t width, height;

@@ -39,10 +39,62 @@ static void host_only() {
     EXPECT(throws(K::InvalidImageSize, [&] { pre.run_raw(nullptr, 16 * 8, 16, 8, nullptr, 8, 8); }));  // luma only: chroma plane missing
     Preprocessor yuyv(borrowed, ResizeMode::Stretch, SourceFormat::Yuyv);
     EXPECT(throws(K::InvalidImageSize, [&] { yuyv.run_raw(nullptr, 16 * 8 * 2 - 1, 16, 8, nullptr, 8, 8); }));
+    // allocators (T/allocator.rs:73-146): layouts are validated, host allocations are zeroed and aligned, zero-size is legal
+    using AK = TensorAllocatorError::Kind;
+    auto alloc_throws = [](AK kind, auto&& f) {
+        try { f(); } catch (const TensorAllocatorError& e) { return e.kind() == kind; } catch (...) { return false; }
+        return false;
+    };
+    EXPECT(alloc_throws(AK::LayoutError, [] { Layout(16, 3); }));
+    EXPECT(alloc_throws(AK::LayoutError, [] { Layout(16, 0); }));
+    EXPECT(Layout::array<float>(10).size == 40 && Layout::array<float>(10).align == alignof(float));
+    {
+        const TensorAllocator& ha = host_alloc();
+        EXPECT(&host_alloc() == &host_alloc() && ha.domain() == MemoryDomain::Host);
+        MemoryResource r = ha.allocate(Layout(1000, 256));
+        EXPECT(r.as_ptr() && r.len_bytes() == 1000 && r.domain() == MemoryDomain::Host && reinterpret_cast<uintptr_t>(r.as_ptr()) % 256 == 0 && !r.is_readonly());
+        bool zero = true;
+        for (size_t i = 0; i < 1000; ++i) zero = zero && static_cast<const unsigned char*>(r.as_ptr())[i] == 0;
+        EXPECT(zero && r.stream() == nullptr);
+        MemoryResource moved = std::move(r);
+        EXPECT(r.as_ptr() == nullptr && moved.len_bytes() == 1000);
+        MemoryResource empty = ha.allocate(Layout(0, 64));
+        EXPECT(empty.as_ptr() == nullptr && empty.len_bytes() == 0);
+    }
 }
 
 static void on_device() {
     Stream s = Stream::create(0), other = Stream::create(0);
+    {   // the HIP allocators that replace CudaAllocator / PinnedAllocator / CudaUnifiedAllocator (T/cuda.rs:214-262, 355-380, 440-511)
+        HipAllocator da(s);
+        PinnedAllocator pa;
+        HipUnifiedAllocator ua(s);
+        EXPECT(da.domain() == MemoryDomain::Device && pa.domain() == MemoryDomain::Host && ua.domain() == MemoryDomain::Unified);
+        const Layout l = Layout::array<uint32_t>(1024);
+        MemoryResource d = da.allocate(l), pin = pa.allocate(l), uni = ua.allocate(l);
+        int32_t dom = -1, dev = -1;
+        EXPECT(kh_pointer_domain(d.as_ptr(), &dom, &dev) == KH_OK && dom == KH_DOMAIN_DEVICE && dev == 0);
+        EXPECT(kh_pointer_domain(pin.as_ptr(), &dom, &dev) == KH_OK && dom == KH_DOMAIN_HOST_PINNED);
+        EXPECT(kh_pointer_domain(uni.as_ptr(), &dom, &dev) == KH_OK && dom == KH_DOMAIN_UNIFIED);
+        EXPECT(d.len_bytes() == 4096 && d.stream() && d.stream()->same_as(s) && uni.stream() && pin.stream() == nullptr);
+        // zero-filled on the stream: device -> pinned copy reads zeros; then a pinned -> device -> managed round trip
+        uint32_t* hp = static_cast<uint32_t*>(pin.as_ptr());
+        for (int i = 0; i < 1024; ++i) hp[i] = 0xdeadbeefu;
+        EXPECT(kh_memcpy_d2h_async(hp, d.as_ptr(), 4096, s.handle()) == KH_OK);
+        s.synchronize();
+        bool zero = true;
+        for (int i = 0; i < 1024; ++i) zero = zero && hp[i] == 0;
+        EXPECT(zero);
+        for (int i = 0; i < 1024; ++i) hp[i] = 3u * i + 1u;
+        EXPECT(kh_memcpy_h2d_async(d.as_ptr(), hp, 4096, s.handle()) == KH_OK);
+        EXPECT(kh_memcpy_d2d_async(uni.as_ptr(), d.as_ptr(), 4096, s.handle()) == KH_OK);
+        s.synchronize();
+        bool same = true;
+        for (int i = 0; i < 1024; ++i) same = same && static_cast<const uint32_t*>(uni.as_ptr())[i] == 3u * i + 1u;   // managed memory read by the host
+        EXPECT(same);
+        MemoryResource raw = HipAllocator(s, false).allocate(Layout(0, 16));   // uninit, zero-size
+        EXPECT(raw.len_bytes() == 0);
+    }
     // gray [0,128,255],[128,0,128] -> [104, 53]  (P/color/gray/mod.rs:395-412)
     auto rgb = Image<uint8_t, 3>::from_size_vec({2, 1}, {0, 128, 255, 128, 0, 128}).to_hip(s);
     auto gray = Image<uint8_t, 1>::zeros_hip({2, 1}, s);
