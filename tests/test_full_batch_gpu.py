@@ -1,0 +1,163 @@
+"""Parity at the BASELINE *batch* sizes: every bench workload behind a BASELINE config runs ONE step at its
+real batch — configs[2] N = 1024 (28.7 GB), configs[1,3,4] N = 256 (25.5 GB buffers), the u8 4K twins N = 256 — and a handful
+of frames spread over the batch is copied back and compared bit-for-bit with the CPU restatement.  The sampled frames sit on
+both sides of every offset where 32-bit arithmetic would wrap inside the batch buffer: 2^31 bytes, 2^32 bytes, 2^31 elements,
+2^32 elements, plus the first and the last frame and (u8 staged gathers: 16 images per block, kh_u8.hip) a block seam.
+
+The reference's contract for the batch loop: crates/kornia-imgproc/src/preprocess.rs:1258-1282 (frame k at src + k*stride,
+dst + k*3*oh*ow) and its test :1852-1893.  Device-only: the host simulator would need the same 25 GB in host memory."""
+import importlib.util
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(autouse=True)
+def _device_only():
+    import os
+    if os.environ.get("KH_HOSTSIM") == "1":
+        pytest.skip("full BASELINE batches (25-29 GB) are a device-only check")
+
+
+class _Args:
+    batch = 0  # the BASELINE batch of each workload
+
+
+def boundary_frames(n: int, frame_bytes: int, elem_bytes: int, extra=()):
+    """Frame indices on both sides of the 2^31-B, 2^32-B, 2^31-element and 2^32-element offsets of an n-frame buffer, plus the
+    first, the last and `extra`."""
+    ks = {0, n - 1, *extra}
+    for limit in (1 << 31, 1 << 32, (1 << 31) * elem_bytes, (1 << 32) * elem_bytes):
+        k = limit // frame_bytes          # the frame that CONTAINS the limit
+        ks.update((k - 1, k, k + 1))
+    return sorted(k for k in ks if 0 <= k < n)
+
+
+def _run(bench, name, stream):
+    wl = bench.WORKLOADS[name](_Args)
+    wl.setup(stream)
+    wl.step()
+    stream.synchronize()
+    return wl
+
+
+def _fetch(buf, k, dtype, shape):
+    """Frame k of a batch buffer (DeviceBuffer or Tensor) as a host array — one frame's D2H, not the batch's."""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if hasattr(buf, "to_numpy"):
+        return buf.to_numpy(dtype, shape, offset=k * nbytes)
+    from kornia_rs.hip import d2h
+    out = np.empty(shape, dtype)
+    d2h(out, buf.data_ptr + k * nbytes, buf.stream)
+    return out
+
+
+def _same(got, want, what):
+    g = np.ascontiguousarray(got).reshape(-1)
+    w = np.ascontiguousarray(want).reshape(-1)
+    g, w = (g.view(np.uint32), w.view(np.uint32)) if g.dtype == np.float32 else (g, w)
+    assert g.shape == w.shape, (what, g.shape, w.shape)
+    bad = np.flatnonzero(g != w)
+    assert bad.size == 0, f"{what}: {bad.size} of {g.size} elements differ, flat span [{bad[0]}, {bad[-1]}]"
+
+
+def test_boundary_frames_cover_the_wrap_points():
+    # north star: 24 883 200-B output frames -> 2^31 B inside frame 86, 4 GiB inside 172, 2^31 floats inside 345, 2^32 floats inside 690
+    ks = boundary_frames(1024, 1920 * 1080 * 12, 4)
+    for k in (0, 85, 86, 87, 171, 172, 173, 344, 345, 346, 689, 690, 691, 1023):
+        assert k in ks, k
+    # 4K f32 x3 images (99 532 800 B): 2^31 B inside image 21, 4 GiB inside 43, 2^31 floats inside 86, 2^32 floats inside 172
+    ks = boundary_frames(256, 3840 * 2160 * 12, 4)
+    for k in (0, 21, 22, 43, 44, 86, 87, 172, 173, 255):
+        assert k in ks, k
+
+
+def test_north_star_full_batch(gpu_stream, bench):
+    """configs[2]: 1024 NV12 1080p frames -> [1024,3,1080,1920] f32 in ONE launch; 3 110 400-B input frames, 24 883 200-B outputs."""
+    wl = _run(bench, "nv12_chw", gpu_stream)
+    assert wl.N == 1024
+    ks = sorted(set(boundary_frames(wl.N, wl.W * wl.H * 12, 4)) | set(boundary_frames(wl.N, wl.frame_bytes, 1)))
+    for k in ks:
+        raw = wl.base[31 * k: 31 * k + wl.frame_bytes]
+        want = O.preprocess(raw, wl.W, wl.H, wl.W, wl.H, fmt="nv12", mode="stretch", mean=MEAN, std=STD)[0]
+        _same(_fetch(wl.dst, k, np.float32, (3, wl.H, wl.W)), want, f"nv12_chw frame {k}")
+
+
+def test_north_star_letterbox_full_batch(gpu_stream, bench):
+    """The 640x640 letterbox secondary at N = 1024 (4 915 200-B outputs: the wrap points sit at frames 436, 873)."""
+    wl = _run(bench, "nv12_chw_640", gpu_stream)
+    ks = sorted(set(boundary_frames(wl.N, 640 * 640 * 12, 4)) | set(boundary_frames(wl.N, wl.frame_bytes, 1)))
+    for k in ks:
+        raw = wl.base[31 * k: 31 * k + wl.frame_bytes]
+        want = O.preprocess(raw, wl.W, wl.H, 640, 640, fmt="nv12", mode="letterbox", mean=MEAN, std=STD)[0]
+        _same(_fetch(wl.dst, k, np.float32, (3, 640, 640)), want, f"nv12_chw_640 frame {k}")
+
+
+def test_resize_full_batch(gpu_stream, bench):
+    """configs[1]: 256 x (1920x1080x3 f32 -> 224x224x3): the SOURCE buffer is the 25.5 GB one."""
+    wl = _run(bench, "resize_224", gpu_stream)
+    assert wl.N == 256
+    n = wl.SW * wl.SH * wl.C
+    for k in boundary_frames(wl.N, n * 4, 4):
+        want = O.resize(wl.base[31 * k: 31 * k + n].reshape(wl.SH, wl.SW, wl.C), wl.DW, wl.DH)
+        _same(_fetch(wl.dst, k, np.float32, (wl.DH, wl.DW, wl.C)), want, f"resize_224 image {k}")
+
+
+def test_gaussian_full_batch(gpu_stream, bench):
+    """configs[3]: 256 x 3840x2160x3 f32, 7x7 gaussian, one launch over 25.5 GB in and out."""
+    wl = _run(bench, "gaussian_4k", gpu_stream)
+    assert wl.N == 256
+    n = wl.W * wl.H * wl.C
+    for k in boundary_frames(wl.N, n * 4, 4):
+        want = O.gaussian_blur(wl.base[31 * k: 31 * k + n].reshape(wl.H, wl.W, wl.C), (7, 7), (1.5, 1.5))
+        _same(_fetch(wl.dst, k, np.float32, (wl.H, wl.W, wl.C)), want, f"gaussian_4k image {k}")
+
+
+def test_undistort_warp_full_batch(gpu_stream, bench):
+    """configs[4] per-GPU share: remap then warp_perspective over 256 4K f32 images (three 25.5 GB buffers)."""
+    wl = _run(bench, "undistort_warp_4k", gpu_stream)
+    assert wl.N == 256
+    n = wl.W * wl.H * wl.C
+    mx, my = O.correction_map(wl.INTR, wl.DIST, wl.W, wl.H)
+    for k in boundary_frames(wl.N, n * 4, 4, extra=(3, 4)):  # the maps are shared by groups of 4 images in the remap kernel
+        src = wl.base[31 * k: 31 * k + n].reshape(wl.H, wl.W, wl.C)
+        mid = O.remap(src, mx, my)
+        _same(_fetch(wl.tmp, k, np.float32, (wl.H, wl.W, wl.C)), mid, f"undistort remap image {k}")
+        _same(_fetch(wl.dst, k, np.float32, (wl.H, wl.W, wl.C)), O.warp_perspective(mid, wl.hm, wl.W, wl.H), f"undistort warp image {k}")
+
+
+@pytest.mark.parametrize("name", ["warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k", "gaussian_u8_4k"])
+def test_u8_4k_full_batch(gpu_stream, bench, name):
+    """The u8 4K twins at N = 256 (24 883 200-B images: 2^31 B inside image 86, 4 GiB inside 172); the staged gather handles
+    16 images per block (kh_u8.hip), so the 15|16 seam is sampled too."""
+    wl = _run(bench, name, gpu_stream)
+    assert wl.N == 256
+    n = wl.W * wl.H * wl.C
+    if name == "remap_u8_4k":
+        mx, my = O.correction_map(bench.UndistortWarp4K.INTR, bench.UndistortWarp4K.DIST, wl.W, wl.H)
+    for k in boundary_frames(wl.N, n, 1, extra=(15, 16)):
+        src = wl.base[31 * k: 31 * k + n].reshape(wl.H, wl.W, wl.C)
+        if name == "warp_affine_u8_4k":
+            want = O.warp_affine_u8(src, np.array(list(wl.m), np.float32), wl.W, wl.H)
+        elif name == "warp_perspective_u8_4k":
+            want = O.warp_perspective_u8(src, wl.hm, wl.W, wl.H)
+        elif name == "remap_u8_4k":
+            want = O.remap_u8(src, mx, my, "bilinear")
+        else:
+            want = O.gaussian_blur_u8(src, (7, 7), (1.5, 1.5))[0]
+        _same(_fetch(wl.dst, k, np.uint8, (wl.H, wl.W, wl.C)), want, f"{name} image {k}")
