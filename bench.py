@@ -75,29 +75,54 @@ class Workload:
 
 
 class NorthStarNV12(Workload):
-    """configs[2]: fused NV12 -> normalized CHW f32, 1920x1080, batch 1024 on 1 GPU."""
+    """configs[2]: fused NV12 -> normalized CHW f32, 1920x1080, batch 1024 on 1 GPU — and its secondaries: the same frames
+    letterboxed to `out` x `out` (640: the reference's own preprocess_nv12_640; 608: a geometry whose taps do NOT fall on whole
+    pixels, so the general four-tap kernel is in the record), and the YUYV source format (fmt="yuyv": the reference's
+    published 1080p -> 640 fused configuration, docs/benchmark-cuda-color-conversions.md:104)."""
 
     name = "nv12_1080p_to_chw_f32_b1024"
     W, H = 1920, 1080
     kernel = "preprocess_nv12_identity"
     dtype = "f32"
 
-    def __init__(self, batch: int = 1024, out: int = 0, sampling: str = "bilinear"):
+    def __init__(self, batch: int = 1024, out: int = 0, sampling: str = "bilinear", fmt: str = "nv12"):
         self.N = batch
         self.sampling = sampling
-        self.out = out  # 0: same-size (north star); else letterbox to out x out (secondary row)
-        self.frame_bytes = self.W * self.H * 3 // 2
+        self.fmt = fmt
+        self.out = out  # 0: same-size (north star); else letterbox to out x out (secondary rows)
         px = self.W * self.H
+        self.frame_bytes = px * 3 // 2 if fmt == "nv12" else px * 2
+        self.src_bytes_per_px = 1.5 if fmt == "nv12" else 2.0
         self.units_per_step = self.N * px / 1e6
         if out == 0:
             # SURVEY.md §8(d): 1.5 B/px read + 12 B/px written = 27 993 600 B per frame
             self.alg_bytes_per_launch = self.N * (self.frame_bytes + 12 * px)
         else:
-            self.name = f"nv12_1080p_to_chw_f32_letterbox{out}{'' if sampling == 'bilinear' else '_' + sampling}_b{batch}"
+            self.name = f"{fmt}_1080p_to_chw_f32_letterbox{out}{'' if sampling == 'bilinear' else '_' + sampling}_b{batch}"
             self.kernel = "preprocess_generic"
-            # out*out*12 B written + taps actually required (<= 4 taps * 1.5 B per output pixel; 36 for Lanczos-3)
-            taps = 36 if sampling == "lanczos" else 4
-            self.alg_bytes_per_launch = self.N * (out * out * 12 + out * out * taps * 3 // 2)
+            self.alg_bytes_per_launch = 0  # priced in setup(): it depends on the variant the library launches for this geometry
+
+    def _price_letterbox(self):
+        """Algorithmic bytes of a letterboxed launch = every destination float written + the source taps the LAUNCHED variant
+        needs for the ACTIVE destination pixels only (padding pixels read nothing): one tap when the library reports the
+        on-grid form (every source coordinate a whole number: `generic_bilinear_on_grid`) or nearest sampling, four for the
+        general bilinear kernel, 36 for Lanczos-3 — each tap `src_bytes_per_px` (1.5 B NV12, 2 B YUYV), SURVEY.md §8(d).
+        Active pixels are counted with the kernel's own f32 coordinate expression (plan_pixel, P/preprocess.rs:437-448)."""
+        from kornia_rs import _ffi
+        f = self.pre.source_format
+        p = self.pre._params(self.W, self.H, f.pitch(self.W), f.bpp, f.fmt_code, self.out, self.out, self.N, self.frame_bytes, False, False)
+        self.variant = _ffi.lib.kh_preprocess_variant(C.byref(p)).decode()
+        f32 = np.float32
+
+        def active(n, pad, scale, length):
+            s = (np.arange(n, dtype=f32) - f32(pad)) / f32(scale)
+            return int(((s >= 0) & (s < f32(length))).sum())
+
+        ax, ay = active(self.out, p.pad_x, p.scale_x, self.W), active(self.out, p.pad_y, p.scale_y, self.H)
+        taps = 36 if self.sampling == "lanczos" else (1 if (self.variant.endswith("on_grid") or self.sampling == "nearest") else 4)
+        self.active_px, self.taps = ax * ay, taps
+        self.kernel = f"preprocess_generic ({self.variant})"
+        self.alg_bytes_per_launch = int(self.N * (self.out * self.out * 12 + ax * ay * taps * self.src_bytes_per_px))
 
     def setup(self, stream):
         from kornia_rs import Preprocessor, Tensor
@@ -113,30 +138,37 @@ class NorthStarNV12(Workload):
         self.base = base
         oh, ow = (self.H, self.W) if self.out == 0 else (self.out, self.out)
         self.dst = Tensor.uninit((self.N, 3, oh, ow), "float32", stream)
-        self.pre = Preprocessor(mode="stretch" if self.out == 0 else "letterbox", format="nv12",
+        self.pre = Preprocessor(mode="stretch" if self.out == 0 else "letterbox", format=self.fmt,
                                 sampling=self.sampling, mean=IMAGENET_MEAN, std=IMAGENET_STD,
                                 stream=stream)
+        if self.out:
+            self._price_letterbox()
 
     def step(self):
         self.pre.run_raw_batch(self.src, self.W, self.H, self.dst, frame_stride=self.frame_bytes)
 
     def describe(self):
-        return {"workload": self.name, "op": "Preprocessor.run_raw_batch (fused NV12 decode + "
-                "bilinear + ImageNet normalize + HWC->CHW)", "src": "1920x1080 NV12",
-                "dst": f"[{self.N},3,{self.dst.shape[2]},{self.dst.shape[3]}] f32",
-                "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+        d = {"workload": self.name, "op": f"Preprocessor.run_raw_batch (fused {self.fmt.upper()} decode + "
+             f"{self.sampling} + ImageNet normalize + HWC->CHW)", "src": f"1920x1080 {self.fmt.upper()}",
+             "dst": f"[{self.N},3,{self.dst.shape[2]},{self.dst.shape[3]}] f32",
+             "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+        if self.out:
+            d.update(variant=self.variant, active_dst_px=self.active_px, taps_per_active_px=self.taps,
+                     pricing="dst floats written + taps x source bytes per ACTIVE dst pixel of the launched variant")
+        return d
 
     def cpu_baseline(self):
-        """Chained rgb_from_nv12 (Q20) -> direct bilinear/normalise/CHW, the comparator BASELINE.md
-        §3 names (the reference has no CPU fused-NV12 path).  Bounded to ~10-20 s."""
+        """Chained rgb_from_nv12 / rgb_from_yuyv (Q20) -> direct bilinear/normalise/CHW, the comparator BASELINE.md
+        §3 names (the reference has no CPU fused camera-format path).  Bounded to ~10-20 s."""
         sys.path.insert(0, str(ROOT / "tests"))
         import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
         threads = O.ko.ko_max_threads()
         oh, ow = (self.H, self.W) if self.out == 0 else (self.out, self.out)
+        decode = O.rgb_from_nv12 if self.fmt == "nv12" else O.rgb_from_yuyv
         frames, t0, budget = 0, time.perf_counter(), 12.0 * CPU_BUDGET_SCALE
         while True:
             raw = self.base[31 * (frames % self.N): 31 * (frames % self.N) + self.frame_bytes]
-            rgb = O.rgb_from_nv12(raw, self.W, self.H)
+            rgb = decode(raw, self.W, self.H)
             O.preprocess(rgb, self.W, self.H, ow, oh, fmt="rgb",
                          mode="stretch" if self.out == 0 else "letterbox", sampling=self.sampling,
                          mean=IMAGENET_MEAN, std=IMAGENET_STD)
@@ -146,9 +178,9 @@ class NorthStarNV12(Workload):
                 break
         return {"value": round(frames * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s",
                 "cores": threads, "kind": "port",
-                "sample": f"{frames} frames of the same 1080p NV12 workload in {dt:.1f} s; C oracle "
+                "sample": f"{frames} frames of the same 1080p {self.fmt.upper()} workload in {dt:.1f} s; C oracle "
                           "(faithful restatement of kornia-imgproc, not the upstream Rust binary), "
-                          f"chained rgb_from_nv12 -> {self.sampling}/normalize/CHW, OpenMP x{threads}"}
+                          f"chained rgb_from_{self.fmt} -> {self.sampling}/normalize/CHW, OpenMP x{threads}"}
 
 
 class F32Images(Workload):
@@ -368,6 +400,151 @@ class UndistortWarp4K(F32Images):
                 "kind": "port", "sample": f"{frames} images in {dt:.1f} s; C oracle remap+warp_perspective "
                 f"(restatement, not the upstream Rust binary), OpenMP x{threads} over rows"}
 
+
+
+class ResizeBicubic540(ResizeBilinear):
+    """resize bicubic (Keys a = -0.5) 1920x1080 -> 960x540 f32x3, batch 256 — the reference's CUDA bicubic launcher
+    (P/cuda/resize.rs:245) on its published 1080p -> 540p shape (benchmarks.md:374).  At exactly 2x the 4x4 windows of the
+    destination pixels cover every source pixel, so the algorithmic traffic is the whole source once + the destination."""
+
+    name, kernel = "resize_bicubic_1080p_to_540p_f32_b256", "resize_kernel<3,bicubic>"
+    DW, DH = 960, 540
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.SW * self.SH / 1e6
+        self.alg_bytes_per_launch = self.N * (self.SW * self.SH + self.DW * self.DH) * self.C * 4
+
+    def step(self):
+        from kornia_rs import _ffi
+        _ffi.check(_ffi.lib.kh_resize_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.SW, self.SH, self.DW,
+                                          self.DH, self.C, _ffi.KH_INTERP_BICUBIC, self.N, self.SW * self.SH * self.C,
+                                          self.DW * self.DH * self.C))
+
+    def describe(self):
+        return {"workload": self.name, "op": "imgproc::resize (bicubic, half-pixel)", "src": "1920x1080x3 f32", "dst": "960x540x3 f32",
+                "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
+
+    def cpu_baseline(self):
+        O = self._oracle()
+        threads, n = O.ko.ko_max_threads(), self.SW * self.SH * self.C
+        frames, t0 = 0, time.perf_counter()
+        while True:
+            O.resize(self.base[31 * (frames % self.N): 31 * (frames % self.N) + n].reshape(self.SH, self.SW, self.C), self.DW, self.DH, "bicubic")
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt > 8.0 * CPU_BUDGET_SCALE or frames >= 64:
+                break
+        return {"value": round(frames * self.SW * self.SH / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+                "sample": f"{frames} images in {dt:.1f} s; C oracle of resize bicubic (not the upstream Rust binary), OpenMP x{threads} over output rows"}
+
+
+class SameSizeF32(F32Images):
+    """Shared body of the same-size f32x3 maps / stencils / warps: 1R + 1W of the image per launch."""
+
+    W, H, C = 1920, 1080, 3
+    op = ""
+
+    def __init__(self, batch):
+        self.N = batch
+        self.units_per_step = self.N * self.W * self.H / 1e6
+        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C * 4
+
+    def setup(self, stream):
+        from kornia_rs.hip import DeviceBuffer
+        self.stream = stream
+        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
+        self.dst = DeviceBuffer(self.N * self.W * self.H * self.C * 4, stream, zeroed=False)
+
+    def describe(self):
+        return {"workload": self.name, "op": self.op, "src": f"{self.W}x{self.H}x3 f32", "dst": "same", "batch_per_gpu": self.N,
+                "parallelism": "batch-sharded, no collective"}
+
+    def oracle_call(self, O, img):
+        raise NotImplementedError
+
+    def cpu_baseline(self):
+        O = self._oracle()
+        threads, n = O.ko.ko_max_threads(), self.W * self.H * self.C
+        frames, t0 = 0, time.perf_counter()
+        while True:
+            self.oracle_call(O, self.base[31 * (frames % self.N): 31 * (frames % self.N) + n].reshape(self.H, self.W, self.C))
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt > 8.0 * CPU_BUDGET_SCALE or frames >= 64:
+                break
+        return {"value": round(frames * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+                "sample": f"{frames} images in {dt:.1f} s; C oracle of {self.op} (not the upstream Rust binary), OpenMP x{threads}"}
+
+
+class WarpAffineF32_1080p(SameSizeF32):
+    """warp_affine bilinear f32x3 (rotation 12 deg about the centre, scale 0.9) 1920x1080, batch 256 (P/cuda/warp_affine.rs:75,
+    published at benchmarks.md:285).  Out-of-bounds destination pixels write 0 and read nothing; priced as 1R + 1W."""
+
+    name, kernel, op = "warp_affine_f32_1080p_b256", "warp_affine_kernel<3,bilinear>", "imgproc::warp::warp_affine (rot 12 deg, scale 0.9, bilinear)"
+
+    def setup(self, stream):
+        import ctypes as C
+        from kornia_rs._ffi import lib
+        super().setup(stream)
+        self.m = (C.c_float * 6)()
+        lib.kh_get_rotation_matrix2d(self.W / 2.0, self.H / 2.0, 12.0, 0.9, self.m)
+
+    def step(self):
+        from kornia_rs import _ffi
+        n = self.W * self.H * self.C
+        _ffi.check(_ffi.lib.kh_warp_affine_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.W, self.H,
+                                               self.C, self.m, _ffi.KH_INTERP_BILINEAR, self.N, n, n))
+
+    def oracle_call(self, O, img):
+        return O.warp_affine(img, list(self.m), self.W, self.H)
+
+
+class Sobel4K(SameSizeF32):
+    """sobel (3x3, magnitude sqrt(gx^2 + gy^2)) f32x3 3840x2160, batch 128 (P/filter/ops.rs:174, published at benchmarks.md:477)."""
+
+    W, H = 3840, 2160
+    name, kernel, op = "sobel_3x3_4k_f32_b128", "gradient_magnitude kernel (fused gx, gy, sqrt)", "imgproc::filter::sobel (kernel_size 3)"
+
+    def step(self):
+        from kornia_rs import _ffi
+        n = self.W * self.H * self.C
+        _ffi.check(_ffi.lib.kh_gradient_magnitude_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.C,
+                                                      _ffi.KH_GRAD_SOBEL, 3, self.N, n, n))
+
+    def oracle_call(self, O, img):
+        return O.gradient_magnitude(img, 0, 3)
+
+
+class BoxBlur4K(SameSizeF32):
+    """box_blur (5, 5) f32x3 3840x2160, batch 128 (P/filter/ops.rs:39): the separable path with 1/5 taps."""
+
+    W, H = 3840, 2160
+    name, kernel, op = "box_blur_5x5_4k_f32_b128", "sep_roll4_kernel<5,3>", "imgproc::filter::box_blur (5, 5)"
+
+    def step(self):
+        from kornia_rs import _ffi
+        n = self.W * self.H * self.C
+        _ffi.check(_ffi.lib.kh_box_blur_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.C, 5, 5, self.N, n, n))
+
+    def oracle_call(self, O, img):
+        return O.separable_filter(img, O.box_kernel_1d(5), O.box_kernel_1d(5))
+
+
+class NormalizeMeanStd1080p(SameSizeF32):
+    """normalize_mean_std f32x3 (ImageNet mean / std, true IEEE division) 1920x1080, batch 512 (P/normalize.rs:56; the reference
+    has no CUDA twin of it — its CPU path is published at 3.8 ms per 1080p frame on Orin)."""
+
+    name, kernel, op = "normalize_mean_std_1080p_f32_b512", "normalize_mean_std kernel", "imgproc::normalize::normalize_mean_std (ImageNet)"
+
+    def step(self):
+        import ctypes as C
+        from kornia_rs import _ffi
+        _ffi.check(_ffi.lib.kh_normalize_mean_std_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.N * self.W * self.H, self.C,
+                                                      (C.c_float * 3)(*IMAGENET_MEAN), (C.c_float * 3)(*IMAGENET_STD)))
+
+    def oracle_call(self, O, img):
+        return O.normalize_mean_std(img, IMAGENET_MEAN, IMAGENET_STD)
 
 
 class U8Images(Workload):
@@ -790,45 +967,6 @@ class DilateU8_4K(U8Images):
         return self._time_cpu(lambda O: O.morphology_u8(img, "dilate", O.morph_kernel("box", 5)), "dilate")
 
 
-class LabFromRgb4K(U8Images):
-    """lab_from_rgb f32 on 3840x2160x3, batch 64 (6.4 GB in + 6.4 GB out)."""
-
-    name, kernel = "lab_from_rgb_f32_4k_b64", "map_kernel<CieF32>"
-    dtype = "f32"
-
-    def __init__(self, batch):
-        self.N = batch
-        self.units_per_step = self.N * self.W * self.H / 1e6
-        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * 12
-
-    def setup(self, stream):
-        from kornia_rs.hip import DeviceBuffer
-        from kornia_rs._ffi import lib, check
-        self.stream = stream
-        n = self.W * self.H * 3
-        x = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761)) >> np.uint32(8)  # values in [0, 1)
-        self.host = (x.astype(np.float32) / np.float32(1 << 24)).astype(np.float32)
-        one = DeviceBuffer.from_numpy(self.host, stream)
-        self.src = DeviceBuffer(self.N * n * 4, stream, zeroed=False)
-        for k in range(self.N):
-            check(lib.kh_memcpy_d2d_async(self.src.ptr + k * n * 4, one.ptr, n * 4, stream.cuda_stream_ptr))
-        stream.synchronize()
-        self.dst = DeviceBuffer(self.N * n * 4, stream, zeroed=False)
-
-    def step(self):
-        from kornia_rs import _ffi
-        _ffi.check(_ffi.lib.kh_cie_convert_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.N * self.W * self.H,
-                                               _ffi.KH_CIE["lab_from_rgb"]))
-
-    def describe(self):
-        return {"workload": self.name, "op": "imgproc::color::lab_from_rgb (f32)", "src": "3840x2160x3 f32", "dst": "same",
-                "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
-
-    def cpu_baseline(self):
-        img = self.host.reshape(self.H, self.W, 3)
-        return self._time_cpu(lambda O: O.cie("lab_from_rgb", img), "lab_from_rgb")
-
-
 class SpatialGradient1080p(F32Images):
     """spatial_gradient_float (normalised 3x3 Sobel, dx + dy) on 1920x1080 f32x3, batch 256."""
 
@@ -902,58 +1040,6 @@ class BoxBlurFast1080p(SpatialGradient1080p):
                 "sample": f"{reps} images in {dt:.1f} s; C oracle of box_blur_fast (single-threaded in the reference), OpenMP x{threads} over rows"}
 
 
-class Median5U8_1080p(U8Images):
-    """median_blur 5x5 on 1920x1080 RGB8, batch 256 (compute-bound: packed min/max selection network)."""
-
-    name, kernel = "median_blur_5x5_1080p_rgb8_b256", "median_kernel<5,3>"
-    W, H, C = 1920, 1080, 3
-
-    def __init__(self, batch):
-        self.N = batch
-        self.units_per_step = self.N * self.W * self.H / 1e6
-        self.alg_bytes_per_launch = self.N * 2 * self.W * self.H * self.C
-
-    def setup(self, stream):
-        from kornia_rs.hip import DeviceBuffer
-        self.stream = stream
-        self.src = self._make_src(stream, self.W, self.H, self.C, self.N)
-        self.dst = DeviceBuffer(self.N * self.W * self.H * self.C, stream, zeroed=False)
-
-    def step(self):
-        from kornia_rs._ffi import lib, check
-        n = self.W * self.H * self.C
-        check(lib.kh_median_blur_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, self.C, 5, self.N, n, n))
-
-    def describe(self):
-        return {"workload": self.name, "op": "imgproc::filter::median_blur ksize 5 (replicate border)", "src": "1920x1080x3 u8", "dst": "same",
-                "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
-
-    def cpu_baseline(self):
-        img = self.base[: self.W * self.H * self.C].reshape(self.H, self.W, self.C)
-        return self._time_cpu(lambda O: O.median_blur(img, 5), "median_blur (counting form)")
-
-
-class Bilateral1080p(Median5U8_1080p):
-    """bilateral_filter d=5 sigma (50, 50) on 1920x1080 gray u8, batch 256 — the reference's probe shape (median.rs:1143-1178)."""
-
-    name, kernel = "bilateral_d5_1080p_gray8_b256", "bilateral_kernel"
-    C = 1
-
-    def step(self):
-        from kornia_rs._ffi import lib, check
-        n = self.W * self.H
-        check(lib.kh_bilateral_filter_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W, self.H, 5, 50.0, 50.0, self.N, n, n))
-
-    def describe(self):
-        return {"workload": self.name, "op": "imgproc::filter::bilateral_filter d=5 sigma_color=50 sigma_space=50 (cv2-compatible)",
-                "src": "1920x1080x1 u8", "dst": "same", "batch_per_gpu": self.N, "parallelism": "batch-sharded, no collective"}
-
-    def cpu_baseline(self):
-        img = self.base[: self.W * self.H].reshape(self.H, self.W, 1)
-        return self._time_cpu(lambda O: O.bilateral_filter(img, 5, 50.0, 50.0), "bilateral_filter")
-
-
-
 class ColorMap1080p(Workload):
     """Pointwise colour maps on 1920x1080 images, batch 1024 (one launch over N*W*H pixels): the reference's own headline
     GPU claim is gray_from_rgb f32 at 87 % of its part's peak (crates/kornia-imgproc/benchmarks.md:72)."""
@@ -964,7 +1050,11 @@ class ColorMap1080p(Workload):
         "gray_f32": ("kh_gray_from_rgb_f32", "f32", 3, 1, "map_f32<Gray>"),
         "hsv_f32": ("kh_hsv_from_rgb_f32", "f32", 3, 3, "map_f32<Hsv>"),
         "bgr_u8": ("kh_bgr_from_rgb_u8", "u8", 3, 3, "map_u8_quads<Swizzle>"),
+        # ycbcr_from_rgb (Family A, full-range Q14 / f32; P/cuda/color/yuv.rs:110): the entry takes the channel order as a 5th argument
+        "ycbcr_u8": ("kh_ycc_from_rgb_u8", "u8", 3, 3, "map_u8_quads<Ycc>"),
+        "ycbcr_f32": ("kh_ycc_from_rgb_f32", "f32", 3, 3, "map_f32<Ycc>"),
     }
+    EXTRA = {"kh_ycc_from_rgb_u8": (0,), "kh_ycc_from_rgb_f32": (0,)}  # KH_YCC_YCRCB
 
     def __init__(self, which, batch):
         self.which, self.N = which, batch
@@ -992,7 +1082,8 @@ class ColorMap1080p(Workload):
 
     def step(self):
         from kornia_rs._ffi import lib, check
-        check(getattr(lib, self.entry)(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.N * self.W * self.H))
+        check(getattr(lib, self.entry)(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.N * self.W * self.H,
+                                       *self.EXTRA.get(self.entry, ())))
 
     def describe(self):
         return {"workload": self.name, "op": f"imgproc::color::{self.entry[3:]}", "src": f"1920x1080x{self.cin} {self.dtype}",
@@ -1006,7 +1097,7 @@ class ColorMap1080p(Workload):
         name = self.entry[3:]
         reps, t0 = 0, time.perf_counter()
         while True:
-            O.color_map(name, img, self.cout)
+            O.color_map(name, img, self.cout, *self.EXTRA.get(self.entry, ()))
             reps += 1
             dt = time.perf_counter() - t0
             if dt > 6.0 * CPU_BUDGET_SCALE or reps >= 64:
@@ -1067,11 +1158,18 @@ class GrayPlumbing258x195(Workload):
 WORKLOADS = {
     "nv12_chw": lambda a: NorthStarNV12(a.batch or 1024, 0),
     "nv12_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640),
+    "nv12_chw_608": lambda a: NorthStarNV12(a.batch or 1024, 608),
     "nv12_chw_640_lanczos": lambda a: NorthStarNV12(a.batch or 256, 640, "lanczos"),
+    "yuyv_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640, "bilinear", "yuyv"),
     "resize_224": lambda a: ResizeBilinear(a.batch or 256),
+    "resize_bicubic_540": lambda a: ResizeBicubic540(a.batch or 256),
     "resize_normalize_f32_224": lambda a: ResizeNormalizeF32(a.batch or 256),
     "gaussian_4k": lambda a: Gaussian4K(a.batch or 256),
+    "sobel_4k": lambda a: Sobel4K(a.batch or 128),
+    "box_blur_4k": lambda a: BoxBlur4K(a.batch or 128),
     "undistort_warp_4k": lambda a: UndistortWarp4K(a.batch or 256),
+    "warp_affine_f32_1080p": lambda a: WarpAffineF32_1080p(a.batch or 256),
+    "normalize_1080p": lambda a: NormalizeMeanStd1080p(a.batch or 512),
     "gaussian_u8_4k": lambda a: GaussianU8_4K(a.batch or 256),
     "warp_affine_u8_4k": lambda a: WarpAffineU8_4K(a.batch or 256),
     "warp_perspective_u8_4k": lambda a: WarpPerspectiveU8_4K(a.batch or 256),
@@ -1084,23 +1182,26 @@ WORKLOADS = {
     "pyrup_u8_4k": lambda a: PyramidLevel("pyrup_u8", a.batch or 256),
     "pyrdown_f32_4k": lambda a: PyramidLevel("pyrdown_f32", a.batch or 64),
     "pyrup_f32_4k": lambda a: PyramidLevel("pyrup_f32", a.batch or 64),
-    "lab_from_rgb_4k": lambda a: LabFromRgb4K(a.batch or 64),
     "spatial_gradient_1080p": lambda a: SpatialGradient1080p(a.batch or 256),
     "box_blur_fast_1080p": lambda a: BoxBlurFast1080p(a.batch or 64),
-    "median5_u8_1080p": lambda a: Median5U8_1080p(a.batch or 256),
-    "bilateral_1080p": lambda a: Bilateral1080p(a.batch or 256),
     "gray_u8_1080p": lambda a: ColorMap1080p("gray_u8", a.batch or 1024),
     "gray_f32_1080p": lambda a: ColorMap1080p("gray_f32", a.batch or 1024),
     "hsv_f32_1080p": lambda a: ColorMap1080p("hsv_f32", a.batch or 512),
+    "ycbcr_u8_1080p": lambda a: ColorMap1080p("ycbcr_u8", a.batch or 1024),
+    "ycbcr_f32_1080p": lambda a: ColorMap1080p("ycbcr_f32", a.batch or 512),
     "bgr_u8_1080p": lambda a: ColorMap1080p("bgr_u8", a.batch or 1024),
     "gray_258x195": lambda a: GrayPlumbing258x195(),
 }
 
-# What the default run measures after the headline workload, in the same process ("put C2 / C4 / C5 and the
-# 640 secondary into the driver's single run"): the other BASELINE configs, the north star's letterbox secondary, the
-# pointwise colour maps and the two weakest kernels of round 1.  Each entry is a full roofline record.
-ALSO_DEFAULT = ["nv12_chw_640", "resize_224", "gaussian_4k", "undistort_warp_4k", "gray_258x195", "gray_u8_1080p",
-                "gray_f32_1080p", "hsv_f32_1080p", "warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k", "gaussian_u8_4k"]
+# What the default run measures after the headline workload, in the same process: the other BASELINE configs, the north star's
+# letterbox secondaries (on-grid 640, off-grid 608, the YUYV source format) and one line for every operator `north_star` names
+# (resize bilinear / bicubic, gray + YCbCr + HSV converts, gaussian / box / sobel, warp_affine / warp_perspective + undistort,
+# normalize), then the u8 twins.  Each entry is a full roofline record with its own cpu_baseline.  (Median / bilateral / Lab
+# are out of SURVEY.md §8 and have no bench line; their kernels are covered by the parity tests only.)
+ALSO_DEFAULT = ["nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "resize_224", "resize_bicubic_540", "gaussian_4k", "box_blur_4k", "sobel_4k",
+                "undistort_warp_4k", "warp_affine_f32_1080p", "normalize_1080p", "gray_258x195", "gray_u8_1080p", "gray_f32_1080p",
+                "ycbcr_u8_1080p", "ycbcr_f32_1080p", "hsv_f32_1080p", "warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k",
+                "gaussian_u8_4k"]
 CPU_BUDGET_SCALE = 1.0  # lowered for the `also` entries so the default run stays within a few minutes
 
 
@@ -1414,7 +1515,18 @@ def main():
 
     if rank == 0:
         name, cus, mem = hip.device_info(local_rank)
-        dev = {"name": name, "cus": cus, "hbm_bytes": mem, "host_cpus": os.cpu_count(), "hip_runtime": str(hip.runtime_info().get("choice"))[:80]}
+        try:
+            affinity = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            affinity = None
+        dev = {"name": name, "cus": cus, "hbm_bytes": mem, "host_cpus": os.cpu_count(), "host_affinity_cpus": affinity,
+               "hip_runtime": str(hip.runtime_info().get("choice"))[:80]}
+        if world == 1 and not args.no_cpu_baseline:
+            # why `cores` can be below host_cpus: the OpenMP team of the CPU baseline is omp_get_max_threads(), which libgomp sizes from
+            # the process's affinity mask (the box's cgroup cpuset), not from the logical CPUs the kernel enumerates
+            dev["cpu_cores_note"] = (f"cpu_baseline.cores = omp_get_max_threads() of the oracle's OpenMP runtime = the {affinity} CPUs of this process's "
+                                     f"affinity mask (sched_getaffinity); os.cpu_count() = {os.cpu_count()} counts every logical CPU of the host, "
+                                     "including those outside the container's cpuset; cores = 1 where the reference's CPU path is single-threaded")
         if ceilings:
             dev.update(ceilings)
             ms = line["roofline"]["mean_launch_ms"]

@@ -242,99 +242,8 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
     }
 }
 
-// ---- rolling-column kernel, TWO columns per lane ------------------------------------------------------------------------------
-// A lane owns two adjacent flat columns as a float2: one 8-byte global load / store per row, one ds_read2_b32 per tap, and
-// v_pk_mul_f32 / v_pk_add_f32 for both passes — the same IEEE operations in the same order per element as the one-column kernel,
-// half the vector instructions (35 instead of 70 per row step in the 7-tap kernel).  A wave covers 128 columns (halo lanes as
-// before, at most 32 floats per side), a 256-thread block 512.
-// Measured on C4, same box, interleaved (profiles/r02u_filter_ab.txt): 9.11 ms against 9.16 ms for the one-column kernel — a
-// wash, which settles what bounds this kernel: NOT instruction issue (by SQ_INSTS_VALU x 4 cycles the one-column kernel keeps the
-// vector ALUs about 80 % busy, yet halving that changes nothing), but the memory system: 52.7 GB of counted traffic in 9.1 ms = 5.8 TB/s
-// for a 50 % read / 50 % write stream, against 6.2-6.3 TB/s for the best plain copies measured on this part.  Round 1 reached the
-// same conclusion from a similar variant (profiles/r01n_ab.log).  A second same-box A/B at the end of the round (r02zk, three
-// interleaved runs each) has the one-column kernel 1.5 % ahead (9.17 vs 9.30 ms), so it stays the default; KH_FILTER_TWO_COLUMNS=1
-// selects this kernel (even rows of at least 512 floats; tests/test_filter_gpu.py runs it in a child process).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-constexpr int kTF2 = 2 * kTF;  // flat columns per 256-thread block
-constexpr bool kFourColumnsDefault = true;   // sep_roll4_kernel where it applies: 2-7 % faster than one column per lane on C4, same box, interleaved (profiles/r03k, r03l); KH_FILTER_FOUR_COLUMNS=0 turns it off
-
-template <int K>
-__global__ __launch_bounds__(kBlock) void sep_roll2_kernel(FilterArgs a, TapsK kx, TapsK ky) {
-    __shared__ float rowbuf[4][224];  // 32 left halo + 128 main + 32 right halo + 32 spare (the parking slot)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    constexpr int H = K / 2;
-    const int halo = H * a.C;  // <= 32 (checked on the host)
-    unsigned tx, ty, bz;
-    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
-    const int gx0 = tx * kTF2 + wv * 128;  // first flat column of this wave
-    if (gx0 >= a.rowlen) return;            // whole wave idle (no block barrier below)
-    const int y0 = ty * a.th;
-    const float* __restrict__ src = a.src + (long long)bz * a.src_stride;
-    float* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
-    float* buf = rowbuf[wv];
-
-    const int gx = gx0 + 2 * lane;          // this lane's columns gx, gx + 1 (rowlen is even: host-checked)
-    const bool is_halo = lane < 2 * halo;   // lanes [0, halo) fetch the left neighbours, [halo, 2*halo) the right ones
-    const int hgx = lane < halo ? gx0 - halo + lane : gx0 + 128 + (lane - halo);
-    const int hslot = lane < halo ? lane : 128 + lane;   // buffer layout: left [0,halo), main [halo,halo+128), right after
-    const bool gx_ok = gx < a.rowlen, hgx_ok = is_halo && hgx >= 0 && hgx < a.rowlen;
-    const int nrows = min(a.th, a.rows - y0) + 2 * H;
-
-    const int cx_m = min(gx, a.rowlen - 2);
-    const int cx_h = is_halo ? min(max(hgx, 0), a.rowlen - 1) : cx_m;
-    int pf_row = y0 - H;
-
-    f32x2_t qm[K];
-    float qh[K];
-    auto prefetch = [&](f32x2_t& m, float& hv) {
-        const int base = min(max(pf_row, 0), a.rows - 1) * a.rowlen;  // 32-bit: host-checked
-        m = *reinterpret_cast<const f32x2_t*>(src + base + cx_m);     // 8-byte load; rowlen even and gx even -> 8-byte aligned when src is
-        hv = src[base + cx_h];
-        ++pf_row;
-    };
-#pragma unroll
-    for (int p = 0; p < K; ++p) prefetch(qm[p], qh[p]);
-
-    f32x2_t ring[K];
-#pragma unroll
-    for (int i = 0; i < K; ++i) ring[i] = f32x2_t{0.0f, 0.0f};
-
-    const int hs = is_halo ? hslot : 223;  // non-halo lanes park their duplicate in a slot nobody reads
-    const __amdgpu_buffer_rsrc_t ow = stream_window(dst + (long long)y0 * a.rowlen, (long long)(a.rows - y0) * a.rowlen * 4);
-    int out_off = (gx - 2 * H * a.rowlen) * 4;
-    const float* tap = buf + halo + 2 * lane - H * a.C;
-    for (int rb = 0; rb < nrows; rb += K) {
-#pragma unroll
-        for (int p = 0; p < K; ++p) {
-            const int r = rb + p;
-            const int row = y0 - H + r;
-            const bool row_ok = row >= 0 && row < a.rows;  // wave-uniform
-            const f32x2_t m = (row_ok && gx_ok) ? qm[p] : f32x2_t{0.0f, 0.0f};
-            const float hv = (row_ok && hgx_ok) ? qh[p] : 0.0f;
-            prefetch(qm[p], qh[p]);
-            buf[halo + 2 * lane] = m.x;
-            buf[halo + 2 * lane + 1] = m.y;
-            buf[hs] = hv;
-            __builtin_amdgcn_wave_barrier();
-            f32x2_t h1 = {0.0f, 0.0f};
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const f32x2_t v = {tap[i * a.C], tap[i * a.C + 1]};
-                h1 += v * kx.k[i];       // v_pk_mul_f32 then v_pk_add_f32: two roundings per element, as the reference
-            }
-            __builtin_amdgcn_wave_barrier();
-            ring[p] = h1;
-            f32x2_t o = {0.0f, 0.0f};
-#pragma unroll
-            for (int i = 0; i < K; ++i) o += ring[(p + 1 + i) % K] * ky.k[i];
-            if (gx_ok && r >= 2 * H && r < nrows) {
-                const uint32_t bits[2] = {__float_as_uint(o.x), __float_as_uint(o.y)};
-                stream_store<2>(ow, out_off, bits);
-            }
-            out_off += a.rowlen * 4;
-        }
-    }
-}
+constexpr bool kFourColumnsDefault = true;   // sep_roll4_kernel where it applies: 2-7 % faster than one column per lane on C4, same box, interleaved (profiles/r03k, r03l); test option filter_four_columns = 0 turns it off
 
 
 // ---- rolling-column kernel, FOUR columns per lane (round 3) -------------------------------------------------------------------
@@ -435,17 +344,6 @@ __global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK k
     }
 }
 
-// tuning knob (dev): KH_FILTER_STRIP = output rows per strip
-int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e && *e ? atoi(e) : dflt;
-}
-
-template <int K>
-void launch_roll2(hipStream_t st, dim3 grid, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
-    hipLaunchKernelGGL((sep_roll2_kernel<K>), grid, dim3(kBlock), 0, st, a, kx, ky);
-}
-
 template <int K>
 bool launch_roll4(hipStream_t st, dim3 grid, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
     switch (a.C) {
@@ -479,11 +377,8 @@ int32_t set_taps(Taps& t, const float* k, int n, const char* what) {
     return KH_OK;
 }
 
-// KH_FILTER_FORCE_TILE=1 routes every call to the LDS-tile kernel (parity tests cover both).
-bool force_tile_kernel() {
-    const char* e = getenv("KH_FILTER_FORCE_TILE");
-    return e && e[0] == '1';
-}
+// test option filter_force_tile = 1 routes every call to the LDS-tile kernel (parity tests cover both).
+bool force_tile_kernel() { return dev_opt(kOptFilterForceTile) == 1; }
 
 int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int rows, int C, const Taps& kx,
                const Taps& ky, bool grad, int batch, int64_t ss, int64_t ds, const char* what) {
@@ -511,20 +406,15 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         TapsK px, py;
         pad_taps(px, kx, K);
         pad_taps(py, ky, K);
-        // KH_FILTER_TWO_COLUMNS=1 (dev / test knob): two columns per lane (packed f32 math) for rows of even length that fill at
-        // least one 512-column block; gradients and narrow / odd rows always take the one-column kernel.
-        const char* two_env = getenv("KH_FILTER_TWO_COLUMNS");  // read per call, like KH_FILTER_FORCE_TILE: the tests flip it
-        const bool two_cols = two_env && two_env[0] == '1';
-        const bool two = !grad && two_cols && (a.rowlen % 2 == 0) && a.rowlen >= kTF2 && (reinterpret_cast<uintptr_t>(src) % 8 == 0) &&
-                         (batch == 1 || ss % 2 == 0);
-        // KH_FILTER_FOUR_COLUMNS (dev / test knob, read per call): four columns per lane (sep_roll4_kernel) for K <= 9, C in {1, 3, 4},
-        // rows that are a multiple of four floats and fill one 1024-column block, 16-byte aligned images.
-        const char* four_env = getenv("KH_FILTER_FOUR_COLUMNS");
-        const bool four_cols = four_env ? four_env[0] == '1' : kFourColumnsDefault;
-        const bool four = !grad && !two && four_cols && K <= 9 && (C == 1 || C == 3 || C == 4) && (a.rowlen % 4 == 0) && a.rowlen >= kTF4 &&
+        // four columns per lane (sep_roll4_kernel) for K <= 9, C in {1, 3, 4}, rows that are a multiple of four floats and fill one
+        // 1024-column block, 16-byte aligned images; everything else (and test option filter_four_columns = 0) takes one column per lane.
+        // (A two-column packed-f32 kernel was measured in round 2 and is not in the library.)
+        const int four_opt = dev_opt(kOptFilterFourColumns);
+        const bool four_cols = four_opt < 0 ? kFourColumnsDefault : four_opt == 1;
+        const bool four = !grad && four_cols && K <= 9 && (C == 1 || C == 3 || C == 4) && (a.rowlen % 4 == 0) && a.rowlen >= kTF4 &&
                           (reinterpret_cast<uintptr_t>(src) % 16 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
                           (batch == 1 || (ss % 4 == 0 && ds % 4 == 0));
-        const unsigned tiles_x = cdiv(a.rowlen, four ? kTF4 : (two ? kTF2 : kTF));  // 256-thread blocks: 512 measured +1 %, 1024 +9 % (r01q)
+        const unsigned tiles_x = cdiv(a.rowlen, four ? kTF4 : kTF);  // 256-thread blocks: 512 measured +1 %, 1024 +9 % (r01q)
         // Strip height: tall strips amortise the ky-1 warm-up rows (4K x 256 images: 360 rows is
         // 5 % faster than 90), short strips keep a small launch wide enough to fill 256 CUs.
         {
@@ -532,7 +422,7 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
             long long strips = (2048 + cols_blocks - 1) / cols_blocks;          // >= 8 blocks per CU
             const long long min_strips = cdiv(rows, kRollStripMax), max_strips = cdiv(rows, 32);
             strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
-            a.th = env_int("KH_FILTER_STRIP", (int)cdiv(rows, strips));
+            a.th = (int)cdiv(rows, strips);
         }
         a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch, kXcdEighth);
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
@@ -544,18 +434,6 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
                 case 5: launch_roll4<5>(st, grid, a, px, py); break;
                 case 7: launch_roll4<7>(st, grid, a, px, py); break;
                 default: launch_roll4<9>(st, grid, a, px, py); break;
-            }
-            return check_launch(what);
-        }
-        if (two) {
-            switch (K) {
-                case 3: launch_roll2<3>(st, grid, a, px, py); break;
-                case 5: launch_roll2<5>(st, grid, a, px, py); break;
-                case 7: launch_roll2<7>(st, grid, a, px, py); break;
-                case 9: launch_roll2<9>(st, grid, a, px, py); break;
-                case 11: launch_roll2<11>(st, grid, a, px, py); break;
-                case 13: launch_roll2<13>(st, grid, a, px, py); break;
-                default: launch_roll2<15>(st, grid, a, px, py); break;
             }
             return check_launch(what);
         }

@@ -241,7 +241,7 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // extracts — 2..6 vector-memory instructions per row instead of (K + 1) * C byte loads (these kernels are otherwise bound by
 // load instructions, like the u8 gathers: DESIGN.md section 5).  The dword run may cover up to 3 bytes more than the window; it
 // is taken only when those bytes are still inside the row, so nothing is read outside the image.  WIDE = false (dev knob
-// KH_MEDIAN_BYTES=1) keeps the byte loads everywhere for A/B.
+// the `false` instantiation, not built) keeps the byte loads everywhere for A/B.
 template <int K, int C, bool WIDE>
 __global__ __launch_bounds__(kBx* kBy) void median_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int cols,
                                                           long long ss, long long ds) {
@@ -500,7 +500,7 @@ int32_t kh_spatial_gradient_f32(kh_stream_t stream, const float* src, float* dx,
     KH_REQUIRE(src != dx && src != dy && dx != dy, KH_ERR_INVALID_ARG, "%s: src, dx and dy must be distinct images", what);
     const float a = kind == KH_GRAD_SOBEL ? 0.125f : 0.09375f, b = kind == KH_GRAD_SOBEL ? 0.25f : 0.3125f;
     const int64_t rowlen = (int64_t)cols * channels;
-    static const bool force_scalar = [] { const char* e = getenv("KH_GRAD_SCALAR"); return e && e[0] == '1'; }();  // dev knob for A/B
+    const bool force_scalar = dev_opt(kOptGradScalar) == 1;  // test option: the unaligned fallback on aligned images
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dy)) % 16) == 0 &&
                          rowlen % 4 == 0 && (batch == 1 || (src_stride % 4 == 0 && dst_stride % 4 == 0));
     if (!force_scalar && aligned && channels <= 4) {
@@ -549,8 +549,8 @@ int32_t kh_fast_horizontal_filter_f32(kh_stream_t stream, const float* src, floa
     KH_REQUIRE(src && dst_transposed && src != dst_transposed, KH_ERR_INVALID_ARG, "%s: null or aliased device pointer", what);
     const dim3 grid(cdiv((int64_t)rows * channels, kBlock), batch);
     // LDS-staged rows when a useful chunk fits: ~(256 / C + 2) rows x (T + 2 * half + 1) columns.  64 KiB keeps two blocks per CU;
-    // wide boxes may take up to 150 KiB; beyond that the direct kernel runs.  KH_HFILTER_DIRECT=1 (dev knob) forces it for A/B.
-    static const bool force_direct = [] { const char* e = getenv("KH_HFILTER_DIRECT"); return e && e[0] == '1'; }();
+    // wide boxes may take up to 150 KiB; beyond that the direct kernel runs.  kh_debug_set_option("hfilter_direct", 1) forces it (test option).
+    const bool force_direct = dev_opt(kOptHfilterDirect) == 1;
     const int nrows_max = (kBlock + channels - 1) / channels + 1;
     auto chunk_for = [&](size_t budget) { return (int)(budget / (sizeof(float) * (size_t)nrows_max * channels)) - (2 * half + 1) - 1; };
     int T = chunk_for(64 * 1024);
@@ -607,10 +607,10 @@ int32_t kh_median_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     const dim3 grid(cdiv(cdiv(cols, 2), kBx), cdiv(rows, kBy), batch), blk(kBx, kBy);
     hipStream_t st = as_hip(stream);
     const long long ss = src_stride, ds = dst_stride;
-    static const bool bytes_only = [] { const char* e = getenv("KH_MEDIAN_BYTES"); return e && e[0] == '1'; }();
+    constexpr bool bytes_only = false;  // (the byte-wise selection network was the round-2 A/B partner of the packed one; not instantiated)
 #define KH_MEDIAN_LAUNCH(K, CH)                                                                                                   \
     do {                                                                                                                          \
-        if (bytes_only) hipLaunchKernelGGL((median_kernel<K, CH, false>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); \
+        if constexpr (bytes_only) hipLaunchKernelGGL((median_kernel<K, CH, false>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds); \
         else hipLaunchKernelGGL((median_kernel<K, CH, true>), grid, blk, 0, st, src, dst, (int)rows, (int)cols, ss, ds);          \
     } while (0)
     switch (ksize * 10 + channels) {

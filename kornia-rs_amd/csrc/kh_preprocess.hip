@@ -412,9 +412,60 @@ __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __re
     }
 }
 
-// ---- north-star fast path ------------------------------------------------------------------
-
+// ---- generic kernel, flattened destination quads (round 4) ------------------------------------------------------------------------
+// profiles/r04c: the kernel above runs the 1080p -> 640 / 608 letterboxes at 4.2-4.6 TB/s with every wave slot occupied and 75-80 %
+// of the wave-cycles parked on memory (SQ_WAIT_ANY): bounded by (resident waves) x (bytes a wave has in flight) / (wave lifetime),
+// not by the vector ALUs (35-40 % busy) or by HBM.  Two things waste slots there: the 64 x kGenPx = 256-pixel block rows leave the
+// third block of a 640- / 608-pixel row half empty (17-21 % of the lanes exit at once), and a lane keeps 4 pixels x 12 B in flight
+// as twelve 4-byte stores.  Here the destination is walked as a flat list of 4-pixel quads (dst_w % 4 == 0): no idle lanes but the
+// last block's tail, a lane owns K quads (kQuadBlock apart, so a wave still stores 1 KiB contiguous per instruction) and writes each
+// plane with one 16-byte streaming buffer store, like the identity kernel.  Same per-pixel expressions, bit-identical.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kQuadBlock = 256;
+constexpr int kQuadsPerLane = 1;   // production choice (profiles/r04d)
+template <int FMT, int SAMPLER, bool WIDE, int K>
+__global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uint8_t* __restrict__ src_base, float* __restrict__ dst_base,
+                                                                       PreArgs a, FastDiv by_wq) {
+    const int wq = a.dst_w >> 2, groups = wq * a.dst_h, plane = a.dst_w * a.dst_h;   // host-checked: 12 * plane < 2^31
+    const uint8_t* src = src_base + (long long)blockIdx.y * a.src_frame_stride;
+    const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_base + (long long)blockIdx.y * a.dst_frame_stride, (uint32_t)(12 * plane));
+    f32x4 o[K][3];
+    int g0[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        g0[k] = (blockIdx.x * K + k) * kQuadBlock + threadIdx.x;
+        const int g = min(g0[k], groups - 1);
+        const int oy = (int)fast_quot((uint32_t)g, by_wq), ox0 = 4 * (g - oy * wq);
+        const float ny = (float)oy - a.pad_y;
+        const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // plan_pixel (P/preprocess.rs:437-448)
+            const float nx = (float)(ox0 + j) - a.pad_x;
+            const float sx = a.fast_div ? quot3(nx, a.scale_x, a.rc_x) : nx / a.scale_x;
+            float px[3];
+            if (!(sx < 0.0f || sy < 0.0f || sx >= (float)a.src_w || sy >= (float)a.src_h)) {
+                if constexpr (SAMPLER == KH_SAMPLE_NEAREST) nearest_tap<FMT, WIDE>(src, sx, sy, a, px);
+                else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) bilinear_quad<FMT, WIDE>(src, sx, sy, a, px);
+                else tap_rgb<FMT, WIDE>(src, (int)sx, (int)sy, a, px);   // kSampleBilinearOnGrid: sx, sy whole and in range (host-checked)
+            } else {
+                px[0] = a.pad_value; px[1] = a.pad_value; px[2] = a.pad_value;
+            }
+            o[k][0][j] = (div255_any(px[0]) - a.m0) * a.is0;
+            o[k][1][j] = (div255_any(px[1]) - a.m1) * a.is1;
+            o[k][2][j] = (div255_any(px[2]) - a.m2) * a.is2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (g0[k] >= groups) break;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)  // plane offset in the vector offset, never in an SGPR soffset (kh_common.h)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[k][c]), rdst, 16 * g0[k] + c * (4 * plane), 0, kAuxStream);
+    }
+}
+
+// ---- north-star fast path ------------------------------------------------------------------
 
 template <bool NT>
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
@@ -457,21 +508,13 @@ __device__ __forceinline__ float div255_u8(float x) {
 // 640 -12 %, 1024 -18 %).  Ceilings on the same boxes: these three plane stores with no loads or decode 4.04 ms, a flat fill of the
 // same bytes 3.55-3.63 ms.
 constexpr int kIdBlock = 512;  // 8 KiB contiguous per plane per block; 256 / 384 / 640 / 768 / 1024 are 2-11 % slower (r02e, r02f)
-// XCDF (dev knob KH_NV12_XCD_FRAMES=1): a 1-D launch in which XCD k walks frames k, k + 8, ... chunk by chunk.  Measured in
-// round 2: 4.84 ms against 4.65 ms for the default order (profiles/r02a_ab.log) — kept only as the A/B it was, off by default.
-struct XcdFrames { FastDiv by_bpf; unsigned bpf, nframes; };
-template <bool XCDF>
+// (An XCD-per-frame block order — XCD k walks frames k, k + 8, ... — measured 4.84 ms against 4.65 ms for this order in round 2,
+// profiles/r02a_ab.log, and is not in the library.)
 __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
-    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a, XcdFrames xf) {
+    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a) {
     const int wq = a.src_w >> 2;     // 4-pixel groups per row
     const int groups = wq * a.src_h;
-    unsigned chunk = blockIdx.x, frame = blockIdx.y;
-    if constexpr (XCDF) {
-        const unsigned xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds, fgrp = fast_quot(slot, xf.by_bpf);
-        chunk = slot - fgrp * xf.bpf;
-        frame = fgrp * kXcds + xcd;
-        if (frame >= xf.nframes) return;
-    }
+    const unsigned chunk = blockIdx.x, frame = blockIdx.y;
     const int g = chunk * kIdBlock + threadIdx.x;
     if (g >= groups) return;
     const int plane = a.src_w * a.src_h;           // host-checked: 12 * plane < 2^31
@@ -552,7 +595,7 @@ int32_t lanczos_tables(PreArgs& a, hipStream_t stream, TableLease& lease) {
 // Does quot3 reproduce IEEE division for every (o - pad) / scale the launch will evaluate?  dst_w +
 // dst_h host evaluations (microseconds), memoised on the last geometry.
 bool plan_division_is_exact(const PreArgs& a) {
-    if (const char* e = getenv("KH_PRE_IEEE_DIV"); e && e[0] == '1') return false;  // dev/test knob: always divide
+    if (dev_opt(kOptPreIeeeDiv) == 1) return false;  // test option: always divide
     struct Key { float sx, sy, px, py; int w, h; bool ok; };
     static thread_local Key last = {0, 0, 0, 0, 0, 0, false};
     if (last.w == a.dst_w && last.h == a.dst_h && last.sx == a.scale_x && last.sy == a.scale_y && last.px == a.pad_x &&
@@ -577,9 +620,9 @@ bool plan_division_is_exact(const PreArgs& a) {
 // t00 + (t10 - t00) * 0 ... returns the first tap bit for bit: the kernel decodes ONE tap per pixel instead of four — the generic
 // bilinear path is bound by its vector ALUs (four exact BT.601 decodes + blend: ~103 instructions per pixel, r02t), not by memory.
 // Decided by evaluating the kernel's own coordinate expression for every column and row (dst_w + dst_h host evaluations,
-// memoised on the last geometry) — not by looking at the scale.  KH_PRE_GRID=0 (dev / test knob) keeps the four-tap kernel.
+// memoised on the last geometry) — not by looking at the scale.  kh_debug_set_option("pre_grid", 0) (test option) keeps the four-tap kernel.
 bool bilinear_taps_on_grid(const PreArgs& a) {
-    if (const char* e = getenv("KH_PRE_GRID"); e && e[0] == '0') return false;
+    if (dev_opt(kOptPreGrid) == 0) return false;
     struct Key { float sx, sy, px, py; int w, h, sw, sh; bool ok; };
     static thread_local Key last = {0, 0, 0, 0, 0, 0, 0, 0, false};
     if (last.w == a.dst_w && last.h == a.dst_h && last.sw == a.src_w && last.sh == a.src_h && last.sx == a.scale_x && last.sy == a.scale_y &&
@@ -657,6 +700,23 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
     else if (FMT == KH_FMT_YUYV) wide = base % 4 == 0 && a.src_frame_stride % 4 == 0 && a.src_pitch % 4 == 0;
     else if (FMT == KH_FMT_RGB || FMT == KH_FMT_BGR)
         wide = a.src_bpp == 4 && base % 4 == 0 && a.src_frame_stride % 4 == 0 && a.src_pitch % 4 == 0;
+    // flattened quads with 16-byte streaming stores (preprocess_generic_quads) for f32 outputs whose rows are whole quads; Lanczos,
+    // f16 and ragged widths keep the per-pixel kernel.  Test option pre_quads: 0 = per-pixel kernel, 1 / 2 = quads per lane.
+    if constexpr (SAMPLER != KH_SAMPLE_LANCZOS) {
+        const int opt = dev_opt(kOptPreQuads);
+        const bool quads_ok = out_dtype == KH_OUT_F32 && a.dst_w % 4 == 0 && (int64_t)a.dst_w * a.dst_h * 12 <= kI32Max &&
+                              reinterpret_cast<uintptr_t>(dst) % 16 == 0 && a.dst_frame_stride % 4 == 0;
+        if (quads_ok && opt != 0) {
+            const int wq = a.dst_w / 4, groups = wq * a.dst_h, kq = opt == 1 ? 1 : (opt == 2 ? 2 : kQuadsPerLane);
+            const dim3 qgrid(cdiv(groups, kQuadBlock * kq), grid.z);
+            const FastDiv by_wq = fast_div((uint32_t)wq);
+#define KH_GENQ(W, KQ) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, W, KQ>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, a, by_wq)
+            if (kq == 1) { if (wide) KH_GENQ(true, 1); else KH_GENQ(false, 1); }
+            else { if (wide) KH_GENQ(true, 2); else KH_GENQ(false, 2); }
+#undef KH_GENQ
+            return;
+        }
+    }
     const dim3 blk(64, 4);
 #define KH_GEN(T, W) hipLaunchKernelGGL((preprocess_generic<FMT, SAMPLER, T, W>), grid, blk, 0, s, src, (T*)dst, a)
     if (out_dtype == KH_OUT_F32) { if (wide) KH_GEN(float, true); else KH_GEN(float, false); }
@@ -723,15 +783,7 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
     if (identity_fast_path(p, src, dst)) {
         const int groups = (p->src_w / 4) * p->src_h;
         const unsigned bpf = cdiv(groups, kIdBlock);
-        static const bool xcd_frames = [] { const char* e = getenv("KH_NV12_XCD_FRAMES"); return e && e[0] == '1'; }();
-        const uint64_t remapped = (uint64_t)bpf * kXcds * cdiv(p->nframes, kXcds);
-        if (xcd_frames && remapped < 0x7ff00000ull) {
-            const XcdFrames xf{fast_div(bpf), bpf, (unsigned)p->nframes};
-            hipLaunchKernelGGL((preprocess_nv12_identity<true>), dim3((unsigned)remapped), dim3(kIdBlock), 0, s, src, (float*)dst, a, xf);
-        } else {
-            hipLaunchKernelGGL((preprocess_nv12_identity<false>), dim3(bpf, (unsigned)p->nframes), dim3(kIdBlock), 0, s, src, (float*)dst, a,
-                               XcdFrames{});
-        }
+        hipLaunchKernelGGL(preprocess_nv12_identity, dim3(bpf, (unsigned)p->nframes), dim3(kIdBlock), 0, s, src, (float*)dst, a);
         return check_launch("preprocess_nv12_identity");
     }
 

@@ -1291,8 +1291,8 @@ int32_t check_pyr(const char* what, const T* src, T* dst, int sw, int sh, int ch
         return check_launch(#NAME);                                                                               \
     }
 
-KH_PYR_ENTRY(kh_pyrdown_u8_direct, uint8_t, pyrdown_u8_kernel, (sw + 1) / 2, (sh + 1) / 2)  // per-pixel kernel: KH_PYR_DIRECT=1 only
-KH_PYR_ENTRY(kh_pyrup_f32_direct, float, pyrup_f32_kernel, sw * 2, sh * 2)  // per destination pixel: KH_PYR_DIRECT=1 only
+KH_PYR_ENTRY(kh_pyrdown_u8_direct, uint8_t, pyrdown_u8_kernel, (sw + 1) / 2, (sh + 1) / 2)  // per-pixel kernel: test option pyr_direct = 1 only
+KH_PYR_ENTRY(kh_pyrup_f32_direct, float, pyrup_f32_kernel, sw * 2, sh * 2)  // per destination pixel: test option pyr_direct = 1 only
 KH_PYR_ENTRY(kh_pyrup_u8_direct, uint8_t, pyrup_u8_kernel, sw * 2, sh * 2)
 
 }  // namespace
@@ -1302,13 +1302,13 @@ extern "C" {
 KH_PYR_ENTRY(kh_pyrdown_f32, float, pyrdown_f32_kernel, (sw + 1) / 2, (sh + 1) / 2)
 int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch,
                       int64_t ss, int64_t ds) {
-    static const bool direct = [] { const char* e = getenv("KH_PYR_DIRECT"); return e && e[0] == '1'; }();
+    const bool direct = dev_opt(kOptPyrDirect) == 1;
     // (rows of 2^24 bytes or more: the tile kernel forms its 32-bit offsets with 24-bit multiplies)
     if (direct || (int64_t)sw * channels >= (1 << 24)) return kh_pyrdown_u8_direct(stream, src, dst, sw, sh, channels, batch, ss, ds);
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     if (int32_t rc = check_pyr("kh_pyrdown_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
-    static const bool no_roll = [] { const char* e = getenv("KH_PYR_ROLL"); return e && e[0] == '0'; }();   // dev / test knob: the tile kernel
+    const bool no_roll = dev_opt(kOptPyrRoll) == 0;   // dev / test knob: the tile kernel
     if (channels == 3 && sw >= 8 && !no_roll) {   // RGB8: the rolling planar kernel
         PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
         const unsigned tiles_x = cdiv(dw, kPdRollTileDst);
@@ -1317,7 +1317,6 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
         const long long min_strips = cdiv(dh, 360), max_strips = cdiv(dh, 16);
         strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
         r.th = (int)cdiv(dh, strips);
-        if (const char* e = getenv("KH_PYR_STRIP"); e && *e) r.th = std::max(1, atoi(e));   // dev knob: destination rows per strip
         r.tiles = xcd_tiles(tiles_x, cdiv(dh, r.th), (unsigned)batch, kXcdEighth);
         KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrdown_u8: batch x tiles exceeds one launch");
         hipLaunchKernelGGL(pyrdown_u8_rgb_roll_kernel, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
@@ -1337,7 +1336,7 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
 #define KH_PYRUP_ENTRY(NAME, T, KERNEL, PX)                                                                                         \
     int32_t NAME(kh_stream_t stream, const T* src, T* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch, int64_t ss,     \
                  int64_t ds) {                                                                                                     \
-        static const bool direct = [] { const char* e = getenv("KH_PYR_DIRECT"); return e && e[0] == '1'; }();                     \
+        const bool direct = dev_opt(kOptPyrDirect) == 1;                     \
         if (direct || sw < 2) return NAME##_direct(stream, src, dst, sw, sh, channels, batch, ss, ds); /* 1-pixel rows: own rule */ \
         const int dw = sw * 2, dh = sh * 2;                                                                                        \
         if (int32_t rc = check_pyr(#NAME, src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;                           \
@@ -1360,8 +1359,8 @@ static int32_t kh_pyrup_u8_pairs_direct(kh_stream_t stream, const uint8_t* src, 
 static KH_PYRUP_ENTRY(kh_pyrup_u8_pairs, uint8_t, pyrup_u8_pair_kernel, 2)   // every channel count; RGB8 takes the rolling kernel below
 int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch, int64_t ss,
                     int64_t ds) {
-    static const bool direct = [] { const char* e = getenv("KH_PYR_DIRECT"); return e && e[0] == '1'; }();
-    static const bool no_roll = [] { const char* e = getenv("KH_PYR_ROLL"); return e && e[0] == '0'; }();
+    const bool direct = dev_opt(kOptPyrDirect) == 1;
+    const bool no_roll = dev_opt(kOptPyrRoll) == 0;
     if (direct || no_roll || channels != 3 || sw < 4 || (int64_t)sw * 6 >= (1 << 24)) return kh_pyrup_u8_pairs(stream, src, dst, sw, sh, channels, batch, ss, ds);
     const int dw = sw * 2, dh = sh * 2;
     if (int32_t rc = check_pyr("kh_pyrup_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
@@ -1423,11 +1422,11 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     for (int c = 0; c < 4; ++c) a.cval[c] = (cval && c < channels) ? cval[c] : 0;
     hipStream_t st = as_hip(stream);
     // tiled kernel (LDS-staged window; separable for all-ones masks) unless the mask has no active tap (the per-pixel kernel's
-    // "no tap" rule), the window does not fit 150 KiB of LDS, or KH_MORPH_DIRECT=1 (dev / test knob)
+    // "no tap" rule), the window does not fit 150 KiB of LDS, or test option morph_direct = 1
     bool any = false, box = true;
     for (int ky = 0; ky < kh_; ++ky) { any = any || a.rows[ky]; box = box && a.rows[ky] == (kw == 32 ? 0xffffffffu : (1u << kw) - 1u); }
-    static const bool direct = [] { const char* e = getenv("KH_MORPH_DIRECT"); return e && e[0] == '1'; }();
-    static const bool no_roll = [] { const char* e = getenv("KH_MORPH_ROLL"); return e && e[0] == '0'; }();   // dev / test knob: the tile kernel
+    const bool direct = dev_opt(kOptMorphDirect) == 1;
+    const bool no_roll = dev_opt(kOptMorphRoll) == 0;   // dev / test knob: the tile kernel
     if (any && box && !direct && !no_roll && channels == 3 && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && w >= 4 &&
         (int64_t)w * 3 < (1 << 24)) {   // RGB8, square box of 3 / 5 / 7: the rolling planar kernel
         MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], a.cval[1], a.cval[2]}, XcdTiles{}};

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBx* kBy) void bilinear_u8_kernel(Rz a) {
 }
 
 // ---- separable Q14 ------------------------------------------------------------------------------------
-struct SepTab { const int32_t* ofs; const int16_t* w; int k, kp, span64, span16; };  // k taps; rows of kp = roundup(k, 4) weights (zero padded); span64: see get_tab
+struct SepTab { const int32_t* ofs; const int16_t* w; int k, kp, span64; };  // k taps; rows of kp = roundup(k, 4) weights (zero padded); span64: see get_tab
 
 // horizontal_row_scalar (kernels.rs:403-425): (x, source row) -> i16
 template <int C>
@@ -278,125 +278,6 @@ __global__ __launch_bounds__(256) void sep_h_u8_tile_kernel(Rz a, int16_t* __res
         int16_t* o = hbuf + (((long long)bz_ * a.sh + sy0 + r) * a.dw + x) * C;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) o[ch] = (int16_t)min(max((acc[i][ch] + 8192) >> 14, -32768), 32767);
-    }
-}
-
-// horizontal pass, lanes = source rows (round 2, second version).  In the kernel above a wave's lanes are 64 destination columns:
-// their LDS reads sit `scale` pixels (25.7 bytes for 1080p -> 224) apart, and r02zb counts 75 % of its LDS cycles as bank
-// conflicts.  Here a block owns kSepRowsTX destination columns x 64 source rows and a LANE IS A ROW: every lane of a wave reads
-// the same column offset of its own LDS row (odd dword pitch: no conflicts), a wave takes every fourth column, and — the column
-// being wave-uniform — its table offset and weights are one broadcast load per wave.  The i16 results of the tile go through LDS
-// once more so that each source row's kSepRowsTX * C values leave as one contiguous run.  Same products and i32 sums as above.
-// Result (r02zm, same box): 2.11 ms against 2.12 ms for the kernel above on 256 1080p -> 224 frames — removing the conflicts
-// changes nothing, so they were not what bounds the pass; the columns kernel stays the default, this one is KH_RESIZE_U8_ROWS=1.
-constexpr int kSepRowsTX = 16, kSepRowsTY = 64;
-
-template <int C>
-__global__ __launch_bounds__(256) void sep_h_u8_rows_kernel(Rz a, int16_t* __restrict__ hbuf, SepTab tx, int pitch) {
-    uint8_t* S = kh_sep_lds;                                                 // [kSepRowsTY][pitch] staged source bytes
-    int16_t* R = reinterpret_cast<int16_t*>(kh_sep_lds + kSepRowsTY * pitch);  // [kSepRowsTY][kSepRowsTX * C + 2] results (odd dword pitch for C = 1, 3)
-    constexpr int kRP = kSepRowsTX * C + 2;
-    unsigned bx_, by_, bz_;
-    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int X0 = bx_ * kSepRowsTX, sy0 = by_ * kSepRowsTY;
-    const int ncols = min(kSepRowsTX, a.dw - X0), nrows = min(kSepRowsTY, a.sh - sy0);
-    const int p0 = tx.ofs[X0], span = tx.ofs[X0 + ncols - 1] + tx.kp - p0;   // block-uniform
-    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
-    const long long img_bytes = (long long)a.sw * a.sh * C;
-    auto row_mis = [&](int r, bool& dwords) -> int {  // as in sep_h_u8_tile_kernel
-        const long long g = ((long long)(sy0 + r) * a.sw + p0) * C;
-        const int mis = (int)((uintptr_t)(src + g) & 3);
-        dwords = p0 >= 0 && p0 + span <= a.sw && g - mis >= 0 && g - mis + (((long long)mis + span * C + 3) & ~3ll) <= img_bytes;
-        return dwords ? mis : 0;
-    };
-    // 1. stage: a wave takes every fourth row, four rows x two 64-dword segments of loads in flight
-    for (int r0 = wave; r0 < nrows; r0 += 16) {
-        const uint32_t* q[4];
-        int ndw[4], mis[4];
-        bool fast[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = min(r0 + 4 * i, nrows - 1);
-            mis[i] = row_mis(r, fast[i]);
-            q[i] = reinterpret_cast<const uint32_t*>(src + ((long long)(sy0 + r) * a.sw + p0) * C - mis[i]);
-            ndw[i] = (mis[i] + span * C + 3) >> 2;
-        }
-        const bool all_fast = fast[0] && fast[1] && fast[2] && fast[3];   // wave-uniform
-        if (all_fast) {
-            for (int d0 = lane; d0 < ndw[0] + 1; d0 += 128) {             // ndw differs by at most one dword between rows
-                uint32_t v[4][2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) v[i][j] = q[i][min(d0 + 64 * j, ndw[i] - 1)];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (r0 + 4 * i < nrows && d0 + 64 * j < ndw[i])
-                            reinterpret_cast<uint32_t*>(S + (r0 + 4 * i) * pitch)[d0 + 64 * j] = v[i][j];
-            }
-        } else {
-            for (int i = 0; i < 4 && r0 + 4 * i < nrows; ++i) {
-                const int r = r0 + 4 * i;
-                uint8_t* row = S + r * pitch;
-                if (fast[i]) {
-                    for (int d = lane; d < ndw[i]; d += 64) reinterpret_cast<uint32_t*>(row)[d] = q[i][d];
-                } else {
-                    const uint8_t* grow = src + (long long)(sy0 + r) * a.sw * C;
-                    for (int j = lane; j < span * C; j += 64) {
-                        const int px = j / C, c = j - px * C;
-                        row[j] = grow[min(max(p0 + px, 0), a.sw - 1) * C + c];  // build_xsrc_lut, common.rs:127-137
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // 2. lane = row; the wave's columns one after the other
-    {
-        const int r = min(lane, nrows - 1);
-        bool dwords;
-        const int rowo = r * pitch + row_mis(r, dwords);
-        for (int xc = __builtin_amdgcn_readfirstlane(wave); xc < ncols; xc += 4) {  // tell the compiler the column is wave-uniform:
-            const int x = X0 + xc;                                                   // its offset and weights become scalar loads
-            const int rel = (tx.ofs[x] - p0) * C;
-            const uint32_t* wrow = reinterpret_cast<const uint32_t*>(tx.w + (long long)x * tx.kp);
-            int32_t acc[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = 0;
-            for (int t4 = 0; t4 < tx.kp; t4 += 4) {
-                const uint32_t w01 = wrow[t4 >> 1], w23 = wrow[(t4 >> 1) + 1];
-                const int o = rowo + rel + t4 * C;
-                const uint32_t* p = reinterpret_cast<const uint32_t*>(kh_sep_lds + (o & ~3));
-                const uint32_t sh = (uint32_t)(o & 3);
-                uint32_t e[C];
-#pragma unroll
-                for (int j = 0; j < C; ++j) e[j] = __builtin_amdgcn_alignbyte(p[j + 1], p[j], sh);
-                if constexpr (C == 1) {
-                    acc[0] = dot2_i16(pixel_pair<1, 2>(e), w23, dot2_i16(pixel_pair<1, 0>(e), w01, acc[0]));
-                } else if constexpr (C == 3) {
-                    acc[0] = dot2_i16(pixel_pair<3, 6>(e), w23, dot2_i16(pixel_pair<3, 0>(e), w01, acc[0]));
-                    acc[1] = dot2_i16(pixel_pair<3, 7>(e), w23, dot2_i16(pixel_pair<3, 1>(e), w01, acc[1]));
-                    acc[2] = dot2_i16(pixel_pair<3, 8>(e), w23, dot2_i16(pixel_pair<3, 2>(e), w01, acc[2]));
-                } else {
-                    acc[0] = dot2_i16(pixel_pair<4, 8>(e), w23, dot2_i16(pixel_pair<4, 0>(e), w01, acc[0]));
-                    acc[1] = dot2_i16(pixel_pair<4, 9>(e), w23, dot2_i16(pixel_pair<4, 1>(e), w01, acc[1]));
-                    acc[2] = dot2_i16(pixel_pair<4, 10>(e), w23, dot2_i16(pixel_pair<4, 2>(e), w01, acc[2]));
-                    acc[3] = dot2_i16(pixel_pair<4, 11>(e), w23, dot2_i16(pixel_pair<4, 3>(e), w01, acc[3]));
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) R[lane * kRP + xc * C + c] = (int16_t)min(max((acc[c] + 8192) >> 14, -32768), 32767);
-        }
-    }
-    __syncthreads();
-    // 3. each row's ncols * C results are contiguous in the intermediate: i16 by i16 (the run starts on any 2-byte boundary)
-    const int run = ncols * C;
-    for (int i = tid; i < nrows * run; i += 256) {
-        const int r = i / run, j = i - r * run;
-        hbuf[(((long long)bz_ * a.sh + sy0 + r) * a.dw + X0) * C + j] = R[r * kRP + j];
     }
 }
 
@@ -628,9 +509,7 @@ int32_t get_tab(int src_size, int dst_size, int filt, bool aa, hipStream_t strea
         for (int i = 0; i < dst_size; ++i) std::copy(wk.begin() + (size_t)i * k, wk.begin() + (size_t)(i + 1) * k, w.begin() + (size_t)i * kp);
         int span64 = 0;                      // widest source span (pixels) one tile of kSepTX destination columns taps
         for (int x0 = 0; x0 < dst_size; x0 += kSepTX) span64 = std::max(span64, ofs[std::min(x0 + kSepTX, dst_size) - 1] + kp - ofs[x0]);
-        int span16 = 0;                      // the same for tiles of kSepRowsTX columns (sep_h_u8_rows_kernel)
-        for (int x0 = 0; x0 < dst_size; x0 += kSepRowsTX) span16 = std::max(span16, ofs[std::min(x0 + kSepRowsTX, dst_size) - 1] + kp - ofs[x0]);
-        t.meta[0] = k; t.meta[1] = dst_size; t.meta[2] = kp; t.meta[3] = span64; t.meta[4] = span16;
+        t.meta[0] = k; t.meta[1] = dst_size; t.meta[2] = kp; t.meta[3] = span64;
         ofs.resize((ofs.size() + 3) & ~(size_t)3, 0);  // the weight block starts 16-byte aligned
         const size_t ofs_bytes = sizeof(int32_t) * ofs.size(), w_bytes = sizeof(int16_t) * w.size();
         t.bytes = ofs_bytes + w_bytes;
@@ -643,7 +522,7 @@ int32_t get_tab(int src_size, int dst_size, int filt, bool aa, hipStream_t strea
     if (rc != KH_OK) return rc;
     out.ofs = (const int32_t*)lease->dev;
     out.w = (const int16_t*)((const char*)lease->dev + sizeof(int32_t) * (((size_t)lease->meta[1] + 3) & ~(size_t)3));
-    out.k = lease->meta[0]; out.kp = lease->meta[2]; out.span64 = lease->meta[3]; out.span16 = lease->meta[4];
+    out.k = lease->meta[0]; out.kp = lease->meta[2]; out.span64 = lease->meta[3];
     return KH_OK;
 }
 
@@ -672,35 +551,10 @@ Rz make_rz(const void* src, void* dst, int sw, int sh, int dw, int dh, int64_t s
     return a;
 }
 
-// horizontal pass: the LDS-staged kernel when its tile fits 64 KiB, else (or with KH_RESIZE_U8_GATHER=1, dev / test knob) the gather
+// horizontal pass: the LDS-staged kernel when its tile fits 64 KiB, else (or with test option resize_u8_gather = 1) the gather
 int32_t launch_sep_h(hipStream_t st, const void* src, int sw, int sh, int dw, int dh, int channels, int batch, int64_t ss,
                      int16_t* hbuf, const SepTab& tx, const char* what) {
-    static const bool gather = [] { const char* e = getenv("KH_RESIZE_U8_GATHER"); return e && e[0] == '1'; }();
-    const char* rows_env = getenv("KH_RESIZE_U8_ROWS");  // dev / test knob, read per call (the tests flip it)
-    const bool by_columns = !(rows_env && rows_env[0] == '1');
-    {   // lanes = rows (KH_RESIZE_U8_ROWS=1, when its tile fits): odd dword pitch, results tile behind the staged rows.  Measured
-        // equal to the lanes = columns kernel (2.11 vs 2.12 ms, r02zm), so the bank conflicts it removes were not the limiter
-        int rpitch = (((tx.span16 * channels + 3) + 3) & ~3) + 8;
-        if (((rpitch >> 2) & 1) == 0) rpitch += 4;
-        const size_t rlds = (size_t)rpitch * kSepRowsTY + sizeof(int16_t) * kSepRowsTY * (kSepRowsTX * channels + 2);
-        if (!gather && !by_columns && rlds <= 64 * 1024) {
-            Rz ah = make_rz(src, nullptr, sw, sh, dw, dh, ss, 0, batch, dw, sh);
-            ah.tiles = xcd_tiles(cdiv(dw, kSepRowsTX), cdiv(sh, kSepRowsTY), (unsigned)batch, cdiv(dw, kSepRowsTX) * 2);
-            if (ah.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-            const dim3 grid = xcd_grid(ah.tiles), blk(256);
-            if (rlds > 48 * 1024) {
-                if (channels == 1) KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-                else if (channels == 3) KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_rows_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-                else KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_rows_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            }
-            switch (channels) {
-                case 1: hipLaunchKernelGGL(sep_h_u8_rows_kernel<1>, grid, blk, rlds, st, ah, hbuf, tx, rpitch); break;
-                case 3: hipLaunchKernelGGL(sep_h_u8_rows_kernel<3>, grid, blk, rlds, st, ah, hbuf, tx, rpitch); break;
-                default: hipLaunchKernelGGL(sep_h_u8_rows_kernel<4>, grid, blk, rlds, st, ah, hbuf, tx, rpitch); break;
-            }
-            return KH_OK;
-        }
-    }
+    const bool gather = dev_opt(kOptResizeU8Gather) == 1;  // test option: the gather kernel (the fallback for spans beyond 64 KiB of LDS)
     const int pitch = (((tx.span64 * channels + 3) + 3) & ~3) + 8;
     const size_t lds = (size_t)pitch * kSepRows;
     if (!gather && lds <= 64 * 1024) {

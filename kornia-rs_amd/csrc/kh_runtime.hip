@@ -20,6 +20,15 @@
 
 namespace kh {
 
+// development / test options (kh_common.h::DevOpt); -1 = unset
+struct DevOpts {
+    std::atomic<int> v[kOptCount];
+    DevOpts() { for (auto& x : v) x.store(-1, std::memory_order_relaxed); }
+};
+static DevOpts g_dev_opts_storage;
+std::atomic<int>* const g_dev_opts = g_dev_opts_storage.v;
+int dev_opt(DevOpt o) { return g_dev_opts[o].load(std::memory_order_relaxed); }
+
 static thread_local char g_err[512] = {0};
 
 void set_error(const char* fmt, ...) {
@@ -108,6 +117,21 @@ void kh_dlpack_noop_deleter(void* managed_tensor) { (void)managed_tensor; }
 
 // test hook: the launch-constant division used to decode tile ids (kh_common.h::FastDiv), on the host
 uint32_t kh_debug_fast_quot(uint32_t n, uint32_t d) { return kh::fast_quot(n, kh::fast_div(d)); }
+
+// test hook: force one of the alternate code paths a launcher can take (kh_common.h::DevOpt).  `value` -1 restores the production
+// choice.  Unknown names are an error, so a stale test cannot silently test nothing.
+int32_t kh_debug_set_option(const char* name, int32_t value) {
+    static const char* const names[kh::kOptCount] = {
+        "pre_ieee_div", "pre_grid", "pre_quads", "filter_force_tile", "filter_four_columns", "grad_scalar", "hfilter_direct",
+        "resize_u8_gather", "pyr_direct", "pyr_roll", "morph_direct", "morph_roll", "u8_blur_rgb", "u8_blur_swar", "warp_u8_direct"};
+    if (name)
+        for (int i = 0; i < kh::kOptCount; ++i)
+            if (strcmp(name, names[i]) == 0) {
+                kh::g_dev_opts[i].store(value, std::memory_order_relaxed);
+                return KH_OK;
+            }
+    return kh::fail(KH_ERR_INVALID_ARG, "kh_debug_set_option: unknown option '%s'", name ? name : "(null)");
+}
 
 // How many HIP runtime images (libamdhip64*) are mapped into this process, and which.  More than one is unsafe: each
 // brings its own HSA runtime, and copies / stream waits issued through one do not order against the other (the

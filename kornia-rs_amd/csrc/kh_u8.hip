@@ -397,7 +397,7 @@ void launch_blur_kc(hipStream_t st, bool binomial, const U8FilterArgs& a, const 
     }
     unsigned sx = 0, sy = 0;
     for (int i = 0; i < 16; ++i) { sx += kx.k[i]; sy += ky.k[i]; }
-    static const bool no_swar = [] { const char* e = getenv("KH_U8_BLUR_SWAR"); return e && e[0] == '0'; }();  // dev knob
+    const bool no_swar = dev_opt(kOptU8BlurSwar) == 0;  // test option: the plain-integer kernel (the fallback for tap sums above 256)
     if (sx <= 256 && sy <= 256 && !no_swar) hipLaunchKernelGGL((blur_u8_roll_kernel<K, C, 2>), grid, dim3(kBlock), 0, st, a, kx, ky);
     else hipLaunchKernelGGL((blur_u8_roll_kernel<K, C, 0>), grid, dim3(kBlock), 0, st, a, kx, ky);
 }
@@ -429,7 +429,7 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         a.src_stride = ss; a.dst_stride = ds;
         unsigned sxq = 0, syq = 0;
         for (int i = 0; i < 16; ++i) { sxq += px.k[i]; syq += py.k[i]; }
-        static const bool rgb_off = [] { const char* e = getenv("KH_U8_BLUR_RGB"); return e && e[0] == '0'; }();   // dev / test knob: the interleaved kernel
+        const bool rgb_off = dev_opt(kOptU8BlurRgb) == 0;   // test option: the interleaved kernel (what the other channel counts take)
         const bool rgb = C == 3 && K <= 9 && !binomial && sxq <= 256 && syq <= 256 && cols >= 4 && !rgb_off;
         const unsigned tiles_x = rgb ? cdiv(cols, kRgbTilePx) : cdiv(rowlen, kU8Tile);
         const long long cols_blocks = (long long)tiles_x * batch;
@@ -1136,10 +1136,10 @@ ImgU8 make_img_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int 
     } while (0)
 
 
-// The staged gather serves images up to 65535 x 65535 (16-bit box fields); KH_WARP_U8_DIRECT=1 (dev / test knob, read once) keeps
+// The staged gather serves images up to 65535 x 65535 (16-bit box fields); kh_debug_set_option("warp_u8_direct", 1) (test option) keeps
 // the per-pixel kernels for all three operators.
 bool use_staged_gather(int sw, int sh) {
-    static const bool direct = [] { const char* e = getenv("KH_WARP_U8_DIRECT"); return e && e[0] == '1'; }();
+    const bool direct = dev_opt(kOptWarpU8Direct) == 1;
     return !direct && sw <= 65535 && sh <= 65535 && sw >= 4;   // 16-bit box fields; a staged quad is four pixels of one row
 }
 template <int OP>
@@ -1147,10 +1147,9 @@ int32_t launch_staged_gather(hipStream_t st, const uint8_t* src, uint8_t* dst, i
                              int64_t ss, int64_t ds, const GatherOp& op_, const char* what) {
     // images per block: 16 for batches of 128 and more — the geometry phase (perspective divisions, the remap's map reads) is paid once
     // per block: perspective 3.50-3.60 -> 3.27 ms, remap 3.53-3.64 -> 3.11-3.13 ms, affine unchanged; 32 and 64 are slower (r03ze) —
-    // 8 otherwise.  KH_GATHER_NB: dev knob for A/Bs.
-    static const int env_nb = [] { const char* e = getenv("KH_GATHER_NB"); return e && *e ? atoi(e) : 0; }();
+    // 8 otherwise.
     GatherOp op = op_;
-    op.nb = env_nb > 0 ? env_nb : (batch >= 128 ? 2 * kStageNB : kStageNB);
+    op.nb = batch >= 128 ? 2 * kStageNB : kStageNB;
     const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, kStageH), groups = cdiv(batch, op.nb);
     // 64 x 32 tiles, dealt to the XCDs in runs of 8 tile rows like the other gathers
     const ImgU8 im{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(tiles_x, tiles_y, groups, tiles_x * 8)};

@@ -83,6 +83,7 @@ _P = C.POINTER
 SIGNATURES = {
     "kh_last_error": (_sz, [C.c_char_p, _sz]),
     "kh_debug_fast_quot": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+    "kh_debug_set_option": (_i32, [C.c_char_p, _i32]),
     "kh_version": (C.c_char_p, []),
     "kh_hip_runtime_images": (_i32, [C.c_char_p, C.c_size_t]),
     "kh_dlpack_noop_deleter": (None, [_vp]),

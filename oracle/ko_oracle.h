@@ -174,6 +174,10 @@ int ko_bilateral_tables(int d, double sigma_color, double sigma_space, int capac
                         float* space_weight, float* color_weight, int* simd_order);
 int ko_bilateral_filter_u8(const uint8_t* src, uint8_t* dst, int cols, int rows, int d, double sigma_color, double sigma_space);
 
+/* normalize_mean_std (P/normalize.rs:56-87): (src - mean[c]) / std[c], IEEE division; rows in parallel like par_iter_rows */
+void ko_normalize_mean_std_f32(const float* src, float* dst, int width, int height, int channels, const float* mean,
+                               const float* std);
+
 #ifdef __cplusplus
 }
 #endif

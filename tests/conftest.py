@@ -44,6 +44,23 @@ def _ensure_built():
 _ensure_built()
 
 
+@pytest.fixture
+def dev_option():
+    """Force one of the library's alternate code paths for the duration of a test: `dev_option("pre_grid", 0)`
+    (kh_debug_set_option, include/kornia_hip.h).  Everything set is restored to the production choice afterwards.  The options are
+    process-wide; pytest-xdist workers are separate processes."""
+    from kornia_rs import _ffi
+    touched = []
+
+    def set_(name, value):
+        _ffi.check(_ffi.lib.kh_debug_set_option(name.encode(), int(value)))
+        touched.append(name)
+
+    yield set_
+    for name in touched:
+        _ffi.lib.kh_debug_set_option(name.encode(), -1)
+
+
 @pytest.fixture(scope="session")
 def gpu_stream():
     """A non-default HIP stream on device 0; GPU tests fail (not skip) if the device or the

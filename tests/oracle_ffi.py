@@ -715,3 +715,17 @@ def bilateral_filter(src, d, sigma_color, sigma_space):
     out = np.empty_like(src)
     assert ko.ko_bilateral_filter_u8(src.reshape(-1), out.reshape(-1), w, h, d, sigma_color, sigma_space) == 0
     return out
+
+
+# ---- pointwise (ko_pointwise.c) --------------------------------------------------------------------------
+ko.ko_normalize_mean_std_f32.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p]
+
+
+def normalize_mean_std(src, mean, std):
+    """normalize_mean_std (P/normalize.rs:56-87) on an HWC f32 image."""
+    src = _img(src)
+    h, w, c = src.shape
+    out = np.empty_like(src)
+    ko.ko_normalize_mean_std_f32(src.reshape(-1), out.reshape(-1), w, h, c, np.ascontiguousarray(mean, np.float32),
+                                 np.ascontiguousarray(std, np.float32))
+    return out

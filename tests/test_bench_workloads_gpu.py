@@ -45,14 +45,20 @@ def _frame(wl, k, n, shape):
     return wl.base[31 * k: 31 * k + n].reshape(shape)
 
 
-@pytest.mark.parametrize("name,size", [("nv12_chw", 0), ("nv12_chw_640", 640)])
-def test_north_star_workloads(gpu_stream, bench, name, size):
+@pytest.mark.parametrize("name,size,fmt", [("nv12_chw", 0, "nv12"), ("nv12_chw_640", 640, "nv12"), ("nv12_chw_608", 608, "nv12"),
+                                           ("yuyv_chw_640", 640, "yuyv")])
+def test_north_star_workloads(gpu_stream, bench, name, size, fmt):
     wl = _run(bench, name, gpu_stream)
     oh, ow = (wl.H, wl.W) if size == 0 else (size, size)
     got = _out(wl, np.float32, (3, oh, ow))
+    if size:  # the roofline numerator follows the variant that really runs: one tap on the 1/3 grid, four off it; padding reads nothing
+        assert wl.variant == ("generic_bilinear_on_grid" if size == 640 else "generic"), wl.variant
+        assert wl.taps == (1 if size == 640 else 4)
+        assert wl.active_px == {640: 640 * 360, 608: 608 * 342}[size]
+        assert wl.alg_bytes_per_launch == int(wl.N * (size * size * 12 + wl.active_px * wl.taps * wl.src_bytes_per_px))
     for k in range(wl.N):
         raw = wl.base[31 * k: 31 * k + wl.frame_bytes]
-        want = O.preprocess(raw, wl.W, wl.H, ow, oh, fmt="nv12", mode="stretch" if size == 0 else "letterbox", mean=MEAN, std=STD)[0]
+        want = O.preprocess(raw, wl.W, wl.H, ow, oh, fmt=fmt, mode="stretch" if size == 0 else "letterbox", mean=MEAN, std=STD)[0]
         if not np.array_equal(got[k], want):   # say where: a hole of zeros / stale bytes (a copy problem) looks different from wrong arithmetic
             bad = np.argwhere(got[k].view(np.uint32) != want.view(np.uint32))
             flat = np.flatnonzero(got[k].view(np.uint32).reshape(-1) != want.view(np.uint32).reshape(-1))
@@ -148,14 +154,6 @@ def test_gather_workloads_4k(gpu_stream, bench):
         assert np.array_equal(got[k], O.remap_u8(_frame(wl, k, n, (wl.H, wl.W, wl.C)), mx, my, "bilinear")), k
 
 
-def test_lab_workload_4k(gpu_stream, bench):
-    wl = _run(bench, "lab_from_rgb_4k", gpu_stream)
-    got = _out(wl, np.float32, (wl.H, wl.W, 3))
-    want = O.cie("lab_from_rgb", wl.host.reshape(wl.H, wl.W, 3))
-    for k in range(wl.N):  # every image is the same pattern here; bit-identical since round 3 (the device evaluates glibc's powf / cbrtf)
-        assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), k
-
-
 def test_filter_extra_workloads_1080p(gpu_stream, bench):
     wl = _run(bench, "spatial_gradient_1080p", gpu_stream)
     n = wl.W * wl.H * wl.C
@@ -167,24 +165,33 @@ def test_filter_extra_workloads_1080p(gpu_stream, bench):
     got = _out(wl, np.float32, (wl.H, wl.W, wl.C))
     for k in range(wl.N):
         assert np.array_equal(got[k], O.box_blur_fast(_frame(wl, k, n, (wl.H, wl.W, wl.C)), (2.0, 2.0))), k
-    wl = _run(bench, "median5_u8_1080p", gpu_stream)
-    got = _out(wl, np.uint8, (wl.H, wl.W, wl.C))
+
+
+def test_north_star_operator_workloads(gpu_stream, bench):
+    """The operators `north_star` names that joined the default run in round 4: bicubic resize, warp_affine f32, sobel, box_blur,
+    normalize_mean_std — two images each at the real image size, bit for bit against the restatement."""
+    wl = _run(bench, "resize_bicubic_540", gpu_stream)
+    n = wl.SW * wl.SH * wl.C
+    got = _out(wl, np.float32, (wl.DH, wl.DW, wl.C))
     for k in range(wl.N):
-        assert np.array_equal(got[k], O.median_blur(_frame(wl, k, n, (wl.H, wl.W, wl.C)), 5)), k
-    wl = _run(bench, "bilateral_1080p", gpu_stream)
-    got = _out(wl, np.uint8, (wl.H, wl.W, 1))
-    for k in range(wl.N):
-        assert np.array_equal(got[k], O.bilateral_filter(_frame(wl, k, wl.W * wl.H, (wl.H, wl.W, 1)), 5, 50.0, 50.0)), k
+        assert np.array_equal(got[k], O.resize(_frame(wl, k, n, (wl.SH, wl.SW, wl.C)), wl.DW, wl.DH, "bicubic")), k
+    for name in ("warp_affine_f32_1080p", "sobel_4k", "box_blur_4k", "normalize_1080p"):
+        wl = _run(bench, name, gpu_stream)
+        n = wl.W * wl.H * wl.C
+        got = _out(wl, np.float32, (wl.H, wl.W, wl.C))
+        for k in range(wl.N):
+            want = wl.oracle_call(O, _frame(wl, k, n, (wl.H, wl.W, wl.C)))
+            assert np.array_equal(got[k].view(np.uint32), np.ascontiguousarray(want).view(np.uint32).reshape(got[k].shape)), (name, k)
 
 
 def test_colour_map_workloads_1080p(gpu_stream, bench):
-    for name in ("gray_u8_1080p", "gray_f32_1080p", "hsv_f32_1080p", "bgr_u8_1080p"):
+    for name in ("gray_u8_1080p", "gray_f32_1080p", "hsv_f32_1080p", "bgr_u8_1080p", "ycbcr_u8_1080p", "ycbcr_f32_1080p"):
         wl = _run(bench, name, gpu_stream)
         np_dt = np.uint8 if wl.dtype == "u8" else np.float32
         n = wl.W * wl.H * wl.cin
         got = _out(wl, np_dt, (wl.H, wl.W, wl.cout))
         for k in range(wl.N):
-            want = O.color_map(wl.entry[3:], _frame(wl, k, n, (wl.H, wl.W, wl.cin)), wl.cout)
+            want = O.color_map(wl.entry[3:], _frame(wl, k, n, (wl.H, wl.W, wl.cin)), wl.cout, *wl.EXTRA.get(wl.entry, ()))
             assert np.array_equal(got[k].view(np.uint32 if np_dt == np.float32 else np.uint8),
                                   want.reshape(got[k].shape).view(np.uint32 if np_dt == np.float32 else np.uint8)), (name, k)
     wl = _run(bench, "gray_258x195", gpu_stream)  # BASELINE configs[0]
@@ -193,9 +200,10 @@ def test_colour_map_workloads_1080p(gpu_stream, bench):
 
 
 def test_every_workload_is_covered(bench):
-    covered = {"nv12_chw", "nv12_chw_640", "resize_224", "resize_normalize_f32_224", "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640",
-               "gaussian_4k", "gaussian_u8_4k", "pyrdown_u8_4k", "pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k", "lab_from_rgb_4k",
-               "spatial_gradient_1080p", "box_blur_fast_1080p", "median5_u8_1080p", "bilateral_1080p",
-               "gray_u8_1080p", "gray_f32_1080p", "hsv_f32_1080p", "bgr_u8_1080p", "gray_258x195", "nv12_chw_640_lanczos"}
+    covered = {"nv12_chw", "nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_chw_640_lanczos", "resize_224", "resize_bicubic_540", "resize_normalize_f32_224",
+               "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640", "gaussian_4k", "sobel_4k", "box_blur_4k", "gaussian_u8_4k", "pyrdown_u8_4k",
+               "pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_f32_1080p", "normalize_1080p",
+               "warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k", "spatial_gradient_1080p", "box_blur_fast_1080p",
+               "gray_u8_1080p", "gray_f32_1080p", "hsv_f32_1080p", "ycbcr_u8_1080p", "ycbcr_f32_1080p", "bgr_u8_1080p", "gray_258x195"}
     assert set(bench.ALSO_DEFAULT) <= set(bench.WORKLOADS)
     assert covered == set(bench.WORKLOADS)

@@ -66,18 +66,14 @@ def test_non_finite_pixels_poison_only_their_own_window(gpu_stream, ks):
     assert_same_bits(np.nan_to_num(got, nan=7.0, posinf=8.0, neginf=9.0), np.nan_to_num(want, nan=7.0, posinf=8.0, neginf=9.0), f"non-finite {ks}")
 
 
-@pytest.fixture(params=["roll", "roll2", "roll4", "tile"])
-def kernel_path(request, monkeypatch):
-    """The device kernels behind the filter entry points: the rolling-column fast path, its two- and four-columns-per-lane variants
-    (KH_FILTER_TWO_COLUMNS=1: rows of even length >= 512 floats; KH_FILTER_FOUR_COLUMNS=1: rows of a multiple of four floats >= 1024,
-    kernels up to 9 taps) and the LDS-tile kernel (KH_FILTER_FORCE_TILE=1)."""
-    monkeypatch.delenv("KH_FILTER_FORCE_TILE", raising=False)
-    monkeypatch.delenv("KH_FILTER_TWO_COLUMNS", raising=False)
-    monkeypatch.setenv("KH_FILTER_FOUR_COLUMNS", "1" if request.param == "roll4" else "0")
+@pytest.fixture(params=["roll", "roll4", "tile"])
+def kernel_path(request, dev_option):
+    """The device kernels behind the filter entry points: the rolling-column fast path (one column per lane), its four-columns-per-lane
+    form (rows of a multiple of four floats >= 1024, kernels up to 9 taps: the default where it applies) and the LDS-tile kernel —
+    each forced through the library's test options so that every geometry below reaches it."""
+    dev_option("filter_four_columns", 1 if request.param == "roll4" else 0)
     if request.param == "tile":
-        monkeypatch.setenv("KH_FILTER_FORCE_TILE", "1")
-    elif request.param == "roll2":
-        monkeypatch.setenv("KH_FILTER_TWO_COLUMNS", "1")
+        dev_option("filter_force_tile", 1)
     return request.param
 
 

@@ -17,3 +17,12 @@ def test_no_scratch_no_spills_no_flat_memory_instructions():
     m = re.search(r"kernels with flat memory instructions: (\d+)", head[2])
     assert m and m.group(1) == "0", "\n".join(l for l in out.stdout.splitlines() if l.startswith("#"))
     assert int(re.match(r"# (\d+) kernels", head[0]).group(1)) > 300
+
+
+def test_no_getenv_in_the_product_sources():
+    """Static half of the rule: no source of the shipped library calls getenv."""
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent / "kornia-rs_amd" / "csrc"
+    hits = [f"{p.name}:{i + 1}" for p in sorted(root.iterdir()) for i, line in enumerate(p.read_text().splitlines())
+            if "getenv(" in line and not line.lstrip().startswith("//")]
+    assert not hits, hits

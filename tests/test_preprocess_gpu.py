@@ -253,26 +253,25 @@ def test_python_run_api(gpu_stream):
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "rgb", "yuyv"])
-def test_quotient_shortcut_equals_ieee_division_path(gpu_stream, fmt, monkeypatch):
-    """The generic kernel replaces (o - pad) / scale by a host-verified 3-op quotient; KH_PRE_IEEE_DIV=1
+def test_quotient_shortcut_equals_ieee_division_path(gpu_stream, fmt, dev_option):
+    """The generic kernel replaces (o - pad) / scale by a host-verified 3-op quotient; the test option pre_ieee_div = 1
     forces the plain divisions.  Both must give the oracle's bits on awkward scales."""
     for (w, h), (dw, dh), mode in [((1920, 1080), (640, 640), "letterbox"), ((130, 98), (97, 55), "stretch"),
                                    ((64, 48), (333, 171), "letterbox"), ((258, 194), (224, 224), "stretch")]:
         raw = _raw_for(fmt, w, h, seed=5)
         kw = dict(fmt=fmt, mode=mode, sampling="bilinear", **IMAGENET)
         want = O.preprocess(raw, w, h, dw, dh, **kw)
-        monkeypatch.delenv("KH_PRE_IEEE_DIV", raising=False)
+        dev_option("pre_ieee_div", -1)
         _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), want, f"{fmt} {w}x{h}->{dw}x{dh} shortcut")
-        monkeypatch.setenv("KH_PRE_IEEE_DIV", "1")
+        dev_option("pre_ieee_div", 1)
         _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), want, f"{fmt} {w}x{h}->{dw}x{dh} ieee")
-    monkeypatch.delenv("KH_PRE_IEEE_DIV", raising=False)
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "rgb", "bgra", "yuyv", "gray"])
 @pytest.mark.parametrize("f16", [False, True])
-def test_bilinear_on_whole_pixel_grid_equals_the_four_tap_kernel_and_the_oracle(gpu_stream, fmt, f16, monkeypatch):
+def test_bilinear_on_whole_pixel_grid_equals_the_four_tap_kernel_and_the_oracle(gpu_stream, fmt, f16, dev_option):
     """When every source coordinate of a launch is a whole number (1080p -> 640 letterbox: sx = 3 ox exactly) the bilinear weights are 0
-    and the kernel decodes one tap per pixel; KH_PRE_GRID=0 keeps the four-tap kernel.  Both must give the restatement's bits — on
+    and the kernel decodes one tap per pixel; the test option pre_grid = 0 keeps the four-tap kernel.  Both must give the restatement's bits — on
     such geometries, on near misses (a fractional pad, scale 1/5 whose f32 quotients are not all whole) and on an upscale."""
     import ctypes as C
     from kornia_rs import _ffi
@@ -283,15 +282,14 @@ def test_bilinear_on_whole_pixel_grid_equals_the_four_tap_kernel_and_the_oracle(
         raw = _raw_for(fmt, w, h, seed=3)
         kw = dict(fmt=fmt, mode=mode, sampling="bilinear", f16=f16, **IMAGENET)
         want = O.preprocess(raw, w, h, dw, dh, **kw)
-        monkeypatch.delenv("KH_PRE_GRID", raising=False)
+        dev_option("pre_grid", -1)
         if on_grid is not None and fmt == "nv12" and not f16:
             pre = _pre(gpu_stream, mode=mode, format=fmt, sampling="bilinear", **IMAGENET)
             p = pre._params(w, h, w, 1, _ffi.KH_FMT_NV12, dw, dh, 1, 0, False, False)
             assert _ffi.lib.kh_preprocess_variant(C.byref(p)) == (b"generic_bilinear_on_grid" if on_grid else b"generic"), (w, h, dw, dh, mode)
         _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), want, f"{fmt} {w}x{h}->{dw}x{dh} {mode} default")
-        monkeypatch.setenv("KH_PRE_GRID", "0")
+        dev_option("pre_grid", 0)
         _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), want, f"{fmt} {w}x{h}->{dw}x{dh} {mode} four taps")
-    monkeypatch.delenv("KH_PRE_GRID", raising=False)
 
 
 def test_python_run_reuses_pinned_staging_in_a_frame_loop(gpu_stream):

@@ -63,19 +63,17 @@ def test_separable_q14(gpu_stream, mode, aa):  # cuda.rs:420-440
         assert check(gpu_stream, s, d, c, mode, aa) == "separable"
 
 
-@pytest.mark.parametrize("lanes", ["columns", "rows"])
+@pytest.mark.parametrize("path", ["staged", "gather"])
 @pytest.mark.parametrize("c", [1, 3, 4])
-def test_separable_staged_horizontal_pass_tiles(gpu_stream, c, lanes, monkeypatch):
-    """The LDS-staged horizontal passes (lanes = rows: 16 destination columns x 64 source rows per block; lanes = columns: 64 x 16):
-    several interior tiles whose rows start at every address alignment (odd widths), ragged last tiles, upsampling (k = 6 padded
-    to 8 taps), a span that fits only the columns-per-lane tile, and one too wide for 64 KiB of LDS (the gather kernel)."""
-    if lanes == "rows":
-        monkeypatch.setenv("KH_RESIZE_U8_ROWS", "1")
-    else:
-        monkeypatch.delenv("KH_RESIZE_U8_ROWS", raising=False)
+def test_separable_staged_horizontal_pass_tiles(gpu_stream, c, path, dev_option):
+    """The LDS-staged horizontal pass (64 destination columns x 16 source rows per block): several interior tiles whose rows start
+    at every address alignment (odd widths), ragged last tiles, upsampling (k = 6 padded to 8 taps) and a span too wide for 64 KiB
+    of LDS (the gather kernel); `gather` forces that fallback for every case."""
+    if path == "gather":
+        dev_option("resize_u8_gather", 1)
     for s, d, mode, aa in [((517, 70), (300, 40), "lanczos", True), ((1001, 37), (230, 37), "lanczos", True), ((333, 50), (700, 50), "lanczos", False),
                            ((415, 35), (200, 20), "bicubic", True), ((415, 35), (200, 20), "bicubic", False), ((20000, 4), (70, 4), "lanczos", True),
-                           ((1100, 20), (64, 20), "lanczos", True)]:  # 17x: the rows-per-lane tile does not fit, the columns-per-lane tile does
+                           ((1100, 20), (64, 20), "lanczos", True)]:  # 17x
         assert check(gpu_stream, s, d, c, mode, aa) == "separable"
 
 

@@ -160,24 +160,17 @@ def test_warp_affine_u8_staged_tiles_match_oracle(gpu_stream, c, name):
     assert_same_bits(got, O.warp_affine_u8(src, m, dw, dh), f"staged affine_u8 {name} c{c}")
 
 
-def test_warp_affine_u8_both_kernels_agree(gpu_stream, tmp_path):
-    """KH_WARP_U8_DIRECT=1 selects the per-pixel kernel (read once per process): a child process runs it on the same inputs and the
-    bytes must equal this process's LDS-staged result."""
-    import os, subprocess, sys
-    from pathlib import Path
-    root = Path(__file__).resolve().parent.parent
+def test_warp_affine_u8_both_kernels_agree(gpu_stream, dev_option):
+    """The test option warp_u8_direct = 1 selects the per-pixel kernel (what images beyond the staged gather's 16-bit box fields
+    take): same inputs, the bytes must equal the LDS-staged result."""
     src = pat(421, 150, 3)
     m = rotation(210.0, 75.0, 12.0, 0.9)
-    staged = warp_u8_gpu(gpu_stream, "affine", np.stack([src, src[::-1].copy()]), m, 421, 150, batch=2)
-    np.save(tmp_path / "src.npy", src)
-    code = (f"import sys, numpy as np; sys.path[:0] = [{str(root / 'kornia-rs_amd')!r}, {str(root / 'tests')!r}]\n"
-            "import conftest, test_u8_gpu as T\nfrom kornia_rs import hip\n"
-            f"src = np.load({str(tmp_path / 'src.npy')!r}); st = hip.Stream.new(0)\n"
-            f"out = T.warp_u8_gpu(st, 'affine', np.stack([src, src[::-1].copy()]), {m!r}, 421, 150, batch=2)\n"
-            f"np.save({str(tmp_path / 'direct.npy')!r}, out)\n")
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KH_WARP_U8_DIRECT="1"), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert np.array_equal(np.load(tmp_path / "direct.npy"), staged)
+    batch = np.stack([src, src[::-1].copy()])
+    staged = warp_u8_gpu(gpu_stream, "affine", batch, m, 421, 150, batch=2)
+    dev_option("warp_u8_direct", 1)
+    direct = warp_u8_gpu(gpu_stream, "affine", batch, m, 421, 150, batch=2)
+    assert np.array_equal(direct, staged)
+    assert np.array_equal(direct[0], O.warp_affine_u8(src, m, 421, 150))
 
 
 PROJ = [0.9, 0.12, 4.0, -0.08, 1.05, -2.0, 6.0e-4, -4.5e-4, 1.0]

@@ -396,36 +396,3 @@ def test_rust_api_spellings_on_device(gpu_stream):
     from kornia_rs.hip import DeviceBuffer
     R.rgb_from_planar420(DeviceBuffer.from_numpy(nv12, gpu_stream), 32, 16, out, "nv12")
     assert np.array_equal(out.numpy(), O.rgb_from_nv12(nv12, 32, 16))
-
-
-def test_north_star_xcd_frame_order_knob_is_bit_identical():
-    """KH_NV12_XCD_FRAMES=1 (dev knob, read once per process): XCD k walks frames k, k + 8, ... — a different block -> (frame,
-    chunk) map, same bytes.  11 frames (not a multiple of 8) of 64x34 NV12 in a child process with the knob set."""
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
-    root = Path(__file__).resolve().parent.parent
-    code = r'''
-import sys, numpy as np
-sys.path[:0] = ["{root}/kornia-rs_amd", "{root}/tests"]
-import oracle_ffi as O
-from kornia_rs import Preprocessor, Tensor, hip
-from kornia_rs.hip import DeviceBuffer
-s = hip.Stream.new(0)
-w, h, n = 64, 34, 11
-fb = w * h * 3 // 2
-raw = O.pattern_u8(fb * n)
-kw = dict(mean=hip.IMAGENET_MEAN, std=hip.IMAGENET_STD)
-pre = Preprocessor(mode="stretch", format="nv12", stream=s, **kw)
-dst = Tensor.uninit((n, 3, h, w), "float32", s)
-pre.run_raw_batch(DeviceBuffer.from_numpy(raw, s), w, h, dst, frame_stride=fb)
-got = dst.numpy_raw()
-for k in range(n):
-    want = O.preprocess(raw[k * fb:(k + 1) * fb], w, h, w, h, fmt="nv12", mode="stretch", **kw)[0]
-    assert np.array_equal(got[k], want), k
-print("xcd-frames ok")
-'''.replace("{root}", str(root))
-    env = dict(os.environ, KH_NV12_XCD_FRAMES="1")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and "xcd-frames ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
