@@ -1285,16 +1285,18 @@ def respawn_under_torchrun(args) -> int:
 class Runner:
     """Times workloads on this rank's device: K steps bracketed by barrier + sync, per-step HIP events on the launch stream."""
 
-    def __init__(self, hip, torch, dist, stream, rank, local_rank, world):
+    def __init__(self, hip, torch, dist, stream, rank, local_rank, world, on_gpu=True):
         self.hip, self.torch, self.dist, self.stream = hip, torch, dist, stream
         self.rank, self.local_rank, self.world = rank, local_rank, world
+        self.on_gpu = on_gpu   # False only under the host simulator (tests/hostsim): gloo ranks, no torch device
         self.traffic_source = None
 
     def barrier(self):
         self.stream.synchronize()
-        self.torch.cuda.synchronize()
+        if self.on_gpu:
+            self.torch.cuda.synchronize()
         if self.world > 1:
-            self.dist.barrier(device_ids=[self.local_rank])
+            self.dist.barrier(device_ids=[self.local_rank]) if self.on_gpu else self.dist.barrier()
 
     def time(self, wl, steps, warmup):
         hip, stream = self.hip, self.stream
@@ -1309,13 +1311,14 @@ class Runner:
             wl.step()
             stops[k].record(stream)
         stream.synchronize()
-        self.torch.cuda.synchronize()
+        if self.on_gpu:
+            self.torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if self.world > 1:
-            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda")
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda" if self.on_gpu else "cpu")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            self.dist.barrier(device_ids=[self.local_rank])
+            self.dist.barrier(device_ids=[self.local_rank]) if self.on_gpu else self.dist.barrier()
         kernel_ms = [starts[k].elapsed_ms(stops[k]) for k in range(steps)]
         return elapsed, kernel_ms
 
@@ -1434,6 +1437,8 @@ def main():
                                                  "\"also\" (default: the other BASELINE configs etc. when the headline is the north star; 'none' disables)")
     ap.add_argument("--also-batch", type=int, default=0, help="batch override for the --also workloads (quick checks)")
     ap.add_argument("--in-process", action="store_true", help="shard across --gpus devices inside ONE process (a thread + stream per device)")
+    ap.add_argument("--dev-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B runs only: force a library test option (kh_debug_set_option) for this process, e.g. pre_quads=0")
     args = ap.parse_args()
 
     if args.in_process:
@@ -1449,17 +1454,34 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    # KH_HOSTSIM=1 + KORNIA_HIP_LIB=<tests/hostsim build>: the launcher exercised end to end on a GPU-less box — the product's kernels
+    # compiled for x86 (TEST INFRASTRUCTURE, tests/test_sharding_gloo.py), one simulated device per rank, gloo instead of RCCL.  The
+    # numbers of such a line mean nothing; its shape (n_gpus, aggregate over ranks, max-over-ranks time) is what is checked.
+    hostsim = os.environ.get("KH_HOSTSIM") == "1"
+    on_gpu = torch.cuda.is_available()
+    if not on_gpu and not hostsim:
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from kornia_rs import hip
-    hip.set_device(local_rank)
-    stream = hip.Stream.new(local_rank)
-    run = Runner(hip, torch, dist, stream, rank, local_rank, world)
+    if not on_gpu:
+        local_dev = 0          # every simulated process owns one device, ordinal 0
+    else:
+        local_dev = local_rank
+    hip.set_device(local_dev)
+    for opt in args.dev_option:
+        from kornia_rs import _ffi
+        name, _, value = opt.partition("=")
+        _ffi.check(_ffi.lib.kh_debug_set_option(name.encode(), int(value)))
+    stream = hip.Stream.new(local_dev)
+    run = Runner(hip, torch, dist, stream, rank, local_rank, world, on_gpu)
 
     wl = make_workload(args.workload, args)
     wl.setup(stream)
@@ -1469,7 +1491,7 @@ def main():
         ceilings = store_ceilings(hip, stream, wl.dst.data_ptr, wl.W, wl.H, wl.N)
     if rank == 0:
         rec = run.record(wl, args.steps, args.warmup, elapsed, kernel_ms, args.workload)
-        name, cus, mem = hip.device_info(local_rank)
+        name, cus, mem = hip.device_info(local_dev)
         line = {"metric": ("Mpixels/s, fused 1080p NV12->normalized CHW f32 (achieved HBM GB/s in roofline)"
                            if args.workload.startswith("nv12") else f"Mpixels/s (source pixels), {wl.name}"),
                 "value": rec["value"], "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1514,7 +1536,7 @@ def main():
             rows += [summary_row(r) for r in records]
 
     if rank == 0:
-        name, cus, mem = hip.device_info(local_rank)
+        name, cus, mem = hip.device_info(local_dev)
         try:
             affinity = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
@@ -1536,6 +1558,10 @@ def main():
                 dev["note"] = ("flat_fill / three_plane_store_only: the output bytes written with the production store policy and no loads or "
                                "decode, same process, same buffer, same events (kornia-rs_amd/diag/kh_diag.hip)")
         line["device"] = dev
+        if args.dev_option:
+            line["dev_options"] = args.dev_option   # a line produced with forced code paths says so
+        if not on_gpu:
+            line["data"] += "; HOST SIMULATOR run (KH_HOSTSIM=1): launcher check only, the numbers are meaningless"
         if run.traffic_source:
             line["traffic_source"] = run.traffic_source
         # LAST key: [workload, ms_per_step, frac, traffic_frac, cpu Mpx/s, cpu cores] per workload

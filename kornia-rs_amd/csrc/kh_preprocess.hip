@@ -418,51 +418,42 @@ __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __re
 // not by the vector ALUs (35-40 % busy) or by HBM.  Two things waste slots there: the 64 x kGenPx = 256-pixel block rows leave the
 // third block of a 640- / 608-pixel row half empty (17-21 % of the lanes exit at once), and a lane keeps 4 pixels x 12 B in flight
 // as twelve 4-byte stores.  Here the destination is walked as a flat list of 4-pixel quads (dst_w % 4 == 0): no idle lanes but the
-// last block's tail, a lane owns K quads (kQuadBlock apart, so a wave still stores 1 KiB contiguous per instruction) and writes each
-// plane with one 16-byte streaming buffer store, like the identity kernel.  Same per-pixel expressions, bit-identical.
+// last block's tail, a lane owns one quad and writes each plane with one 16-byte streaming buffer store (a wave: 1 KiB contiguous per
+// instruction), like the identity kernel.  Same per-pixel expressions, bit-identical.  (Two quads per lane: slower, r04d.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kQuadBlock = 256;
-constexpr int kQuadsPerLane = 1;   // production choice (profiles/r04d)
-template <int FMT, int SAMPLER, bool WIDE, int K>
+template <int FMT, int SAMPLER, bool WIDE>
 __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uint8_t* __restrict__ src_base, float* __restrict__ dst_base,
                                                                        PreArgs a, FastDiv by_wq) {
     const int wq = a.dst_w >> 2, groups = wq * a.dst_h, plane = a.dst_w * a.dst_h;   // host-checked: 12 * plane < 2^31
+    const int g = blockIdx.x * kQuadBlock + threadIdx.x;
+    if (g >= groups) return;
     const uint8_t* src = src_base + (long long)blockIdx.y * a.src_frame_stride;
     const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_base + (long long)blockIdx.y * a.dst_frame_stride, (uint32_t)(12 * plane));
-    f32x4 o[K][3];
-    int g0[K];
+    const int oy = (int)fast_quot((uint32_t)g, by_wq), ox0 = 4 * (g - oy * wq);
+    const float ny = (float)oy - a.pad_y;
+    const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
+    f32x4 o[3];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        g0[k] = (blockIdx.x * K + k) * kQuadBlock + threadIdx.x;
-        const int g = min(g0[k], groups - 1);
-        const int oy = (int)fast_quot((uint32_t)g, by_wq), ox0 = 4 * (g - oy * wq);
-        const float ny = (float)oy - a.pad_y;
-        const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // plan_pixel (P/preprocess.rs:437-448)
-            const float nx = (float)(ox0 + j) - a.pad_x;
-            const float sx = a.fast_div ? quot3(nx, a.scale_x, a.rc_x) : nx / a.scale_x;
-            float px[3];
-            if (!(sx < 0.0f || sy < 0.0f || sx >= (float)a.src_w || sy >= (float)a.src_h)) {
-                if constexpr (SAMPLER == KH_SAMPLE_NEAREST) nearest_tap<FMT, WIDE>(src, sx, sy, a, px);
-                else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) bilinear_quad<FMT, WIDE>(src, sx, sy, a, px);
-                else tap_rgb<FMT, WIDE>(src, (int)sx, (int)sy, a, px);   // kSampleBilinearOnGrid: sx, sy whole and in range (host-checked)
-            } else {
-                px[0] = a.pad_value; px[1] = a.pad_value; px[2] = a.pad_value;
-            }
-            o[k][0][j] = (div255_any(px[0]) - a.m0) * a.is0;
-            o[k][1][j] = (div255_any(px[1]) - a.m1) * a.is1;
-            o[k][2][j] = (div255_any(px[2]) - a.m2) * a.is2;
+    for (int j = 0; j < 4; ++j) {
+        // plan_pixel (P/preprocess.rs:437-448)
+        const float nx = (float)(ox0 + j) - a.pad_x;
+        const float sx = a.fast_div ? quot3(nx, a.scale_x, a.rc_x) : nx / a.scale_x;
+        float px[3];
+        if (!(sx < 0.0f || sy < 0.0f || sx >= (float)a.src_w || sy >= (float)a.src_h)) {
+            if constexpr (SAMPLER == KH_SAMPLE_NEAREST) nearest_tap<FMT, WIDE>(src, sx, sy, a, px);
+            else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) bilinear_quad<FMT, WIDE>(src, sx, sy, a, px);
+            else tap_rgb<FMT, WIDE>(src, (int)sx, (int)sy, a, px);   // kSampleBilinearOnGrid: sx, sy whole and in range (host-checked)
+        } else {
+            px[0] = a.pad_value; px[1] = a.pad_value; px[2] = a.pad_value;
         }
+        o[0][j] = (div255_any(px[0]) - a.m0) * a.is0;
+        o[1][j] = (div255_any(px[1]) - a.m1) * a.is1;
+        o[2][j] = (div255_any(px[2]) - a.m2) * a.is2;
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (g0[k] >= groups) break;
-#pragma unroll
-        for (int c = 0; c < 3; ++c)  // plane offset in the vector offset, never in an SGPR soffset (kh_common.h)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[k][c]), rdst, 16 * g0[k] + c * (4 * plane), 0, kAuxStream);
-    }
+    for (int c = 0; c < 3; ++c)  // plane offset in the vector offset, never in an SGPR soffset (kh_common.h)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[c]), rdst, 16 * g + c * (4 * plane), 0, kAuxStream);
 }
 
 // ---- north-star fast path ------------------------------------------------------------------
@@ -700,20 +691,20 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
     else if (FMT == KH_FMT_YUYV) wide = base % 4 == 0 && a.src_frame_stride % 4 == 0 && a.src_pitch % 4 == 0;
     else if (FMT == KH_FMT_RGB || FMT == KH_FMT_BGR)
         wide = a.src_bpp == 4 && base % 4 == 0 && a.src_frame_stride % 4 == 0 && a.src_pitch % 4 == 0;
-    // flattened quads with 16-byte streaming stores (preprocess_generic_quads) for f32 outputs whose rows are whole quads; Lanczos,
-    // f16 and ragged widths keep the per-pixel kernel.  Test option pre_quads: 0 = per-pixel kernel, 1 / 2 = quads per lane.
+    // flattened quads with 16-byte streaming stores (preprocess_generic_quads) for the ONE-tap samplers (nearest, on-grid bilinear), f32
+    // outputs whose rows are whole quads.  Measured on one box, three interleaved rounds (profiles/r04d_quads_ab.txt): 1080p NV12 -> 640
+    // on-grid 1.227 vs 1.329 ms, YUYV 1.206 vs 1.279 ms; the four-tap bilinear kernel does NOT gain from it (608: 1.464 vs 1.443 ms) and
+    // two quads per lane lose everywhere, so those keep the per-pixel kernel.  Test option pre_quads: 0 = never, 1 = also for four taps.
     if constexpr (SAMPLER != KH_SAMPLE_LANCZOS) {
         const int opt = dev_opt(kOptPreQuads);
         const bool quads_ok = out_dtype == KH_OUT_F32 && a.dst_w % 4 == 0 && (int64_t)a.dst_w * a.dst_h * 12 <= kI32Max &&
                               reinterpret_cast<uintptr_t>(dst) % 16 == 0 && a.dst_frame_stride % 4 == 0;
-        if (quads_ok && opt != 0) {
-            const int wq = a.dst_w / 4, groups = wq * a.dst_h, kq = opt == 1 ? 1 : (opt == 2 ? 2 : kQuadsPerLane);
-            const dim3 qgrid(cdiv(groups, kQuadBlock * kq), grid.z);
+        if (quads_ok && opt != 0 && (SAMPLER != KH_SAMPLE_BILINEAR || opt == 1)) {
+            const int wq = a.dst_w / 4, groups = wq * a.dst_h;
+            const dim3 qgrid(cdiv(groups, kQuadBlock), grid.z);
             const FastDiv by_wq = fast_div((uint32_t)wq);
-#define KH_GENQ(W, KQ) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, W, KQ>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, a, by_wq)
-            if (kq == 1) { if (wide) KH_GENQ(true, 1); else KH_GENQ(false, 1); }
-            else { if (wide) KH_GENQ(true, 2); else KH_GENQ(false, 2); }
-#undef KH_GENQ
+            if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, a, by_wq);
+            else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, a, by_wq);
             return;
         }
     }

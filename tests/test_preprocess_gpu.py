@@ -312,3 +312,34 @@ def test_python_run_reuses_pinned_staging_in_a_frame_loop(gpu_stream):
     again = pre.run(frames[:4], w, h, 24, 40)
     assert pre._staging.allocations == 4
     _assert_bits_equal(again.numpy(), batch.numpy(), "staging reuse")
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "rgb", "bgra", "yuyv", "gray"])
+@pytest.mark.parametrize("sampling", ["bilinear", "nearest"])
+@pytest.mark.parametrize("quads", [-1, 0, 1])
+def test_flattened_quad_kernel_equals_the_per_pixel_kernel_and_the_oracle(gpu_stream, fmt, sampling, quads, dev_option):
+    """f32 outputs of the one-tap samplers (nearest, on-grid bilinear) whose rows are whole quads go through preprocess_generic_quads (a
+    lane owns one four-pixel quad of the flattened destination, 16-byte plane stores); the test option pre_quads = 0 keeps the
+    per-pixel kernel everywhere, 1 takes the quad kernel for four-tap bilinear as well.  Geometries: the
+    1080p letterboxes (on-grid 640, off-grid 608), a tail that does not fill the last block, quads that straddle the padding edge
+    (pad 2.5 px), an upscale, a batch, and a ragged width that must fall back to the per-pixel kernel on its own."""
+    from kornia_rs import Tensor
+    from kornia_rs.hip import DeviceBuffer
+    dev_option("pre_quads", quads)
+    cases = [((1920, 1080), (640, 640), "letterbox"), ((1920, 1080), (608, 608), "letterbox"), ((130, 98), (96, 55), "stretch"),
+             ((64, 48), (332, 171), "letterbox"), ((50, 90), (28, 40), "letterbox"), ((46, 34), (36, 27), "stretch"), ((258, 194), (224, 224), "stretch"),
+             ((46, 34), (31, 27), "stretch"), ((8, 6), (4, 1), "stretch")]
+    for (w, h), (dw, dh), mode in cases:
+        raw = _raw_for(fmt, w, h, seed=7)
+        kw = dict(fmt=fmt, mode=mode, sampling=sampling, **IMAGENET)
+        _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), O.preprocess(raw, w, h, dw, dh, **kw), f"{fmt} {sampling} {w}x{h}->{dw}x{dh} {mode} quads={quads}")
+    if fmt == "nv12":   # batched launch: frame k at its own source / destination stride
+        w, h, dw, dh, n = 64, 34, 40, 24, 5
+        fb = w * h * 3 // 2
+        frames = np.stack([_raw_for(fmt, w, h, seed=k) for k in range(n)])
+        pre = _pre(gpu_stream, mode="letterbox", format="nv12", sampling=sampling, **IMAGENET)
+        dst = Tensor.uninit((n, 3, dh, dw), "float32", gpu_stream)
+        pre.run_raw_batch(DeviceBuffer.from_numpy(frames.reshape(-1), gpu_stream), w, h, dst, frame_stride=fb)
+        got = dst.numpy_raw()
+        for k in range(n):
+            _assert_bits_equal(got[k], O.preprocess(frames[k], w, h, dw, dh, fmt="nv12", mode="letterbox", sampling=sampling, **IMAGENET)[0], f"batch frame {k} quads={quads}")
