@@ -183,6 +183,84 @@ class NorthStarNV12(Workload):
                           f"chained rgb_from_{self.fmt} -> {self.sampling}/normalize/CHW, OpenMP x{threads}"}
 
 
+class H2DPreprocess1080p(NorthStarNV12):
+    """SURVEY.md §8(f)4, the capture side of the path: HOST NV12 frames -> page-locked capture buffers -> H2D -> fused preprocess,
+    through Preprocessor.run_host_batch (the two-deep upload ring of kornia_rs/preprocess.py::_Staging on a copy stream; the
+    reference's staging is kornia-py/src/cuda_ext/mod.rs:647-731, its H2D / kernel / D2H harness
+    crates/kornia-imgproc/benches/bench_cuda_imgproc.rs:87-139).  One step = `batch` 1080p frames that start in host memory.
+    The path is bound by the host link, not by HBM: beside the usual record, `roofline` carries the event-timed breakdown —
+    the pinned H2D of one batch alone, the kernel alone on resident frames, the end-to-end step in steady state, how much of the
+    kernel the ring hides behind the next upload, and end-to-end as a fraction of the pinned-H2D rate measured in this process."""
+
+    def __init__(self, batch: int = 64, pageable: bool = False):
+        super().__init__(batch, 0)
+        self.pageable = pageable
+        self.name = f"nv12_h2d_preprocess_1080p{'_pageable' if pageable else ''}_b{batch}"
+        self.kernel = "hipMemcpyAsync(H2D, pinned) + preprocess_nv12_identity"
+
+    RING = 3   # capture buffers in flight: one being filled / uploaded per ring slot + one spare
+
+    def setup(self, stream):
+        from kornia_rs import Preprocessor, Tensor
+        from kornia_rs.hip import PinnedBuffer
+        self.stream = stream
+        fb = self.frame_bytes
+        self.base = lcg_bytes(fb + 31 * self.N * self.RING)
+        self.cap = PinnedBuffer(self.RING * self.N * fb)
+        view = self.cap.view()
+        self.host_frames = []
+        for b in range(self.RING):
+            rows = []
+            for k in range(self.N):
+                i = b * self.N + k
+                view[i * fb:(i + 1) * fb] = self.base[31 * i: 31 * i + fb]
+                rows.append(view[i * fb:(i + 1) * fb] if not self.pageable else self.base[31 * i: 31 * i + fb].copy())
+            self.host_frames.append(rows)
+        self.dst = Tensor.uninit((self.N, 3, self.H, self.W), "float32", stream)
+        self.pre = Preprocessor(mode="stretch", format="nv12", mean=IMAGENET_MEAN, std=IMAGENET_STD, stream=stream)
+        self.turn = 0
+
+    def step(self):
+        self.pre.run_host_batch(self.host_frames[self.turn % self.RING], self.W, self.H, self.dst)
+        self.turn += 1
+
+    def roofline_extra(self, mean_step_s):
+        """H2D alone / kernel alone, timed with events in this process after the headline steps."""
+        from kornia_rs import hip
+        from kornia_rs.hip import DeviceBuffer, lib, check
+        st = self.stream
+        fb, n = self.frame_bytes, self.N
+        dev = DeviceBuffer(n * fb, st, zeroed=False)
+
+        def timed(fn, reps=8):
+            fn(); st.synchronize()
+            e0, e1 = hip.Event(timing=True), hip.Event(timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                fn()
+            e1.record(st); st.synchronize()
+            return e0.elapsed_ms(e1) / reps
+
+        h2d_ms = timed(lambda: check(lib.kh_memcpy_h2d_async(dev.ptr, self.cap.ptr, n * fb, st.cuda_stream_ptr)))
+        ker_ms = timed(lambda: self.pre.run_raw_batch(dev, self.W, self.H, self.dst, frame_stride=fb))
+        e2e_ms = mean_step_s * 1e3
+        h2d_ms, ker_ms = max(h2d_ms, 1e-9), max(ker_ms, 1e-9)   # (the host simulator's events have no resolution)
+        gbs = n * fb / h2d_ms / 1e6
+        return {"bound_note": "host link (PCIe H2D), not HBM: frac is reported against 8 TB/s only for uniformity",
+                "h2d_only_ms": round(h2d_ms, 4), "h2d_pinned_GBps": round(gbs, 2), "kernel_only_ms": round(ker_ms, 4),
+                "end_to_end_ms": round(e2e_ms, 4), "serial_sum_ms": round(h2d_ms + ker_ms, 4),
+                "hidden_by_overlap_ms": round(h2d_ms + ker_ms - e2e_ms, 4),
+                "end_to_end_frac_of_pinned_h2d": round(h2d_ms / max(e2e_ms, 1e-9), 4),
+                "source": "pageable numpy frames (host memcpy into the ring's pinned slot, then DMA)" if self.pageable
+                          else "page-locked capture buffers, DMA'd in place (zero-copy upload)"}
+
+    def describe(self):
+        d = super().describe()
+        d.update(op="Preprocessor.run_host_batch: host frames -> upload ring (copy stream) -> fused NV12 decode + normalize + CHW",
+                 src="1920x1080 NV12 in HOST memory (" + ("pageable" if self.pageable else "page-locked capture buffers") + ")")
+        return d
+
+
 class F32Images(Workload):
     """Shared setup for the f32 HWC configs: `batch` images assembled on device from one LCG
     base pattern (image k = base shifted by 31*k floats, values u8/255)."""
@@ -1161,6 +1239,8 @@ WORKLOADS = {
     "nv12_chw_608": lambda a: NorthStarNV12(a.batch or 1024, 608),
     "nv12_chw_640_lanczos": lambda a: NorthStarNV12(a.batch or 256, 640, "lanczos"),
     "yuyv_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640, "bilinear", "yuyv"),
+    "nv12_h2d_preprocess": lambda a: H2DPreprocess1080p(a.batch or 64),
+    "nv12_h2d_preprocess_pageable": lambda a: H2DPreprocess1080p(a.batch or 64, pageable=True),
     "resize_224": lambda a: ResizeBilinear(a.batch or 256),
     "resize_bicubic_540": lambda a: ResizeBicubic540(a.batch or 256),
     "resize_normalize_f32_224": lambda a: ResizeNormalizeF32(a.batch or 256),
@@ -1198,7 +1278,7 @@ WORKLOADS = {
 # (resize bilinear / bicubic, gray + YCbCr + HSV converts, gaussian / box / sobel, warp_affine / warp_perspective + undistort,
 # normalize), then the u8 twins.  Each entry is a full roofline record with its own cpu_baseline.  (Median / bilateral / Lab
 # are out of SURVEY.md §8 and have no bench line; their kernels are covered by the parity tests only.)
-ALSO_DEFAULT = ["nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "resize_224", "resize_bicubic_540", "gaussian_4k", "box_blur_4k", "sobel_4k",
+ALSO_DEFAULT = ["nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_h2d_preprocess", "resize_224", "resize_bicubic_540", "gaussian_4k", "box_blur_4k", "sobel_4k",
                 "undistort_warp_4k", "warp_affine_f32_1080p", "normalize_1080p", "gray_258x195", "gray_u8_1080p", "gray_f32_1080p",
                 "ycbcr_u8_1080p", "ycbcr_f32_1080p", "hsv_f32_1080p", "warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k",
                 "gaussian_u8_4k"]
@@ -1233,25 +1313,19 @@ def store_ceilings(hip, stream, dst_ptr: int, w: int, h: int, nframes: int, reps
         return {"store_ceilings_error": str(e)[:120]}
 
 
-def compact_record(rec: dict) -> dict:
-    """`also` entries in the ONE JSON line: the numbers, not the prose (the full records, with `config`, the whole `roofline` and
-    the `cpu_baseline.sample` text, go to gpurun_out/bench_full.json).  `roofline` keeps the contract's keys; peak / unit / bound
-    are the headline's (8000 GB/s, hbm)."""
-    r, c = rec["roofline"], rec.get("cpu_baseline") or {}
-    out = {"workload": rec["config"]["workload"], "value": rec["value"], "ms_per_step": rec["ms_per_step"], "dtype": rec["dtype"],
-           "roofline": {"achieved": r["achieved"], "frac": r["frac"], "traffic": r.get("traffic"), "kernel": str(r.get("kernel", ""))[:48]}}
-    if r.get("traffic_frac") is not None:
-        out["roofline"]["traffic_frac"] = r["traffic_frac"]
-    if c:
-        out["cpu_baseline"] = {"value": c.get("value"), "cores": c.get("cores"), "kind": c.get("kind")}
-    return out
+SUMMARY_COLUMNS = ["workload", "Mpx_s", "ms_per_step", "dtype", "roofline_GBps", "roofline_frac", "traffic_frac", "cpu_Mpx_s", "cpu_cores"]
 
 
 def summary_row(rec: dict) -> list:
-    """[workload, ms_per_step, roofline.frac, traffic_frac | null, cpu Mpx/s | null, cpu cores | null] — emitted as the LAST key so it
-    survives any tail truncation of the line."""
+    """One row per workload of the default run — the headline first — emitted as the LAST key of the line, so that it survives any
+    tail truncation.  Round 3 carried every `also` record twice (a compact object AND a summary row); with 22 workloads that no longer
+    fits the driver's 8 KB stdout tail, so the table is the record: [workload, Mpixels/s, ms per step, dtype, algorithmic GB/s,
+    roofline frac = algorithmic GB/s / 8000, counted-traffic frac | null, CPU baseline Mpixels/s | null, CPU threads | null].  The full
+    records (config, the whole roofline object, the cpu_baseline sample text) go to gpurun_out/bench_full.json and, for the round's
+    reference run, to profiles/."""
     r, c = rec["roofline"], rec.get("cpu_baseline") or {}
-    return [rec["config"]["workload"], rec["ms_per_step"], r["frac"], r.get("traffic_frac"), c.get("value"), c.get("cores")]
+    return [rec["config"]["workload"], rec["value"], rec["ms_per_step"], rec["dtype"], r["achieved"], r["frac"], r.get("traffic_frac"),
+            c.get("value"), c.get("cores")]
 
 
 def make_workload(name: str, args) -> Workload:
@@ -1532,7 +1606,6 @@ def main():
             stream.synchronize()
         if rank == 0:
             full["also"] = records
-            line["also"] = [compact_record(r) for r in records]
             rows += [summary_row(r) for r in records]
 
     if rank == 0:
@@ -1564,8 +1637,8 @@ def main():
             line["data"] += "; HOST SIMULATOR run (KH_HOSTSIM=1): launcher check only, the numbers are meaningless"
         if run.traffic_source:
             line["traffic_source"] = run.traffic_source
-        # LAST key: [workload, ms_per_step, frac, traffic_frac, cpu Mpx/s, cpu cores] per workload
-        line["summary_columns"] = ["workload", "ms_per_step", "roofline_frac", "traffic_frac", "cpu_Mpx_s", "cpu_cores"]
+        # LAST key: one row per workload (SUMMARY_COLUMNS)
+        line["summary_columns"] = SUMMARY_COLUMNS
         line["summary"] = rows
         try:  # the uncompacted records, for profiles/ (scratch on the driver's box)
             outdir = ROOT / "gpurun_out"

@@ -200,41 +200,120 @@ def _ptr_len(src: Any) -> Tuple[int, Optional[int]]:
     return int(src), None
 
 
-class _Staging:
-    """Persistent upload staging for host frames (``Staging``, PY/cuda_ext/mod.rs:688-745): ONE page-locked
-    host buffer holding the frames of a call back to back and one device buffer, both grown on demand and
-    reused across calls.  Page-locking is far too expensive for a frame loop, and pinned memory makes the
-    H2D copy a stream-ordered DMA.  The event recorded after each upload is host-waited before the pinned
-    bytes are overwritten by the next call (the plain host copy is not stream-ordered)."""
+class _Slot:
+    """One entry of the staging ring: a page-locked host buffer, a device buffer, the event after the last upload INTO the slot
+    (host-waited before the pinned bytes change) and the event after the last kernel that READ the slot's device buffer (the copy
+    stream waits for it before the next upload overwrites that buffer)."""
+
+    __slots__ = ("pinned", "device", "upload_done", "consumed", "used")
 
     def __init__(self):
-        self.pinned = None
-        self.device = None
-        self.upload_done = None
-        self.allocations = 0  # grows only; exposed for the tests
+        self.pinned = self.device = self.upload_done = self.consumed = None
+        self.used = False
+
+
+class _Staging:
+    """Persistent upload staging for host frames (``Staging``, PY/cuda_ext/mod.rs:647-745), as a TWO-DEEP RING on a copy stream.
+
+    The reference keeps one page-locked buffer + one device buffer per preprocessor and host-waits the previous upload before
+    the pinned bytes are overwritten; with one slot on one stream, call k + 1 can neither copy its frames into pinned memory nor
+    start its DMA while kernel k runs.  Here call k uses slot ``k % 2``:
+
+      1. host-wait the upload issued from this slot two calls ago (long finished), grow the slot's buffers if needed;
+      2. host memcpy of the frames into the slot's pinned buffer — kernel k - 1 and upload k - 1 are still in flight;
+         frames that ALREADY live in page-locked memory (``hip.PinnedBuffer`` capture buffers) skip this copy and are DMA'd from
+         where they are;
+      3. on the COPY stream: wait for the kernel that last read this slot's device buffer (call k - 2), H2D, record ``upload_done``;
+      4. the compute stream waits for that one event and the caller launches the kernel; ``mark_consumed`` records the event step 3 of
+         call k + 2 will wait for.
+
+    Page-locking is far too expensive for a frame loop (buffers are grown on demand, never per call: ``allocations`` counts them),
+    and pinned memory makes the H2D copy a stream-ordered DMA."""
+
+    DEPTH = 2
+
+    def __init__(self):
+        self.slots = [_Slot() for _ in range(self.DEPTH)]
+        self.turn = 0
+        self.current: Optional[_Slot] = None
+        self.copy_stream: Optional[Stream] = None
+        self.allocations = 0   # grows only; exposed for the tests
+        self.zero_copy_uploads = 0
+
+    @staticmethod
+    def _pinned_sources(frames) -> bool:
+        """True when every frame's bytes are page-locked host memory the runtime can DMA from directly."""
+        from .hip import pointer_domain
+        try:
+            return all(pointer_domain(int(fr.ctypes.data))[0] == _ffi.KH_DOMAIN_HOST_PINNED for fr in frames)
+        except Exception:
+            return False
 
     def upload(self, stream: Stream, frames):
         from .hip import Event, PinnedBuffer
+        slot = self.slots[self.turn % self.DEPTH]
+        self.turn += 1
+        self.current = slot
         frame_len = int(frames[0].size)
         stride = (frame_len + 255) // 256 * 256  # keep every frame 256-byte aligned on the device
         total = stride * len(frames)
-        if self.upload_done is not None:  # wait_prev_upload: BEFORE touching (or re-allocating) the pinned buffer
-            self.upload_done.synchronize()
-            self.upload_done = None
-        if self.pinned is None or self.pinned.nbytes < total:
-            self.pinned = PinnedBuffer(total)
+        if slot.upload_done is not None:  # wait_prev_upload: BEFORE touching (or re-allocating) the slot's pinned buffer
+            slot.upload_done.synchronize()
+            slot.upload_done = None
+        if self.copy_stream is None:
+            self.copy_stream = Stream.new(stream.device)
+        cs = self.copy_stream
+        zero_copy = self._pinned_sources(frames)
+        if not zero_copy and (slot.pinned is None or slot.pinned.nbytes < total):
+            slot.pinned = PinnedBuffer(total)
             self.allocations += 1
-        if self.device is None or self.device.nbytes < total:
-            self.device = DeviceBuffer(total, stream, zeroed=False)
+        fresh_device = slot.device is None or slot.device.nbytes < total
+        if fresh_device:
+            slot.device = DeviceBuffer(total, stream, zeroed=False)   # stream-ordered on the COMPUTE stream ...
             self.allocations += 1
-        view = self.pinned.view()
-        for k, fr in enumerate(frames):
-            view[k * stride: k * stride + frame_len] = fr
-        check(lib.kh_memcpy_h2d_async(self.device.ptr, self.pinned.ptr, total, stream.cuda_stream_ptr))
+        if not zero_copy:
+            view = slot.pinned.view()
+            for k, fr in enumerate(frames):
+                view[k * stride: k * stride + frame_len] = fr
+        # the copy stream may write the slot's device buffer once (a) a fresh allocation exists there and (b) the kernel that last
+        # read the buffer has finished; both are events of the compute stream
+        if fresh_device or (slot.used and slot.consumed is None):
+            fence = Event(timing=False)      # ... so the copy stream waits for the allocation (and, if the caller never marked the
+            fence.record(stream)             # last read, for everything queued so far: correct, merely without overlap)
+            check(lib.kh_stream_wait_event(cs.cuda_stream_ptr, fence._handle))
+        elif slot.consumed is not None:
+            check(lib.kh_stream_wait_event(cs.cuda_stream_ptr, slot.consumed._handle))
+        if zero_copy:
+            self.zero_copy_uploads += 1
+            ptrs = [int(fr.ctypes.data) for fr in frames]
+            gaps = {q - p_ for p_, q in zip(ptrs, ptrs[1:])}
+            if len(frames) == 1 or gaps == {stride}:   # one contiguous run at the device stride: one DMA
+                check(lib.kh_memcpy_h2d_async(slot.device.ptr, ptrs[0], stride * (len(frames) - 1) + frame_len, cs.cuda_stream_ptr))
+            else:
+                for k, ptr in enumerate(ptrs):
+                    check(lib.kh_memcpy_h2d_async(slot.device.ptr + k * stride, ptr, frame_len, cs.cuda_stream_ptr))
+        else:
+            check(lib.kh_memcpy_h2d_async(slot.device.ptr, slot.pinned.ptr, total, cs.cuda_stream_ptr))
         ev = Event(timing=False)
-        ev.record(stream)  # mark_upload
-        self.upload_done = ev
-        return _DeviceView(self.device, frame_len if len(frames) == 1 else total), stride
+        ev.record(cs)  # mark_upload
+        slot.upload_done = ev
+        check(lib.kh_stream_wait_event(stream.cuda_stream_ptr, ev._handle))   # the kernel of THIS call waits for THIS upload only
+        slot.used, slot.consumed = True, None
+        return _DeviceView(slot.device, frame_len if len(frames) == 1 else total), stride
+
+    def mark_consumed(self, stream: Stream) -> None:
+        """Call after the kernel that reads the last ``upload`` has been enqueued on ``stream``."""
+        from .hip import Event
+        if self.current is not None:
+            ev = Event(timing=False)
+            ev.record(stream)
+            self.current.consumed = ev
+
+    def wait_uploads(self) -> None:
+        """Block until every upload issued so far has left host memory (zero-copy capture buffers may then be rewritten)."""
+        for slot in self.slots:
+            if slot.upload_done is not None:
+                slot.upload_done.synchronize()
 
 
 class _DeviceView:
@@ -519,6 +598,24 @@ class Preprocessor:
         return Tensor.zeros((batch, 3, out_height, out_width),
                             "float16" if self.f16 else "float32", stream=self.stream)
 
+    def run_host_batch(self, frames: Sequence[np.ndarray], width: int, height: int, dst: Tensor) -> None:
+        """``N`` same-sized HOST frames (1-D uint8 arrays) -> ``dst`` ``[N, 3, H, W]``: staged through the two-deep upload ring (see
+        ``_Staging``) — the host copy and the DMA of this call overlap the previous call's kernel — then ONE batched launch.  Frames
+        that live in page-locked memory (``hip.PinnedBuffer`` capture buffers) are DMA'd in place; such buffers may be rewritten
+        after ``wait_uploads()``.  Pageable frames may be reused as soon as this returns."""
+        frames = [np.asarray(a).reshape(-1) for a in frames]
+        if any(a.dtype != np.uint8 for a in frames):
+            raise TypeError("raw frames must be uint8")
+        if len({a.size for a in frames}) != 1:
+            raise PreprocessError("InvalidRawSource", "batched frames must have the same length")
+        dev, stride = self._staging.upload(self.stream, frames)
+        self.run_raw_batch(dev, width, height, dst, frame_stride=stride)
+        self._staging.mark_consumed(self.stream)
+
+    def wait_uploads(self) -> None:
+        """Block until every host -> device upload issued by ``run`` / ``run_host_batch`` has completed."""
+        self._staging.wait_uploads()
+
     def run(self, frame: Any, width: int, height: int, out_height: int, out_width: int,
             out: Optional[Tensor] = None, consumer_stream: Any = None) -> Tensor:
         """A raw frame (1-D uint8 numpy array, uploaded on the preprocessor's stream), a list of
@@ -545,8 +642,7 @@ class Preprocessor:
             sizes = {a.size for a in frames}
             if len(sizes) != 1:
                 raise PreprocessError("InvalidRawSource", "batched frames must have the same length")
-            dev, stride = self._staging.upload(self.stream, [a.reshape(-1) for a in frames])
-            self.run_raw_batch(dev, width, height, dst, frame_stride=stride)
+            self.run_host_batch(frames, width, height, dst)
         elif frames is not None:
             self.run_raw_batch([DeviceBuffer.from_numpy(a.reshape(-1), self.stream) if host(a) else a for a in frames],
                                width, height, dst)
@@ -555,6 +651,7 @@ class Preprocessor:
         elif host(frame):
             dev, _ = self._staging.upload(self.stream, [frame.reshape(-1)])
             self.run_raw(dev, width, height, dst)
+            self._staging.mark_consumed(self.stream)
         else:
             self.run_raw(frame, width, height, dst)
         if consumer_stream is not None:

@@ -257,6 +257,8 @@ class ShardedPreprocessor(ShardPool):
                 raise ImageError("DeviceMismatch", f"shard {g} runs on device {self.devices[g]} but its destination lives on "
                                                    f"device {dsts[g].device_id}")
             self.shards[g].run_raw_batch(buf, src_w, src_h, dsts[g], frame_stride=frame_stride)
+            if not device_parts:
+                self.shards[g]._staging.mark_consumed(self.streams[g])   # the upload ring may reuse the slot once this launch is done
             return None
 
         self._each(run)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Pretty-print bench.py JSON lines (stdin) as a table: headline + every `also` entry (round-3 compact format)."""
+"""Pretty-print bench.py JSON lines (stdin) as a table: the headline, then every row of the line's `summary` table."""
 import json
 import sys
 
@@ -11,13 +11,17 @@ for l in sys.stdin:
     c = j.get("cpu_baseline") or {}
     print("%-56s %8.3f ms/step %10.0f Mpx/s  frac %.3f  launch %.3f ms  cpu %s x%s   [line %d chars]" % (
         j["config"]["workload"], j["ms_per_step"], j["value"], r.get("frac") or 0, r.get("mean_launch_ms") or 0, c.get("value"), c.get("cores"), len(l)))
-    for a in j.get("also", []):
-        r, c = a["roofline"], a.get("cpu_baseline") or {}
+    cols = j.get("summary_columns") or []
+    for row in (j.get("summary") or [])[1:]:
+        d = dict(zip(cols, row))
         print("  also %-51s %8.3f ms/step %10.0f Mpx/s  frac %.3f  traffic_frac %s  cpu %s x%s" % (
-            a.get("workload") or a["config"]["workload"], a["ms_per_step"], a["value"], r["frac"], r.get("traffic_frac"), c.get("value"), c.get("cores")))
+            d.get("workload"), d.get("ms_per_step") or 0, d.get("Mpx_s") or 0, d.get("roofline_frac") or 0, d.get("traffic_frac"), d.get("cpu_Mpx_s"), d.get("cpu_cores")))
     d = j.get("device", {})
     if "flat_fill_ms" in d:
         print("  ceilings: flat_fill %.3f ms, three_plane_store_only %.3f ms; kernel = %.3f of flat fill, %.3f of the three-plane stores" % (
             d["flat_fill_ms"], d["three_plane_store_only_ms"], d.get("frac_of_flat_fill", 0), d.get("frac_of_three_plane_store", 0)))
     elif "store_ceilings_error" in d:
         print("  ceilings: ERROR", d["store_ceilings_error"])
+    ex = {k: v for k, v in r.items() if k.startswith(("h2d_", "kernel_only", "end_to_end", "hidden_by", "serial_sum"))}
+    if ex:
+        print("  breakdown:", ex)

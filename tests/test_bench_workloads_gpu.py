@@ -66,6 +66,25 @@ def test_north_star_workloads(gpu_stream, bench, name, size, fmt):
                                  f"[{flat[0]}, {flat[-1]}]; got {got[k].reshape(-1)[flat[:4]].tolist()} want {want.reshape(-1)[flat[:4]].tolist()}")
 
 
+@pytest.mark.parametrize("name", ["nv12_h2d_preprocess", "nv12_h2d_preprocess_pageable"])
+def test_h2d_preprocess_workload(gpu_stream, bench, name):
+    """The capture-side workload: four steps through the upload ring (so both slots and a reused capture buffer are exercised); the
+    last step's output equals the oracle on the frames of the capture buffer it consumed."""
+    wl = bench.WORKLOADS[name](_Args)
+    wl.setup(gpu_stream)
+    for _ in range(4):
+        wl.step()
+    gpu_stream.synchronize()
+    got = _out(wl, np.float32, (3, wl.H, wl.W))
+    b = (wl.turn - 1) % wl.RING
+    for k in range(wl.N):
+        i = b * wl.N + k
+        want = O.preprocess(wl.base[31 * i: 31 * i + wl.frame_bytes], wl.W, wl.H, wl.W, wl.H, fmt="nv12", mode="stretch", mean=MEAN, std=STD)[0]
+        assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), (name, k)
+    extra = wl.roofline_extra(1e-3)   # (the host simulator's events have no resolution: only the keys are checked there)
+    assert {"h2d_only_ms", "kernel_only_ms", "end_to_end_ms", "hidden_by_overlap_ms", "end_to_end_frac_of_pinned_h2d"} <= set(extra)
+
+
 def test_lanczos_secondary_workload(gpu_stream, bench):
     wl = _run(bench, "nv12_chw_640_lanczos", gpu_stream)
     got = _out(wl, np.float32, (3, 640, 640))
@@ -200,7 +219,7 @@ def test_colour_map_workloads_1080p(gpu_stream, bench):
 
 
 def test_every_workload_is_covered(bench):
-    covered = {"nv12_chw", "nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_chw_640_lanczos", "resize_224", "resize_bicubic_540", "resize_normalize_f32_224",
+    covered = {"nv12_h2d_preprocess", "nv12_h2d_preprocess_pageable", "nv12_chw", "nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_chw_640_lanczos", "resize_224", "resize_bicubic_540", "resize_normalize_f32_224",
                "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640", "gaussian_4k", "sobel_4k", "box_blur_4k", "gaussian_u8_4k", "pyrdown_u8_4k",
                "pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_f32_1080p", "normalize_1080p",
                "warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k", "spatial_gradient_1080p", "box_blur_fast_1080p",

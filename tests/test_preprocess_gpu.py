@@ -293,25 +293,66 @@ def test_bilinear_on_whole_pixel_grid_equals_the_four_tap_kernel_and_the_oracle(
 
 
 def test_python_run_reuses_pinned_staging_in_a_frame_loop(gpu_stream):
-    """PY/cuda_ext/mod.rs:647-745: host frames go through ONE persistent page-locked buffer + device buffer
-    (grown on demand, never per call); the previous upload is waited before the pinned bytes are reused,
-    so back-to-back calls with different frames stay correct."""
+    """PY/cuda_ext/mod.rs:647-745: host frames go through PERSISTENT page-locked + device buffers (grown on demand, never per call)
+    — here a two-deep ring on a copy stream — and a slot's previous upload is waited before its pinned bytes are reused, so
+    back-to-back calls with different frames stay correct."""
     w, h = 64, 32
     pre = _pre(gpu_stream, mode="letterbox", format="nv12", **IMAGENET)
-    frames = [_raw_for("nv12", w, h, seed=7 * k) for k in range(6)]
-    outs = [pre.run(fr, w, h, 24, 40) for fr in frames]          # no sync between calls
-    assert pre._staging.allocations == 2                          # one pinned + one device allocation in total
+    frames = [_raw_for("nv12", w, h, seed=7 * k) for k in range(7)]
+    outs = [pre.run(fr, w, h, 24, 40) for fr in frames]          # no sync between calls: slots 0, 1, 0, 1, ...
+    assert pre._staging.allocations == 4                          # one pinned + one device allocation per ring slot, in total
     for fr, out in zip(frames, outs):
         want = O.preprocess(fr, w, h, 40, 24, fmt="nv12", mode="letterbox", sampling="bilinear", **IMAGENET)
         _assert_bits_equal(out.numpy()[0], want[0] if want.ndim == 4 else want, "frame loop")
-    batch = pre.run(frames[:4], w, h, 24, 40)                     # grows both buffers once
-    assert pre._staging.allocations == 4 and batch.shape == (4, 3, 24, 40)
+    batch = pre.run(frames[:4], w, h, 24, 40)                     # grows one slot's buffers
+    again = pre.run(frames[:4], w, h, 24, 40)                     # ... and the other's
+    assert pre._staging.allocations == 8 and batch.shape == (4, 3, 24, 40)
     for k in range(4):
         want = O.preprocess(frames[k], w, h, 40, 24, fmt="nv12", mode="letterbox", sampling="bilinear", **IMAGENET)
         _assert_bits_equal(batch.numpy()[k], want[0] if want.ndim == 4 else want, f"batch frame {k}")
-    again = pre.run(frames[:4], w, h, 24, 40)
-    assert pre._staging.allocations == 4
+    for _ in range(3):
+        third = pre.run(frames[:4], w, h, 24, 40)
+    assert pre._staging.allocations == 8
     _assert_bits_equal(again.numpy(), batch.numpy(), "staging reuse")
+    _assert_bits_equal(third.numpy(), batch.numpy(), "staging reuse, later turn")
+
+
+def test_staging_ring_overlaps_and_stays_ordered(gpu_stream):
+    """The ring under load: 24 back-to-back batches of DIFFERENT frames into two alternating outputs, no host sync in between — every
+    kernel must have read the upload of its own call (a slot's device buffer is not overwritten before the kernel two calls back has
+    finished; the pinned bytes are not overwritten before their DMA has).  Then the zero-copy form: frames that already live in
+    page-locked memory are DMA'd in place (no host copy, no pinned allocation)."""
+    from kornia_rs import Tensor
+    from kornia_rs.hip import PinnedBuffer
+    w, h, n = 64, 34, 6
+    fb = w * h * 3 // 2
+    pre = _pre(gpu_stream, mode="stretch", format="nv12", **IMAGENET)
+    outs = [Tensor.uninit((n, 3, h, w), "float32", gpu_stream) for _ in range(24)]
+    batches = [[_raw_for("nv12", w, h, seed=100 * r + k) for k in range(n)] for r in range(24)]
+    for r in range(24):
+        pre.run_host_batch(batches[r], w, h, outs[r])
+    for r in (0, 1, 2, 11, 22, 23):
+        got = outs[r].numpy_raw()
+        for k in range(n):
+            want = O.preprocess(batches[r][k], w, h, w, h, fmt="nv12", mode="stretch", **IMAGENET)[0]
+            _assert_bits_equal(got[k], want, f"ring round {r} frame {k}")
+    base_allocs = pre._staging.allocations
+    cap = PinnedBuffer(3 * n * fb)                                # three capture buffers of n frames each, page-locked
+    view = cap.view()
+    zc = [Tensor.uninit((n, 3, h, w), "float32", gpu_stream) for _ in range(6)]
+    for r in range(6):
+        b = r % 3
+        if r >= 3:
+            pre.wait_uploads()                                    # the capture side may rewrite a buffer once its DMA has left it
+        for k in range(n):
+            view[(b * n + k) * fb: (b * n + k + 1) * fb] = batches[r][k]
+        pre.run_host_batch([view[(b * n + k) * fb: (b * n + k + 1) * fb] for k in range(n)], w, h, zc[r])
+    assert pre._staging.zero_copy_uploads == 6 and pre._staging.allocations == base_allocs
+    for r in range(6):
+        got = zc[r].numpy_raw()
+        for k in range(n):
+            want = O.preprocess(batches[r][k], w, h, w, h, fmt="nv12", mode="stretch", **IMAGENET)[0]
+            _assert_bits_equal(got[k], want, f"zero-copy round {r} frame {k}")
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "rgb", "bgra", "yuyv", "gray"])
