@@ -78,6 +78,112 @@ __global__ __launch_bounds__(kBx* kBy) void pyrdown_f32_kernel(Pyr<float> a) {
     for (int c = 0; c < C; ++c) o[c] = sum[c];
 }
 
+// ---- pyrdown_f32, streaming wave (round 4) ------------------------------------------------------------------------------------------
+// Limiter of the per-pixel kernel above (profiles/r04a_limiter_pyrdown_f32.txt): 25 strided 12-byte loads per destination pixel put
+// 25x the source through the vector L1 — 51.8 M wave-loads per 64 4K images at ~24 address / data cycles each keep every CU's
+// texture addresser busy for the whole 2.0 ms (TA_BUSY = kernel time, 60 % of the wave-cycles are VMEM issue stalls) while HBM moves
+// 8.3 GB at 4.1 TB/s.  The round-3 attempts cut the load COUNT but paid for it in registers (146 VGPRs, 3 waves per SIMD) or in
+// dependent DPP chains.  Here a wave owns 64 adjacent flat destination floats and walks DOWN a strip, streaming the source rows once:
+//   * per source row the wave loads only its span — the pixels 2 px0 - 2 .. 2 px1 + 2 its 64 outputs tap (at most 160 floats: up to three
+//     coalesced dword loads per lane, reflect-101 applied to the loaded element's pixel index, so borders need no other code) — into a
+//     wave-private LDS row; no block barrier (DS operations of one wave execute in order);
+//   * a lane reads its 5 horizontal taps of that row from LDS and adds their products straight into the (up to) three destination rows
+//     the source row belongs to: rows arrive in increasing ky for each of them, so every output still sees the reference's 25 products
+//     in the reference's order (ky-major, `sum += v * (k1[ky] * k1[kx])`, starting from +0) — bit-identical — with THREE running sums
+//     per lane instead of a 5 x 5 register window: 10 LDS reads per output instead of 25 vector-memory loads, ~40 VGPRs.
+// A 256-thread block = 4 independent waves = 256 flat destination floats; kPdfQ source rows of loads are in flight per lane.
+constexpr int kPdfQ = 6, kPdfSpan = 160, kPdfStripMax = 360;
+struct PyrF32Roll { const float* src; float* dst; int sw, sh, dw, dh, th, C; long long ss, ds; XcdTiles tiles; };
+
+template <int C>
+__global__ __launch_bounds__(256) void pyrdown_f32_roll_kernel(PyrF32Roll a) {
+    __shared__ float rowbuf[4][kPdfSpan + 32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int rowlen_d = a.dw * C, rowlen_s = a.sw * C;
+    const int gx0 = tx * 256 + wv * 64;   // first flat destination float of this wave
+    if (gx0 >= rowlen_d) return;          // whole wave idle (no block barrier below)
+    const int Y0 = ty * a.th, nrows = min(a.th, a.dh - Y0);
+    const float* __restrict__ src = a.src + (long long)bz * a.ss;
+    float* buf = rowbuf[wv];
+
+    const int gx = gx0 + lane;
+    const bool gx_ok = gx < rowlen_d;
+    const int px0 = gx0 / C;                                  // first destination pixel this wave touches
+    const int pxl = min(gx, rowlen_d - 1) / C, ch = min(gx, rowlen_d - 1) - pxl * C;
+    const int tap0 = (2 * (pxl - px0)) * C + ch;             // LDS index of this lane's kx = 0 tap; tap kx sits kx * C further
+    // the three span elements this lane loads per source row: e = lane + 64 j <-> source pixel 2 px0 - 2 + e / C, channel e % C
+    int soff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int e = min(lane + 64 * j, kPdfSpan - 1);
+        soff[j] = reflect_101(2 * px0 - 2 + e / C, a.sw) * C + e % C;   // always inside the row
+    }
+    const bool third = lane < kPdfSpan - 128;
+
+    float q[kPdfQ][3];
+    int pf = 0;   // source walk step of the next prefetch: source row 2 Y0 - 2 + pf
+    auto prefetch = [&](float (&d)[3]) {
+        const int base = reflect_101(2 * Y0 - 2 + pf, a.sh) * rowlen_s;   // 32-bit: host-checked
+        d[0] = src[base + soff[0]];
+        d[1] = src[base + soff[1]];
+        d[2] = src[base + soff[2]];   // lanes >= 32 re-load element 159's neighbourhood (an L1 hit): no exec mask, no vmcnt(0) drain
+        ++pf;
+    };
+#pragma unroll
+    for (int p = 0; p < kPdfQ; ++p) prefetch(q[p]);
+
+    const float k1[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;   // running sums of destination rows m, m - 1, m - 2 of the walk
+    const __amdgpu_buffer_rsrc_t ow = stream_window(a.dst + (long long)bz * a.ds + (long long)Y0 * rowlen_d, (long long)(a.dh - Y0) * rowlen_d * 4);
+    int out_off = (gx - 2 * rowlen_d) * 4;   // byte offset of destination row m - 2 inside the window (negative during the warm-up: never stored)
+
+    auto stage = [&](const float (&d)[3]) {
+        buf[lane] = d[0];
+        buf[lane + 64] = d[1];
+        if (third) buf[lane + 128] = d[2];
+        __builtin_amdgcn_wave_barrier();   // one wave: DS operations execute in issue order; this only pins the compiler's order
+    };
+    // one walk step = one destination row = source rows 2 m (even: ky = 0 / 2 / 4 of rows m, m - 1, m - 2) and 2 m + 1 (odd: ky = 1 / 3)
+    const int steps = nrows + 2;
+    for (int mb = 0; mb < steps; mb += kPdfQ / 2) {
+#pragma unroll
+        for (int u = 0; u < kPdfQ / 2; ++u) {
+            const int m = mb + u;
+            float t[5];
+            // even source row
+            stage(q[2 * u]);
+            prefetch(q[2 * u]);
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) t[kx] = buf[tap0 + kx * C];
+            __builtin_amdgcn_wave_barrier();   // every lane has read the row before it is overwritten
+            s0 = 0.0f;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                s2 += t[kx] * (k1[4] * k1[kx]);
+                s1 += t[kx] * (k1[2] * k1[kx]);
+                s0 += t[kx] * (k1[0] * k1[kx]);
+            }
+            if (gx_ok && m >= 2 && m < steps) { const uint32_t bits = __float_as_uint(s2); stream_store<1>(ow, out_off, &bits); }
+            out_off += rowlen_d * 4;
+            // odd source row
+            stage(q[2 * u + 1]);
+            prefetch(q[2 * u + 1]);
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) t[kx] = buf[tap0 + kx * C];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                s1 += t[kx] * (k1[3] * k1[kx]);
+                s0 += t[kx] * (k1[1] * k1[kx]);
+            }
+            s2 = s1;
+            s1 = s0;
+        }
+    }
+}
+
 // pyrup_horizontal_pass_f32 (:22-96) at column X of one source row
 template <int C>
 __device__ __forceinline__ float pyrup_h(const float* __restrict__ row, int sw, int X, int c) {
@@ -1292,6 +1398,7 @@ int32_t check_pyr(const char* what, const T* src, T* dst, int sw, int sh, int ch
     }
 
 KH_PYR_ENTRY(kh_pyrdown_u8_direct, uint8_t, pyrdown_u8_kernel, (sw + 1) / 2, (sh + 1) / 2)  // per-pixel kernel: test option pyr_direct = 1 only
+KH_PYR_ENTRY(kh_pyrdown_f32_direct, float, pyrdown_f32_kernel, (sw + 1) / 2, (sh + 1) / 2)
 KH_PYR_ENTRY(kh_pyrup_f32_direct, float, pyrup_f32_kernel, sw * 2, sh * 2)  // per destination pixel: test option pyr_direct = 1 only
 KH_PYR_ENTRY(kh_pyrup_u8_direct, uint8_t, pyrup_u8_kernel, sw * 2, sh * 2)
 
@@ -1299,7 +1406,28 @@ KH_PYR_ENTRY(kh_pyrup_u8_direct, uint8_t, pyrup_u8_kernel, sw * 2, sh * 2)
 
 extern "C" {
 
-KH_PYR_ENTRY(kh_pyrdown_f32, float, pyrdown_f32_kernel, (sw + 1) / 2, (sh + 1) / 2)
+int32_t kh_pyrdown_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch,
+                       int64_t ss, int64_t ds) {
+    if (dev_opt(kOptPyrDirect) == 1) return kh_pyrdown_f32_direct(stream, src, dst, sw, sh, channels, batch, ss, ds);   // test option: per-pixel kernel
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    if (int32_t rc = check_pyr("kh_pyrdown_f32", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
+    if (batch == 0) return KH_OK;
+    PyrF32Roll r{src, dst, sw, sh, dw, dh, 0, channels, ss, ds, XcdTiles{}};
+    const unsigned tiles_x = cdiv(dw * channels, 256);
+    const long long cols_blocks = (long long)tiles_x * batch;
+    long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
+    const long long min_strips = cdiv(dh, kPdfStripMax), max_strips = cdiv(dh, 16);
+    strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
+    r.th = (int)cdiv(dh, strips);
+    r.tiles = xcd_tiles(tiles_x, cdiv(dh, r.th), (unsigned)batch, kXcdEighth);
+    KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrdown_f32: batch x tiles exceeds one launch");
+    const dim3 grid = xcd_grid(r.tiles), blk(256);
+    hipStream_t st = as_hip(stream);
+    if (channels == 1) hipLaunchKernelGGL(pyrdown_f32_roll_kernel<1>, grid, blk, 0, st, r);
+    else if (channels == 3) hipLaunchKernelGGL(pyrdown_f32_roll_kernel<3>, grid, blk, 0, st, r);
+    else hipLaunchKernelGGL(pyrdown_f32_roll_kernel<4>, grid, blk, 0, st, r);
+    return check_launch("kh_pyrdown_f32");
+}
 int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch,
                       int64_t ss, int64_t ds) {
     const bool direct = dev_opt(kOptPyrDirect) == 1;

@@ -50,6 +50,7 @@ def test_pyramid_fallbacks(gpu_stream, dev_option, option, value):
         assert_same_bits(pyr_gpu(gpu_stream, src, True)[0], O.pyrup(src), f"{option} pyrup_u8 {w}x{h}")
     srcf = make(131, 67, 3, np.float32, seed=5)
     assert_same_bits(pyr_gpu(gpu_stream, srcf, True)[0], O.pyrup(srcf), f"{option} pyrup_f32")
+    assert_same_bits(pyr_gpu(gpu_stream, srcf, False)[0], O.pyrdown(srcf), f"{option} pyrdown_f32")
 
 
 @pytest.mark.parametrize("option,value", [("morph_direct", 1), ("morph_roll", 0)])
