@@ -1561,7 +1561,7 @@ def main():
     wl.setup(stream)
     elapsed, kernel_ms = run.time(wl, args.steps, args.warmup)
     line, ceilings, full = None, None, {}
-    if rank == 0 and isinstance(wl, NorthStarNV12) and wl.out == 0:
+    if rank == 0 and type(wl) is NorthStarNV12 and wl.out == 0:
         ceilings = store_ceilings(hip, stream, wl.dst.data_ptr, wl.W, wl.H, wl.N)
     if rank == 0:
         rec = run.record(wl, args.steps, args.warmup, elapsed, kernel_ms, args.workload)

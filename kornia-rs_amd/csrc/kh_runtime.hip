@@ -385,6 +385,16 @@ int32_t kh_stream_set_workspace(kh_stream_t stream, void* device_ptr, size_t byt
     // The entry belongs to the CURRENT device (the one `stream` was created on; hosts select it before the call, as for every
     // launch).  A buffer that lives on another device is refused instead of being handed to kernels that cannot reach it.
     const int dev = current_device_or_zero();
+    if (stream) {   // a created stream knows its device: a registration made with another device selected would be filed where no
+                    // launch on this stream ever looks — refuse it instead of losing the workspace silently
+        hipDevice_t sdev = 0;
+        if (hipStreamGetDevice(as_hip(stream), &sdev) == hipSuccess) {
+            KH_REQUIRE((int)sdev == dev, KH_ERR_INVALID_ARG,
+                       "kh_stream_set_workspace: the stream belongs to device %d but device %d is current — select the stream's device first", (int)sdev, dev);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (device_ptr) {
         hipPointerAttribute_t at{};
         if (hipPointerGetAttributes(&at, device_ptr) == hipSuccess) {

@@ -49,6 +49,14 @@ struct DevTable {
         }
         std::lock_guard<std::mutex> lock(use_mu_);
         auto it = last_use_.find(stream);
+        if (it == last_use_.end() && last_use_.size() >= kMaxFences) {
+            // A long-lived table in a process that creates and destroys many streams must not collect one event per stream handle it
+            // ever saw: fences whose launch has completed protect nothing any more — drop them before adding another.
+            for (auto f = last_use_.begin(); f != last_use_.end();) {
+                if (hipEventQuery(f->second) == hipSuccess) { (void)hipEventDestroy(f->second); f = last_use_.erase(f); }
+                else { (void)hipGetLastError(); ++f; }
+            }
+        }
         if (it == last_use_.end()) {
             hipEvent_t ev = nullptr;
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {  // no fence possible: make the user wait now
@@ -62,6 +70,7 @@ struct DevTable {
     }
 
 private:
+    static constexpr size_t kMaxFences = 8;
     std::mutex use_mu_;
     std::map<hipStream_t, hipEvent_t> last_use_;
 };

@@ -219,7 +219,28 @@ def mapped_hip_runtimes() -> dict:
     return {k: sorted(v) for k, v in found.items()}
 
 
-_RUNTIME_CHECKED_AT = -1  # len(sys.modules) at the last check that found a single runtime
+_RUNTIME_CHECKED_AT = None  # loaded_objects_key() at the last check that found a single runtime
+
+_PHDR_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+def loaded_objects_key():
+    """(number of shared objects mapped into the process, xor of their load addresses) from ``dl_iterate_phdr`` — tens of
+    microseconds, and it changes with EVERY dlopen / dlclose, whoever performs it (a Python import, ``ctypes.CDLL`` from an
+    already-imported module, a lazy native load inside another library).  ``None`` where the libc has no ``dl_iterate_phdr``."""
+    try:
+        libc = C.CDLL(None)
+        acc = [0, 0]
+
+        def cb(info, _size, _data):
+            acc[0] += 1
+            acc[1] ^= C.cast(info, C.POINTER(C.c_size_t))[0]   # dl_phdr_info.dlpi_addr is the first member
+            return 0
+
+        libc.dl_iterate_phdr(_PHDR_CB(cb), None)
+        return tuple(acc)
+    except (OSError, AttributeError, ValueError):
+        return None
 
 
 class MultipleHipRuntimes(RuntimeError):
@@ -231,16 +252,16 @@ def assert_single_runtime() -> None:
     or from another library (DLPack / ``__cuda_array_interface__`` import and export): that is the only way a second
     runtime can enter a process that loaded this package first with ``KORNIA_HIP_RUNTIME=system``."""
     # /proc/self/maps has thousands of lines once torch is loaded and this sits on the per-frame zero-copy path: re-parse only
-    # when the set of loaded Python modules could have brought in a new native library (a second runtime can only arrive with
-    # an import), i.e. when sys.modules has grown since the last clean check (ADVICE r02).
+    # when the set of MAPPED IMAGES has changed since the last clean check.  (Round 3 keyed this on len(sys.modules); a second
+    # runtime can arrive without that changing — ctypes.CDLL from an imported module, a lazy native load — ADVICE r03.)
     global _RUNTIME_CHECKED_AT
-    n_mod = len(sys.modules)
-    if _RUNTIME_CHECKED_AT == n_mod:
+    key = loaded_objects_key()
+    if key is not None and _RUNTIME_CHECKED_AT == key:
         return
     rt = mapped_hip_runtimes()
     dup = {k: v for k, v in rt.items() if len(v) > 1}
     if not dup:
-        _RUNTIME_CHECKED_AT = n_mod
+        _RUNTIME_CHECKED_AT = key
     if dup:
         raise MultipleHipRuntimes(
             f"two HIP/HSA runtimes are mapped into this process: {dup}.  Copies and stream waits issued through one do not "

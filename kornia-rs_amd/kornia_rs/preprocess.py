@@ -272,9 +272,7 @@ class _Staging:
             slot.device = DeviceBuffer(total, stream, zeroed=False)   # stream-ordered on the COMPUTE stream ...
             self.allocations += 1
         if not zero_copy:
-            view = slot.pinned.view()
-            for k, fr in enumerate(frames):
-                view[k * stride: k * stride + frame_len] = fr
+            self._host_copy(slot.pinned, frames, frame_len, stride)
         # the copy stream may write the slot's device buffer once (a) a fresh allocation exists there and (b) the kernel that last
         # read the buffer has finished; both are events of the compute stream
         if fresh_device or (slot.used and slot.consumed is None):
@@ -300,6 +298,34 @@ class _Staging:
         check(lib.kh_stream_wait_event(stream.cuda_stream_ptr, ev._handle))   # the kernel of THIS call waits for THIS upload only
         slot.used, slot.consumed = True, None
         return _DeviceView(slot.device, frame_len if len(frames) == 1 else total), stride
+
+    _copy_pool = None   # shared by every preprocessor of the process: eight memcpy workers
+
+    @classmethod
+    def _host_copy(cls, pinned, frames, frame_len: int, stride: int) -> None:
+        """Pageable frames -> the slot's page-locked buffer.  One thread moves ~25 GB/s here, half of what the host link takes
+        (57 GB/s measured, profiles/r04e): above 4 MiB the frames are split over eight workers (ctypes.memmove drops the GIL)."""
+        import ctypes
+        total = frame_len * len(frames)
+        srcs = [np.ascontiguousarray(fr) for fr in frames]
+        if total < (4 << 20) or len(frames) < 2:
+            view = pinned.view()
+            for k, fr in enumerate(srcs):
+                view[k * stride: k * stride + frame_len] = fr
+            return
+        if cls._copy_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            cls._copy_pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="kornia-stage")
+        base = pinned.ptr
+
+        def move(lo, hi):
+            for k in range(lo, hi):
+                ctypes.memmove(base + k * stride, srcs[k].ctypes.data, frame_len)
+
+        n, w = len(srcs), 8
+        futs = [cls._copy_pool.submit(move, n * i // w, n * (i + 1) // w) for i in range(w)]
+        for f in futs:
+            f.result()
 
     def mark_consumed(self, stream: Stream) -> None:
         """Call after the kernel that reads the last ``upload`` has been enqueued on ``stream``."""

@@ -169,6 +169,9 @@ hipError_t hipMemGetInfo(size_t* f, size_t* t);
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
 hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);
 hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* status);
+typedef int hipDevice_t;
+hipError_t hipStreamGetDevice(hipStream_t s, hipDevice_t* device);
+hipError_t hipEventQuery(hipEvent_t e);
 hipError_t hipGraphGetNodes(hipGraph_t g, hipGraphNode_t* nodes, size_t* n);
 hipError_t hipGraphDestroy(hipGraph_t g);
 hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t* err, char* log, size_t n);

@@ -180,6 +180,8 @@ hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
     hostsim::g_capture = nullptr;
     return hipSuccess;
 }
+hipError_t hipStreamGetDevice(hipStream_t, hipDevice_t* device) { *device = 0; return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* status) {
     *status = hostsim::g_capture ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone;
     return hipSuccess;

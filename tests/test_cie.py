@@ -48,7 +48,7 @@ def test_black_and_white_known_values():  # mod.rs:243-275
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(O.CIE))
-def test_device_cie_matches_oracle(gpu_stream, name):
+def test_device_cie_matches_oracle(gpu_stream, name, libm_agrees):
     from kornia_rs import _ffi
     from gpu_util import assert_same_bits, dev, out_buf
     rng = np.random.default_rng(11)
@@ -62,9 +62,14 @@ def test_device_cie_matches_oracle(gpu_stream, name):
     _ffi.check(_ffi.lib.kh_cie_convert_f32(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, src.size // 3, O.CIE[name]))
     got = d_dst.to_numpy(np.float32, src.shape)
     want32 = O.cie(name, src)
-    # Bit-identical for every conversion since round 3: the device evaluates glibc 2.35's powf / cbrtf (csrc/kh_libm_glibc.h), the
-    # functions the restatement calls, instead of the device library's (2e-4 + 2e-5 |v| in round 2).
-    assert_same_bits(got, want32, name)
+    # Bit-identical for every conversion WHERE THE BOX'S LIBM IS THE RESTATED ONE: the device evaluates glibc 2.35's powf / cbrtf
+    # (csrc/kh_libm_glibc.h), the functions the restatement calls here, instead of the device library's.  Parity must not depend on
+    # the test box's libm release (another glibc, an FMA-dispatched powf, musl, aarch64): when the host check below reports any
+    # difference, the bound is round 2's 2e-4 + 2e-5 |v| — far inside the reference's own CIE tolerances (P/color/cie/mod.rs:150-341).
+    if libm_agrees:
+        assert_same_bits(got, want32, name)
+    else:
+        assert np.all(np.abs(got.astype(np.float64) - want32) <= 2e-4 + 2e-5 * np.abs(want32)), name
     want64 = O.cie(name, src.astype(np.float64))
     tol = np.array(TOL.get(name, [1e-3] * 3))
     assert np.all(np.abs(got.astype(np.float64) - want64).reshape(-1, 3).max(axis=0) <= tol)
@@ -103,12 +108,31 @@ def libm_host(tmp_path_factory):
     return lib
 
 
+def _libm_mismatches(lib) -> int:
+    """How many of the sampled arguments the restated powf / cbrtf and THIS box's libm disagree on (0 on glibc 2.35 x86-64)."""
+    import ctypes as C
+    first = C.c_uint32(0)
+    bad = 0
+    for y in (2.4, 1.0 / 2.4, 3.0):
+        bad += lib.host_check_powf(y, 0x30800000, 0x4E800001, 1009, C.byref(first))
+    bad += lib.host_check_cbrtf(0x00000001, 0x7F800000, 4093, C.byref(first))
+    return int(bad)
+
+
+@pytest.fixture(scope="module")
+def libm_agrees(libm_host):
+    return _libm_mismatches(libm_host) == 0
+
+
 def test_restated_powf_and_cbrtf_equal_this_boxes_libm(libm_host):
     """csrc/kh_libm_glibc.h (generated by scripts/gen_libm_tables.py from glibc 2.35's tables and algorithm) is what the device
     evaluates for the sRGB transfer and the Lab / Luv cube roots.  Here it is built for the host and compared with the libm the
     restatement (and the reference's f32::powf / f32::cbrt) use on this box, bit for bit: ~3.5 M arguments per exponent over the
     whole admitted domain, ~4.4 M cube roots over every binade incl. subnormals and negatives."""
     import ctypes as C
+    import platform
+    if _libm_mismatches(libm_host) and platform.libc_ver() != ("glibc", "2.35"):
+        pytest.skip(f"this box's libm is {platform.libc_ver()}, not the glibc 2.35 the tables restate: the device tests use the tolerance bound here")
     first = C.c_uint32(0)
     for y in (2.4, 1.0 / 2.4, 3.0, 0.37, -1.7):
         bad = libm_host.host_check_powf(y, 0x30800000, 0x4E800001, 143, C.byref(first))
