@@ -69,6 +69,7 @@ class Stream:
         self._handle = int(handle)
         self.device = int(device)
         self._owned = owned
+        self._workspace = None   # owned streams: the registered scratch buffer (set_workspace)
 
     @staticmethod
     def new(device: int = 0) -> "Stream":
@@ -128,12 +129,19 @@ class Stream:
                 check(lib.kh_stream_set_workspace(self._handle, buf.ptr, buf.nbytes))
         finally:
             set_device(prev)
-        old = _WORKSPACES.pop(key, None)
+        old = _WORKSPACES.pop(key, None) or getattr(self, "_workspace", None)
         if old is not None:
             old._ws_keys.discard(key)
+        self._workspace = None
         if buf is not None:
-            _WORKSPACES[key] = buf
             buf._ws_keys.add(key)
+            if self._owned:
+                # An OWNED stream is one Python object: it keeps its workspace alive itself.  stream -> buf -> buf.stream is then
+                # an ordinary reference cycle the collector can reclaim; a module-global entry would pin all three for the life
+                # of the process — a service creating a stream + workspace per request leaked both.
+                self._workspace = buf
+            else:
+                _WORKSPACES[key] = buf   # default / adopted handles: wrappers are temporaries, the registration must outlive them
 
     @property
     def cuda_stream_ptr(self) -> int:
@@ -147,9 +155,13 @@ class Stream:
     def __del__(self):
         if getattr(self, "_owned", False) and self._handle:
             try:
-                old = _WORKSPACES.pop((self.device, self._handle), None)  # kh_stream_destroy erases the C entry
+                key = (self.device, self._handle)
+                old = _WORKSPACES.pop(key, None) or getattr(self, "_workspace", None)  # kh_stream_destroy erases the C entry
+                self._workspace = None
                 if old is not None:
-                    old._ws_keys.discard((self.device, self._handle))
+                    old._ws_keys.discard(key)
+                    if getattr(old, "stream", None) is self:
+                        old.free()   # collected together with this stream: release it while the stream it frees on still exists
                 lib.kh_stream_destroy(self._handle)
             except Exception:
                 pass
@@ -230,27 +242,40 @@ class Graph:
             lib.kh_graph_destroy(h)
 
 
-_STAGE_BYTES = 16 << 20
+_STAGE_BYTES = 16 << 20          # page-locked bounce memory per copying thread, used as two halves
+_PIECE = _STAGE_BYTES // 2
 _stage_local = threading.local()
 
 
 def _stage() -> "PinnedBuffer":
-    """This thread's page-locked bounce buffer for pageable host <-> device copies (16 MiB, allocated on first use, freed with the
-    thread).  Per thread: the sharders upload from one worker thread per device at the same time."""
+    """This thread's page-locked bounce buffer for pageable host <-> device copies (16 MiB = two 8 MiB halves, allocated on first
+    use; ``release_thread_staging`` or the end of the thread frees it).  Per thread: the sharders upload from one worker thread
+    per device at the same time."""
     buf = getattr(_stage_local, "buf", None)
     if buf is None:
         buf = _stage_local.buf = PinnedBuffer(_STAGE_BYTES)
+        _stage_local.events = (Event(timing=False), Event(timing=False))
     return buf
 
 
+def release_thread_staging() -> None:
+    """Free the calling thread's bounce buffer (``ShardPool.close`` runs this on every worker: a pool that is shut down must not
+    keep 16 MiB pinned per worker for the life of the process)."""
+    buf = getattr(_stage_local, "buf", None)
+    _stage_local.buf = None
+    _stage_local.events = None
+    if buf is not None:
+        buf.free()
+
+
 def d2h(out: np.ndarray, device_ptr: int, stream: Stream) -> None:
-    """Device -> pageable host copy (to_host, crates/kornia-tensor/src/cuda.rs:1258-1300), staged through page-locked memory in
-    16 MiB pieces: every transfer the runtime sees is a true stream-ordered DMA into pinned memory, followed by a host memcpy.
-    Handing the runtime a large PAGEABLE destination instead was seen to complete `hipStreamSynchronize` with a hole in the data
-    (round 1: a 4 - 16 MiB run of stale bytes in a 48 MiB copy; once more in round 3 under four concurrent processes, r03m, with a
-    single HIP runtime mapped) and small pageable copies were seen overtaking kernels queued on the stream — neither can happen to
-    a pinned DMA.  The stream is drained before the first piece (the producer kernels) and after every piece (the bounce buffer is
-    reused)."""
+    """Device -> pageable host copy (to_host, crates/kornia-tensor/src/cuda.rs:1258-1300), staged through page-locked memory:
+    every transfer the runtime sees is a true stream-ordered DMA into pinned memory, followed by a host memcpy.  Handing the runtime
+    a large PAGEABLE destination instead was seen to complete `hipStreamSynchronize` with a hole in the data (round 1: a 4 - 16 MiB
+    run of stale bytes in a 48 MiB copy; once more in round 3 under four concurrent processes, r03m, with a single HIP runtime
+    mapped) and small pageable copies were seen overtaking kernels queued on the stream — neither can happen to a pinned DMA.
+    Double-buffered (round 4): the DMA of piece k + 1 into one half runs while the host copies piece k out of the other; each
+    half has its own event, host-waited before the half is read.  The stream is drained once, before the first piece."""
     if out.nbytes == 0:
         return
     flat = out.reshape(-1).view(np.uint8) if out.flags["C_CONTIGUOUS"] else None
@@ -260,29 +285,43 @@ def d2h(out: np.ndarray, device_ptr: int, stream: Stream) -> None:
         out[...] = tmp
         return
     stage = _stage()
-    view = stage.view()
-    stream.synchronize()
-    for off in range(0, flat.size, _STAGE_BYTES):
-        n = min(_STAGE_BYTES, flat.size - off)
-        check(lib.kh_memcpy_d2h_async(stage.ptr, device_ptr + off, n, stream.cuda_stream_ptr))
-        stream.synchronize()
-        flat[off:off + n] = view[:n]
+    view, events = stage.view(), _stage_local.events
+    stream.synchronize()   # the producer kernels
+    pieces = [(off, min(_PIECE, flat.size - off)) for off in range(0, flat.size, _PIECE)]
+
+    def issue(i):
+        off, n = pieces[i]
+        check(lib.kh_memcpy_d2h_async(stage.ptr + (i & 1) * _PIECE, device_ptr + off, n, stream.cuda_stream_ptr))
+        events[i & 1].record(stream)
+
+    issue(0)
+    for i, (off, n) in enumerate(pieces):
+        if i + 1 < len(pieces):
+            issue(i + 1)           # the other half: its previous contents were copied out in iteration i - 1
+        events[i & 1].synchronize()
+        h = (i & 1) * _PIECE
+        flat[off:off + n] = view[h:h + n]
 
 
 def h2d(device_ptr: int, a: np.ndarray, stream: Stream) -> None:
-    """Pageable host -> device copy through the same page-locked bounce buffer (see d2h)."""
+    """Pageable host -> device copy through the same two-half page-locked bounce buffer (see d2h): the host fills one half while the
+    DMA of the other is in flight; a half is refilled only after the event of its last DMA."""
     a = np.ascontiguousarray(a)
     if a.nbytes == 0:
         return
     flat = a.reshape(-1).view(np.uint8)
     stage = _stage()
-    view = stage.view()
+    view, events = stage.view(), _stage_local.events
     stream.synchronize()   # a queued memset / kernel on this stream must not be overtaken
-    for off in range(0, flat.size, _STAGE_BYTES):
-        n = min(_STAGE_BYTES, flat.size - off)
-        view[:n] = flat[off:off + n]
-        check(lib.kh_memcpy_h2d_async(device_ptr + off, stage.ptr, n, stream.cuda_stream_ptr))
-        stream.synchronize()   # the bounce buffer is reused by the next piece / the next call
+    for i, off in enumerate(range(0, flat.size, _PIECE)):
+        n = min(_PIECE, flat.size - off)
+        h = (i & 1) * _PIECE
+        if i >= 2:
+            events[i & 1].synchronize()   # the DMA that last read this half
+        view[h:h + n] = flat[off:off + n]
+        check(lib.kh_memcpy_h2d_async(device_ptr + off, stage.ptr + h, n, stream.cuda_stream_ptr))
+        events[i & 1].record(stream)
+    stream.synchronize()   # the bounce buffer is reused by the next call
 
 
 def _stream_handle(stream: Optional[Stream]) -> int:
@@ -398,6 +437,8 @@ class DeviceBuffer:
                 finally:
                     set_device(prev)
                 _WORKSPACES.pop((dev, handle), None)
+                if getattr(self.stream, "_workspace", None) is self:
+                    self.stream._workspace = None
             self._ws_keys = set()
             lib.kh_free_async(self.ptr, self.stream.cuda_stream_ptr)
             self.ptr = 0

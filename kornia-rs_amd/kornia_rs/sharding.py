@@ -97,6 +97,11 @@ class ShardPool:
         return len(self.devices)
 
     def close(self) -> None:
+        from . import hip
+        try:   # every worker lets go of its page-locked bounce buffer (hip.d2h / hip.h2d pin 16 MiB per copying thread)
+            list(self._pool.map(lambda _g: hip.release_thread_staging(), range(self.world)))
+        except RuntimeError:
+            pass   # already shut down
         self._pool.shutdown(wait=True)
 
     def __del__(self):

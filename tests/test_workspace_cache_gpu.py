@@ -162,3 +162,23 @@ def test_destroying_a_stream_drops_its_workspace():
     _ffi.check(_ffi.lib.kh_stream_destroy(h))
     _ffi.check(_ffi.lib.kh_stream_workspace_bytes(h, C.byref(n)))  # a map lookup by value; the handle is not dereferenced
     assert n.value == 0
+
+
+def test_a_dropped_stream_and_its_workspace_are_collected():
+    """the usual pattern `ws = DeviceBuffer(n, s); s.set_workspace(ws)` made a module-global table pin ws -> s for the
+    life of the process, so a service that creates a stream + workspace per request leaked both.  An owned stream now holds its
+    workspace itself: dropping the two objects leaves a plain cycle the collector reclaims (stream destroyed, buffer freed)."""
+    import gc
+    import weakref
+    from kornia_rs import hip
+    from kornia_rs.hip import DeviceBuffer
+    refs = []
+    for _ in range(8):
+        s = hip.Stream.new(0)
+        ws = DeviceBuffer(1 << 20, s, zeroed=False)
+        s.set_workspace(ws)
+        assert _registered(s) == 1 << 20 and (0, s.cuda_stream_ptr) not in hip._WORKSPACES
+        refs.append((weakref.ref(s), weakref.ref(ws)))
+        del s, ws
+    gc.collect()
+    assert all(rs() is None and rw() is None for rs, rw in refs)
