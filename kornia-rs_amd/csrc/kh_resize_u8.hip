@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBx* kBy) void bilinear_u8_kernel(Rz a) {
 }
 
 // ---- separable Q14 ------------------------------------------------------------------------------------
-struct SepTab { const int32_t* ofs; const int16_t* w; int k, kp, span64; };  // k taps; rows of kp = roundup(k, 4) weights (zero padded); span64: see get_tab
+struct SepTab { const int32_t* ofs; const int16_t* w; int k, kp, span64; const int32_t* aofs; const uint32_t* w8; int kp8, span8; };  // aofs / w8 / kp8 / span8: sep_h_u8_dot4_kernel  // k taps; rows of kp = roundup(k, 4) weights (zero padded); span64: see get_tab
 
 // horizontal_row_scalar (kernels.rs:403-425): (x, source row) -> i16
 template <int C>
@@ -278,6 +278,101 @@ __global__ __launch_bounds__(256) void sep_h_u8_tile_kernel(Rz a, int16_t* __res
         int16_t* o = hbuf + (((long long)bz_ * a.sh + sy0 + r) * a.dw + x) * C;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) o[ch] = (int16_t)min(max((acc[i][ch] + 8192) >> 14, -32768), 32767);
+    }
+}
+
+// horizontal pass, planar i8 + v_dot4 (round 4).  profiles/r04a_limiter_resize_u8.txt: the kernel above spends 1849 vector instructions per
+// wave-tile — 3.4 per multiply-add — and 75 % of its LDS cycles in bank conflicts: per four taps of one row it reads C + 1 dwords of
+// INTERLEAVED bytes, re-aligns them (v_alignbyte), picks pixel pairs out per channel (v_perm) and only then multiplies (v_dot2).  Here
+// the staging pass de-interleaves once: LDS holds each source row as C PLANES of signed bytes p - 128, and a destination column's
+// taps are read as aligned 8-byte runs of ONE plane that feed v_dot4_i32_i8 directly:
+//   * the tap window of column x is widened down to a multiple of 8 source pixels (aofs[x] = ofs[x] & ~7) and its weight row is
+//     shifted to match, the new leading / trailing taps being ZERO weights (kp8 = roundup8(k + 7) taps): every LDS read is an
+//     aligned ds_read_b64, no v_alignbyte, no v_perm;
+//   * a Q14 weight w is split on the host into w = 256 * wh + wl with wl, wh signed bytes, so that
+//         sum p w = 256 * dot4(p - 128, wh) + dot4(p - 128, wl) + 128 * sum w,   sum w == 16384 exactly (precompute_contribs),
+//     all in i32 — the same integer as the reference's scalar sum, so the i16 intermediate is byte-identical;
+//   * one 16-byte weight load (8 wl + 8 wh) serves the thread's four rows x C channels: 4 v_dot4 per 8 taps per (row, channel) =
+//     0.5 vector instructions per multiply-add.
+// Tile, thread mapping and edge handling (per-byte staging with the reference's clamp) are those of the kernel above.
+template <int C>
+__device__ __forceinline__ uint32_t plane4(const uint32_t (&d)[C], int c) {   // bytes c, C + c, 2C + c, 3C + c of the 4 C-byte pixels in d[]
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = j * C + c;
+        r |= ((d[b >> 2] >> (8 * (b & 3))) & 0xFFu) << (8 * j);
+    }
+    return r;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __restrict__ hbuf, SepTab tx, int pitchp) {
+    uint8_t* S = kh_sep_lds;  // [kSepRows][C][pitchp] signed bytes (p - 128)
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int X0 = bx_ * kSepTX, sy0 = by_ * kSepRows;
+    const int p0a = tx.aofs[X0], span = tx.aofs[min(X0 + kSepTX, a.dw) - 1] + tx.kp8 - p0a;   // block-uniform, multiples of 8
+    const int nrows = min(kSepRows, a.sh - sy0);
+    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
+    const bool inside = p0a >= 0 && p0a + span <= a.sw;   // every staged pixel exists: whole 4-pixel groups, no clamp
+    for (int r = wave; r < nrows; r += 4) {
+        uint8_t* row = S + r * (C * pitchp);
+        const uint8_t* grow = src + (long long)(sy0 + r) * a.sw * C;
+        if (inside) {
+            for (int q = lane; q < (span >> 2); q += 64) {
+                const uint8_t* g = grow + (long long)(p0a + 4 * q) * C;
+                uint32_t d[C];
+#pragma unroll
+                for (int j = 0; j < C; ++j) d[j] = *reinterpret_cast<const u32_unaligned*>(g + 4 * j);
+#pragma unroll
+                for (int c = 0; c < C; ++c) *reinterpret_cast<uint32_t*>(row + c * pitchp + 4 * q) = plane4<C>(d, c) ^ 0x80808080u;
+            }
+        } else {
+            for (int j = lane; j < span * C; j += 64) {
+                const int px = j / C, c = j - px * C;
+                row[c * pitchp + px] = grow[min(max(p0a + px, 0), a.sw - 1) * C + c] ^ 0x80u;  // build_xsrc_lut, common.rs:127-137
+            }
+        }
+    }
+    __syncthreads();
+    const int x = X0 + lane;
+    if (x >= a.dw) return;
+    const int rel = tx.aofs[x] - p0a;   // multiple of 8
+    const int steps = tx.kp8 >> 3;
+    const u32x4_t* wrow = reinterpret_cast<const u32x4_t*>(tx.w8) + (long long)x * steps;
+    int rowo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowo[i] = min(wave * 4 + i, nrows - 1) * (C * pitchp) + rel;   // rows past the image repeat the last one and are not stored
+    int32_t al[4][C], ah[4][C];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < C; ++c) { al[i][c] = 0; ah[i][c] = 0; }
+    for (int s8 = 0; s8 < steps; ++s8) {
+        const u32x4_t w = wrow[s8];   // {wl[0..3], wl[4..7], wh[0..3], wh[4..7]}
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const u32x2_t p = *reinterpret_cast<const u32x2_t*>(kh_sep_lds + rowo[i] + c * pitchp + 8 * s8);
+                al[i][c] = __builtin_amdgcn_sdot4((int)p.x, (int)w.x, al[i][c], false);
+                al[i][c] = __builtin_amdgcn_sdot4((int)p.y, (int)w.y, al[i][c], false);
+                ah[i][c] = __builtin_amdgcn_sdot4((int)p.x, (int)w.z, ah[i][c], false);
+                ah[i][c] = __builtin_amdgcn_sdot4((int)p.y, (int)w.w, ah[i][c], false);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 4 + i;
+        if (r >= nrows) break;
+        int16_t* o = hbuf + (((long long)bz_ * a.sh + sy0 + r) * a.dw + x) * C;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            const int32_t acc = ah[i][ch] * 256 + al[i][ch] + (128 << 14);
+            o[ch] = (int16_t)min(max((acc + 8192) >> 14, -32768), 32767);
+        }
     }
 }
 
@@ -509,13 +604,37 @@ int32_t get_tab(int src_size, int dst_size, int filt, bool aa, hipStream_t strea
         for (int i = 0; i < dst_size; ++i) std::copy(wk.begin() + (size_t)i * k, wk.begin() + (size_t)(i + 1) * k, w.begin() + (size_t)i * kp);
         int span64 = 0;                      // widest source span (pixels) one tile of kSepTX destination columns taps
         for (int x0 = 0; x0 < dst_size; x0 += kSepTX) span64 = std::max(span64, ofs[std::min(x0 + kSepTX, dst_size) - 1] + kp - ofs[x0]);
-        t.meta[0] = k; t.meta[1] = dst_size; t.meta[2] = kp; t.meta[3] = span64;
+        // sep_h_u8_dot4_kernel: windows widened down to multiples of 8 source pixels, weights shifted to match (zero taps around them) and
+        // split into signed bytes w = 256 wh + wl; per column and 8 taps: wl[0..7] then wh[0..7] (16 bytes)
+        const int kp8 = (k + 7 + 7) & ~7, steps = kp8 / 8;
+        std::vector<int32_t> aofs(dst_size);
+        std::vector<int8_t> w8((size_t)dst_size * steps * 16, 0);
+        for (int i = 0; i < dst_size; ++i) {
+            aofs[i] = ofs[i] & ~7;   // rounds towards -inf for negative offsets too (two's complement)
+            const int shift = ofs[i] - aofs[i];
+            for (int t_ = 0; t_ < k; ++t_) {
+                const int wq = wk[(size_t)i * k + t_], j = shift + t_;
+                const int wl = ((wq + 128) & 255) - 128, wh = (wq - wl) / 256;   // wl in [-128, 127]; |wh| <= 127 for any i16 weight below 32640
+                w8[((size_t)i * steps + j / 8) * 16 + (j & 7)] = (int8_t)wl;
+                w8[((size_t)i * steps + j / 8) * 16 + 8 + (j & 7)] = (int8_t)wh;
+            }
+        }
+        int span8 = 0;
+        for (int x0 = 0; x0 < dst_size; x0 += kSepTX) span8 = std::max(span8, aofs[std::min(x0 + kSepTX, dst_size) - 1] + kp8 - aofs[x0]);
+        int wmax = 0;
+        for (int16_t v : wk) wmax = std::max(wmax, abs((int)v));
+        t.meta[0] = k; t.meta[1] = dst_size; t.meta[2] = kp; t.meta[3] = span64; t.meta[4] = kp8; t.meta[5] = wmax < 32640 ? span8 : 0;   // span8 0: the split does not fit signed bytes
         ofs.resize((ofs.size() + 3) & ~(size_t)3, 0);  // the weight block starts 16-byte aligned
-        const size_t ofs_bytes = sizeof(int32_t) * ofs.size(), w_bytes = sizeof(int16_t) * w.size();
-        t.bytes = ofs_bytes + w_bytes;
+        aofs.resize((aofs.size() + 3) & ~(size_t)3, 0);
+        w.resize((w.size() + 7) & ~(size_t)7, 0);      // ... and so do the two blocks after it
+        const size_t ofs_bytes = sizeof(int32_t) * ofs.size(), w_bytes = sizeof(int16_t) * w.size(), aofs_bytes = sizeof(int32_t) * aofs.size();
+        t.meta[6] = (int)(ofs_bytes + w_bytes); t.meta[7] = (int)(ofs_bytes + w_bytes + aofs_bytes);
+        t.bytes = ofs_bytes + w_bytes + aofs_bytes + w8.size();
         KH_HIP(hipMalloc(&t.dev, t.bytes));
         hipError_t err = hipMemcpy(t.dev, ofs.data(), ofs_bytes, hipMemcpyHostToDevice);
         if (err == hipSuccess) err = hipMemcpy((char*)t.dev + ofs_bytes, w.data(), w_bytes, hipMemcpyHostToDevice);
+        if (err == hipSuccess) err = hipMemcpy((char*)t.dev + t.meta[6], aofs.data(), aofs_bytes, hipMemcpyHostToDevice);
+        if (err == hipSuccess) err = hipMemcpy((char*)t.dev + t.meta[7], w8.data(), w8.size(), hipMemcpyHostToDevice);
         if (err != hipSuccess) return fail_hip(err, "hipMemcpy (resize contribution table)");  // ~DevTable frees the allocation
         return KH_OK;
     }, lease);
@@ -523,6 +642,9 @@ int32_t get_tab(int src_size, int dst_size, int filt, bool aa, hipStream_t strea
     out.ofs = (const int32_t*)lease->dev;
     out.w = (const int16_t*)((const char*)lease->dev + sizeof(int32_t) * (((size_t)lease->meta[1] + 3) & ~(size_t)3));
     out.k = lease->meta[0]; out.kp = lease->meta[2]; out.span64 = lease->meta[3];
+    out.kp8 = lease->meta[4]; out.span8 = lease->meta[5];
+    out.aofs = (const int32_t*)((const char*)lease->dev + lease->meta[6]);
+    out.w8 = (const uint32_t*)((const char*)lease->dev + lease->meta[7]);
     return KH_OK;
 }
 
@@ -554,7 +676,27 @@ Rz make_rz(const void* src, void* dst, int sw, int sh, int dw, int dh, int64_t s
 // horizontal pass: the LDS-staged kernel when its tile fits 64 KiB, else (or with test option resize_u8_gather = 1) the gather
 int32_t launch_sep_h(hipStream_t st, const void* src, int sw, int sh, int dw, int dh, int channels, int batch, int64_t ss,
                      int16_t* hbuf, const SepTab& tx, const char* what) {
-    const bool gather = dev_opt(kOptResizeU8Gather) == 1;  // test option: the gather kernel (the fallback for spans beyond 64 KiB of LDS)
+    const bool gather = dev_opt(kOptResizeU8Gather) == 1;
+    const int opt = dev_opt(kOptResizeU8Gather);   // test option: 1 = the gather kernel, 2 = the round-2 interleaved-bytes tile kernel
+    const int pitchp = tx.span8 + 8;   // multiple of 8
+    const size_t lds8 = (size_t)pitchp * channels * kSepRows;
+    if (opt < 1 && tx.span8 > 0 && lds8 <= 64 * 1024 && channels != 2) {
+        Rz ah = make_rz(src, nullptr, sw, sh, dw, dh, ss, 0, batch, dw, sh);
+        ah.tiles = xcd_tiles(cdiv(dw, kSepTX), cdiv(sh, kSepRows), (unsigned)batch, cdiv(dw, kSepTX) * 8);
+        if (ah.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        const dim3 grid = xcd_grid(ah.tiles), blk(256);
+        if (lds8 > 48 * 1024) {
+            if (channels == 1) KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_dot4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            else if (channels == 3) KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_dot4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            else KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_dot4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        }
+        switch (channels) {
+            case 1: hipLaunchKernelGGL(sep_h_u8_dot4_kernel<1>, grid, blk, lds8, st, ah, hbuf, tx, pitchp); break;
+            case 3: hipLaunchKernelGGL(sep_h_u8_dot4_kernel<3>, grid, blk, lds8, st, ah, hbuf, tx, pitchp); break;
+            default: hipLaunchKernelGGL(sep_h_u8_dot4_kernel<4>, grid, blk, lds8, st, ah, hbuf, tx, pitchp); break;
+        }
+        return KH_OK;
+    }
     const int pitch = (((tx.span64 * channels + 3) + 3) & ~3) + 8;
     const size_t lds = (size_t)pitch * kSepRows;
     if (!gather && lds <= 64 * 1024) {

@@ -86,6 +86,7 @@ inline uint32_t hostsim_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
 }
 #define __builtin_amdgcn_perm(a, b, sel) hostsim_perm((a), (b), (sel))
 #define __builtin_amdgcn_alignbyte(hi, lo, s) ((uint32_t)(((((uint64_t)(uint32_t)(hi)) << 32) | (uint32_t)(lo)) >> (8 * ((s) & 3))))
+#define __builtin_amdgcn_sdot4(a, b, c, clamp) ((int)((c) + (int)(int8_t)((uint32_t)(a)) * (int)(int8_t)((uint32_t)(b)) + (int)(int8_t)((uint32_t)(a) >> 8) * (int)(int8_t)((uint32_t)(b) >> 8) + (int)(int8_t)((uint32_t)(a) >> 16) * (int)(int8_t)((uint32_t)(b) >> 16) + (int)(int8_t)((uint32_t)(a) >> 24) * (int)(int8_t)((uint32_t)(b) >> 24)))
 #define __builtin_amdgcn_sdot2(a, b, c, clamp) ((int)((c) + (int)(a)[0] * (int)(b)[0] + (int)(a)[1] * (int)(b)[1]))
 #define __builtin_amdgcn_udot4(a, b, c, clamp) ((uint32_t)((c) + ((uint32_t)(a) & 0xffu) * ((uint32_t)(b) & 0xffu) + (((uint32_t)(a) >> 8) & 0xffu) * (((uint32_t)(b) >> 8) & 0xffu) + \
                                                           (((uint32_t)(a) >> 16) & 0xffu) * (((uint32_t)(b) >> 16) & 0xffu) + ((uint32_t)(a) >> 24) * ((uint32_t)(b) >> 24)))
