@@ -23,6 +23,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "kh_common.h"
@@ -136,7 +137,10 @@ __global__ __launch_bounds__(kBx* kBy) void bilinear_u8_kernel(Rz a) {
 }
 
 // ---- separable Q14 ------------------------------------------------------------------------------------
-struct SepTab { const int32_t* ofs; const int16_t* w; int k, kp, span64; const int32_t* aofs; const uint32_t* w8; int kp8, span8; };  // aofs / w8 / kp8 / span8: sep_h_u8_dot4_kernel  // k taps; rows of kp = roundup(k, 4) weights (zero padded); span64: see get_tab
+// k taps per destination sample; `w` rows of kp = roundup(k, 4) i16 weights (zero padded).  aofs / w8 / kp8 / span8: the aligned windows,
+// byte-split weights, padded tap count and widest tile span of sep_h_u8_dot4_kernel; vty / vrows: segment height and staged rows of
+// sep_v_u8_lds_kernel (see get_tab).
+struct SepTab { const int32_t* ofs; const int16_t* w; int k, kp; const int32_t* aofs; const uint32_t* w8; int kp8, span8, vty, vrows; };
 
 // horizontal_row_scalar (kernels.rs:403-425): (x, source row) -> i16
 template <int C>
@@ -162,15 +166,9 @@ __global__ __launch_bounds__(kBx* kBy) void sep_h_u8_kernel(Rz a, int16_t* __res
     for (int ch = 0; ch < C; ++ch) o[ch] = (int16_t)min(max((acc[ch] + 8192) >> 14, -32768), 32767);
 }
 
-// horizontal pass, LDS-staged (round 2).  The kernel above gathers: neighbouring lanes read bytes `scale` pixels apart, k taps x C
-// byte loads per destination sample, each wave-load touching a dozen cache lines — the address path (TA), not HBM, sets its time
-// (8.4 ms per 256 1080p -> 224 Lanczos-3 antialiased frames, 0.02 of the roofline).  Here a 256-thread block owns kSepTX
-// destination columns x kSepRows source rows:
-//   1. the source span those columns tap (table offsets are monotonic: ofs[first] .. ofs[last] + kp) is staged in LDS once per
-//      row with aligned dword copies (edge tiles: per byte, with the reference's clamp to the row);
-//   2. each thread accumulates one destination column for four rows, four taps at a time: one 8-byte weight load serves the four
-//      rows, the 4 x C source bytes come from LDS as C + 1 dwords re-aligned with v_alignbyte, and each channel's four products
-//      are two v_dot2_i32_i16 (pixel pairs x weight pairs) — i32 sums of the same i16 x u8 products, so the same integers.
+// The LDS-staged horizontal pass works on tiles of kSepTX destination columns x kSepRows source rows (256 threads: a thread owns one
+// column for four rows).  Round 2's version of it kept the source bytes INTERLEAVED in LDS (v_alignbyte + v_perm + v_dot2 per four
+// taps: 1.53 ms per 256 1080p -> 224 Lanczos frames, profiles/r04f); the planar v_dot4 kernel below replaced it.
 constexpr int kSepTX = 64, kSepRows = 16;
 extern __shared__ __attribute__((aligned(16))) uint8_t kh_sep_lds[];
 
@@ -178,110 +176,8 @@ typedef short i16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int32_t dot2_i16(uint32_t a, uint32_t b, int32_t c) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, a), __builtin_bit_cast(i16x2_t, b), c, false);
 }
-// {byte n1, 0, byte n2, 0} of the byte string e[0], e[1], ...: two pixels' samples of one channel as an i16 pair
-template <int C, int N1>
-__device__ __forceinline__ uint32_t pixel_pair(const uint32_t (&e)[C]) {
-    constexpr int b = N1 >> 2, i1 = N1 - 4 * b, i2 = N1 + C - 4 * b;
-    constexpr uint32_t sel = 0x0c000c00u | (uint32_t)i1 | ((uint32_t)i2 << 16);
-    return __builtin_amdgcn_perm(e[b + 1 < C ? b + 1 : b], e[b], sel);
-}
 
-template <int C>
-__global__ __launch_bounds__(256) void sep_h_u8_tile_kernel(Rz a, int16_t* __restrict__ hbuf, SepTab tx, int pitch) {
-    uint8_t* S = kh_sep_lds;  // [kSepRows][pitch]
-    unsigned bx_, by_, bz_;
-    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int X0 = bx_ * kSepTX, sy0 = by_ * kSepRows;
-    const int p0 = tx.ofs[X0], span = tx.ofs[min(X0 + kSepTX, a.dw) - 1] + tx.kp - p0;   // block-uniform
-    const int nrows = min(kSepRows, a.sh - sy0);
-    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
-    const long long img_bytes = (long long)a.sw * a.sh * C;
-    // per staged row: where its first tapped byte sits in the LDS row (`mis` = the source address modulo 4 when the row is copied
-    // as aligned dwords, which needs the whole aligned window inside the image; 0 when it is staged per byte)
-    auto row_mis = [&](int r, bool& dwords) -> int {
-        const long long g = ((long long)(sy0 + r) * a.sw + p0) * C;
-        const int mis = (int)((uintptr_t)(src + g) & 3);
-        dwords = p0 >= 0 && p0 + span <= a.sw && g - mis >= 0 && g - mis + (((long long)mis + span * C + 3) & ~3ll) <= img_bytes;
-        return dwords ? mis : 0;
-    };
-    for (int r = wave; r < nrows; r += 4) {
-        bool dwords;
-        const int mis = row_mis(r, dwords);
-        uint8_t* row = S + r * pitch;
-        if (dwords) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(src + ((long long)(sy0 + r) * a.sw + p0) * C - mis);
-            const int ndw = (mis + span * C + 3) >> 2;
-            // eight independent loads in flight before the first LDS write (one per trip = one memory round trip per trip)
-            for (int d0 = lane; d0 < ndw; d0 += 64 * 8) {
-                uint32_t v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = q[min(d0 + 64 * k, ndw - 1)];
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (d0 + 64 * k < ndw) reinterpret_cast<uint32_t*>(row)[d0 + 64 * k] = v[k];
-            }
-        } else {
-            const uint8_t* grow = src + (long long)(sy0 + r) * a.sw * C;
-            for (int j = lane; j < span * C; j += 64) {
-                const int px = j / C, c = j - px * C;
-                row[j] = grow[min(max(p0 + px, 0), a.sw - 1) * C + c];  // build_xsrc_lut, common.rs:127-137
-            }
-        }
-    }
-    __syncthreads();
-    const int x = X0 + lane;
-    if (x >= a.dw) return;
-    const int rel = (tx.ofs[x] - p0) * C;
-    const uint32_t* wrow = reinterpret_cast<const uint32_t*>(tx.w + (long long)x * tx.kp);
-    int rowo[4];  // byte offsets into the LDS tile (kept as integers: a pointer round trip through uintptr_t would turn the
-                  // ds_read into flat loads)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = min(wave * 4 + i, nrows - 1);  // rows past the image repeat the last one and are not stored
-        bool dwords;
-        rowo[i] = r * pitch + row_mis(r, dwords) + rel;
-    }
-    int32_t acc[4][C];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[i][c] = 0;
-    for (int t4 = 0; t4 < tx.kp; t4 += 4) {
-        const uint32_t w01 = wrow[t4 >> 1], w23 = wrow[(t4 >> 1) + 1];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = rowo[i] + t4 * C;
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(kh_sep_lds + (o & ~3));
-            const uint32_t sh = (uint32_t)(o & 3);
-            uint32_t e[C];
-#pragma unroll
-            for (int j = 0; j < C; ++j) e[j] = __builtin_amdgcn_alignbyte(p[j + 1], p[j], sh);
-            if constexpr (C == 1) {
-                acc[i][0] = dot2_i16(pixel_pair<1, 2>(e), w23, dot2_i16(pixel_pair<1, 0>(e), w01, acc[i][0]));
-            } else if constexpr (C == 3) {
-                acc[i][0] = dot2_i16(pixel_pair<3, 6>(e), w23, dot2_i16(pixel_pair<3, 0>(e), w01, acc[i][0]));
-                acc[i][1] = dot2_i16(pixel_pair<3, 7>(e), w23, dot2_i16(pixel_pair<3, 1>(e), w01, acc[i][1]));
-                acc[i][2] = dot2_i16(pixel_pair<3, 8>(e), w23, dot2_i16(pixel_pair<3, 2>(e), w01, acc[i][2]));
-            } else {
-                acc[i][0] = dot2_i16(pixel_pair<4, 8>(e), w23, dot2_i16(pixel_pair<4, 0>(e), w01, acc[i][0]));
-                acc[i][1] = dot2_i16(pixel_pair<4, 9>(e), w23, dot2_i16(pixel_pair<4, 1>(e), w01, acc[i][1]));
-                acc[i][2] = dot2_i16(pixel_pair<4, 10>(e), w23, dot2_i16(pixel_pair<4, 2>(e), w01, acc[i][2]));
-                acc[i][3] = dot2_i16(pixel_pair<4, 11>(e), w23, dot2_i16(pixel_pair<4, 3>(e), w01, acc[i][3]));
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 4 + i;
-        if (r >= nrows) break;
-        int16_t* o = hbuf + (((long long)bz_ * a.sh + sy0 + r) * a.dw + x) * C;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) o[ch] = (int16_t)min(max((acc[i][ch] + 8192) >> 14, -32768), 32767);
-    }
-}
-
-// horizontal pass, planar i8 + v_dot4 (round 4).  profiles/r04a_limiter_resize_u8.txt: the kernel above spends 1849 vector instructions per
+// horizontal pass, planar i8 + v_dot4 (round 4).  profiles/r04a_limiter_resize_u8.txt: round 2's tile kernel spent 1849 vector instructions per
 // wave-tile — 3.4 per multiply-add — and 75 % of its LDS cycles in bank conflicts: per four taps of one row it reads C + 1 dwords of
 // INTERLEAVED bytes, re-aligns them (v_alignbyte), picks pixel pairs out per channel (v_perm) and only then multiplies (v_dot2).  Here
 // the staging pass de-interleaves once: LDS holds each source row as C PLANES of signed bytes p - 128, and a destination column's
@@ -295,68 +191,117 @@ __global__ __launch_bounds__(256) void sep_h_u8_tile_kernel(Rz a, int16_t* __res
 //   * one 16-byte weight load (8 wl + 8 wh) serves the thread's four rows x C channels: 4 v_dot4 per 8 taps per (row, channel) =
 //     0.5 vector instructions per multiply-add.
 // Tile, thread mapping and edge handling (per-byte staging with the reference's clamp) are those of the kernel above.
-template <int C>
-__device__ __forceinline__ uint32_t plane4(const uint32_t (&d)[C], int c) {   // bytes c, C + c, 2C + c, 3C + c of the 4 C-byte pixels in d[]
-    uint32_t r = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int b = j * C + c;
-        r |= ((d[b >> 2] >> (8 * (b & 3))) & 0xFFu) << (8 * j);
+// bytes c, C + c, 2C + c, 3C + c of the 4 C-byte pixels in d[] — one plane's four samples — with v_perm_b32 (2 per plane for RGB, 3 for
+// RGBA) instead of the shift / mask / or chains the generic expression compiles to (r04k: the staging arithmetic, not the dot
+// products, kept the vector ALUs 86 % busy)
+constexpr uint32_t rgb_sel1(int ch, int j) { return 3 * j + ch < 8 ? (uint32_t)(3 * j + ch) : 0u; }              // sample j of channel ch is byte 3 j + ch
+constexpr uint32_t rgb_sel2(int ch, int j) { return 3 * j + ch < 8 ? (uint32_t)j : (uint32_t)(4 + 3 * j + ch - 8); }
+template <int C, int CH>
+__device__ __forceinline__ uint32_t plane4(const uint32_t (&d)[C]) {
+    if constexpr (C == 1) {
+        return d[0];
+    } else if constexpr (C == 3) {
+        constexpr uint32_t sel1 = rgb_sel1(CH, 0) | (rgb_sel1(CH, 1) << 8) | (rgb_sel1(CH, 2) << 16) | (rgb_sel1(CH, 3) << 24);   // from {d1 : d0}
+        constexpr uint32_t sel2 = rgb_sel2(CH, 0) | (rgb_sel2(CH, 1) << 8) | (rgb_sel2(CH, 2) << 16) | (rgb_sel2(CH, 3) << 24);   // from {d2 : t}
+        return __builtin_amdgcn_perm(d[2], __builtin_amdgcn_perm(d[1], d[0], sel1), sel2);
+    } else {
+        static_assert(C == 4, "1, 3 or 4 channels");
+        constexpr uint32_t lo = (uint32_t)CH | ((uint32_t)(4 + CH) << 8);           // bytes CH of d0, d1 (and of d2, d3)
+        const uint32_t t01 = __builtin_amdgcn_perm(d[1], d[0], lo), t23 = __builtin_amdgcn_perm(d[3], d[2], lo);
+        return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
     }
-    return r;
+}
+template <int C, int... CH>
+__device__ __forceinline__ void store_planes(uint8_t* base, int pitchp, const uint32_t (&d)[C], std::integer_sequence<int, CH...>) {
+    ((*reinterpret_cast<uint32_t*>(base + CH * pitchp) = plane4<C, CH>(d) ^ 0x80808080u), ...);
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __restrict__ hbuf, SepTab tx, int pitchp) {
-    uint8_t* S = kh_sep_lds;  // [kSepRows][C][pitchp] signed bytes (p - 128)
+// PITCH (bytes per plane row in LDS) is a template constant so that the twelve (row, plane) reads of a step are ONE address register plus
+// immediate offsets.
+template <int C, int PITCH>
+__global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __restrict__ hbuf, SepTab tx) {
+    constexpr int pitchp = PITCH;
+    uint8_t* S = kh_sep_lds;  // [kSepRows][C][pitchp] signed bytes (p - 128), then the tile's weights [steps][kSepTX] x 16 B
     unsigned bx_, by_, bz_;
     if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int X0 = bx_ * kSepTX, sy0 = by_ * kSepRows;
     const int p0a = tx.aofs[X0], span = tx.aofs[min(X0 + kSepTX, a.dw) - 1] + tx.kp8 - p0a;   // block-uniform, multiples of 8
-    const int nrows = min(kSepRows, a.sh - sy0);
-    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
-    const bool inside = p0a >= 0 && p0a + span <= a.sw;   // every staged pixel exists: whole 4-pixel groups, no clamp
-    for (int r = wave; r < nrows; r += 4) {
-        uint8_t* row = S + r * (C * pitchp);
-        const uint8_t* grow = src + (long long)(sy0 + r) * a.sw * C;
-        if (inside) {
-            for (int q = lane; q < (span >> 2); q += 64) {
-                const uint8_t* g = grow + (long long)(p0a + 4 * q) * C;
-                uint32_t d[C];
+    const int nrows = min(kSepRows, a.sh - sy0), steps = tx.kp8 >> 3;
+    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss + (long long)sy0 * a.sw * C;
+    u32x4_t* W = reinterpret_cast<u32x4_t*>(S + kSepRows * C * pitchp);
+    // Staging is where this pass used to lose its time (r04f: 10 % of the vector ALUs busy): a loop of load -> LDS write round trips
+    // per row, and a per-BYTE path for every tile that touches the left or right image border — half of the tiles of a 224-wide
+    // destination.  Now a thread has all its wide loads in flight before the first LDS write, and only the few groups that actually
+    // straddle a border take the clamped bytes.
+    // thread -> (4-pixel group q = lane + 64 j, row 4 i + wave): no per-item division; kQ x 4 independent wide loads in flight per thread
+    constexpr int kQ = 3;
+    const int nq = span >> 2;
+    for (int q0 = lane; q0 < nq; q0 += 64 * kQ) {
+        uint32_t d[4][kQ][C];
 #pragma unroll
-                for (int j = 0; j < C; ++j) d[j] = *reinterpret_cast<const u32_unaligned*>(g + 4 * j);
+        for (int i = 0; i < 4; ++i) {
+            const int r = min(4 * i + wave, nrows - 1);
 #pragma unroll
-                for (int c = 0; c < C; ++c) *reinterpret_cast<uint32_t*>(row + c * pitchp + 4 * q) = plane4<C>(d, c) ^ 0x80808080u;
-            }
-        } else {
-            for (int j = lane; j < span * C; j += 64) {
-                const int px = j / C, c = j - px * C;
-                row[c * pitchp + px] = grow[min(max(p0a + px, 0), a.sw - 1) * C + c] ^ 0x80u;  // build_xsrc_lut, common.rs:127-137
+            for (int j = 0; j < kQ; ++j) {
+                const int q = min(q0 + 64 * j, nq - 1), px0 = p0a + 4 * q;
+                const uint8_t* g = src + (uint32_t)((r * a.sw + min(max(px0, 0), a.sw - 4)) * C);   // always 4 whole pixels of the row (sw >= 4: host); 32-bit offsets: one image < 2^31 B (check_rz)
+#pragma unroll
+                for (int c = 0; c < C; ++c) d[i][j][c] = *reinterpret_cast<const u32_unaligned*>(g + 4 * c);
             }
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * i + wave;
+            if (r >= nrows) break;
+#pragma unroll
+            for (int j = 0; j < kQ; ++j) {
+                const int q = q0 + 64 * j, px0 = p0a + 4 * q;
+                if (q >= nq) break;
+                uint8_t* o = S + r * (C * pitchp) + 4 * q;
+                if (px0 >= 0 && px0 + 3 < a.sw) {
+                    store_planes<C>(o, pitchp, d[i][j], std::make_integer_sequence<int, C>{});
+                } else {   // a group across the image border: the reference's clamp, per pixel (build_xsrc_lut, common.rs:127-137)
+                    const uint8_t* grow = src + (uint32_t)(r * a.sw * C);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v |= (uint32_t)grow[min(max(px0 + k, 0), a.sw - 1) * C + c] << (8 * k);
+                        *reinterpret_cast<uint32_t*>(o + c * pitchp) = v ^ 0x80808080u;
+                    }
+                }
+            }
+        }
+    }
+    for (int e = tid; e < kSepTX * steps; e += 256) {   // the tile's weight rows, transposed to [step][column]: contiguous in global memory
+        const int xr = e / steps, st = e - xr * steps;
+        W[st * kSepTX + xr] = reinterpret_cast<const u32x4_t*>(tx.w8)[(uint32_t)(min(X0 + xr, a.dw - 1) * steps + st)];
     }
     __syncthreads();
     const int x = X0 + lane;
     if (x >= a.dw) return;
     const int rel = tx.aofs[x] - p0a;   // multiple of 8
-    const int steps = tx.kp8 >> 3;
-    const u32x4_t* wrow = reinterpret_cast<const u32x4_t*>(tx.w8) + (long long)x * steps;
-    int rowo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rowo[i] = min(wave * 4 + i, nrows - 1) * (C * pitchp) + rel;   // rows past the image repeat the last one and are not stored
+    // rows past the image (a ragged last tile) read LDS rows nobody staged — whatever they hold is finite integer data, and the
+    // results are not stored — so the four rows of a thread are always base + i * C * PITCH
+    const uint8_t* base = kh_sep_lds + wave * 4 * (C * pitchp) + rel;
     int32_t al[4][C], ah[4][C];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int c = 0; c < C; ++c) { al[i][c] = 0; ah[i][c] = 0; }
+        for (int c = 0; c < C; ++c) { al[i][c] = (128 << 14) + 8192; ah[i][c] = 0; }   // 128 * sum(w) and the rounding constant ride in the low sum
+    // NOT unrolled: with two steps in one body the compiler fuses the two 8-byte reads of a (row, plane) into one ds_read_b128 at an
+    // address that is only 8-byte aligned — legal, and measured at 700 M unaligned-stall cycles per launch (SQ_LDS_UNALIGNED_STALL,
+    // profiles/r04h): 43 % of the wave-cycles waiting on the LDS queue.
+#pragma unroll 1
     for (int s8 = 0; s8 < steps; ++s8) {
-        const u32x4_t w = wrow[s8];   // {wl[0..3], wl[4..7], wh[0..3], wh[4..7]}
+        const u32x4_t w = W[s8 * kSepTX + lane];   // {wl[0..3], wl[4..7], wh[0..3], wh[4..7]}
+        const uint8_t* pb = base + 8 * s8;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const u32x2_t p = *reinterpret_cast<const u32x2_t*>(kh_sep_lds + rowo[i] + c * pitchp + 8 * s8);
+                const u32x2_t p = *reinterpret_cast<const u32x2_t*>(pb + (i * C + c) * pitchp);
                 al[i][c] = __builtin_amdgcn_sdot4((int)p.x, (int)w.x, al[i][c], false);
                 al[i][c] = __builtin_amdgcn_sdot4((int)p.y, (int)w.y, al[i][c], false);
                 ah[i][c] = __builtin_amdgcn_sdot4((int)p.x, (int)w.z, ah[i][c], false);
@@ -367,11 +312,10 @@ __global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __res
     for (int i = 0; i < 4; ++i) {
         const int r = wave * 4 + i;
         if (r >= nrows) break;
-        int16_t* o = hbuf + (((long long)bz_ * a.sh + sy0 + r) * a.dw + x) * C;
+        int16_t* o = hbuf + (long long)bz_ * a.sh * a.dw * C + (uint32_t)(((sy0 + r) * a.dw + x) * C);
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
-            const int32_t acc = ah[i][ch] * 256 + al[i][ch] + (128 << 14);
-            o[ch] = (int16_t)min(max((acc + 8192) >> 14, -32768), 32767);
+            o[ch] = (int16_t)min(max((ah[i][ch] * 256 + al[i][ch]) >> 14, -32768), 32767);
         }
     }
 }
@@ -391,6 +335,57 @@ __global__ __launch_bounds__(kBx* kBy) void sep_v_u8_kernel(Rz a, const int16_t*
         acc += (int32_t)h[(long long)sy * hrow] * (int32_t)w[k];
     }
     a.dst[(long long)bz_ * a.ds + (long long)y * hrow + i] = (uint8_t)min(max((acc + 8192) >> 14, 0), 255);
+}
+
+// vertical pass, LDS-staged (round 4).  The kernel above reads every tap from global memory: 1.6 vector loads per multiply-add, each a
+// 2-byte gather a whole intermediate row apart, 13 instructions per tap (profiles/r04a_limiter_resize_u8.txt: 0.55 ms for 1.1 G
+// multiply-adds).  Here a block owns 128 flat columns x a SEGMENT of ty.vty destination rows: the i16 rows that segment taps
+// (ofs[Y0] .. ofs[Y1 - 1] + k, each clamped to the image like the reference's row index) are staged in LDS once, two columns per
+// dword; a wave then walks its destination rows with one conflict-free ds_read_b32 + two v_dot2 per tap (weights are wave-uniform).
+// i32 sums of the same products: byte-identical.
+constexpr int kSepVRows = 192;   // staged intermediate rows per block (192 x 256 B = 48 KiB)
+__global__ __launch_bounds__(256) void sep_v_u8_lds_kernel(Rz a, const int16_t* __restrict__ hbuf, SepTab ty, int hrow) {
+    uint32_t* S = reinterpret_cast<uint32_t*>(kh_sep_lds);   // [ty.vrows][64] dwords (dynamic: the launch asks for what this table needs)
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (bx_ * 64 + lane) * 2;                       // this lane's two flat columns: col, col + 1
+    const int Y0 = by_ * ty.vty, Y1 = min(Y0 + ty.vty, a.dh);
+    const int r0 = ty.ofs[Y0], nr = ty.ofs[Y1 - 1] + ty.k - r0;  // block-uniform; nr <= kSepVRows (host-checked per table)
+    const int16_t* __restrict__ h = hbuf + (long long)bz_ * a.sh * hrow;
+    const int c0 = min(col, hrow - 1), c1 = min(col + 1, hrow - 1);
+    const bool pairs = (hrow & 1) == 0;   // rows start dword-aligned: one load per (row, column pair) instead of two 2-byte loads
+    for (int rb = wave; rb < nr; rb += 4 * 16) {   // sixteen rows of loads in flight per lane before the first LDS write
+        uint32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int16_t* row = h + (long long)min(max(r0 + min(rb + 4 * j, nr - 1), 0), a.sh - 1) * hrow;   // vertical_row_scalar's clamp, kernels.rs:699-708
+            if (pairs) v[j] = *reinterpret_cast<const uint32_t*>(row + c0);   // c0 even; c1 == c0 + 1 (hrow even) or the lane is past the row
+            else v[j] = (uint32_t)(uint16_t)row[c0] | ((uint32_t)(uint16_t)row[c1] << 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (rb + 4 * j < nr) S[(rb + 4 * j) * 64 + lane] = v[j];
+    }
+    // the segment's weight rows: a tap's weight is wave-uniform but 16-bit, which has no scalar load on this part — read from global
+    // memory inside the tap loop it was one dependent vector load per tap (r04h: 69 % of the wave-cycles parked)
+    uint16_t* Wv = reinterpret_cast<uint16_t*>(S + ty.vrows * 64);   // [vty][kp]
+    for (int e = threadIdx.x; e < (Y1 - Y0) * ty.kp; e += 256) Wv[e] = (uint16_t)ty.w[(long long)Y0 * ty.kp + e];
+    __syncthreads();
+    for (int y = Y0 + wave; y < Y1; y += 4) {
+        const uint32_t* tap = S + (ty.ofs[y] - r0) * 64 + lane;
+        const uint16_t* w = Wv + (y - Y0) * ty.kp;
+        int32_t acc0 = 0, acc1 = 0;
+        for (int t = 0; t < ty.k; ++t) {
+            const uint32_t v = tap[t * 64];
+            const uint32_t wt = w[t];   // {wt, 0} and {0, wt} as i16 pairs
+            acc0 = dot2_i16(v, wt, acc0);
+            acc1 = dot2_i16(v, wt << 16, acc1);
+        }
+        uint8_t* o = a.dst + (long long)bz_ * a.ds + (long long)y * hrow;
+        if (col < hrow) o[col] = (uint8_t)min(max((acc0 + 8192) >> 14, 0), 255);
+        if (col + 1 < hrow) o[col + 1] = (uint8_t)min(max((acc1 + 8192) >> 14, 0), 255);
+    }
 }
 
 // ---- fused RGB8 -> normalised CHW f32 (P/resize/fused.rs) ---------------------------------------------
@@ -600,10 +595,8 @@ int32_t get_tab(int src_size, int dst_size, int filt, bool aa, hipStream_t strea
         std::vector<int32_t> ofs;
         std::vector<int16_t> wk, w;
         const int k = build_contribs(src_size, dst_size, filt, aa, ofs, wk), kp = (k + 3) & ~3;
-        w.assign((size_t)dst_size * kp, 0);  // rows padded to a multiple of four taps with zero weights (sep_h_u8_tile_kernel)
+        w.assign((size_t)dst_size * kp, 0);  // rows padded to a multiple of four taps with zero weights
         for (int i = 0; i < dst_size; ++i) std::copy(wk.begin() + (size_t)i * k, wk.begin() + (size_t)(i + 1) * k, w.begin() + (size_t)i * kp);
-        int span64 = 0;                      // widest source span (pixels) one tile of kSepTX destination columns taps
-        for (int x0 = 0; x0 < dst_size; x0 += kSepTX) span64 = std::max(span64, ofs[std::min(x0 + kSepTX, dst_size) - 1] + kp - ofs[x0]);
         // sep_h_u8_dot4_kernel: windows widened down to multiples of 8 source pixels, weights shifted to match (zero taps around them) and
         // split into signed bytes w = 256 wh + wl; per column and 8 taps: wl[0..7] then wh[0..7] (16 bytes)
         const int kp8 = (k + 7 + 7) & ~7, steps = kp8 / 8;
@@ -621,9 +614,17 @@ int32_t get_tab(int src_size, int dst_size, int filt, bool aa, hipStream_t strea
         }
         int span8 = 0;
         for (int x0 = 0; x0 < dst_size; x0 += kSepTX) span8 = std::max(span8, aofs[std::min(x0 + kSepTX, dst_size) - 1] + kp8 - aofs[x0]);
+        // sep_v_u8_lds_kernel (this table as the VERTICAL one): the tallest segment of destination rows whose source-row window fits kSepVRows
+        int vty = 0, vrows = 0;
+        for (int ty_ = 16; ty_ >= 1 && !vty; ty_ >>= 1) {
+            int rows = 0;
+            for (int y0 = 0; y0 < dst_size; y0 += ty_) rows = std::max(rows, ofs[std::min(y0 + ty_, dst_size) - 1] + k - ofs[y0]);
+            if (rows <= kSepVRows) { vty = ty_; vrows = rows; }
+        }
+        t.meta[8] = vty; t.meta[9] = vrows;
         int wmax = 0;
         for (int16_t v : wk) wmax = std::max(wmax, abs((int)v));
-        t.meta[0] = k; t.meta[1] = dst_size; t.meta[2] = kp; t.meta[3] = span64; t.meta[4] = kp8; t.meta[5] = wmax < 32640 ? span8 : 0;   // span8 0: the split does not fit signed bytes
+        t.meta[0] = k; t.meta[1] = dst_size; t.meta[2] = kp; t.meta[3] = 0; t.meta[4] = kp8; t.meta[5] = wmax < 32640 ? span8 : 0;   // span8 0: the split does not fit signed bytes
         ofs.resize((ofs.size() + 3) & ~(size_t)3, 0);  // the weight block starts 16-byte aligned
         aofs.resize((aofs.size() + 3) & ~(size_t)3, 0);
         w.resize((w.size() + 7) & ~(size_t)7, 0);      // ... and so do the two blocks after it
@@ -641,8 +642,8 @@ int32_t get_tab(int src_size, int dst_size, int filt, bool aa, hipStream_t strea
     if (rc != KH_OK) return rc;
     out.ofs = (const int32_t*)lease->dev;
     out.w = (const int16_t*)((const char*)lease->dev + sizeof(int32_t) * (((size_t)lease->meta[1] + 3) & ~(size_t)3));
-    out.k = lease->meta[0]; out.kp = lease->meta[2]; out.span64 = lease->meta[3];
-    out.kp8 = lease->meta[4]; out.span8 = lease->meta[5];
+    out.k = lease->meta[0]; out.kp = lease->meta[2];
+    out.kp8 = lease->meta[4]; out.span8 = lease->meta[5]; out.vty = lease->meta[8]; out.vrows = lease->meta[9];
     out.aofs = (const int32_t*)((const char*)lease->dev + lease->meta[6]);
     out.w8 = (const uint32_t*)((const char*)lease->dev + lease->meta[7]);
     return KH_OK;
@@ -676,39 +677,24 @@ Rz make_rz(const void* src, void* dst, int sw, int sh, int dw, int dh, int64_t s
 // horizontal pass: the LDS-staged kernel when its tile fits 64 KiB, else (or with test option resize_u8_gather = 1) the gather
 int32_t launch_sep_h(hipStream_t st, const void* src, int sw, int sh, int dw, int dh, int channels, int batch, int64_t ss,
                      int16_t* hbuf, const SepTab& tx, const char* what) {
-    const bool gather = dev_opt(kOptResizeU8Gather) == 1;
-    const int opt = dev_opt(kOptResizeU8Gather);   // test option: 1 = the gather kernel, 2 = the round-2 interleaved-bytes tile kernel
-    const int pitchp = tx.span8 + 8;   // multiple of 8
-    const size_t lds8 = (size_t)pitchp * channels * kSepRows;
-    if (opt < 1 && tx.span8 > 0 && lds8 <= 64 * 1024 && channels != 2) {
+    const int opt = dev_opt(kOptResizeU8Gather);   // test option: 1 = the per-tap gather kernels for both passes (the fallback for windows beyond the LDS budgets)
+    // plane pitch classes (a template constant of the kernel): the smallest that holds the widest tile span of this geometry
+    const int pitchp = tx.span8 + 8 <= 320 ? 320 : (tx.span8 + 8 <= 640 ? 640 : (tx.span8 + 8 <= 1280 ? 1280 : 0));
+    const size_t lds8 = (size_t)pitchp * channels * kSepRows + (size_t)(tx.kp8 / 8) * kSepTX * 16;   // staged rows + the tile's weights
+    if (opt < 1 && tx.span8 > 0 && pitchp > 0 && lds8 <= 64 * 1024 && channels != 2 && sw >= 4) {
         Rz ah = make_rz(src, nullptr, sw, sh, dw, dh, ss, 0, batch, dw, sh);
         ah.tiles = xcd_tiles(cdiv(dw, kSepTX), cdiv(sh, kSepRows), (unsigned)batch, cdiv(dw, kSepTX) * 8);
         if (ah.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const dim3 grid = xcd_grid(ah.tiles), blk(256);
-        if (lds8 > 48 * 1024) {
-            if (channels == 1) KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_dot4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            else if (channels == 3) KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_dot4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            else KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_dot4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        }
-        switch (channels) {
-            case 1: hipLaunchKernelGGL(sep_h_u8_dot4_kernel<1>, grid, blk, lds8, st, ah, hbuf, tx, pitchp); break;
-            case 3: hipLaunchKernelGGL(sep_h_u8_dot4_kernel<3>, grid, blk, lds8, st, ah, hbuf, tx, pitchp); break;
-            default: hipLaunchKernelGGL(sep_h_u8_dot4_kernel<4>, grid, blk, lds8, st, ah, hbuf, tx, pitchp); break;
-        }
-        return KH_OK;
-    }
-    const int pitch = (((tx.span64 * channels + 3) + 3) & ~3) + 8;
-    const size_t lds = (size_t)pitch * kSepRows;
-    if (!gather && lds <= 64 * 1024) {
-        Rz ah = make_rz(src, nullptr, sw, sh, dw, dh, ss, 0, batch, dw, sh);
-        ah.tiles = xcd_tiles(cdiv(dw, kSepTX), cdiv(sh, kSepRows), (unsigned)batch, cdiv(dw, kSepTX) * 8);
-        if (ah.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-        const dim3 grid = xcd_grid(ah.tiles), blk(256);
-        switch (channels) {
-            case 1: hipLaunchKernelGGL(sep_h_u8_tile_kernel<1>, grid, blk, lds, st, ah, hbuf, tx, pitch); break;
-            case 3: hipLaunchKernelGGL(sep_h_u8_tile_kernel<3>, grid, blk, lds, st, ah, hbuf, tx, pitch); break;
-            default: hipLaunchKernelGGL(sep_h_u8_tile_kernel<4>, grid, blk, lds, st, ah, hbuf, tx, pitch); break;
-        }
+#define KH_SEPH(CC, PP)                                                                                                                     \
+    do {                                                                                                                                    \
+        if (lds8 > 48 * 1024) KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_dot4_kernel<CC, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+        hipLaunchKernelGGL((sep_h_u8_dot4_kernel<CC, PP>), grid, blk, lds8, st, ah, hbuf, tx);                                              \
+    } while (0)
+#define KH_SEPH_C(CC) do { if (pitchp == 320) KH_SEPH(CC, 320); else if (pitchp == 640) KH_SEPH(CC, 640); else KH_SEPH(CC, 1280); } while (0)
+        if (channels == 1) KH_SEPH_C(1); else if (channels == 3) KH_SEPH_C(3); else KH_SEPH_C(4);
+#undef KH_SEPH_C
+#undef KH_SEPH
         return KH_OK;
     }
     Rz ah = make_rz(src, nullptr, sw, sh, dw, dh, ss, 0, batch, dw, sh);
@@ -780,7 +766,14 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
         Rz av = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, hrow, dh);
         if (av.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         if (int32_t rc = launch_sep_h(st, src, sw, sh, dw, dh, channels, batch, src_stride, hbuf, tx, what)) return rc;
-        hipLaunchKernelGGL(sep_v_u8_kernel, xcd_grid(av.tiles), blk, 0, st, av, (const int16_t*)hbuf, ty, hrow);
+        if (ty.vty > 0 && dev_opt(kOptResizeU8Gather) < 1) {   // LDS-staged vertical pass; the per-tap kernel for windows beyond kSepVRows rows
+            Rz al = av;
+            al.tiles = xcd_tiles(cdiv(hrow, 128), cdiv(dh, ty.vty), (unsigned)batch, cdiv(hrow, 128) * 4);
+            if (al.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+            hipLaunchKernelGGL(sep_v_u8_lds_kernel, xcd_grid(al.tiles), dim3(256), (size_t)ty.vrows * 256 + (size_t)ty.vty * ty.kp * 2, st, al, (const int16_t*)hbuf, ty, hrow);
+        } else {
+            hipLaunchKernelGGL(sep_v_u8_kernel, xcd_grid(av.tiles), blk, 0, st, av, (const int16_t*)hbuf, ty, hrow);
+        }
         const int32_t rc = check_launch(what);
         lx->used_on(st); ly->used_on(st);
         return rc;

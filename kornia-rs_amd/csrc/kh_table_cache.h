@@ -28,7 +28,7 @@ namespace kh {
 struct DevTable {
     void* dev = nullptr;
     size_t bytes = 0;
-    int meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // small per-table facts (tap count, radius ...)
+    int meta[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // small per-table facts (tap count, radius ...)
     std::atomic<bool> pinned{false};  // referenced by a captured graph: never evicted (read by the evictor, written by users)
     int device = 0;
     DevTable() = default;

@@ -66,14 +66,21 @@ def test_separable_q14(gpu_stream, mode, aa):  # cuda.rs:420-440
 @pytest.mark.parametrize("path", ["staged", "gather"])
 @pytest.mark.parametrize("c", [1, 3, 4])
 def test_separable_staged_horizontal_pass_tiles(gpu_stream, c, path, dev_option):
-    """The LDS-staged horizontal pass (64 destination columns x 16 source rows per block): several interior tiles whose rows start
-    at every address alignment (odd widths), ragged last tiles, upsampling (k = 6 padded to 8 taps) and a span too wide for 64 KiB
-    of LDS (the gather kernel); `gather` forces that fallback for every case."""
+    """The LDS-staged passes (horizontal: 64 destination columns x 16 source rows per block, planar signed bytes + v_dot4; vertical:
+    128 flat columns x a segment of destination rows): several interior tiles whose rows start at every address alignment (odd
+    widths), ragged last tiles, 4-pixel groups that straddle the image border, upsampling, every plane-pitch class, vertical windows
+    of 6 .. 390 taps, and spans / windows too large for the LDS budgets (the per-tap kernels); `gather` forces those fallbacks for
+    every case."""
     if path == "gather":
         dev_option("resize_u8_gather", 1)
     for s, d, mode, aa in [((517, 70), (300, 40), "lanczos", True), ((1001, 37), (230, 37), "lanczos", True), ((333, 50), (700, 50), "lanczos", False),
                            ((415, 35), (200, 20), "bicubic", True), ((415, 35), (200, 20), "bicubic", False), ((20000, 4), (70, 4), "lanczos", True),
-                           ((1100, 20), (64, 20), "lanczos", True)]:  # 17x
+                           ((1100, 20), (64, 20), "lanczos", True),  # 17x
+                           ((3000, 20), (200, 20), "lanczos", True),   # 15x: the widest plane-pitch class of the v_dot4 kernel (1280 B)
+                           ((40, 600), (30, 50), "lanczos", True),     # 12x vertically: 72-tap windows, segments of 8 destination rows
+                           ((40, 2000), (30, 50), "bicubic", True),    # 40x vertically: 160-tap windows, segments of 1 row
+                           ((24, 2600), (24, 40), "lanczos", True),    # 65x vertically: windows beyond the LDS budget (the per-tap vertical kernel)
+                           ((5, 40), (3, 17), "lanczos", True)]:       # rows narrower than one 4-pixel staging group on the right edge
         assert check(gpu_stream, s, d, c, mode, aa) == "separable"
 
 
