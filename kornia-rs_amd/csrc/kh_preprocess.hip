@@ -24,6 +24,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <tuple>
 #include <vector>
 
@@ -46,6 +47,7 @@ struct PreArgs {
     int fast_div;                // host-verified: the 3-op quotient equals IEEE division on this grid
     const float* lz_wx;          // Lanczos only: 6 axis weights per destination column / row, built on the host (see lanczos_tables)
     const float* lz_wy;
+    int quad_wide;               // preprocess_generic_quads, NV12: the taps of every destination quad fit one 16-byte run per plane row (host-checked)
 };
 
 // BT.601 limited-range Q20 decode, constants of P/color/yuv/kernels.rs:696-702 and the fused
@@ -420,6 +422,64 @@ __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __re
 // as twelve 4-byte stores.  Here the destination is walked as a flat list of 4-pixel quads (dst_w % 4 == 0): no idle lanes but the
 // last block's tail, a lane owns one quad and writes each plane with one 16-byte streaming buffer store (a wave: 1 KiB contiguous per
 // instruction), like the identity kernel.  Same per-pixel expressions, bit-identical.  (Two quads per lane: slower, r04d.)
+// Byte `i` (0..15) of a 16-byte run held in four dwords.
+__device__ __forceinline__ uint32_t byte16(const u32x4_t& v, int i) {
+    const uint64_t lo = ((uint64_t)v.y << 32) | v.x, hi = ((uint64_t)v.w << 32) | v.z;
+    return (uint32_t)((i & 8 ? hi : lo) >> (8 * (i & 7))) & 0xFFu;
+}
+// The one-tap NV12 samples of a destination quad from TWO 16-byte loads (luma row, chroma row) instead of eight 1- / 2-byte gathers:
+// profiles/r04c has the texture addresser 80-90 % busy in the letterbox kernels (a gather instruction costs it a cycle per few lanes,
+// whatever it fetches).  Valid when every quad's columns x[0] <= .. <= x[3] satisfy x[3] - (x[0] & ~1) <= 15 (host-checked for the
+// launch: scale >= ~1/4) and src_w >= 16; `xs` are clamped into the row, so the run [xb, xb + 16) with xb = min(x[0] & ~1, src_w - 16)
+// lies inside the luma row and the same byte range of the chroma row holds the pairs of pixels xb .. xb + 15.
+__device__ __forceinline__ void quad_taps_nv12(const uint8_t* __restrict__ src, const int (&xs)[4], int y, const PreArgs& a, float (&px)[4][3]) {
+    const int xb = min(xs[0] & ~1, a.src_w - 16);
+    const u32x4_t yv = *reinterpret_cast<const u32x4_unaligned*>(src + (unsigned)(y * a.src_w + xb));
+    const u32x4_t cv = *reinterpret_cast<const u32x4_unaligned*>(src + (unsigned)(a.src_w * a.src_h + (y >> 1) * a.src_w + xb));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = xs[j] - xb, ci = i & ~1;
+        bt601_q20_to_rgb((int)byte16(yv, i), (int)byte16(cv, ci), (int)byte16(cv, ci + 1), px[j]);
+    }
+}
+
+// The same for the FOUR-tap bilinear sampler: the quad's taps x0[0] .. x0[3] + 1 of rows y0 and y1 = min(y0 + 1, h - 1) come from four
+// 16-byte loads (two luma rows, their chroma rows) instead of sixteen gathers; tap (x, y) decodes Y[y][x] with the chroma pair
+// (y >> 1, x >> 1), which is what fetch_pair's parity cases amount to, and the blend is bilinear_quad's expression.
+__device__ __forceinline__ void quad_taps_nv12_bilinear(const uint8_t* __restrict__ src, const float (&sxs)[4], float sy, const PreArgs& a,
+                                                        float (&px)[4][3]) {
+    const int y0 = min(max((int)floorf(sy), 0), a.src_h - 1), y1 = min(y0 + 1, a.src_h - 1);
+    const float ay = sy - (float)(int)floorf(sy);
+    int x0[4], x1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x0[j] = min(max((int)floorf(sxs[j]), 0), a.src_w - 1);
+        x1[j] = min(x0[j] + 1, a.src_w - 1);
+    }
+    const int xb = min(x0[0] & ~1, a.src_w - 16);
+    const unsigned cbase = (unsigned)(a.src_w * a.src_h + xb);
+    const u32x4_t yv0 = *reinterpret_cast<const u32x4_unaligned*>(src + (unsigned)(y0 * a.src_w + xb));
+    const u32x4_t yv1 = *reinterpret_cast<const u32x4_unaligned*>(src + (unsigned)(y1 * a.src_w + xb));
+    const u32x4_t cv0 = *reinterpret_cast<const u32x4_unaligned*>(src + cbase + (unsigned)((y0 >> 1) * a.src_w));
+    const u32x4_t cv1 = *reinterpret_cast<const u32x4_unaligned*>(src + cbase + (unsigned)((y1 >> 1) * a.src_w));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i0 = x0[j] - xb, i1 = x1[j] - xb, c0 = i0 & ~1, c1 = i1 & ~1;
+        const float ax = sxs[j] - (float)(int)floorf(sxs[j]);
+        float t00[3], t10[3], t01[3], t11[3];
+        bt601_q20_to_rgb((int)byte16(yv0, i0), (int)byte16(cv0, c0), (int)byte16(cv0, c0 + 1), t00);
+        bt601_q20_to_rgb((int)byte16(yv0, i1), (int)byte16(cv0, c1), (int)byte16(cv0, c1 + 1), t10);
+        bt601_q20_to_rgb((int)byte16(yv1, i0), (int)byte16(cv1, c0), (int)byte16(cv1, c0 + 1), t01);
+        bt601_q20_to_rgb((int)byte16(yv1, i1), (int)byte16(cv1, c1), (int)byte16(cv1, c1 + 1), t11);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = t00[c] + (t10[c] - t00[c]) * ax;
+            const float bot = t01[c] + (t11[c] - t01[c]) * ax;
+            px[j][c] = top + (bot - top) * ay;
+        }
+    }
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kQuadBlock = 256;
 template <int FMT, int SAMPLER, bool WIDE>
@@ -434,6 +494,38 @@ __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uin
     const float ny = (float)oy - a.pad_y;
     const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
     f32x4 o[3];
+    if constexpr (FMT == KH_FMT_NV12 && (SAMPLER == kSampleBilinearOnGrid || SAMPLER == KH_SAMPLE_BILINEAR)) {
+        if (a.quad_wide) {   // uniform
+            float sxs[4], px[4][3];
+            int xs[4];
+            bool in[4], any = false;
+            const bool row_in = !(sy < 0.0f || sy >= (float)a.src_h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float nx = (float)(ox0 + j) - a.pad_x;
+                sxs[j] = a.fast_div ? quot3(nx, a.scale_x, a.rc_x) : nx / a.scale_x;
+                in[j] = row_in && !(sxs[j] < 0.0f || sxs[j] >= (float)a.src_w);
+                any = any || in[j];
+                xs[j] = min(max((int)sxs[j], 0), a.src_w - 1);
+            }
+            if (any) {
+                if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) quad_taps_nv12_bilinear(src, sxs, sy, a, px);
+                else quad_taps_nv12(src, xs, min(max((int)sy, 0), a.src_h - 1), a, px);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[j][c] = in[j] ? px[j][c] : a.pad_value;
+                o[0][j] = (div255_any(px[j][0]) - a.m0) * a.is0;
+                o[1][j] = (div255_any(px[j][1]) - a.m1) * a.is1;
+                o[2][j] = (div255_any(px[j][2]) - a.m2) * a.is2;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[c]), rdst, 16 * g + c * (4 * plane), 0, kAuxStream);
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // plan_pixel (P/preprocess.rs:437-448)
@@ -632,6 +724,26 @@ bool bilinear_taps_on_grid(const PreArgs& a) {
     return ok;
 }
 
+// quad_taps_nv12's precondition, decided like the other launch checks by evaluating the kernel's own column expression for every
+// destination quad (dst_w / 4 groups of four host evaluations, memoised on the last geometry).
+bool quad_taps_fit_16(const PreArgs& a, int extra) {   // extra = 1: the bilinear sampler also reads column x + 1
+    struct Key { float sx, px; int w, sw, extra; bool ok; };
+    static thread_local Key last = {0, 0, 0, 0, 0, false};
+    if (last.w == a.dst_w && last.sw == a.src_w && last.sx == a.scale_x && last.px == a.pad_x && last.extra == extra) return last.ok;
+    bool ok = a.src_w >= 16 && a.dst_w % 4 == 0 && a.scale_x != 0.0f;
+    for (int q = 0; ok && q < a.dst_w / 4; ++q) {
+        int x[4];
+        for (int j = 0; j < 4; ++j) {
+            const float s = ((float)(4 * q + j) - a.pad_x) / a.scale_x;   // plan_pixel; the kernel's quotient equals this or it divides itself
+            x[j] = s >= 2147483520.0f ? a.src_w - 1 : std::min(std::max((int)s, 0), a.src_w - 1);
+            if (!(s == s)) ok = false;
+        }
+        ok = ok && x[0] <= x[1] && x[1] <= x[2] && x[2] <= x[3] && std::min(x[3] + extra, a.src_w - 1) - (x[0] & ~1) <= 15;
+    }
+    last = Key{a.scale_x, a.pad_x, a.dst_w, a.src_w, extra, ok};
+    return ok;
+}
+
 bool identity_fast_path(const kh_preprocess_params* p, const uint8_t* src, const void* dst) {
     return !(p->flags & KH_PRE_FORCE_GENERIC) && p->fmt == KH_FMT_NV12 &&
            p->out_dtype == KH_OUT_F32 &&
@@ -694,17 +806,22 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
     // flattened quads with 16-byte streaming stores (preprocess_generic_quads) for the ONE-tap samplers (nearest, on-grid bilinear), f32
     // outputs whose rows are whole quads.  Measured on one box, three interleaved rounds (profiles/r04d_quads_ab.txt): 1080p NV12 -> 640
     // on-grid 1.227 vs 1.329 ms, YUYV 1.206 vs 1.279 ms; the four-tap bilinear kernel does NOT gain from it (608: 1.464 vs 1.443 ms) and
-    // two quads per lane lose everywhere, so those keep the per-pixel kernel.  Test option pre_quads: 0 = never, 1 = also for four taps.
+    // two quads per lane lose everywhere, so those keep the per-pixel kernel — unless the source is NV12 and a quad's taps fit one 16-byte
+    // run per plane row (quad_taps_nv12*: wide loads instead of gathers, r04q / r04r).  Test option pre_quads: 0 = never, 1 = also for
+    // four taps with per-tap loads, 3 = no wide loads.
     if constexpr (SAMPLER != KH_SAMPLE_LANCZOS) {
         const int opt = dev_opt(kOptPreQuads);
         const bool quads_ok = out_dtype == KH_OUT_F32 && a.dst_w % 4 == 0 && (int64_t)a.dst_w * a.dst_h * 12 <= kI32Max &&
                               reinterpret_cast<uintptr_t>(dst) % 16 == 0 && a.dst_frame_stride % 4 == 0;
-        if (quads_ok && opt != 0 && (SAMPLER != KH_SAMPLE_BILINEAR || opt == 1)) {
+        const bool wide_nv12 = FMT == KH_FMT_NV12 && SAMPLER != KH_SAMPLE_NEAREST && opt != 3 && quads_ok && quad_taps_fit_16(a, SAMPLER == KH_SAMPLE_BILINEAR ? 1 : 0);
+        if (quads_ok && opt != 0 && (SAMPLER != KH_SAMPLE_BILINEAR || opt == 1 || wide_nv12)) {
             const int wq = a.dst_w / 4, groups = wq * a.dst_h;
             const dim3 qgrid(cdiv(groups, kQuadBlock), grid.z);
             const FastDiv by_wq = fast_div((uint32_t)wq);
-            if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, a, by_wq);
-            else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, a, by_wq);
+            PreArgs aq = a;
+            aq.quad_wide = wide_nv12 ? 1 : 0;   // test option pre_quads = 3: per-tap loads everywhere
+            if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq);
+            else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq);
             return;
         }
     }
@@ -769,6 +886,7 @@ int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
     a.rc_y = 1.0f / a.scale_y;
     a.fast_div = plan_division_is_exact(a) ? 1 : 0;
     a.lz_wx = a.lz_wy = nullptr;
+    a.quad_wide = 0;
     hipStream_t s = as_hip(stream);
 
     if (identity_fast_path(p, src, dst)) {
