@@ -47,7 +47,7 @@ struct PreArgs {
     int fast_div;                // host-verified: the 3-op quotient equals IEEE division on this grid
     const float* lz_wx;          // Lanczos only: 6 axis weights per destination column / row, built on the host (see lanczos_tables)
     const float* lz_wy;
-    int quad_wide;               // preprocess_generic_quads, NV12: the taps of every destination quad fit one 16-byte run per plane row (host-checked)
+    int quad_wide;               // preprocess_generic_quads, NV12 / YUYV: the taps of every destination quad fit one 16-byte run per plane row (host-checked)
 };
 
 // BT.601 limited-range Q20 decode, constants of P/color/yuv/kernels.rs:696-702 and the fused
@@ -443,6 +443,23 @@ __device__ __forceinline__ void quad_taps_nv12(const uint8_t* __restrict__ src, 
     }
 }
 
+// YUYV (Y0 U Y1 V per pixel pair): the quad's one-tap samples from one 32-byte run (two 16-byte loads).  Pixel xb + i: Y = byte 2 i,
+// U = byte 4 (i >> 1) + 1, V = byte 4 (i >> 1) + 3.  Same precondition as quad_taps_nv12 (x[3] - (x[0] & ~1) <= 15, src_w >= 16).
+__device__ __forceinline__ uint32_t byte32(const u32x4_t& lo, const u32x4_t& hi, int k) {
+    const u32x4_t v = (k & 16) ? hi : lo;
+    return byte16(v, k & 15);
+}
+__device__ __forceinline__ void quad_taps_yuyv(const uint8_t* __restrict__ src, const int (&xs)[4], int y, const PreArgs& a, float (&px)[4][3]) {
+    const int xb = min(xs[0] & ~1, a.src_w - 16);
+    const uint8_t* p = src + (unsigned)(y * a.src_pitch + 2 * xb);
+    const u32x4_t lo = *reinterpret_cast<const u32x4_unaligned*>(p), hi = *reinterpret_cast<const u32x4_unaligned*>(p + 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = xs[j] - xb, g = 4 * (i >> 1);
+        bt601_q20_to_rgb((int)byte32(lo, hi, 2 * i), (int)byte32(lo, hi, g + 1), (int)byte32(lo, hi, g + 3), px[j]);
+    }
+}
+
 // The same for the FOUR-tap bilinear sampler: the quad's taps x0[0] .. x0[3] + 1 of rows y0 and y1 = min(y0 + 1, h - 1) come from four
 // 16-byte loads (two luma rows, their chroma rows) instead of sixteen gathers; tap (x, y) decodes Y[y][x] with the chroma pair
 // (y >> 1, x >> 1), which is what fetch_pair's parity cases amount to, and the blend is bilinear_quad's expression.
@@ -494,7 +511,8 @@ __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uin
     const float ny = (float)oy - a.pad_y;
     const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
     f32x4 o[3];
-    if constexpr (FMT == KH_FMT_NV12 && (SAMPLER == kSampleBilinearOnGrid || SAMPLER == KH_SAMPLE_BILINEAR)) {
+    if constexpr ((FMT == KH_FMT_NV12 && (SAMPLER == kSampleBilinearOnGrid || SAMPLER == KH_SAMPLE_BILINEAR)) ||
+                  (FMT == KH_FMT_YUYV && SAMPLER == kSampleBilinearOnGrid)) {
         if (a.quad_wide) {   // uniform
             float sxs[4], px[4][3];
             int xs[4];
@@ -509,7 +527,8 @@ __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uin
                 xs[j] = min(max((int)sxs[j], 0), a.src_w - 1);
             }
             if (any) {
-                if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) quad_taps_nv12_bilinear(src, sxs, sy, a, px);
+                if constexpr (FMT == KH_FMT_YUYV) quad_taps_yuyv(src, xs, min(max((int)sy, 0), a.src_h - 1), a, px);
+                else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) quad_taps_nv12_bilinear(src, sxs, sy, a, px);
                 else quad_taps_nv12(src, xs, min(max((int)sy, 0), a.src_h - 1), a, px);
             }
 #pragma unroll
@@ -813,7 +832,8 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
         const int opt = dev_opt(kOptPreQuads);
         const bool quads_ok = out_dtype == KH_OUT_F32 && a.dst_w % 4 == 0 && (int64_t)a.dst_w * a.dst_h * 12 <= kI32Max &&
                               reinterpret_cast<uintptr_t>(dst) % 16 == 0 && a.dst_frame_stride % 4 == 0;
-        const bool wide_nv12 = FMT == KH_FMT_NV12 && SAMPLER != KH_SAMPLE_NEAREST && opt != 3 && quads_ok && quad_taps_fit_16(a, SAMPLER == KH_SAMPLE_BILINEAR ? 1 : 0);
+        const bool wide_nv12 = ((FMT == KH_FMT_NV12 && SAMPLER != KH_SAMPLE_NEAREST) || (FMT == KH_FMT_YUYV && SAMPLER == kSampleBilinearOnGrid && a.src_pitch >= 2 * a.src_w)) &&
+                               opt != 3 && quads_ok && quad_taps_fit_16(a, SAMPLER == KH_SAMPLE_BILINEAR ? 1 : 0);
         if (quads_ok && opt != 0 && (SAMPLER != KH_SAMPLE_BILINEAR || opt == 1 || wide_nv12)) {
             const int wq = a.dst_w / 4, groups = wq * a.dst_h;
             const dim3 qgrid(cdiv(groups, kQuadBlock), grid.z);
