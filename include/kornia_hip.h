@@ -79,6 +79,9 @@ KH_API int32_t kh_debug_set_option(const char* name, int32_t value);
  * waits against each other.  A result above 1 means device work through this library is unsafe — make every HIP
  * user of the process resolve to one image (INTEGRATION.md "One HIP runtime per process").                        */
 KH_API int32_t kh_hip_runtime_images(char* buf, size_t cap);
+/* HIP version the library was compiled against / the bound runtime reports (major * 10^7 + minor * 10^5 + patch; 0 = unknown):
+ * a host that shares another library's bundled runtime (torch wheels) can see a version skew before it bites.              */
+KH_API int32_t kh_hip_versions(int32_t* build_version, int32_t* runtime_version);
 
 KH_API int32_t kh_device_count(int32_t* count);
 KH_API int32_t kh_set_device(int32_t device);

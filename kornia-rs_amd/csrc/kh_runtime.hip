@@ -164,6 +164,19 @@ int32_t kh_hip_runtime_images(char* buf, size_t cap) {
     return (int32_t)images.size();
 }
 
+// The HIP version this library was COMPILED against and the one the runtime image it is bound to reports (both encoded
+// major * 10 000 000 + minor * 100 000 + patch).  The Python host binds the library to the torch wheel's bundled runtime when one is
+// installed (one runtime per process, see above), which can be OLDER than the ROCm the library was built with: the host layer warns
+// when the runtime's major differs or its (major, minor) is below the build's, instead of finding out through a missing symbol.
+int32_t kh_hip_versions(int32_t* build_version, int32_t* runtime_version) {
+    KH_REQUIRE(build_version && runtime_version, KH_ERR_INVALID_ARG, "kh_hip_versions: null out pointer");
+    *build_version = HIP_VERSION;
+    int rv = 0;
+    if (hipRuntimeGetVersion(&rv) != hipSuccess) { (void)hipGetLastError(); rv = 0; }
+    *runtime_version = rv;
+    return KH_OK;
+}
+
 int32_t kh_device_count(int32_t* count) {
     KH_REQUIRE(count, KH_ERR_INVALID_ARG, "kh_device_count: null out pointer");
     int n = 0;

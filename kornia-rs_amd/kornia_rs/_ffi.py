@@ -86,6 +86,7 @@ SIGNATURES = {
     "kh_debug_set_option": (_i32, [C.c_char_p, _i32]),
     "kh_version": (C.c_char_p, []),
     "kh_hip_runtime_images": (_i32, [C.c_char_p, C.c_size_t]),
+    "kh_hip_versions": (_i32, [_P(_i32), _P(_i32)]),
     "kh_dlpack_noop_deleter": (None, [_vp]),
     "kh_device_count": (_i32, [_P(_i32)]),
     "kh_set_device": (_i32, [_i32]),
@@ -395,6 +396,35 @@ def _load() -> C.CDLL:
 
 
 lib = _load()
+
+
+def hip_versions() -> tuple:
+    """((major, minor, patch) the library was built against, (major, minor, patch) of the runtime it is bound to)."""
+    b, r = C.c_int32(0), C.c_int32(0)
+    lib.kh_hip_versions(C.byref(b), C.byref(r))
+    split = lambda v: (v // 10_000_000, v // 100_000 % 100, v % 100_000)
+    return split(b.value), split(r.value)
+
+
+RUNTIME_VERSION_NOTE = ""
+
+
+def _check_runtime_version() -> None:
+    """The torch-bundle preload (one runtime per process) can bind a library built with ROCm 7.2 to the wheel's 7.0 runtime.  Same major
+    = same SONAME (libamdhip64.so.7) and ABI: recorded in ``hip.runtime_info()["version"]``, no noise.  Another MAJOR is a warning."""
+    global RUNTIME_VERSION_NOTE
+    try:
+        build, run = hip_versions()
+    except Exception:
+        return
+    RUNTIME_VERSION_NOTE = f"built against HIP {build[0]}.{build[1]}.{build[2]}, runtime reports {run[0]}.{run[1]}.{run[2]}"
+    if run != (0, 0, 0) and build != (0, 0, 0) and run[0] != build[0]:
+        import warnings
+        warnings.warn(f"libkornia_hip.so: {RUNTIME_VERSION_NOTE} ({RUNTIME_CHOICE}) — different major versions; set KORNIA_HIP_RUNTIME=system "
+                      "or to a matching libamdhip64", RuntimeWarning, stacklevel=2)
+
+
+_check_runtime_version()
 
 
 def last_error() -> str:

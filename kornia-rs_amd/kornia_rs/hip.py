@@ -459,7 +459,7 @@ def last_workspace_bytes() -> int:
 
 def runtime_info() -> dict:
     """Which HIP runtime image this process uses and how it was chosen (``_ffi._preload_hip_runtime``)."""
-    return {"choice": _ffi.RUNTIME_CHOICE, **_ffi.mapped_hip_runtimes()}
+    return {"choice": _ffi.RUNTIME_CHOICE, "version": _ffi.RUNTIME_VERSION_NOTE, **_ffi.mapped_hip_runtimes()}
 
 
 def pointer_domain(ptr: int) -> Tuple[int, int]:

@@ -173,6 +173,8 @@ hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* status);
 typedef int hipDevice_t;
 hipError_t hipStreamGetDevice(hipStream_t s, hipDevice_t* device);
 hipError_t hipEventQuery(hipEvent_t e);
+#define HIP_VERSION 0
+inline hipError_t hipRuntimeGetVersion(int* v) { *v = 0; return hipSuccess; }
 hipError_t hipGraphGetNodes(hipGraph_t g, hipGraphNode_t* nodes, size_t* n);
 hipError_t hipGraphDestroy(hipGraph_t g);
 hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t* err, char* log, size_t n);

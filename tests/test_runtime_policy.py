@@ -163,3 +163,12 @@ def test_a_bundle_with_another_soname_is_not_preloaded():
     pytest.importorskip("torch")
     out = _load_child("soname_mismatch")
     assert "CHOICE system (torch bundle" in out and "MAPPED 1" in out, out
+
+
+def test_hip_versions_are_reported():
+    """kh_hip_versions: what the library was compiled against and what the bound runtime reports — the skew check behind the torch-bundle
+    preload (a torch wheel can bundle an older ROCm than the one the library was built with)."""
+    from kornia_rs import _ffi
+    build, run = _ffi.hip_versions()
+    assert build[0] >= 6 and len(build) == 3 and len(run) == 3        # built with ROCm 6+ (this image: 7.2)
+    assert _ffi.lib.kh_hip_versions(None, None) == _ffi.KH_ERR_INVALID_ARG
