@@ -355,12 +355,13 @@ __global__ __launch_bounds__(256) void sep_v_u8_lds_kernel(Rz a, const int16_t* 
     const int16_t* __restrict__ h = hbuf + (long long)bz_ * a.sh * hrow;
     const int c0 = min(col, hrow - 1), c1 = min(col + 1, hrow - 1);
     const bool pairs = (hrow & 1) == 0;   // rows start dword-aligned: one load per (row, column pair) instead of two 2-byte loads
+    const int cp = min(col, max(hrow - 2, 0));   // even
     for (int rb = wave; rb < nr; rb += 4 * 16) {   // sixteen rows of loads in flight per lane before the first LDS write
         uint32_t v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int16_t* row = h + (long long)min(max(r0 + min(rb + 4 * j, nr - 1), 0), a.sh - 1) * hrow;   // vertical_row_scalar's clamp, kernels.rs:699-708
-            if (pairs) v[j] = *reinterpret_cast<const uint32_t*>(row + c0);   // c0 even; c1 == c0 + 1 (hrow even) or the lane is past the row
+            if (pairs) v[j] = *reinterpret_cast<const uint32_t*>(row + cp);   // lanes past the row re-read its last pair (found by the ASan build: row + hrow - 1 is not)
             else v[j] = (uint32_t)(uint16_t)row[c0] | ((uint32_t)(uint16_t)row[c1] << 16);
         }
 #pragma unroll

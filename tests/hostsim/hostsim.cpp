@@ -125,12 +125,12 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 // ---- runtime: one synchronous "device 0", device memory = host memory ----------------------------------------------------
 namespace {
 std::mutex g_mem_lock;
-std::map<const void*, hipMemoryType> g_allocs;  // base pointers only: enough for kh_pointer_domain
+std::map<const void*, std::pair<hipMemoryType, size_t>> g_allocs;  // base -> (kind, bytes): kh_pointer_domain, the staging ring's pinned-source test
 hipError_t track(void** p, size_t n, hipMemoryType type) {
     *p = calloc(n ? n : 1, 1);
     if (!*p) return hipErrorOutOfMemory;
     std::lock_guard<std::mutex> g(g_mem_lock);
-    g_allocs[*p] = type;
+    g_allocs[*p] = {type, n ? n : 1};
     return hipSuccess;
 }
 hipError_t untrack(void* p) {
@@ -216,7 +216,8 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
     auto it = g_allocs.upper_bound(p);  // the allocation that starts at or before p
     if (it == g_allocs.begin()) return hipErrorInvalidValue;
     --it;
-    a->type = it->second; a->device = 0;
-    return hipSuccess;  // (no size tracking: any address above a live base is attributed to it — fine for the tests)
+    if ((const char*)p >= (const char*)it->first + it->second.second) return hipErrorInvalidValue;   // past the end of that allocation: plain host memory
+    a->type = it->second.first; a->device = 0;
+    return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
