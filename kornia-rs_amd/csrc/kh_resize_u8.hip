@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kBx* kBy) void sep_h_u8_kernel(Rz a, int16_t* __res
 // The LDS-staged horizontal pass works on tiles of kSepTX destination columns x kSepRows source rows (256 threads: a thread owns one
 // column for four rows).  Round 2's version of it kept the source bytes INTERLEAVED in LDS (v_alignbyte + v_perm + v_dot2 per four
 // taps: 1.53 ms per 256 1080p -> 224 Lanczos frames, profiles/r04f); the planar v_dot4 kernel below replaced it.
-constexpr int kSepTX = 64, kSepRows = 16;
+constexpr int kSepTX = 64, kSepRows = 16, kSepRpt = 2;   // kSepRpt: rows per thread of the v_dot4 kernel (r04t: 2 vs 4)
 extern __shared__ __attribute__((aligned(16))) uint8_t kh_sep_lds[];
 
 typedef short i16x2_t __attribute__((ext_vector_type(2)));
@@ -218,9 +218,11 @@ __device__ __forceinline__ void store_planes(uint8_t* base, int pitchp, const ui
 
 // PITCH (bytes per plane row in LDS) is a template constant so that the twelve (row, plane) reads of a step are ONE address register plus
 // immediate offsets.
-template <int C, int PITCH>
-__global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __restrict__ hbuf, SepTab tx) {
-    constexpr int pitchp = PITCH;
+// RPT rows per thread: a block is 64 x (kSepRows / RPT) threads.  RPT = 2 (512 threads, 8 waves) keeps twice the waves resident
+// per staged tile — the tile's LDS, not registers, limits the blocks per CU — at the price of reading each weight twice.
+template <int C, int PITCH, int RPT>
+__global__ __launch_bounds__(64 * (kSepRows / RPT)) void sep_h_u8_dot4_kernel(Rz a, int16_t* __restrict__ hbuf, SepTab tx) {
+    constexpr int pitchp = PITCH, NW = kSepRows / RPT, NT = 64 * NW;   // waves, threads per block
     uint8_t* S = kh_sep_lds;  // [kSepRows][C][pitchp] signed bytes (p - 128), then the tile's weights [steps][kSepTX] x 16 B
     unsigned bx_, by_, bz_;
     if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
@@ -234,14 +236,14 @@ __global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __res
     // per row, and a per-BYTE path for every tile that touches the left or right image border — half of the tiles of a 224-wide
     // destination.  Now a thread has all its wide loads in flight before the first LDS write, and only the few groups that actually
     // straddle a border take the clamped bytes.
-    // thread -> (4-pixel group q = lane + 64 j, row 4 i + wave): no per-item division; kQ x 4 independent wide loads in flight per thread
+    // thread -> (4-pixel group q = lane + 64 j, row NW i + wave): no per-item division; kQ x RPT independent wide loads in flight per thread
     constexpr int kQ = 3;
     const int nq = span >> 2;
     for (int q0 = lane; q0 < nq; q0 += 64 * kQ) {
-        uint32_t d[4][kQ][C];
+        uint32_t d[RPT][kQ][C];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = min(4 * i + wave, nrows - 1);
+        for (int i = 0; i < RPT; ++i) {
+            const int r = min(NW * i + wave, nrows - 1);
 #pragma unroll
             for (int j = 0; j < kQ; ++j) {
                 const int q = min(q0 + 64 * j, nq - 1), px0 = p0a + 4 * q;
@@ -251,8 +253,8 @@ __global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __res
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 4 * i + wave;
+        for (int i = 0; i < RPT; ++i) {
+            const int r = NW * i + wave;
             if (r >= nrows) break;
 #pragma unroll
             for (int j = 0; j < kQ; ++j) {
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __res
             }
         }
     }
-    for (int e = tid; e < kSepTX * steps; e += 256) {   // the tile's weight rows, transposed to [step][column]: contiguous in global memory
+    for (int e = tid; e < kSepTX * steps; e += NT) {   // the tile's weight rows, transposed to [step][column]: contiguous in global memory
         const int xr = e / steps, st = e - xr * steps;
         W[st * kSepTX + xr] = reinterpret_cast<const u32x4_t*>(tx.w8)[(uint32_t)(min(X0 + xr, a.dw - 1) * steps + st)];
     }
@@ -284,10 +286,10 @@ __global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __res
     const int rel = tx.aofs[x] - p0a;   // multiple of 8
     // rows past the image (a ragged last tile) read LDS rows nobody staged — whatever they hold is finite integer data, and the
     // results are not stored — so the four rows of a thread are always base + i * C * PITCH
-    const uint8_t* base = kh_sep_lds + wave * 4 * (C * pitchp) + rel;
-    int32_t al[4][C], ah[4][C];
+    const uint8_t* base = kh_sep_lds + wave * RPT * (C * pitchp) + rel;
+    int32_t al[RPT][C], ah[RPT][C];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RPT; ++i)
 #pragma unroll
         for (int c = 0; c < C; ++c) { al[i][c] = (128 << 14) + 8192; ah[i][c] = 0; }   // 128 * sum(w) and the rounding constant ride in the low sum
     // NOT unrolled: with two steps in one body the compiler fuses the two 8-byte reads of a (row, plane) into one ds_read_b128 at an
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __res
         const u32x4_t w = W[s8 * kSepTX + lane];   // {wl[0..3], wl[4..7], wh[0..3], wh[4..7]}
         const uint8_t* pb = base + 8 * s8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RPT; ++i)
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const u32x2_t p = *reinterpret_cast<const u32x2_t*>(pb + (i * C + c) * pitchp);
@@ -309,8 +311,8 @@ __global__ __launch_bounds__(256) void sep_h_u8_dot4_kernel(Rz a, int16_t* __res
             }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 4 + i;
+    for (int i = 0; i < RPT; ++i) {
+        const int r = wave * RPT + i;
         if (r >= nrows) break;
         int16_t* o = hbuf + (long long)bz_ * a.sh * a.dw * C + (uint32_t)(((sy0 + r) * a.dw + x) * C);
 #pragma unroll
@@ -686,11 +688,11 @@ int32_t launch_sep_h(hipStream_t st, const void* src, int sw, int sh, int dw, in
         Rz ah = make_rz(src, nullptr, sw, sh, dw, dh, ss, 0, batch, dw, sh);
         ah.tiles = xcd_tiles(cdiv(dw, kSepTX), cdiv(sh, kSepRows), (unsigned)batch, cdiv(dw, kSepTX) * 8);
         if (ah.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-        const dim3 grid = xcd_grid(ah.tiles), blk(256);
+        const dim3 grid = xcd_grid(ah.tiles), blk(64 * (kSepRows / kSepRpt));
 #define KH_SEPH(CC, PP)                                                                                                                     \
     do {                                                                                                                                    \
-        if (lds8 > 48 * 1024) KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_dot4_kernel<CC, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
-        hipLaunchKernelGGL((sep_h_u8_dot4_kernel<CC, PP>), grid, blk, lds8, st, ah, hbuf, tx);                                              \
+        if (lds8 > 48 * 1024) KH_HIP(hipFuncSetAttribute((const void*)sep_h_u8_dot4_kernel<CC, PP, kSepRpt>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+        hipLaunchKernelGGL((sep_h_u8_dot4_kernel<CC, PP, kSepRpt>), grid, blk, lds8, st, ah, hbuf, tx);                                              \
     } while (0)
 #define KH_SEPH_C(CC) do { if (pitchp == 320) KH_SEPH(CC, 320); else if (pitchp == 640) KH_SEPH(CC, 640); else KH_SEPH(CC, 1280); } while (0)
         if (channels == 1) KH_SEPH_C(1); else if (channels == 3) KH_SEPH_C(3); else KH_SEPH_C(4);

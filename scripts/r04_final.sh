@@ -32,4 +32,14 @@ done
 cd "$REPO"
 python scripts/pmc_to_traffic.py "$OUT/default_pmc_FETCH_SIZE_counter_collection.csv" "$OUT/default_pmc_WRITE_SIZE_counter_collection.csv" "profiles/${TAG}_default_pmc_{FETCH,WRITE}_SIZE_counter_collection.csv: rocprofv3 --pmc passes of the default bench run (scripts/r04_final.sh)" | tee "$OUT/traffic.txt"
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"
-du -sh "$OUT"; ls -la "$OUT" | head -30
+if [ "${COUNTERS:-1}" = "1" ]; then
+  echo "== SQ / TA counters of the kernels re-designed in round 4"
+  for wl in pyrdown_f32_4k nv12_chw_640 nv12_chw_608 resize_u8_224; do
+    bash scripts/diag/pmc_cmd.sh $TAG/after_$wl "python $REPO/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --also none" \
+      "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+      "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
+      "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum" 2>&1 | tail -4 | cut -c1-400
+    cp "$OUT/after_$wl/pmc_table.txt" "$OUT/after_${wl}_counters.csv" 2>/dev/null
+  done
+fi
+du -sh "$OUT"; ls "$OUT" | head -40
