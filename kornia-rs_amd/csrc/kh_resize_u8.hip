@@ -372,18 +372,24 @@ __global__ __launch_bounds__(256) void sep_v_u8_lds_kernel(Rz a, const int16_t* 
     }
     // the segment's weight rows: a tap's weight is wave-uniform but 16-bit, which has no scalar load on this part — read from global
     // memory inside the tap loop it was one dependent vector load per tap (r04h: 69 % of the wave-cycles parked)
-    uint16_t* Wv = reinterpret_cast<uint16_t*>(S + ty.vrows * 64);   // [vty][kp]
+    uint16_t* Wv = reinterpret_cast<uint16_t*>(S + (ty.vrows + 3) * 64);   // [vty][kp], after three spare rows (see the tap loop)
     for (int e = threadIdx.x; e < (Y1 - Y0) * ty.kp; e += 256) Wv[e] = (uint16_t)ty.w[(long long)Y0 * ty.kp + e];
     __syncthreads();
     for (int y = Y0 + wave; y < Y1; y += 4) {
         const uint32_t* tap = S + (ty.ofs[y] - r0) * 64 + lane;
         const uint16_t* w = Wv + (y - Y0) * ty.kp;
         int32_t acc0 = 0, acc1 = 0;
-        for (int t = 0; t < ty.k; ++t) {
-            const uint32_t v = tap[t * 64];
-            const uint32_t wt = w[t];   // {wt, 0} and {0, wt} as i16 pairs
-            acc0 = dot2_i16(v, wt, acc0);
-            acc1 = dot2_i16(v, wt << 16, acc1);
+        // four taps per trip (kp is a multiple of four, padded with ZERO weights; the staged window is followed by the weight rows, so the
+        // up to three rows read past it are finite data times zero): four independent LDS reads in flight instead of one per dependent step
+        for (int t = 0; t < ty.kp; t += 4) {
+            uint32_t v[4], wt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v[u] = tap[(t + u) * 64]; wt[u] = w[t + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc0 = dot2_i16(v[u], wt[u], acc0);          // {wt, 0} and {0, wt} as i16 pairs
+                acc1 = dot2_i16(v[u], wt[u] << 16, acc1);
+            }
         }
         uint8_t* o = a.dst + (long long)bz_ * a.ds + (long long)y * hrow;
         if (col < hrow) o[col] = (uint8_t)min(max((acc0 + 8192) >> 14, 0), 255);
@@ -773,7 +779,9 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
             Rz al = av;
             al.tiles = xcd_tiles(cdiv(hrow, 128), cdiv(dh, ty.vty), (unsigned)batch, cdiv(hrow, 128) * 4);
             if (al.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-            hipLaunchKernelGGL(sep_v_u8_lds_kernel, xcd_grid(al.tiles), dim3(256), (size_t)ty.vrows * 256 + (size_t)ty.vty * ty.kp * 2, st, al, (const int16_t*)hbuf, ty, hrow);
+            const size_t vlds = (size_t)(ty.vrows + 3) * 256 + (size_t)ty.vty * ty.kp * 2;
+            if (vlds > 48 * 1024) KH_HIP(hipFuncSetAttribute((const void*)sep_v_u8_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            hipLaunchKernelGGL(sep_v_u8_lds_kernel, xcd_grid(al.tiles), dim3(256), vlds, st, al, (const int16_t*)hbuf, ty, hrow);
         } else {
             hipLaunchKernelGGL(sep_v_u8_kernel, xcd_grid(av.tiles), blk, 0, st, av, (const int16_t*)hbuf, ty, hrow);
         }
