@@ -22,7 +22,7 @@ KERNELS = {
     "gray_from_rgb_u8_1080p_b1024": ["GrayFromRgbU8"],
     "nv12_1080p_to_chw_f32_b1024": ["preprocess_nv12_identity"],
     "nv12_1080p_to_chw_f32_letterbox640_b1024": ["preprocess_generic_quads<3, 100"],
-    "nv12_1080p_to_chw_f32_letterbox608_b1024": ["preprocess_generic<3, 1, float"],
+    "nv12_1080p_to_chw_f32_letterbox608_b1024": ["preprocess_generic_quads<3, 1,", "preprocess_generic<3, 1, float"],
     "yuyv_1080p_to_chw_f32_letterbox640_b1024": ["preprocess_generic_quads<4, 100"],
     "resize_bilinear_1080p_to_224_f32_b256": ["resize_kernel<3, 1", "resize_kernel<3,bilinear"],
     "resize_bicubic_1080p_to_540p_f32_b256": ["resize_kernel<3, 2", "resize_kernel<3,bicubic"],
