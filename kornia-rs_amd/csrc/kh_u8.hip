@@ -823,6 +823,7 @@ __global__ __launch_bounds__(kBx* kBy) void warp_perspective_u8_kernel(ImgU8 im,
 // floors and integer blend as those kernels: byte-identical (tests run both).
 constexpr int kStageW = 64, kStageH = 32;   // destination tile (same-box A/B on the 4K rotation, r02p: 8 rows 5.05 ms, 16 rows 4.60, 32 rows 4.46)
 constexpr int kStageCap = 8192;             // staged pixels per block: 32 KiB of LDS; four 512-thread blocks per CU (the wave limit)
+constexpr int kSpanRows = 128;             // boxes of at most this many rows keep a per-row column span (affine)
 constexpr int kStageNB = 8;                 // images per block (4 -> 8: the geometry phase was still ~15 of 43 VALU instructions per pixel and image, r03f)
 enum { kOpAffine = 0, kOpPersp = 1, kOpRemap = 2 };
 struct GatherOp {
@@ -831,6 +832,8 @@ struct GatherOp {
     int dsx_q, dsy_q;                         // affine: Q16 column steps
     int batch;
     int nb = kStageNB;                        // images per block (set by launch_staged_gather)
+    int lds_mod = 0;                          // test option warp_u8_lds_pitch: LDS row pitch = roundup32(box pitch) + 4 * (lds_mod - 1) when it fits
+    int spans = 1;                            // affine: stage only the quads inside the per-row spans of the box (test option warp_u8_spans = 0: the whole box)
 };
 
 // bilinear_sample_u8's admission rule (P/warp/common.rs:16-70), as in sample_q10_checked: non-finite or outside -> not sampled
@@ -876,14 +879,15 @@ __device__ __forceinline__ u32x4_t unpack_raw_quad(const RawQuad<C>& r) {
 
 // The same for a box that reaches past the last image column (tiles at the right border only; a rolled loop, one quad at a time):
 // such a quad was loaded from the row's last four columns and is re-indexed so that cells past the edge replicate it.
-template <int C>
-__device__ __forceinline__ void stage_rounds_edge(uint32_t* __restrict__ tile, const uint8_t* __restrict__ src, const uint32_t (&soff)[4], int tid, int nq,
-                                               int kmax, int xmin, int pitch, int sw) {
+template <int C, int NT>
+__device__ __forceinline__ void stage_rounds_edge(uint32_t* __restrict__ tile, const uint8_t* __restrict__ src, const uint32_t (&soff)[4], unsigned wmask, int tid, int nq,
+                                               int kmax, int xmin, int pitch, int lpitch, int sw) {
     const int qpr = pitch >> 2;
 #pragma unroll 1
     for (int k = 0; k < kmax; ++k) {
-        const int q = tid + k * (16 * kStageH);
+        const int q = tid + k * NT;
         if (q >= nq) break;
+        if (!((wmask >> k) & 1u)) continue;   // a quad outside its row's span: not staged
         uint32_t a[4];
         load_quad_px<C>(src + soff[k], a);
         const int c0 = xmin + 4 * (q % qpr), d = c0 - min(c0, sw - 4);   // 0 for the quads inside the row
@@ -893,7 +897,7 @@ __device__ __forceinline__ void stage_rounds_edge(uint32_t* __restrict__ tile, c
             const int t = min(d + j, 3);
             o[j] = t == 0 ? a[0] : (t == 1 ? a[1] : (t == 2 ? a[2] : a[3]));
         }
-        *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = u32x4_t{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<u32x4_t*>(&tile[(q / qpr) * lpitch + 4 * (q % qpr)]) = u32x4_t{o[0], o[1], o[2], o[3]};
     }
 }
 
@@ -903,7 +907,7 @@ __device__ __forceinline__ void stage_rounds_edge(uint32_t* __restrict__ tile, c
 // (Tried, r03ze: boxes of at most half the tile alternating between its two halves — ONE barrier per image instead of two: no change
 // in time on any of the three operators; the barriers are not what bounds the kernel.)
 template <int C, int KM>
-__device__ __forceinline__ void staged_images(uint32_t* __restrict__ tile, const ImgU8& im, int z0, int nimg, const uint32_t (&soff)[4], int tid, int nq,
+__device__ __forceinline__ void staged_images(uint32_t* __restrict__ tile, const ImgU8& im, int z0, int nimg, const uint32_t (&soff)[4], const int (&sdst)[4], unsigned wmask, int tid,
                                               const int (&la)[4], int pitch, const uint32_t (&fxp)[4], const uint32_t (&fy16)[4], unsigned valid,
                                               long long dst_off, bool mine, bool whole, int x4) {
     const uint8_t* src = im.src + (long long)z0 * im.src_stride;
@@ -914,8 +918,7 @@ __device__ __forceinline__ void staged_images(uint32_t* __restrict__ tile, const
     for (int b = 0; b < nimg; ++b) {
         #pragma unroll
         for (int k = 0; k < KM; ++k) {
-            const int q = tid + k * (16 * kStageH);
-            if (q < nq) *reinterpret_cast<u32x4_t*>(&tile[q * 4]) = unpack_raw_quad<C>(raw[k]);   // q * 4 == r * pitch + 4 * c4
+            if ((wmask >> k) & 1u) *reinterpret_cast<u32x4_t*>(&tile[sdst[k]]) = unpack_raw_quad<C>(raw[k]);   // r * lpitch + 4 * c4
         }
         __syncthreads();
         if (b + 1 < nimg) {   // block-uniform
@@ -949,14 +952,16 @@ __device__ __forceinline__ void staged_images(uint32_t* __restrict__ tile, const
     }
 }
 
-template <int C, int OP>
-__global__ __launch_bounds__(16 * kStageH) void gather_u8_staged_kernel(ImgU8 im, GatherOp op) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[kStageCap];
+template <int C, int OP, int TH>
+__global__ __launch_bounds__(kStageW / 4 * TH) void gather_u8_staged_kernel(ImgU8 im, GatherOp op) {
+    constexpr int TW = kStageW, QX = TW / 4, NT = QX * TH, CAP = kStageCap * TH / kStageH;
+    __shared__ __attribute__((aligned(16))) uint32_t tile[CAP];
     __shared__ uint32_t red[16];
+    __shared__ uint32_t span_lo[OP == kOpAffine ? kSpanRows : 1], span_hi[OP == kOpAffine ? kSpanRows : 1];
     unsigned bx_, by_, bz_;
     if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;   // block-uniform
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;   // block (16, 32): 16 four-pixel groups x 32 rows
-    const int x4 = bx_ * kStageW + 4 * tx, y = by_ * kStageH + ty;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * QX + tx;   // block (QX, TH): QX four-pixel groups x TH rows
+    const int x4 = bx_ * TW + 4 * tx, y = by_ * TH + ty;
     const bool row_in = y < im.dh;
     const int yc = min(y, im.dh - 1);
 
@@ -1024,7 +1029,7 @@ __global__ __launch_bounds__(16 * kStageH) void gather_u8_staged_kernel(ImgU8 im
     if ((tid & 63) == 0) { red[2 * (tid >> 6)] = __builtin_bit_cast(uint32_t, lo2); red[2 * (tid >> 6) + 1] = __builtin_bit_cast(uint32_t, hi2); }
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
         lo2 = __builtin_elementwise_min(lo2, __builtin_bit_cast(u16x2_t, red[2 * w]));
         hi2 = __builtin_elementwise_max(hi2, __builtin_bit_cast(u16x2_t, red[2 * w + 1]));
     }
@@ -1036,29 +1041,71 @@ __global__ __launch_bounds__(16 * kStageH) void gather_u8_staged_kernel(ImgU8 im
 
     // staged box: columns [xmin, xmin + pitch), rows [ymin, ymax + 1]: one column / row more than the first taps reach
     const int bh = ymax + 2 - ymin, pitch = (xmax + 2 - xmin + 3) & ~3;
-    const bool staged = any && pitch * bh <= kStageCap;         // block-uniform
+    const bool staged = any && pitch * bh <= CAP;         // block-uniform
+    int lpitch = pitch;                                         // LDS row pitch (dwords, a multiple of 4)
+    if (op.lds_mod > 0) {
+        const int p2 = ((pitch + 31) & ~31) + 4 * (op.lds_mod - 1);
+        if (p2 * bh <= CAP) lpitch = p2;
+    }
 
     // C. per-thread plan, from the box: LDS tap index per pixel; source byte offset of the (up to four) quads this thread stages.
-    int la[4];
+    // C0 (affine).  The box of a rotated tile is up to twice its footprint (64 x 32 at 12 degrees: 1.97 staged source pixels per
+    // destination pixel, the footprint 1.24): each box row keeps the column span its taps use — per thread the columns of its four
+    // pixels, on the rows they touch (min / max through LDS atomics, once per block) — and only the quads inside a row's span
+    // are loaded and written (1.39 per pixel).  Exact by construction like the box: a cell outside every span is never read.
+    bool spans = false;   // block-uniform
+    if constexpr (OP == kOpAffine) {
+        spans = staged && op.spans != 0 && bh <= kSpanRows;
+        if (spans) {
+            if (tid < bh) { span_lo[tid] = 0xFFFFu; span_hi[tid] = 0u; }
+            __syncthreads();
+            if (valid) {
+                uint32_t cmin = 0xFFFFu, cmax = 0u, rmin = 0xFFFFu, rmax = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((valid >> j) & 1u) {
+                        const uint32_t c = (xy[j] & 0xFFFFu) - (uint32_t)xmin, r = (xy[j] >> 16) - (uint32_t)ymin;
+                        cmin = min(cmin, c); cmax = max(cmax, c); rmin = min(rmin, r); rmax = max(rmax, r);
+                    }
+                for (uint32_t r = rmin; r <= rmax + 1u; ++r) { atomicMin(&span_lo[r], cmin); atomicMax(&span_hi[r], cmax + 1u); }
+            }
+            __syncthreads();
+        }
+    }
+    int la[4], sdst[4];
     uint32_t soff[4];
+    unsigned wmask = 0;      // bit k: this thread stages the quad of round k
     int kmax = 0, nq = 0;    // block-uniform: staging rounds (512 quads each), quads in the box
     bool at_edge = false;    // block-uniform: the box reaches past the last image column (replicated cells)
     if (staged) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            la[j] = ((valid >> j) & 1u) ? (int)__umul24((xy[j] >> 16) - (uint32_t)ymin, (uint32_t)pitch) + (int)((xy[j] & 0xFFFFu) - (uint32_t)xmin) : 0;
+            la[j] = ((valid >> j) & 1u) ? (int)__umul24((xy[j] >> 16) - (uint32_t)ymin, (uint32_t)lpitch) + (int)((xy[j] & 0xFFFFu) - (uint32_t)xmin) : 0;
         const int qpr = pitch >> 2;
         nq = qpr * bh;
-        kmax = (nq + 16 * kStageH - 1) / (16 * kStageH);
+        kmax = (nq + NT - 1) / NT;
         at_edge = xmin + pitch > im.sw;
         const float inv_qpr = 1.0f / (float)qpr;   // q / qpr for q < 2048: the float quotient is within one of the integer one
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int q0 = tid + k * (16 * kStageH), q = q0 < nq ? q0 : 0;   // idle lanes re-load the box's first quad (and do not write it)
+            const int q0 = tid + k * NT, q = q0 < nq ? q0 : 0;   // idle lanes re-load the box's first quad (and do not write it)
             int r_ = (int)((float)q * inv_qpr);
             r_ -= (r_ * qpr > q);
             r_ += ((r_ + 1) * qpr <= q);
-            const int c0 = xmin + 4 * (q - r_ * qpr);
+            int c4 = q - r_ * qpr;
+            sdst[k] = r_ * lpitch + 4 * c4;
+            bool need = q0 < nq;
+            if constexpr (OP == kOpAffine) {
+                if (spans) {
+                    const int lo = (int)span_lo[r_], hi = (int)span_hi[r_];
+                    if (lo <= hi) {   // (every row of the box is touched; an untouched one would be staged whole)
+                        need = need && 4 * c4 + 3 >= lo && 4 * c4 <= hi;
+                        c4 = min(max(c4, lo >> 2), hi >> 2);   // a skipped quad re-loads a quad of its row that is staged anyway
+                    }
+                }
+            }
+            wmask |= (need ? 1u : 0u) << k;
+            const int c0 = xmin + 4 * c4;
             // an edge quad is loaded from the last four columns of its row and re-indexed afterwards (sw >= 4: host-checked)
             const int cl = at_edge ? min(c0, im.sw - 4) : c0;
             soff[k] = __umul24((uint32_t)min(ymin + r_, im.sh - 1), (uint32_t)(im.sw * C)) + (uint32_t)(cl * C);
@@ -1067,7 +1114,7 @@ __global__ __launch_bounds__(16 * kStageH) void gather_u8_staged_kernel(ImgU8 im
 #pragma unroll
         for (int j = 0; j < 4; ++j) la[j] = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) soff[k] = 0u;
+        for (int k = 0; k < 4; ++k) { soff[k] = 0u; sdst[k] = 0; }
     }
 
     // D. the images of this block: stage the box, barrier, sample, store; the second barrier keeps the next image's staging off a box
@@ -1085,23 +1132,23 @@ __global__ __launch_bounds__(16 * kStageH) void gather_u8_staged_kernel(ImgU8 im
     };
     if (staged && !at_edge) {
         switch (kmax) {   // block-uniform
-            case 1: staged_images<C, 1>(tile, im, z0, nimg, soff, tid, nq, la, pitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
-            case 2: staged_images<C, 2>(tile, im, z0, nimg, soff, tid, nq, la, pitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
-            case 3: staged_images<C, 3>(tile, im, z0, nimg, soff, tid, nq, la, pitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
-            default: staged_images<C, 4>(tile, im, z0, nimg, soff, tid, nq, la, pitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
+            case 1: staged_images<C, 1>(tile, im, z0, nimg, soff, sdst, wmask, tid, la, lpitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
+            case 2: staged_images<C, 2>(tile, im, z0, nimg, soff, sdst, wmask, tid, la, lpitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
+            case 3: staged_images<C, 3>(tile, im, z0, nimg, soff, sdst, wmask, tid, la, lpitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
+            default: staged_images<C, 4>(tile, im, z0, nimg, soff, sdst, wmask, tid, la, lpitch, fxp, fy16, valid, dst_off, mine, whole, x4); break;
         }
     } else if (staged) {   // tiles whose box reaches past the last image column: rolled staging loop, no pipelining
 #pragma unroll 1
         for (int b = 0; b < nimg; ++b) {
             const uint8_t* src = im.src + (long long)(z0 + b) * im.src_stride;
             if (b > 0) __syncthreads();
-            stage_rounds_edge<C>(tile, src, soff, tid, nq, kmax, xmin, pitch, im.sw);
+            stage_rounds_edge<C, NT>(tile, src, soff, wmask, tid, nq, kmax, xmin, pitch, lpitch, im.sw);
             __syncthreads();
             uint32_t out[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t* t0 = tile + la[j];
-                const uint32_t px = blend_q10_w<C>(t0[0], t0[1], t0[pitch], t0[pitch + 1], fxp[j], fy16[j]);
+                const uint32_t px = blend_q10_w<C>(t0[0], t0[1], t0[lpitch], t0[lpitch + 1], fxp[j], fy16[j]);
                 out[j] = ((valid >> j) & 1u) ? px : 0u;
             }
             emit(im.dst + (long long)(z0 + b) * im.dst_stride + dst_off, out);
@@ -1150,17 +1197,27 @@ int32_t launch_staged_gather(hipStream_t st, const uint8_t* src, uint8_t* dst, i
     // 8 otherwise.
     GatherOp op = op_;
     op.nb = batch >= 128 ? 2 * kStageNB : kStageNB;
-    const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, kStageH), groups = cdiv(batch, op.nb);
-    // 64 x 32 tiles, dealt to the XCDs in runs of 8 tile rows like the other gathers
-    const ImgU8 im{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(tiles_x, tiles_y, groups, tiles_x * 8)};
+    op.lds_mod = max(dev_opt(kOptWarpU8LdsPitch), 0);
+    op.spans = dev_opt(kOptWarpU8Spans) != 0;
+    const int th = dev_opt(kOptWarpU8Rows) == 16 ? 16 : kStageH;
+    const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, th), groups = cdiv(batch, op.nb);
+    // 64 x 32 tiles, dealt to the XCDs in runs of 256 destination rows like the other gathers.  (128 x 16 tiles — whole 384-byte store rows,
+    // WRITE_SIZE 6.50 -> 6.22 GB — r04z1: perspective -2 %, remap +6 %, the 12-degree rotation +34 %: its box needs four staging rounds.)
+    const ImgU8 im{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(tiles_x, tiles_y, groups, tiles_x * (256 / th))};
     KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-    const dim3 grid = xcd_grid(im.tiles), blk(16, kStageH);
+    const dim3 grid = xcd_grid(im.tiles), blk(kStageW / 4, th);
+#define KH_STAGED(CH)                                                                                                \
+    do {                                                                                                             \
+        if (th == 16) hipLaunchKernelGGL((gather_u8_staged_kernel<CH, OP, 16>), grid, blk, 0, st, im, op);           \
+        else hipLaunchKernelGGL((gather_u8_staged_kernel<CH, OP, kStageH>), grid, blk, 0, st, im, op);               \
+    } while (0)
     switch (channels) {
-        case 1: hipLaunchKernelGGL((gather_u8_staged_kernel<1, OP>), grid, blk, 0, st, im, op); break;
-        case 2: hipLaunchKernelGGL((gather_u8_staged_kernel<2, OP>), grid, blk, 0, st, im, op); break;
-        case 3: hipLaunchKernelGGL((gather_u8_staged_kernel<3, OP>), grid, blk, 0, st, im, op); break;
-        default: hipLaunchKernelGGL((gather_u8_staged_kernel<4, OP>), grid, blk, 0, st, im, op); break;
+        case 1: KH_STAGED(1); break;
+        case 2: KH_STAGED(2); break;
+        case 3: KH_STAGED(3); break;
+        default: KH_STAGED(4); break;
     }
+#undef KH_STAGED
     return check_launch(what);
 }
 

@@ -173,6 +173,36 @@ def test_warp_affine_u8_both_kernels_agree(gpu_stream, dev_option):
     assert np.array_equal(direct[0], O.warp_affine_u8(src, m, 421, 150))
 
 
+@pytest.mark.parametrize("mod", [1, 6])
+@pytest.mark.parametrize("name", ["rot12_wide", "rot77_tall", "magnify5", "shear_out", "last_row"])
+def test_warp_affine_u8_lds_pitch_option(gpu_stream, dev_option, name, mod):
+    """Test option warp_u8_lds_pitch: the staged box keeps its LDS rows at a pitch rounded up to 32 dwords (+ 4 * (mod - 1)) —
+    a bank-conflict experiment (profiles/r04x); the bytes do not change."""
+    build, (w, h), (dw, dh) = STAGED_CASES[name]
+    m = build()
+    src = pat(w, h, 3)
+    dev_option("warp_u8_lds_pitch", mod)
+    got = warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0]
+    assert_same_bits(got, O.warp_affine_u8(src, m, dw, dh), f"staged affine_u8 {name} lds pitch option {mod}")
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("name", list(STAGED_CASES))
+def test_warp_affine_u8_whole_box_option(gpu_stream, dev_option, name, c):
+    """Production stages only the quads inside each box row's span (affine); the test option warp_u8_spans = 0 keeps the whole box.
+    Both are the restatement's bytes."""
+    build, (w, h), (dw, dh) = STAGED_CASES[name]
+    m = build()
+    src = pat(w, h, c)
+    want = O.warp_affine_u8(src, m, dw, dh)
+    assert_same_bits(warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0], want, f"staged affine_u8 {name} c{c} spans")
+    dev_option("warp_u8_spans", 0)
+    assert_same_bits(warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0], want, f"staged affine_u8 {name} c{c} whole box")
+    dev_option("warp_u8_spans", -1)
+    dev_option("warp_u8_rows", 16)
+    assert_same_bits(warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0], want, f"staged affine_u8 {name} c{c} 64 x 16 tiles")
+
+
 PROJ = [0.9, 0.12, 4.0, -0.08, 1.05, -2.0, 6.0e-4, -4.5e-4, 1.0]
 HOMOGRAPHIES = {"proj": PROJ, "affine_h": [1.1, 0.1, -3.0, -0.05, 0.95, 2.0, 0.0, 0.0, 1.0], "neg": [-v for v in PROJ],
                 "flip": [-1, 0, 128, 0, 1, 0, 0, 0, 1], "identity": [1, 0, 0, 0, 1, 0, 0, 0, 1],
