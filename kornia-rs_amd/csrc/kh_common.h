@@ -163,6 +163,8 @@ __device__ __forceinline__ void stream_store(__amdgpu_buffer_rsrc_t rs, int byte
 typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+// s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched): every vector-memory load and store of this wave has completed
+__device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 typedef u32x4_t u32x4_unaligned __attribute__((aligned(1)));
 
 // The four u8 taps of a bilinear sample — pixels x0 and x1 = min(x0 + 1, w - 1) of two rows, C channels

@@ -48,6 +48,7 @@ int lane_id();
 // ---- device intrinsics used by the kernels -------------------------------------------------------------------------
 inline void __syncthreads() { hostsim::block_barrier(); }
 #define __builtin_amdgcn_wave_barrier() hostsim::wave_barrier()
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
 inline int __shfl(int v, int lane) { return (int)hostsim::shfl_bits((uint32_t)v, lane); }
 inline int __shfl_xor(int v, int mask) { return (int)hostsim::shfl_bits((uint32_t)v, hostsim::lane_id() ^ mask); }
 // HIP: lanes whose source falls outside the wave keep their own value
