@@ -832,7 +832,7 @@ struct GatherOp {
     int dsx_q, dsy_q;                         // affine: Q16 column steps
     int batch;
     int nb = kStageNB;                        // images per block (set by launch_staged_gather)
-    int lds_mod = 0;                          // test option warp_u8_lds_pitch: LDS row pitch = roundup32(box pitch) + 4 * (lds_mod - 1) when it fits
+    int tile_rows = kStageH;                  // 32 or 16 destination rows per block (stage_rows below)
     int spans = 1;                            // affine: stage only the quads inside the per-row spans of the box (test option warp_u8_spans = 0: the whole box)
 };
 
@@ -1054,11 +1054,9 @@ __global__ __launch_bounds__(kStageW / 4 * TH) void gather_u8_staged_kernel(ImgU
     // staged box: columns [xmin, xmin + pitch), rows [ymin, ymax + 1]: one column / row more than the first taps reach
     const int bh = ymax + 2 - ymin, pitch = (xmax + 2 - xmin + 3) & ~3;
     const bool staged = any && pitch * bh <= CAP;         // block-uniform
-    int lpitch = pitch;                                         // LDS row pitch (dwords, a multiple of 4)
-    if (op.lds_mod > 0) {
-        const int p2 = ((pitch + 31) & ~31) + 4 * (op.lds_mod - 1);
-        if (p2 * bh <= CAP) lpitch = p2;
-    }
+    // LDS row pitch (dwords).  A pitch of 0 mod 32 takes a quarter off the tap reads' bank conflicts on the rotation (309 M -> 233 M
+    // cycles, as scripts/diag/lds_bank_sim.py predicts) for 1 % of the time (r04x): the LDS is a third busy; the box pitch stays.
+    const int lpitch = pitch;
 
     // C. per-thread plan, from the box: LDS tap index per pixel; source byte offset of the (up to four) quads this thread stages.
     // C0 (affine).  The box of a rotated tile is up to twice its footprint (64 x 32 at 12 degrees: 1.97 staged source pixels per
@@ -1201,6 +1199,15 @@ bool use_staged_gather(int sw, int sh) {
     const bool direct = dev_opt(kOptWarpU8Direct) == 1;
     return !direct && sw <= 65535 && sh <= 65535 && sw >= 4;   // 16-bit box fields; a staged quad is four pixels of one row
 }
+// Rows of the destination tile, from the Jacobian [a b; c d] of the destination -> source map (the matrix of an affine warp, a
+// homography's at the image centre): 64 x 16 tiles in 256-thread blocks — six per CU instead of three — when the box of such a tile
+// is staged in two rounds (near axis-aligned maps: perspective -5 %, remap -2 %, r04z2); a rotated tile's box needs the 512 threads of
+// a 64 x 32 tile (the 12-degree rotation: +12 % with 16 rows).
+int stage_rows(float a, float b, float c, float d) {
+    const float bw = 64.0f * fabsf(a) + 16.0f * fabsf(b) + 2.0f, bh = 64.0f * fabsf(c) + 16.0f * fabsf(d) + 2.0f;
+    if (!(bw < 1e6f && bh < 1e6f)) return kStageH;
+    return (ceilf(bw * 0.25f) + 1.0f) * ceilf(bh) <= 512.0f ? 16 : kStageH;
+}
 template <int OP>
 int32_t launch_staged_gather(hipStream_t st, const uint8_t* src, uint8_t* dst, int sw, int sh, int dw, int dh, int channels, int batch,
                              int64_t ss, int64_t ds, const GatherOp& op_, const char* what) {
@@ -1209,9 +1216,8 @@ int32_t launch_staged_gather(hipStream_t st, const uint8_t* src, uint8_t* dst, i
     // 8 otherwise.
     GatherOp op = op_;
     op.nb = batch >= 128 ? 2 * kStageNB : kStageNB;
-    op.lds_mod = max(dev_opt(kOptWarpU8LdsPitch), 0);
     op.spans = dev_opt(kOptWarpU8Spans) != 0;
-    const int th = dev_opt(kOptWarpU8Rows) == 16 ? 16 : kStageH;
+    const int forced = dev_opt(kOptWarpU8Rows), th = forced == 16 || forced == 32 ? forced : op.tile_rows;   // test option warp_u8_rows
     const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, th), groups = cdiv(batch, op.nb);
     // 64 x 32 tiles, dealt to the XCDs in runs of 256 destination rows like the other gathers.  (128 x 16 tiles — whole 384-byte store rows,
     // WRITE_SIZE 6.50 -> 6.22 GB — r04z1: perspective -2 %, remap +6 %, the 12-degree rotation +34 %: its box needs four staging rounds.
@@ -1309,7 +1315,8 @@ int32_t kh_remap_u8(kh_stream_t stream, const uint8_t* src, const float* map_x, 
     if (batch == 0) return KH_OK;
     KH_REQUIRE(map_x && map_y, KH_ERR_INVALID_ARG, "kh_remap_u8: null map pointer");
     if (mode == KH_INTERP_BILINEAR && use_staged_gather(sw, sh)) {
-        const GatherOp op{nullptr, map_x, map_y, 0, 0, batch};
+        GatherOp op{nullptr, map_x, map_y, 0, 0, batch};
+        op.tile_rows = 16;   // a correction map is close to the identity
         return launch_staged_gather<kOpRemap>(as_hip(stream), src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, op, "kh_remap_u8");
     }
     const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, (batch + kU8RemapNB - 1) / kU8RemapNB);
@@ -1346,7 +1353,8 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     AffineRow* rows = scratch.as<AffineRow>();
     hipLaunchKernelGGL(affine_rows_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, as_hip(stream), rows, dw, dh, sw, sh, mi);
     if (use_staged_gather(sw, sh)) {
-        const GatherOp op{rows, nullptr, nullptr, dsx_q, dsy_q, batch};
+        GatherOp op{rows, nullptr, nullptr, dsx_q, dsy_q, batch};
+        op.tile_rows = stage_rows(mi.m[0], mi.m[1], mi.m[3], mi.m[4]);
         return launch_staged_gather<kOpAffine>(as_hip(stream), src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, op, "kh_warp_affine_u8");
     }
     KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const AffineRow*)rows, dsx_q, dsy_q);
@@ -1369,7 +1377,12 @@ int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, uint8_t* 
     PerspRow* rows = scratch.as<PerspRow>();
     hipLaunchKernelGGL(persp_rows_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, as_hip(stream), rows, dw, dh, sw, sh, inv);
     if (use_staged_gather(sw, sh)) {
-        const GatherOp op{rows, nullptr, nullptr, 0, 0, batch};
+        GatherOp op{rows, nullptr, nullptr, 0, 0, batch};
+        {   // Jacobian of (x, y) -> (nx / nd, ny / nd) at the centre of the destination
+            const float x = 0.5f * (float)dw, y = 0.5f * (float)dh;
+            const float nd = inv.m[6] * x + inv.m[7] * y + inv.m[8], xs = (inv.m[0] * x + inv.m[1] * y + inv.m[2]) / nd, ys = (inv.m[3] * x + inv.m[4] * y + inv.m[5]) / nd;
+            op.tile_rows = stage_rows((inv.m[0] - xs * inv.m[6]) / nd, (inv.m[1] - xs * inv.m[7]) / nd, (inv.m[3] - ys * inv.m[6]) / nd, (inv.m[4] - ys * inv.m[7]) / nd);
+        }
         return launch_staged_gather<kOpPersp>(as_hip(stream), src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, op, "kh_warp_perspective_u8");
     }
     KH_DISPATCH_C(warp_perspective_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const PerspRow*)rows);

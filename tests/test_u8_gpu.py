@@ -173,19 +173,6 @@ def test_warp_affine_u8_both_kernels_agree(gpu_stream, dev_option):
     assert np.array_equal(direct[0], O.warp_affine_u8(src, m, 421, 150))
 
 
-@pytest.mark.parametrize("mod", [1, 6])
-@pytest.mark.parametrize("name", ["rot12_wide", "rot77_tall", "magnify5", "shear_out", "last_row"])
-def test_warp_affine_u8_lds_pitch_option(gpu_stream, dev_option, name, mod):
-    """Test option warp_u8_lds_pitch: the staged box keeps its LDS rows at a pitch rounded up to 32 dwords (+ 4 * (mod - 1)) —
-    a bank-conflict experiment (profiles/r04x); the bytes do not change."""
-    build, (w, h), (dw, dh) = STAGED_CASES[name]
-    m = build()
-    src = pat(w, h, 3)
-    dev_option("warp_u8_lds_pitch", mod)
-    got = warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0]
-    assert_same_bits(got, O.warp_affine_u8(src, m, dw, dh), f"staged affine_u8 {name} lds pitch option {mod}")
-
-
 @pytest.mark.parametrize("c", [1, 3, 4])
 @pytest.mark.parametrize("name", list(STAGED_CASES))
 def test_warp_affine_u8_whole_box_option(gpu_stream, dev_option, name, c):
@@ -199,8 +186,9 @@ def test_warp_affine_u8_whole_box_option(gpu_stream, dev_option, name, c):
     dev_option("warp_u8_spans", 0)
     assert_same_bits(warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0], want, f"staged affine_u8 {name} c{c} whole box")
     dev_option("warp_u8_spans", -1)
-    dev_option("warp_u8_rows", 16)
-    assert_same_bits(warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0], want, f"staged affine_u8 {name} c{c} 64 x 16 tiles")
+    for rows in (16, 32):   # production picks the tile height from the matrix (kh_u8.hip::stage_rows); both, forced
+        dev_option("warp_u8_rows", rows)
+        assert_same_bits(warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0], want, f"staged affine_u8 {name} c{c} 64 x {rows} tiles")
 
 
 PROJ = [0.9, 0.12, 4.0, -0.08, 1.05, -2.0, 6.0e-4, -4.5e-4, 1.0]
@@ -286,10 +274,12 @@ def test_remap_u8_known_answers_and_identity(gpu_stream):  # remap.rs:552-672
 
 
 # ---- the staged gather (round 3) on the other two operators: multi-tile images, partial image groups, tiles whose box does not fit ----
+@pytest.mark.parametrize("rows", [-1, 16, 32])   # -1: the launcher's choice (kh_u8.hip::stage_rows); 64 x 16 / 64 x 32 tiles forced
 @pytest.mark.parametrize("c", [1, 3, 4])
 @pytest.mark.parametrize("name", ["proj", "strong", "horizon", "neg"])
-def test_warp_perspective_u8_staged_tiles_match_oracle(gpu_stream, c, name):
+def test_warp_perspective_u8_staged_tiles_match_oracle(gpu_stream, dev_option, c, name, rows):
     m = HOMOGRAPHIES[name]
+    dev_option("warp_u8_rows", rows)
     for (w, h), (dw, dh), n in [((421, 150), (421, 150), 9), ((900, 500), (140, 75), 2), ((70, 45), (330, 215), 1)]:
         src = np.stack([pat(w, h, c, seed=31 * k) for k in range(n)])
         got = warp_u8_gpu(gpu_stream, "perspective", src, m, dw, dh, batch=n)
@@ -297,12 +287,14 @@ def test_warp_perspective_u8_staged_tiles_match_oracle(gpu_stream, c, name):
             assert_same_bits(got[k], O.warp_perspective_u8(src[k], m, dw, dh), f"staged perspective_u8 {name} c{c} {w}x{h}->{dw}x{dh} frame {k}")
 
 
+@pytest.mark.parametrize("rows", [-1, 32])   # production: 64 x 16 tiles; 64 x 32 forced
 @pytest.mark.parametrize("c", [1, 3])
 @pytest.mark.parametrize("kind", ["smooth", "magnify", "minify", "wild", "all_outside"])
-def test_remap_u8_staged_tiles_match_oracle(gpu_stream, c, kind):
+def test_remap_u8_staged_tiles_match_oracle(gpu_stream, dev_option, c, kind, rows):
     """Bilinear remap_u8 through the staged gather: smooth maps (boxes fit), magnification, strong minification and random maps (boxes do
     not fit: block-uniform global fallback), maps that leave the image everywhere (zero tiles); 5 images = one full group + 1."""
     from kornia_rs import _ffi
+    dev_option("warp_u8_rows", rows)
     w, h, dw, dh, n = 300, 170, 257, 131, 10   # 10 images = one full group of kStageNB = 8 + a partial one
     src = np.stack([pat(w, h, c, seed=31 * k) for k in range(n)])
     rng = np.random.default_rng(11)
@@ -328,11 +320,13 @@ def test_remap_u8_staged_tiles_match_oracle(gpu_stream, c, kind):
         assert_same_bits(got[k], O.remap_u8(src[k], mx, my, "bilinear"), f"staged remap_u8 {kind} c{c} frame {k}")
 
 
+@pytest.mark.parametrize("rows", [16, 32])
 @pytest.mark.parametrize("kind", ["affine", "perspective"])
-def test_staged_gather_sixteen_images_per_block(gpu_stream, kind):
+def test_staged_gather_sixteen_images_per_block(gpu_stream, dev_option, kind, rows):
     """Batches of 128 and more put 16 consecutive images in a block (8 below that).  130 images = eight full groups + a group of
     two; a mild rotation (boxes of ~3 000 pixels, two staging rounds), 30 degrees (~5 200, three) and 45 degrees at magnification
     1 / 0.6 (~12 800: no staging, the block-uniform global fallback)."""
+    dev_option("warp_u8_rows", rows)
     n, w, h, c = 130, 150, 70, 3
     src = np.stack([pat(w, h, c, seed=7 * k + 1) for k in range(n)])
     for ang, scale in [(9.0, 0.95), (30.0, 0.9), (45.0, 0.6)]:
