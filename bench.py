@@ -1417,7 +1417,8 @@ class Runner:
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": wl.kernel,
                 "alg_bytes_per_launch": wl.alg_bytes_per_launch, "mean_launch_ms": round(mean_kernel_s * 1e3, 4),
-                "min_launch_ms": round(float(np.min(kernel_ms)), 4)}
+                "min_launch_ms": round(float(np.min(kernel_ms)), 4),
+                "launch_ms": [round(float(v), 3) for v in kernel_ms[:32]]}
         if traffic:
             # Where the algorithmic figure counts only the taps a gather needs (C2) the kernel really moves whole 128-B
             # lines: report the HBM rate of the counted traffic next to the algorithmic one.

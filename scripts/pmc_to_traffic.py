@@ -36,9 +36,9 @@ KERNELS = {
     "hsv_from_rgb_f32_1080p_b512": ["HsvFromRgbF32"],
     "ycc_from_rgb_u8_1080p_b1024": ["YccFromRgbU8"],
     "ycc_from_rgb_f32_1080p_b512": ["YccFromRgbF32"],
-    "warp_affine_u8_4k_b256": ["gather_u8_staged_kernel<3, 0>"],
-    "warp_perspective_u8_4k_b256": ["gather_u8_staged_kernel<3, 1>"],
-    "remap_u8_undistort_4k_b256": ["gather_u8_staged_kernel<3, 2>"],
+    "warp_affine_u8_4k_b256": ["gather_u8_staged_kernel<3, 0,"],
+    "warp_perspective_u8_4k_b256": ["gather_u8_staged_kernel<3, 1,"],
+    "remap_u8_undistort_4k_b256": ["gather_u8_staged_kernel<3, 2,"],
     "gaussian_blur_u8_7x7_4k_b256": ["blur_u8_rgb_kernel<7>", "blur_u8_roll_kernel<7, 3"],
 }
 

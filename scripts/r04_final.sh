@@ -34,7 +34,7 @@ python scripts/pmc_to_traffic.py "$OUT/default_pmc_FETCH_SIZE_counter_collection
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"
 if [ "${COUNTERS:-1}" = "1" ]; then
   echo "== SQ / TA counters of the kernels re-designed in round 4"
-  for wl in pyrdown_f32_4k nv12_chw_640 nv12_chw_608 resize_u8_224; do
+  for wl in pyrdown_f32_4k nv12_chw_640 nv12_chw_608 resize_u8_224 warp_affine_u8_4k warp_perspective_u8_4k remap_u8_4k; do
     bash scripts/diag/pmc_cmd.sh $TAG/after_$wl "python $REPO/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --also none" \
       "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
       "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
