@@ -1376,8 +1376,15 @@ class Runner:
         if self.world > 1:
             self.dist.barrier(device_ids=[self.local_rank]) if self.on_gpu else self.dist.barrier()
 
-    def time(self, wl, steps, warmup):
+    def time(self, wl, steps, warmup, spinup_s=0.0):
         hip, stream = self.hip, self.stream
+        # Secondary rows only (spinup_s > 0): the previous row's CPU-baseline leg leaves the GPU idle for 10-30 s and its clocks down;
+        # two warm-up steps of a 4 ms kernel do not bring them back (box blur 5.2 ms in the line, 4.4 alone or in the kernel trace
+        # of the same command, profiles/r04zj_steps.txt).  Untimed steps of the row's own work for `spinup_s` of wall clock first.
+        t_end = time.perf_counter() + spinup_s
+        while spinup_s > 0.0 and self.on_gpu and time.perf_counter() < t_end:
+            wl.step()
+            stream.synchronize()
         for _ in range(warmup):
             wl.step()
         starts = [hip.Event(timing=True) for _ in range(steps)]
@@ -1599,7 +1606,7 @@ def main():
             w2 = make_workload(n, argparse.Namespace(batch=args.also_batch))
             w2.setup(stream)
             steps2 = 200 if n == "gray_258x195" else a_steps  # a 7 us launch needs more samples than a 10 ms one
-            e2, k2 = run.time(w2, steps2, a_warm)
+            e2, k2 = run.time(w2, steps2, a_warm, spinup_s=0.0 if args.no_cpu_baseline else 0.25)
             if rank == 0:
                 r2 = run.record(w2, steps2, a_warm, e2, k2, n)
                 r2["n_gpus"] = world
