@@ -210,7 +210,11 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
     const float* src = im.src + (long long)bz_ * im.src_stride;       \
     float* o = im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C;
 
-// resize (P/resize/mod.rs:161-176): half-pixel grid a*x + b, clamped to the source
+// resize (P/resize/mod.rs:161-176): half-pixel grid a*x + b, clamped to the source.
+// Bound by the texture addresser on moderate scales (1080p -> 540p bicubic: sixteen 12-byte gathers per pixel, TA_BUSY 100 %,
+// profiles/r04zk_resize_counters.csv).  An LDS-staged twin (64 x 8 tiles, the box copied with coalesced 16-byte loads, TA_BUSY 33 %)
+// was built, bit-identical, and measured 9 % SLOWER (1.85 vs 1.69 ms, profiles/r04zl_*): one box per block leaves the wave waiting
+// 69 % of its cycles (load -> LDS -> barrier -> sample, nothing to overlap with) and costs 1.6x the vector instructions.  Not kept.
 template <int C, int MODE>
 __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, float bx, float ay, float by) {
     KH_PIXEL_PROLOGUE
