@@ -87,7 +87,7 @@ __host__ __device__ __forceinline__ uint32_t fast_quot(uint32_t n, const FastDiv
 // decides; -1 = unset (the production choice).  Variants that were measured and rejected are not in the library at all.
 enum DevOpt : int {
     kOptPreIeeeDiv, kOptPreGrid, kOptPreQuads, kOptFilterForceTile, kOptFilterFourColumns, kOptGradScalar, kOptHfilterDirect,
-    kOptResizeU8Gather, kOptPyrDirect, kOptPyrRoll, kOptMorphDirect, kOptMorphRoll, kOptU8BlurRgb, kOptU8BlurSwar, kOptWarpU8Direct, kOptWarpU8Spans, kOptWarpU8Rows, kOptResizeStaged,
+    kOptResizeU8Gather, kOptPyrDirect, kOptPyrRoll, kOptMorphDirect, kOptMorphRoll, kOptU8BlurRgb, kOptU8BlurSwar, kOptWarpU8Direct, kOptWarpU8Spans, kOptWarpU8Rows,
     kOptCount
 };
 int dev_opt(DevOpt o);  // kh_runtime.hip

@@ -225,122 +225,6 @@ __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, floa
     put<C>(o, v);
 }
 
-// ---- staged resize (round 4): bilinear / bicubic taps from an LDS copy of the tile's source box ---------------------------------
-// The per-pixel kernel above is bound by the texture addresser on moderate scales: 1080p -> 540p bicubic issues sixteen 12-byte gathers
-// per pixel and keeps TA_BUSY at 100 % (profiles/r04zk_resize_counters.csv), although neighbouring pixels share half of their taps.
-// Here a 256-thread block owns a 64 x 8 destination tile, copies the tile's source box into LDS with coalesced 16-byte loads (4.9
-// source pixels per destination pixel at 2x instead of 16 gathers), and the same sampler expressions read their taps from there — the
-// arithmetic, its order and the edge rules are those of sample_bilinear / sample_bicubic, so the bits do not change.  Launched when the
-// box of such a tile fits 30 KiB (any scale up to ~2.5x minification); a tile whose exact box does not fit samples from global
-// memory (block-uniform).  Strong minification (C2: 8.6x) keeps the per-pixel kernel: its taps share nothing.
-constexpr int kRsRows = 8;       // destination rows per block: two per thread
-constexpr int kRsCap = 7680;     // floats of LDS per block (30 KiB: five blocks per CU)
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef f32x4_t f32x4_align4 __attribute__((aligned(4)));
-
-// first / last source index one axis of the tile touches (the samplers' own tap rules)
-template <int MODE>
-__device__ __forceinline__ void axis_span(float a, float b, int first, int last, int n, int& lo, int& hi) {
-    const float s0 = clampf(a * (float)first + b, 0.0f, (float)(n - 1)), s1 = clampf(a * (float)last + b, 0.0f, (float)(n - 1));
-    if constexpr (MODE == KH_INTERP_BICUBIC) {
-        lo = max((int)floorf(s0) - 1, 0);
-        hi = min((int)floorf(s1) + 2, n - 1);
-    } else {
-        lo = (int)s0;
-        hi = min((int)s1 + 1, n - 1);
-    }
-}
-
-template <int C, int MODE>
-__device__ __forceinline__ void sample_box(const float* __restrict__ tile, int pitch, int xmin, int ymin, int rows, int cols, float u, float v,
-                                           float out[C]) {
-    if constexpr (MODE == KH_INTERP_BILINEAR) {   // sample_bilinear, taps from the box
-        const int iu = (int)u, iv = (int)v;
-        const float frac_u = u - truncf(u), frac_v = v - truncf(v);
-        const float* p00 = tile + (iv - ymin) * pitch + (iu - xmin) * C;
-        const bool hx = iu + 1 < cols, hy = iv + 1 < rows;
-        const float* p01 = hx ? p00 + C : p00;
-        const float* p10 = hy ? p00 + pitch : p00;
-        const float* p11 = (hx && hy) ? p00 + pitch + C : p00;
-        const float frac_uu = 1.0f - frac_u, frac_vv = 1.0f - frac_v;
-        const float w00 = frac_vv * frac_uu, w10 = frac_vv * frac_u, w01 = frac_v * frac_uu, w11 = frac_v * frac_u;
-#pragma unroll
-        for (int c = 0; c < C; ++c) out[c] = w00 * p00[c] + w10 * p01[c] + w01 * p10[c] + w11 * p11[c];
-    } else {                                      // sample_bicubic, taps from the box
-        const float x0f = floorf(u), y0f = floorf(v);
-        float wx[4], wy[4];
-        keys_weights(u - x0f, wx);
-        keys_weights(v - y0f, wy);
-        const int x0 = (int)x0f, y0 = (int)y0f;
-        int xo[4];
-#pragma unroll
-        for (int dx = 0; dx < 4; ++dx) xo[dx] = (min(max(x0 + dx - 1, 0), cols - 1) - xmin) * C;
-        float acc[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = 0.0f;
-#pragma unroll
-        for (int dy = 0; dy < 4; ++dy) {
-            const float* row = tile + (min(max(y0 + dy - 1, 0), rows - 1) - ymin) * pitch;
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const float w = wx[dx] * wy[dy];
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(w, row[xo[dx] + c], acc[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c) out[c] = acc[c];
-    }
-}
-
-template <int C, int MODE>
-__global__ __launch_bounds__(kBx* kBy) void resize_staged_kernel(Img im, float ax, float bx, float ay, float by) {
-    __shared__ __attribute__((aligned(16))) float tile[kRsCap];
-    unsigned bx_, by_, bz_;
-    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;   // block-uniform
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kBx + tx;
-    const int xf = bx_ * kBx, xl = min(xf + kBx - 1, im.dw - 1), yf = by_ * kRsRows, yl = min(yf + kRsRows - 1, im.dh - 1);
-    int xmin, xmax, ymin, ymax;
-    axis_span<MODE>(ax, bx, xf, xl, im.sw, xmin, xmax);
-    axis_span<MODE>(ay, by, yf, yl, im.sh, ymin, ymax);
-    const int pitch = ((xmax - xmin + 1) * C + 3) & ~3, rows = ymax - ymin + 1;   // floats per box row (16-byte rows in LDS)
-    const bool staged = pitch * rows <= kRsCap;                                       // block-uniform
-    const float* src = im.src + (long long)bz_ * im.src_stride;
-    if (staged) {
-        const int qpr = pitch >> 2, nq = qpr * rows;
-        const long long img_floats = (long long)im.sw * im.sh * C;
-        const float inv_qpr = 1.0f / (float)qpr;
-        for (int q = tid; q < nq; q += kBx * kBy) {
-            int r = (int)((float)q * inv_qpr);   // q / qpr for q < 2^11: the float quotient is within one of the integer one
-            r -= (r * qpr > q);
-            r += ((r + 1) * qpr <= q);
-            const int i = q - r * qpr;
-            const long long g = ((long long)(ymin + r) * im.sw + xmin) * C + 4 * i;   // the last chunk of a row may run into the next row
-            f32x4_t v;
-            if (g + 3 < img_floats) {
-                v = *reinterpret_cast<const f32x4_align4*>(src + g);
-            } else {   // ... but never past the image
-                v = f32x4_t{g < img_floats ? src[g] : 0.0f, g + 1 < img_floats ? src[g + 1] : 0.0f, g + 2 < img_floats ? src[g + 2] : 0.0f, 0.0f};
-            }
-            *reinterpret_cast<f32x4_t*>(&tile[r * pitch + 4 * i]) = v;
-        }
-        __syncthreads();
-    }
-    const int x = xf + tx;
-    if (x >= im.dw) return;
-    const float sx = clampf(ax * (float)x + bx, 0.0f, (float)(im.sw - 1));
-#pragma unroll
-    for (int k = 0; k < kRsRows / kBy; ++k) {
-        const int y = yf + ty + k * kBy;
-        if (y >= im.dh) break;
-        const float sy = clampf(ay * (float)y + by, 0.0f, (float)(im.sh - 1));
-        float v[C];
-        if (staged) sample_box<C, MODE>(tile, pitch, xmin, ymin, im.sh, im.sw, sx, sy, v);
-        else sample<C, MODE>(src, im.sh, im.sw, sx, sy, v);
-        put<C>(im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C, v);
-    }
-}
-
 // resize_bilinear_normalize_3c (P/cuda/resize.rs:184-236): bilinear resize fused with `(px - mean) * inv_std`, HWC in,
 // HWC out — the sample is the same bilinear sampler as `resize`, the epilogue the reference kernel's expression.
 struct Norm3f { float mean[3], inv_std[3]; };
@@ -648,26 +532,6 @@ int32_t kh_resize_mapped_f32(kh_stream_t stream, const float* src, float* dst, i
             default: hipLaunchKernelGGL(resize_lanczos_kernel<4>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw); break;
         }
         return check_launch("kh_resize_f32 (lanczos)");
-    }
-    if ((mode == KH_INTERP_BILINEAR || mode == KH_INTERP_BICUBIC) && dev_opt(kOptResizeStaged) != 0) {
-        // the box of a 64 x 8 tile, a few columns / rows generous: staged when it fits the LDS budget
-        const float bw = ceilf(63.0f * ax) + 5.0f, bh = ceilf((float)(kRsRows - 1) * ay) + 5.0f;
-        if (bw < 1e5f && bh < 1e5f && (float)((((int)bw * channels) + 3) & ~3) * bh <= (float)kRsCap) {
-            Img st = im;
-            st.tiles = xcd_tiles(cdiv(dw, kBx), cdiv(dh, kRsRows), (unsigned)batch, cdiv(dw, kBx) * 8);
-            KH_REQUIRE_TILES("kh_resize_f32", st);
-            const dim3 grid = xcd_grid(st.tiles), blk(kBx, kBy);
-            hipStream_t hs = as_hip(stream);
-            switch (channels * 10 + mode) {
-                case 11: hipLaunchKernelGGL((resize_staged_kernel<1, 1>), grid, blk, 0, hs, st, ax, bx, ay, by); break;
-                case 12: hipLaunchKernelGGL((resize_staged_kernel<1, 2>), grid, blk, 0, hs, st, ax, bx, ay, by); break;
-                case 31: hipLaunchKernelGGL((resize_staged_kernel<3, 1>), grid, blk, 0, hs, st, ax, bx, ay, by); break;
-                case 32: hipLaunchKernelGGL((resize_staged_kernel<3, 2>), grid, blk, 0, hs, st, ax, bx, ay, by); break;
-                case 41: hipLaunchKernelGGL((resize_staged_kernel<4, 1>), grid, blk, 0, hs, st, ax, bx, ay, by); break;
-                default: hipLaunchKernelGGL((resize_staged_kernel<4, 2>), grid, blk, 0, hs, st, ax, bx, ay, by); break;
-            }
-            return check_launch("kh_resize_f32 (staged)");
-        }
     }
     KH_DISPATCH_C_MODE(resize_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, ax, bx, ay, by);
     return check_launch("kh_resize_f32");

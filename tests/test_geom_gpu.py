@@ -44,24 +44,6 @@ def test_resize_matches_oracle(gpu_stream, mode, shape, c):
     assert_same_bits(got, O.resize(src, dw, dh, mode), f"resize {shape} c{c} {mode}")
 
 
-@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
-@pytest.mark.parametrize("shape", [(400, 150, 200, 75), (401, 151, 199, 77), (131, 67, 262, 134), (300, 90, 300, 90), (333, 100, 140, 41),
-                                   (70, 300, 33, 290), (200, 64, 640, 9), (900, 40, 100, 40)])
-@pytest.mark.parametrize("c", [1, 3, 4])
-def test_resize_staged_tiles_match_oracle(gpu_stream, dev_option, mode, shape, c):
-    """The LDS-staged resize (64 x 8 destination tiles, kh_geom.hip::resize_staged_kernel): several tiles per axis with ragged edges,
-    2x down / 2x up / identity / 2.4x down (the largest box that still fits) / anisotropic scales, 9x down in x (the launcher keeps the
-    per-pixel kernel); a batch of three so that frame offsets count; the test option resize_staged = 0 is the per-pixel kernel."""
-    sw, sh, dw, dh = shape
-    src = np.stack([img(sw, sh, c, seed=17 * k) for k in range(3)])
-    want = [O.resize(src[k], dw, dh, mode) for k in range(3)]
-    for opt in (-1, 0):
-        dev_option("resize_staged", opt)
-        got = resize_gpu(gpu_stream, src, dw, dh, mode, batch=3)
-        for k in range(3):
-            assert_same_bits(got[k], want[k], f"resize {shape} c{c} {mode} frame {k} resize_staged={opt}")
-
-
 def test_resize_smoke_known_answer(gpu_stream):  # resize/mod.rs:447-490
     src = np.arange(36, dtype=np.float32).reshape(4, 3, 3)
     got = resize_gpu(gpu_stream, src, 2, 3, "bilinear")[0].reshape(-1)
