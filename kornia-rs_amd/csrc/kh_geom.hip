@@ -215,6 +215,8 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 // profiles/r04zk_resize_counters.csv).  An LDS-staged twin (64 x 8 tiles, the box copied with coalesced 16-byte loads, TA_BUSY 33 %)
 // was built, bit-identical, and measured 9 % SLOWER (1.85 vs 1.69 ms, profiles/r04zl_*): one box per block leaves the wave waiting
 // 69 % of its cycles (load -> LDS -> barrier -> sample, nothing to overlap with) and costs 1.6x the vector instructions.  Not kept.
+// Taking a row's four interior taps as three 16-byte loads instead of four 12-byte ones: no change (r04zm): the addresser's cost
+// follows the bytes, not the instruction count.
 template <int C, int MODE>
 __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, float bx, float ay, float by) {
     KH_PIXEL_PROLOGUE
