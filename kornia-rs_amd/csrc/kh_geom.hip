@@ -188,15 +188,30 @@ __device__ __forceinline__ void sample(const float* __restrict__ img, int rows, 
     else sample_lanczos<C>(img, rows, cols, u, v, out);
 }
 
+// Output pixels leave through the streaming store path (write-through, non-temporal: kh_common.h::stream_store) — the destination is
+// written once and never read by the kernel.  The V# covers what is left of the pixel's ROW: a wave is one row of a 64 x 4 tile
+// (kBx == 64), so the row base is wave-uniform and only x * C * 4 travels in the vector offset.
+struct OutRow { __amdgpu_buffer_rsrc_t rs; };
 template <int C>
-__device__ __forceinline__ void put(float* p, const float v[C]) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) p[c] = v[c];
+__device__ __forceinline__ OutRow out_row(float* row_base_of_this_wave, int dw) {
+    const uint64_t p = reinterpret_cast<uint64_t>(row_base_of_this_wave);
+    const uint64_t u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)p) |   // (the builtin returns a signed int)
+                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(p >> 32)) << 32);
+    return OutRow{stream_window(reinterpret_cast<const void*>(u), (long long)dw * C * 4)};
 }
 template <int C>
-__device__ __forceinline__ void put_zero(float* p) {
+__device__ __forceinline__ void put(const OutRow& r, int x, const float v[C]) {
+    uint32_t w[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) p[c] = 0.0f;
+    for (int c = 0; c < C; ++c) w[c] = __float_as_uint(v[c]);
+    stream_store<C>(r.rs, x * C * 4, w);
+}
+template <int C>
+__device__ __forceinline__ void put_zero(const OutRow& r, int x) {
+    uint32_t w[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) w[c] = 0u;
+    stream_store<C>(r.rs, x * C * 4, w);
 }
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
@@ -208,7 +223,7 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
     const int y = by_ * kBy + threadIdx.y;                            \
     if (x >= im.dw || y >= im.dh) return;                             \
     const float* src = im.src + (long long)bz_ * im.src_stride;       \
-    float* o = im.dst + (long long)bz_ * im.dst_stride + ((long long)y * im.dw + x) * C;
+    const OutRow o = out_row<C>(im.dst + (long long)bz_ * im.dst_stride + (long long)y * im.dw * C, im.dw);
 
 // resize (P/resize/mod.rs:161-176): half-pixel grid a*x + b, clamped to the source.
 // Bound by the texture addresser on moderate scales (1080p -> 540p bicubic: sixteen 12-byte gathers per pixel, TA_BUSY 100 %,
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, floa
     const float sy = clampf(ay * (float)y + by, 0.0f, (float)(im.sh - 1));
     float v[C];
     sample<C, MODE>(src, im.sh, im.sw, sx, sy, v);
-    put<C>(o, v);
+    put<C>(o, x, v);
 }
 
 // resize_bilinear_normalize_3c (P/cuda/resize.rs:184-236): bilinear resize fused with `(px - mean) * inv_std`, HWC in,
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(kBx* kBy) void resize_normalize_kernel(Img im, floa
     sample<C, KH_INTERP_BILINEAR>(src, im.sh, im.sw, sx, sy, v);
 #pragma unroll
     for (int c = 0; c < C; ++c) v[c] = (v[c] - n.mean[c]) * n.inv_std[c];
-    put<C>(o, v);
+    put<C>(o, x, v);
 }
 
 // Lanczos resize is separable in the reference (resize_lanczos_separable, lanczos.rs:189-245): an H
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(kBx* kBy) void resize_lanczos_kernel(Img im, const 
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(ay.w[dy], rx[c], acc[c]);
     }
-    put<C>(o, acc);
+    put<C>(o, x, acc);
 }
 
 struct Mat6 { float m[6]; };
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi) 
     // in_bounds incl. the degenerate-axis rule (:201-215)
     const bool x_ok = fabsf(mi.m[0]) < 1e-6f ? (sx0 >= 0.0f && sx0 < swf) : (sx >= 0.0f && sx < swf);
     const bool y_ok = fabsf(mi.m[3]) < 1e-6f ? (sy0 >= 0.0f && sy0 < shf) : (sy >= 0.0f && sy < shf);
-    if (!(x_ok && y_ok)) { put_zero<C>(o); return; }
+    if (!(x_ok && y_ok)) { put_zero<C>(o, x); return; }
     float v[C];
     if constexpr (MODE == KH_INTERP_NEAREST) {  // :270-276
         const long long xi = (long long)clampf(roundf(sx), 0.0f, swf - 1.0f);
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi) 
     } else {  // per-pixel samplers on the unclamped coordinate (:322-362)
         sample<C, MODE>(src, im.sh, im.sw, sx, sy, v);
     }
-    put<C>(o, v);
+    put<C>(o, x, v);
 }
 
 // warp_perspective (P/warp/perspective.rs:67-72,115-166); im9 = inverse 3x3
@@ -345,9 +360,9 @@ __global__ __launch_bounds__(kBx* kBy) void warp_perspective_kernel(Img im, Mat9
     if (u >= 0.0f && u < (float)im.sw && v >= 0.0f && v < (float)im.sh) {
         float val[C];
         sample<C, MODE>(src, im.sh, im.sw, u, v, val);
-        put<C>(o, val);
+        put<C>(o, x, val);
     } else {
-        put_zero<C>(o);  // also catches NaN / Inf from w == 0
+        put_zero<C>(o, x);  // also catches NaN / Inf from w == 0
     }
 }
 
@@ -372,13 +387,13 @@ __global__ __launch_bounds__(kBx* kBy) void remap_kernel(Img im, const float* __
         const int z = z0 + k;
         if (z >= batch) break;
         const float* src = im.src + (long long)z * im.src_stride;
-        float* o = im.dst + (long long)z * im.dst_stride + i * C;
+        const OutRow o = out_row<C>(im.dst + (long long)z * im.dst_stride + (long long)y * im.dw * C, im.dw);
         if (inside) {
             float val[C];
             sample<C, MODE>(src, im.sh, im.sw, u, v, val);
-            put<C>(o, val);
+            put<C>(o, x, val);
         } else {
-            put_zero<C>(o);
+            put_zero<C>(o, x);
         }
     }
 }
