@@ -746,6 +746,14 @@ __device__ __forceinline__ void store_quad_px(uint8_t* o, const uint32_t px[4]) 
         *reinterpret_cast<u32_unaligned*>(o) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
     }
 }
+// the same 4*C bytes as C dwords (a quad of C-channel pixels is exactly C dwords), for the streaming buffer store
+template <int C>
+__device__ __forceinline__ void pack_quad_px(const uint32_t px[4], uint32_t w[C]) {
+    if constexpr (C == 4) { w[0] = px[0]; w[1] = px[1]; w[2] = px[2]; w[3] = px[3]; }
+    else if constexpr (C == 3) { w[0] = px[0] | (px[1] << 24); w[1] = (px[1] >> 8) | (px[2] << 16); w[2] = (px[2] >> 16) | (px[3] << 8); }
+    else if constexpr (C == 2) { w[0] = px[0] | (px[1] << 16); w[1] = px[2] | (px[3] << 16); }
+    else w[0] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+}
 template <int C>
 __device__ __forceinline__ void store_one_px(uint8_t* o, uint32_t px) {
 #pragma unroll
@@ -910,6 +918,8 @@ template <int C, int KM>
 __device__ __forceinline__ void staged_images(uint32_t* __restrict__ tile, const ImgU8& im, int z0, int nimg, const uint32_t (&soff)[4], const int (&sdst)[4], unsigned wmask, int tid,
                                               const int (&la)[4], int pitch, const uint32_t (&fxp)[4], const uint32_t (&fy16)[4], unsigned valid,
                                               long long dst_off, bool mine, bool whole, int x4) {
+    // block-uniform: every quad offset of the image is a multiple of four bytes and fits the V#'s 2 GiB window
+    const bool stream_ok = ((im.dw * C) & 3) == 0 && (long long)im.dw * im.dh * C <= 0x7fffffffLL;
     const uint8_t* src = im.src + (long long)z0 * im.src_stride;
     RawQuad<C> raw[KM];
 #pragma unroll
@@ -922,7 +932,11 @@ __device__ __forceinline__ void staged_images(uint32_t* __restrict__ tile, const
     auto emit = [&](int b_, const uint32_t (&px)[4]) {
         uint8_t* o = im.dst + (long long)(z0 + b_) * im.dst_stride + dst_off;
         if (mine) {
-            if (whole) {
+            if (whole && stream_ok) {   // write-through non-temporal buffer store: the image is written once and never read back
+                uint32_t w[C];
+                pack_quad_px<C>(px, w);
+                stream_store<C>(stream_window(im.dst + (long long)(z0 + b_) * im.dst_stride, (long long)im.dw * im.dh * C), (int)dst_off, w);
+            } else if (whole) {
                 store_quad_px<C>(o, px);
             } else {
 #pragma unroll
