@@ -572,6 +572,9 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) 
     const int Y0 = ty * a.th, thr = min(a.th, a.dh - Y0);
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
+    // block-uniform: 12-byte quad offsets are dword-aligned and the image fits the V#'s 2 GiB window -> streaming stores (kh_common.h)
+    const bool stream_ok = ((a.dw * 3) & 3) == 0 && (long long)a.dw * a.dh * 3 <= 0x7fffffffLL;
+    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.dw * a.dh * 3);
     const int p = 2 * X0 + 8 * lane;                                  // this lane's source pixels p .. p + 7
     const int ph = lane < 32 ? 2 * X0 - 4 : 2 * X0 + 2 * kPdRollWaveDst;   // the wave's halo quads: left in the lower half's lanes, right in the upper's
     const bool edge = 2 * X0 < 4 || 2 * X0 + 2 * kPdRollWaveDst + 4 > a.sw;   // wave-uniform: some lane's pixels need re-indexing
@@ -659,7 +662,10 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) 
                 const uint32_t w2 = __builtin_amdgcn_perm(v[2][1], rg23, 0x06030204u);        // B2 R3 G3 B3
                 uint8_t* o = dst + out_off;
                 const int off = 12 * lane;
-                if (off + 12 <= seg_bytes) {
+                if (off + 12 <= seg_bytes && stream_ok) {
+                    const uint32_t w[3] = {w0, w1, w2};
+                    stream_store<3>(out_win, (int)out_off + off, w);
+                } else if (off + 12 <= seg_bytes) {
                     *reinterpret_cast<u32_unaligned*>(o + off) = w0; *reinterpret_cast<u32_unaligned*>(o + off + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + off + 8) = w2;
                 } else {
                     const uint32_t w[3] = {w0, w1, w2};
@@ -704,6 +710,8 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) { 
     const int y0 = ty * a.th, thr = min(a.th, a.sh - y0);
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
+    const bool stream_ok = ((a.dw * 3) & 3) == 0 && (long long)a.dw * a.dh * 3 <= 0x7fffffffLL;   // block-uniform (see pyrdown above)
+    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.dw * a.dh * 3);
     const int p = x0 + 4 * lane;                                      // this lane's source pixels p .. p + 3
     const int ph = lane < 32 ? x0 - 4 : x0 + kPuRollWaveSrc;          // the wave's halo quads: left in the lower half's lanes, right in the upper's
     const bool edge = x0 < 4 || x0 + kPuRollWaveSrc + 4 > a.sw;       // wave-uniform
@@ -814,7 +822,12 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) { 
                         const int off = 16 * (lane + 64 * t);
                         if (off + 16 <= seg_bytes) {
                             const uint64_t lo = *reinterpret_cast<const uint64_t*>(xb + off), hi = *reinterpret_cast<const uint64_t*>(xb + off + 8);
-                            *reinterpret_cast<u64_unaligned*>(o + off) = lo; *reinterpret_cast<u64_unaligned*>(o + off + 8) = hi;
+                            if (stream_ok) {
+                                const uint32_t w[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+                                stream_store<4>(out_win, (int)(row_off + r * drow) + off, w);
+                            } else {
+                                *reinterpret_cast<u64_unaligned*>(o + off) = lo; *reinterpret_cast<u64_unaligned*>(o + off + 8) = hi;
+                            }
                         } else if (off < seg_bytes) {   // the segment's last, partial chunk (one lane)
                             for (int b = off; b < seg_bytes; ++b) o[b] = xb[b];
                         }
@@ -1012,6 +1025,8 @@ __global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_r
     const int y0 = ty * a.th;
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
+    const bool stream_ok = ((a.w * 3) & 3) == 0 && (long long)a.w * a.h * 3 <= 0x7fffffffLL;   // block-uniform: streaming stores (kh_common.h)
+    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.w * a.h * 3);
     const int p = p0 + 4 * lane;                            // this lane's quad
     const int ph = lane < 32 ? p0 - 4 : p0 + kMrWavePx;     // the wave's halo quads: left in the lower half's lanes, right in the upper's
     const bool edge = p0 < 4 || p0 + kMrWavePx + 4 > a.w;   // wave-uniform
@@ -1098,7 +1113,10 @@ __global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_r
                 const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2], rg, 0x0c0c0503u), rg2, 0x01000504u);
                 const uint32_t w2 = __builtin_amdgcn_perm(pl[2], rg2, 0x07030206u);
                 uint8_t* o = dst + out_off;
-                if (full) {
+                if (full && stream_ok) {
+                    const uint32_t w[3] = {w0, w1, w2};
+                    stream_store<3>(out_win, (int)out_off, w);
+                } else if (full) {
                     *reinterpret_cast<u32_unaligned*>(o) = w0; *reinterpret_cast<u32_unaligned*>(o + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + 8) = w2;
                 } else {
                     const uint32_t w[3] = {w0, w1, w2};

@@ -242,6 +242,9 @@ __global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8F
     const int y0 = ty * a.th;
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.src_stride;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
+    // block-uniform: quad offsets are multiples of four bytes and the image fits the V#'s 2 GiB window
+    const bool stream_ok = (a.rowlen & 3) == 0 && (long long)a.rows * a.rowlen <= 0x7fffffffLL;
+    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.rows * a.rowlen);
     const int p = p0 + 4 * lane;                            // this lane's quad: pixels p .. p + 3
     const int ph = lane < 32 ? p0 - 4 : p0 + kRgbWavePx;    // the wave's halo quads: left in the lower half's lanes, right in the upper's
     const bool edge = p0 < 4 || p0 + kRgbWavePx + 4 > a.cols;   // wave-uniform: some quad of the wave needs clamping
@@ -342,7 +345,10 @@ __global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8F
                 const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2], rg, 0x0c0c0503u), rg2, 0x01000504u);   // G1 B1 | R2 G2
                 const uint32_t w2 = __builtin_amdgcn_perm(pl[2], rg2, 0x07030206u);     // B2 R3 G3 B3
                 uint8_t* o = dst + out_off;
-                if (full) {
+                if (full && stream_ok) {   // write-through non-temporal buffer store (kh_common.h::stream_store)
+                    const uint32_t w[3] = {w0, w1, w2};
+                    stream_store<3>(out_win, (int)out_off, w);
+                } else if (full) {
                     *reinterpret_cast<u32u*>(o) = w0; *reinterpret_cast<u32u*>(o + 4) = w1; *reinterpret_cast<u32u*>(o + 8) = w2;
                 } else {
                     const uint32_t w[3] = {w0, w1, w2};
