@@ -80,8 +80,17 @@ __global__ __launch_bounds__(kBx* kBy) void fused_pipeline_kernel(FusedProgram P
 
     // sink
     const size_t di = (size_t)y * P.dw + x;
-    if constexpr (SINK == KH_FUSE_WRITE_CHW_F32) {  // :657-661
-        const size_t plane = (size_t)P.dw * P.dh;
+    // (streaming stores, kh_common.h::stream_store: the tensor is written once; a frame beyond the V#'s 2 GiB window keeps plain stores)
+    const size_t plane = (size_t)P.dw * P.dh;
+    constexpr int kPlanes = SINK == KH_FUSE_WRITE_CHW_F32 ? 3 : 1;
+    if (plane * kPlanes * 4u <= 0x7fffffffu) {   // launch-uniform
+        const __amdgpu_buffer_rsrc_t rs = stream_window(dst, (long long)(plane * kPlanes * 4u));
+#pragma unroll
+        for (int c = 0; c < kPlanes; ++c) {
+            const uint32_t bits = __float_as_uint(v[c]);
+            stream_store<1>(rs, (int)((di + c * plane) * 4u), &bits);
+        }
+    } else if constexpr (SINK == KH_FUSE_WRITE_CHW_F32) {  // :657-661
         dst[di] = v[0];
         dst[di + plane] = v[1];
         dst[di + 2u * plane] = v[2];
