@@ -134,6 +134,16 @@ __global__ __launch_bounds__(kBx* kBy) void spatial_gradient_x4_kernel(const flo
         ox[e] = sx;
         oy[e] = sy;
     }
+    // both gradients leave through streaming stores (kh_common.h::stream_store); an image beyond the V#'s 2 GiB window keeps plain ones
+    const long long img = (long long)rows * rowlen * 4;
+    if (img <= 0x7fffffffLL) {   // launch-uniform
+        const uint32_t bx_[4] = {__float_as_uint(ox[0]), __float_as_uint(ox[1]), __float_as_uint(ox[2]), __float_as_uint(ox[3])};
+        const uint32_t by_[4] = {__float_as_uint(oy[0]), __float_as_uint(oy[1]), __float_as_uint(oy[2]), __float_as_uint(oy[3])};
+        const int off = (r * rowlen + i) * 4;
+        stream_store<4>(stream_window(gx + (long long)blockIdx.z * ds, img), off, bx_);
+        stream_store<4>(stream_window(gy + (long long)blockIdx.z * ds, img), off, by_);
+        return;
+    }
     const long long o = (long long)blockIdx.z * ds + (long long)r * rowlen + i;
     *reinterpret_cast<f32x4v*>(gx + o) = f32x4v{ox[0], ox[1], ox[2], ox[3]};
     *reinterpret_cast<f32x4v*>(gy + o) = f32x4v{oy[0], oy[1], oy[2], oy[3]};
