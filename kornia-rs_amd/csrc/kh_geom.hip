@@ -427,6 +427,8 @@ int32_t check_img(const char* what, const void* src, const void* dst, int sw, in
     KH_REQUIRE(batch >= 0 && batch <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, batch);
     KH_REQUIRE((int64_t)sw * sh * channels <= kI32Max && (int64_t)dw * dh * channels <= kI32Max, KH_ERR_TOO_LARGE,
                "%s: image exceeds 32-bit indexing", what);
+    // a destination row is one streaming-store window (out_row): 2 GiB at most
+    KH_REQUIRE((int64_t)dw * channels * 4 <= kI32Max, KH_ERR_TOO_LARGE, "%s: destination rows of %d x %d floats exceed the 2 GiB store window", what, dw, channels);
     KH_REQUIRE(ss >= 0 && ds >= 0, KH_ERR_INVALID_ARG, "%s: negative batch stride", what);
     if (batch > 0) KH_REQUIRE(src && dst, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
     return KH_OK;
