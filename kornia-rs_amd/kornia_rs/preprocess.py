@@ -306,7 +306,8 @@ class _Staging:
         slot.used, slot.consumed = True, None
         return _DeviceView(slot.device, frame_len if len(frames) == 1 else total), stride
 
-    _copy_pool = None   # shared by every preprocessor of the process: eight memcpy workers
+    _copy_pool = None   # shared by every preprocessor of the process
+    copy_workers = 8    # memcpy workers of that pool (set before the first pageable upload)
 
     @classmethod
     def _host_copy(cls, pinned, frames, frame_len: int, stride: int) -> None:
@@ -322,14 +323,14 @@ class _Staging:
             return
         if cls._copy_pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            cls._copy_pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="kornia-stage")
+            cls._copy_pool = ThreadPoolExecutor(max_workers=cls.copy_workers, thread_name_prefix="kornia-stage")
         base = pinned.ptr
 
         def move(lo, hi):
             for k in range(lo, hi):
                 ctypes.memmove(base + k * stride, srcs[k].ctypes.data, frame_len)
 
-        n, w = len(srcs), 8
+        n, w = len(srcs), cls.copy_workers
         futs = [cls._copy_pool.submit(move, n * i // w, n * (i + 1) // w) for i in range(w)]
         for f in futs:
             f.result()
