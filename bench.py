@@ -1378,9 +1378,11 @@ class Runner:
 
     def time(self, wl, steps, warmup, spinup_s=0.0):
         hip, stream = self.hip, self.stream
-        # Secondary rows only (spinup_s > 0): the previous row's CPU-baseline leg leaves the GPU idle for 10-30 s and its clocks down;
-        # two warm-up steps of a 4 ms kernel do not bring them back (box blur 5.2 ms in the line, 4.4 alone or in the kernel trace
-        # of the same command, profiles/r04zj_steps.txt).  Untimed steps of the row's own work for `spinup_s` of wall clock first.
+        # Secondary rows only (spinup_s > 0): the previous row's CPU-baseline leg leaves the GPU idle for 10-30 s and its clocks down,
+        # and even between back-to-back rows the host-side setup does: two warm-up steps of a 1-4 ms kernel do not bring them back
+        # (box blur 5.2 ms in the line, 4.4 alone, profiles/r04zj_steps.txt; the ALU-heavy 608 letterbox 1.50 ms after 2 warm-up steps,
+        # 1.31 after 40, 1.305 after 200, profiles/r04zu_warmup.txt).  Untimed steps of the row's own work for `spinup_s` of wall clock
+        # first: the rows are steady-state numbers, like the headline's after its --warmup.
         t_end = time.perf_counter() + spinup_s
         while spinup_s > 0.0 and self.on_gpu and time.perf_counter() < t_end:
             wl.step()
@@ -1515,7 +1517,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=20)   # ~90 ms of the headline kernel: 4.39 ms/step after 2 warm-up steps, 4.35 after 20 or 60 (r04zu)
     ap.add_argument("--workload", default="nv12_chw", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1606,7 +1608,7 @@ def main():
             w2 = make_workload(n, argparse.Namespace(batch=args.also_batch))
             w2.setup(stream)
             steps2 = 200 if n == "gray_258x195" else a_steps  # a 7 us launch needs more samples than a 10 ms one
-            e2, k2 = run.time(w2, steps2, a_warm, spinup_s=0.0 if args.no_cpu_baseline else 0.25)
+            e2, k2 = run.time(w2, steps2, a_warm, spinup_s=0.25)
             if rank == 0:
                 r2 = run.record(w2, steps2, a_warm, e2, k2, n)
                 r2["n_gpus"] = world
