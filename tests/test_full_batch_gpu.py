@@ -1,4 +1,5 @@
-"""Parity at the BASELINE *batch* sizes: every bench workload behind a BASELINE config runs ONE step at its
+"""Parity at the BASELINE *batch* sizes: every workload of the default bench line — the BASELINE configs and,
+further down, every other `summary` row — runs ONE step at its
 real batch — configs[2] N = 1024 (28.7 GB), configs[1,3,4] N = 256 (25.5 GB buffers), the u8 4K twins N = 256 — and a handful
 of frames spread over the batch is copied back and compared bit-for-bit with the CPU restatement.  The sampled frames sit on
 both sides of every offset where 32-bit arithmetic would wrap inside the batch buffer: 2^31 bytes, 2^32 bytes, 2^31 elements,
@@ -161,3 +162,49 @@ def test_u8_4k_full_batch(gpu_stream, bench, name):
         else:
             want = O.gaussian_blur_u8(src, (7, 7), (1.5, 1.5))[0]
         _same(_fetch(wl.dst, k, np.uint8, (wl.H, wl.W, wl.C)), want, f"{name} image {k}")
+
+
+# ---- the other rows of the default bench line, at their bench batch (round 4: every `summary` row is backed by a parity check on the
+# ---- bytes the timed launch writes) ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["warp_affine_f32_1080p", "sobel_4k", "box_blur_4k", "normalize_1080p"])
+def test_same_size_f32_rows_full_batch(gpu_stream, bench, name):
+    """1R + 1W f32x3 operators: warp_affine 1080p b256 (6.4 GB buffers), sobel / box blur 4K b128 (12.7 GB), normalize 1080p b512
+    (12.7 GB).  The f32 geometry kernels store through a per-ROW window (kh_geom.hip::out_row): frames past 2^31 B / 2^32 B matter."""
+    wl = _run(bench, name, gpu_stream)
+    n = wl.W * wl.H * wl.C
+    for k in boundary_frames(wl.N, n * 4, 4):
+        img = wl.base[31 * k: 31 * k + n].reshape(wl.H, wl.W, wl.C)
+        _same(_fetch(wl.dst, k, np.float32, (wl.H, wl.W, wl.C)), wl.oracle_call(O, img), f"{name} image {k}")
+
+
+def test_resize_bicubic_full_batch(gpu_stream, bench):
+    wl = _run(bench, "resize_bicubic_540", gpu_stream)
+    assert wl.N == 256
+    n = wl.SW * wl.SH * wl.C
+    ks = sorted(set(boundary_frames(wl.N, n * 4, 4)) | set(boundary_frames(wl.N, wl.DW * wl.DH * wl.C * 4, 4)))
+    for k in ks:
+        want = O.resize(wl.base[31 * k: 31 * k + n].reshape(wl.SH, wl.SW, wl.C), wl.DW, wl.DH, "bicubic")
+        _same(_fetch(wl.dst, k, np.float32, (wl.DH, wl.DW, wl.C)), want, f"resize_bicubic_540 image {k}")
+
+
+@pytest.mark.parametrize("name", ["gray_u8_1080p", "gray_f32_1080p", "ycbcr_u8_1080p", "ycbcr_f32_1080p", "hsv_f32_1080p"])
+def test_colour_map_rows_full_batch(gpu_stream, bench, name):
+    """Pointwise maps over N x 1080p pixels in one launch (gray f32: 25.5 GB in, 8.5 GB out)."""
+    wl = _run(bench, name, gpu_stream)
+    dt = np.uint8 if wl.dtype == "u8" else np.float32
+    n_in, n_out = wl.W * wl.H * wl.cin, wl.W * wl.H * wl.cout
+    ks = sorted(set(boundary_frames(wl.N, n_in * wl.item, wl.item)) | set(boundary_frames(wl.N, n_out * wl.item, wl.item)))
+    for k in ks[:: max(1, len(ks) // 12)] + [wl.N - 1]:
+        img = wl.base[31 * k: 31 * k + n_in].reshape(wl.H, wl.W, wl.cin)
+        want = O.color_map(wl.entry[3:], img, wl.cout, *wl.EXTRA.get(wl.entry, ()))
+        _same(_fetch(wl.dst, k, dt, (wl.H, wl.W, wl.cout)), want, f"{name} frame {k}")
+
+
+@pytest.mark.parametrize("name,fmt,out", [("nv12_chw_608", "nv12", 608), ("yuyv_chw_640", "yuyv", 640)])
+def test_letterbox_secondaries_full_batch(gpu_stream, bench, name, fmt, out):
+    wl = _run(bench, name, gpu_stream)
+    ks = sorted(set(boundary_frames(wl.N, out * out * 12, 4)) | set(boundary_frames(wl.N, wl.frame_bytes, 1)))
+    for k in ks:
+        raw = wl.base[31 * k: 31 * k + wl.frame_bytes]
+        want = O.preprocess(raw, wl.W, wl.H, out, out, fmt=fmt, mode="letterbox", mean=MEAN, std=STD)[0]
+        _same(_fetch(wl.dst, k, np.float32, (3, out, out)), want, f"{name} frame {k}")
