@@ -208,3 +208,34 @@ def test_letterbox_secondaries_full_batch(gpu_stream, bench, name, fmt, out):
         raw = wl.base[31 * k: 31 * k + wl.frame_bytes]
         want = O.preprocess(raw, wl.W, wl.H, out, out, fmt=fmt, mode="letterbox", mean=MEAN, std=STD)[0]
         _same(_fetch(wl.dst, k, np.float32, (3, out, out)), want, f"{name} frame {k}")
+
+
+# ---- opt-in rows whose kernels write through an image-wide streaming-store window (round 4) --------------------------------------
+@pytest.mark.parametrize("name", ["pyrdown_u8_4k", "pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k"])
+def test_pyramid_rows_full_batch(gpu_stream, bench, name):
+    wl = _run(bench, name, gpu_stream)
+    if name == "pyrdown_u8_4k":
+        sw, sh, dw, dh, es, dt, fn = wl.W, wl.H, wl.W // 2, wl.H // 2, 1, np.uint8, O.pyrdown
+    else:
+        sw, sh, dw, dh, es, dt, fn = wl.sw, wl.sh, wl.dw, wl.dh, wl.es, (np.float32 if wl.f32 else np.uint8), (O.pyrup if wl.up else O.pyrdown)
+    n_in, n_out = sw * sh * 3, dw * dh * 3
+    ks = sorted(set(boundary_frames(wl.N, n_in * es, es)) | set(boundary_frames(wl.N, n_out * es, es)))
+    for k in ks:
+        img = wl.base[31 * k: 31 * k + n_in].reshape(sh, sw, 3)
+        _same(_fetch(wl.dst, k, dt, (dh, dw, 3)), fn(img), f"{name} image {k}")
+
+
+def test_dilate_and_gradient_full_batch(gpu_stream, bench):
+    wl = _run(bench, "dilate_u8_4k", gpu_stream)
+    n = wl.W * wl.H * wl.C
+    for k in boundary_frames(wl.N, n, 1):
+        img = wl.base[31 * k: 31 * k + n].reshape(wl.H, wl.W, wl.C)
+        _same(_fetch(wl.dst, k, np.uint8, (wl.H, wl.W, wl.C)), O.morphology_u8(img, "dilate", O.morph_kernel("box", 5)), f"dilate image {k}")
+    del wl
+    wl = _run(bench, "spatial_gradient_1080p", gpu_stream)
+    n = wl.W * wl.H * wl.C
+    for k in boundary_frames(wl.N, n * 4, 4):
+        img = wl.base[31 * k: 31 * k + n].reshape(wl.H, wl.W, wl.C)
+        gx, gy = O.spatial_gradient(img, "sobel")
+        _same(_fetch(wl.dst, k, np.float32, (wl.H, wl.W, wl.C)), gx, f"spatial_gradient dx image {k}")
+        _same(_fetch(wl.dst_y, k, np.float32, (wl.H, wl.W, wl.C)), gy, f"spatial_gradient dy image {k}")
