@@ -345,55 +345,75 @@ __global__ __launch_bounds__(kBx* kBy) void sep_v_u8_kernel(Rz a, const int16_t*
 // (ofs[Y0] .. ofs[Y1 - 1] + k, each clamped to the image like the reference's row index) are staged in LDS once, two columns per
 // dword; a wave then walks its destination rows with one conflict-free ds_read_b32 + two v_dot2 per tap (weights are wave-uniform).
 // i32 sums of the same products: byte-identical.
-constexpr int kSepVRows = 192;   // staged intermediate rows per block (192 x 256 B = 48 KiB)
+constexpr int kSepVRows = 192;   // staged intermediate rows per block (96 row pairs x 512 B = 48 KiB)
+// Second form (r04zw): a dword of the staged window holds one COLUMN's values of two consecutive ROWS, so that one v_dot2_i32_i16
+// multiplies two taps — with a column pair per dword (the first form) every v_dot2 carried a zero weight and the tap loop spent 6
+// vector + 4 LDS instructions per two taps of two columns; now 2 + 3.  A destination row whose first tap sits on an odd window row
+// takes its weights shifted by one slot ({0, w0}, {w1, w2}, ...): the weight rows are laid out per destination row accordingly.
+// A lane owns columns `lane` and `lane + 64` of the block's 128.  i32 sums of the same products: byte-identical.
 __global__ __launch_bounds__(256) void sep_v_u8_lds_kernel(Rz a, const int16_t* __restrict__ hbuf, SepTab ty, int hrow) {
-    uint32_t* S = reinterpret_cast<uint32_t*>(kh_sep_lds);   // [ty.vrows][64] dwords (dynamic: the launch asks for what this table needs)
+    uint32_t* S = reinterpret_cast<uint32_t*>(kh_sep_lds);   // [row pairs][128] dwords (dynamic: the launch asks for what this table needs)
     unsigned bx_, by_, bz_;
     if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = (bx_ * 64 + lane) * 2;                       // this lane's two flat columns: col, col + 1
+    const int colb = bx_ * 128;                                  // the block's first flat column
     const int Y0 = by_ * ty.vty, Y1 = min(Y0 + ty.vty, a.dh);
     const int r0 = ty.ofs[Y0], nr = ty.ofs[Y1 - 1] + ty.k - r0;  // block-uniform; nr <= kSepVRows (host-checked per table)
+    const int npairs = (nr + 1) >> 1;
     const int16_t* __restrict__ h = hbuf + (long long)bz_ * a.sh * hrow;
-    const int c0 = min(col, hrow - 1), c1 = min(col + 1, hrow - 1);
+    // staging: lane = column pair (colb + 2 lane, + 1) of one row pair; sixteen loads (eight row pairs) in flight per lane
+    const int col = colb + 2 * lane, c0 = min(col, hrow - 1), c1 = min(col + 1, hrow - 1);
     const bool pairs = (hrow & 1) == 0;   // rows start dword-aligned: one load per (row, column pair) instead of two 2-byte loads
-    const int cp = min(col, max(hrow - 2, 0));   // even
-    for (int rb = wave; rb < nr; rb += 4 * 16) {   // sixteen rows of loads in flight per lane before the first LDS write
-        uint32_t v[16];
+    const int cp = min(col, max(hrow - 2, 0));   // even (lanes past the row re-read its last pair: row + hrow - 1 alone is out of bounds)
+    // Everything the block needs from memory is requested before the first wait: up to sixteen row pairs per lane (thirty-two loads;
+    // 128 window rows, the usual segment has ~100), then the weight rows' table reads; a taller window takes a second trip.
+    const int wpr = (ty.kp >> 1) + 1;
+    uint32_t* Wp = S + (((ty.vrows + 1) >> 1) + 2) * 128;   // after two spare row pairs (finite data for the zero-weight slots past the window)
+    for (int pb = wave; pb < npairs; pb += 4 * 16) {
+        uint32_t v[32];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int16_t* row = h + (long long)min(max(r0 + min(rb + 4 * j, nr - 1), 0), a.sh - 1) * hrow;   // vertical_row_scalar's clamp, kernels.rs:699-708
-            if (pairs) v[j] = *reinterpret_cast<const uint32_t*>(row + cp);   // lanes past the row re-read its last pair (found by the ASan build: row + hrow - 1 is not)
+        for (int j = 0; j < 32; ++j) {
+            const int wr = min(2 * (pb + 4 * (j >> 1)) + (j & 1), nr - 1);                                 // window row (the last pair may repeat the last row)
+            const int16_t* row = h + (long long)min(max(r0 + wr, 0), a.sh - 1) * hrow;                      // vertical_row_scalar's clamp, kernels.rs:699-708
+            if (pairs) v[j] = *reinterpret_cast<const uint32_t*>(row + cp);
             else v[j] = (uint32_t)(uint16_t)row[c0] | ((uint32_t)(uint16_t)row[c1] << 16);
         }
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (rb + 4 * j < nr) S[(rb + 4 * j) * 64 + lane] = v[j];
-    }
-    // the segment's weight rows: a tap's weight is wave-uniform but 16-bit, which has no scalar load on this part — read from global
-    // memory inside the tap loop it was one dependent vector load per tap (r04h: 69 % of the wave-cycles parked)
-    uint16_t* Wv = reinterpret_cast<uint16_t*>(S + (ty.vrows + 3) * 64);   // [vty][kp], after three spare rows (see the tap loop)
-    for (int e = threadIdx.x; e < (Y1 - Y0) * ty.kp; e += 256) Wv[e] = (uint16_t)ty.w[(long long)Y0 * ty.kp + e];
-    __syncthreads();
-    for (int y = Y0 + wave; y < Y1; y += 4) {
-        const uint32_t* tap = S + (ty.ofs[y] - r0) * 64 + lane;
-        const uint16_t* w = Wv + (y - Y0) * ty.kp;
-        int32_t acc0 = 0, acc1 = 0;
-        // four taps per trip (kp is a multiple of four, padded with ZERO weights; the staged window is followed by the weight rows, so the
-        // up to three rows read past it are finite data times zero): four independent LDS reads in flight instead of one per dependent step
-        for (int t = 0; t < ty.kp; t += 4) {
-            uint32_t v[4], wt[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { v[u] = tap[(t + u) * 64]; wt[u] = w[t + u]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc0 = dot2_i16(v[u], wt[u], acc0);          // {wt, 0} and {0, wt} as i16 pairs
-                acc1 = dot2_i16(v[u], wt[u] << 16, acc1);
+        if (pb == wave) {
+            // weight rows, one per destination row of the segment, as dwords {w[2 j - p], w[2 j + 1 - p]} with p = parity of the row's
+            // first window row (slots outside 0 .. k - 1 are zero): kp / 2 + 1 dwords each
+            for (int e = threadIdx.x; e < (Y1 - Y0) * wpr; e += 256) {
+                const int yy = e / wpr, j = e - yy * wpr, y = Y0 + yy, p = (ty.ofs[y] - r0) & 1;
+                const int16_t* w = ty.w + (long long)y * ty.kp;
+                const int t0 = 2 * j - p, t1 = t0 + 1;
+                const uint32_t lo = (t0 >= 0 && t0 < ty.k) ? (uint16_t)w[t0] : 0u, hi = (t1 >= 0 && t1 < ty.k) ? (uint16_t)w[t1] : 0u;
+                Wp[e] = lo | (hi << 16);
             }
         }
-        uint8_t* o = a.dst + (long long)bz_ * a.ds + (long long)y * hrow;
-        if (col < hrow) o[col] = (uint8_t)min(max((acc0 + 8192) >> 14, 0), 255);
-        if (col + 1 < hrow) o[col + 1] = (uint8_t)min(max((acc1 + 8192) >> 14, 0), 255);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int rp = pb + 4 * j;
+            if (rp < npairs) {   // (even row, odd row) of column 2 lane, then of column 2 lane + 1: 8 bytes, adjacent columns
+                const uint32_t e = v[2 * j], o = v[2 * j + 1];
+                *reinterpret_cast<u32x2_t*>(&S[rp * 128 + 2 * lane]) =
+                    u32x2_t{__builtin_amdgcn_perm(o, e, 0x05040100u), __builtin_amdgcn_perm(o, e, 0x07060302u)};
+            }
+        }
+    }
+    __syncthreads();
+    for (int y = Y0 + wave; y < Y1; y += 4) {
+        const int s0 = ty.ofs[y] - r0, p = s0 & 1, nj = (ty.k + p + 1) >> 1;
+        const uint32_t* tap = S + (s0 >> 1) * 128 + lane;
+        const uint32_t* w = Wp + (y - Y0) * wpr;
+        int32_t acc0 = 0, acc1 = 0;
+        for (int j = 0; j < nj; j += 2) {   // two row pairs per trip: independent LDS reads in flight (slot nj, if read, has zero weights)
+            const uint32_t a0 = tap[j * 128], b0 = tap[j * 128 + 64], a1 = tap[(j + 1) * 128], b1 = tap[(j + 1) * 128 + 64];
+            const uint32_t w0 = w[j], w1 = j + 1 < wpr ? w[j + 1] : 0u;
+            acc0 = dot2_i16(a0, w0, acc0); acc1 = dot2_i16(b0, w0, acc1);
+            acc0 = dot2_i16(a1, w1, acc0); acc1 = dot2_i16(b1, w1, acc1);
+        }
+        uint8_t* o = a.dst + (long long)bz_ * a.ds + (long long)y * hrow + colb;
+        if (colb + lane < hrow) o[lane] = (uint8_t)min(max((acc0 + 8192) >> 14, 0), 255);
+        if (colb + lane + 64 < hrow) o[lane + 64] = (uint8_t)min(max((acc1 + 8192) >> 14, 0), 255);
     }
 }
 
@@ -779,7 +799,7 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
             Rz al = av;
             al.tiles = xcd_tiles(cdiv(hrow, 128), cdiv(dh, ty.vty), (unsigned)batch, cdiv(hrow, 128) * 4);
             if (al.tiles.total == 0) return fail(KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-            const size_t vlds = (size_t)(ty.vrows + 3) * 256 + (size_t)ty.vty * ty.kp * 2;
+            const size_t vlds = (size_t)(((ty.vrows + 1) >> 1) + 2) * 512 + (size_t)ty.vty * ((ty.kp >> 1) + 1) * 4;   // row pairs + two spare, weight rows
             if (vlds > 48 * 1024) KH_HIP(hipFuncSetAttribute((const void*)sep_v_u8_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             hipLaunchKernelGGL(sep_v_u8_lds_kernel, xcd_grid(al.tiles), dim3(256), vlds, st, al, (const int16_t*)hbuf, ty, hrow);
         } else {
