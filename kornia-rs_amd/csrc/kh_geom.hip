@@ -191,6 +191,7 @@ __device__ __forceinline__ void sample(const float* __restrict__ img, int rows, 
 // Output pixels leave through the streaming store path (write-through, non-temporal: kh_common.h::stream_store) — the destination is
 // written once and never read by the kernel.  The V# covers what is left of the pixel's ROW: a wave is one row of a 64 x 4 tile
 // (kBx == 64), so the row base is wave-uniform and only x * C * 4 travels in the vector offset.
+static_assert(kBx == 64, "out_row: a wave must be exactly one tile row");
 struct OutRow { __amdgpu_buffer_rsrc_t rs; };
 template <int C>
 __device__ __forceinline__ OutRow out_row(float* row_base_of_this_wave, int dw) {
