@@ -225,7 +225,7 @@ class H2DPreprocess1080p(NorthStarNV12):
         self.turn = 0
 
     def step(self):
-        self.pre.run_host_batch(self.host_frames[self.turn % self.RING], self.W, self.H, self.dst)
+        self.pre.run_host_batch(self.host_frames[self.turn % self.RING], self.W, self.H, self.dst, zero_copy=not self.pageable)
         self.turn += 1
 
     def roofline_extra(self, mean_step_s):
@@ -256,7 +256,7 @@ class H2DPreprocess1080p(NorthStarNV12):
                 "hidden_by_overlap_ms": round(h2d_ms + ker_ms - e2e_ms, 4),
                 "end_to_end_frac_of_pinned_h2d": round(h2d_ms / max(e2e_ms, 1e-9), 4),
                 "source": "pageable numpy frames (host memcpy into the ring's pinned slot, then DMA)" if self.pageable
-                          else "page-locked capture buffers, DMA'd in place (zero-copy upload)"}
+                          else "page-locked capture buffers, DMA'd in place (run_host_batch(..., zero_copy=True): opt-in)"}
 
     def describe(self):
         d = super().describe()

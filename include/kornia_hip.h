@@ -61,13 +61,8 @@ KH_API const char* kh_version(void);
 /* A no-op `void (*deleter)(DLManagedTensor*)`: hosts swap it into tensors still exported through DLPack when their own
  * deleter callback is about to become uncallable (interpreter shutdown).  T/dlpack.rs:72-170 relies on Rust's Box for this. */
 KH_API void kh_dlpack_noop_deleter(void* managed_tensor);
-/* test hook: floor(n / d) through the multiply-shift division the kernels use for tile ids (n < 2^31)   */
-KH_API uint32_t kh_debug_fast_quot(uint32_t n, uint32_t d);
-/* test hook: force one of the alternate code paths a launcher can take on inputs that would not reach it (the IEEE-division /
- * four-tap / LDS-tile / per-pixel fallbacks other geometries use anyway), e.g. ("pre_grid", 0), ("filter_force_tile", 1),
- * ("warp_u8_direct", 1); value -1 restores the production choice; an unknown name is KH_ERR_INVALID_ARG.  Process-wide.  The
- * library never reads the environment.                                                                  */
-KH_API int32_t kh_debug_set_option(const char* name, int32_t value);
+/* (The library's two test hooks — kh_debug_fast_quot, kh_debug_set_option — are declared in kornia_hip_testing.h: they are not part
+ * of the boundary a host binds.)                                                                          */
 
 /* ------------------------------------------------------------------------------------------ */
 /* Device runtime: replaces cudarc's CudaContext/CudaStream/CudaEvent use in T/cuda.rs and

@@ -83,15 +83,17 @@ __host__ __device__ __forceinline__ uint32_t fast_quot(uint32_t n, const FastDiv
 // Nothing in this library reads the environment (round 3 had 26 getenv knobs, several on launch paths).  The ALTERNATE kernels a
 // launcher can route to — the fallbacks other geometries, alignments or channel counts take anyway: IEEE division, the four-tap
 // sampler, the LDS-tile filter, the per-pixel warps ... — can be FORCED by a test through kh_debug_set_option(name, value)
-// (include/kornia_hip.h), so that the parity tests reach them on convenient inputs.  One relaxed atomic load where a launcher
-// decides; -1 = unset (the production choice).  Variants that were measured and rejected are not in the library at all.
+// (include/kornia_hip_testing.h — not part of the drop-in boundary), so that the parity tests reach them on convenient inputs.  The
+// options are per THREAD (a launcher reads those of the thread calling it): one thread-local load where a launcher decides, nothing
+// process-wide to reroute other callers; -1 = unset (the production choice).  Variants that were measured and rejected are not in
+// the library at all.
 enum DevOpt : int {
     kOptPreIeeeDiv, kOptPreGrid, kOptPreQuads, kOptFilterForceTile, kOptFilterFourColumns, kOptGradScalar, kOptHfilterDirect,
     kOptResizeU8Gather, kOptPyrDirect, kOptPyrRoll, kOptMorphDirect, kOptMorphRoll, kOptU8BlurRgb, kOptU8BlurSwar, kOptWarpU8Direct, kOptWarpU8Spans, kOptWarpU8Rows,
     kOptCount
 };
-int dev_opt(DevOpt o);  // kh_runtime.hip
-extern std::atomic<int>* const g_dev_opts;
+int dev_opt(DevOpt o);               // kh_runtime.hip: the calling thread's value
+void set_dev_opt(int o, int value);  // kh_debug_set_option only
 
 struct XcdTiles { unsigned tiles_x, tiles_y, total, run; FastDiv by_run, by_img, by_row; };
 constexpr int kXcds = 8;

@@ -754,8 +754,9 @@ bool quad_taps_fit_16(const PreArgs& a, int extra) {   // extra = 1: the bilinea
         int x[4];
         for (int j = 0; j < 4; ++j) {
             const float s = ((float)(4 * q + j) - a.pad_x) / a.scale_x;   // plan_pixel; the kernel's quotient equals this or it divides itself
-            x[j] = s >= 2147483520.0f ? a.src_w - 1 : std::min(std::max((int)s, 0), a.src_w - 1);
-            if (!(s == s)) ok = false;
+            // the float -> int cast is defined only inside the int range: NaN and anything below it are sorted out BEFORE the cast
+            if (!(s == s)) { ok = false; x[j] = 0; }
+            else x[j] = s >= 2147483520.0f ? a.src_w - 1 : s <= -2147483648.0f ? 0 : std::min(std::max((int)s, 0), a.src_w - 1);
         }
         ok = ok && x[0] <= x[1] && x[1] <= x[2] && x[2] <= x[3] && std::min(x[3] + extra, a.src_w - 1) - (x[0] & ~1) <= 15;
     }

@@ -369,6 +369,20 @@ __global__ __launch_bounds__(256) void sep_v_u8_lds_kernel(Rz a, const int16_t* 
     // 128 window rows, the usual segment has ~100), then the weight rows' table reads; a taller window takes a second trip.
     const int wpr = (ty.kp >> 1) + 1;
     uint32_t* Wp = S + (((ty.vrows + 1) >> 1) + 2) * 128;   // after two spare row pairs (finite data for the zero-weight slots past the window)
+    // weight rows, one per destination row of the segment, as dwords {w[2 j - p], w[2 j + 1 - p]} with p = parity of the row's
+    // first window row (slots outside 0 .. k - 1 are zero): kp / 2 + 1 dwords each.  EVERY thread of the block fills its share —
+    // a wave with no row pair to stage (wave >= npairs: a one-row window) still runs it, after the loop below.
+    auto fill_weights = [&]() {
+        for (int e = threadIdx.x; e < (Y1 - Y0) * wpr; e += 256) {
+            const int yy = e / wpr, j = e - yy * wpr, y = Y0 + yy, p = (ty.ofs[y] - r0) & 1;
+            const int16_t* w = ty.w + (long long)y * ty.kp;
+            const int t0 = 2 * j - p, t1 = t0 + 1;
+            const uint32_t lo = (t0 >= 0 && t0 < ty.k) ? (uint16_t)w[t0] : 0u, hi = (t1 >= 0 && t1 < ty.k) ? (uint16_t)w[t1] : 0u;
+            Wp[e] = lo | (hi << 16);
+        }
+    };
+    S[npairs * 128 + threadIdx.x] = 0u;   // the two spare row pairs: the tap loop's rounded-up last trip reads one of them (zero weights)
+    bool weights_done = false;
     for (int pb = wave; pb < npairs; pb += 4 * 16) {
         uint32_t v[32];
 #pragma unroll
@@ -378,16 +392,9 @@ __global__ __launch_bounds__(256) void sep_v_u8_lds_kernel(Rz a, const int16_t* 
             if (pairs) v[j] = *reinterpret_cast<const uint32_t*>(row + cp);
             else v[j] = (uint32_t)(uint16_t)row[c0] | ((uint32_t)(uint16_t)row[c1] << 16);
         }
-        if (pb == wave) {
-            // weight rows, one per destination row of the segment, as dwords {w[2 j - p], w[2 j + 1 - p]} with p = parity of the row's
-            // first window row (slots outside 0 .. k - 1 are zero): kp / 2 + 1 dwords each
-            for (int e = threadIdx.x; e < (Y1 - Y0) * wpr; e += 256) {
-                const int yy = e / wpr, j = e - yy * wpr, y = Y0 + yy, p = (ty.ofs[y] - r0) & 1;
-                const int16_t* w = ty.w + (long long)y * ty.kp;
-                const int t0 = 2 * j - p, t1 = t0 + 1;
-                const uint32_t lo = (t0 >= 0 && t0 < ty.k) ? (uint16_t)w[t0] : 0u, hi = (t1 >= 0 && t1 < ty.k) ? (uint16_t)w[t1] : 0u;
-                Wp[e] = lo | (hi << 16);
-            }
+        if (!weights_done) {   // behind the first trip's loads: the table reads join them in flight
+            fill_weights();
+            weights_done = true;
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -399,6 +406,7 @@ __global__ __launch_bounds__(256) void sep_v_u8_lds_kernel(Rz a, const int16_t* 
             }
         }
     }
+    if (!weights_done) fill_weights();
     __syncthreads();
     for (int y = Y0 + wave; y < Y1; y += 4) {
         const int s0 = ty.ofs[y] - r0, p = s0 & 1, nj = (ty.k + p + 1) >> 1;

@@ -17,17 +17,20 @@
 #include <string>
 
 #include "kh_common.h"
+#include "kornia_hip_testing.h"   // the two kh_debug_* test hooks are defined here
 
 namespace kh {
 
-// development / test options (kh_common.h::DevOpt); -1 = unset
+// development / test options (kh_common.h::DevOpt); -1 = unset.  PER THREAD: a launcher reads the options of the thread that calls
+// it, so a test that forces a fallback kernel reroutes its own launches only — no other thread of the process (another component
+// sharing the library, a sharding worker) is affected, and there is nothing to race on.
 struct DevOpts {
-    std::atomic<int> v[kOptCount];
-    DevOpts() { for (auto& x : v) x.store(-1, std::memory_order_relaxed); }
+    int v[kOptCount];
+    DevOpts() { for (int& x : v) x = -1; }
 };
-static DevOpts g_dev_opts_storage;
-std::atomic<int>* const g_dev_opts = g_dev_opts_storage.v;
-int dev_opt(DevOpt o) { return g_dev_opts[o].load(std::memory_order_relaxed); }
+static thread_local DevOpts g_dev_opts;
+int dev_opt(DevOpt o) { return g_dev_opts.v[o]; }
+void set_dev_opt(int o, int value) { g_dev_opts.v[o] = value; }
 
 static thread_local char g_err[512] = {0};
 
@@ -118,8 +121,9 @@ void kh_dlpack_noop_deleter(void* managed_tensor) { (void)managed_tensor; }
 // test hook: the launch-constant division used to decode tile ids (kh_common.h::FastDiv), on the host
 uint32_t kh_debug_fast_quot(uint32_t n, uint32_t d) { return kh::fast_quot(n, kh::fast_div(d)); }
 
-// test hook: force one of the alternate code paths a launcher can take (kh_common.h::DevOpt).  `value` -1 restores the production
-// choice.  Unknown names are an error, so a stale test cannot silently test nothing.
+// test hook (include/kornia_hip_testing.h): force one of the alternate code paths a launcher can take (kh_common.h::DevOpt) for the
+// CALLING THREAD's launches.  `value` -1 restores the production choice.  Unknown names are an error, so a stale test cannot
+// silently test nothing.
 int32_t kh_debug_set_option(const char* name, int32_t value) {
     static const char* const names[kh::kOptCount] = {
         "pre_ieee_div", "pre_grid", "pre_quads", "filter_force_tile", "filter_four_columns", "grad_scalar", "hfilter_direct",
@@ -127,7 +131,7 @@ int32_t kh_debug_set_option(const char* name, int32_t value) {
     if (name)
         for (int i = 0; i < kh::kOptCount; ++i)
             if (strcmp(name, names[i]) == 0) {
-                kh::g_dev_opts[i].store(value, std::memory_order_relaxed);
+                kh::set_dev_opt(i, value);
                 return KH_OK;
             }
     return kh::fail(KH_ERR_INVALID_ARG, "kh_debug_set_option: unknown option '%s'", name ? name : "(null)");
@@ -274,13 +278,23 @@ int32_t kh_event_elapsed_ms(kh_event_t start, kh_event_t stop, float* ms) {
 
 int32_t kh_stream_fence(kh_stream_t producer, kh_stream_t consumer) {
     if (producer == consumer) return KH_OK;  // same queue: already ordered
+    // The event must belong to the PRODUCER's device: hipEventRecord rejects an event of another device (hipErrorInvalidHandle),
+    // while hipStreamWaitEvent accepts one — that is how a consumer stream of GPU b is ordered after a producer of GPU a.  A
+    // null producer is the current device's null stream, so the current device is already the right one for it.
+    int prev = -1;
+    hipDevice_t pdev = -1;
+    KH_HIP(hipGetDevice(&prev));
+    const bool hop = producer && hipStreamGetDevice(as_hip(producer), &pdev) == hipSuccess && (int)pdev != prev;
+    if (hop) KH_HIP(hipSetDevice((int)pdev));
     hipEvent_t e = nullptr;
-    KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipError_t r = hipEventRecord(e, as_hip(producer));
+    hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (r == hipSuccess) r = hipEventRecord(e, as_hip(producer));
     if (r == hipSuccess) r = hipStreamWaitEvent(as_hip(consumer), e, 0);
-    hipError_t d = hipEventDestroy(e);  // safe: the wait keeps its own reference
+    const hipError_t d = e ? hipEventDestroy(e) : hipSuccess;  // safe: the wait keeps its own reference
+    const hipError_t b = hop ? hipSetDevice(prev) : hipSuccess;
     if (r != hipSuccess) return fail_hip(r, "kh_stream_fence");
     if (d != hipSuccess) return fail_hip(d, "kh_stream_fence(destroy)");
+    if (b != hipSuccess) return fail_hip(b, "kh_stream_fence(restore device)");
     return KH_OK;
 }
 

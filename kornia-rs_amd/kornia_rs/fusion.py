@@ -139,3 +139,12 @@ class FusedPipeline:
         h, self._h = getattr(self, "_h", None), None
         if h:
             lib.kh_fused_pipeline_destroy(h)
+
+
+def _bind_pipeline_methods() -> None:
+    from .hip import on_operand_device   # launch with the stream's device current (the first device operand: the stream argument)
+    for name in ("launch_batched", "launch"):
+        setattr(FusedPipeline, name, on_operand_device(getattr(FusedPipeline, name)))
+
+
+_bind_pipeline_methods()

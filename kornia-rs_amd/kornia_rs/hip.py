@@ -43,6 +43,75 @@ def current_device() -> int:
     return int(d.value)
 
 
+class _device_guard:
+    """``with _device_guard(d):`` — device ``d`` current inside, the previous one restored after.  Needed wherever a handle's meaning
+    depends on the current device: the NULL stream (``Stream.default(d)`` has handle 0) and event / buffer creation."""
+
+    __slots__ = ("device", "prev")
+
+    def __init__(self, device: int):
+        self.device, self.prev = int(device), None
+
+    def __enter__(self):
+        self.prev = current_device()
+        if self.prev != self.device:
+            set_device(self.device)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != self.device:
+            set_device(self.prev)
+        return False
+
+
+def _operand_device(obj) -> Optional[int]:
+    """The device an operand lives on, if it says so: a device Image / Tensor (``is_device`` + ``device_id``), a DeviceBuffer /
+    anything carrying a ``stream``, a Stream."""
+    if isinstance(obj, Stream):
+        return obj.device
+    if getattr(obj, "is_device", False) and hasattr(obj, "device_id"):
+        return int(obj.device_id)
+    st = getattr(obj, "stream", None)
+    if isinstance(st, Stream):
+        return st.device
+    return None
+
+
+def on_operand_device(fn):
+    """Decorator for the host layer's device operators: run ``fn`` with the device of its first device operand current (restored
+    afterwards).  The C ABI keeps HIP's rule — the caller selects the device a stream belongs to before it launches on it (the table
+    caches, the workspace registry and a NULL stream handle all mean "the current device") — and the reference binds its context per
+    call the same way (``ctx.bind_to_thread()``, T/cuda.rs); this is that bind, so an operator on a device-1 image works from a thread
+    whose current device is 0 (tests/test_multi_device_gpu.py)."""
+    import functools
+
+    @functools.wraps(fn)
+    def bound(*args, **kwargs):
+        dev = None
+        for a in args:
+            dev = _operand_device(a)
+            if dev is not None:
+                break
+        else:
+            for a in kwargs.values():
+                dev = _operand_device(a)
+                if dev is not None:
+                    break
+        if dev is None:
+            return fn(*args, **kwargs)
+        guard = _device_guard(dev)
+        try:
+            guard.__enter__()
+        except _ffi.KorniaHipError:      # no usable device at all: let the operator report its own typed error (residency, KH_ERR_HIP)
+            return fn(*args, **kwargs)
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            guard.__exit__(None, None, None)
+
+    return bound
+
+
 def device_info(device: int = 0) -> Tuple[str, int, int]:
     """(name, compute units, total bytes)."""
     name = C.create_string_buffer(256)
@@ -247,24 +316,28 @@ _PIECE = _STAGE_BYTES // 2
 _stage_local = threading.local()
 
 
-def _stage() -> "PinnedBuffer":
-    """This thread's page-locked bounce buffer for pageable host <-> device copies (16 MiB = two 8 MiB halves, allocated on first
-    use; ``release_thread_staging`` or the end of the thread frees it).  Per thread: the sharders upload from one worker thread
-    per device at the same time."""
-    buf = getattr(_stage_local, "buf", None)
-    if buf is None:
-        buf = _stage_local.buf = PinnedBuffer(_STAGE_BYTES)
-        _stage_local.events = (Event(timing=False), Event(timing=False))
-    return buf
+def _stage(device: int):
+    """This thread's page-locked bounce buffer and its two half-events for pageable host <-> device copies on ``device`` (16 MiB =
+    two 8 MiB halves, allocated on first use; ``release_thread_staging`` or the end of the thread frees them).  Keyed by (thread,
+    device): one thread may copy for several devices — ``ShardedBatch.numpy()`` walks every shard from the calling thread, and a pool
+    worker is not pinned to one shard — and HIP rejects ``hipEventRecord`` when the event and the stream belong to different devices
+    (``hipErrorInvalidHandle``), so the events (and the buffer) are created with the stream's device current and used for it only."""
+    slots = getattr(_stage_local, "slots", None)
+    if slots is None:
+        slots = _stage_local.slots = {}
+    slot = slots.get(device)
+    if slot is None:
+        with _device_guard(device):
+            slot = slots[device] = (PinnedBuffer(_STAGE_BYTES), (Event(timing=False), Event(timing=False)))
+    return slot
 
 
 def release_thread_staging() -> None:
-    """Free the calling thread's bounce buffer (``ShardPool.close`` runs this on every worker: a pool that is shut down must not
-    keep 16 MiB pinned per worker for the life of the process)."""
-    buf = getattr(_stage_local, "buf", None)
-    _stage_local.buf = None
-    _stage_local.events = None
-    if buf is not None:
+    """Free the calling thread's bounce buffers (``ShardPool.close`` runs this on every worker: a pool that is shut down must not
+    keep 16 MiB pinned per worker and device for the life of the process)."""
+    slots = getattr(_stage_local, "slots", None)
+    _stage_local.slots = None
+    for buf, _events in (slots or {}).values():
         buf.free()
 
 
@@ -284,8 +357,13 @@ def d2h(out: np.ndarray, device_ptr: int, stream: Stream) -> None:
         d2h(tmp, device_ptr, stream)
         out[...] = tmp
         return
-    stage = _stage()
-    view, events = stage.view(), _stage_local.events
+    with _device_guard(stream.device):   # Stream.default(d) is handle 0: "the current device's null stream"
+        _d2h_pieces(flat, device_ptr, stream)
+
+
+def _d2h_pieces(flat: np.ndarray, device_ptr: int, stream: Stream) -> None:
+    stage, events = _stage(stream.device)
+    view = stage.view()
     stream.synchronize()   # the producer kernels
     pieces = [(off, min(_PIECE, flat.size - off)) for off in range(0, flat.size, _PIECE)]
 
@@ -310,18 +388,19 @@ def h2d(device_ptr: int, a: np.ndarray, stream: Stream) -> None:
     if a.nbytes == 0:
         return
     flat = a.reshape(-1).view(np.uint8)
-    stage = _stage()
-    view, events = stage.view(), _stage_local.events
-    stream.synchronize()   # a queued memset / kernel on this stream must not be overtaken
-    for i, off in enumerate(range(0, flat.size, _PIECE)):
-        n = min(_PIECE, flat.size - off)
-        h = (i & 1) * _PIECE
-        if i >= 2:
-            events[i & 1].synchronize()   # the DMA that last read this half
-        view[h:h + n] = flat[off:off + n]
-        check(lib.kh_memcpy_h2d_async(device_ptr + off, stage.ptr + h, n, stream.cuda_stream_ptr))
-        events[i & 1].record(stream)
-    stream.synchronize()   # the bounce buffer is reused by the next call
+    with _device_guard(stream.device):
+        stage, events = _stage(stream.device)
+        view = stage.view()
+        stream.synchronize()   # a queued memset / kernel on this stream must not be overtaken
+        for i, off in enumerate(range(0, flat.size, _PIECE)):
+            n = min(_PIECE, flat.size - off)
+            h = (i & 1) * _PIECE
+            if i >= 2:
+                events[i & 1].synchronize()   # the DMA that last read this half
+            view[h:h + n] = flat[off:off + n]
+            check(lib.kh_memcpy_h2d_async(device_ptr + off, stage.ptr + h, n, stream.cuda_stream_ptr))
+            events[i & 1].record(stream)
+        stream.synchronize()   # the bounce buffer is reused by the next call
 
 
 def _stream_handle(stream: Optional[Stream]) -> int:
@@ -379,8 +458,9 @@ class ManagedBuffer:
     def free(self) -> None:
         p, self.ptr = self.ptr, 0
         if p:
-            lib.kh_stream_synchronize(self.stream.cuda_stream_ptr)
-            lib.kh_free(p)
+            with _device_guard(self.stream.device):
+                lib.kh_stream_synchronize(self.stream.cuda_stream_ptr)
+                lib.kh_free(p)
 
     def __del__(self):
         try:
@@ -440,8 +520,13 @@ class DeviceBuffer:
                 if getattr(self.stream, "_workspace", None) is self:
                     self.stream._workspace = None
             self._ws_keys = set()
-            lib.kh_free_async(self.ptr, self.stream.cuda_stream_ptr)
+            with _device_guard(self.stream.device):   # a null stream handle means "the current device's": free where it was allocated
+                lib.kh_free_async(self.ptr, self.stream.cuda_stream_ptr)
             self.ptr = 0
+
+    @property
+    def device_id(self) -> int:
+        return self.stream.device
 
     def __del__(self):
         try:

@@ -966,3 +966,17 @@ rgb_from_luv = _cie("rgb_from_luv")
 
 
 crop = crop_image  # short name used by the Python stubs; `crop_image` is the Rust name (P/crop.rs:187)
+
+
+def _bind_public_operators() -> None:
+    """Every public operator of this module runs with its first device operand's device current (``hip.on_operand_device``): the
+    launch, its scratch / table lookups and a NULL stream handle all refer to "the current device"."""
+    import inspect
+    from .hip import on_operand_device
+    g = globals()
+    for name, obj in list(g.items()):
+        if not name.startswith("_") and inspect.isfunction(obj) and obj.__module__ == __name__:
+            g[name] = on_operand_device(obj)
+
+
+_bind_public_operators()

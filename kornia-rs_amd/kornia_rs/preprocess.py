@@ -221,8 +221,8 @@ class _Staging:
 
       1. host-wait the upload issued from this slot two calls ago (long finished), grow the slot's buffers if needed;
       2. host memcpy of the frames into the slot's pinned buffer — kernel k - 1 and upload k - 1 are still in flight;
-         frames that ALREADY live in page-locked memory (``hip.PinnedBuffer`` capture buffers) skip this copy and are DMA'd from
-         where they are;
+         with ``zero_copy=True`` (opt-in) frames that ALREADY live in page-locked memory (``hip.PinnedBuffer`` capture buffers)
+         skip this copy and are DMA'd from where they are — the caller must then leave them alone until ``wait_uploads()``;
       3. on the COPY stream: wait for the kernel that last read this slot's device buffer (call k - 2), H2D, record ``upload_done``;
       4. the compute stream waits for that one event and the caller launches the kernel; ``mark_consumed`` records the event step 3 of
          call k + 2 will wait for.
@@ -250,7 +250,16 @@ class _Staging:
         except Exception:
             return False
 
-    def upload(self, stream: Stream, frames):
+    def upload(self, stream: Stream, frames, zero_copy: bool = False):
+        """``zero_copy=True`` lets frames that already live in page-locked memory be DMA'd from where they are (no host copy): the
+        caller then owns the hazard — such a frame must not be rewritten before ``wait_uploads()``.  The default copies every frame
+        into the ring's own pinned slot, so the caller may reuse its frames as soon as this returns, pinned or not: the reference's
+        ``Staging`` contract (PY/cuda_ext/mod.rs:647-745)."""
+        from .hip import _device_guard
+        with _device_guard(stream.device):   # events / buffers are created for the stream's device, whatever the caller had current
+            return self._upload(stream, frames, zero_copy)
+
+    def _upload(self, stream: Stream, frames, zero_copy: bool):
         from .hip import Event, PinnedBuffer
         slot = self.slots[self.turn % self.DEPTH]
         self.turn += 1
@@ -264,7 +273,7 @@ class _Staging:
         if self.copy_stream is None:
             self.copy_stream = Stream.new(stream.device)
         cs = self.copy_stream
-        zero_copy = self._pinned_sources(frames)
+        zero_copy = bool(zero_copy) and self._pinned_sources(frames)
         if not zero_copy and (slot.pinned is None or slot.pinned.nbytes < total):
             slot.pinned = PinnedBuffer(total)
             self.allocations += 1
@@ -337,10 +346,11 @@ class _Staging:
 
     def mark_consumed(self, stream: Stream) -> None:
         """Call after the kernel that reads the last ``upload`` has been enqueued on ``stream``."""
-        from .hip import Event
+        from .hip import Event, _device_guard
         if self.current is not None:
-            ev = Event(timing=False)
-            ev.record(stream)
+            with _device_guard(stream.device):
+                ev = Event(timing=False)
+                ev.record(stream)
             self.current.consumed = ev
 
     def wait_uploads(self) -> None:
@@ -632,17 +642,19 @@ class Preprocessor:
         return Tensor.zeros((batch, 3, out_height, out_width),
                             "float16" if self.f16 else "float32", stream=self.stream)
 
-    def run_host_batch(self, frames: Sequence[np.ndarray], width: int, height: int, dst: Tensor) -> None:
+    def run_host_batch(self, frames: Sequence[np.ndarray], width: int, height: int, dst: Tensor, *, zero_copy: bool = False) -> None:
         """``N`` same-sized HOST frames (1-D uint8 arrays) -> ``dst`` ``[N, 3, H, W]``: staged through the two-deep upload ring (see
-        ``_Staging``) — the host copy and the DMA of this call overlap the previous call's kernel — then ONE batched launch.  Frames
-        that live in page-locked memory (``hip.PinnedBuffer`` capture buffers) are DMA'd in place; such buffers may be rewritten
-        after ``wait_uploads()``.  Pageable frames may be reused as soon as this returns."""
+        ``_Staging``) — the host copy and the DMA of this call overlap the previous call's kernel — then ONE batched launch.
+        The frames may be reused as soon as this returns (the reference's staging contract), page-locked or not.
+        ``zero_copy=True`` is the capture-ring fast path: frames that live in page-locked memory (``hip.PinnedBuffer``,
+        ``hipHostRegister``-ed or torch ``pin_memory`` buffers) are DMA'd in place, and the CALLER must not rewrite them before
+        ``wait_uploads()``; frames that are not page-locked are staged as usual."""
         frames = [np.asarray(a).reshape(-1) for a in frames]
         if any(a.dtype != np.uint8 for a in frames):
             raise TypeError("raw frames must be uint8")
         if len({a.size for a in frames}) != 1:
             raise PreprocessError("InvalidRawSource", "batched frames must have the same length")
-        dev, stride = self._staging.upload(self.stream, frames)
+        dev, stride = self._staging.upload(self.stream, frames, zero_copy=zero_copy)
         self.run_raw_batch(dev, width, height, dst, frame_stride=stride)
         self._staging.mark_consumed(self.stream)
 
@@ -692,3 +704,15 @@ class Preprocessor:
             cs = Stream.from_cuda_stream(consumer_stream)
             check(lib.kh_stream_fence(self.stream.cuda_stream_ptr, cs.cuda_stream_ptr))
         return dst
+
+
+def _bind_preprocessor_methods() -> None:
+    """Every launching method of ``Preprocessor`` runs with its stream's device current (``hip.on_operand_device``: the preprocessor
+    carries its stream), like the reference binds its context per call."""
+    from .hip import on_operand_device
+    for name in ("run_raw", "run_raw_batch", "run_raw_f16", "run_raw_batch_f16", "run_surface", "run_image", "alloc_output",
+                 "run_host_batch", "run"):
+        setattr(Preprocessor, name, on_operand_device(getattr(Preprocessor, name)))
+
+
+_bind_preprocessor_methods()

@@ -97,12 +97,38 @@ class ShardPool:
         return len(self.devices)
 
     def close(self) -> None:
+        """Every worker lets go of its page-locked bounce buffers (hip.d2h / hip.h2d pin 16 MiB per copying thread and device),
+        then the pool shuts down.  The ``world`` release tasks meet at a barrier before they free anything, so each of the pool's
+        workers runs exactly one of them — an idle worker cannot take two and leave another's buffer pinned until thread exit.
+        Errors raised by the release itself are re-raised, not swallowed."""
+        import threading
         from . import hip
-        try:   # every worker lets go of its page-locked bounce buffer (hip.d2h / hip.h2d pin 16 MiB per copying thread)
-            list(self._pool.map(lambda _g: hip.release_thread_staging(), range(self.world)))
-        except RuntimeError:
-            pass   # already shut down
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
+        barrier = threading.Barrier(self.world)
+
+        def release(_g: int):
+            try:
+                barrier.wait(timeout=30.0)   # all `world` tasks are running, i.e. one per worker thread
+            except threading.BrokenBarrierError:
+                pass                         # a worker died or the pool is wedged: still free what this thread holds
+            hip.release_thread_staging()
+
+        try:
+            futures = [self._pool.submit(release, g) for g in range(self.world)]
+        except RuntimeError:                 # "cannot schedule new futures after shutdown": nothing left to release through the pool
+            futures = []
+            barrier.abort()
+        errors = []
+        for f in futures:
+            try:
+                f.result()
+            except Exception as e:           # noqa: BLE001 — collected, reported after the pool is down
+                errors.append(e)
         self._pool.shutdown(wait=True)
+        if errors:
+            raise errors[0]
 
     def __del__(self):
         try:

@@ -5,6 +5,8 @@ libkornia_hip.so is made under a temporary directory and pytest runs there; noth
 
     python scripts/hostsim_run.py tests/test_geom_gpu.py -x -q
     KH_HOSTSIM_SANITIZE=address python scripts/hostsim_run.py tests -q -n 16     # AddressSanitizer: out-of-bounds kernel accesses
+    KH_HOSTSIM_DEVICES=2 python scripts/hostsim_run.py tests/test_multi_device_gpu.py tests/test_sharding_gpu.py   # two simulated GPUs
+    KH_HOSTSIM_PREBUILT=/tmp/sim.so ...   # reuse a library built by tests/hostsim/build.py instead of building one per run
 """
 import os
 import shutil
@@ -22,7 +24,12 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         tree = os.path.join(tmp, "repo")
         shutil.copytree(ROOT, tree, ignore=shutil.ignore_patterns(".git", "gpurun_out", "profiles", "__pycache__", "build", ".pytest_cache"))
-        hostsim_build.build(os.path.join(tree, "kornia-rs_amd", "lib", "libkornia_hip.so"))
+        lib = os.path.join(tree, "kornia-rs_amd", "lib", "libkornia_hip.so")
+        prebuilt = os.environ.get("KH_HOSTSIM_PREBUILT")
+        if prebuilt and os.path.exists(prebuilt):
+            shutil.copyfile(prebuilt, lib)
+        else:
+            hostsim_build.build(lib)
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", KH_HOSTSIM="1")
         if os.environ.get("KH_HOSTSIM_SANITIZE") == "undefined":
             rt = subprocess.check_output([hostsim_build.CXX, "-print-file-name=libclang_rt.ubsan_standalone-x86_64.so"], text=True).strip()

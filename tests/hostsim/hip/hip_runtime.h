@@ -28,12 +28,14 @@ struct dim3 {
     constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
+struct hostsim_stream;
 namespace hostsim {
 struct Lane { dim3 tid, bid, bdim, gdim; };
 extern Lane* cur;                       // the fiber that is running
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void block_barrier();
 void wave_barrier();
+void launch_on(struct ::hostsim_stream* stream, dim3 grid, dim3 block, const std::function<void()>& body);
 uint32_t shfl_bits(uint32_t v, int src_lane);  // value of `v` in lane `src_lane` of the caller's wave
 int lane_id();
 }  // namespace hostsim
@@ -42,8 +44,10 @@ int lane_id();
 #define blockIdx (hostsim::cur->bid)
 #define blockDim (hostsim::cur->bdim)
 #define gridDim (hostsim::cur->gdim)
+// a launch on a stream that belongs to another device than the calling thread's current one is refused (sticky error, read by
+// hipGetLastError) — stricter than some runtimes, so that a host layer that forgets hipSetDevice fails here, not on an 8-GPU node
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hostsim::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+    hostsim::launch_on((stream), dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
 
 // ---- device intrinsics used by the kernels -------------------------------------------------------------------------
 inline void __syncthreads() { hostsim::block_barrier(); }
@@ -135,7 +139,7 @@ inline unsigned max(int a, unsigned b) { return (unsigned)a > b ? (unsigned)a : 
 
 // ---- runtime API (tests/hostsim/hostsim.cpp) ---------------------------------------------------------------------------
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101, hipErrorInvalidHandle = 400, hipErrorNotSupported = 801 };
 typedef struct hostsim_stream* hipStream_t;
 typedef struct hostsim_event* hipEvent_t;
 typedef struct hostsim_pool* hipMemPool_t;

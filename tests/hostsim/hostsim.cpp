@@ -122,15 +122,31 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 
 }  // namespace hostsim
 
-// ---- runtime: one synchronous "device 0", device memory = host memory ----------------------------------------------------
+// ---- runtime: KH_HOSTSIM_DEVICES (default 1) synchronous devices, device memory = host memory ---------------------------------
+// Several devices are modelled as far as the HOST LAYER can get them wrong: the current device is per thread, a stream and an event
+// belong to the device that was current when they were created, an allocation to the device current at that moment;
+// hipEventRecord refuses an event of another device than the stream's (hipErrorInvalidHandle, as HIP does), a launch on a stream of
+// another device than the current one is refused, a NULL stream is the current device's.  (the double-buffered copies
+// recorded per-thread events on streams of whatever device — found by review, because no test box has two GPUs.)
+struct hostsim_stream { int device; };
+struct hostsim_event { int device; };
 namespace {
+int device_count() {
+    static const int n = [] { const char* e = getenv("KH_HOSTSIM_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+    return n;
+}
+thread_local int t_device = 0;
+thread_local hipError_t t_last_error = hipSuccess;
+int stream_device(hipStream_t s) { return s ? s->device : t_device; }
+
+struct Alloc { hipMemoryType type; size_t bytes; int device; };
 std::mutex g_mem_lock;
-std::map<const void*, std::pair<hipMemoryType, size_t>> g_allocs;  // base -> (kind, bytes): kh_pointer_domain, the staging ring's pinned-source test
+std::map<const void*, Alloc> g_allocs;  // base -> (kind, bytes, device): kh_pointer_domain, the staging ring's pinned-source test
 hipError_t track(void** p, size_t n, hipMemoryType type) {
     *p = calloc(n ? n : 1, 1);
     if (!*p) return hipErrorOutOfMemory;
     std::lock_guard<std::mutex> g(g_mem_lock);
-    g_allocs[*p] = {type, n ? n : 1};
+    g_allocs[*p] = Alloc{type, n ? n : 1, t_device};
     return hipSuccess;
 }
 hipError_t untrack(void* p) {
@@ -141,25 +157,37 @@ hipError_t untrack(void* p) {
 }
 }  // namespace
 
-const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : (e == hipErrorNotSupported ? "not supported by the host simulator" : "error"); }
-hipError_t hipGetLastError() { return hipSuccess; }
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
-hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+namespace hostsim {
+void launch_on(hipStream_t stream, dim3 grid, dim3 block, const std::function<void()>& body) {
+    if (stream_device(stream) != t_device) { t_last_error = hipErrorInvalidHandle; return; }   // the launch does not happen
+    launch(grid, block, body);
+}
+}  // namespace hostsim
+
+const char* hipGetErrorString(hipError_t e) {
+    return e == hipSuccess ? "success" : e == hipErrorNotSupported ? "not supported by the host simulator"
+         : e == hipErrorInvalidHandle ? "invalid resource handle (event / stream / launch on another device than the one it belongs to)"
+         : e == hipErrorInvalidDevice ? "invalid device ordinal" : "error";
+}
+hipError_t hipGetLastError() { const hipError_t e = t_last_error; t_last_error = hipSuccess; return e; }
+hipError_t hipGetDeviceCount(int* n) { *n = device_count(); return hipSuccess; }
+hipError_t hipSetDevice(int d) { if (d < 0 || d >= device_count()) return hipErrorInvalidDevice; t_device = d; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = t_device; return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d) {
+    if (d < 0 || d >= device_count()) return hipErrorInvalidDevice;
     memset(p, 0, sizeof *p);
     snprintf(p->name, sizeof p->name, "host simulator");
     snprintf(p->gcnArchName, sizeof p->gcnArchName, "x86 fibers");
     p->multiProcessorCount = 1; p->totalGlobalMem = (size_t)64 << 30;
     return hipSuccess;
 }
-hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
-hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hostsim_stream{t_device}; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
-hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   // any device's event: how GPUs are ordered against each other
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hostsim_event{t_device}; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { return e->device == stream_device(s) ? hipSuccess : hipErrorInvalidHandle; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)32 << 30; *t = (size_t)64 << 30; return hipSuccess; }
@@ -180,7 +208,7 @@ hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
     hostsim::g_capture = nullptr;
     return hipSuccess;
 }
-hipError_t hipStreamGetDevice(hipStream_t, hipDevice_t* device) { *device = 0; return hipSuccess; }
+hipError_t hipStreamGetDevice(hipStream_t s, hipDevice_t* device) { *device = stream_device(s); return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* status) {
     *status = hostsim::g_capture ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone;
@@ -216,8 +244,8 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
     auto it = g_allocs.upper_bound(p);  // the allocation that starts at or before p
     if (it == g_allocs.begin()) return hipErrorInvalidValue;
     --it;
-    if ((const char*)p >= (const char*)it->first + it->second.second) return hipErrorInvalidValue;   // past the end of that allocation: plain host memory
-    a->type = it->second.first; a->device = 0;
+    if ((const char*)p >= (const char*)it->first + it->second.bytes) return hipErrorInvalidValue;   // past the end of that allocation: plain host memory
+    a->type = it->second.type; a->device = it->second.device;
     return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }

@@ -9,11 +9,24 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 HEADER = ROOT / "include" / "kornia_hip.h"
+TEST_HEADER = ROOT / "include" / "kornia_hip_testing.h"   # the two test hooks: exported, but not part of the boundary a host binds
 
 
-def declared_symbols():
-    text = HEADER.read_text()
+def declared_symbols(boundary_only: bool = False):
+    text = HEADER.read_text() + ("" if boundary_only else TEST_HEADER.read_text())
     return sorted(set(re.findall(r"KH_API\s+[\w\s\*]+?\b(kh_\w+)\s*\(", text)))
+
+
+def test_test_hooks_are_not_part_of_the_boundary():
+    """kh_debug_* live in kornia_hip_testing.h only: not in the boundary header, not in the generated Rust sys crate, and the
+    product's host layer never calls them (tests and bench.py's A/B switch do)."""
+    hooks = sorted(set(declared_symbols()) - set(declared_symbols(boundary_only=True)))
+    assert hooks == ["kh_debug_fast_quot", "kh_debug_set_option"]
+    assert "kh_debug_" not in re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    assert "kh_debug_" not in (ROOT / "integration" / "kornia-hip-sys" / "src" / "lib.rs").read_text()
+    for path in (ROOT / "kornia-rs_amd" / "kornia_rs").glob("*.py"):
+        if path.name != "_ffi.py":
+            assert "kh_debug_" not in path.read_text(), f"{path} calls a test hook"
 
 
 def test_header_declares_symbols():
@@ -146,7 +159,7 @@ def test_rust_sys_crate_is_in_step_with_the_header():
     committed = (ROOT / "integration" / "kornia-hip-sys" / "src" / "lib.rs").read_text()
     assert gen.generate() == committed, "run scripts/gen_rust_ffi.py"
     bound = set(re.findall(r"pub fn (kh_\w+)\(", committed))
-    assert bound == set(_ffi.SIGNATURES)
+    assert bound == set(declared_symbols(boundary_only=True)) == set(_ffi.SIGNATURES) - {"kh_debug_fast_quot", "kh_debug_set_option"}
     for const in ("KH_OK", "KH_ERR_HIP", "KH_ERR_SINGULAR", "KH_FMT_NV12", "KH_INTERP_LANCZOS", "KH_FUSE_WRITE_CHW_F32"):
         assert re.search(rf"pub const {const}: i32 = -?\d+;", committed), const
     fields = re.search(r"pub struct kh_preprocess_params \{(.*?)\}", committed, re.S).group(1)

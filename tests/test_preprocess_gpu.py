@@ -320,8 +320,9 @@ def test_python_run_reuses_pinned_staging_in_a_frame_loop(gpu_stream):
 def test_staging_ring_overlaps_and_stays_ordered(gpu_stream):
     """The ring under load: 24 back-to-back batches of DIFFERENT frames into two alternating outputs, no host sync in between — every
     kernel must have read the upload of its own call (a slot's device buffer is not overwritten before the kernel two calls back has
-    finished; the pinned bytes are not overwritten before their DMA has).  Then the zero-copy form: frames that already live in
-    page-locked memory are DMA'd in place (no host copy, no pinned allocation)."""
+    finished; the pinned bytes are not overwritten before their DMA has).  Then the zero-copy form (opt-in): frames that already live
+    in page-locked memory are DMA'd in place (no host copy, no pinned allocation).  Without the flag page-locked frames are staged
+    like any others — the reference's contract: a frame may be rewritten as soon as the call returns."""
     from kornia_rs import Tensor
     from kornia_rs.hip import PinnedBuffer
     w, h, n = 64, 34, 6
@@ -346,13 +347,28 @@ def test_staging_ring_overlaps_and_stays_ordered(gpu_stream):
             pre.wait_uploads()                                    # the capture side may rewrite a buffer once its DMA has left it
         for k in range(n):
             view[(b * n + k) * fb: (b * n + k + 1) * fb] = batches[r][k]
-        pre.run_host_batch([view[(b * n + k) * fb: (b * n + k + 1) * fb] for k in range(n)], w, h, zc[r])
+        pre.run_host_batch([view[(b * n + k) * fb: (b * n + k + 1) * fb] for k in range(n)], w, h, zc[r], zero_copy=True)
     assert pre._staging.zero_copy_uploads - base_zc == 6 and pre._staging.allocations == base_allocs
     for r in range(6):
         got = zc[r].numpy_raw()
         for k in range(n):
             want = O.preprocess(batches[r][k], w, h, w, h, fmt="nv12", mode="stretch", **IMAGENET)[0]
             _assert_bits_equal(got[k], want, f"zero-copy round {r} frame {k}")
+    # default: page-locked frames are copied into the ring's own slot, so they may be scribbled on the moment the call returns
+    pre.wait_uploads()
+    base_zc = pre._staging.zero_copy_uploads
+    safe = [Tensor.uninit((n, 3, h, w), "float32", gpu_stream) for _ in range(4)]
+    for r in range(4):
+        for k in range(n):
+            view[k * fb: (k + 1) * fb] = batches[r][k]
+        pre.run_host_batch([view[k * fb: (k + 1) * fb] for k in range(n)], w, h, safe[r])
+        view[: n * fb] = 0xA5                                      # no wait_uploads(): the staged copy has already left these bytes
+    assert pre._staging.zero_copy_uploads == base_zc
+    for r in range(4):
+        got = safe[r].numpy_raw()
+        for k in range(n):
+            want = O.preprocess(batches[r][k], w, h, w, h, fmt="nv12", mode="stretch", **IMAGENET)[0]
+            _assert_bits_equal(got[k], want, f"staged page-locked round {r} frame {k}")
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "rgb", "bgra", "yuyv", "gray"])

@@ -11,10 +11,39 @@ import subprocess
 import sys
 from pathlib import Path
 
+import pytest
+
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def test_gpu_suite_passes_on_the_host_simulator():
+@pytest.fixture(scope="module")
+def sim_env(tmp_path_factory):
+    """One simulator build for both runs below."""
+    sys.path.insert(0, str(ROOT / "tests" / "hostsim"))
+    import build as hostsim_build
+    lib = tmp_path_factory.mktemp("hostsim") / "libkornia_hip_hostsim.so"
+    hostsim_build.build(str(lib))
+    return dict(os.environ, KH_HOSTSIM_PREBUILT=str(lib))
+
+
+def test_multi_device_host_layer_on_two_simulated_gpus(sim_env):
+    """SURVEY.md §8e on the only two-GPU "node" any round had: the simulator with KH_HOSTSIM_DEVICES=2 (per-thread current device,
+    streams / events / allocations that belong to a device, hipEventRecord refusing another device's event, launches refused on a
+    stream of another device than the current one).  Runs the in-process sharders on devices [0, 1] / [1, 0, 1] and the device-1
+    -from-a-device-0-thread tests; skipped tests would mean the second device was not seen."""
+    cmd = [sys.executable, str(ROOT / "scripts" / "hostsim_run.py"), "tests/test_multi_device_gpu.py", "tests/test_sharding_gpu.py",
+           "tests/test_preprocess_gpu.py", "tests/test_host_api_gpu.py", "tests/test_unified_gpu.py", "-q", "-x", "-rs",
+           "--deselect", "tests/test_host_api_gpu.py::test_torch_rocm_zero_copy_interop",
+           "--deselect", "tests/test_unified_gpu.py::test_unified_torch_consumer"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(sim_env, KH_HOSTSIM_DEVICES="2"))
+    out = r.stdout + r.stderr
+    tail = "\n".join(out.splitlines()[-25:])
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
+    assert "needs two HIP devices" not in out, tail
+
+
+def test_gpu_suite_passes_on_the_host_simulator(sim_env):
     workers = str(max(1, min(16, (os.cpu_count() or 2) // 2)))
     cmd = [sys.executable, str(ROOT / "scripts" / "hostsim_run.py"), "tests", "-q", "-n", workers, "-x",
            "--deselect", "tests/test_host_api_gpu.py::test_torch_rocm_zero_copy_interop",  # needs torch to see a real device
@@ -23,7 +52,7 @@ def test_gpu_suite_passes_on_the_host_simulator():
            # tests/test_bench_workloads_gpu.py -n 8) but are left to the device to keep this suite short
            "--deselect", "tests/test_bench_workloads_gpu.py::test_gather_workloads_4k",
            "--deselect", "tests/test_bench_workloads_gpu.py::test_filter_workloads_4k"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3000)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=sim_env)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
     assert r.returncode == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
