@@ -973,10 +973,12 @@ def _bind_public_operators() -> None:
     launch, its scratch / table lookups and a NULL stream handle all refer to "the current device"."""
     import inspect
     from .hip import on_operand_device
-    g = globals()
+    g, bound = globals(), {}
     for name, obj in list(g.items()):
         if not name.startswith("_") and inspect.isfunction(obj) and obj.__module__ == __name__:
-            g[name] = on_operand_device(obj)
+            if obj not in bound:          # aliases (crop is crop_image) stay one object
+                bound[obj] = on_operand_device(obj)
+            g[name] = bound[obj]
 
 
 _bind_public_operators()
