@@ -1559,8 +1559,8 @@ def main():
             dist.init_process_group("gloo")
 
     from kornia_rs import hip
-    if not on_gpu:
-        local_dev = 0          # every simulated process owns one device, ordinal 0
+    if not on_gpu:   # the simulator shows KH_HOSTSIM_DEVICES devices (default 1): rank r owns device r when it exists, as on a node
+        local_dev = local_rank if local_rank < hip.device_count() else 0
     else:
         local_dev = local_rank
     hip.set_device(local_dev)

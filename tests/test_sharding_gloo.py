@@ -171,7 +171,7 @@ def test_two_ranks_run_their_slices_through_the_real_kernels(tmp_path, hostsim_l
     script.write_text(KERNEL_WORKER)
     port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KORNIA_HIP_LIB=str(hostsim_lib), KH_HOSTSIM="1",
-               OMP_NUM_THREADS="4")
+               KH_HOSTSIM_DEVICES="2", OMP_NUM_THREADS="4")   # two simulated GPUs: rank 1 selects device 1, as on a node
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
          "--master-port", str(port), str(script), str(ROOT)],
@@ -187,7 +187,7 @@ def test_bench_two_ranks_produce_one_valid_line(hostsim_lib):
     import json
     port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KORNIA_HIP_LIB=str(hostsim_lib), KH_HOSTSIM="1",
-               OMP_NUM_THREADS="4")
+               KH_HOSTSIM_DEVICES="2", OMP_NUM_THREADS="4")   # two simulated GPUs: rank 1 selects device 1, as on a node
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
          "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"],
