@@ -1290,16 +1290,22 @@ CPU_BUDGET_SCALE = 1.0  # lowered for the `also` entries so the default run stay
 
 
 def store_ceilings(hip, stream, dst_ptr: int, w: int, h: int, nframes: int, reps: int = 5):
-    """The two write ceilings of the north star, timed in THIS process on the headline's own output buffer with the same HIP
-    events: a flat fill of the output bytes and the production store shape with no loads / decode
-    (kornia-rs_amd/diag/kh_diag.hip -> lib/libkornia_hip_diag.so, a measurement-only library the product never loads)."""
+    """The ceilings of the north star, timed in THIS process on the headline's own output buffer with the same HIP events
+    (VERDICT r02 1c): a flat fill of the output bytes, the production store shape with no loads / decode, and (round 5) a pure READ
+    stream of the same bytes (kornia-rs_amd/diag/kh_diag.hip -> lib/libkornia_hip_diag.so, a measurement-only library the product
+    never loads)."""
     try:
         d = C.CDLL(str(ROOT / "kornia-rs_amd" / "lib" / "libkornia_hip_diag.so"))
         d.khd_flat_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
         d.khd_three_plane_store.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong]
+        d.khd_read_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+        from kornia_rs.hip import DeviceBuffer
         nbytes = 12 * w * h * nframes
+        sink = DeviceBuffer(16, stream)
+        # read_stream LAST: it reads what the two fills wrote (never the kernel's output pattern the compare could match)
         runs = {"flat_fill_ms": lambda: d.khd_flat_fill(stream.cuda_stream_ptr, dst_ptr, nbytes),
-                "three_plane_store_only_ms": lambda: d.khd_three_plane_store(stream.cuda_stream_ptr, dst_ptr, w, h, nframes, 3 * w * h)}
+                "three_plane_store_only_ms": lambda: d.khd_three_plane_store(stream.cuda_stream_ptr, dst_ptr, w, h, nframes, 3 * w * h),
+                "read_stream_ms": lambda: d.khd_read_stream(stream.cuda_stream_ptr, dst_ptr, nbytes, sink.ptr)}
         out = {}
         for key, fn in runs.items():
             if fn() != 0:
@@ -1644,6 +1650,12 @@ def main():
                 dev["frac_of_three_plane_store"] = round(ceilings["three_plane_store_only_ms"] / ms, 4)
                 dev["note"] = ("flat_fill / three_plane_store_only: the output bytes written with the production store policy and no loads or "
                                "decode, same process, same buffer, same events (kornia-rs_amd/diag/kh_diag.hip)")
+            if ceilings.get("read_stream_ms") and ms:
+                # the measured pure-read rate of this part (16 B / lane over the same 25.5 GB) and the kernel's total R + W rate against it:
+                # north_star's "HBM-read roofline" taken as what a read stream actually reaches, beside roofline.frac (datasheet 8 TB/s)
+                rd = ceilings["store_bytes"] / ceilings["read_stream_ms"] / 1e6
+                dev["read_stream_GBps"] = round(rd, 1)
+                dev["kernel_rate_over_read_stream_rate"] = round(line["roofline"]["achieved"] / rd, 4)
         line["device"] = dev
         if args.dev_option:
             line["dev_options"] = args.dev_option   # a line produced with forced code paths says so

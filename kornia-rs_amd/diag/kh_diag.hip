@@ -6,7 +6,10 @@
 //                          non-temporal buffer stores): the best this part does for a pure write stream;
 //   khd_three_plane_store  the production kernel's STORE SHAPE — 512-thread blocks, a thread stores 16 B into each of the three
 //                          f32 planes of its frame, back to back — with no loads and no decode.
-// bench.py times both in the same process, on the same buffers, with the same HIP events, so "fraction of the achievable" is
+//   khd_read_stream        (round 5) a pure READ of the same bytes, 16 B / lane buffer loads, nothing written: the rate this part
+//                          streams reads at.  north_star words its target as a fraction of the "HBM-read roofline"; the kernel's
+//                          total R + W rate is reported next to this measured read rate as well as against the 8 TB/s datasheet peak.
+// bench.py times all three in the same process, on the same buffers, with the same HIP events, so "fraction of the achievable" is
 // driver-timed instead of quoted from an earlier box.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,9 +35,29 @@ __global__ __launch_bounds__(512) void three_plane_store_kernel(float* __restric
     for (int c = 0; c < 3; ++c) __builtin_amdgcn_raw_buffer_store_b128(u32x4{1u, 2u, 3u, (unsigned)c}, rs, off + c * plane * 4, 0, kAux);
 }
 
+// every lane reads 16 B; the xor of what it read is compared with a value the buffer's contents practically never produce, so
+// the loads cannot be dropped and nothing is stored
+__global__ __launch_bounds__(256) void read_stream_kernel(const float* __restrict__ sb, long long n4, unsigned* __restrict__ sink) {
+    const long long i = (long long)blockIdx.y * gridDim.x * 256 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const long long base = i & ~((1ll << 26) - 1);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sb) + 4 * base, 0, 0x7fffffff, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(16 * (i - base)), 0, 0);
+    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9e3779b9u && v.x == 0x00012345u) atomicAdd(sink, 1u);
+}
+
 }  // namespace
 
 extern "C" {
+
+__attribute__((visibility("default"))) int khd_read_stream(void* stream, const float* src, long long nbytes, unsigned* sink) {
+    const long long n4 = nbytes / 16;
+    if (n4 <= 0) return 0;
+    const unsigned gy = (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256));
+    hipLaunchKernelGGL(read_stream_kernel, dim3(65536, gy), dim3(256), 0, (hipStream_t)stream, src, n4, sink);
+    return (int)hipGetLastError();
+}
+
 
 __attribute__((visibility("default"))) int khd_flat_fill(void* stream, float* dst, long long nbytes) {
     const long long n4 = nbytes / 16;

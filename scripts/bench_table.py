@@ -20,6 +20,9 @@ for l in sys.stdin:
     if "flat_fill_ms" in d:
         print("  ceilings: flat_fill %.3f ms, three_plane_store_only %.3f ms; kernel = %.3f of flat fill, %.3f of the three-plane stores" % (
             d["flat_fill_ms"], d["three_plane_store_only_ms"], d.get("frac_of_flat_fill", 0), d.get("frac_of_three_plane_store", 0)))
+        if "read_stream_ms" in d:
+            print("  read stream of the same bytes %.3f ms = %.0f GB/s; kernel R + W rate = %.3f of that measured read rate" % (
+                d["read_stream_ms"], d.get("read_stream_GBps", 0), d.get("kernel_rate_over_read_stream_rate", 0)))
     elif "store_ceilings_error" in d:
         print("  ceilings: ERROR", d["store_ceilings_error"])
     ex = {k: v for k, v in r.items() if k.startswith(("h2d_", "kernel_only", "end_to_end", "hidden_by", "serial_sum"))}
