@@ -424,28 +424,61 @@ private:
 
 // ---- residency dispatch (pair_residency / DeviceExec::for_streams, P/cuda/dispatch.rs:50-130) ---------------
 namespace detail {
+// `device` current for the scope, the caller's restored at its end: for the entries that take a stream and raw device pointers
+// (camera-format decoders / encoders, the preprocessor, graph capture and replay) — the operators on Images bind through DeviceExec.
+class DeviceScope {
+public:
+    explicit DeviceScope(int device) {   // never throws: without a usable device the entry that follows reports its own typed error
+        int32_t cur = -1;
+        if (kh_get_device(&cur) == KH_OK && cur != device && kh_set_device(device) == KH_OK) prev_ = cur;
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+    ~DeviceScope() { if (prev_ >= 0) kh_set_device(prev_); }
+
+private:
+    int prev_ = -1;
+};
 // DeviceExec (P/cuda/dispatch.rs:28-82): the stream an op launches on — the SOURCE image's — with the destination's
 // stream fenced IN before the launch (for_streams) and the launch stream fenced BACK into it when the exec goes out of
 // scope, i.e. right after the launch in every operator below (run): dst's own stream — its to_host(), the next op that
 // reads it, its stream-ordered free — is ordered after the kernel that writes it.  Same-stream pairs cost nothing.
 class DeviceExec {
 public:
+    // The exec also BINDS the launch stream's device for its lifetime (the reference binds its context per call,
+    // `ctx.bind_to_thread()`): the C ABI keeps HIP's rule that the caller selects a stream's device before launching on it — the
+    // table caches, the workspace registry and a NULL stream handle all mean "the current device" — so an operator on device-1
+    // images works from a thread whose current device is 0, and the caller's device is restored when the exec goes out of scope.
     DeviceExec(const Stream& launch, const Stream& dst) : launch_(launch), dst_(dst), cross_(!launch.same_as(dst)) {
-        if (cross_) check(kh_stream_fence(dst_.handle(), launch_.handle()));  // dst's pending work first
+        int32_t cur = -1;
+        if (kh_get_device(&cur) == KH_OK && cur != launch_.device() && kh_set_device(launch_.device()) == KH_OK) prev_device_ = cur;
+        if (cross_) {
+            const int32_t rc = kh_stream_fence(dst_.handle(), launch_.handle());  // dst's pending work first
+            if (rc != 0) { restore(); check(rc); }
+        }
     }
     DeviceExec(const DeviceExec&) = delete;
     DeviceExec& operator=(const DeviceExec&) = delete;
-    DeviceExec(DeviceExec&& o) noexcept : launch_(o.launch_), dst_(o.dst_), cross_(o.cross_) { o.cross_ = false; }
+    DeviceExec(DeviceExec&& o) noexcept : launch_(o.launch_), dst_(o.dst_), cross_(o.cross_), prev_device_(o.prev_device_) {
+        o.cross_ = false;
+        o.prev_device_ = -1;
+    }
     ~DeviceExec() {
         if (cross_) kh_stream_fence(launch_.handle(), dst_.handle());  // best effort in a destructor; a failed launch has already thrown
+        restore();
     }
     kh_stream_t handle() const { return launch_.handle(); }
     const Stream& stream() const { return launch_; }
     operator const Stream&() const { return launch_; }
 
 private:
+    void restore() noexcept {
+        if (prev_device_ >= 0) kh_set_device(prev_device_);
+        prev_device_ = -1;
+    }
     Stream launch_, dst_;
     bool cross_;
+    int prev_device_ = -1;
 };
 template <typename TS, int CS, typename TD, int CD>
 inline DeviceExec device_exec_for(const Image<TS, CS>& src, const Image<TD, CD>& dst, const char* what) {
@@ -701,23 +734,28 @@ inline const Stream& raw_to_image(const Image<uint8_t, 3>& dst, const uint8_t* r
 }  // namespace helpers
 inline void rgb_from_planar420(const uint8_t* raw_device, size_t raw_bytes, Image<uint8_t, 3>& dst, Planar420 layout) {
     const Stream& s = helpers::raw_to_image(dst, raw_device, raw_bytes, dst.width() * dst.height() * 3 / 2, "rgb_from_planar420");
+    const detail::DeviceScope bind(s.device());
     detail::check(kh_rgb_from_planar420_u8(s.handle(), raw_device, dst.device_ptr_mut(), detail::i32(dst.width()), detail::i32(dst.height()), (int32_t)layout));
 }
 inline void rgb_from_packed422(const uint8_t* raw_device, size_t raw_bytes, Image<uint8_t, 3>& dst, Packed422 layout) {
     const Stream& s = helpers::raw_to_image(dst, raw_device, raw_bytes, dst.width() * dst.height() * 2, "rgb_from_packed422");
+    const detail::DeviceScope bind(s.device());
     detail::check(kh_rgb_from_packed422_u8(s.handle(), raw_device, dst.device_ptr_mut(), detail::i32(dst.width()), detail::i32(dst.height()), (int32_t)layout));
 }
 inline void convert_yuyv_to_rgb_u8(const uint8_t* raw_device, size_t raw_bytes, Image<uint8_t, 3>& dst, YuvToRgbMode mode) {
     const Stream& s = helpers::raw_to_image(dst, raw_device, raw_bytes, dst.width() * dst.height() * 2, "convert_yuyv_to_rgb_u8");
+    const detail::DeviceScope bind(s.device());
     detail::check(kh_yuyv_to_rgb_mode_u8(s.handle(), raw_device, dst.device_ptr_mut(), detail::i32(dst.width()), detail::i32(dst.height()), (int32_t)mode));
 }
 // encoders write width*height*3/2 (NV12) or width*height*2 (YUYV) bytes at `out_device`
 inline void nv12_from_rgb(const Image<uint8_t, 3>& src, uint8_t* out_device) {
     if (!src.is_device()) throw ImageError(ImageError::Kind::HostPathUnavailable, "nv12_from_rgb: host image — device backend only");
+    const detail::DeviceScope bind(src.stream()->device());
     detail::check(kh_nv12_from_rgb_u8(src.stream()->handle(), src.device_ptr(), out_device, detail::i32(src.width()), detail::i32(src.height())));
 }
 inline void yuyv_from_rgb(const Image<uint8_t, 3>& src, uint8_t* out_device) {
     if (!src.is_device()) throw ImageError(ImageError::Kind::HostPathUnavailable, "yuyv_from_rgb: host image — device backend only");
+    const detail::DeviceScope bind(src.stream()->device());
     detail::check(kh_yuyv_from_rgb_u8(src.stream()->handle(), src.device_ptr(), out_device, detail::i32(src.width()), detail::i32(src.height())));
 }
 
@@ -937,6 +975,7 @@ template <int C>
 inline std::pair<float, float> find_min_max(const Image<float, C>& src) {
     if (!src.is_device()) throw ImageError(ImageError::Kind::HostPathUnavailable, "find_min_max: host image — device backend only");
     const Stream& s = *src.stream();
+    const detail::DeviceScope bind(s.device());
     void* scratch = nullptr;
     detail::check(kh_malloc_async(&scratch, 16, 1, s.handle()));
     float* mm = static_cast<float*>(scratch);
@@ -1011,6 +1050,7 @@ public:
         for (int c = 0; c < 3; ++c) { p.mean[c] = mean_[c]; p.inv_std[c] = inv_std_[c]; }
         p.pad_value = pad_value_; p.sampling = sampling_; p.out_dtype = KH_OUT_F32; p.nframes = nframes; p.flags = 0;
         p.src_frame_stride = src_frame_stride; p.dst_frame_stride = (int64_t)3 * dst_w * dst_h;
+        const detail::DeviceScope bind(stream_.device());
         detail::check(kh_preprocess_to_chw(stream_.handle(), src_device, dst_device, &p));
     }
     const Stream& stream() const { return stream_; }
@@ -1031,6 +1071,7 @@ public:
     // f() enqueues the work on `stream` (preallocated outputs only); the capture is always ended, also when f throws
     template <typename F>
     static Graph capture(const Stream& stream, F&& f) {
+        const detail::DeviceScope bind(stream.device());   // the captured launches and the capture itself: the stream's device
         detail::check(kh_graph_capture_begin(stream.handle()));
         kh_graph_t g = nullptr;
         try {
@@ -1042,7 +1083,10 @@ public:
         detail::check(kh_graph_capture_end(stream.handle(), &g));
         return Graph(g, stream);
     }
-    void replay() const { detail::check(kh_graph_launch(g_.get(), stream_.handle())); }
+    void replay() const {
+        const detail::DeviceScope bind(stream_.device());
+        detail::check(kh_graph_launch(g_.get(), stream_.handle()));
+    }
 
 private:
     Graph(kh_graph_t g, const Stream& s) : g_(g, [](kh_graph_t p) { kh_graph_destroy(p); }), stream_(s) {}

@@ -155,10 +155,56 @@ static void on_device() {
     EXPECT(throws(K::InvalidImageSize, [&] { pre.run_raw(frame.device_ptr(), nv.size() - 1, w, h, chw.device_ptr_mut(), 12, 6); }));
 }
 
+// Device affinity: everything on DEVICE 1 from a thread whose current device stays 0 — the operators bind the launch
+// stream's device for the call (detail::DeviceExec) and restore the caller's.  Runs where two devices exist: the host simulator with
+// KH_HOSTSIM_DEVICES=2 (tests/test_zz_hostsim.py) or a multi-GPU node.
+static void on_second_device() {
+    int32_t n = 0;
+    if (kh_device_count(&n) != KH_OK || n < 2) { std::printf("second device: skipped (%d device(s))\n", (int)n); return; }
+    EXPECT(kh_set_device(0) == KH_OK);
+    Stream s1 = Stream::create(1), other1 = Stream::create(1);
+    auto current = [] { int32_t d = -1; kh_get_device(&d); return d; };
+    auto rgb = Image<uint8_t, 3>::from_size_vec({2, 1}, {0, 128, 255, 128, 0, 128}).to_hip(s1);
+    auto gray = Image<uint8_t, 1>::zeros_hip({2, 1}, other1);   // another stream of device 1: fenced in and back
+    int32_t dom = -1, dev = -1;
+    EXPECT(kh_pointer_domain(rgb.device_ptr(), &dom, &dev) == KH_OK && dom == KH_DOMAIN_DEVICE && dev == 1);
+    imgproc::gray_from_rgb(rgb, gray);
+    EXPECT(current() == 0);
+    auto g = gray.to_host();
+    EXPECT(g.as_slice()[0] == 104 && g.as_slice()[1] == 53);
+    // an operator with stream-ordered scratch and a cached table (Lanczos resize): both are filed under the CURRENT device
+    std::vector<float> ramp(64 * 48 * 3);
+    for (size_t i = 0; i < ramp.size(); ++i) ramp[i] = (float)((i * 7 + 13) % 251) / 255.0f;
+    auto src0 = Image<float, 3>::from_size_vec({64, 48}, ramp).to_hip(Stream::create(0));
+    auto src1 = Image<float, 3>::from_size_vec({64, 48}, ramp).to_hip(s1);
+    auto d0 = Image<float, 3>::zeros_hip({23, 17}, *src0.stream());
+    auto d1 = Image<float, 3>::zeros_hip({23, 17}, s1);
+    imgproc::resize(src0, d0, InterpolationMode::Lanczos);
+    imgproc::resize(src1, d1, InterpolationMode::Lanczos);
+    EXPECT(current() == 0);
+    auto h0 = d0.to_host(), h1 = d1.to_host();
+    EXPECT(std::memcmp(h0.as_slice().data(), h1.as_slice().data(), h0.as_slice().size() * sizeof(float)) == 0);
+    // operands on different devices are a typed error, never a peer access (P/cuda/dispatch.rs:51-53)
+    EXPECT(throws(K::DeviceMismatch, [&] { imgproc::resize(src0, d1, InterpolationMode::Bilinear); }));
+    EXPECT(current() == 0);
+    // the fused preprocess on device 1
+    const int w = 16, h = 8;
+    std::vector<uint8_t> nv(w * h * 3 / 2, 128);
+    std::memset(nv.data(), 235, w * h);
+    auto frame = Image<uint8_t, 1>::from_size_vec({(size_t)w * h * 3 / 2, 1}, nv).to_hip(s1);
+    auto chw = Image<float, 1>::zeros_hip({(size_t)3 * 12 * 6, 1}, s1);
+    Preprocessor pre(s1, ResizeMode::Stretch, SourceFormat::Nv12);
+    pre.run_raw(frame.device_ptr(), nv.size(), w, h, chw.device_ptr_mut(), 12, 6);
+    EXPECT(current() == 0);
+    auto t = chw.to_host();
+    for (float v : t.as_slice()) EXPECT(std::fabs(v - 1.0f) < 1e-6f);
+    std::printf("second device: checked\n");
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "host";
     host_only();
-    if (mode == "gpu") on_device();
+    if (mode == "gpu") { on_device(); on_second_device(); }
     std::printf("%s: %d failure(s) [%s]\n", mode.c_str(), failures, kh_version());
     return failures ? 1 : 0;
 }

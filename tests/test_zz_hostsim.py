@@ -32,7 +32,7 @@ def test_multi_device_host_layer_on_two_simulated_gpus(sim_env):
     stream of another device than the current one).  Runs the in-process sharders on devices [0, 1] / [1, 0, 1] and the device-1
     -from-a-device-0-thread tests; skipped tests would mean the second device was not seen."""
     cmd = [sys.executable, str(ROOT / "scripts" / "hostsim_run.py"), "tests/test_multi_device_gpu.py", "tests/test_sharding_gpu.py",
-           "tests/test_preprocess_gpu.py", "tests/test_host_api_gpu.py", "tests/test_unified_gpu.py", "-q", "-x", "-rs",
+           "tests/test_preprocess_gpu.py", "tests/test_host_api_gpu.py", "tests/test_unified_gpu.py", "tests/test_cpp_mirror.py", "-q", "-x", "-rs",
            "--deselect", "tests/test_host_api_gpu.py::test_torch_rocm_zero_copy_interop",
            "--deselect", "tests/test_unified_gpu.py::test_unified_torch_consumer"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(sim_env, KH_HOSTSIM_DEVICES="2"))
