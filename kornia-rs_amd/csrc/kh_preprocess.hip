@@ -499,8 +499,9 @@ __device__ __forceinline__ void quad_taps_nv12_bilinear(const uint8_t* __restric
 
 // (Round 5: picking the 48 bytes of a four-tap quad through a lane-private LDS slot — ds_read_u8 at run-time addresses instead of
 // 64-bit shifts and selects — takes 15 % of the kernel's vector instructions away, 682 M -> 577 M per launch, and not a microsecond:
-// 1.295 ms both ways (profiles/r05b_four_tap_lds_picks_ab.txt, r05c_*_counters.csv).  A wave64 VALU instruction issues in 2 cycles
-// on this part, so the kernel keeps its vector ALUs about 55 % busy; it is bound by the memory system.  Not kept.)
+// 1.295 ms both ways (profiles/r05b_four_tap_lds_picks_ab.txt, r05c_*_counters.csv).  Decoding one tap per pixel instead of four
+// (a diagnostic build: half of the arithmetic gone, every load and store kept) runs 1.21 ms: the row is bound by the memory system,
+// 6 % above its floor (profiles/r05j_four_tap_decode_ablation.txt).  Not kept.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kQuadBlock = 256;
 template <int FMT, int SAMPLER, bool WIDE>
