@@ -1637,11 +1637,23 @@ def main():
         dev = {"name": name, "cus": cus, "hbm_bytes": mem, "host_cpus": os.cpu_count(), "host_affinity_cpus": affinity,
                "hip_runtime": str(hip.runtime_info().get("choice"))[:80]}
         if world == 1 and not args.no_cpu_baseline:
-            # why `cores` can be below host_cpus: the OpenMP team of the CPU baseline is omp_get_max_threads(), which libgomp sizes from
-            # the process's affinity mask (the box's cgroup cpuset), not from the logical CPUs the kernel enumerates
-            dev["cpu_cores_note"] = (f"cpu_baseline.cores = omp_get_max_threads() of the oracle's OpenMP runtime = the {affinity} CPUs of this process's "
-                                     f"affinity mask (sched_getaffinity); os.cpu_count() = {os.cpu_count()} counts every logical CPU of the host, "
-                                     "including those outside the container's cpuset; cores = 1 where the reference's CPU path is single-threaded")
+            # `cores` = the threads the CPU baseline actually ran: omp_get_max_threads() of the OpenMP runtime the oracle shares with this
+            # process.  Measured on the pool's boxes (round 5): 2 x 64-core EPYC 9575F, 256 hardware threads, all 256 in the affinity mask;
+            # `import torch` sizes the process's OpenMP team to the PHYSICAL cores (128), and the container's cgroup grants a CPU-time
+            # quota far below either (cpu.max) — the baseline is what this container lets 128 threads do, and says so.
+            threads = line["cpu_baseline"]["cores"] if line.get("cpu_baseline") else None
+            quota = None
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                quota = None if q == "max" else round(int(q) / int(per), 2)
+            except (OSError, ValueError):
+                pass
+            dev["host_cpu_quota"] = quota
+            why = ("the affinity mask" if threads == affinity else
+                   f"torch's intra-op team = the physical cores (torch.get_num_threads() = {torch.get_num_threads()})" if threads == torch.get_num_threads()
+                   else "OMP_NUM_THREADS / the runtime's default")
+            dev["cpu_cores_note"] = (f"cpu_baseline.cores = omp_get_max_threads() = {threads}: {why}; affinity mask {affinity} CPUs, os.cpu_count() {os.cpu_count()}, "
+                                     f"cgroup cpu.max quota {quota if quota is not None else 'none'} CPUs; cores = 1 where the reference's CPU path is single-threaded")
         if ceilings:
             dev.update(ceilings)
             ms = line["roofline"]["mean_launch_ms"]

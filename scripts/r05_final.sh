@@ -22,6 +22,14 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/
 cd "$REPO"
 f=$(find "$OUT/prof_default" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/default_kernel_stats.csv" && head -30 "$f" | cut -c1-190
 rm -rf "$OUT/prof_default"
+echo "== rocprofv3 kernel trace of the HEADLINE alone (the default run also launches preprocess_nv12_identity on 64-frame batches in its"
+echo "   H2D row, which pulls that kernel's average in default_kernel_stats.csv down: this is the file to check roofline.mean_launch_ms against)"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/prof_headline" -o kt -- python "$REPO/bench.py" --no-cpu-baseline --also none > "$REPO/$OUT/prof_headline.log" 2>&1
+cd "$REPO"
+f=$(find "$OUT/prof_headline" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/headline_kernel_stats.csv" && head -5 "$f" | cut -c1-190
+grep '^{' "$OUT/prof_headline.log" | python scripts/bench_table.py | head -1
+rm -rf "$OUT/prof_headline"
 echo "== PMC passes (FETCH_SIZE, WRITE_SIZE) of the default run"
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
