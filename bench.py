@@ -1369,18 +1369,20 @@ def respawn_under_torchrun(args) -> int:
 class Runner:
     """Times workloads on this rank's device: K steps bracketed by barrier + sync, per-step HIP events on the launch stream."""
 
-    def __init__(self, hip, torch, dist, stream, rank, local_rank, world, on_gpu=True):
+    def __init__(self, hip, torch, dist, stream, rank, local_rank, world, on_gpu=True, use_dist=None, dist_on_gpu=None):
         self.hip, self.torch, self.dist, self.stream = hip, torch, dist, stream
         self.rank, self.local_rank, self.world = rank, local_rank, world
         self.on_gpu = on_gpu   # False only under the host simulator (tests/hostsim): gloo ranks, no torch device
+        self.use_dist = world > 1 if use_dist is None else use_dist          # a process group exists: barrier + max-over-ranks through it
+        self.dist_on_gpu = on_gpu if dist_on_gpu is None else dist_on_gpu    # RCCL (device tensors) or gloo (host tensors)
         self.traffic_source = None
 
     def barrier(self):
         self.stream.synchronize()
         if self.on_gpu:
             self.torch.cuda.synchronize()
-        if self.world > 1:
-            self.dist.barrier(device_ids=[self.local_rank]) if self.on_gpu else self.dist.barrier()
+        if self.use_dist:
+            self.dist.barrier(device_ids=[self.local_rank]) if self.dist_on_gpu else self.dist.barrier()
 
     def time(self, wl, steps, warmup, spinup_s=0.0):
         hip, stream = self.hip, self.stream
@@ -1407,11 +1409,11 @@ class Runner:
         if self.on_gpu:
             self.torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        if self.world > 1:
-            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda" if self.on_gpu else "cpu")
+        if self.use_dist:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda" if self.dist_on_gpu else "cpu")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            self.dist.barrier(device_ids=[self.local_rank]) if self.on_gpu else self.dist.barrier()
+            self.dist.barrier(device_ids=[self.local_rank]) if self.dist_on_gpu else self.dist.barrier()
         kernel_ms = [starts[k].elapsed_ms(stops[k]) for k in range(steps)]
         return elapsed, kernel_ms
 
@@ -1555,27 +1557,38 @@ def main():
     on_gpu = torch.cuda.is_available()
     if not on_gpu and not hostsim:
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    # KORNIA_BENCH_DIST_TEST (tests/test_dist_launcher_gpu.py — what a ONE-GPU box can check of the multi-process launcher):
+    #   "force": create the RCCL process group at world size 1 too, so that init / barrier(device_ids) / all_reduce(MAX) on a device
+    #            tensor / destroy run on real hardware;
+    #   "share": every rank uses GPU 0 and the group is gloo (RCCL refuses two ranks on one device): two bench processes launched by
+    #            torch.distributed.run drive real kernels at the same time, barrier and aggregate as on a node.
+    dist_test = os.environ.get("KORNIA_BENCH_DIST_TEST", "")
+    share_gpu = on_gpu and dist_test == "share"
+    use_dist = world > 1 or dist_test == "force"
+    dist_on_gpu = on_gpu and not share_gpu
+    gpu_ordinal = 0 if share_gpu else local_rank
     if on_gpu:
-        torch.cuda.set_device(local_rank)
-    if world > 1:
+        torch.cuda.set_device(gpu_ordinal)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if on_gpu:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if dist_on_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu_ordinal), rank=rank, world_size=world)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from kornia_rs import hip
     if not on_gpu:   # the simulator shows KH_HOSTSIM_DEVICES devices (default 1): rank r owns device r when it exists, as on a node
         local_dev = local_rank if local_rank < hip.device_count() else 0
     else:
-        local_dev = local_rank
+        local_dev = gpu_ordinal
     hip.set_device(local_dev)
     for opt in args.dev_option:
         from kornia_rs import _ffi
         name, _, value = opt.partition("=")
         _ffi.check(_ffi.lib.kh_debug_set_option(name.encode(), int(value)))
     stream = hip.Stream.new(local_dev)
-    run = Runner(hip, torch, dist, stream, rank, local_rank, world, on_gpu)
+    run = Runner(hip, torch, dist, stream, rank, gpu_ordinal, world, on_gpu, use_dist, dist_on_gpu)
 
     wl = make_workload(args.workload, args)
     wl.setup(stream)
@@ -1686,7 +1699,7 @@ def main():
             pass
         print(json.dumps(line, separators=(",", ":")), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     return 0
 
