@@ -1,0 +1,202 @@
+// Dev micro-benchmark (round 5, not shipped): the C4 gaussian takes the same time with its arithmetic and its LDS traffic removed
+// (profiles/r05l): what bounds it is the ACCESS PATTERN of the rolling kernels — a wave walks down a strip, reads and writes LW floats
+// per lane per row, K rows of loads in flight — which moves 51 GB at 0.63-0.72 of 8 TB/s where a flat 1R + 1W map of the same bytes
+// reaches 0.78.  This is that pattern as a pure copy (256 f32x3 4K images), one knob at a time.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int ROWLEN = 3840 * 3, ROWS = 2160;          // floats per row, rows
+constexpr long long IMG = (long long)ROWLEN * ROWS;    // floats per image
+
+struct P { const float* src; float* dst; int th, tiles_x, strips, images, order; };
+
+// block id -> (tile_x, strip, image).  order 0: x fastest, then strip, then image.  order 1: the same list dealt to the 8 XCDs in
+// contiguous eighths (block b runs on XCD b % 8: XCD k walks ids [k * total / 8, (k + 1) * total / 8)), as kh_common.h::xcd_tile does.
+// order 2: strip fastest, then x, then image (vertically adjacent strips launch together).  order 3: image fastest.
+__device__ __forceinline__ bool decode(const P& p, unsigned b, int& tx, int& ty, int& tz) {
+    const unsigned total = (unsigned)p.tiles_x * p.strips * p.images;
+    unsigned id = b;
+    if (p.order == 1) {
+        const unsigned per = (total + 7) / 8, xcd = b % 8, slot = b / 8;
+        if (slot >= per) return false;
+        id = xcd * per + slot;
+    }
+    if (id >= total) return false;
+    if (p.order == 2) { ty = id % p.strips; id /= p.strips; tx = id % p.tiles_x; tz = id / p.tiles_x; return true; }
+    if (p.order == 3) { tz = id % p.images; id /= p.images; tx = id % p.tiles_x; ty = id / p.tiles_x; return true; }
+    tx = id % p.tiles_x; id /= p.tiles_x; ty = id % p.strips; tz = id / p.strips;
+    return true;
+}
+
+// LW4: float4 per lane per row (1 or 2); K rows of loads in flight; WAVES per block; ST 1 = write-through nt buffer stores, 0 = plain
+template <int LW4, int K, int WAVES, int ST>
+__global__ __launch_bounds__(64 * WAVES) void strip_copy(P p) {
+    extern __shared__ float pad_[];
+    if (p.th < 0) pad_[threadIdx.x] = 1.0f;
+    int tx, ty, tz;
+    if (!decode(p, blockIdx.x, tx, ty, tz)) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gx = (tx * WAVES + wv) * (256 * LW4) + 4 * LW4 * lane;
+    if (gx >= ROWLEN) return;
+    const int y0 = ty * p.th, nrows = min(p.th, ROWS - y0);
+    const float* src = p.src + (long long)tz * IMG + gx;
+    float* dst = p.dst + (long long)tz * IMG + gx;
+    f32x4 q[K][LW4];
+    int pf = y0;
+    auto prefetch = [&](f32x4 (&d)[LW4]) {
+        const int r = min(pf, ROWS - 1);
+#pragma unroll
+        for (int j = 0; j < LW4; ++j) d[j] = *reinterpret_cast<const f32x4*>(src + (long long)r * ROWLEN + 4 * j);
+        ++pf;
+    };
+#pragma unroll
+    for (int i = 0; i < K; ++i) prefetch(q[i]);
+    // wave-uniform window over this strip's rows of the image (a per-lane base would be a 64-trip waterfall loop)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)tz * IMG + (long long)y0 * ROWLEN, 0, (int)min((long long)nrows * ROWLEN * 4, 0x7fffffffll), 0x00020000);
+    int off = gx * 4;
+    for (int rb = 0; rb < nrows; rb += K) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            if (rb + i < nrows) {
+                f32x4 v[LW4];
+#pragma unroll
+                for (int j = 0; j < LW4; ++j) v[j] = q[i][j];
+                prefetch(q[i]);
+#pragma unroll
+                for (int j = 0; j < LW4; ++j) {
+                    if (ST) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs, off + 16 * j, 0, 19);
+                    else *reinterpret_cast<f32x4*>(dst + (long long)(y0 + rb + i) * ROWLEN + 4 * j) = v[j];
+                }
+            }
+            off += ROWLEN * 4;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void flat_copy(const float* __restrict__ src, float* __restrict__ dst, long long n4) {
+    const long long i = (long long)blockIdx.y * gridDim.x * 256 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    const long long base = i & ~((1ll << 26) - 1);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst + 4 * base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(16 * (i - base)), 0, 19);
+}
+
+// flat copies with S chunks of 1 KiB per WAVE.  MODE 0: chunk ids w + k * G (grid-stride); 1: S adjacent chunks per wave; 2: ONE chunk
+// per wave at a permuted position (short-lived waves, scattered 1 KiB accesses).  PIPE 1: all S loads first, then S stores; 0: one at a time.
+template <int S, int MODE, int PIPE>
+__global__ __launch_bounds__(256) void flat_multi(const float* __restrict__ src, float* __restrict__ dst, long long nchunks, int group = 1) {
+    const long long w = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);   // wave id
+    const int lane = threadIdx.x & 63;
+    const long long G = (nchunks + S - 1) / S;   // waves in the grid (rounded)
+    if (w >= G) return;
+    long long id[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        if (MODE == 0) id[k] = w + k * G;
+        else if (MODE == 1) id[k] = w * S + k;
+        else if (MODE == 3) id[k] = (w / group) * ((long long)group * S) + (long long)k * group + (w % group);   // `group` consecutive waves stream one contiguous region together
+        else { const long long h = (w * 2654435761ll) % nchunks; id[k] = h < 0 ? h + nchunks : h; }   // odd multiplier: a permutation when nchunks is a power of two; close enough otherwise (a few chunks written twice)
+        if (id[k] >= nchunks) id[k] = nchunks - 1;
+    }
+    f32x4 v[S];
+    if (PIPE) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) v[k] = reinterpret_cast<const f32x4*>(src)[id[k] * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const long long e = id[k] * 64 + lane, base = e & ~((1ll << 26) - 1);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst + 4 * base, 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[k]), rs, (int)(16 * (e - base)), 0, 19);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const long long e = id[k] * 64 + lane;
+            const f32x4 t = reinterpret_cast<const f32x4*>(src)[e];
+            reinterpret_cast<f32x4*>(dst)[e] = t;
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+        }
+    }
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 256, ROUNDS = argc > 2 ? atoi(argv[2]) : 5;
+    const char* only = argc > 3 ? argv[3] : "";
+    float *src, *dst;
+    CK(hipMalloc(&src, IMG * N * 4)); CK(hipMalloc(&dst, IMG * N * 4));
+    CK(hipMemset(src, 0x3c, IMG * N * 4));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    struct V { std::string name; std::function<void()> run; std::vector<float> ms; };
+    std::vector<V> vs;
+    const long long n4 = IMG * N / 4;
+    vs.push_back({"flat copy 16 B / lane (the 0.78 row)", [&] { hipLaunchKernelGGL(flat_copy, dim3(65536, (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), 0, st, src, dst, n4); }, {}});
+    const long long nchunks = n4 / 64;
+#define FM(S, MODE, PIPE, NAME) vs.push_back({NAME, [&] { const long long G = (nchunks + S - 1) / S, blocks = (G + 3) / 4; hipLaunchKernelGGL((flat_multi<S, MODE, PIPE>), dim3(65536, (unsigned)((blocks + 65535) / 65536)), dim3(256), 0, st, src, dst, nchunks); }, {}});
+    FM(1, 0, 1, "flat 1 chunk per wave (in order)")
+    FM(1, 2, 1, "flat 1 chunk per wave, permuted positions (scattered 1 KiB)")
+    FM(2, 0, 1, "flat 2 chunks per wave, grid-stride, loads first")
+    FM(2, 1, 1, "flat 2 chunks per wave, adjacent, loads first")
+    FM(4, 0, 1, "flat 4 chunks per wave, grid-stride, loads first")
+    FM(8, 0, 1, "flat 8 chunks per wave, grid-stride, loads first")
+    FM(8, 1, 1, "flat 8 chunks per wave, adjacent, loads first")
+    FM(8, 0, 0, "flat 8 chunks per wave, grid-stride, one at a time")
+    FM(8, 1, 0, "flat 8 chunks per wave, adjacent, one at a time")
+    FM(32, 0, 1, "flat 32 chunks per wave, grid-stride, loads first")
+    for (int g : {4, 16, 45, 128, 512, 2048, 8192, 32768}) {
+        vs.push_back({"flat 8 chunks per wave, groups of " + std::to_string(g) + " waves stream together (" + std::to_string(g) + " KiB per step)",
+                      [&, g] { const long long G = (nchunks + 7) / 8, blocks = (G + 3) / 4; hipLaunchKernelGGL((flat_multi<8, 3, 1>), dim3(65536, (unsigned)((blocks + 65535) / 65536)), dim3(256), 0, st, src, dst, nchunks, g); }, {}});
+    }
+    auto add = [&](const std::string& name, auto kernel, int lw4, int waves, int th, int order, int lds) {
+        P p{src, dst, th, (ROWLEN + 256 * lw4 * waves - 1) / (256 * lw4 * waves), (ROWS + th - 1) / th, N, order};
+        unsigned total = (unsigned)p.tiles_x * p.strips * p.images;
+        if (order == 1) total = (total + 7) / 8 * 8;
+        vs.push_back({name, [=] { hipLaunchKernelGGL(kernel, dim3(total), dim3(64 * waves), lds, st, p); }, {}});
+    };
+    add("strip LW4 K7 4w th360 xcd-eighth (= production shape)", strip_copy<1, 7, 4, 1>, 1, 4, 360, 1, 0);
+    add("strip LW4 K7 4w th360 linear order", strip_copy<1, 7, 4, 1>, 1, 4, 360, 0, 0);
+    add("strip LW4 K7 4w th360 strip-fastest order", strip_copy<1, 7, 4, 1>, 1, 4, 360, 2, 0);
+    add("strip LW4 K7 4w th360 image-fastest order", strip_copy<1, 7, 4, 1>, 1, 4, 360, 3, 0);
+    add("strip LW4 K7 4w th2160 xcd-eighth", strip_copy<1, 7, 4, 1>, 1, 4, 2160, 1, 0);
+    add("strip LW4 K7 4w th90 xcd-eighth", strip_copy<1, 7, 4, 1>, 1, 4, 90, 1, 0);
+    add("strip LW4 K7 4w th360 xcd-eighth plain stores", strip_copy<1, 7, 4, 0>, 1, 4, 360, 1, 0);
+    add("strip LW4 K3 4w th360 xcd-eighth", strip_copy<1, 3, 4, 1>, 1, 4, 360, 1, 0);
+    add("strip LW4 K2 4w th360 xcd-eighth", strip_copy<1, 2, 4, 1>, 1, 4, 360, 1, 0);
+    add("strip LW4 K1 4w th360 xcd-eighth", strip_copy<1, 1, 4, 1>, 1, 4, 360, 1, 0);
+    add("strip LW4 K4 4w th360 xcd-eighth", strip_copy<1, 4, 4, 1>, 1, 4, 360, 1, 0);
+    add("strip LW4 K7 1w th360 xcd-eighth", strip_copy<1, 7, 1, 1>, 1, 1, 360, 1, 0);
+    add("strip LW4 K7 8w th360 xcd-eighth", strip_copy<1, 7, 8, 1>, 1, 8, 360, 1, 0);
+    add("strip LW4 K7 12w th360 xcd-eighth (whole row per block)", strip_copy<1, 7, 12, 1>, 1, 12, 360, 1, 0);
+    add("strip LW8 K7 4w th360 xcd-eighth", strip_copy<2, 7, 4, 1>, 2, 4, 360, 1, 0);
+    add("strip LW8 K4 4w th360 xcd-eighth", strip_copy<2, 4, 4, 1>, 2, 4, 360, 1, 0);
+    add("strip LW8 K4 6w th360 xcd-eighth (whole row per block)", strip_copy<2, 4, 6, 1>, 2, 6, 360, 1, 0);
+    add("strip LW4 K7 4w th360 xcd-eighth occupancy 4 blocks/CU", strip_copy<1, 7, 4, 1>, 1, 4, 360, 1, 40 * 1024);
+    add("strip LW4 K7 4w th360 xcd-eighth occupancy 2 blocks/CU", strip_copy<1, 7, 4, 1>, 1, 4, 360, 1, 64 * 1024);
+    add("strip LW4 K7 4w th360 xcd-eighth occupancy 1 block/CU", strip_copy<1, 7, 4, 1>, 1, 4, 360, 1, 100 * 1024);
+    if (*only) vs.erase(std::remove_if(vs.begin(), vs.end(), [&](const V& v) { return !strstr(v.name.c_str(), only) && v.name.rfind("flat copy", 0) != 0; }), vs.end());
+    for (int r = 0; r < ROUNDS + 1; ++r)
+        for (auto& v : vs) {
+            CK(hipEventRecord(e0, st)); v.run(); CK(hipGetLastError()); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) v.ms.push_back(ms);
+        }
+    const double bytes = 2.0 * IMG * N * 4;
+    printf("# %d f32x3 4K images, copy (R + W = %.2f GB), %d rounds interleaved; frac = GB/s / 8000\n", N, bytes / 1e9, ROUNDS);
+    printf("%-66s %9s %9s %9s %6s\n", "variant", "med ms", "min ms", "GB/s@med", "frac");
+    for (auto& v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        const float med = v.ms[v.ms.size() / 2];
+        printf("%-66s %9.3f %9.3f %9.0f %6.3f\n", v.name.c_str(), med, v.ms[0], bytes / med / 1e6, bytes / med / 1e6 / 8000);
+    }
+    return 0;
+}
