@@ -129,6 +129,46 @@ __global__ __launch_bounds__(256) void flat_multi(const float* __restrict__ src,
     }
 }
 
+// the strip walk with its stores held back: SB output rows are kept in registers and written back to back (the 45 waves of a strip row then
+// write SB rows = SB x 45 KiB of consecutive addresses together instead of one row per step)
+template <int K, int SB>
+__global__ __launch_bounds__(256) void strip_copy_sb(P p) {
+    int tx, ty, tz;
+    if (!decode(p, blockIdx.x, tx, ty, tz)) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gx = (tx * 4 + wv) * 256 + 4 * lane;
+    if (gx >= ROWLEN) return;
+    const int y0 = ty * p.th, nrows = min(p.th, ROWS - y0);
+    const float* src = p.src + (long long)tz * IMG + gx;
+    f32x4 q[K];
+    int pf = y0;
+    auto prefetch = [&](f32x4& d) { d = *reinterpret_cast<const f32x4*>(src + (long long)min(pf, ROWS - 1) * ROWLEN); ++pf; };
+#pragma unroll
+    for (int i = 0; i < K; ++i) prefetch(q[i]);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)tz * IMG + (long long)y0 * ROWLEN, 0, (int)min((long long)nrows * ROWLEN * 4, 0x7fffffffll), 0x00020000);
+    int off = gx * 4;
+    static_assert((K * SB) % K == 0, "");
+    for (int rb = 0; rb < nrows; rb += K * SB) {
+#pragma unroll
+        for (int g = 0; g < K; ++g) {          // K groups of SB rows per trip (so the prefetch ring index stays a compile-time constant)
+            f32x4 hold[SB];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                constexpr int dummy = 0; (void)dummy;
+                const int i = (g * SB + j) % K;
+                hold[j] = q[i];
+                prefetch(q[i]);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                if (rb + g * SB + j < nrows) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hold[j]), rs, off, 0, 19);
+                off += ROWLEN * 4;
+            }
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 256, ROUNDS = argc > 2 ? atoi(argv[2]) : 5;
     const char* only = argc > 3 ? argv[3] : "";
@@ -183,6 +223,10 @@ int main(int argc, char** argv) {
     add("strip LW4 K7 4w th360 xcd-eighth occupancy 4 blocks/CU", strip_copy<1, 7, 4, 1>, 1, 4, 360, 1, 40 * 1024);
     add("strip LW4 K7 4w th360 xcd-eighth occupancy 2 blocks/CU", strip_copy<1, 7, 4, 1>, 1, 4, 360, 1, 64 * 1024);
     add("strip LW4 K7 4w th360 xcd-eighth occupancy 1 block/CU", strip_copy<1, 7, 4, 1>, 1, 4, 360, 1, 100 * 1024);
+#define SBV(K, SB, NAME) { P p{src, dst, 360, (ROWLEN + 1023) / 1024, (ROWS + 359) / 360, N, 1}; unsigned total = ((unsigned)p.tiles_x * p.strips * p.images + 7) / 8 * 8; \
+        vs.push_back({NAME, [=] { hipLaunchKernelGGL((strip_copy_sb<K, SB>), dim3(total), dim3(256), 0, st, p); }, {}}); }
+    SBV(7, 1, "stores held: K7 SB1 (control)") SBV(7, 2, "stores held: K7 SB2") SBV(7, 3, "stores held: K7 SB3") SBV(7, 4, "stores held: K7 SB4") SBV(7, 8, "stores held: K7 SB8")
+    SBV(4, 4, "stores held: K4 SB4") SBV(8, 8, "stores held: K8 SB8") SBV(2, 16, "stores held: K2 SB16")
     if (*only) vs.erase(std::remove_if(vs.begin(), vs.end(), [&](const V& v) { return !strstr(v.name.c_str(), only) && v.name.rfind("flat copy", 0) != 0; }), vs.end());
     for (int r = 0; r < ROUNDS + 1; ++r)
         for (auto& v : vs) {
