@@ -169,6 +169,36 @@ __global__ __launch_bounds__(256) void strip_copy_sb(P p) {
     }
 }
 
+// the strip walk with ROW PHASES: a block is 4 column groups x RP waves; wave (c, j) copies rows y0 + RP t + j of column group c, so that the
+// waves of a strip move RP consecutive image rows (RP x 45 KiB of consecutive addresses) per step instead of one (best case of a filter whose
+// waves would share their horizontal results through LDS: no LDS and no synchronisation here)
+template <int K, int RP>
+__global__ __launch_bounds__(64 * 4 * RP) void strip_copy_rp(P p) {
+    int tx, ty, tz;
+    if (!decode(p, blockIdx.x, tx, ty, tz)) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = wv % 4, j = wv / 4;
+    const int gx = (tx * 4 + c) * 256 + 4 * lane;
+    if (gx >= ROWLEN) return;
+    const int y0 = ty * p.th, nrows = min(p.th, ROWS - y0);
+    const float* src = p.src + (long long)tz * IMG + gx;
+    f32x4 q[K];
+    int pf = y0 + j;
+    auto prefetch = [&](f32x4& d) { d = *reinterpret_cast<const f32x4*>(src + (long long)min(pf, ROWS - 1) * ROWLEN); pf += RP; };
+#pragma unroll
+    for (int i = 0; i < K; ++i) prefetch(q[i]);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)tz * IMG + (long long)y0 * ROWLEN, 0, (int)min((long long)nrows * ROWLEN * 4, 0x7fffffffll), 0x00020000);
+    int off = gx * 4 + j * ROWLEN * 4;
+    for (int rb = j; rb < nrows; rb += K * RP) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const f32x4 v = q[i];
+            prefetch(q[i]);
+            if (rb + i * RP < nrows) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 19);
+            off += RP * ROWLEN * 4;
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 256, ROUNDS = argc > 2 ? atoi(argv[2]) : 5;
     const char* only = argc > 3 ? argv[3] : "";
@@ -227,6 +257,10 @@ int main(int argc, char** argv) {
         vs.push_back({NAME, [=] { hipLaunchKernelGGL((strip_copy_sb<K, SB>), dim3(total), dim3(256), 0, st, p); }, {}}); }
     SBV(7, 1, "stores held: K7 SB1 (control)") SBV(7, 2, "stores held: K7 SB2") SBV(7, 3, "stores held: K7 SB3") SBV(7, 4, "stores held: K7 SB4") SBV(7, 8, "stores held: K7 SB8")
     SBV(4, 4, "stores held: K4 SB4") SBV(8, 8, "stores held: K8 SB8") SBV(2, 16, "stores held: K2 SB16")
+#define RPV(K, RP, NAME) { P p{src, dst, 360, (ROWLEN + 1023) / 1024, (ROWS + 359) / 360, N, 1}; unsigned total = ((unsigned)p.tiles_x * p.strips * p.images + 7) / 8 * 8; \
+        vs.push_back({NAME, [=] { hipLaunchKernelGGL((strip_copy_rp<K, RP>), dim3(total), dim3(64 * 4 * RP), 0, st, p); }, {}}); }
+    RPV(7, 1, "row phases: K7 RP1 (control, 256 thr)") RPV(7, 2, "row phases: K7 RP2 (512 thr)") RPV(7, 3, "row phases: K7 RP3 (768 thr)") RPV(7, 4, "row phases: K7 RP4 (1024 thr)")
+    RPV(4, 3, "row phases: K4 RP3") RPV(3, 4, "row phases: K3 RP4") RPV(2, 4, "row phases: K2 RP4")
     if (*only) vs.erase(std::remove_if(vs.begin(), vs.end(), [&](const V& v) { return !strstr(v.name.c_str(), only) && v.name.rfind("flat copy", 0) != 0; }), vs.end());
     for (int r = 0; r < ROUNDS + 1; ++r)
         for (auto& v : vs) {
