@@ -128,6 +128,55 @@ __global__ __launch_bounds__(BLOCK) void k_ackwait(const uint8_t* __restrict__ s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- tri: the store shape of profiles/r05q — a wave's three stores a third of the batch apart.  Thread = quad g; it writes plane R of frame
+// t, plane G of frame (t + T) % N and plane B of frame (t + 2 T) % N (T = N / 3), decoding ONE channel of each of the three frames' quads:
+// every plane of every frame is written exactly once, bit-identical; three times the source loads.
+template <int CH>
+__device__ __forceinline__ f32x4 decode1(uint32_t y4, uint32_t uv4, const Args& a) {
+    int t[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = (int)((uv4 >> (16 * k)) & 0xFFu) - 128, v = (int)((uv4 >> (16 * k + 8)) & 0xFFu) - 128;
+        t[k] = CH == 0 ? kCVR * v + kHalf20 : CH == 1 ? kCUG * u + kCVG * v + kHalf20 : kCUB * u + kHalf20;
+    }
+    const float m = CH == 0 ? a.m0 : CH == 1 ? a.m1 : a.m2, is = CH == 0 ? a.is0 : CH == 1 ? a.is1 : a.is2;
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int yy = max((int)((y4 >> (8 * j)) & 0xFFu) - 16, 0) * kCY;
+        o[j] = norm1(clamp255((yy + t[j >> 1]) >> 20), m, is);
+    }
+    return o;
+}
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_tri(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a, int nframes, int third) {
+    const int wq = a.w >> 2, groups = wq * a.h, plane = a.w * a.h;
+    const int g0 = blockIdx.x * BLOCK + threadIdx.x, g = min(g0, groups - 1);
+    const int r = g / wq, xq = g - r * wq;
+    const int off = g0 < groups ? 16 * g : kDrop - 8 * plane;
+    int f[3];
+    f[0] = blockIdx.y;
+    f[1] = f[0] + third; f[1] -= f[1] >= nframes ? nframes : 0;
+    f[2] = f[1] + third; f[2] -= f[2] >= nframes ? nframes : 0;
+    uint32_t y4[3], uv4[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sb + (long long)f[c] * a.sfs), 0, plane + plane / 2, 0x00020000);
+        y4[c] = __builtin_amdgcn_raw_buffer_load_b32(rl, r * a.w + 4 * xq, 0, 0);
+        uv4[c] = __builtin_amdgcn_raw_buffer_load_b32(rl, plane + (r >> 1) * a.w + 4 * xq, 0, 0);
+    }
+    f32x4 o[3];
+    o[0] = decode1<0>(y4[0], uv4[0], a);
+    o[1] = decode1<1>(y4[1], uv4[1], a);
+    o[2] = decode1<2>(y4[2], uv4[2], a);
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(db + (long long)f[c] * a.dfs, 0, 12 * plane, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[c]), rs, off + c * (4 * plane), 0, AUX);
+    }
+}
+
 // ---- lds<Q>: one store per wave, decode by the first Q threads, hand-over through LDS
 template <int Q, int MODE>  // MODE 0: decode by threads 0..Q-1;  1: every thread loads, thread (c, i) decodes channel c only (no LDS)
 __global__ __launch_bounds__(3 * Q) void k_split(const uint8_t* __restrict__ sb, float* __restrict__ db, Args a) {
@@ -276,6 +325,11 @@ int main(int argc, char** argv) {
     GATE(512, 1, 0, "gate b512 L1 issue-only") GATE(512, 2, 0, "gate b512 L2 issue-only") GATE(512, 4, 0, "gate b512 L4 issue-only")
     GATE(256, 1, 1, "gate b256 L1 ack") GATE(256, 2, 1, "gate b256 L2 ack") GATE(256, 1, 0, "gate b256 L1 issue-only") GATE(256, 2, 0, "gate b256 L2 issue-only")
     GATE(1024, 2, 1, "gate b1024 L2 ack") GATE(1024, 4, 1, "gate b1024 L4 ack") GATE(1024, 8, 1, "gate b1024 L8 ack")
+    for (int third : {N / 3, N / 2, 1, 8, 64}) {
+        vs.push_back({"tri b512: R of frame t, G of t + " + std::to_string(third) + ", B of t + " + std::to_string(2 * third) + " (3x loads)", full, true,
+                      [&, third] { hipLaunchKernelGGL((k_tri<512>), G(512), dim3(512), 0, st, src, dst, a, N, third); }, {}, 0});
+    }
+    vs.push_back({"tri b256: thirds of the batch", full, true, [&] { hipLaunchKernelGGL((k_tri<256>), G(256), dim3(256), 0, st, src, dst, a, N, N / 3); }, {}, 0});
     vs.push_back({"ackwait b512 (production + vmcnt(0) before the end)", full, true, [&] { hipLaunchKernelGGL((k_ackwait<512>), G(512), dim3(512), 0, st, src, dst, a); }, {}, 0});
     vs.push_back({"F0 fill flat [sc0 sc1 nt]", wonly, false, [&] { hipLaunchKernelGGL(f_flat, dim3(65536, (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256))), dim3(256), 0, st, dst, n4); }, {}, 0});
     vs.push_back({"F1 W-only 3 planes/thread b512 [sc0 sc1 nt]", wonly, false, [&] { hipLaunchKernelGGL((f_3plane<512>), G(512), dim3(512), 0, st, dst, a); }, {}, 0});
