@@ -86,6 +86,9 @@ __global__ __launch_bounds__(kBlock) void map_f32(const float* __restrict__ src,
     stream_store<COUT>(stream_window(dst + p0 * COUT, (npx - p0) * COUT * 4), (int)threadIdx.x * COUT * 4, w);
 }
 
+// (Round 5: a gray kernel whose lanes own FOUR pixels — three 16-byte loads 48 bytes apart per lane, one 16-byte store — measured 5.69 ms against
+// 5.57 for the pixel-per-lane form above on 1024 1080p frames, three interleaved rounds: the strided loads cost more than the 1 KiB store
+// segments return (profiles/r05t_gray_f32_quads_ab.txt).  normalize_mean_std, whose lanes can own four FLOATS, gained 3 % from that width.)
 int32_t check_map(const void* src, const void* dst, int64_t npx, const char* what) {
     KH_REQUIRE(npx >= 0, KH_ERR_INVALID_ARG, "%s: negative pixel count", what);
     if (npx == 0) return KH_OK;

@@ -30,6 +30,27 @@ __global__ __launch_bounds__(kBlock) void normalize_mean_std_kernel(const float*
     stream_store<C>(stream_window(dst + p0 * C, (npx - p0) * C * 4), (int)threadIdx.x * C * 4, w);
 }
 
+// Three-channel images whose float count is a multiple of four and whose buffers are 16-byte aligned: a lane owns FOUR consecutive
+// floats (16 B in, 16 B out: a wave moves 1 KiB per instruction, the access width of the part's best copy, against 768 B for the
+// pixel-per-lane form above).  Element e has channel e % 3; quad q = 256 b + t starts at element 4 q === q (mod 3), and 256 === 1, so the
+// first channel of a lane's quad is (b % 3 + t % 3) % 3 — no 64-bit remainder per element (what made round 3's flat kernel slow).
+// Same expression per element: bit-identical.
+typedef float f32x4_pw __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kBlock) void normalize_mean_std_quads3_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                            long long nquads, Vec4 mean, Vec4 stdv) {
+    const long long q0 = (long long)blockIdx.x * kBlock, q = q0 + threadIdx.x;
+    if (q >= nquads) return;
+    const f32x4_pw in = reinterpret_cast<const f32x4_pw*>(src)[q];
+    const unsigned c0 = ((unsigned)blockIdx.x % 3u + (unsigned)threadIdx.x % 3u) % 3u;
+    // channels of the four elements: c0, c0 + 1, c0 + 2, c0 (mod 3)
+    const float m0 = c0 == 0 ? mean.v[0] : c0 == 1 ? mean.v[1] : mean.v[2], s0 = c0 == 0 ? stdv.v[0] : c0 == 1 ? stdv.v[1] : stdv.v[2];
+    const float m1 = c0 == 0 ? mean.v[1] : c0 == 1 ? mean.v[2] : mean.v[0], s1 = c0 == 0 ? stdv.v[1] : c0 == 1 ? stdv.v[2] : stdv.v[0];
+    const float m2 = c0 == 0 ? mean.v[2] : c0 == 1 ? mean.v[0] : mean.v[1], s2 = c0 == 0 ? stdv.v[2] : c0 == 1 ? stdv.v[0] : stdv.v[1];
+    const uint32_t w[4] = {__float_as_uint((in.x - m0) / s0), __float_as_uint((in.y - m1) / s1), __float_as_uint((in.z - m2) / s2),
+                           __float_as_uint((in.w - m0) / s0)};   // true division (normalize.rs:78)
+    stream_store<4>(stream_window(dst + q0 * 4, (nquads - q0) * 16), (int)threadIdx.x * 16, w);
+}
+
 __global__ __launch_bounds__(kBlock) void normalize_rgb_u8_kernel(const uint8_t* __restrict__ src,
                                                                    float* __restrict__ dst, long long npx,
                                                                    Vec4 scale, Vec4 offset) {
@@ -134,6 +155,11 @@ int32_t kh_normalize_mean_std_f32(kh_stream_t stream, const float* src, float* d
     for (int c = 0; c < channels; ++c) { m.v[c] = mean[c]; s.v[c] = stdv[c]; }
     const dim3 g(cdiv(npixels, kBlock)), b(kBlock);
     hipStream_t st = as_hip(stream);
+    if (channels == 3 && (npixels * 3) % 4 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0) {
+        const long long nquads = (long long)npixels * 3 / 4;
+        hipLaunchKernelGGL(normalize_mean_std_quads3_kernel, dim3(cdiv(nquads, kBlock)), b, 0, st, src, dst, nquads, m, s);
+        return check_launch("kh_normalize_mean_std_f32");
+    }
     switch (channels) {
         case 1: hipLaunchKernelGGL(normalize_mean_std_kernel<1>, g, b, 0, st, src, dst, (long long)npixels, m, s); break;
         case 2: hipLaunchKernelGGL(normalize_mean_std_kernel<2>, g, b, 0, st, src, dst, (long long)npixels, m, s); break;

@@ -31,7 +31,7 @@ KERNELS = {
     "sobel_3x3_4k_f32_b128": ["sep_roll_kernel<3, true"],
     "undistort_remap_then_warp_perspective_4k_f32_b256": ["remap_kernel<", "warp_perspective_kernel<"],
     "warp_affine_f32_1080p_b256": ["warp_affine_kernel<"],
-    "normalize_mean_std_1080p_f32_b512": ["normalize_mean_std_kernel<3"],
+    "normalize_mean_std_1080p_f32_b512": ["normalize_mean_std_quads3_kernel", "normalize_mean_std_kernel<3"],
     "gray_from_rgb_f32_1080p_b1024": ["GrayFromRgbF32"],
     "hsv_from_rgb_f32_1080p_b512": ["HsvFromRgbF32"],
     "ycc_from_rgb_u8_1080p_b1024": ["YccFromRgbU8"],

@@ -19,7 +19,7 @@ def lib_s(gpu_stream):
 
 
 @pytest.mark.parametrize("c", [1, 3, 4])
-@pytest.mark.parametrize("n", [258 * 195, 5, 0])
+@pytest.mark.parametrize("n", [258 * 195, 260 * 196, 1920 * 1080, 1028, 5, 4, 0])   # 3 n % 4 == 0: the four-floats-per-lane kernel (round 5)
 def test_normalize_mean_std(gpu_stream, c, n):
     _ffi, lib, s = lib_s(gpu_stream)
     src = O.pattern_f32(n * c)
@@ -29,6 +29,19 @@ def test_normalize_mean_std(gpu_stream, c, n):
     _ffi.check(lib.kh_normalize_mean_std_f32(s, d_src.ptr, d_dst.ptr, n, c, fptr(mean), fptr(std)))
     want = ((src.reshape(-1, c) - mean) / std).astype(f32).reshape(-1)
     assert_same_bits(d_dst.to_numpy(f32, (n * c,)), want, "normalize_mean_std")
+
+
+def test_normalize_mean_std_unaligned_buffers_take_the_per_pixel_kernel(gpu_stream):
+    """A source or destination that is not 16-byte aligned cannot use the four-floats-per-lane kernel: same values either way."""
+    _ffi, lib, s = lib_s(gpu_stream)
+    n, c = 260 * 196, 3
+    src = O.pattern_f32(n * c + 8)
+    mean, std = np.array([0.485, 0.456, 0.406], f32), np.array([0.229, 0.224, 0.225], f32)
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, src.nbytes)
+    for so, do in ((4, 0), (0, 4), (4, 4), (8, 12)):
+        _ffi.check(lib.kh_normalize_mean_std_f32(s, d_src.ptr + so, d_dst.ptr + do, n, c, fptr(mean), fptr(std)))
+        want = ((src[so // 4: so // 4 + n * c].reshape(-1, c) - mean) / std).astype(f32).reshape(-1)
+        assert_same_bits(d_dst.to_numpy(f32, (n * c + 8,))[do // 4: do // 4 + n * c], want, f"offsets {so} / {do}")
 
 
 def test_normalize_mean_std_reference_example(gpu_stream):  # normalize.rs doc example / tests
