@@ -88,7 +88,9 @@ __global__ __launch_bounds__(kBlock) void map_f32(const float* __restrict__ src,
 
 // (Round 5: a gray kernel whose lanes own FOUR pixels — three 16-byte loads 48 bytes apart per lane, one 16-byte store — measured 5.69 ms against
 // 5.57 for the pixel-per-lane form above on 1024 1080p frames, three interleaved rounds: the strided loads cost more than the 1 KiB store
-// segments return (profiles/r05t_gray_f32_quads_ab.txt).  normalize_mean_std, whose lanes can own four FLOATS, gained 3 % from that width.)
+// segments return (profiles/r05t_gray_f32_quads_ab.txt).  normalize_mean_std, whose lanes can own four FLOATS, gained 3 % from that width.
+// A second form — every global access 16 bytes and lane-contiguous, the pixels re-assembled through a wave-private LDS slot, for 3 -> 1
+// and 3 -> 3 channel maps — also lost: gray 5.73 vs 5.57 ms, YCbCr 4.48 vs 4.15, HSV 4.32 vs 4.31 (profiles/r05u_f32_maps_lds_transpose_ab.txt).)
 int32_t check_map(const void* src, const void* dst, int64_t npx, const char* what) {
     KH_REQUIRE(npx >= 0, KH_ERR_INVALID_ARG, "%s: negative pixel count", what);
     if (npx == 0) return KH_OK;
