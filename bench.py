@@ -183,6 +183,46 @@ class NorthStarNV12(Workload):
                           f"chained rgb_from_{self.fmt} -> {self.sampling}/normalize/CHW, OpenMP x{threads}"}
 
 
+class NorthStarNV12List(NorthStarNV12):
+    """The north star through the reference's OWN batch signature — `run_raw_batch(frames: &[&CudaSlice<u8>], ..)`
+    (P/preprocess.rs:1258-1282): 1024 SEPARATELY ALLOCATED 1080p NV12 frame buffers (unequal spacing), one [1024, 3, 1080, 1920]
+    destination.  The reference launches once per frame; here the frame bases travel in the kernel arguments, 256 per launch
+    (kh_preprocess_to_chw_list).  Must sit within 2 % of the equally spaced headline."""
+
+    def __init__(self, batch: int = 1024):
+        super().__init__(batch, 0)
+        self.cpu_twin = "nv12_chw"
+        self.name = f"nv12_1080p_to_chw_f32_frame_list_b{batch}"
+        self.kernel = "preprocess_nv12_identity_list"
+
+    def setup(self, stream):
+        from kornia_rs import Preprocessor, Tensor
+        from kornia_rs.hip import DeviceBuffer, lib, check
+        self.stream = stream
+        self.base = lcg_bytes(self.frame_bytes + 31 * self.N)
+        dbase = DeviceBuffer.from_numpy(self.base, stream)
+        self.frames = []
+        for k in range(self.N):   # every frame its own allocation, padded by a varying amount: the bases are not equally spaced
+            buf = DeviceBuffer(self.frame_bytes + 256 * ((5 * k) % 7), stream, zeroed=False)
+            check(lib.kh_memcpy_d2d_async(buf.ptr, dbase.ptr + 31 * k, self.frame_bytes, stream.cuda_stream_ptr))
+            self.frames.append(buf)
+        stream.synchronize()
+        gaps = {b.ptr - a.ptr for a, b in zip(self.frames, self.frames[1:])}
+        assert self.N < 3 or len(gaps) > 1, "the frame buffers came out equally spaced: this row would measure the strided launch"
+        self.dst = Tensor.uninit((self.N, 3, self.H, self.W), "float32", stream)
+        self.pre = Preprocessor(mode="stretch", format="nv12", sampling=self.sampling, mean=IMAGENET_MEAN, std=IMAGENET_STD, stream=stream)
+
+    def step(self):
+        self.pre.run_raw_batch(self.frames, self.W, self.H, self.dst)
+
+    def describe(self):
+        d = super().describe()
+        d.update(op="Preprocessor.run_raw_batch([frame_0 .. frame_N-1]) — a LIST of separately allocated device buffers, the reference's "
+                    "signature — -> kh_preprocess_to_chw_list (256 frame bases per launch)",
+                 src=f"{self.N} separately allocated 1920x1080 NV12 buffers")
+        return d
+
+
 class H2DPreprocess1080p(NorthStarNV12):
     """SURVEY.md §8(f)4, the capture side of the path: HOST NV12 frames -> page-locked capture buffers -> H2D -> fused preprocess,
     through Preprocessor.run_host_batch (the two-deep upload ring of kornia_rs/preprocess.py::_Staging on a copy stream; the
@@ -192,13 +232,17 @@ class H2DPreprocess1080p(NorthStarNV12):
     the pinned H2D of one batch alone, the kernel alone on resident frames, the end-to-end step in steady state, how much of the
     kernel the ring hides behind the next upload, and end-to-end as a fraction of the pinned-H2D rate measured in this process."""
 
-    def __init__(self, batch: int = 64, pageable: bool = False):
+    def __init__(self, batch: int = 64, pageable: bool = True):
         super().__init__(batch, 0)
+        # pageable = True (the default row): the reference's staging contract — host frames are COPIED into the upload ring's page-locked
+        # slot and may be reused as soon as the call returns (kornia-py/src/cuda_ext/mod.rs:647-745).  pageable = False is the opt-in
+        # `zero_copy=True` path: frames that already live in page-locked capture buffers are DMA'd in place and stay the caller's hazard
+        # until wait_uploads() — a labelled extra, not the default (VERDICT r05 item 6b).
         self.pageable = pageable
-        self.name = f"nv12_h2d_preprocess_1080p{'_pageable' if pageable else ''}_b{batch}"
-        self.kernel = "hipMemcpyAsync(H2D, pinned) + preprocess_nv12_identity"
+        self.name = f"nv12_h2d_preprocess_1080p{'' if pageable else '_zero_copy'}_b{batch}"
+        self.kernel = ("host memcpy into the ring + " if pageable else "") + "hipMemcpyAsync(H2D, pinned) + preprocess_nv12_identity"
 
-    RING = 3   # capture buffers in flight: one being filled / uploaded per ring slot + one spare
+    RING = 4   # distinct host batches rotated through (SURVEY.md §8d: >= 4; a 199 MB batch fits the 256 MB Infinity Cache)
 
     def setup(self, stream):
         from kornia_rs import Preprocessor, Tensor
@@ -288,6 +332,38 @@ class F32Images(Workload):
         import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
         return O
 
+    def _make_images(self, stream, w, h, c, batch, fill=True):
+        """`batch` SEPARATELY ALLOCATED device Images (the operands the reference's per-image operators are handed), image k = the
+        base pattern shifted by 31 k floats like `_make_src`; a spacer allocation of varying size between consecutive images keeps
+        their bases from being equally spaced."""
+        from kornia_rs import Image
+        from kornia_rs.hip import DeviceBuffer, lib, check
+        n = w * h * c
+        dbase = None
+        if fill:
+            self.base = (lcg_bytes(n + 31 * batch).astype(np.float32) / np.float32(255.0))
+            dbase = DeviceBuffer.from_numpy(self.base, stream)
+        imgs, spacers = [], []
+        for k in range(batch):
+            spacers.append(DeviceBuffer(256 * (1 + (5 * k) % 7), stream, zeroed=False))
+            im = Image.uninit(w, h, c, "float32", stream)
+            if fill:
+                check(lib.kh_memcpy_d2d_async(im.data_ptr, dbase.ptr + 31 * k * 4, n * 4, stream.cuda_stream_ptr))
+            imgs.append(im)
+        stream.synchronize()
+        return ImageList(imgs, spacers)
+
+
+class ImageList(list):
+    """N separately allocated device Images standing where a packed batch buffer stands in the strided workloads."""
+
+    def __init__(self, images, keep=()):
+        super().__init__(images)
+        self._keep = list(keep)
+
+    def to_numpy(self, dtype, shape):
+        return np.stack([im.numpy() for im in self]).astype(dtype, copy=False).reshape(shape)
+
 
 class ResizeBilinear(F32Images):
     """configs[1]: resize bilinear 1920x1080 -> 224x224 f32x3, batch 256."""
@@ -301,16 +377,48 @@ class ResizeBilinear(F32Images):
         # taps actually required = 224*224*(4 taps*12 B + 12 B) = 3 010 560 B / image
         self.alg_bytes_per_launch = self.N * self.DW * self.DH * (4 * 12 + 12)
 
+    ROTATE = 4   # >= 4 rotating buffers where a step's set is small — the 154 MB output fits the 256 MB Infinity Cache
+
     def setup(self, stream):
         from kornia_rs.hip import DeviceBuffer
         self.stream = stream
         self.src = self._make_src(stream, self.SW, self.SH, self.C, self.N)
-        self.dst = DeviceBuffer(self.N * self.DW * self.DH * self.C * 4, stream, zeroed=False)
+        self.dsts = [DeviceBuffer(self.N * self.DW * self.DH * self.C * 4, stream, zeroed=False) for _ in range(self.ROTATE)]
+        self.dst, self.turn = self.dsts[0], 0
+
+    def _next_dst(self):
+        self.dst = self.dsts[self.turn % len(self.dsts)]   # `dst` = the buffer the LAST step wrote (what the parity test reads back)
+        self.turn += 1
+        return self.dst
 
     def step(self):
         from kornia_rs._ffi import lib, check
-        check(lib.kh_resize_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.SW, self.SH, self.DW,
+        check(lib.kh_resize_f32(self.stream.cuda_stream_ptr, self.src.ptr, self._next_dst().ptr, self.SW, self.SH, self.DW,
                                 self.DH, self.C, 1, self.N, self.SW * self.SH * self.C, self.DW * self.DH * self.C))
+
+    def floor_bytes(self):
+        """What the memory system must move at its own granularity: every 128-byte line of the source that holds a byte of some tap,
+        once per image (lines of consecutive taps overlap), + the destination.  Evaluated with the kernel's own f32 coordinate
+        expression (half-pixel a * i + b, clamped; P/resize/mod.rs:161-176)."""
+        f32 = np.float32
+
+        def axis(src_len, dst_len):
+            a = f32(src_len) / f32(dst_len)
+            b = f32(0.5) * a - f32(0.5)
+            s = np.clip(a * np.arange(dst_len, dtype=f32) + b, f32(0), f32(src_len - 1))
+            i0 = s.astype(np.int64)
+            return i0, np.minimum(i0 + 1, src_len - 1)
+
+        x0, x1 = axis(self.SW, self.DW)
+        y0, y1 = axis(self.SH, self.DH)
+        px = self.C * 4
+        lines = set()
+        for xa, xb in zip(x0, x1):
+            for x in (int(xa), int(xb)):
+                lines.update(range(x * px // 128, (x * px + px - 1) // 128 + 1))
+        # a source row starts at a multiple of SW * C * 4 = 23 040 = 180 * 128 bytes: the line pattern is the same for every row
+        rows = len(set(y0.tolist()) | set(y1.tolist()))
+        return int(self.N * (rows * len(lines) * 128 + self.DW * self.DH * px))
 
     def describe(self):
         return {"workload": self.name, "op": "imgproc::resize (bilinear, half-pixel)", "src": "1920x1080x3 f32",
@@ -333,6 +441,54 @@ class ResizeBilinear(F32Images):
                 f"resize, not the upstream Rust binary), OpenMP x{threads} over output rows"}
 
 
+class ResizeBilinearApi(ResizeBilinear):
+    """configs[1] THROUGH THE OPERATOR API with separately allocated operands: 256 independent 1080p `Image`s
+    into 256 independent 224 x 224 `Image`s —
+      how = "eager": 256 calls of `imgproc.resize(&Image, &mut Image)` per step, the reference's own signature
+                     (P/resize/mod.rs:114-132): one launch per image, launch-bound (a 2 us kernel behind a Python call);
+      how = "graph": the same 256 calls captured once into a `hip.Graph` and replayed per step — the reference's mechanism for
+                     amortising per-image launches (kornia-py/src/cuda_ext/mod.rs:1684-1790);
+      how = "list":  `imgproc.resize_batch(images, outs=...)` -> `kh_resize_f32_list`: the 256 (src, dst) bases in the kernel
+                     arguments, two launches of 128 images."""
+
+    def __init__(self, batch, how):
+        super().__init__(batch)
+        self.how = how
+        self.cpu_twin = "resize_224"
+        self.name = f"resize_bilinear_1080p_to_224_f32_api_{how}_b{batch}"
+
+    def setup(self, stream):
+        from kornia_rs import hip, imgproc
+        self.stream = stream
+        self.src = self._make_images(stream, self.SW, self.SH, self.C, self.N)
+        self.dsts = [self._make_images(stream, self.DW, self.DH, self.C, self.N, fill=False) for _ in range(self.ROTATE)]
+        self.dst, self.turn = self.dsts[0], 0
+        if self.how == "graph":
+            def record(outs):
+                for s_, d_ in zip(self.src, outs):
+                    imgproc.resize(s_, None, "bilinear", out=d_)
+            self.graphs = [hip.Graph.capture(lambda o=o: record(o), retain=[self.src, o], stream=stream) for o in self.dsts]
+
+    def step(self):
+        from kornia_rs import imgproc
+        dst = self._next_dst()
+        if self.how == "eager":
+            for s_, d_ in zip(self.src, dst):
+                imgproc.resize(s_, None, "bilinear", out=d_)
+        elif self.how == "graph":
+            self.graphs[(self.turn - 1) % len(self.graphs)].replay()
+        else:
+            imgproc.resize_batch(self.src, None, "bilinear", outs=dst)
+
+    def describe(self):
+        d = super().describe()
+        d.update(workload=self.name, operands=f"{self.N} separately allocated source Images -> {self.N} separately allocated destination Images",
+                 op={"eager": "imgproc.resize(src_k, out=dst_k) x N per step (one launch per image)",
+                     "graph": "hip.Graph replay of N captured imgproc.resize calls",
+                     "list": "imgproc.resize_batch(srcs, outs=dsts) -> kh_resize_f32_list (128 images per launch)"}[self.how])
+        return d
+
+
 class ResizeNormalizeF32(ResizeBilinear):
     """The reference's own fused launcher on the configs[1] shape: bilinear resize 1920x1080 -> 224x224 f32x3 fused with
     (px - mean) * (1 / std) (launch_resize_bilinear_normalize_cuda, bench_cuda_resize.rs:456), batch 256."""
@@ -343,7 +499,7 @@ class ResizeNormalizeF32(ResizeBilinear):
         import ctypes as C
         from kornia_rs._ffi import lib, check
         from kornia_rs.hip import IMAGENET_MEAN, IMAGENET_STD
-        check(lib.kh_resize_bilinear_normalize_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.SW, self.SH,
+        check(lib.kh_resize_bilinear_normalize_f32(self.stream.cuda_stream_ptr, self.src.ptr, self._next_dst().ptr, self.SW, self.SH,
                                                    self.DW, self.DH, (C.c_float * 3)(*IMAGENET_MEAN), (C.c_float * 3)(*IMAGENET_STD),
                                                    0, self.N, self.SW * self.SH * self.C, self.DW * self.DH * self.C))
 
@@ -404,7 +560,7 @@ class Gaussian4K(F32Images):
         t0 = time.perf_counter()
         O.gaussian_blur(img, (7, 7), (1.5, 1.5))
         dt1 = time.perf_counter() - t0
-        O.ko.ko_set_threads(0)
+        O.ko.ko_set_threads(CPU_TEAM["threads"] if CPU_TEAM else 0)
         threads = O.ko.ko_max_threads()
         t0 = time.perf_counter()
         reps = 0
@@ -415,6 +571,31 @@ class Gaussian4K(F32Images):
         return {"value": round(self.W * self.H / 1e6 / dt1, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
                 "sample": f"1 image, single thread as in the reference ({dt1:.2f} s); beyond-reference OpenMP x{threads}: "
                           f"{self.W * self.H / 1e6 / dtn:.1f} Mpixels/s; C oracle, not the upstream Rust binary"}
+
+
+class Gaussian4KList(Gaussian4K):
+    """configs[3] through `imgproc.gaussian_blur_batch` with 256 separately allocated 4K source and destination Images
+    (kh_gaussian_blur_f32_list: two launches of 128 images)."""
+
+    def __init__(self, batch):
+        super().__init__(batch)
+        self.cpu_twin = "gaussian_4k"
+        self.name = f"gaussian_blur_7x7_4k_f32_api_list_b{batch}"
+
+    def setup(self, stream):
+        self.stream = stream
+        self.src = self._make_images(stream, self.W, self.H, self.C, self.N)
+        self.dst = self._make_images(stream, self.W, self.H, self.C, self.N, fill=False)
+
+    def step(self):
+        from kornia_rs import imgproc
+        imgproc.gaussian_blur_batch(self.src, (7, 7), (1.5, 1.5), outs=self.dst)
+
+    def describe(self):
+        d = super().describe()
+        d.update(workload=self.name, op="imgproc.gaussian_blur_batch(srcs, (7,7), (1.5,1.5), outs=dsts) -> kh_gaussian_blur_f32_list",
+                 operands=f"{self.N} separately allocated Images each side")
+        return d
 
 
 class UndistortWarp4K(F32Images):
@@ -432,7 +613,11 @@ class UndistortWarp4K(F32Images):
         self.N = batch
         self.units_per_step = self.N * self.W * self.H / 1e6
         img = self.W * self.H * self.C * 4
-        self.alg_bytes_per_launch = self.N * (4 * img + 2 * self.W * self.H * 4)  # 464 486 400 B / image (two passes + maps)
+        # SURVEY.md §8(d)'s contract figure: 464 486 400 B / image (two passes, every tap, the maps once per image).  The kernels need
+        # less — out-of-bounds destination pixels read nothing, and remap reads the two maps once per FOUR images — so `frac` is priced
+        # on what they need (`_price`, set in setup) and the contract figure rides along as `survey_bytes_per_launch`.
+        self.survey_bytes_per_launch = self.N * (4 * img + 2 * self.W * self.H * 4)
+        self.alg_bytes_per_launch = self.survey_bytes_per_launch
         w, h = float(self.W), float(self.H)
         self.hm = [1.03, 0.05, -3.0 * w / 129.0, -0.02, 0.97, 4.0 * h / 97.0, 2.0 / (h * w), 1.5 / (w * h), 1.0]
 
@@ -450,6 +635,34 @@ class UndistortWarp4K(F32Images):
         check(lib.kh_correction_map_polynomial_f32(stream.cuda_stream_ptr, self.mx.ptr, self.my.ptr, self.W, self.H,
                                                    (C.c_double * 4)(*self.INTR), (C.c_double * 8)(*self.DIST)))
         self.hptr = (C.c_float * 9)(*self.hm)
+        self._price(stream, self.mx.ptr, self.my.ptr)
+
+    def _price(self, stream, mx_ptr, my_ptr):
+        """Needed bytes per image: both destinations written (2 x 99.5 MB); per pass the source pixels of the IN-BOUNDS destination
+        pixels once (a 1:1-scale gather touches each source pixel about once: in-bounds share x 99.5 MB); the maps, 66 MB, once per
+        kRemapNB = 4 images.  In-bounds shares: the maps read back from the device; the homography evaluated in f32 like the kernel."""
+        from kornia_rs import hip
+        f32 = np.float32
+        n = self.W * self.H
+        mx, my = np.empty(n, f32), np.empty(n, f32)
+        hip.d2h(mx, mx_ptr, stream)
+        hip.d2h(my, my_ptr, stream)
+        in_remap = float(np.mean((mx >= 0) & (mx < f32(self.W)) & (my >= 0) & (my < f32(self.H))))
+        inv = np.linalg.inv(np.array(self.hm, np.float64).reshape(3, 3)).astype(f32).reshape(-1)
+        ys, xs = np.mgrid[0:self.H, 0:self.W].astype(f32)
+        wv = inv[6] * xs + inv[7] * ys + inv[8]
+        u, v = (inv[0] * xs + inv[1] * ys + inv[2]) / wv, (inv[3] * xs + inv[4] * ys + inv[5]) / wv
+        in_warp = float(np.mean((u >= 0) & (u < f32(self.W)) & (v >= 0) & (v < f32(self.H))))
+        img = self.W * self.H * self.C * 4
+        self.in_bounds = (round(in_remap, 4), round(in_warp, 4))
+        self.alg_bytes_per_launch = int(self.N * (2 * img + (in_remap + in_warp) * img + 2 * n * 4 / 4))
+
+    def roofline_extra(self, mean_step_s):
+        return {"survey_bytes_per_launch": self.survey_bytes_per_launch,
+                "frac_on_survey_bytes": round(self.survey_bytes_per_launch / mean_step_s / 1e9 / HBM_PEAK_GBS, 4),
+                "in_bounds_share_remap_warp": list(self.in_bounds),
+                "pricing": "needed bytes: 2 destinations + in-bounds share of the source per pass + maps once per 4 images; "
+                           "survey_bytes = SURVEY.md 8(d)'s 464 486 400 B / image"}
 
     def step(self):
         from kornia_rs._ffi import lib, check
@@ -484,6 +697,35 @@ class UndistortWarp4K(F32Images):
 
 
 
+class UndistortWarp4KList(UndistortWarp4K):
+    """configs[4] per-GPU share through `imgproc.remap_batch` + `imgproc.warp_perspective_batch` with separately allocated Images."""
+
+    def __init__(self, batch):
+        super().__init__(batch)
+        self.cpu_twin = "undistort_warp_4k"
+        self.name = f"undistort_remap_then_warp_perspective_4k_f32_api_list_b{batch}"
+
+    def setup(self, stream):
+        from kornia_rs import imgproc
+        self.stream = stream
+        self.src = self._make_images(stream, self.W, self.H, self.C, self.N)
+        self.tmp = self._make_images(stream, self.W, self.H, self.C, self.N, fill=False)
+        self.dst = self._make_images(stream, self.W, self.H, self.C, self.N, fill=False)
+        self.mx, self.my = imgproc.generate_correction_map_polynomial(self.INTR, self.DIST, (self.W, self.H), stream)
+        self._price(stream, self.mx.data_ptr, self.my.data_ptr)
+
+    def step(self):
+        from kornia_rs import imgproc
+        imgproc.remap_batch(self.src, self.mx, self.my, "bilinear", outs=self.tmp)
+        imgproc.warp_perspective_batch(self.tmp, self.hm, None, "bilinear", outs=self.dst)
+
+    def describe(self):
+        d = super().describe()
+        d.update(workload=self.name, op="imgproc.remap_batch -> imgproc.warp_perspective_batch (kh_remap_f32_list, kh_warp_perspective_f32_list)",
+                 operands=f"{self.N} separately allocated Images per stage")
+        return d
+
+
 class ResizeBicubic540(ResizeBilinear):
     """resize bicubic (Keys a = -0.5) 1920x1080 -> 960x540 f32x3, batch 256 — the reference's CUDA bicubic launcher
     (P/cuda/resize.rs:245) on its published 1080p -> 540p shape (benchmarks.md:374).  At exactly 2x the 4x4 windows of the
@@ -499,7 +741,7 @@ class ResizeBicubic540(ResizeBilinear):
 
     def step(self):
         from kornia_rs import _ffi
-        _ffi.check(_ffi.lib.kh_resize_f32(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.SW, self.SH, self.DW,
+        _ffi.check(_ffi.lib.kh_resize_f32(self.stream.cuda_stream_ptr, self.src.ptr, self._next_dst().ptr, self.SW, self.SH, self.DW,
                                           self.DH, self.C, _ffi.KH_INTERP_BICUBIC, self.N, self.SW * self.SH * self.C,
                                           self.DW * self.DH * self.C))
 
@@ -1208,11 +1450,15 @@ class GrayPlumbing258x195(Workload):
         from kornia_rs.hip import DeviceBuffer
         self.stream = stream
         self.base = lcg_bytes(self.W * self.H * 3)
-        self.src = DeviceBuffer.from_numpy(self.base, stream)
-        self.dst = DeviceBuffer(self.W * self.H, stream, zeroed=False)
+        # eight (source, destination) pairs rotated through, as the reference's harness rotates 8 source buffers (benchmarks.md:29)
+        self.pairs = [(DeviceBuffer.from_numpy(self.base, stream), DeviceBuffer(self.W * self.H, stream, zeroed=False)) for _ in range(8)]
+        self.src, self.dst = self.pairs[0]
+        self.turn = 0
 
     def step(self):
         from kornia_rs._ffi import lib, check
+        self.src, self.dst = self.pairs[self.turn % len(self.pairs)]
+        self.turn += 1
         check(lib.kh_gray_from_rgb_u8(self.stream.cuda_stream_ptr, self.src.ptr, self.dst.ptr, self.W * self.H))
 
     def describe(self):
@@ -1243,9 +1489,15 @@ WORKLOADS = {
     "nv12_chw_608": lambda a: NorthStarNV12(a.batch or 1024, 608),
     "nv12_chw_640_lanczos": lambda a: NorthStarNV12(a.batch or 256, 640, "lanczos"),
     "yuyv_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640, "bilinear", "yuyv"),
+    "nv12_chw_list": lambda a: NorthStarNV12List(a.batch or 1024),
     "nv12_h2d_preprocess": lambda a: H2DPreprocess1080p(a.batch or 64),
-    "nv12_h2d_preprocess_pageable": lambda a: H2DPreprocess1080p(a.batch or 64, pageable=True),
+    "nv12_h2d_preprocess_zero_copy": lambda a: H2DPreprocess1080p(a.batch or 64, pageable=False),
     "resize_224": lambda a: ResizeBilinear(a.batch or 256),
+    "resize_224_api_eager": lambda a: ResizeBilinearApi(a.batch or 256, "eager"),
+    "resize_224_api_graph": lambda a: ResizeBilinearApi(a.batch or 256, "graph"),
+    "resize_224_api_list": lambda a: ResizeBilinearApi(a.batch or 256, "list"),
+    "gaussian_4k_api_list": lambda a: Gaussian4KList(a.batch or 256),
+    "undistort_warp_4k_api_list": lambda a: UndistortWarp4KList(a.batch or 256),
     "resize_bicubic_540": lambda a: ResizeBicubic540(a.batch or 256),
     "resize_normalize_f32_224": lambda a: ResizeNormalizeF32(a.batch or 256),
     "gaussian_4k": lambda a: Gaussian4K(a.batch or 256),
@@ -1282,11 +1534,68 @@ WORKLOADS = {
 # (resize bilinear / bicubic, gray + YCbCr + HSV converts, gaussian / box / sobel, warp_affine / warp_perspective + undistort,
 # normalize), then the u8 twins.  Each entry is a full roofline record with its own cpu_baseline.  (Median / bilateral / Lab
 # are out of SURVEY.md §8 and have no bench line; their kernels are covered by the parity tests only.)
-ALSO_DEFAULT = ["nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_h2d_preprocess", "resize_224", "resize_bicubic_540", "gaussian_4k", "box_blur_4k", "sobel_4k",
+ALSO_DEFAULT = ["nv12_chw_list", "nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_h2d_preprocess", "nv12_h2d_preprocess_zero_copy", "resize_224",
+                "resize_224_api_list", "resize_224_api_graph", "resize_224_api_eager", "gaussian_4k_api_list", "undistort_warp_4k_api_list",
+                "resize_bicubic_540", "gaussian_4k", "box_blur_4k", "sobel_4k",
                 "undistort_warp_4k", "warp_affine_f32_1080p", "normalize_1080p", "gray_258x195", "gray_u8_1080p", "gray_f32_1080p",
                 "ycbcr_u8_1080p", "ycbcr_f32_1080p", "hsv_f32_1080p", "warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k",
                 "gaussian_u8_4k"]
+CPU_TEAM: dict = {}     # cpu_team(), set once in main()
 CPU_BUDGET_SCALE = 1.0  # lowered for the `also` entries so the default run stays within a few minutes
+
+
+def cpu_team() -> dict:
+    """How many threads the CPU baseline gets, and why (the reference sizes its Rayon pool to the cores it may
+    use, P/parallel.rs:8-10): threads = min(physical cores, CPUs in the affinity mask, ceil(cgroup CPU quota)).  On the pool's boxes
+    that is 16 (2 x 64-core EPYC, all 256 hardware threads in the mask, cpu.max = 16 CPUs): round 5 ran 128 spinning OpenMP threads on
+    that quota and under-reported the CPU."""
+    import math
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = os.cpu_count() or 1
+    physical = None
+    try:
+        cores = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        physical = len(cores) or None
+    except OSError:
+        pass
+    if physical is None:
+        physical = max(1, (os.cpu_count() or 2) // 2)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    threads = max(1, min(physical, affinity, math.ceil(quota) if quota else physical))
+    return {"threads": threads, "physical_cores": physical, "affinity_cpus": affinity, "cgroup_cpus": quota, "logical_cpus": os.cpu_count()}
+
+
+def run_cpu_baseline(wl, team: dict) -> dict:
+    """One workload's CPU leg on the sized team.  `cores` stays what the contract names (the threads that ran: 1 where the reference's
+    CPU path is serial); `threads` repeats it, `team_threads` is what the threaded legs were given, and the three host figures it was
+    derived from ride INSIDE the object."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
+    if getattr(wl, "cpu_twin", None):   # an API-form row of a workload whose CPU leg is already in the line: name it, do not time it again
+        return {"value": None, "unit": "Mpixels/s", "cores": None, "kind": "port", "sample": f"see the row of {wl.cpu_twin}: same arithmetic, same CPU leg"}
+    O.ko.ko_set_threads(team["threads"])
+    cb = wl.cpu_baseline()
+    O.ko.ko_set_threads(team["threads"])   # (a leg that pinned 1 thread restores the OpenMP default, not the team)
+    cb.update(threads=cb.get("cores"), team_threads=team["threads"], cgroup_cpus=team["cgroup_cpus"], physical_cores=team["physical_cores"],
+              affinity_cpus=team["affinity_cpus"])
+    return cb
 
 
 def store_ceilings(hip, stream, dst_ptr: int, w: int, h: int, nframes: int, reps: int = 5):
@@ -1323,18 +1632,20 @@ def store_ceilings(hip, stream, dst_ptr: int, w: int, h: int, nframes: int, reps
         return {"store_ceilings_error": str(e)[:120]}
 
 
-SUMMARY_COLUMNS = ["workload", "Mpx_s", "ms_per_step", "dtype", "roofline_GBps", "roofline_frac", "traffic_frac", "cpu_Mpx_s", "cpu_cores"]
+SUMMARY_COLUMNS = ["workload", "Mpx_s", "ms_per_step", "dtype", "roofline_GBps", "roofline_frac", "traffic_over_alg", "cpu_Mpx_s", "cpu_cores"]
 
 
 def summary_row(rec: dict) -> list:
     """One row per workload of the default run — the headline first — emitted as the LAST key of the line, so that it survives any
     tail truncation.  Round 3 carried every `also` record twice (a compact object AND a summary row); with 22 workloads that no longer
     fits the driver's 8 KB stdout tail, so the table is the record: [workload, Mpixels/s, ms per step, dtype, algorithmic GB/s,
-    roofline frac = algorithmic GB/s / 8000, counted-traffic frac | null, CPU baseline Mpixels/s | null, CPU threads | null].  The full
+    roofline frac = algorithmic GB/s / 8000, counted HBM bytes / algorithmic bytes | null (a byte ratio: the counters are replayed from
+    a separate --pmc run, so no rate is built from them), CPU baseline Mpixels/s | null, CPU threads | null].  The full
     records (config, the whole roofline object, the cpu_baseline sample text) go to gpurun_out/bench_full.json and, for the round's
     reference run, to profiles/."""
     r, c = rec["roofline"], rec.get("cpu_baseline") or {}
-    return [rec["config"]["workload"], rec["value"], rec["ms_per_step"], rec["dtype"], r["achieved"], r["frac"], r.get("traffic_frac"),
+    # (the row is labelled with the short --workload key + batch: the long names of 30 rows no longer fit the driver's 8 KB tail)
+    return [rec.get("key") or rec["config"]["workload"], rec["value"], rec["ms_per_step"], rec["dtype"], r["achieved"], r["frac"], r.get("traffic_over_alg"),
             c.get("value"), c.get("cores")]
 
 
@@ -1436,15 +1747,27 @@ class Runner:
                 "alg_bytes_per_launch": wl.alg_bytes_per_launch, "mean_launch_ms": round(mean_kernel_s * 1e3, 4),
                 "min_launch_ms": round(float(np.min(kernel_ms)), 4),
                 "launch_ms": [round(float(v), 3) for v in kernel_ms[:32]]}
+        # Counted HBM bytes are REPLAYED from a separate --pmc run on another box (profiles/pmc_traffic.json): a byte count is a
+        # property of the kernel and the input, so its ratio to the algorithmic bytes is reported (wasted re-reads show there); a RATE
+        # built from that run's bytes and THIS run's time would mix two boxes, so traffic_frac stays null unless the counters were
+        # taken in this very run.
+        roof["traffic_frac"] = None
         if traffic:
-            # Where the algorithmic figure counts only the taps a gather needs (C2) the kernel really moves whole 128-B
-            # lines: report the HBM rate of the counted traffic next to the algorithmic one.
-            roof["traffic_GBps"] = round(traffic / mean_kernel_s / 1e9, 1)
-            roof["traffic_frac"] = round(traffic / mean_kernel_s / 1e9 / HBM_PEAK_GBS, 4)
+            roof["traffic_over_alg"] = round(traffic / wl.alg_bytes_per_launch, 3)
+        floor = getattr(wl, "floor_bytes", None)
+        if floor:
+            # where the algorithmic figure counts only the bytes of the taps (C2) the memory system still moves whole 128-byte lines:
+            # the line-granular floor of the access pattern, and the rate at which the kernel moves THAT
+            fb = floor()
+            roof["floor_bytes"] = fb
+            roof["floor_GBps"] = round(fb / mean_kernel_s / 1e9, 1)
+            roof["floor_frac"] = round(fb / mean_kernel_s / 1e9 / HBM_PEAK_GBS, 4)
         extra = getattr(wl, "roofline_extra", None)
         if extra:
             roof.update(extra(mean_kernel_s))
-        return {"value": round(self.world * wl.units_per_step * steps / elapsed, 1), "unit": "Mpixels/s", "steps": steps, "warmup": warmup,
+        n = getattr(wl, "N", None)
+        return {"key": f"{key}_b{n}" if n else key,
+                "value": round(self.world * wl.units_per_step * steps / elapsed, 1), "unit": "Mpixels/s", "steps": steps, "warmup": warmup,
                 "ms_per_step": round(elapsed / steps * 1e3, 4), "dtype": wl.dtype, "config": wl.describe(), "roofline": roof}
 
 
@@ -1590,6 +1913,14 @@ def main():
     stream = hip.Stream.new(local_dev)
     run = Runner(hip, torch, dist, stream, rank, gpu_ordinal, world, on_gpu, use_dist, dist_on_gpu)
 
+    global CPU_TEAM
+    CPU_TEAM = cpu_team()
+    ranks_seen = world
+    if use_dist:   # every rank adds 1 through the process group: the line shows that RCCL (gloo under the simulator) really saw N ranks
+        one = torch.ones(1, dtype=torch.float64, device="cuda" if dist_on_gpu else "cpu")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(one.item())))
+
     wl = make_workload(args.workload, args)
     wl.setup(stream)
     elapsed, kernel_ms = run.time(wl, args.steps, args.warmup)
@@ -1601,17 +1932,18 @@ def main():
         name, cus, mem = hip.device_info(local_dev)
         line = {"metric": ("Mpixels/s, fused 1080p NV12->normalized CHW f32 (achieved HBM GB/s in roofline)"
                            if args.workload.startswith("nv12") else f"Mpixels/s (source pixels), {wl.name}"),
-                "value": rec["value"], "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "value": rec["value"], "unit": "Mpixels/s", "n_gpus": world, "n_ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,
                 "data": "synthetic (LCG bytes, reference pattern_u8; frame k shifted by 31k)", "config": rec["config"],
                 "roofline": rec["roofline"]}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = wl.cpu_baseline()
+            line["cpu_baseline"] = run_cpu_baseline(wl, CPU_TEAM)
         rows = [summary_row({**rec, "cpu_baseline": line.get("cpu_baseline")})]
 
     also = args.also
     if also is None:
-        also = ",".join(ALSO_DEFAULT) if args.workload == "nv12_chw" and not args.batch else "none"
+        # the secondary rows belong to the one-GPU record; an N-GPU line is the headline only (seconds per rank) unless --also asks
+        also = ",".join(ALSO_DEFAULT) if args.workload == "nv12_chw" and not args.batch and world == 1 else "none"
     names = [n for n in also.split(",") if n and n != "none"]
     if names:
         del wl  # frees the headline batch (28.7 GB) before the 4K configs allocate theirs
@@ -1632,7 +1964,7 @@ def main():
                 r2 = run.record(w2, steps2, a_warm, e2, k2, n)
                 r2["n_gpus"] = world
                 if world == 1 and not args.no_cpu_baseline:
-                    r2["cpu_baseline"] = w2.cpu_baseline()
+                    r2["cpu_baseline"] = run_cpu_baseline(w2, CPU_TEAM)
                 records.append(r2)
             del w2
             gc.collect()
@@ -1649,24 +1981,7 @@ def main():
             affinity = None
         dev = {"name": name, "cus": cus, "hbm_bytes": mem, "host_cpus": os.cpu_count(), "host_affinity_cpus": affinity,
                "hip_runtime": str(hip.runtime_info().get("choice"))[:80]}
-        if world == 1 and not args.no_cpu_baseline:
-            # `cores` = the threads the CPU baseline actually ran: omp_get_max_threads() of the OpenMP runtime the oracle shares with this
-            # process.  Measured on the pool's boxes (round 5): 2 x 64-core EPYC 9575F, 256 hardware threads, all 256 in the affinity mask;
-            # `import torch` sizes the process's OpenMP team to the PHYSICAL cores (128), and the container's cgroup grants a CPU-time
-            # quota far below either (cpu.max) — the baseline is what this container lets 128 threads do, and says so.
-            threads = line["cpu_baseline"]["cores"] if line.get("cpu_baseline") else None
-            quota = None
-            try:
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-                quota = None if q == "max" else round(int(q) / int(per), 2)
-            except (OSError, ValueError):
-                pass
-            dev["host_cpu_quota"] = quota
-            why = ("the affinity mask" if threads == affinity else
-                   f"torch's intra-op team = the physical cores (torch.get_num_threads() = {torch.get_num_threads()})" if threads == torch.get_num_threads()
-                   else "OMP_NUM_THREADS / the runtime's default")
-            dev["cpu_cores_note"] = (f"cpu_baseline.cores = omp_get_max_threads() = {threads}: {why}; affinity mask {affinity} CPUs, os.cpu_count() {os.cpu_count()}, "
-                                     f"cgroup cpu.max quota {quota if quota is not None else 'none'} CPUs; cores = 1 where the reference's CPU path is single-threaded")
+        dev["cpu_team"] = CPU_TEAM   # what the CPU baseline's thread count was derived from (the same figures ride inside cpu_baseline)
         if ceilings:
             dev.update(ceilings)
             ms = line["roofline"]["mean_launch_ms"]

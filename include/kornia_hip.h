@@ -202,6 +202,14 @@ enum { KH_PRE_FORCE_GENERIC = 1 };
 KH_API int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
                                     const kh_preprocess_params* p);
 
+/* The same for frames that are NOT equally spaced — the reference's own batch signature, `Preprocessor::run_raw_batch(frames:
+ * &[&CudaSlice<u8>], ..)` (P/preprocess.rs:1234-1282), which it walks with one launch per frame (:1277-1280).  `frames`: HOST
+ * array of p->nframes device pointers, read during the call (it may be reused on return); p->src_frame_stride is ignored.  The
+ * frame bases travel in the kernel arguments, 256 per launch — nothing is allocated or uploaded, and the call can be captured
+ * into a graph.  dst is one [nframes, 3, dst_h, dst_w] tensor, as in the reference (:1243-1256).                                 */
+KH_API int32_t kh_preprocess_to_chw_list(kh_stream_t stream, const uint8_t* const* frames, void* dst,
+                                         const kh_preprocess_params* p);
+
 /* Name of the kernel variant kh_preprocess_to_chw would launch for `p` (for profiles/benches):
  * "generic", "generic_bilinear_on_grid" (bilinear whose source coordinates all fall on whole pixels: one tap per
  * pixel, same bits) or "nv12_identity".  Returns NULL and sets the error on invalid params.                       */
@@ -307,6 +315,26 @@ KH_API int32_t kh_warp_perspective_f32(kh_stream_t stream, const float* src, flo
 KH_API int32_t kh_remap_f32(kh_stream_t stream, const float* src, const float* map_x, const float* map_y, float* dst,
                             int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode,
                             int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* `_list` forms: n same-sized images that are NOT equally spaced — separately allocated `Image`s, which is what the reference's
+ * per-image operators are handed (`resize(&Image, &mut Image, ..)` P/resize/mod.rs:114-132, `warp_affine` P/warp/affine.rs:123,
+ * `warp_perspective` P/warp/perspective.rs:115, `remap` P/interpolation/remap.rs:43; a host that loops them pays one launch per
+ * image and amortises that with a captured graph, kornia-py/src/cuda_ext/mod.rs:1684-1790).  `srcs` / `dsts`: HOST arrays of n
+ * device pointers, read during the call; the (source, destination) bases travel in the kernel arguments, 128 images per launch;
+ * nothing is allocated or uploaded.  Results are those of n single-image calls, bit for bit.                                    */
+KH_API int32_t kh_resize_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t src_w,
+                                  int32_t src_h, int32_t dst_w, int32_t dst_h, int32_t channels, int32_t mode, int32_t mapping);
+KH_API int32_t kh_resize_bilinear_normalize_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n,
+                                                     int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h, const float* mean,
+                                                     const float* std_dev, int32_t mapping);
+KH_API int32_t kh_warp_affine_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t src_w,
+                                       int32_t src_h, int32_t dst_w, int32_t dst_h, int32_t channels, const float* m2x3,
+                                       int32_t mode);
+KH_API int32_t kh_warp_perspective_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n,
+                                            int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h, int32_t channels,
+                                            const float* m3x3, int32_t mode);
+KH_API int32_t kh_remap_f32_list(kh_stream_t stream, const float* const* srcs, const float* map_x, const float* map_y,
+                                 float* const* dsts, int32_t n, int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h,
+                                 int32_t channels, int32_t mode);
 /* Brown-Conrady undistortion maps written directly in device memory (the reference builds them
  * on the host: P/calibration/distortion.rs:135-152).  intrinsic = {fx, fy, cx, cy},
  * distortion = {k1, k2, k3, k4, k5, k6, p1, p2}, host pointers, all-f64 arithmetic.          */
@@ -340,6 +368,18 @@ KH_API int32_t kh_box_blur_f32(kh_stream_t stream, const float* src, float* dst,
 KH_API int32_t kh_gradient_magnitude_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
                                          int32_t channels, int32_t kind, int32_t ksize, int32_t batch,
                                          int64_t src_stride, int64_t dst_stride);
+/* `_list` forms (see kh_resize_f32_list): n separately allocated images per call, 128 per launch; the reference's filters take one
+ * `&Image` per call (P/filter/ops.rs:39,116,174,214; P/filter/separable_filter.rs:87).                                        */
+KH_API int32_t kh_separable_filter_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n,
+                                            int32_t cols, int32_t rows, int32_t channels, const float* kernel_x, int32_t nx,
+                                            const float* kernel_y, int32_t ny);
+KH_API int32_t kh_gaussian_blur_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t cols,
+                                         int32_t rows, int32_t channels, int32_t ksize_x, int32_t ksize_y, float sigma_x,
+                                         float sigma_y);
+KH_API int32_t kh_box_blur_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t cols,
+                                    int32_t rows, int32_t channels, int32_t ksize_x, int32_t ksize_y);
+KH_API int32_t kh_gradient_magnitude_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n,
+                                              int32_t cols, int32_t rows, int32_t channels, int32_t kind, int32_t ksize);
 /* host tap builders (P/filter/kernels.rs:10-43) and parameter resolution                      */
 KH_API int32_t kh_box_blur_kernel_1d(int32_t n, float* out);
 KH_API int32_t kh_gaussian_kernel_1d(int32_t n, float sigma, float* out);

@@ -79,6 +79,59 @@ __host__ __device__ __forceinline__ uint32_t fast_quot(uint32_t n, const FastDiv
     return f.m ? (uint32_t)(((uint64_t)n * f.m) >> 32) >> f.sh : n;
 }
 
+// ---- batches whose images are NOT equally spaced: pointer lists --------------------------------------------------------------------
+// The reference's operators take ONE image per call (`resize(&Image, &mut Image)`, P/resize/mod.rs:114-132) and its batch entry a
+// slice of separately allocated frame buffers (`run_raw_batch(frames: &[&CudaSlice<u8>], ..)`, P/preprocess.rs:1258-1282) that it
+// walks with one launch per frame.  Here the `*_list` entry points take HOST arrays of n device pointers and launch once per kListMax
+// images: the (source, destination) bases of a launch travel BY VALUE in the kernel arguments (2 KiB), where a block picks its image's
+// pair with one scalar load — no device-side table to allocate, upload or keep alive, nothing a stream capture cannot record.
+// Measured on the north star (profiles/r06a_ubench_nv12_one_store.txt): 1024 frame bases through such a table, 448 or 128 per launch,
+// 4.374 / 4.373 ms against 4.373 ms for base + k * stride.  Kernels take the list as their LAST argument and select at run time
+// (`listed` is launch-uniform: a scalar branch); contiguous launches pass a zeroed list.
+constexpr int kListMax = 128;
+struct PtrList { const void* src[kListMax]; void* dst[kListMax]; };
+// What a batched launcher is handed: `n` images at src + k * ss / dst + k * ds (ELEMENTS of the operator's type, or bytes where the
+// entry says so), or — srcs != nullptr — at srcs[k] / dsts[k].
+struct BatchRef {
+    const void* src; void* dst; int64_t ss, ds; int n;
+    const void* const* srcs; void* const* dsts;
+    bool list;                               // a `_list` entry made this batch (the arrays themselves may still be NULL: check_list)
+    bool listed() const { return list; }
+};
+inline BatchRef strided_batch(const void* src, void* dst, int n, int64_t ss, int64_t ds) { return BatchRef{src, dst, ss, ds, n, nullptr, nullptr, false}; }
+template <typename T>
+inline BatchRef listed_batch(const T* const* srcs, T* const* dsts, int n) {
+    return BatchRef{nullptr, nullptr, 0, 0, n, reinterpret_cast<const void* const*>(srcs), reinterpret_cast<void* const*>(dsts), true};
+}
+// every pointer of a list present (n > 0); `what` names the entry in the message
+int32_t check_list(const char* what, const void* const* srcs, void* const* dsts, int n);
+// do all the images of the batch satisfy `align` bytes (sources and destinations; strides given in units of `elem` bytes)?
+bool batch_aligned(const BatchRef& b, size_t align, size_t elem);
+// Runs `launch(chunk, first, lst)` once for a strided batch (chunk == b, lst zeroed) or once per kListMax images of a list (chunk =
+// that slice re-based at its first image, `first` = index of its first image in the whole batch); stops at the first failure.
+template <typename F>
+int32_t for_each_launch(const BatchRef& b, F&& launch) {
+    static const PtrList kNoList{};
+    if (!b.listed()) return launch(b, 0, kNoList);
+    for (int first = 0; first < b.n; first += kListMax) {
+        PtrList lst{};
+        const int n = b.n - first < kListMax ? b.n - first : kListMax;
+        for (int k = 0; k < n; ++k) { lst.src[k] = b.srcs[first + k]; lst.dst[k] = b.dsts[first + k]; }
+        const BatchRef chunk{lst.src[0], lst.dst[0], 0, 0, n, b.srcs + first, b.dsts + first, true};
+        if (int32_t rc = launch(chunk, first, lst)) return rc;
+    }
+    return KH_OK;
+}
+// device side: the bases of image `k` of the launch
+template <typename T>
+__device__ __forceinline__ const T* list_src(const PtrList& l, bool listed, const T* base, long long stride, unsigned k) {
+    return listed ? static_cast<const T*>(l.src[k]) : base + (long long)k * stride;
+}
+template <typename T>
+__device__ __forceinline__ T* list_dst(const PtrList& l, bool listed, T* base, long long stride, unsigned k) {
+    return listed ? static_cast<T*>(l.dst[k]) : base + (long long)k * stride;
+}
+
 // ---- development / test options ---------------------------------------------------------------------------------------------------
 // Nothing in this library reads the environment (round 3 had 26 getenv knobs, several on launch paths).  The ALTERNATE kernels a
 // launcher can route to — the fallbacks other geometries, alignments or channel counts take anyway: IEEE division, the four-tap

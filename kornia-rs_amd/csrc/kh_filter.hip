@@ -41,6 +41,7 @@ struct FilterArgs {
     int th;               // output rows per tile (multiple of kVR)
     long long src_stride, dst_stride;
     XcdTiles tiles;  // (column tile, row strip, image), XCD-contiguous order
+    int listed;      // image bases from the launch's PtrList (kh_common.h) instead of base + k * stride
 };
 
 extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -48,7 +49,7 @@ extern __shared__ __attribute__((aligned(16))) float lds_f[];
 // GRAD = false: dst = V_ky(H_kx(src)).  GRAD = true: dst = sqrt(gx^2 + gy^2) with
 // gx = V_ky(H_kx(src)), gy = V_kx(H_ky(src))  (sobel / scharr, P/filter/ops.rs:174-247).
 template <bool GRAD>
-__global__ __launch_bounds__(kBlock) void sep_filter_kernel(FilterArgs a, Taps kx, Taps ky) {
+__global__ __launch_bounds__(kBlock) void sep_filter_kernel(FilterArgs a, Taps kx, Taps ky, PtrList lst) {
     const int tid = threadIdx.x;
     const int hx = kx.n / 2, hy = ky.n / 2;
     const int halo = (GRAD ? max(hx, hy) : hx) * a.C;  // flat floats on each side
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(kBlock) void sep_filter_kernel(FilterArgs a, Taps k
     unsigned tx, ty, bz;
     if (!xcd_tile(a.tiles, tx, ty, bz)) return;  // block-uniform
     const int x0 = tx * kTF, y0 = ty * a.th;
-    const float* src = a.src + (long long)bz * a.src_stride;
-    float* dst = a.dst + (long long)bz * a.dst_stride;
+    const float* src = list_src(lst, a.listed, a.src, a.src_stride, bz);
+    float* dst = list_dst(lst, a.listed, a.dst, a.dst_stride, bz);
 
     // 1. stage the input tile, zero outside the image
     for (int r = 0; r < in_h; ++r) {
@@ -147,7 +148,7 @@ constexpr int kRollStripMax = 360;  // tallest strip (output rows)
 struct TapsK { float k[16]; };
 
 template <int K, bool GRAD>
-__global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx, TapsK ky) {
+__global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx, TapsK ky, PtrList lst) {
     __shared__ float rowbuf[4][160];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int H = K / 2;
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
     const int gx0 = tx * kTF + wv * 64;  // first flat column of this wave
     if (gx0 >= a.rowlen) return;         // whole wave idle (no block barrier below)
     const int y0 = ty * a.th;
-    const float* __restrict__ src = a.src + (long long)bz * a.src_stride;
-    float* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
+    const float* __restrict__ src = list_src(lst, a.listed, a.src, a.src_stride, bz);
+    float* __restrict__ dst = list_dst(lst, a.listed, a.dst, a.dst_stride, bz);
     float* buf = rowbuf[wv];
 
     const int gx = gx0 + lane;
@@ -257,7 +258,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kTF4 = 4 * kTF;  // flat columns per 256-thread block
 
 template <int K, int C>
-__global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK kx, TapsK ky) {
+__global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK kx, TapsK ky, PtrList lst) {
     constexpr int H = K / 2, HALO = H * C;       // <= 32 (checked on the host)
     constexpr int HQ = (HALO + 3) / 4;           // halo in float4 chunks
     constexpr int NCH = 2 * HQ + 1;              // chunks a lane reads per row
@@ -268,8 +269,8 @@ __global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK k
     const int gx0 = tx * kTF4 + wv * 256;   // first flat column of this wave
     if (gx0 >= a.rowlen) return;             // whole wave idle (no block barrier below)
     const int y0 = ty * a.th;
-    const float* __restrict__ src = a.src + (long long)bz * a.src_stride;
-    float* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
+    const float* __restrict__ src = list_src(lst, a.listed, a.src, a.src_stride, bz);
+    float* __restrict__ dst = list_dst(lst, a.listed, a.dst, a.dst_stride, bz);
     float* buf = rowbuf[wv];
 
     const int gx = gx0 + 4 * lane;           // this lane's columns gx .. gx + 3 (rowlen % 4 == 0: all four in or all four out)
@@ -345,19 +346,19 @@ __global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK k
 }
 
 template <int K>
-bool launch_roll4(hipStream_t st, dim3 grid, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
+bool launch_roll4(hipStream_t st, dim3 grid, const FilterArgs& a, const TapsK& kx, const TapsK& ky, const PtrList& lst) {
     switch (a.C) {
-        case 1: hipLaunchKernelGGL((sep_roll4_kernel<K, 1>), grid, dim3(kBlock), 0, st, a, kx, ky); return true;
-        case 3: hipLaunchKernelGGL((sep_roll4_kernel<K, 3>), grid, dim3(kBlock), 0, st, a, kx, ky); return true;
-        case 4: hipLaunchKernelGGL((sep_roll4_kernel<K, 4>), grid, dim3(kBlock), 0, st, a, kx, ky); return true;
+        case 1: hipLaunchKernelGGL((sep_roll4_kernel<K, 1>), grid, dim3(kBlock), 0, st, a, kx, ky, lst); return true;
+        case 3: hipLaunchKernelGGL((sep_roll4_kernel<K, 3>), grid, dim3(kBlock), 0, st, a, kx, ky, lst); return true;
+        case 4: hipLaunchKernelGGL((sep_roll4_kernel<K, 4>), grid, dim3(kBlock), 0, st, a, kx, ky, lst); return true;
         default: return false;
     }
 }
 
 template <int K>
-void launch_roll(hipStream_t st, dim3 grid, bool grad, const FilterArgs& a, const TapsK& kx, const TapsK& ky) {
-    if (grad) hipLaunchKernelGGL((sep_roll_kernel<K, true>), grid, dim3(kBlock), 0, st, a, kx, ky);
-    else hipLaunchKernelGGL((sep_roll_kernel<K, false>), grid, dim3(kBlock), 0, st, a, kx, ky);
+void launch_roll(hipStream_t st, dim3 grid, bool grad, const FilterArgs& a, const TapsK& kx, const TapsK& ky, const PtrList& lst) {
+    if (grad) hipLaunchKernelGGL((sep_roll_kernel<K, true>), grid, dim3(kBlock), 0, st, a, kx, ky, lst);
+    else hipLaunchKernelGGL((sep_roll_kernel<K, false>), grid, dim3(kBlock), 0, st, a, kx, ky, lst);
 }
 
 // Centre an n-tap kernel inside K taps.  The zero pad taps contribute (+-0) to the accumulator,
@@ -380,18 +381,26 @@ int32_t set_taps(Taps& t, const float* k, int n, const char* what) {
 // test option filter_force_tile = 1 routes every call to the LDS-tile kernel (parity tests cover both).
 bool force_tile_kernel() { return dev_opt(kOptFilterForceTile) == 1; }
 
-int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int rows, int C, const Taps& kx,
-               const Taps& ky, bool grad, int batch, int64_t ss, int64_t ds, const char* what) {
+// `whole`: the batch as the caller gave it (strided, or host lists of device pointers); one launch per for_each_launch slice
+int32_t launch(kh_stream_t stream, const BatchRef& whole, int cols, int rows, int C, const Taps& kx, const Taps& ky, bool grad,
+               const char* what) {
     KH_REQUIRE(cols > 0 && rows > 0 && C > 0, KH_ERR_INVALID_ARG, "%s: zero-sized image %dx%dx%d", what, cols, rows, C);
-    KH_REQUIRE(batch >= 0 && batch <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, batch);
+    KH_REQUIRE(whole.n >= 0 && whole.n <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, whole.n);
     KH_REQUIRE((int64_t)cols * rows * C <= kI32Max, KH_ERR_TOO_LARGE, "%s: image exceeds 32-bit indexing", what);
-    if (batch == 0) return KH_OK;
-    KH_REQUIRE(src && dst, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
-    KH_REQUIRE(src != dst, KH_ERR_INVALID_ARG, "%s: in-place filtering is not supported", what);
-
+    if (whole.n == 0) return KH_OK;
+    if (whole.listed()) {
+        if (int32_t rc = check_list(what, whole.srcs, whole.dsts, whole.n)) return rc;   // (also rejects srcs[k] == dsts[k])
+    } else {
+        KH_REQUIRE(whole.src && whole.dst, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
+        KH_REQUIRE(whole.src != whole.dst, KH_ERR_INVALID_ARG, "%s: in-place filtering is not supported", what);
+    }
+    const bool all_16B = batch_aligned(whole, 16, sizeof(float));
+    return for_each_launch(whole, [&](const BatchRef& b, int, const PtrList& lst) -> int32_t {
+    const int batch = b.n;
     FilterArgs a;
-    a.src = src; a.dst = dst; a.rows = rows; a.rowlen = cols * C; a.C = C;
-    a.src_stride = ss; a.dst_stride = ds;
+    a.src = static_cast<const float*>(b.src); a.dst = static_cast<float*>(b.dst); a.rows = rows; a.rowlen = cols * C; a.C = C;
+    a.src_stride = b.ss; a.dst_stride = b.ds;
+    a.listed = b.listed() ? 1 : 0;
 
     // Fast path: rolling-column kernel for odd kernels up to 15 taps whose horizontal halo fits
     // the 32-float side buffers; everything else takes the LDS-tile kernel below.
@@ -411,9 +420,7 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         // (A two-column packed-f32 kernel was measured in round 2 and is not in the library.)
         const int four_opt = dev_opt(kOptFilterFourColumns);
         const bool four_cols = four_opt < 0 ? kFourColumnsDefault : four_opt == 1;
-        const bool four = !grad && four_cols && K <= 9 && (C == 1 || C == 3 || C == 4) && (a.rowlen % 4 == 0) && a.rowlen >= kTF4 &&
-                          (reinterpret_cast<uintptr_t>(src) % 16 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0) &&
-                          (batch == 1 || (ss % 4 == 0 && ds % 4 == 0));
+        const bool four = !grad && four_cols && K <= 9 && (C == 1 || C == 3 || C == 4) && (a.rowlen % 4 == 0) && a.rowlen >= kTF4 && all_16B;
         const unsigned tiles_x = cdiv(a.rowlen, four ? kTF4 : kTF);  // 256-thread blocks: 512 measured +1 %, 1024 +9 % (r01q)
         // Strip height: tall strips amortise the ky-1 warm-up rows (4K x 256 images: 360 rows is
         // 5 % faster than 90), short strips keep a small launch wide enough to fill 256 CUs.
@@ -430,21 +437,21 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
         hipStream_t st = as_hip(stream);
         if (four) {
             switch (K) {
-                case 3: launch_roll4<3>(st, grid, a, px, py); break;
-                case 5: launch_roll4<5>(st, grid, a, px, py); break;
-                case 7: launch_roll4<7>(st, grid, a, px, py); break;
-                default: launch_roll4<9>(st, grid, a, px, py); break;
+                case 3: launch_roll4<3>(st, grid, a, px, py, lst); break;
+                case 5: launch_roll4<5>(st, grid, a, px, py, lst); break;
+                case 7: launch_roll4<7>(st, grid, a, px, py, lst); break;
+                default: launch_roll4<9>(st, grid, a, px, py, lst); break;
             }
             return check_launch(what);
         }
         switch (K) {
-            case 3: launch_roll<3>(st, grid, grad, a, px, py); break;
-            case 5: launch_roll<5>(st, grid, grad, a, px, py); break;
-            case 7: launch_roll<7>(st, grid, grad, a, px, py); break;
-            case 9: launch_roll<9>(st, grid, grad, a, px, py); break;
-            case 11: launch_roll<11>(st, grid, grad, a, px, py); break;
-            case 13: launch_roll<13>(st, grid, grad, a, px, py); break;
-            default: launch_roll<15>(st, grid, grad, a, px, py); break;
+            case 3: launch_roll<3>(st, grid, grad, a, px, py, lst); break;
+            case 5: launch_roll<5>(st, grid, grad, a, px, py, lst); break;
+            case 7: launch_roll<7>(st, grid, grad, a, px, py, lst); break;
+            case 9: launch_roll<9>(st, grid, grad, a, px, py, lst); break;
+            case 11: launch_roll<11>(st, grid, grad, a, px, py, lst); break;
+            case 13: launch_roll<13>(st, grid, grad, a, px, py, lst); break;
+            default: launch_roll<15>(st, grid, grad, a, px, py, lst); break;
         }
         return check_launch(what);
     }
@@ -470,8 +477,9 @@ int32_t launch(kh_stream_t stream, const float* src, float* dst, int cols, int r
     bytes = (in_h * (kTF + 2 * halo) + in_h * kTF * (grad ? 2 : 1)) * sizeof(float);
     if (bytes > 48 * 1024)  // opt in to the full 160 KiB LDS of a gfx950 CU (per device, idempotent)
         KH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(kern, xcd_grid(a.tiles), dim3(kBlock), bytes, as_hip(stream), a, kx, ky);
+    hipLaunchKernelGGL(kern, xcd_grid(a.tiles), dim3(kBlock), bytes, as_hip(stream), a, kx, ky, lst);
     return check_launch(what);
+    });
 }
 
 }  // namespace
@@ -517,51 +525,47 @@ int32_t kh_gaussian_resolve(int32_t k[2], float s[2]) {
     return KH_OK;
 }
 
-int32_t kh_separable_filter_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
-                                int32_t channels, const float* kernel_x, int32_t nx, const float* kernel_y, int32_t ny,
-                                int32_t batch, int64_t src_stride, int64_t dst_stride) {
+}  // extern "C"
+
+namespace {
+
+int32_t separable_impl(const char* what, kh_stream_t stream, const BatchRef& b, int cols, int rows, int channels, const float* kernel_x, int nx,
+                       const float* kernel_y, int ny) {
     Taps kx, ky;
-    if (int32_t rc = set_taps(kx, kernel_x, nx, "kh_separable_filter_f32")) return rc;
-    if (int32_t rc = set_taps(ky, kernel_y, ny, "kh_separable_filter_f32")) return rc;
-    return launch(stream, src, dst, cols, rows, channels, kx, ky, false, batch, src_stride, dst_stride,
-                  "kh_separable_filter_f32");
+    if (int32_t rc = set_taps(kx, kernel_x, nx, what)) return rc;
+    if (int32_t rc = set_taps(ky, kernel_y, ny, what)) return rc;
+    return launch(stream, b, cols, rows, channels, kx, ky, false, what);
 }
 
-int32_t kh_gaussian_blur_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
-                             int32_t channels, int32_t ksize_x, int32_t ksize_y, float sigma_x, float sigma_y,
-                             int32_t batch, int64_t src_stride, int64_t dst_stride) {
+int32_t gaussian_impl(const char* what, kh_stream_t stream, const BatchRef& b, int cols, int rows, int channels, int ksize_x, int ksize_y,
+                      float sigma_x, float sigma_y) {
     int32_t k[2] = {ksize_x, ksize_y};
     float s[2] = {sigma_x, sigma_y};
     if (int32_t rc = kh_gaussian_resolve(k, s)) return rc;
-    KH_REQUIRE(k[0] <= kMaxTaps && k[1] <= kMaxTaps, KH_ERR_UNSUPPORTED, "kh_gaussian_blur_f32: kernel (%d, %d) exceeds %d taps",
-               k[0], k[1], kMaxTaps);
+    KH_REQUIRE(k[0] <= kMaxTaps && k[1] <= kMaxTaps, KH_ERR_UNSUPPORTED, "%s: kernel (%d, %d) exceeds %d taps", what, k[0], k[1], kMaxTaps);
     float tx[64], ty[64];
     kh_gaussian_kernel_1d(k[0], s[0], tx);
     kh_gaussian_kernel_1d(k[1], s[1], ty);
     Taps kx, ky;
-    set_taps(kx, tx, k[0], "kh_gaussian_blur_f32");
-    set_taps(ky, ty, k[1], "kh_gaussian_blur_f32");
-    return launch(stream, src, dst, cols, rows, channels, kx, ky, false, batch, src_stride, dst_stride, "kh_gaussian_blur_f32");
+    set_taps(kx, tx, k[0], what);
+    set_taps(ky, ty, k[1], what);
+    return launch(stream, b, cols, rows, channels, kx, ky, false, what);
 }
 
-int32_t kh_box_blur_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows, int32_t channels,
-                        int32_t ksize_x, int32_t ksize_y, int32_t batch, int64_t src_stride, int64_t dst_stride) {
-    KH_REQUIRE(ksize_x >= 1 && ksize_y >= 1, KH_ERR_INVALID_ARG, "kh_box_blur_f32: invalid kernel length (%d, %d)", ksize_x, ksize_y);
-    KH_REQUIRE(ksize_x <= kMaxTaps && ksize_y <= kMaxTaps, KH_ERR_UNSUPPORTED, "kh_box_blur_f32: kernel (%d, %d) exceeds %d taps",
-               ksize_x, ksize_y, kMaxTaps);
+int32_t box_impl(const char* what, kh_stream_t stream, const BatchRef& b, int cols, int rows, int channels, int ksize_x, int ksize_y) {
+    KH_REQUIRE(ksize_x >= 1 && ksize_y >= 1, KH_ERR_INVALID_ARG, "%s: invalid kernel length (%d, %d)", what, ksize_x, ksize_y);
+    KH_REQUIRE(ksize_x <= kMaxTaps && ksize_y <= kMaxTaps, KH_ERR_UNSUPPORTED, "%s: kernel (%d, %d) exceeds %d taps", what, ksize_x, ksize_y, kMaxTaps);
     float tx[64], ty[64];
     kh_box_blur_kernel_1d(ksize_x, tx);
     kh_box_blur_kernel_1d(ksize_y, ty);
     Taps kx, ky;
-    set_taps(kx, tx, ksize_x, "kh_box_blur_f32");
-    set_taps(ky, ty, ksize_y, "kh_box_blur_f32");
-    return launch(stream, src, dst, cols, rows, channels, kx, ky, false, batch, src_stride, dst_stride, "kh_box_blur_f32");
+    set_taps(kx, tx, ksize_x, what);
+    set_taps(ky, ty, ksize_y, what);
+    return launch(stream, b, cols, rows, channels, kx, ky, false, what);
 }
 
 // kind: KH_GRAD_SOBEL (size 3 | 5) or KH_GRAD_SCHARR (size 3) — P/filter/kernels.rs:55-100
-int32_t kh_gradient_magnitude_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
-                                  int32_t channels, int32_t kind, int32_t ksize, int32_t batch, int64_t src_stride,
-                                  int64_t dst_stride) {
+int32_t gradient_impl(const char* what, kh_stream_t stream, const BatchRef& b, int cols, int rows, int channels, int kind, int ksize) {
     static const float s3x[3] = {-1, 0, 1}, s3y[3] = {1, 2, 1}, s5x[5] = {-1, -2, 0, 2, 1}, s5y[5] = {1, 4, 6, 4, 1},
                        c3y[3] = {3, 10, 3};
     const float *tx = nullptr, *ty = nullptr;
@@ -570,10 +574,55 @@ int32_t kh_gradient_magnitude_f32(kh_stream_t stream, const float* src, float* d
     else if (kind == KH_GRAD_SCHARR && ksize == 3) { tx = s3x; ty = c3y; }
     KH_REQUIRE(tx, KH_ERR_INVALID_ARG, "invalid kernel length %d for gradient kind %d", ksize, kind);
     Taps kx, ky;
-    set_taps(kx, tx, ksize, "kh_gradient_magnitude_f32");
-    set_taps(ky, ty, ksize, "kh_gradient_magnitude_f32");
-    return launch(stream, src, dst, cols, rows, channels, kx, ky, true, batch, src_stride, dst_stride,
-                  "kh_gradient_magnitude_f32");
+    set_taps(kx, tx, ksize, what);
+    set_taps(ky, ty, ksize, what);
+    return launch(stream, b, cols, rows, channels, kx, ky, true, what);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t kh_separable_filter_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
+                                int32_t channels, const float* kernel_x, int32_t nx, const float* kernel_y, int32_t ny,
+                                int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    return separable_impl("kh_separable_filter_f32", stream, strided_batch(src, dst, batch, src_stride, dst_stride), cols, rows, channels,
+                          kernel_x, nx, kernel_y, ny);
+}
+int32_t kh_separable_filter_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t cols,
+                                     int32_t rows, int32_t channels, const float* kernel_x, int32_t nx, const float* kernel_y,
+                                     int32_t ny) {
+    return separable_impl("kh_separable_filter_f32_list", stream, listed_batch(srcs, dsts, n), cols, rows, channels, kernel_x, nx, kernel_y, ny);
+}
+
+int32_t kh_gaussian_blur_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
+                             int32_t channels, int32_t ksize_x, int32_t ksize_y, float sigma_x, float sigma_y,
+                             int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    return gaussian_impl("kh_gaussian_blur_f32", stream, strided_batch(src, dst, batch, src_stride, dst_stride), cols, rows, channels, ksize_x,
+                         ksize_y, sigma_x, sigma_y);
+}
+int32_t kh_gaussian_blur_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t cols,
+                                  int32_t rows, int32_t channels, int32_t ksize_x, int32_t ksize_y, float sigma_x, float sigma_y) {
+    return gaussian_impl("kh_gaussian_blur_f32_list", stream, listed_batch(srcs, dsts, n), cols, rows, channels, ksize_x, ksize_y, sigma_x, sigma_y);
+}
+
+int32_t kh_box_blur_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows, int32_t channels,
+                        int32_t ksize_x, int32_t ksize_y, int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    return box_impl("kh_box_blur_f32", stream, strided_batch(src, dst, batch, src_stride, dst_stride), cols, rows, channels, ksize_x, ksize_y);
+}
+int32_t kh_box_blur_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t cols, int32_t rows,
+                             int32_t channels, int32_t ksize_x, int32_t ksize_y) {
+    return box_impl("kh_box_blur_f32_list", stream, listed_batch(srcs, dsts, n), cols, rows, channels, ksize_x, ksize_y);
+}
+
+int32_t kh_gradient_magnitude_f32(kh_stream_t stream, const float* src, float* dst, int32_t cols, int32_t rows,
+                                  int32_t channels, int32_t kind, int32_t ksize, int32_t batch, int64_t src_stride,
+                                  int64_t dst_stride) {
+    return gradient_impl("kh_gradient_magnitude_f32", stream, strided_batch(src, dst, batch, src_stride, dst_stride), cols, rows, channels, kind, ksize);
+}
+int32_t kh_gradient_magnitude_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t cols,
+                                       int32_t rows, int32_t channels, int32_t kind, int32_t ksize) {
+    return gradient_impl("kh_gradient_magnitude_f32_list", stream, listed_batch(srcs, dsts, n), cols, rows, channels, kind, ksize);
 }
 
 }  // extern "C"

@@ -28,6 +28,7 @@ struct Img {  // one batch of same-sized HWC f32 images
     int sw, sh, dw, dh;
     long long src_stride, dst_stride;  // elements between consecutive images
     XcdTiles tiles;                    // kBx x kBy output tiles, XCD-contiguous order
+    int listed;                        // the images' bases come from the launch's PtrList (kh_common.h) instead of base + k * stride
 };
 
 // ---- samplers (expression trees of P/interpolation/*.rs; do not regroup) --------------------------
@@ -223,8 +224,8 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
     const int x = bx_ * kBx + threadIdx.x;                            \
     const int y = by_ * kBy + threadIdx.y;                            \
     if (x >= im.dw || y >= im.dh) return;                             \
-    const float* src = im.src + (long long)bz_ * im.src_stride;       \
-    const OutRow o = out_row<C>(im.dst + (long long)bz_ * im.dst_stride + (long long)y * im.dw * C, im.dw);
+    const float* src = list_src(lst, im.listed, im.src, im.src_stride, bz_);                                          \
+    const OutRow o = out_row<C>(list_dst(lst, im.listed, im.dst, im.dst_stride, bz_) + (long long)y * im.dw * C, im.dw);
 
 // resize (P/resize/mod.rs:161-176): half-pixel grid a*x + b, clamped to the source.
 // Bound by the texture addresser on moderate scales (1080p -> 540p bicubic: sixteen 12-byte gathers per pixel, TA_BUSY 100 %,
@@ -234,7 +235,7 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 // Taking a row's four interior taps as three 16-byte loads instead of four 12-byte ones: no change (r04zm): the addresser's cost
 // follows the bytes, not the instruction count.
 template <int C, int MODE>
-__global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, float bx, float ay, float by) {
+__global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, float bx, float ay, float by, PtrList lst) {
     KH_PIXEL_PROLOGUE
     const float sx = clampf(ax * (float)x + bx, 0.0f, (float)(im.sw - 1));
     const float sy = clampf(ay * (float)y + by, 0.0f, (float)(im.sh - 1));
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, floa
 // resize_bilinear_normalize_3c (P/cuda/resize.rs:184-236): bilinear resize fused with `(px - mean) * inv_std`, HWC in,
 // HWC out — the sample is the same bilinear sampler as `resize`, the epilogue the reference kernel's expression.
 struct Norm3f { float mean[3], inv_std[3]; };
-__global__ __launch_bounds__(kBx* kBy) void resize_normalize_kernel(Img im, float ax, float bx, float ay, float by, Norm3f n) {
+__global__ __launch_bounds__(kBx* kBy) void resize_normalize_kernel(Img im, float ax, float bx, float ay, float by, Norm3f n, PtrList lst) {
     constexpr int C = 3;
     KH_PIXEL_PROLOGUE
     const float sx = clampf(ax * (float)x + bx, 0.0f, (float)(im.sw - 1));
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void lanczos_axis_kernel(LzTap* __restrict_
 
 template <int C>
 __global__ __launch_bounds__(kBx* kBy) void resize_lanczos_kernel(Img im, const LzTap* __restrict__ tx,
-                                                                  const LzTap* __restrict__ ty) {
+                                                                  const LzTap* __restrict__ ty, PtrList lst) {
     KH_PIXEL_PROLOGUE
     const LzTap ax = tx[x], ay = ty[y];
     int xo[6];
@@ -316,7 +317,7 @@ struct Mat9 { float m[9]; };
 
 // warp_affine (P/warp/affine.rs:123-372); mi = inverse 2x3
 template <int C, int MODE>
-__global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi) {
+__global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi, PtrList lst) {
     KH_PIXEL_PROLOGUE
     const float swf = (float)im.sw, shf = (float)im.sh;
     const float sx0 = mi.m[1] * (float)y + mi.m[2], sy0 = mi.m[4] * (float)y + mi.m[5];
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi) 
 
 // warp_perspective (P/warp/perspective.rs:67-72,115-166); im9 = inverse 3x3
 template <int C, int MODE>
-__global__ __launch_bounds__(kBx* kBy) void warp_perspective_kernel(Img im, Mat9 h) {
+__global__ __launch_bounds__(kBx* kBy) void warp_perspective_kernel(Img im, Mat9 h, PtrList lst) {
     KH_PIXEL_PROLOGUE
     const float xf = (float)x, yf = (float)y;
     const float w = h.m[6] * xf + h.m[7] * yf + h.m[8];
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(kBx* kBy) void warp_perspective_kernel(Img im, Mat9
 constexpr int kRemapNB = 4;
 template <int C, int MODE>
 __global__ __launch_bounds__(kBx* kBy) void remap_kernel(Img im, const float* __restrict__ map_x,
-                                                         const float* __restrict__ map_y, int batch) {
+                                                         const float* __restrict__ map_y, int batch, PtrList lst) {
     unsigned bx_, by_, bz_;
     if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;
     const int x = bx_ * kBx + threadIdx.x;
@@ -387,8 +388,8 @@ __global__ __launch_bounds__(kBx* kBy) void remap_kernel(Img im, const float* __
     for (int k = 0; k < kRemapNB; ++k) {
         const int z = z0 + k;
         if (z >= batch) break;
-        const float* src = im.src + (long long)z * im.src_stride;
-        const OutRow o = out_row<C>(im.dst + (long long)z * im.dst_stride + (long long)y * im.dw * C, im.dw);
+        const float* src = list_src(lst, im.listed, im.src, im.src_stride, (unsigned)z);
+        const OutRow o = out_row<C>(list_dst(lst, im.listed, im.dst, im.dst_stride, (unsigned)z) + (long long)y * im.dw * C, im.dw);
         if (inside) {
             float val[C];
             sample<C, MODE>(src, im.sh, im.sw, u, v, val);
@@ -417,26 +418,28 @@ __global__ __launch_bounds__(kBx* kBy) void correction_map_kernel(float* __restr
 
 // ---- host side ----------------------------------------------------------------------------------
 
-int32_t check_img(const char* what, const void* src, const void* dst, int sw, int sh, int dw, int dh, int channels,
-                  int mode, int batch, int64_t ss, int64_t ds) {
+int32_t check_img(const char* what, const BatchRef& b, int sw, int sh, int dw, int dh, int channels, int mode) {
     KH_REQUIRE(sw > 0 && sh > 0 && dw > 0 && dh > 0, KH_ERR_INVALID_ARG, "%s: zero-sized image (src %dx%d, dst %dx%d)",
                what, sw, sh, dw, dh);
     KH_REQUIRE(channels == 1 || channels == 3 || channels == 4, KH_ERR_UNSUPPORTED,
                "%s: no device kernel for %d channels (supported: 1, 3, 4)", what, channels);
     KH_REQUIRE(mode >= KH_INTERP_NEAREST && mode <= KH_INTERP_LANCZOS, KH_ERR_UNSUPPORTED,
                "%s: interpolation mode %d has no device kernel (nearest, bilinear, bicubic, lanczos)", what, mode);
-    KH_REQUIRE(batch >= 0 && batch <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, batch);
+    KH_REQUIRE(b.n >= 0 && b.n <= 65535, KH_ERR_TOO_LARGE, "%s: batch %d outside [0, 65535]", what, b.n);
     KH_REQUIRE((int64_t)sw * sh * channels <= kI32Max && (int64_t)dw * dh * channels <= kI32Max, KH_ERR_TOO_LARGE,
                "%s: image exceeds 32-bit indexing", what);
     // a destination row is one streaming-store window (out_row): 2 GiB at most
     KH_REQUIRE((int64_t)dw * channels * 4 <= kI32Max, KH_ERR_TOO_LARGE, "%s: destination rows of %d x %d floats exceed the 2 GiB store window", what, dw, channels);
-    KH_REQUIRE(ss >= 0 && ds >= 0, KH_ERR_INVALID_ARG, "%s: negative batch stride", what);
-    if (batch > 0) KH_REQUIRE(src && dst, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
+    if (b.listed()) return check_list(what, b.srcs, b.dsts, b.n);
+    KH_REQUIRE(b.ss >= 0 && b.ds >= 0, KH_ERR_INVALID_ARG, "%s: negative batch stride", what);
+    if (b.n > 0) KH_REQUIRE(b.src && b.dst, KH_ERR_INVALID_ARG, "%s: null device pointer", what);
     return KH_OK;
 }
 
-Img make_img(const float* src, float* dst, int sw, int sh, int dw, int dh, int64_t ss, int64_t ds, int groups) {
-    return Img{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups, cdiv(dw, kBx) * 8)};
+// `b`: a strided batch or one <= kListMax slice of a list (for_each_launch); `groups` = images (or image groups) the tile grid covers
+Img make_img(const BatchRef& b, int sw, int sh, int dw, int dh, int groups) {
+    return Img{static_cast<const float*>(b.src), static_cast<float*>(b.dst), sw, sh, dw, dh, b.ss, b.ds,
+               xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups, cdiv(dw, kBx) * 8), b.listed() ? 1 : 0};
 }
 #define KH_REQUIRE_TILES(what, im) \
     KH_REQUIRE((im).tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what)
@@ -517,51 +520,52 @@ int32_t kh_pixel_mapping_coeffs(int32_t mapping, int32_t src_len, int32_t dst_le
     return KH_OK;
 }
 
-int32_t kh_resize_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw, int32_t dh,
-                      int32_t channels, int32_t mode, int32_t batch, int64_t src_stride, int64_t dst_stride) {
-    return kh_resize_mapped_f32(stream, src, dst, sw, sh, dw, dh, channels, mode, KH_MAP_HALF_PIXEL, batch, src_stride, dst_stride);
-}
+}  // extern "C"
 
-int32_t kh_resize_mapped_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw, int32_t dh,
-                             int32_t channels, int32_t mode, int32_t mapping, int32_t batch, int64_t src_stride,
-                             int64_t dst_stride) {
-    if (int32_t rc = check_img("kh_resize_f32", src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride, dst_stride))
-        return rc;
+namespace {
+
+int32_t resize_impl(const char* what, kh_stream_t stream, const BatchRef& b, int sw, int sh, int dw, int dh, int channels, int mode,
+                    int mapping) {
+    if (int32_t rc = check_img(what, b, sw, sh, dw, dh, channels, mode)) return rc;
     float cx[2], cy[2];
     if (int32_t rc = kh_pixel_mapping_coeffs(mapping, sw, dw, cx)) return rc;
     if (int32_t rc = kh_pixel_mapping_coeffs(mapping, sh, dh, cy)) return rc;
-    if (batch == 0) return KH_OK;
+    if (b.n == 0) return KH_OK;
     const float ax = cx[0], bx = cx[1], ay = cy[0], by = cy[1];
-    const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
-    KH_REQUIRE_TILES("kh_resize_f32", im);
+    hipStream_t st = as_hip(stream);
     if (mode == KH_INTERP_LANCZOS) {  // P/resize/mod.rs:139-146
         // (dw + dh) x 28 B of stream-ordered scratch for the axis tables, as the reference adapter
         // allocates its tables/intermediate per call (P/resize/cuda.rs:151-190)
         Scratch scratch;
         if (int32_t rc = get_scratch(stream, sizeof(LzTap) * ((size_t)dw + dh), "kh_resize_f32 (lanczos)", scratch)) return rc;
         LzTap* tab = scratch.as<LzTap>();
-        hipStream_t st = as_hip(stream);
         hipLaunchKernelGGL(lanczos_axis_kernel, dim3(cdiv(dw, kBlock)), dim3(kBlock), 0, st, tab, dw, ax, bx,
                            (float)(sw - 1));
         hipLaunchKernelGGL(lanczos_axis_kernel, dim3(cdiv(dh, kBlock)), dim3(kBlock), 0, st, tab + dw, dh, ay, by,
                            (float)(sh - 1));
-        const dim3 blk(kBx, kBy);
-        switch (channels) {
-            case 1: hipLaunchKernelGGL(resize_lanczos_kernel<1>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw); break;
-            case 3: hipLaunchKernelGGL(resize_lanczos_kernel<3>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw); break;
-            default: hipLaunchKernelGGL(resize_lanczos_kernel<4>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw); break;
-        }
-        return check_launch("kh_resize_f32 (lanczos)");
+        return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+            const Img im = make_img(c, sw, sh, dw, dh, c.n);
+            KH_REQUIRE_TILES(what, im);
+            const dim3 blk(kBx, kBy);
+            switch (channels) {
+                case 1: hipLaunchKernelGGL(resize_lanczos_kernel<1>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw, lst); break;
+                case 3: hipLaunchKernelGGL(resize_lanczos_kernel<3>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw, lst); break;
+                default: hipLaunchKernelGGL(resize_lanczos_kernel<4>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw, lst); break;
+            }
+            return check_launch("kh_resize_f32 (lanczos)");
+        });
     }
-    KH_DISPATCH_C_MODE(resize_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, ax, bx, ay, by);
-    return check_launch("kh_resize_f32");
+    return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+        const Img im = make_img(c, sw, sh, dw, dh, c.n);
+        KH_REQUIRE_TILES(what, im);
+        KH_DISPATCH_C_MODE(resize_kernel, channels, mode, xcd_grid(im.tiles), st, im, ax, bx, ay, by, lst);
+        return check_launch(what);
+    });
 }
 
-int32_t kh_resize_bilinear_normalize_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw,
-                                         int32_t dh, const float* mean, const float* std_dev, int32_t mapping, int32_t batch,
-                                         int64_t src_stride, int64_t dst_stride) {
-    const char* what = "kh_resize_bilinear_normalize_f32";
-    if (int32_t rc = check_img(what, src, dst, sw, sh, dw, dh, 3, KH_INTERP_BILINEAR, batch, src_stride, dst_stride)) return rc;
+int32_t resize_normalize_impl(const char* what, kh_stream_t stream, const BatchRef& b, int sw, int sh, int dw, int dh, const float* mean,
+                              const float* std_dev, int mapping) {
+    if (int32_t rc = check_img(what, b, sw, sh, dw, dh, 3, KH_INTERP_BILINEAR)) return rc;
     KH_REQUIRE(mean && std_dev, KH_ERR_INVALID_ARG, "%s: null mean / std", what);
     // launch_resize_bilinear_normalize_cuda, P/cuda/resize.rs:606-610
     KH_REQUIRE(std_dev[0] != 0.0f && std_dev[1] != 0.0f && std_dev[2] != 0.0f, KH_ERR_INVALID_ARG,
@@ -569,57 +573,125 @@ int32_t kh_resize_bilinear_normalize_f32(kh_stream_t stream, const float* src, f
     float cx[2], cy[2];
     if (int32_t rc = kh_pixel_mapping_coeffs(mapping, sw, dw, cx)) return rc;
     if (int32_t rc = kh_pixel_mapping_coeffs(mapping, sh, dh, cy)) return rc;
-    if (batch == 0) return KH_OK;
+    if (b.n == 0) return KH_OK;
     Norm3f n;
     for (int c = 0; c < 3; ++c) { n.mean[c] = mean[c]; n.inv_std[c] = 1.0f / std_dev[c]; }
-    const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
-    KH_REQUIRE_TILES(what, im);
-    hipLaunchKernelGGL(resize_normalize_kernel, xcd_grid(im.tiles), dim3(kBx, kBy), 0, as_hip(stream), im, cx[0], cx[1], cy[0], cy[1], n);
-    return check_launch(what);
+    return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+        const Img im = make_img(c, sw, sh, dw, dh, c.n);
+        KH_REQUIRE_TILES(what, im);
+        hipLaunchKernelGGL(resize_normalize_kernel, xcd_grid(im.tiles), dim3(kBx, kBy), 0, as_hip(stream), im, cx[0], cx[1], cy[0], cy[1], n, lst);
+        return check_launch(what);
+    });
+}
+
+int32_t warp_affine_impl(const char* what, kh_stream_t stream, const BatchRef& b, int sw, int sh, int dw, int dh, int channels,
+                         const float* m, int mode) {
+    if (int32_t rc = check_img(what, b, sw, sh, dw, dh, channels, mode)) return rc;
+    KH_REQUIRE(m, KH_ERR_INVALID_ARG, "%s: null matrix", what);
+    if (b.n == 0) return KH_OK;
+    Mat6 mi;
+    kh_invert_affine_transform(m, mi.m);
+    return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+        const Img im = make_img(c, sw, sh, dw, dh, c.n);
+        KH_REQUIRE_TILES(what, im);
+        KH_DISPATCH_C_MODE(warp_affine_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, mi, lst);
+        return check_launch(what);
+    });
+}
+
+int32_t warp_perspective_impl(const char* what, kh_stream_t stream, const BatchRef& b, int sw, int sh, int dw, int dh, int channels,
+                              const float* m, int mode) {
+    if (int32_t rc = check_img(what, b, sw, sh, dw, dh, channels, mode)) return rc;
+    KH_REQUIRE(m, KH_ERR_INVALID_ARG, "%s: null matrix", what);
+    Mat9 h;
+    if (int32_t rc = kh_invert_homography(m, h.m)) return rc;  // rejected on the host, before any launch
+    if (b.n == 0) return KH_OK;
+    return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+        const Img im = make_img(c, sw, sh, dw, dh, c.n);
+        KH_REQUIRE_TILES(what, im);
+        KH_DISPATCH_C_MODE(warp_perspective_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, h, lst);
+        return check_launch(what);
+    });
+}
+
+int32_t remap_impl(const char* what, kh_stream_t stream, const BatchRef& b, const float* map_x, const float* map_y, int sw, int sh,
+                   int dw, int dh, int channels, int mode) {
+    if (int32_t rc = check_img(what, b, sw, sh, dw, dh, channels, mode)) return rc;
+    if (b.n == 0) return KH_OK;
+    KH_REQUIRE(map_x && map_y, KH_ERR_INVALID_ARG, "%s: null map pointer", what);
+    return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+        const Img im = make_img(c, sw, sh, dw, dh, (c.n + kRemapNB - 1) / kRemapNB);
+        KH_REQUIRE_TILES(what, im);
+        KH_DISPATCH_C_MODE(remap_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, map_x, map_y, c.n, lst);
+        return check_launch(what);
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t kh_resize_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw, int32_t dh,
+                      int32_t channels, int32_t mode, int32_t batch, int64_t src_stride, int64_t dst_stride) {
+    return resize_impl("kh_resize_f32", stream, strided_batch(src, dst, batch, src_stride, dst_stride), sw, sh, dw, dh, channels, mode, KH_MAP_HALF_PIXEL);
+}
+
+int32_t kh_resize_mapped_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw, int32_t dh,
+                             int32_t channels, int32_t mode, int32_t mapping, int32_t batch, int64_t src_stride,
+                             int64_t dst_stride) {
+    return resize_impl("kh_resize_f32", stream, strided_batch(src, dst, batch, src_stride, dst_stride), sw, sh, dw, dh, channels, mode, mapping);
+}
+
+int32_t kh_resize_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t sw, int32_t sh,
+                           int32_t dw, int32_t dh, int32_t channels, int32_t mode, int32_t mapping) {
+    return resize_impl("kh_resize_f32_list", stream, listed_batch(srcs, dsts, n), sw, sh, dw, dh, channels, mode, mapping);
+}
+
+int32_t kh_resize_bilinear_normalize_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw,
+                                         int32_t dh, const float* mean, const float* std_dev, int32_t mapping, int32_t batch,
+                                         int64_t src_stride, int64_t dst_stride) {
+    return resize_normalize_impl("kh_resize_bilinear_normalize_f32", stream, strided_batch(src, dst, batch, src_stride, dst_stride), sw, sh, dw, dh,
+                                 mean, std_dev, mapping);
+}
+
+int32_t kh_resize_bilinear_normalize_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t sw,
+                                              int32_t sh, int32_t dw, int32_t dh, const float* mean, const float* std_dev,
+                                              int32_t mapping) {
+    return resize_normalize_impl("kh_resize_bilinear_normalize_f32_list", stream, listed_batch(srcs, dsts, n), sw, sh, dw, dh, mean, std_dev, mapping);
 }
 
 int32_t kh_warp_affine_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw,
                            int32_t dh, int32_t channels, const float* m, int32_t mode, int32_t batch,
                            int64_t src_stride, int64_t dst_stride) {
-    if (int32_t rc = check_img("kh_warp_affine_f32", src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride, dst_stride))
-        return rc;
-    KH_REQUIRE(m, KH_ERR_INVALID_ARG, "kh_warp_affine_f32: null matrix");
-    if (batch == 0) return KH_OK;
-    Mat6 mi;
-    kh_invert_affine_transform(m, mi.m);
-    const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
-    KH_REQUIRE_TILES("kh_warp_affine_f32", im);
-    KH_DISPATCH_C_MODE(warp_affine_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, mi);
-    return check_launch("kh_warp_affine_f32");
+    return warp_affine_impl("kh_warp_affine_f32", stream, strided_batch(src, dst, batch, src_stride, dst_stride), sw, sh, dw, dh, channels, m, mode);
+}
+
+int32_t kh_warp_affine_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t sw, int32_t sh,
+                                int32_t dw, int32_t dh, int32_t channels, const float* m, int32_t mode) {
+    return warp_affine_impl("kh_warp_affine_f32_list", stream, listed_batch(srcs, dsts, n), sw, sh, dw, dh, channels, m, mode);
 }
 
 int32_t kh_warp_perspective_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t dw,
                                 int32_t dh, int32_t channels, const float* m, int32_t mode, int32_t batch,
                                 int64_t src_stride, int64_t dst_stride) {
-    if (int32_t rc = check_img("kh_warp_perspective_f32", src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride, dst_stride))
-        return rc;
-    KH_REQUIRE(m, KH_ERR_INVALID_ARG, "kh_warp_perspective_f32: null matrix");
-    Mat9 h;
-    if (int32_t rc = kh_invert_homography(m, h.m)) return rc;  // rejected on the host, before any launch
-    if (batch == 0) return KH_OK;
-    const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch);
-    KH_REQUIRE_TILES("kh_warp_perspective_f32", im);
-    KH_DISPATCH_C_MODE(warp_perspective_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, h);
-    return check_launch("kh_warp_perspective_f32");
+    return warp_perspective_impl("kh_warp_perspective_f32", stream, strided_batch(src, dst, batch, src_stride, dst_stride), sw, sh, dw, dh, channels,
+                                 m, mode);
+}
+
+int32_t kh_warp_perspective_f32_list(kh_stream_t stream, const float* const* srcs, float* const* dsts, int32_t n, int32_t sw,
+                                     int32_t sh, int32_t dw, int32_t dh, int32_t channels, const float* m, int32_t mode) {
+    return warp_perspective_impl("kh_warp_perspective_f32_list", stream, listed_batch(srcs, dsts, n), sw, sh, dw, dh, channels, m, mode);
 }
 
 int32_t kh_remap_f32(kh_stream_t stream, const float* src, const float* map_x, const float* map_y, float* dst,
                      int32_t sw, int32_t sh, int32_t dw, int32_t dh, int32_t channels, int32_t mode, int32_t batch,
                      int64_t src_stride, int64_t dst_stride) {
-    if (int32_t rc = check_img("kh_remap_f32", src, dst, sw, sh, dw, dh, channels, mode, batch, src_stride, dst_stride))
-        return rc;
-    if (batch == 0) return KH_OK;
-    KH_REQUIRE(map_x && map_y, KH_ERR_INVALID_ARG, "kh_remap_f32: null map pointer");
-    const Img im = make_img(src, dst, sw, sh, dw, dh, src_stride, dst_stride, (batch + kRemapNB - 1) / kRemapNB);
-    KH_REQUIRE_TILES("kh_remap_f32", im);
-    KH_DISPATCH_C_MODE(remap_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im,
-                       map_x, map_y, batch);
-    return check_launch("kh_remap_f32");
+    return remap_impl("kh_remap_f32", stream, strided_batch(src, dst, batch, src_stride, dst_stride), map_x, map_y, sw, sh, dw, dh, channels, mode);
+}
+
+int32_t kh_remap_f32_list(kh_stream_t stream, const float* const* srcs, const float* map_x, const float* map_y, float* const* dsts,
+                          int32_t n, int32_t sw, int32_t sh, int32_t dw, int32_t dh, int32_t channels, int32_t mode) {
+    return remap_impl("kh_remap_f32_list", stream, listed_batch(srcs, dsts, n), map_x, map_y, sw, sh, dw, dh, channels, mode);
 }
 
 int32_t kh_correction_map_polynomial_f32(kh_stream_t stream, float* map_x, float* map_y, int32_t w, int32_t h,

@@ -48,7 +48,18 @@ struct PreArgs {
     const float* lz_wx;          // Lanczos only: 6 axis weights per destination column / row, built on the host (see lanczos_tables)
     const float* lz_wy;
     int quad_wide;               // preprocess_generic_quads, NV12 / YUYV: the taps of every destination quad fit one 16-byte run per plane row (host-checked)
+    int listed;                  // frame bases from the launch's FrameList instead of src_base + frame * src_frame_stride
 };
+
+// kh_preprocess_to_chw_list: the reference's `run_raw_batch(frames: &[&CudaSlice<u8>], ..)` (P/preprocess.rs:1258-1282) hands over
+// separately allocated frame buffers and launches once per frame.  Here the bases of up to kFrameListMax frames travel by value in the
+// kernel arguments (2 KiB; a block reads its frame's base with one scalar load) and the batch goes out as ceil(n / 256) launches:
+// 4.374 ms against 4.373 ms for the equally spaced form on the north star (profiles/r06a_ubench_nv12_one_store.txt).
+constexpr int kFrameListMax = 256;
+struct FrameList { const uint8_t* p[kFrameListMax]; };
+__device__ __forceinline__ const uint8_t* frame_base(const FrameList& fl, const PreArgs& a, const uint8_t* src_base, unsigned frame) {
+    return a.listed ? fl.p[frame] : src_base + (long long)frame * a.src_frame_stride;
+}
 
 // BT.601 limited-range Q20 decode, constants of P/color/yuv/kernels.rs:696-702 and the fused
 // kernel's bt601_q20_to_rgb (P/preprocess.rs:501-508).
@@ -375,12 +386,12 @@ constexpr int kSampleBilinearOnGrid = 100;   // internal sampler id: bilinear wh
 template <int FMT, int SAMPLER, typename OutT, bool WIDE>
 __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __restrict__ src_base,
                                                              OutT* __restrict__ dst_base,
-                                                             PreArgs a) {
+                                                             PreArgs a, FrameList fl) {
     const int pixels = a.dst_w * a.dst_h;
     const int ox0 = blockIdx.x * (64 * kGenPx) + threadIdx.x;
     const int oy = blockIdx.y * 4 + threadIdx.y;
     if (ox0 >= a.dst_w || oy >= a.dst_h) return;
-    const uint8_t* src = src_base + (long long)blockIdx.z * a.src_frame_stride;
+    const uint8_t* src = frame_base(fl, a, src_base, blockIdx.z);
     OutT* dst = dst_base + (long long)blockIdx.z * a.dst_frame_stride;
     const float ny = (float)oy - a.pad_y;
     const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
@@ -506,11 +517,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kQuadBlock = 256;
 template <int FMT, int SAMPLER, bool WIDE>
 __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uint8_t* __restrict__ src_base, float* __restrict__ dst_base,
-                                                                       PreArgs a, FastDiv by_wq) {
+                                                                       PreArgs a, FastDiv by_wq, FrameList fl) {
     const int wq = a.dst_w >> 2, groups = wq * a.dst_h, plane = a.dst_w * a.dst_h;   // host-checked: 12 * plane < 2^31
     const int g = blockIdx.x * kQuadBlock + threadIdx.x;
     if (g >= groups) return;
-    const uint8_t* src = src_base + (long long)blockIdx.y * a.src_frame_stride;
+    const uint8_t* src = frame_base(fl, a, src_base, blockIdx.y);
     const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_base + (long long)blockIdx.y * a.dst_frame_stride, (uint32_t)(12 * plane));
     const int oy = (int)fast_quot((uint32_t)g, by_wq), ox0 = 4 * (g - oy * wq);
     const float ny = (float)oy - a.pad_y;
@@ -617,17 +628,16 @@ __device__ __forceinline__ float div255_u8(float x) {
 constexpr int kIdBlock = 512;  // 8 KiB contiguous per plane per block; 256 / 384 / 640 / 768 / 1024 are 2-11 % slower (r02e, r02f)
 // (An XCD-per-frame block order — XCD k walks frames k, k + 8, ... — measured 4.84 ms against 4.65 ms for this order in round 2,
 // profiles/r02a_ab.log, and is not in the library.)
-__global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
-    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a) {
+__device__ __forceinline__ void nv12_identity_body(const uint8_t* __restrict__ src_frame, float* __restrict__ dst_frame, const PreArgs& a) {
     const int wq = a.src_w >> 2;     // 4-pixel groups per row
     const int groups = wq * a.src_h;
-    const unsigned chunk = blockIdx.x, frame = blockIdx.y;
+    const unsigned chunk = blockIdx.x;
     const int g = chunk * kIdBlock + threadIdx.x;
     if (g >= groups) return;
     const int plane = a.src_w * a.src_h;           // host-checked: 12 * plane < 2^31
     // one V# per frame: source = plane * 3 / 2 bytes, destination = 3 planes of f32
-    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(src_base + (long long)frame * a.src_frame_stride, (uint32_t)(plane + plane / 2));
-    const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_base + (long long)frame * a.dst_frame_stride, (uint32_t)(12 * plane));
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(src_frame, (uint32_t)(plane + plane / 2));
+    const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_frame, (uint32_t)(12 * plane));
 
     const int r = g / wq;  // deliberately NOT fast_quot(g, by_wq): see the header comment (the division paces the loads)
     const int xq = g - r * wq;
@@ -662,6 +672,16 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
 #pragma unroll
     for (int c = 0; c < 3; ++c)  // plane offset in the vector offset, never in an SGPR soffset (kh_common.h)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[c]), rdst, 16 * g + c * (4 * plane), 0, kAuxStream);
+}
+__global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity(
+    const uint8_t* __restrict__ src_base, float* __restrict__ dst_base, PreArgs a) {
+    const unsigned frame = blockIdx.y;
+    nv12_identity_body(src_base + (long long)frame * a.src_frame_stride, dst_base + (long long)frame * a.dst_frame_stride, a);
+}
+// the same kernel for separately allocated frames (kh_preprocess_to_chw_list): the frame's base is one scalar load from the kernel arguments
+__global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity_list(FrameList fl, float* __restrict__ dst_base, PreArgs a) {
+    const unsigned frame = blockIdx.y;
+    nv12_identity_body(fl.p[frame], dst_base + (long long)frame * a.dst_frame_stride, a);
 }
 
 // Lanczos axis-weight tables: wx[dst_w][6] then wy[dst_h][6], cached per (device, geometry) like the reference's tap tables
@@ -769,18 +789,29 @@ bool quad_taps_fit_16(const PreArgs& a, int extra) {   // extra = 1: the bilinea
     return ok;
 }
 
-bool identity_fast_path(const kh_preprocess_params* p, const uint8_t* src, const void* dst) {
+// The source frames of a call: n frames `stride` bytes apart from `src`, or — list != nullptr — at list[k] (host array of device pointers).
+struct Frames {
+    const uint8_t* src; int64_t stride; const uint8_t* const* list; int n;
+    bool listed() const { return list != nullptr; }
+    bool aligned(unsigned align) const {   // every frame base a multiple of `align` bytes
+        if (!listed()) return reinterpret_cast<uintptr_t>(src) % align == 0 && (n <= 1 || stride % align == 0);
+        for (int k = 0; k < n; ++k) if (reinterpret_cast<uintptr_t>(list[k]) % align) return false;
+        return true;
+    }
+};
+
+bool identity_fast_path(const kh_preprocess_params* p, const Frames& f, const void* dst) {
     return !(p->flags & KH_PRE_FORCE_GENERIC) && p->fmt == KH_FMT_NV12 &&
            p->out_dtype == KH_OUT_F32 &&
            (p->sampling == KH_SAMPLE_BILINEAR || p->sampling == KH_SAMPLE_NEAREST) &&
            p->scale_x == 1.0f && p->scale_y == 1.0f && p->pad_x == 0.0f && p->pad_y == 0.0f &&
            p->dst_w == p->src_w && p->dst_h == p->src_h && (p->src_w % 4) == 0 &&
            (int64_t)p->src_w * p->src_h * 12 <= kI32Max &&  // 32-bit buffer offsets within one frame's three planes
-           (reinterpret_cast<uintptr_t>(src) % 4) == 0 && (p->src_frame_stride % 4) == 0 &&
+           f.aligned(4) && (f.listed() || (p->src_frame_stride % 4) == 0) &&
            (reinterpret_cast<uintptr_t>(dst) % 16) == 0 && (p->dst_frame_stride % 4) == 0;
 }
 
-int32_t validate(const kh_preprocess_params* p, const uint8_t* src, const void* dst) {
+int32_t validate(const kh_preprocess_params* p, const Frames& f, const void* dst) {
     KH_REQUIRE(p, KH_ERR_INVALID_ARG, "preprocess: null params");
     KH_REQUIRE(p->nframes >= 0, KH_ERR_INVALID_ARG, "preprocess: negative frame count");
     KH_REQUIRE(p->src_w > 0 && p->src_h > 0 && p->dst_w > 0 && p->dst_h > 0, KH_ERR_INVALID_ARG,
@@ -813,21 +844,26 @@ int32_t validate(const kh_preprocess_params* p, const uint8_t* src, const void* 
     KH_REQUIRE(p->nframes <= 65535, KH_ERR_TOO_LARGE,
                "preprocess: at most 65535 frames per launch, got %d", p->nframes);
     if (p->nframes > 0) {
-        KH_REQUIRE(src && dst, KH_ERR_INVALID_ARG, "preprocess: null device pointer");
+        KH_REQUIRE(dst, KH_ERR_INVALID_ARG, "preprocess: null device pointer");
+        if (f.listed()) {
+            for (int k = 0; k < f.n; ++k) KH_REQUIRE(f.list[k], KH_ERR_INVALID_ARG, "preprocess: null frame pointer at list index %d", k);
+        } else {
+            KH_REQUIRE(f.src, KH_ERR_INVALID_ARG, "preprocess: null device pointer");
+        }
     }
     return KH_OK;
 }
 
+// `wide_ok`: every frame base of the CALL (not only of this launch's slice) is aligned for the format's one-load taps
 template <int FMT, int SAMPLER>
 void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst, const PreArgs& a,
-                        int out_dtype) {
+                        int out_dtype, const Frames& f, const FrameList& fl) {
     // one-load taps need the frame base and the row pitch aligned to the tap's width
-    const uintptr_t base = reinterpret_cast<uintptr_t>(src);
     bool wide = false;
-    if (FMT == KH_FMT_NV12) wide = base % 2 == 0 && a.src_frame_stride % 2 == 0 && a.src_w % 2 == 0;
-    else if (FMT == KH_FMT_YUYV) wide = base % 4 == 0 && a.src_frame_stride % 4 == 0 && a.src_pitch % 4 == 0;
+    if (FMT == KH_FMT_NV12) wide = f.aligned(2) && a.src_w % 2 == 0;
+    else if (FMT == KH_FMT_YUYV) wide = f.aligned(4) && a.src_pitch % 4 == 0;
     else if (FMT == KH_FMT_RGB || FMT == KH_FMT_BGR)
-        wide = a.src_bpp == 4 && base % 4 == 0 && a.src_frame_stride % 4 == 0 && a.src_pitch % 4 == 0;
+        wide = a.src_bpp == 4 && f.aligned(4) && a.src_pitch % 4 == 0;
     // flattened quads with 16-byte streaming stores (preprocess_generic_quads) for the ONE-tap samplers (nearest, on-grid bilinear), f32
     // outputs whose rows are whole quads.  Measured on one box, three interleaved rounds (profiles/r04d_quads_ab.txt): 1080p NV12 -> 640
     // on-grid 1.227 vs 1.329 ms, YUYV 1.206 vs 1.279 ms; the four-tap bilinear kernel does NOT gain from it (608: 1.464 vs 1.443 ms) and
@@ -846,13 +882,13 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
             const FastDiv by_wq = fast_div((uint32_t)wq);
             PreArgs aq = a;
             aq.quad_wide = wide_nv12 ? 1 : 0;   // test option pre_quads = 3: per-tap loads everywhere
-            if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq);
-            else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq);
+            if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, fl);
+            else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, fl);
             return;
         }
     }
     const dim3 blk(64, 4);
-#define KH_GEN(T, W) hipLaunchKernelGGL((preprocess_generic<FMT, SAMPLER, T, W>), grid, blk, 0, s, src, (T*)dst, a)
+#define KH_GEN(T, W) hipLaunchKernelGGL((preprocess_generic<FMT, SAMPLER, T, W>), grid, blk, 0, s, src, (T*)dst, a, fl)
     if (out_dtype == KH_OUT_F32) { if (wide) KH_GEN(float, true); else KH_GEN(float, false); }
     else { if (wide) KH_GEN(unsigned short, true); else KH_GEN(unsigned short, false); }
 #undef KH_GEN
@@ -860,19 +896,79 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
 
 template <int FMT>
 void launch_generic_fmt(hipStream_t s, dim3 grid, const uint8_t* src, void* dst, const PreArgs& a,
-                        int sampling, int out_dtype) {
+                        int sampling, int out_dtype, const Frames& f, const FrameList& fl) {
     switch (sampling) {
         case KH_SAMPLE_NEAREST:
-            launch_generic_out<FMT, KH_SAMPLE_NEAREST>(s, grid, src, dst, a, out_dtype);
+            launch_generic_out<FMT, KH_SAMPLE_NEAREST>(s, grid, src, dst, a, out_dtype, f, fl);
             break;
         case KH_SAMPLE_BILINEAR:
-            if (bilinear_taps_on_grid(a)) launch_generic_out<FMT, kSampleBilinearOnGrid>(s, grid, src, dst, a, out_dtype);
-            else launch_generic_out<FMT, KH_SAMPLE_BILINEAR>(s, grid, src, dst, a, out_dtype);
+            if (bilinear_taps_on_grid(a)) launch_generic_out<FMT, kSampleBilinearOnGrid>(s, grid, src, dst, a, out_dtype, f, fl);
+            else launch_generic_out<FMT, KH_SAMPLE_BILINEAR>(s, grid, src, dst, a, out_dtype, f, fl);
             break;
         default:
-            launch_generic_out<FMT, KH_SAMPLE_LANCZOS>(s, grid, src, dst, a, out_dtype);
+            launch_generic_out<FMT, KH_SAMPLE_LANCZOS>(s, grid, src, dst, a, out_dtype, f, fl);
             break;
     }
+}
+
+int32_t preprocess_impl(kh_stream_t stream, const Frames& f, void* dst, const kh_preprocess_params* p) {
+    int32_t rc = validate(p, f, dst);
+    if (rc != KH_OK) return rc;
+    if (p->nframes == 0) return KH_OK;
+
+    PreArgs a;
+    a.scale_x = p->scale_x; a.scale_y = p->scale_y; a.pad_x = p->pad_x; a.pad_y = p->pad_y;
+    a.src_w = p->src_w; a.src_h = p->src_h; a.src_pitch = p->src_pitch; a.src_bpp = p->src_bpp;
+    a.dst_w = p->dst_w; a.dst_h = p->dst_h;
+    a.m0 = p->mean[0]; a.m1 = p->mean[1]; a.m2 = p->mean[2];
+    a.is0 = p->inv_std[0]; a.is1 = p->inv_std[1]; a.is2 = p->inv_std[2];
+    a.pad_value = p->pad_value;
+    a.src_frame_stride = f.listed() ? 0 : p->src_frame_stride;
+    a.dst_frame_stride = p->dst_frame_stride;
+    a.rc_x = 1.0f / a.scale_x;
+    a.rc_y = 1.0f / a.scale_y;
+    a.fast_div = plan_division_is_exact(a) ? 1 : 0;
+    a.lz_wx = a.lz_wy = nullptr;
+    a.quad_wide = 0;
+    a.listed = f.listed() ? 1 : 0;
+    hipStream_t s = as_hip(stream);
+
+    const bool identity = identity_fast_path(p, f, dst);
+    TableLease lz;  // keeps the weight table alive until the launch that reads it is enqueued and recorded
+    if (!identity && p->sampling == KH_SAMPLE_LANCZOS) {
+        rc = lanczos_tables(a, s, lz);
+        if (rc != KH_OK) return rc;
+    }
+    const size_t out_elem = p->out_dtype == KH_OUT_F16 ? 2 : 4;
+    static const FrameList kNoFrames{};
+    // one launch for an equally spaced batch; one per kFrameListMax frames of a list
+    for (int first = 0; first < p->nframes; first += f.listed() ? kFrameListMax : p->nframes) {
+        const int n = f.listed() ? std::min(kFrameListMax, p->nframes - first) : p->nframes;
+        FrameList fl_chunk;
+        if (f.listed()) for (int k = 0; k < n; ++k) fl_chunk.p[k] = f.list[first + k];
+        const FrameList& fl = f.listed() ? fl_chunk : kNoFrames;
+        void* dst_chunk = static_cast<char*>(dst) + (size_t)first * (size_t)p->dst_frame_stride * out_elem;
+        if (identity) {
+            const int groups = (p->src_w / 4) * p->src_h;
+            const unsigned bpf = cdiv(groups, kIdBlock);
+            if (f.listed()) hipLaunchKernelGGL(preprocess_nv12_identity_list, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, fl, (float*)dst_chunk, a);
+            else hipLaunchKernelGGL(preprocess_nv12_identity, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, f.src, (float*)dst_chunk, a);
+            rc = check_launch("preprocess_nv12_identity");
+        } else {
+            dim3 grid(cdiv(p->dst_w, 64 * kGenPx), cdiv(p->dst_h, 4), (unsigned)n);
+            switch (p->fmt) {
+                case KH_FMT_RGB: launch_generic_fmt<KH_FMT_RGB>(s, grid, f.src, dst_chunk, a, p->sampling, p->out_dtype, f, fl); break;
+                case KH_FMT_BGR: launch_generic_fmt<KH_FMT_BGR>(s, grid, f.src, dst_chunk, a, p->sampling, p->out_dtype, f, fl); break;
+                case KH_FMT_GRAY: launch_generic_fmt<KH_FMT_GRAY>(s, grid, f.src, dst_chunk, a, p->sampling, p->out_dtype, f, fl); break;
+                case KH_FMT_NV12: launch_generic_fmt<KH_FMT_NV12>(s, grid, f.src, dst_chunk, a, p->sampling, p->out_dtype, f, fl); break;
+                default: launch_generic_fmt<KH_FMT_YUYV>(s, grid, f.src, dst_chunk, a, p->sampling, p->out_dtype, f, fl); break;
+            }
+            rc = check_launch("preprocess_generic");
+        }
+        if (rc != KH_OK) break;
+    }
+    if (lz) lz->used_on(s);
+    return rc;
 }
 
 }  // namespace
@@ -881,9 +977,10 @@ extern "C" {
 
 const char* kh_preprocess_variant(const kh_preprocess_params* p) {
     // Alignment of the actual buffers is only known at launch; report for aligned buffers.
-    if (validate(p, reinterpret_cast<const uint8_t*>(16), reinterpret_cast<void*>(16)) != KH_OK)
+    const Frames aligned{reinterpret_cast<const uint8_t*>(16), p ? p->src_frame_stride : 0, nullptr, p ? p->nframes : 0};
+    if (validate(p, aligned, reinterpret_cast<void*>(16)) != KH_OK)
         return nullptr;
-    if (identity_fast_path(p, reinterpret_cast<const uint8_t*>(16), reinterpret_cast<void*>(16))) return "nv12_identity";
+    if (identity_fast_path(p, aligned, reinterpret_cast<void*>(16))) return "nv12_identity";
     if (p->sampling == KH_SAMPLE_BILINEAR) {
         PreArgs a{};
         a.scale_x = p->scale_x; a.scale_y = p->scale_y; a.pad_x = p->pad_x; a.pad_y = p->pad_y;
@@ -895,48 +992,14 @@ const char* kh_preprocess_variant(const kh_preprocess_params* p) {
 
 int32_t kh_preprocess_to_chw(kh_stream_t stream, const uint8_t* src, void* dst,
                              const kh_preprocess_params* p) {
-    int32_t rc = validate(p, src, dst);
-    if (rc != KH_OK) return rc;
-    if (p->nframes == 0) return KH_OK;
+    return preprocess_impl(stream, Frames{src, p ? p->src_frame_stride : 0, nullptr, p ? p->nframes : 0}, dst, p);
+}
 
-    PreArgs a;
-    a.scale_x = p->scale_x; a.scale_y = p->scale_y; a.pad_x = p->pad_x; a.pad_y = p->pad_y;
-    a.src_w = p->src_w; a.src_h = p->src_h; a.src_pitch = p->src_pitch; a.src_bpp = p->src_bpp;
-    a.dst_w = p->dst_w; a.dst_h = p->dst_h;
-    a.m0 = p->mean[0]; a.m1 = p->mean[1]; a.m2 = p->mean[2];
-    a.is0 = p->inv_std[0]; a.is1 = p->inv_std[1]; a.is2 = p->inv_std[2];
-    a.pad_value = p->pad_value;
-    a.src_frame_stride = p->src_frame_stride;
-    a.dst_frame_stride = p->dst_frame_stride;
-    a.rc_x = 1.0f / a.scale_x;
-    a.rc_y = 1.0f / a.scale_y;
-    a.fast_div = plan_division_is_exact(a) ? 1 : 0;
-    a.lz_wx = a.lz_wy = nullptr;
-    a.quad_wide = 0;
-    hipStream_t s = as_hip(stream);
-
-    if (identity_fast_path(p, src, dst)) {
-        const int groups = (p->src_w / 4) * p->src_h;
-        const unsigned bpf = cdiv(groups, kIdBlock);
-        hipLaunchKernelGGL(preprocess_nv12_identity, dim3(bpf, (unsigned)p->nframes), dim3(kIdBlock), 0, s, src, (float*)dst, a);
-        return check_launch("preprocess_nv12_identity");
-    }
-
-    TableLease lz;  // keeps the weight table alive until the launch that reads it is enqueued and recorded
-    if (p->sampling == KH_SAMPLE_LANCZOS) {
-        rc = lanczos_tables(a, s, lz);
-        if (rc != KH_OK) return rc;
-    }
-    dim3 grid(cdiv(p->dst_w, 64 * kGenPx), cdiv(p->dst_h, 4), (unsigned)p->nframes);
-    switch (p->fmt) {
-        case KH_FMT_RGB: launch_generic_fmt<KH_FMT_RGB>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
-        case KH_FMT_BGR: launch_generic_fmt<KH_FMT_BGR>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
-        case KH_FMT_GRAY: launch_generic_fmt<KH_FMT_GRAY>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
-        case KH_FMT_NV12: launch_generic_fmt<KH_FMT_NV12>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
-        default: launch_generic_fmt<KH_FMT_YUYV>(s, grid, src, dst, a, p->sampling, p->out_dtype); break;
-    }
-    if (lz) lz->used_on(s);
-    return check_launch("preprocess_generic");
+int32_t kh_preprocess_to_chw_list(kh_stream_t stream, const uint8_t* const* frames, void* dst,
+                                  const kh_preprocess_params* p) {
+    KH_REQUIRE(!p || p->nframes <= 0 || frames, KH_ERR_INVALID_ARG, "preprocess: null frame list");
+    static const uint8_t* const kEmpty[1] = {nullptr};
+    return preprocess_impl(stream, Frames{nullptr, 0, frames ? frames : kEmpty, p ? p->nframes : 0}, dst, p);
 }
 
 }  // extern "C"

@@ -95,6 +95,26 @@ int32_t get_scratch(kh_stream_t stream, size_t bytes, const char* what, Scratch&
     return KH_OK;
 }
 
+int32_t check_list(const char* what, const void* const* srcs, void* const* dsts, int n) {
+    KH_REQUIRE(n >= 0 && n <= 65535, KH_ERR_TOO_LARGE, "%s: %d images outside [0, 65535]", what, n);
+    if (n == 0) return KH_OK;
+    KH_REQUIRE(srcs && dsts, KH_ERR_INVALID_ARG, "%s: null pointer list", what);
+    for (int k = 0; k < n; ++k) {
+        KH_REQUIRE(srcs[k] && dsts[k], KH_ERR_INVALID_ARG, "%s: null device pointer at list index %d", what, k);
+        KH_REQUIRE(srcs[k] != dsts[k], KH_ERR_INVALID_ARG, "%s: source and destination alias at list index %d", what, k);
+    }
+    return KH_OK;
+}
+
+bool batch_aligned(const BatchRef& b, size_t align, size_t elem) {
+    if (!b.listed())
+        return reinterpret_cast<uintptr_t>(b.src) % align == 0 && reinterpret_cast<uintptr_t>(b.dst) % align == 0 &&
+               (b.n <= 1 || ((uint64_t)b.ss * elem % align == 0 && (uint64_t)b.ds * elem % align == 0));
+    for (int k = 0; k < b.n; ++k)
+        if (reinterpret_cast<uintptr_t>(b.srcs[k]) % align || reinterpret_cast<uintptr_t>(b.dsts[k]) % align) return false;
+    return true;
+}
+
 }  // namespace kh
 
 using namespace kh;
@@ -289,9 +309,11 @@ int32_t kh_stream_fence(kh_stream_t producer, kh_stream_t consumer) {
     hipEvent_t e = nullptr;
     hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
     if (r == hipSuccess) r = hipEventRecord(e, as_hip(producer));
-    if (r == hipSuccess) r = hipStreamWaitEvent(as_hip(consumer), e, 0);
-    const hipError_t d = e ? hipEventDestroy(e) : hipSuccess;  // safe: the wait keeps its own reference
+    // back on the CALLER's device before the wait: a NULL consumer is the caller's current-device null stream, as the header says —
+    // waiting while the producer's device is current would order that device's null stream instead
     const hipError_t b = hop ? hipSetDevice(prev) : hipSuccess;
+    if (r == hipSuccess && b == hipSuccess) r = hipStreamWaitEvent(as_hip(consumer), e, 0);
+    const hipError_t d = e ? hipEventDestroy(e) : hipSuccess;  // safe: the wait keeps its own reference
     if (r != hipSuccess) return fail_hip(r, "kh_stream_fence");
     if (d != hipSuccess) return fail_hip(d, "kh_stream_fence(destroy)");
     if (b != hipSuccess) return fail_hip(b, "kh_stream_fence(restore device)");

@@ -123,6 +123,7 @@ SIGNATURES = {
     "kh_memset_async": (_i32, [_vp, _i32, _sz, _vp]),
     "kh_pointer_domain": (_i32, [_vp, _P(_i32), _P(_i32)]),
     "kh_preprocess_to_chw": (_i32, [_vp, _vp, _vp, _P(PreprocessParams)]),
+    "kh_preprocess_to_chw_list": (_i32, [_vp, _P(_vp), _vp, _P(PreprocessParams)]),
     "kh_preprocess_variant": (C.c_char_p, [_P(PreprocessParams)]),
     # colour
     **{n: (_i32, [_vp, _vp, _vp, _i64]) for n in (
@@ -150,6 +151,12 @@ SIGNATURES = {
     "kh_warp_affine_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i32, _i64, _i64]),
     "kh_warp_perspective_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32, _i32, _i64, _i64]),
     "kh_remap_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    # pointer-list batches: (stream, srcs[n], dsts[n], n, ...) — host arrays of device pointers (`pointer_array`)
+    "kh_resize_f32_list": (_i32, [_vp, _P(_vp), _P(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "kh_resize_bilinear_normalize_f32_list": (_i32, [_vp, _P(_vp), _P(_vp), _i32, _i32, _i32, _i32, _i32, _P(_f32), _P(_f32), _i32]),
+    "kh_warp_affine_f32_list": (_i32, [_vp, _P(_vp), _P(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32]),
+    "kh_warp_perspective_f32_list": (_i32, [_vp, _P(_vp), _P(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _P(_f32), _i32]),
+    "kh_remap_f32_list": (_i32, [_vp, _P(_vp), _vp, _vp, _P(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "kh_correction_map_polynomial_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _P(C.c_double), _P(C.c_double)]),
     "kh_invert_affine_transform": (None, [_P(_f32), _P(_f32)]),
     "kh_get_rotation_matrix2d": (None, [_f32, _f32, _f32, _f32, _P(_f32)]),
@@ -159,6 +166,10 @@ SIGNATURES = {
     "kh_gaussian_blur_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i64, _i64]),
     "kh_box_blur_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
     "kh_gradient_magnitude_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "kh_separable_filter_f32_list": (_i32, [_vp, _P(_vp), _P(_vp), _i32, _i32, _i32, _i32, _P(_f32), _i32, _P(_f32), _i32]),
+    "kh_gaussian_blur_f32_list": (_i32, [_vp, _P(_vp), _P(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32]),
+    "kh_box_blur_f32_list": (_i32, [_vp, _P(_vp), _P(_vp), _i32, _i32, _i32, _i32, _i32, _i32]),
+    "kh_gradient_magnitude_f32_list": (_i32, [_vp, _P(_vp), _P(_vp), _i32, _i32, _i32, _i32, _i32, _i32]),
     "kh_spatial_gradient_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
     "kh_box_blur_fast_kernels_1d": (_i32, [_f32, _i32, _P(_i32)]),
     "kh_fast_horizontal_filter_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64]),
@@ -199,6 +210,12 @@ SIGNATURES = {
     "kh_crop": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "kh_flip": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32]),
 }
+
+
+def pointer_array(ptrs):
+    """A host ``void*[n]`` for the ``*_list`` entry points: the device pointers of separately allocated images / frames.  The
+    library reads it during the call only (the bases travel in the kernel arguments), so a temporary is fine."""
+    return (C.c_void_p * len(ptrs))(*ptrs)
 
 
 def mapped_hip_runtimes() -> dict:

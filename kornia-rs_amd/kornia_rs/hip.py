@@ -69,6 +69,12 @@ def _operand_device(obj) -> Optional[int]:
     anything carrying a ``stream``, a Stream."""
     if isinstance(obj, Stream):
         return obj.device
+    if isinstance(obj, (list, tuple)):     # a batch of images / frames (imgproc.*_batch, run_raw_batch): its first device operand
+        for item in obj:
+            d = _operand_device(item)
+            if d is not None:
+                return d
+        return None
     if getattr(obj, "is_device", False) and hasattr(obj, "device_id"):
         return int(obj.device_id)
     st = getattr(obj, "stream", None)
@@ -99,15 +105,14 @@ def on_operand_device(fn):
                     break
         if dev is None:
             return fn(*args, **kwargs)
-        guard = _device_guard(dev)
         try:
-            guard.__enter__()
+            current_device()
         except _ffi.KorniaHipError:      # no usable device at all: let the operator report its own typed error (residency, KH_ERR_HIP)
             return fn(*args, **kwargs)
-        try:
+        # a device exists: failing to select the operand's one is an error of THIS layer — running the operator with another device
+        # current would file its table caches, workspace lookups and NULL-stream meaning under the wrong device
+        with _device_guard(dev):
             return fn(*args, **kwargs)
-        finally:
-            guard.__exit__(None, None, None)
 
     return bound
 
@@ -180,7 +185,11 @@ class Stream:
         raise TypeError(f"cannot adopt a stream from {type(obj).__name__}")
 
     def synchronize(self) -> None:
-        check(lib.kh_stream_synchronize(self._handle))
+        if self._handle:
+            check(lib.kh_stream_synchronize(self._handle))
+        else:   # the NULL handle means "the CURRENT device's default stream": Stream.default(1).synchronize() from a device-0 thread
+            with _device_guard(self.device):
+                check(lib.kh_stream_synchronize(0))
 
     def set_workspace(self, buf: Optional["DeviceBuffer"]) -> None:
         """Register ``buf`` as the scratch the operators with an intermediate (separable u8 resize, wide u8 blurs, u8 warps,
@@ -245,13 +254,24 @@ _WORKSPACES: dict = {}
 
 
 class Event:
-    def __init__(self, timing: bool = True):
+    """``device``: the device the event belongs to (HIP refuses to record an event on another device's stream); default = the
+    calling thread's current device."""
+
+    def __init__(self, timing: bool = True, device: Optional[int] = None):
         h = C.c_void_p(0)
-        check(lib.kh_event_create(C.byref(h), 1 if timing else 0))
+        if device is None:
+            check(lib.kh_event_create(C.byref(h), 1 if timing else 0))
+        else:
+            with _device_guard(device):
+                check(lib.kh_event_create(C.byref(h), 1 if timing else 0))
         self._handle = h.value
 
     def record(self, stream: Stream) -> None:
-        check(lib.kh_event_record(self._handle, stream.cuda_stream_ptr))
+        if stream.cuda_stream_ptr:
+            check(lib.kh_event_record(self._handle, stream.cuda_stream_ptr))
+        else:   # NULL handle: the default stream of the STREAM's device, not of whichever device is current
+            with _device_guard(stream.device):
+                check(lib.kh_event_record(self._handle, 0))
 
     def synchronize(self) -> None:
         check(lib.kh_event_synchronize(self._handle))
@@ -283,14 +303,15 @@ class Graph:
     def capture(f, retain, stream: Optional[Stream] = None) -> "Graph":
         if stream is None or not stream.cuda_stream_ptr:
             raise _ffi.KorniaHipError(_ffi.KH_ERR_INVALID_ARG, "Graph.capture: capture needs a non-default stream (Stream.new())")
-        check(lib.kh_graph_capture_begin(stream.cuda_stream_ptr))
-        error = None
-        try:
-            f()
-        except BaseException as e:  # always end the capture so the stream is usable again, then surface the error
-            error = e
-        handle = C.c_void_p()
-        rc = lib.kh_graph_capture_end(stream.cuda_stream_ptr, C.byref(handle))
+        with _device_guard(stream.device):   # the capture, the captured launches and the instantiation all belong to the stream's device
+            check(lib.kh_graph_capture_begin(stream.cuda_stream_ptr))
+            error = None
+            try:
+                f()
+            except BaseException as e:  # always end the capture so the stream is usable again, then surface the error
+                error = e
+            handle = C.c_void_p()
+            rc = lib.kh_graph_capture_end(stream.cuda_stream_ptr, C.byref(handle))
         if error is not None:
             if rc == _ffi.KH_OK:
                 lib.kh_graph_destroy(handle)
@@ -303,7 +324,8 @@ class Graph:
         return Graph(handle.value, stream, retain)
 
     def replay(self) -> None:
-        check(lib.kh_graph_launch(self._handle, self.stream.cuda_stream_ptr))
+        with _device_guard(self.stream.device):
+            check(lib.kh_graph_launch(self._handle, self.stream.cuda_stream_ptr))
 
     def __del__(self):
         h, self._handle = getattr(self, "_handle", None), None

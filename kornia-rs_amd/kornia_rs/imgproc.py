@@ -540,6 +540,148 @@ def remap(src: Image, map_x: Image, map_y: Image, interpolation: str = "bilinear
     return dst
 
 
+# ---- batches of separately allocated images ------------------------------------------------------------
+# The reference's operators take one `&Image` per call (P/resize/mod.rs:114-132, P/warp/affine.rs:123, P/warp/perspective.rs:115,
+# P/interpolation/remap.rs:43, P/filter/ops.rs:39,116), so a batch is a host loop of launches — 256 launches of a 2 us kernel for
+# BASELINE configs[1] — which kornia-py amortises with a captured graph (kornia-py/src/cuda_ext/mod.rs:1684-1790; here `hip.Graph`).
+# The `*_batch` forms take the SAME operands as N calls would — lists of independent `Image`s, wherever each was allocated — and hand
+# their device pointers to the `kh_*_list` entry points: one launch per 128 images, the (src, dst) bases in the kernel arguments.
+# Results equal those of the N single calls bit for bit (tests/test_list_batches_gpu.py).
+
+def _batch_pairs(srcs: Sequence[Image], outs: Optional[Sequence[Image]], new_size: Optional[Tuple[int, int]], what: str,
+                 channels: Tuple[int, ...] = (1, 3, 4)):
+    """Validate N (source, destination) pairs of one batch — same size / dtype / channel count on each side, every image
+    device-resident on ONE device — allocate missing destinations on their source's stream, and return
+    ``(outs, exec, src_ptrs, dst_ptrs)``: the launch goes on the FIRST source's stream with every other operand stream fenced in
+    (and back by ``exec.check``), exactly what N single calls on that stream would order."""
+    srcs = list(srcs)
+    if not srcs:
+        raise ImageError("InvalidArgument", f"{what}: empty batch")
+    first = srcs[0]
+    _pair_residency(first, *srcs[1:])   # mixed host / device sources, host-only batches, device mismatch: typed, before anything is allocated
+    for im in srcs:
+        _require(im, "float32", channels, what)
+        if im.size != first.size or im.channels != first.channels:
+            raise ImageError("InvalidImageSize", f"{what}: every source of a batch must be {first.width}x{first.height}x{first.channels}, "
+                                                 f"got {im.width}x{im.height}x{im.channels}")
+    if outs is None:
+        if new_size is None:
+            new_size = (first.height, first.width)
+        h, w = new_size  # the Python API takes (height, width)
+        outs = [_new_like(im, size=(w, h)) for im in srcs]
+    outs = list(outs)
+    if len(outs) != len(srcs):
+        raise ImageError("InvalidArgument", f"{what}: {len(srcs)} sources but {len(outs)} destinations")
+    for o in outs:
+        _require(o, "float32", (first.channels,), what)
+        if o.size != outs[0].size:
+            raise ImageError("InvalidImageSize", f"{what}: every destination of a batch must have the same size")
+    ex = _pair_residency(first, *srcs[1:], *outs)
+    return outs, ex, _ffi.pointer_array([im.data_ptr for im in srcs]), _ffi.pointer_array([o.data_ptr for o in outs])
+
+
+def resize_batch(srcs: Sequence[Image], new_size: Optional[Tuple[int, int]] = None, interpolation: str = "bilinear",
+                 outs: Optional[Sequence[Image]] = None, mapping: str = "half_pixel") -> list:
+    """``resize`` of N separately allocated float32 images in ceil(N / 128) launches (``new_size`` = (height, width))."""
+    mode = _interp(interpolation)
+    outs, ex, sp, dp = _batch_pairs(srcs, outs, new_size, "resize_batch")
+    s0, d0 = srcs[0], outs[0]
+    ex.check(lib.kh_resize_f32_list(ex.cuda_stream_ptr, sp, dp, len(outs), s0.width, s0.height, d0.width, d0.height, s0.channels,
+                                    mode, _mapping(mapping)))
+    return outs
+
+
+def warp_affine_batch(srcs: Sequence[Image], m: Sequence[float], new_size: Optional[Tuple[int, int]] = None,
+                      interpolation: str = "bilinear", outs: Optional[Sequence[Image]] = None) -> list:
+    mode = _interp(interpolation)
+    outs, ex, sp, dp = _batch_pairs(srcs, outs, new_size, "warp_affine_batch")
+    s0, d0 = srcs[0], outs[0]
+    ex.check(lib.kh_warp_affine_f32_list(ex.cuda_stream_ptr, sp, dp, len(outs), s0.width, s0.height, d0.width, d0.height, s0.channels,
+                                         _matrix(m, 6, "warp_affine_batch"), mode))
+    return outs
+
+
+def warp_perspective_batch(srcs: Sequence[Image], m: Sequence[float], new_size: Optional[Tuple[int, int]] = None,
+                           interpolation: str = "bilinear", outs: Optional[Sequence[Image]] = None) -> list:
+    mode = _interp(interpolation)
+    mm = _matrix(m, 9, "warp_perspective_batch")
+    inv = (C.c_float * 9)()
+    _check(lib.kh_invert_homography(mm, inv))  # singular matrices are rejected before anything is allocated
+    outs, ex, sp, dp = _batch_pairs(srcs, outs, new_size, "warp_perspective_batch")
+    s0, d0 = srcs[0], outs[0]
+    ex.check(lib.kh_warp_perspective_f32_list(ex.cuda_stream_ptr, sp, dp, len(outs), s0.width, s0.height, d0.width, d0.height,
+                                              s0.channels, mm, mode))
+    return outs
+
+
+def remap_batch(srcs: Sequence[Image], map_x: Image, map_y: Image, interpolation: str = "bilinear",
+                outs: Optional[Sequence[Image]] = None) -> list:
+    """``remap`` of N images through ONE pair of maps (one camera): the maps are read once per four images."""
+    mode = _interp(interpolation)
+    if map_x.size != map_y.size:
+        raise ImageError("InvalidImageSize", "map_x and map_y must have the same size")
+    for mp in (map_x, map_y):
+        _require(mp, "float32", (1,), "remap map")
+    if not (map_x.is_device and map_y.is_device):
+        raise ImageError("Hip", "remap: map_x and map_y must be device-resident when src/dst are on GPU")
+    outs, ex, sp, dp = _batch_pairs(srcs, outs, (map_x.height, map_x.width), "remap_batch")
+    s0, d0 = srcs[0], outs[0]
+    if d0.size != map_x.size:
+        raise ImageError("InvalidImageSize", "dst must have the size of the maps")
+    for mp in (map_x, map_y):
+        ex.join(mp.stream)
+    ex.check(lib.kh_remap_f32_list(ex.cuda_stream_ptr, sp, map_x.data_ptr, map_y.data_ptr, dp, len(outs), s0.width, s0.height,
+                                   d0.width, d0.height, s0.channels, mode))
+    return outs
+
+
+def _same_size_batch(srcs, outs, what):
+    outs, ex, sp, dp = _batch_pairs(srcs, outs, None, what, channels=tuple(range(1, 9)))
+    if outs[0].size != srcs[0].size:
+        raise ImageError("InvalidImageSize", f"{what}: destinations must have the sources' size")
+    return outs, ex, sp, dp
+
+
+def gaussian_blur_batch(srcs: Sequence[Image], kernel_size: Tuple[int, int], sigma: Tuple[float, float],
+                        outs: Optional[Sequence[Image]] = None) -> list:
+    k = (C.c_int32 * 2)(*kernel_size)
+    s = (C.c_float * 2)(*sigma)
+    if lib.kh_gaussian_resolve(k, s) != _ffi.KH_OK:
+        raise ImageError("InvalidSigmaValue", _ffi.last_error())
+    outs, ex, sp, dp = _same_size_batch(srcs, outs, "gaussian_blur_batch")
+    s0 = srcs[0]
+    ex.check(lib.kh_gaussian_blur_f32_list(ex.cuda_stream_ptr, sp, dp, len(outs), s0.width, s0.height, s0.channels, kernel_size[0],
+                                           kernel_size[1], sigma[0], sigma[1]))
+    return outs
+
+
+def box_blur_batch(srcs: Sequence[Image], kernel_size: Tuple[int, int], outs: Optional[Sequence[Image]] = None) -> list:
+    outs, ex, sp, dp = _same_size_batch(srcs, outs, "box_blur_batch")
+    s0 = srcs[0]
+    ex.check(lib.kh_box_blur_f32_list(ex.cuda_stream_ptr, sp, dp, len(outs), s0.width, s0.height, s0.channels, kernel_size[0], kernel_size[1]))
+    return outs
+
+
+def sobel_batch(srcs: Sequence[Image], kernel_size: int = 3, outs: Optional[Sequence[Image]] = None) -> list:
+    if kernel_size not in (3, 5):
+        raise ImageError("InvalidKernelLength", f"sobel_batch: invalid kernel length ({kernel_size}, {kernel_size})")
+    outs, ex, sp, dp = _same_size_batch(srcs, outs, "sobel_batch")
+    s0 = srcs[0]
+    ex.check(lib.kh_gradient_magnitude_f32_list(ex.cuda_stream_ptr, sp, dp, len(outs), s0.width, s0.height, s0.channels,
+                                                _ffi.KH_GRAD_SOBEL, kernel_size))
+    return outs
+
+
+def separable_filter_batch(srcs: Sequence[Image], kernel_x: Sequence[float], kernel_y: Sequence[float],
+                           outs: Optional[Sequence[Image]] = None) -> list:
+    kx, ky = np.asarray(kernel_x, np.float32), np.asarray(kernel_y, np.float32)
+    outs, ex, sp, dp = _same_size_batch(srcs, outs, "separable_filter_batch")
+    s0 = srcs[0]
+    ex.check(lib.kh_separable_filter_f32_list(ex.cuda_stream_ptr, sp, dp, len(outs), s0.width, s0.height, s0.channels,
+                                              (C.c_float * kx.size)(*kx), kx.size, (C.c_float * ky.size)(*ky), ky.size))
+    return outs
+
+
 def generate_correction_map_polynomial(intrinsic: Sequence[float], distortion: Sequence[float], size: Tuple[int, int],
                                        stream: Stream) -> Tuple[Image, Image]:
     """``intrinsic`` = (fx, fy, cx, cy), ``distortion`` = (k1..k6, p1, p2), ``size`` = (width, height);

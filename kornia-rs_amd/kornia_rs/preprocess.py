@@ -453,14 +453,17 @@ class Preprocessor:
                 f"invalid raw source for {f.name} at {w}x{h} (got {got} bytes, need {need})",
                 format=f.name, width=w, height=h, got=got, need=need)
 
-    def _launch(self, src_ptr: int, dst: Tensor, p: PreprocessParams) -> None:
+    def _launch(self, src_ptr: Optional[int], dst: Tensor, p: PreprocessParams, frame_ptrs: Optional[Sequence[int]] = None) -> None:
         # Launch on the preprocessor's stream.  If dst carries another stream it is fenced in before the launch and the
         # launch stream is fenced back into it afterwards (DeviceExec::for_streams + run, P/cuda/dispatch.rs:50-82), so
         # dst's own stream — its numpy(), the next op that reads it, its stream-ordered free — is ordered after the kernel.
         other = dst.stream is not None and dst.stream.cuda_stream_ptr != self.stream.cuda_stream_ptr
         if other:
             check(lib.kh_stream_fence(dst.stream.cuda_stream_ptr, self.stream.cuda_stream_ptr))
-        check(lib.kh_preprocess_to_chw(self.stream.cuda_stream_ptr, src_ptr, dst.data_ptr, C.byref(p)))
+        if frame_ptrs is not None:
+            check(lib.kh_preprocess_to_chw_list(self.stream.cuda_stream_ptr, _ffi.pointer_array(frame_ptrs), dst.data_ptr, C.byref(p)))
+        else:
+            check(lib.kh_preprocess_to_chw(self.stream.cuda_stream_ptr, src_ptr, dst.data_ptr, C.byref(p)))
         if other:
             check(lib.kh_stream_fence(self.stream.cuda_stream_ptr, dst.stream.cuda_stream_ptr))
 
@@ -493,8 +496,9 @@ class Preprocessor:
 
         ``frames`` is either a sequence of per-frame device buffers (the reference signature) or
         ONE device buffer holding ``N`` frames ``frame_stride`` bytes apart.  Equally-spaced
-        frames go out as a single batched launch; otherwise one launch per frame, like the
-        reference.
+        frames go out as a single launch; separately allocated ones as one launch per 256 frames
+        (``kh_preprocess_to_chw_list``: the frame bases travel in the kernel arguments) — the
+        reference launches once per frame (:1277-1280).
 
         ``devices=[g0, g1, ...]`` shards the batch across GPUs in this process (contiguous slices, one
         host thread + one stream per device, no collective): ``frames`` is then a host ``[N, frame_bytes]`` uint8 array /
@@ -544,14 +548,10 @@ class Preprocessor:
                              stride, want_f16, _force_generic)
             self._launch(ptrs[0], dst, p)
         else:
-            item = 2 if want_f16 else 4
-            plane = 3 * dw * dh
-            for k, ptr in enumerate(ptrs):
-                view = Tensor((1, 3, dh, dw), dst.dtype, device_ptr=dst.data_ptr + k * plane * item,
-                              device=dst.device_id, stream=dst.stream, keepalive=dst)
-                p = self._params(src_w, src_h, f.pitch(src_w), f.bpp, f.fmt_code, dw, dh, 1, 0,
-                                 want_f16, _force_generic)
-                self._launch(ptr, view, p)
+            # separately allocated frame buffers — the reference's own signature (&[&CudaSlice<u8>]): the bases go to the
+            # library as a host pointer array and out as ceil(N / 256) launches (kh_preprocess_to_chw_list), not N
+            p = self._params(src_w, src_h, f.pitch(src_w), f.bpp, f.fmt_code, dw, dh, len(ptrs), 0, want_f16, _force_generic)
+            self._launch(None, dst, p, frame_ptrs=ptrs)
 
     def run_surface(self, data: RawSource, width: int, height: int, row_pitch: int, channels: int,
                     dst: Tensor) -> None:

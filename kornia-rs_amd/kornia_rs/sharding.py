@@ -106,6 +106,13 @@ class ShardPool:
         if getattr(self, "_closed", False):
             return
         self._closed = True
+        if threading.current_thread().name.startswith("kornia-shard"):
+            # close() running ON one of the pool's own workers (e.g. a finaliser the collector ran there): the barrier below could only
+            # ever see world - 1 parties and shutdown(wait=True) would join the calling thread.  Let go of what this thread holds and
+            # shut down without waiting; the other workers release their buffers when their threads end.
+            hip.release_thread_staging()
+            self._pool.shutdown(wait=False)
+            return
         barrier = threading.Barrier(self.world)
 
         def release(_g: int):

@@ -47,8 +47,10 @@ _ensure_built()
 @pytest.fixture
 def dev_option():
     """Force one of the library's alternate code paths for the duration of a test: `dev_option("pre_grid", 0)`
-    (kh_debug_set_option, include/kornia_hip.h).  Everything set is restored to the production choice afterwards.  The options are
-    process-wide; pytest-xdist workers are separate processes."""
+    (kh_debug_set_option, include/kornia_hip_testing.h).  Everything set is restored to the production choice afterwards.  The options
+    are PER THREAD (kh_runtime.hip::g_dev_opts): they reroute the launches of the thread that set them — this test's main thread — and
+    nothing launched from another thread (a ShardPool worker, a thread the test starts).  A test that needs a forced path on pool
+    threads sets the option inside the worker (e.g. `pool._each(lambda g: set_option(...))`)."""
     from kornia_rs import _ffi
     touched = []
 

@@ -116,6 +116,21 @@ def test_preprocess_null_and_empty():
     assert _ffi.lib.kh_preprocess_variant(C.byref(_params(dst_w=7, dst_h=5, sampling=_ffi.KH_SAMPLE_NEAREST))) == b"generic"
 
 
+def test_preprocess_list_validation():
+    """kh_preprocess_to_chw_list: the frame list is checked on the host before anything is launched; an empty batch needs nothing."""
+    from kornia_rs import _ffi
+    p = _params(nframes=3)
+    frames = _ffi.pointer_array([64, 0, 192])
+    assert _ffi.lib.kh_preprocess_to_chw_list(None, frames, C.c_void_p(64), C.byref(p)) == -1
+    assert "list index 1" in _ffi.last_error()
+    assert _ffi.lib.kh_preprocess_to_chw_list(None, None, C.c_void_p(64), C.byref(p)) == -1
+    assert "null frame list" in _ffi.last_error()
+    assert _ffi.lib.kh_preprocess_to_chw_list(None, frames, None, C.byref(p)) == -1
+    assert _ffi.lib.kh_preprocess_to_chw_list(None, frames, C.c_void_p(64), None) == -1
+    p.nframes = 0
+    assert _ffi.lib.kh_preprocess_to_chw_list(None, None, None, C.byref(p)) == 0
+
+
 def test_no_device_fails_loudly_not_silently():
     """On a box without a GPU the runtime entry points return KH_ERR_HIP with a message — the
     product never computes on the CPU instead."""

@@ -17,6 +17,7 @@ SING = (C.c_float * 9)(1, 2, 3, 2, 4, 6, 3, 6, 9)
 K3 = (C.c_float * 3)(0.25, 0.5, 0.25)
 MASK = (C.c_uint8 * 9)(*[1] * 9)
 D4, D8 = (C.c_double * 4)(), (C.c_double * 8)()
+PA = lambda *ptrs: _ffi.pointer_array(list(ptrs))  # noqa: E731  a host void*[n] of fake device addresses
 INVALID, UNSUPPORTED, TOO_LARGE, SINGULAR = _ffi.KH_ERR_INVALID_ARG, _ffi.KH_ERR_UNSUPPORTED, _ffi.KH_ERR_TOO_LARGE, _ffi.KH_ERR_SINGULAR
 
 CASES = [
@@ -47,6 +48,22 @@ CASES = [
     ("separable: empty kernel", lambda: L.kh_separable_filter_f32(S, P, Q, 8, 8, 3, K3, 3, K3, 0, 1, 0, 0), INVALID, "kernel length"),
     ("gradient: unknown kind", lambda: L.kh_gradient_magnitude_f32(S, P, Q, 8, 8, 3, 9, 3, 1, 0, 0), INVALID, "kind 9"),
     ("gradient: sobel size 4", lambda: L.kh_gradient_magnitude_f32(S, P, Q, 8, 8, 3, 0, 4, 1, 0, 0), INVALID, "kernel length"),
+    # ---- pointer-list batches (round 6): host arrays of device pointers, checked before any launch
+    ("resize_list: null lists", lambda: L.kh_resize_f32_list(S, None, None, 2, 8, 8, 4, 4, 3, 1, 0), INVALID, "null pointer list"),
+    ("resize_list: null entry", lambda: L.kh_resize_f32_list(S, PA(P, 0), PA(Q, R3), 2, 8, 8, 4, 4, 3, 1, 0), INVALID, "list index 1"),
+    ("resize_list: src == dst", lambda: L.kh_resize_f32_list(S, PA(P, Q), PA(R3, Q), 2, 8, 8, 4, 4, 3, 1, 0), INVALID, "alias"),
+    ("resize_list: > 65535 images", lambda: L.kh_resize_f32_list(S, PA(P), PA(Q), 70000, 8, 8, 4, 4, 3, 1, 0), TOO_LARGE, "65535"),
+    ("resize_list: 2 channels", lambda: L.kh_resize_f32_list(S, PA(P), PA(Q), 1, 8, 8, 4, 4, 2, 1, 0), UNSUPPORTED, "2 channels"),
+    ("resize_list: unknown mapping", lambda: L.kh_resize_f32_list(S, PA(P), PA(Q), 1, 8, 8, 4, 4, 3, 1, 5), INVALID, "mapping 5"),
+    ("resize_normalize_list: zero std", lambda: L.kh_resize_bilinear_normalize_f32_list(S, PA(P), PA(Q), 1, 8, 8, 4, 4, K3, (C.c_float * 3)(1, 0, 1), 0), INVALID, "non-zero"),
+    ("warp_affine_list: null matrix", lambda: L.kh_warp_affine_f32_list(S, PA(P), PA(Q), 1, 8, 8, 8, 8, 3, None, 1), INVALID, "matrix"),
+    ("warp_perspective_list: singular", lambda: L.kh_warp_perspective_f32_list(S, PA(P), PA(Q), 1, 8, 8, 8, 8, 3, SING, 1), SINGULAR, "determinant"),
+    ("remap_list: null map", lambda: L.kh_remap_f32_list(S, PA(P), None, P, PA(Q), 1, 8, 8, 8, 8, 3, 1), INVALID, "map"),
+    ("gaussian_list: even kernel", lambda: L.kh_gaussian_blur_f32_list(S, PA(P), PA(Q), 1, 8, 8, 3, 4, 3, 1.0, 1.0), INVALID, "sigma"),
+    ("gaussian_list: in place", lambda: L.kh_gaussian_blur_f32_list(S, PA(P), PA(P), 1, 8, 8, 3, 3, 3, 1.0, 1.0), INVALID, "alias"),
+    ("box_list: > 63 taps", lambda: L.kh_box_blur_f32_list(S, PA(P), PA(Q), 1, 8, 8, 3, 65, 3), UNSUPPORTED, "63"),
+    ("separable_list: empty kernel", lambda: L.kh_separable_filter_f32_list(S, PA(P), PA(Q), 1, 8, 8, 3, K3, 3, K3, 0), INVALID, "kernel length"),
+    ("gradient_list: sobel size 4", lambda: L.kh_gradient_magnitude_f32_list(S, PA(P), PA(Q), 1, 8, 8, 3, 0, 4), INVALID, "kernel length"),
     # ---- the rest of the filter module
     ("spatial_gradient: unknown kind", lambda: L.kh_spatial_gradient_f32(S, P, Q, R3, 8, 8, 3, 4, 1, 0, 0), INVALID, "kind 4"),
     ("spatial_gradient: dx aliases src", lambda: L.kh_spatial_gradient_f32(S, P, P, Q, 8, 8, 3, 0, 1, 0, 0), INVALID, "distinct"),

@@ -16,14 +16,16 @@ def _bench():
 
 
 def _fake(name):
-    return {"value": 482690.2, "unit": "Mpixels/s", "steps": 10, "warmup": 2, "ms_per_step": 19.5512, "dtype": "f32",
+    return {"key": name, "value": 482690.2, "unit": "Mpixels/s", "steps": 10, "warmup": 2, "ms_per_step": 19.5512, "dtype": "f32",
             "config": {"workload": name, "op": "x" * 120, "src": "3840x2160x3 f32", "dst": "same", "batch_per_gpu": 256,
                        "parallelism": "batch-sharded, no collective"},
             "roofline": {"bound": "hbm", "achieved": 6081.3, "peak": 8000.0, "unit": "GB/s", "frac": 0.7602, "traffic": 98012345678,
                          "kernel": "remap_kernel<3,bilinear>+warp_perspective_kernel<3,bilinear>", "alg_bytes_per_launch": 118908518400,
-                         "mean_launch_ms": 19.5512, "min_launch_ms": 19.4, "traffic_GBps": 5012.2, "traffic_frac": 0.6265},
+                         "mean_launch_ms": 19.5512, "min_launch_ms": 19.4, "traffic_frac": None, "traffic_over_alg": 1.035, "floor_bytes": 2812345678,
+                         "floor_GBps": 6012.2, "floor_frac": 0.7515},
             "n_gpus": 1,
-            "cpu_baseline": {"value": 219.33, "unit": "Mpixels/s", "cores": 128, "kind": "port", "sample": "y" * 200}}
+            "cpu_baseline": {"value": 219.33, "unit": "Mpixels/s", "cores": 128, "kind": "port", "sample": "y" * 200, "threads": 128, "team_threads": 16,
+                             "cgroup_cpus": 16.0, "physical_cores": 128, "affinity_cpus": 256}}
 
 
 def test_line_fits_the_drivers_tail_and_ends_with_the_summary():
@@ -36,6 +38,7 @@ def test_line_fits_the_drivers_tail_and_ends_with_the_summary():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (LCG bytes, reference pattern_u8; frame k shifted by 31k)",
             "config": head["config"], "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"]}
     line["device"] = {"name": "AMD Instinct MI355X", "cus": 256, "hbm_bytes": 309220868096, "host_cpus": 128, "hip_runtime": "z" * 80,
+                      "cpu_team": {"threads": 16, "physical_cores": 128, "affinity_cpus": 256, "cgroup_cpus": 16.0, "logical_cpus": 256},
                       "flat_fill_ms": 3.55, "three_plane_store_only_ms": 4.04, "store_bytes": 25480396800, "frac_of_flat_fill": 0.82,
                       "frac_of_three_plane_store": 0.93, "note": "n" * 230}
     line["traffic_source"] = "t" * 260

@@ -66,15 +66,16 @@ def test_north_star_workloads(gpu_stream, bench, name, size, fmt):
                                  f"[{flat[0]}, {flat[-1]}]; got {got[k].reshape(-1)[flat[:4]].tolist()} want {want.reshape(-1)[flat[:4]].tolist()}")
 
 
-@pytest.mark.parametrize("name", ["nv12_h2d_preprocess", "nv12_h2d_preprocess_pageable"])
+@pytest.mark.parametrize("name", ["nv12_h2d_preprocess", "nv12_h2d_preprocess_zero_copy"])
 def test_h2d_preprocess_workload(gpu_stream, bench, name):
     """The capture-side workload: four steps through the upload ring (so both slots and a reused capture buffer are exercised); the
     last step's output equals the oracle on the frames of the capture buffer it consumed."""
     wl = bench.WORKLOADS[name](_Args)
     wl.setup(gpu_stream)
-    for _ in range(4):
+    for _ in range(wl.RING + 1):
         wl.step()
     gpu_stream.synchronize()
+    assert wl.pageable == (name == "nv12_h2d_preprocess")   # the default row is the copy-into-the-ring contract; zero-copy is the opt-in
     got = _out(wl, np.float32, (3, wl.H, wl.W))
     b = (wl.turn - 1) % wl.RING
     for k in range(wl.N):
@@ -83,6 +84,46 @@ def test_h2d_preprocess_workload(gpu_stream, bench, name):
         assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), (name, k)
     extra = wl.roofline_extra(1e-3)   # (the host simulator's events have no resolution: only the keys are checked there)
     assert {"h2d_only_ms", "kernel_only_ms", "end_to_end_ms", "hidden_by_overlap_ms", "end_to_end_frac_of_pinned_h2d"} <= set(extra)
+
+
+def test_frame_list_workload(gpu_stream, bench):
+    """The north star through the reference's batch signature (a list of separately allocated frame buffers): same bits."""
+    wl = _run(bench, "nv12_chw_list", gpu_stream)
+    assert wl.kernel == "preprocess_nv12_identity_list" and wl.alg_bytes_per_launch == wl.N * (wl.frame_bytes + 12 * wl.W * wl.H)
+    got = _out(wl, np.float32, (3, wl.H, wl.W))
+    for k in range(wl.N):
+        want = O.preprocess(wl.base[31 * k: 31 * k + wl.frame_bytes], wl.W, wl.H, wl.W, wl.H, fmt="nv12", mode="stretch", mean=MEAN, std=STD)[0]
+        assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), k
+
+
+@pytest.mark.parametrize("how", ["eager", "graph", "list"])
+def test_resize_api_workloads(gpu_stream, bench, how):
+    """configs[1] through imgproc.resize / hip.Graph / imgproc.resize_batch on separately allocated Images; ROTATE + 1 steps so that
+    every rotating destination set (and every captured graph) has run and the first one has been rewritten."""
+    wl = bench.WORKLOADS[f"resize_224_api_{how}"](_Args)
+    wl.setup(gpu_stream)
+    for _ in range(wl.ROTATE + 1):
+        wl.step()
+    gpu_stream.synchronize()
+    n = wl.SW * wl.SH * wl.C
+    for dst in wl.dsts:
+        got = dst.to_numpy(np.float32, (wl.N, wl.DH, wl.DW, wl.C))
+        for k in range(wl.N):
+            assert np.array_equal(got[k], O.resize(_frame(wl, k, n, (wl.SH, wl.SW, wl.C)), wl.DW, wl.DH)), (how, k)
+
+
+def test_list_workloads_4k(gpu_stream, bench):
+    wl = _run(bench, "gaussian_4k_api_list", gpu_stream)
+    n = wl.W * wl.H * wl.C
+    got = _out(wl, np.float32, (wl.H, wl.W, wl.C))
+    for k in range(wl.N):
+        assert np.array_equal(got[k], O.gaussian_blur(_frame(wl, k, n, (wl.H, wl.W, wl.C)), (7, 7), (1.5, 1.5))), k
+    wl = _run(bench, "undistort_warp_4k_api_list", gpu_stream)
+    mx, my = O.correction_map(wl.INTR, wl.DIST, wl.W, wl.H)
+    got = _out(wl, np.float32, (wl.H, wl.W, wl.C))
+    for k in range(wl.N):
+        want = O.warp_perspective(O.remap(_frame(wl, k, n, (wl.H, wl.W, wl.C)), mx, my), wl.hm, wl.W, wl.H)
+        assert np.array_equal(got[k], want), k
 
 
 def test_lanczos_secondary_workload(gpu_stream, bench):
@@ -100,6 +141,10 @@ def test_resize_workloads(gpu_stream, bench):
     got = _out(wl, np.float32, (wl.DH, wl.DW, wl.C))
     for k in range(wl.N):
         assert np.array_equal(got[k], O.resize(_frame(wl, k, n, (wl.SH, wl.SW, wl.C)), wl.DW, wl.DH)), k
+    # the line-granular floor (roofline.floor_bytes): between the tap bytes (alg) and the whole source; 128-byte lines
+    fb = wl.floor_bytes()
+    assert wl.alg_bytes_per_launch < fb < wl.N * (wl.SW * wl.SH + wl.DW * wl.DH) * wl.C * 4 and (fb - wl.N * wl.DW * wl.DH * wl.C * 4) % 128 == 0
+    assert 2.5e9 < fb * 256 / wl.N < 3.2e9     # ~2.8 GB per 256-image step
     wl = _run(bench, "resize_normalize_f32_224", gpu_stream)
     got = _out(wl, np.float32, (wl.DH, wl.DW, wl.C))
     for k in range(wl.N):
@@ -154,6 +199,9 @@ def test_pyramid_workloads_4k(gpu_stream, bench, name):
 def test_gather_workloads_4k(gpu_stream, bench):
     wl = _run(bench, "undistort_warp_4k", gpu_stream)
     n = wl.W * wl.H * wl.C
+    # priced on the bytes the two kernels need (in-bounds taps, maps once per four images): below SURVEY 8(d)'s contract figure
+    assert 0.75 * wl.survey_bytes_per_launch < wl.alg_bytes_per_launch < wl.survey_bytes_per_launch, (wl.alg_bytes_per_launch, wl.in_bounds)
+    assert 0.9 < wl.in_bounds[0] <= 1.0 and 0.5 < wl.in_bounds[1] <= 1.0, wl.in_bounds
     mx, my = O.correction_map(wl.INTR, wl.DIST, wl.W, wl.H)
     got = _out(wl, np.float32, (wl.H, wl.W, wl.C))
     for k in range(wl.N):
@@ -219,7 +267,8 @@ def test_colour_map_workloads_1080p(gpu_stream, bench):
 
 
 def test_every_workload_is_covered(bench):
-    covered = {"nv12_h2d_preprocess", "nv12_h2d_preprocess_pageable", "nv12_chw", "nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_chw_640_lanczos", "resize_224", "resize_bicubic_540", "resize_normalize_f32_224",
+    covered = {"nv12_h2d_preprocess", "nv12_h2d_preprocess_zero_copy", "nv12_chw_list", "resize_224_api_eager", "resize_224_api_graph", "resize_224_api_list",
+               "gaussian_4k_api_list", "undistort_warp_4k_api_list", "nv12_chw", "nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_chw_640_lanczos", "resize_224", "resize_bicubic_540", "resize_normalize_f32_224",
                "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640", "gaussian_4k", "sobel_4k", "box_blur_4k", "gaussian_u8_4k", "pyrdown_u8_4k",
                "pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_f32_1080p", "normalize_1080p",
                "warp_affine_u8_4k", "warp_perspective_u8_4k", "remap_u8_4k", "spatial_gradient_1080p", "box_blur_fast_1080p",

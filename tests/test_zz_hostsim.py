@@ -51,7 +51,8 @@ def test_gpu_suite_passes_on_the_host_simulator(sim_env):
            # the 4K bench-workload checks take minutes of fibers; they pass here too (python scripts/hostsim_run.py
            # tests/test_bench_workloads_gpu.py -n 8) but are left to the device to keep this suite short
            "--deselect", "tests/test_bench_workloads_gpu.py::test_gather_workloads_4k",
-           "--deselect", "tests/test_bench_workloads_gpu.py::test_filter_workloads_4k"]
+           "--deselect", "tests/test_bench_workloads_gpu.py::test_filter_workloads_4k",
+           "--deselect", "tests/test_bench_workloads_gpu.py::test_list_workloads_4k"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=sim_env)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
     assert r.returncode == 0, tail
