@@ -201,9 +201,11 @@ class NorthStarNV12List(NorthStarNV12):
         self.stream = stream
         self.base = lcg_bytes(self.frame_bytes + 31 * self.N)
         dbase = DeviceBuffer.from_numpy(self.base, stream)
-        self.frames = []
-        for k in range(self.N):   # every frame its own allocation, padded by a varying amount: the bases are not equally spaced
-            buf = DeviceBuffer(self.frame_bytes + 256 * ((5 * k) % 7), stream, zeroed=False)
+        self.frames, self._spacers = [], []
+        for k in range(self.N):   # every frame its own allocation; 0 / 2 / 4 MiB spacer allocations in between: the bases are not equally spaced
+            if (5 * k) % 3:
+                self._spacers.append(DeviceBuffer(((5 * k) % 3) << 21, stream, zeroed=False))
+            buf = DeviceBuffer(self.frame_bytes, stream, zeroed=False)
             check(lib.kh_memcpy_d2d_async(buf.ptr, dbase.ptr + 31 * k, self.frame_bytes, stream.cuda_stream_ptr))
             self.frames.append(buf)
         stream.synchronize()
@@ -345,12 +347,17 @@ class F32Images(Workload):
             dbase = DeviceBuffer.from_numpy(self.base, stream)
         imgs, spacers = [], []
         for k in range(batch):
-            spacers.append(DeviceBuffer(256 * (1 + (5 * k) % 7), stream, zeroed=False))
+            # (the stream-ordered pool rounds allocations up: only gaps of whole megabytes are sure to differ — measured in round 6,
+            # where 1024 frames padded by k * 256 B came out equally spaced)
+            if (5 * k) % 3:
+                spacers.append(DeviceBuffer(((5 * k) % 3) << 21, stream, zeroed=False))
             im = Image.uninit(w, h, c, "float32", stream)
             if fill:
                 check(lib.kh_memcpy_d2d_async(im.data_ptr, dbase.ptr + 31 * k * 4, n * 4, stream.cuda_stream_ptr))
             imgs.append(im)
         stream.synchronize()
+        gaps = {b.data_ptr - a.data_ptr for a, b in zip(imgs, imgs[1:])}
+        assert batch < 3 or len(gaps) > 1, "the images came out equally spaced: an API row built on them would not exercise the pointer list"
         return ImageList(imgs, spacers)
 
 
@@ -463,6 +470,8 @@ class ResizeBilinearApi(ResizeBilinear):
         self.src = self._make_images(stream, self.SW, self.SH, self.C, self.N)
         self.dsts = [self._make_images(stream, self.DW, self.DH, self.C, self.N, fill=False) for _ in range(self.ROTATE)]
         self.dst, self.turn = self.dsts[0], 0
+        if self.how == "list":   # the host keeps the pointer arrays beside its images (imgproc.ImageBatch), as a Rust host would a Vec<*const f32>
+            self.src_b, self.dst_b = imgproc.ImageBatch(self.src), [imgproc.ImageBatch(d) for d in self.dsts]
         if self.how == "graph":
             def record(outs):
                 for s_, d_ in zip(self.src, outs):
@@ -478,7 +487,7 @@ class ResizeBilinearApi(ResizeBilinear):
         elif self.how == "graph":
             self.graphs[(self.turn - 1) % len(self.graphs)].replay()
         else:
-            imgproc.resize_batch(self.src, None, "bilinear", outs=dst)
+            imgproc.resize_batch(self.src_b, None, "bilinear", outs=self.dst_b[(self.turn - 1) % len(self.dst_b)])
 
     def describe(self):
         d = super().describe()
@@ -584,12 +593,14 @@ class Gaussian4KList(Gaussian4K):
 
     def setup(self, stream):
         self.stream = stream
+        from kornia_rs import imgproc
         self.src = self._make_images(stream, self.W, self.H, self.C, self.N)
         self.dst = self._make_images(stream, self.W, self.H, self.C, self.N, fill=False)
+        self.src_b, self.dst_b = imgproc.ImageBatch(self.src), imgproc.ImageBatch(self.dst)
 
     def step(self):
         from kornia_rs import imgproc
-        imgproc.gaussian_blur_batch(self.src, (7, 7), (1.5, 1.5), outs=self.dst)
+        imgproc.gaussian_blur_batch(self.src_b, (7, 7), (1.5, 1.5), outs=self.dst_b)
 
     def describe(self):
         d = super().describe()
@@ -713,11 +724,12 @@ class UndistortWarp4KList(UndistortWarp4K):
         self.dst = self._make_images(stream, self.W, self.H, self.C, self.N, fill=False)
         self.mx, self.my = imgproc.generate_correction_map_polynomial(self.INTR, self.DIST, (self.W, self.H), stream)
         self._price(stream, self.mx.data_ptr, self.my.data_ptr)
+        self.src_b, self.tmp_b, self.dst_b = imgproc.ImageBatch(self.src), imgproc.ImageBatch(self.tmp), imgproc.ImageBatch(self.dst)
 
     def step(self):
         from kornia_rs import imgproc
-        imgproc.remap_batch(self.src, self.mx, self.my, "bilinear", outs=self.tmp)
-        imgproc.warp_perspective_batch(self.tmp, self.hm, None, "bilinear", outs=self.dst)
+        imgproc.remap_batch(self.src_b, self.mx, self.my, "bilinear", outs=self.tmp_b)
+        imgproc.warp_perspective_batch(self.tmp_b, self.hm, None, "bilinear", outs=self.dst_b)
 
     def describe(self):
         d = super().describe()

@@ -28,8 +28,18 @@ struct Img {  // one batch of same-sized HWC f32 images
     int sw, sh, dw, dh;
     long long src_stride, dst_stride;  // elements between consecutive images
     XcdTiles tiles;                    // kBx x kBy output tiles, XCD-contiguous order
-    int listed;                        // the images' bases come from the launch's PtrList (kh_common.h) instead of base + k * stride
 };
+
+// Pointer-list launches (kh_*_f32_list, kh_common.h::PtrList) are separate instantiations (LIST = true) of the same kernels: the image's
+// (src, dst) pair is one scalar load from the kernel arguments where an equally spaced batch computes base + k * stride.  Measured in
+// round 6, same box, C5 shape (profiles/r06c, r06d, r06h): selecting between the two at RUN time inside one kernel cost the equally
+// spaced launches 8 % (C5 20.4-20.8 vs 18.7-19.1 ms) — so LIST = false is the round-5 kernel, argument for argument; a 2-D grid with the
+// image in blockIdx.y (so that the pair's load does not wait for the tile decode), with or without pinning the loaded pointers in
+// the entry block, ran the list kernels SLOWER than the flattened XCD grid used here (remap 5.69 vs 5.35 ms, warp_perspective 4.88 vs
+// 4.59 ms per 128 4K images; equally spaced 4.70 / 4.69 ms).
+struct NoList { int unused; };
+template <bool LIST> struct ListArg { typedef NoList type; };
+template <> struct ListArg<true> { typedef PtrList type; };
 
 // ---- samplers (expression trees of P/interpolation/*.rs; do not regroup) --------------------------
 
@@ -218,14 +228,26 @@ __device__ __forceinline__ void put_zero(const OutRow& r, int x) {
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
+// The bases of image `k` of the launch.
+template <bool LIST>
+__device__ __forceinline__ const float* image_src(const Img& im, const typename ListArg<LIST>::type& lst, unsigned k) {
+    if constexpr (LIST) return static_cast<const float*>(lst.src[k]);
+    else return im.src + (long long)k * im.src_stride;
+}
+template <bool LIST>
+__device__ __forceinline__ float* image_dst(const Img& im, const typename ListArg<LIST>::type& lst, unsigned k) {
+    if constexpr (LIST) return static_cast<float*>(lst.dst[k]);
+    else return im.dst + (long long)k * im.dst_stride;
+}
+
 #define KH_PIXEL_PROLOGUE                                             \
     unsigned bx_, by_, bz_;                                           \
     if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;                   \
     const int x = bx_ * kBx + threadIdx.x;                            \
     const int y = by_ * kBy + threadIdx.y;                            \
     if (x >= im.dw || y >= im.dh) return;                             \
-    const float* src = list_src(lst, im.listed, im.src, im.src_stride, bz_);                                          \
-    const OutRow o = out_row<C>(list_dst(lst, im.listed, im.dst, im.dst_stride, bz_) + (long long)y * im.dw * C, im.dw);
+    const float* src = image_src<LIST>(im, lst, bz_);                 \
+    const OutRow o = out_row<C>(image_dst<LIST>(im, lst, bz_) + (long long)y * im.dw * C, im.dw);
 
 // resize (P/resize/mod.rs:161-176): half-pixel grid a*x + b, clamped to the source.
 // Bound by the texture addresser on moderate scales (1080p -> 540p bicubic: sixteen 12-byte gathers per pixel, TA_BUSY 100 %,
@@ -234,8 +256,8 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 // 69 % of its cycles (load -> LDS -> barrier -> sample, nothing to overlap with) and costs 1.6x the vector instructions.  Not kept.
 // Taking a row's four interior taps as three 16-byte loads instead of four 12-byte ones: no change (r04zm): the addresser's cost
 // follows the bytes, not the instruction count.
-template <int C, int MODE>
-__global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, float bx, float ay, float by, PtrList lst) {
+template <int C, int MODE, bool LIST>
+__global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, float bx, float ay, float by, typename ListArg<LIST>::type lst) {
     KH_PIXEL_PROLOGUE
     const float sx = clampf(ax * (float)x + bx, 0.0f, (float)(im.sw - 1));
     const float sy = clampf(ay * (float)y + by, 0.0f, (float)(im.sh - 1));
@@ -247,7 +269,8 @@ __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, floa
 // resize_bilinear_normalize_3c (P/cuda/resize.rs:184-236): bilinear resize fused with `(px - mean) * inv_std`, HWC in,
 // HWC out — the sample is the same bilinear sampler as `resize`, the epilogue the reference kernel's expression.
 struct Norm3f { float mean[3], inv_std[3]; };
-__global__ __launch_bounds__(kBx* kBy) void resize_normalize_kernel(Img im, float ax, float bx, float ay, float by, Norm3f n, PtrList lst) {
+template <bool LIST>
+__global__ __launch_bounds__(kBx* kBy) void resize_normalize_kernel(Img im, float ax, float bx, float ay, float by, Norm3f n, typename ListArg<LIST>::type lst) {
     constexpr int C = 3;
     KH_PIXEL_PROLOGUE
     const float sx = clampf(ax * (float)x + bx, 0.0f, (float)(im.sw - 1));
@@ -283,9 +306,9 @@ __global__ __launch_bounds__(kBlock) void lanczos_axis_kernel(LzTap* __restrict_
     tab[i] = t;
 }
 
-template <int C>
+template <int C, bool LIST>
 __global__ __launch_bounds__(kBx* kBy) void resize_lanczos_kernel(Img im, const LzTap* __restrict__ tx,
-                                                                  const LzTap* __restrict__ ty, PtrList lst) {
+                                                                  const LzTap* __restrict__ ty, typename ListArg<LIST>::type lst) {
     KH_PIXEL_PROLOGUE
     const LzTap ax = tx[x], ay = ty[y];
     int xo[6];
@@ -316,8 +339,8 @@ struct Mat6 { float m[6]; };
 struct Mat9 { float m[9]; };
 
 // warp_affine (P/warp/affine.rs:123-372); mi = inverse 2x3
-template <int C, int MODE>
-__global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi, PtrList lst) {
+template <int C, int MODE, bool LIST>
+__global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi, typename ListArg<LIST>::type lst) {
     KH_PIXEL_PROLOGUE
     const float swf = (float)im.sw, shf = (float)im.sh;
     const float sx0 = mi.m[1] * (float)y + mi.m[2], sy0 = mi.m[4] * (float)y + mi.m[5];
@@ -352,8 +375,8 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi, 
 }
 
 // warp_perspective (P/warp/perspective.rs:67-72,115-166); im9 = inverse 3x3
-template <int C, int MODE>
-__global__ __launch_bounds__(kBx* kBy) void warp_perspective_kernel(Img im, Mat9 h, PtrList lst) {
+template <int C, int MODE, bool LIST>
+__global__ __launch_bounds__(kBx* kBy) void warp_perspective_kernel(Img im, Mat9 h, typename ListArg<LIST>::type lst) {
     KH_PIXEL_PROLOGUE
     const float xf = (float)x, yf = (float)y;
     const float w = h.m[6] * xf + h.m[7] * yf + h.m[8];
@@ -372,9 +395,10 @@ __global__ __launch_bounds__(kBx* kBy) void warp_perspective_kernel(Img im, Mat9
 // a thread owns pixel (x, y) of kRemapNB consecutive images: the 8 B/px of map coordinates are
 // read once per kRemapNB images instead of once per image (C5: 66 MB of maps per 99.5 MB image).
 constexpr int kRemapNB = 4;
-template <int C, int MODE>
+template <int C, int MODE, bool LIST>
 __global__ __launch_bounds__(kBx* kBy) void remap_kernel(Img im, const float* __restrict__ map_x,
-                                                         const float* __restrict__ map_y, int batch, PtrList lst) {
+                                                         const float* __restrict__ map_y, int batch, typename ListArg<LIST>::type lst) {
+    static_assert(kListMax % kRemapNB == 0, "remap_kernel: a block's group of images never straddles the end of a list slice");
     unsigned bx_, by_, bz_;
     if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;
     const int x = bx_ * kBx + threadIdx.x;
@@ -388,8 +412,8 @@ __global__ __launch_bounds__(kBx* kBy) void remap_kernel(Img im, const float* __
     for (int k = 0; k < kRemapNB; ++k) {
         const int z = z0 + k;
         if (z >= batch) break;
-        const float* src = list_src(lst, im.listed, im.src, im.src_stride, (unsigned)z);
-        const OutRow o = out_row<C>(list_dst(lst, im.listed, im.dst, im.dst_stride, (unsigned)z) + (long long)y * im.dw * C, im.dw);
+        const float* src = image_src<LIST>(im, lst, (unsigned)z);
+        const OutRow o = out_row<C>(image_dst<LIST>(im, lst, (unsigned)z) + (long long)y * im.dw * C, im.dw);
         if (inside) {
             float val[C];
             sample<C, MODE>(src, im.sh, im.sw, u, v, val);
@@ -439,28 +463,34 @@ int32_t check_img(const char* what, const BatchRef& b, int sw, int sh, int dw, i
 // `b`: a strided batch or one <= kListMax slice of a list (for_each_launch); `groups` = images (or image groups) the tile grid covers
 Img make_img(const BatchRef& b, int sw, int sh, int dw, int dh, int groups) {
     return Img{static_cast<const float*>(b.src), static_cast<float*>(b.dst), sw, sh, dw, dh, b.ss, b.ds,
-               xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups, cdiv(dw, kBx) * 8), b.listed() ? 1 : 0};
+               xcd_tiles(cdiv(dw, kBx), cdiv(dh, kBy), (unsigned)groups, cdiv(dw, kBx) * 8)};
 }
 #define KH_REQUIRE_TILES(what, im) \
     KH_REQUIRE((im).tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what)
 
-#define KH_DISPATCH_C_MODE(KERNEL, channels, mode, grid, stream, ...)                                              \
+#define KH_DISPATCH_C_MODE_L(KERNEL, LIST, channels, mode, grid, stream, ...)                                        \
     do {                                                                                                           \
         const dim3 blk(kBx, kBy);                                                                                  \
         switch ((channels) * 10 + (mode)) {                                                                        \
-            case 10: hipLaunchKernelGGL((KERNEL<1, 0>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            case 11: hipLaunchKernelGGL((KERNEL<1, 1>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            case 12: hipLaunchKernelGGL((KERNEL<1, 2>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            case 30: hipLaunchKernelGGL((KERNEL<3, 0>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            case 31: hipLaunchKernelGGL((KERNEL<3, 1>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            case 32: hipLaunchKernelGGL((KERNEL<3, 2>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            case 13: hipLaunchKernelGGL((KERNEL<1, 3>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            case 33: hipLaunchKernelGGL((KERNEL<3, 3>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            case 43: hipLaunchKernelGGL((KERNEL<4, 3>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            case 40: hipLaunchKernelGGL((KERNEL<4, 0>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            case 41: hipLaunchKernelGGL((KERNEL<4, 1>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
-            default: hipLaunchKernelGGL((KERNEL<4, 2>), grid, blk, 0, stream, __VA_ARGS__); break;                 \
+            case 10: hipLaunchKernelGGL((KERNEL<1, 0, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            case 11: hipLaunchKernelGGL((KERNEL<1, 1, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            case 12: hipLaunchKernelGGL((KERNEL<1, 2, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            case 30: hipLaunchKernelGGL((KERNEL<3, 0, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            case 31: hipLaunchKernelGGL((KERNEL<3, 1, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            case 32: hipLaunchKernelGGL((KERNEL<3, 2, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            case 13: hipLaunchKernelGGL((KERNEL<1, 3, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            case 33: hipLaunchKernelGGL((KERNEL<3, 3, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            case 43: hipLaunchKernelGGL((KERNEL<4, 3, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            case 40: hipLaunchKernelGGL((KERNEL<4, 0, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            case 41: hipLaunchKernelGGL((KERNEL<4, 1, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
+            default: hipLaunchKernelGGL((KERNEL<4, 2, LIST>), grid, blk, 0, stream, __VA_ARGS__); break;           \
         }                                                                                                          \
+    } while (0)
+// the arguments end with `lst` (the launch's PtrList) for a list slice; an equally spaced batch passes the NoList placeholder instead
+#define KH_DISPATCH_C_MODE(KERNEL, listed, channels, mode, grid, stream, lst, ...)                                  \
+    do {                                                                                                           \
+        if (listed) KH_DISPATCH_C_MODE_L(KERNEL, true, channels, mode, grid, stream, __VA_ARGS__, lst);            \
+        else KH_DISPATCH_C_MODE_L(KERNEL, false, channels, mode, grid, stream, __VA_ARGS__, NoList{0});            \
     } while (0)
 
 }  // namespace
@@ -546,11 +576,16 @@ int32_t resize_impl(const char* what, kh_stream_t stream, const BatchRef& b, int
         return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
             const Img im = make_img(c, sw, sh, dw, dh, c.n);
             KH_REQUIRE_TILES(what, im);
-            const dim3 blk(kBx, kBy);
-            switch (channels) {
-                case 1: hipLaunchKernelGGL(resize_lanczos_kernel<1>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw, lst); break;
-                case 3: hipLaunchKernelGGL(resize_lanczos_kernel<3>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw, lst); break;
-                default: hipLaunchKernelGGL(resize_lanczos_kernel<4>, xcd_grid(im.tiles), blk, 0, st, im, tab, tab + dw, lst); break;
+            const dim3 blk(kBx, kBy), grid = xcd_grid(im.tiles);
+            const NoList none{0};
+            if (c.listed()) switch (channels) {
+                case 1: hipLaunchKernelGGL((resize_lanczos_kernel<1, true>), grid, blk, 0, st, im, tab, tab + dw, lst); break;
+                case 3: hipLaunchKernelGGL((resize_lanczos_kernel<3, true>), grid, blk, 0, st, im, tab, tab + dw, lst); break;
+                default: hipLaunchKernelGGL((resize_lanczos_kernel<4, true>), grid, blk, 0, st, im, tab, tab + dw, lst); break;
+            } else switch (channels) {
+                case 1: hipLaunchKernelGGL((resize_lanczos_kernel<1, false>), grid, blk, 0, st, im, tab, tab + dw, none); break;
+                case 3: hipLaunchKernelGGL((resize_lanczos_kernel<3, false>), grid, blk, 0, st, im, tab, tab + dw, none); break;
+                default: hipLaunchKernelGGL((resize_lanczos_kernel<4, false>), grid, blk, 0, st, im, tab, tab + dw, none); break;
             }
             return check_launch("kh_resize_f32 (lanczos)");
         });
@@ -558,7 +593,7 @@ int32_t resize_impl(const char* what, kh_stream_t stream, const BatchRef& b, int
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
         const Img im = make_img(c, sw, sh, dw, dh, c.n);
         KH_REQUIRE_TILES(what, im);
-        KH_DISPATCH_C_MODE(resize_kernel, channels, mode, xcd_grid(im.tiles), st, im, ax, bx, ay, by, lst);
+        KH_DISPATCH_C_MODE(resize_kernel, c.listed(), channels, mode, xcd_grid(im.tiles), st, lst, im, ax, bx, ay, by);
         return check_launch(what);
     });
 }
@@ -579,7 +614,8 @@ int32_t resize_normalize_impl(const char* what, kh_stream_t stream, const BatchR
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
         const Img im = make_img(c, sw, sh, dw, dh, c.n);
         KH_REQUIRE_TILES(what, im);
-        hipLaunchKernelGGL(resize_normalize_kernel, xcd_grid(im.tiles), dim3(kBx, kBy), 0, as_hip(stream), im, cx[0], cx[1], cy[0], cy[1], n, lst);
+        if (c.listed()) hipLaunchKernelGGL(resize_normalize_kernel<true>, xcd_grid(im.tiles), dim3(kBx, kBy), 0, as_hip(stream), im, cx[0], cx[1], cy[0], cy[1], n, lst);
+        else hipLaunchKernelGGL(resize_normalize_kernel<false>, xcd_grid(im.tiles), dim3(kBx, kBy), 0, as_hip(stream), im, cx[0], cx[1], cy[0], cy[1], n, NoList{0});
         return check_launch(what);
     });
 }
@@ -594,7 +630,7 @@ int32_t warp_affine_impl(const char* what, kh_stream_t stream, const BatchRef& b
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
         const Img im = make_img(c, sw, sh, dw, dh, c.n);
         KH_REQUIRE_TILES(what, im);
-        KH_DISPATCH_C_MODE(warp_affine_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, mi, lst);
+        KH_DISPATCH_C_MODE(warp_affine_kernel, c.listed(), channels, mode, xcd_grid(im.tiles), as_hip(stream), lst, im, mi);
         return check_launch(what);
     });
 }
@@ -609,7 +645,7 @@ int32_t warp_perspective_impl(const char* what, kh_stream_t stream, const BatchR
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
         const Img im = make_img(c, sw, sh, dw, dh, c.n);
         KH_REQUIRE_TILES(what, im);
-        KH_DISPATCH_C_MODE(warp_perspective_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, h, lst);
+        KH_DISPATCH_C_MODE(warp_perspective_kernel, c.listed(), channels, mode, xcd_grid(im.tiles), as_hip(stream), lst, im, h);
         return check_launch(what);
     });
 }
@@ -620,9 +656,10 @@ int32_t remap_impl(const char* what, kh_stream_t stream, const BatchRef& b, cons
     if (b.n == 0) return KH_OK;
     KH_REQUIRE(map_x && map_y, KH_ERR_INVALID_ARG, "%s: null map pointer", what);
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
-        const Img im = make_img(c, sw, sh, dw, dh, (c.n + kRemapNB - 1) / kRemapNB);
+        const int groups = (c.n + kRemapNB - 1) / kRemapNB;
+        const Img im = make_img(c, sw, sh, dw, dh, groups);
         KH_REQUIRE_TILES(what, im);
-        KH_DISPATCH_C_MODE(remap_kernel, channels, mode, xcd_grid(im.tiles), as_hip(stream), im, map_x, map_y, c.n, lst);
+        KH_DISPATCH_C_MODE(remap_kernel, c.listed(), channels, mode, xcd_grid(im.tiles), as_hip(stream), lst, im, map_x, map_y, c.n);
         return check_launch(what);
     });
 }

@@ -548,36 +548,66 @@ def remap(src: Image, map_x: Image, map_y: Image, interpolation: str = "bilinear
 # their device pointers to the `kh_*_list` entry points: one launch per 128 images, the (src, dst) bases in the kernel arguments.
 # Results equal those of the N single calls bit for bit (tests/test_list_batches_gpu.py).
 
+class ImageBatch(tuple):
+    """N same-sized float32 device Images of ONE device, validated once, with their device pointers laid out as the host array the
+    ``kh_*_list`` entry points read — what a Rust host would keep as a ``Vec<*const f32>`` beside its images.  The ``*_batch``
+    operators accept plain lists too (and build this per call: a Python loop over N images); a caller that runs the same batch
+    repeatedly builds it once, and a call then costs what one launch costs."""
+
+    def __new__(cls, images: Sequence[Image], what: str = "ImageBatch", channels: Optional[Tuple[int, ...]] = None):
+        self = super().__new__(cls, images)
+        if not len(self):
+            raise ImageError("InvalidArgument", f"{what}: empty batch")
+        first = self[0]
+        for im in self:   # Host / Device / Mixed classification first (P/cuda/dispatch.rs:105-133): typed, before anything is allocated
+            if im.is_device != first.is_device:
+                raise ImageError("MixedResidency", "the images of a batch must all be on the host or all on the device; there is no implicit transfer")
+        if not first.is_device:
+            raise ImageError("HostPathUnavailable", "host images: this build provides the HIP device backend only — move the images with .to_hip(stream)")
+        streams, seen = [], set()
+        for im in self:
+            _require(im, "float32", channels if channels is not None else tuple(range(1, 9)), what)
+            if im.size != first.size or im.channels != first.channels:
+                raise ImageError("InvalidImageSize", f"{what}: every image of a batch must be {first.width}x{first.height}x{first.channels}, "
+                                                     f"got {im.width}x{im.height}x{im.channels}")
+            if im.device_id != first.device_id:
+                raise ImageError("DeviceMismatch", f"images live on different devices ({first.device} vs {im.device})")
+            if im.stream is None:
+                raise ImageError("UnsupportedDevice", "device image without a stream (untyped foreign memory); re-wrap it with Image.from_dlpack(obj, stream=...)")
+            if im.stream.cuda_stream_ptr not in seen:
+                seen.add(im.stream.cuda_stream_ptr)
+                streams.append(im.stream)
+        self.width, self.height, self.channels = first.width, first.height, first.channels
+        self.size, self.device_id, self.streams = first.size, first.device_id, streams
+        self.pointers = _ffi.pointer_array([im.data_ptr for im in self])
+        self.stream = first.stream          # (what hip.on_operand_device looks at)
+        self.is_device = True
+        return self
+
+
 def _batch_pairs(srcs: Sequence[Image], outs: Optional[Sequence[Image]], new_size: Optional[Tuple[int, int]], what: str,
                  channels: Tuple[int, ...] = (1, 3, 4)):
-    """Validate N (source, destination) pairs of one batch — same size / dtype / channel count on each side, every image
-    device-resident on ONE device — allocate missing destinations on their source's stream, and return
+    """N (source, destination) pairs of one batch: same size / dtype / channel count on each side, every image device-resident
+    on ONE device (``ImageBatch`` checks that once); missing destinations are allocated on their source's stream.  Returns
     ``(outs, exec, src_ptrs, dst_ptrs)``: the launch goes on the FIRST source's stream with every other operand stream fenced in
     (and back by ``exec.check``), exactly what N single calls on that stream would order."""
-    srcs = list(srcs)
-    if not srcs:
-        raise ImageError("InvalidArgument", f"{what}: empty batch")
-    first = srcs[0]
-    _pair_residency(first, *srcs[1:])   # mixed host / device sources, host-only batches, device mismatch: typed, before anything is allocated
-    for im in srcs:
-        _require(im, "float32", channels, what)
-        if im.size != first.size or im.channels != first.channels:
-            raise ImageError("InvalidImageSize", f"{what}: every source of a batch must be {first.width}x{first.height}x{first.channels}, "
-                                                 f"got {im.width}x{im.height}x{im.channels}")
+    sb = srcs if isinstance(srcs, ImageBatch) else ImageBatch(srcs, what)
+    if sb.channels not in channels:
+        raise ImageError("NoDeviceKernel", f"{what}: no device kernel for float32 x {sb.channels} channels (supported: {channels})")
     if outs is None:
         if new_size is None:
-            new_size = (first.height, first.width)
+            new_size = (sb.height, sb.width)
         h, w = new_size  # the Python API takes (height, width)
-        outs = [_new_like(im, size=(w, h)) for im in srcs]
-    outs = list(outs)
-    if len(outs) != len(srcs):
-        raise ImageError("InvalidArgument", f"{what}: {len(srcs)} sources but {len(outs)} destinations")
-    for o in outs:
-        _require(o, "float32", (first.channels,), what)
-        if o.size != outs[0].size:
-            raise ImageError("InvalidImageSize", f"{what}: every destination of a batch must have the same size")
-    ex = _pair_residency(first, *srcs[1:], *outs)
-    return outs, ex, _ffi.pointer_array([im.data_ptr for im in srcs]), _ffi.pointer_array([o.data_ptr for o in outs])
+        outs = [_new_like(im, size=(w, h)) for im in sb]
+    ob = outs if isinstance(outs, ImageBatch) else ImageBatch(outs, what)
+    if len(ob) != len(sb):
+        raise ImageError("InvalidArgument", f"{what}: {len(sb)} sources but {len(ob)} destinations")
+    if ob.channels != sb.channels:
+        raise ImageError("NoDeviceKernel", f"{what}: destinations have {ob.channels} channels, sources {sb.channels}")
+    if ob.device_id != sb.device_id:
+        raise ImageError("DeviceMismatch", "sources and destinations live on different devices")
+    ex = _DeviceExec(sb.streams[0], sb.streams[1:] + ob.streams)
+    return ob, ex, sb.pointers, ob.pointers
 
 
 def resize_batch(srcs: Sequence[Image], new_size: Optional[Tuple[int, int]] = None, interpolation: str = "bilinear",

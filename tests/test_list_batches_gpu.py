@@ -23,21 +23,29 @@ def _raw(fmt, w, h, k):
 class _View:
     """A frame inside a larger device allocation (what `_ptr_len` accepts through the CUDA array interface)."""
 
+    def copy_from_host(self, raw):
+        self._buf.copy_from_host(raw, offset=self._off)
+
     def __init__(self, buf, offset, nbytes):
-        self._buf = buf
+        self._buf, self.ptr, self._off = buf, buf.ptr + offset, offset
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (buf.ptr + offset, False), "version": 3}
 
 
 def _scattered_frames(stream, raws, misalign=0):
-    """Each frame in its OWN allocation, padded by a different amount so the bases are not equally spaced; `misalign` puts every
-    frame at that byte offset inside its allocation."""
+    """Frames at UNEQUALLY spaced bases, whatever the allocator's granularity (on the device the stream-ordered pool rounds small
+    allocations to one size, so separate allocations alone come out equally spaced): two arenas, frame k in arena k % 2 at an
+    offset whose gaps vary (multiples of 64 bytes, + `misalign` for the alignment tests)."""
     from kornia_rs.hip import DeviceBuffer
-    out = []
+    fb = raws[0].size
+    slot = (fb + 63) // 64 * 64 + 64 * 5
+    arenas = [DeviceBuffer(slot * (len(raws) // 2 + 2) + 64, stream, zeroed=False) for _ in range(2)]
+    out, cursor = [], [0, 0]
     for k, raw in enumerate(raws):
-        pad = 64 * ((k * 7) % 5)
-        buf = DeviceBuffer(raw.size + pad + misalign + 16, stream, zeroed=False)
-        buf.copy_from_host(raw, offset=misalign)
-        out.append(_View(buf, misalign, raw.size) if misalign else buf)
+        a = k % 2
+        off = cursor[a] + 64 * ((k * 7) % 5) + misalign
+        arenas[a].copy_from_host(raw, offset=off)
+        out.append(_View(arenas[a], off, raw.size))
+        cursor[a] = (off + fb + 63) // 64 * 64
     return out
 
 
@@ -131,14 +139,22 @@ def _img(w, h, c, seed):
 
 
 def _images(stream, arrs):
-    """Each image its own allocation, with a spacer allocation of varying size kept alive in between."""
-    from kornia_rs import Image
+    """Device Images at unequally spaced bases (see _scattered_frames): views into two arenas with varying gaps."""
+    from kornia_rs import Image, Tensor
     from kornia_rs.hip import DeviceBuffer
-    imgs, spacers = [], []
+    nb = arrs[0].nbytes
+    slot = (nb + 255) // 256 * 256 + 256 * 7
+    arenas = [DeviceBuffer(slot * (len(arrs) // 2 + 2), stream, zeroed=False) for _ in range(2)]
+    imgs, cursor = [], [0, 0]
     for k, a in enumerate(arrs):
-        spacers.append(DeviceBuffer(256 * (1 + (k * 5) % 7), stream, zeroed=False))
-        imgs.append(Image.from_numpy(a).to_hip(stream))
-    return imgs, spacers
+        ar = k % 2
+        off = cursor[ar] + 256 * ((k * 5) % 7)
+        arenas[ar].copy_from_host(a.reshape(-1), offset=off)
+        imgs.append(Image(Tensor(a.shape, "float32", device_ptr=arenas[ar].ptr + off, device=stream.device, stream=stream, keepalive=arenas[ar])))
+        cursor[ar] = (off + nb + 255) // 256 * 256
+    ptrs = [im.data_ptr for im in imgs]
+    assert len(imgs) < 3 or len({b - a for a, b in zip(ptrs, ptrs[1:])}) > 1
+    return imgs, arenas
 
 
 @pytest.mark.parametrize("mode", ["nearest", "bilinear", "bicubic", "lanczos"])
@@ -165,6 +181,26 @@ def test_resize_batch_crosses_the_launch_slices(gpu_stream):
     assert all(a is b for a, b in zip(back, outs))
     for k in (0, 127, 128, 129, 255, 256, 299):
         assert_same_bits(outs[k].numpy(), O.resize(arrs[k], dw, dh, "bilinear"), f"image {k}")
+
+
+def test_image_batch_is_validated_once_and_reusable(gpu_stream):
+    """imgproc.ImageBatch: the pointer arrays built once; repeated calls on the same batches (new contents) give the oracle's bits."""
+    from kornia_rs import Image, imgproc
+    n, (sw, sh, dw, dh) = 5, (40, 24, 17, 11)
+    arrs = [_img(sw, sh, 3, 31 * k) for k in range(n)]
+    imgs, arenas = _images(gpu_stream, arrs)
+    sb = imgproc.ImageBatch(imgs)
+    ob = imgproc.ImageBatch([Image.uninit(dw, dh, 3, "float32", gpu_stream) for _ in range(n)])
+    assert (sb.width, sb.height, sb.channels, len(sb.streams)) == (sw, sh, 3, 1)
+    for rnd in range(2):
+        back = imgproc.resize_batch(sb, None, "bicubic", outs=ob)
+        assert back is ob
+        for k in range(n):
+            assert_same_bits(ob[k].numpy(), O.resize(arrs[k], dw, dh, "bicubic"), f"round {rnd} image {k}")
+        arrs = [_img(sw, sh, 3, 31 * k + 7) for k in range(n)]      # rewrite the sources in place: the batch reads current contents
+        for im, a in zip(imgs, arrs):
+            from kornia_rs import hip
+            hip.h2d(im.data_ptr, a.reshape(-1), gpu_stream)
 
 
 def test_warp_and_remap_batches_match_oracle(gpu_stream):
@@ -216,9 +252,9 @@ def test_batch_operand_errors_are_typed(gpu_stream):
     from kornia_rs.image import ImageError
     a = Image.from_numpy(_img(8, 6, 3, 0)).to_hip(gpu_stream)
     b = Image.from_numpy(_img(9, 6, 3, 0)).to_hip(gpu_stream)
-    with pytest.raises(ImageError, match="InvalidImageSize|every source"):
+    with pytest.raises(ImageError, match="every image of a batch must be"):
         imgproc.resize_batch([a, b], (4, 4))
-    with pytest.raises(ImageError, match="MixedResidency|must both"):
+    with pytest.raises(ImageError, match="must all be on the host or all on the device"):
         imgproc.resize_batch([a, Image.from_numpy(_img(8, 6, 3, 0))], (4, 4))
     with pytest.raises(ImageError, match="empty batch"):
         imgproc.resize_batch([], (4, 4))
