@@ -14,6 +14,8 @@
 // batch (the reference launches once per image).
 #include <math.h>
 
+#include <algorithm>
+
 #include "kh_common.h"
 
 using namespace kh;
@@ -264,6 +266,83 @@ __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, floa
     float v[C];
     sample<C, MODE>(src, im.sh, im.sw, sx, sy, v);
     put<C>(o, x, v);
+}
+
+// ---- bilinear downscale, row-streamed (round 6; BASELINE configs[1]) -------------------------------------------------------------------
+// 1920 x 1080 -> 224 x 224: an output row needs exactly TWO source rows, and with a tap pair (24 bytes) every 103 bytes nearly every
+// 128-byte line of both rows holds a tap byte — the gather kernel above already moved that line-granular floor (2.8 GB per 256 images
+// against 0.77 GB of tap bytes), but as 896 scattered 12-byte requests per output row, at 5.3 TB/s (profiles/r05zzz_traffic.txt).  Here
+// a 256-thread block owns ONE output row: it streams the two source rows it needs into LDS with 16-byte lane-contiguous loads — every
+// load of the block requested before the first is waited for — and blends from LDS.  Same sampler expression as sample_bilinear
+// (P/interpolation/bilinear.rs:16-66: trunc, edge taps replicate val00), so the bits are those of resize_kernel; the host routes a
+// launch here when the rows are whole float4s on 16-byte-aligned images, a row pair fits LDS, the vertical step skips rows (>= 1.5:
+// no row is shared by two output rows) and the horizontal tap stride is at most one line (every line is needed anyway).
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+constexpr int kRowsBlockDefault = 256;
+extern __shared__ __attribute__((aligned(16))) float lds_rows[];
+// `split` blocks share an output row (each a run of output columns and the source-row segment under it): the LDS footprint of a block
+// is what bounds the blocks per CU here, and a 1080p row pair is 46 KB.
+__host__ __device__ __forceinline__ int rows_src_px(float ax, float bx, int x, int sw) {   // first tap column of output column x
+    return (int)fminf(fmaxf(ax * (float)x + bx, 0.0f), (float)(sw - 1));
+}
+template <int C, int ITER, int BLOCK, bool LIST>
+__global__ __launch_bounds__(BLOCK) void resize_rows_bilinear_kernel(Img im, float ax, float bx, float ay, float by, FastDiv by_rows, FastDiv by_parts,
+                                                                     int parts, int part_cols, int seg4_max, typename ListArg<LIST>::type lst) {
+    constexpr int kRowsBlock = BLOCK;
+    const int t = threadIdx.x;
+    // block -> (image z, output row y, column part): parts of `part_cols` output columns
+    const unsigned rows_total = im.dh * (unsigned)parts;
+    const unsigned z = fast_quot(blockIdx.x, by_rows), rem = blockIdx.x - z * rows_total;
+    const unsigned y = fast_quot(rem, by_parts), part = rem - y * (unsigned)parts;
+    const int x_lo = (int)part * part_cols, x_hi = min(x_lo + part_cols, im.dw);   // block-uniform
+    const float* src = image_src<LIST>(im, lst, z);
+    const float sy = clampf(ay * (float)y + by, 0.0f, (float)(im.sh - 1));
+    const int iv = (int)sy;
+    const float frac_v = sy - truncf(sy);
+    const bool hy = iv + 1 < im.sh;                      // block-uniform
+    // the float4 segment [s4, s4 + n4) of a source row that holds every tap of columns [x_lo, x_hi)
+    const int n4row = (im.sw * C) >> 2;
+    const int s4 = (rows_src_px(ax, bx, x_lo, im.sw) * C) >> 2;
+    const int e4 = min(((min(rows_src_px(ax, bx, x_hi - 1, im.sw) + 1, im.sw - 1) + 1) * C + 3) >> 2, n4row);
+    const int n4 = min(e4 - s4, seg4_max);              // (host-checked: e4 - s4 <= seg4_max <= ITER * 256)
+    const f32x4g* g0 = reinterpret_cast<const f32x4g*>(src + (long long)iv * im.sw * C) + s4;
+    const f32x4g* g1 = g0 + (hy ? n4row : 0);            // no row below: its taps replicate val00 and row 1 is never read; load row 0 twice
+    f32x4g q0[ITER], q1[ITER];
+#pragma unroll
+    for (int j = 0; j < ITER; ++j) {                     // unconditional loads at clamped indices: 2 * ITER requests in flight per lane
+        const int i = min(t + kRowsBlock * j, n4 - 1);
+        q0[j] = g0[i];
+        q1[j] = g1[i];
+    }
+    f32x4g* r0v = reinterpret_cast<f32x4g*>(lds_rows);
+    f32x4g* r1v = r0v + seg4_max;
+#pragma unroll
+    for (int j = 0; j < ITER; ++j) {
+        const int i = min(t + kRowsBlock * j, n4 - 1);   // (lanes past the segment rewrite its last float4 with the same value)
+        r0v[i] = q0[j];
+        r1v[i] = q1[j];
+    }
+    __syncthreads();
+    const float* r0 = lds_rows - 4 * s4;                 // indexed by the ROW's float index
+    const float* r1 = r0 + 4 * seg4_max;
+    const __amdgpu_buffer_rsrc_t ow = stream_window(image_dst<LIST>(im, lst, z) + (long long)y * im.dw * C, (long long)im.dw * C * 4);
+    const float frac_vv = 1.0f - frac_v;
+    for (int x = x_lo + t; x < x_hi; x += kRowsBlock) {
+        const float sx = clampf(ax * (float)x + bx, 0.0f, (float)(im.sw - 1));
+        const int iu = (int)sx;
+        const float frac_u = sx - truncf(sx);
+        const bool hx = iu + 1 < im.sw;
+        const float frac_uu = 1.0f - frac_u;
+        const float w00 = frac_vv * frac_uu, w10 = frac_vv * frac_u, w01 = frac_v * frac_uu, w11 = frac_v * frac_u;
+        const float* p00 = r0 + iu * C;
+        const float* p01 = hx ? p00 + C : p00;
+        const float* p10 = hy ? r1 + iu * C : p00;
+        const float* p11 = (hx && hy) ? r1 + iu * C + C : p00;
+        uint32_t w[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) w[c] = __float_as_uint(w00 * p00[c] + w10 * p01[c] + w01 * p10[c] + w11 * p11[c]);
+        stream_store<C>(ow, x * C * 4, w);
+    }
 }
 
 // resize_bilinear_normalize_3c (P/cuda/resize.rs:184-236): bilinear resize fused with `(px - mean) * inv_std`, HWC in,
@@ -589,6 +668,54 @@ int32_t resize_impl(const char* what, kh_stream_t stream, const BatchRef& b, int
             }
             return check_launch("kh_resize_f32 (lanczos)");
         });
+    }
+    // bilinear downscales whose taps touch nearly every line of two source rows per output row: the row-streamed kernel (test option
+    // resize_rows = 0 keeps the gather kernel)
+    const bool rows_ok = mode == KH_INTERP_BILINEAR && dev_opt(kOptResizeRows) != 0 && (sw * channels) % 4 == 0 && ay >= 1.5f &&
+                         ax * (float)(channels * 4) <= 128.0f && batch_aligned(b, 16, sizeof(float));
+    if (rows_ok) {
+        // An output row is cut into parts of `part_cols` columns, one block each (a block stages only the source-row segments under its
+        // columns).  Two things decide the width (profiles/r06k_resize_rows_split.txt, C2: 7 parts of 32 columns 0.450 ms; 1 / 2 / 4 / 8
+        // parts 0.484-0.492; 16 parts 0.90): a part's output bytes should be WHOLE 128-byte lines — two blocks writing halves of one line
+        // cost more than anything else here — and its segment pair small enough that eight blocks share a CU's LDS.  So: a multiple of
+        // the columns that make a whole line (32 for C = 1 / 3, 8 for C = 4) whose source segment is about 4 KB.
+        // Test option resize_rows = N > 0: N columns per part; + 1000: 64-thread blocks, + 2000: 128-thread blocks.
+        const int opt = dev_opt(kOptResizeRows);
+        const int block = opt >= 2000 ? 128 : (opt >= 1000 ? 64 : kRowsBlockDefault);
+        const int unit = channels == 4 ? 8 : 32;
+        int part_cols = opt > 0 && opt % 1000 ? opt % 1000 : std::max(1, (int)(4096.0f / (ax * (float)(channels * 4))) / unit) * unit;
+        if (part_cols > dw) part_cols = dw;
+        const int parts = (dw + part_cols - 1) / part_cols;
+        // the longest source segment any part needs (host evaluation of the kernel's own expressions)
+        int seg4_max = 1;
+        for (int part = 0; part < parts; ++part) {
+            const int x_lo = part * part_cols, x_hi = std::min(x_lo + part_cols, dw);
+            const int s4 = (rows_src_px(ax, bx, x_lo, sw) * channels) >> 2;
+            const int e4 = std::min(((std::min(rows_src_px(ax, bx, x_hi - 1, sw) + 1, sw - 1) + 1) * channels + 3) >> 2, (sw * channels) >> 2);
+            seg4_max = std::max(seg4_max, e4 - s4);
+        }
+        const int iters = (seg4_max + block - 1) / block;
+        if (iters <= 8 && (int64_t)dh * parts * b.n <= kI32Max && (size_t)seg4_max * 32 <= 64 * 1024)
+            return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+                Img im = make_img(c, sw, sh, dw, dh, c.n);
+                const dim3 grid((unsigned)dh * (unsigned)parts * (unsigned)c.n), blk(block);
+                const size_t lds = (size_t)2 * seg4_max * 16;
+                const FastDiv by_rows = fast_div((uint32_t)dh * (uint32_t)parts), by_parts = fast_div((uint32_t)parts);
+                const NoList none{0};
+                const int it = iters <= 1 ? 1 : (iters <= 2 ? 2 : (iters <= 4 ? 4 : 8));
+#define KH_ROWS(CC, IT, BL)                                                                                                                                       \
+    do {                                                                                                                                                          \
+        if (c.listed()) hipLaunchKernelGGL((resize_rows_bilinear_kernel<CC, IT, BL, true>), grid, blk, lds, st, im, ax, bx, ay, by, by_rows, by_parts, parts, part_cols, seg4_max, lst); \
+        else hipLaunchKernelGGL((resize_rows_bilinear_kernel<CC, IT, BL, false>), grid, blk, lds, st, im, ax, bx, ay, by, by_rows, by_parts, parts, part_cols, seg4_max, none);          \
+    } while (0)
+#define KH_ROWS_B(CC, IT) do { if (block == 64) KH_ROWS(CC, IT, 64); else if (block == 128) KH_ROWS(CC, IT, 128); else KH_ROWS(CC, IT, 256); } while (0)
+#define KH_ROWS_C(CC) do { switch (it) { case 1: KH_ROWS_B(CC, 1); break; case 2: KH_ROWS_B(CC, 2); break; case 4: KH_ROWS_B(CC, 4); break; default: KH_ROWS_B(CC, 8); break; } } while (0)
+                switch (channels) { case 1: KH_ROWS_C(1); break; case 3: KH_ROWS_C(3); break; default: KH_ROWS_C(4); break; }
+#undef KH_ROWS_C
+#undef KH_ROWS_B
+#undef KH_ROWS
+                return check_launch(what);
+            });
     }
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
         const Img im = make_img(c, sw, sh, dw, dh, c.n);

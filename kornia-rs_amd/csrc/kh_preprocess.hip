@@ -48,17 +48,23 @@ struct PreArgs {
     const float* lz_wx;          // Lanczos only: 6 axis weights per destination column / row, built on the host (see lanczos_tables)
     const float* lz_wy;
     int quad_wide;               // preprocess_generic_quads, NV12 / YUYV: the taps of every destination quad fit one 16-byte run per plane row (host-checked)
-    int listed;                  // frame bases from the launch's FrameList instead of src_base + frame * src_frame_stride
 };
 
 // kh_preprocess_to_chw_list: the reference's `run_raw_batch(frames: &[&CudaSlice<u8>], ..)` (P/preprocess.rs:1258-1282) hands over
 // separately allocated frame buffers and launches once per frame.  Here the bases of up to kFrameListMax frames travel by value in the
 // kernel arguments (2 KiB; a block reads its frame's base with one scalar load) and the batch goes out as ceil(n / 256) launches:
 // 4.374 ms against 4.373 ms for the equally spaced form on the north star (profiles/r06a_ubench_nv12_one_store.txt).
+// The list kernels are separate instantiations (LIST = true): selecting at run time inside one kernel cost the equally spaced launches
+// of the short-lived gather kernels a few per cent (round 6, profiles/r06c / r06i), so LIST = false is the round-5 kernel argument for argument.
 constexpr int kFrameListMax = 256;
 struct FrameList { const uint8_t* p[kFrameListMax]; };
-__device__ __forceinline__ const uint8_t* frame_base(const FrameList& fl, const PreArgs& a, const uint8_t* src_base, unsigned frame) {
-    return a.listed ? fl.p[frame] : src_base + (long long)frame * a.src_frame_stride;
+struct NoFrames { int unused; };
+template <bool LIST> struct FrameArg { typedef NoFrames type; };
+template <> struct FrameArg<true> { typedef FrameList type; };
+template <bool LIST>
+__device__ __forceinline__ const uint8_t* frame_base(const typename FrameArg<LIST>::type& fl, const PreArgs& a, const uint8_t* src_base, unsigned frame) {
+    if constexpr (LIST) return fl.p[frame];
+    else return src_base + (long long)frame * a.src_frame_stride;
 }
 
 // BT.601 limited-range Q20 decode, constants of P/color/yuv/kernels.rs:696-702 and the fused
@@ -383,15 +389,15 @@ __host__ __device__ __forceinline__ float quot3(float n, float d, float rc) {
 // 2.46 ms on 1080p -> 640x640 x 1024; no per-pixel integer division either).  grid.z = frame.
 constexpr int kGenPx = 4;
 constexpr int kSampleBilinearOnGrid = 100;   // internal sampler id: bilinear whose taps all sit on whole source pixels (bilinear_taps_on_grid below)
-template <int FMT, int SAMPLER, typename OutT, bool WIDE>
+template <int FMT, int SAMPLER, typename OutT, bool WIDE, bool LIST>
 __global__ __launch_bounds__(kBlock) void preprocess_generic(const uint8_t* __restrict__ src_base,
                                                              OutT* __restrict__ dst_base,
-                                                             PreArgs a, FrameList fl) {
+                                                             PreArgs a, typename FrameArg<LIST>::type fl) {
     const int pixels = a.dst_w * a.dst_h;
     const int ox0 = blockIdx.x * (64 * kGenPx) + threadIdx.x;
     const int oy = blockIdx.y * 4 + threadIdx.y;
     if (ox0 >= a.dst_w || oy >= a.dst_h) return;
-    const uint8_t* src = frame_base(fl, a, src_base, blockIdx.z);
+    const uint8_t* src = frame_base<LIST>(fl, a, src_base, blockIdx.z);
     OutT* dst = dst_base + (long long)blockIdx.z * a.dst_frame_stride;
     const float ny = (float)oy - a.pad_y;
     const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
@@ -515,13 +521,13 @@ __device__ __forceinline__ void quad_taps_nv12_bilinear(const uint8_t* __restric
 // 6 % above its floor (profiles/r05j_four_tap_decode_ablation.txt).  Not kept.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kQuadBlock = 256;
-template <int FMT, int SAMPLER, bool WIDE>
+template <int FMT, int SAMPLER, bool WIDE, bool LIST>
 __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uint8_t* __restrict__ src_base, float* __restrict__ dst_base,
-                                                                       PreArgs a, FastDiv by_wq, FrameList fl) {
+                                                                       PreArgs a, FastDiv by_wq, typename FrameArg<LIST>::type fl) {
     const int wq = a.dst_w >> 2, groups = wq * a.dst_h, plane = a.dst_w * a.dst_h;   // host-checked: 12 * plane < 2^31
     const int g = blockIdx.x * kQuadBlock + threadIdx.x;
     if (g >= groups) return;
-    const uint8_t* src = frame_base(fl, a, src_base, blockIdx.y);
+    const uint8_t* src = frame_base<LIST>(fl, a, src_base, blockIdx.y);
     const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_base + (long long)blockIdx.y * a.dst_frame_stride, (uint32_t)(12 * plane));
     const int oy = (int)fast_quot((uint32_t)g, by_wq), ox0 = 4 * (g - oy * wq);
     const float ny = (float)oy - a.pad_y;
@@ -882,13 +888,21 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
             const FastDiv by_wq = fast_div((uint32_t)wq);
             PreArgs aq = a;
             aq.quad_wide = wide_nv12 ? 1 : 0;   // test option pre_quads = 3: per-tap loads everywhere
-            if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, fl);
-            else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, fl);
+            const NoFrames none{0};
+            if (f.listed()) {
+                if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true, true>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, fl);
+                else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false, true>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, fl);
+            } else {
+                if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true, false>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, none);
+                else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false, false>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, none);
+            }
             return;
         }
     }
     const dim3 blk(64, 4);
-#define KH_GEN(T, W) hipLaunchKernelGGL((preprocess_generic<FMT, SAMPLER, T, W>), grid, blk, 0, s, src, (T*)dst, a, fl)
+    const NoFrames none{0};
+#define KH_GEN(T, W) do { if (f.listed()) hipLaunchKernelGGL((preprocess_generic<FMT, SAMPLER, T, W, true>), grid, blk, 0, s, src, (T*)dst, a, fl); \
+                          else hipLaunchKernelGGL((preprocess_generic<FMT, SAMPLER, T, W, false>), grid, blk, 0, s, src, (T*)dst, a, none); } while (0)
     if (out_dtype == KH_OUT_F32) { if (wide) KH_GEN(float, true); else KH_GEN(float, false); }
     else { if (wide) KH_GEN(unsigned short, true); else KH_GEN(unsigned short, false); }
 #undef KH_GEN
@@ -930,7 +944,6 @@ int32_t preprocess_impl(kh_stream_t stream, const Frames& f, void* dst, const kh
     a.fast_div = plan_division_is_exact(a) ? 1 : 0;
     a.lz_wx = a.lz_wy = nullptr;
     a.quad_wide = 0;
-    a.listed = f.listed() ? 1 : 0;
     hipStream_t s = as_hip(stream);
 
     const bool identity = identity_fast_path(p, f, dst);

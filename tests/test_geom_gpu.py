@@ -44,6 +44,27 @@ def test_resize_matches_oracle(gpu_stream, mode, shape, c):
     assert_same_bits(got, O.resize(src, dw, dh, mode), f"resize {shape} c{c} {mode}")
 
 
+@pytest.mark.parametrize("shape", [(128, 96, 30, 22), (1920, 40, 224, 8), (64, 300, 20, 7), (2048, 12, 200, 5), (16, 64, 4, 3)])
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_resize_bilinear_row_streamed_kernel(gpu_stream, dev_option, shape, c):
+    """Bilinear downscales with whole-float4 rows and a vertical step >= 1.5 take the row-streamed kernel (two source rows per output
+    row through LDS): the oracle's bits, in a batch (block -> (image, row) decode), with the last source row / column among the taps;
+    test option resize_rows = 0 routes the same call to the gather kernel."""
+    sw, sh, dw, dh = shape
+    if sw / dw * c * 4 > 128:
+        pytest.skip("tap stride wider than one line: the launcher keeps the gather kernel")
+    n = 3
+    src = np.stack([img(sw, sh, c, seed=31 * k) for k in range(n)])
+    got = resize_gpu(gpu_stream, src, dw, dh, "bilinear", batch=n)
+    for k in range(n):
+        assert_same_bits(got[k], O.resize(src[k], dw, dh, "bilinear"), f"rows kernel {shape} c{c} image {k}")
+    for cols in (dw, 32, 7, 1008, 2003, 1):   # columns per part (each part stages its own source-row segments); + 1000 / 2000: 64- / 128-thread blocks
+        dev_option("resize_rows", cols)
+        assert_same_bits(resize_gpu(gpu_stream, src, dw, dh, "bilinear", batch=n), got, f"part width option {cols}")
+    dev_option("resize_rows", 0)
+    assert_same_bits(resize_gpu(gpu_stream, src, dw, dh, "bilinear", batch=n), got, "gather kernel vs row-streamed kernel")
+
+
 def test_resize_smoke_known_answer(gpu_stream):  # resize/mod.rs:447-490
     src = np.arange(36, dtype=np.float32).reshape(4, 3, 3)
     got = resize_gpu(gpu_stream, src, 2, 3, "bilinear")[0].reshape(-1)
