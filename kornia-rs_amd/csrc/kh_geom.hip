@@ -23,6 +23,7 @@ using namespace kh;
 namespace {
 
 constexpr int kBx = 64, kBy = 4;
+constexpr float kPxMaxRows = 8.0f;   // two-pixels-per-lane warps: the most source rows a 128-pixel destination run may cross
 
 struct Img {  // one batch of same-sized HWC f32 images
     const float* src;
@@ -417,18 +418,16 @@ __global__ __launch_bounds__(kBx* kBy) void resize_lanczos_kernel(Img im, const 
 struct Mat6 { float m[6]; };
 struct Mat9 { float m[9]; };
 
-// warp_affine (P/warp/affine.rs:123-372); mi = inverse 2x3
-template <int C, int MODE, bool LIST>
-__global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi, typename ListArg<LIST>::type lst) {
-    KH_PIXEL_PROLOGUE
+// warp_affine (P/warp/affine.rs:123-372); mi = inverse 2x3.  One destination pixel: false = out of bounds (the caller writes 0).
+template <int C, int MODE>
+__device__ __forceinline__ bool affine_pixel(const float* __restrict__ src, const Img& im, const Mat6& mi, int x, int y, float v[C]) {
     const float swf = (float)im.sw, shf = (float)im.sh;
     const float sx0 = mi.m[1] * (float)y + mi.m[2], sy0 = mi.m[4] * (float)y + mi.m[5];
     const float sx = mi.m[0] * (float)x + sx0, sy = mi.m[3] * (float)x + sy0;
     // in_bounds incl. the degenerate-axis rule (:201-215)
     const bool x_ok = fabsf(mi.m[0]) < 1e-6f ? (sx0 >= 0.0f && sx0 < swf) : (sx >= 0.0f && sx < swf);
     const bool y_ok = fabsf(mi.m[3]) < 1e-6f ? (sy0 >= 0.0f && sy0 < shf) : (sy >= 0.0f && sy < shf);
-    if (!(x_ok && y_ok)) { put_zero<C>(o, x); return; }
-    float v[C];
+    if (!(x_ok && y_ok)) return false;
     if constexpr (MODE == KH_INTERP_NEAREST) {  // :270-276
         const long long xi = (long long)clampf(roundf(sx), 0.0f, swf - 1.0f);
         const long long yi = (long long)clampf(roundf(sy), 0.0f, shf - 1.0f);
@@ -450,7 +449,36 @@ __global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi, 
     } else {  // per-pixel samplers on the unclamped coordinate (:322-362)
         sample<C, MODE>(src, im.sh, im.sw, sx, sy, v);
     }
-    put<C>(o, x, v);
+    return true;
+}
+template <int C, int MODE, bool LIST>
+__global__ __launch_bounds__(kBx* kBy) void warp_affine_kernel(Img im, Mat6 mi, typename ListArg<LIST>::type lst) {
+    KH_PIXEL_PROLOGUE
+    float v[C];
+    if (affine_pixel<C, MODE>(src, im, mi, x, y, v)) put<C>(o, x, v);
+    else put_zero<C>(o, x);
+}
+// PX pixels of one row per lane, 64 apart (see warp_perspective_px_kernel)
+template <int C, int MODE, int PX, bool LIST>
+__global__ __launch_bounds__(kBx* kBy) void warp_affine_px_kernel(Img im, Mat6 mi, typename ListArg<LIST>::type lst) {
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;
+    const int x0 = bx_ * (kBx * PX) + threadIdx.x;
+    const int y = by_ * kBy + threadIdx.y;
+    if (x0 >= im.dw || y >= im.dh) return;
+    const float* src = image_src<LIST>(im, lst, bz_);
+    const OutRow o = out_row<C>(image_dst<LIST>(im, lst, bz_) + (long long)y * im.dw * C, im.dw);
+    float val[PX][C];
+    bool in[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) in[j] = affine_pixel<C, MODE>(src, im, mi, min(x0 + kBx * j, im.dw - 1), y, val[j]);   // lanes past the row recompute its last pixel and store nothing
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int x = x0 + kBx * j;
+        if (x >= im.dw) break;
+        if (in[j]) put<C>(o, x, val[j]);
+        else put_zero<C>(o, x);
+    }
 }
 
 // warp_perspective (P/warp/perspective.rs:67-72,115-166); im9 = inverse 3x3
@@ -467,6 +495,40 @@ __global__ __launch_bounds__(kBx* kBy) void warp_perspective_kernel(Img im, Mat9
         put<C>(o, x, val);
     } else {
         put_zero<C>(o, x);  // also catches NaN / Inf from w == 0
+    }
+}
+
+// warp_perspective, PX pixels of one row per lane, 64 apart (round 6): every load / store instruction of a wave still covers 64
+// consecutive pixels while PX independent tap quads are in flight per lane — what made the generic preprocess kernel (kGenPx = 4).
+// Same expressions per pixel as warp_perspective_kernel.
+template <int C, int MODE, int PX, bool LIST>
+__global__ __launch_bounds__(kBx* kBy) void warp_perspective_px_kernel(Img im, Mat9 h, typename ListArg<LIST>::type lst) {
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;
+    const int x0 = bx_ * (kBx * PX) + threadIdx.x;
+    const int y = by_ * kBy + threadIdx.y;
+    if (x0 >= im.dw || y >= im.dh) return;
+    const float* src = image_src<LIST>(im, lst, bz_);
+    const OutRow o = out_row<C>(image_dst<LIST>(im, lst, bz_) + (long long)y * im.dw * C, im.dw);
+    const float yf = (float)y;
+    float val[PX][C];
+    bool in[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int x = min(x0 + kBx * j, im.dw - 1);   // lanes past the row recompute its last pixel and store nothing
+        const float xf = (float)x;
+        const float w = h.m[6] * xf + h.m[7] * yf + h.m[8];
+        const float u = (h.m[0] * xf + h.m[1] * yf + h.m[2]) / w;
+        const float v = (h.m[3] * xf + h.m[4] * yf + h.m[5]) / w;
+        in[j] = u >= 0.0f && u < (float)im.sw && v >= 0.0f && v < (float)im.sh;
+        if (in[j]) sample<C, MODE>(src, im.sh, im.sw, u, v, val[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int x = x0 + kBx * j;
+        if (x >= im.dw) break;
+        if (in[j]) put<C>(o, x, val[j]);
+        else put_zero<C>(o, x);
     }
 }
 
@@ -754,6 +816,24 @@ int32_t warp_affine_impl(const char* what, kh_stream_t stream, const BatchRef& b
     if (b.n == 0) return KH_OK;
     Mat6 mi;
     kh_invert_affine_transform(m, mi.m);
+    // Two pixels per lane (see kh_warp_perspective_f32) only where a destination row maps to a nearly horizontal source run: the 12-degree
+    // rotation of the bench (a 128-pixel run crosses 27 source rows) LOSES 10 % with it (2.62 vs 2.38 ms, profiles/r06p_px2_bench.txt).
+    // Test option warp_f32_px: 1 = never, 2 = always.
+    const int px_opt = dev_opt(kOptWarpF32Px);
+    if (mode == KH_INTERP_BILINEAR && px_opt != 1 && (px_opt == 2 || fabsf(mi.m[3]) * (float)(2 * kBx) <= kPxMaxRows))
+        return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+            constexpr int PX = 2;
+            Img im = make_img(c, sw, sh, dw, dh, c.n);
+            im.tiles = xcd_tiles(cdiv(dw, kBx * PX), cdiv(dh, kBy), (unsigned)c.n, cdiv(dw, kBx * PX) * 8);
+            KH_REQUIRE_TILES(what, im);
+            const dim3 blk(kBx, kBy), grid = xcd_grid(im.tiles);
+            const NoList none{0};
+#define KH_PX(CC) do { if (c.listed()) hipLaunchKernelGGL((warp_affine_px_kernel<CC, KH_INTERP_BILINEAR, PX, true>), grid, blk, 0, as_hip(stream), im, mi, lst); \
+                       else hipLaunchKernelGGL((warp_affine_px_kernel<CC, KH_INTERP_BILINEAR, PX, false>), grid, blk, 0, as_hip(stream), im, mi, none); } while (0)
+            switch (channels) { case 1: KH_PX(1); break; case 3: KH_PX(3); break; default: KH_PX(4); break; }
+#undef KH_PX
+            return check_launch(what);
+        });
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
         const Img im = make_img(c, sw, sh, dw, dh, c.n);
         KH_REQUIRE_TILES(what, im);
@@ -769,6 +849,34 @@ int32_t warp_perspective_impl(const char* what, kh_stream_t stream, const BatchR
     Mat9 h;
     if (int32_t rc = kh_invert_homography(m, h.m)) return rc;  // rejected on the host, before any launch
     if (b.n == 0) return KH_OK;
+    // Bilinear: two pixels of a row per lane, 64 apart (warp_perspective_px_kernel): 4.58 vs 4.88 ms per 128 4K images, four pixels
+    // 4.76 (profiles/r06n_warp_px.txt); an LDS-staged twin of the u8 gather (source box of a 64 x 16 tile copied with 16-byte loads,
+    // four images per block, next box requested while the current one is sampled) ran 7.77 ms (r06o) and is not in the library.
+    // Only where a destination row maps to a nearly horizontal source run (source rows crossed by a 128-pixel destination run, sampled at
+    // the corners and the centre of the destination <= kPxMaxRows): a rotated run spreads a wave's taps over many rows and the wider
+    // tile then loses (warp_affine by 12 degrees: -10 %, r06p).  Test option warp_f32_px: 1 = the one-pixel kernel, 2 = always two.
+    const int px_opt = dev_opt(kOptWarpF32Px);
+    bool flat_rows = true;
+    for (int k = 0; k < 5 && flat_rows; ++k) {
+        const float xs = k == 4 ? 0.5f * (float)dw : ((k & 1) ? (float)(dw - 1) : 0.0f), ys = k == 4 ? 0.5f * (float)dh : ((k & 2) ? (float)(dh - 1) : 0.0f);
+        auto vmap = [&](float xf, float yf) { return (h.m[3] * xf + h.m[4] * yf + h.m[5]) / (h.m[6] * xf + h.m[7] * yf + h.m[8]); };
+        const float tilt = fabsf(vmap(xs + 1.0f, ys) - vmap(xs, ys)) * (float)(2 * kBx);
+        flat_rows = tilt <= kPxMaxRows;   // (false for NaN)
+    }
+    if (mode == KH_INTERP_BILINEAR && px_opt != 1 && (px_opt == 2 || flat_rows))
+        return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+            constexpr int PX = 2;
+            Img im = make_img(c, sw, sh, dw, dh, c.n);
+            im.tiles = xcd_tiles(cdiv(dw, kBx * PX), cdiv(dh, kBy), (unsigned)c.n, cdiv(dw, kBx * PX) * 8);
+            KH_REQUIRE_TILES(what, im);
+            const dim3 blk(kBx, kBy), grid = xcd_grid(im.tiles);
+            const NoList none{0};
+#define KH_PX(CC) do { if (c.listed()) hipLaunchKernelGGL((warp_perspective_px_kernel<CC, KH_INTERP_BILINEAR, PX, true>), grid, blk, 0, as_hip(stream), im, h, lst); \
+                       else hipLaunchKernelGGL((warp_perspective_px_kernel<CC, KH_INTERP_BILINEAR, PX, false>), grid, blk, 0, as_hip(stream), im, h, none); } while (0)
+            switch (channels) { case 1: KH_PX(1); break; case 3: KH_PX(3); break; default: KH_PX(4); break; }
+#undef KH_PX
+            return check_launch(what);
+        });
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
         const Img im = make_img(c, sw, sh, dw, dh, c.n);
         KH_REQUIRE_TILES(what, im);

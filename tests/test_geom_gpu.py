@@ -121,6 +121,23 @@ def test_warp_affine_matches_oracle(gpu_stream, mode, name):
         assert_same_bits(got, O.warp_affine(src, m, dw, dh, mode), f"affine {name} {mode} -> {dw}x{dh}")
 
 
+@pytest.mark.parametrize("name", ["identity", "rot30", "shear", "rot180x2"])
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_warp_affine_two_pixels_per_lane(gpu_stream, dev_option, name, c):
+    """Bilinear warp_affine: the one-pixel kernel, the two-pixels-per-lane kernel (forced; the launcher takes it for nearly horizontal
+    source runs only) and the launcher's own choice all give the oracle's bits; widths that leave partial 128-pixel tiles; a batch."""
+    w, h = 129, 97
+    m = {"identity": [1, 0, 0, 0, 1, 0], "shear": [1.0, 0.3, -4.0, 0.02, 0.95, 3.0], "rot30": rotation(64.0, 48.0, 30.0, 1.1),
+         "rot180x2": rotation(64.5, 48.5, 180.0, 2.0)}[name]
+    n = 3
+    src = np.stack([img(w, h, c, seed=31 * k) for k in range(n)])
+    for dw, dh in [(w, h), (64, 5), (65, 7), (200, 30)]:
+        want = np.stack([O.warp_affine(src[k], m, dw, dh, "bilinear") for k in range(n)])
+        for opt in (-1, 1, 2):
+            dev_option("warp_f32_px", opt)
+            assert_same_bits(warp_gpu(gpu_stream, "affine", src, m, dw, dh, "bilinear", batch=n), want, f"affine {name} c{c} -> {dw}x{dh} option {opt}")
+
+
 def test_warp_affine_known_answers(gpu_stream):  # warp/affine.rs:471-640
     src = np.array([[1, 2, 3, 4], [5, 6, 7, 8]], np.float32)[:, :, None]
     got = warp_gpu(gpu_stream, "affine", src, [-1, 0, 3, 0, 1, 0], 4, 2, "nearest")[0]
@@ -149,6 +166,28 @@ def test_warp_perspective_matches_oracle(gpu_stream, mode, name, c):
     assert_same_bits(got, O.warp_perspective(src, m, w, h, mode), f"perspective {name} {mode}")
     if name == "identity" and mode not in ("bicubic", "lanczos"):
         assert np.array_equal(got, src)
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("case", ["near_affine", "identity", "strong", "shrink", "all_outside", "upscale"])
+def test_warp_perspective_two_pixels_per_lane(gpu_stream, dev_option, case, c):
+    """Bilinear warp_perspective runs two pixels of a row per lane (128 x 4 tiles): the oracle's bits for mild and strong
+    homographies, shrinks and upscales, all-outside tiles, batches, destination widths that leave a partial half-tile; test option
+    warp_f32_px = 1 routes the same call to the one-pixel kernel."""
+    sw, sh, dw, dh = 132, 70, 150, 61
+    m = {"near_affine": [1.03, 0.05, -3.0, -0.02, 0.97, 4.0, 2e-5, 1.5e-5, 1.0], "identity": [1, 0, 0, 0, 1, 0, 0, 0, 1],
+         "strong": [0.9, 0.2, 5.0, -0.1, 1.1, -3.0, 2e-3, 1e-3, 1.0], "shrink": [3.0, 0, 0, 0, 3.0, 0, 0, 0, 1.0],
+         "all_outside": [1, 0, 1000.0, 0, 1, 0, 0, 0, 1], "upscale": [0.4, 0.01, 1.0, 0.0, 0.45, 2.0, 0, 0, 1.0]}[case]
+    for n, (w_, h_) in ((1, (dw, dh)), (5, (64, 9)), (2, (65, 4)), (2, (129, 5))):
+        src = np.stack([img(sw, sh, c, seed=31 * k) for k in range(n)])
+        want = np.stack([O.warp_perspective(src[k], m, w_, h_, "bilinear") for k in range(n)])
+        dev_option("warp_f32_px", 2)   # (the launcher itself takes the two-pixel kernel only for nearly horizontal source runs)
+        assert_same_bits(warp_gpu(gpu_stream, "perspective", src, m, w_, h_, "bilinear", batch=n), want, f"two pixels per lane {case} c{c} n{n}")
+        dev_option("warp_f32_px", -1)
+        assert_same_bits(warp_gpu(gpu_stream, "perspective", src, m, w_, h_, "bilinear", batch=n), want, f"launcher's choice {case} c{c} n{n}")
+        dev_option("warp_f32_px", 1)
+        assert_same_bits(warp_gpu(gpu_stream, "perspective", src, m, w_, h_, "bilinear", batch=n), want, f"one pixel per lane {case} c{c} n{n}")
+        dev_option("warp_f32_px", -1)
 
 
 def test_warp_perspective_known_and_singular(gpu_stream):  # warp/perspective.rs:497-590
