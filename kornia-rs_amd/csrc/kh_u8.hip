@@ -846,7 +846,7 @@ struct GatherOp {
     int dsx_q, dsy_q;                         // affine: Q16 column steps
     int batch;
     int nb = kStageNB;                        // images per block (set by launch_staged_gather)
-    int tile_rows = kStageH;                  // 32 or 16 destination rows per block (stage_rows below)
+    int tile_rows = kStageH;                  // 32 or 16 destination rows per block (stage_rows below); 8 = a 128 x 8 tile (perspective)
     int spans = 1;                            // affine: stage only the quads inside the per-row spans of the box (test option warp_u8_spans = 0: the whole box)
 };
 
@@ -984,9 +984,9 @@ __device__ __forceinline__ void staged_images(uint32_t* __restrict__ tile, const
     emit(nimg - 1, pend);
 }
 
-template <int C, int OP, int TH>
-__global__ __launch_bounds__(kStageW / 4 * TH) void gather_u8_staged_kernel(ImgU8 im, GatherOp op) {
-    constexpr int TW = kStageW, QX = TW / 4, NT = QX * TH, CAP = kStageCap * TH / kStageH;
+template <int C, int OP, int TH, int TW = kStageW>
+__global__ __launch_bounds__(TW / 4 * TH) void gather_u8_staged_kernel(ImgU8 im, GatherOp op) {
+    constexpr int QX = TW / 4, NT = QX * TH, CAP = kStageCap * (TW * TH) / (kStageW * kStageH);
     __shared__ __attribute__((aligned(16))) uint32_t tile[CAP];
     __shared__ uint32_t red[16];
     __shared__ uint32_t span_lo[OP == kOpAffine ? kSpanRows : 1], span_hi[OP == kOpAffine ? kSpanRows : 1];
@@ -1237,18 +1237,20 @@ int32_t launch_staged_gather(hipStream_t st, const uint8_t* src, uint8_t* dst, i
     GatherOp op = op_;
     op.nb = batch >= 128 ? 2 * kStageNB : kStageNB;
     op.spans = dev_opt(kOptWarpU8Spans) != 0;
-    const int forced = dev_opt(kOptWarpU8Rows), th = forced == 16 || forced == 32 ? forced : op.tile_rows;   // test option warp_u8_rows
-    const unsigned tiles_x = cdiv(dw, kStageW), tiles_y = cdiv(dh, th), groups = cdiv(batch, op.nb);
+    const int forced = dev_opt(kOptWarpU8Rows), th = forced == 16 || forced == 32 || forced == 8 ? forced : op.tile_rows;   // test option warp_u8_rows (8 = 128 x 8 tiles)
+    const int tw = th == 8 ? 128 : kStageW;
+    const unsigned tiles_x = cdiv(dw, tw), tiles_y = cdiv(dh, th), groups = cdiv(batch, op.nb);
     // 64 x 32 tiles, dealt to the XCDs in runs of 256 destination rows like the other gathers.  (128 x 16 tiles — whole 384-byte store rows,
     // WRITE_SIZE 6.50 -> 6.22 GB — r04z1: perspective -2 %, remap +6 %, the 12-degree rotation +34 %: its box needs four staging rounds.
     // Walking each band column-major, so that the blocks in flight form a 2-D patch — r04z5: reads 8.36 -> 7.27 GB on the rotation at
     // the same 3.19 ms, perspective and remap +3 %: the kernel is not bound by its traffic.)
     const ImgU8 im{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(tiles_x, tiles_y, groups, tiles_x * (256 / th))};
     KH_REQUIRE(im.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
-    const dim3 grid = xcd_grid(im.tiles), blk(kStageW / 4, th);
+    const dim3 grid = xcd_grid(im.tiles), blk(tw / 4, th);
 #define KH_STAGED(CH)                                                                                                \
     do {                                                                                                             \
-        if (th == 16) hipLaunchKernelGGL((gather_u8_staged_kernel<CH, OP, 16>), grid, blk, 0, st, im, op);           \
+        if (th == 8) hipLaunchKernelGGL((gather_u8_staged_kernel<CH, OP, 8, 128>), grid, blk, 0, st, im, op);        \
+        else if (th == 16) hipLaunchKernelGGL((gather_u8_staged_kernel<CH, OP, 16>), grid, blk, 0, st, im, op);      \
         else hipLaunchKernelGGL((gather_u8_staged_kernel<CH, OP, kStageH>), grid, blk, 0, st, im, op);               \
     } while (0)
     switch (channels) {
@@ -1401,7 +1403,13 @@ int32_t kh_warp_perspective_u8(kh_stream_t stream, const uint8_t* src, uint8_t* 
         {   // Jacobian of (x, y) -> (nx / nd, ny / nd) at the centre of the destination
             const float x = 0.5f * (float)dw, y = 0.5f * (float)dh;
             const float nd = inv.m[6] * x + inv.m[7] * y + inv.m[8], xs = (inv.m[0] * x + inv.m[1] * y + inv.m[2]) / nd, ys = (inv.m[3] * x + inv.m[4] * y + inv.m[5]) / nd;
-            op.tile_rows = stage_rows((inv.m[0] - xs * inv.m[6]) / nd, (inv.m[1] - xs * inv.m[7]) / nd, (inv.m[3] - ys * inv.m[6]) / nd, (inv.m[4] - ys * inv.m[7]) / nd);
+            const float ja = (inv.m[0] - xs * inv.m[6]) / nd, jb = (inv.m[1] - xs * inv.m[7]) / nd, jc = (inv.m[3] - ys * inv.m[6]) / nd, jd = (inv.m[4] - ys * inv.m[7]) / nd;
+            op.tile_rows = stage_rows(ja, jb, jc, jd);
+            // Round 6 (profiles/r06q_u8_gather_128x8.txt): 128 x 8 tiles — whole 384-byte store rows, the box of a
+            // near-axis-aligned map still staged in two rounds of the 256 threads — perspective 2.99 -> 2.87 ms (0.533 -> 0.557); remap
+            // +3 % and the 12-degree rotation falls off the box capacity (10.3 ms), so only this operator, only where the box fits.
+            const float bw = 128.0f * fabsf(ja) + 8.0f * fabsf(jb) + 2.0f, bh = 128.0f * fabsf(jc) + 8.0f * fabsf(jd) + 2.0f;
+            if (op.tile_rows == 16 && bw < 1e6f && bh < 1e6f && (ceilf(bw * 0.25f) + 1.0f) * ceilf(bh) <= 512.0f) op.tile_rows = 8;
         }
         return launch_staged_gather<kOpPersp>(as_hip(stream), src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, op, "kh_warp_perspective_u8");
     }

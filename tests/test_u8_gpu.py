@@ -186,7 +186,7 @@ def test_warp_affine_u8_whole_box_option(gpu_stream, dev_option, name, c):
     dev_option("warp_u8_spans", 0)
     assert_same_bits(warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0], want, f"staged affine_u8 {name} c{c} whole box")
     dev_option("warp_u8_spans", -1)
-    for rows in (16, 32):   # production picks the tile height from the matrix (kh_u8.hip::stage_rows); both, forced
+    for rows in (8, 16, 32):   # production picks the tile height from the matrix (kh_u8.hip::stage_rows); both, forced
         dev_option("warp_u8_rows", rows)
         assert_same_bits(warp_u8_gpu(gpu_stream, "affine", src, m, dw, dh)[0], want, f"staged affine_u8 {name} c{c} 64 x {rows} tiles")
 
@@ -274,7 +274,7 @@ def test_remap_u8_known_answers_and_identity(gpu_stream):  # remap.rs:552-672
 
 
 # ---- the staged gather (round 3) on the other two operators: multi-tile images, partial image groups, tiles whose box does not fit ----
-@pytest.mark.parametrize("rows", [-1, 16, 32])   # -1: the launcher's choice (kh_u8.hip::stage_rows); 64 x 16 / 64 x 32 tiles forced
+@pytest.mark.parametrize("rows", [-1, 8, 16, 32])   # -1: the launcher's choice (kh_u8.hip::stage_rows); 64 x 16 / 64 x 32 tiles forced
 @pytest.mark.parametrize("c", [1, 3, 4])
 @pytest.mark.parametrize("name", ["proj", "strong", "horizon", "neg"])
 def test_warp_perspective_u8_staged_tiles_match_oracle(gpu_stream, dev_option, c, name, rows):
@@ -287,7 +287,7 @@ def test_warp_perspective_u8_staged_tiles_match_oracle(gpu_stream, dev_option, c
             assert_same_bits(got[k], O.warp_perspective_u8(src[k], m, dw, dh), f"staged perspective_u8 {name} c{c} {w}x{h}->{dw}x{dh} frame {k}")
 
 
-@pytest.mark.parametrize("rows", [-1, 32])   # production: 64 x 16 tiles; 64 x 32 forced
+@pytest.mark.parametrize("rows", [-1, 8, 32])   # production: 64 x 16 tiles; 64 x 32 forced
 @pytest.mark.parametrize("c", [1, 3])
 @pytest.mark.parametrize("kind", ["smooth", "magnify", "minify", "wild", "all_outside"])
 def test_remap_u8_staged_tiles_match_oracle(gpu_stream, dev_option, c, kind, rows):
@@ -320,7 +320,7 @@ def test_remap_u8_staged_tiles_match_oracle(gpu_stream, dev_option, c, kind, row
         assert_same_bits(got[k], O.remap_u8(src[k], mx, my, "bilinear"), f"staged remap_u8 {kind} c{c} frame {k}")
 
 
-@pytest.mark.parametrize("rows", [16, 32])
+@pytest.mark.parametrize("rows", [8, 16, 32])
 @pytest.mark.parametrize("kind", ["affine", "perspective"])
 def test_staged_gather_sixteen_images_per_block(gpu_stream, dev_option, kind, rows):
     """Batches of 128 and more put 16 consecutive images in a block (8 below that).  130 images = eight full groups + a group of
