@@ -375,7 +375,7 @@ class ImageList(list):
 class ResizeBilinear(F32Images):
     """configs[1]: resize bilinear 1920x1080 -> 224x224 f32x3, batch 256."""
 
-    name, kernel = "resize_bilinear_1080p_to_224_f32_b256", "resize_kernel<3,bilinear>"
+    name, kernel = "resize_bilinear_1080p_to_224_f32_b256", "resize_rows_bilinear_kernel<3>"
     SW, SH, DW, DH, C = 1920, 1080, 224, 224, 3
 
     def __init__(self, batch):
@@ -613,7 +613,7 @@ class UndistortWarp4K(F32Images):
     """configs[4] per-GPU share: remap (Brown-Conrady maps, Oak-D parameters scaled to 4K) then
     warp_perspective (projective H), bilinear, f32x3 3840x2160, batch 256 per GPU."""
 
-    name, kernel = "undistort_remap_then_warp_perspective_4k_f32_b256", "remap_kernel<3,bilinear>+warp_perspective_kernel<3,bilinear>"
+    name, kernel = "undistort_remap_then_warp_perspective_4k_f32_b256", "remap_kernel<3,bilinear>+warp_perspective_px_kernel<3,bilinear,2>"
     W, H, C = 3840, 2160, 3
     # examples/undistort_image/src/main.rs:30-50 (1280x800 calibration), intrinsics scaled by 3840/1280, 2160/800
     INTR = (577.48583984375 * 3.0, 652.8748779296875 * 3.0, 577.48583984375 * 2.7, 386.1428833007812 * 2.7)

@@ -20,17 +20,21 @@ ROOT = Path(__file__).resolve().parents[1]
 # workload (bench.py name incl. batch) -> substrings of the kernels one step launches
 KERNELS = {
     "gray_from_rgb_u8_1080p_b1024": ["GrayFromRgbU8"],
-    "nv12_1080p_to_chw_f32_b1024": ["preprocess_nv12_identity"],
+    "nv12_1080p_to_chw_f32_b1024": ["preprocess_nv12_identity("],
     "nv12_1080p_to_chw_f32_letterbox640_b1024": ["preprocess_generic_quads<3, 100"],
     "nv12_1080p_to_chw_f32_letterbox608_b1024": ["preprocess_generic_quads<3, 1,", "preprocess_generic<3, 1, float"],
     "yuyv_1080p_to_chw_f32_letterbox640_b1024": ["preprocess_generic_quads<4, 100"],
-    "resize_bilinear_1080p_to_224_f32_b256": ["resize_kernel<3, 1", "resize_kernel<3,bilinear"],
-    "resize_bicubic_1080p_to_540p_f32_b256": ["resize_kernel<3, 2", "resize_kernel<3,bicubic"],
+    "resize_bilinear_1080p_to_224_f32_b256": ["resize_rows_bilinear_kernel<3, 1, 256, false"],
+    "resize_bilinear_1080p_to_224_f32_api_list_b256": ["resize_rows_bilinear_kernel<3, 1, 256, true"],
+    "resize_bicubic_1080p_to_540p_f32_b256": ["resize_kernel<3, 2, false"],
     "gaussian_blur_7x7_4k_f32_b256": ["sep_roll4_kernel<7"],
     "box_blur_5x5_4k_f32_b128": ["sep_roll4_kernel<5"],
     "sobel_3x3_4k_f32_b128": ["sep_roll_kernel<3, true"],
-    "undistort_remap_then_warp_perspective_4k_f32_b256": ["remap_kernel<", "warp_perspective_kernel<"],
-    "warp_affine_f32_1080p_b256": ["warp_affine_kernel<"],
+    "undistort_remap_then_warp_perspective_4k_f32_b256": ["remap_kernel<3, 1, false", "warp_perspective_px_kernel<3, 1, 2, false"],
+    "undistort_remap_then_warp_perspective_4k_f32_api_list_b256": ["remap_kernel<3, 1, true", "warp_perspective_px_kernel<3, 1, 2, true"],
+    "warp_affine_f32_1080p_b256": ["warp_affine_kernel<3, 1, false", "warp_affine_px_kernel<3, 1, 2, false"],
+    "nv12_1080p_to_chw_f32_frame_list_b1024": ["preprocess_nv12_identity_list"],
+    "gaussian_blur_7x7_4k_f32_api_list_b256": [],   # (shares sep_roll4_kernel<7 with the equally spaced row: not separable by name)
     "normalize_mean_std_1080p_f32_b512": ["normalize_mean_std_quads3_kernel", "normalize_mean_std_kernel<3"],
     "gray_from_rgb_f32_1080p_b1024": ["GrayFromRgbF32"],
     "hsv_from_rgb_f32_1080p_b512": ["HsvFromRgbF32"],
@@ -41,6 +45,11 @@ KERNELS = {
     "remap_u8_undistort_4k_b256": ["gather_u8_staged_kernel<3, 2,"],
     "gaussian_blur_u8_7x7_4k_b256": ["blur_u8_rgb_kernel<7>", "blur_u8_roll_kernel<7, 3"],
 }
+
+
+# launches of each matched kernel per step, where a step is more than one (pointer-list rows: 256 frames / 128 images per launch)
+LAUNCHES = {"nv12_1080p_to_chw_f32_frame_list_b1024": 4, "resize_bilinear_1080p_to_224_f32_api_list_b256": 2,
+            "undistort_remap_then_warp_perspective_4k_f32_api_list_b256": 2}
 
 
 def read(path, counter):
@@ -74,7 +83,7 @@ def main():
         total, hit = 0.0, False
         for k in fetch:
             if any(p in k for p in pats):
-                total += (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
+                total += (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0 * LAUNCHES.get(wl, 1)
                 hit = True
         if hit:
             res[wl] = int(round(total))
