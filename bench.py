@@ -174,7 +174,7 @@ class NorthStarNV12(Workload):
                          mean=IMAGENET_MEAN, std=IMAGENET_STD)
             frames += 1
             dt = time.perf_counter() - t0
-            if dt > budget or frames >= 256:
+            if dt > budget or frames >= 16384:
                 break
         return {"value": round(frames * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s",
                 "cores": threads, "kind": "port",
