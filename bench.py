@@ -649,30 +649,43 @@ class UndistortWarp4K(F32Images):
         self._price(stream, self.mx.ptr, self.my.ptr)
 
     def _price(self, stream, mx_ptr, my_ptr):
-        """Needed bytes per image: both destinations written (2 x 99.5 MB); per pass the source pixels of the IN-BOUNDS destination
-        pixels once (a 1:1-scale gather touches each source pixel about once: in-bounds share x 99.5 MB); the maps, 66 MB, once per
-        kRemapNB = 4 images.  In-bounds shares: the maps read back from the device; the homography evaluated in f32 like the kernel."""
+        """Needed bytes per image: both destinations written (2 x 99.5 MB); per pass the DISTINCT source pixels among the four taps of
+        the in-bounds destination pixels, 12 B each (an undistortion zooms in: its taps cover only part of the source; out-of-bounds
+        destination pixels read nothing); the maps, 66 MB, once per kRemapNB = 4 images.  Taps: the maps read back from the device; the
+        homography evaluated in f32 like the kernel.  The counted HBM traffic (profiles/pmc_traffic.json) cannot be below this at line
+        granularity, so frac <= the traffic-based rate."""
         from kornia_rs import hip
         f32 = np.float32
         n = self.W * self.H
         mx, my = np.empty(n, f32), np.empty(n, f32)
         hip.d2h(mx, mx_ptr, stream)
         hip.d2h(my, my_ptr, stream)
-        in_remap = float(np.mean((mx >= 0) & (mx < f32(self.W)) & (my >= 0) & (my < f32(self.H))))
+
+        def touched(u, v):
+            inside = (u >= 0) & (u < f32(self.W)) & (v >= 0) & (v < f32(self.H))
+            iu, iv = u[inside].astype(np.int64), v[inside].astype(np.int64)
+            iu1, iv1 = np.minimum(iu + 1, self.W - 1), np.minimum(iv + 1, self.H - 1)
+            seen = np.zeros(n, np.bool_)
+            for yy in (iv, iv1):
+                for xx in (iu, iu1):
+                    seen[yy * self.W + xx] = True
+            return float(inside.mean()), int(seen.sum())
+
+        in_remap, px_remap = touched(mx, my)
         inv = np.linalg.inv(np.array(self.hm, np.float64).reshape(3, 3)).astype(f32).reshape(-1)
         ys, xs = np.mgrid[0:self.H, 0:self.W].astype(f32)
         wv = inv[6] * xs + inv[7] * ys + inv[8]
-        u, v = (inv[0] * xs + inv[1] * ys + inv[2]) / wv, (inv[3] * xs + inv[4] * ys + inv[5]) / wv
-        in_warp = float(np.mean((u >= 0) & (u < f32(self.W)) & (v >= 0) & (v < f32(self.H))))
+        in_warp, px_warp = touched(((inv[0] * xs + inv[1] * ys + inv[2]) / wv).reshape(-1), ((inv[3] * xs + inv[4] * ys + inv[5]) / wv).reshape(-1))
         img = self.W * self.H * self.C * 4
         self.in_bounds = (round(in_remap, 4), round(in_warp, 4))
-        self.alg_bytes_per_launch = int(self.N * (2 * img + (in_remap + in_warp) * img + 2 * n * 4 / 4))
+        self.src_share = (round(px_remap / n, 4), round(px_warp / n, 4))   # share of the source each pass actually reads
+        self.alg_bytes_per_launch = int(self.N * (2 * img + (px_remap + px_warp) * self.C * 4 + 2 * n * 4 / 4))
 
     def roofline_extra(self, mean_step_s):
         return {"survey_bytes_per_launch": self.survey_bytes_per_launch,
                 "frac_on_survey_bytes": round(self.survey_bytes_per_launch / mean_step_s / 1e9 / HBM_PEAK_GBS, 4),
-                "in_bounds_share_remap_warp": list(self.in_bounds),
-                "pricing": "needed bytes: 2 destinations + in-bounds share of the source per pass + maps once per 4 images; "
+                "in_bounds_share_remap_warp": list(self.in_bounds), "source_share_read_remap_warp": list(self.src_share),
+                "pricing": "needed bytes: 2 destinations + the distinct source pixels under the taps of each pass + maps once per 4 images; "
                            "survey_bytes = SURVEY.md 8(d)'s 464 486 400 B / image"}
 
     def step(self):

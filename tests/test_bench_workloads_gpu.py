@@ -202,6 +202,7 @@ def test_gather_workloads_4k(gpu_stream, bench):
     # priced on the bytes the two kernels need (in-bounds taps, maps once per four images): below SURVEY 8(d)'s contract figure
     assert 0.75 * wl.survey_bytes_per_launch < wl.alg_bytes_per_launch < wl.survey_bytes_per_launch, (wl.alg_bytes_per_launch, wl.in_bounds)
     assert 0.9 < wl.in_bounds[0] <= 1.0 and 0.5 < wl.in_bounds[1] <= 1.0, wl.in_bounds
+    assert all(0.5 < s_ <= 1.0 for s_ in wl.src_share), wl.src_share
     mx, my = O.correction_map(wl.INTR, wl.DIST, wl.W, wl.H)
     got = _out(wl, np.float32, (wl.H, wl.W, wl.C))
     for k in range(wl.N):
