@@ -21,6 +21,11 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 W, H, Cc = 3840, 2160, 3
 n = W * H * Cc
 hip.set_device(0)
+import os
+for opt in filter(None, os.environ.get("KH_DIAG_OPTS", "").split(",")):   # e.g. KH_DIAG_OPTS=warp_f32_px=1
+    name, _, value = opt.partition("=")
+    check(lib.kh_debug_set_option(name.encode(), int(value)))
+    print("# test option", opt)
 st = hip.Stream.new(0)
 s = st.cuda_stream_ptr
 big = [DeviceBuffer(N * n * 4, st, zeroed=(k == 0)) for k in range(3)]
