@@ -756,7 +756,7 @@ class ResizeBicubic540(ResizeBilinear):
     (P/cuda/resize.rs:245) on its published 1080p -> 540p shape (benchmarks.md:374).  At exactly 2x the 4x4 windows of the
     destination pixels cover every source pixel, so the algorithmic traffic is the whole source once + the destination."""
 
-    name, kernel = "resize_bicubic_1080p_to_540p_f32_b256", "resize_kernel<3,bicubic>"
+    name, kernel = "resize_bicubic_1080p_to_540p_f32_b256", "resize_bicubic_half_kernel<3,vh>"
     DW, DH = 960, 540
 
     def __init__(self, batch):

@@ -269,6 +269,95 @@ __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, floa
     put<C>(o, x, v);
 }
 
+// ---- bicubic, horizontal step exactly 2 (round 6; the reference's published 1080p -> 540p shape, benchmarks.md:374) ------------------------
+// At sx = 2 x + 0.5 the four columns of output pixel x are source pixels 2x - 1 .. 2x + 2: a lane's window shares its outer columns
+// with its neighbours' inner ones, and resize_kernel fetches every source pixel twice — 3 KiB of 12-byte gathers per wave and row for
+// 1.5 KiB of source, with the texture addresser 100 % busy (profiles/r04zk_resize_counters.csv).  Here a lane loads ONLY its own two
+// pixels of each of the four rows (24 contiguous bytes; a wave reads 1.5 KiB contiguous per row) and takes column 2x - 1 from the lane
+// below and 2x + 2 from the lane above with wave shifts (v_mov_b32_dpp, kh_common.h::from_lane_below / above); the wave's first and
+// last lanes load their outer column themselves.  Same expression as sample_bicubic (Keys weights at frac = sx - floor(sx) = 0.5,
+// rows outer, columns inner, acc = fma(wx * wy, v, acc), taps clamped to the image), so the bits are resize_kernel's.
+// VH: the vertical step is exactly 2 as well (sh == 2 dh): a lane owns TWO vertically adjacent outputs, whose windows share two of their
+// four rows — six row loads for two outputs instead of eight (a 64 x 8 tile per block).  Each output's sixteen products are still added
+// rows outer / columns inner in ascending order.
+template <int C, bool VH, bool LIST>
+__global__ __launch_bounds__(kBx* kBy) void resize_bicubic_half_kernel(Img im, float ax, float bx, float ay, float by, typename ListArg<LIST>::type lst) {
+    constexpr int NY = VH ? 2 : 1, NR = VH ? 6 : 4;
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;
+    const int lane = threadIdx.x;                        // a wave = one row (VH: two rows) of the tile
+    const int x = bx_ * kBx + lane, ya = (by_ * kBy + threadIdx.y) * NY;
+    if (ya >= im.dh) return;                             // wave-uniform
+    const int xl = min(x, im.dw - 1);                    // lanes past the row keep computing (their neighbours read them) and store nothing
+    const float* src = image_src<LIST>(im, lst, bz_);
+    const float sx = clampf(ax * (float)xl + bx, 0.0f, (float)(im.sw - 1));   // == 2 xl + 0.5 (host-checked)
+    const float x0f = floorf(sx);
+    float wx[4], wy[NY][4];
+    keys_weights(sx - x0f, wx);
+    int y0[NY];
+#pragma unroll
+    for (int o = 0; o < NY; ++o) {
+        const float sy = clampf(ay * (float)min(ya + o, im.dh - 1) + by, 0.0f, (float)(im.sh - 1));
+        const float y0f = floorf(sy);
+        keys_weights(sy - y0f, wy[o]);
+        y0[o] = (int)y0f;                                // VH: y0[1] == y0[0] + 2 (host-checked: sy = 2 y + 0.5 unclamped)
+    }
+    const int x0 = (int)x0f;                             // == 2 xl
+    const bool first = lane == 0, last = lane == kBx - 1;
+    // the outer column this lane must fetch itself if it is an end of the wave: 2x - 1 (first lane) / 2x + 2 (last lane), clamped like a tap
+    const int xh = first ? max(x0 - 1, 0) : min(x0 + 2, im.sw - 1);
+    float acc[NY][C];
+#pragma unroll
+    for (int o = 0; o < NY; ++o)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[o][c] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int yi = min(max(y0[0] + j - 1, 0), im.sh - 1);   // (output o's tap dy sits at j = dy + 2 o; the clamp is the tap's own)
+        const float* row = src + (long long)yi * im.sw * C;
+        float own[2 * C], halo[C];
+#pragma unroll
+        for (int k = 0; k < 2 * C; ++k) own[k] = row[(long long)x0 * C + k];   // pixels x0, x0 + 1 (x0 + 1 <= sw - 1: sw == 2 dw)
+#pragma unroll
+        for (int c = 0; c < C; ++c) halo[c] = 0.0f;
+        if (first || last) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) halo[c] = row[(long long)xh * C + c];
+        }
+        float t[4][C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            // column x0 - 1 = the lane below's second pixel (clamped to 0 at the image's left edge = this lane's own first pixel)
+            const float below = __uint_as_float(from_lane_below(__float_as_uint(own[C + c]), __float_as_uint(halo[c])));
+            // column x0 + 2 = the lane above's first pixel (clamped to sw - 1 at the right edge = this lane's own second pixel)
+            const float above = __uint_as_float(from_lane_above(__float_as_uint(own[c]), __float_as_uint(halo[c])));
+            t[0][c] = x0 - 1 < 0 ? own[c] : below;
+            t[1][c] = own[c];
+            t[2][c] = own[C + c];
+            t[3][c] = x0 + 2 > im.sw - 1 ? own[C + c] : above;
+        }
+#pragma unroll
+        for (int o = 0; o < NY; ++o) {
+            const int dy = j - 2 * o;
+            if (dy < 0 || dy > 3) continue;              // compile-time after unrolling
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const float w = wx[dx] * wy[o][dy];
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[o][c] = __builtin_fmaf(w, t[dx][c], acc[o][c]);
+            }
+        }
+    }
+    if (x < im.dw) {
+#pragma unroll
+        for (int o = 0; o < NY; ++o) {
+            if (ya + o >= im.dh) break;
+            const OutRow orow = out_row<C>(image_dst<LIST>(im, lst, bz_) + (long long)(ya + o) * im.dw * C, im.dw);
+            put<C>(orow, x, acc[o]);
+        }
+    }
+}
+
 // ---- bilinear downscale, row-streamed (round 6; BASELINE configs[1]) -------------------------------------------------------------------
 // 1920 x 1080 -> 224 x 224: an output row needs exactly TWO source rows, and with a tap pair (24 bytes) every 103 bytes nearly every
 // 128-byte line of both rows holds a tap byte — the gather kernel above already moved that line-granular floor (2.8 GB per 256 images
@@ -778,6 +867,26 @@ int32_t resize_impl(const char* what, kh_stream_t stream, const BatchRef& b, int
 #undef KH_ROWS
                 return check_launch(what);
             });
+    }
+    // bicubic with a horizontal step of exactly 2 (sw == 2 dw, half-pixel grid): neighbours' columns through wave shifts
+    // (resize_bicubic_half_kernel).  Test option resize_rows = 0 keeps the gather kernel here too.
+    if (mode == KH_INTERP_BICUBIC && dev_opt(kOptResizeRows) != 0 && sw == 2 * dw && ax == 2.0f && bx == 0.5f && dw < (1 << 22)) {
+        // both steps exactly 2: two output rows per lane (test option resize_rows = 1: one)
+        const bool vh = sh == 2 * dh && ay == 2.0f && by == 0.5f && dh < (1 << 22) && dev_opt(kOptResizeRows) != 1;
+        return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+            Img im = make_img(c, sw, sh, dw, dh, c.n);
+            if (vh) im.tiles = xcd_tiles(cdiv(dw, kBx), cdiv(dh, 2 * kBy), (unsigned)c.n, cdiv(dw, kBx) * 4);
+            KH_REQUIRE_TILES(what, im);
+            const dim3 blk(kBx, kBy), grid = xcd_grid(im.tiles);
+            const NoList none{0};
+#define KH_HALF(CC, VH) do { if (c.listed()) hipLaunchKernelGGL((resize_bicubic_half_kernel<CC, VH, true>), grid, blk, 0, st, im, ax, bx, ay, by, lst); \
+                             else hipLaunchKernelGGL((resize_bicubic_half_kernel<CC, VH, false>), grid, blk, 0, st, im, ax, bx, ay, by, none); } while (0)
+#define KH_HALF_C(CC) do { if (vh) KH_HALF(CC, true); else KH_HALF(CC, false); } while (0)
+            switch (channels) { case 1: KH_HALF_C(1); break; case 3: KH_HALF_C(3); break; default: KH_HALF_C(4); break; }
+#undef KH_HALF_C
+#undef KH_HALF
+            return check_launch(what);
+        });
     }
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
         const Img im = make_img(c, sw, sh, dw, dh, c.n);

@@ -26,7 +26,7 @@ KERNELS = {
     "yuyv_1080p_to_chw_f32_letterbox640_b1024": ["preprocess_generic_quads<4, 100"],
     "resize_bilinear_1080p_to_224_f32_b256": ["resize_rows_bilinear_kernel<3, 1, 256, false"],
     "resize_bilinear_1080p_to_224_f32_api_list_b256": ["resize_rows_bilinear_kernel<3, 1, 256, true"],
-    "resize_bicubic_1080p_to_540p_f32_b256": ["resize_kernel<3, 2, false"],
+    "resize_bicubic_1080p_to_540p_f32_b256": ["resize_bicubic_half_kernel<3, true, false", "resize_kernel<3, 2, false"],
     "gaussian_blur_7x7_4k_f32_b256": ["sep_roll4_kernel<7"],
     "box_blur_5x5_4k_f32_b128": ["sep_roll4_kernel<5"],
     "sobel_3x3_4k_f32_b128": ["sep_roll_kernel<3, true"],

@@ -65,6 +65,23 @@ def test_resize_bilinear_row_streamed_kernel(gpu_stream, dev_option, shape, c):
     assert_same_bits(resize_gpu(gpu_stream, src, dw, dh, "bilinear", batch=n), got, "gather kernel vs row-streamed kernel")
 
 
+@pytest.mark.parametrize("shape", [(128, 96, 64, 48), (130, 50, 65, 25), (130, 50, 65, 31), (2, 7, 1, 3), (2, 2, 1, 1), (256, 9, 128, 20), (258, 34, 129, 17), (258, 33, 129, 11)])
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_resize_bicubic_exact_half_kernel(gpu_stream, dev_option, shape, c):
+    """Bicubic with a horizontal step of exactly 2 takes the wave-shift kernel (a lane loads its own two source pixels per row and
+    gets the outer columns from its neighbours): the oracle's bits for widths that fill whole waves, leave partial ones, are a single
+    pixel; vertical down- and up-scaling (the row taps stay general); a batch.  resize_rows = 0: the gather kernel."""
+    sw, sh, dw, dh = shape
+    n = 2
+    src = np.stack([img(sw, sh, c, seed=31 * k) for k in range(n)])
+    got = resize_gpu(gpu_stream, src, dw, dh, "bicubic", batch=n)
+    for k in range(n):
+        assert_same_bits(got[k], O.resize(src[k], dw, dh, "bicubic"), f"bicubic half {shape} c{c} image {k}")
+    for opt in (1, 0):   # 1: one output row per lane even where both steps are 2; 0: the gather kernel
+        dev_option("resize_rows", opt)
+        assert_same_bits(resize_gpu(gpu_stream, src, dw, dh, "bicubic", batch=n), got, f"resize_rows = {opt} vs the launcher's choice")
+
+
 def test_resize_smoke_known_answer(gpu_stream):  # resize/mod.rs:447-490
     src = np.arange(36, dtype=np.float32).reshape(4, 3, 3)
     got = resize_gpu(gpu_stream, src, 2, 3, "bilinear")[0].reshape(-1)
