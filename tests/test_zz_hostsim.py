@@ -44,7 +44,7 @@ def test_multi_device_host_layer_on_two_simulated_gpus(sim_env):
 
 
 def test_gpu_suite_passes_on_the_host_simulator(sim_env):
-    workers = str(max(1, min(16, (os.cpu_count() or 2) // 2)))
+    workers = str(max(1, min(16, (os.cpu_count() or 2) - 1)))   # fibers are CPU-bound and the OpenMP teams are capped (conftest.py)
     cmd = [sys.executable, str(ROOT / "scripts" / "hostsim_run.py"), "tests", "-q", "-n", workers, "-x",
            "--deselect", "tests/test_host_api_gpu.py::test_torch_rocm_zero_copy_interop",  # needs torch to see a real device
            "--deselect", "tests/test_unified_gpu.py::test_unified_torch_consumer",
@@ -52,7 +52,9 @@ def test_gpu_suite_passes_on_the_host_simulator(sim_env):
            # tests/test_bench_workloads_gpu.py -n 8) but are left to the device to keep this suite short
            "--deselect", "tests/test_bench_workloads_gpu.py::test_gather_workloads_4k",
            "--deselect", "tests/test_bench_workloads_gpu.py::test_filter_workloads_4k",
-           "--deselect", "tests/test_bench_workloads_gpu.py::test_list_workloads_4k"]
+           "--deselect", "tests/test_bench_workloads_gpu.py::test_list_workloads_4k",
+           "--deselect", "tests/test_bench_workloads_gpu.py::test_north_star_operator_workloads",
+           "--deselect", "tests/test_bench_workloads_gpu.py::test_pyramid_workloads_4k"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=sim_env)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
     assert r.returncode == 0, tail
