@@ -413,8 +413,9 @@ __global__ __launch_bounds__(BLOCK) void resize_rows_bilinear_kernel(Img im, flo
         r1v[i] = q1[j];
     }
     __syncthreads();
-    const float* r0 = lds_rows - 4 * s4;                 // indexed by the ROW's float index
+    const float* r0 = lds_rows;                          // segment-relative: float index of a row minus 4 * s4
     const float* r1 = r0 + 4 * seg4_max;
+    const int base = 4 * s4;
     const __amdgpu_buffer_rsrc_t ow = stream_window(image_dst<LIST>(im, lst, z) + (long long)y * im.dw * C, (long long)im.dw * C * 4);
     const float frac_vv = 1.0f - frac_v;
     for (int x = x_lo + t; x < x_hi; x += kRowsBlock) {
@@ -424,10 +425,10 @@ __global__ __launch_bounds__(BLOCK) void resize_rows_bilinear_kernel(Img im, flo
         const bool hx = iu + 1 < im.sw;
         const float frac_uu = 1.0f - frac_u;
         const float w00 = frac_vv * frac_uu, w10 = frac_vv * frac_u, w01 = frac_v * frac_uu, w11 = frac_v * frac_u;
-        const float* p00 = r0 + iu * C;
+        const float* p00 = r0 + (iu * C - base);
         const float* p01 = hx ? p00 + C : p00;
-        const float* p10 = hy ? r1 + iu * C : p00;
-        const float* p11 = (hx && hy) ? r1 + iu * C + C : p00;
+        const float* p10 = hy ? r1 + (iu * C - base) : p00;
+        const float* p11 = (hx && hy) ? r1 + (iu * C - base) + C : p00;
         uint32_t w[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) w[c] = __float_as_uint(w00 * p00[c] + w10 * p01[c] + w01 * p10[c] + w11 * p11[c]);
