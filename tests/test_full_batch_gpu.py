@@ -99,6 +99,45 @@ def test_north_star_full_batch(gpu_stream, bench):
         _same(_fetch(wl.dst, k, np.float32, (3, wl.H, wl.W)), want, f"nv12_chw frame {k}")
 
 
+def test_north_star_frame_list_full_batch(gpu_stream, bench):
+    """configs[2] through the reference's own batch signature: 1024 SEPARATELY ALLOCATED 1080p NV12 buffers handed to
+    `Preprocessor.run_raw_batch` as a list -> kh_preprocess_to_chw_list, four launches of 256 frame bases each.  The frames on both
+    sides of every launch slice (255 | 256, 511 | 512, 767 | 768) and of the destination's 2^31 / 2^32 offsets, bit for bit."""
+    wl = _run(bench, "nv12_chw_list", gpu_stream)
+    assert wl.N == 1024 and len(wl.frames) == 1024
+    assert len({b.ptr - a.ptr for a, b in zip(wl.frames, wl.frames[1:])}) > 1, "equally spaced frames would take the strided launch"
+    ks = sorted(set(boundary_frames(wl.N, wl.W * wl.H * 12, 4)) | {254, 255, 256, 257, 511, 512, 767, 768})
+    for k in ks:
+        raw = wl.base[31 * k: 31 * k + wl.frame_bytes]
+        want = O.preprocess(raw, wl.W, wl.H, wl.W, wl.H, fmt="nv12", mode="stretch", mean=MEAN, std=STD)[0]
+        _same(_fetch(wl.dst, k, np.float32, (3, wl.H, wl.W)), want, f"nv12_chw_list frame {k}")
+
+
+def test_api_list_rows_full_batch(gpu_stream, bench):
+    """configs[1] / [3] / [4] through imgproc.*_batch on 256 separately allocated Images each side (two launches of 128 (src, dst)
+    pairs per operator): the images at the launch seam (127 | 128), the group-of-four seams of remap, the first and the last."""
+    ks = (0, 1, 3, 4, 126, 127, 128, 129, 255)
+    wl = _run(bench, "resize_224_api_list", gpu_stream)
+    assert wl.N == 256
+    n = wl.SW * wl.SH * wl.C
+    for k in ks:
+        want = O.resize(wl.base[31 * k: 31 * k + n].reshape(wl.SH, wl.SW, wl.C), wl.DW, wl.DH)
+        _same(wl.dst[k].numpy(), want, f"resize_224_api_list image {k}")
+    del wl
+    wl = _run(bench, "gaussian_4k_api_list", gpu_stream)
+    n = wl.W * wl.H * wl.C
+    for k in (0, 127, 128, 255):
+        want = O.gaussian_blur(wl.base[31 * k: 31 * k + n].reshape(wl.H, wl.W, wl.C), (7, 7), (1.5, 1.5))
+        _same(wl.dst[k].numpy(), want, f"gaussian_4k_api_list image {k}")
+    del wl
+    wl = _run(bench, "undistort_warp_4k_api_list", gpu_stream)
+    mx, my = O.correction_map(wl.INTR, wl.DIST, wl.W, wl.H)
+    for k in (0, 3, 4, 127, 128, 255):
+        mid = O.remap(wl.base[31 * k: 31 * k + n].reshape(wl.H, wl.W, wl.C), mx, my)
+        _same(wl.tmp[k].numpy(), mid, f"undistort (list) remap image {k}")
+        _same(wl.dst[k].numpy(), O.warp_perspective(mid, wl.hm, wl.W, wl.H), f"undistort (list) warp image {k}")
+
+
 def test_north_star_letterbox_full_batch(gpu_stream, bench):
     """The 640x640 letterbox secondary at N = 1024 (4 915 200-B outputs: the wrap points sit at frames 436, 873)."""
     wl = _run(bench, "nv12_chw_640", gpu_stream)
