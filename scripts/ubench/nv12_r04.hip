@@ -102,7 +102,8 @@ __global__ __launch_bounds__(3 * Q) void k_split(const uint8_t* __restrict__ sb,
         const uint32_t y4 = __builtin_amdgcn_raw_buffer_load_b32(rl, r * a.w + 4 * xq, 0, 0);
         const uint32_t uv4 = __builtin_amdgcn_raw_buffer_load_b32(rl, plane + (r >> 1) * a.w + 4 * xq, 0, 0);
         f32x4 o[3];
-        decode4(y4, uv4, a, o);   // the compiler keeps only channel c's arithmetic live per branch
+        decode4(y4, uv4, a, o);   // WRONG as measured in round 4: `c` is not known wave-uniform, so all three channels are decoded and then selected (159 VALU per
+                                  // thread); redone with readfirstlane + a scalar branch in nv12_r06.hip (profiles/r06a_ubench_nv12_one_store.txt)
         v = c == 0 ? o[0] : (c == 1 ? o[1] : o[2]);
     }
     const int g0 = gbase + i;

@@ -65,6 +65,24 @@ def test_resize_bilinear_row_streamed_kernel(gpu_stream, dev_option, shape, c):
     assert_same_bits(resize_gpu(gpu_stream, src, dw, dh, "bilinear", batch=n), got, "gather kernel vs row-streamed kernel")
 
 
+@pytest.mark.parametrize("shape", [(128, 96, 30, 22), (1920, 40, 224, 8), (64, 300, 20, 7), (128, 96, 64, 48)])
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+def test_resize_mapped_align_corners_through_the_new_kernels(gpu_stream, dev_option, shape, mode):
+    """PixelMapping::AlignCorners (src = dst * (src_len - 1) / (dst_len - 1)) through the launcher's shape-specialised paths: the
+    row-streamed bilinear kernel takes any (a, b) grid; the exact-2x bicubic kernel must NOT be taken (its grid is half-pixel only)."""
+    from kornia_rs import _ffi
+    sw, sh, dw, dh = shape
+    n, c = 2, 3
+    src = np.stack([img(sw, sh, c, seed=31 * k) for k in range(n)])
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * dh * dw * c * 4)
+    for opt in (-1, 0):
+        dev_option("resize_rows", opt)
+        _ffi.check(_ffi.lib.kh_resize_mapped_f32(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, sw, sh, dw, dh, c, O.MODE[mode], 1, n, sh * sw * c, dh * dw * c))
+        got = d_dst.to_numpy(np.float32, (n, dh, dw, c))
+        for k in range(n):
+            assert_same_bits(got[k], O.resize_mapped(src[k], dw, dh, mode, "align_corners"), f"align_corners {mode} {shape} option {opt} image {k}")
+
+
 @pytest.mark.parametrize("shape", [(128, 96, 64, 48), (130, 50, 65, 25), (130, 50, 65, 31), (2, 7, 1, 3), (2, 2, 1, 1), (256, 9, 128, 20), (258, 34, 129, 17), (258, 33, 129, 11)])
 @pytest.mark.parametrize("c", [1, 3, 4])
 def test_resize_bicubic_exact_half_kernel(gpu_stream, dev_option, shape, c):
