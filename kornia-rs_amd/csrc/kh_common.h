@@ -86,12 +86,14 @@ __host__ __device__ __forceinline__ uint32_t fast_quot(uint32_t n, const FastDiv
 // images: the (source, destination) bases of a launch travel BY VALUE in the kernel arguments (2 KiB), where a block picks its image's
 // pair with one scalar load — no device-side table to allocate, upload or keep alive, nothing a stream capture cannot record.
 // Measured on the north star (profiles/r06a_ubench_nv12_one_store.txt): 1024 frame bases through such a table, 448 or 128 per launch,
-// 4.374 / 4.373 ms against 4.373 ms for base + k * stride.  Kernels take the list as their LAST argument and select at run time
-// (`listed` is launch-uniform: a scalar branch); contiguous launches pass a zeroed list.
+// 4.374 / 4.373 ms against 4.373 ms for base + k * stride.  The short-lived gather / preprocess kernels have a separate LIST
+// instantiation (selecting at run time inside one kernel cost their equally spaced launches up to 8 %, kh_geom.hip); the strip-walking
+// filters, whose waves live for hundreds of rows, take the list as their last argument and select at run time (`listed` is
+// launch-uniform: a scalar branch; equally spaced launches pass a zeroed list) — same-box A/B within noise (profiles/r06d, r06i).
 constexpr int kListMax = 128;
 struct PtrList { const void* src[kListMax]; void* dst[kListMax]; };
 // What a batched launcher is handed: `n` images at src + k * ss / dst + k * ds (ELEMENTS of the operator's type, or bytes where the
-// entry says so), or — srcs != nullptr — at srcs[k] / dsts[k].
+// entry says so), or — `list` — at srcs[k] / dsts[k].
 struct BatchRef {
     const void* src; void* dst; int64_t ss, ds; int n;
     const void* const* srcs; void* const* dsts;
