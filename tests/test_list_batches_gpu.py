@@ -203,6 +203,31 @@ def test_image_batch_is_validated_once_and_reusable(gpu_stream):
             hip.h2d(im.data_ptr, a.reshape(-1), gpu_stream)
 
 
+def test_image_batch_calls_are_capturable(gpu_stream):
+    """The *_batch forms allocate nothing when the destinations are given (pointer arrays in the kernel arguments): a chain of them
+    records into one graph; the replay reads the sources' current contents."""
+    from kornia_rs import Image, hip, imgproc
+    n, (sw, sh, dw, dh) = 5, (64, 40, 24, 16)
+    arrs = [_img(sw, sh, 3, 31 * k) for k in range(n)]
+    imgs, arenas = _images(gpu_stream, arrs)
+    sb = imgproc.ImageBatch(imgs)
+    mid = imgproc.ImageBatch([Image.uninit(dw, dh, 3, "float32", gpu_stream) for _ in range(n)])
+    out = imgproc.ImageBatch([Image.uninit(dw, dh, 3, "float32", gpu_stream) for _ in range(n)])
+
+    def chain():
+        imgproc.resize_batch(sb, None, "bilinear", outs=mid)
+        imgproc.gaussian_blur_batch(mid, (3, 3), (0.8, 0.8), outs=out)
+
+    g = hip.Graph.capture(chain, retain=[sb, mid, out, arenas], stream=gpu_stream)
+    arrs = [_img(sw, sh, 3, 31 * k + 5) for k in range(n)]
+    for im, a in zip(imgs, arrs):
+        hip.h2d(im.data_ptr, a.reshape(-1), gpu_stream)
+    g.replay()
+    for k in range(n):
+        want = O.gaussian_blur(O.resize(arrs[k], dw, dh, "bilinear"), (3, 3), (0.8, 0.8))
+        assert_same_bits(out[k].numpy(), want, f"replayed image {k}")
+
+
 def test_warp_and_remap_batches_match_oracle(gpu_stream):
     from kornia_rs import Image, imgproc
     n, (w, h) = 6, (96, 64)   # remap: 6 = one full group of four images + a partial one
