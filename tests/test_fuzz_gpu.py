@@ -53,6 +53,59 @@ def test_fuzz_f32_resize_and_warps(gpu_stream, seed):
 
 
 @pytest.mark.parametrize("seed", range(6 + EXTRA))
+def test_fuzz_round6_resize_shapes_and_list_batches(gpu_stream, seed):
+    """Shapes drawn INTO the gates of the round-6 kernels: bilinear downscales with whole-float4 rows and a vertical step >= 1.5
+    (row-streamed kernel, random part splits), bicubic at a horizontal step of exactly 2 (wave-shift kernel; vertical step 2 or not),
+    near-horizontal and tilted bilinear warps (two / one pixel per lane) — each also through the pointer-list batch form with a
+    random number of separately placed images."""
+    from kornia_rs import Image, Tensor, imgproc
+    from kornia_rs.hip import DeviceBuffer
+    rng = np.random.default_rng(7000 + seed)
+
+    def batch(arrs):   # images at unequally spaced offsets of one arena
+        nb = arrs[0].nbytes
+        arena = DeviceBuffer((nb + 256 * 9) * len(arrs) + 256, gpu_stream, zeroed=False)
+        imgs, off = [], 0
+        for k, a in enumerate(arrs):
+            off += 256 * int(rng.integers(0, 8))
+            arena.copy_from_host(a.reshape(-1), offset=off)
+            imgs.append(Image(Tensor(a.shape, "float32", device_ptr=arena.ptr + off, device=gpu_stream.device, stream=gpu_stream, keepalive=arena)))
+            off = (off + nb + 255) // 256 * 256
+        return imgs
+
+    for _ in range(4):
+        c = int(rng.choice([1, 3, 4]))
+        n = int(rng.integers(1, 6))
+        # (a) bilinear downscale into the row-streamed kernel's gate
+        dw, dh = int(rng.integers(1, 40)), int(rng.integers(1, 20))
+        sw = int(rng.integers(max(4, dw), max(5, min(8 * dw, 32 * dw // c + 4)))) // 4 * 4 + (0 if c != 3 else 0)
+        sw = max(4, sw)
+        sh = int(rng.integers(int(1.5 * dh) + 1, 6 * dh + 3))
+        arrs = [_f32(rng, sh, sw, c) for _ in range(n)]
+        outs = imgproc.resize_batch(batch(arrs), (dh, dw), "bilinear")
+        for k in range(n):
+            assert np.array_equal(outs[k].numpy(), O.resize(arrs[k], dw, dh, "bilinear")), ("rows", sw, sh, dw, dh, c, k)
+        # (b) bicubic, horizontal step exactly 2
+        dw2, dh2 = int(rng.integers(1, 90)), int(rng.integers(1, 24))
+        sh2 = 2 * dh2 if rng.integers(0, 2) else int(rng.integers(1, 60))
+        arrs = [_f32(rng, sh2, 2 * dw2, c) for _ in range(n)]
+        outs = imgproc.resize_batch(batch(arrs), (dh2, dw2), "bicubic")
+        for k in range(n):
+            assert np.array_equal(outs[k].numpy(), O.resize(arrs[k], dw2, dh2, "bicubic")), ("bicubic half", 2 * dw2, sh2, dw2, dh2, c, k)
+        # (c) bilinear warps, nearly horizontal source runs or tilted ones
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 24))
+        tilt = float(rng.choice([0.0, 0.01, 0.3]))
+        m = [float(rng.uniform(0.8, 1.2)), float(rng.uniform(-0.1, 0.1)), float(rng.uniform(-5, 5)), tilt, float(rng.uniform(0.8, 1.2)), float(rng.uniform(-3, 3))]
+        arrs = [_f32(rng, int(rng.integers(1, 40)) if False else h + 3, w + 2, c) for _ in range(n)]
+        outs = imgproc.warp_affine_batch(batch(arrs), m, (h, w), "bilinear")
+        hm = m + [float(rng.uniform(-1e-4, 1e-4)), float(rng.uniform(-1e-4, 1e-4)), 1.0]
+        outs_p = imgproc.warp_perspective_batch(batch(arrs), hm, (h, w), "bilinear")
+        for k in range(n):
+            assert np.array_equal(outs[k].numpy(), O.warp_affine(arrs[k], m, w, h, "bilinear")), ("affine px", w, h, c, m, k)
+            assert np.array_equal(outs_p[k].numpy(), O.warp_perspective(arrs[k], hm, w, h, "bilinear")), ("perspective px", w, h, c, hm, k)
+
+
+@pytest.mark.parametrize("seed", range(6 + EXTRA))
 def test_fuzz_filters(gpu_stream, seed):
     from kornia_rs import imgproc
     rng = np.random.default_rng(2000 + seed)
