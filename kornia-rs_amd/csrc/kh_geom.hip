@@ -654,6 +654,12 @@ __global__ __launch_bounds__(kBx* kBy) void remap_kernel(Img im, const float* __
         }
     }
 }
+// Measured against this kernel and warp_perspective_px_kernel in round 6 and not kept (scripts/ubench/bilinear3_wave_staged_r06.hip.txt,
+// profiles/r06y_*): each WAVE staging the source box of its 64 x 4 / 64 x 8 tile of four images in its own LDS rows (no block barrier,
+// geometry once per four images): remap 5.26 / 5.88 ms against 4.76, warp_perspective 4.62 / 4.58 against 4.63 per 128 4K images — 0.75x
+// the vector-memory reads, but every wave re-reads the box rows its neighbours stage too (1.2x the L1 -> L2 requests); this kernel in
+// 64 x 8 / 64 x 16 blocks: -1.6 %; neighbour-shared right-hand taps decided from the coordinates (wave shifts): -1.9 % with two pixels
+// per lane, +3 % with one (scripts/ubench/warp_perspective_share2_r06.patch.txt, profiles/r06x_warp_share2.txt).
 
 // generate_correction_map_polynomial (P/calibration/distortion.rs:68-152): all-f64 Brown-Conrady
 struct Camera { double fx, fy, cx, cy, k1, k2, k3, k4, k5, k6, p1, p2; };
