@@ -1633,12 +1633,15 @@ def store_ceilings(hip, stream, dst_ptr: int, w: int, h: int, nframes: int, reps
         d.khd_flat_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
         d.khd_three_plane_store.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong]
         d.khd_read_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+        d.khd_stream_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
         from kornia_rs.hip import DeviceBuffer
         nbytes = 12 * w * h * nframes
         sink = DeviceBuffer(16, stream)
         # read_stream LAST: it reads what the two fills wrote (never the kernel's output pattern the compare could match)
         runs = {"flat_fill_ms": lambda: d.khd_flat_fill(stream.cuda_stream_ptr, dst_ptr, nbytes),
                 "three_plane_store_only_ms": lambda: d.khd_three_plane_store(stream.cuda_stream_ptr, dst_ptr, w, h, nframes, 3 * w * h),
+                # the first half of the buffer copied onto the second: R + W = the same bytes (the stream-copy ceiling)
+                "stream_copy_ms": lambda: d.khd_stream_copy(stream.cuda_stream_ptr, dst_ptr, dst_ptr + (nbytes // 32) * 16, (nbytes // 32) * 16),
                 "read_stream_ms": lambda: d.khd_read_stream(stream.cuda_stream_ptr, dst_ptr, nbytes, sink.ptr)}
         out = {}
         for key, fn in runs.items():
@@ -2015,6 +2018,10 @@ def main():
                 dev["frac_of_three_plane_store"] = round(ceilings["three_plane_store_only_ms"] / ms, 4)
                 dev["note"] = ("flat_fill / three_plane_store_only: the output bytes written with the production store policy and no loads or "
                                "decode, same process, same buffer, same events (kornia-rs_amd/diag/kh_diag.hip)")
+            if ceilings.get("stream_copy_ms"):
+                # a flat 1R + 1W copy moving the same number of bytes (half read, half written): the measured ceiling of the same-size maps,
+                # filters and warps of the summary, next to the datasheet peak
+                dev["stream_copy_GBps"] = round(2 * ((ceilings["store_bytes"] // 32) * 16) / ceilings["stream_copy_ms"] / 1e6, 1)
             if ceilings.get("read_stream_ms") and ms:
                 # the measured pure-read rate of this part (16 B / lane over the same 25.5 GB) and the kernel's total R + W rate against it:
                 # north_star's "HBM-read roofline" taken as what a read stream actually reaches, beside roofline.frac (datasheet 8 TB/s)

@@ -9,7 +9,9 @@
 //   khd_read_stream        (round 5) a pure READ of the same bytes, 16 B / lane buffer loads, nothing written: the rate this part
 //                          streams reads at.  north_star words its target as a fraction of the "HBM-read roofline"; the kernel's
 //                          total R + W rate is reported next to this measured read rate as well as against the 8 TB/s datasheet peak.
-// bench.py times all three in the same process, on the same buffers, with the same HIP events, so "fraction of the achievable" is
+//   khd_stream_copy        (round 6) a flat 1R + 1W copy, 16 B / lane buffer loads and the production stores: the stream-copy ceiling SURVEY.md
+//                          8(d) asks to have recorded next to the datasheet peak — what bounds the same-size maps, filters and warps.
+// bench.py times all of them in the same process, on the same buffers, with the same HIP events, so "fraction of the achievable" is
 // driver-timed instead of quoted from an earlier box.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,9 +48,27 @@ __global__ __launch_bounds__(256) void read_stream_kernel(const float* __restric
     if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9e3779b9u && v.x == 0x00012345u) atomicAdd(sink, 1u);
 }
 
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float* __restrict__ sb, float* __restrict__ db, long long n4) {
+    const long long i = (long long)blockIdx.y * gridDim.x * 256 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const long long base = i & ~((1ll << 26) - 1);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sb) + 4 * base, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(db + 4 * base, 0, 0x7fffffff, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(16 * (i - base)), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(16 * (i - base)), 0, kAux);
+}
+
 }  // namespace
 
 extern "C" {
+
+__attribute__((visibility("default"))) int khd_stream_copy(void* stream, const float* src, float* dst, long long nbytes) {
+    const long long n4 = nbytes / 16;
+    if (n4 <= 0) return 0;
+    const unsigned gy = (unsigned)((n4 + 65536LL * 256 - 1) / (65536LL * 256));
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(65536, gy), dim3(256), 0, (hipStream_t)stream, src, dst, n4);
+    return (int)hipGetLastError();
+}
 
 __attribute__((visibility("default"))) int khd_read_stream(void* stream, const float* src, long long nbytes, unsigned* sink) {
     const long long n4 = nbytes / 16;
