@@ -257,7 +257,9 @@ constexpr bool kFourColumnsDefault = true;   // sep_roll4_kernel where it applie
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kTF4 = 4 * kTF;  // flat columns per 256-thread block
 
-template <int K, int C>
+// GRAD (round 6): the gradient magnitude of sep_roll_kernel<K, true> — gx = V_ky(H_kx), gy = V_kx(H_ky), sqrt(gx^2 + gy^2) — on the same
+// four-column walk: a second register ring, the same products in the same order per element.
+template <int K, int C, bool GRAD = false>
 __global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK kx, TapsK ky, PtrList lst) {
     constexpr int H = K / 2, HALO = H * C;       // <= 32 (checked on the host)
     constexpr int HQ = (HALO + 3) / 4;           // halo in float4 chunks
@@ -294,9 +296,12 @@ __global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK k
 #pragma unroll
     for (int p = 0; p < K; ++p) prefetch(qm[p], qh[p]);
 
-    f32x2_t ring[K][2];
+    f32x2_t ring[K][2], ring2[GRAD ? K : 1][2];
 #pragma unroll
-    for (int i = 0; i < K; ++i) { ring[i][0] = f32x2_t{0.0f, 0.0f}; ring[i][1] = f32x2_t{0.0f, 0.0f}; }
+    for (int i = 0; i < K; ++i) {
+        ring[i][0] = f32x2_t{0.0f, 0.0f}; ring[i][1] = f32x2_t{0.0f, 0.0f};
+        if constexpr (GRAD) { ring2[i][0] = f32x2_t{0.0f, 0.0f}; ring2[i][1] = f32x2_t{0.0f, 0.0f}; }
+    }
 
     const int hs = is_halo ? hslot : 320;  // non-halo lanes park their duplicate in a slot nobody reads
     const __amdgpu_buffer_rsrc_t ow = stream_window(dst + (long long)y0 * a.rowlen, (long long)(a.rows - y0) * a.rowlen * 4);
@@ -322,19 +327,32 @@ __global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK k
                 span[4 * c] = v.x; span[4 * c + 1] = v.y; span[4 * c + 2] = v.z; span[4 * c + 3] = v.w;
             }
             __builtin_amdgcn_wave_barrier();  // every lane has read the row before it is overwritten
-            f32x2_t h01 = {0.0f, 0.0f}, h23 = {0.0f, 0.0f};
+            f32x2_t h01 = {0.0f, 0.0f}, h23 = {0.0f, 0.0f}, g01 = {0.0f, 0.0f}, g23 = {0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const f32x2_t v01 = {span[kOff + i * C], span[kOff + i * C + 1]}, v23 = {span[kOff + i * C + 2], span[kOff + i * C + 3]};
                 h01 += v01 * kx.k[i];   // v_pk_mul_f32 then v_pk_add_f32: two roundings per element, as the reference
                 h23 += v23 * kx.k[i];
+                if constexpr (GRAD) { g01 += v01 * ky.k[i]; g23 += v23 * ky.k[i]; }
             }
             ring[p][0] = h01; ring[p][1] = h23;
+            if constexpr (GRAD) { ring2[p][0] = g01; ring2[p][1] = g23; }
             f32x2_t o01 = {0.0f, 0.0f}, o23 = {0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < K; ++i) {  // oldest row first: ascending vertical taps
                 o01 += ring[(p + 1 + i) % K][0] * ky.k[i];
                 o23 += ring[(p + 1 + i) % K][1] * ky.k[i];
+            }
+            if constexpr (GRAD) {
+                f32x2_t p01 = {0.0f, 0.0f}, p23 = {0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    p01 += ring2[(p + 1 + i) % K][0] * kx.k[i];
+                    p23 += ring2[(p + 1 + i) % K][1] * kx.k[i];
+                }
+                const f32x2_t s01 = o01 * o01 + p01 * p01, s23 = o23 * o23 + p23 * p23;   // sqrt(gx^2 + gy^2), P/filter/ops.rs:174-247
+                o01 = f32x2_t{sqrtf(s01.x), sqrtf(s01.y)};
+                o23 = f32x2_t{sqrtf(s23.x), sqrtf(s23.y)};
             }
             if (gx_ok && r >= 2 * H && r < nrows) {
                 const uint32_t bits[4] = {__float_as_uint(o01.x), __float_as_uint(o01.y), __float_as_uint(o23.x), __float_as_uint(o23.y)};
@@ -345,6 +363,15 @@ __global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK k
     }
 }
 
+template <int K>
+bool launch_roll4_grad(hipStream_t st, dim3 grid, const FilterArgs& a, const TapsK& kx, const TapsK& ky, const PtrList& lst) {
+    switch (a.C) {
+        case 1: hipLaunchKernelGGL((sep_roll4_kernel<K, 1, true>), grid, dim3(kBlock), 0, st, a, kx, ky, lst); return true;
+        case 3: hipLaunchKernelGGL((sep_roll4_kernel<K, 3, true>), grid, dim3(kBlock), 0, st, a, kx, ky, lst); return true;
+        case 4: hipLaunchKernelGGL((sep_roll4_kernel<K, 4, true>), grid, dim3(kBlock), 0, st, a, kx, ky, lst); return true;
+        default: return false;
+    }
+}
 template <int K>
 bool launch_roll4(hipStream_t st, dim3 grid, const FilterArgs& a, const TapsK& kx, const TapsK& ky, const PtrList& lst) {
     switch (a.C) {
@@ -420,7 +447,8 @@ int32_t launch(kh_stream_t stream, const BatchRef& whole, int cols, int rows, in
         // (A two-column packed-f32 kernel was measured in round 2 and is not in the library.)
         const int four_opt = dev_opt(kOptFilterFourColumns);
         const bool four_cols = four_opt < 0 ? kFourColumnsDefault : four_opt == 1;
-        const bool four = !grad && four_cols && K <= 9 && (C == 1 || C == 3 || C == 4) && (a.rowlen % 4 == 0) && a.rowlen >= kTF4 && all_16B;
+        // (gradients: K = 3 and 5 only — sobel / scharr — since round 6)
+        const bool four = (!grad || K <= 5) && four_cols && K <= 9 && (C == 1 || C == 3 || C == 4) && (a.rowlen % 4 == 0) && a.rowlen >= kTF4 && all_16B;
         const unsigned tiles_x = cdiv(a.rowlen, four ? kTF4 : kTF);  // 256-thread blocks: 512 measured +1 %, 1024 +9 % (r01q)
         // Strip height: tall strips amortise the ky-1 warm-up rows (4K x 256 images: 360 rows is
         // 5 % faster than 90), short strips keep a small launch wide enough to fill 256 CUs.
@@ -435,6 +463,11 @@ int32_t launch(kh_stream_t stream, const BatchRef& whole, int cols, int rows, in
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const dim3 grid = xcd_grid(a.tiles);
         hipStream_t st = as_hip(stream);
+        if (four && grad) {
+            if (K == 3) launch_roll4_grad<3>(st, grid, a, px, py, lst);
+            else launch_roll4_grad<5>(st, grid, a, px, py, lst);
+            return check_launch(what);
+        }
         if (four) {
             switch (K) {
                 case 3: launch_roll4<3>(st, grid, a, px, py, lst); break;

@@ -29,7 +29,7 @@ KERNELS = {
     "resize_bicubic_1080p_to_540p_f32_b256": ["resize_bicubic_half_kernel<3, true, false", "resize_kernel<3, 2, false"],
     "gaussian_blur_7x7_4k_f32_b256": ["sep_roll4_kernel<7"],
     "box_blur_5x5_4k_f32_b128": ["sep_roll4_kernel<5"],
-    "sobel_3x3_4k_f32_b128": ["sep_roll_kernel<3, true"],
+    "sobel_3x3_4k_f32_b128": ["sep_roll4_kernel<3, 3, true", "sep_roll_kernel<3, true"],
     "undistort_remap_then_warp_perspective_4k_f32_b256": ["remap_kernel<3, 1, false", "warp_perspective_px_kernel<3, 1, 2, false"],
     "undistort_remap_then_warp_perspective_4k_f32_api_list_b256": ["remap_kernel<3, 1, true", "warp_perspective_px_kernel<3, 1, 2, true"],
     "warp_affine_f32_1080p_b256": ["warp_affine_kernel<3, 1, false", "warp_affine_px_kernel<3, 1, 2, false"],

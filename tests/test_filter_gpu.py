@@ -140,6 +140,22 @@ def test_sobel_scharr(gpu_stream, kind, n, c):
         assert_same_bits(got, O.gradient_magnitude(src, kind, n), f"grad kind{kind} k{n} {w}x{h} c{c}")
 
 
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("kind,n", [(0, 3), (0, 5), (1, 3)])
+def test_gradient_magnitude_wide_rows(gpu_stream, kernel_path, c, kind, n):
+    """sobel / scharr on rows of >= 1024 floats: the four-columns-per-lane rolling kernel carries the gradient pair since round 6 (a
+    second register ring; 16-byte loads and stores) where the rows are whole float4s on aligned images; the one-column kernel and the
+    LDS-tile kernel (forced) and rows that are not whole float4s give the same bits; a batch."""
+    for (w, h) in [(1028, 37), (1030, 21), (344, 50), (2052, 9), (3840, 12)]:
+        src = img(w, h, c, seed=5)
+        got = run(gpu_stream, "kh_gradient_magnitude_f32", src, kind, n)
+        assert_same_bits(got, O.gradient_magnitude(src, kind, n), f"{kernel_path} grad kind{kind} k{n} {w}x{h} c{c}")
+    both = np.stack([img(1028, 23, c, seed=k) for k in range(2)])
+    got = run(gpu_stream, "kh_gradient_magnitude_f32", both, kind, n, batch=2)
+    for k in range(2):
+        assert_same_bits(got[k], O.gradient_magnitude(both[k], kind, n), f"{kernel_path} batch image {k}")
+
+
 def test_filter_validation(gpu_stream):
     from kornia_rs import _ffi
     lib, s = _ffi.lib, gpu_stream.cuda_stream_ptr
