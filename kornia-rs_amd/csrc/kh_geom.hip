@@ -375,9 +375,11 @@ extern __shared__ __attribute__((aligned(16))) float lds_rows[];
 __host__ __device__ __forceinline__ int rows_src_px(float ax, float bx, int x, int sw) {   // first tap column of output column x
     return (int)fminf(fmaxf(ax * (float)x + bx, 0.0f), (float)(sw - 1));
 }
-template <int C, int ITER, int BLOCK, bool LIST>
-__global__ __launch_bounds__(BLOCK) void resize_rows_bilinear_kernel(Img im, float ax, float bx, float ay, float by, FastDiv by_rows, FastDiv by_parts,
-                                                                     int parts, int part_cols, int seg4_max, typename ListArg<LIST>::type lst) {
+struct Norm3f { float mean[3], inv_std[3]; };
+// NORM: the epilogue of resize_bilinear_normalize_3c (P/cuda/resize.rs:184-236), `(px - mean) * inv_std` per channel, on the blended value
+template <int C, int ITER, int BLOCK, bool LIST, bool NORM>
+__device__ __forceinline__ void resize_rows_body(const Img& im, float ax, float bx, float ay, float by, const FastDiv& by_rows, const FastDiv& by_parts,
+                                                 int parts, int part_cols, int seg4_max, const typename ListArg<LIST>::type& lst, const Norm3f& nrm) {
     constexpr int kRowsBlock = BLOCK;
     const int t = threadIdx.x;
     // block -> (image z, output row y, column part): parts of `part_cols` output columns
@@ -431,14 +433,28 @@ __global__ __launch_bounds__(BLOCK) void resize_rows_bilinear_kernel(Img im, flo
         const float* p11 = (hx && hy) ? r1 + (iu * C - base) + C : p00;
         uint32_t w[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) w[c] = __float_as_uint(w00 * p00[c] + w10 * p01[c] + w01 * p10[c] + w11 * p11[c]);
+        for (int c = 0; c < C; ++c) {
+            float val = w00 * p00[c] + w10 * p01[c] + w01 * p10[c] + w11 * p11[c];
+            if constexpr (NORM) val = (val - nrm.mean[c]) * nrm.inv_std[c];
+            w[c] = __float_as_uint(val);
+        }
         stream_store<C>(ow, x * C * 4, w);
     }
+}
+template <int C, int ITER, int BLOCK, bool LIST>
+__global__ __launch_bounds__(BLOCK) void resize_rows_bilinear_kernel(Img im, float ax, float bx, float ay, float by, FastDiv by_rows, FastDiv by_parts,
+                                                                     int parts, int part_cols, int seg4_max, typename ListArg<LIST>::type lst) {
+    resize_rows_body<C, ITER, BLOCK, LIST, false>(im, ax, bx, ay, by, by_rows, by_parts, parts, part_cols, seg4_max, lst, Norm3f{});
+}
+// the same walk with the normalisation epilogue (three channels, 256-thread blocks)
+template <int ITER, bool LIST>
+__global__ __launch_bounds__(kRowsBlockDefault) void resize_rows_bilinear_normalize_kernel(Img im, float ax, float bx, float ay, float by, FastDiv by_rows, FastDiv by_parts,
+                                                                                          int parts, int part_cols, int seg4_max, Norm3f nrm, typename ListArg<LIST>::type lst) {
+    resize_rows_body<3, ITER, kRowsBlockDefault, LIST, true>(im, ax, bx, ay, by, by_rows, by_parts, parts, part_cols, seg4_max, lst, nrm);
 }
 
 // resize_bilinear_normalize_3c (P/cuda/resize.rs:184-236): bilinear resize fused with `(px - mean) * inv_std`, HWC in,
 // HWC out — the sample is the same bilinear sampler as `resize`, the epilogue the reference kernel's expression.
-struct Norm3f { float mean[3], inv_std[3]; };
 template <bool LIST>
 __global__ __launch_bounds__(kBx* kBy) void resize_normalize_kernel(Img im, float ax, float bx, float ay, float by, Norm3f n, typename ListArg<LIST>::type lst) {
     constexpr int C = 3;
@@ -791,6 +807,37 @@ int32_t kh_pixel_mapping_coeffs(int32_t mapping, int32_t src_len, int32_t dst_le
 
 namespace {
 
+// The row-streamed bilinear downscale (resize_rows_bilinear_kernel): does this launch qualify, and how is an output row cut?
+// Rows of whole float4s on 16-byte-aligned images, a vertical step >= 1.5 (no source row shared by two output rows), a tap stride of at
+// most one 128-byte line (every line of the two rows is needed anyway); test option resize_rows = 0 keeps the gather kernel.
+// An output row is cut into parts of `part_cols` columns, one block each (a block stages only the source-row segments under its
+// columns).  Two things decide the width (profiles/r06k_resize_rows_split.txt, C2: 7 parts of 32 columns 0.450 ms; 1 / 2 / 4 / 8
+// parts 0.484-0.492; 16 parts 0.90): a part's output bytes should be WHOLE 128-byte lines — two blocks writing halves of one line
+// cost more than anything else here — and its segment pair small enough that eight blocks share a CU's LDS.  So: a multiple of
+// the columns that make a whole line (32 for C = 1 / 3, 8 for C = 4) whose source segment is about 4 KB.
+// Test option resize_rows = N > 0: N columns per part; + 1000: 64-thread blocks, + 2000: 128-thread blocks (plain resize only).
+struct RowsPlan { int block, parts, part_cols, seg4_max, it; };
+bool plan_rows(const BatchRef& b, int sw, int dw, int dh, int channels, float ax, float bx, float ay, RowsPlan& rp) {
+    const int opt = dev_opt(kOptResizeRows);
+    if (opt == 0 || (sw * channels) % 4 != 0 || !(ay >= 1.5f) || !(ax * (float)(channels * 4) <= 128.0f) || !batch_aligned(b, 16, sizeof(float))) return false;
+    rp.block = opt >= 2000 ? 128 : (opt >= 1000 ? 64 : kRowsBlockDefault);
+    const int unit = channels == 4 ? 8 : 32;
+    rp.part_cols = opt > 0 && opt % 1000 ? opt % 1000 : std::max(1, (int)(4096.0f / (ax * (float)(channels * 4))) / unit) * unit;
+    if (rp.part_cols > dw) rp.part_cols = dw;
+    rp.parts = (dw + rp.part_cols - 1) / rp.part_cols;
+    // the longest source segment any part needs (host evaluation of the kernel's own expressions)
+    rp.seg4_max = 1;
+    for (int part = 0; part < rp.parts; ++part) {
+        const int x_lo = part * rp.part_cols, x_hi = std::min(x_lo + rp.part_cols, dw);
+        const int s4 = (rows_src_px(ax, bx, x_lo, sw) * channels) >> 2;
+        const int e4 = std::min(((std::min(rows_src_px(ax, bx, x_hi - 1, sw) + 1, sw - 1) + 1) * channels + 3) >> 2, (sw * channels) >> 2);
+        rp.seg4_max = std::max(rp.seg4_max, e4 - s4);
+    }
+    const int iters = (rp.seg4_max + rp.block - 1) / rp.block;
+    rp.it = iters <= 1 ? 1 : (iters <= 2 ? 2 : (iters <= 4 ? 4 : 8));
+    return iters <= 8 && (int64_t)dh * rp.parts * b.n <= kI32Max && (size_t)rp.seg4_max * 32 <= 64 * 1024;
+}
+
 int32_t resize_impl(const char* what, kh_stream_t stream, const BatchRef& b, int sw, int sh, int dw, int dh, int channels, int mode,
                     int mapping) {
     if (int32_t rc = check_img(what, b, sw, sh, dw, dh, channels, mode)) return rc;
@@ -829,52 +876,28 @@ int32_t resize_impl(const char* what, kh_stream_t stream, const BatchRef& b, int
     }
     // bilinear downscales whose taps touch nearly every line of two source rows per output row: the row-streamed kernel (test option
     // resize_rows = 0 keeps the gather kernel)
-    const bool rows_ok = mode == KH_INTERP_BILINEAR && dev_opt(kOptResizeRows) != 0 && (sw * channels) % 4 == 0 && ay >= 1.5f &&
-                         ax * (float)(channels * 4) <= 128.0f && batch_aligned(b, 16, sizeof(float));
-    if (rows_ok) {
-        // An output row is cut into parts of `part_cols` columns, one block each (a block stages only the source-row segments under its
-        // columns).  Two things decide the width (profiles/r06k_resize_rows_split.txt, C2: 7 parts of 32 columns 0.450 ms; 1 / 2 / 4 / 8
-        // parts 0.484-0.492; 16 parts 0.90): a part's output bytes should be WHOLE 128-byte lines — two blocks writing halves of one line
-        // cost more than anything else here — and its segment pair small enough that eight blocks share a CU's LDS.  So: a multiple of
-        // the columns that make a whole line (32 for C = 1 / 3, 8 for C = 4) whose source segment is about 4 KB.
-        // Test option resize_rows = N > 0: N columns per part; + 1000: 64-thread blocks, + 2000: 128-thread blocks.
-        const int opt = dev_opt(kOptResizeRows);
-        const int block = opt >= 2000 ? 128 : (opt >= 1000 ? 64 : kRowsBlockDefault);
-        const int unit = channels == 4 ? 8 : 32;
-        int part_cols = opt > 0 && opt % 1000 ? opt % 1000 : std::max(1, (int)(4096.0f / (ax * (float)(channels * 4))) / unit) * unit;
-        if (part_cols > dw) part_cols = dw;
-        const int parts = (dw + part_cols - 1) / part_cols;
-        // the longest source segment any part needs (host evaluation of the kernel's own expressions)
-        int seg4_max = 1;
-        for (int part = 0; part < parts; ++part) {
-            const int x_lo = part * part_cols, x_hi = std::min(x_lo + part_cols, dw);
-            const int s4 = (rows_src_px(ax, bx, x_lo, sw) * channels) >> 2;
-            const int e4 = std::min(((std::min(rows_src_px(ax, bx, x_hi - 1, sw) + 1, sw - 1) + 1) * channels + 3) >> 2, (sw * channels) >> 2);
-            seg4_max = std::max(seg4_max, e4 - s4);
-        }
-        const int iters = (seg4_max + block - 1) / block;
-        if (iters <= 8 && (int64_t)dh * parts * b.n <= kI32Max && (size_t)seg4_max * 32 <= 64 * 1024)
-            return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
-                Img im = make_img(c, sw, sh, dw, dh, c.n);
-                const dim3 grid((unsigned)dh * (unsigned)parts * (unsigned)c.n), blk(block);
-                const size_t lds = (size_t)2 * seg4_max * 16;
-                const FastDiv by_rows = fast_div((uint32_t)dh * (uint32_t)parts), by_parts = fast_div((uint32_t)parts);
-                const NoList none{0};
-                const int it = iters <= 1 ? 1 : (iters <= 2 ? 2 : (iters <= 4 ? 4 : 8));
+    RowsPlan rp;
+    if (mode == KH_INTERP_BILINEAR && plan_rows(b, sw, dw, dh, channels, ax, bx, ay, rp))
+        return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+            Img im = make_img(c, sw, sh, dw, dh, c.n);
+            const dim3 grid((unsigned)dh * (unsigned)rp.parts * (unsigned)c.n), blk(rp.block);
+            const size_t lds = (size_t)2 * rp.seg4_max * 16;
+            const FastDiv by_rows = fast_div((uint32_t)dh * (uint32_t)rp.parts), by_parts = fast_div((uint32_t)rp.parts);
+            const NoList none{0};
+            const int parts = rp.parts, part_cols = rp.part_cols, seg4_max = rp.seg4_max, block = rp.block;
 #define KH_ROWS(CC, IT, BL)                                                                                                                                       \
     do {                                                                                                                                                          \
         if (c.listed()) hipLaunchKernelGGL((resize_rows_bilinear_kernel<CC, IT, BL, true>), grid, blk, lds, st, im, ax, bx, ay, by, by_rows, by_parts, parts, part_cols, seg4_max, lst); \
         else hipLaunchKernelGGL((resize_rows_bilinear_kernel<CC, IT, BL, false>), grid, blk, lds, st, im, ax, bx, ay, by, by_rows, by_parts, parts, part_cols, seg4_max, none);          \
     } while (0)
 #define KH_ROWS_B(CC, IT) do { if (block == 64) KH_ROWS(CC, IT, 64); else if (block == 128) KH_ROWS(CC, IT, 128); else KH_ROWS(CC, IT, 256); } while (0)
-#define KH_ROWS_C(CC) do { switch (it) { case 1: KH_ROWS_B(CC, 1); break; case 2: KH_ROWS_B(CC, 2); break; case 4: KH_ROWS_B(CC, 4); break; default: KH_ROWS_B(CC, 8); break; } } while (0)
-                switch (channels) { case 1: KH_ROWS_C(1); break; case 3: KH_ROWS_C(3); break; default: KH_ROWS_C(4); break; }
+#define KH_ROWS_C(CC) do { switch (rp.it) { case 1: KH_ROWS_B(CC, 1); break; case 2: KH_ROWS_B(CC, 2); break; case 4: KH_ROWS_B(CC, 4); break; default: KH_ROWS_B(CC, 8); break; } } while (0)
+            switch (channels) { case 1: KH_ROWS_C(1); break; case 3: KH_ROWS_C(3); break; default: KH_ROWS_C(4); break; }
 #undef KH_ROWS_C
 #undef KH_ROWS_B
 #undef KH_ROWS
-                return check_launch(what);
-            });
-    }
+            return check_launch(what);
+        });
     // bicubic with a horizontal step of exactly 2 (sw == 2 dw, half-pixel grid): neighbours' columns through wave shifts
     // (resize_bicubic_half_kernel).  Test option resize_rows = 0 keeps the gather kernel here too.
     if (mode == KH_INTERP_BICUBIC && dev_opt(kOptResizeRows) != 0 && sw == 2 * dw && ax == 2.0f && bx == 0.5f && dw < (1 << 22)) {
@@ -916,6 +939,22 @@ int32_t resize_normalize_impl(const char* what, kh_stream_t stream, const BatchR
     if (b.n == 0) return KH_OK;
     Norm3f n;
     for (int c = 0; c < 3; ++c) { n.mean[c] = mean[c]; n.inv_std[c] = 1.0f / std_dev[c]; }
+    // the row-streamed walk of `resize` with the normalisation epilogue (round 6), where a plain resize of this geometry takes it
+    RowsPlan rp;
+    if (plan_rows(b, sw, dw, dh, 3, cx[0], cx[1], cy[0], rp) && rp.block == kRowsBlockDefault)
+        return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
+            Img im = make_img(c, sw, sh, dw, dh, c.n);
+            const dim3 grid((unsigned)dh * (unsigned)rp.parts * (unsigned)c.n), blk(rp.block);
+            const size_t lds = (size_t)2 * rp.seg4_max * 16;
+            const FastDiv by_rows = fast_div((uint32_t)dh * (uint32_t)rp.parts), by_parts = fast_div((uint32_t)rp.parts);
+            const NoList none{0};
+            hipStream_t st = as_hip(stream);
+#define KH_ROWSN(IT) do { if (c.listed()) hipLaunchKernelGGL((resize_rows_bilinear_normalize_kernel<IT, true>), grid, blk, lds, st, im, cx[0], cx[1], cy[0], cy[1], by_rows, by_parts, rp.parts, rp.part_cols, rp.seg4_max, n, lst); \
+                          else hipLaunchKernelGGL((resize_rows_bilinear_normalize_kernel<IT, false>), grid, blk, lds, st, im, cx[0], cx[1], cy[0], cy[1], by_rows, by_parts, rp.parts, rp.part_cols, rp.seg4_max, n, none); } while (0)
+            switch (rp.it) { case 1: KH_ROWSN(1); break; case 2: KH_ROWSN(2); break; case 4: KH_ROWSN(4); break; default: KH_ROWSN(8); break; }
+#undef KH_ROWSN
+            return check_launch(what);
+        });
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
         const Img im = make_img(c, sw, sh, dw, dh, c.n);
         KH_REQUIRE_TILES(what, im);

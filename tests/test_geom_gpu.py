@@ -65,6 +65,34 @@ def test_resize_bilinear_row_streamed_kernel(gpu_stream, dev_option, shape, c):
     assert_same_bits(resize_gpu(gpu_stream, src, dw, dh, "bilinear", batch=n), got, "gather kernel vs row-streamed kernel")
 
 
+@pytest.mark.parametrize("shape", [(128, 96, 30, 22), (1920, 40, 224, 8), (64, 300, 20, 7), (2048, 12, 200, 5), (16, 64, 4, 3), (128, 96, 100, 90)])
+def test_resize_bilinear_normalize_row_streamed_kernel(gpu_stream, dev_option, shape):
+    """resize_bilinear_normalize_3c (P/cuda/resize.rs:184-236) takes the row-streamed walk of `resize` with the `(px - mean) * inv_std`
+    epilogue where a plain resize of the geometry does (round 6): the oracle's bits in a batch and through a pointer list, part widths
+    forced through the test option, resize_rows = 0 (the per-pixel kernel) the same; the last shape (a vertical step below 1.5) never
+    leaves the per-pixel kernel."""
+    from kornia_rs import _ffi
+    from kornia_rs.hip import DeviceBuffer
+    sw, sh, dw, dh = shape
+    n, mean, std = 3, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    src = np.stack([img(sw, sh, 3, seed=31 * k) for k in range(n)])
+    want = np.stack([O.resize_bilinear_normalize(src[k], dw, dh, mean, std) for k in range(n)])
+    d_src = dev(gpu_stream, src)
+    for opt in (-1, 32, 7, 0):
+        dev_option("resize_rows", opt)
+        d_dst = out_buf(gpu_stream, n * dh * dw * 3 * 4)
+        _ffi.check(_ffi.lib.kh_resize_bilinear_normalize_f32(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr, sw, sh, dw, dh, fptr(mean), fptr(std), 0, n,
+                                                             sh * sw * 3, dh * dw * 3))
+        assert_same_bits(d_dst.to_numpy(np.float32, (n, dh, dw, 3)), want, f"resize + normalize {shape} option {opt}")
+    dev_option("resize_rows", -1)
+    srcs = [DeviceBuffer.from_numpy(src[k].reshape(-1), gpu_stream) for k in range(n)]
+    dsts = [out_buf(gpu_stream, dh * dw * 3 * 4) for _ in range(n)]
+    _ffi.check(_ffi.lib.kh_resize_bilinear_normalize_f32_list(gpu_stream.cuda_stream_ptr, _ffi.pointer_array([b.ptr for b in srcs]), _ffi.pointer_array([b.ptr for b in dsts]),
+                                                              n, sw, sh, dw, dh, fptr(mean), fptr(std), 0))
+    for k in range(n):
+        assert_same_bits(dsts[k].to_numpy(np.float32, (dh, dw, 3)), want[k], f"list image {k} {shape}")
+
+
 @pytest.mark.parametrize("shape", [(128, 96, 30, 22), (1920, 40, 224, 8), (64, 300, 20, 7), (128, 96, 64, 48)])
 @pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
 def test_resize_mapped_align_corners_through_the_new_kernels(gpu_stream, dev_option, shape, mode):
