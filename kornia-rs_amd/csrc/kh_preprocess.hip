@@ -690,6 +690,79 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity_list(FrameL
     nv12_identity_body(fl.p[frame], dst_base + (long long)frame * a.dst_frame_stride, a);
 }
 
+// ---- the same case into binary16 planes (round 6; run_raw_batch_f16, P/preprocess.rs:1234-1256) -------------------------------------
+// The f16 twin took the generic kernel until round 6 and ran SLOWER than the f32 north star (6.11 ms against 4.31 per 1024 frames for
+// 55 % of the bytes).  Here a thread owns EIGHT pixels of one row — two dwords of luma, two of chroma — so that each of its three stores
+// is still 16 bytes (eight binary16 values; a wave writes 1 KiB contiguous per plane): the f32 kernel's store shape at half the output
+// bytes.  Same integer decode, same `(x / 255 - m) * is`, then the reference's f32 -> f16 rounding: 2.75 ms (profiles/r06ze_f16_identity.txt;
+// 64-bit source loads instead of pairs of dwords: 2.73, not taken).
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {   // two round-to-nearest-even conversions, one dword
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void nv12_identity_f16_body(const uint8_t* __restrict__ src_frame, unsigned short* __restrict__ dst_frame, const PreArgs& a) {
+    const int wo = a.src_w >> 3;     // 8-pixel groups per row
+    const int groups = wo * a.src_h;
+    const int g = blockIdx.x * kIdBlock + threadIdx.x;
+    if (g >= groups) return;
+    const int plane = a.src_w * a.src_h;
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(src_frame, (uint32_t)(plane + plane / 2));
+    const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_frame, (uint32_t)(6 * plane));
+    const int r = g / wo;            // (a plain division, as in the f32 kernel)
+    const int xo = g - r * wo;
+    uint32_t y4[2], uv4[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        y4[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, r * a.src_w + 8 * xo + 4 * q, 0, 0);
+        uv4[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, plane + (r >> 1) * a.src_w + 8 * xo + 4 * q, 0, 0);
+    }
+    u32x4_t o[3];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int tb[2], tg[2], tr[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = (int)((uv4[q] >> (16 * k)) & 0xFFu) - 128;
+            const int v = (int)((uv4[q] >> (16 * k + 8)) & 0xFFu) - 128;
+            tb[k] = kCUB * u + kHalf20;
+            tg[k] = kCUG * u + kCVG * v + kHalf20;
+            tr[k] = kCVR * v + kHalf20;
+        }
+        float f[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int yy = max((int)((y4[q] >> (8 * j)) & 0xFFu) - 16, 0) * kCY;
+            const int k = j >> 1;
+            const float rr = (float)clamp255((yy + tr[k]) >> 20);
+            const float gg = (float)clamp255((yy + tg[k]) >> 20);
+            const float bb = (float)clamp255((yy + tb[k]) >> 20);
+            f[0][j] = (div255_u8(rr) - a.m0) * a.is0;
+            f[1][j] = (div255_u8(gg) - a.m1) * a.is1;
+            f[2][j] = (div255_u8(bb) - a.m2) * a.is2;
+        }
+        // f2h_bits without its >= 2^16 branch: the host proved that no value of this launch reaches it (identity_fast_path), and below
+        // it the reference's rounding IS the round-to-nearest-even conversion instruction
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            o[c][2 * q] = pack_h2(f[c][0], f[c][1]);
+            o[c][2 * q + 1] = pack_h2(f[c][2], f[c][3]);
+        }
+    }
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));  // all twenty-four values exist here: the stores issue back to back
+#pragma unroll
+    for (int c = 0; c < 3; ++c) __builtin_amdgcn_raw_buffer_store_b128(o[c], rdst, 16 * g + c * (2 * plane), 0, kAuxStream);
+}
+__global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity_f16(
+    const uint8_t* __restrict__ src_base, unsigned short* __restrict__ dst_base, PreArgs a) {
+    const unsigned frame = blockIdx.y;
+    nv12_identity_f16_body(src_base + (long long)frame * a.src_frame_stride, dst_base + (long long)frame * a.dst_frame_stride, a);
+}
+__global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity_f16_list(FrameList fl, unsigned short* __restrict__ dst_base, PreArgs a) {
+    const unsigned frame = blockIdx.y;
+    nv12_identity_f16_body(fl.p[frame], dst_base + (long long)frame * a.dst_frame_stride, a);
+}
+
 // Lanczos axis-weight tables: wx[dst_w][6] then wy[dst_h][6], cached per (device, geometry) like the reference's tap tables
 // (P/resize/cuda.rs:151-190): blocking upload before publication, leased until the launch is recorded, a cold table under stream
 // capture is a typed error (kh_table_cache.h).  `s` is evaluated exactly as the kernel's plan_pixel does ((o - pad) / scale, IEEE).
@@ -807,14 +880,24 @@ struct Frames {
 };
 
 bool identity_fast_path(const kh_preprocess_params* p, const Frames& f, const void* dst) {
+    const bool f16 = p->out_dtype == KH_OUT_F16;   // eight pixels per thread, eight halves per 16-byte store
+    // The f16 kernel converts with the plain round-to-nearest-even instruction.  The reference's f2h differs from it only at |v| >= 2^16
+    // (NaN patterns instead of Inf, see f2h_bits), and v = (q - m) * is with q in [0, 1] is monotone in q (subtraction and multiplication
+    // by a constant round monotonically), so its largest magnitude is at q = 0 or q = 1: both below 2^16 for every channel, or the
+    // generic kernel with the full f2h_bits takes the launch.  (False for NaN / Inf parameters.)
+    if (f16)
+        for (int c = 0; c < 3; ++c) {
+            const float v0 = (0.0f - p->mean[c]) * p->inv_std[c], v1 = (1.0f - p->mean[c]) * p->inv_std[c];
+            if (!(fabsf(v0) < 65536.0f && fabsf(v1) < 65536.0f)) return false;
+        }
     return !(p->flags & KH_PRE_FORCE_GENERIC) && p->fmt == KH_FMT_NV12 &&
-           p->out_dtype == KH_OUT_F32 &&
+           (p->out_dtype == KH_OUT_F32 || f16) &&
            (p->sampling == KH_SAMPLE_BILINEAR || p->sampling == KH_SAMPLE_NEAREST) &&
            p->scale_x == 1.0f && p->scale_y == 1.0f && p->pad_x == 0.0f && p->pad_y == 0.0f &&
-           p->dst_w == p->src_w && p->dst_h == p->src_h && (p->src_w % 4) == 0 &&
+           p->dst_w == p->src_w && p->dst_h == p->src_h && (p->src_w % (f16 ? 8 : 4)) == 0 &&
            (int64_t)p->src_w * p->src_h * 12 <= kI32Max &&  // 32-bit buffer offsets within one frame's three planes
            f.aligned(4) && (f.listed() || (p->src_frame_stride % 4) == 0) &&
-           (reinterpret_cast<uintptr_t>(dst) % 16) == 0 && (p->dst_frame_stride % 4) == 0;
+           (reinterpret_cast<uintptr_t>(dst) % 16) == 0 && (p->dst_frame_stride % (f16 ? 8 : 4)) == 0;
 }
 
 int32_t validate(const kh_preprocess_params* p, const Frames& f, const void* dst) {
@@ -961,7 +1044,12 @@ int32_t preprocess_impl(kh_stream_t stream, const Frames& f, void* dst, const kh
         if (f.listed()) for (int k = 0; k < n; ++k) fl_chunk.p[k] = f.list[first + k];
         const FrameList& fl = f.listed() ? fl_chunk : kNoFrames;
         void* dst_chunk = static_cast<char*>(dst) + (size_t)first * (size_t)p->dst_frame_stride * out_elem;
-        if (identity) {
+        if (identity && p->out_dtype == KH_OUT_F16) {
+            const unsigned bpf = cdiv((p->src_w / 8) * p->src_h, kIdBlock);
+            if (f.listed()) hipLaunchKernelGGL(preprocess_nv12_identity_f16_list, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, fl, (unsigned short*)dst_chunk, a);
+            else hipLaunchKernelGGL(preprocess_nv12_identity_f16, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, f.src, (unsigned short*)dst_chunk, a);
+            rc = check_launch("preprocess_nv12_identity_f16");
+        } else if (identity) {
             const int groups = (p->src_w / 4) * p->src_h;
             const unsigned bpf = cdiv(groups, kIdBlock);
             if (f.listed()) hipLaunchKernelGGL(preprocess_nv12_identity_list, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, fl, (float*)dst_chunk, a);
@@ -993,7 +1081,7 @@ const char* kh_preprocess_variant(const kh_preprocess_params* p) {
     const Frames aligned{reinterpret_cast<const uint8_t*>(16), p ? p->src_frame_stride : 0, nullptr, p ? p->nframes : 0};
     if (validate(p, aligned, reinterpret_cast<void*>(16)) != KH_OK)
         return nullptr;
-    if (identity_fast_path(p, aligned, reinterpret_cast<void*>(16))) return "nv12_identity";
+    if (identity_fast_path(p, aligned, reinterpret_cast<void*>(16))) return p->out_dtype == KH_OUT_F16 ? "nv12_identity_f16" : "nv12_identity";
     if (p->sampling == KH_SAMPLE_BILINEAR) {
         PreArgs a{};
         a.scale_x = p->scale_x; a.scale_y = p->scale_y; a.pad_x = p->pad_x; a.pad_y = p->pad_y;

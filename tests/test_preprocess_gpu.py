@@ -226,6 +226,59 @@ def test_nv12_identity_batch_1080p(gpu_stream):
         assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), f"frame {k}"
 
 
+@pytest.mark.parametrize("w,h", [(64, 32), (1920, 1080), (24, 6), (8, 2), (20, 6)])
+@pytest.mark.parametrize("sampling", ["bilinear", "nearest"])
+def test_nv12_identity_f16_fast_path_equals_generic_and_oracle(gpu_stream, w, h, sampling):
+    """run_raw_f16 on the north-star geometry (P/preprocess.rs:1234-1256): since round 6 its own kernel — eight pixels per thread, three
+    16-byte stores of eight binary16 values — where the width is a multiple of eight; the oracle's bits, the generic kernel's bits
+    (forced), and a width of 20 (not a multiple of eight) keeps the generic kernel."""
+    import ctypes as C
+    from kornia_rs import _ffi
+    raw = _raw_for("nv12", w, h, seed=5)
+    kw = dict(fmt="nv12", mode="stretch", sampling=sampling, f16=True, **IMAGENET)
+    fast = _run(gpu_stream, raw, w, h, w, h, **kw)
+    slow = _run(gpu_stream, raw, w, h, w, h, force_generic=True, **kw)
+    want = O.preprocess(raw, w, h, w, h, **kw)
+    _assert_bits_equal(fast, want, "f16 fast path vs oracle")
+    _assert_bits_equal(slow, want, "f16 generic vs oracle")
+    pre = _pre(gpu_stream, mode="stretch", format="nv12", sampling=sampling, f16=True, **IMAGENET)
+    p = pre._params(w, h, w, 1, _ffi.KH_FMT_NV12, w, h, 1, 0, True, False)
+    assert _ffi.lib.kh_preprocess_variant(C.byref(p)) == (b"nv12_identity_f16" if w % 8 == 0 else (b"generic_bilinear_on_grid" if sampling == "bilinear" else b"generic"))
+
+
+def test_nv12_identity_f16_batch_strided_and_list(gpu_stream):
+    """A batch of 1080p frames into binary16 planes, equally spaced and as a list of separately allocated frames: every frame equals the
+    generic kernel's result, two sampled frames equal the oracle, and the f16 overflow quirk (values >= 2^16 become NaN patterns, not Inf)
+    survives the fast path."""
+    from kornia_rs import Tensor
+    from kornia_rs.hip import DeviceBuffer
+    w, h, n = 1920, 1080, 6
+    fb = w * h * 3 // 2
+    base = O.pattern_u8(fb + 31 * n)
+    frames = np.stack([base[31 * k: 31 * k + fb] for k in range(n)])
+    pre = _pre(gpu_stream, mode="stretch", format="nv12", f16=True, **IMAGENET)
+    src = DeviceBuffer.from_numpy(frames.reshape(-1), gpu_stream)
+    dst = Tensor.uninit((n, 3, h, w), "float16", gpu_stream)
+    pre.run_raw_batch(src, w, h, dst, frame_stride=fb)
+    got = dst.numpy_raw().view(np.uint16)
+    gen = Tensor.uninit((n, 3, h, w), "float16", gpu_stream)
+    pre.run_raw_batch(src, w, h, gen, frame_stride=fb, _force_generic=True)
+    assert np.array_equal(got, gen.numpy_raw().view(np.uint16))
+    for k in (0, n - 1):
+        want = O.preprocess(frames[k], w, h, w, h, fmt="nv12", mode="stretch", f16=True, **IMAGENET)[0]
+        assert np.array_equal(got[k], want.view(np.uint16)), f"frame {k}"
+    bufs = [DeviceBuffer.from_numpy(frames[k], gpu_stream) for k in range(n)]
+    lst = Tensor.uninit((n, 3, h, w), "float16", gpu_stream)
+    pre.run_raw_batch(bufs, w, h, lst)
+    assert np.array_equal(lst.numpy_raw().view(np.uint16), got)
+    big = _pre(gpu_stream, mode="stretch", format="nv12", f16=True, mean=(0.0, 0.0, 0.0), std=(1e-6, 2.0 ** -17, 1.0))
+    raw = _raw_for("nv12", 64, 8, seed=1)
+    q = Tensor.uninit((1, 3, 8, 64), "float16", gpu_stream)
+    big.run_raw(DeviceBuffer.from_numpy(raw, gpu_stream), 64, 8, q)
+    want = O.preprocess(raw, 64, 8, 64, 8, fmt="nv12", mode="stretch", f16=True, mean=(0.0, 0.0, 0.0), std=(1e-6, 2.0 ** -17, 1.0))
+    assert np.array_equal(q.numpy_raw().view(np.uint16), want.view(np.uint16))
+
+
 def test_unaligned_nv12_identity_falls_back_to_generic_kernel(gpu_stream):
     """Width not divisible by 4: the dispatcher must use the generic kernel (still on device) and
     stay bit-exact."""
