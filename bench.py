@@ -227,6 +227,48 @@ class NorthStarNV12List(NorthStarNV12):
         return d
 
 
+class NorthStarNV12F16(NorthStarNV12):
+    """The north star's binary16 twin — `run_raw_batch_f16` (P/preprocess.rs:1234-1256): the same 1024 NV12 1080p frames into
+    [1024, 3, 1080, 1920] f16 planes (decode and normalisation in int32 / f32, the reference's f32 -> f16 rounding at the store).  Since
+    round 6 its own kernel (eight pixels per thread, three 16-byte stores of eight halves); it took the generic kernel before and ran
+    slower than the f32 headline."""
+
+    def __init__(self, batch: int = 1024):
+        super().__init__(batch, 0)
+        self.name = f"nv12_1080p_to_chw_f16_b{batch}"
+        self.kernel = "preprocess_nv12_identity_f16"
+        self.dtype = "f32 -> f16 store"
+        self.alg_bytes_per_launch = self.N * (self.frame_bytes + 6 * self.W * self.H)   # 1.5 B/px read + 3 x 2 B/px written
+
+    def setup(self, stream):
+        from kornia_rs import Preprocessor, Tensor
+        super().setup(stream)
+        self.dst = Tensor.uninit((self.N, 3, self.H, self.W), "float16", stream)
+        self.pre = Preprocessor(mode="stretch", format="nv12", sampling=self.sampling, f16=True, mean=IMAGENET_MEAN, std=IMAGENET_STD, stream=stream)
+
+    def describe(self):
+        d = super().describe()
+        d.update(op="Preprocessor.run_raw_batch -> f16 planes (run_raw_batch_f16: fused NV12 decode + ImageNet normalize + HWC->CHW, f32 -> f16 at the store)",
+                 dst=f"[{self.N},3,{self.H},{self.W}] f16")
+        return d
+
+    def cpu_baseline(self):
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_ffi as O  # test infrastructure: used here ONLY as the timed CPU baseline
+        threads = O.ko.ko_max_threads()
+        frames, t0, budget = 0, time.perf_counter(), 8.0 * CPU_BUDGET_SCALE
+        while True:
+            raw = self.base[31 * (frames % self.N): 31 * (frames % self.N) + self.frame_bytes]
+            O.preprocess(O.rgb_from_nv12(raw, self.W, self.H), self.W, self.H, self.W, self.H, fmt="rgb", mode="stretch", sampling=self.sampling,
+                         f16=True, mean=IMAGENET_MEAN, std=IMAGENET_STD)
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or frames >= 16384:
+                break
+        return {"value": round(frames * self.W * self.H / 1e6 / dt, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+                "sample": f"{frames} frames in {dt:.1f} s; C oracle, chained rgb_from_nv12 -> normalize / CHW / f16, OpenMP x{threads}"}
+
+
 class H2DPreprocess1080p(NorthStarNV12):
     """SURVEY.md §8(f)4, the capture side of the path: HOST NV12 frames -> page-locked capture buffers -> H2D -> fused preprocess,
     through Preprocessor.run_host_batch (the two-deep upload ring of kornia_rs/preprocess.py::_Staging on a copy stream; the
@@ -1515,6 +1557,7 @@ WORKLOADS = {
     "nv12_chw_640_lanczos": lambda a: NorthStarNV12(a.batch or 256, 640, "lanczos"),
     "yuyv_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640, "bilinear", "yuyv"),
     "nv12_chw_list": lambda a: NorthStarNV12List(a.batch or 1024),
+    "nv12_chw_f16": lambda a: NorthStarNV12F16(a.batch or 1024),
     "nv12_h2d_preprocess": lambda a: H2DPreprocess1080p(a.batch or 64),
     "nv12_h2d_preprocess_zero_copy": lambda a: H2DPreprocess1080p(a.batch or 64, pageable=False),
     "resize_224": lambda a: ResizeBilinear(a.batch or 256),
@@ -1559,7 +1602,7 @@ WORKLOADS = {
 # (resize bilinear / bicubic, gray + YCbCr + HSV converts, gaussian / box / sobel, warp_affine / warp_perspective + undistort,
 # normalize), then the u8 twins.  Each entry is a full roofline record with its own cpu_baseline.  (Median / bilateral / Lab
 # are out of SURVEY.md §8 and have no bench line; their kernels are covered by the parity tests only.)
-ALSO_DEFAULT = ["nv12_chw_list", "nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_h2d_preprocess", "nv12_h2d_preprocess_zero_copy", "resize_224",
+ALSO_DEFAULT = ["nv12_chw_list", "nv12_chw_f16", "nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_h2d_preprocess", "nv12_h2d_preprocess_zero_copy", "resize_224",
                 "resize_224_api_list", "resize_224_api_graph", "resize_224_api_eager", "gaussian_4k_api_list", "undistort_warp_4k_api_list",
                 "resize_bicubic_540", "gaussian_4k", "box_blur_4k", "sobel_4k",
                 "undistort_warp_4k", "warp_affine_f32_1080p", "normalize_1080p", "gray_258x195", "gray_u8_1080p", "gray_f32_1080p",

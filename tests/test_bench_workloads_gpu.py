@@ -96,6 +96,20 @@ def test_frame_list_workload(gpu_stream, bench):
         assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), k
 
 
+def test_f16_twin_workload(gpu_stream, bench):
+    """The north star's binary16 twin (run_raw_batch_f16): its own kernel since round 6; the oracle's f16 bits on every frame."""
+    import ctypes as C
+    from kornia_rs import _ffi
+    wl = _run(bench, "nv12_chw_f16", gpu_stream)
+    assert wl.kernel == "preprocess_nv12_identity_f16" and wl.alg_bytes_per_launch == wl.N * (wl.frame_bytes + 6 * wl.W * wl.H)
+    p = wl.pre._params(wl.W, wl.H, wl.W, 1, _ffi.KH_FMT_NV12, wl.W, wl.H, wl.N, wl.frame_bytes, True, False)
+    assert _ffi.lib.kh_preprocess_variant(C.byref(p)) == b"nv12_identity_f16"
+    got = wl.dst.numpy_raw().view(np.uint16).reshape(wl.N, 3, wl.H, wl.W)
+    for k in range(wl.N):
+        want = O.preprocess(wl.base[31 * k: 31 * k + wl.frame_bytes], wl.W, wl.H, wl.W, wl.H, fmt="nv12", mode="stretch", f16=True, mean=MEAN, std=STD)[0]
+        assert np.array_equal(got[k], want.view(np.uint16)), k
+
+
 @pytest.mark.parametrize("how", ["eager", "graph", "list"])
 def test_resize_api_workloads(gpu_stream, bench, how):
     """configs[1] through imgproc.resize / hip.Graph / imgproc.resize_batch on separately allocated Images; ROTATE + 1 steps so that
@@ -268,7 +282,7 @@ def test_colour_map_workloads_1080p(gpu_stream, bench):
 
 
 def test_every_workload_is_covered(bench):
-    covered = {"nv12_h2d_preprocess", "nv12_h2d_preprocess_zero_copy", "nv12_chw_list", "resize_224_api_eager", "resize_224_api_graph", "resize_224_api_list",
+    covered = {"nv12_h2d_preprocess", "nv12_h2d_preprocess_zero_copy", "nv12_chw_list", "nv12_chw_f16", "resize_224_api_eager", "resize_224_api_graph", "resize_224_api_list",
                "gaussian_4k_api_list", "undistort_warp_4k_api_list", "nv12_chw", "nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_chw_640_lanczos", "resize_224", "resize_bicubic_540", "resize_normalize_f32_224",
                "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640", "gaussian_4k", "sobel_4k", "box_blur_4k", "gaussian_u8_4k", "pyrdown_u8_4k",
                "pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_f32_1080p", "normalize_1080p",
