@@ -269,6 +269,33 @@ class NorthStarNV12F16(NorthStarNV12):
                 "sample": f"{frames} frames in {dt:.1f} s; C oracle, chained rgb_from_nv12 -> normalize / CHW / f16, OpenMP x{threads}"}
 
 
+class LetterboxF16(NorthStarNV12):
+    """The letterbox secondaries into binary16 planes (run_raw_batch_f16; the shape a half-precision detector consumes): opt-in rows.
+    Since round 6 through the flattened-quad kernel with one 8-byte store of four halves per plane (the per-pixel kernel with 2-byte
+    stores before: no faster than f32 for half the bytes)."""
+
+    def __init__(self, batch: int = 1024, out: int = 640, fmt: str = "nv12"):
+        super().__init__(batch, out, "bilinear", fmt)
+        self.name = f"{fmt}_1080p_to_chw_f16_letterbox{out}_b{batch}"
+        self.dtype = "f32 -> f16 store"
+
+    def setup(self, stream):
+        from kornia_rs import Preprocessor, Tensor
+        super().setup(stream)
+        self.dst = Tensor.uninit((self.N, 3, self.out, self.out), "float16", stream)
+        self.pre = Preprocessor(mode="letterbox", format=self.fmt, sampling=self.sampling, f16=True, mean=IMAGENET_MEAN, std=IMAGENET_STD, stream=stream)
+        # priced like the f32 row, with 2 bytes per destination value
+        self.alg_bytes_per_launch = int(self.N * (self.out * self.out * 6 + self.active_px * self.taps * self.src_bytes_per_px))
+
+    def describe(self):
+        d = super().describe()
+        d.update(dst=f"[{self.N},3,{self.out},{self.out}] f16")
+        return d
+
+    def cpu_baseline(self):
+        return {"value": None, "unit": "Mpixels/s", "cores": None, "kind": "port", "sample": "see the f32 row of the same geometry"}
+
+
 class H2DPreprocess1080p(NorthStarNV12):
     """SURVEY.md §8(f)4, the capture side of the path: HOST NV12 frames -> page-locked capture buffers -> H2D -> fused preprocess,
     through Preprocessor.run_host_batch (the two-deep upload ring of kornia_rs/preprocess.py::_Staging on a copy stream; the
@@ -1558,6 +1585,9 @@ WORKLOADS = {
     "yuyv_chw_640": lambda a: NorthStarNV12(a.batch or 1024, 640, "bilinear", "yuyv"),
     "nv12_chw_list": lambda a: NorthStarNV12List(a.batch or 1024),
     "nv12_chw_f16": lambda a: NorthStarNV12F16(a.batch or 1024),
+    "nv12_chw_640_f16": lambda a: LetterboxF16(a.batch or 1024, 640, "nv12"),
+    "nv12_chw_608_f16": lambda a: LetterboxF16(a.batch or 1024, 608, "nv12"),
+    "yuyv_chw_640_f16": lambda a: LetterboxF16(a.batch or 1024, 640, "yuyv"),
     "nv12_h2d_preprocess": lambda a: H2DPreprocess1080p(a.batch or 64),
     "nv12_h2d_preprocess_zero_copy": lambda a: H2DPreprocess1080p(a.batch or 64, pageable=False),
     "resize_224": lambda a: ResizeBilinear(a.batch or 256),

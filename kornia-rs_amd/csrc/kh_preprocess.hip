@@ -48,6 +48,7 @@ struct PreArgs {
     const float* lz_wx;          // Lanczos only: 6 axis weights per destination column / row, built on the host (see lanczos_tables)
     const float* lz_wy;
     int quad_wide;               // preprocess_generic_quads, NV12 / YUYV: the taps of every destination quad fit one 16-byte run per plane row (host-checked)
+    int f16_plain;               // f16 outputs of the nearest / bilinear samplers: no value of the launch reaches 2^16 (host-proved, f16_in_range): plain conversions
 };
 
 // kh_preprocess_to_chw_list: the reference's `run_raw_batch(frames: &[&CudaSlice<u8>], ..)` (P/preprocess.rs:1258-1282) hands over
@@ -355,6 +356,12 @@ __device__ __forceinline__ unsigned short f2h_bits(float f) {
     return __builtin_bit_cast(unsigned short, h);
 }
 
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {   // two round-to-nearest-even conversions, one dword (valid below 2^16)
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 template <typename OutT>
 __device__ __forceinline__ OutT to_out(float v);
 template <>
@@ -521,18 +528,32 @@ __device__ __forceinline__ void quad_taps_nv12_bilinear(const uint8_t* __restric
 // 6 % above its floor (profiles/r05j_four_tap_decode_ablation.txt).  Not kept.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kQuadBlock = 256;
-template <int FMT, int SAMPLER, bool WIDE, bool LIST>
-__global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uint8_t* __restrict__ src_base, float* __restrict__ dst_base,
+// A quad's four values of plane `c`: one 16-byte store of f32, or (round 6) one 8-byte store of four binary16 values (f2h_bits: the
+// reference's rounding) — the f16 outputs took the per-pixel kernel with 2-byte stores before and ran no faster than f32 for half the bytes.
+template <typename OutT>
+__device__ __forceinline__ void store_quad(__amdgpu_buffer_rsrc_t rdst, int g, int c, int plane, const float (&v)[4], int f16_plain) {
+    if constexpr (sizeof(OutT) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}), rdst,
+                                               16 * g + c * (4 * plane), 0, kAuxStream);
+    } else {
+        uint32_t lo, hi;
+        if (f16_plain) { lo = pack_h2(v[0], v[1]); hi = pack_h2(v[2], v[3]); }   // launch-uniform (f16_in_range on the host)
+        else { lo = (uint32_t)f2h_bits(v[0]) | ((uint32_t)f2h_bits(v[1]) << 16); hi = (uint32_t)f2h_bits(v[2]) | ((uint32_t)f2h_bits(v[3]) << 16); }
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2_t{lo, hi}), rdst, 8 * g + c * (2 * plane), 0, kAuxStream);
+    }
+}
+template <int FMT, int SAMPLER, bool WIDE, bool LIST, typename OutT>
+__global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uint8_t* __restrict__ src_base, OutT* __restrict__ dst_base,
                                                                        PreArgs a, FastDiv by_wq, typename FrameArg<LIST>::type fl) {
     const int wq = a.dst_w >> 2, groups = wq * a.dst_h, plane = a.dst_w * a.dst_h;   // host-checked: 12 * plane < 2^31
     const int g = blockIdx.x * kQuadBlock + threadIdx.x;
     if (g >= groups) return;
     const uint8_t* src = frame_base<LIST>(fl, a, src_base, blockIdx.y);
-    const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_base + (long long)blockIdx.y * a.dst_frame_stride, (uint32_t)(12 * plane));
+    const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_base + (long long)blockIdx.y * a.dst_frame_stride, (uint32_t)(3 * (int)sizeof(OutT) * plane));
     const int oy = (int)fast_quot((uint32_t)g, by_wq), ox0 = 4 * (g - oy * wq);
     const float ny = (float)oy - a.pad_y;
     const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
-    f32x4 o[3];
+    float o[3][4];
     if constexpr ((FMT == KH_FMT_NV12 && (SAMPLER == kSampleBilinearOnGrid || SAMPLER == KH_SAMPLE_BILINEAR)) ||
                   (FMT == KH_FMT_YUYV && SAMPLER == kSampleBilinearOnGrid)) {
         if (a.quad_wide) {   // uniform
@@ -562,8 +583,7 @@ __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uin
                 o[2][j] = (div255_any(px[j][2]) - a.m2) * a.is2;
             }
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[c]), rdst, 16 * g + c * (4 * plane), 0, kAuxStream);
+            for (int c = 0; c < 3; ++c) store_quad<OutT>(rdst, g, c, plane, o[c], a.f16_plain);
             return;
         }
     }
@@ -585,8 +605,7 @@ __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uin
         o[2][j] = (div255_any(px[2]) - a.m2) * a.is2;
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c)  // plane offset in the vector offset, never in an SGPR soffset (kh_common.h)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[c]), rdst, 16 * g + c * (4 * plane), 0, kAuxStream);
+    for (int c = 0; c < 3; ++c) store_quad<OutT>(rdst, g, c, plane, o[c], a.f16_plain);  // plane offset in the vector offset, never in an SGPR soffset (kh_common.h)
 }
 
 // ---- north-star fast path ------------------------------------------------------------------
@@ -696,11 +715,6 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity_list(FrameL
 // is still 16 bytes (eight binary16 values; a wave writes 1 KiB contiguous per plane): the f32 kernel's store shape at half the output
 // bytes.  Same integer decode, same `(x / 255 - m) * is`, then the reference's f32 -> f16 rounding: 2.75 ms (profiles/r06ze_f16_identity.txt;
 // 64-bit source loads instead of pairs of dwords: 2.73, not taken).
-__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {   // two round-to-nearest-even conversions, one dword
-    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-    const h2_t v = {(_Float16)lo, (_Float16)hi};
-    return __builtin_bit_cast(uint32_t, v);
-}
 __device__ __forceinline__ void nv12_identity_f16_body(const uint8_t* __restrict__ src_frame, unsigned short* __restrict__ dst_frame, const PreArgs& a) {
     const int wo = a.src_w >> 3;     // 8-pixel groups per row
     const int groups = wo * a.src_h;
@@ -879,17 +893,25 @@ struct Frames {
     }
 };
 
-bool identity_fast_path(const kh_preprocess_params* p, const Frames& f, const void* dst) {
-    const bool f16 = p->out_dtype == KH_OUT_F16;   // eight pixels per thread, eight halves per 16-byte store
-    // The f16 kernel converts with the plain round-to-nearest-even instruction.  The reference's f2h differs from it only at |v| >= 2^16
-    // (NaN patterns instead of Inf, see f2h_bits), and v = (q - m) * is with q in [0, 1] is monotone in q (subtraction and multiplication
-    // by a constant round monotonically), so its largest magnitude is at q = 0 or q = 1: both below 2^16 for every channel, or the
-    // generic kernel with the full f2h_bits takes the launch.  (False for NaN / Inf parameters.)
-    if (f16)
-        for (int c = 0; c < 3; ++c) {
-            const float v0 = (0.0f - p->mean[c]) * p->inv_std[c], v1 = (1.0f - p->mean[c]) * p->inv_std[c];
-            if (!(fabsf(v0) < 65536.0f && fabsf(v1) < 65536.0f)) return false;
+// The f16 fast paths convert with the plain round-to-nearest-even instruction.  The reference's f2h differs from it only at |v| >= 2^16
+// (NaN patterns instead of Inf, see f2h_bits), and v = (q - m) * is is monotone in q (subtraction and multiplication by a constant round
+// monotonically), so its largest magnitude is at the ends of q's range: q = x / 255 of a decoded or bilinearly blended sample lies in
+// [0, 1] up to the blend's rounding (evaluated here at -0.01 and 1.01), and the padding value contributes pad_value / 255.  All below
+// 2^16 for every channel, or the full f2h_bits runs.  (False for NaN / Inf parameters.  Not for Lanczos, whose samples overshoot.)
+bool f16_in_range(const kh_preprocess_params* p) {
+    for (int c = 0; c < 3; ++c) {
+        const float qs[3] = {-0.01f, 1.01f, p->pad_value / 255.0f};
+        for (float q : qs) {
+            const float v = (q - p->mean[c]) * p->inv_std[c];
+            if (!(fabsf(v) < 65536.0f)) return false;
         }
+    }
+    return true;
+}
+
+bool identity_fast_path(const kh_preprocess_params* p, const Frames& f, const void* dst) {
+    const bool f16 = p->out_dtype == KH_OUT_F16;   // eight pixels per thread, eight halves per 16-byte store; plain conversions
+    if (f16 && !f16_in_range(p)) return false;
     return !(p->flags & KH_PRE_FORCE_GENERIC) && p->fmt == KH_FMT_NV12 &&
            (p->out_dtype == KH_OUT_F32 || f16) &&
            (p->sampling == KH_SAMPLE_BILINEAR || p->sampling == KH_SAMPLE_NEAREST) &&
@@ -961,8 +983,8 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
     // four taps with per-tap loads, 3 = no wide loads.
     if constexpr (SAMPLER != KH_SAMPLE_LANCZOS) {
         const int opt = dev_opt(kOptPreQuads);
-        const bool quads_ok = out_dtype == KH_OUT_F32 && a.dst_w % 4 == 0 && (int64_t)a.dst_w * a.dst_h * 12 <= kI32Max &&
-                              reinterpret_cast<uintptr_t>(dst) % 16 == 0 && a.dst_frame_stride % 4 == 0;
+        const bool quads_ok = a.dst_w % 4 == 0 && (int64_t)a.dst_w * a.dst_h * 12 <= kI32Max &&
+                              reinterpret_cast<uintptr_t>(dst) % 16 == 0 && a.dst_frame_stride % 4 == 0;   // (f16 since round 6: 8-byte stores)
         const bool wide_nv12 = ((FMT == KH_FMT_NV12 && SAMPLER != KH_SAMPLE_NEAREST) || (FMT == KH_FMT_YUYV && SAMPLER == kSampleBilinearOnGrid && a.src_pitch >= 2 * a.src_w)) &&
                                opt != 3 && quads_ok && quad_taps_fit_16(a, SAMPLER == KH_SAMPLE_BILINEAR ? 1 : 0);
         if (quads_ok && opt != 0 && (SAMPLER != KH_SAMPLE_BILINEAR || opt == 1 || wide_nv12)) {
@@ -972,13 +994,16 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
             PreArgs aq = a;
             aq.quad_wide = wide_nv12 ? 1 : 0;   // test option pre_quads = 3: per-tap loads everywhere
             const NoFrames none{0};
-            if (f.listed()) {
-                if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true, true>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, fl);
-                else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false, true>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, fl);
-            } else {
-                if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true, false>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, none);
-                else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false, false>), qgrid, dim3(kQuadBlock), 0, s, src, (float*)dst, aq, by_wq, none);
-            }
+#define KH_QUADS(T) do { \
+            if (f.listed()) { \
+                if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true, true, T>), qgrid, dim3(kQuadBlock), 0, s, src, (T*)dst, aq, by_wq, fl); \
+                else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false, true, T>), qgrid, dim3(kQuadBlock), 0, s, src, (T*)dst, aq, by_wq, fl); \
+            } else { \
+                if (wide) hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, true, false, T>), qgrid, dim3(kQuadBlock), 0, s, src, (T*)dst, aq, by_wq, none); \
+                else hipLaunchKernelGGL((preprocess_generic_quads<FMT, SAMPLER, false, false, T>), qgrid, dim3(kQuadBlock), 0, s, src, (T*)dst, aq, by_wq, none); \
+            } } while (0)
+            if (out_dtype == KH_OUT_F32) KH_QUADS(float); else KH_QUADS(unsigned short);
+#undef KH_QUADS
             return;
         }
     }
@@ -1027,6 +1052,7 @@ int32_t preprocess_impl(kh_stream_t stream, const Frames& f, void* dst, const kh
     a.fast_div = plan_division_is_exact(a) ? 1 : 0;
     a.lz_wx = a.lz_wy = nullptr;
     a.quad_wide = 0;
+    a.f16_plain = p->out_dtype == KH_OUT_F16 && p->sampling != KH_SAMPLE_LANCZOS && f16_in_range(p) ? 1 : 0;
     hipStream_t s = as_hip(stream);
 
     const bool identity = identity_fast_path(p, f, dst);

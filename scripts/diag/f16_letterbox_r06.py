@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Round 6: NV12 / YUYV 1080p x 1024 -> letterbox 640 / 608 CHW into f32 and f16 planes (Preprocessor.run_raw_batch), HIP-event timed."""
+import sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT / "kornia-rs_amd")); sys.path.insert(0, str(ROOT))
+import torch  # noqa: F401
+from kornia_rs import Preprocessor, Tensor, hip
+from kornia_rs.hip import DeviceBuffer, lib, check
+import bench
+hip.set_device(0); st = hip.Stream.new(0)
+N, W, H = 1024, 1920, 1080
+for fmt in ("nv12", "yuyv"):
+    fb = W * H * 3 // 2 if fmt == "nv12" else W * H * 2
+    base = bench.lcg_bytes(fb + 31 * N)
+    dbase = DeviceBuffer.from_numpy(base, st)
+    src = DeviceBuffer(fb * N, st, zeroed=False)
+    for k in range(N):
+        check(lib.kh_memcpy_d2d_async(src.ptr + k * fb, dbase.ptr + 31 * k, fb, st.cuda_stream_ptr))
+    for out in (640, 608):
+        for f16 in (False, True):
+            dst = Tensor.uninit((N, 3, out, out), "float16" if f16 else "float32", st)
+            pre = Preprocessor(mode="letterbox", format=fmt, sampling="bilinear", f16=f16, mean=bench.IMAGENET_MEAN, std=bench.IMAGENET_STD, stream=st)
+            ts = []
+            for r in range(6):
+                pre.run_raw_batch(src, W, H, dst, frame_stride=fb); st.synchronize()
+                e0, e1 = hip.Event(), hip.Event(); e0.record(st)
+                for _ in range(5):
+                    pre.run_raw_batch(src, W, H, dst, frame_stride=fb)
+                e1.record(st); st.synchronize()
+                if r:
+                    ts.append(e0.elapsed_ms(e1) / 5)
+            print(f"{fmt} -> {out} f16={f16}: {np.median(ts):.3f} ms")
+            del dst
+    del src

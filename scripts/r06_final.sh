@@ -14,7 +14,7 @@ grep '^{' "$OUT/bench_raw.log" > "$OUT/bench.log"; python scripts/bench_table.py
 grep "^real" "$OUT/bench_raw.log" | tee -a "$OUT/bench_table.txt"
 cp gpurun_out/bench_full.json "$OUT/bench_full.json" 2>/dev/null
 echo "== opt-in workloads" | tee -a "$OUT/bench_table.txt"
-timeout 1200 python bench.py --workload fused_rgb_640 --no-cpu-baseline --also resize_normalize_f32_224,resize_u8_224,resize_norm_chw_224,pyrdown_u8_4k,pyrup_u8_4k,pyrdown_f32_4k,pyrup_f32_4k,dilate_u8_4k,nv12_chw_640_lanczos,spatial_gradient_1080p,box_blur_fast_1080p,bgr_u8_1080p 2>&1 | grep '^{' | tee -a "$OUT/bench.log" | python scripts/bench_table.py | tee -a "$OUT/bench_table.txt"
+timeout 1200 python bench.py --workload fused_rgb_640 --no-cpu-baseline --also resize_normalize_f32_224,resize_u8_224,resize_norm_chw_224,pyrdown_u8_4k,pyrup_u8_4k,pyrdown_f32_4k,pyrup_f32_4k,dilate_u8_4k,nv12_chw_640_lanczos,spatial_gradient_1080p,box_blur_fast_1080p,bgr_u8_1080p,nv12_chw_640_f16,nv12_chw_608_f16,yuyv_chw_640_f16 2>&1 | grep '^{' | tee -a "$OUT/bench.log" | python scripts/bench_table.py | tee -a "$OUT/bench_table.txt"
 cp gpurun_out/bench_full.json "$OUT/bench_full_optin.json" 2>/dev/null
 echo "== rocprofv3 kernel trace of the default run"
 cd /tmp

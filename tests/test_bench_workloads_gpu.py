@@ -110,6 +110,17 @@ def test_f16_twin_workload(gpu_stream, bench):
         assert np.array_equal(got[k], want.view(np.uint16)), k
 
 
+@pytest.mark.parametrize("name,size,fmt", [("nv12_chw_640_f16", 640, "nv12"), ("nv12_chw_608_f16", 608, "nv12"), ("yuyv_chw_640_f16", 640, "yuyv")])
+def test_f16_letterbox_workloads(gpu_stream, bench, name, size, fmt):
+    """The opt-in f16 letterbox rows: the oracle's binary16 bits on every frame; priced with two bytes per destination value."""
+    wl = _run(bench, name, gpu_stream)
+    assert wl.alg_bytes_per_launch == int(wl.N * (size * size * 6 + wl.active_px * wl.taps * wl.src_bytes_per_px))
+    got = wl.dst.numpy_raw().view(np.uint16).reshape(wl.N, 3, size, size)
+    for k in range(wl.N):
+        want = O.preprocess(wl.base[31 * k: 31 * k + wl.frame_bytes], wl.W, wl.H, size, size, fmt=fmt, mode="letterbox", f16=True, mean=MEAN, std=STD)[0]
+        assert np.array_equal(got[k], want.view(np.uint16)), (name, k)
+
+
 @pytest.mark.parametrize("how", ["eager", "graph", "list"])
 def test_resize_api_workloads(gpu_stream, bench, how):
     """configs[1] through imgproc.resize / hip.Graph / imgproc.resize_batch on separately allocated Images; ROTATE + 1 steps so that
@@ -282,7 +293,7 @@ def test_colour_map_workloads_1080p(gpu_stream, bench):
 
 
 def test_every_workload_is_covered(bench):
-    covered = {"nv12_h2d_preprocess", "nv12_h2d_preprocess_zero_copy", "nv12_chw_list", "nv12_chw_f16", "resize_224_api_eager", "resize_224_api_graph", "resize_224_api_list",
+    covered = {"nv12_h2d_preprocess", "nv12_h2d_preprocess_zero_copy", "nv12_chw_list", "nv12_chw_f16", "nv12_chw_640_f16", "nv12_chw_608_f16", "yuyv_chw_640_f16", "resize_224_api_eager", "resize_224_api_graph", "resize_224_api_list",
                "gaussian_4k_api_list", "undistort_warp_4k_api_list", "nv12_chw", "nv12_chw_640", "nv12_chw_608", "yuyv_chw_640", "nv12_chw_640_lanczos", "resize_224", "resize_bicubic_540", "resize_normalize_f32_224",
                "resize_u8_224", "resize_norm_chw_224", "fused_rgb_640", "gaussian_4k", "sobel_4k", "box_blur_4k", "gaussian_u8_4k", "pyrdown_u8_4k",
                "pyrup_u8_4k", "pyrdown_f32_4k", "pyrup_f32_4k", "dilate_u8_4k", "undistort_warp_4k", "warp_affine_f32_1080p", "normalize_1080p",

@@ -427,8 +427,10 @@ def test_staging_ring_overlaps_and_stays_ordered(gpu_stream):
 @pytest.mark.parametrize("fmt", ["nv12", "rgb", "bgra", "yuyv", "gray"])
 @pytest.mark.parametrize("sampling", ["bilinear", "nearest"])
 @pytest.mark.parametrize("quads", [-1, 0, 1])
-def test_flattened_quad_kernel_equals_the_per_pixel_kernel_and_the_oracle(gpu_stream, fmt, sampling, quads, dev_option):
-    """f32 outputs of the one-tap samplers (nearest, on-grid bilinear) whose rows are whole quads go through preprocess_generic_quads (a
+@pytest.mark.parametrize("f16", [False, True])
+def test_flattened_quad_kernel_equals_the_per_pixel_kernel_and_the_oracle(gpu_stream, fmt, sampling, quads, f16, dev_option):
+    """(f16 = True, round 6: the same kernel with one 8-byte store of four binary16 values per plane.)
+    f32 outputs of the one-tap samplers (nearest, on-grid bilinear) whose rows are whole quads go through preprocess_generic_quads (a
     lane owns one four-pixel quad of the flattened destination, 16-byte plane stores); the test option pre_quads = 0 keeps the
     per-pixel kernel everywhere, 1 takes the quad kernel for four-tap bilinear as well.  Geometries: the
     1080p letterboxes (on-grid 640, off-grid 608), a tail that does not fill the last block, quads that straddle the padding edge
@@ -441,15 +443,19 @@ def test_flattened_quad_kernel_equals_the_per_pixel_kernel_and_the_oracle(gpu_st
              ((46, 34), (31, 27), "stretch"), ((8, 6), (4, 1), "stretch")]
     for (w, h), (dw, dh), mode in cases:
         raw = _raw_for(fmt, w, h, seed=7)
-        kw = dict(fmt=fmt, mode=mode, sampling=sampling, **IMAGENET)
-        _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), O.preprocess(raw, w, h, dw, dh, **kw), f"{fmt} {sampling} {w}x{h}->{dw}x{dh} {mode} quads={quads}")
-    if fmt == "nv12":   # batched launch: frame k at its own source / destination stride
+        kw = dict(fmt=fmt, mode=mode, sampling=sampling, f16=f16, **IMAGENET)
+        _assert_bits_equal(_run(gpu_stream, raw, w, h, dw, dh, **kw), O.preprocess(raw, w, h, dw, dh, **kw), f"{fmt} {sampling} {w}x{h}->{dw}x{dh} {mode} quads={quads} f16={f16}")
+    if fmt == "nv12":   # batched launch: frame k at its own source / destination stride; and the same frames as a list
         w, h, dw, dh, n = 64, 34, 40, 24, 5
         fb = w * h * 3 // 2
         frames = np.stack([_raw_for(fmt, w, h, seed=k) for k in range(n)])
-        pre = _pre(gpu_stream, mode="letterbox", format="nv12", sampling=sampling, **IMAGENET)
-        dst = Tensor.uninit((n, 3, dh, dw), "float32", gpu_stream)
+        pre = _pre(gpu_stream, mode="letterbox", format="nv12", sampling=sampling, f16=f16, **IMAGENET)
+        dst = Tensor.uninit((n, 3, dh, dw), "float16" if f16 else "float32", gpu_stream)
         pre.run_raw_batch(DeviceBuffer.from_numpy(frames.reshape(-1), gpu_stream), w, h, dst, frame_stride=fb)
         got = dst.numpy_raw()
+        lst = Tensor.uninit((n, 3, dh, dw), "float16" if f16 else "float32", gpu_stream)
+        pre.run_raw_batch([DeviceBuffer.from_numpy(frames[k], gpu_stream) for k in range(n)], w, h, lst)
         for k in range(n):
-            _assert_bits_equal(got[k], O.preprocess(frames[k], w, h, dw, dh, fmt="nv12", mode="letterbox", sampling=sampling, **IMAGENET)[0], f"batch frame {k} quads={quads}")
+            want = O.preprocess(frames[k], w, h, dw, dh, fmt="nv12", mode="letterbox", sampling=sampling, f16=f16, **IMAGENET)[0]
+            _assert_bits_equal(got[k].view(np.uint16) if f16 else got[k], want.view(np.uint16) if f16 else want, f"batch frame {k} quads={quads} f16={f16}")
+            _assert_bits_equal(lst.numpy_raw()[k].view(np.uint16) if f16 else lst.numpy_raw()[k], want.view(np.uint16) if f16 else want, f"list frame {k} quads={quads} f16={f16}")
