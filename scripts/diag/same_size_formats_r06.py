@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Round 6: every source format of the fused preprocess at the north star's geometry (1080p x 512 -> CHW same size), f32 and f16 planes."""
+import sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT / "kornia-rs_amd")); sys.path.insert(0, str(ROOT))
+import torch  # noqa: F401
+from kornia_rs import Preprocessor, Tensor, hip
+from kornia_rs.hip import DeviceBuffer, lib, check
+import bench
+hip.set_device(0); st = hip.Stream.new(0)
+N, W, H = 512, 1920, 1080
+BPP = {"nv12": 1.5, "yuyv": 2, "rgb": 3, "bgra": 4, "gray": 1}
+for fmt in sys.argv[1:] or ["nv12", "yuyv", "rgb", "bgra", "gray"]:
+    fb = int(W * H * BPP[fmt])
+    base = bench.lcg_bytes(fb + 31 * N)
+    dbase = DeviceBuffer.from_numpy(base, st)
+    src = DeviceBuffer(fb * N, st, zeroed=False)
+    for k in range(N):
+        check(lib.kh_memcpy_d2d_async(src.ptr + k * fb, dbase.ptr + 31 * k, fb, st.cuda_stream_ptr))
+    for f16 in (False, True):
+        dst = Tensor.uninit((N, 3, H, W), "float16" if f16 else "float32", st)
+        pre = Preprocessor(mode="stretch", format=fmt, sampling="bilinear", f16=f16, mean=bench.IMAGENET_MEAN, std=bench.IMAGENET_STD, stream=st)
+        def run():
+            if fmt in ("nv12", "yuyv", "gray"):
+                pre.run_raw_batch(src, W, H, dst, frame_stride=fb)
+            else:
+                pre.run_surface_batch(src, W, H, W * int(BPP[fmt]), int(BPP[fmt]), dst, frame_stride=fb) if hasattr(pre, "run_surface_batch") else pre.run_raw_batch(src, W, H, dst, frame_stride=fb)
+        ts = []
+        for r in range(5):
+            run(); st.synchronize()
+            e0, e1 = hip.Event(), hip.Event(); e0.record(st)
+            for _ in range(5):
+                run()
+            e1.record(st); st.synchronize()
+            if r:
+                ts.append(e0.elapsed_ms(e1) / 5)
+        nbytes = N * (fb + W * H * 3 * (2 if f16 else 4))
+        print(f"{fmt:5s} f16={f16}: {np.median(ts):.3f} ms  frac {nbytes / np.median(ts) / 1e6 / 8000:.3f}")
+        del dst
+    del src

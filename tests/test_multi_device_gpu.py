@@ -153,9 +153,11 @@ def test_shard_pool_close_releases_every_worker(two_devices):
     sp = ShardedImgproc([0, 1, 1])
     imgs = [O.pattern_f32(40 * 30 * 3 + 31 * k)[31 * k:].reshape(30, 40, 3).copy() for k in range(5)]
     held = []
+    together = threading.Barrier(3)   # the pool starts its threads on demand: without this a quick first task lets its worker take a second one
 
     def touch(g):   # every worker copies through its own bounce buffer
         from kornia_rs.hip import DeviceBuffer
+        together.wait(timeout=60.0)
         raw = imgs[g].reshape(-1).view(np.uint8)
         b = DeviceBuffer.from_numpy(raw, sp.streams[g])
         assert np.array_equal(b.to_numpy(np.uint8, raw.shape), raw)
