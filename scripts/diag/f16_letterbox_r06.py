@@ -11,8 +11,9 @@ from kornia_rs.hip import DeviceBuffer, lib, check
 import bench
 hip.set_device(0); st = hip.Stream.new(0)
 N, W, H = 1024, 1920, 1080
-for fmt in ("nv12", "yuyv"):
-    fb = W * H * 3 // 2 if fmt == "nv12" else W * H * 2
+BPP = {"nv12": 1.5, "yuyv": 2, "rgb": 3, "bgra": 4, "gray": 1}
+for fmt in sys.argv[1:] or ["nv12", "yuyv"]:
+    fb = int(W * H * BPP[fmt])
     base = bench.lcg_bytes(fb + 31 * N)
     dbase = DeviceBuffer.from_numpy(base, st)
     src = DeviceBuffer(fb * N, st, zeroed=False)
