@@ -54,13 +54,15 @@ struct Rz {
     uint8_t* __restrict__ dst = a.dst + (long long)bz_ * a.ds;
 
 // ---- exact-2x RGB -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBx* kBy) void pyrdown2x_rgb_kernel(Rz a) {
-    KH_RZ_PROLOGUE
+// Every simple path below computes ONE destination pixel as a packed word (channel c = bits [8c, 8c + 8)); the scalar kernel stores its
+// C bytes, the quad kernel (round 6) four consecutive pixels of a row as C dwords.
+__device__ __forceinline__ uint32_t px_down2(const Rz& a, const uint8_t* __restrict__ src, int x, int y) {
     const uint8_t* r0 = src + ((long long)(2 * y) * a.sw + 2 * x) * 3;
     const uint8_t* r1 = r0 + (long long)a.sw * 3;
-    uint8_t* o = dst + ((long long)y * a.dw + x) * 3;
+    uint32_t v = 0;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) o[ch] = (uint8_t)(((uint32_t)r0[ch] + r0[3 + ch] + r1[ch] + r1[3 + ch] + 2u) >> 2);
+    for (int ch = 0; ch < 3; ++ch) v |= ((((uint32_t)r0[ch] + r0[3 + ch] + r1[ch] + r1[3 + ch] + 2u) >> 2) & 0xffu) << (8 * ch);
+    return v;
 }
 
 __device__ __forceinline__ uint32_t rh(uint32_t p, uint32_t q) { return (p + q + 1u) >> 1; }
@@ -72,10 +74,9 @@ __device__ __forceinline__ uint32_t hval(const uint8_t* row, int sw, int X, int 
     const uint32_t p = row[j * 3 + ch], q = row[(j + 1) * 3 + ch], avg = rh(p, q);
     return (X & 1) ? rh(p, avg) : rh(q, avg);
 }
-__global__ __launch_bounds__(kBx* kBy) void pyrup2x_rgb_kernel(Rz a) {
-    KH_RZ_PROLOGUE
-    uint8_t* o = dst + ((long long)y * a.dw + x) * 3;
+__device__ __forceinline__ uint32_t px_up2(const Rz& a, const uint8_t* __restrict__ src, int x, int y) {
     const long long stride = (long long)a.sw * 3;
+    uint32_t out = 0;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         uint32_t v;
@@ -86,8 +87,9 @@ __global__ __launch_bounds__(kBx* kBy) void pyrup2x_rgb_kernel(Rz a) {
             const uint32_t ha = hval(src + i * stride, a.sw, x, ch), hb = hval(src + (i + 1) * stride, a.sw, x, ch);
             v = (y & 1) ? rh(ha, rh(ha, hb)) : rh(hb, rh(hb, ha));  // blend_75_25_row
         }
-        o[ch] = (uint8_t)v;
+        out |= (v & 0xffu) << (8 * ch);
     }
+    return out;
 }
 
 // ---- nearest / bilinear -------------------------------------------------------------------------------
@@ -106,34 +108,80 @@ __device__ __forceinline__ void bilinear_tap(int i, double scale, int src_len, i
     ofs = (int)i0;
     fq = q > 16384u ? 16384u : q;
 }
-
 template <int C>
-__global__ __launch_bounds__(kBx* kBy) void nearest_u8_kernel(Rz a) {
-    KH_RZ_PROLOGUE
-    const int sx = nearest_index(x, a.scale_x, a.sw), sy = nearest_index(y, a.scale_y, a.sh);
-    const uint8_t* p = src + ((long long)sy * a.sw + sx) * C;
-    uint8_t* o = dst + ((long long)y * a.dw + x) * C;
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) o[ch] = p[ch];
+__device__ __forceinline__ uint32_t px_nearest(const Rz& a, const uint8_t* __restrict__ src, int x, int sy) {
+    const int sx = nearest_index(x, a.scale_x, a.sw);
+    return load_px_u8<C>(src + ((long long)sy * a.sw + sx) * C);
 }
-
 template <int C>
-__global__ __launch_bounds__(kBx* kBy) void bilinear_u8_kernel(Rz a) {
-    KH_RZ_PROLOGUE
-    int xi, yi;
-    uint32_t fx, fy;
+__device__ __forceinline__ uint32_t px_bilinear(const Rz& a, const uint8_t* __restrict__ src, int x, int yi, uint32_t fy) {
+    int xi;
+    uint32_t fx;
     bilinear_tap(x, a.scale_x, a.sw, xi, fx);
-    bilinear_tap(y, a.scale_y, a.sh, yi, fy);
     const uint64_t fx1 = 16384u - fx, fy1 = 16384u - fy;
     // xi <= sw - 2, yi <= sh - 2: both neighbours exist
     const QuadU8 q = load_quad_u8<C>(src + (unsigned)(yi * a.sw) * C, src + (unsigned)((yi + 1) * a.sw) * C, xi, a.sw);
-    uint8_t* o = dst + ((long long)y * a.dw + x) * C;
+    uint32_t out = 0;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) {  // bilinear_row_u8_scalar, kernels.rs:1141-1165 (u64 accumulate)
         const uint64_t top = (uint64_t)chan_u8(q.p00, ch) * fx1 + (uint64_t)chan_u8(q.p01, ch) * fx;
         const uint64_t bot = (uint64_t)chan_u8(q.p10, ch) * fx1 + (uint64_t)chan_u8(q.p11, ch) * fx;
-        o[ch] = (uint8_t)((top * fy1 + bot * fy + (1ull << 27)) >> 28);
+        out |= ((uint32_t)((top * fy1 + bot * fy + (1ull << 27)) >> 28) & 0xffu) << (8 * ch);
     }
+    return out;
+}
+// OP: 0 nearest, 1 Q14 bilinear, 2 exact-2x RGB box, 3 exact-2x RGB upscale (75 / 25)
+enum { kRzNearest = 0, kRzBilinear = 1, kRzDown2 = 2, kRzUp2 = 3 };
+template <int OP>
+__device__ __forceinline__ void px_row_setup(const Rz& a, int y, int& yi, uint32_t& fy) {
+    yi = y; fy = 0;
+    if constexpr (OP == kRzNearest) yi = nearest_index(y, a.scale_y, a.sh);
+    else if constexpr (OP == kRzBilinear) bilinear_tap(y, a.scale_y, a.sh, yi, fy);
+}
+template <int C, int OP>
+__device__ __forceinline__ uint32_t px_any(const Rz& a, const uint8_t* __restrict__ src, int x, int y, int yi, uint32_t fy) {
+    if constexpr (OP == kRzNearest) return px_nearest<C>(a, src, x, yi);
+    else if constexpr (OP == kRzBilinear) return px_bilinear<C>(a, src, x, yi, fy);
+    else if constexpr (OP == kRzDown2) return px_down2(a, src, x, y);
+    else return px_up2(a, src, x, y);
+}
+template <int C, int OP>
+__global__ __launch_bounds__(kBx* kBy) void resize_u8_px_kernel(Rz a) {
+    KH_RZ_PROLOGUE
+    int yi;
+    uint32_t fy;
+    px_row_setup<OP>(a, y, yi, fy);
+    const uint32_t v = px_any<C, OP>(a, src, x, y, yi, fy);
+    uint8_t* o = dst + ((long long)y * a.dw + x) * C;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) o[ch] = (uint8_t)(v >> (8 * ch));
+}
+// Four consecutive destination pixels of a row per lane, written as C dwords through the streaming store path (round 6): the byte
+// stores of the kernel above — three per pixel for RGB — cost far more than the arithmetic on the large outputs (1080p -> 720p, 2x
+// downscales, upscales: 2.5-5x the time of a copy of the same bytes, profiles/r06zg_resize_u8_modes.txt).  dw % 4 == 0 and 4-byte
+// aligned destination images (host-checked); a wave is one row of the 256 x 4 tile.
+template <int C, int OP>
+__global__ __launch_bounds__(kBx* kBy) void resize_u8_quads_kernel(Rz a) {
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int x0 = (bx_ * kBx + threadIdx.x) * 4;
+    const int y = by_ * kBy + __builtin_amdgcn_readfirstlane(threadIdx.y);
+    if (y >= a.dh) return;   // wave-uniform
+    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
+    const __amdgpu_buffer_rsrc_t ow = stream_window(a.dst + (long long)bz_ * a.ds + (long long)y * a.dw * C, (long long)a.dw * C);
+    if (x0 >= a.dw) return;
+    int yi;
+    uint32_t fy;
+    px_row_setup<OP>(a, y, yi, fy);
+    uint32_t p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = px_any<C, OP>(a, src, x0 + j, y, yi, fy);
+    uint32_t w[C];
+    if constexpr (C == 1) w[0] = p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24);
+    else if constexpr (C == 2) { w[0] = p[0] | (p[1] << 16); w[1] = p[2] | (p[3] << 16); }
+    else if constexpr (C == 3) { w[0] = p[0] | (p[1] << 24); w[1] = (p[1] >> 8) | (p[2] << 16); w[2] = (p[2] >> 16) | (p[3] << 8); }
+    else { w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3]; }
+    stream_store<C>(ow, x0 * C, w);
 }
 
 // ---- separable Q14 ------------------------------------------------------------------------------------
@@ -782,14 +830,26 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     Rz a = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, dw, dh);
     KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
     const dim3 blk(kBx, kBy);
+    // the simple paths: four pixels per lane with dword stores where the destination rows are whole quads on 4-byte-aligned images
+    // (test option resize_u8_px = 1: one pixel per thread, byte stores)
+    // Q14 bilinear only up to a 2x horizontal downscale: beyond it a lane's four tap pairs — and the 64 lanes of a load — spread over so
+    // many lines that the one-pixel mapping (adjacent lanes = adjacent taps) wins again (1080p -> 640 x 360: 0.257 vs 0.321 ms per 256
+    // images; -> 1280 x 720: 0.896 vs 0.714; profiles/r06zg_resize_u8_quads.txt).  resize_u8_px = 4: quads wherever they are possible.
+    const int px_opt = dev_opt(kOptResizeU8Px);
+    const bool quads = dw % 4 == 0 && px_opt != 1 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || dst_stride % 4 == 0) &&
+                       (int64_t)dw * channels <= kI32Max && (px_opt == 4 || down2 || up2 || mode == KH_INTERP_NEAREST || sw <= 2 * dw);
+    if (quads) a.tiles = xcd_tiles(cdiv(dw, kBx * 4), cdiv(dh, kBy), (unsigned)batch, cdiv(dw, kBx * 4) * 8);
+#define KH_RZ_OP(CC, OP) do { if (quads) hipLaunchKernelGGL((resize_u8_quads_kernel<CC, OP>), xcd_grid(a.tiles), blk, 0, st, a); \
+                              else hipLaunchKernelGGL((resize_u8_px_kernel<CC, OP>), xcd_grid(a.tiles), blk, 0, st, a); } while (0)
+#define KH_RZ_OP_C(OP) do { switch (channels) { case 1: KH_RZ_OP(1, OP); break; case 2: KH_RZ_OP(2, OP); break; case 3: KH_RZ_OP(3, OP); break; default: KH_RZ_OP(4, OP); break; } } while (0)
     if (down2) {
-        hipLaunchKernelGGL(pyrdown2x_rgb_kernel, xcd_grid(a.tiles), blk, 0, st, a);
+        KH_RZ_OP(3, kRzDown2);
     } else if (up2) {
-        hipLaunchKernelGGL(pyrup2x_rgb_kernel, xcd_grid(a.tiles), blk, 0, st, a);
+        KH_RZ_OP(3, kRzUp2);
     } else if (mode == KH_INTERP_NEAREST) {
-        KH_RZ_LAUNCH_C(nearest_u8_kernel, channels, a, st);
+        KH_RZ_OP_C(kRzNearest);
     } else if (mode == KH_INTERP_BILINEAR) {
-        KH_RZ_LAUNCH_C(bilinear_u8_kernel, channels, a, st);
+        KH_RZ_OP_C(kRzBilinear);
     } else {
         const int filt = mode == KH_INTERP_BICUBIC ? 0 : 1;
         SepTab tx, ty;

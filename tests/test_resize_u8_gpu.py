@@ -55,6 +55,35 @@ def test_bilinear_q14(gpu_stream, c):  # cuda.rs:405-418
         assert check(gpu_stream, s, d, c, "bilinear") == "bilinear"
 
 
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+def test_simple_paths_four_pixels_per_lane(gpu_stream, dev_option, c, mode):
+    """nearest / Q14 bilinear / the exact-2x RGB paths write four consecutive pixels of a row per lane as dwords where the destination rows
+    are whole quads on 4-byte-aligned images (round 6); test option resize_u8_px = 1 keeps one pixel per thread with byte stores.  Same
+    bytes as the oracle: down- and upscales, exact 2x both ways, widths that leave partial 256-pixel tiles, a batch whose destination
+    stride is / is not a multiple of four (the latter keeps the byte-store kernel), a destination 2 bytes off alignment."""
+    from kornia_rs import _ffi
+    if mode == "bilinear" and c == 2:
+        pytest.skip("Q14 bilinear: 1, 3 or 4 channels")
+    shapes = [((129, 97), (64, 48)), ((63, 41), (128, 90)), ((130, 98), (260, 196)), ((264, 40), (132, 20)), ((1920, 24), (1280, 16)), ((50, 30), (300, 7)), ((40, 9), (4, 3))]
+    for s, d in shapes:
+        src = pat(s[0], s[1], c, seed=3)
+        want, _ = O.resize_fast_u8(src, d[0], d[1], mode, True)
+        for opt in (-1, 1, 4):   # the launcher's choice (quads for bilinear only up to a 2x downscale), one pixel per thread, quads wherever possible
+            dev_option("resize_u8_px", opt)
+            assert_same_bits(resize_gpu(gpu_stream, src, d[0], d[1], mode)[0], want, f"{s}->{d} c{c} {mode} option {opt}")
+    dev_option("resize_u8_px", -1)
+    n, (sw, sh), (dw, dh) = 3, (96, 40), (132, 27)   # dw * dh * c: a multiple of four only for some c -> both kernels across the parametrisation
+    srcs = np.stack([pat(sw, sh, c, seed=31 * k) for k in range(n)])
+    got = resize_gpu(gpu_stream, srcs, dw, dh, mode, batch=n)
+    for k in range(n):
+        assert_same_bits(got[k], O.resize_fast_u8(srcs[k], dw, dh, mode, True)[0], f"batch image {k} c{c} {mode}")
+    src = pat(sw, sh, c)
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, dh * dw * c + 8)
+    _ffi.check(_ffi.lib.kh_resize_fast_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 2, sw, sh, dw, dh, c, O.MODE[mode], 1, 1, 0, 0))
+    assert_same_bits(d_dst.to_numpy(np.uint8, (dh * dw * c + 8,))[2:2 + dh * dw * c].reshape(dh, dw, c), O.resize_fast_u8(src, dw, dh, mode, True)[0], "destination 2 bytes off")
+
+
 @pytest.mark.parametrize("mode", ["bicubic", "lanczos"])
 @pytest.mark.parametrize("aa", [True, False])
 def test_separable_q14(gpu_stream, mode, aa):  # cuda.rs:420-440
