@@ -145,6 +145,16 @@ __device__ __forceinline__ uint32_t px_any(const Rz& a, const uint8_t* __restric
     else if constexpr (OP == kRzDown2) return px_down2(a, src, x, y);
     else return px_up2(a, src, x, y);
 }
+// four packed pixels -> C dwords -> one streaming store at pixel x0 of the row window
+template <int C>
+__device__ __forceinline__ void store_quad_u8(__amdgpu_buffer_rsrc_t ow, int x0, const uint32_t (&p)[4]) {
+    uint32_t w[C];
+    if constexpr (C == 1) w[0] = p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24);
+    else if constexpr (C == 2) { w[0] = p[0] | (p[1] << 16); w[1] = p[2] | (p[3] << 16); }
+    else if constexpr (C == 3) { w[0] = p[0] | (p[1] << 24); w[1] = (p[1] >> 8) | (p[2] << 16); w[2] = (p[2] >> 16) | (p[3] << 8); }
+    else { w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3]; }
+    stream_store<C>(ow, x0 * C, w);
+}
 template <int C, int OP>
 __global__ __launch_bounds__(kBx* kBy) void resize_u8_px_kernel(Rz a) {
     KH_RZ_PROLOGUE
@@ -176,12 +186,7 @@ __global__ __launch_bounds__(kBx* kBy) void resize_u8_quads_kernel(Rz a) {
     uint32_t p[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = px_any<C, OP>(a, src, x0 + j, y, yi, fy);
-    uint32_t w[C];
-    if constexpr (C == 1) w[0] = p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24);
-    else if constexpr (C == 2) { w[0] = p[0] | (p[1] << 16); w[1] = p[2] | (p[3] << 16); }
-    else if constexpr (C == 3) { w[0] = p[0] | (p[1] << 24); w[1] = (p[1] >> 8) | (p[2] << 16); w[2] = (p[2] >> 16) | (p[3] << 8); }
-    else { w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3]; }
-    stream_store<C>(ow, x0 * C, w);
+    store_quad_u8<C>(ow, x0, p);
 }
 
 // ---- separable Q14 ------------------------------------------------------------------------------------
@@ -573,21 +578,52 @@ __global__ __launch_bounds__(kBx* kBy) void cv_nearest_kernel(Rz a) {
 }
 
 template <int C>
-__global__ __launch_bounds__(kBx* kBy) void cv_linear_u8_kernel(Rz a) {  // resize_linear_u8, :139-195
-    KH_RZ_PROLOGUE
-    const LinTap tx = linear_tap(x, a.scale_x, a.sw), ty = linear_tap(y, a.scale_y, a.sh);
+__device__ __forceinline__ uint32_t px_cv_linear_u8(const Rz& a, const uint8_t* __restrict__ src, int x, const LinTap& ty) {  // resize_linear_u8, :139-195
+    const LinTap tx = linear_tap(x, a.scale_x, a.sw);
     const int sy1 = min(ty.ofs + 1, a.sh - 1);
     // border columns (ofs == sw - 1) only use the first pixel
     const QuadU8 q = load_quad_u8<C>(src + (unsigned)(ty.ofs * a.sw) * C, src + (unsigned)(sy1 * a.sw) * C, tx.ofs, a.sw);
-    uint8_t* o = dst + ((long long)y * a.dw + x) * C;
+    uint32_t out = 0;
 #pragma unroll
     for (int k = 0; k < C; ++k) {
         const int32_t p00 = (int32_t)chan_u8(q.p00, k), p01 = (int32_t)chan_u8(q.p01, k), p10 = (int32_t)chan_u8(q.p10, k), p11 = (int32_t)chan_u8(q.p11, k);
         int32_t s0, s1;
         if (tx.border) { s0 = p00 << 11; s1 = p10 << 11; }
         else { s0 = p00 * tx.i0 + p01 * tx.i1; s1 = p10 * tx.i0 + p11 * tx.i1; }
-        o[k] = (uint8_t)((((ty.i0 * (s0 >> 4)) >> 16) + ((ty.i1 * (s1 >> 4)) >> 16) + 2) >> 2);
+        out |= ((uint32_t)((((ty.i0 * (s0 >> 4)) >> 16) + ((ty.i1 * (s1 >> 4)) >> 16) + 2) >> 2) & 0xffu) << (8 * k);
     }
+    return out;
+}
+template <int C>
+__global__ __launch_bounds__(kBx* kBy) void cv_linear_u8_kernel(Rz a) {
+    KH_RZ_PROLOGUE
+    const uint32_t v = px_cv_linear_u8<C>(a, src, x, linear_tap(y, a.scale_y, a.sh));
+    uint8_t* o = dst + ((long long)y * a.dw + x) * C;
+#pragma unroll
+    for (int k = 0; k < C; ++k) o[k] = (uint8_t)(v >> (8 * k));
+}
+// u8, four pixels per lane with dword stores (see resize_u8_quads_kernel); LINEAR = false: INTER_NEAREST
+template <int C, bool LINEAR>
+__global__ __launch_bounds__(kBx* kBy) void cv_u8_quads_kernel(Rz a) {
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int x0 = (bx_ * kBx + threadIdx.x) * 4;
+    const int y = by_ * kBy + __builtin_amdgcn_readfirstlane(threadIdx.y);
+    if (y >= a.dh) return;   // wave-uniform
+    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
+    const __amdgpu_buffer_rsrc_t ow = stream_window(a.dst + (long long)bz_ * a.ds + (long long)y * a.dw * C, (long long)a.dw * C);
+    if (x0 >= a.dw) return;
+    uint32_t p[4];
+    if constexpr (LINEAR) {
+        const LinTap ty = linear_tap(y, a.scale_y, a.sh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = px_cv_linear_u8<C>(a, src, x0 + j, ty);
+    } else {
+        const int sy = cv_nearest_index(y, a.scale_y, a.sh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = load_px_u8<C>(src + ((long long)sy * a.sw + cv_nearest_index(x0 + j, a.scale_x, a.sw)) * C);
+    }
+    store_quad_u8<C>(ow, x0, p);
 }
 
 template <int C>
@@ -933,6 +969,18 @@ static int32_t resize_opencv(const char* what, kh_stream_t stream, const void* s
     a.scale_x = 1.0 / ((double)dw / (double)sw);
     a.scale_y = 1.0 / ((double)dh / (double)sh);
     KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+    // u8: four pixels per lane with dword stores under the conditions of kh_resize_fast_u8's simple paths (linear up to a 2x downscale)
+    const int px_opt = dev_opt(kOptResizeU8Px);
+    if (elem == 1 && dw % 4 == 0 && px_opt != 1 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0) && (int64_t)dw * channels <= kI32Max &&
+        (px_opt == 4 || mode == KH_INTERP_NEAREST || sw <= 2 * dw)) {
+        a.tiles = xcd_tiles(cdiv(dw, kBx * 4), cdiv(dh, kBy), (unsigned)batch, cdiv(dw, kBx * 4) * 8);
+        const dim3 qblk(kBx, kBy), qgrid = xcd_grid(a.tiles);
+#define KH_CVQ(CC) do { if (mode == KH_INTERP_NEAREST) hipLaunchKernelGGL((cv_u8_quads_kernel<CC, false>), qgrid, qblk, 0, st, a); \
+                        else hipLaunchKernelGGL((cv_u8_quads_kernel<CC, true>), qgrid, qblk, 0, st, a); } while (0)
+        switch (channels) { case 1: KH_CVQ(1); break; case 2: KH_CVQ(2); break; case 3: KH_CVQ(3); break; default: KH_CVQ(4); break; }
+#undef KH_CVQ
+        return check_launch(what);
+    }
     const dim3 blk(kBx, kBy), grid = xcd_grid(a.tiles);
     if (mode == KH_INTERP_NEAREST) {
         if (elem == 1) {

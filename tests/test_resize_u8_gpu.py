@@ -153,13 +153,28 @@ def cv_gpu(gpu_stream, src, dw, dh, mode):
 
 
 @pytest.mark.parametrize("key", KEYS)
-def test_opencv_resize_golden_vectors(gpu_stream, key):
+def test_opencv_resize_golden_vectors(gpu_stream, key, dev_option):
     src, want, mode = load_case(key)
     src = np.ascontiguousarray(src.astype(src.dtype.newbyteorder("=")))
     got = cv_gpu(gpu_stream, src, want.shape[1], want.shape[0], mode)
     assert_same_bits(got, O.resize_opencv(src, want.shape[1], want.shape[0], mode), key)  # bit-exact vs oracle
     ok, d = corridor_ok(got, want, mode)                                                   # reference corridor vs cv2
     assert ok, f"{key}: max deviation {d}"
+    for opt in (1, 4):   # u8: one pixel per thread / four pixels per lane wherever the rows are whole quads (round 6) — the same bytes
+        dev_option("resize_u8_px", opt)
+        assert_same_bits(cv_gpu(gpu_stream, src, want.shape[1], want.shape[0], mode), got, f"{key} resize_u8_px = {opt}")
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+def test_opencv_resize_u8_four_pixels_per_lane(gpu_stream, dev_option, c, mode):
+    """kh_resize_opencv_u8 through the quad kernel (destination widths that are multiples of four) and the byte-store kernel: oracle's bytes."""
+    for (sw, sh), (dw, dh) in [((129, 97), (64, 48)), ((63, 41), (128, 90)), ((264, 40), (132, 20)), ((50, 30), (300, 7)), ((1920, 12), (1280, 8)), ((40, 9), (4, 3))]:
+        src = pat(sw, sh, c, seed=9)
+        want = O.resize_opencv(src, dw, dh, mode)
+        for opt in (-1, 1, 4):
+            dev_option("resize_u8_px", opt)
+            assert_same_bits(cv_gpu(gpu_stream, src, dw, dh, mode), want, f"cv u8 c{c} {mode} {sw}x{sh}->{dw}x{dh} option {opt}")
 
 
 def test_opencv_resize_unit_vectors_and_channels(gpu_stream):  # opencv_compat.rs:253-330
