@@ -243,6 +243,92 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
     }
 }
 
+// ---- rolling-column kernel for WIDE kernels, 17..31 taps (round 6) -------------------------------------------------------------------
+// The rolling kernels above stop at 15 taps (register ring, 32-float side buffers, 16-tap argument struct); everything wider took the
+// LDS-tile kernel, which is 12x (17 x 17) to 65x (31 x 31) slower per image (profiles/r06zh_blur_sizes.txt) — and a gaussian of sigma 3-5
+// is 19-31 taps.  The same walk with a K-deep ring, side buffers of up to 64 floats ((K / 2) * C <= 64: two halo loads per lane and
+// row) and 32-tap arguments.  Same products in the same order as sep_roll_kernel<K, false>.
+struct TapsW { float k[32]; };
+template <int K>
+__global__ __launch_bounds__(kBlock) void sep_roll_wide_kernel(FilterArgs a, TapsW kx, TapsW ky, PtrList lst) {
+    __shared__ float rowbuf[4][64 + 64 + 64 + 4];   // left halo | main | right halo | parking slot
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int H = K / 2;
+    const int halo = H * a.C;  // <= 64 (checked on the host)
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int gx0 = tx * kTF + wv * 64;
+    if (gx0 >= a.rowlen) return;
+    const int y0 = ty * a.th;
+    const float* __restrict__ src = list_src(lst, a.listed, a.src, a.src_stride, bz);
+    float* __restrict__ dst = list_dst(lst, a.listed, a.dst, a.dst_stride, bz);
+    float* buf = rowbuf[wv];
+    const int gx = gx0 + lane;
+    const bool gx_ok = gx < a.rowlen;
+    // halo elements e = lane and lane + 64 of the 2 * halo neighbours: [0, halo) the left ones, [halo, 2 halo) the right ones
+    int hcx[2], hslot[2];
+    bool h_ok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = lane + 64 * q;
+        const bool is_halo = e < 2 * halo;
+        const int hgx = e < halo ? gx0 - halo + e : gx0 + 64 + (e - halo);
+        h_ok[q] = is_halo && hgx >= 0 && hgx < a.rowlen;
+        hcx[q] = is_halo ? min(max(hgx, 0), a.rowlen - 1) : min(gx, a.rowlen - 1);
+        hslot[q] = is_halo ? (e < halo ? e : 64 + e) : 192 + (q << 1);   // non-halo lanes park their duplicate where nobody reads
+    }
+    const int nrows = min(a.th, a.rows - y0) + 2 * H;
+    const int cx_m = min(gx, a.rowlen - 1);
+    int pf_row = y0 - H;
+    float qm[K], qh[K][2];
+    auto prefetch = [&](float& m, float (&hv)[2]) {
+        const int base = min(max(pf_row, 0), a.rows - 1) * a.rowlen;  // 32-bit: host-checked
+        m = src[base + cx_m];
+        hv[0] = src[base + hcx[0]];
+        hv[1] = src[base + hcx[1]];
+        ++pf_row;
+    };
+#pragma unroll
+    for (int p = 0; p < K; ++p) prefetch(qm[p], qh[p]);
+    float ring[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) ring[i] = 0.0f;
+    const __amdgpu_buffer_rsrc_t ow = stream_window(dst + (long long)y0 * a.rowlen, (long long)(a.rows - y0) * a.rowlen * 4);
+    int out_off = (gx - 2 * H * a.rowlen) * 4;
+    const float* tap = buf + halo + lane - H * a.C;
+    for (int rb = 0; rb < nrows; rb += K) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            const int r = rb + p;
+            const int row = y0 - H + r;
+            const bool row_ok = row >= 0 && row < a.rows;  // wave-uniform
+            const float m = (row_ok && gx_ok) ? qm[p] : 0.0f;
+            const float hv0 = (row_ok && h_ok[0]) ? qh[p][0] : 0.0f, hv1 = (row_ok && h_ok[1]) ? qh[p][1] : 0.0f;
+            prefetch(qm[p], qh[p]);
+            buf[halo + lane] = m;
+            buf[hslot[0]] = hv0;
+            buf[hslot[1]] = hv1;
+            __builtin_amdgcn_wave_barrier();
+            float h1 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) h1 += tap[i * a.C] * kx.k[i];
+            __builtin_amdgcn_wave_barrier();  // every lane has read the row before it is overwritten
+            ring[p] = h1;
+            float o = 0.0f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) o += ring[(p + 1 + i) % K] * ky.k[i];   // oldest row first: ascending vertical taps
+            if (gx_ok && r >= 2 * H && r < nrows) { const uint32_t ow_bits = __float_as_uint(o); stream_store<1>(ow, out_off, &ow_bits); }
+            out_off += a.rowlen * 4;
+        }
+    }
+}
+template <int K>
+void launch_roll_wide(hipStream_t st, dim3 grid, const FilterArgs& a, const Taps& kx, const Taps& ky, const PtrList& lst) {
+    TapsW wx, wy;
+    for (int i = 0; i < 32; ++i) { wx.k[i] = i < kx.n ? kx.k[i] : 0.0f; wy.k[i] = i < ky.n ? ky.k[i] : 0.0f; }
+    hipLaunchKernelGGL((sep_roll_wide_kernel<K>), grid, dim3(kBlock), 0, st, a, wx, wy, lst);
+}
+
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr bool kFourColumnsDefault = true;   // sep_roll4_kernel where it applies: 2-7 % faster than one column per lane on C4, same box, interleaved (profiles/r03k, r03l); test option filter_four_columns = 0 turns it off
 
@@ -489,6 +575,33 @@ int32_t launch(kh_stream_t stream, const BatchRef& whole, int cols, int rows, in
         return check_launch(what);
     }
 
+    // 17..31 equal odd tap counts: the wide rolling kernel (side buffers of (K / 2) * C <= 64 floats)
+    if (!grad && kx.n == ky.n && (kx.n & 1) && kx.n >= 17 && kx.n <= 31 && (kx.n / 2) * C <= 64 && (int64_t)(kRollStripMax + 32) * a.rowlen * 4 <= kI32Max && !force_tile_kernel()) {
+        const unsigned tiles_x = cdiv(a.rowlen, kTF);
+        {
+            const long long cols_blocks = (long long)tiles_x * batch;
+            long long strips = (2048 + cols_blocks - 1) / cols_blocks;
+            const long long min_strips = cdiv(rows, kRollStripMax), max_strips = cdiv(rows, 4 * kx.n);   // strips of at least four kernel heights: the K - 1 warm-up rows
+            strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
+            if (strips < 1) strips = 1;
+            a.th = (int)cdiv(rows, strips);
+        }
+        a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch, kXcdEighth);
+        KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        const dim3 grid = xcd_grid(a.tiles);
+        hipStream_t st = as_hip(stream);
+        switch (kx.n) {
+            case 17: launch_roll_wide<17>(st, grid, a, kx, ky, lst); break;
+            case 19: launch_roll_wide<19>(st, grid, a, kx, ky, lst); break;
+            case 21: launch_roll_wide<21>(st, grid, a, kx, ky, lst); break;
+            case 23: launch_roll_wide<23>(st, grid, a, kx, ky, lst); break;
+            case 25: launch_roll_wide<25>(st, grid, a, kx, ky, lst); break;
+            case 27: launch_roll_wide<27>(st, grid, a, kx, ky, lst); break;
+            case 29: launch_roll_wide<29>(st, grid, a, kx, ky, lst); break;
+            default: launch_roll_wide<31>(st, grid, a, kx, ky, lst); break;
+        }
+        return check_launch(what);
+    }
     const int hmax = grad ? (kx.n > ky.n ? kx.n : ky.n) / 2 : 0;
     const int halo = (grad ? hmax : kx.n / 2) * C, vhalo = grad ? hmax : ky.n / 2;
     // Pick the tallest tile (fewest halo re-reads) that still lets two blocks share a CU's LDS.

@@ -156,6 +156,28 @@ def test_gradient_magnitude_wide_rows(gpu_stream, kernel_path, c, kind, n):
         assert_same_bits(got[k], O.gradient_magnitude(both[k], kind, n), f"{kernel_path} batch image {k}")
 
 
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("k", [17, 19, 21, 23, 25, 27, 29, 31])
+def test_wide_kernels_rolling_path(gpu_stream, dev_option, c, k):
+    """Gaussians of 17..31 taps (sigma 3-5) take the wide rolling kernel since round 6 (the LDS-tile kernel before: 12-65x slower per 4K
+    image): the oracle's bits on images shorter than the kernel, narrower than a wave, with partial tiles and several strips; the tile
+    kernel (forced) the same; a batch; box blur of the same size."""
+    sig = 0.3 * ((k - 1) * 0.5 - 1) + 0.8
+    for (w, h) in [(67, 43), (300, 130), (20, 9), (1030, 37), (64, 400)]:
+        src = img(w, h, c, seed=7)
+        want = O.gaussian_blur(src, (k, k), (sig, sig))
+        for opt in (-1, 1):
+            dev_option("filter_force_tile", opt)
+            assert_same_bits(run(gpu_stream, "kh_gaussian_blur_f32", src, k, k, sig, sig), want, f"gaussian {k}x{k} {w}x{h} c{c} force_tile={opt}")
+    dev_option("filter_force_tile", -1)
+    both = np.stack([img(131, 77, c, seed=s_) for s_ in range(2)])
+    got = run(gpu_stream, "kh_gaussian_blur_f32", both, k, k, sig, sig, batch=2)
+    for i in range(2):
+        assert_same_bits(got[i], O.gaussian_blur(both[i], (k, k), (sig, sig)), f"batch image {i} {k}x{k} c{c}")
+    src = img(150, 60, c)
+    assert_same_bits(run(gpu_stream, "kh_box_blur_f32", src, k, k), O.separable_filter(src, O.box_kernel_1d(k), O.box_kernel_1d(k)), f"box {k}x{k} c{c}")
+
+
 def test_filter_validation(gpu_stream):
     from kornia_rs import _ffi
     lib, s = _ffi.lib, gpu_stream.cuda_stream_ptr
