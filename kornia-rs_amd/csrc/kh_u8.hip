@@ -392,6 +392,88 @@ __global__ __launch_bounds__(kBlock) void blur_u8_pass_kernel(const uint8_t* __r
     dst[(long long)blockIdx.y * ds + i] = (uint8_t)o;
 }
 
+// The same pass with FOUR consecutive bytes of a row per thread (round 6; rows of a multiple of four bytes): the four source bytes of
+// tap t sit in ONE dword — at byte offset (t - half) * C from the thread's own (horizontal pass; unaligned dword loads) or in row
+// y + t - half at the thread's column (vertical pass) — so a tap costs one load and, with the taps of a pass summing to <= 256
+// (quantize_kernel_256), two 24-bit multiply-adds on byte pairs held in 16-bit lanes (SWAR, as blur_u8_roll_kernel's MODE 2) instead of
+// four byte loads and four multiply-adds; the result leaves as one dword.  Threads whose horizontal taps reach over a row end (the
+// replicated border) take the per-byte expression.  Gaussians of 17-31 taps: 12-19 ms -> 1.1-1.6 ms per 32 4K images
+// (profiles/r06zi_blur_u8_wide.txt).
+template <bool HORIZ, bool SWAR, int C>
+__global__ __launch_bounds__(kBlock) void blur_u8_pass4_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                               int cols, int rows, long long ss, long long ds, Taps64 k) {
+    const int rowlen = cols * C, nq = rowlen >> 2;
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (long long)rows * nq) return;
+    const int y = (int)(i / nq), f0 = 4 * (int)(i - (long long)y * nq);
+    const uint8_t* s = src + (long long)blockIdx.y * ss;
+    const int half = k.n / 2;
+    uint32_t out;
+    const bool interior = !HORIZ || (f0 >= half * C && f0 + 3 + half * C < rowlen);
+    if (interior) {
+        uint32_t a02 = 0, a13 = 0, acc[4] = {0, 0, 0, 0};
+        for (int t = 0; t < k.n; ++t) {
+            const long long off = HORIZ ? (long long)y * rowlen + f0 + (t - half) * C : (long long)min(max(y + t - half, 0), rows - 1) * rowlen + f0;
+            const uint32_t d = *reinterpret_cast<const u32u*>(s + off);
+            const uint32_t w = k.k[t];
+            if constexpr (SWAR) {
+                a02 += (d & 0x00ff00ffu) * w;
+                a13 += ((d >> 8) & 0x00ff00ffu) * w;
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[b] += ((d >> (8 * b)) & 0xffu) * w;
+            }
+        }
+        if constexpr (SWAR) out = (((a02 + 0x00800080u) >> 8) & 0x00ff00ffu) | ((a13 + 0x00800080u) & 0xff00ff00u);
+        else out = (((acc[0] + 128u) >> 8) & 0xffu) | ((((acc[1] + 128u) >> 8) & 0xffu) << 8) | ((((acc[2] + 128u) >> 8) & 0xffu) << 16) | ((((acc[3] + 128u) >> 8) & 0xffu) << 24);
+    } else {   // a horizontal window over the replicated border: blur_u8_pass_kernel's expression per byte
+        out = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int f = f0 + b, x = f / C, ch = f - x * C;
+            uint32_t acc = 0;
+            for (int t = 0; t < k.n; ++t) acc += (uint32_t)s[((long long)y * cols + min(max(x + t - half, 0), cols - 1)) * C + ch] * k.k[t];
+            out |= (((acc + 128u) >> 8) & 0xffu) << (8 * b);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(dst + (long long)blockIdx.y * ds + 4 * i) = out;
+}
+
+// The vertical pass with R consecutive rows per thread (a sliding window down one dword column): K + R - 1 row loads for R outputs
+// instead of K each — the per-row form above re-read every row K times through the L2.  Byte pairs in 16-bit lanes (tap sums <= 256).
+constexpr int kPassRows = 8;
+template <int C_UNUSED>
+__global__ __launch_bounds__(kBlock) void blur_u8_vpass_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                    int rowlen, int rows, long long ss, long long ds, Taps64 k) {
+    constexpr int R = kPassRows;
+    const int nq = rowlen >> 2;
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int bands = (rows + R - 1) / R;
+    if (i >= (long long)bands * nq) return;
+    const int yb = (int)(i / nq), f0 = 4 * (int)(i - (long long)yb * nq), y0 = yb * R;
+    const uint8_t* s = src + (long long)blockIdx.y * ss + f0;
+    const int half = k.n / 2;
+    uint32_t a02[R], a13[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { a02[r] = 0; a13[r] = 0; }
+    for (int j = 0; j < k.n + R - 1; ++j) {   // source row y0 - half + j feeds output row y0 + r with tap t = j - r
+        const uint32_t d = *reinterpret_cast<const u32u*>(s + (long long)min(max(y0 - half + j, 0), rows - 1) * rowlen);
+        const uint32_t e = d & 0x00ff00ffu, o = (d >> 8) & 0x00ff00ffu;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = j - r;
+            const uint32_t w = (t >= 0 && t < k.n) ? (uint32_t)k.k[t] : 0u;   // wave-uniform
+            a02[r] += e * w;
+            a13[r] += o * w;
+        }
+    }
+    uint8_t* d0 = dst + (long long)blockIdx.y * ds + f0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (y0 + r < rows)
+            *reinterpret_cast<uint32_t*>(d0 + (long long)(y0 + r) * rowlen) = (((a02[r] + 0x00800080u) >> 8) & 0x00ff00ffu) | ((a13[r] + 0x00800080u) & 0xff00ff00u);
+}
+
 template <int K, int C>
 void launch_blur_kc(hipStream_t st, bool binomial, const U8FilterArgs& a, const TapsQ& kx, const TapsQ& ky) {
     const dim3 grid = xcd_grid(a.tiles);
@@ -475,6 +557,26 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
     tx.n = nx; tyv.n = ny;
     for (int i = 0; i < nx; ++i) tx.k[i] = qx[i];
     for (int i = 0; i < ny; ++i) tyv.k[i] = qy[i];
+    unsigned sum_x = 0, sum_y = 0;
+    for (int i = 0; i < nx; ++i) sum_x += qx[i];
+    for (int i = 0; i < ny; ++i) sum_y += qy[i];
+    // four bytes per thread (test option u8_blur_swar = 0: multiply-adds per byte; 2: the one-byte-per-thread kernel)
+    const int swar_opt = dev_opt(kOptU8BlurSwar);
+    if (!binomial && rowlen % 4 == 0 && swar_opt != 2 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && reinterpret_cast<uintptr_t>(tmp) % 4 == 0 &&
+        (batch <= 1 || ds % 4 == 0) && img % 4 == 0) {
+        const dim3 g4(cdiv((int64_t)(img / 4), kBlock), (unsigned)batch);
+#define KH_P4(H, S, CC, SRC, DST, SS, DS, T) hipLaunchKernelGGL((blur_u8_pass4_kernel<H, S, CC>), g4, dim3(kBlock), 0, st, SRC, DST, cols, rows, (long long)(SS), (long long)(DS), T)
+#define KH_P4_C(H, S, SRC, DST, SS, DS, T) do { if (C == 1) KH_P4(H, S, 1, SRC, DST, SS, DS, T); else if (C == 3) KH_P4(H, S, 3, SRC, DST, SS, DS, T); else KH_P4(H, S, 4, SRC, DST, SS, DS, T); } while (0)
+        if (sum_x <= 256 && swar_opt != 0) KH_P4_C(true, true, src, tmp, ss, img, tx); else KH_P4_C(true, false, src, tmp, ss, img, tx);
+        if (sum_y <= 256 && swar_opt != 0 && swar_opt != 3) {   // R rows per thread (test option u8_blur_swar = 3: one row per thread)
+            const dim3 gv(cdiv((int64_t)cdiv(rows, kPassRows) * (rowlen / 4), kBlock), (unsigned)batch);
+            hipLaunchKernelGGL((blur_u8_vpass_rows_kernel<0>), gv, dim3(kBlock), 0, st, (const uint8_t*)tmp, dst, rowlen, rows, (long long)img, (long long)ds, tyv);
+        } else if (sum_y <= 256 && swar_opt != 0) KH_P4_C(false, true, (const uint8_t*)tmp, dst, img, ds, tyv);
+        else KH_P4_C(false, false, (const uint8_t*)tmp, dst, img, ds, tyv);
+#undef KH_P4_C
+#undef KH_P4
+        return check_launch(what);
+    }
     const dim3 grid(cdiv((int64_t)img, kBlock), (unsigned)batch);
     if (binomial) {
         hipLaunchKernelGGL((blur_u8_pass_kernel<true, true>), grid, dim3(kBlock), 0, st, src, tmp, cols, rows, C,

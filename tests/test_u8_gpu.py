@@ -54,6 +54,29 @@ def test_box_blur_u8_matches_oracle(gpu_stream, c, ksize):
     assert_same_bits(got, O.box_blur_u8(src, ksize), f"box_u8 {ksize} c{c}")
 
 
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("ksize,sigma", [((17, 17), (3.0, 3.0)), ((21, 21), (3.5, 3.5)), ((31, 31), (5.0, 5.0)), ((5, 21), (1.0, 4.0)), ((31, 5), (6.0, 1.0)), ((63, 63), (10.0, 10.0))])
+def test_blur_u8_wide_kernels_four_bytes_per_thread(gpu_stream, dev_option, c, ksize, sigma):
+    """Kernels beyond the rolling kernel's 15 taps: the two-pass fallback with four bytes per thread (one dword load per tap, byte pairs
+    in 16-bit lanes; round 6), its per-byte multiply-add form (u8_blur_swar = 0) and the one-byte-per-thread kernel (2) give the
+    oracle's bytes — images narrower than the kernel (every thread on the replicated border), rows that are / are not whole dwords, a
+    batch; the box blur of the same size (taps that do not sum to 256 exactly)."""
+    for w, h in [(83, 37), (300, 41), (12, 9), (128, 70), (5, 40)]:
+        src = hash_image(h, w, c)
+        want = O.gaussian_blur_u8(src, ksize, sigma)[0]
+        for opt in (-1, 0, 2, 3):   # 3: the vertical pass with one row per thread (the launcher's choice: eight)
+            dev_option("u8_blur_swar", opt)
+            assert_same_bits(blur_gpu(gpu_stream, "gaussian", src, ksize, sigma)[0], want, f"gaussian_u8 {ksize} c{c} {w}x{h} option {opt}")
+    dev_option("u8_blur_swar", -1)
+    both = np.stack([hash_image(33, 64, c), hash_image(33, 64, c)[::-1].copy()])
+    got = blur_gpu(gpu_stream, "gaussian", both, ksize, sigma, batch=2)
+    for k in range(2):
+        assert_same_bits(got[k], O.gaussian_blur_u8(both[k], ksize, sigma)[0], f"batch image {k}")
+    if ksize[0] <= 31:
+        src = hash_image(45, 132, c)
+        assert_same_bits(blur_gpu(gpu_stream, "box", src, ksize)[0], O.box_blur_u8(src, ksize), f"box_u8 {ksize} c{c}")
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (1, 5, 1), (5, 1, 1), (1, 1, 3), (2, 1, 3), (3, 2, 1), (4, 1, 1), (257, 3, 1),
                                    (1024, 2, 1), (1025, 2, 3), (342, 5, 3), (85, 400, 3), (64, 33, 4), (1, 700, 4)])
 def test_blur_u8_edge_shapes(gpu_stream, shape):
