@@ -230,8 +230,14 @@ __global__ __launch_bounds__(kBlock) void blur_u8_roll_kernel(U8FilterArgs a, Ta
 constexpr int kRgbWavePx = 256;                 // output pixels per wave (64 lanes x 4)
 constexpr int kRgbTilePx = 4 * kRgbWavePx;      // per 256-thread block
 
-template <int K>
+// per-byte rounding halving add of four packed bytes: (a + b + 1) >> 1 without leaving the byte
+__device__ __forceinline__ uint32_t rhadd4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }
+// BINOMIAL (round 6, K = 3): the reference's 3 x 3 [1 2 1] / 4 case — what a gaussian of 3 taps and sigma in [0.6, 1.2] is, the default
+// sigma included — as rounding halving adds on the planar dwords (rhadd(rhadd(l, c), rhadd(c, r)) per pass, four pixels per
+// instruction); it took the interleaved one-accumulator-per-byte kernel before and ran slower than the 5 x 5 gaussian.
+template <int K, bool BINOMIAL = false>
 __global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky) {   // K = 7: 131 -> 128 VGPRs keeps 4 waves per SIMD
+    static_assert(!BINOMIAL || K == 3, "the binomial is 3 x 3");
     constexpr int H = K / 2, G = (K + 3) / 4;   // taps are consumed four at a time
     static_assert(K >= 3 && K <= 9 && (K & 1), "3..9 taps: one neighbour quad on each side covers the window");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -308,6 +314,11 @@ __global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8F
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const uint32_t prev = from_lane_below(cur[c], halo[c]), next = from_lane_above(cur[c], halo[c]);
+                if constexpr (BINOMIAL) {
+                    const uint32_t lft = __builtin_amdgcn_alignbyte(cur[c], prev, 3u), rgt = __builtin_amdgcn_alignbyte(next, cur[c], 1u);   // pixels p - 1 .. p + 2, p + 1 .. p + 4
+                    ring[s][c][0] = rhadd4(rhadd4(lft, cur[c]), rhadd4(cur[c], rgt));
+                    continue;
+                }
                 const uint32_t str[4] = {prev, cur[c], next, next};   // bytes 0..11 = pixels p - 4 .. p + 7 of this channel (+ a don't-care dword)
                 uint32_t sum[4];
 #pragma unroll
@@ -329,6 +340,11 @@ __global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8F
             uint32_t pl[3];   // vertical pass, then one dword per channel again (pixel j = byte j)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
+                if constexpr (BINOMIAL) {   // rows oldest first: s + 1, s + 2, s (mod 3)
+                    const uint32_t r0 = ring[(s + 1) % K][c][0], r1 = ring[(s + 2) % K][c][0], r2 = ring[s][c][0];
+                    pl[c] = rhadd4(rhadd4(r0, r1), rhadd4(r1, r2));
+                    continue;
+                }
                 uint32_t oe = 0x00800080u, oo = 0x00800080u;
 #pragma unroll
                 for (int i = 0; i < K; ++i) {   // oldest row first
@@ -518,7 +534,7 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         unsigned sxq = 0, syq = 0;
         for (int i = 0; i < 16; ++i) { sxq += px.k[i]; syq += py.k[i]; }
         const bool rgb_off = dev_opt(kOptU8BlurRgb) == 0;   // test option: the interleaved kernel (what the other channel counts take)
-        const bool rgb = C == 3 && K <= 9 && !binomial && sxq <= 256 && syq <= 256 && cols >= 4 && !rgb_off;
+        const bool rgb = C == 3 && K <= 9 && (binomial ? K == 3 : (sxq <= 256 && syq <= 256)) && cols >= 4 && !rgb_off;
         const unsigned tiles_x = rgb ? cdiv(cols, kRgbTilePx) : cdiv(rowlen, kU8Tile);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;  // >= 8 blocks per CU
@@ -530,7 +546,9 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         if (rgb) {
             const dim3 grid = xcd_grid(a.tiles);
             switch (K) {
-                case 3: hipLaunchKernelGGL(blur_u8_rgb_kernel<3>, grid, dim3(kBlock), 0, st, a, px, py); break;
+                case 3: if (binomial) hipLaunchKernelGGL((blur_u8_rgb_kernel<3, true>), grid, dim3(kBlock), 0, st, a, px, py);
+                        else hipLaunchKernelGGL((blur_u8_rgb_kernel<3, false>), grid, dim3(kBlock), 0, st, a, px, py);
+                        break;
                 case 5: hipLaunchKernelGGL(blur_u8_rgb_kernel<5>, grid, dim3(kBlock), 0, st, a, px, py); break;
                 case 7: hipLaunchKernelGGL(blur_u8_rgb_kernel<7>, grid, dim3(kBlock), 0, st, a, px, py); break;
                 default: hipLaunchKernelGGL(blur_u8_rgb_kernel<9>, grid, dim3(kBlock), 0, st, a, px, py); break;

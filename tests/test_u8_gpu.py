@@ -103,6 +103,25 @@ def test_blur_u8_rgb_wave_and_block_seams(gpu_stream, k):
     assert_same_bits(blur_gpu(gpu_stream, "box", src, (k, k))[0], O.box_blur_u8(src, (k, k)), f"box {k}")
 
 
+def test_blur_u8_binomial_planar_kernel(gpu_stream, dev_option):
+    """The 3 x 3 binomial (a 3-tap gaussian with sigma in [0.6, 1.2], the default sigma included) on RGB: the planar kernel's rounding
+    halving adds on four pixels per dword (round 6) against the interleaved kernel (test option u8_blur_rgb = 0) and the oracle, on the
+    widths either side of every wave / block seam, rows fewer than taps, a batch; sigmas just outside the band stay Q8 gaussians."""
+    for w, h in [(4, 5), (5, 1), (6, 2), (7, 11), (253, 4), (256, 9), (257, 3), (260, 4), (511, 3), (1023, 2), (1024, 5), (1025, 3), (1029, 7), (2050, 2), (130, 300)]:
+        src = pat(w, h, 3, seed=w * 3 + h)
+        for sig in ((1.0, 1.0), (0.6, 1.2), (0.8, 0.8), (0.59, 1.0), (1.21, 1.21)):
+            want = O.gaussian_blur_u8(src, (3, 3), sig)[0]
+            for opt in (-1, 0):
+                dev_option("u8_blur_rgb", opt)
+                assert_same_bits(blur_gpu(gpu_stream, "gaussian", src, (3, 3), sig)[0], want, f"3x3 sigma {sig} {w}x{h} u8_blur_rgb={opt}")
+    dev_option("u8_blur_rgb", -1)
+    n = 3
+    src = np.stack([pat(1920, 270, 3, seed=31 * k) for k in range(n)])
+    got = blur_gpu(gpu_stream, "gaussian", src, (3, 3), (0.8, 0.8), batch=n)
+    for k in range(n):
+        assert_same_bits(got[k], O.gaussian_blur_u8(src[k], (3, 3), (0.8, 0.8))[0], f"frame {k}")
+
+
 def test_blur_u8_batch_4k_strip_and_errors(gpu_stream):
     from kornia_rs import _ffi
     n = 3
