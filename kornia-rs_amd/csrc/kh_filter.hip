@@ -42,6 +42,7 @@ struct FilterArgs {
     long long src_stride, dst_stride;
     XcdTiles tiles;  // (column tile, row strip, image), XCD-contiguous order
     int listed;      // image bases from the launch's PtrList (kh_common.h) instead of base + k * stride
+    int xlo, xhi, ylo, yhi;   // MASKED rolling launches (unequal tap counts): the real taps of each pass inside the K padded ones
 };
 
 extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -147,7 +148,11 @@ constexpr int kRollStripMax = 360;  // tallest strip (output rows)
 
 struct TapsK { float k[16]; };
 
-template <int K, bool GRAD>
+// MASKED (round 6): kx and ky of DIFFERENT lengths (gaussian (3, 7), a one-dimensional blur (9, 1), ...) centred in K = the longer one.
+// A padded tap must not see its pixel: 0 * Inf would put a NaN where the reference's shorter window never looks — so the value is
+// replaced by 0 outside the real taps [lo, hi) of the pass (a wave-uniform select per tap), and `acc + (+0)` leaves every accumulator
+// as it is (it starts at +0 and cannot become -0).  These launches took the LDS-tile kernel before, 8-10x slower per image.
+template <int K, bool GRAD, bool MASKED = false>
 __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx, TapsK ky, PtrList lst) {
     __shared__ float rowbuf[4][160];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -190,6 +195,11 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
 #pragma unroll
     for (int p = 0; p < K; ++p) prefetch(qm[p], qh[p]);
 
+    uint32_t xm[MASKED ? K : 1], ym[MASKED ? K : 1];   // MASKED: all ones for the real taps of a pass, zero for the padded ones (scalar registers)
+    if constexpr (MASKED) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { xm[i] = (i >= a.xlo && i < a.xhi) ? 0xffffffffu : 0u; ym[i] = (i >= a.ylo && i < a.yhi) ? 0xffffffffu : 0u; }
+    }
     float ring[K], ring2[GRAD ? K : 1];  // slot p holds the horizontal result of walk step == p (mod K)
 #pragma unroll
     for (int i = 0; i < K; ++i) { ring[i] = 0.0f; if constexpr (GRAD) ring2[i] = 0.0f; }
@@ -223,7 +233,8 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
             float h1 = 0.0f, h2 = 0.0f;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                const float v = tap[i * a.C];
+                float v = tap[i * a.C];
+                if constexpr (MASKED) v = __uint_as_float(__float_as_uint(v) & xm[i]);
                 h1 += v * kx.k[i];
                 if constexpr (GRAD) h2 += v * ky.k[i];
             }
@@ -233,7 +244,9 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
             float o = 0.0f, o2 = 0.0f;
 #pragma unroll
             for (int i = 0; i < K; ++i) {  // oldest row first: ascending vertical taps
-                o += ring[(p + 1 + i) % K] * ky.k[i];
+                float rv = ring[(p + 1 + i) % K];
+                if constexpr (MASKED) rv = __uint_as_float(__float_as_uint(rv) & ym[i]);
+                o += rv * ky.k[i];
                 if constexpr (GRAD) o2 += ring2[(p + 1 + i) % K] * kx.k[i];
             }
             if constexpr (GRAD) o = sqrtf(o * o + o2 * o2);
@@ -469,6 +482,10 @@ bool launch_roll4(hipStream_t st, dim3 grid, const FilterArgs& a, const TapsK& k
 }
 
 template <int K>
+void launch_roll_masked(hipStream_t st, dim3 grid, const FilterArgs& a, const TapsK& kx, const TapsK& ky, const PtrList& lst) {
+    hipLaunchKernelGGL((sep_roll_kernel<K, false, true>), grid, dim3(kBlock), 0, st, a, kx, ky, lst);
+}
+template <int K>
 void launch_roll(hipStream_t st, dim3 grid, bool grad, const FilterArgs& a, const TapsK& kx, const TapsK& ky, const PtrList& lst) {
     if (grad) hipLaunchKernelGGL((sep_roll_kernel<K, true>), grid, dim3(kBlock), 0, st, a, kx, ky, lst);
     else hipLaunchKernelGGL((sep_roll_kernel<K, false>), grid, dim3(kBlock), 0, st, a, kx, ky, lst);
@@ -514,6 +531,7 @@ int32_t launch(kh_stream_t stream, const BatchRef& whole, int cols, int rows, in
     a.src = static_cast<const float*>(b.src); a.dst = static_cast<float*>(b.dst); a.rows = rows; a.rowlen = cols * C; a.C = C;
     a.src_stride = b.ss; a.dst_stride = b.ds;
     a.listed = b.listed() ? 1 : 0;
+    a.xlo = a.xhi = a.ylo = a.yhi = 0;
 
     // Fast path: rolling-column kernel for odd kernels up to 15 taps whose horizontal halo fits
     // the 32-float side buffers; everything else takes the LDS-tile kernel below.
@@ -523,7 +541,8 @@ int32_t launch(kh_stream_t stream, const BatchRef& whole, int cols, int rows, in
     // smallest rolling instantiation, so a 1-tap pair goes to the tile kernel as well.
     const int kmax = kx.n > ky.n ? kx.n : ky.n;
     const bool strip_fits_32bit = (int64_t)(kRollStripMax + 16) * a.rowlen * 4 <= kI32Max;  // byte offsets inside a strip's output window
-    if (kx.n == ky.n && (kx.n & 1) && kmax >= 3 && kmax <= 15 && (kmax / 2) * C <= 32 && strip_fits_32bit && !force_tile_kernel()) {
+    const bool unequal_ok = !grad && kx.n != ky.n && (kx.n & 1) && (ky.n & 1);   // (round 6: the MASKED rolling kernel)
+    if ((kx.n == ky.n || unequal_ok) && (kx.n & 1) && kmax >= 3 && kmax <= 15 && (kmax / 2) * C <= 32 && strip_fits_32bit && !force_tile_kernel()) {
         const int K = kmax < 3 ? 3 : kmax;
         TapsK px, py;
         pad_taps(px, kx, K);
@@ -534,7 +553,8 @@ int32_t launch(kh_stream_t stream, const BatchRef& whole, int cols, int rows, in
         const int four_opt = dev_opt(kOptFilterFourColumns);
         const bool four_cols = four_opt < 0 ? kFourColumnsDefault : four_opt == 1;
         // (gradients: K = 3 and 5 only — sobel / scharr — since round 6)
-        const bool four = (!grad || K <= 5) && four_cols && K <= 9 && (C == 1 || C == 3 || C == 4) && (a.rowlen % 4 == 0) && a.rowlen >= kTF4 && all_16B;
+        a.xlo = (K - kx.n) / 2; a.xhi = a.xlo + kx.n; a.ylo = (K - ky.n) / 2; a.yhi = a.ylo + ky.n;
+        const bool four = !unequal_ok && (!grad || K <= 5) && four_cols && K <= 9 && (C == 1 || C == 3 || C == 4) && (a.rowlen % 4 == 0) && a.rowlen >= kTF4 && all_16B;
         const unsigned tiles_x = cdiv(a.rowlen, four ? kTF4 : kTF);  // 256-thread blocks: 512 measured +1 %, 1024 +9 % (r01q)
         // Strip height: tall strips amortise the ky-1 warm-up rows (4K x 256 images: 360 rows is
         // 5 % faster than 90), short strips keep a small launch wide enough to fill 256 CUs.
@@ -560,6 +580,18 @@ int32_t launch(kh_stream_t stream, const BatchRef& whole, int cols, int rows, in
                 case 5: launch_roll4<5>(st, grid, a, px, py, lst); break;
                 case 7: launch_roll4<7>(st, grid, a, px, py, lst); break;
                 default: launch_roll4<9>(st, grid, a, px, py, lst); break;
+            }
+            return check_launch(what);
+        }
+        if (unequal_ok) {
+            switch (K) {
+                case 3: launch_roll_masked<3>(st, grid, a, px, py, lst); break;
+                case 5: launch_roll_masked<5>(st, grid, a, px, py, lst); break;
+                case 7: launch_roll_masked<7>(st, grid, a, px, py, lst); break;
+                case 9: launch_roll_masked<9>(st, grid, a, px, py, lst); break;
+                case 11: launch_roll_masked<11>(st, grid, a, px, py, lst); break;
+                case 13: launch_roll_masked<13>(st, grid, a, px, py, lst); break;
+                default: launch_roll_masked<15>(st, grid, a, px, py, lst); break;
             }
             return check_launch(what);
         }

@@ -44,7 +44,8 @@ def test_gaussian_exact_reference_vectors(gpu_stream):
 
 @pytest.mark.parametrize("c", [1, 3, 4])
 @pytest.mark.parametrize("shape", [(67, 43), (300, 70), (1, 1), (5, 200), (257, 9)])
-@pytest.mark.parametrize("ks", [((3, 3), (0.8, 0.8)), ((7, 7), (1.5, 1.5)), ((5, 9), (1.0, 2.0)), ((13, 3), (2.5, 0.0))])
+@pytest.mark.parametrize("ks", [((3, 3), (0.8, 0.8)), ((7, 7), (1.5, 1.5)), ((5, 9), (1.0, 2.0)), ((13, 3), (2.5, 0.0)), ((1, 7), (0.0, 1.5)), ((9, 1), (2.0, 0.0)),
+                                ((3, 15), (0.8, 3.0))])
 def test_gaussian_matches_oracle(gpu_stream, c, shape, ks):
     (w, h), ((kx, ky), (sx, sy)) = shape, ks
     src = img(w, h, c)
@@ -52,7 +53,7 @@ def test_gaussian_matches_oracle(gpu_stream, c, shape, ks):
     assert_same_bits(got, O.gaussian_blur(src, (kx, ky), (sx, sy)), f"gaussian {shape} c{c} k{kx}x{ky}")
 
 
-@pytest.mark.parametrize("ks", [((3, 7), (0.8, 1.5)), ((9, 5), (2.0, 1.0)), ((7, 7), (1.5, 1.5)), ((5, 5), (1.0, 1.0))])
+@pytest.mark.parametrize("ks", [((3, 7), (0.8, 1.5)), ((9, 5), (2.0, 1.0)), ((7, 7), (1.5, 1.5)), ((5, 5), (1.0, 1.0)), ((1, 7), (0.0, 1.5)), ((15, 1), (3.0, 0.0)), ((3, 15), (0.8, 3.0))])
 def test_non_finite_pixels_poison_only_their_own_window(gpu_stream, ks):
     """An Inf / NaN pixel reaches exactly the outputs whose n-tap windows contain it — also when kx and ky differ in length
     (a kernel padded with zero taps would compute 0 * Inf = NaN outside the reference's window)."""
