@@ -148,6 +148,29 @@ def test_morphology_rgb_rolling_wave_boundaries(gpu_stream, k, border):
         assert_same_bits(got[i], O.morphology_u8(src[i], "erode", mask, border, cval), f"batch frame {i}")
 
 
+@pytest.mark.parametrize("border", ["constant", "replicate", "reflect101", "reflect"])
+@pytest.mark.parametrize("k", [9, 11, 13, 15, 21, 31])
+def test_morphology_rgb_large_boxes_as_a_chain(gpu_stream, dev_option, k, border):
+    """Square RGB boxes of 9 .. 31 run as a chain of rolling-kernel passes (boxes of 7 and one of 3 / 5 / 7 through one scratch image;
+    round 6): max / min compose exactly and every border mode commutes with the composition — the oracle's bytes on images smaller
+    than the mask, narrower than a wave, with per-channel border values that win (dilate, 251) or lose, and a batch; test option
+    morph_roll = 2 keeps the tile kernel."""
+    mask = O.morph_kernel("box", k, k)
+    cval = [9, 130, 251]
+    for (w, h) in [(4, 9), (7, 40), (40, 7), (131, 97), (260, 33), (1029, 12), (64, 200)]:
+        src = make(w, h, 3, np.uint8, seed=w + h + k)
+        for op in ("dilate", "erode"):
+            want = O.morphology_u8(src, op, mask, border, cval)
+            for opt in (-1, 2):
+                dev_option("morph_roll", opt)
+                assert_same_bits(morph_gpu(gpu_stream, src, op, mask, border, cval)[0], want, f"{op} box{k} {border} {w}x{h} morph_roll={opt}")
+    dev_option("morph_roll", -1)
+    src = np.stack([make(300, 75, 3, np.uint8, seed=s) for s in (4, 5, 6)])
+    got = morph_gpu(gpu_stream, src, "dilate", mask, border, cval, batch=3)
+    for i in range(3):
+        assert_same_bits(got[i], O.morphology_u8(src[i], "dilate", mask, border, cval), f"batch frame {i}")
+
+
 def test_morphology_both_kernels_agree(gpu_stream, tmp_path):
     """KH_MORPH_DIRECT=1 selects the per-pixel kernel (read once per process): a child process runs it on the same inputs and the
     bytes must equal this process's tiled result."""
