@@ -1130,6 +1130,112 @@ __global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_r
     }
 }
 
+// ---- box dilate / erode for single-channel u8, rolling wave (round 6) -------------------------------------------------------------------
+// Masks and gray images are what morphology mostly runs on, and they took the LDS-tile kernel at 0.23-0.31 of peak against 0.57-0.66 for
+// the planar RGB kernel above.  The same walk on one plane: a lane owns SIXTEEN pixels of a row (one 16-byte load and store, 1 KiB per
+// wave and row), its four dwords go through exactly the per-channel code of the RGB kernel — the twelve-byte string (previous dword |
+// this dword | next dword), byte pairs in 16-bit lanes, K + 1 packed max / min per dword, the pair-maxima column pass — with the dword
+// before the lane's first and after its last taken from the neighbouring lanes by wave shifts and, at the ends of the wave, from one
+// halo dword per half-wave.  Borders as in the RGB kernel: rows through map_index (constant: the whole row is the border value); the
+// three pixels beyond a row end that a 7-tap window can reach are re-indexed (or replaced by the border value) with one v_perm_b32
+// whose per-lane selector is computed once.  For square all-ones masks of 3 / 5 / 7, widths that are multiples of 16, every border mode
+// but wrap; byte-identical to the other kernels (max / min are exact and order-independent).
+constexpr int kMgWavePx = 1024, kMgTilePx = 4 * kMgWavePx;
+template <int K, bool DILATE>
+__global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_gray_roll_kernel(MorphRoll a) {
+    constexpr int H = K / 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int p0 = (int)tx * kMgTilePx + wv * kMgWavePx;    // first output pixel of this wave
+    if (p0 >= a.w) return;                                  // whole wave idle (no block barrier below)
+    const int y0 = ty * a.th;
+    const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
+    uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
+    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.w * a.h);   // (w * h < 2^31: host-checked)
+    const int p = p0 + 16 * lane;                           // this lane's sixteen pixels
+    const bool inside = p < a.w;                            // all sixteen or none (w % 16 == 0: host-checked)
+    const int ph = lane < 32 ? p0 - 4 : p0 + kMgWavePx;     // the wave's halo dwords: left in the lower half's lanes, right in the upper's
+    const bool edge = p0 < 4 || p0 + kMgWavePx + 4 > a.w;   // wave-uniform
+    const int pc = min(p, a.w - 16), phc = min(max(ph, 0), a.w - 4);
+    // a lane past the row end supplies the pixels its inside neighbour's window reaches: its first dword <- the row's last dword re-indexed
+    uint32_t esel = 0x03020100u, hsel = 0x03020100u;   // byte j: 0..3 = loaded pixel, 4 = the constant border value
+    if (edge) {
+        esel = hsel = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = map_index(a.border, p + j, a.w), mh = map_index(a.border, ph + j, a.w);
+            esel |= (uint32_t)(m < 0 ? 4 : min(max(m - (a.w - 4), 0), 3)) << (8 * j);
+            hsel |= (uint32_t)(mh < 0 ? 4 : min(max(mh - phc, 0), 3)) << (8 * j);
+        }
+    }
+    const int nrows = min(a.th, a.h - y0) + 2 * H;
+    int pf_row = y0 - H;
+    const uint32_t cv = a.cval[0] * 0x01010101u;
+
+    uint32_t q[K][5];   // the lane's sixteen pixels and its half-wave's halo dword
+    auto prefetch = [&](uint32_t (&d)[5]) {
+        const uint8_t* rp = src + (long long)max(map_index(a.border, pf_row, a.h), 0) * a.w;
+        const u32x4_t v = *reinterpret_cast<const u32x4_unaligned*>(rp + pc);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        d[4] = *reinterpret_cast<const u32_unaligned*>(rp + phc);
+        ++pf_row;
+    };
+#pragma unroll
+    for (int i = 0; i < K; ++i) prefetch(q[i]);
+
+    constexpr uint32_t kInit = DILATE ? 0u : 0x00ff00ffu;
+    uint32_t pr[K][4][2], last[4][2];   // pair maxima of consecutive rows, as in the RGB kernel
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        last[c][0] = kInit; last[c][1] = kInit;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { pr[i][c][0] = kInit; pr[i][c][1] = kInit; }
+    }
+
+    int out_off = (y0 - 2 * H) * a.w + p;
+    for (int rb = 0; rb < nrows; rb += K) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const int r = rb + s, row = y0 - H + r;
+            const bool row_out = a.border == KH_BORDER_CONSTANT && (row < 0 || row >= a.h);   // wave-uniform: the whole row is the border value
+            uint32_t cur[4] = {q[s][0], q[s][1], q[s][2], q[s][3]}, halo = q[s][4];
+            prefetch(q[s]);
+            if (edge) {
+                const uint32_t beyond = __builtin_amdgcn_perm(cv, cur[3], esel);   // (of a lane past the row end: the loaded sixteen are the row's last)
+                cur[0] = inside ? cur[0] : beyond;
+                halo = __builtin_amdgcn_perm(cv, halo, hsel);
+            }
+            if (row_out) { cur[0] = cv; cur[1] = cv; cur[2] = cv; cur[3] = cv; halo = cv; }
+            const uint32_t prevd = from_lane_below(cur[3], halo), nextd = from_lane_above(cur[0], halo);
+            uint32_t pl[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t prev = c == 0 ? prevd : cur[c - 1], next = c == 3 ? nextd : cur[c + 1], mid = cur[c];
+                auto P = [&](int i) -> uint32_t {   // (b[i], b[i + 2]) of prev | mid | next in 16-bit lanes; i is a compile-time constant after unrolling
+                    return i <= 5 ? __builtin_amdgcn_perm(mid, prev, 0x0c000c00u | (uint32_t)i | ((uint32_t)(i + 2) << 16))
+                                  : __builtin_amdgcn_perm(next, mid, 0x0c000c00u | (uint32_t)(i - 4) | ((uint32_t)(i - 2) << 16));
+                };
+                uint32_t m = P(5 - H);
+#pragma unroll
+                for (int i = 6 - H; i <= 4 + H; ++i) m = pk_minmax<DILATE>(m, P(i));
+                const uint32_t re = pk_minmax<DILATE>(m, P(4 - H)), ro = pk_minmax<DILATE>(m, P(5 + H));
+                uint32_t ve = re, vo = ro;
+#pragma unroll
+                for (int j = 1; j <= H; ++j) {
+                    ve = pk_minmax<DILATE>(ve, pr[(s + K - (2 * j - 1)) % K][c][0]);
+                    vo = pk_minmax<DILATE>(vo, pr[(s + K - (2 * j - 1)) % K][c][1]);
+                }
+                pr[s][c][0] = pk_minmax<DILATE>(re, last[c][0]); pr[s][c][1] = pk_minmax<DILATE>(ro, last[c][1]);
+                last[c][0] = re; last[c][1] = ro;
+                pl[c] = __builtin_amdgcn_perm(vo, ve, 0x06020400u);   // pixels 0, 1, 2, 3 of this dword
+            }
+            if (inside && r >= 2 * H && r < nrows) stream_store<4>(out_win, out_off, pl);
+            out_off += a.w;
+        }
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(kBx* kBy) void morphology_u8_kernel(Morph a) {
     unsigned bx_, by_, bz_;
@@ -1578,12 +1684,13 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     // re-applying it to an intermediate equals the K-box on the padded source.  A chain of rolling-kernel passes through one scratch
     // image and `dst` replaces the LDS-tile kernel: 9 x 9 1.20 -> 0.7 ms, 15 x 15 2.6 -> 1.1, 31 x 31 4.6 -> 2.0 per 32 4K images
     // (profiles/r06zl_morph_chain.txt).  Without scratch (stream capture and no registered workspace) the tile kernel keeps the call.
-    if (any && box && !direct && !no_roll && channels == 3 && kw == kh_ && (kw & 1) && kw >= 9 && kw <= 31 && border != KH_BORDER_WRAP && w >= 4 &&
+    const bool gray_roll_ok = channels == 1 && w % 16 == 0 && w >= 16 && (int64_t)w * h <= kI32Max && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);
+    if (any && box && !direct && !no_roll && (channels == 3 || gray_roll_ok) && kw == kh_ && (kw & 1) && kw >= 9 && kw <= 31 && border != KH_BORDER_WRAP && w >= 4 &&
         (int64_t)w * 3 < (1 << 24) && dev_opt(kOptMorphRoll) != 2) {
         int chain[8], nchain = 0, rem = kw;
         while (rem > 7) { chain[nchain++] = 7; rem -= 6; }
         if (rem >= 3) chain[nchain++] = rem;
-        const size_t img = (size_t)w * h * 3;
+        const size_t img = ((size_t)w * h * channels + 15) & ~(size_t)15;
         Scratch scratch;
         if (get_scratch(stream, img * (size_t)batch, what, scratch) == KH_OK) {
             uint8_t* tmp = scratch.as<uint8_t>();
@@ -1596,11 +1703,35 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
                 uint8_t box_mask[49];
                 for (int k = 0; k < chain[i] * chain[i]; ++k) box_mask[k] = 1;
                 const uint8_t cv[4] = {(uint8_t)a.cval[0], (uint8_t)a.cval[1], (uint8_t)a.cval[2], 0};
-                if (int32_t rc = kh_morphology_u8(stream, cur, out, w, h, 3, op, box_mask, chain[i], chain[i], border, cv, batch, cur_stride, out_stride)) return rc;
+                if (int32_t rc = kh_morphology_u8(stream, cur, out, w, h, channels, op, box_mask, chain[i], chain[i], border, cv, batch, cur_stride, out_stride)) return rc;
                 cur = out; cur_stride = out_stride;
             }
             return KH_OK;
         }
+    }
+    if (any && box && !direct && !no_roll && gray_roll_ok && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && dev_opt(kOptMorphRoll) != 2) {
+        // one channel, square box of 3 / 5 / 7, rows of whole 16-pixel groups: the rolling gray kernel (test option morph_roll = 2: the tile kernel)
+        MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], 0, 0}, XcdTiles{}};
+        const unsigned tiles_x = cdiv(w, kMgTilePx);
+        const long long cols_blocks = (long long)tiles_x * batch;
+        long long strips = (2048 + cols_blocks - 1) / cols_blocks;
+        const long long min_strips = cdiv(h, 360), max_strips = cdiv(h, 32);
+        strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
+        r.th = (int)cdiv(h, strips);
+        r.tiles = xcd_tiles(tiles_x, cdiv(h, r.th), (unsigned)batch, kXcdEighth);
+        KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        const dim3 grid = xcd_grid(r.tiles);
+        const bool dil = op == KH_MORPH_DILATE;
+#define KH_MG(KK)                                                                                        \
+    do {                                                                                                 \
+        if (dil) hipLaunchKernelGGL((morph_u8_gray_roll_kernel<KK, true>), grid, dim3(256), 0, st, r);   \
+        else hipLaunchKernelGGL((morph_u8_gray_roll_kernel<KK, false>), grid, dim3(256), 0, st, r);      \
+    } while (0)
+        if (kw == 3) KH_MG(3);
+        else if (kw == 5) KH_MG(5);
+        else KH_MG(7);
+#undef KH_MG
+        return check_launch(what);
     }
     if (any && box && !direct && !no_roll && channels == 3 && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && w >= 4 &&
         (int64_t)w * 3 < (1 << 24)) {   // RGB8, square box of 3 / 5 / 7: the rolling planar kernel

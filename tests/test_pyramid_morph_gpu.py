@@ -171,6 +171,28 @@ def test_morphology_rgb_large_boxes_as_a_chain(gpu_stream, dev_option, k, border
         assert_same_bits(got[i], O.morphology_u8(src[i], "dilate", mask, border, cval), f"batch frame {i}")
 
 
+@pytest.mark.parametrize("border", ["constant", "replicate", "reflect101", "reflect"])
+@pytest.mark.parametrize("k", [3, 5, 7, 9, 15, 31])
+def test_morphology_gray_rolling_kernel(gpu_stream, dev_option, k, border):
+    """Single-channel images whose rows are whole 16-pixel groups take the rolling gray kernel (sixteen pixels per lane, 1024 per wave;
+    round 6) for square boxes of 3 / 5 / 7 and the chain of such passes for 9 .. 31: the oracle's bytes on widths either side of the
+    wave (1024) and block (4096) seams, the narrowest rows (16 pixels), heights below the mask's, a border value that wins / loses, a
+    batch; morph_roll = 2 keeps the tile kernel; widths that are not multiples of 16 never leave it."""
+    mask = O.morph_kernel("box", k, k)
+    for (w, h) in [(16, 9), (32, 2), (48, 1), (64, 40), (1008, 5), (1024, 4), (1040, 6), (2048, 3), (2064, 4), (4096, 3), (4112, 5), (3840, 12), (128, 400), (100, 9), (1030, 4)]:
+        src = make(w, h, 1, np.uint8, seed=w + h + k)
+        for op, cval in (("dilate", [250]), ("erode", [9]), ("dilate", [3])):
+            want = O.morphology_u8(src, op, mask, border, cval)
+            for opt in (-1, 2):
+                dev_option("morph_roll", opt)
+                assert_same_bits(morph_gpu(gpu_stream, src, op, mask, border, cval)[0], want, f"{op} gray box{k} {border} {w}x{h} cval {cval} morph_roll={opt}")
+    dev_option("morph_roll", -1)
+    src = np.stack([make(1056, 75, 1, np.uint8, seed=s_) for s_ in (4, 5, 6)])
+    got = morph_gpu(gpu_stream, src, "erode", mask, border, [200], batch=3)
+    for i in range(3):
+        assert_same_bits(got[i], O.morphology_u8(src[i], "erode", mask, border, [200]), f"batch frame {i}")
+
+
 def test_morphology_both_kernels_agree(gpu_stream, tmp_path):
     """KH_MORPH_DIRECT=1 selects the per-pixel kernel (read once per process): a child process runs it on the same inputs and the
     bytes must equal this process's tiled result."""
