@@ -53,15 +53,20 @@ def test_normalize_mean_std_reference_example(gpu_stream):  # normalize.rs doc e
 
 
 def test_normalize_rgb_u8(gpu_stream):
+    """Pixel counts that are / are not multiples of four (four pixels per lane with 16-byte stores since round 6 / one pixel per lane),
+    a source 1 byte and a destination 4 bytes off alignment (the one-pixel kernel), a count that leaves a partial last block."""
     _ffi, lib, s = lib_s(gpu_stream)
-    n = 258 * 195
-    src = O.pattern_u8(3 * n)
     scale = (f32(1.0) / (np.array([0.229, 0.224, 0.225], f32) * f32(255.0))).astype(f32)
     offset = (-np.array([0.485, 0.456, 0.406], f32) / np.array([0.229, 0.224, 0.225], f32)).astype(f32)
-    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, 12 * n)
-    _ffi.check(lib.kh_normalize_rgb_u8_f32(s, d_src.ptr, d_dst.ptr, n, fptr(scale), fptr(offset)))
-    want = (src.reshape(-1, 3).astype(f32) * scale + offset).astype(f32).reshape(-1)
-    assert_same_bits(d_dst.to_numpy(f32, (3 * n,)), want, "normalize_rgb_u8")
+    for n in (258 * 195, 258 * 195 + 2, 4, 1, 1024 * 4 + 4, 1920 * 1080):
+        src = O.pattern_u8(3 * n + 1)
+        want = (src[:3 * n].reshape(-1, 3).astype(f32) * scale + offset).astype(f32).reshape(-1)
+        d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, 12 * n + 16)
+        _ffi.check(lib.kh_normalize_rgb_u8_f32(s, d_src.ptr, d_dst.ptr, n, fptr(scale), fptr(offset)))
+        assert_same_bits(d_dst.to_numpy(f32, (3 * n + 4,))[:3 * n], want, f"normalize_rgb_u8 n={n}")
+        want1 = (src[1:3 * n + 1].reshape(-1, 3).astype(f32) * scale + offset).astype(f32).reshape(-1)
+        _ffi.check(lib.kh_normalize_rgb_u8_f32(s, d_src.ptr + 1, d_dst.ptr + 4, n, fptr(scale), fptr(offset)))
+        assert_same_bits(d_dst.to_numpy(f32, (3 * n + 4,))[1:3 * n + 1], want1, f"normalize_rgb_u8 n={n}, unaligned")
 
 
 def test_min_max_and_normalize_min_max(gpu_stream):
