@@ -554,8 +554,8 @@ __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uin
     const float ny = (float)oy - a.pad_y;
     const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
     float o[3][4];
-    if constexpr ((FMT == KH_FMT_NV12 && (SAMPLER == kSampleBilinearOnGrid || SAMPLER == KH_SAMPLE_BILINEAR)) ||
-                  (FMT == KH_FMT_YUYV && SAMPLER == kSampleBilinearOnGrid)) {
+    if constexpr ((FMT == KH_FMT_NV12 && (SAMPLER == kSampleBilinearOnGrid || SAMPLER == KH_SAMPLE_BILINEAR || SAMPLER == KH_SAMPLE_NEAREST)) ||
+                  (FMT == KH_FMT_YUYV && (SAMPLER == kSampleBilinearOnGrid || SAMPLER == KH_SAMPLE_NEAREST))) {
         if (a.quad_wide) {   // uniform
             float sxs[4], px[4][3];
             int xs[4];
@@ -567,12 +567,14 @@ __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uin
                 sxs[j] = a.fast_div ? quot3(nx, a.scale_x, a.rc_x) : nx / a.scale_x;
                 in[j] = row_in && !(sxs[j] < 0.0f || sxs[j] >= (float)a.src_w);
                 any = any || in[j];
-                xs[j] = min(max((int)sxs[j], 0), a.src_w - 1);
+                // nearest (round 6): nearest_tap's column, round half away from zero, instead of the truncated one
+                xs[j] = min(max(SAMPLER == KH_SAMPLE_NEAREST ? (int)roundf(sxs[j]) : (int)sxs[j], 0), a.src_w - 1);
             }
             if (any) {
-                if constexpr (FMT == KH_FMT_YUYV) quad_taps_yuyv(src, xs, min(max((int)sy, 0), a.src_h - 1), a, px);
+                const int yn = min(max(SAMPLER == KH_SAMPLE_NEAREST ? (int)roundf(sy) : (int)sy, 0), a.src_h - 1);
+                if constexpr (FMT == KH_FMT_YUYV) quad_taps_yuyv(src, xs, yn, a, px);
                 else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) quad_taps_nv12_bilinear(src, sxs, sy, a, px);
-                else quad_taps_nv12(src, xs, min(max((int)sy, 0), a.src_h - 1), a, px);
+                else quad_taps_nv12(src, xs, yn, a, px);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -863,7 +865,7 @@ bool bilinear_taps_on_grid(const PreArgs& a) {
 
 // quad_taps_nv12's precondition, decided like the other launch checks by evaluating the kernel's own column expression for every
 // destination quad (dst_w / 4 groups of four host evaluations, memoised on the last geometry).
-bool quad_taps_fit_16(const PreArgs& a, int extra) {   // extra = 1: the bilinear sampler also reads column x + 1
+bool quad_taps_fit_16(const PreArgs& a, int extra) {   // extra = 1: the bilinear sampler also reads column x + 1; 2: nearest (rounded columns)
     struct Key { float sx, px; int w, sw, extra; bool ok; };
     static thread_local Key last = {0, 0, 0, 0, 0, false};
     if (last.w == a.dst_w && last.sw == a.src_w && last.sx == a.scale_x && last.px == a.pad_x && last.extra == extra) return last.ok;
@@ -874,9 +876,10 @@ bool quad_taps_fit_16(const PreArgs& a, int extra) {   // extra = 1: the bilinea
             const float s = ((float)(4 * q + j) - a.pad_x) / a.scale_x;   // plan_pixel; the kernel's quotient equals this or it divides itself
             // the float -> int cast is defined only inside the int range: NaN and anything below it are sorted out BEFORE the cast
             if (!(s == s)) { ok = false; x[j] = 0; }
+            else if (extra == 2) { const float r = roundf(s); x[j] = r >= 2147483520.0f ? a.src_w - 1 : r <= -2147483648.0f ? 0 : std::min(std::max((int)r, 0), a.src_w - 1); }
             else x[j] = s >= 2147483520.0f ? a.src_w - 1 : s <= -2147483648.0f ? 0 : std::min(std::max((int)s, 0), a.src_w - 1);
         }
-        ok = ok && x[0] <= x[1] && x[1] <= x[2] && x[2] <= x[3] && std::min(x[3] + extra, a.src_w - 1) - (x[0] & ~1) <= 15;
+        ok = ok && x[0] <= x[1] && x[1] <= x[2] && x[2] <= x[3] && std::min(x[3] + (extra == 1 ? 1 : 0), a.src_w - 1) - (x[0] & ~1) <= 15;
     }
     last = Key{a.scale_x, a.pad_x, a.dst_w, a.src_w, extra, ok};
     return ok;
@@ -985,8 +988,8 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
         const int opt = dev_opt(kOptPreQuads);
         const bool quads_ok = a.dst_w % 4 == 0 && (int64_t)a.dst_w * a.dst_h * 12 <= kI32Max &&
                               reinterpret_cast<uintptr_t>(dst) % 16 == 0 && a.dst_frame_stride % 4 == 0;   // (f16 since round 6: 8-byte stores)
-        const bool wide_nv12 = ((FMT == KH_FMT_NV12 && SAMPLER != KH_SAMPLE_NEAREST) || (FMT == KH_FMT_YUYV && SAMPLER == kSampleBilinearOnGrid && a.src_pitch >= 2 * a.src_w)) &&
-                               opt != 3 && quads_ok && quad_taps_fit_16(a, SAMPLER == KH_SAMPLE_BILINEAR ? 1 : 0);
+        const bool wide_nv12 = (FMT == KH_FMT_NV12 || (FMT == KH_FMT_YUYV && SAMPLER != KH_SAMPLE_BILINEAR && a.src_pitch >= 2 * a.src_w)) &&
+                               opt != 3 && quads_ok && quad_taps_fit_16(a, SAMPLER == KH_SAMPLE_BILINEAR ? 1 : (SAMPLER == KH_SAMPLE_NEAREST ? 2 : 0));
         if (quads_ok && opt != 0 && (SAMPLER != KH_SAMPLE_BILINEAR || opt == 1 || wide_nv12)) {
             const int wq = a.dst_w / 4, groups = wq * a.dst_h;
             const dim3 qgrid(cdiv(groups, kQuadBlock), grid.z);
