@@ -521,6 +521,41 @@ __device__ __forceinline__ void quad_taps_nv12_bilinear(const uint8_t* __restric
     }
 }
 
+// YUYV twin (round 6): the sixteen taps of a quad from four 16-byte loads (two per row: pixels xb .. xb + 15 are 32 bytes) instead of
+// per-tap gathers; tap (x, y) = Y byte 2 i, chroma bytes 4 (i >> 1) + 1 / + 3 of its own row, the blend bilinear_quad's expression.
+__device__ __forceinline__ void quad_taps_yuyv_bilinear(const uint8_t* __restrict__ src, const float (&sxs)[4], float sy, const PreArgs& a,
+                                                        float (&px)[4][3]) {
+    const int y0 = min(max((int)floorf(sy), 0), a.src_h - 1), y1 = min(y0 + 1, a.src_h - 1);
+    const float ay = sy - (float)(int)floorf(sy);
+    int x0[4], x1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x0[j] = min(max((int)floorf(sxs[j]), 0), a.src_w - 1);
+        x1[j] = min(x0[j] + 1, a.src_w - 1);
+    }
+    const int xb = min(x0[0] & ~1, a.src_w - 16);
+    const uint8_t* p0 = src + (unsigned)(y0 * a.src_pitch + 2 * xb);
+    const uint8_t* p1 = src + (unsigned)(y1 * a.src_pitch + 2 * xb);
+    const u32x4_t lo0 = *reinterpret_cast<const u32x4_unaligned*>(p0), hi0 = *reinterpret_cast<const u32x4_unaligned*>(p0 + 16);
+    const u32x4_t lo1 = *reinterpret_cast<const u32x4_unaligned*>(p1), hi1 = *reinterpret_cast<const u32x4_unaligned*>(p1 + 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i0 = x0[j] - xb, i1 = x1[j] - xb, g0 = 4 * (i0 >> 1), g1 = 4 * (i1 >> 1);
+        const float ax = sxs[j] - (float)(int)floorf(sxs[j]);
+        float t00[3], t10[3], t01[3], t11[3];
+        bt601_q20_to_rgb((int)byte32(lo0, hi0, 2 * i0), (int)byte32(lo0, hi0, g0 + 1), (int)byte32(lo0, hi0, g0 + 3), t00);
+        bt601_q20_to_rgb((int)byte32(lo0, hi0, 2 * i1), (int)byte32(lo0, hi0, g1 + 1), (int)byte32(lo0, hi0, g1 + 3), t10);
+        bt601_q20_to_rgb((int)byte32(lo1, hi1, 2 * i0), (int)byte32(lo1, hi1, g0 + 1), (int)byte32(lo1, hi1, g0 + 3), t01);
+        bt601_q20_to_rgb((int)byte32(lo1, hi1, 2 * i1), (int)byte32(lo1, hi1, g1 + 1), (int)byte32(lo1, hi1, g1 + 3), t11);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = t00[c] + (t10[c] - t00[c]) * ax;
+            const float bot = t01[c] + (t11[c] - t01[c]) * ax;
+            px[j][c] = top + (bot - top) * ay;
+        }
+    }
+}
+
 // (Round 5: picking the 48 bytes of a four-tap quad through a lane-private LDS slot — ds_read_u8 at run-time addresses instead of
 // 64-bit shifts and selects — takes 15 % of the kernel's vector instructions away, 682 M -> 577 M per launch, and not a microsecond:
 // 1.295 ms both ways (profiles/r05b_four_tap_lds_picks_ab.txt, r05c_*_counters.csv).  Decoding one tap per pixel instead of four
@@ -555,7 +590,7 @@ __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uin
     const float sy = a.fast_div ? quot3(ny, a.scale_y, a.rc_y) : ny / a.scale_y;
     float o[3][4];
     if constexpr ((FMT == KH_FMT_NV12 && (SAMPLER == kSampleBilinearOnGrid || SAMPLER == KH_SAMPLE_BILINEAR || SAMPLER == KH_SAMPLE_NEAREST)) ||
-                  (FMT == KH_FMT_YUYV && (SAMPLER == kSampleBilinearOnGrid || SAMPLER == KH_SAMPLE_NEAREST))) {
+                  (FMT == KH_FMT_YUYV && (SAMPLER == kSampleBilinearOnGrid || SAMPLER == KH_SAMPLE_NEAREST || SAMPLER == KH_SAMPLE_BILINEAR))) {
         if (a.quad_wide) {   // uniform
             float sxs[4], px[4][3];
             int xs[4];
@@ -572,7 +607,8 @@ __global__ __launch_bounds__(kQuadBlock) void preprocess_generic_quads(const uin
             }
             if (any) {
                 const int yn = min(max(SAMPLER == KH_SAMPLE_NEAREST ? (int)roundf(sy) : (int)sy, 0), a.src_h - 1);
-                if constexpr (FMT == KH_FMT_YUYV) quad_taps_yuyv(src, xs, yn, a, px);
+                if constexpr (FMT == KH_FMT_YUYV && SAMPLER == KH_SAMPLE_BILINEAR) quad_taps_yuyv_bilinear(src, sxs, sy, a, px);
+                else if constexpr (FMT == KH_FMT_YUYV) quad_taps_yuyv(src, xs, yn, a, px);
                 else if constexpr (SAMPLER == KH_SAMPLE_BILINEAR) quad_taps_nv12_bilinear(src, sxs, sy, a, px);
                 else quad_taps_nv12(src, xs, yn, a, px);
             }
@@ -988,7 +1024,7 @@ void launch_generic_out(hipStream_t s, dim3 grid, const uint8_t* src, void* dst,
         const int opt = dev_opt(kOptPreQuads);
         const bool quads_ok = a.dst_w % 4 == 0 && (int64_t)a.dst_w * a.dst_h * 12 <= kI32Max &&
                               reinterpret_cast<uintptr_t>(dst) % 16 == 0 && a.dst_frame_stride % 4 == 0;   // (f16 since round 6: 8-byte stores)
-        const bool wide_nv12 = (FMT == KH_FMT_NV12 || (FMT == KH_FMT_YUYV && SAMPLER != KH_SAMPLE_BILINEAR && a.src_pitch >= 2 * a.src_w)) &&
+        const bool wide_nv12 = (FMT == KH_FMT_NV12 || (FMT == KH_FMT_YUYV && a.src_pitch >= 2 * a.src_w)) &&
                                opt != 3 && quads_ok && quad_taps_fit_16(a, SAMPLER == KH_SAMPLE_BILINEAR ? 1 : (SAMPLER == KH_SAMPLE_NEAREST ? 2 : 0));
         if (quads_ok && opt != 0 && (SAMPLER != KH_SAMPLE_BILINEAR || opt == 1 || wide_nv12)) {
             const int wq = a.dst_w / 4, groups = wq * a.dst_h;
