@@ -1004,6 +1004,59 @@ __device__ __forceinline__ uint32_t pk_minmax(uint32_t a, uint32_t b) {
     const u16x2_t x = __builtin_bit_cast(u16x2_t, a), y = __builtin_bit_cast(u16x2_t, b);
     return __builtin_bit_cast(uint32_t, DILATE ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y));
 }
+// Cross and "ellipse" structuring elements of 3 / 5 / 7 (round 6).  They took the LDS-tile kernel's mask scan at 2-6x the time of the
+// box (profiles/r06zo_morph_shapes.txt).  Each of them is a union of at most two RECTANGLES of the K x K window — the cross its middle row
+// and its middle column; the reference's ellipse (kernels.rs:163-190: centre (K / 2.0, K / 2.0), so the disc sits half a pixel down /
+// right of the anchor) is the 2 x 2 block [1, 2]^2 for K = 3, the 4 x 4 block [1, 4]^2 for K = 5, and rows 2..5 x columns 1..6 joined
+// with rows 1..6 x columns 2..5 for K = 7 — and max / min over a union is the max / min of the parts, each of which is separable.  The
+// rolling kernels below keep, per rectangle, the last K rows' maxima over the rectangle's column run and combine the rows of its band.
+enum { kMsBox = 0, kMsCross = 1, kMsEllipse = 2 };
+struct MRect { int xl, xh, yt, yb; };   // columns xl..xh, rows yt..yb of the window (tap (ky, kx) reads pixel (y + ky - K / 2, x + kx - K / 2))
+template <int K, int SHAPE> __host__ __device__ constexpr int morph_nrects() { return SHAPE == kMsCross ? 2 : (SHAPE == kMsEllipse && K == 7 ? 2 : 1); }
+template <int K, int SHAPE> __host__ __device__ constexpr MRect morph_rect(int j) {
+    if (SHAPE == kMsCross) return j == 0 ? MRect{0, K - 1, K / 2, K / 2} : MRect{K / 2, K / 2, 0, K - 1};
+    if (SHAPE == kMsEllipse) return K == 3 ? MRect{1, 2, 1, 2} : K == 5 ? MRect{1, 4, 1, 4} : (j == 0 ? MRect{1, 6, 2, 5} : MRect{2, 5, 1, 6});
+    return MRect{0, K - 1, 0, K - 1};
+}
+// One loaded row of one register column (four pixels of a plane in `P`'s twelve-byte string): the row's maxima over the rectangle's
+// run for the pixel pairs (0, 2) and (1, 3) go into slot `s` of the rectangle's ring; returned are the maxima over its band of rows,
+// the newest loaded row being the window's LAST.  `s` is a compile-time constant after unrolling.
+template <int K, int XL, int XH, int YT, int YB, bool DILATE, class PF>
+__device__ __forceinline__ void morph_rect_step(uint32_t (&hist)[K][2], int s, PF P, uint32_t& ve, uint32_t& vo) {
+    constexpr int H = K / 2;
+    uint32_t re, ro;
+    if constexpr (XL == XH) { re = P(4 - H + XL); ro = P(5 - H + XL); }
+    else {   // pixels (0, 2) take P(4 - H + XL .. 4 - H + XH), pixels (1, 3) the same range one up: all but one term in common
+        uint32_t m = P(5 - H + XL);
+#pragma unroll
+        for (int i = 6 - H + XL; i <= 4 - H + XH; ++i) m = pk_minmax<DILATE>(m, P(i));
+        re = pk_minmax<DILATE>(m, P(4 - H + XL)); ro = pk_minmax<DILATE>(m, P(5 - H + XH));
+    }
+    hist[s][0] = re; hist[s][1] = ro;
+    constexpr int a0 = K - 1 - YB, a1 = K - 1 - YT;   // ages of the band's rows (0 = the row just loaded)
+    ve = hist[(s + K - a0) % K][0]; vo = hist[(s + K - a0) % K][1];
+#pragma unroll
+    for (int d = a0 + 1; d <= a1; ++d) {
+        ve = pk_minmax<DILATE>(ve, hist[(s + K - d) % K][0]);
+        vo = pk_minmax<DILATE>(vo, hist[(s + K - d) % K][1]);
+    }
+}
+template <int K, int SHAPE, bool DILATE, class PF>
+__device__ __forceinline__ void morph_shape_step(uint32_t (&hist)[2][K][2], int s, PF P, uint32_t& ve, uint32_t& vo) {
+    constexpr MRect r0 = morph_rect<K, SHAPE>(0);
+    morph_rect_step<K, r0.xl, r0.xh, r0.yt, r0.yb, DILATE>(hist[0], s, P, ve, vo);
+    if constexpr (morph_nrects<K, SHAPE>() == 2) {
+        constexpr MRect r1 = morph_rect<K, SHAPE>(1);
+        uint32_t ve1, vo1;
+        morph_rect_step<K, r1.xl, r1.xh, r1.yt, r1.yb, DILATE>(hist[1], s, P, ve1, vo1);
+        ve = pk_minmax<DILATE>(ve, ve1); vo = pk_minmax<DILATE>(vo, vo1);
+    }
+}
+// register targets for the scheduler (blocks of 4 waves per CU = waves per SIMD): the box kernels 64 / 96 / 128 VGPRs; a cross or the
+// two-rectangle ellipse keeps a second ring per register column and gets the next step down
+__host__ __device__ constexpr int morph_roll_blocks(int K, int shape) {
+    return shape == kMsBox || (shape == kMsEllipse && K < 7) ? (K <= 3 ? 8 : (K <= 5 ? 5 : 4)) : (K <= 3 ? 6 : (K <= 5 ? 4 : 3));
+}
 struct MorphRoll {
     const uint8_t* src;
     uint8_t* dst;
@@ -1014,8 +1067,8 @@ struct MorphRoll {
 };
 constexpr int kMrWavePx = 256, kMrTilePx = 4 * kMrWavePx;
 
-template <int K, bool DILATE>
-__global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_rgb_roll_kernel(MorphRoll a) {   // a register target for the scheduler: 5 x 5 105 -> <= 96, 7 x 7 137 -> <= 128 VGPRs
+template <int K, bool DILATE, int SHAPE = kMsBox>
+__global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_rgb_roll_kernel(MorphRoll a) {   // a register target for the scheduler: 5 x 5 105 -> <= 96, 7 x 7 137 -> <= 128 VGPRs
     constexpr int H = K / 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
@@ -1063,11 +1116,15 @@ __global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_r
     // column pass on pair maxima: pr[t] = max(row t - 1, row t), so the K-row maximum ending at row t is row t with pr[t - 1], pr[t - 3] ...:
     // 1 + K / 2 packed max per register instead of K - 1
     uint32_t pr[K][3][2], last[3][2];
+    uint32_t hist[3][2][K][2];   // (cross / ellipse: per channel and rectangle, the last K rows' run maxima)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         last[c][0] = kInit; last[c][1] = kInit;
 #pragma unroll
-        for (int i = 0; i < K; ++i) { pr[i][c][0] = kInit; pr[i][c][1] = kInit; }
+        for (int i = 0; i < K; ++i) {
+            pr[i][c][0] = kInit; pr[i][c][1] = kInit;
+            hist[c][0][i][0] = kInit; hist[c][0][i][1] = kInit; hist[c][1][i][0] = kInit; hist[c][1][i][1] = kInit;
+        }
     }
 
     long long out_off = (long long)(y0 - 2 * H) * rowb + 3 * p;
@@ -1092,19 +1149,23 @@ __global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_r
                     return i <= 5 ? __builtin_amdgcn_perm(cur, prev, 0x0c000c00u | (uint32_t)i | ((uint32_t)(i + 2) << 16))
                                   : __builtin_amdgcn_perm(next, cur, 0x0c000c00u | (uint32_t)(i - 4) | ((uint32_t)(i - 2) << 16));
                 };
-                // pixels (0, 2) take P(4 - H .. 4 + H), pixels (1, 3) P(5 - H .. 5 + H): K - 1 terms in common
-                uint32_t m = P(5 - H);
+                uint32_t ve, vo;
+                if constexpr (SHAPE != kMsBox) morph_shape_step<K, SHAPE, DILATE>(hist[c], s, P, ve, vo);
+                else {
+                    // pixels (0, 2) take P(4 - H .. 4 + H), pixels (1, 3) P(5 - H .. 5 + H): K - 1 terms in common
+                    uint32_t m = P(5 - H);
 #pragma unroll
-                for (int i = 6 - H; i <= 4 + H; ++i) m = pk_minmax<DILATE>(m, P(i));
-                const uint32_t re = pk_minmax<DILATE>(m, P(4 - H)), ro = pk_minmax<DILATE>(m, P(5 + H));
-                uint32_t ve = re, vo = ro;
+                    for (int i = 6 - H; i <= 4 + H; ++i) m = pk_minmax<DILATE>(m, P(i));
+                    const uint32_t re = pk_minmax<DILATE>(m, P(4 - H)), ro = pk_minmax<DILATE>(m, P(5 + H));
+                    ve = re; vo = ro;
 #pragma unroll
-                for (int j = 1; j <= H; ++j) {
-                    ve = pk_minmax<DILATE>(ve, pr[(s + K - (2 * j - 1)) % K][c][0]);
-                    vo = pk_minmax<DILATE>(vo, pr[(s + K - (2 * j - 1)) % K][c][1]);
+                    for (int j = 1; j <= H; ++j) {
+                        ve = pk_minmax<DILATE>(ve, pr[(s + K - (2 * j - 1)) % K][c][0]);
+                        vo = pk_minmax<DILATE>(vo, pr[(s + K - (2 * j - 1)) % K][c][1]);
+                    }
+                    pr[s][c][0] = pk_minmax<DILATE>(re, last[c][0]); pr[s][c][1] = pk_minmax<DILATE>(ro, last[c][1]);
+                    last[c][0] = re; last[c][1] = ro;
                 }
-                pr[s][c][0] = pk_minmax<DILATE>(re, last[c][0]); pr[s][c][1] = pk_minmax<DILATE>(ro, last[c][1]);
-                last[c][0] = re; last[c][1] = ro;
                 pl[c] = __builtin_amdgcn_perm(vo, ve, 0x06020400u);   // pixels 0, 1, 2, 3 of this channel
             }
             if (writer && r >= 2 * H && r < nrows) {
@@ -1141,8 +1202,8 @@ __global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_r
 // whose per-lane selector is computed once.  For square all-ones masks of 3 / 5 / 7, widths that are multiples of 16, every border mode
 // but wrap; byte-identical to the other kernels (max / min are exact and order-independent).
 constexpr int kMgWavePx = 1024, kMgTilePx = 4 * kMgWavePx;
-template <int K, bool DILATE>
-__global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_gray_roll_kernel(MorphRoll a) {
+template <int K, bool DILATE, int SHAPE = kMsBox>
+__global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_gray_roll_kernel(MorphRoll a) {
     constexpr int H = K / 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
@@ -1186,11 +1247,15 @@ __global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_g
 
     constexpr uint32_t kInit = DILATE ? 0u : 0x00ff00ffu;
     uint32_t pr[K][4][2], last[4][2];   // pair maxima of consecutive rows, as in the RGB kernel
+    uint32_t hist[4][2][K][2];          // (cross / ellipse: per dword and rectangle, the last K rows' run maxima)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         last[c][0] = kInit; last[c][1] = kInit;
 #pragma unroll
-        for (int i = 0; i < K; ++i) { pr[i][c][0] = kInit; pr[i][c][1] = kInit; }
+        for (int i = 0; i < K; ++i) {
+            pr[i][c][0] = kInit; pr[i][c][1] = kInit;
+            hist[c][0][i][0] = kInit; hist[c][0][i][1] = kInit; hist[c][1][i][0] = kInit; hist[c][1][i][1] = kInit;
+        }
     }
 
     int out_off = (y0 - 2 * H) * a.w + p;
@@ -1216,18 +1281,22 @@ __global__ __launch_bounds__(256, K <= 3 ? 8 : (K <= 5 ? 5 : 4)) void morph_u8_g
                     return i <= 5 ? __builtin_amdgcn_perm(mid, prev, 0x0c000c00u | (uint32_t)i | ((uint32_t)(i + 2) << 16))
                                   : __builtin_amdgcn_perm(next, mid, 0x0c000c00u | (uint32_t)(i - 4) | ((uint32_t)(i - 2) << 16));
                 };
-                uint32_t m = P(5 - H);
+                uint32_t ve, vo;
+                if constexpr (SHAPE != kMsBox) morph_shape_step<K, SHAPE, DILATE>(hist[c], s, P, ve, vo);
+                else {
+                    uint32_t m = P(5 - H);
 #pragma unroll
-                for (int i = 6 - H; i <= 4 + H; ++i) m = pk_minmax<DILATE>(m, P(i));
-                const uint32_t re = pk_minmax<DILATE>(m, P(4 - H)), ro = pk_minmax<DILATE>(m, P(5 + H));
-                uint32_t ve = re, vo = ro;
+                    for (int i = 6 - H; i <= 4 + H; ++i) m = pk_minmax<DILATE>(m, P(i));
+                    const uint32_t re = pk_minmax<DILATE>(m, P(4 - H)), ro = pk_minmax<DILATE>(m, P(5 + H));
+                    ve = re; vo = ro;
 #pragma unroll
-                for (int j = 1; j <= H; ++j) {
-                    ve = pk_minmax<DILATE>(ve, pr[(s + K - (2 * j - 1)) % K][c][0]);
-                    vo = pk_minmax<DILATE>(vo, pr[(s + K - (2 * j - 1)) % K][c][1]);
+                    for (int j = 1; j <= H; ++j) {
+                        ve = pk_minmax<DILATE>(ve, pr[(s + K - (2 * j - 1)) % K][c][0]);
+                        vo = pk_minmax<DILATE>(vo, pr[(s + K - (2 * j - 1)) % K][c][1]);
+                    }
+                    pr[s][c][0] = pk_minmax<DILATE>(re, last[c][0]); pr[s][c][1] = pk_minmax<DILATE>(ro, last[c][1]);
+                    last[c][0] = re; last[c][1] = ro;
                 }
-                pr[s][c][0] = pk_minmax<DILATE>(re, last[c][0]); pr[s][c][1] = pk_minmax<DILATE>(ro, last[c][1]);
-                last[c][0] = re; last[c][1] = ro;
                 pl[c] = __builtin_amdgcn_perm(vo, ve, 0x06020400u);   // pixels 0, 1, 2, 3 of this dword
             }
             if (inside && r >= 2 * H && r < nrows) stream_store<4>(out_win, out_off, pl);
@@ -1679,6 +1748,18 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     for (int ky = 0; ky < kh_; ++ky) { any = any || a.rows[ky]; box = box && a.rows[ky] == (kw == 32 ? 0xffffffffu : (1u << kw) - 1u); }
     const bool direct = dev_opt(kOptMorphDirect) == 1;
     const bool no_roll = dev_opt(kOptMorphRoll) == 0;   // dev / test knob: the tile kernel
+    // the rolling kernels' shapes: the all-ones box, and kh_morph_kernel's cross / ellipse of 3 / 5 / 7 (unions of two rectangles)
+    int shape = box ? kMsBox : -1;
+    if (!box && kw == kh_ && (kw == 3 || kw == 5 || kw == 7)) {
+        for (int sh = kMsCross; sh <= kMsEllipse && shape < 0; ++sh) {
+            uint8_t ref[49];
+            kh_morph_kernel(sh, kw, kw, ref);
+            bool same = true;
+            for (int ky = 0; ky < kw && same; ++ky)
+                for (int kx = 0; kx < kw; ++kx) same = same && ((a.rows[ky] >> kx) & 1u) == ref[ky * kw + kx];
+            if (same) shape = sh;
+        }
+    }
     // Square boxes of 9 .. 31 (round 6): max / min over a K-box IS the composition of boxes of 7 (and one of 3 / 5 / 7) — K = 1 + sum (k_i - 1),
     // exact, order-independent arithmetic — and every border mode extends the image evenly / periodically / by a constant, so
     // re-applying it to an intermediate equals the K-box on the padded source.  A chain of rolling-kernel passes through one scratch
@@ -1709,8 +1790,8 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
             return KH_OK;
         }
     }
-    if (any && box && !direct && !no_roll && gray_roll_ok && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && dev_opt(kOptMorphRoll) != 2) {
-        // one channel, square box of 3 / 5 / 7, rows of whole 16-pixel groups: the rolling gray kernel (test option morph_roll = 2: the tile kernel)
+    if (any && shape >= 0 && !direct && !no_roll && gray_roll_ok && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && dev_opt(kOptMorphRoll) != 2) {
+        // one channel, square box / cross / ellipse of 3 / 5 / 7, rows of whole 16-pixel groups: the rolling gray kernel (test option morph_roll = 2: the tile kernel)
         MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], 0, 0}, XcdTiles{}};
         const unsigned tiles_x = cdiv(w, kMgTilePx);
         const long long cols_blocks = (long long)tiles_x * batch;
@@ -1722,19 +1803,21 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
         KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const dim3 grid = xcd_grid(r.tiles);
         const bool dil = op == KH_MORPH_DILATE;
-#define KH_MG(KK)                                                                                        \
-    do {                                                                                                 \
-        if (dil) hipLaunchKernelGGL((morph_u8_gray_roll_kernel<KK, true>), grid, dim3(256), 0, st, r);   \
-        else hipLaunchKernelGGL((morph_u8_gray_roll_kernel<KK, false>), grid, dim3(256), 0, st, r);      \
+#define KH_MG_S(KK, SH)                                                                                      \
+    do {                                                                                                     \
+        if (dil) hipLaunchKernelGGL((morph_u8_gray_roll_kernel<KK, true, SH>), grid, dim3(256), 0, st, r);   \
+        else hipLaunchKernelGGL((morph_u8_gray_roll_kernel<KK, false, SH>), grid, dim3(256), 0, st, r);      \
     } while (0)
+#define KH_MG(KK) do { if (shape == kMsBox) KH_MG_S(KK, kMsBox); else if (shape == kMsCross) KH_MG_S(KK, kMsCross); else KH_MG_S(KK, kMsEllipse); } while (0)
         if (kw == 3) KH_MG(3);
         else if (kw == 5) KH_MG(5);
         else KH_MG(7);
 #undef KH_MG
+#undef KH_MG_S
         return check_launch(what);
     }
-    if (any && box && !direct && !no_roll && channels == 3 && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && w >= 4 &&
-        (int64_t)w * 3 < (1 << 24)) {   // RGB8, square box of 3 / 5 / 7: the rolling planar kernel
+    if (any && shape >= 0 && !direct && !no_roll && channels == 3 && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && w >= 4 &&
+        (int64_t)w * 3 < (1 << 24) && (shape == kMsBox || dev_opt(kOptMorphRoll) != 2)) {   // RGB8, square box / cross / ellipse of 3 / 5 / 7: the rolling planar kernel
         MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], a.cval[1], a.cval[2]}, XcdTiles{}};
         const unsigned tiles_x = cdiv(w, kMrTilePx);
         const long long cols_blocks = (long long)tiles_x * batch;
@@ -1746,15 +1829,17 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
         KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const dim3 grid = xcd_grid(r.tiles);
         const bool dil = op == KH_MORPH_DILATE;
-#define KH_MR(KK)                                                                                       \
-    do {                                                                                                \
-        if (dil) hipLaunchKernelGGL((morph_u8_rgb_roll_kernel<KK, true>), grid, dim3(256), 0, st, r);   \
-        else hipLaunchKernelGGL((morph_u8_rgb_roll_kernel<KK, false>), grid, dim3(256), 0, st, r);      \
+#define KH_MR_S(KK, SH)                                                                                     \
+    do {                                                                                                    \
+        if (dil) hipLaunchKernelGGL((morph_u8_rgb_roll_kernel<KK, true, SH>), grid, dim3(256), 0, st, r);   \
+        else hipLaunchKernelGGL((morph_u8_rgb_roll_kernel<KK, false, SH>), grid, dim3(256), 0, st, r);      \
     } while (0)
+#define KH_MR(KK) do { if (shape == kMsBox) KH_MR_S(KK, kMsBox); else if (shape == kMsCross) KH_MR_S(KK, kMsCross); else KH_MR_S(KK, kMsEllipse); } while (0)
         if (kw == 3) KH_MR(3);
         else if (kw == 5) KH_MR(5);
         else KH_MR(7);
 #undef KH_MR
+#undef KH_MR_S
         return check_launch(what);
     }
     const int srows = kMorphTH + kh_ - 1, sp = ((kMorphFW + (kw - 1) * channels + 3) & ~3) + 4;

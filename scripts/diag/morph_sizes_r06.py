@@ -12,6 +12,10 @@ from kornia_rs.hip import DeviceBuffer
 import bench
 lib, check = _ffi.lib, _ffi.check
 hip.set_device(0); st = hip.Stream.new(0)
+if len(sys.argv) > 1:   # e.g. morph_roll=2: the tile kernel instead of the rolling kernels (A/B)
+    name, val = sys.argv[1].split("=")
+    check(lib.kh_debug_set_option(name.encode(), int(val)))
+    print(f"# dev option {name} = {val}")
 N, W, H = 32, 3840, 2160
 for ch in (3, 1):
     n = W * H * ch

@@ -193,6 +193,33 @@ def test_morphology_gray_rolling_kernel(gpu_stream, dev_option, k, border):
         assert_same_bits(got[i], O.morphology_u8(src[i], "erode", mask, border, [200]), f"batch frame {i}")
 
 
+@pytest.mark.parametrize("border", ["constant", "replicate", "reflect101", "reflect"])
+@pytest.mark.parametrize("kshape", [("cross", 3), ("cross", 5), ("cross", 7), ("ellipse", 3), ("ellipse", 5), ("ellipse", 7)])
+def test_morphology_cross_and_ellipse_on_the_rolling_kernels(gpu_stream, dev_option, kshape, border):
+    """kh_morph_kernel's cross and ellipse of 3 / 5 / 7 are unions of at most two rectangles of the window (the ellipse sits half a
+    pixel down / right of the anchor: a 2 x 2 / 4 x 4 block, two overlapping 4 x 6 blocks) and run on the rolling RGB and gray kernels
+    (round 6): the oracle's bytes either side of the wave / block seams, on the narrowest images, heights below the mask's, border
+    values that win or lose, a batch; morph_roll = 2 keeps the tile kernel's mask scan."""
+    shape, k = kshape
+    mask = O.morph_kernel(shape, k, k)
+    for c, sizes in ((3, [(4, 9), (5, 2), (6, 1), (7, 40), (3, 8), (248, 3), (251, 7), (255, 3), (256, 8), (257, 5), (260, 3), (1023, 3), (1024, 6), (1025, 4),
+                          (1029, 2), (131, 200)]),
+                     (1, [(16, 9), (32, 2), (48, 1), (64, 40), (1008, 5), (1024, 4), (1040, 6), (4096, 3), (4112, 5), (128, 200), (100, 9)])):
+        for (w, h) in sizes:
+            src = make(w, h, c, np.uint8, seed=w + h + k)
+            for op, cval in (("dilate", [250, 3, 130][:c]), ("erode", [9, 251, 130][:c])):
+                want = O.morphology_u8(src, op, mask, border, cval)
+                for opt in (-1, 2):
+                    dev_option("morph_roll", opt)
+                    assert_same_bits(morph_gpu(gpu_stream, src, op, mask, border, cval)[0], want, f"{op} c{c} {shape}{k} {border} {w}x{h} morph_roll={opt}")
+    dev_option("morph_roll", -1)
+    for c, w in ((3, 1000), (1, 1056)):
+        src = np.stack([make(w, 75, c, np.uint8, seed=s_) for s_ in (4, 5, 6)])
+        got = morph_gpu(gpu_stream, src, "erode", mask, border, [200] * c, batch=3)
+        for i in range(3):
+            assert_same_bits(got[i], O.morphology_u8(src[i], "erode", mask, border, [200] * c), f"batch frame {i} c{c}")
+
+
 def test_morphology_both_kernels_agree(gpu_stream, tmp_path):
     """KH_MORPH_DIRECT=1 selects the per-pixel kernel (read once per process): a child process runs it on the same inputs and the
     bytes must equal this process's tiled result."""
