@@ -67,6 +67,24 @@ def test_pyrdown_u8_tiled_interior_and_edge_tiles(gpu_stream, c):
         assert_same_bits(got[k], O.pyrdown(batch[k]), f"pyrdown u8 batch frame {k}")
 
 
+def test_pyrdown_u8_gray_rolling_kernel(gpu_stream, dev_option):
+    """Single-channel sources whose rows are whole 16-pixel groups take the rolling gray kernel (sixteen source pixels per lane, 1024
+    per wave, 4096 per block; round 6): the oracle's bytes on widths either side of those seams, the narrowest rows, one- to
+    five-row images, odd heights, strips of a few rows, a batch; pyr_roll = 0 keeps the tile kernel; other widths never leave it."""
+    for w, h in [(16, 1), (16, 2), (32, 3), (48, 5), (64, 40), (1008, 5), (1024, 4), (1040, 7), (2032, 3), (2048, 6), (2064, 4), (4080, 3), (4096, 5), (4112, 4),
+                 (3840, 31), (128, 401), (100, 9), (1030, 4)]:
+        src = make(w, h, 1, np.uint8, seed=w + h)
+        want = O.pyrdown(src)
+        for opt in (-1, 0):
+            dev_option("pyr_roll", opt)
+            assert_same_bits(pyr_gpu(gpu_stream, src, False)[0], want, f"pyrdown u8 gray {w}x{h} pyr_roll={opt}")
+    dev_option("pyr_roll", -1)
+    batch = np.stack([make(1056, 75, 1, np.uint8, seed=k) for k in range(3)])
+    got = pyr_gpu(gpu_stream, batch, False, batch=3)
+    for k in range(3):
+        assert_same_bits(got[k], O.pyrdown(batch[k]), f"pyrdown u8 gray batch frame {k}")
+
+
 def test_pyramid_batch_and_host_api(gpu_stream):
     from kornia_rs import Image, ImageError, imgproc
     n = 3
