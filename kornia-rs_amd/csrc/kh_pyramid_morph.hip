@@ -940,6 +940,115 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) { 
     }
 }
 
+// ---- pyrup_u8 for single-channel images, rolling wave (round 6) -----------------------------------------------------------------------
+// The gray twin of the kernel above (the pair kernel ran at 0.29 of peak): a lane owns EIGHT source pixels of a row (one 8-byte load)
+// and their sixteen destination pixels of both destination rows (one 16-byte store each, 1 KiB = whole lines per wave and row —
+// straight from the owning lanes, no LDS transposition: one plane needs no re-interleaving).  Its two dwords go through the RGB
+// kernel's per-channel code; the dword before the lane's first and after its last come from the neighbouring lanes by wave shifts
+// and, at the ends of the wave, from one halo dword per half-wave; reflect-101 columns -1 and sw by one v_perm_b32 (edge waves).
+// For source widths that are multiples of 8; byte-identical to the other kernels.
+constexpr int kPuGrayWaveSrc = 512;                  // source pixels per wave (64 lanes x 8)
+constexpr int kPuGrayTileSrc = 4 * kPuGrayWaveSrc;
+__global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {   // th = SOURCE rows per strip
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int x0 = (int)tx * kPuGrayTileSrc + wv * kPuGrayWaveSrc;   // first source pixel of this wave
+    if (x0 >= a.sw) return;
+    const int y0 = ty * a.th, thr = min(a.th, a.sh - y0);
+    const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
+    uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
+    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.dw * a.dh);   // (dw * dh < 2^31: host-checked)
+    const int p = x0 + 8 * lane;                                      // this lane's source pixels p .. p + 7
+    const bool inside = p < a.sw;                                     // all eight or none (sw % 8 == 0: host-checked)
+    const int ph = lane < 32 ? x0 - 4 : x0 + kPuGrayWaveSrc;          // the wave's halo dwords: left in the lower half's lanes, right in the upper's
+    const bool edge = x0 < 4 || x0 + kPuGrayWaveSrc + 4 > a.sw;       // wave-uniform
+    const int pc = min(p, a.sw - 8), phc = min(max(ph, 0), a.sw - 4);
+    uint32_t esel = 0x03020100u, hsel = 0x03020100u;   // (esel: the first lane past the row end re-indexes the row's last dword into its first)
+    if (edge) {
+        esel = hsel = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            esel |= (uint32_t)min(max(reflect_101(p + j, a.sw) - (a.sw - 4), 0), 3) << (8 * j);
+            hsel |= (uint32_t)min(max(reflect_101(ph + j, a.sw) - phc, 0), 3) << (8 * j);
+        }
+    }
+    const int n = thr + 2;                                            // source rows walked: y0 - 1 .. y0 + thr
+    int pf = y0 - 1;
+
+    uint32_t q[3][3];   // the lane's eight pixels and its half-wave's halo dword
+    auto prefetch = [&](uint32_t (&d)[3]) {
+        const uint8_t* row = src + (long long)reflect_101(pf, a.sh) * a.sw;
+        d[0] = *reinterpret_cast<const u32_unaligned*>(row + pc); d[1] = *reinterpret_cast<const u32_unaligned*>(row + pc + 4);
+        d[2] = *reinterpret_cast<const u32_unaligned*>(row + phc);
+        ++pf;
+    };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prefetch(q[i]);
+
+    // the row pass of three source rows: [row][dword][even / odd destination columns], packed bytes, and unpacked 16-bit lanes
+    uint32_t hp_[3][2][2], hl[3][2][2], hh[3][2][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { hp_[i][c][e] = 0; hl[i][c][e] = 0; hh[i][c][e] = 0; }
+
+    int row_off = 2 * y0 * a.dw + 2 * p;   // this lane's sixteen destination pixels of destination row 2 y0
+    for (int ib = 0; ib < n; ib += 3) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int i = ib + s;
+            uint32_t cur[2] = {q[s][0], q[s][1]}, halo = q[s][2];
+            prefetch(q[s]);
+            if (edge) {   // wave-uniform
+                const uint32_t beyond = __builtin_amdgcn_perm(0u, cur[1], esel);   // (of a lane past the row end: the loaded eight are the row's last)
+                cur[0] = inside ? cur[0] : beyond;
+                halo = __builtin_amdgcn_perm(0u, halo, hsel);
+            }
+            const uint32_t prevd = from_lane_below(cur[1], halo), nextd = from_lane_above(cur[0], halo);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t A = cur[c], prev = c == 0 ? prevd : cur[0], next = c == 0 ? cur[1] : nextd;
+                const uint32_t w2 = __builtin_amdgcn_alignbyte(next, A, 1);                 // p[x+1] for the four pixels
+                constexpr uint32_t kT = 0x0020c020u;   // taps (1, 6, 1, 0) x 32; accumulator 4 x 32
+                const uint32_t t0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A, prev, 3), kT, 128u, false);
+                const uint32_t t1 = __builtin_amdgcn_udot4(A, kT, 128u, false);
+                const uint32_t t2 = __builtin_amdgcn_udot4(w2, kT, 128u, false);
+                const uint32_t t3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(next, A, 2), kT, 128u, false);
+                const uint32_t ev = __builtin_amdgcn_perm(__builtin_amdgcn_perm(t3, t2, 0x0c0c0501u), __builtin_amdgcn_perm(t1, t0, 0x0c0c0501u), 0x05040100u);
+                const uint32_t od = avg_round_u8x4(A, w2);
+                hp_[s][c][0] = ev; hp_[s][c][1] = od;
+                hl[s][c][0] = ev & 0x00ff00ffu; hh[s][c][0] = (ev >> 8) & 0x00ff00ffu;
+                hl[s][c][1] = od & 0x00ff00ffu; hh[s][c][1] = (od >> 8) & 0x00ff00ffu;
+            }
+            if (i >= 2 && i < n) {   // rows y - 1, y, y + 1 are in: destination rows 2 y and 2 y + 1 (y = y0 + i - 2)
+                const int sp = (s + 1) % 3, sc = (s + 2) % 3, sn = s;   // compile-time after unrolling
+                uint32_t w[2][4];   // [destination row][dword]
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    uint32_t ve[2], vo[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint32_t lo = ((mad24(hl[sc][c][e], 6u, hl[sp][c][e]) + hl[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
+                        const uint32_t hi = ((mad24(hh[sc][c][e], 6u, hh[sp][c][e]) + hh[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
+                        ve[e] = lo | (hi << 8);
+                        vo[e] = avg_round_u8x4(hp_[sc][c][e], hp_[sn][c][e]);
+                    }
+                    w[0][2 * c] = __builtin_amdgcn_perm(ve[1], ve[0], 0x05010400u); w[0][2 * c + 1] = __builtin_amdgcn_perm(ve[1], ve[0], 0x07030602u);   // e0 o0 e1 o1 | e2 o2 e3 o3
+                    w[1][2 * c] = __builtin_amdgcn_perm(vo[1], vo[0], 0x05010400u); w[1][2 * c + 1] = __builtin_amdgcn_perm(vo[1], vo[0], 0x07030602u);
+                }
+                if (inside) {
+                    stream_store<4>(out_win, row_off, w[0]);
+                    stream_store<4>(out_win, row_off + a.dw, w[1]);
+                }
+                row_off += 2 * a.dw;
+            }
+        }
+    }
+}
+
 // pyrup_u8 (:656-840): horizontal pass to a u8 intermediate, then the same taps vertically
 template <int C>
 __device__ __forceinline__ uint32_t pyrup_h_u8(const uint8_t* __restrict__ row, int sw, int X, int c) {
@@ -1796,11 +1905,25 @@ int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_
                     int64_t ds) {
     const bool direct = dev_opt(kOptPyrDirect) == 1;
     const bool no_roll = dev_opt(kOptPyrRoll) == 0;
-    if (direct || no_roll || channels != 3 || sw < 4 || (int64_t)sw * 6 >= (1 << 24)) return kh_pyrup_u8_pairs(stream, src, dst, sw, sh, channels, batch, ss, ds);
+    // one channel, rows of whole 8-pixel groups: the rolling gray kernel (16-byte stores: a dword-aligned destination)
+    const bool gray = channels == 1 && sw % 8 == 0 && sw >= 8 && (int64_t)sw * sh * 4 <= kI32Max && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);
+    if (direct || no_roll || !(channels == 3 || gray) || sw < 4 || (int64_t)sw * 6 >= (1 << 24)) return kh_pyrup_u8_pairs(stream, src, dst, sw, sh, channels, batch, ss, ds);
     const int dw = sw * 2, dh = sh * 2;
     if (int32_t rc = check_pyr("kh_pyrup_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
     PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
+    if (gray) {
+        const unsigned gtiles_x = cdiv(sw, kPuGrayTileSrc);
+        const long long gcols = (long long)gtiles_x * batch;
+        long long gstrips = (2048 + gcols - 1) / gcols;   // >= 8 blocks per CU
+        const long long gmin = cdiv(sh, 360), gmax = cdiv(sh, 16);
+        gstrips = gstrips < gmin ? gmin : (gstrips > gmax ? gmax : gstrips);
+        r.th = (int)cdiv(sh, gstrips);
+        r.tiles = xcd_tiles(gtiles_x, cdiv(sh, r.th), (unsigned)batch, kXcdEighth);
+        KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrup_u8: batch x tiles exceeds one launch");
+        hipLaunchKernelGGL(pyrup_u8_gray_roll_kernel, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+        return check_launch("kh_pyrup_u8");
+    }
     const unsigned tiles_x = cdiv(sw, kPuRollTileSrc);
     const long long cols_blocks = (long long)tiles_x * batch;
     long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU

@@ -85,6 +85,24 @@ def test_pyrdown_u8_gray_rolling_kernel(gpu_stream, dev_option):
         assert_same_bits(got[k], O.pyrdown(batch[k]), f"pyrdown u8 gray batch frame {k}")
 
 
+def test_pyrup_u8_gray_rolling_kernel(gpu_stream, dev_option):
+    """Single-channel sources whose rows are whole 8-pixel groups take the rolling gray pyrup kernel (eight source pixels per lane, 512
+    per wave, 2048 per block; round 6): the oracle's bytes on widths either side of those seams, the narrowest rows, one- to
+    four-row images, strips of a few rows, a batch; pyr_roll = 0 keeps the pair kernel; other widths never leave it."""
+    for w, h in [(8, 1), (8, 2), (16, 3), (24, 4), (64, 40), (504, 5), (512, 4), (520, 7), (1016, 3), (1024, 6), (1032, 4), (2040, 3), (2048, 5), (2056, 4),
+                 (1920, 31), (128, 201), (100, 9), (518, 4)]:
+        src = make(w, h, 1, np.uint8, seed=w + h)
+        want = O.pyrup(src)
+        for opt in (-1, 0):
+            dev_option("pyr_roll", opt)
+            assert_same_bits(pyr_gpu(gpu_stream, src, True)[0], want, f"pyrup u8 gray {w}x{h} pyr_roll={opt}")
+    dev_option("pyr_roll", -1)
+    batch = np.stack([make(528, 75, 1, np.uint8, seed=k) for k in range(3)])
+    got = pyr_gpu(gpu_stream, batch, True, batch=3)
+    for k in range(3):
+        assert_same_bits(got[k], O.pyrup(batch[k]), f"pyrup u8 gray batch frame {k}")
+
+
 def test_pyramid_batch_and_host_api(gpu_stream):
     from kornia_rs import Image, ImageError, imgproc
     n = 3
