@@ -144,7 +144,7 @@ __device__ __forceinline__ T* list_dst(const PtrList& l, bool listed, T* base, l
 // the library at all.
 enum DevOpt : int {
     kOptPreIeeeDiv, kOptPreGrid, kOptPreQuads, kOptFilterForceTile, kOptFilterFourColumns, kOptGradScalar, kOptHfilterDirect,
-    kOptResizeU8Gather, kOptPyrDirect, kOptPyrRoll, kOptMorphDirect, kOptMorphRoll, kOptU8BlurRgb, kOptU8BlurSwar, kOptWarpU8Direct, kOptWarpU8Spans, kOptWarpU8Rows, kOptResizeRows, kOptWarpF32Px, kOptResizeU8Px,
+    kOptResizeU8Gather, kOptPyrDirect, kOptPyrRoll, kOptMorphDirect, kOptMorphRoll, kOptU8BlurRgb, kOptU8BlurSwar, kOptWarpU8Direct, kOptWarpU8Spans, kOptWarpU8Rows, kOptResizeRows, kOptWarpF32Px, kOptResizeU8Px, kOptRowStores,
     kOptCount
 };
 int dev_opt(DevOpt o);               // kh_runtime.hip: the calling thread's value
@@ -214,6 +214,28 @@ __device__ __forceinline__ void stream_store(__amdgpu_buffer_rsrc_t rs, int byte
     else if constexpr (NDW == 2) __builtin_amdgcn_raw_buffer_store_b64((u32x2_t{w[0], w[1]}), rs, byte_off, 0, kAuxStream);
     else if constexpr (NDW == 3) __builtin_amdgcn_raw_buffer_store_b96((u32x3_t{w[0], w[1], w[2]}), rs, byte_off, 0, kAuxStream);
     else __builtin_amdgcn_raw_buffer_store_b128((u32x4_t{w[0], w[1], w[2], w[3]}), rs, byte_off, 0, kAuxStream);
+}
+
+// ROW-structured kernels (a wave owns a fixed column segment and walks down the rows) and the streaming policy (round 6,
+// profiles/r06zq_row_stores.txt): a write-through store pays for every 128-byte line it writes PARTIALLY, and when the rows of an
+// image are not whole lines (row bytes % 128 != 0, or an image base off a line) every wave segment of every row starts and ends inside
+// a line.  The f32 rolling filters then ran 1.5x slower than with ordinary write-back stores (3839-pixel rows: 0.41 vs 0.26 ms per 16
+// 4K planes; 1001 x 3: 0.62 vs 0.43), while on line-aligned rows the streaming policy wins by 3-30 %.  Launchers of such kernels pass
+// `plain_row_stores(...)` to the kernel, which stores through `row_store` (a wave-uniform branch around the two policies).
+template <int NDW>
+__device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rs, int byte_off, const uint32_t* w, int plain) {
+    if (!plain) { stream_store<NDW>(rs, byte_off, w); return; }
+    static_assert(NDW >= 1 && NDW <= 4, "1..4 dwords");
+    if constexpr (NDW == 1) __builtin_amdgcn_raw_buffer_store_b32(w[0], rs, byte_off, 0, 0);
+    else if constexpr (NDW == 2) __builtin_amdgcn_raw_buffer_store_b64((u32x2_t{w[0], w[1]}), rs, byte_off, 0, 0);
+    else if constexpr (NDW == 3) __builtin_amdgcn_raw_buffer_store_b96((u32x3_t{w[0], w[1], w[2]}), rs, byte_off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128((u32x4_t{w[0], w[1], w[2], w[3]}), rs, byte_off, 0, 0);
+}
+// 1 = write-back stores: the destination's rows are not whole 128-byte lines (test option row_stores: 0 = streaming, 1 = write-back always)
+inline int plain_row_stores(int64_t row_bytes, const void* dst, int64_t image_stride_bytes, int batch) {
+    const int opt = dev_opt(kOptRowStores);
+    if (opt >= 0) return opt ? 1 : 0;
+    return (row_bytes % 128 != 0 || reinterpret_cast<uintptr_t>(dst) % 128 != 0 || (batch > 1 && image_stride_bytes % 128 != 0)) ? 1 : 0;
 }
 
 // Unaligned 2/4/8-byte global accesses (fine on gfx950; the compiler emits single dword/dwordx2 ops).

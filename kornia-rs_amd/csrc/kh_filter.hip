@@ -43,7 +43,9 @@ struct FilterArgs {
     XcdTiles tiles;  // (column tile, row strip, image), XCD-contiguous order
     int listed;      // image bases from the launch's PtrList (kh_common.h) instead of base + k * stride
     int xlo, xhi, ylo, yhi;   // MASKED rolling launches (unequal tap counts): the real taps of each pass inside the K padded ones
+    int plain;                // rolling kernels: write-back stores instead of the streaming policy (kh_common.h::plain_row_stores)
 };
+
 
 extern __shared__ __attribute__((aligned(16))) float lds_f[];
 
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void sep_roll_kernel(FilterArgs a, TapsK kx
                 if constexpr (GRAD) o2 += ring2[(p + 1 + i) % K] * kx.k[i];
             }
             if constexpr (GRAD) o = sqrtf(o * o + o2 * o2);
-            if (gx_ok && r >= 2 * H && r < nrows) { const uint32_t ow_bits = __float_as_uint(o); stream_store<1>(ow, out_off, &ow_bits); }
+            if (gx_ok && r >= 2 * H && r < nrows) { const uint32_t ow_bits = __float_as_uint(o); row_store<1>(ow, out_off, &ow_bits, a.plain); }
             out_off += a.rowlen * 4;
         }
     }
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void sep_roll_wide_kernel(FilterArgs a, Tap
             float o = 0.0f;
 #pragma unroll
             for (int i = 0; i < K; ++i) o += ring[(p + 1 + i) % K] * ky.k[i];   // oldest row first: ascending vertical taps
-            if (gx_ok && r >= 2 * H && r < nrows) { const uint32_t ow_bits = __float_as_uint(o); stream_store<1>(ow, out_off, &ow_bits); }
+            if (gx_ok && r >= 2 * H && r < nrows) { const uint32_t ow_bits = __float_as_uint(o); row_store<1>(ow, out_off, &ow_bits, a.plain); }
             out_off += a.rowlen * 4;
         }
     }
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void sep_roll4_kernel(FilterArgs a, TapsK k
             }
             if (gx_ok && r >= 2 * H && r < nrows) {
                 const uint32_t bits[4] = {__float_as_uint(o01.x), __float_as_uint(o01.y), __float_as_uint(o23.x), __float_as_uint(o23.y)};
-                stream_store<4>(ow, out_off, bits);
+                row_store<4>(ow, out_off, bits, a.plain);
             }
             out_off += a.rowlen * 4;
         }
@@ -532,6 +534,7 @@ int32_t launch(kh_stream_t stream, const BatchRef& whole, int cols, int rows, in
     a.src_stride = b.ss; a.dst_stride = b.ds;
     a.listed = b.listed() ? 1 : 0;
     a.xlo = a.xhi = a.ylo = a.yhi = 0;
+    a.plain = plain_row_stores((int64_t)a.rowlen * 4, b.listed() ? nullptr : b.dst, b.ds * 4, batch);
 
     // Fast path: rolling-column kernel for odd kernels up to 15 taps whose horizontal halo fits
     // the 32-float side buffers; everything else takes the LDS-tile kernel below.

@@ -179,6 +179,23 @@ def test_wide_kernels_rolling_path(gpu_stream, dev_option, c, k):
     assert_same_bits(run(gpu_stream, "kh_box_blur_f32", src, k, k), O.separable_filter(src, O.box_kernel_1d(k), O.box_kernel_1d(k)), f"box {k}x{k} c{c}")
 
 
+@pytest.mark.parametrize("policy", [-1, 0, 1])
+def test_row_store_policy_changes_no_bit(gpu_stream, dev_option, policy):
+    """Rows that are not whole 128-byte lines take write-back stores in the rolling kernels, line-aligned rows the streaming policy
+    (round 6, kh_common.h::plain_row_stores); test option row_stores forces either: the oracle's bits every way, on row lengths
+    either side of the rule, for the one-column, four-column and wide kernels, a gradient and a batch."""
+    dev_option("row_stores", policy)
+    for (w, h, c) in [(1024, 12, 1), (1023, 9, 1), (1028, 7, 1), (352, 11, 3), (351, 8, 3), (344, 9, 3), (256, 6, 4), (257, 5, 4)]:
+        src = img(w, h, c, seed=w + c)
+        for k, sig in ((5, 1.0), (11, 2.0), (17, 3.0)):
+            assert_same_bits(run(gpu_stream, "kh_gaussian_blur_f32", src, k, k, sig, sig), O.gaussian_blur(src, (k, k), (sig, sig)), f"gaussian {w}x{h} c{c} k{k} row_stores={policy}")
+        assert_same_bits(run(gpu_stream, "kh_gradient_magnitude_f32", src, 0, 3), O.gradient_magnitude(src, 0, 3), f"sobel {w}x{h} c{c} row_stores={policy}")
+    batch = np.stack([img(1031, 9, 1, seed=k) for k in range(3)])
+    got = run(gpu_stream, "kh_gaussian_blur_f32", batch, 5, 5, 1.0, 1.0, batch=3)
+    for k in range(3):
+        assert_same_bits(got[k], O.gaussian_blur(batch[k], (5, 5), (1.0, 1.0)), f"batch frame {k} row_stores={policy}")
+
+
 def test_filter_validation(gpu_stream):
     from kornia_rs import _ffi
     lib, s = _ffi.lib, gpu_stream.cuda_stream_ptr
