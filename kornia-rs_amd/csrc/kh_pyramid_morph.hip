@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBx* kBy) void pyrdown_f32_kernel(Pyr<float> a) {
 //     per lane instead of a 5 x 5 register window: 10 LDS reads per output instead of 25 vector-memory loads, ~40 VGPRs.
 // A 256-thread block = 4 independent waves = 256 flat destination floats; kPdfQ source rows of loads are in flight per lane.
 constexpr int kPdfQ = 6, kPdfSpan = 160, kPdfStripMax = 360;
-struct PyrF32Roll { const float* src; float* dst; int sw, sh, dw, dh, th, C; long long ss, ds; XcdTiles tiles; };
+struct PyrF32Roll { const float* src; float* dst; int sw, sh, dw, dh, th, C; long long ss, ds; XcdTiles tiles; int plain; };   // plain: kh_common.h::plain_row_stores
 
 template <int C>
 __global__ __launch_bounds__(256) void pyrdown_f32_roll_kernel(PyrF32Roll a) {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void pyrdown_f32_roll_kernel(PyrF32Roll a) {
                 s1 += t[kx] * (k1[2] * k1[kx]);
                 s0 += t[kx] * (k1[0] * k1[kx]);
             }
-            if (gx_ok && m >= 2 && m < steps) { const uint32_t bits = __float_as_uint(s2); stream_store<1>(ow, out_off, &bits); }
+            if (gx_ok && m >= 2 && m < steps) { const uint32_t bits = __float_as_uint(s2); row_store<1>(ow, out_off, &bits, a.plain); }
             out_off += rowlen_d * 4;
             // odd source row
             stage(q[2 * u + 1]);
@@ -561,6 +561,7 @@ struct PyrRoll {
     int sw, sh, dw, dh, th;   // th = destination rows (pyrdown) / source rows (pyrup) per strip
     long long ss, ds;
     XcdTiles tiles;
+    int plain;                // write-back instead of streaming stores (kh_common.h::plain_row_stores)
 };
 
 __global__ __launch_bounds__(256, 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) 
                 const int off = 12 * lane;
                 if (off + 12 <= seg_bytes && stream_ok) {
                     const uint32_t w[3] = {w0, w1, w2};
-                    stream_store<3>(out_win, (int)out_off + off, w);
+                    row_store<3>(out_win, (int)out_off + off, w, a.plain);
                 } else if (off + 12 <= seg_bytes) {
                     *reinterpret_cast<u32_unaligned*>(o + off) = w0; *reinterpret_cast<u32_unaligned*>(o + off + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + off + 8) = w2;
                 } else {
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_gray_roll_kernel(PyrRoll a)
                     }
                     w[c] = __builtin_amdgcn_perm(v[1], v[0], 0x06040200u);   // four destination pixels
                 }
-                if (inside) stream_store<2>(out_win, out_off, w);
+                if (inside) row_store<2>(out_win, out_off, w, a.plain);
                 out_off += a.dw;
             }
         }
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) { 
                             const uint64_t lo = *reinterpret_cast<const uint64_t*>(xb + off), hi = *reinterpret_cast<const uint64_t*>(xb + off + 8);
                             if (stream_ok) {
                                 const uint32_t w[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-                                stream_store<4>(out_win, (int)(row_off + r * drow) + off, w);
+                                row_store<4>(out_win, (int)(row_off + r * drow) + off, w, a.plain);
                             } else {
                                 *reinterpret_cast<u64_unaligned*>(o + off) = lo; *reinterpret_cast<u64_unaligned*>(o + off + 8) = hi;
                             }
@@ -1040,8 +1041,8 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
                     w[1][2 * c] = __builtin_amdgcn_perm(vo[1], vo[0], 0x05010400u); w[1][2 * c + 1] = __builtin_amdgcn_perm(vo[1], vo[0], 0x07030602u);
                 }
                 if (inside) {
-                    stream_store<4>(out_win, row_off, w[0]);
-                    stream_store<4>(out_win, row_off + a.dw, w[1]);
+                    row_store<4>(out_win, row_off, w[0], a.plain);
+                    row_store<4>(out_win, row_off + a.dw, w[1], a.plain);
                 }
                 row_off += 2 * a.dw;
             }
@@ -1273,6 +1274,7 @@ struct MorphRoll {
     long long ss, ds;
     uint32_t cval[3];
     XcdTiles tiles;
+    int plain;                // write-back instead of streaming stores (kh_common.h::plain_row_stores)
 };
 constexpr int kMrWavePx = 256, kMrTilePx = 4 * kMrWavePx;
 
@@ -1385,7 +1387,7 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_rgb
                 uint8_t* o = dst + out_off;
                 if (full && stream_ok) {
                     const uint32_t w[3] = {w0, w1, w2};
-                    stream_store<3>(out_win, (int)out_off, w);
+                    row_store<3>(out_win, (int)out_off, w, a.plain);
                 } else if (full) {
                     *reinterpret_cast<u32_unaligned*>(o) = w0; *reinterpret_cast<u32_unaligned*>(o + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + 8) = w2;
                 } else {
@@ -1508,7 +1510,7 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_gra
                 }
                 pl[c] = __builtin_amdgcn_perm(vo, ve, 0x06020400u);   // pixels 0, 1, 2, 3 of this dword
             }
-            if (inside && r >= 2 * H && r < nrows) stream_store<4>(out_win, out_off, pl);
+            if (inside && r >= 2 * H && r < nrows) row_store<4>(out_win, out_off, pl, a.plain);
             out_off += a.w;
         }
     }
@@ -1814,7 +1816,7 @@ int32_t kh_pyrdown_f32(kh_stream_t stream, const float* src, float* dst, int32_t
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     if (int32_t rc = check_pyr("kh_pyrdown_f32", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
-    PyrF32Roll r{src, dst, sw, sh, dw, dh, 0, channels, ss, ds, XcdTiles{}};
+    PyrF32Roll r{src, dst, sw, sh, dw, dh, 0, channels, ss, ds, XcdTiles{}, plain_row_stores((int64_t)dw * channels * 4, dst, ds * 4, batch)};
     const unsigned tiles_x = cdiv(dw * channels, 256);
     const long long cols_blocks = (long long)tiles_x * batch;
     long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
@@ -1840,7 +1842,7 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
     if (batch == 0) return KH_OK;
     const bool no_roll = dev_opt(kOptPyrRoll) == 0;   // dev / test knob: the tile kernel
     if (channels == 3 && sw >= 8 && !no_roll) {   // RGB8: the rolling planar kernel
-        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
+        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}, plain_row_stores((int64_t)dw * channels, dst, ds, batch)};
         const unsigned tiles_x = cdiv(dw, kPdRollTileDst);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
@@ -1854,7 +1856,7 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
     }
     if (channels == 1 && sw % 16 == 0 && sw >= 16 && !no_roll && (int64_t)dw * dh <= kI32Max && reinterpret_cast<uintptr_t>(dst) % 4 == 0 &&
         (batch <= 1 || ds % 4 == 0)) {   // one channel, rows of whole 16-pixel groups: the rolling gray kernel
-        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
+        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}, plain_row_stores((int64_t)dw * channels, dst, ds, batch)};
         const unsigned tiles_x = cdiv(dw, kPgRollTileDst);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
@@ -1911,7 +1913,7 @@ int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_
     const int dw = sw * 2, dh = sh * 2;
     if (int32_t rc = check_pyr("kh_pyrup_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
-    PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}};
+    PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}, plain_row_stores((int64_t)dw * channels, dst, ds, batch)};
     if (gray) {
         const unsigned gtiles_x = cdiv(sw, kPuGrayTileSrc);
         const long long gcols = (long long)gtiles_x * batch;
@@ -2029,7 +2031,7 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     }
     if (any && shape >= 0 && !direct && !no_roll && gray_roll_ok && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && dev_opt(kOptMorphRoll) != 2) {
         // one channel, square box / cross / ellipse of 3 / 5 / 7, rows of whole 16-pixel groups: the rolling gray kernel (test option morph_roll = 2: the tile kernel)
-        MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], 0, 0}, XcdTiles{}};
+        MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], 0, 0}, XcdTiles{}, plain_row_stores((int64_t)w, dst, ds, batch)};
         const unsigned tiles_x = cdiv(w, kMgTilePx);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;
@@ -2055,7 +2057,7 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     }
     if (any && shape >= 0 && !direct && !no_roll && channels == 3 && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && w >= 4 &&
         (int64_t)w * 3 < (1 << 24) && (shape == kMsBox || dev_opt(kOptMorphRoll) != 2)) {   // RGB8, square box / cross / ellipse of 3 / 5 / 7: the rolling planar kernel
-        MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], a.cval[1], a.cval[2]}, XcdTiles{}};
+        MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], a.cval[1], a.cval[2]}, XcdTiles{}, plain_row_stores((int64_t)w * 3, dst, ds, batch)};
         const unsigned tiles_x = cdiv(w, kMrTilePx);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU

@@ -42,6 +42,7 @@ struct Rz {
     long long ss, ds;  // bytes between consecutive images
     double scale_x, scale_y;
     XcdTiles tiles;
+    int plain;         // quad kernels: write-back instead of streaming stores (kh_common.h::plain_row_stores)
 };
 
 #define KH_RZ_PROLOGUE                                          \
@@ -147,13 +148,13 @@ __device__ __forceinline__ uint32_t px_any(const Rz& a, const uint8_t* __restric
 }
 // four packed pixels -> C dwords -> one streaming store at pixel x0 of the row window
 template <int C>
-__device__ __forceinline__ void store_quad_u8(__amdgpu_buffer_rsrc_t ow, int x0, const uint32_t (&p)[4]) {
+__device__ __forceinline__ void store_quad_u8(__amdgpu_buffer_rsrc_t ow, int x0, const uint32_t (&p)[4], int plain) {
     uint32_t w[C];
     if constexpr (C == 1) w[0] = p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24);
     else if constexpr (C == 2) { w[0] = p[0] | (p[1] << 16); w[1] = p[2] | (p[3] << 16); }
     else if constexpr (C == 3) { w[0] = p[0] | (p[1] << 24); w[1] = (p[1] >> 8) | (p[2] << 16); w[2] = (p[2] >> 16) | (p[3] << 8); }
     else { w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3]; }
-    stream_store<C>(ow, x0 * C, w);
+    row_store<C>(ow, x0 * C, w, plain);
 }
 template <int C, int OP>
 __global__ __launch_bounds__(kBx* kBy) void resize_u8_px_kernel(Rz a) {
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kBx* kBy) void resize_u8_quads_kernel(Rz a) {
     uint32_t p[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = px_any<C, OP>(a, src, x0 + j, y, yi, fy);
-    store_quad_u8<C>(ow, x0, p);
+    store_quad_u8<C>(ow, x0, p, a.plain);
 }
 
 // ---- separable Q14 ------------------------------------------------------------------------------------
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(kBx* kBy) void cv_u8_quads_kernel(Rz a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) p[j] = load_px_u8<C>(src + ((long long)sy * a.sw + cv_nearest_index(x0 + j, a.scale_x, a.sw)) * C);
     }
-    store_quad_u8<C>(ow, x0, p);
+    store_quad_u8<C>(ow, x0, p, a.plain);
 }
 
 template <int C>
@@ -792,6 +793,7 @@ Rz make_rz(const void* src, void* dst, int sw, int sh, int dw, int dh, int64_t s
     a.scale_x = (double)sw / (double)dw;
     a.scale_y = (double)sh / (double)dh;
     a.tiles = xcd_tiles(cdiv(gw, kBx), cdiv(gh, kBy), (unsigned)batch, cdiv(gw, kBx) * 8);
+    a.plain = 0;
     return a;
 }
 
@@ -875,6 +877,7 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     const bool quads = dw % 4 == 0 && px_opt != 1 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || dst_stride % 4 == 0) &&
                        (int64_t)dw * channels <= kI32Max && (px_opt == 4 || down2 || up2 || mode == KH_INTERP_NEAREST || sw <= 2 * dw);
     if (quads) a.tiles = xcd_tiles(cdiv(dw, kBx * 4), cdiv(dh, kBy), (unsigned)batch, cdiv(dw, kBx * 4) * 8);
+    if (quads) a.plain = plain_row_stores((int64_t)dw * channels, dst, dst_stride, batch);
 #define KH_RZ_OP(CC, OP) do { if (quads) hipLaunchKernelGGL((resize_u8_quads_kernel<CC, OP>), xcd_grid(a.tiles), blk, 0, st, a); \
                               else hipLaunchKernelGGL((resize_u8_px_kernel<CC, OP>), xcd_grid(a.tiles), blk, 0, st, a); } while (0)
 #define KH_RZ_OP_C(OP) do { switch (channels) { case 1: KH_RZ_OP(1, OP); break; case 2: KH_RZ_OP(2, OP); break; case 3: KH_RZ_OP(3, OP); break; default: KH_RZ_OP(4, OP); break; } } while (0)
@@ -974,6 +977,7 @@ static int32_t resize_opencv(const char* what, kh_stream_t stream, const void* s
     if (elem == 1 && dw % 4 == 0 && px_opt != 1 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0) && (int64_t)dw * channels <= kI32Max &&
         (px_opt == 4 || mode == KH_INTERP_NEAREST || sw <= 2 * dw)) {
         a.tiles = xcd_tiles(cdiv(dw, kBx * 4), cdiv(dh, kBy), (unsigned)batch, cdiv(dw, kBx * 4) * 8);
+        a.plain = plain_row_stores((int64_t)dw * channels, dst, ds, batch);
         const dim3 qblk(kBx, kBy), qgrid = xcd_grid(a.tiles);
 #define KH_CVQ(CC) do { if (mode == KH_INTERP_NEAREST) hipLaunchKernelGGL((cv_u8_quads_kernel<CC, false>), qgrid, qblk, 0, st, a); \
                         else hipLaunchKernelGGL((cv_u8_quads_kernel<CC, true>), qgrid, qblk, 0, st, a); } while (0)
