@@ -50,6 +50,56 @@ __device__ __forceinline__ int reflect_101(int p, int len) {  // pyramid.rs:252-
     return p >= len ? period - p : p;
 }
 
+// Ragged rows in the single-channel rolling kernels (round 6).  Those kernels give a lane SIXTEEN (pyrup: eight) pixels of a row with one
+// wide load and took only widths that are whole lanes; every other width fell to the tile kernels, 2.4-4x slower (1000-pixel rows,
+// profiles/r06zr_misaligned_rows.txt).  On a wave that reaches the row end every lane now loads the sixteen bytes at pc = min(p, w - 16)
+// and re-indexes them: lane byte j (pixel p + j) <- loaded byte map(p + j) - pc, or the border constant — which covers the lane the row
+// ends in (its own pixels shifted, then border pixels), the lane after it (border pixels only: what its neighbour's windows reach) and,
+// with identity selectors, every lane before.  Per output dword the four source indices lie within four consecutive bytes (ascending
+// pixels, a reflection, or one replicated pixel), i.e. in ONE of the dword pairs (L1:L0), (L2:L1), (L3:L2): three v_perm_b32 and two
+// selects with per-lane selectors computed once.
+struct Remap16 { uint32_t sel[4], cmask[4]; int k[4]; };
+template <class MapFn>
+__device__ __forceinline__ Remap16 remap16_setup(int p, int pc, MapFn map) {   // map(x): source pixel index, or < 0 for the constant
+    Remap16 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int id[4], lo = 15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = map(p + 4 * c + j);
+            id[j] = m < 0 ? -1 : min(max(m - pc, 0), 15);
+            lo = id[j] < 0 ? lo : min(lo, id[j]);
+        }
+        const int k = min(lo >> 2, 2);
+        uint32_t sel = 0, cm = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sel |= (uint32_t)(id[j] < 0 ? 0 : min(max(id[j] - 4 * k, 0), 7)) << (8 * j);
+            cm |= id[j] < 0 ? 0xffu << (8 * j) : 0u;
+        }
+        r.sel[c] = sel; r.cmask[c] = cm; r.k[c] = k;
+    }
+    return r;
+}
+__device__ __forceinline__ void remap16_apply(const Remap16& r, uint32_t (&L)[4], uint32_t cv) {
+    uint32_t o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t r0 = __builtin_amdgcn_perm(L[1], L[0], r.sel[c]), r1 = __builtin_amdgcn_perm(L[2], L[1], r.sel[c]), r2 = __builtin_amdgcn_perm(L[3], L[2], r.sel[c]);
+        const uint32_t v = r.k[c] == 0 ? r0 : (r.k[c] == 1 ? r1 : r2);
+        o[c] = (v & ~r.cmask[c]) | (cv & r.cmask[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) L[c] = o[c];
+}
+// the first `n` (1..15) bytes of four dwords to a byte-aligned address (the lane a ragged row ends in)
+__device__ __forceinline__ void store_head_bytes(uint8_t* o, const uint32_t (&w)[4], int n) {
+#pragma unroll
+    for (int b = 0; b < 15; ++b)
+        if (b < n) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+}
+
 // pyrdown_f32 (:312-430): 5x5 outer-product taps, ky-major accumulation, reflect-101 border.
 // (Round 3 tried sharing source pixels along the wave — a lane loads only its own pair and takes the other three pixels from the
 // lanes either side by DPP shifts, 10 full-wave loads per pixel instead of 25: 2.53 ms against this kernel's 2.22 on one box,
@@ -1264,8 +1314,9 @@ __device__ __forceinline__ void morph_shape_step(uint32_t (&hist)[2][K][2], int 
 }
 // register targets for the scheduler (blocks of 4 waves per CU = waves per SIMD): the box kernels 64 / 96 / 128 VGPRs; a cross or the
 // two-rectangle ellipse keeps a second ring per register column and gets the next step down
-__host__ __device__ constexpr int morph_roll_blocks(int K, int shape) {
-    return shape == kMsBox || (shape == kMsEllipse && K < 7) ? (K <= 3 ? 8 : (K <= 5 ? 5 : 4)) : (K <= 3 ? 6 : (K <= 5 ? 4 : 3));
+__host__ __device__ constexpr int morph_roll_blocks(int K, int shape, bool ragged = false) {   // (ragged: twelve more registers of selectors)
+    const int b = shape == kMsBox || (shape == kMsEllipse && K < 7) ? (K <= 3 ? 8 : (K <= 5 ? 5 : 4)) : (K <= 3 ? 6 : (K <= 5 ? 4 : 3));
+    return !ragged ? b : (b >= 8 ? 6 : (b >= 3 ? b - 1 : 2));
 }
 struct MorphRoll {
     const uint8_t* src;
@@ -1413,8 +1464,9 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_rgb
 // whose per-lane selector is computed once.  For square all-ones masks of 3 / 5 / 7, widths that are multiples of 16, every border mode
 // but wrap; byte-identical to the other kernels (max / min are exact and order-independent).
 constexpr int kMgWavePx = 1024, kMgTilePx = 4 * kMgWavePx;
-template <int K, bool DILATE, int SHAPE = kMsBox>
-__global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_gray_roll_kernel(MorphRoll a) {
+// RAGGED (round 6): any width >= 16 and any alignment (remap16_* above); plain = 2: rows or images off a dword, unaligned global stores.
+template <int K, bool DILATE, int SHAPE = kMsBox, bool RAGGED = false>
+__global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE, RAGGED)) void morph_u8_gray_roll_kernel(MorphRoll a) {
     constexpr int H = K / 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
@@ -1426,7 +1478,8 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_gra
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
     const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.w * a.h);   // (w * h < 2^31: host-checked)
     const int p = p0 + 16 * lane;                           // this lane's sixteen pixels
-    const bool inside = p < a.w;                            // all sixteen or none (w % 16 == 0: host-checked)
+    const int nvalid = min(max(a.w - p, 0), 16);            // RAGGED: 0 .. 16; otherwise all sixteen or none (w % 16 == 0: host-checked)
+    const bool inside = nvalid > 0;
     const int ph = lane < 32 ? p0 - 4 : p0 + kMgWavePx;     // the wave's halo dwords: left in the lower half's lanes, right in the upper's
     const bool edge = p0 < 4 || p0 + kMgWavePx + 4 > a.w;   // wave-uniform
     const int pc = min(p, a.w - 16), phc = min(max(ph, 0), a.w - 4);
@@ -1441,6 +1494,8 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_gra
             hsel |= (uint32_t)(mh < 0 ? 4 : min(max(mh - phc, 0), 3)) << (8 * j);
         }
     }
+    Remap16 rm{};
+    if (RAGGED && edge) rm = remap16_setup(p, pc, [&](int x) { return map_index(a.border, x, a.w); });
     const int nrows = min(a.th, a.h - y0) + 2 * H;
     int pf_row = y0 - H;
     const uint32_t cv = a.cval[0] * 0x01010101u;
@@ -1478,8 +1533,11 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_gra
             uint32_t cur[4] = {q[s][0], q[s][1], q[s][2], q[s][3]}, halo = q[s][4];
             prefetch(q[s]);
             if (edge) {
-                const uint32_t beyond = __builtin_amdgcn_perm(cv, cur[3], esel);   // (of a lane past the row end: the loaded sixteen are the row's last)
-                cur[0] = inside ? cur[0] : beyond;
+                if constexpr (RAGGED) remap16_apply(rm, cur, cv);
+                else {
+                    const uint32_t beyond = __builtin_amdgcn_perm(cv, cur[3], esel);   // (of a lane past the row end: the loaded sixteen are the row's last)
+                    cur[0] = inside ? cur[0] : beyond;
+                }
                 halo = __builtin_amdgcn_perm(cv, halo, hsel);
             }
             if (row_out) { cur[0] = cv; cur[1] = cv; cur[2] = cv; cur[3] = cv; halo = cv; }
@@ -1510,7 +1568,13 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_gra
                 }
                 pl[c] = __builtin_amdgcn_perm(vo, ve, 0x06020400u);   // pixels 0, 1, 2, 3 of this dword
             }
-            if (inside && r >= 2 * H && r < nrows) row_store<4>(out_win, out_off, pl, a.plain);
+            if constexpr (RAGGED) {
+                if (r >= 2 * H && r < nrows) {
+                    if (nvalid == 16 && a.plain != 2) row_store<4>(out_win, out_off, pl, a.plain);
+                    else if (nvalid == 16) *reinterpret_cast<u32x4_unaligned*>(dst + out_off) = u32x4_t{pl[0], pl[1], pl[2], pl[3]};
+                    else if (nvalid > 0) store_head_bytes(dst + out_off, pl, nvalid);
+                }
+            } else if (inside && r >= 2 * H && r < nrows) row_store<4>(out_win, out_off, pl, a.plain);
             out_off += a.w;
         }
     }
@@ -2004,7 +2068,9 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     // re-applying it to an intermediate equals the K-box on the padded source.  A chain of rolling-kernel passes through one scratch
     // image and `dst` replaces the LDS-tile kernel: 9 x 9 1.20 -> 0.7 ms, 15 x 15 2.6 -> 1.1, 31 x 31 4.6 -> 2.0 per 32 4K images
     // (profiles/r06zl_morph_chain.txt).  Without scratch (stream capture and no registered workspace) the tile kernel keeps the call.
-    const bool gray_roll_ok = channels == 1 && w % 16 == 0 && w >= 16 && (int64_t)w * h <= kI32Max && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);
+    const bool gray_roll_ok = channels == 1 && w >= 16 && (int64_t)w * h <= kI32Max;
+    const bool gray_dword_ok = w % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
+    const bool gray_ragged = w % 16 != 0 || !gray_dword_ok;   // (round 6: any width / alignment on the RAGGED instantiation)
     if (any && box && !direct && !no_roll && (channels == 3 || gray_roll_ok) && kw == kh_ && (kw & 1) && kw >= 9 && kw <= 31 && border != KH_BORDER_WRAP && w >= 4 &&
         (int64_t)w * 3 < (1 << 24) && dev_opt(kOptMorphRoll) != 2) {
         int chain[8], nchain = 0, rem = kw;
@@ -2031,7 +2097,7 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     }
     if (any && shape >= 0 && !direct && !no_roll && gray_roll_ok && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && dev_opt(kOptMorphRoll) != 2) {
         // one channel, square box / cross / ellipse of 3 / 5 / 7, rows of whole 16-pixel groups: the rolling gray kernel (test option morph_roll = 2: the tile kernel)
-        MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], 0, 0}, XcdTiles{}, plain_row_stores((int64_t)w, dst, ds, batch)};
+        MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], 0, 0}, XcdTiles{}, gray_dword_ok ? plain_row_stores((int64_t)w, dst, ds, batch) : 2};
         const unsigned tiles_x = cdiv(w, kMgTilePx);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;
@@ -2042,17 +2108,19 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
         KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const dim3 grid = xcd_grid(r.tiles);
         const bool dil = op == KH_MORPH_DILATE;
-#define KH_MG_S(KK, SH)                                                                                      \
-    do {                                                                                                     \
-        if (dil) hipLaunchKernelGGL((morph_u8_gray_roll_kernel<KK, true, SH>), grid, dim3(256), 0, st, r);   \
-        else hipLaunchKernelGGL((morph_u8_gray_roll_kernel<KK, false, SH>), grid, dim3(256), 0, st, r);      \
+#define KH_MG_R(KK, SH, RG)                                                                                      \
+    do {                                                                                                         \
+        if (dil) hipLaunchKernelGGL((morph_u8_gray_roll_kernel<KK, true, SH, RG>), grid, dim3(256), 0, st, r);   \
+        else hipLaunchKernelGGL((morph_u8_gray_roll_kernel<KK, false, SH, RG>), grid, dim3(256), 0, st, r);      \
     } while (0)
+#define KH_MG_S(KK, SH) do { if (gray_ragged) KH_MG_R(KK, SH, true); else KH_MG_R(KK, SH, false); } while (0)
 #define KH_MG(KK) do { if (shape == kMsBox) KH_MG_S(KK, kMsBox); else if (shape == kMsCross) KH_MG_S(KK, kMsCross); else KH_MG_S(KK, kMsEllipse); } while (0)
         if (kw == 3) KH_MG(3);
         else if (kw == 5) KH_MG(5);
         else KH_MG(7);
 #undef KH_MG
 #undef KH_MG_S
+#undef KH_MG_R
         return check_launch(what);
     }
     if (any && shape >= 0 && !direct && !no_roll && channels == 3 && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && w >= 4 &&

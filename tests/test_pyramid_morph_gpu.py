@@ -256,6 +256,39 @@ def test_morphology_cross_and_ellipse_on_the_rolling_kernels(gpu_stream, dev_opt
             assert_same_bits(got[i], O.morphology_u8(src[i], "erode", mask, border, [200] * c), f"batch frame {i} c{c}")
 
 
+@pytest.mark.parametrize("border", ["constant", "replicate", "reflect101", "reflect"])
+@pytest.mark.parametrize("kshape", [("box", 3), ("box", 5), ("box", 7), ("cross", 5), ("ellipse", 7), ("box", 9)])
+def test_morphology_gray_ragged_widths(gpu_stream, dev_option, kshape, border):
+    """Single-channel widths that are not whole 16-pixel lanes run on the RAGGED instantiation of the rolling gray kernel (round 6): the
+    lane a row ends in re-indexes its sixteen loaded bytes, stores its first 1 .. 15, and rows off a dword leave through unaligned
+    stores.  The oracle's bytes for every residue of the width mod 16 next to a lane, wave and block seam, the narrowest rows, borders
+    that win or lose, destinations off a dword, a batch with an odd image stride; morph_roll = 2 keeps the tile kernel."""
+    shape, k = kshape
+    mask = O.morph_kernel(shape, k, k)
+    sizes = [(16 + r, 5) for r in range(1, 16)] + [(1024 + r, 3) for r in (-3, -1, 1, 2, 5, 8, 13)] + [(4096 + r, 3) for r in (-5, 3)] + [(1000, 40), (37, 90), (250, 7)]
+    for (w, h) in sizes:
+        src = make(w, h, 1, np.uint8, seed=w + h + k)
+        for op, cval in (("dilate", [250]), ("erode", [9])):
+            want = O.morphology_u8(src, op, mask, border, cval)
+            for opt in ((-1, 2) if w in (1000, 37, 1025) else (-1,)):
+                dev_option("morph_roll", opt)
+                assert_same_bits(morph_gpu(gpu_stream, src, op, mask, border, cval)[0], want, f"{op} gray {shape}{k} {border} {w}x{h} morph_roll={opt}")
+    dev_option("morph_roll", -1)
+    # a destination off a dword (the aligned 1024-pixel rows then take the unaligned stores too) and a batch whose images are 1001 * 7 bytes apart
+    from kornia_rs import _ffi
+    for (w, h, n) in [(1024, 6, 1), (1001, 7, 3)]:
+        src = np.stack([make(w, h, 1, np.uint8, seed=s_) for s_ in range(n)])
+        d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * w * h + 8)
+        m = np.ascontiguousarray(mask, np.uint8)
+        cv = (C.c_uint8 * 4)(77, 0, 0, 0)
+        _ffi.check(_ffi.lib.kh_morphology_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 3, w, h, 1, 0, m.ctypes.data_as(C.POINTER(C.c_uint8)), k, k,
+                                             O.BORDER[border], cv, n, w * h, w * h))
+        got = d_dst.to_numpy(np.uint8, (n * w * h + 8,))
+        assert got[:3].tolist() == [255] * 3 and got[3 + n * w * h:3 + n * w * h + 5].tolist() == [255] * 5, "bytes outside the destination were written"
+        for i in range(n):
+            assert_same_bits(got[3 + i * w * h:3 + (i + 1) * w * h].reshape(h, w, 1), O.morphology_u8(src[i], "dilate", mask, border, [77]), f"offset destination {w}x{h} frame {i}")
+
+
 def test_morphology_both_kernels_agree(gpu_stream, tmp_path):
     """KH_MORPH_DIRECT=1 selects the per-pixel kernel (read once per process): a child process runs it on the same inputs and the
     bytes must equal this process's tiled result."""
