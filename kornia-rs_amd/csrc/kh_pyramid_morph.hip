@@ -742,6 +742,8 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) 
 // source widths that are multiples of 16; byte-identical to the other kernels (same integers).
 constexpr int kPgRollWaveDst = 512;                  // destination pixels per wave (64 lanes x 8)
 constexpr int kPgRollTileDst = 4 * kPgRollWaveDst;   // per 256-thread block
+// RAGGED (round 6): any source width >= 16 and any alignment (remap16_* above); plain = 2: unaligned global stores.
+template <bool RAGGED>
 __global__ __launch_bounds__(256, 4) void pyrdown_u8_gray_roll_kernel(PyrRoll a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
@@ -753,7 +755,8 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_gray_roll_kernel(PyrRoll a)
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
     const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.dw * a.dh);   // (dw * dh < 2^31: host-checked)
     const int p = 2 * X0 + 16 * lane;                                 // this lane's source pixels p .. p + 15
-    const bool inside = p < a.sw;                                     // all sixteen or none (sw % 16 == 0: host-checked)
+    const int nvalid = min(max(a.dw - (X0 + 8 * lane), 0), 8);        // destination pixels of this lane (RAGGED: 0 .. 8; otherwise 0 or 8, sw % 16 == 0)
+    const bool inside = nvalid > 0;
     const int ph = lane < 32 ? 2 * X0 - 4 : 2 * X0 + 2 * kPgRollWaveDst;   // the wave's halo dwords: left in the lower half's lanes, right in the upper's
     const bool edge = 2 * X0 < 4 || 2 * X0 + 2 * kPgRollWaveDst + 4 > a.sw;   // wave-uniform
     const int pc = min(p, a.sw - 16), phc = min(max(ph, 0), a.sw - 4);
@@ -767,6 +770,8 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_gray_roll_kernel(PyrRoll a)
             selH |= (uint32_t)min(max(reflect_101(ph + j, a.sw) - phc, 0), 3) << (8 * j);
         }
     }
+    Remap16 rm{};
+    if (RAGGED && edge) rm = remap16_setup(p, pc, [&](int x) { return reflect_101(x, a.sw); });
     const int n = 2 * thr + 3;                                        // source rows walked: 2 Y0 - 2 .. 2 (Y0 + thr - 1) + 2
     int pf = 2 * Y0 - 2;
 
@@ -795,8 +800,11 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_gray_roll_kernel(PyrRoll a)
             uint32_t cur[4] = {q[slot][0], q[slot][1], q[slot][2], q[slot][3]}, halo = q[slot][4];
             prefetch(q[slot]);
             if (edge) {   // wave-uniform
-                const uint32_t beyond = __builtin_amdgcn_perm(0u, cur[3], esel);   // (of a lane past the row end: the loaded sixteen are the row's last)
-                cur[0] = inside ? cur[0] : beyond;
+                if constexpr (RAGGED) remap16_apply(rm, cur, 0u);
+                else {
+                    const uint32_t beyond = __builtin_amdgcn_perm(0u, cur[3], esel);   // (of a lane past the row end: the loaded sixteen are the row's last)
+                    cur[0] = inside ? cur[0] : beyond;
+                }
                 halo = __builtin_amdgcn_perm(0u, halo, selH);
             }
             const uint32_t prevd = from_lane_below(cur[3], halo), nextd = from_lane_above(cur[0], halo);
@@ -824,7 +832,11 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_gray_roll_kernel(PyrRoll a)
                     }
                     w[c] = __builtin_amdgcn_perm(v[1], v[0], 0x06040200u);   // four destination pixels
                 }
-                if (inside) row_store<2>(out_win, out_off, w, a.plain);
+                if constexpr (RAGGED) {
+                    if (nvalid == 8 && a.plain != 2) row_store<2>(out_win, out_off, w, a.plain);
+                    else if (nvalid == 8) *reinterpret_cast<u64_unaligned*>(dst + out_off) = ((uint64_t)w[1] << 32) | w[0];
+                    else if (nvalid > 0) { const uint32_t w4[4] = {w[0], w[1], 0u, 0u}; store_head_bytes(dst + out_off, w4, nvalid); }
+                } else if (inside) row_store<2>(out_win, out_off, w, a.plain);
                 out_off += a.dw;
             }
         }
@@ -1000,6 +1012,8 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) { 
 // For source widths that are multiples of 8; byte-identical to the other kernels.
 constexpr int kPuGrayWaveSrc = 512;                  // source pixels per wave (64 lanes x 8)
 constexpr int kPuGrayTileSrc = 4 * kPuGrayWaveSrc;
+// RAGGED (round 6): any source width >= 8 and any alignment — a lane's eight loaded bytes re-indexed by ONE v_perm_b32 per dword; plain = 2: unaligned stores.
+template <bool RAGGED>
 __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {   // th = SOURCE rows per strip
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
@@ -1011,7 +1025,8 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
     const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.dw * a.dh);   // (dw * dh < 2^31: host-checked)
     const int p = x0 + 8 * lane;                                      // this lane's source pixels p .. p + 7
-    const bool inside = p < a.sw;                                     // all eight or none (sw % 8 == 0: host-checked)
+    const int nvalid = min(max(a.sw - p, 0), 8);                      // source pixels of this lane (RAGGED: 0 .. 8; otherwise 0 or 8, sw % 8 == 0)
+    const bool inside = nvalid > 0;
     const int ph = lane < 32 ? x0 - 4 : x0 + kPuGrayWaveSrc;          // the wave's halo dwords: left in the lower half's lanes, right in the upper's
     const bool edge = x0 < 4 || x0 + kPuGrayWaveSrc + 4 > a.sw;       // wave-uniform
     const int pc = min(p, a.sw - 8), phc = min(max(ph, 0), a.sw - 4);
@@ -1022,6 +1037,15 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
         for (int j = 0; j < 4; ++j) {
             esel |= (uint32_t)min(max(reflect_101(p + j, a.sw) - (a.sw - 4), 0), 3) << (8 * j);
             hsel |= (uint32_t)min(max(reflect_101(ph + j, a.sw) - phc, 0), 3) << (8 * j);
+        }
+    }
+    uint32_t rsel[2] = {0x03020100u, 0x07060504u};   // RAGGED: lane byte j <- loaded byte reflect_101(p + j) - pc of the eight
+    if (RAGGED && edge) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            rsel[c] = 0;
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) rsel[c] |= (uint32_t)min(max(reflect_101(p + 4 * c + j2, a.sw) - pc, 0), 7) << (8 * j2);
         }
     }
     const int n = thr + 2;                                            // source rows walked: y0 - 1 .. y0 + thr
@@ -1054,8 +1078,13 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
             uint32_t cur[2] = {q[s][0], q[s][1]}, halo = q[s][2];
             prefetch(q[s]);
             if (edge) {   // wave-uniform
-                const uint32_t beyond = __builtin_amdgcn_perm(0u, cur[1], esel);   // (of a lane past the row end: the loaded eight are the row's last)
-                cur[0] = inside ? cur[0] : beyond;
+                if constexpr (RAGGED) {
+                    const uint32_t l0 = cur[0], l1 = cur[1];
+                    cur[0] = __builtin_amdgcn_perm(l1, l0, rsel[0]); cur[1] = __builtin_amdgcn_perm(l1, l0, rsel[1]);
+                } else {
+                    const uint32_t beyond = __builtin_amdgcn_perm(0u, cur[1], esel);   // (of a lane past the row end: the loaded eight are the row's last)
+                    cur[0] = inside ? cur[0] : beyond;
+                }
                 halo = __builtin_amdgcn_perm(0u, halo, hsel);
             }
             const uint32_t prevd = from_lane_below(cur[1], halo), nextd = from_lane_above(cur[0], halo);
@@ -1090,7 +1119,15 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
                     w[0][2 * c] = __builtin_amdgcn_perm(ve[1], ve[0], 0x05010400u); w[0][2 * c + 1] = __builtin_amdgcn_perm(ve[1], ve[0], 0x07030602u);   // e0 o0 e1 o1 | e2 o2 e3 o3
                     w[1][2 * c] = __builtin_amdgcn_perm(vo[1], vo[0], 0x05010400u); w[1][2 * c + 1] = __builtin_amdgcn_perm(vo[1], vo[0], 0x07030602u);
                 }
-                if (inside) {
+                if constexpr (RAGGED) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const int off = row_off + r * a.dw;
+                        if (nvalid == 8 && a.plain != 2) row_store<4>(out_win, off, w[r], a.plain);
+                        else if (nvalid == 8) *reinterpret_cast<u32x4_unaligned*>(dst + off) = u32x4_t{w[r][0], w[r][1], w[r][2], w[r][3]};
+                        else if (nvalid > 0) store_head_bytes(dst + off, w[r], 2 * nvalid);
+                    }
+                } else if (inside) {
                     row_store<4>(out_win, row_off, w[0], a.plain);
                     row_store<4>(out_win, row_off + a.dw, w[1], a.plain);
                 }
@@ -1918,9 +1955,10 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
         hipLaunchKernelGGL(pyrdown_u8_rgb_roll_kernel, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
         return check_launch("kh_pyrdown_u8");
     }
-    if (channels == 1 && sw % 16 == 0 && sw >= 16 && !no_roll && (int64_t)dw * dh <= kI32Max && reinterpret_cast<uintptr_t>(dst) % 4 == 0 &&
-        (batch <= 1 || ds % 4 == 0)) {   // one channel, rows of whole 16-pixel groups: the rolling gray kernel
-        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}, plain_row_stores((int64_t)dw * channels, dst, ds, batch)};
+    if (channels == 1 && sw >= 16 && !no_roll && (int64_t)dw * dh <= kI32Max) {   // one channel: the rolling gray kernel
+        const bool dword_ok = dw % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
+        const bool ragged = sw % 16 != 0 || !dword_ok;   // (round 6: any width / alignment on the RAGGED instantiation)
+        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}, dword_ok ? plain_row_stores((int64_t)dw, dst, ds, batch) : 2};
         const unsigned tiles_x = cdiv(dw, kPgRollTileDst);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
@@ -1929,7 +1967,8 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
         r.th = (int)cdiv(dh, strips);
         r.tiles = xcd_tiles(tiles_x, cdiv(dh, r.th), (unsigned)batch, kXcdEighth);
         KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrdown_u8: batch x tiles exceeds one launch");
-        hipLaunchKernelGGL(pyrdown_u8_gray_roll_kernel, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+        if (ragged) hipLaunchKernelGGL(pyrdown_u8_gray_roll_kernel<true>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+        else hipLaunchKernelGGL(pyrdown_u8_gray_roll_kernel<false>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
         return check_launch("kh_pyrdown_u8");
     }
     Pyr<uint8_t> a{src, dst, sw, sh, dw, dh, ss, ds, xcd_tiles(cdiv(dw, kPdTW), cdiv(dh, kPdTH), (unsigned)batch, cdiv(dw, kPdTW) * 4)};
@@ -1971,8 +2010,10 @@ int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_
                     int64_t ds) {
     const bool direct = dev_opt(kOptPyrDirect) == 1;
     const bool no_roll = dev_opt(kOptPyrRoll) == 0;
-    // one channel, rows of whole 8-pixel groups: the rolling gray kernel (16-byte stores: a dword-aligned destination)
-    const bool gray = channels == 1 && sw % 8 == 0 && sw >= 8 && (int64_t)sw * sh * 4 <= kI32Max && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);
+    // one channel: the rolling gray kernel
+    const bool gray = channels == 1 && sw >= 8 && (int64_t)sw * sh * 4 <= kI32Max;
+    const bool gray_dword_ok = sw % 2 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
+    const bool gray_ragged = sw % 8 != 0 || !gray_dword_ok;   // (round 6: any width / alignment on the RAGGED instantiation)
     if (direct || no_roll || !(channels == 3 || gray) || sw < 4 || (int64_t)sw * 6 >= (1 << 24)) return kh_pyrup_u8_pairs(stream, src, dst, sw, sh, channels, batch, ss, ds);
     const int dw = sw * 2, dh = sh * 2;
     if (int32_t rc = check_pyr("kh_pyrup_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
@@ -1987,7 +2028,9 @@ int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_
         r.th = (int)cdiv(sh, gstrips);
         r.tiles = xcd_tiles(gtiles_x, cdiv(sh, r.th), (unsigned)batch, kXcdEighth);
         KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrup_u8: batch x tiles exceeds one launch");
-        hipLaunchKernelGGL(pyrup_u8_gray_roll_kernel, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+        if (!gray_dword_ok) r.plain = 2;
+        if (gray_ragged) hipLaunchKernelGGL(pyrup_u8_gray_roll_kernel<true>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+        else hipLaunchKernelGGL(pyrup_u8_gray_roll_kernel<false>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
         return check_launch("kh_pyrup_u8");
     }
     const unsigned tiles_x = cdiv(sw, kPuRollTileSrc);

@@ -103,6 +103,33 @@ def test_pyrup_u8_gray_rolling_kernel(gpu_stream, dev_option):
         assert_same_bits(got[k], O.pyrup(batch[k]), f"pyrup u8 gray batch frame {k}")
 
 
+def test_pyramid_u8_gray_ragged_widths(gpu_stream, dev_option):
+    """Single-channel source widths that are not whole lanes (16 pixels for pyrdown, 8 for pyrup) run on the RAGGED instantiations of the
+    rolling gray kernels (round 6): every residue of the width next to a lane, wave and block seam, odd widths (pyrdown's last
+    destination pixel has one source pixel), the narrowest rows, destinations off a dword, a batch; pyr_roll = 0 keeps the old kernels."""
+    from kornia_rs import _ffi
+    down = [(16 + r, 5) for r in range(1, 16)] + [(1024 + r, 4) for r in (-3, -1, 1, 2, 5, 8, 13)] + [(4096 + r, 3) for r in (-5, 3)] + [(1000, 41), (37, 90), (251, 7)]
+    up = [(8 + r, 5) for r in range(1, 8)] + [(512 + r, 4) for r in (-3, -1, 1, 2, 5)] + [(2048 + r, 3) for r in (-5, 3)] + [(500, 41), (19, 90), (125, 7)]
+    for is_up, sizes in ((False, down), (True, up)):
+        for (w, h) in sizes:
+            src = make(w, h, 1, np.uint8, seed=w + h)
+            want = O.pyrup(src) if is_up else O.pyrdown(src)
+            for opt in ((-1, 0) if w in (1000, 37, 500, 19, 1025, 513) else (-1,)):
+                dev_option("pyr_roll", opt)
+                assert_same_bits(pyr_gpu(gpu_stream, src, is_up)[0], want, f"{'pyrup' if is_up else 'pyrdown'} u8 gray {w}x{h} pyr_roll={opt}")
+    dev_option("pyr_roll", -1)
+    for is_up, (w, h, n) in ((False, (1024, 6, 1)), (False, (1001, 7, 3)), (True, (512, 6, 1)), (True, (501, 7, 3))):
+        src = np.stack([make(w, h, 1, np.uint8, seed=s_) for s_ in range(n)])
+        dh, dw = (2 * h, 2 * w) if is_up else ((h + 1) // 2, (w + 1) // 2)
+        d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * dw * dh + 8)
+        fn = _ffi.lib.kh_pyrup_u8 if is_up else _ffi.lib.kh_pyrdown_u8
+        _ffi.check(fn(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 3, w, h, 1, n, w * h, dw * dh))   # a destination off a dword
+        got = d_dst.to_numpy(np.uint8, (n * dw * dh + 8,))
+        assert got[:3].tolist() == [255] * 3 and got[3 + n * dw * dh:3 + n * dw * dh + 5].tolist() == [255] * 5, "bytes outside the destination were written"
+        for i in range(n):
+            assert_same_bits(got[3 + i * dw * dh:3 + (i + 1) * dw * dh].reshape(dh, dw, 1), O.pyrup(src[i]) if is_up else O.pyrdown(src[i]), f"offset destination {'up' if is_up else 'down'} {w}x{h} frame {i}")
+
+
 def test_pyramid_batch_and_host_api(gpu_stream):
     from kornia_rs import Image, ImageError, imgproc
     n = 3
