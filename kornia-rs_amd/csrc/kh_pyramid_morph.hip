@@ -50,56 +50,6 @@ __device__ __forceinline__ int reflect_101(int p, int len) {  // pyramid.rs:252-
     return p >= len ? period - p : p;
 }
 
-// Ragged rows in the single-channel rolling kernels (round 6).  Those kernels give a lane SIXTEEN (pyrup: eight) pixels of a row with one
-// wide load and took only widths that are whole lanes; every other width fell to the tile kernels, 2.4-4x slower (1000-pixel rows,
-// profiles/r06zr_misaligned_rows.txt).  On a wave that reaches the row end every lane now loads the sixteen bytes at pc = min(p, w - 16)
-// and re-indexes them: lane byte j (pixel p + j) <- loaded byte map(p + j) - pc, or the border constant — which covers the lane the row
-// ends in (its own pixels shifted, then border pixels), the lane after it (border pixels only: what its neighbour's windows reach) and,
-// with identity selectors, every lane before.  Per output dword the four source indices lie within four consecutive bytes (ascending
-// pixels, a reflection, or one replicated pixel), i.e. in ONE of the dword pairs (L1:L0), (L2:L1), (L3:L2): three v_perm_b32 and two
-// selects with per-lane selectors computed once.
-struct Remap16 { uint32_t sel[4], cmask[4]; int k[4]; };
-template <class MapFn>
-__device__ __forceinline__ Remap16 remap16_setup(int p, int pc, MapFn map) {   // map(x): source pixel index, or < 0 for the constant
-    Remap16 r;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        int id[4], lo = 15;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = map(p + 4 * c + j);
-            id[j] = m < 0 ? -1 : min(max(m - pc, 0), 15);
-            lo = id[j] < 0 ? lo : min(lo, id[j]);
-        }
-        const int k = min(lo >> 2, 2);
-        uint32_t sel = 0, cm = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sel |= (uint32_t)(id[j] < 0 ? 0 : min(max(id[j] - 4 * k, 0), 7)) << (8 * j);
-            cm |= id[j] < 0 ? 0xffu << (8 * j) : 0u;
-        }
-        r.sel[c] = sel; r.cmask[c] = cm; r.k[c] = k;
-    }
-    return r;
-}
-__device__ __forceinline__ void remap16_apply(const Remap16& r, uint32_t (&L)[4], uint32_t cv) {
-    uint32_t o[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const uint32_t r0 = __builtin_amdgcn_perm(L[1], L[0], r.sel[c]), r1 = __builtin_amdgcn_perm(L[2], L[1], r.sel[c]), r2 = __builtin_amdgcn_perm(L[3], L[2], r.sel[c]);
-        const uint32_t v = r.k[c] == 0 ? r0 : (r.k[c] == 1 ? r1 : r2);
-        o[c] = (v & ~r.cmask[c]) | (cv & r.cmask[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) L[c] = o[c];
-}
-// the first `n` (1..15) bytes of four dwords to a byte-aligned address (the lane a ragged row ends in)
-__device__ __forceinline__ void store_head_bytes(uint8_t* o, const uint32_t (&w)[4], int n) {
-#pragma unroll
-    for (int b = 0; b < 15; ++b)
-        if (b < n) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
-}
-
 // pyrdown_f32 (:312-430): 5x5 outer-product taps, ky-major accumulation, reflect-101 border.
 // (Round 3 tried sharing source pixels along the wave — a lane loads only its own pair and takes the other three pixels from the
 // lanes either side by DPP shifts, 10 full-wave loads per pixel instead of 25: 2.53 ms against this kernel's 2.22 on one box,

@@ -378,6 +378,131 @@ __global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8F
     }
 }
 
+// ---- single-channel blur, rolling wave (round 6) -----------------------------------------------------------------------------------
+// Gray u8 images (what feature detectors smooth) took blur_u8_roll_kernel at 0.33-0.53 of peak; one plane needs no de-interleaving at
+// all.  The walk of the RGB kernel above with a lane owning SIXTEEN pixels of a row (one 16-byte load and store, 1 KiB per wave and
+// row): each of its four dwords is the RGB kernel's channel dword — the same v_dot4_u32_u8 row pass on the twelve-byte string
+// (previous dword | this dword | next dword), the same 16-bit-lane pair form and 24-bit multiply-add column pass, the binomial's
+// rounding halving adds — with the dword before the lane's first and after its last from the neighbouring lanes by wave shifts and,
+// at the ends of the wave, from one halo dword per half-wave.  Replicate borders: rows by clamping the row index, columns (edge
+// waves) by re-indexing.  RAGGED: any width >= 16 and any alignment (kh_common.h::remap16_*; plain = 2: unaligned global stores).
+// Same integers as the other kernels: byte-identical (tests run both).  3..9 taps per axis whose quantised taps sum to <= 256.
+constexpr int kGrayWavePx = 1024, kGrayTilePx = 4 * kGrayWavePx;
+template <int K, bool BINOMIAL, bool RAGGED>
+__global__ __launch_bounds__(kBlock, K <= 3 ? 6 : (K <= 5 ? 5 : (K <= 7 ? 4 : 3))) void blur_u8_gray_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky, int plain) {
+    static_assert(!BINOMIAL || K == 3, "the binomial is 3 x 3");
+    constexpr int H = K / 2, G = (K + 3) / 4;   // taps are consumed four at a time
+    static_assert(K >= 3 && K <= 9 && (K & 1), "3..9 taps: one neighbour dword on each side covers the window");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned tx, ty, bz;
+    if (!xcd_tile(a.tiles, tx, ty, bz)) return;
+    const int p0 = (int)tx * kGrayTilePx + wv * kGrayWavePx;   // first output pixel of this wave
+    if (p0 >= a.cols) return;                                 // whole wave idle (no block barrier below)
+    const int y0 = ty * a.th;
+    const uint8_t* __restrict__ src = a.src + (long long)bz * a.src_stride;
+    uint8_t* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
+    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.rows * a.cols);   // (rows * cols < 2^31: host-checked)
+    const int p = p0 + 16 * lane;                             // this lane's sixteen pixels
+    const int nvalid = min(max(a.cols - p, 0), 16);           // RAGGED: 0 .. 16; otherwise all sixteen or none (cols % 16 == 0: host-checked)
+    const int ph = lane < 32 ? p0 - 4 : p0 + kGrayWavePx;     // the wave's halo dwords: left in the lower half's lanes, right in the upper's
+    const bool edge = p0 < 4 || p0 + kGrayWavePx + 4 > a.cols;   // wave-uniform
+    const int pc = min(p, a.cols - 16), phc = min(max(ph, 0), a.cols - 4);   // cols >= 16: host-checked
+    uint32_t hsel = 0x03020100u;
+    Remap16 rm{};
+    if (edge) {
+        hsel = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hsel |= (uint32_t)min(max(min(max(ph + j, 0), a.cols - 1) - phc, 0), 3) << (8 * j);
+        if constexpr (RAGGED) rm = remap16_setup(p, pc, [&](int x) { return min(x, a.cols - 1); });
+    }
+    const int nrows = min(a.th, a.rows - y0) + 2 * H;
+    int pf_row = y0 - H;
+
+    uint32_t wq[3];   // horizontal taps as bytes, four per dword (zero padded): tap t = byte t & 3 of wq[t >> 2]
+#pragma unroll
+    for (int g = 0; g < 3; ++g) wq[g] = kx.k[4 * g] | (kx.k[4 * g + 1] << 8) | (kx.k[4 * g + 2] << 16) | (kx.k[4 * g + 3] << 24);
+
+    uint32_t q[K][5];  // K rows of raw loads in flight per lane: its sixteen pixels and its half-wave's halo dword
+    auto prefetch = [&](uint32_t (&d)[5]) {
+        const uint8_t* rp = src + (long long)min(max(pf_row, 0), a.rows - 1) * a.cols;   // replicate rows
+        const u32x4_t v = *reinterpret_cast<const u32x4_unaligned*>(rp + pc);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        d[4] = *reinterpret_cast<const u32u*>(rp + phc);
+        ++pf_row;
+    };
+#pragma unroll
+    for (int i = 0; i < K; ++i) prefetch(q[i]);
+
+    uint32_t ring[K][4][2];  // [row][dword][even / odd pixel pair], 16-bit lanes (binomial: [0] = the packed row)
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ring[i][c][0] = 0; ring[i][c][1] = 0; }
+
+    int out_off = (y0 - 2 * H) * a.cols + p;
+    for (int rb = 0; rb < nrows; rb += K) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const int r = rb + s;
+            uint32_t cur[4] = {q[s][0], q[s][1], q[s][2], q[s][3]}, halo = q[s][4];
+            prefetch(q[s]);
+            if (edge) {   // wave-uniform
+                if constexpr (RAGGED) remap16_apply(rm, cur, 0u);
+                else cur[0] = nvalid ? cur[0] : __builtin_amdgcn_perm(0u, cur[3], 0x03030303u);   // a lane past the row end: the row's last pixel, replicated
+                halo = __builtin_amdgcn_perm(0u, halo, hsel);
+            }
+            const uint32_t prevd = from_lane_below(cur[3], halo), nextd = from_lane_above(cur[0], halo);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t prev = c == 0 ? prevd : cur[c - 1], next = c == 3 ? nextd : cur[c + 1];
+                if constexpr (BINOMIAL) {
+                    const uint32_t lft = __builtin_amdgcn_alignbyte(cur[c], prev, 3u), rgt = __builtin_amdgcn_alignbyte(next, cur[c], 1u);
+                    ring[s][c][0] = rhadd4(rhadd4(lft, cur[c]), rhadd4(cur[c], rgt));
+                    continue;
+                }
+                const uint32_t str[4] = {prev, cur[c], next, next};   // bytes 0..11 = pixels -4 .. +7 of this dword (+ a don't-care dword)
+                uint32_t sum[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t acc = 128u;   // the reference's rounding half
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        constexpr int kBase = 4 - H;
+                        const int off = kBase + j + 4 * g;   // compile-time after unrolling: first byte of this group of four taps
+                        const uint32_t win = (off & 3) == 0 ? str[off >> 2] : __builtin_amdgcn_alignbyte(str[(off >> 2) + 1], str[off >> 2], (uint32_t)(off & 3));
+                        acc = __builtin_amdgcn_udot4(win, wq[g], acc, false);
+                    }
+                    sum[j] = acc;   // < 2^16: the taps sum to <= 256
+                }
+                ring[s][c][0] = __builtin_amdgcn_perm(sum[2], sum[0], 0x0c050c01u);   // (sum >> 8) of pixels (0, 2) in 16-bit lanes
+                ring[s][c][1] = __builtin_amdgcn_perm(sum[3], sum[1], 0x0c050c01u);   // and of pixels (1, 3)
+            }
+            uint32_t pl[4];   // vertical pass, four pixels per dword again
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if constexpr (BINOMIAL) {   // rows oldest first: s + 1, s + 2, s (mod 3)
+                    const uint32_t r0 = ring[(s + 1) % K][c][0], r1 = ring[(s + 2) % K][c][0], r2 = ring[s][c][0];
+                    pl[c] = rhadd4(rhadd4(r0, r1), rhadd4(r1, r2));
+                    continue;
+                }
+                uint32_t oe = 0x00800080u, oo = 0x00800080u;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {   // oldest row first
+                    oe = mad24(ring[(s + 1 + i) % K][c][0], ky.k[i], oe);
+                    oo = mad24(ring[(s + 1 + i) % K][c][1], ky.k[i], oo);
+                }
+                pl[c] = __builtin_amdgcn_perm(oo, oe, 0x07030501u);   // (oe.b1, oo.b1, oe.b3, oo.b3) = pixels 0, 1, 2, 3
+            }
+            if (r >= 2 * H && r < nrows) {
+                if (nvalid == 16 && (!RAGGED || plain != 2)) row_store<4>(out_win, out_off, pl, plain);
+                else if (nvalid == 16) *reinterpret_cast<u32x4_unaligned*>(dst + out_off) = u32x4_t{pl[0], pl[1], pl[2], pl[3]};
+                else if (RAGGED && nvalid > 0) store_head_bytes(dst + out_off, pl, nvalid);
+            }
+            out_off += a.cols;
+        }
+    }
+}
+
 // Fallback for what the rolling kernel does not take (kernels wider than 15 taps, halos beyond 32
 // bytes, rows shorter than 4 bytes): one Q8 pass per launch through a scratch image, one thread per
 // byte — the reference's own structure (P/cuda/filter.rs:116-165).
@@ -535,7 +660,11 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         for (int i = 0; i < 16; ++i) { sxq += px.k[i]; syq += py.k[i]; }
         const bool rgb_off = dev_opt(kOptU8BlurRgb) == 0;   // test option: the interleaved kernel (what the other channel counts take)
         const bool rgb = C == 3 && K <= 9 && (binomial ? K == 3 : (sxq <= 256 && syq <= 256)) && cols >= 4 && !rgb_off;
-        const unsigned tiles_x = rgb ? cdiv(cols, kRgbTilePx) : cdiv(rowlen, kU8Tile);
+        // one channel, 3..9 taps: the rolling gray kernel (round 6; the same test option keeps the interleaved kernel)
+        const bool gray = C == 1 && K <= 9 && (binomial ? K == 3 : (sxq <= 256 && syq <= 256)) && cols >= 16 && (int64_t)rows * cols <= kI32Max && !rgb_off;
+        const bool gray_dword_ok = cols % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
+        const bool gray_ragged = cols % 16 != 0 || !gray_dword_ok;
+        const unsigned tiles_x = rgb ? cdiv(cols, kRgbTilePx) : (gray ? cdiv(cols, kGrayTilePx) : cdiv(rowlen, kU8Tile));
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;  // >= 8 blocks per CU
         const long long min_strips = cdiv(rows, kU8StripMax), max_strips = cdiv(rows, 32);
@@ -543,6 +672,20 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         a.th = (int)cdiv(rows, strips);
         a.tiles = xcd_tiles(tiles_x, cdiv(rows, a.th), (unsigned)batch, kXcdEighth);
         KH_REQUIRE(a.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+        if (gray) {
+            const dim3 grid = xcd_grid(a.tiles);
+            const int plain = gray_dword_ok ? plain_row_stores((int64_t)cols, dst, ds, batch) : 2;
+#define KH_GB(KK, BIN) do { if (gray_ragged) hipLaunchKernelGGL((blur_u8_gray_kernel<KK, BIN, true>), grid, dim3(kBlock), 0, st, a, px, py, plain); \
+                            else hipLaunchKernelGGL((blur_u8_gray_kernel<KK, BIN, false>), grid, dim3(kBlock), 0, st, a, px, py, plain); } while (0)
+            switch (K) {
+                case 3: if (binomial) KH_GB(3, true); else KH_GB(3, false); break;
+                case 5: KH_GB(5, false); break;
+                case 7: KH_GB(7, false); break;
+                default: KH_GB(9, false); break;
+            }
+#undef KH_GB
+            return check_launch(what);
+        }
         if (rgb) {
             const dim3 grid = xcd_grid(a.tiles);
             switch (K) {

@@ -122,6 +122,37 @@ def test_blur_u8_binomial_planar_kernel(gpu_stream, dev_option):
         assert_same_bits(got[k], O.gaussian_blur_u8(src[k], (3, 3), (0.8, 0.8))[0], f"frame {k}")
 
 
+@pytest.mark.parametrize("k", [3, 5, 7, 9])
+def test_blur_u8_gray_rolling_kernel(gpu_stream, dev_option, k):
+    """Single-channel images take the rolling gray kernel for 3..9 taps (sixteen pixels per lane, 1024 per wave, 4096 per block; round 6),
+    widths that are not whole lanes — or destinations off a dword — its RAGGED instantiation: the oracle's bytes for every residue of
+    the width mod 16, either side of the lane / wave / block seams, rows fewer than taps, the binomial band and sigmas just outside it,
+    box kernels, unequal tap counts, a batch, a destination at an odd address; u8_blur_rgb = 0 keeps the interleaved kernel."""
+    from kornia_rs import _ffi
+    sizes = [(16 + r, 5) for r in range(0, 16)] + [(1024 + r, 3) for r in (-16, -3, -1, 0, 1, 2, 5, 8, 13, 16)] + [(4096 + r, 3) for r in (-5, 0, 3)] + [(1000, 41), (37, 90), (3840, 9), (64, 1), (48, 2)]
+    sigmas = ((0.3 * k, 0.2 * k + 0.5),) if k > 3 else ((1.0, 1.0), (0.6, 1.2), (0.59, 1.3), (0.9, 0.45))
+    for w, h in sizes:
+        src = pat(w, h, 1, seed=w * 7 + h)
+        for sig in sigmas:
+            want = O.gaussian_blur_u8(src, (k, k), sig)[0]
+            for opt in ((-1, 0) if w in (1000, 37, 1025, 16, 4096) else (-1,)):
+                dev_option("u8_blur_rgb", opt)
+                assert_same_bits(blur_gpu(gpu_stream, "gaussian", src, (k, k), sig)[0], want, f"gaussian {k} sigma {sig} gray {w}x{h} u8_blur_rgb={opt}")
+        dev_option("u8_blur_rgb", -1)
+    for w, h in [(1030, 40), (1040, 7)]:
+        src = pat(w, h, 1, seed=5)
+        assert_same_bits(blur_gpu(gpu_stream, "box", src, (k, k))[0], O.box_blur_u8(src, (k, k)), f"box {k} gray {w}")
+        assert_same_bits(blur_gpu(gpu_stream, "gaussian", src, (k, 3), (1.5, 0.8))[0], O.gaussian_blur_u8(src, (k, 3), (1.5, 0.8))[0], f"gaussian {k}x3 gray {w}")
+    for (w, h, n) in [(1024, 6, 1), (1001, 7, 3)]:
+        src = np.stack([pat(w, h, 1, seed=s_) for s_ in range(n)])
+        d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * w * h + 8)
+        _ffi.check(_ffi.lib.kh_gaussian_blur_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 3, w, h, 1, k, k, 1.1, 1.1, n, w * h, w * h))
+        got = d_dst.to_numpy(np.uint8, (n * w * h + 8,))
+        assert got[:3].tolist() == [255] * 3 and got[3 + n * w * h:3 + n * w * h + 5].tolist() == [255] * 5, "bytes outside the destination were written"
+        for i in range(n):
+            assert_same_bits(got[3 + i * w * h:3 + (i + 1) * w * h].reshape(h, w, 1), O.gaussian_blur_u8(src[i], (k, k), (1.1, 1.1))[0], f"offset destination {w}x{h} frame {i}")
+
+
 def test_blur_u8_batch_4k_strip_and_errors(gpu_stream):
     from kornia_rs import _ffi
     n = 3
