@@ -1602,6 +1602,9 @@ int32_t kh_remap_u8(kh_stream_t stream, const uint8_t* src, const float* map_x, 
     if (mode == KH_INTERP_BILINEAR && use_staged_gather(sw, sh)) {
         GatherOp op{nullptr, map_x, map_y, 0, 0, batch};
         op.tile_rows = 16;   // a correction map is close to the identity
+        // one channel (round 6, profiles/r06zu_warp_gray_tiles.txt): a 64-pixel tile row is HALF a cache line; 128 x 8 tiles 0.194 -> 0.146 ms per
+        // 16 4K planes (RGB / RGBA: +-3 %, they keep 64 x 16)
+        if (channels == 1) op.tile_rows = 8;
         return launch_staged_gather<kOpRemap>(as_hip(stream), src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, op, "kh_remap_u8");
     }
     const ImgU8 im = make_img_u8(src, dst, sw, sh, dw, dh, src_stride, dst_stride, (batch + kU8RemapNB - 1) / kU8RemapNB);
@@ -1640,6 +1643,10 @@ int32_t kh_warp_affine_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     if (use_staged_gather(sw, sh)) {
         GatherOp op{rows, nullptr, nullptr, dsx_q, dsy_q, batch};
         op.tile_rows = stage_rows(mi.m[0], mi.m[1], mi.m[3], mi.m[4]);
+        if (channels == 1 && op.tile_rows == 16) {   // one channel: whole 128-byte tile rows where the box of a 128 x 8 tile still fits two staging rounds
+            const float bw = 128.0f * fabsf(mi.m[0]) + 8.0f * fabsf(mi.m[1]) + 2.0f, bh = 128.0f * fabsf(mi.m[3]) + 8.0f * fabsf(mi.m[4]) + 2.0f;
+            if (bw < 1e6f && bh < 1e6f && (ceilf(bw * 0.25f) + 1.0f) * ceilf(bh) <= 512.0f) op.tile_rows = 8;
+        }
         return launch_staged_gather<kOpAffine>(as_hip(stream), src, dst, sw, sh, dw, dh, channels, batch, src_stride, dst_stride, op, "kh_warp_affine_u8");
     }
     KH_DISPATCH_C(warp_affine_u8_kernel, channels, xcd_grid(im.tiles), as_hip(stream), im, (const AffineRow*)rows, dsx_q, dsy_q);

@@ -13,6 +13,10 @@ import bench
 lib, check = _ffi.lib, _ffi.check
 hip.set_device(0); st = hip.Stream.new(0)
 s = st.cuda_stream_ptr
+for arg in sys.argv[1:]:
+    name, val = arg.split("=")
+    check(lib.kh_debug_set_option(name.encode(), int(val)))
+    print(f"# dev option {name} = {val}")
 def timeit(fn):
     rc = fn()
     if rc != 0:
