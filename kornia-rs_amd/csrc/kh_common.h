@@ -144,7 +144,7 @@ __device__ __forceinline__ T* list_dst(const PtrList& l, bool listed, T* base, l
 // the library at all.
 enum DevOpt : int {
     kOptPreIeeeDiv, kOptPreGrid, kOptPreQuads, kOptFilterForceTile, kOptFilterFourColumns, kOptGradScalar, kOptHfilterDirect,
-    kOptResizeU8Gather, kOptPyrDirect, kOptPyrRoll, kOptMorphDirect, kOptMorphRoll, kOptU8BlurRgb, kOptU8BlurSwar, kOptWarpU8Direct, kOptWarpU8Spans, kOptWarpU8Rows, kOptResizeRows, kOptWarpF32Px, kOptResizeU8Px, kOptRowStores,
+    kOptResizeU8Gather, kOptPyrDirect, kOptPyrRoll, kOptMorphDirect, kOptMorphRoll, kOptU8BlurRgb, kOptU8BlurSwar, kOptWarpU8Direct, kOptWarpU8Spans, kOptWarpU8Rows, kOptResizeRows, kOptWarpF32Px, kOptResizeU8Px, kOptRowStores, kOptPreF16Lut,
     kOptCount
 };
 int dev_opt(DevOpt o);               // kh_runtime.hip: the calling thread's value

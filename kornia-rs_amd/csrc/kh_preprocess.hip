@@ -753,11 +753,18 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity_list(FrameL
 // is still 16 bytes (eight binary16 values; a wave writes 1 KiB contiguous per plane): the f32 kernel's store shape at half the output
 // bytes.  Same integer decode, same `(x / 255 - m) * is`, then the reference's f32 -> f16 rounding: 2.75 ms (profiles/r06ze_f16_identity.txt;
 // 64-bit source loads instead of pairs of dwords: 2.73, not taken).
+// LUT (round 6): the kernel above it is bound by its vector ALUs as much as by memory (250 instructions per thread; the f32 kernel's
+// store stream is half as long here).  `(x / 255 - m_c) * is_c` rounded to binary16 depends on the clamped 8-bit channel value only: each
+// block builds the 3 x 256 table once in LDS with the very expressions it replaces (two entries per thread of the first six waves), and a
+// channel value then costs its integer decode and ONE ds_read_u16 instead of nine float instructions.
+template <bool LUT>
 __device__ __forceinline__ void nv12_identity_f16_body(const uint8_t* __restrict__ src_frame, unsigned short* __restrict__ dst_frame, const PreArgs& a) {
+    __shared__ unsigned short lut[LUT ? 768 : 2];
     const int wo = a.src_w >> 3;     // 8-pixel groups per row
     const int groups = wo * a.src_h;
-    const int g = blockIdx.x * kIdBlock + threadIdx.x;
-    if (g >= groups) return;
+    const int g0 = blockIdx.x * kIdBlock + threadIdx.x;
+    if (!LUT && g0 >= groups) return;
+    const int g = LUT ? min(g0, groups - 1) : g0;   // (LUT: every thread reaches the barrier; the tail's stores are dropped below)
     const int plane = a.src_w * a.src_h;
     const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(src_frame, (uint32_t)(plane + plane / 2));
     const __amdgpu_buffer_rsrc_t rdst = buffer_rsrc(dst_frame, (uint32_t)(6 * plane));
@@ -768,6 +775,15 @@ __device__ __forceinline__ void nv12_identity_f16_body(const uint8_t* __restrict
     for (int q = 0; q < 2; ++q) {
         y4[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, r * a.src_w + 8 * xo + 4 * q, 0, 0);
         uv4[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, plane + (r >> 1) * a.src_w + 8 * xo + 4 * q, 0, 0);
+    }
+    if constexpr (LUT) {   // after the loads were issued: the table does not depend on them
+        const int t = threadIdx.x;
+        if (t < 384) {
+            const int c = t >> 7, x = 2 * (t & 127);
+            const float m = c == 0 ? a.m0 : (c == 1 ? a.m1 : a.m2), is = c == 0 ? a.is0 : (c == 1 ? a.is1 : a.is2);
+            reinterpret_cast<uint32_t*>(lut)[t] = pack_h2((div255_u8((float)x) - m) * is, (div255_u8((float)(x + 1)) - m) * is);
+        }
+        __syncthreads();
     }
     u32x4_t o[3];
 #pragma unroll
@@ -780,6 +796,23 @@ __device__ __forceinline__ void nv12_identity_f16_body(const uint8_t* __restrict
             tb[k] = kCUB * u + kHalf20;
             tg[k] = kCUG * u + kCVG * v + kHalf20;
             tr[k] = kCVR * v + kHalf20;
+        }
+        if constexpr (LUT) {
+            unsigned short hv[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yy = max((int)((y4[q] >> (8 * j)) & 0xFFu) - 16, 0) * kCY;
+                const int k = j >> 1;
+                hv[0][j] = lut[clamp255((yy + tr[k]) >> 20)];
+                hv[1][j] = lut[256 + clamp255((yy + tg[k]) >> 20)];
+                hv[2][j] = lut[512 + clamp255((yy + tb[k]) >> 20)];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                o[c][2 * q] = (uint32_t)hv[c][0] | ((uint32_t)hv[c][1] << 16);
+                o[c][2 * q + 1] = (uint32_t)hv[c][2] | ((uint32_t)hv[c][3] << 16);
+            }
+            continue;
         }
         float f[3][4];
 #pragma unroll
@@ -803,16 +836,18 @@ __device__ __forceinline__ void nv12_identity_f16_body(const uint8_t* __restrict
     }
     asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));  // all twenty-four values exist here: the stores issue back to back
 #pragma unroll
-    for (int c = 0; c < 3; ++c) __builtin_amdgcn_raw_buffer_store_b128(o[c], rdst, 16 * g + c * (2 * plane), 0, kAuxStream);
+    for (int c = 0; c < 3; ++c) __builtin_amdgcn_raw_buffer_store_b128(o[c], rdst, g0 < groups ? 16 * g + c * (2 * plane) : 0x7ffffff0, 0, kAuxStream);   // (past the V#'s range: dropped)
 }
+template <bool LUT>
 __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity_f16(
     const uint8_t* __restrict__ src_base, unsigned short* __restrict__ dst_base, PreArgs a) {
     const unsigned frame = blockIdx.y;
-    nv12_identity_f16_body(src_base + (long long)frame * a.src_frame_stride, dst_base + (long long)frame * a.dst_frame_stride, a);
+    nv12_identity_f16_body<LUT>(src_base + (long long)frame * a.src_frame_stride, dst_base + (long long)frame * a.dst_frame_stride, a);
 }
+template <bool LUT>
 __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity_f16_list(FrameList fl, unsigned short* __restrict__ dst_base, PreArgs a) {
     const unsigned frame = blockIdx.y;
-    nv12_identity_f16_body(fl.p[frame], dst_base + (long long)frame * a.dst_frame_stride, a);
+    nv12_identity_f16_body<LUT>(fl.p[frame], dst_base + (long long)frame * a.dst_frame_stride, a);
 }
 
 // Lanczos axis-weight tables: wx[dst_w][6] then wy[dst_h][6], cached per (device, geometry) like the reference's tap tables
@@ -1111,8 +1146,11 @@ int32_t preprocess_impl(kh_stream_t stream, const Frames& f, void* dst, const kh
         void* dst_chunk = static_cast<char*>(dst) + (size_t)first * (size_t)p->dst_frame_stride * out_elem;
         if (identity && p->out_dtype == KH_OUT_F16) {
             const unsigned bpf = cdiv((p->src_w / 8) * p->src_h, kIdBlock);
-            if (f.listed()) hipLaunchKernelGGL(preprocess_nv12_identity_f16_list, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, fl, (unsigned short*)dst_chunk, a);
-            else hipLaunchKernelGGL(preprocess_nv12_identity_f16, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, f.src, (unsigned short*)dst_chunk, a);
+            const bool lut = dev_opt(kOptPreF16Lut) != 0;   // the table kernel (test option pre_f16_lut = 0: the arithmetic one); 2.73 -> 2.57 ms per 1024 frames, profiles/r06zv_f16_lut.txt
+            if (f.listed() && lut) hipLaunchKernelGGL(preprocess_nv12_identity_f16_list<true>, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, fl, (unsigned short*)dst_chunk, a);
+            else if (f.listed()) hipLaunchKernelGGL(preprocess_nv12_identity_f16_list<false>, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, fl, (unsigned short*)dst_chunk, a);
+            else if (lut) hipLaunchKernelGGL(preprocess_nv12_identity_f16<true>, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, f.src, (unsigned short*)dst_chunk, a);
+            else hipLaunchKernelGGL(preprocess_nv12_identity_f16<false>, dim3(bpf, (unsigned)n), dim3(kIdBlock), 0, s, f.src, (unsigned short*)dst_chunk, a);
             rc = check_launch("preprocess_nv12_identity_f16");
         } else if (identity) {
             const int groups = (p->src_w / 4) * p->src_h;

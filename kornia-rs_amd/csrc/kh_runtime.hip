@@ -147,7 +147,7 @@ uint32_t kh_debug_fast_quot(uint32_t n, uint32_t d) { return kh::fast_quot(n, kh
 int32_t kh_debug_set_option(const char* name, int32_t value) {
     static const char* const names[kh::kOptCount] = {
         "pre_ieee_div", "pre_grid", "pre_quads", "filter_force_tile", "filter_four_columns", "grad_scalar", "hfilter_direct",
-        "resize_u8_gather", "pyr_direct", "pyr_roll", "morph_direct", "morph_roll", "u8_blur_rgb", "u8_blur_swar", "warp_u8_direct", "warp_u8_spans", "warp_u8_rows", "resize_rows", "warp_f32_px", "resize_u8_px", "row_stores"};
+        "resize_u8_gather", "pyr_direct", "pyr_roll", "morph_direct", "morph_roll", "u8_blur_rgb", "u8_blur_swar", "warp_u8_direct", "warp_u8_spans", "warp_u8_rows", "resize_rows", "warp_f32_px", "resize_u8_px", "row_stores", "pre_f16_lut"};
     if (name)
         for (int i = 0; i < kh::kOptCount; ++i)
             if (strcmp(name, names[i]) == 0) {

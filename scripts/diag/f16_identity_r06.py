@@ -10,6 +10,10 @@ from kornia_rs import Preprocessor, Tensor, hip
 from kornia_rs.hip import DeviceBuffer, lib, check
 import bench
 hip.set_device(0); st = hip.Stream.new(0)
+for arg in sys.argv[1:]:   # name=value dev options
+    name, val = arg.split("=")
+    check(lib.kh_debug_set_option(name.encode(), int(val)))
+    print(f"# dev option {name} = {val}")
 N, W, H = 1024, 1920, 1080
 fb = W * H * 3 // 2
 base = bench.lcg_bytes(fb + 31 * N)

@@ -22,7 +22,7 @@ def test_unknown_option_is_a_typed_error(gpu_stream):
     assert "no_such_option" in _ffi.last_error()
     assert _ffi.lib.kh_debug_set_option(None, 1) == _ffi.KH_ERR_INVALID_ARG
     for name in (b"pre_ieee_div", b"pre_grid", b"pre_quads", b"filter_force_tile", b"filter_four_columns", b"grad_scalar", b"hfilter_direct",
-                 b"resize_u8_gather", b"pyr_direct", b"pyr_roll", b"morph_direct", b"morph_roll", b"u8_blur_rgb", b"u8_blur_swar", b"warp_u8_direct", b"warp_u8_spans", b"warp_u8_rows", b"resize_rows", b"warp_f32_px", b"resize_u8_px", b"row_stores"):
+                 b"resize_u8_gather", b"pyr_direct", b"pyr_roll", b"morph_direct", b"morph_roll", b"u8_blur_rgb", b"u8_blur_swar", b"warp_u8_direct", b"warp_u8_spans", b"warp_u8_rows", b"resize_rows", b"warp_f32_px", b"resize_u8_px", b"row_stores", b"pre_f16_lut"):
         assert _ffi.lib.kh_debug_set_option(name, -1) == _ffi.KH_OK, name
 
 

@@ -226,14 +226,16 @@ def test_nv12_identity_batch_1080p(gpu_stream):
         assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), f"frame {k}"
 
 
-@pytest.mark.parametrize("w,h", [(64, 32), (1920, 1080), (24, 6), (8, 2), (20, 6)])
+@pytest.mark.parametrize("lut", [-1, 0])   # production: the per-block table of binary16 results (round 6); 0: the arithmetic kernel
+@pytest.mark.parametrize("w,h", [(64, 32), (1920, 1080), (24, 6), (8, 2), (20, 6), (4104, 2)])
 @pytest.mark.parametrize("sampling", ["bilinear", "nearest"])
-def test_nv12_identity_f16_fast_path_equals_generic_and_oracle(gpu_stream, w, h, sampling):
+def test_nv12_identity_f16_fast_path_equals_generic_and_oracle(gpu_stream, dev_option, w, h, sampling, lut):
     """run_raw_f16 on the north-star geometry (P/preprocess.rs:1234-1256): since round 6 its own kernel — eight pixels per thread, three
     16-byte stores of eight binary16 values — where the width is a multiple of eight; the oracle's bits, the generic kernel's bits
     (forced), and a width of 20 (not a multiple of eight) keeps the generic kernel."""
     import ctypes as C
     from kornia_rs import _ffi
+    dev_option("pre_f16_lut", lut)
     raw = _raw_for("nv12", w, h, seed=5)
     kw = dict(fmt="nv12", mode="stretch", sampling=sampling, f16=True, **IMAGENET)
     fast = _run(gpu_stream, raw, w, h, w, h, **kw)
