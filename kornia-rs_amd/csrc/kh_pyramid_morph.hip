@@ -1310,14 +1310,44 @@ struct MorphRoll {
     uint8_t* dst;
     int w, h, th, border;
     long long ss, ds;
-    uint32_t cval[3];
+    uint32_t cval[4];
     XcdTiles tiles;
     int plain;                // write-back instead of streaming stores (kh_common.h::plain_row_stores)
 };
 constexpr int kMrWavePx = 256, kMrTilePx = 4 * kMrWavePx;
 
-template <int K, bool DILATE, int SHAPE = kMsBox>
-__global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_rgb_roll_kernel(MorphRoll a) {   // a register target for the scheduler: 5 x 5 105 -> <= 96, 7 x 7 137 -> <= 128 VGPRs
+// C = 4 (round 6): RGBA / BGRA images took the LDS-tile kernel at 0.40 of peak.  The same kernel with a 16-byte quad per lane (one load and
+// one store of whole pixels, 1 KiB per wave and row), de-interleaved into four channel dwords by a 4 x 4 byte transpose (eight v_perm_b32,
+// and eight back) instead of RGB's six / nine; everything between is per channel and unchanged.
+template <int C>
+__device__ __forceinline__ void deinterleave_quad(const uint32_t* d, uint32_t (&ch)[C]) {   // four pixels of C bytes -> one dword per channel (pixel j = byte j)
+    if constexpr (C == 3) {
+        constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ch[c] = __builtin_amdgcn_perm(d[2], __builtin_amdgcn_perm(d[1], d[0], in1[c]), in2[c]);
+    } else {
+        const uint32_t a = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u), b = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);
+        const uint32_t c_ = __builtin_amdgcn_perm(d[3], d[2], 0x05010400u), e = __builtin_amdgcn_perm(d[3], d[2], 0x07030602u);
+        ch[0] = __builtin_amdgcn_perm(c_, a, 0x05040100u); ch[1] = __builtin_amdgcn_perm(c_, a, 0x07060302u);
+        ch[2] = __builtin_amdgcn_perm(e, b, 0x05040100u); ch[3] = __builtin_amdgcn_perm(e, b, 0x07060302u);
+    }
+}
+template <int C>
+__device__ __forceinline__ void interleave_quad(const uint32_t (&pl)[C], uint32_t (&w)[C]) {   // the inverse: C dwords of four whole pixels
+    if constexpr (C == 3) {
+        const uint32_t rg = __builtin_amdgcn_perm(pl[1], pl[0], 0x05010400u), rg2 = __builtin_amdgcn_perm(pl[1], pl[0], 0x07030602u);
+        w[0] = __builtin_amdgcn_perm(pl[2], rg, 0x02040100u);
+        w[1] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2], rg, 0x0c0c0503u), rg2, 0x01000504u);
+        w[2] = __builtin_amdgcn_perm(pl[2], rg2, 0x07030206u);
+    } else {
+        uint32_t t[4];
+        deinterleave_quad<4>(pl, t);   // a 4 x 4 byte transpose is its own inverse
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c] = t[c];
+    }
+}
+template <int K, bool DILATE, int SHAPE = kMsBox, int C = 3>
+__global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE, C == 4)) void morph_u8_rgb_roll_kernel(MorphRoll a) {   // a register target for the scheduler: 5 x 5 105 -> <= 96, 7 x 7 137 -> <= 128 VGPRs
     constexpr int H = K / 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
@@ -1327,8 +1357,8 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_rgb
     const int y0 = ty * a.th;
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
-    const bool stream_ok = ((a.w * 3) & 3) == 0 && (long long)a.w * a.h * 3 <= 0x7fffffffLL;   // block-uniform: streaming stores (kh_common.h)
-    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.w * a.h * 3);
+    const bool stream_ok = ((a.w * C) & 3) == 0 && (long long)a.w * a.h * C <= 0x7fffffffLL && (C == 3 || a.plain != 2);   // block-uniform: streaming stores (kh_common.h); C = 4, plain = 2: a destination off a dword
+    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.w * a.h * C);
     const int p = p0 + 4 * lane;                            // this lane's quad
     const int ph = lane < 32 ? p0 - 4 : p0 + kMrWavePx;     // the wave's halo quads: left in the lower half's lanes, right in the upper's
     const bool edge = p0 < 4 || p0 + kMrWavePx + 4 > a.w;   // wave-uniform
@@ -1345,17 +1375,24 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_rgb
     }
     const bool writer = p < a.w;
     const bool full = p + 3 < a.w;
-    const int rowb = a.w * 3;
+    const int rowb = a.w * C;
     const int nrows = min(a.th, a.h - y0) + 2 * H;
     int pf_row = y0 - H;
-    const uint32_t cv[3] = {a.cval[0] * 0x01010101u, a.cval[1] * 0x01010101u, a.cval[2] * 0x01010101u};
+    uint32_t cv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) cv[c] = a.cval[c] * 0x01010101u;
 
-    uint32_t q[K][6];   // the lane's quad and its half-wave's halo quad
-    auto prefetch = [&](uint32_t (&d)[6]) {
+    uint32_t q[K][2 * C];   // the lane's quad and its half-wave's halo quad
+    auto prefetch = [&](uint32_t (&d)[2 * C]) {
         const uint8_t* rp = src + (long long)max(map_index(a.border, pf_row, a.h), 0) * rowb;
-        const uint8_t *rq = rp + 3 * pc, *rh = rp + 3 * phc;
-        d[0] = *reinterpret_cast<const u32_unaligned*>(rq); d[1] = *reinterpret_cast<const u32_unaligned*>(rq + 4); d[2] = *reinterpret_cast<const u32_unaligned*>(rq + 8);
-        d[3] = *reinterpret_cast<const u32_unaligned*>(rh); d[4] = *reinterpret_cast<const u32_unaligned*>(rh + 4); d[5] = *reinterpret_cast<const u32_unaligned*>(rh + 8);
+        const uint8_t *rq = rp + C * pc, *rh = rp + C * phc;
+        if constexpr (C == 4) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_unaligned*>(rq), hq = *reinterpret_cast<const u32x4_unaligned*>(rh);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; d[4] = hq.x; d[5] = hq.y; d[6] = hq.z; d[7] = hq.w;
+        } else {
+            d[0] = *reinterpret_cast<const u32_unaligned*>(rq); d[1] = *reinterpret_cast<const u32_unaligned*>(rq + 4); d[2] = *reinterpret_cast<const u32_unaligned*>(rq + 8);
+            d[3] = *reinterpret_cast<const u32_unaligned*>(rh); d[4] = *reinterpret_cast<const u32_unaligned*>(rh + 4); d[5] = *reinterpret_cast<const u32_unaligned*>(rh + 8);
+        }
         ++pf_row;
     };
 #pragma unroll
@@ -1364,10 +1401,10 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_rgb
     constexpr uint32_t kInit = DILATE ? 0u : 0x00ff00ffu;
     // column pass on pair maxima: pr[t] = max(row t - 1, row t), so the K-row maximum ending at row t is row t with pr[t - 1], pr[t - 3] ...:
     // 1 + K / 2 packed max per register instead of K - 1
-    uint32_t pr[K][3][2], last[3][2];
-    uint32_t hist[3][2][K][2];   // (cross / ellipse: per channel and rectangle, the last K rows' run maxima)
+    uint32_t pr[K][C][2], last[C][2];
+    uint32_t hist[C][2][K][2];   // (cross / ellipse: per channel and rectangle, the last K rows' run maxima)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < C; ++c) {
         last[c][0] = kInit; last[c][1] = kInit;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
@@ -1376,20 +1413,22 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_rgb
         }
     }
 
-    long long out_off = (long long)(y0 - 2 * H) * rowb + 3 * p;
+    long long out_off = (long long)(y0 - 2 * H) * rowb + C * p;
     for (int rb = 0; rb < nrows; rb += K) {
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             const int r = rb + s, row = y0 - H + r;
             const bool row_out = a.border == KH_BORDER_CONSTANT && (row < 0 || row >= a.h);   // wave-uniform: the whole row is the border value
-            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2], h0 = q[s][3], h1 = q[s][4], h2 = q[s][5];
-            prefetch(q[s]);
-            uint32_t pl[3];
+            uint32_t dq[2 * C];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
-                uint32_t cur = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, in1[c]), in2[c]);
-                uint32_t halo = __builtin_amdgcn_perm(h2, __builtin_amdgcn_perm(h1, h0, in1[c]), in2[c]);
+            for (int k = 0; k < 2 * C; ++k) dq[k] = q[s][k];
+            prefetch(q[s]);
+            uint32_t curs[C], halos[C], pl[C];
+            deinterleave_quad<C>(dq, curs);
+            deinterleave_quad<C>(dq + C, halos);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                uint32_t cur = curs[c], halo = halos[c];
                 if (edge) { cur = __builtin_amdgcn_perm(cv[c], cur, esel); halo = __builtin_amdgcn_perm(cv[c], halo, hsel); }
                 if (row_out) { cur = cv[c]; halo = cv[c]; }
                 const uint32_t prev = from_lane_below(cur, halo), next = from_lane_above(cur, halo);
@@ -1418,21 +1457,18 @@ __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE)) void morph_u8_rgb
                 pl[c] = __builtin_amdgcn_perm(vo, ve, 0x06020400u);   // pixels 0, 1, 2, 3 of this channel
             }
             if (writer && r >= 2 * H && r < nrows) {
-                const uint32_t rg = __builtin_amdgcn_perm(pl[1], pl[0], 0x05010400u), rg2 = __builtin_amdgcn_perm(pl[1], pl[0], 0x07030602u);
-                const uint32_t w0 = __builtin_amdgcn_perm(pl[2], rg, 0x02040100u);
-                const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2], rg, 0x0c0c0503u), rg2, 0x01000504u);
-                const uint32_t w2 = __builtin_amdgcn_perm(pl[2], rg2, 0x07030206u);
+                uint32_t w[C];
+                interleave_quad<C>(pl, w);
                 uint8_t* o = dst + out_off;
                 if (full && stream_ok) {
-                    const uint32_t w[3] = {w0, w1, w2};
-                    row_store<3>(out_win, (int)out_off, w, a.plain);
+                    row_store<C>(out_win, (int)out_off, w, a.plain);
                 } else if (full) {
-                    *reinterpret_cast<u32_unaligned*>(o) = w0; *reinterpret_cast<u32_unaligned*>(o + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + 8) = w2;
-                } else {
-                    const uint32_t w[3] = {w0, w1, w2};
 #pragma unroll
-                    for (int b = 0; b < 9; ++b)
-                        if (p + b / 3 < a.w) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                    for (int k = 0; k < C; ++k) *reinterpret_cast<u32_unaligned*>(o + 4 * k) = w[k];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 3 * C; ++b)   // at most three pixels of a quad that reaches past the last column
+                        if (p + b / C < a.w) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
                 }
             }
             out_off += rowb;
@@ -2064,8 +2100,8 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
     const bool gray_roll_ok = channels == 1 && w >= 16 && (int64_t)w * h <= kI32Max;
     const bool gray_dword_ok = w % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
     const bool gray_ragged = w % 16 != 0 || !gray_dword_ok;   // (round 6: any width / alignment on the RAGGED instantiation)
-    if (any && box && !direct && !no_roll && (channels == 3 || gray_roll_ok) && kw == kh_ && (kw & 1) && kw >= 9 && kw <= 31 && border != KH_BORDER_WRAP && w >= 4 &&
-        (int64_t)w * 3 < (1 << 24) && dev_opt(kOptMorphRoll) != 2) {
+    if (any && box && !direct && !no_roll && (channels == 3 || channels == 4 || gray_roll_ok) && kw == kh_ && (kw & 1) && kw >= 9 && kw <= 31 && border != KH_BORDER_WRAP && w >= 4 &&
+        (int64_t)w * channels < (1 << 24) && dev_opt(kOptMorphRoll) != 2) {
         int chain[8], nchain = 0, rem = kw;
         while (rem > 7) { chain[nchain++] = 7; rem -= 6; }
         if (rem >= 3) chain[nchain++] = rem;
@@ -2081,7 +2117,7 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
                 const long long out_stride = to_dst ? ds : (long long)img;
                 uint8_t box_mask[49];
                 for (int k = 0; k < chain[i] * chain[i]; ++k) box_mask[k] = 1;
-                const uint8_t cv[4] = {(uint8_t)a.cval[0], (uint8_t)a.cval[1], (uint8_t)a.cval[2], 0};
+                const uint8_t cv[4] = {(uint8_t)a.cval[0], (uint8_t)a.cval[1], (uint8_t)a.cval[2], (uint8_t)a.cval[3]};
                 if (int32_t rc = kh_morphology_u8(stream, cur, out, w, h, channels, op, box_mask, chain[i], chain[i], border, cv, batch, cur_stride, out_stride)) return rc;
                 cur = out; cur_stride = out_stride;
             }
@@ -2116,9 +2152,12 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
 #undef KH_MG_R
         return check_launch(what);
     }
-    if (any && shape >= 0 && !direct && !no_roll && channels == 3 && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && w >= 4 &&
-        (int64_t)w * 3 < (1 << 24) && (shape == kMsBox || dev_opt(kOptMorphRoll) != 2)) {   // RGB8, square box / cross / ellipse of 3 / 5 / 7: the rolling planar kernel
-        MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], a.cval[1], a.cval[2]}, XcdTiles{}, plain_row_stores((int64_t)w * 3, dst, ds, batch)};
+    if (any && shape >= 0 && !direct && !no_roll && (channels == 3 || channels == 4) && kw == kh_ && (kw == 3 || kw == 5 || kw == 7) && border != KH_BORDER_WRAP && w >= 4 &&
+        (int64_t)w * channels < (1 << 24) && (shape == kMsBox || dev_opt(kOptMorphRoll) != 2) && (channels == 3 || dev_opt(kOptMorphRoll) != 2)) {
+        // RGB8 / RGBA8 (round 6), square box / cross / ellipse of 3 / 5 / 7: the rolling planar kernel
+        const bool dword_ok = reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);
+        MorphRoll r{src, dst, w, h, 0, border, ss, ds, {a.cval[0], a.cval[1], a.cval[2], a.cval[3]}, XcdTiles{},
+                    channels == 4 && !dword_ok ? 2 : plain_row_stores((int64_t)w * channels, dst, ds, batch)};
         const unsigned tiles_x = cdiv(w, kMrTilePx);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
@@ -2129,17 +2168,19 @@ int32_t kh_morphology_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, i
         KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
         const dim3 grid = xcd_grid(r.tiles);
         const bool dil = op == KH_MORPH_DILATE;
-#define KH_MR_S(KK, SH)                                                                                     \
-    do {                                                                                                    \
-        if (dil) hipLaunchKernelGGL((morph_u8_rgb_roll_kernel<KK, true, SH>), grid, dim3(256), 0, st, r);   \
-        else hipLaunchKernelGGL((morph_u8_rgb_roll_kernel<KK, false, SH>), grid, dim3(256), 0, st, r);      \
+#define KH_MR_C(KK, SH, CC)                                                                                     \
+    do {                                                                                                        \
+        if (dil) hipLaunchKernelGGL((morph_u8_rgb_roll_kernel<KK, true, SH, CC>), grid, dim3(256), 0, st, r);   \
+        else hipLaunchKernelGGL((morph_u8_rgb_roll_kernel<KK, false, SH, CC>), grid, dim3(256), 0, st, r);      \
     } while (0)
+#define KH_MR_S(KK, SH) do { if (channels == 4) KH_MR_C(KK, SH, 4); else KH_MR_C(KK, SH, 3); } while (0)
 #define KH_MR(KK) do { if (shape == kMsBox) KH_MR_S(KK, kMsBox); else if (shape == kMsCross) KH_MR_S(KK, kMsCross); else KH_MR_S(KK, kMsEllipse); } while (0)
         if (kw == 3) KH_MR(3);
         else if (kw == 5) KH_MR(5);
         else KH_MR(7);
 #undef KH_MR
 #undef KH_MR_S
+#undef KH_MR_C
         return check_launch(what);
     }
     const int srows = kMorphTH + kh_ - 1, sp = ((kMorphFW + (kw - 1) * channels + 3) & ~3) + 4;

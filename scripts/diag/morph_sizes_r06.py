@@ -17,7 +17,7 @@ if len(sys.argv) > 1:   # e.g. morph_roll=2: the tile kernel instead of the roll
     check(lib.kh_debug_set_option(name.encode(), int(val)))
     print(f"# dev option {name} = {val}")
 N, W, H = 32, 3840, 2160
-for ch in (3, 1):
+for ch in (3, 1, 4):
     n = W * H * ch
     src = DeviceBuffer.from_numpy(bench.lcg_bytes(N * n), st); dst = DeviceBuffer(N * n, st, zeroed=False)
     cval = (C.c_uint8 * 4)(0, 0, 0, 0)

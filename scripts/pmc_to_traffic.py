@@ -34,7 +34,7 @@ KERNELS = {
     "undistort_remap_then_warp_perspective_4k_f32_api_list_b256": ["remap_kernel<3, 1, true", "warp_perspective_px_kernel<3, 1, 2, true"],
     "warp_affine_f32_1080p_b256": ["warp_affine_kernel<3, 1, false", "warp_affine_px_kernel<3, 1, 2, false"],
     "nv12_1080p_to_chw_f32_frame_list_b1024": ["preprocess_nv12_identity_list"],
-    "nv12_1080p_to_chw_f16_b1024": ["preprocess_nv12_identity_f16("],
+    "nv12_1080p_to_chw_f16_b1024": ["preprocess_nv12_identity_f16<true>(", "preprocess_nv12_identity_f16("],
     "gaussian_blur_7x7_4k_f32_api_list_b256": [],   # (shares sep_roll4_kernel<7 with the equally spaced row: not separable by name)
     "normalize_mean_std_1080p_f32_b512": ["normalize_mean_std_quads3_kernel", "normalize_mean_std_kernel<3"],
     "gray_from_rgb_f32_1080p_b1024": ["GrayFromRgbF32"],
@@ -44,7 +44,7 @@ KERNELS = {
     "warp_affine_u8_4k_b256": ["gather_u8_staged_kernel<3, 0,"],
     "warp_perspective_u8_4k_b256": ["gather_u8_staged_kernel<3, 1,"],
     "remap_u8_undistort_4k_b256": ["gather_u8_staged_kernel<3, 2,"],
-    "gaussian_blur_u8_7x7_4k_b256": ["blur_u8_rgb_kernel<7>", "blur_u8_roll_kernel<7, 3"],
+    "gaussian_blur_u8_7x7_4k_b256": ["blur_u8_rgb_kernel<7, false>", "blur_u8_rgb_kernel<7>", "blur_u8_roll_kernel<7, 3"],
 }
 
 

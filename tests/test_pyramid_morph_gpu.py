@@ -316,6 +316,42 @@ def test_morphology_gray_ragged_widths(gpu_stream, dev_option, kshape, border):
             assert_same_bits(got[3 + i * w * h:3 + (i + 1) * w * h].reshape(h, w, 1), O.morphology_u8(src[i], "dilate", mask, border, [77]), f"offset destination {w}x{h} frame {i}")
 
 
+@pytest.mark.parametrize("border", ["constant", "replicate", "reflect101", "reflect"])
+@pytest.mark.parametrize("kshape", [("box", 3), ("box", 5), ("box", 7), ("cross", 5), ("ellipse", 7), ("box", 9), ("box", 15)])
+def test_morphology_rgba_rolling_kernel(gpu_stream, dev_option, kshape, border):
+    """Four-channel images on the rolling planar kernel (round 6: a 16-byte quad per lane, a 4 x 4 byte transpose either side of the RGB
+    kernel's per-channel code): the oracle's bytes either side of the wave (256 pixels) and block (1024) seams, the narrowest images,
+    partial last quads, heights below the mask's, per-channel border values that win or lose, the chain for boxes of 9 / 15, a batch, a
+    destination off a dword; morph_roll = 2 keeps the tile kernel."""
+    from kornia_rs import _ffi
+    shape, k = kshape
+    mask = O.morph_kernel(shape, k, k)
+    cval = [9, 130, 251, 77]
+    for (w, h) in [(4, 9), (5, 2), (6, 1), (7, 40), (3, 8), (248, 3), (251, 7), (255, 3), (256, 8), (257, 5), (260, 3), (1023, 3), (1024, 6), (1025, 4), (1029, 2), (131, 200)]:
+        src = make(w, h, 4, np.uint8, seed=w + h + k)
+        for op in ("dilate", "erode"):
+            want = O.morphology_u8(src, op, mask, border, cval)
+            for opt in ((-1, 2) if w in (7, 257, 1025, 131) else (-1,)):
+                dev_option("morph_roll", opt)
+                assert_same_bits(morph_gpu(gpu_stream, src, op, mask, border, cval)[0], want, f"{op} c4 {shape}{k} {border} {w}x{h} morph_roll={opt}")
+    dev_option("morph_roll", -1)
+    src = np.stack([make(1000, 75, 4, np.uint8, seed=s_) for s_ in (4, 5, 6)])
+    got = morph_gpu(gpu_stream, src, "erode", mask, border, cval, batch=3)
+    for i in range(3):
+        assert_same_bits(got[i], O.morphology_u8(src[i], "erode", mask, border, cval), f"batch frame {i}")
+    w, h, n = 301, 7, 2
+    src = np.stack([make(w, h, 4, np.uint8, seed=s_) for s_ in range(n)])
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * w * h * 4 + 8)
+    m = np.ascontiguousarray(mask, np.uint8)
+    cv = (C.c_uint8 * 4)(*cval)
+    _ffi.check(_ffi.lib.kh_morphology_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 3, w, h, 4, 0, m.ctypes.data_as(C.POINTER(C.c_uint8)), k, k,
+                                         O.BORDER[border], cv, n, w * h * 4, w * h * 4))
+    got = d_dst.to_numpy(np.uint8, (n * w * h * 4 + 8,))
+    assert got[:3].tolist() == [255] * 3 and got[3 + n * w * h * 4:3 + n * w * h * 4 + 5].tolist() == [255] * 5, "bytes outside the destination were written"
+    for i in range(n):
+        assert_same_bits(got[3 + i * w * h * 4:3 + (i + 1) * w * h * 4].reshape(h, w, 4), O.morphology_u8(src[i], "dilate", mask, border, cval), f"offset destination frame {i}")
+
+
 def test_morphology_both_kernels_agree(gpu_stream, tmp_path):
     """KH_MORPH_DIRECT=1 selects the per-pixel kernel (read once per process): a child process runs it on the same inputs and the
     bytes must equal this process's tiled result."""
