@@ -323,6 +323,35 @@ __device__ __forceinline__ void store_head_bytes(uint8_t* o, const uint32_t (&w)
         if (b < n) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
 }
 
+// Four pixels of C = 3 / 4 bytes <-> one dword per channel (pixel j = byte j): the planar u8 rolling kernels' (kh_u8.hip, kh_pyramid_morph.hip)
+// view of a lane's quad.  RGB: six v_perm_b32 in, five out; RGBA: a 4 x 4 byte transpose, eight each way.
+template <int C>
+__device__ __forceinline__ void deinterleave_quad(const uint32_t* d, uint32_t (&ch)[C]) {   // four pixels of C bytes -> one dword per channel (pixel j = byte j)
+    if constexpr (C == 3) {
+        constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ch[c] = __builtin_amdgcn_perm(d[2], __builtin_amdgcn_perm(d[1], d[0], in1[c]), in2[c]);
+    } else {
+        const uint32_t a = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u), b = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);
+        const uint32_t c_ = __builtin_amdgcn_perm(d[3], d[2], 0x05010400u), e = __builtin_amdgcn_perm(d[3], d[2], 0x07030602u);
+        ch[0] = __builtin_amdgcn_perm(c_, a, 0x05040100u); ch[1] = __builtin_amdgcn_perm(c_, a, 0x07060302u);
+        ch[2] = __builtin_amdgcn_perm(e, b, 0x05040100u); ch[3] = __builtin_amdgcn_perm(e, b, 0x07060302u);
+    }
+}
+template <int C>
+__device__ __forceinline__ void interleave_quad(const uint32_t (&pl)[C], uint32_t (&w)[C]) {   // the inverse: C dwords of four whole pixels
+    if constexpr (C == 3) {
+        const uint32_t rg = __builtin_amdgcn_perm(pl[1], pl[0], 0x05010400u), rg2 = __builtin_amdgcn_perm(pl[1], pl[0], 0x07030602u);
+        w[0] = __builtin_amdgcn_perm(pl[2], rg, 0x02040100u);
+        w[1] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2], rg, 0x0c0c0503u), rg2, 0x01000504u);
+        w[2] = __builtin_amdgcn_perm(pl[2], rg2, 0x07030206u);
+    } else {
+        uint32_t t[4];
+        deinterleave_quad<4>(pl, t);   // a 4 x 4 byte transpose is its own inverse
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c] = t[c];
+    }
+}
 struct QuadU8 { uint32_t p00, p01, p10, p11; };
 __device__ __forceinline__ uint32_t chan_u8(uint32_t px, int c) { return (px >> (8 * c)) & 0xffu; }
 

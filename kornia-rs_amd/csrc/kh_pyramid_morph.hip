@@ -1319,33 +1319,6 @@ constexpr int kMrWavePx = 256, kMrTilePx = 4 * kMrWavePx;
 // C = 4 (round 6): RGBA / BGRA images took the LDS-tile kernel at 0.40 of peak.  The same kernel with a 16-byte quad per lane (one load and
 // one store of whole pixels, 1 KiB per wave and row), de-interleaved into four channel dwords by a 4 x 4 byte transpose (eight v_perm_b32,
 // and eight back) instead of RGB's six / nine; everything between is per channel and unchanged.
-template <int C>
-__device__ __forceinline__ void deinterleave_quad(const uint32_t* d, uint32_t (&ch)[C]) {   // four pixels of C bytes -> one dword per channel (pixel j = byte j)
-    if constexpr (C == 3) {
-        constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ch[c] = __builtin_amdgcn_perm(d[2], __builtin_amdgcn_perm(d[1], d[0], in1[c]), in2[c]);
-    } else {
-        const uint32_t a = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u), b = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);
-        const uint32_t c_ = __builtin_amdgcn_perm(d[3], d[2], 0x05010400u), e = __builtin_amdgcn_perm(d[3], d[2], 0x07030602u);
-        ch[0] = __builtin_amdgcn_perm(c_, a, 0x05040100u); ch[1] = __builtin_amdgcn_perm(c_, a, 0x07060302u);
-        ch[2] = __builtin_amdgcn_perm(e, b, 0x05040100u); ch[3] = __builtin_amdgcn_perm(e, b, 0x07060302u);
-    }
-}
-template <int C>
-__device__ __forceinline__ void interleave_quad(const uint32_t (&pl)[C], uint32_t (&w)[C]) {   // the inverse: C dwords of four whole pixels
-    if constexpr (C == 3) {
-        const uint32_t rg = __builtin_amdgcn_perm(pl[1], pl[0], 0x05010400u), rg2 = __builtin_amdgcn_perm(pl[1], pl[0], 0x07030602u);
-        w[0] = __builtin_amdgcn_perm(pl[2], rg, 0x02040100u);
-        w[1] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2], rg, 0x0c0c0503u), rg2, 0x01000504u);
-        w[2] = __builtin_amdgcn_perm(pl[2], rg2, 0x07030206u);
-    } else {
-        uint32_t t[4];
-        deinterleave_quad<4>(pl, t);   // a 4 x 4 byte transpose is its own inverse
-#pragma unroll
-        for (int c = 0; c < 4; ++c) w[c] = t[c];
-    }
-}
 template <int K, bool DILATE, int SHAPE = kMsBox, int C = 3>
 __global__ __launch_bounds__(256, morph_roll_blocks(K, SHAPE, C == 4)) void morph_u8_rgb_roll_kernel(MorphRoll a) {   // a register target for the scheduler: 5 x 5 105 -> <= 96, 7 x 7 137 -> <= 128 VGPRs
     constexpr int H = K / 2;

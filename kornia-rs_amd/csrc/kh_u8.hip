@@ -235,8 +235,10 @@ __device__ __forceinline__ uint32_t rhadd4(uint32_t a, uint32_t b) { return (a |
 // BINOMIAL (round 6, K = 3): the reference's 3 x 3 [1 2 1] / 4 case — what a gaussian of 3 taps and sigma in [0.6, 1.2] is, the default
 // sigma included — as rounding halving adds on the planar dwords (rhadd(rhadd(l, c), rhadd(c, r)) per pass, four pixels per
 // instruction); it took the interleaved one-accumulator-per-byte kernel before and ran slower than the 5 x 5 gaussian.
-template <int K, bool BINOMIAL = false>
-__global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky) {   // K = 7: 131 -> 128 VGPRs keeps 4 waves per SIMD
+// C = 4 (round 6): RGBA images took the interleaved kernel at 0.25-0.50 of peak; here a lane's quad is 16 bytes (one load, one store of whole
+// pixels) de-interleaved by a 4 x 4 byte transpose (kh_common.h::deinterleave_quad); `plain`: kh_common.h::plain_row_stores, 2 = a destination off a dword.
+template <int K, bool BINOMIAL = false, int C = 3>
+__global__ __launch_bounds__(kBlock, C == 4 ? (K <= 3 ? 5 : (K <= 5 ? 4 : (K <= 7 ? 3 : 2))) : (K <= 7 ? 4 : 3)) void blur_u8_rgb_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky, int plain) {   // K = 7: 131 -> 128 VGPRs keeps 4 waves per SIMD
     static_assert(!BINOMIAL || K == 3, "the binomial is 3 x 3");
     constexpr int H = K / 2, G = (K + 3) / 4;   // taps are consumed four at a time
     static_assert(K >= 3 && K <= 9 && (K & 1), "3..9 taps: one neighbour quad on each side covers the window");
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8F
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.src_stride;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.dst_stride;
     // block-uniform: quad offsets are multiples of four bytes and the image fits the V#'s 2 GiB window
-    const bool stream_ok = (a.rowlen & 3) == 0 && (long long)a.rows * a.rowlen <= 0x7fffffffLL;
+    const bool stream_ok = (a.rowlen & 3) == 0 && (long long)a.rows * a.rowlen <= 0x7fffffffLL && plain != 2;
     const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.rows * a.rowlen);
     const int p = p0 + 4 * lane;                            // this lane's quad: pixels p .. p + 3
     const int ph = lane < 32 ? p0 - 4 : p0 + kRgbWavePx;    // the wave's halo quads: left in the lower half's lanes, right in the upper's
@@ -275,44 +277,47 @@ __global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8F
 #pragma unroll
     for (int g = 0; g < 3; ++g) wq[g] = kx.k[4 * g] | (kx.k[4 * g + 1] << 8) | (kx.k[4 * g + 2] << 16) | (kx.k[4 * g + 3] << 24);
 
-    uint32_t q[K][6];  // K rows of raw loads in flight per lane: its quad and its half-wave's halo quad
-    auto prefetch = [&](uint32_t (&d)[6]) {
+    uint32_t q[K][2 * C];  // K rows of raw loads in flight per lane: its quad and its half-wave's halo quad
+    auto prefetch = [&](uint32_t (&d)[2 * C]) {
         const uint8_t* rp = src + (long long)min(max(pf_row, 0), a.rows - 1) * a.rowlen;   // replicate rows
-        const uint8_t *rq = rp + 3 * pc, *rh = rp + 3 * phc;
-        d[0] = *reinterpret_cast<const u32u*>(rq); d[1] = *reinterpret_cast<const u32u*>(rq + 4); d[2] = *reinterpret_cast<const u32u*>(rq + 8);
-        d[3] = *reinterpret_cast<const u32u*>(rh); d[4] = *reinterpret_cast<const u32u*>(rh + 4); d[5] = *reinterpret_cast<const u32u*>(rh + 8);
+        const uint8_t *rq = rp + C * pc, *rh = rp + C * phc;
+        if constexpr (C == 4) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_unaligned*>(rq), hq = *reinterpret_cast<const u32x4_unaligned*>(rh);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; d[4] = hq.x; d[5] = hq.y; d[6] = hq.z; d[7] = hq.w;
+        } else {
+            d[0] = *reinterpret_cast<const u32u*>(rq); d[1] = *reinterpret_cast<const u32u*>(rq + 4); d[2] = *reinterpret_cast<const u32u*>(rq + 8);
+            d[3] = *reinterpret_cast<const u32u*>(rh); d[4] = *reinterpret_cast<const u32u*>(rh + 4); d[5] = *reinterpret_cast<const u32u*>(rh + 8);
+        }
         ++pf_row;
     };
 #pragma unroll
     for (int i = 0; i < K; ++i) prefetch(q[i]);
 
-    uint32_t ring[K][3][2];  // [row][channel][even / odd pixel pair], 16-bit lanes
+    uint32_t ring[K][C][2];  // [row][channel][even / odd pixel pair], 16-bit lanes
 #pragma unroll
     for (int i = 0; i < K; ++i)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { ring[i][c][0] = 0; ring[i][c][1] = 0; }
+        for (int c = 0; c < C; ++c) { ring[i][c][0] = 0; ring[i][c][1] = 0; }
 
-    long long out_off = (long long)(y0 - 2 * H) * a.rowlen + 3 * p;
+    long long out_off = (long long)(y0 - 2 * H) * a.rowlen + C * p;
     for (int rb = 0; rb < nrows; rb += K) {
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             const int r = rb + s;
-            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2], h0 = q[s][3], h1 = q[s][4], h2 = q[s][5];
+            uint32_t dq[2 * C];
+#pragma unroll
+            for (int k = 0; k < 2 * C; ++k) dq[k] = q[s][k];
             prefetch(q[s]);
             // de-interleave: [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3] -> one dword per channel, pixel j = byte j
-            uint32_t cur[3], halo[3];
-            cur[0] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c060300u), 0x05020100u);   // d0.b0 d0.b3 d1.b2 d2.b1
-            cur[1] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);   // d0.b1 d1.b0 d1.b3 d2.b2
-            cur[2] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);   // d0.b2 d1.b1 d2.b0 d2.b3
-            halo[0] = __builtin_amdgcn_perm(h2, __builtin_amdgcn_perm(h1, h0, 0x0c060300u), 0x05020100u);
-            halo[1] = __builtin_amdgcn_perm(h2, __builtin_amdgcn_perm(h1, h0, 0x0c070401u), 0x06020100u);
-            halo[2] = __builtin_amdgcn_perm(h2, __builtin_amdgcn_perm(h1, h0, 0x0c0c0502u), 0x07040100u);
+            uint32_t cur[C], halo[C];
+            deinterleave_quad<C>(dq, cur);
+            deinterleave_quad<C>(dq + C, halo);
             if (edge) {   // wave-uniform
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { cur[c] = __builtin_amdgcn_perm(0u, cur[c], esel); halo[c] = __builtin_amdgcn_perm(0u, halo[c], hsel); }
+                for (int c = 0; c < C; ++c) { cur[c] = __builtin_amdgcn_perm(0u, cur[c], esel); halo[c] = __builtin_amdgcn_perm(0u, halo[c], hsel); }
             }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < C; ++c) {
                 const uint32_t prev = from_lane_below(cur[c], halo[c]), next = from_lane_above(cur[c], halo[c]);
                 if constexpr (BINOMIAL) {
                     const uint32_t lft = __builtin_amdgcn_alignbyte(cur[c], prev, 3u), rgt = __builtin_amdgcn_alignbyte(next, cur[c], 1u);   // pixels p - 1 .. p + 2, p + 1 .. p + 4
@@ -337,9 +342,9 @@ __global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8F
                 ring[s][c][0] = __builtin_amdgcn_perm(sum[2], sum[0], 0x0c050c01u);
                 ring[s][c][1] = __builtin_amdgcn_perm(sum[3], sum[1], 0x0c050c01u);
             }
-            uint32_t pl[3];   // vertical pass, then one dword per channel again (pixel j = byte j)
+            uint32_t pl[C];   // vertical pass, then one dword per channel again (pixel j = byte j)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < C; ++c) {
                 if constexpr (BINOMIAL) {   // rows oldest first: s + 1, s + 2, s (mod 3)
                     const uint32_t r0 = ring[(s + 1) % K][c][0], r1 = ring[(s + 2) % K][c][0], r2 = ring[s][c][0];
                     pl[c] = rhadd4(rhadd4(r0, r1), rhadd4(r1, r2));
@@ -354,23 +359,18 @@ __global__ __launch_bounds__(kBlock, K <= 7 ? 4 : 3) void blur_u8_rgb_kernel(U8F
                 pl[c] = __builtin_amdgcn_perm(oo, oe, 0x07030501u);   // (oe.b1, oo.b1, oe.b3, oo.b3) = pixels 0, 1, 2, 3
             }
             if (writer && r >= 2 * H && r < nrows) {
-                // re-interleave: [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3]
-                const uint32_t rg = __builtin_amdgcn_perm(pl[1], pl[0], 0x05010400u);   // R0 G0 R1 G1
-                const uint32_t rg2 = __builtin_amdgcn_perm(pl[1], pl[0], 0x07030602u); // R2 G2 R3 G3
-                const uint32_t w0 = __builtin_amdgcn_perm(pl[2], rg, 0x02040100u);      // R0 G0 B0 R1
-                const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2], rg, 0x0c0c0503u), rg2, 0x01000504u);   // G1 B1 | R2 G2
-                const uint32_t w2 = __builtin_amdgcn_perm(pl[2], rg2, 0x07030206u);     // B2 R3 G3 B3
+                uint32_t w[C];   // re-interleave: [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3]
+                interleave_quad<C>(pl, w);
                 uint8_t* o = dst + out_off;
-                if (full && stream_ok) {   // write-through non-temporal buffer store (kh_common.h::stream_store)
-                    const uint32_t w[3] = {w0, w1, w2};
-                    stream_store<3>(out_win, (int)out_off, w);
+                if (full && stream_ok) {   // write-through non-temporal buffer store (kh_common.h::stream_store), or write-back on rows that are not whole lines
+                    row_store<C>(out_win, (int)out_off, w, plain);
                 } else if (full) {
-                    *reinterpret_cast<u32u*>(o) = w0; *reinterpret_cast<u32u*>(o + 4) = w1; *reinterpret_cast<u32u*>(o + 8) = w2;
-                } else {
-                    const uint32_t w[3] = {w0, w1, w2};
 #pragma unroll
-                    for (int b = 0; b < 9; ++b)   // at most three pixels of a quad that reaches past the last column
-                        if (p + b / 3 < a.cols) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                    for (int k = 0; k < C; ++k) *reinterpret_cast<u32u*>(o + 4 * k) = w[k];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 3 * C; ++b)   // at most three pixels of a quad that reaches past the last column
+                        if (p + b / C < a.cols) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
                 }
             }
             out_off += a.rowlen;
@@ -659,7 +659,7 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         unsigned sxq = 0, syq = 0;
         for (int i = 0; i < 16; ++i) { sxq += px.k[i]; syq += py.k[i]; }
         const bool rgb_off = dev_opt(kOptU8BlurRgb) == 0;   // test option: the interleaved kernel (what the other channel counts take)
-        const bool rgb = C == 3 && K <= 9 && (binomial ? K == 3 : (sxq <= 256 && syq <= 256)) && cols >= 4 && !rgb_off;
+        const bool rgb = (C == 3 || C == 4) && K <= 9 && (binomial ? K == 3 : (sxq <= 256 && syq <= 256)) && cols >= 4 && !rgb_off;   // (C = 4: round 6)
         // one channel, 3..9 taps: the rolling gray kernel (round 6; the same test option keeps the interleaved kernel)
         const bool gray = C == 1 && K <= 9 && (binomial ? K == 3 : (sxq <= 256 && syq <= 256)) && cols >= 16 && (int64_t)rows * cols <= kI32Max && !rgb_off;
         const bool gray_dword_ok = cols % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
@@ -688,14 +688,18 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         }
         if (rgb) {
             const dim3 grid = xcd_grid(a.tiles);
+            // RGB keeps the streaming stores on every width (profiles/r06zr: it does not gain from write-back); RGBA: the row rule, 2 = a destination off a dword
+            const bool dword_ok = reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);
+            const int plain = C == 3 ? 0 : (dword_ok ? plain_row_stores((int64_t)rowlen, dst, ds, batch) : 2);
+#define KH_RB(KK, BIN) do { if (C == 4) hipLaunchKernelGGL((blur_u8_rgb_kernel<KK, BIN, 4>), grid, dim3(kBlock), 0, st, a, px, py, plain); \
+                            else hipLaunchKernelGGL((blur_u8_rgb_kernel<KK, BIN, 3>), grid, dim3(kBlock), 0, st, a, px, py, plain); } while (0)
             switch (K) {
-                case 3: if (binomial) hipLaunchKernelGGL((blur_u8_rgb_kernel<3, true>), grid, dim3(kBlock), 0, st, a, px, py);
-                        else hipLaunchKernelGGL((blur_u8_rgb_kernel<3, false>), grid, dim3(kBlock), 0, st, a, px, py);
-                        break;
-                case 5: hipLaunchKernelGGL(blur_u8_rgb_kernel<5>, grid, dim3(kBlock), 0, st, a, px, py); break;
-                case 7: hipLaunchKernelGGL(blur_u8_rgb_kernel<7>, grid, dim3(kBlock), 0, st, a, px, py); break;
-                default: hipLaunchKernelGGL(blur_u8_rgb_kernel<9>, grid, dim3(kBlock), 0, st, a, px, py); break;
+                case 3: if (binomial) KH_RB(3, true); else KH_RB(3, false); break;
+                case 5: KH_RB(5, false); break;
+                case 7: KH_RB(7, false); break;
+                default: KH_RB(9, false); break;
             }
+#undef KH_RB
             return check_launch(what);
         }
         switch (K) {

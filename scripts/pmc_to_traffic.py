@@ -44,7 +44,7 @@ KERNELS = {
     "warp_affine_u8_4k_b256": ["gather_u8_staged_kernel<3, 0,"],
     "warp_perspective_u8_4k_b256": ["gather_u8_staged_kernel<3, 1,"],
     "remap_u8_undistort_4k_b256": ["gather_u8_staged_kernel<3, 2,"],
-    "gaussian_blur_u8_7x7_4k_b256": ["blur_u8_rgb_kernel<7, false>", "blur_u8_rgb_kernel<7>", "blur_u8_roll_kernel<7, 3"],
+    "gaussian_blur_u8_7x7_4k_b256": ["blur_u8_rgb_kernel<7, false, 3>", "blur_u8_roll_kernel<7, 3"],
 }
 
 

@@ -153,6 +153,35 @@ def test_blur_u8_gray_rolling_kernel(gpu_stream, dev_option, k):
             assert_same_bits(got[3 + i * w * h:3 + (i + 1) * w * h].reshape(h, w, 1), O.gaussian_blur_u8(src[i], (k, k), (1.1, 1.1))[0], f"offset destination {w}x{h} frame {i}")
 
 
+@pytest.mark.parametrize("k", [3, 5, 7, 9])
+def test_blur_u8_rgba_planar_kernel(gpu_stream, dev_option, k):
+    """Four-channel images on the planar rolling kernel (round 6: a 16-byte quad per lane, a 4 x 4 byte transpose either side of the RGB
+    kernel's per-channel code): the oracle's bytes either side of the wave (256 pixels) / block (1024) seams, the narrowest rows,
+    partial last quads, fewer rows than taps, the binomial band, a box, unequal taps, a batch, a destination off a dword;
+    u8_blur_rgb = 0 keeps the interleaved kernel."""
+    from kornia_rs import _ffi
+    sigmas = ((0.3 * k, 0.2 * k + 0.5),) if k > 3 else ((1.0, 1.0), (0.6, 1.2), (0.59, 1.3))
+    for w, h in [(4, 5), (5, 1), (6, 2), (7, 11), (253, 4), (255, 2), (256, 9), (257, 3), (260, 4), (1023, 2), (1024, 5), (1025, 3), (1029, 7), (2050, 2), (130, 300), (1000, 9)]:
+        src = pat(w, h, 4, seed=w * 7 + h)
+        for sig in sigmas:
+            want = O.gaussian_blur_u8(src, (k, k), sig)[0]
+            for opt in ((-1, 0) if w in (7, 257, 1025, 1000) else (-1,)):
+                dev_option("u8_blur_rgb", opt)
+                assert_same_bits(blur_gpu(gpu_stream, "gaussian", src, (k, k), sig)[0], want, f"gaussian {k} sigma {sig} rgba {w}x{h} u8_blur_rgb={opt}")
+        dev_option("u8_blur_rgb", -1)
+    src = pat(1030, 40, 4, seed=5)
+    assert_same_bits(blur_gpu(gpu_stream, "box", src, (k, k))[0], O.box_blur_u8(src, (k, k)), f"box {k} rgba")
+    assert_same_bits(blur_gpu(gpu_stream, "gaussian", src, (k, 3), (1.5, 0.8))[0], O.gaussian_blur_u8(src, (k, 3), (1.5, 0.8))[0], f"gaussian {k}x3 rgba")
+    for (w, h, n) in [(256, 6, 1), (301, 7, 3)]:
+        src = np.stack([pat(w, h, 4, seed=s_) for s_ in range(n)])
+        d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * w * h * 4 + 8)
+        _ffi.check(_ffi.lib.kh_gaussian_blur_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 3, w, h, 4, k, k, 1.1, 1.1, n, w * h * 4, w * h * 4))
+        got = d_dst.to_numpy(np.uint8, (n * w * h * 4 + 8,))
+        assert got[:3].tolist() == [255] * 3 and got[3 + n * w * h * 4:3 + n * w * h * 4 + 5].tolist() == [255] * 5, "bytes outside the destination were written"
+        for i in range(n):
+            assert_same_bits(got[3 + i * w * h * 4:3 + (i + 1) * w * h * 4].reshape(h, w, 4), O.gaussian_blur_u8(src[i], (k, k), (1.1, 1.1))[0], f"offset destination {w}x{h} frame {i}")
+
+
 def test_blur_u8_batch_4k_strip_and_errors(gpu_stream):
     from kornia_rs import _ffi
     n = 3
