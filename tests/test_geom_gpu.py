@@ -219,6 +219,26 @@ HOMOGRAPHIES = {
 }
 
 
+def test_one_channel_bilinear_taps_at_the_image_edges(gpu_stream):
+    """One-channel bilinear taps at the image edges (written for a round-6 experiment that fetched a tap row with one 8-byte load — no
+    faster, not kept; the cases stay): translations that put taps on the last column / row, half-pixel shifts, the narrowest sources
+    (1 and 2 pixels wide / tall), through warp_affine, warp_perspective, remap and the gather resize."""
+    for (w, h) in [(1, 1), (2, 1), (1, 2), (2, 2), (3, 5), (65, 9), (130, 4)]:
+        src = img(w, h, 1, seed=w + h)
+        for (tx, ty) in [(0.0, 0.0), (0.5, 0.5), (-0.25, 0.75), (1.0, 0.0), (-1.5, -0.5), (0.999, 0.001)]:
+            m = [1.0, 0.0, tx, 0.0, 1.0, ty]
+            assert_same_bits(warp_gpu(gpu_stream, "affine", src, m, w + 2, h + 1, "bilinear")[0], O.warp_affine(src, m, w + 2, h + 1, "bilinear"), f"affine {w}x{h} shift {tx},{ty}")
+            hm = [1.0, 0.0, tx, 0.0, 1.0, ty, 0.0, 0.0, 1.0]
+            assert_same_bits(warp_gpu(gpu_stream, "perspective", src, hm, w + 2, h + 1, "bilinear")[0], O.warp_perspective(src, hm, w + 2, h + 1, "bilinear"), f"perspective {w}x{h} shift {tx},{ty}")
+        dw, dh = w + 3, h + 2
+        mx = np.ascontiguousarray(np.tile(np.linspace(-0.5, w - 0.5, dw, dtype=np.float32), (dh, 1)))
+        my = np.ascontiguousarray(np.tile(np.linspace(-0.5, h - 0.5, dh, dtype=np.float32)[:, None], (1, dw)))
+        d_src, d_mx, d_my, d_dst = dev(gpu_stream, src), dev(gpu_stream, mx), dev(gpu_stream, my), out_buf(gpu_stream, dw * dh * 4)
+        call(gpu_stream, "kh_remap_f32", d_src.ptr, d_mx.ptr, d_my.ptr, d_dst.ptr, w, h, dw, dh, 1, O.MODE["bilinear"], 1, 0, 0)
+        assert_same_bits(d_dst.to_numpy(np.float32, (dh, dw, 1)), O.remap(src, mx, my, "bilinear"), f"remap {w}x{h}")
+        assert_same_bits(resize_gpu(gpu_stream, src, 2 * w + 1, 2 * h + 1, "bilinear")[0], O.resize(src, 2 * w + 1, 2 * h + 1, "bilinear"), f"resize {w}x{h}")
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", list(HOMOGRAPHIES))
 @pytest.mark.parametrize("c", [1, 3])
