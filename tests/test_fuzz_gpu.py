@@ -200,6 +200,40 @@ def test_fuzz_tiled_kernels_large_shapes(gpu_stream, seed):
         assert np.array_equal(imgproc.resize_fast(ud, (dh, dw), mode, aa).numpy(), want), ("resize_fast", w, h, dw, dh, c, mode, aa)
 
 
+@pytest.mark.parametrize("seed", range(4 + EXTRA))
+def test_fuzz_round6_rolling_kernels_wide_rows(gpu_stream, seed):
+    """The round-6 rolling kernels (gray / RGBA morphology, shapes, gray pyramids and blurs with ragged widths, the row-store rule) meet
+    their lane / wave / block seams on rows of about a thousand to four thousand pixels: random widths there, a few rows, every channel
+    count, random shapes / borders / kernel sizes, against the restatement."""
+    from kornia_rs import imgproc
+    rng = np.random.default_rng(12000 + seed)
+    for _ in range(3):
+        base = int(rng.choice([256, 512, 1024, 2048, 4096]))
+        w, h, c = base + int(rng.integers(-17, 18)), int(rng.integers(1, 12)), int(rng.choice([1, 3, 4]))
+        u = _u8(rng, h, w, c)
+        ud = _up(u, gpu_stream)
+        assert np.array_equal(imgproc.pyrdown(ud).numpy(), O.pyrdown(u)), ("pyrdown", w, h, c)
+        assert np.array_equal(imgproc.pyrup(ud).numpy(), O.pyrup(u)), ("pyrup", w, h, c)
+        shape = str(rng.choice(["box", "box", "cross", "ellipse"]))
+        k = int(rng.choice([3, 5, 7, 9, 13])) if shape == "box" else int(rng.choice([3, 5, 7]))
+        border = str(rng.choice(["constant", "replicate", "reflect101", "reflect"]))
+        if border in ("reflect101", "reflect") and k // 2 >= h:
+            border = "replicate"
+        cv = int(rng.choice([0, 9, 250]))
+        for op, fn in (("dilate", imgproc.dilate), ("erode", imgproc.erode)):
+            got = fn(ud, shape, size=(k, k), border=border, constant_value=cv).numpy()
+            assert np.array_equal(got, O.morphology_u8(u, op, O.morph_kernel(shape, k, k), border, [cv] * c)), (op, w, h, c, shape, k, border, cv)
+        kb = int(rng.choice([3, 5, 7, 9, 11]))
+        sig = (float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 3.0)))
+        assert np.array_equal(imgproc.gaussian_blur(ud, (kb, kb), sig).numpy(), O.gaussian_blur_u8(u, (kb, kb), sig)[0]), ("gaussian u8", w, h, c, kb, sig)
+        assert np.array_equal(imgproc.box_blur(ud, (kb, 3)).numpy(), O.box_blur_u8(u, (kb, 3))), ("box u8", w, h, c, kb)
+        f = _f32(rng, h, w, c)
+        fd = _up(f, gpu_stream)
+        kf = int(rng.choice([3, 5, 9, 13, 19]))
+        got = imgproc.gaussian_blur(fd, (kf, kf), sig).numpy()
+        assert np.array_equal(got.view(np.uint32), O.gaussian_blur(f, (kf, kf), sig).view(np.uint32)), ("gaussian f32", w, h, c, kf, sig)
+
+
 @pytest.mark.parametrize("seed", range(6 + EXTRA))
 def test_fuzz_fused_preprocess(gpu_stream, seed):
     """The north-star family: every source format x resize mode x sampler x f32 / f16 at random (even where 4:2:x needs it)
