@@ -564,7 +564,10 @@ struct PyrRoll {
     int plain;                // write-back instead of streaming stores (kh_common.h::plain_row_stores)
 };
 
-__global__ __launch_bounds__(256, 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {
+// C = 4 (round 6): RGBA images — eight source pixels are two 16-byte loads, four destination pixels one 16-byte store; 4 x 4 byte transposes
+// (kh_common.h::deinterleave_quad) around the same per-channel code.  plain = 2: a destination off a dword (C = 4 only).
+template <int C>
+__global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) {   // (C = 4 at four waves per SIMD spills 28 dwords and runs 9 % slower)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
     if (!xcd_tile(a.tiles, tx, ty, bz)) return;
@@ -574,8 +577,8 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) 
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
     // block-uniform: 12-byte quad offsets are dword-aligned and the image fits the V#'s 2 GiB window -> streaming stores (kh_common.h)
-    const bool stream_ok = ((a.dw * 3) & 3) == 0 && (long long)a.dw * a.dh * 3 <= 0x7fffffffLL;
-    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.dw * a.dh * 3);
+    const bool stream_ok = ((a.dw * C) & 3) == 0 && (long long)a.dw * a.dh * C <= 0x7fffffffLL && (C == 3 || a.plain != 2);
+    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.dw * a.dh * C);
     const int p = 2 * X0 + 8 * lane;                                  // this lane's source pixels p .. p + 7
     const int ph = lane < 32 ? 2 * X0 - 4 : 2 * X0 + 2 * kPdRollWaveDst;   // the wave's halo quads: left in the lower half's lanes, right in the upper's
     const bool edge = 2 * X0 < 4 || 2 * X0 + 2 * kPdRollWaveDst + 4 > a.sw;   // wave-uniform: some lane's pixels need re-indexing
@@ -590,46 +593,53 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) 
             selH |= (uint32_t)min(max(reflect_101(ph + j, a.sw) - phc, 0), 3) << (8 * j);
         }
     }
-    const int seg_bytes = 3 * min(kPdRollWaveDst, a.dw - X0);         // destination bytes of this wave per row (wave-uniform)
-    const int rowb = a.sw * 3;
+    const int seg_bytes = C * min(kPdRollWaveDst, a.dw - X0);         // destination bytes of this wave per row (wave-uniform)
+    const int rowb = a.sw * C;
     const int n = 2 * thr + 3;                                        // source rows walked: 2 Y0 - 2 .. 2 (Y0 + thr - 1) + 2
     int pf = 2 * Y0 - 2;
 
-    uint32_t q[5][9];  // five rows of raw loads in flight per lane: its eight pixels (six dwords) and its half-wave's halo quad
-    auto prefetch = [&](uint32_t (&d)[9]) {
+    uint32_t q[5][3 * C];  // five rows of raw loads in flight per lane: its eight pixels (2 C dwords) and its half-wave's halo quad (C dwords)
+    auto prefetch = [&](uint32_t (&d)[3 * C]) {
         const uint8_t* row = src + (long long)reflect_101(pf, a.sh) * rowb;
-        const uint8_t *rp = row + 3 * pc, *rh = row + 3 * phc;
+        const uint8_t *rp = row + C * pc, *rh = row + C * phc;
+        if constexpr (C == 4) {
+            const u32x4_t v0 = *reinterpret_cast<const u32x4_unaligned*>(rp), v1 = *reinterpret_cast<const u32x4_unaligned*>(rp + 16), hq = *reinterpret_cast<const u32x4_unaligned*>(rh);
+            d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+            d[8] = hq.x; d[9] = hq.y; d[10] = hq.z; d[11] = hq.w;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] = *reinterpret_cast<const u32_unaligned*>(rp + 4 * k);
+            for (int k = 0; k < 2 * C; ++k) d[k] = *reinterpret_cast<const u32_unaligned*>(rp + 4 * k);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) d[6 + k] = *reinterpret_cast<const u32_unaligned*>(rh + 4 * k);
+            for (int k = 0; k < C; ++k) d[2 * C + k] = *reinterpret_cast<const u32_unaligned*>(rh + 4 * k);
+        }
         ++pf;
     };
 #pragma unroll
     for (int i = 0; i < 5; ++i) prefetch(q[i]);
 
-    u16x2_t ring[5][3][2];   // [row][channel][destination pixel pair]: the row pass, 16-bit lanes
+    u16x2_t ring[5][C][2];   // [row][channel][destination pixel pair]: the row pass, 16-bit lanes
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { ring[i][c][0] = u16x2_t{0, 0}; ring[i][c][1] = u16x2_t{0, 0}; }
+        for (int c = 0; c < C; ++c) { ring[i][c][0] = u16x2_t{0, 0}; ring[i][c][1] = u16x2_t{0, 0}; }
 
-    long long out_off = (long long)Y0 * a.dw * 3 + 3 * (long long)X0;   // destination pixel X0 of destination row Y0
+    long long out_off = (long long)Y0 * a.dw * C + C * (long long)X0;   // destination pixel X0 of destination row Y0
     for (int ib = 0; ib < n; ib += 10) {   // 10 = lcm(ring depth, row parity): ring slots and the emit test are compile-time
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
             const int i = ib + s, slot = s % 5;
-            uint32_t d[9];
+            uint32_t d[3 * C];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) d[k] = q[slot][k];
+            for (int k = 0; k < 3 * C; ++k) d[k] = q[slot][k];
             prefetch(q[slot]);
+            // de-interleave: quad [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3] -> one dword per channel (pixel j = byte j), three times
+            uint32_t As[C], Bs[C], Hs[C];
+            deinterleave_quad<C>(d, As);
+            deinterleave_quad<C>(d + C, Bs);
+            deinterleave_quad<C>(d + 2 * C, Hs);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                // de-interleave: quad [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3] -> one dword per channel (pixel j = byte j), three times
-                constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
-                uint32_t A = __builtin_amdgcn_perm(d[2], __builtin_amdgcn_perm(d[1], d[0], in1[c]), in2[c]);
-                uint32_t B = __builtin_amdgcn_perm(d[5], __builtin_amdgcn_perm(d[4], d[3], in1[c]), in2[c]);
-                uint32_t Hq = __builtin_amdgcn_perm(d[8], __builtin_amdgcn_perm(d[7], d[6], in1[c]), in2[c]);
+            for (int c = 0; c < C; ++c) {
+                uint32_t A = As[c], B = Bs[c], Hq = Hs[c];
                 if (edge) {   // wave-uniform
                     const uint32_t a0 = A, b0 = B;
                     A = __builtin_amdgcn_perm(b0, a0, selA);
@@ -646,35 +656,42 @@ __global__ __launch_bounds__(256, 4) void pyrdown_u8_rgb_roll_kernel(PyrRoll a) 
                 ring[slot][c][1] = as_u16x2(h2 | (h3 << 16));
             }
             if ((s & 1) == 0 && i >= 4 && i < n) {   // source row 2 Y + 2 is in: destination row Y = Y0 + (i - 4) / 2
-                uint32_t v[3][2];
+                uint32_t v[C][2];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+                for (int c = 0; c < C; ++c)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const u16x2_t half = {128, 128}, eight = {8, 8}, top = {255, 255};
                         const u16x2_t b5 = binomial5(ring[(s + 1) % 5][c][h], ring[(s + 2) % 5][c][h], ring[(s + 3) % 5][c][h], ring[(s + 4) % 5][c][h], ring[slot][c][h]);
                         v[c][h] = as_u32(__builtin_elementwise_min((b5 + half) >> eight, top));   // pixels (2h, 2h + 1) in bytes 0 and 2
                     }
-                // re-interleave; 12 bytes straight from the owning lane
-                const uint32_t rg01 = __builtin_amdgcn_perm(v[1][0], v[0][0], 0x06020400u);   // R0 G0 R1 G1
-                const uint32_t rg23 = __builtin_amdgcn_perm(v[1][1], v[0][1], 0x06020400u);   // R2 G2 R3 G3
-                const uint32_t w0 = __builtin_amdgcn_perm(v[2][0], rg01, 0x02040100u);        // R0 G0 B0 R1
-                const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[2][0], rg01, 0x0c0c0603u), rg23, 0x01000504u);   // G1 B1 | R2 G2
-                const uint32_t w2 = __builtin_amdgcn_perm(v[2][1], rg23, 0x06030204u);        // B2 R3 G3 B3
-                uint8_t* o = dst + out_off;
-                const int off = 12 * lane;
-                if (off + 12 <= seg_bytes && stream_ok) {
-                    const uint32_t w[3] = {w0, w1, w2};
-                    row_store<3>(out_win, (int)out_off + off, w, a.plain);
-                } else if (off + 12 <= seg_bytes) {
-                    *reinterpret_cast<u32_unaligned*>(o + off) = w0; *reinterpret_cast<u32_unaligned*>(o + off + 4) = w1; *reinterpret_cast<u32_unaligned*>(o + off + 8) = w2;
+                // re-interleave; 4 C bytes straight from the owning lane
+                uint32_t w[C];
+                if constexpr (C == 3) {
+                    const uint32_t rg01 = __builtin_amdgcn_perm(v[1][0], v[0][0], 0x06020400u);   // R0 G0 R1 G1
+                    const uint32_t rg23 = __builtin_amdgcn_perm(v[1][1], v[0][1], 0x06020400u);   // R2 G2 R3 G3
+                    w[0] = __builtin_amdgcn_perm(v[2][0], rg01, 0x02040100u);        // R0 G0 B0 R1
+                    w[1] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[2][0], rg01, 0x0c0c0603u), rg23, 0x01000504u);   // G1 B1 | R2 G2
+                    w[2] = __builtin_amdgcn_perm(v[2][1], rg23, 0x06030204u);        // B2 R3 G3 B3
                 } else {
-                    const uint32_t w[3] = {w0, w1, w2};
+                    uint32_t pl[C];   // one dword per channel (pixel j = byte j) from the pairs in bytes 0 and 2
 #pragma unroll
-                    for (int b = 0; b < 9; ++b)   // at most three pixels of a quad that reaches past the last destination column
+                    for (int c = 0; c < C; ++c) pl[c] = __builtin_amdgcn_perm(v[c][1], v[c][0], 0x06040200u);
+                    interleave_quad<C>(pl, w);
+                }
+                uint8_t* o = dst + out_off;
+                const int off = 4 * C * lane;
+                if (off + 4 * C <= seg_bytes && stream_ok) {
+                    row_store<C>(out_win, (int)out_off + off, w, a.plain);
+                } else if (off + 4 * C <= seg_bytes) {
+#pragma unroll
+                    for (int k = 0; k < C; ++k) *reinterpret_cast<u32_unaligned*>(o + off + 4 * k) = w[k];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 3 * C; ++b)   // at most three pixels of a quad that reaches past the last destination column
                         if (off + b < seg_bytes) o[off + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
                 }
-                out_off += (long long)a.dw * 3;
+                out_off += (long long)a.dw * C;
             }
         }
     }
@@ -1901,8 +1918,9 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
     if (int32_t rc = check_pyr("kh_pyrdown_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
     const bool no_roll = dev_opt(kOptPyrRoll) == 0;   // dev / test knob: the tile kernel
-    if (channels == 3 && sw >= 8 && !no_roll) {   // RGB8: the rolling planar kernel
-        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}, plain_row_stores((int64_t)dw * channels, dst, ds, batch)};
+    if ((channels == 3 || channels == 4) && sw >= 8 && !no_roll) {   // RGB8 / RGBA8 (round 6): the rolling planar kernel
+        const bool dword_ok = reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);
+        PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}, channels == 4 && !dword_ok ? 2 : plain_row_stores((int64_t)dw * channels, dst, ds, batch)};
         const unsigned tiles_x = cdiv(dw, kPdRollTileDst);
         const long long cols_blocks = (long long)tiles_x * batch;
         long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
@@ -1911,7 +1929,8 @@ int32_t kh_pyrdown_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int3
         r.th = (int)cdiv(dh, strips);
         r.tiles = xcd_tiles(tiles_x, cdiv(dh, r.th), (unsigned)batch, kXcdEighth);
         KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrdown_u8: batch x tiles exceeds one launch");
-        hipLaunchKernelGGL(pyrdown_u8_rgb_roll_kernel, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+        if (channels == 4) hipLaunchKernelGGL(pyrdown_u8_rgb_roll_kernel<4>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+        else hipLaunchKernelGGL(pyrdown_u8_rgb_roll_kernel<3>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
         return check_launch("kh_pyrdown_u8");
     }
     if (channels == 1 && sw >= 16 && !no_roll && (int64_t)dw * dh <= kI32Max) {   // one channel: the rolling gray kernel

@@ -16,7 +16,8 @@ if len(sys.argv) > 1:
     check(lib.kh_debug_set_option(name.encode(), int(val)))
     print(f"# dev option {name} = {val}")
 N, W, H = 32, 3840, 2160
-for dt, es in (("u8", 1), ("f32", 4)):
+import os
+for dt, es in ((("u8", 1),) if os.environ.get("U8_ONLY") else (("u8", 1), ("f32", 4))):
     for ch in (1, 3, 4):
         for up in (False, True):
             n = W * H * ch

@@ -130,6 +130,34 @@ def test_pyramid_u8_gray_ragged_widths(gpu_stream, dev_option):
             assert_same_bits(got[3 + i * dw * dh:3 + (i + 1) * dw * dh].reshape(dh, dw, 1), O.pyrup(src[i]) if is_up else O.pyrdown(src[i]), f"offset destination {'up' if is_up else 'down'} {w}x{h} frame {i}")
 
 
+def test_pyrdown_u8_rgba_rolling_kernel(gpu_stream, dev_option):
+    """Four-channel sources on the rolling planar pyrdown kernel (round 6: two 16-byte loads and one 16-byte store per lane, 4 x 4 byte
+    transposes around the RGB kernel's per-channel code): the oracle's bytes on widths either side of the wave (512 source pixels) and
+    block (2048) seams, partial last quads, odd widths and heights, the narrowest images, a batch, a destination off a dword;
+    pyr_roll = 0 keeps the tile kernel."""
+    from kornia_rs import _ffi
+    for w, h in [(8, 9), (9, 8), (10, 3), (11, 5), (15, 1), (497, 12), (503, 7), (511, 9), (512, 7), (513, 6), (514, 8), (519, 5), (520, 6), (521, 4), (2047, 5), (2049, 6), (2056, 4), (2057, 3), (300, 131)]:
+        src = make(w, h, 4, np.uint8, seed=w + h)
+        want = O.pyrdown(src)
+        for opt in ((-1, 0) if w in (9, 513, 2057, 300) else (-1,)):
+            dev_option("pyr_roll", opt)
+            assert_same_bits(pyr_gpu(gpu_stream, src, False)[0], want, f"pyrdown u8 rgba {w}x{h} pyr_roll={opt}")
+    dev_option("pyr_roll", -1)
+    batch = np.stack([make(301, 70, 4, np.uint8, seed=k) for k in range(3)])
+    got = pyr_gpu(gpu_stream, batch, False, batch=3)
+    for k in range(3):
+        assert_same_bits(got[k], O.pyrdown(batch[k]), f"pyrdown u8 rgba batch frame {k}")
+    w, h, n = 301, 7, 2
+    src = np.stack([make(w, h, 4, np.uint8, seed=s_) for s_ in range(n)])
+    dw, dh = (w + 1) // 2, (h + 1) // 2
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * dw * dh * 4 + 8)
+    _ffi.check(_ffi.lib.kh_pyrdown_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 3, w, h, 4, n, w * h * 4, dw * dh * 4))
+    got = d_dst.to_numpy(np.uint8, (n * dw * dh * 4 + 8,))
+    assert got[:3].tolist() == [255] * 3 and got[3 + n * dw * dh * 4:3 + n * dw * dh * 4 + 5].tolist() == [255] * 5, "bytes outside the destination were written"
+    for i in range(n):
+        assert_same_bits(got[3 + i * dw * dh * 4:3 + (i + 1) * dw * dh * 4].reshape(dh, dw, 4), O.pyrdown(src[i]), f"offset destination frame {i}")
+
+
 def test_pyramid_batch_and_host_api(gpu_stream):
     from kornia_rs import Image, ImageError, imgproc
     n = 3
