@@ -831,7 +831,9 @@ constexpr int kPuRollTileSrc = 4 * kPuRollWaveSrc;
 
 __device__ __forceinline__ uint32_t avg_round_u8x4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
 
-__global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) {   // th = SOURCE rows per strip here
+// C = 4 (round 6): RGBA images — a 16-byte source quad per lane, 32 destination bytes per lane and row through the same LDS transposition.
+template <int C>
+__global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) {   // th = SOURCE rows per strip here
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
     if (!xcd_tile(a.tiles, tx, ty, bz)) return;
@@ -840,8 +842,8 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) { 
     const int y0 = ty * a.th, thr = min(a.th, a.sh - y0);
     const uint8_t* __restrict__ src = a.src + (long long)bz * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz * a.ds;
-    const bool stream_ok = ((a.dw * 3) & 3) == 0 && (long long)a.dw * a.dh * 3 <= 0x7fffffffLL;   // block-uniform (see pyrdown above)
-    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.dw * a.dh * 3);
+    const bool stream_ok = ((a.dw * C) & 3) == 0 && (long long)a.dw * a.dh * C <= 0x7fffffffLL && (C == 3 || a.plain != 2);   // block-uniform (see pyrdown above)
+    const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.dw * a.dh * C);
     const int p = x0 + 4 * lane;                                      // this lane's source pixels p .. p + 3
     const int ph = lane < 32 ? x0 - 4 : x0 + kPuRollWaveSrc;          // the wave's halo quads: left in the lower half's lanes, right in the upper's
     const bool edge = x0 < 4 || x0 + kPuRollWaveSrc + 4 > a.sw;       // wave-uniform
@@ -855,45 +857,53 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) { 
             hsel |= (uint32_t)min(max(reflect_101(ph + j, a.sw) - phc, 0), 3) << (8 * j);
         }
     }
-    const int rowb = a.sw * 3;
-    const long long drow = (long long)a.dw * 3;
-    const int seg_bytes = 6 * min(kPuRollWaveSrc, a.sw - x0);        // destination bytes of this wave per row (wave-uniform)
-    __shared__ __attribute__((aligned(16))) uint32_t xpose[4][2][6 * 64];   // per wave, per destination row of a step: 64 lanes x 24 bytes
+    const int rowb = a.sw * C;
+    const long long drow = (long long)a.dw * C;
+    const int seg_bytes = 2 * C * min(kPuRollWaveSrc, a.sw - x0);    // destination bytes of this wave per row (wave-uniform)
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[4][2][2 * C * 64];   // per wave, per destination row of a step: 64 lanes x 8 C bytes
     const int n = thr + 2;                                            // source rows walked: y0 - 1 .. y0 + thr
     int pf = y0 - 1;
 
-    uint32_t q[3][6];   // the lane's quad and its half-wave's halo quad
-    auto prefetch = [&](uint32_t (&d)[6]) {
+    uint32_t q[3][2 * C];   // the lane's quad and its half-wave's halo quad
+    auto prefetch = [&](uint32_t (&d)[2 * C]) {
         const uint8_t* row = src + (long long)reflect_101(pf, a.sh) * rowb;
-        const uint8_t *rp = row + 3 * pc, *rh = row + 3 * phc;
-        d[0] = *reinterpret_cast<const u32_unaligned*>(rp); d[1] = *reinterpret_cast<const u32_unaligned*>(rp + 4); d[2] = *reinterpret_cast<const u32_unaligned*>(rp + 8);
-        d[3] = *reinterpret_cast<const u32_unaligned*>(rh); d[4] = *reinterpret_cast<const u32_unaligned*>(rh + 4); d[5] = *reinterpret_cast<const u32_unaligned*>(rh + 8);
+        const uint8_t *rp = row + C * pc, *rh = row + C * phc;
+        if constexpr (C == 4) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_unaligned*>(rp), hq = *reinterpret_cast<const u32x4_unaligned*>(rh);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; d[4] = hq.x; d[5] = hq.y; d[6] = hq.z; d[7] = hq.w;
+        } else {
+            d[0] = *reinterpret_cast<const u32_unaligned*>(rp); d[1] = *reinterpret_cast<const u32_unaligned*>(rp + 4); d[2] = *reinterpret_cast<const u32_unaligned*>(rp + 8);
+            d[3] = *reinterpret_cast<const u32_unaligned*>(rh); d[4] = *reinterpret_cast<const u32_unaligned*>(rh + 4); d[5] = *reinterpret_cast<const u32_unaligned*>(rh + 8);
+        }
         ++pf;
     };
 #pragma unroll
     for (int i = 0; i < 3; ++i) prefetch(q[i]);
 
     // the row pass of three source rows: [row][channel][even / odd destination columns], packed bytes, and unpacked 16-bit lanes
-    uint32_t hp_[3][3][2], hl[3][3][2], hh[3][3][2];
+    uint32_t hp_[3][C][2], hl[3][C][2], hh[3][C][2];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < C; ++c)
 #pragma unroll
             for (int e = 0; e < 2; ++e) { hp_[i][c][e] = 0; hl[i][c][e] = 0; hh[i][c][e] = 0; }
 
-    long long row_off = (long long)(2 * y0) * drow + 6 * (long long)x0;   // destination pixel 2 x0 of destination row 2 y0
+    long long row_off = (long long)(2 * y0) * drow + 2 * C * (long long)x0;   // destination pixel 2 x0 of destination row 2 y0
     for (int ib = 0; ib < n; ib += 3) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int i = ib + s;
-            const uint32_t d0 = q[s][0], d1 = q[s][1], d2 = q[s][2], g0 = q[s][3], g1 = q[s][4], g2 = q[s][5];
-            prefetch(q[s]);
+            uint32_t dq[2 * C];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                constexpr uint32_t in1[3] = {0x0c060300u, 0x0c070401u, 0x0c0c0502u}, in2[3] = {0x05020100u, 0x06020100u, 0x07040100u};
-                uint32_t A = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, in1[c]), in2[c]);   // this channel's four pixels
-                uint32_t Hq = __builtin_amdgcn_perm(g2, __builtin_amdgcn_perm(g1, g0, in1[c]), in2[c]);  // and the halo quad's
+            for (int k = 0; k < 2 * C; ++k) dq[k] = q[s][k];
+            prefetch(q[s]);
+            uint32_t As[C], Hs[C];
+            deinterleave_quad<C>(dq, As);       // each channel's four pixels
+            deinterleave_quad<C>(dq + C, Hs);   // and the halo quad's
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                uint32_t A = As[c], Hq = Hs[c];
                 if (edge) { A = __builtin_amdgcn_perm(0u, A, esel); Hq = __builtin_amdgcn_perm(0u, Hq, hsel); }
                 const uint32_t prev = from_lane_below(A, Hq), next = from_lane_above(A, Hq);
                 const uint32_t w2 = __builtin_amdgcn_alignbyte(next, A, 1);                 // p[x+1] for the four pixels
@@ -910,9 +920,9 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) { 
             }
             if (i >= 2 && i < n) {   // rows y - 1, y, y + 1 are in: destination rows 2 y and 2 y + 1 (y = y0 + i - 2)
                 const int sp = (s + 1) % 3, sc = (s + 2) % 3, sn = s;   // compile-time after unrolling
-                uint32_t ve[3][2], vo[3][2];
+                uint32_t ve[C][2], vo[C][2];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+                for (int c = 0; c < C; ++c)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const uint32_t lo = ((mad24(hl[sc][c][e], 6u, hl[sp][c][e]) + hl[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
@@ -926,9 +936,9 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) { 
                 // of the segment with a third of its bytes: 2.63 ms per 256 4K outputs, the vector ALUs 28 % busy (r03r).
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    uint32_t pl[3][2];   // per channel: destination pixels 0..3 and 4..7 (even / odd columns merged)
+                    uint32_t pl[C][2];   // per channel: destination pixels 0..3 and 4..7 (even / odd columns merged)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
+                    for (int c = 0; c < C; ++c) {
                         const uint32_t ee = r ? vo[c][0] : ve[c][0], oo = r ? vo[c][1] : ve[c][1];
                         pl[c][0] = __builtin_amdgcn_perm(oo, ee, 0x05010400u);   // e0 o0 e1 o1
                         pl[c][1] = __builtin_amdgcn_perm(oo, ee, 0x07030602u);   // e2 o2 e3 o3
@@ -936,10 +946,12 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) { 
                     uint32_t* xr = xpose[wv][r];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {   // re-interleave four pixels: [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3]
-                        const uint32_t rg = __builtin_amdgcn_perm(pl[1][h], pl[0][h], 0x05010400u), rg2 = __builtin_amdgcn_perm(pl[1][h], pl[0][h], 0x07030602u);
-                        xr[6 * lane + 3 * h] = __builtin_amdgcn_perm(pl[2][h], rg, 0x02040100u);
-                        xr[6 * lane + 3 * h + 1] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pl[2][h], rg, 0x0c0c0503u), rg2, 0x01000504u);
-                        xr[6 * lane + 3 * h + 2] = __builtin_amdgcn_perm(pl[2][h], rg2, 0x07030206u);
+                        uint32_t ph_[C], wq[C];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) ph_[c] = pl[c][h];
+                        interleave_quad<C>(ph_, wq);
+#pragma unroll
+                        for (int k = 0; k < C; ++k) xr[2 * C * lane + C * h + k] = wq[k];
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1992,7 +2004,7 @@ int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_
     const bool gray = channels == 1 && sw >= 8 && (int64_t)sw * sh * 4 <= kI32Max;
     const bool gray_dword_ok = sw % 2 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
     const bool gray_ragged = sw % 8 != 0 || !gray_dword_ok;   // (round 6: any width / alignment on the RAGGED instantiation)
-    if (direct || no_roll || !(channels == 3 || gray) || sw < 4 || (int64_t)sw * 6 >= (1 << 24)) return kh_pyrup_u8_pairs(stream, src, dst, sw, sh, channels, batch, ss, ds);
+    if (direct || no_roll || !(channels == 3 || channels == 4 || gray) || sw < 4 || (int64_t)sw * 8 >= (1 << 24)) return kh_pyrup_u8_pairs(stream, src, dst, sw, sh, channels, batch, ss, ds);
     const int dw = sw * 2, dh = sh * 2;
     if (int32_t rc = check_pyr("kh_pyrup_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
@@ -2019,7 +2031,10 @@ int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_
     r.th = (int)cdiv(sh, strips);
     r.tiles = xcd_tiles(tiles_x, cdiv(sh, r.th), (unsigned)batch, kXcdEighth);
     KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrup_u8: batch x tiles exceeds one launch");
-    hipLaunchKernelGGL(pyrup_u8_rgb_roll_kernel, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+    if (channels == 4) {   // RGBA (round 6); plain = 2: a destination off a dword
+        if (!(reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0))) r.plain = 2;
+        hipLaunchKernelGGL(pyrup_u8_rgb_roll_kernel<4>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
+    } else hipLaunchKernelGGL(pyrup_u8_rgb_roll_kernel<3>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
     return check_launch("kh_pyrup_u8");
 }
 

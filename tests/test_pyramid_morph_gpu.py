@@ -158,6 +158,35 @@ def test_pyrdown_u8_rgba_rolling_kernel(gpu_stream, dev_option):
         assert_same_bits(got[3 + i * dw * dh * 4:3 + (i + 1) * dw * dh * 4].reshape(dh, dw, 4), O.pyrdown(src[i]), f"offset destination frame {i}")
 
 
+def test_pyrup_u8_rgba_rolling_kernel(gpu_stream, dev_option):
+    """Four-channel sources on the rolling planar pyrup kernel (round 6: a 16-byte quad per lane, 32 destination bytes per lane and row
+    through the wave's LDS transposition): the oracle's bytes on widths either side of the wave (256 source pixels) and block (1024)
+    seams, partial last quads, the narrowest images, strips of a few rows, a batch, a destination off a dword; pyr_roll = 0 keeps the
+    pair kernel."""
+    from kornia_rs import _ffi
+    for w, h in [(4, 3), (5, 2), (7, 9), (247, 5), (248, 17), (249, 3), (251, 4), (253, 6), (255, 4), (256, 6), (257, 5), (259, 3), (260, 7), (261, 2), (992, 3), (1003, 8), (1023, 3), (1024, 4),
+                 (1025, 5), (1028, 2), (1029, 3), (3, 40), (500, 47)]:
+        src = make(w, h, 4, np.uint8, seed=w + h)
+        want = O.pyrup(src)
+        for opt in ((-1, 0) if w in (5, 257, 1029, 500) else (-1,)):
+            dev_option("pyr_roll", opt)
+            assert_same_bits(pyr_gpu(gpu_stream, src, True)[0], want, f"pyrup u8 rgba {w}x{h} pyr_roll={opt}")
+    dev_option("pyr_roll", -1)
+    batch = np.stack([make(301, 70, 4, np.uint8, seed=k) for k in range(3)])
+    got = pyr_gpu(gpu_stream, batch, True, batch=3)
+    for k in range(3):
+        assert_same_bits(got[k], O.pyrup(batch[k]), f"pyrup u8 rgba batch frame {k}")
+    w, h, n = 301, 7, 2
+    src = np.stack([make(w, h, 4, np.uint8, seed=s_) for s_ in range(n)])
+    dw, dh = 2 * w, 2 * h
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * dw * dh * 4 + 8)
+    _ffi.check(_ffi.lib.kh_pyrup_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 3, w, h, 4, n, w * h * 4, dw * dh * 4))
+    got = d_dst.to_numpy(np.uint8, (n * dw * dh * 4 + 8,))
+    assert got[:3].tolist() == [255] * 3 and got[3 + n * dw * dh * 4:3 + n * dw * dh * 4 + 5].tolist() == [255] * 5, "bytes outside the destination were written"
+    for i in range(n):
+        assert_same_bits(got[3 + i * dw * dh * 4:3 + (i + 1) * dw * dh * 4].reshape(dh, dw, 4), O.pyrup(src[i]), f"offset destination frame {i}")
+
+
 def test_pyramid_batch_and_host_api(gpu_stream):
     from kornia_rs import Image, ImageError, imgproc
     n = 3
