@@ -388,11 +388,15 @@ __global__ __launch_bounds__(kBlock, C == 4 ? (K <= 3 ? 5 : (K <= 5 ? 4 : (K <= 
 // waves) by re-indexing.  RAGGED: any width >= 16 and any alignment (kh_common.h::remap16_*; plain = 2: unaligned global stores).
 // Same integers as the other kernels: byte-identical (tests run both).  3..9 taps per axis whose quantised taps sum to <= 256.
 constexpr int kGrayWavePx = 1024, kGrayTilePx = 4 * kGrayWavePx;
+// K = 11 / 13 / 15: the window reaches seven pixels either side, so the string around a dword is (two before | it | two after) and a half-wave's
+// halo is eight bytes; 200-250 registers (two waves per SIMD) — the K rows of loads in flight per lane still cover the latency.
 template <int K, bool BINOMIAL, bool RAGGED>
-__global__ __launch_bounds__(kBlock, K <= 3 ? 6 : (K <= 5 ? 5 : (K <= 7 ? 4 : 3))) void blur_u8_gray_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky, int plain) {
+__global__ __launch_bounds__(kBlock, K <= 3 ? 6 : (K <= 5 ? 5 : (K <= 7 ? 4 : (K <= 9 ? 3 : (K == 15 && RAGGED ? 1 : 2))))) void blur_u8_gray_kernel(U8FilterArgs a, TapsQ kx, TapsQ ky, int plain) {
     static_assert(!BINOMIAL || K == 3, "the binomial is 3 x 3");
     constexpr int H = K / 2, G = (K + 3) / 4;   // taps are consumed four at a time
-    static_assert(K >= 3 && K <= 9 && (K & 1), "3..9 taps: one neighbour dword on each side covers the window");
+    constexpr bool WIDE = K > 9;                // two neighbour dwords on each side
+    constexpr int NH = WIDE ? 2 : 1, HP = 4 * NH;   // halo dwords / pixels per half-wave
+    static_assert(K >= 3 && K <= 15 && (K & 1), "3..15 taps");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
     if (!xcd_tile(a.tiles, tx, ty, bz)) return;
@@ -404,30 +408,34 @@ __global__ __launch_bounds__(kBlock, K <= 3 ? 6 : (K <= 5 ? 5 : (K <= 7 ? 4 : 3)
     const __amdgpu_buffer_rsrc_t out_win = stream_window(dst, (long long)a.rows * a.cols);   // (rows * cols < 2^31: host-checked)
     const int p = p0 + 16 * lane;                             // this lane's sixteen pixels
     const int nvalid = min(max(a.cols - p, 0), 16);           // RAGGED: 0 .. 16; otherwise all sixteen or none (cols % 16 == 0: host-checked)
-    const int ph = lane < 32 ? p0 - 4 : p0 + kGrayWavePx;     // the wave's halo dwords: left in the lower half's lanes, right in the upper's
-    const bool edge = p0 < 4 || p0 + kGrayWavePx + 4 > a.cols;   // wave-uniform
-    const int pc = min(p, a.cols - 16), phc = min(max(ph, 0), a.cols - 4);   // cols >= 16: host-checked
-    uint32_t hsel = 0x03020100u;
+    const int ph = lane < 32 ? p0 - HP : p0 + kGrayWavePx;    // the wave's halo dwords: left in the lower half's lanes, right in the upper's
+    const bool edge = p0 < HP || p0 + kGrayWavePx + HP > a.cols;   // wave-uniform
+    const int pc = min(p, a.cols - 16), phc = min(max(ph, 0), a.cols - HP);   // cols >= 16: host-checked
+    uint32_t hsel = 0x03020100u, hsel2 = 0x07060504u;   // halo byte j <- loaded halo byte clamp(ph + j) - phc (two dwords when WIDE)
     Remap16 rm{};
     if (edge) {
-        hsel = 0;
+        hsel = hsel2 = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hsel |= (uint32_t)min(max(min(max(ph + j, 0), a.cols - 1) - phc, 0), 3) << (8 * j);
+        for (int j = 0; j < 4; ++j) {
+            hsel |= (uint32_t)min(max(min(max(ph + j, 0), a.cols - 1) - phc, 0), HP - 1) << (8 * j);
+            hsel2 |= (uint32_t)min(max(min(max(ph + 4 + j, 0), a.cols - 1) - phc, 0), HP - 1) << (8 * j);
+        }
         if constexpr (RAGGED) rm = remap16_setup(p, pc, [&](int x) { return min(x, a.cols - 1); });
     }
     const int nrows = min(a.th, a.rows - y0) + 2 * H;
     int pf_row = y0 - H;
 
-    uint32_t wq[3];   // horizontal taps as bytes, four per dword (zero padded): tap t = byte t & 3 of wq[t >> 2]
+    uint32_t wq[4];   // horizontal taps as bytes, four per dword (zero padded): tap t = byte t & 3 of wq[t >> 2]
 #pragma unroll
-    for (int g = 0; g < 3; ++g) wq[g] = kx.k[4 * g] | (kx.k[4 * g + 1] << 8) | (kx.k[4 * g + 2] << 16) | (kx.k[4 * g + 3] << 24);
+    for (int g = 0; g < 4; ++g) wq[g] = kx.k[4 * g] | (kx.k[4 * g + 1] << 8) | (kx.k[4 * g + 2] << 16) | (kx.k[4 * g + 3] << 24);
 
-    uint32_t q[K][5];  // K rows of raw loads in flight per lane: its sixteen pixels and its half-wave's halo dword
-    auto prefetch = [&](uint32_t (&d)[5]) {
+    uint32_t q[K][4 + NH];  // K rows of raw loads in flight per lane: its sixteen pixels and its half-wave's halo dword(s)
+    auto prefetch = [&](uint32_t (&d)[4 + NH]) {
         const uint8_t* rp = src + (long long)min(max(pf_row, 0), a.rows - 1) * a.cols;   // replicate rows
         const u32x4_t v = *reinterpret_cast<const u32x4_unaligned*>(rp + pc);
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         d[4] = *reinterpret_cast<const u32u*>(rp + phc);
+        if constexpr (WIDE) d[5] = *reinterpret_cast<const u32u*>(rp + phc + 4);
         ++pf_row;
     };
 #pragma unroll
@@ -444,14 +452,17 @@ __global__ __launch_bounds__(kBlock, K <= 3 ? 6 : (K <= 5 ? 5 : (K <= 7 ? 4 : 3)
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             const int r = rb + s;
-            uint32_t cur[4] = {q[s][0], q[s][1], q[s][2], q[s][3]}, halo = q[s][4];
+            uint32_t cur[4] = {q[s][0], q[s][1], q[s][2], q[s][3]}, halo = q[s][4], halo2 = WIDE ? q[s][4 + NH - 1] : 0u;
             prefetch(q[s]);
             if (edge) {   // wave-uniform
                 if constexpr (RAGGED) remap16_apply(rm, cur, 0u);
-                else cur[0] = nvalid ? cur[0] : __builtin_amdgcn_perm(0u, cur[3], 0x03030303u);   // a lane past the row end: the row's last pixel, replicated
-                halo = __builtin_amdgcn_perm(0u, halo, hsel);
+                else if (!nvalid) { cur[0] = __builtin_amdgcn_perm(0u, cur[3], 0x03030303u); cur[1] = cur[0]; }   // a lane past the row end: the row's last pixel, replicated
+                if constexpr (WIDE) { const uint32_t h0 = halo, h1 = halo2; halo = __builtin_amdgcn_perm(h1, h0, hsel); halo2 = __builtin_amdgcn_perm(h1, h0, hsel2); }
+                else halo = __builtin_amdgcn_perm(0u, halo, hsel);
             }
-            const uint32_t prevd = from_lane_below(cur[3], halo), nextd = from_lane_above(cur[0], halo);
+            // (WIDE: lane 0's fills are its halo dwords (p0 - 8 .., p0 - 4 ..), lane 63's (p0 + 1024 .., p0 + 1028 ..))
+            const uint32_t prevd = from_lane_below(cur[3], WIDE ? halo2 : halo), nextd = from_lane_above(cur[0], halo);
+            const uint32_t prevd2 = WIDE ? from_lane_below(cur[2], halo) : 0u, nextd2 = WIDE ? from_lane_above(cur[1], halo2) : 0u;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t prev = c == 0 ? prevd : cur[c - 1], next = c == 3 ? nextd : cur[c + 1];
@@ -460,14 +471,16 @@ __global__ __launch_bounds__(kBlock, K <= 3 ? 6 : (K <= 5 ? 5 : (K <= 7 ? 4 : 3)
                     ring[s][c][0] = rhadd4(rhadd4(lft, cur[c]), rhadd4(cur[c], rgt));
                     continue;
                 }
-                const uint32_t str[4] = {prev, cur[c], next, next};   // bytes 0..11 = pixels -4 .. +7 of this dword (+ a don't-care dword)
+                const uint32_t prev2 = c >= 2 ? cur[c >= 2 ? c - 2 : 0] : (c == 1 ? prevd : prevd2), next2 = c <= 1 ? cur[c <= 1 ? c + 2 : 3] : (c == 2 ? nextd : nextd2);
+                // bytes 0.. = pixels -4 (WIDE: -8) .. of this dword (+ a don't-care dword)
+                const uint32_t str[6] = {WIDE ? prev2 : prev, WIDE ? prev : cur[c], WIDE ? cur[c] : next, WIDE ? next : next, next2, next2};
                 uint32_t sum[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint32_t acc = 128u;   // the reference's rounding half
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
-                        constexpr int kBase = 4 - H;
+                        constexpr int kBase = (WIDE ? 8 : 4) - H;
                         const int off = kBase + j + 4 * g;   // compile-time after unrolling: first byte of this group of four taps
                         const uint32_t win = (off & 3) == 0 ? str[off >> 2] : __builtin_amdgcn_alignbyte(str[(off >> 2) + 1], str[off >> 2], (uint32_t)(off & 3));
                         acc = __builtin_amdgcn_udot4(win, wq[g], acc, false);
@@ -661,7 +674,7 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
         const bool rgb_off = dev_opt(kOptU8BlurRgb) == 0;   // test option: the interleaved kernel (what the other channel counts take)
         const bool rgb = (C == 3 || C == 4) && K <= 9 && (binomial ? K == 3 : (sxq <= 256 && syq <= 256)) && cols >= 4 && !rgb_off;   // (C = 4: round 6)
         // one channel, 3..9 taps: the rolling gray kernel (round 6; the same test option keeps the interleaved kernel)
-        const bool gray = C == 1 && K <= 9 && (binomial ? K == 3 : (sxq <= 256 && syq <= 256)) && cols >= 16 && (int64_t)rows * cols <= kI32Max && !rgb_off;
+        const bool gray = C == 1 && K <= 15 && (binomial ? K == 3 : (sxq <= 256 && syq <= 256)) && cols >= 16 && (int64_t)rows * cols <= kI32Max && !rgb_off;   // (11-15 taps: round 6, later)
         const bool gray_dword_ok = cols % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
         const bool gray_ragged = cols % 16 != 0 || !gray_dword_ok;
         const unsigned tiles_x = rgb ? cdiv(cols, kRgbTilePx) : (gray ? cdiv(cols, kGrayTilePx) : cdiv(rowlen, kU8Tile));
@@ -681,7 +694,10 @@ int32_t launch_blur_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int
                 case 3: if (binomial) KH_GB(3, true); else KH_GB(3, false); break;
                 case 5: KH_GB(5, false); break;
                 case 7: KH_GB(7, false); break;
-                default: KH_GB(9, false); break;
+                case 9: KH_GB(9, false); break;
+                case 11: KH_GB(11, false); break;
+                case 13: KH_GB(13, false); break;
+                default: KH_GB(15, false); break;
             }
 #undef KH_GB
             return check_launch(what);

@@ -122,9 +122,10 @@ def test_blur_u8_binomial_planar_kernel(gpu_stream, dev_option):
         assert_same_bits(got[k], O.gaussian_blur_u8(src[k], (3, 3), (0.8, 0.8))[0], f"frame {k}")
 
 
-@pytest.mark.parametrize("k", [3, 5, 7, 9])
+@pytest.mark.parametrize("k", [3, 5, 7, 9, 11, 13, 15])
 def test_blur_u8_gray_rolling_kernel(gpu_stream, dev_option, k):
-    """Single-channel images take the rolling gray kernel for 3..9 taps (sixteen pixels per lane, 1024 per wave, 4096 per block; round 6),
+    """Single-channel images take the rolling gray kernel for 3..15 taps (sixteen pixels per lane, 1024 per wave, 4096 per block; round 6;
+    beyond 9 taps with two neighbour dwords and an eight-byte halo on each side),
     widths that are not whole lanes — or destinations off a dword — its RAGGED instantiation: the oracle's bytes for every residue of
     the width mod 16, either side of the lane / wave / block seams, rows fewer than taps, the binomial band and sigmas just outside it,
     box kernels, unequal tap counts, a batch, a destination at an odd address; u8_blur_rgb = 0 keeps the interleaved kernel."""
