@@ -143,7 +143,7 @@ template <int C, int OP>
 __device__ __forceinline__ uint32_t px_any(const Rz& a, const uint8_t* __restrict__ src, int x, int y, int yi, uint32_t fy) {
     if constexpr (OP == kRzNearest) return px_nearest<C>(a, src, x, yi);
     else if constexpr (OP == kRzBilinear) return px_bilinear<C>(a, src, x, yi, fy);
-    else if constexpr (OP == kRzDown2) return px_down2(a, src, x, y);
+    else if constexpr (OP == kRzDown2) { static_assert(C == 3, "px_down2 is the RGB special case"); return px_down2(a, src, x, y); }
     else return px_up2(a, src, x, y);
 }
 // four packed pixels -> C dwords -> one streaming store at pixel x0 of the row window
@@ -181,13 +181,70 @@ __global__ __launch_bounds__(kBx* kBy) void resize_u8_quads_kernel(Rz a) {
     const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
     const __amdgpu_buffer_rsrc_t ow = stream_window(a.dst + (long long)bz_ * a.ds + (long long)y * a.dw * C, (long long)a.dw * C);
     if (x0 >= a.dw) return;
-    int yi;
-    uint32_t fy;
-    px_row_setup<OP>(a, y, yi, fy);
-    uint32_t p[4];
+    if constexpr (OP == kRzDown2 && C == 3) {
+        // RGB exact 2x (round 6, later): the per-pixel form above costs 24 byte loads per output pixel; here a lane's four outputs come from six
+        // dword loads per source row (eight pixels = 24 bytes), de-interleaved into channel dwords (kh_common.h::deinterleave_quad), the
+        // 2 x 2 sums on packed bytes as for one channel, and three dwords out.  Same integers: (a + b + c + d + 2) >> 2.
+        const uint8_t* r0 = src + ((long long)(2 * y) * a.sw + 2 * x0) * 3;
+        const uint8_t* r1 = r0 + (long long)a.sw * 3;
+        constexpr uint32_t kM = 0x00ff00ffu;
+        uint32_t t[6], b[6];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = px_any<C, OP>(a, src, x0 + j, y, yi, fy);
-    store_quad_u8<C>(ow, x0, p, a.plain);
+        for (int k = 0; k < 6; ++k) { t[k] = *reinterpret_cast<const u32_unaligned*>(r0 + 4 * k); b[k] = *reinterpret_cast<const u32_unaligned*>(r1 + 4 * k); }
+        uint32_t tA[3], tB[3], bA[3], bB[3], pl[3], w[3];
+        deinterleave_quad<3>(t, tA); deinterleave_quad<3>(t + 3, tB);
+        deinterleave_quad<3>(b, bA); deinterleave_quad<3>(b + 3, bB);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t s0 = (tA[c] & kM) + ((tA[c] >> 8) & kM) + (bA[c] & kM) + ((bA[c] >> 8) & kM) + 0x00020002u;   // outputs 0, 1 in 16-bit lanes
+            const uint32_t s1 = (tB[c] & kM) + ((tB[c] >> 8) & kM) + (bB[c] & kM) + ((bB[c] >> 8) & kM) + 0x00020002u;   // outputs 2, 3
+            pl[c] = __builtin_amdgcn_perm((s1 >> 2) & kM, (s0 >> 2) & kM, 0x06040200u);
+        }
+        interleave_quad<3>(pl, w);
+        row_store<3>(ow, x0 * 3, w, a.plain);
+        return;
+    } else if constexpr (OP == kRzDown2) {
+        // Exact 2x downscale of 1 / 4 channels (round 6).  The reference has the box special case for RGB only; its generic Q14 bilinear
+        // at this scale has fx = fy = 8192 for every pixel (s = 2 i + 0.5, no clamp reached), and ((p00 + p01) 2^13 2^13 + (p10 + p11) 2^13 2^13
+        // + 2^27) >> 28 == (p00 + p01 + p10 + p11 + 2) >> 2 exactly: the 2 x 2 box on packed bytes (two bytes per 16-bit lane) instead
+        // of four u64 multiply-accumulates per channel.  The byte-pair sums stay below 2^10.
+        const uint8_t* r0 = src + ((long long)(2 * y) * a.sw + 2 * x0) * C;
+        const uint8_t* r1 = r0 + (long long)a.sw * C;
+        constexpr uint32_t kM = 0x00ff00ffu;
+        if constexpr (C == 1) {
+            const uint64_t t = *reinterpret_cast<const u64_unaligned*>(r0), b = *reinterpret_cast<const u64_unaligned*>(r1);
+            uint32_t o2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {   // four source pixels of both rows -> two outputs in 16-bit lanes
+                const uint32_t tv = (uint32_t)(t >> (32 * h)), bv = (uint32_t)(b >> (32 * h));
+                const uint32_t sum = (tv & kM) + ((tv >> 8) & kM) + (bv & kM) + ((bv >> 8) & kM) + 0x00020002u;
+                o2[h] = (sum >> 2) & kM;
+            }
+            const uint32_t w[1] = {__builtin_amdgcn_perm(o2[1], o2[0], 0x06040200u)};
+            row_store<1>(ow, x0, w, a.plain);
+        } else {
+            static_assert(C == 4, "exact-2x box: 1, 3 or 4 channels");
+            uint32_t p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {   // two source pixels of both rows -> one output pixel, even / odd channel bytes in 16-bit lanes
+                const uint64_t t = *reinterpret_cast<const u64_unaligned*>(r0 + 8 * j), b = *reinterpret_cast<const u64_unaligned*>(r1 + 8 * j);
+                const uint32_t t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+                const uint32_t ev = (t0 & kM) + (t1 & kM) + (b0 & kM) + (b1 & kM) + 0x00020002u;
+                const uint32_t od = ((t0 >> 8) & kM) + ((t1 >> 8) & kM) + ((b0 >> 8) & kM) + ((b1 >> 8) & kM) + 0x00020002u;
+                p[j] = ((ev >> 2) & kM) | (((od >> 2) & kM) << 8);
+            }
+            store_quad_u8<C>(ow, x0, p, a.plain);
+        }
+        return;
+    } else {
+        int yi;
+        uint32_t fy;
+        px_row_setup<OP>(a, y, yi, fy);
+        uint32_t p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = px_any<C, OP>(a, src, x0 + j, y, yi, fy);
+        store_quad_u8<C>(ow, x0, p, a.plain);
+    }
 }
 
 // ---- separable Q14 ------------------------------------------------------------------------------------
@@ -881,8 +938,14 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
 #define KH_RZ_OP(CC, OP) do { if (quads) hipLaunchKernelGGL((resize_u8_quads_kernel<CC, OP>), xcd_grid(a.tiles), blk, 0, st, a); \
                               else hipLaunchKernelGGL((resize_u8_px_kernel<CC, OP>), xcd_grid(a.tiles), blk, 0, st, a); } while (0)
 #define KH_RZ_OP_C(OP) do { switch (channels) { case 1: KH_RZ_OP(1, OP); break; case 2: KH_RZ_OP(2, OP); break; case 3: KH_RZ_OP(3, OP); break; default: KH_RZ_OP(4, OP); break; } } while (0)
+    // exact 2x downscale of 1 / 4 channels on whole-quad rows: the generic Q14 bilinear equals the 2 x 2 box there (see resize_u8_quads_kernel)
+    const bool down2_any = mode == KH_INTERP_BILINEAR && (channels == 1 || channels == 4) && sw == dw * 2 && sh == dh * 2 && quads && px_opt != 2 &&
+                           (int64_t)sw * sh * channels <= kI32Max;
     if (down2) {
         KH_RZ_OP(3, kRzDown2);
+    } else if (down2_any) {
+        if (channels == 1) hipLaunchKernelGGL((resize_u8_quads_kernel<1, kRzDown2>), xcd_grid(a.tiles), blk, 0, st, a);
+        else hipLaunchKernelGGL((resize_u8_quads_kernel<4, kRzDown2>), xcd_grid(a.tiles), blk, 0, st, a);
     } else if (up2) {
         KH_RZ_OP(3, kRzUp2);
     } else if (mode == KH_INTERP_NEAREST) {

@@ -84,6 +84,29 @@ def test_simple_paths_four_pixels_per_lane(gpu_stream, dev_option, c, mode):
     assert_same_bits(d_dst.to_numpy(np.uint8, (dh * dw * c + 8,))[2:2 + dh * dw * c].reshape(dh, dw, c), O.resize_fast_u8(src, dw, dh, mode, True)[0], "destination 2 bytes off")
 
 
+@pytest.mark.parametrize("c", [1, 4])
+def test_exact_half_bilinear_box_for_one_and_four_channels(gpu_stream, dev_option, c):
+    """The reference has the exact-2x box only for RGB; on 1 / 4 channels its generic Q14 bilinear has fx = fy = 8192 at that scale and
+    equals (p00 + p01 + p10 + p11 + 2) >> 2 exactly, which the quad kernel computes on packed bytes (round 6): the oracle's bytes (its
+    generic path) for destination rows of whole quads — every byte value meets every other in the pattern — next to sizes that keep the
+    generic kernel (destination width not a multiple of four), a batch; resize_u8_px = 2 keeps the generic quad kernel."""
+    for (dw, dh) in [(4, 1), (8, 3), (64, 5), (256, 4), (260, 3), (1024, 2), (1028, 3), (960, 7), (6, 4), (65, 9)]:
+        src = pat(2 * dw, 2 * dh, c, seed=dw + dh)
+        want, path = O.resize_fast_u8(src, dw, dh, "bilinear", True)
+        assert path == "bilinear"
+        for opt in (-1, 2):
+            dev_option("resize_u8_px", opt)
+            assert_same_bits(resize_gpu(gpu_stream, src, dw, dh, "bilinear")[0], want, f"exact half c{c} -> {dw}x{dh} resize_u8_px={opt}")
+    dev_option("resize_u8_px", -1)
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (3, 36, 520, c), dtype=np.uint8)
+    got = resize_gpu(gpu_stream, src, 260, 18, "bilinear", batch=3)
+    for k in range(3):
+        assert_same_bits(got[k], O.resize_fast_u8(src[k], 260, 18, "bilinear", True)[0], f"batch frame {k}")
+    sat = np.full((8, 16, c), 255, np.uint8); sat[::2, 1::2] = 254   # sums that reach 4 * 255 and the rounding either side
+    assert_same_bits(resize_gpu(gpu_stream, sat, 8, 4, "bilinear")[0], O.resize_fast_u8(sat, 8, 4, "bilinear", True)[0], "saturated")
+
+
 @pytest.mark.parametrize("mode", ["bicubic", "lanczos"])
 @pytest.mark.parametrize("aa", [True, False])
 def test_separable_q14(gpu_stream, mode, aa):  # cuda.rs:420-440
