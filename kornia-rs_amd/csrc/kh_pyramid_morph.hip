@@ -830,9 +830,20 @@ constexpr int kPuRollWaveSrc = 256;                  // source pixels per wave (
 constexpr int kPuRollTileSrc = 4 * kPuRollWaveSrc;
 
 __device__ __forceinline__ uint32_t avg_round_u8x4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
+// AR (round 6): the same walks serve resize_fast_u8's EXACT 2x bilinear upscale, which ran per pixel with byte loads at 0.09 of peak
+// (1080p -> 4K RGB 0.73 ms per 16 images).  A destination pixel pair (2x, 2x + 1) of that resize is centred on source pixel x exactly as
+// in pyrup; what differs is the arithmetic and the border (replicate instead of reflect-101, which reproduces the reference's first /
+// last column and row rules):
+//   kUpRh  — the reference's RGB special case (P/resize/kernels.rs:166-183, blend_75_25_row): rounding-halving chains,
+//            even = rh(c, rh(prev, c)), odd = rh(c, rh(c, next)), on packed bytes (four pixels per instruction), both axes;
+//   kUpQ14 — every other channel count takes the generic Q14 bilinear, whose weights at this scale are 4096 / 12288 for every pixel:
+//            ((3 a + b) 4096 x 12288-or-4096 ... + 2^27) >> 28 == (9 a + 3 b + 3 c + d + 8) >> 4 exactly; the horizontal 3 c + n stays
+//            unrounded in 16-bit lanes (<= 1020), the vertical pass adds, rounds and shifts once.
+enum { kUpPyr = 0, kUpRh = 1, kUpQ14 = 2 };
+template <int AR> __device__ __forceinline__ int up_index(int i, int len) { return AR == kUpPyr ? reflect_101(i, len) : min(max(i, 0), len - 1); }
 
 // C = 4 (round 6): RGBA images — a 16-byte source quad per lane, 32 destination bytes per lane and row through the same LDS transposition.
-template <int C>
+template <int C, int AR = kUpPyr>
 __global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(PyrRoll a) {   // th = SOURCE rows per strip here
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
@@ -853,8 +864,8 @@ __global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(
         esel = hsel = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            esel |= (uint32_t)min(max(reflect_101(p + j, a.sw) - pc, 0), 3) << (8 * j);
-            hsel |= (uint32_t)min(max(reflect_101(ph + j, a.sw) - phc, 0), 3) << (8 * j);
+            esel |= (uint32_t)min(max(up_index<AR>(p + j, a.sw) - pc, 0), 3) << (8 * j);
+            hsel |= (uint32_t)min(max(up_index<AR>(ph + j, a.sw) - phc, 0), 3) << (8 * j);
         }
     }
     const int rowb = a.sw * C;
@@ -866,7 +877,7 @@ __global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(
 
     uint32_t q[3][2 * C];   // the lane's quad and its half-wave's halo quad
     auto prefetch = [&](uint32_t (&d)[2 * C]) {
-        const uint8_t* row = src + (long long)reflect_101(pf, a.sh) * rowb;
+        const uint8_t* row = src + (long long)up_index<AR>(pf, a.sh) * rowb;
         const uint8_t *rp = row + C * pc, *rh = row + C * phc;
         if constexpr (C == 4) {
             const u32x4_t v = *reinterpret_cast<const u32x4_unaligned*>(rp), hq = *reinterpret_cast<const u32x4_unaligned*>(rh);
@@ -907,6 +918,17 @@ __global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(
                 if (edge) { A = __builtin_amdgcn_perm(0u, A, esel); Hq = __builtin_amdgcn_perm(0u, Hq, hsel); }
                 const uint32_t prev = from_lane_below(A, Hq), next = from_lane_above(A, Hq);
                 const uint32_t w2 = __builtin_amdgcn_alignbyte(next, A, 1);                 // p[x+1] for the four pixels
+                if constexpr (AR != kUpPyr) {
+                    const uint32_t wm = __builtin_amdgcn_alignbyte(A, prev, 3);             // p[x-1]
+                    if constexpr (AR == kUpRh) {
+                        hp_[s][c][0] = avg_round_u8x4(A, avg_round_u8x4(wm, A)); hp_[s][c][1] = avg_round_u8x4(A, avg_round_u8x4(A, w2));
+                    } else {   // 3 c + neighbour, unrounded, even / odd bytes in 16-bit lanes
+                        const uint32_t al = A & 0x00ff00ffu, ah = (A >> 8) & 0x00ff00ffu;
+                        hl[s][c][0] = mad24(al, 3u, wm & 0x00ff00ffu); hh[s][c][0] = mad24(ah, 3u, (wm >> 8) & 0x00ff00ffu);
+                        hl[s][c][1] = mad24(al, 3u, w2 & 0x00ff00ffu); hh[s][c][1] = mad24(ah, 3u, (w2 >> 8) & 0x00ff00ffu);
+                    }
+                    continue;
+                }
                 constexpr uint32_t kT = 0x0020c020u;   // taps (1, 6, 1, 0) x 32; accumulator 4 x 32
                 const uint32_t t0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A, prev, 3), kT, 128u, false);
                 const uint32_t t1 = __builtin_amdgcn_udot4(A, kT, 128u, false);
@@ -925,6 +947,17 @@ __global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(
                 for (int c = 0; c < C; ++c)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
+                        if constexpr (AR == kUpRh) {
+                            ve[c][e] = avg_round_u8x4(hp_[sc][c][e], avg_round_u8x4(hp_[sp][c][e], hp_[sc][c][e]));
+                            vo[c][e] = avg_round_u8x4(hp_[sc][c][e], avg_round_u8x4(hp_[sc][c][e], hp_[sn][c][e]));
+                            continue;
+                        } else if constexpr (AR == kUpQ14) {
+                            const uint32_t cl3 = hl[sc][c][e] + (hl[sc][c][e] << 1), ch3 = hh[sc][c][e] + (hh[sc][c][e] << 1);   // (10-bit lanes: beyond mad24's 24-bit operands)
+                            const uint32_t el = ((cl3 + hl[sp][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu, eh = ((ch3 + hh[sp][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu;
+                            const uint32_t ol = ((cl3 + hl[sn][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu, oh = ((ch3 + hh[sn][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu;
+                            ve[c][e] = el | (eh << 8); vo[c][e] = ol | (oh << 8);
+                            continue;
+                        }
                         const uint32_t lo = ((mad24(hl[sc][c][e], 6u, hl[sp][c][e]) + hl[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
                         const uint32_t hi = ((mad24(hh[sc][c][e], 6u, hh[sp][c][e]) + hh[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
                         ve[c][e] = lo | (hi << 8);
@@ -992,7 +1025,7 @@ __global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(
 constexpr int kPuGrayWaveSrc = 512;                  // source pixels per wave (64 lanes x 8)
 constexpr int kPuGrayTileSrc = 4 * kPuGrayWaveSrc;
 // RAGGED (round 6): any source width >= 8 and any alignment — a lane's eight loaded bytes re-indexed by ONE v_perm_b32 per dword; plain = 2: unaligned stores.
-template <bool RAGGED>
+template <bool RAGGED, int AR = kUpPyr>
 __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {   // th = SOURCE rows per strip
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned tx, ty, bz;
@@ -1014,8 +1047,8 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
         esel = hsel = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            esel |= (uint32_t)min(max(reflect_101(p + j, a.sw) - (a.sw - 4), 0), 3) << (8 * j);
-            hsel |= (uint32_t)min(max(reflect_101(ph + j, a.sw) - phc, 0), 3) << (8 * j);
+            esel |= (uint32_t)min(max(up_index<AR>(p + j, a.sw) - (a.sw - 4), 0), 3) << (8 * j);
+            hsel |= (uint32_t)min(max(up_index<AR>(ph + j, a.sw) - phc, 0), 3) << (8 * j);
         }
     }
     uint32_t rsel[2] = {0x03020100u, 0x07060504u};   // RAGGED: lane byte j <- loaded byte reflect_101(p + j) - pc of the eight
@@ -1024,7 +1057,7 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
         for (int c = 0; c < 2; ++c) {
             rsel[c] = 0;
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) rsel[c] |= (uint32_t)min(max(reflect_101(p + 4 * c + j2, a.sw) - pc, 0), 7) << (8 * j2);
+            for (int j2 = 0; j2 < 4; ++j2) rsel[c] |= (uint32_t)min(max(up_index<AR>(p + 4 * c + j2, a.sw) - pc, 0), 7) << (8 * j2);
         }
     }
     const int n = thr + 2;                                            // source rows walked: y0 - 1 .. y0 + thr
@@ -1032,7 +1065,7 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
 
     uint32_t q[3][3];   // the lane's eight pixels and its half-wave's halo dword
     auto prefetch = [&](uint32_t (&d)[3]) {
-        const uint8_t* row = src + (long long)reflect_101(pf, a.sh) * a.sw;
+        const uint8_t* row = src + (long long)up_index<AR>(pf, a.sh) * a.sw;
         d[0] = *reinterpret_cast<const u32_unaligned*>(row + pc); d[1] = *reinterpret_cast<const u32_unaligned*>(row + pc + 4);
         d[2] = *reinterpret_cast<const u32_unaligned*>(row + phc);
         ++pf;
@@ -1071,6 +1104,17 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
             for (int c = 0; c < 2; ++c) {
                 const uint32_t A = cur[c], prev = c == 0 ? prevd : cur[0], next = c == 0 ? cur[1] : nextd;
                 const uint32_t w2 = __builtin_amdgcn_alignbyte(next, A, 1);                 // p[x+1] for the four pixels
+                if constexpr (AR != kUpPyr) {   // (see kUpRh / kUpQ14 above)
+                    const uint32_t wm = __builtin_amdgcn_alignbyte(A, prev, 3);             // p[x-1]
+                    if constexpr (AR == kUpRh) {
+                        hp_[s][c][0] = avg_round_u8x4(A, avg_round_u8x4(wm, A)); hp_[s][c][1] = avg_round_u8x4(A, avg_round_u8x4(A, w2));
+                    } else {
+                        const uint32_t al = A & 0x00ff00ffu, ah = (A >> 8) & 0x00ff00ffu;
+                        hl[s][c][0] = mad24(al, 3u, wm & 0x00ff00ffu); hh[s][c][0] = mad24(ah, 3u, (wm >> 8) & 0x00ff00ffu);
+                        hl[s][c][1] = mad24(al, 3u, w2 & 0x00ff00ffu); hh[s][c][1] = mad24(ah, 3u, (w2 >> 8) & 0x00ff00ffu);
+                    }
+                    continue;
+                }
                 constexpr uint32_t kT = 0x0020c020u;   // taps (1, 6, 1, 0) x 32; accumulator 4 x 32
                 const uint32_t t0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A, prev, 3), kT, 128u, false);
                 const uint32_t t1 = __builtin_amdgcn_udot4(A, kT, 128u, false);
@@ -1090,6 +1134,17 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
                     uint32_t ve[2], vo[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
+                        if constexpr (AR == kUpRh) {
+                            ve[e] = avg_round_u8x4(hp_[sc][c][e], avg_round_u8x4(hp_[sp][c][e], hp_[sc][c][e]));
+                            vo[e] = avg_round_u8x4(hp_[sc][c][e], avg_round_u8x4(hp_[sc][c][e], hp_[sn][c][e]));
+                            continue;
+                        } else if constexpr (AR == kUpQ14) {
+                            const uint32_t cl3 = hl[sc][c][e] + (hl[sc][c][e] << 1), ch3 = hh[sc][c][e] + (hh[sc][c][e] << 1);   // (10-bit lanes: beyond mad24's 24-bit operands)
+                            const uint32_t el = ((cl3 + hl[sp][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu, eh = ((ch3 + hh[sp][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu;
+                            const uint32_t ol = ((cl3 + hl[sn][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu, oh = ((ch3 + hh[sn][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu;
+                            ve[e] = el | (eh << 8); vo[e] = ol | (oh << 8);
+                            continue;
+                        }
                         const uint32_t lo = ((mad24(hl[sc][c][e], 6u, hl[sp][c][e]) + hl[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
                         const uint32_t hi = ((mad24(hh[sc][c][e], 6u, hh[sp][c][e]) + hh[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
                         ve[e] = lo | (hi << 8);
@@ -1897,6 +1952,51 @@ KH_PYR_ENTRY(kh_pyrup_u8_direct, uint8_t, pyrup_u8_kernel, sw * 2, sh * 2)
 
 }  // namespace
 
+// The rolling 2x-upscale kernels (one source quad / eight source pixels per lane), shared by pyrup_u8 (AR = kUpPyr) and resize_fast_u8's
+// exact 2x bilinear upscale (kUpRh: the reference's RGB case; kUpQ14: every other channel count).  Preconditions are the caller's:
+// channels 1 (sw >= 8), 3 or 4 (sw >= 4), sw * 8 < 2^24, sw * sh * 4 * channels within 32 bits for one channel.
+template <int AR>
+static int32_t launch_up2_roll(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int sw, int sh, int channels, int batch, int64_t ss, int64_t ds,
+                               const char* what) {
+    const int dw = sw * 2, dh = sh * 2;
+    const bool dword_dst = reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);
+    PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}, plain_row_stores((int64_t)dw * channels, dst, ds, batch)};
+    const bool gray = channels == 1;
+    const unsigned tiles_x = cdiv(sw, gray ? kPuGrayTileSrc : kPuRollTileSrc);
+    const long long cols_blocks = (long long)tiles_x * batch;
+    long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
+    const long long min_strips = cdiv(sh, 360), max_strips = cdiv(sh, 16);
+    strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
+    r.th = (int)cdiv(sh, strips);
+    r.tiles = xcd_tiles(tiles_x, cdiv(sh, r.th), (unsigned)batch, kXcdEighth);
+    KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "%s: batch x tiles exceeds one launch", what);
+    const dim3 grid = xcd_grid(r.tiles);
+    hipStream_t st = as_hip(stream);
+    if (gray) {
+        const bool dword_ok = sw % 2 == 0 && dword_dst;   // buffer stores need dword-aligned rows
+        if (!dword_ok) r.plain = 2;
+        if (sw % 8 != 0 || !dword_ok) hipLaunchKernelGGL((pyrup_u8_gray_roll_kernel<true, AR>), grid, dim3(256), 0, st, r);   // (any width / alignment: the RAGGED instantiation)
+        else hipLaunchKernelGGL((pyrup_u8_gray_roll_kernel<false, AR>), grid, dim3(256), 0, st, r);
+    } else if (channels == 4) {   // RGBA (round 6); plain = 2: a destination off a dword
+        if (!dword_dst) r.plain = 2;
+        hipLaunchKernelGGL((pyrup_u8_rgb_roll_kernel<4, AR>), grid, dim3(256), 0, st, r);
+    } else hipLaunchKernelGGL((pyrup_u8_rgb_roll_kernel<3, AR>), grid, dim3(256), 0, st, r);
+    return check_launch(what);
+}
+// resize_fast_u8's exact 2x bilinear upscale on the rolling kernels (kh_resize_u8.hip calls this; false = not taken: shapes the rolling
+// kernels do not cover, or test option pyr_roll = 0)
+namespace kh {
+bool resize_up2_u8_rolling(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int sw, int sh, int channels, int batch, int64_t ss, int64_t ds,
+                           const char* what, int32_t& rc) {
+    const bool ok = (channels == 1 ? sw >= 8 && (int64_t)sw * sh * 4 <= kI32Max : (channels == 3 || channels == 4) && sw >= 4) && sh >= 2 &&
+                    (int64_t)sw * 8 < (1 << 24) && (int64_t)sw * sh * 4 * channels <= kI32Max && dev_opt(kOptPyrRoll) != 0;
+    if (!ok) return false;
+    rc = channels == 3 ? launch_up2_roll<kUpRh>(stream, src, dst, sw, sh, channels, batch, ss, ds, what)
+                       : launch_up2_roll<kUpQ14>(stream, src, dst, sw, sh, channels, batch, ss, ds, what);
+    return true;
+}
+}  // namespace kh
+
 extern "C" {
 
 int32_t kh_pyrdown_f32(kh_stream_t stream, const float* src, float* dst, int32_t sw, int32_t sh, int32_t channels, int32_t batch,
@@ -2002,40 +2102,11 @@ int32_t kh_pyrup_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int32_
     const bool no_roll = dev_opt(kOptPyrRoll) == 0;
     // one channel: the rolling gray kernel
     const bool gray = channels == 1 && sw >= 8 && (int64_t)sw * sh * 4 <= kI32Max;
-    const bool gray_dword_ok = sw % 2 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
-    const bool gray_ragged = sw % 8 != 0 || !gray_dword_ok;   // (round 6: any width / alignment on the RAGGED instantiation)
     if (direct || no_roll || !(channels == 3 || channels == 4 || gray) || sw < 4 || (int64_t)sw * 8 >= (1 << 24)) return kh_pyrup_u8_pairs(stream, src, dst, sw, sh, channels, batch, ss, ds);
     const int dw = sw * 2, dh = sh * 2;
     if (int32_t rc = check_pyr("kh_pyrup_u8", src, dst, sw, sh, channels, batch, ss, ds, dw, dh)) return rc;
     if (batch == 0) return KH_OK;
-    PyrRoll r{src, dst, sw, sh, dw, dh, 0, ss, ds, XcdTiles{}, plain_row_stores((int64_t)dw * channels, dst, ds, batch)};
-    if (gray) {
-        const unsigned gtiles_x = cdiv(sw, kPuGrayTileSrc);
-        const long long gcols = (long long)gtiles_x * batch;
-        long long gstrips = (2048 + gcols - 1) / gcols;   // >= 8 blocks per CU
-        const long long gmin = cdiv(sh, 360), gmax = cdiv(sh, 16);
-        gstrips = gstrips < gmin ? gmin : (gstrips > gmax ? gmax : gstrips);
-        r.th = (int)cdiv(sh, gstrips);
-        r.tiles = xcd_tiles(gtiles_x, cdiv(sh, r.th), (unsigned)batch, kXcdEighth);
-        KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrup_u8: batch x tiles exceeds one launch");
-        if (!gray_dword_ok) r.plain = 2;
-        if (gray_ragged) hipLaunchKernelGGL(pyrup_u8_gray_roll_kernel<true>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
-        else hipLaunchKernelGGL(pyrup_u8_gray_roll_kernel<false>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
-        return check_launch("kh_pyrup_u8");
-    }
-    const unsigned tiles_x = cdiv(sw, kPuRollTileSrc);
-    const long long cols_blocks = (long long)tiles_x * batch;
-    long long strips = (2048 + cols_blocks - 1) / cols_blocks;   // >= 8 blocks per CU
-    const long long min_strips = cdiv(sh, 360), max_strips = cdiv(sh, 16);
-    strips = strips < min_strips ? min_strips : (strips > max_strips ? max_strips : strips);
-    r.th = (int)cdiv(sh, strips);
-    r.tiles = xcd_tiles(tiles_x, cdiv(sh, r.th), (unsigned)batch, kXcdEighth);
-    KH_REQUIRE(r.tiles.total > 0, KH_ERR_TOO_LARGE, "kh_pyrup_u8: batch x tiles exceeds one launch");
-    if (channels == 4) {   // RGBA (round 6); plain = 2: a destination off a dword
-        if (!(reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0))) r.plain = 2;
-        hipLaunchKernelGGL(pyrup_u8_rgb_roll_kernel<4>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
-    } else hipLaunchKernelGGL(pyrup_u8_rgb_roll_kernel<3>, xcd_grid(r.tiles), dim3(256), 0, as_hip(stream), r);
-    return check_launch("kh_pyrup_u8");
+    return launch_up2_roll<kUpPyr>(stream, src, dst, sw, sh, channels, batch, ss, ds, "kh_pyrup_u8");
 }
 
 // Kernel::new (P/morphology/kernels.rs:113-185): shape 0 box, 1 cross, 2 ellipse; out = width*height bytes

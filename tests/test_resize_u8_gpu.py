@@ -107,6 +107,39 @@ def test_exact_half_bilinear_box_for_one_and_four_channels(gpu_stream, dev_optio
     assert_same_bits(resize_gpu(gpu_stream, sat, 8, 4, "bilinear")[0], O.resize_fast_u8(sat, 8, 4, "bilinear", True)[0], "saturated")
 
 
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_exact_double_bilinear_on_the_rolling_kernels(gpu_stream, dev_option, c):
+    """The exact 2x bilinear upscale runs on the rolling pyrup kernels with this resize's arithmetic (round 6): the reference's
+    rounding-halving chains for RGB (its pyrup2x path), the generic Q14 weights — (9 a + 3 b + 3 c + d + 8) >> 4 at this scale — for
+    one / four channels, replicate borders.  The oracle's bytes on widths either side of the lane / wave / block seams, the narrowest
+    sources each kernel takes and the ones it leaves to the per-pixel form, ragged gray widths, two-row sources, a batch, a destination
+    off a dword; resize_u8_px = 2 keeps the per-pixel kernels."""
+    from kornia_rs import _ffi
+    sizes = [(2, 2), (3, 4), (4, 2), (5, 3), (7, 9), (8, 2), (9, 5), (12, 3), (17, 9), (32, 5), (33, 6), (255, 3), (256, 4), (257, 5), (260, 3), (511, 2), (512, 3), (513, 4), (1023, 3), (1024, 2), (1025, 3), (2049, 2), (300, 131)]
+    for (w, h) in sizes:
+        src = pat(w, h, c, seed=w + h)
+        want, path = O.resize_fast_u8(src, 2 * w, 2 * h, "bilinear", True)
+        assert path == ("pyrup2x" if c == 3 else "bilinear")
+        for opt in ((-1, 2) if w in (2, 9, 257, 1025, 300) else (-1,)):
+            dev_option("resize_u8_px", opt)
+            assert_same_bits(resize_gpu(gpu_stream, src, 2 * w, 2 * h, "bilinear")[0], want, f"exact double c{c} {w}x{h} resize_u8_px={opt}")
+    dev_option("resize_u8_px", -1)
+    rng = np.random.default_rng(7)
+    src = rng.integers(0, 256, (3, 19, 301, c), dtype=np.uint8)
+    got = resize_gpu(gpu_stream, src, 602, 38, "bilinear", batch=3)
+    for k in range(3):
+        assert_same_bits(got[k], O.resize_fast_u8(src[k], 602, 38, "bilinear", True)[0], f"batch frame {k}")
+    w, h, n = 301, 7, 2
+    src = rng.integers(0, 256, (n, h, w, c), dtype=np.uint8)
+    dw, dh = 2 * w, 2 * h
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * dw * dh * c + 8)
+    _ffi.check(_ffi.lib.kh_resize_fast_u8(gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 3, w, h, dw, dh, c, O.MODE["bilinear"], 1, n, w * h * c, dw * dh * c))
+    got = d_dst.to_numpy(np.uint8, (n * dw * dh * c + 8,))
+    assert got[:3].tolist() == [255] * 3 and got[3 + n * dw * dh * c:3 + n * dw * dh * c + 5].tolist() == [255] * 5, "bytes outside the destination were written"
+    for i in range(n):
+        assert_same_bits(got[3 + i * dw * dh * c:3 + (i + 1) * dw * dh * c].reshape(dh, dw, c), O.resize_fast_u8(src[i], dw, dh, "bilinear", True)[0], f"offset destination frame {i}")
+
+
 @pytest.mark.parametrize("mode", ["bicubic", "lanczos"])
 @pytest.mark.parametrize("aa", [True, False])
 def test_separable_q14(gpu_stream, mode, aa):  # cuda.rs:420-440
