@@ -84,6 +84,23 @@ def test_simple_paths_four_pixels_per_lane(gpu_stream, dev_option, c, mode):
     assert_same_bits(d_dst.to_numpy(np.uint8, (dh * dw * c + 8,))[2:2 + dh * dw * c].reshape(dh, dw, c), O.resize_fast_u8(src, dw, dh, mode, True)[0], "destination 2 bytes off")
 
 
+def test_nearest_many_ratios(gpu_stream, dev_option):
+    """Nearest over many width ratios — upscales, downscales, primes, ratios whose f64 column product lands on or next to whole numbers
+    (written for a round-6 experiment that divided in integers where the host proved the two forms equal: no faster, not kept; the
+    cases stay) — quads and one pixel per thread."""
+    rng = np.random.default_rng(11)
+    pairs = [(63, 127), (127, 63), (100, 300), (300, 100), (1920, 1280), (1280, 1920), (7, 1000), (1000, 7), (333, 999), (997, 1009), (1009, 997), (64, 4096), (3, 5), (5, 3), (640, 224), (224, 640)]
+    pairs += [(int(rng.integers(1, 1500)), int(rng.integers(1, 1500))) for _ in range(24)]
+    for (sw, dw) in pairs:
+        for c in (1, 3):
+            src = pat(sw, 3, c, seed=sw + dw)
+            want, _ = O.resize_fast_u8(src, dw, 5, "nearest", True)
+            for opt in (-1, 1):
+                dev_option("resize_u8_px", opt)
+                assert_same_bits(resize_gpu(gpu_stream, src, dw, 5, "nearest")[0], want, f"nearest {sw}->{dw} c{c} resize_u8_px={opt}")
+    dev_option("resize_u8_px", -1)
+
+
 @pytest.mark.parametrize("c", [1, 4])
 def test_exact_half_bilinear_box_for_one_and_four_channels(gpu_stream, dev_option, c):
     """The reference has the exact-2x box only for RGB; on 1 / 4 channels its generic Q14 bilinear has fx = fy = 8192 at that scale and
