@@ -839,7 +839,8 @@ __device__ __forceinline__ uint32_t avg_round_u8x4(uint32_t a, uint32_t b) { ret
 //   kUpQ14 — every other channel count takes the generic Q14 bilinear, whose weights at this scale are 4096 / 12288 for every pixel:
 //            ((3 a + b) 4096 x 12288-or-4096 ... + 2^27) >> 28 == (9 a + 3 b + 3 c + d + 8) >> 4 exactly; the horizontal 3 c + n stays
 //            unrounded in 16-bit lanes (<= 1020), the vertical pass adds, rounds and shifts once.
-enum { kUpPyr = 0, kUpRh = 1, kUpQ14 = 2 };
+//   kUpNearest — the nearest resize at this scale: column floor((X + 0.5) / 2) = X >> 1, i.e. both pixels of a pair and both rows ARE the source pixel.
+enum { kUpPyr = 0, kUpRh = 1, kUpQ14 = 2, kUpNearest = 3 };
 template <int AR> __device__ __forceinline__ int up_index(int i, int len) { return AR == kUpPyr ? reflect_101(i, len) : min(max(i, 0), len - 1); }
 
 // C = 4 (round 6): RGBA images — a 16-byte source quad per lane, 32 destination bytes per lane and row through the same LDS transposition.
@@ -920,7 +921,9 @@ __global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(
                 const uint32_t w2 = __builtin_amdgcn_alignbyte(next, A, 1);                 // p[x+1] for the four pixels
                 if constexpr (AR != kUpPyr) {
                     const uint32_t wm = __builtin_amdgcn_alignbyte(A, prev, 3);             // p[x-1]
-                    if constexpr (AR == kUpRh) {
+                    if constexpr (AR == kUpNearest) {
+                        hp_[s][c][0] = A; hp_[s][c][1] = A;
+                    } else if constexpr (AR == kUpRh) {
                         hp_[s][c][0] = avg_round_u8x4(A, avg_round_u8x4(wm, A)); hp_[s][c][1] = avg_round_u8x4(A, avg_round_u8x4(A, w2));
                     } else {   // 3 c + neighbour, unrounded, even / odd bytes in 16-bit lanes
                         const uint32_t al = A & 0x00ff00ffu, ah = (A >> 8) & 0x00ff00ffu;
@@ -947,7 +950,10 @@ __global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(
                 for (int c = 0; c < C; ++c)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        if constexpr (AR == kUpRh) {
+                        if constexpr (AR == kUpNearest) {
+                            ve[c][e] = hp_[sc][c][e]; vo[c][e] = hp_[sc][c][e];
+                            continue;
+                        } else if constexpr (AR == kUpRh) {
                             ve[c][e] = avg_round_u8x4(hp_[sc][c][e], avg_round_u8x4(hp_[sp][c][e], hp_[sc][c][e]));
                             vo[c][e] = avg_round_u8x4(hp_[sc][c][e], avg_round_u8x4(hp_[sc][c][e], hp_[sn][c][e]));
                             continue;
@@ -1106,7 +1112,9 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
                 const uint32_t w2 = __builtin_amdgcn_alignbyte(next, A, 1);                 // p[x+1] for the four pixels
                 if constexpr (AR != kUpPyr) {   // (see kUpRh / kUpQ14 above)
                     const uint32_t wm = __builtin_amdgcn_alignbyte(A, prev, 3);             // p[x-1]
-                    if constexpr (AR == kUpRh) {
+                    if constexpr (AR == kUpNearest) {
+                        hp_[s][c][0] = A; hp_[s][c][1] = A;
+                    } else if constexpr (AR == kUpRh) {
                         hp_[s][c][0] = avg_round_u8x4(A, avg_round_u8x4(wm, A)); hp_[s][c][1] = avg_round_u8x4(A, avg_round_u8x4(A, w2));
                     } else {
                         const uint32_t al = A & 0x00ff00ffu, ah = (A >> 8) & 0x00ff00ffu;
@@ -1134,7 +1142,10 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
                     uint32_t ve[2], vo[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        if constexpr (AR == kUpRh) {
+                        if constexpr (AR == kUpNearest) {
+                            ve[e] = hp_[sc][c][e]; vo[e] = hp_[sc][c][e];
+                            continue;
+                        } else if constexpr (AR == kUpRh) {
                             ve[e] = avg_round_u8x4(hp_[sc][c][e], avg_round_u8x4(hp_[sp][c][e], hp_[sc][c][e]));
                             vo[e] = avg_round_u8x4(hp_[sc][c][e], avg_round_u8x4(hp_[sc][c][e], hp_[sn][c][e]));
                             continue;
@@ -1983,15 +1994,16 @@ static int32_t launch_up2_roll(kh_stream_t stream, const uint8_t* src, uint8_t* 
     } else hipLaunchKernelGGL((pyrup_u8_rgb_roll_kernel<3, AR>), grid, dim3(256), 0, st, r);
     return check_launch(what);
 }
-// resize_fast_u8's exact 2x bilinear upscale on the rolling kernels (kh_resize_u8.hip calls this; false = not taken: shapes the rolling
-// kernels do not cover, or test option pyr_roll = 0)
+// resize_fast_u8's exact 2x bilinear / nearest upscale on the rolling kernels (kh_resize_u8.hip calls this; false = not taken: shapes the
+// rolling kernels do not cover, or test option pyr_roll = 0)
 namespace kh {
 bool resize_up2_u8_rolling(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int sw, int sh, int channels, int batch, int64_t ss, int64_t ds,
-                           const char* what, int32_t& rc) {
+                           const char* what, int32_t& rc, bool nearest) {
     const bool ok = (channels == 1 ? sw >= 8 && (int64_t)sw * sh * 4 <= kI32Max : (channels == 3 || channels == 4) && sw >= 4) && sh >= 2 &&
                     (int64_t)sw * 8 < (1 << 24) && (int64_t)sw * sh * 4 * channels <= kI32Max && dev_opt(kOptPyrRoll) != 0;
     if (!ok) return false;
-    rc = channels == 3 ? launch_up2_roll<kUpRh>(stream, src, dst, sw, sh, channels, batch, ss, ds, what)
+    rc = nearest ? launch_up2_roll<kUpNearest>(stream, src, dst, sw, sh, channels, batch, ss, ds, what)
+       : channels == 3 ? launch_up2_roll<kUpRh>(stream, src, dst, sw, sh, channels, batch, ss, ds, what)
                        : launch_up2_roll<kUpQ14>(stream, src, dst, sw, sh, channels, batch, ss, ds, what);
     return true;
 }

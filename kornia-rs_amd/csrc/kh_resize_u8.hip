@@ -924,10 +924,12 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     // Exact 2x bilinear upscale (round 6): the rolling pyrup kernels with this resize's arithmetic — the reference's rounding-halving chains
     // for RGB, the generic Q14 weights (9 3 3 1) / 16 for one / four channels — instead of the per-pixel forms below, which ran at 0.09-0.24
     // of peak (1080p -> 4K RGB 0.73 -> 0.1 ms per 16 images, profiles/r06zz3_resize_up2.txt).  Test option resize_u8_px = 1 / 2 keeps them.
-    if (mode == KH_INTERP_BILINEAR && dw == sw * 2 && dh == sh * 2 && sw >= 2 && sh >= 2 && (channels == 1 || channels == 3 || channels == 4) &&
+    // (nearest at this scale: column X >> 1, the same walk with no arithmetic — label maps are upscaled this way: 0.085 -> 0.03 ms on one channel)
+    if ((mode == KH_INTERP_BILINEAR || mode == KH_INTERP_NEAREST) && dw == sw * 2 && dh == sh * 2 && sw >= 2 && sh >= 2 &&
+        (channels == 1 || channels == 3 || (channels == 4 && mode == KH_INTERP_BILINEAR)) &&   // (RGBA nearest: the quad kernel is already at 0.87 of peak, 0.096 vs 0.109 ms)
         dev_opt(kOptResizeU8Px) != 1 && dev_opt(kOptResizeU8Px) != 2) {
         int32_t rc = KH_OK;
-        if (resize_up2_u8_rolling(stream, src, dst, sw, sh, channels, batch, src_stride, dst_stride, what, rc)) return rc;
+        if (resize_up2_u8_rolling(stream, src, dst, sw, sh, channels, batch, src_stride, dst_stride, what, rc, mode == KH_INTERP_NEAREST)) return rc;
     }
     hipStream_t st = as_hip(stream);
     Rz a = make_rz(src, dst, sw, sh, dw, dh, src_stride, dst_stride, batch, dw, dh);

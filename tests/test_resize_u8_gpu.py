@@ -137,9 +137,11 @@ def test_exact_double_bilinear_on_the_rolling_kernels(gpu_stream, dev_option, c)
         src = pat(w, h, c, seed=w + h)
         want, path = O.resize_fast_u8(src, 2 * w, 2 * h, "bilinear", True)
         assert path == ("pyrup2x" if c == 3 else "bilinear")
+        near = O.resize_fast_u8(src, 2 * w, 2 * h, "nearest", True)[0]
         for opt in ((-1, 2) if w in (2, 9, 257, 1025, 300) else (-1,)):
             dev_option("resize_u8_px", opt)
             assert_same_bits(resize_gpu(gpu_stream, src, 2 * w, 2 * h, "bilinear")[0], want, f"exact double c{c} {w}x{h} resize_u8_px={opt}")
+            assert_same_bits(resize_gpu(gpu_stream, src, 2 * w, 2 * h, "nearest")[0], near, f"exact double nearest c{c} {w}x{h} resize_u8_px={opt}")   # (the same walk, no arithmetic)
     dev_option("resize_u8_px", -1)
     rng = np.random.default_rng(7)
     src = rng.integers(0, 256, (3, 19, 301, c), dtype=np.uint8)
