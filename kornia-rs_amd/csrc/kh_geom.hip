@@ -269,6 +269,29 @@ __global__ __launch_bounds__(kBx* kBy) void resize_kernel(Img im, float ax, floa
     put<C>(o, x, v);
 }
 
+// One channel (round 6): resize_kernel gives a lane ONE float, so a wave stores 256 bytes per instruction and the per-row coordinate
+// work is repeated for every pixel — gray f32 images (heat maps, flow fields) ran at 0.26-0.37 of peak on upscales against 0.65-0.9
+// for RGB.  Four consecutive destination pixels per lane, the same sampler calls in the same order, one 16-byte streaming store
+// (dw % 4 == 0, 16-byte-aligned destination images: host-checked).  A wave = one row of a 256 x 4 tile.
+template <int MODE, bool LIST>
+__global__ __launch_bounds__(kBx* kBy) void resize_quads1_kernel(Img im, float ax, float bx, float ay, float by, typename ListArg<LIST>::type lst) {
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(im.tiles, bx_, by_, bz_)) return;
+    const int x0 = (bx_ * kBx + threadIdx.x) * 4;
+    const int y = by_ * kBy + threadIdx.y;
+    if (x0 >= im.dw || y >= im.dh) return;
+    const float* src = image_src<LIST>(im, lst, bz_);
+    const OutRow o = out_row<4>(image_dst<LIST>(im, lst, bz_) + (long long)y * im.dw, im.dw / 4);   // the row as dw / 4 four-float pixels
+    const float sy = clampf(ay * (float)y + by, 0.0f, (float)(im.sh - 1));
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sx = clampf(ax * (float)(x0 + j) + bx, 0.0f, (float)(im.sw - 1));
+        sample<1, MODE>(src, im.sh, im.sw, sx, sy, &v[j]);
+    }
+    put<4>(o, x0 / 4, v);
+}
+
 // ---- bicubic, horizontal step exactly 2 (round 6; the reference's published 1080p -> 540p shape, benchmarks.md:374) ------------------------
 // At sx = 2 x + 0.5 the four columns of output pixel x are source pixels 2x - 1 .. 2x + 2: a lane's window shares its outer columns
 // with its neighbours' inner ones, and resize_kernel fetches every source pixel twice — 3 KiB of 12-byte gathers per wave and row for
@@ -918,8 +941,23 @@ int32_t resize_impl(const char* what, kh_stream_t stream, const BatchRef& b, int
             return check_launch(what);
         });
     }
+    // one channel, nearest / bilinear, destination rows of whole float4s on 16-byte-aligned images: four pixels per lane — nearest upscales
+    // 0.160 -> 0.072 ms per 8 1080p -> 4K planes, bilinear 0.140 -> 0.130; bicubic LOSES 2x with its 64 gathers per lane (0.22 -> 0.48) and
+    // keeps one pixel per lane (profiles/r06zz5_resize_f32_gray.txt; test option resize_rows = 0 keeps one pixel per lane everywhere)
+    const bool quads1 = channels == 1 && (mode == KH_INTERP_NEAREST || mode == KH_INTERP_BILINEAR) && dw % 4 == 0 && batch_aligned(b, 16, 4) && dev_opt(kOptResizeRows) != 0;
     return for_each_launch(b, [&](const BatchRef& c, int, const PtrList& lst) -> int32_t {
-        const Img im = make_img(c, sw, sh, dw, dh, c.n);
+        Img im = make_img(c, sw, sh, dw, dh, c.n);
+        if (quads1) {
+            im.tiles = xcd_tiles(cdiv(dw, 4 * kBx), cdiv(dh, kBy), (unsigned)c.n, cdiv(dw, 4 * kBx) * 8);
+            KH_REQUIRE_TILES(what, im);
+            const dim3 blk(kBx, kBy), grid = xcd_grid(im.tiles);
+            const NoList none{0};
+#define KH_Q1(MM) do { if (c.listed()) hipLaunchKernelGGL((resize_quads1_kernel<MM, true>), grid, blk, 0, st, im, ax, bx, ay, by, lst); \
+                       else hipLaunchKernelGGL((resize_quads1_kernel<MM, false>), grid, blk, 0, st, im, ax, bx, ay, by, none); } while (0)
+            if (mode == KH_INTERP_NEAREST) KH_Q1(0); else KH_Q1(1);
+#undef KH_Q1
+            return check_launch(what);
+        }
         KH_REQUIRE_TILES(what, im);
         KH_DISPATCH_C_MODE(resize_kernel, c.listed(), channels, mode, xcd_grid(im.tiles), st, lst, im, ax, bx, ay, by);
         return check_launch(what);

@@ -44,6 +44,21 @@ def test_resize_matches_oracle(gpu_stream, mode, shape, c):
     assert_same_bits(got, O.resize(src, dw, dh, mode), f"resize {shape} c{c} {mode}")
 
 
+@pytest.mark.parametrize("mode", ["nearest", "bilinear", "bicubic"])
+def test_resize_one_channel_four_pixels_per_lane(gpu_stream, dev_option, mode):
+    """One-channel resizes whose destination rows are whole float4s take four pixels per lane with 16-byte stores (round 6): the oracle's
+    bits on up- and downscales, destination widths either side of the 256-pixel tile row, a batch and a list; resize_rows = 0 keeps one
+    pixel per lane; widths that are not a multiple of four never leave it."""
+    for (sw, sh, dw, dh) in [(129, 97, 64, 48), (63, 41, 128, 90), (64, 48, 256, 7), (100, 9, 260, 20), (300, 5, 1024, 3), (301, 6, 1028, 4), (2, 2, 8, 8), (1, 1, 4, 3), (500, 40, 252, 21), (90, 30, 127, 40)]:
+        n = 2
+        src = np.stack([img(sw, sh, 1, seed=31 * k + sw) for k in range(n)])
+        want = np.stack([O.resize(src[k], dw, dh, mode) for k in range(n)])
+        for opt in (-1, 0):
+            dev_option("resize_rows", opt)
+            assert_same_bits(resize_gpu(gpu_stream, src, dw, dh, mode, batch=n), want, f"one channel {mode} {sw}x{sh} -> {dw}x{dh} resize_rows={opt}")
+    dev_option("resize_rows", -1)
+
+
 @pytest.mark.parametrize("shape", [(128, 96, 30, 22), (1920, 40, 224, 8), (64, 300, 20, 7), (2048, 12, 200, 5), (16, 64, 4, 3)])
 @pytest.mark.parametrize("c", [1, 3, 4])
 def test_resize_bilinear_row_streamed_kernel(gpu_stream, dev_option, shape, c):
