@@ -27,19 +27,17 @@ FIELDS = [("vgpr", r" VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("sgpr", r"Tota
 def main():
     rows, flat = [], {}
     with tempfile.TemporaryDirectory() as tmp:
-        procs = []
-        for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
-            out = os.path.join(tmp, os.path.basename(src) + ".co")
-            procs.append((src, subprocess.Popen(["/opt/rocm/bin/hipcc", *FLAGS, src, "-o", out], stderr=subprocess.PIPE, text=True)))
+        # ONE compile per source: the ISA (-S) and the resource remarks come out of the same code generation
         asm = []
         for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
             out = os.path.join(tmp, os.path.basename(src) + ".s")
-            asm.append((src, out, subprocess.Popen(["/opt/rocm/bin/hipcc", *[f for f in FLAGS if not f.startswith("-Rpass") and f != "-c"], "-S", src, "-o", out],
-                                                   stderr=subprocess.PIPE, text=True)))
+            asm.append((src, out, subprocess.Popen(["/opt/rocm/bin/hipcc", *[f for f in FLAGS if f != "-c"], "-S", src, "-o", out], stderr=subprocess.PIPE, text=True)))
+        procs = []
         for src, out, p in asm:
             _, err = p.communicate()
             if p.returncode:
                 sys.exit(err)
+            procs.append((src, err))
             label = None
             for line in open(out):
                 m = re.match(r"^(_Z\w+):", line)
@@ -47,10 +45,7 @@ def main():
                     label = m.group(1)
                 elif label and re.match(r"\s+flat_(load|store|atomic)", line):
                     flat[label] = flat.get(label, 0) + 1
-        for src, p in procs:
-            _, err = p.communicate()
-            if p.returncode:
-                sys.exit(err)
+        for src, err in procs:
             cur = None
             for line in err.splitlines():
                 m = re.search(r"Function Name: (\S+)", line)

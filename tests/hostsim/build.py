@@ -21,6 +21,33 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-fno-f
          f"-I{HERE}", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 
 
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(HERE, "**", "*.*"), recursive=True)) + \
+        sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+
+
+def build_cached(out, sanitize=None):
+    """build(), keyed on the content of every source it reads: the CPU suite needs the simulator in two modules (tests/test_sharding_gloo.py,
+    tests/test_zz_hostsim.py) and a build is 90 s of clang.  The cache lives under the system temp directory; a stale entry cannot be hit."""
+    import hashlib
+    import shutil
+    h = hashlib.sha256((sanitize or os.environ.get("KH_HOSTSIM_SANITIZE") or "").encode())
+    for f in _sources():
+        if os.path.isfile(f) and not f.endswith((".so", ".o", ".pyc")):
+            h.update(f.encode()); h.update(open(f, "rb").read())
+    cache = os.path.join(tempfile.gettempdir(), f"kh_hostsim_{os.getuid()}")
+    os.makedirs(cache, exist_ok=True)
+    hit = os.path.join(cache, h.hexdigest()[:32] + ".so")
+    if not os.path.exists(hit):
+        tmp = hit + f".{os.getpid()}.tmp"
+        build(tmp, sanitize)
+        os.replace(tmp, hit)
+        for old in sorted(glob.glob(os.path.join(cache, "*.so")), key=os.path.getmtime)[:-3]:   # keep the three newest builds
+            os.remove(old)
+    shutil.copyfile(hit, out)
+    return out
+
+
 def build(out, sanitize=None):
     """sanitize="address": AddressSanitizer build (KH_HOSTSIM_SANITIZE=address scripts/hostsim_run.py ...): device buffers are
     plain heap blocks here, so a kernel that reads or writes one byte past an image is reported with its source line."""

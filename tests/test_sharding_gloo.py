@@ -148,7 +148,7 @@ def _hostsim_lib(tmp_path_factory):
     sys.path.insert(0, str(ROOT / "tests" / "hostsim"))
     import build as hostsim_build
     out = tmp_path_factory.mktemp("hostsim") / "libkornia_hip_hostsim.so"
-    hostsim_build.build(str(out))
+    hostsim_build.build_cached(str(out))
     return out
 
 

@@ -22,7 +22,7 @@ def sim_env(tmp_path_factory):
     sys.path.insert(0, str(ROOT / "tests" / "hostsim"))
     import build as hostsim_build
     lib = tmp_path_factory.mktemp("hostsim") / "libkornia_hip_hostsim.so"
-    hostsim_build.build(str(lib))
+    hostsim_build.build_cached(str(lib))
     return dict(os.environ, KH_HOSTSIM_PREBUILT=str(lib))
 
 
