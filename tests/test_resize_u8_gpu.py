@@ -252,6 +252,23 @@ def test_opencv_resize_u8_four_pixels_per_lane(gpu_stream, dev_option, c, mode):
             assert_same_bits(cv_gpu(gpu_stream, src, dw, dh, mode), want, f"cv u8 c{c} {mode} {sw}x{sh}->{dw}x{dh} option {opt}")
 
 
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_opencv_linear_exact_half_is_the_box(gpu_stream, dev_option, c):
+    """INTER_LINEAR at an exact 2x downscale: every coefficient is 1024 / 2048 and the reference's shifts drop only zero bits, so the result
+    is (p00 + p01 + p10 + p11 + 2) >> 2 — the packed-byte box kernel (round 6).  The oracle's bytes (its generic fixed-point path) on whole-quad
+    destination rows, random data and saturated sums; resize_u8_px = 2 keeps the generic quad kernel; other widths never leave it."""
+    rng = np.random.default_rng(3)
+    for (dw, dh) in [(4, 1), (8, 3), (64, 5), (256, 4), (260, 3), (1024, 2), (1028, 3), (6, 4), (65, 9)]:
+        src = rng.integers(0, 256, (2 * dh, 2 * dw, c), dtype=np.uint8)
+        want = O.resize_opencv(src, dw, dh, "bilinear")
+        for opt in (-1, 2):
+            dev_option("resize_u8_px", opt)
+            assert_same_bits(cv_gpu(gpu_stream, src, dw, dh, "bilinear"), want, f"cv linear exact half c{c} -> {dw}x{dh} resize_u8_px={opt}")
+    dev_option("resize_u8_px", -1)
+    sat = np.full((8, 16, c), 255, np.uint8); sat[::2, 1::2] = 254
+    assert_same_bits(cv_gpu(gpu_stream, sat, 8, 4, "bilinear"), O.resize_opencv(sat, 8, 4, "bilinear"), "saturated")
+
+
 def test_opencv_resize_unit_vectors_and_channels(gpu_stream):  # opencv_compat.rs:253-330
     from kornia_rs import _ffi
     src = np.array([[0, 100, 200, 255], [0, 100, 200, 255]], np.uint8)[:, :, None]
