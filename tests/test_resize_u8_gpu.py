@@ -267,6 +267,14 @@ def test_opencv_linear_exact_half_is_the_box(gpu_stream, dev_option, c):
     dev_option("resize_u8_px", -1)
     sat = np.full((8, 16, c), 255, np.uint8); sat[::2, 1::2] = 254
     assert_same_bits(cv_gpu(gpu_stream, sat, 8, 4, "bilinear"), O.resize_opencv(sat, 8, 4, "bilinear"), "saturated")
+    # INTER_NEAREST at an exact 2x upscale takes the rolling walk (column i >> 1) on one / three channels
+    for (w, h) in [(2, 2), (4, 3), (9, 5), (33, 6), (256, 4), (257, 5), (513, 3), (1025, 2), (300, 41)]:
+        src = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        want = O.resize_opencv(src, 2 * w, 2 * h, "nearest")
+        for opt in (-1, 2):
+            dev_option("resize_u8_px", opt)
+            assert_same_bits(cv_gpu(gpu_stream, src, 2 * w, 2 * h, "nearest"), want, f"cv nearest exact double c{c} {w}x{h} resize_u8_px={opt}")
+    dev_option("resize_u8_px", -1)
 
 
 def test_opencv_resize_unit_vectors_and_channels(gpu_stream):  # opencv_compat.rs:253-330
