@@ -150,7 +150,7 @@ enum DevOpt : int {
 int dev_opt(DevOpt o);               // kh_runtime.hip: the calling thread's value
 // kh_pyramid_morph.hip: resize_fast_u8's exact 2x bilinear upscale on the rolling pyrup kernels (false = not taken; `rc` = the launch's result)
 bool resize_up2_u8_rolling(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int sw, int sh, int channels, int batch, int64_t ss, int64_t ds,
-                           const char* what, int32_t& rc, bool nearest);
+                           const char* what, int32_t& rc, bool nearest, bool opencv = false);   // opencv: resize_opencv_u8's INTER_LINEAR arithmetic
 void set_dev_opt(int o, int value);  // kh_debug_set_option only
 
 struct XcdTiles { unsigned tiles_x, tiles_y, total, run; FastDiv by_run, by_img, by_row; };

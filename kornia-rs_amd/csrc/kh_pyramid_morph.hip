@@ -840,7 +840,10 @@ __device__ __forceinline__ uint32_t avg_round_u8x4(uint32_t a, uint32_t b) { ret
 //            ((3 a + b) 4096 x 12288-or-4096 ... + 2^27) >> 28 == (9 a + 3 b + 3 c + d + 8) >> 4 exactly; the horizontal 3 c + n stays
 //            unrounded in 16-bit lanes (<= 1020), the vertical pass adds, rounds and shifts once.
 //   kUpNearest — the nearest resize at this scale: column floor((X + 0.5) / 2) = X >> 1, i.e. both pixels of a pair and both rows ARE the source pixel.
-enum { kUpPyr = 0, kUpRh = 1, kUpQ14 = 2, kUpNearest = 3 };
+//   kUpCv — resize_opencv_u8's INTER_LINEAR at this scale (opencv_compat.rs:139-195): coefficients 512 / 1536 of 2048, the horizontal sums as in
+//            kUpQ14 (h = 3 c + n: `s >> 4` drops zero bits), the vertical ((h_far >> 2) + ((3 h_near) >> 2) + 2) >> 2 with the reference's truncations,
+//            and (h + 2) >> 2 on the first / last destination row, where its coefficients are (2048, 0).
+enum { kUpPyr = 0, kUpRh = 1, kUpQ14 = 2, kUpNearest = 3, kUpCv = 4 };
 template <int AR> __device__ __forceinline__ int up_index(int i, int len) { return AR == kUpPyr ? reflect_101(i, len) : min(max(i, 0), len - 1); }
 
 // C = 4 (round 6): RGBA images — a 16-byte source quad per lane, 32 destination bytes per lane and row through the same LDS transposition.
@@ -945,6 +948,7 @@ __global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(
             }
             if (i >= 2 && i < n) {   // rows y - 1, y, y + 1 are in: destination rows 2 y and 2 y + 1 (y = y0 + i - 2)
                 const int sp = (s + 1) % 3, sc = (s + 2) % 3, sn = s;   // compile-time after unrolling
+                [[maybe_unused]] const int yy = y0 + i - 2;   // the source row these two destination rows are centred on
                 uint32_t ve[C][2], vo[C][2];
 #pragma unroll
                 for (int c = 0; c < C; ++c)
@@ -962,6 +966,15 @@ __global__ __launch_bounds__(256, C == 4 ? 3 : 4) void pyrup_u8_rgb_roll_kernel(
                             const uint32_t el = ((cl3 + hl[sp][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu, eh = ((ch3 + hh[sp][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu;
                             const uint32_t ol = ((cl3 + hl[sn][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu, oh = ((ch3 + hh[sn][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu;
                             ve[c][e] = el | (eh << 8); vo[c][e] = ol | (oh << 8);
+                            continue;
+                        } else if constexpr (AR == kUpCv) {
+                            constexpr uint32_t kS = 0x3fff3fffu, kB = 0x00ff00ffu, kR = 0x00020002u;   // per-lane >> 2, byte mask, rounding
+                            const uint32_t cl = hl[sc][c][e], ch = hh[sc][c][e];
+                            const uint32_t nl = ((cl + (cl << 1)) >> 2) & kS, nh = ((ch + (ch << 1)) >> 2) & kS;   // (3 h_near) >> 2
+                            const bool first = yy == 0, last = yy == a.sh - 1;   // wave-uniform
+                            const uint32_t el = first ? cl + kR : ((hl[sp][c][e] >> 2) & kS) + nl + kR, eh = first ? ch + kR : ((hh[sp][c][e] >> 2) & kS) + nh + kR;
+                            const uint32_t ol = last ? cl + kR : ((hl[sn][c][e] >> 2) & kS) + nl + kR, oh = last ? ch + kR : ((hh[sn][c][e] >> 2) & kS) + nh + kR;
+                            ve[c][e] = ((el >> 2) & kB) | (((eh >> 2) & kB) << 8); vo[c][e] = ((ol >> 2) & kB) | (((oh >> 2) & kB) << 8);
                             continue;
                         }
                         const uint32_t lo = ((mad24(hl[sc][c][e], 6u, hl[sp][c][e]) + hl[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
@@ -1136,6 +1149,7 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
             }
             if (i >= 2 && i < n) {   // rows y - 1, y, y + 1 are in: destination rows 2 y and 2 y + 1 (y = y0 + i - 2)
                 const int sp = (s + 1) % 3, sc = (s + 2) % 3, sn = s;   // compile-time after unrolling
+                [[maybe_unused]] const int yy = y0 + i - 2;   // the source row these two destination rows are centred on
                 uint32_t w[2][4];   // [destination row][dword]
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -1154,6 +1168,15 @@ __global__ __launch_bounds__(256, 4) void pyrup_u8_gray_roll_kernel(PyrRoll a) {
                             const uint32_t el = ((cl3 + hl[sp][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu, eh = ((ch3 + hh[sp][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu;
                             const uint32_t ol = ((cl3 + hl[sn][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu, oh = ((ch3 + hh[sn][c][e] + 0x00080008u) >> 4) & 0x00ff00ffu;
                             ve[e] = el | (eh << 8); vo[e] = ol | (oh << 8);
+                            continue;
+                        } else if constexpr (AR == kUpCv) {
+                            constexpr uint32_t kS = 0x3fff3fffu, kB = 0x00ff00ffu, kR = 0x00020002u;   // per-lane >> 2, byte mask, rounding
+                            const uint32_t cl = hl[sc][c][e], ch = hh[sc][c][e];
+                            const uint32_t nl = ((cl + (cl << 1)) >> 2) & kS, nh = ((ch + (ch << 1)) >> 2) & kS;   // (3 h_near) >> 2
+                            const bool first = yy == 0, last = yy == a.sh - 1;   // wave-uniform
+                            const uint32_t el = first ? cl + kR : ((hl[sp][c][e] >> 2) & kS) + nl + kR, eh = first ? ch + kR : ((hh[sp][c][e] >> 2) & kS) + nh + kR;
+                            const uint32_t ol = last ? cl + kR : ((hl[sn][c][e] >> 2) & kS) + nl + kR, oh = last ? ch + kR : ((hh[sn][c][e] >> 2) & kS) + nh + kR;
+                            ve[e] = ((el >> 2) & kB) | (((eh >> 2) & kB) << 8); vo[e] = ((ol >> 2) & kB) | (((oh >> 2) & kB) << 8);
                             continue;
                         }
                         const uint32_t lo = ((mad24(hl[sc][c][e], 6u, hl[sp][c][e]) + hl[sn][c][e] + 0x00040004u) >> 3) & 0x00ff00ffu;
@@ -1998,11 +2021,12 @@ static int32_t launch_up2_roll(kh_stream_t stream, const uint8_t* src, uint8_t* 
 // rolling kernels do not cover, or test option pyr_roll = 0)
 namespace kh {
 bool resize_up2_u8_rolling(kh_stream_t stream, const uint8_t* src, uint8_t* dst, int sw, int sh, int channels, int batch, int64_t ss, int64_t ds,
-                           const char* what, int32_t& rc, bool nearest) {
+                           const char* what, int32_t& rc, bool nearest, bool opencv) {
     const bool ok = (channels == 1 ? sw >= 8 && (int64_t)sw * sh * 4 <= kI32Max : (channels == 3 || channels == 4) && sw >= 4) && sh >= 2 &&
                     (int64_t)sw * 8 < (1 << 24) && (int64_t)sw * sh * 4 * channels <= kI32Max && dev_opt(kOptPyrRoll) != 0;
     if (!ok) return false;
     rc = nearest ? launch_up2_roll<kUpNearest>(stream, src, dst, sw, sh, channels, batch, ss, ds, what)
+       : opencv ? launch_up2_roll<kUpCv>(stream, src, dst, sw, sh, channels, batch, ss, ds, what)
        : channels == 3 ? launch_up2_roll<kUpRh>(stream, src, dst, sw, sh, channels, batch, ss, ds, what)
                        : launch_up2_roll<kUpQ14>(stream, src, dst, sw, sh, channels, batch, ss, ds, what);
     return true;

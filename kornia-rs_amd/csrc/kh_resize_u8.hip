@@ -1048,9 +1048,11 @@ static int32_t resize_opencv(const char* what, kh_stream_t stream, const void* s
     // u8: four pixels per lane with dword stores under the conditions of kh_resize_fast_u8's simple paths (linear up to a 2x downscale)
     const int px_opt = dev_opt(kOptResizeU8Px);
     // INTER_NEAREST at an exact 2x upscale: floor(i * 0.5) = i >> 1 on both axes — the rolling walk of kh_resize_fast_u8's nearest (gray / RGB)
-    if (elem == 1 && mode == KH_INTERP_NEAREST && dw == 2 * sw && dh == 2 * sh && sw >= 2 && sh >= 2 && (channels == 1 || channels == 3) && px_opt != 1 && px_opt != 2) {
+    // INTER_LINEAR at the same scale: the rolling walk with the reference's fixed-point arithmetic (kh_pyramid_morph.hip::kUpCv), 1 / 3 / 4 channels
+    const bool cv_nn = mode == KH_INTERP_NEAREST && (channels == 1 || channels == 3), cv_lin = mode == KH_INTERP_BILINEAR && (channels == 1 || channels == 3 || channels == 4);
+    if (elem == 1 && (cv_nn || cv_lin) && dw == 2 * sw && dh == 2 * sh && sw >= 2 && sh >= 2 && px_opt != 1 && px_opt != 2) {
         int32_t rc = KH_OK;
-        if (resize_up2_u8_rolling(stream, static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), sw, sh, channels, batch, ss, ds, what, rc, true)) return rc;
+        if (resize_up2_u8_rolling(stream, static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), sw, sh, channels, batch, ss, ds, what, rc, cv_nn, cv_lin)) return rc;
     }
     if (elem == 1 && dw % 4 == 0 && px_opt != 1 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0) && (int64_t)dw * channels <= kI32Max &&
         (px_opt == 4 || mode == KH_INTERP_NEAREST || sw <= 2 * dw)) {

@@ -271,10 +271,15 @@ def test_opencv_linear_exact_half_is_the_box(gpu_stream, dev_option, c):
     for (w, h) in [(2, 2), (4, 3), (9, 5), (33, 6), (256, 4), (257, 5), (513, 3), (1025, 2), (300, 41)]:
         src = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
         want = O.resize_opencv(src, 2 * w, 2 * h, "nearest")
+        lin = O.resize_opencv(src, 2 * w, 2 * h, "bilinear")   # INTER_LINEAR: the same walk with the reference's fixed-point arithmetic
         for opt in (-1, 2):
             dev_option("resize_u8_px", opt)
             assert_same_bits(cv_gpu(gpu_stream, src, 2 * w, 2 * h, "nearest"), want, f"cv nearest exact double c{c} {w}x{h} resize_u8_px={opt}")
+            assert_same_bits(cv_gpu(gpu_stream, src, 2 * w, 2 * h, "bilinear"), lin, f"cv linear exact double c{c} {w}x{h} resize_u8_px={opt}")
     dev_option("resize_u8_px", -1)
+    for v0, v1 in ((255, 254), (1, 0), (3, 2), (251, 255)):   # the truncations of (h >> 2) + ((3 h) >> 2) on values around multiples of four
+        edge = np.full((6, 12, c), v0, np.uint8); edge[1::2, ::3] = v1; edge[:, 5] = (v0 + v1) // 2
+        assert_same_bits(cv_gpu(gpu_stream, edge, 24, 12, "bilinear"), O.resize_opencv(edge, 24, 12, "bilinear"), f"cv linear exact double values {v0} {v1}")
 
 
 def test_opencv_resize_unit_vectors_and_channels(gpu_stream):  # opencv_compat.rs:253-330
