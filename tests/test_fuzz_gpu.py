@@ -153,6 +153,24 @@ def test_fuzz_u8_gathers_and_resize(gpu_stream, seed):
 
 
 @pytest.mark.parametrize("seed", range(4 + EXTRA))
+def test_fuzz_exact_double_and_half_resizes(gpu_stream, seed):
+    """The exact-2x cases of the two u8 resizes run on shared special kernels since round 6 (rolling upscale walk with each resize's own
+    arithmetic, packed-byte box): random shapes either side of their lane / wave seams, every channel count, both modes and both APIs."""
+    from kornia_rs import imgproc
+    rng = np.random.default_rng(13000 + seed)
+    for _ in range(6):
+        base = int(rng.choice([2, 8, 64, 256, 512, 1024]))
+        w, h, c = max(2, base + int(rng.integers(-9, 10))), int(rng.integers(2, 9)), int(rng.choice([1, 3, 4]))
+        small, big = _u8(rng, h, w, c), _u8(rng, 2 * h, 2 * w, c)
+        ds, db = _up(small, gpu_stream), _up(big, gpu_stream)
+        for mode in ("nearest", "bilinear"):
+            assert np.array_equal(imgproc.resize_fast(ds, (2 * h, 2 * w), mode, True).numpy(), O.resize_fast_u8(small, 2 * w, 2 * h, mode, True)[0]), ("fast up", w, h, c, mode)
+            assert np.array_equal(imgproc.resize_fast(db, (h, w), mode, True).numpy(), O.resize_fast_u8(big, w, h, mode, True)[0]), ("fast down", w, h, c, mode)
+            assert np.array_equal(imgproc.resize_opencv(ds, (2 * h, 2 * w), mode).numpy(), O.resize_opencv(small, 2 * w, 2 * h, mode)), ("cv up", w, h, c, mode)
+            assert np.array_equal(imgproc.resize_opencv(db, (h, w), mode).numpy(), O.resize_opencv(big, w, h, mode)), ("cv down", w, h, c, mode)
+
+
+@pytest.mark.parametrize("seed", range(4 + EXTRA))
 def test_fuzz_pyramid_morphology_pointwise(gpu_stream, seed):
     from kornia_rs import imgproc
     rng = np.random.default_rng(4000 + seed)
