@@ -98,6 +98,9 @@ __device__ __forceinline__ int nearest_index(int i, double scale, int src_len) {
     const double v = floor(((double)i + 0.5) * scale);
     return (int)fmin(fmax(v, 0.0), (double)(src_len - 1));
 }
+__device__ __forceinline__ int cv_nearest_index(int i, double iscale, int src_len) {  // opencv_compat.rs nearest_axis, :67-74
+    return (int)fmin(floor((double)i * iscale), (double)(src_len - 1));
+}
 __device__ __forceinline__ void bilinear_tap(int i, double scale, int src_len, int& ofs, uint32_t& fq) {  // bilinear.rs:25-39
     const double s = ((double)i + 0.5) * scale - 0.5;
     const double fl = floor(s);
@@ -244,6 +247,40 @@ __global__ __launch_bounds__(kBx* kBy) void resize_u8_quads_kernel(Rz a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) p[j] = px_any<C, OP>(a, src, x0 + j, y, yi, fy);
         store_quad_u8<C>(ow, x0, p, a.plain);
+    }
+}
+
+// ---- nearest UPSCALE of one-channel images (round 6) ---------------------------------------------------------------------------------
+// Label maps and masks are upscaled with nearest; the quad kernel above spends four byte gathers and four f64 index computations per lane
+// and ran at 0.25 of peak (1080p -> 4K gray 0.083 ms per 16 planes).  The column mapping does not depend on the row: a lane owns SIXTEEN
+// destination columns for a strip of rows, evaluates the reference's column index for them ONCE (the same f64 expression), and turns it
+// into byte selectors over the sixteen source bytes at its first column (kh_common.h::remap16_*: with a horizontal step <= 1 the four
+// sources of a destination dword lie within four bytes); per destination row it then does one 16-byte load, twelve v_perm_b32 and one
+// 16-byte store.  CV = the cv2-compatible index (floor(i * iscale)) instead of floor((i + 0.5) * scale).  Any width; sw >= 16, dw >= sw.
+constexpr int kNuRows = 32;   // destination rows per block strip
+template <bool CV>
+__global__ __launch_bounds__(256) void nearest_up_gray_kernel(Rz a) {
+    unsigned bx_, by_, bz_;
+    if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
+    const int X0 = ((int)bx_ * 256 + (int)threadIdx.x) * 16;
+    if (X0 >= a.dw) return;
+    const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
+    uint8_t* __restrict__ dst = a.dst + (long long)bz_ * a.ds;
+    auto col = [&](int X) { return CV ? cv_nearest_index(min(X, a.dw - 1), a.scale_x, a.sw) : nearest_index(min(X, a.dw - 1), a.scale_x, a.sw); };
+    const int pc = min(col(X0), a.sw - 16);
+    const Remap16 rm = remap16_setup(X0, pc, col);
+    const int nvalid = min(a.dw - X0, 16);
+    const int y0 = (int)by_ * kNuRows, y1 = min(y0 + kNuRows, a.dh);
+    const __amdgpu_buffer_rsrc_t ow = stream_window(dst, (long long)a.dw * a.dh);   // (dw * dh < 2^31: host-checked)
+    for (int y = y0; y < y1; ++y) {
+        const int sy = CV ? cv_nearest_index(y, a.scale_y, a.sh) : nearest_index(y, a.scale_y, a.sh);   // block-uniform
+        const u32x4_t v = *reinterpret_cast<const u32x4_unaligned*>(src + (long long)sy * a.sw + pc);
+        uint32_t L[4] = {v.x, v.y, v.z, v.w};
+        remap16_apply(rm, L, 0u);
+        const int off = y * a.dw + X0;
+        if (nvalid == 16 && a.plain != 2) row_store<4>(ow, off, L, a.plain);
+        else if (nvalid == 16) *reinterpret_cast<u32x4_unaligned*>(dst + off) = u32x4_t{L[0], L[1], L[2], L[3]};
+        else store_head_bytes(dst + off, L, nvalid);
     }
 }
 
@@ -621,9 +658,6 @@ __device__ __forceinline__ LinTap linear_tap(int d, double scale, int src_len) {
     t.i1 = (int)rintf(fx * 2048.0f);
     return t;
 }
-__device__ __forceinline__ int cv_nearest_index(int i, double iscale, int src_len) {  // nearest_axis, :67-74
-    return (int)fmin(floor((double)i * iscale), (double)(src_len - 1));
-}
 
 template <typename T, int C>
 __global__ __launch_bounds__(kBx* kBy) void cv_nearest_kernel(Rz a) {
@@ -854,6 +888,18 @@ Rz make_rz(const void* src, void* dst, int sw, int sh, int dw, int dh, int64_t s
     return a;
 }
 
+// nearest upscale of one channel on nearest_up_gray_kernel (false = not taken)
+template <bool CV>
+bool launch_nearest_up_gray(hipStream_t st, Rz a, int sw, int sh, int dw, int dh, int batch, const void* dst, int64_t ds) {
+    if (!(sw >= 16 && dw >= sw && (int64_t)dw * dh <= kI32Max && (int64_t)sw * sh <= kI32Max)) return false;
+    const bool dword_ok = dw % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
+    a.plain = dword_ok ? plain_row_stores((int64_t)dw, dst, ds, batch) : 2;
+    a.tiles = xcd_tiles(cdiv(dw, 256 * 16), cdiv(dh, kNuRows), (unsigned)batch, cdiv(dw, 256 * 16) * 8);
+    if (a.tiles.total == 0) return false;
+    hipLaunchKernelGGL((nearest_up_gray_kernel<CV>), xcd_grid(a.tiles), dim3(256), 0, st, a);
+    return true;
+}
+
 // horizontal pass: the LDS-staged kernel when its tile fits 64 KiB, else (or with test option resize_u8_gather = 1) the gather
 int32_t launch_sep_h(hipStream_t st, const void* src, int sw, int sh, int dw, int dh, int channels, int batch, int64_t ss,
                      int16_t* hbuf, const SepTab& tx, const char* what) {
@@ -959,6 +1005,8 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
     } else if (up2) {
         KH_RZ_OP(3, kRzUp2);
     } else if (mode == KH_INTERP_NEAREST) {
+        // one channel, an upscale: sixteen destination columns per lane with the column selectors computed once (test option resize_u8_px = 1 / 2: the quad / per-pixel kernels)
+        if (channels == 1 && px_opt != 1 && px_opt != 2 && launch_nearest_up_gray<false>(st, a, sw, sh, dw, dh, batch, dst, dst_stride)) return check_launch(what);
         KH_RZ_OP_C(kRzNearest);
     } else if (mode == KH_INTERP_BILINEAR) {
         KH_RZ_OP_C(kRzBilinear);
@@ -1054,6 +1102,8 @@ static int32_t resize_opencv(const char* what, kh_stream_t stream, const void* s
         int32_t rc = KH_OK;
         if (resize_up2_u8_rolling(stream, static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), sw, sh, channels, batch, ss, ds, what, rc, cv_nn, cv_lin)) return rc;
     }
+    // INTER_NEAREST upscales of one channel: the column selectors once per lane (nearest_up_gray_kernel)
+    if (elem == 1 && mode == KH_INTERP_NEAREST && channels == 1 && px_opt != 1 && px_opt != 2 && launch_nearest_up_gray<true>(st, a, sw, sh, dw, dh, batch, dst, ds)) return check_launch(what);
     if (elem == 1 && dw % 4 == 0 && px_opt != 1 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0) && (int64_t)dw * channels <= kI32Max &&
         (px_opt == 4 || mode == KH_INTERP_NEAREST || sw <= 2 * dw)) {
         a.tiles = xcd_tiles(cdiv(dw, kBx * 4), cdiv(dh, kBy), (unsigned)batch, cdiv(dw, kBx * 4) * 8);
