@@ -258,26 +258,34 @@ __global__ __launch_bounds__(kBx* kBy) void resize_u8_quads_kernel(Rz a) {
 // sources of a destination dword lie within four bytes); per destination row it then does one 16-byte load, twelve v_perm_b32 and one
 // 16-byte store.  CV = the cv2-compatible index (floor(i * iscale)) instead of floor((i + 0.5) * scale).  Any width; sw >= 16, dw >= sw.
 constexpr int kNuRows = 32;   // destination rows per block strip
-template <bool CV>
+// C = 3: the same on the ROW BYTES of an interleaved image — destination byte B is channel B % 3 of pixel B / 3 and comes from source byte
+// 3 col(B / 3) + B % 3; the four sources of a destination dword still lie within four bytes, and the launcher checks that the sixteen
+// bytes of every lane span at most sixteen source bytes (upscales of about 1.5x and more).
+template <int C, bool CV>
 __global__ __launch_bounds__(256) void nearest_up_gray_kernel(Rz a) {
     unsigned bx_, by_, bz_;
     if (!xcd_tile(a.tiles, bx_, by_, bz_)) return;
-    const int X0 = ((int)bx_ * 256 + (int)threadIdx.x) * 16;
-    if (X0 >= a.dw) return;
+    const int rowb = a.dw * C, srowb = a.sw * C;
+    const int B0 = ((int)bx_ * 256 + (int)threadIdx.x) * 16;   // this lane's first destination byte of a row
+    if (B0 >= rowb) return;
     const uint8_t* __restrict__ src = a.src + (long long)bz_ * a.ss;
     uint8_t* __restrict__ dst = a.dst + (long long)bz_ * a.ds;
-    auto col = [&](int X) { return CV ? cv_nearest_index(min(X, a.dw - 1), a.scale_x, a.sw) : nearest_index(min(X, a.dw - 1), a.scale_x, a.sw); };
-    const int pc = min(col(X0), a.sw - 16);
-    const Remap16 rm = remap16_setup(X0, pc, col);
-    const int nvalid = min(a.dw - X0, 16);
+    auto sbyte = [&](int B) {   // source byte of destination byte B (clamped to the row: lanes past its end are never stored)
+        const int Bc = min(B, rowb - 1), X = C == 1 ? Bc : Bc / C, ch = C == 1 ? 0 : Bc - X * C;
+        return (CV ? cv_nearest_index(X, a.scale_x, a.sw) : nearest_index(X, a.scale_x, a.sw)) * C + ch;
+    };
+    // the window starts at the first byte of B0's source PIXEL: a later destination pixel that repeats it reaches back to its channel 0
+    const int pc = min(sbyte(B0) - (C == 1 ? 0 : B0 % C), srowb - 16);
+    const Remap16 rm = remap16_setup(B0, pc, sbyte);
+    const int nvalid = min(rowb - B0, 16);
     const int y0 = (int)by_ * kNuRows, y1 = min(y0 + kNuRows, a.dh);
-    const __amdgpu_buffer_rsrc_t ow = stream_window(dst, (long long)a.dw * a.dh);   // (dw * dh < 2^31: host-checked)
+    const __amdgpu_buffer_rsrc_t ow = stream_window(dst, (long long)rowb * a.dh);   // (row bytes * dh < 2^31: host-checked)
     for (int y = y0; y < y1; ++y) {
         const int sy = CV ? cv_nearest_index(y, a.scale_y, a.sh) : nearest_index(y, a.scale_y, a.sh);   // block-uniform
-        const u32x4_t v = *reinterpret_cast<const u32x4_unaligned*>(src + (long long)sy * a.sw + pc);
+        const u32x4_t v = *reinterpret_cast<const u32x4_unaligned*>(src + (long long)sy * srowb + pc);
         uint32_t L[4] = {v.x, v.y, v.z, v.w};
         remap16_apply(rm, L, 0u);
-        const int off = y * a.dw + X0;
+        const int off = y * rowb + B0;
         if (nvalid == 16 && a.plain != 2) row_store<4>(ow, off, L, a.plain);
         else if (nvalid == 16) *reinterpret_cast<u32x4_unaligned*>(dst + off) = u32x4_t{L[0], L[1], L[2], L[3]};
         else store_head_bytes(dst + off, L, nvalid);
@@ -888,15 +896,38 @@ Rz make_rz(const void* src, void* dst, int sw, int sh, int dw, int dh, int64_t s
     return a;
 }
 
-// nearest upscale of one channel on nearest_up_gray_kernel (false = not taken)
+// nearest_index / cv_nearest_index on the host (the same IEEE f64 operations)
+static int nearest_col_host(bool cv, int i, double scale, int src_len) {
+    const double v = cv ? std::floor((double)i * scale) : std::floor(((double)i + 0.5) * scale);
+    return (int)std::fmin(cv ? v : std::fmax(v, 0.0), (double)(src_len - 1));
+}
+// RGB: do the sixteen destination bytes of every lane come from at most sixteen source bytes?  (dw * 3 / 16 evaluations, memoised per thread)
+static bool nearest_up_rgb_spans_fit(bool cv, int sw, int dw, double scale) {
+    static thread_local int last_sw = 0, last_dw = 0; static thread_local bool last_cv = false, last_ok = false;
+    if (sw == last_sw && dw == last_dw && cv == last_cv) return last_ok;
+    bool ok = true;
+    const int rowb = dw * 3;
+    for (int B0 = 0; ok && B0 < rowb; B0 += 16) {
+        const int Bl = std::min(B0 + 15, rowb - 1);
+        const int lo = nearest_col_host(cv, B0 / 3, scale, sw) * 3, hi = nearest_col_host(cv, Bl / 3, scale, sw) * 3 + 2;   // whole source pixels: repeated pixels reach back / ahead inside them
+        const int pc = std::min(lo, sw * 3 - 16);
+        ok = hi - pc <= 15 && lo - pc >= 0;
+    }
+    last_sw = sw; last_dw = dw; last_cv = cv; last_ok = ok;
+    return ok;
+}
+// nearest upscale of one / three channels on nearest_up_gray_kernel (false = not taken)
 template <bool CV>
-bool launch_nearest_up_gray(hipStream_t st, Rz a, int sw, int sh, int dw, int dh, int batch, const void* dst, int64_t ds) {
-    if (!(sw >= 16 && dw >= sw && (int64_t)dw * dh <= kI32Max && (int64_t)sw * sh <= kI32Max)) return false;
-    const bool dword_ok = dw % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
-    a.plain = dword_ok ? plain_row_stores((int64_t)dw, dst, ds, batch) : 2;
-    a.tiles = xcd_tiles(cdiv(dw, 256 * 16), cdiv(dh, kNuRows), (unsigned)batch, cdiv(dw, 256 * 16) * 8);
+bool launch_nearest_up_gray(hipStream_t st, Rz a, int sw, int sh, int dw, int dh, int channels, int batch, const void* dst, int64_t ds) {
+    const int C = channels;
+    if (!((C == 1 || C == 3) && sw * C >= 16 && dw >= sw && (int64_t)dw * C * dh <= kI32Max && (int64_t)sw * C * sh <= kI32Max)) return false;
+    if (C == 3 && !nearest_up_rgb_spans_fit(CV, sw, dw, a.scale_x)) return false;
+    const bool dword_ok = (dw * C) % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0);   // buffer stores need dword-aligned rows
+    a.plain = dword_ok ? plain_row_stores((int64_t)dw * C, dst, ds, batch) : 2;
+    a.tiles = xcd_tiles(cdiv(dw * C, 256 * 16), cdiv(dh, kNuRows), (unsigned)batch, cdiv(dw * C, 256 * 16) * 8);
     if (a.tiles.total == 0) return false;
-    hipLaunchKernelGGL((nearest_up_gray_kernel<CV>), xcd_grid(a.tiles), dim3(256), 0, st, a);
+    if (C == 1) hipLaunchKernelGGL((nearest_up_gray_kernel<1, CV>), xcd_grid(a.tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((nearest_up_gray_kernel<3, CV>), xcd_grid(a.tiles), dim3(256), 0, st, a);
     return true;
 }
 
@@ -1006,7 +1037,7 @@ int32_t kh_resize_fast_u8(kh_stream_t stream, const uint8_t* src, uint8_t* dst, 
         KH_RZ_OP(3, kRzUp2);
     } else if (mode == KH_INTERP_NEAREST) {
         // one channel, an upscale: sixteen destination columns per lane with the column selectors computed once (test option resize_u8_px = 1 / 2: the quad / per-pixel kernels)
-        if (channels == 1 && px_opt != 1 && px_opt != 2 && launch_nearest_up_gray<false>(st, a, sw, sh, dw, dh, batch, dst, dst_stride)) return check_launch(what);
+        if ((channels == 1 || channels == 3) && px_opt != 1 && px_opt != 2 && launch_nearest_up_gray<false>(st, a, sw, sh, dw, dh, channels, batch, dst, dst_stride)) return check_launch(what);
         KH_RZ_OP_C(kRzNearest);
     } else if (mode == KH_INTERP_BILINEAR) {
         KH_RZ_OP_C(kRzBilinear);
@@ -1103,7 +1134,7 @@ static int32_t resize_opencv(const char* what, kh_stream_t stream, const void* s
         if (resize_up2_u8_rolling(stream, static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), sw, sh, channels, batch, ss, ds, what, rc, cv_nn, cv_lin)) return rc;
     }
     // INTER_NEAREST upscales of one channel: the column selectors once per lane (nearest_up_gray_kernel)
-    if (elem == 1 && mode == KH_INTERP_NEAREST && channels == 1 && px_opt != 1 && px_opt != 2 && launch_nearest_up_gray<true>(st, a, sw, sh, dw, dh, batch, dst, ds)) return check_launch(what);
+    if (elem == 1 && mode == KH_INTERP_NEAREST && (channels == 1 || channels == 3) && px_opt != 1 && px_opt != 2 && launch_nearest_up_gray<true>(st, a, sw, sh, dw, dh, channels, batch, dst, ds)) return check_launch(what);
     if (elem == 1 && dw % 4 == 0 && px_opt != 1 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (batch <= 1 || ds % 4 == 0) && (int64_t)dw * channels <= kI32Max &&
         (px_opt == 4 || mode == KH_INTERP_NEAREST || sw <= 2 * dw)) {
         a.tiles = xcd_tiles(cdiv(dw, kBx * 4), cdiv(dh, kBy), (unsigned)batch, cdiv(dw, kBx * 4) * 8);

@@ -16,11 +16,12 @@ for arg in sys.argv[1:]:
     name, val = arg.split("=")
     check(lib.kh_debug_set_option(name.encode(), int(val)))
 N = 16
-src = DeviceBuffer.from_numpy(bench.lcg_bytes(N * 1920 * 1080), st); dst = DeviceBuffer(N * 3840 * 2160, st, zeroed=False)
+src = DeviceBuffer.from_numpy(bench.lcg_bytes(N * 1920 * 1080 * 3), st); dst = DeviceBuffer(N * 3840 * 2160 * 3, st, zeroed=False)
 for (sw, sh, dw, dh) in ((1920, 1080, 3840, 2160), (1280, 720, 3840, 2160), (960, 540, 3840, 2160), (480, 270, 3840, 2160), (1920, 1080, 2560, 1440), (1000, 750, 3000, 2000)):
-    n, m = sw * sh, dw * dh
+  for ch in (1, 3):
+    n, m = sw * sh * ch, dw * dh * ch
     for api in ("fast", "opencv"):
-        fn = (lambda: check(lib.kh_resize_fast_u8(s, src.ptr, dst.ptr, sw, sh, dw, dh, 1, 0, 1, N, n, m))) if api == "fast" else (lambda: check(lib.kh_resize_opencv_u8(s, src.ptr, dst.ptr, sw, sh, dw, dh, 1, 0, N, n, m)))
+        fn = (lambda: check(lib.kh_resize_fast_u8(s, src.ptr, dst.ptr, sw, sh, dw, dh, ch, 0, 1, N, n, m))) if api == "fast" else (lambda: check(lib.kh_resize_opencv_u8(s, src.ptr, dst.ptr, sw, sh, dw, dh, ch, 0, N, n, m)))
         fn(); st.synchronize(); ts = []
         for r in range(3):
             e0, e1 = hip.Event(), hip.Event(); e0.record(st)
@@ -28,4 +29,4 @@ for (sw, sh, dw, dh) in ((1920, 1080, 3840, 2160), (1280, 720, 3840, 2160), (960
                 fn()
             e1.record(st); st.synchronize(); ts.append(e0.elapsed_ms(e1) / 2)
         t = float(np.median(ts))
-        print(f"nearest {api:6s} gray {sw}x{sh} -> {dw}x{dh}: {t:7.3f} ms  frac {(n + m) * N / t / 1e6 / 8000:.3f}")
+        print(f"nearest {api:6s} c{ch} {sw}x{sh} -> {dw}x{dh}: {t:7.3f} ms  frac {(n + m) * N / t / 1e6 / 8000:.3f}")

@@ -101,8 +101,9 @@ def test_nearest_many_ratios(gpu_stream, dev_option):
     dev_option("resize_u8_px", -1)
 
 
+@pytest.mark.parametrize("c", [1, 3])
 @pytest.mark.parametrize("api", ["fast", "opencv"])
-def test_nearest_upscale_of_one_channel_with_column_selectors(gpu_stream, dev_option, api):
+def test_nearest_upscale_of_one_channel_with_column_selectors(gpu_stream, dev_option, api, c):
     """One-channel nearest upscales (label maps, masks): a lane owns sixteen destination columns for a strip of rows, evaluates the
     reference's column index once and re-indexes the sixteen source bytes at its first column with byte selectors (round 6).  The
     oracle's bytes for integer and fractional factors from 1x to 8x, widths that are not multiples of 16 or 4, the narrowest source
@@ -113,24 +114,26 @@ def test_nearest_upscale_of_one_channel_with_column_selectors(gpu_stream, dev_op
     run = (lambda s_, dw_, dh_: resize_gpu(gpu_stream, s_, dw_, dh_, "nearest")[0]) if api == "fast" else (lambda s_, dw_, dh_: cv_gpu(gpu_stream, s_, dw_, dh_, "nearest"))
     ref = (lambda s_, dw_, dh_: O.resize_fast_u8(s_, dw_, dh_, "nearest", True)[0]) if api == "fast" else (lambda s_, dw_, dh_: O.resize_opencv(s_, dw_, dh_, "nearest"))
     cases = [(16, 3, 16, 3), (16, 2, 17, 5), (16, 4, 128, 33), (17, 5, 51, 64), (100, 7, 300, 21), (100, 9, 257, 31), (640, 6, 1920, 18), (333, 4, 1000, 9), (960, 5, 3840, 40),
-             (1000, 3, 1001, 3), (4096, 2, 4100, 5), (63, 9, 4097, 11), (20, 30, 37, 65)]
+             (1000, 3, 1001, 3), (4096, 2, 4100, 5), (63, 9, 4097, 11), (20, 30, 37, 65), (6, 3, 9, 4), (6, 2, 48, 5), (100, 4, 150, 6), (100, 4, 149, 6), (101, 3, 203, 7)]
+    # (three channels: the same kernel on the row BYTES, where every lane's sixteen bytes come from at most sixteen source bytes — factors of about 1.5 and more)
     for (sw, sh, dw, dh) in cases:
-        src = rng.integers(0, 256, (sh, sw, 1), dtype=np.uint8)
+        src = rng.integers(0, 256, (sh, sw, c), dtype=np.uint8)
         want = ref(src, dw, dh)
         for opt in ((-1, 2) if sw in (16, 100, 333, 63) else (-1,)):
             dev_option("resize_u8_px", opt)
             assert_same_bits(run(src, dw, dh), want, f"{api} nearest upscale {sw}x{sh} -> {dw}x{dh} resize_u8_px={opt}")
     dev_option("resize_u8_px", -1)
     sw, sh, dw, dh, n = 301, 7, 903, 20, 3
-    src = rng.integers(0, 256, (n, sh, sw, 1), dtype=np.uint8)
-    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * dw * dh + 8)
+    src = rng.integers(0, 256, (n, sh, sw, c), dtype=np.uint8)
+    m = dw * dh * c
+    d_src, d_dst = dev(gpu_stream, src), out_buf(gpu_stream, n * m + 8)
     fn = _ffi.lib.kh_resize_fast_u8 if api == "fast" else _ffi.lib.kh_resize_opencv_u8
-    args = (gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 3, sw, sh, dw, dh, 1, O.MODE["nearest"]) + ((1,) if api == "fast" else ()) + (n, sw * sh, dw * dh)
+    args = (gpu_stream.cuda_stream_ptr, d_src.ptr, d_dst.ptr + 3, sw, sh, dw, dh, c, O.MODE["nearest"]) + ((1,) if api == "fast" else ()) + (n, sw * sh * c, m)
     _ffi.check(fn(*args))
-    got = d_dst.to_numpy(np.uint8, (n * dw * dh + 8,))
-    assert got[:3].tolist() == [255] * 3 and got[3 + n * dw * dh:3 + n * dw * dh + 5].tolist() == [255] * 5, "bytes outside the destination were written"
+    got = d_dst.to_numpy(np.uint8, (n * m + 8,))
+    assert got[:3].tolist() == [255] * 3 and got[3 + n * m:3 + n * m + 5].tolist() == [255] * 5, "bytes outside the destination were written"
     for i in range(n):
-        assert_same_bits(got[3 + i * dw * dh:3 + (i + 1) * dw * dh].reshape(dh, dw, 1), ref(src[i], dw, dh), f"offset destination frame {i}")
+        assert_same_bits(got[3 + i * m:3 + (i + 1) * m].reshape(dh, dw, c), ref(src[i], dw, dh), f"offset destination frame {i}")
 
 
 @pytest.mark.parametrize("c", [1, 4])
