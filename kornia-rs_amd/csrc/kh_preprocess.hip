@@ -759,7 +759,7 @@ __global__ __launch_bounds__(kIdBlock) void preprocess_nv12_identity_list(FrameL
 // channel value then costs its integer decode and ONE ds_read_u16 instead of nine float instructions.
 template <bool LUT>
 __device__ __forceinline__ void nv12_identity_f16_body(const uint8_t* __restrict__ src_frame, unsigned short* __restrict__ dst_frame, const PreArgs& a) {
-    __shared__ unsigned short lut[LUT ? 768 : 2];
+    __shared__ __attribute__((aligned(4))) unsigned short lut[LUT ? 768 : 2];
     const int wo = a.src_w >> 3;     // 8-pixel groups per row
     const int groups = wo * a.src_h;
     const int g0 = blockIdx.x * kIdBlock + threadIdx.x;
